@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own code.
+
+Runs only in the build container (needs /root/reference, which does not exist on the GPU
+box).  The reference's pure-torch modules run natively; its DGL / torch_cluster call sites run
+on top of tests/golden/ref_shim.py (functional stand-ins authored by this repo).  Weights come
+from oracle.pf_oracle.make_state_dict (a seeded numpy generator) and are loaded into the
+reference model with load_state_dict(strict=True), so no weight file is committed: tests
+regenerate the identical state dict from the seed.  Random draws of the reference
+(torch.randn / torch.randint with torch.manual_seed) are reproduced up front with the same
+seed, call order and shapes and stored next to the outputs.
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_shim  # noqa: E402
+
+ref_shim.install("/root/reference")
+
+import dgl  # noqa: E402  (the shim)
+from oracle import pf_oracle as O  # noqa: E402
+from pharmacoforge.models import gvp as ref_gvp  # noqa: E402
+from pharmacoforge.models import dynamics_gvp as ref_dyn  # noqa: E402
+from pharmacoforge.models import pharmacodiff as ref_pd  # noqa: E402
+from pharmacoforge.utils import get_batch_idxs  # noqa: E402
+
+PH_TYPES = ['Aromatic', 'HydrogenDonor', 'HydrogenAcceptor', 'PositiveIon', 'NegativeIon', 'Hydrophobic']
+
+
+def ref_model(cfg: O.DynamicsConfig, T: int, precision: float, seed: int):
+    graph_config = {"graph_cutoffs": {"pp": cfg.cutoff_pp, "pf": cfg.cutoff_pf, "fp": cfg.cutoff_fp, "ff": cfg.cutoff_ff}}
+    dynamics_config = dict(vector_size=cfg.vector_size, n_convs=cfg.n_convs, n_hidden_scalars=cfg.n_hidden_scalars,
+                           message_norm=cfg.message_norm, dropout=0.1, ff_k=cfg.ff_k, pf_k=cfg.pf_k,
+                           n_message_gvps=cfg.n_message_gvps, n_update_gvps=cfg.n_update_gvps,
+                           n_noise_gvps=cfg.n_noise_gvps)
+    m = ref_pd.PharmacophoreDiff(pharm_nf=cfg.pharm_nf, rec_nf=cfg.rec_nf, ph_type_map=PH_TYPES,
+                                 processed_data_dir=None, n_timesteps=T, graph_config=graph_config,
+                                 dynamics_config=dynamics_config, precision=precision)
+    sd = O.make_state_dict(cfg, seed)
+    full = dict(sd)
+    full["gamma.gamma"] = m.state_dict()["gamma.gamma"]
+    missing = set(m.state_dict().keys()) ^ set(full.keys())
+    assert not missing, missing
+    m.load_state_dict(full, strict=True)
+    m.eval()
+    return m, sd
+
+
+def ref_graph(batch: O.PocketBatch, pharm_x0=None, pharm_h0=None, pharm_nf=6):
+    """Batched reference-style heterograph from a PocketBatch (via per-graph build + dgl.batch)."""
+    gs = []
+    B = batch.batch_size
+    for b in range(B):
+        p0, p1 = int(batch.prot_ptr[b]), int(batch.prot_ptr[b + 1])
+        f0, f1 = int(batch.pharm_ptr[b]), int(batch.pharm_ptr[b + 1])
+        m = (batch.pp_dst >= p0) & (batch.pp_dst < p1)
+        data = {
+            ('prot', 'pp', 'prot'): (batch.pp_src[m] - p0, batch.pp_dst[m] - p0),
+            ('prot', 'pf', 'pharm'): ([], []),
+            ('pharm', 'ff', 'pharm'): ([], []),
+            ('pharm', 'fp', 'prot'): ([], []),
+        }
+        g = dgl.heterograph(data, num_nodes_dict={'prot': p1 - p0, 'pharm': f1 - f0, 'prot_ph': 0})
+        g.nodes['prot'].data['x_0'] = batch.prot_x[p0:p1].clone()
+        g.nodes['prot'].data['h_0'] = batch.prot_h[p0:p1].clone()
+        if pharm_x0 is None:
+            g.nodes['pharm'].data['x_0'] = torch.zeros(f1 - f0, 3)
+            g.nodes['pharm'].data['h_0'] = torch.zeros(f1 - f0, pharm_nf)
+        else:
+            g.nodes['pharm'].data['x_0'] = pharm_x0[f0:f1].clone()
+            g.nodes['pharm'].data['h_0'] = pharm_h0[f0:f1].clone()
+        g.nodes['prot_ph'].data['x_0'] = torch.zeros(0, 3)
+        g.nodes['prot_ph'].data['h_0'] = torch.zeros(0, pharm_nf)
+        gs.append(g)
+    return dgl.batch(gs)
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def batch_arrays(batch: O.PocketBatch, prefix="b_"):
+    return {prefix + k: getattr(batch, k) for k in ("prot_x", "prot_h", "prot_ptr", "pharm_ptr", "pp_src", "pp_dst")}
+
+
+@torch.no_grad()
+def golden_units(cfg):
+    """Pure-torch reference modules: 5 GVP shapes, GVPLayerNorm, _rbf, NoisePredictionBlock."""
+    m, sd = ref_model(cfg, 100, 1e-5, seed=0)
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    conv0 = m.dynamics.noise_predictor.conv_layers[0]
+    n = 37
+    # msg-0 shape (vi17, h17, vo16; 144+17 -> 128)
+    s = torch.randn(n, 144, generator=g)
+    v = torch.randn(n, 17, 3, generator=g)
+    v[3] = 0.0   # zero vectors stay finite
+    fo, vo = conv0.edge_message_fns['prot_pp_prot'][0]((s, v))
+    out.update(msg0_s=s, msg0_v=v, msg0_so=fo, msg0_vo=vo)
+    # msg-1 shape (16,16,16; 128+16 -> 128)
+    s = torch.randn(n, 128, generator=g)
+    v = torch.randn(n, 16, 3, generator=g)
+    fo, vo = conv0.edge_message_fns['pharm_ff_pharm'][1]((s, v))
+    out.update(msg1_s=s, msg1_v=v, msg1_so=fo, msg1_vo=vo)
+    # full 3-GVP message chain
+    s = torch.randn(n, 144, generator=g)
+    v = torch.randn(n, 17, 3, generator=g)
+    fo, vo = conv0.edge_message_fns['prot_pf_pharm']((s, v))
+    out.update(chain_s=s, chain_v=v, chain_so=fo, chain_vo=vo)
+    # update chain
+    s = torch.randn(n, 128, generator=g)
+    v = torch.randn(n, 16, 3, generator=g)
+    fo, vo = conv0.node_update_fns['prot']((s, v))
+    out.update(upd_s=s, upd_v=v, upd_so=fo, upd_vo=vo)
+    # layer norm (incl. an all-zero vector row)
+    v2 = v.clone()
+    v2[5] = 0.0
+    fo, vo = conv0.message_layer_norms['pharm'](s, v2)
+    out.update(ln_s=s, ln_v=v2, ln_so=fo, ln_vo=vo)
+    # rbf incl. d = 0 and d = cutoffs
+    d = torch.tensor([0.0, 1e-8, 0.5, 1.2, 3.5, 8.0, 9.0, 14.9, 15.0, 25.0])
+    out.update(rbf_d=d, rbf_out=ref_gvp._rbf(d, D_max=15, D_count=16))
+    # noise head (last GVP: vo=1, so=64, identity vector activation)
+    s = torch.randn(n, 128, generator=g)
+    v = torch.randn(n, 16, 3, generator=g)
+    eh, ex = m.dynamics.noise_predictor.noise_predictor((s, None, v))
+    out.update(head_s=s, head_v=v, head_eh=eh, head_ex=ex)
+    # encoders
+    hp = torch.randn(n, cfg.pharm_nf + 1, generator=g)
+    hr = torch.randn(n, cfg.rec_nf + 1, generator=g)
+    out.update(enc_pharm_in=hp, enc_pharm_out=m.dynamics.pharm_encoder(hp),
+               enc_prot_in=hr, enc_prot_out=m.dynamics.prot_encoder(hr))
+    npz("units.npz", **out)
+
+
+@torch.no_grad()
+def golden_schedule():
+    out = {}
+    for T in (50, 100, 500, 1000):
+        for prec in (1e-5, 1e-4):
+            tag = f"T{T}_p{prec:g}"
+            sched = ref_pd.PredefinedNoiseSchedule('polynomial_2', T, prec)
+            out["gamma_" + tag] = sched.gamma.detach()
+            # per-step algebra exactly as sample_p_zs_given_zt does it (pharmacodiff.py:387-400)
+            holder = ref_pd.PharmacophoreDiff.__new__(ref_pd.PharmacophoreDiff)
+            s_arr = torch.arange(T).float() / T
+            t_arr = (torch.arange(T) + 1).float() / T
+            g_s, g_t = sched(s_arr), sched(t_arr)
+            s2, s1, a_ts, a_s = ref_pd.PharmacophoreDiff.sigma_and_alpha_t_given_s(holder, g_t, g_s)
+            sig_s = ref_pd.PharmacophoreDiff.sigma(holder, g_s)
+            sig_t = ref_pd.PharmacophoreDiff.sigma(holder, g_t)
+            out["a_ts_" + tag] = a_ts
+            out["var_" + tag] = s2 / a_ts / sig_t
+            out["sigma_" + tag] = s1 * sig_s / sig_t
+            out["alpha_" + tag] = ref_pd.PharmacophoreDiff.alpha(holder, g_t)
+    npz("schedule.npz", **out)
+
+
+@torch.no_grad()
+def golden_conv_and_dynamics(cfg, name, seeds, n_prot, n_pharm, T=100, wseed=0):
+    m, sd = ref_model(cfg, T, 1e-5, seed=wseed)
+    batch = O.synthetic_batch(seeds, n_prot, n_pharm, cfg)
+    g = ref_graph(batch, pharm_nf=cfg.pharm_nf)
+    gen = torch.Generator().manual_seed(11)
+    Nf = int(batch.pharm_ptr[-1])
+    Np = int(batch.prot_ptr[-1])
+    B = batch.batch_size
+    x_t = 2.0 * torch.randn(Nf, 3, generator=gen)
+    h_t = torch.randn(Nf, cfg.pharm_nf, generator=gen)
+    t = torch.randint(1, T + 1, (B,), generator=gen).float() / T
+    # centre the pocket like sample_given_receptor does
+    bidx = get_batch_idxs(g)
+    com = dgl.readout_nodes(g, feat='x_0', ntype='prot', op='mean')
+    g.nodes['prot'].data['x_0'] = g.nodes['prot'].data['x_0'] - com[bidx['prot']]
+    prot_x = g.nodes['prot'].data['x_0'].clone()
+    g.nodes['pharm'].data['x_t'] = x_t
+    g.nodes['pharm'].data['h_t'] = h_t
+    out = dict(batch_arrays(batch), prot_x=prot_x, x_t=x_t, h_t=h_t, t=t, wseed=wseed)
+
+    # (1) one conv layer with non-zero vector inputs (layer index n_convs-1)
+    dyn = m.dynamics
+    dyn.remove_pharm_edges(g)
+    g = dyn.add_pharm_edges(g, bidx['pharm'], bidx['prot'])
+    for et in ('ff', 'pf', 'fp', 'pp'):
+        u, v = g.edges(form='uv', etype=et)
+        out[f"e_{et}_src"], out[f"e_{et}_dst"] = u, v
+    S, V = cfg.n_hidden_scalars, cfg.vector_size
+    nf = {
+        'pharm': (torch.randn(Nf, S, generator=gen), x_t, 0.5 * torch.randn(Nf, V, 3, generator=gen)),
+        'prot': (torch.randn(Np, S, generator=gen), prot_x, 0.5 * torch.randn(Np, V, 3, generator=gen)),
+    }
+    li = cfg.n_convs - 1
+    res = dyn.noise_predictor.conv_layers[li](g, nf, bidx)
+    out.update(conv_layer_index=li,
+               conv_in_h_pharm=nf['pharm'][0], conv_in_v_pharm=nf['pharm'][2],
+               conv_in_h_prot=nf['prot'][0], conv_in_v_prot=nf['prot'][2],
+               conv_out_h_pharm=res['pharm'][0], conv_out_v_pharm=res['pharm'][2],
+               conv_out_h_prot=res['prot'][0], conv_out_v_prot=res['prot'][2])
+    dyn.remove_pharm_edges(g)
+
+    # (2) full dynamics call (the boundary function)
+    eps_h, eps_x = dyn(g, t, bidx)
+    out.update(eps_h=eps_h, eps_x=eps_x)
+    npz(name, **out)
+
+
+@torch.no_grad()
+def golden_trajectory(cfg, name, seeds, n_prot, n_pharm, T, noise_seed=42, wseed=0, traj=True):
+    m, sd = ref_model(cfg, T, 1e-5, seed=wseed)
+    batch = O.synthetic_batch(seeds, n_prot, n_pharm, cfg)
+    g = ref_graph(batch, pharm_nf=cfg.pharm_nf)
+    Nf = int(batch.pharm_ptr[-1])
+    # reproduce the reference's draw order: x then h, initial draw then one pair per step
+    torch.manual_seed(noise_seed)
+    noise = torch.zeros(T + 1, Nf, 3 + cfg.pharm_nf)
+    for i in range(T + 1):
+        noise[i, :, :3] = torch.randn(Nf, 3)
+        noise[i, :, 3:] = torch.randn(Nf, cfg.pharm_nf)
+    torch.manual_seed(noise_seed)
+    pharms = m.sample_given_receptor(g, init_pharm_com=None, visualize_trajectory=traj)
+    x0 = torch.cat([p.ph_coords for p in pharms])
+    h0 = torch.cat([p.g.nodes['pharm'].data['h_0'] for p in pharms])
+    out = dict(batch_arrays(batch), noise=noise, x0=x0, h0=h0, T=T, wseed=wseed,
+               xyz="".join(p.to_xyz_file() for p in pharms))
+    if traj:
+        out["pos_frames"] = torch.cat([p.pos_frames for p in pharms], dim=1)    # [T+1, Nf, 3]
+        out["feat_frames"] = torch.cat([p.feat_frames for p in pharms], dim=1)  # [T+1, Nf, 6]
+    npz(name, **out)
+
+
+@torch.no_grad()
+def golden_train_forward(cfg, name, seeds, n_prot, n_pharm, T=100, wseed=0, rseed=5):
+    m, sd = ref_model(cfg, T, 1e-5, seed=wseed)   # eval(): dropout is the identity
+    batch = O.synthetic_batch(seeds, n_prot, n_pharm, cfg)
+    Nf = int(batch.pharm_ptr[-1])
+    B = batch.batch_size
+    gen = torch.Generator().manual_seed(3)
+    x0 = 3.0 * torch.randn(Nf, 3, generator=gen)
+    types = torch.randint(0, cfg.pharm_nf, (Nf,), generator=gen)
+    h0 = torch.nn.functional.one_hot(types, cfg.pharm_nf).float()
+    g = ref_graph(batch, x0, h0, cfg.pharm_nf)
+    torch.manual_seed(rseed)
+    t_int = torch.randint(0, T, size=(B,))
+    eps_h = torch.randn(Nf, cfg.pharm_nf)
+    eps_x = torch.randn(Nf, 3)
+    torch.manual_seed(rseed)
+    losses, metrics = m.forward(g, 'train')
+    out = dict(batch_arrays(batch), x0=x0, h0=h0, t_int=t_int, eps_h=eps_h, eps_x=eps_x, T=T, wseed=wseed)
+    for k, v in {**losses, **metrics}.items():
+        out["out_" + k.replace(" ", "_")] = v
+    npz(name, **out)
+
+
+def main():
+    cfg = O.DynamicsConfig()                       # dev.yml
+    golden_units(cfg)
+    golden_schedule()
+    # config 1: 64-atom pocket, 4 centers, B=1
+    golden_conv_and_dynamics(cfg, "dynamics_c1.npz", seeds=[0], n_prot=64, n_pharm=4)
+    # ragged batch: B=3, pharm sizes 3/8/5, 48-atom pockets
+    golden_conv_and_dynamics(cfg, "dynamics_ragged.npz", seeds=[1, 2, 3], n_prot=48, n_pharm=[3, 8, 5])
+    # class-default flavour: radius pf edges, numeric message_norm, 3 convs / 3 noise GVPs
+    cfg2 = O.DynamicsConfig(n_convs=3, n_noise_gvps=3, message_norm=10, pf_k=0, ff_k=0)
+    golden_conv_and_dynamics(cfg2, "dynamics_radius.npz", seeds=[4, 5], n_prot=40, n_pharm=[4, 6], wseed=1)
+    # kNN ff edges
+    cfg3 = O.DynamicsConfig(ff_k=2, pf_k=3, message_norm=1)
+    golden_conv_and_dynamics(cfg3, "dynamics_knnff.npz", seeds=[6, 7], n_prot=32, n_pharm=[5, 4], wseed=2)
+    # config 1 trajectory, T=50
+    golden_trajectory(cfg, "traj_c1.npz", seeds=[0], n_prot=64, n_pharm=4, T=50)
+    golden_trajectory(cfg, "traj_ragged.npz", seeds=[8, 9], n_prot=40, n_pharm=[3, 5], T=20, traj=False)
+    golden_train_forward(cfg, "train_fwd.npz", seeds=[10, 11, 12], n_prot=40, n_pharm=[4, 6, 5])
+
+
+if __name__ == "__main__":
+    main()
