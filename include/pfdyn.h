@@ -1,0 +1,162 @@
+/* pfdyn.h -- C ABI of libpfdyn.so: the MI355X (gfx950) implementation of PharmacoForge's
+ * per-timestep denoising network and reverse-diffusion loop.
+ *
+ * Boundary replaced (reference = eflynn8/pharmacophore-diffusion, paths relative to its root):
+ *   pharmacoforge/models/dynamics_gvp.py:131-185   PharmRecDynamicsGVP.forward   -> pf_dynamics_forward
+ *   pharmacoforge/models/dynamics_gvp.py:187-246   add/remove_pharm_edges        -> inside pf_dynamics_forward
+ *                                                                                  (pf_debug_get_edges exposes them)
+ *   pharmacoforge/models/pharmacodiff.py:380-431   sample_p_zs_given_zt          -> pf_denoise_step
+ *   pharmacoforge/models/pharmacodiff.py:433-488   sample_given_receptor (loop)  -> pf_sample
+ *   pharmacoforge/models/pharmacodiff.py:88-108    com_removal                   -> inside pf_denoise_step / pf_sample
+ *   pharmacoforge/dataset/protein_pharm_dataset.py:234-236  static pp radius graph -> pf_build_pp_edges
+ *   checkpoint key layout                                   -> pf_set_weight (names are the
+ *                                                                                  reference state_dict keys)
+ * The reference has no FFI of its own: the seam is a Python method call, so these entry points are
+ * what a ctypes binding added to the reference would bind.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative pf_status; pf_last_error(h) gives text;
+ *     no exceptions cross the ABI;
+ *   - the caller owns every tensor it passes (PyTorch allocations as raw device pointers + sizes);
+ *     the library owns its packed weights and a workspace sized by pf_set_pocket_batch;
+ *   - "dev" pointers are device memory of the current HIP device, "host" pointers host memory;
+ *     all tensors are dense row-major fp32 (indices int32);
+ *   - all work is enqueued on the caller's stream; no call synchronises the device except
+ *     pf_create/pf_commit_weights/pf_set_pocket_batch (allocation + host->device copies of
+ *     small tables) and the pf_debug_* readers;
+ *   - a handle is bound to one device and is not thread-safe (one handle per GPU / process).
+ *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
+ *     PF_ERR_HIP.
+ */
+#ifndef PFDYN_H
+#define PFDYN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_ABI_VERSION 1
+
+typedef struct pf_handle pf_handle;
+typedef void* pf_stream;           /* hipStream_t */
+
+typedef enum pf_status {
+    PF_OK = 0,
+    PF_ERR_ARG = -1,           /* bad argument / unsupported configuration */
+    PF_ERR_HIP = -2,           /* HIP runtime error (no device, OOM, launch failure) */
+    PF_ERR_STATE = -3,         /* call order violated (weights not committed, no batch set ...) */
+    PF_ERR_WEIGHT = -4         /* unknown / missing / mis-shaped weight tensor */
+} pf_status;
+
+/* message_norm of GVPMultiEdgeConv (gvp.py:351,373-389) */
+#define PF_NORM_MEAN 0         /* 'mean': mean reducer, divide by 1 */
+#define PF_NORM_VALUE 1        /* number > 0: sum reducer, divide by message_norm_value */
+#define PF_NORM_GRAPH 2        /* number == 0: sum reducer, divide by (edges into ntype)/(nodes of ntype)+1 per graph */
+
+/* Mirrors PharmRecDynamicsGVP.__init__ (dynamics_gvp.py:96-97) + graph_cutoffs (configs/dev.yml:67-68). */
+typedef struct pf_config {
+    int32_t abi_version;        /* = PF_ABI_VERSION */
+    int32_t pharm_nf;           /* n_pharm_scalars (6) */
+    int32_t rec_nf;             /* n_prot_scalars  (11) */
+    int32_t vector_size;        /* must be 16 */
+    int32_t n_hidden_scalars;   /* must be 128 */
+    int32_t n_convs;
+    int32_t n_message_gvps;
+    int32_t n_update_gvps;
+    int32_t n_noise_gvps;
+    int32_t message_norm_mode;  /* PF_NORM_* */
+    float   message_norm_value;
+    int32_t ff_k;               /* 0 = radius graph with cutoff_ff (max 200 neighbours) */
+    int32_t pf_k;               /* 0 = radius with cutoff_pf (max 100 neighbours) */
+    float   cutoff_pp, cutoff_pf, cutoff_fp, cutoff_ff;
+    float   rbf_dmax;           /* 15 (gvp.py:350) */
+    int32_t rbf_dim;            /* must be 16 */
+} pf_config;
+
+/* per-step scalars of sample_p_zs_given_zt (pharmacodiff.py:387-420), fp32, computed by the host */
+typedef struct pf_step_coef {
+    float t;                    /* (s+1)/T : the timestep fed to the dynamics            (:470) */
+    float alpha_t_given_s;      /*                                                        (:156) */
+    float var_terms;            /* sigma2_t_given_s / alpha_t_given_s / sigma_t           (:397) */
+    float sigma;                /* sigma_t_given_s * sigma_s / sigma_t                    (:400) */
+    float ep_zt;                /* endpoint param: alpha_t_given_s*sigma_s^2/sigma_t^2    (:414) */
+    float ep_pred;              /* endpoint param: alpha_s*sigma2_t_given_s/sigma_t^2     (:414) */
+} pf_step_coef;
+
+const char* pf_version(void);
+const char* pf_last_error(const pf_handle* h);     /* h may be NULL: last error of pf_create */
+
+/* -- lifetime ------------------------------------------------------------------------------ */
+int  pf_create(const pf_config* cfg, pf_handle** out);
+void pf_destroy(pf_handle* h);
+
+/* -- weights: one call per tensor of the reference state_dict under "dynamics." -------------
+ * name: the reference key, e.g. "dynamics.noise_predictor.conv_layers.0.edge_message_fns.prot_pp_prot.0.Wh"
+ * data: host fp32, row-major, shape[ndim].  Zero-size tensors (dropout dummy_param) and
+ * "gamma.gamma" are accepted and ignored.  pf_commit_weights fails if any tensor is missing. */
+int pf_set_weight(pf_handle* h, const char* name, const float* host_data, int32_t ndim, const int64_t* shape);
+int pf_commit_weights(pf_handle* h);
+
+/* -- static per-batch data (the DGL-free batch container) -----------------------------------
+ * B graphs; graph g owns prot atoms [prot_ptr[g], prot_ptr[g+1]) and pharmacophore centers
+ * [pharm_ptr[g], pharm_ptr[g+1]).  pp edges (static prot->prot, batch-local prot ids) may be in
+ * any order.  prot_x / prot_h are copied into the workspace. */
+int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* host_prot_ptr, const int32_t* host_pharm_ptr,
+                        const float* dev_prot_x, const float* dev_prot_h,
+                        int64_t n_pp, const int32_t* host_pp_src, const int32_t* host_pp_dst, pf_stream stream);
+
+/* radius_graph(prot, r=cutoff_pp, max_num_neighbors) per graph on the device; results on the host.
+ * Call with host_src == NULL to get the edge count (return value >= 0), then again with buffers. */
+int64_t pf_build_pp_edges(pf_handle* h, int32_t B, const int32_t* host_prot_ptr, const float* dev_prot_x,
+                          int32_t max_num_neighbors, int32_t* host_src, int32_t* host_dst, int64_t capacity,
+                          pf_stream stream);
+
+/* -- the boundary function: (eps_h, eps_x) = dynamics(g, t) ---------------------------------
+ * dev_prot_x may be NULL (use the coordinates currently held by the handle).
+ * Pure with respect to the handle's sampling state. */
+int pf_dynamics_forward(pf_handle* h, const float* dev_prot_x, const float* dev_pharm_x, const float* dev_pharm_h,
+                        const float* dev_t /*[B]*/, float* dev_eps_h /*[Nf,pharm_nf]*/, float* dev_eps_x /*[Nf,3]*/,
+                        pf_stream stream);
+
+/* -- sampling state machine (sample_given_receptor, pharmacodiff.py:433-488) ----------------
+ * begin : prot -= init_pharm_com[graph] (NULL: protein COM); x_t,h_t := init noise
+ * step  : one sample_p_zs_given_zt with injected noise (x columns before h columns)
+ * end   : remove protein COM, add initial protein COM, multiply h by feat_norm_constant */
+int pf_sample_begin(pf_handle* h, const float* dev_init_pharm_com /*[B,3] or NULL*/,
+                    const float* dev_noise0 /*[Nf,3+pharm_nf]*/, pf_stream stream);
+int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noise /*[Nf,3+pharm_nf]*/,
+                    int32_t endpoint_param_coord, int32_t endpoint_param_feat, pf_stream stream);
+int pf_sample_end(pf_handle* h, float feat_norm_constant, float* dev_x0 /*[Nf,3]*/, float* dev_h0 /*[Nf,pharm_nf]*/,
+                  pf_stream stream);
+/* current frame in the caller's frame of reference (get_pos_feat_for_visual, pharmacodiff.py:360-378) */
+int pf_sample_frame(pf_handle* h, float feat_norm_constant, float* dev_x /*[Nf,3]*/, float* dev_h /*[Nf,pharm_nf]*/,
+                    pf_stream stream);
+/* whole loop: begin + n_steps x step + end, all enqueued on `stream` without host synchronisation.
+ * host_coef[i] is the i-th iteration's coefficients (s = T-1-i); dev_noise is [n_steps+1, Nf, 3+pharm_nf].
+ * dev_traj_x / dev_traj_h (optional) receive n_steps+1 frames. */
+int pf_sample(pf_handle* h, int32_t n_steps, const pf_step_coef* host_coef, const float* dev_noise,
+              const float* dev_init_pharm_com, int32_t endpoint_param_coord, int32_t endpoint_param_feat,
+              float feat_norm_constant, float* dev_x0, float* dev_h0, float* dev_traj_x, float* dev_traj_h,
+              pf_stream stream);
+
+/* -- introspection for tests / profiling ----------------------------------------------------- */
+/* edges of the last dynamics call; etype: 0 ff, 1 pf, 2 fp, 3 pp; ids are ntype-local (reference
+ * convention).  host_src == NULL returns the count.  Synchronises `stream`. */
+int64_t pf_debug_get_edges(pf_handle* h, int32_t etype, int32_t* host_src, int32_t* host_dst, int64_t capacity,
+                           pf_stream stream);
+/* run one GVPMultiEdgeConv layer (gvp.py:459-538) on caller-provided node features, on the edges
+ * built from the given coordinates: tests the conv kernels with non-zero vector inputs. */
+int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, const float* dev_pharm_x,
+                        const float* dev_h_prot /*[Np,128]*/, const float* dev_v_prot /*[Np,16,3]*/,
+                        const float* dev_h_pharm, const float* dev_v_pharm,
+                        float* dev_out_h_prot, float* dev_out_v_prot, float* dev_out_h_pharm, float* dev_out_v_pharm,
+                        pf_stream stream);
+/* algorithmic work of the last dynamics call (SURVEY.md 8(d) formulas on the actual edge counts) */
+int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges /*[4]*/, pf_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFDYN_H */

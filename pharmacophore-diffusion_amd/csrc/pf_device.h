@@ -1,0 +1,156 @@
+// pf_device.h -- shared host/device structures of libpfdyn (gfx950 only).
+//
+// Data layout in HBM (all fp32 / int32, sized by pf_set_pocket_batch):
+//   node ids are GLOBAL: protein atoms [0, Np) first, pharmacophore centers [Np, Np+Nf).
+//   xn    float4[N]        current coordinates (w unused)
+//   h[2]  float[N][128]    node scalars, ping-pong between conv layers
+//   v[2]  float[N][48]     node vectors (16 x 3), ping-pong
+//   edge slots are GLOBAL: [0,Epp) static pp edges sorted by destination, then one fixed-capacity
+//   region per (dynamic etype, graph); each destination's in-edges are contiguous (dst-major),
+//   so a node finds its messages as two ranges (in_start[slot][n], in_cnt[slot][n]).
+//   msg_s float[Ecap][128], msg_v float[Ecap][48]   per-edge messages of the current layer.
+//
+// Register layout used by every MFMA stage ("F-layout", row-on-lane):
+//   a tile is 32 rows (edges or nodes); row j lives on lanes j and j+32 (half hl = lane>>5).
+//   A 128-feature vector is split over the two lanes as 64 registers:
+//       reg q = 16*mt + r   <->   feature 32*mt + rho(r,hl),  rho(r,hl) = (r&3) + 8*(r>>2) + 4*hl
+//   which is exactly the C/D layout of v_mfma_f32_32x32x2_f32 with the row on the lane
+//   (Out^T[feature][row] = W[feature][k] * In^T[k][row]); an output tile is therefore directly
+//   the B operand of the next layer's k-steps and no activation ever goes through LDS.
+//   Weights are pre-packed on the host in A-operand fragment order (pf_host.cpp: pack_linear).
+#pragma once
+#include <stdint.h>
+
+#define PF_S 128          // n_hidden_scalars (compile-time specialisation)
+#define PF_V 16           // vector_size
+#define PF_R 16           // rbf_dim
+#define PF_MAXF 64        // max pharmacophore centers per graph
+#define PF_MAXK 16        // max k for kNN edges
+#define PF_MAX_GVPS 8
+
+enum { ET_FF = 0, ET_PF = 1, ET_FP = 2, ET_PP = 3 };
+
+// Pointers that the device code reads out of memory (not straight out of the kernel-argument
+// segment) carry the global address space explicitly: otherwise hipcc treats them as generic
+// ("flat") pointers, which rules out scalar loads (s_load) for wave-uniform weights.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PF_AS1 __attribute__((address_space(1)))
+#else
+#define PF_AS1
+#endif
+typedef const float PF_AS1* pf_gcf;
+
+struct GvpW {              // packed weights of one GVP (device pointers)
+    pf_gcf wh;             // [VI][H] row-major
+    pf_gcf wu;             // [H][VO] row-major
+    pf_gcf a_main;         // [NKS][64 lanes][NMO]   A fragments of to_feats_out
+    pf_gcf b_main;         // [2 halves][NMO*16]     bias in F-layout
+    pf_gcf a_gate;         // [NMO*16][64 lanes]     A fragments of scalar_to_vector_gates (rows duplicated)
+    pf_gcf b_gate;         // [VO]
+};
+
+struct EdgeTile {          // one wave = 32 edge slots
+    int e0;                // first edge slot
+    int n;                 // slots in this tile (<= 32)
+    int et;                // etype
+    int cnt_idx;           // index into dyn_cnt (et*B+g) or -1 for static tiles
+    int rel;               // e0 - region start (dynamic tiles)
+};
+
+struct NodeTile {          // one wave = 32 nodes of one type
+    int n0;                // first global node id
+    int n;                 // nodes in this tile (<= 32)
+    int ntype;             // 0 prot, 1 pharm
+};
+
+struct EdgeParams {
+    const EdgeTile* tiles;
+    int ntiles;
+    const int* dyn_cnt;
+    const int* esrc;
+    const int* edst;
+    const float4* xn;
+    const float* h;        // [N][128]
+    const float* v;        // [N][48]
+    float* msg_s;
+    float* msg_v;
+    const GvpW* w;         // [4 etypes][n_gvps]
+    int n_gvps;
+    float rbf_mu[PF_R];
+    float rbf_sigma;
+};
+
+struct NodeW {             // per node type
+    pf_gcf ln1_w; pf_gcf ln1_b;               // message_layer_norms
+    pf_gcf ln2_w; pf_gcf ln2_b;               // update_layer_norms
+    const GvpW PF_AS1* upd;                   // [n_upd]
+};
+
+struct NodeParams {
+    const NodeTile* tiles;
+    int ntiles;
+    const int* in_start;   // [2][N]
+    const int* in_cnt;     // [2][N]
+    int N;
+    const float* msg_s;
+    const float* msg_v;
+    const float* h_in; const float* v_in;
+    float* h_out; float* v_out;
+    const int* gid;        // graph of each node
+    const float* gnorm;    // [2 ntypes][B] (PF_NORM_GRAPH)
+    int B;
+    int norm_mode; float norm_value;
+    NodeW w[2];
+    int n_upd;
+};
+
+struct HeadParams {
+    const NodeTile* tiles; // pharm tiles
+    int ntiles;
+    int node_base;         // global id of pharm node 0 (= Np)
+    const float* h; const float* v;
+    const GvpW* gvps;      // [n_noise]
+    int n_gvps;
+    const float* a_out;    // [32 ksteps][64 lanes] packed to_scalar_output
+    const float* b_out;    // [pharm_nf]
+    int pharm_nf;
+    float* eps_h;          // [Nf][pharm_nf]
+    float* eps_x;          // [Nf][3]
+};
+
+struct EncodeParams {
+    int Np, Nf;
+    const float* prot_h0;  // [Np][rec_nf]
+    const float* pharm_h;  // [Nf][pharm_nf]
+    const float* t;        // [B]
+    const int* gid;
+    int rec_nf, pharm_nf;
+    const float* w[2]; const float* b[2]; const float* ln_w[2]; const float* ln_b[2];  // 0 prot, 1 pharm
+    float* h_out;          // [N][128]
+};
+
+struct BuildParams {
+    int B, Np_tot;
+    const int* prot_ptr; const int* pharm_ptr;   // device [B+1]
+    const float4* xn;
+    const int* reg;        // [3][B] region start (absolute edge slot) of ff, pf, fp
+    int* dyn_cnt;          // [3][B]
+    int* esrc; int* edst;
+    int* in_start; int* in_cnt; int N;
+    int ff_k, pf_k;
+    float r2_ff, r2_pf;
+    float* gnorm;          // [2][B]
+    const int* pp_cnt;     // [B] static pp edges per graph
+    int norm_mode;
+};
+
+struct StepParams {
+    int B, Np_tot;
+    const int* prot_ptr; const int* pharm_ptr;
+    float4* xn; float* pharm_h;
+    const float* eps_h; const float* eps_x;
+    const float* noise;        // [Nf][3+nf]
+    int nf;
+    float a_ts, var, sigma, ep_zt, ep_pred;
+    int ep_coord, ep_feat;
+};

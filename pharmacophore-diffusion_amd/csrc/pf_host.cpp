@@ -1,0 +1,848 @@
+// pf_host.cpp -- C ABI of libpfdyn.so (include/pfdyn.h): handle, weight packing, workspace,
+// launch sequencing.  No compute happens on the host; without a HIP device every compute entry
+// point fails (there is no CPU fallback).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pfdyn.h"
+#include "pf_device.h"
+
+extern "C" {
+void pfk_edge_msg(const EdgeParams* p, int layer0, hipStream_t s);
+void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s);
+void pfk_noise_head(const HeadParams* p, hipStream_t s);
+void pfk_encode(const EncodeParams* p, hipStream_t s);
+void pfk_build_edges(const BuildParams* p, hipStream_t s);
+void pfk_load_coords(const float* src, float4* xn, int n, const int* gid, const float* shift, float sign, hipStream_t s);
+void pfk_load_noise0(const float* nz, float4* xn, float* hf, int n, int nf, hipStream_t s);
+void pfk_copy(const float* src, float* dst, size_t n, hipStream_t s);
+void pfk_scale_copy(const float* src, float* dst, size_t n, float sc, hipStream_t s);
+void pfk_segment_mean(const float4* xn, const int* ptr, int base, int B, float* out, hipStream_t s);
+void pfk_step_update(const StepParams* p, hipStream_t s);
+void pfk_export_coords(const float4* xn, int base, int n, const int* gid, const float* add, const float* sub,
+                       float* out, hipStream_t s);
+void pfk_pp_radius(const float4* xn, const int* prot_ptr, int B, float r2, int maxn, int* deg, const int* row_off,
+                   int* src, int* dst, int pass, hipStream_t s);
+}
+
+namespace {
+
+static std::string g_create_error;
+
+struct RawTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+static const char* kEtKey[4] = {"pharm_ff_pharm", "prot_pf_pharm", "pharm_fp_prot", "prot_pp_prot"};
+static const char* kNtKey[2] = {"prot", "pharm"};
+
+inline int rho(int r, int hl) { return (r & 3) + 8 * (r >> 2) + 4 * hl; }
+
+// torch.linspace(start, end, steps) in fp32 (symmetric evaluation like ATen)
+static void linspace_f32(float start, float end, int steps, float* out) {
+    const float step = (end - start) / (float)(steps - 1);
+    const int half = steps / 2;
+    for (int i = 0; i < steps; ++i) out[i] = i < half ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
+}  // namespace
+
+struct pf_handle {
+    pf_config cfg{};
+    std::string err;
+    std::map<std::string, RawTensor> raw;
+    bool committed = false;
+
+    // ---- packed weights (one device allocation)
+    float* d_w = nullptr;
+    std::vector<float> h_w;                 // staging
+    GvpW* d_gvp = nullptr;                  // table of all GvpW
+    std::vector<GvpW> h_gvp;
+    // indices into the GvpW table
+    int msg_base(int layer, int et) const { return ((layer * 4 + et) * cfg.n_message_gvps); }
+    int upd_base(int layer, int nt) const { return n_msg_tot + (layer * 2 + nt) * cfg.n_update_gvps; }
+    int head_base() const { return n_msg_tot + n_upd_tot; }
+    int n_msg_tot = 0, n_upd_tot = 0;
+    // raw (unpacked) device weights: offsets into d_w
+    size_t enc_w[2]{}, enc_b[2]{}, enc_lw[2]{}, enc_lb[2]{};
+    std::vector<size_t> ln_off;             // [layer][nt][4]: ln1_w ln1_b ln2_w ln2_b
+    size_t out_a = 0, out_b = 0;
+
+    // ---- batch / workspace
+    bool have_batch = false;
+    int B = 0, Np = 0, Nf = 0, N = 0;
+    int64_t Epp = 0, Ecap = 0;
+    std::vector<int> h_prot_ptr, h_pharm_ptr;
+    std::vector<int> h_reg;                 // [3][B]
+    std::vector<int> h_cap;                 // [3][B]
+    int n_edge_tiles = 0, n_node_tiles = 0, n_head_tiles = 0;
+    void* d_ws = nullptr;                   // one allocation, carved below
+    int *d_prot_ptr = nullptr, *d_pharm_ptr = nullptr, *d_gid = nullptr, *d_reg = nullptr, *d_dyn_cnt = nullptr,
+        *d_esrc = nullptr, *d_edst = nullptr, *d_in_start = nullptr, *d_in_cnt = nullptr, *d_pp_cnt = nullptr;
+    EdgeTile* d_edge_tiles = nullptr;
+    NodeTile* d_node_tiles = nullptr;
+    NodeTile* d_head_tiles = nullptr;
+    float4* d_xn = nullptr;
+    float *d_prot_x0 = nullptr, *d_prot_h0 = nullptr, *d_pharm_h = nullptr, *d_t = nullptr, *d_h[2] = {nullptr, nullptr},
+          *d_v[2] = {nullptr, nullptr}, *d_msg_s = nullptr, *d_msg_v = nullptr, *d_eps_h = nullptr, *d_eps_x = nullptr,
+          *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr;
+    bool sampling = false;
+};
+
+namespace {
+
+#define PF_FAIL(h, code, ...)                                   \
+    do {                                                        \
+        char _b[512];                                           \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                  \
+        (h)->err = _b;                                          \
+        return (code);                                          \
+    } while (0)
+
+#define PF_HIP(h, call)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (call);                                                                      \
+        if (_e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// expected state-dict layout (mirrors the reference's module tree)
+// ------------------------------------------------------------------------------------------------
+struct GvpSpec { std::string prefix; int vi, vo, si, so; };
+
+static void gvp_names(const GvpSpec& g, std::vector<std::pair<std::string, std::vector<int64_t>>>& out) {
+    const int h = std::max(g.vi, g.vo);
+    out.push_back({g.prefix + "Wh", {g.vi, h}});
+    out.push_back({g.prefix + "Wu", {h, g.vo}});
+    out.push_back({g.prefix + "to_feats_out.0.weight", {g.so, h + g.si}});
+    out.push_back({g.prefix + "to_feats_out.0.bias", {g.so}});
+    out.push_back({g.prefix + "scalar_to_vector_gates.weight", {g.vo, g.so}});
+    out.push_back({g.prefix + "scalar_to_vector_gates.bias", {g.vo}});
+}
+
+static std::string conv_prefix(int layer) {
+    return "dynamics.noise_predictor.conv_layers." + std::to_string(layer) + ".";
+}
+static GvpSpec msg_spec(const pf_config& c, int layer, int et, int j) {
+    GvpSpec g;
+    g.prefix = conv_prefix(layer) + "edge_message_fns." + kEtKey[et] + "." + std::to_string(j) + ".";
+    g.vi = c.vector_size + (j == 0 ? 1 : 0);
+    g.vo = c.vector_size;
+    g.si = c.n_hidden_scalars + (j == 0 ? c.rbf_dim : 0);
+    g.so = c.n_hidden_scalars;
+    return g;
+}
+static GvpSpec upd_spec(const pf_config& c, int layer, int nt, int j) {
+    GvpSpec g;
+    g.prefix = conv_prefix(layer) + "node_update_fns." + kNtKey[nt] + "." + std::to_string(j) + ".";
+    g.vi = g.vo = c.vector_size;
+    g.si = g.so = c.n_hidden_scalars;
+    return g;
+}
+static GvpSpec head_spec(const pf_config& c, int k) {
+    GvpSpec g;
+    g.prefix = "dynamics.noise_predictor.noise_predictor.gvps." + std::to_string(k) + ".";
+    g.vi = c.vector_size;
+    g.si = c.n_hidden_scalars;
+    const bool last = k == c.n_noise_gvps - 1;
+    g.vo = last ? 1 : c.vector_size;
+    g.so = last ? 64 : c.n_hidden_scalars;
+    return g;
+}
+
+static std::vector<std::pair<std::string, std::vector<int64_t>>> expected_tensors(const pf_config& c) {
+    std::vector<std::pair<std::string, std::vector<int64_t>>> v;
+    const int S = c.n_hidden_scalars;
+    for (int nt = 0; nt < 2; ++nt) {
+        const std::string p = std::string("dynamics.") + kNtKey[nt] + "_encoder.";
+        const int nf = nt ? c.pharm_nf : c.rec_nf;
+        v.push_back({p + "0.weight", {S, nf + 1}});
+        v.push_back({p + "0.bias", {S}});
+        v.push_back({p + "2.weight", {S}});
+        v.push_back({p + "2.bias", {S}});
+    }
+    for (int l = 0; l < c.n_convs; ++l) {
+        for (int et = 0; et < 4; ++et)
+            for (int j = 0; j < c.n_message_gvps; ++j) gvp_names(msg_spec(c, l, et, j), v);
+        for (int nt = 0; nt < 2; ++nt) {
+            for (int j = 0; j < c.n_update_gvps; ++j) gvp_names(upd_spec(c, l, nt, j), v);
+            for (const char* which : {"message_layer_norms", "update_layer_norms"}) {
+                const std::string p = conv_prefix(l) + which + "." + kNtKey[nt] + ".feat_norm.";
+                v.push_back({p + "weight", {S}});
+                v.push_back({p + "bias", {S}});
+            }
+        }
+    }
+    for (int k = 0; k < c.n_noise_gvps; ++k) gvp_names(head_spec(c, k), v);
+    v.push_back({"dynamics.noise_predictor.noise_predictor.to_scalar_output.weight", {c.pharm_nf, 64}});
+    v.push_back({"dynamics.noise_predictor.noise_predictor.to_scalar_output.bias", {c.pharm_nf}});
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// packing into MFMA A-operand fragment order (see pf_device.h "F-layout")
+// ------------------------------------------------------------------------------------------------
+static size_t push(std::vector<float>& w, const std::vector<float>& v) {
+    while (w.size() % 64) w.push_back(0.f);     // 256-byte alignment of every block
+    const size_t off = w.size();
+    w.insert(w.end(), v.begin(), v.end());
+    return off;
+}
+
+struct GvpOff { size_t wh, wu, a_main, b_main, a_gate, b_gate; };
+
+static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
+    const int H = std::max(g.vi, g.vo);
+    const int nextra = g.si - h->cfg.n_hidden_scalars;     // 16 (rbf) for the first message GVP
+    const int NMO = g.so / 32;
+    const int NSH = (H + 1) / 2;
+    const int NKS = 64 + nextra / 2 + NSH;
+    const int Kin = H + g.si;
+    const RawTensor& W = h->raw[g.prefix + "to_feats_out.0.weight"];   // [so][si + H]
+    const RawTensor& Bv = h->raw[g.prefix + "to_feats_out.0.bias"];
+    const RawTensor& G = h->raw[g.prefix + "scalar_to_vector_gates.weight"];   // [vo][so]
+    GvpOff o;
+    o.wh = push(h->h_w, h->raw[g.prefix + "Wh"].data);
+    o.wu = push(h->h_w, h->raw[g.prefix + "Wu"].data);
+    std::vector<float> a((size_t)NKS * 64 * NMO, 0.f);
+    for (int ks = 0; ks < NKS; ++ks)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 31, hl = lane >> 5;
+            int col;
+            if (ks < 64) col = 32 * (ks / 16) + rho(ks % 16, hl);
+            else if (ks < 64 + nextra / 2) col = 128 + 2 * (ks - 64) + hl;
+            else {
+                const int idx = 2 * (ks - 64 - nextra / 2) + hl;
+                col = idx < H ? 128 + nextra + idx : -1;
+            }
+            for (int mo = 0; mo < NMO; ++mo) {
+                const int row = 32 * mo + i;
+                a[((size_t)ks * 64 + lane) * NMO + mo] = col >= 0 ? W.data[(size_t)row * Kin + col] : 0.f;
+            }
+        }
+    o.a_main = push(h->h_w, a);
+    std::vector<float> b((size_t)2 * NMO * 16);
+    for (int hl = 0; hl < 2; ++hl)
+        for (int mo = 0; mo < NMO; ++mo)
+            for (int r = 0; r < 16; ++r) b[(size_t)hl * NMO * 16 + mo * 16 + r] = Bv.data[32 * mo + rho(r, hl)];
+    o.b_main = push(h->h_w, b);
+    std::vector<float> ag((size_t)NMO * 16 * 64, 0.f);
+    for (int ks = 0; ks < NMO * 16; ++ks)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 31, hl = lane >> 5;
+            const int k = 32 * (ks / 16) + rho(ks % 16, hl);
+            const int u = i < 16 ? i : ((i - 16) ^ 4);      // rows 16..31 duplicate rows 0..15, bit 2 flipped
+            ag[(size_t)ks * 64 + lane] = u < g.vo ? G.data[(size_t)u * g.so + k] : 0.f;
+        }
+    o.a_gate = push(h->h_w, ag);
+    o.b_gate = push(h->h_w, h->raw[g.prefix + "scalar_to_vector_gates.bias"].data);
+    return o;
+}
+
+static void free_ws(pf_handle* h) {
+    if (h->d_ws) (void)hipFree(h->d_ws);
+    h->d_ws = nullptr;
+    h->have_batch = false;
+}
+
+template <typename T>
+static T* carve(char*& cur, size_t count) {
+    T* p = reinterpret_cast<T*>(cur);
+    size_t bytes = count * sizeof(T);
+    bytes = (bytes + 255) & ~size_t(255);
+    cur += bytes;
+    return p;
+}
+
+// sequence one dynamics call on the handle's state (xn, pharm_h, d_t)
+static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s) {
+    const pf_config& c = h->cfg;
+    EncodeParams ep{};
+    ep.Np = h->Np; ep.Nf = h->Nf;
+    ep.prot_h0 = h->d_prot_h0; ep.pharm_h = h->d_pharm_h; ep.t = h->d_t; ep.gid = h->d_gid;
+    ep.rec_nf = c.rec_nf; ep.pharm_nf = c.pharm_nf;
+    for (int nt = 0; nt < 2; ++nt) {
+        ep.w[nt] = h->d_w + h->enc_w[nt]; ep.b[nt] = h->d_w + h->enc_b[nt];
+        ep.ln_w[nt] = h->d_w + h->enc_lw[nt]; ep.ln_b[nt] = h->d_w + h->enc_lb[nt];
+    }
+    ep.h_out = h->d_h[0];
+    pfk_encode(&ep, s);
+
+    BuildParams bp{};
+    bp.B = h->B; bp.Np_tot = h->Np;
+    bp.prot_ptr = h->d_prot_ptr; bp.pharm_ptr = h->d_pharm_ptr; bp.xn = h->d_xn;
+    bp.reg = h->d_reg; bp.dyn_cnt = h->d_dyn_cnt; bp.esrc = h->d_esrc; bp.edst = h->d_edst;
+    bp.in_start = h->d_in_start; bp.in_cnt = h->d_in_cnt; bp.N = h->N;
+    bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
+    bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
+    bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
+    pfk_build_edges(&bp, s);
+
+    int cur = 0;
+    for (int l = 0; l < c.n_convs; ++l) {
+        EdgeParams e{};
+        e.tiles = h->d_edge_tiles; e.ntiles = h->n_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
+        e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;
+        e.h = h->d_h[cur]; e.v = h->d_v[cur];
+        e.msg_s = h->d_msg_s; e.msg_v = h->d_msg_v;
+        e.w = h->d_gvp + h->msg_base(l, 0); e.n_gvps = c.n_message_gvps;
+        linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
+        e.rbf_sigma = (c.rbf_dmax - 0.f) / (float)c.rbf_dim;
+        pfk_edge_msg(&e, l == 0, s);
+
+        NodeParams n{};
+        n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles;
+        n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
+        n.msg_s = h->d_msg_s; n.msg_v = h->d_msg_v;
+        n.h_in = h->d_h[cur]; n.v_in = h->d_v[cur]; n.h_out = h->d_h[cur ^ 1]; n.v_out = h->d_v[cur ^ 1];
+        n.gid = h->d_gid; n.gnorm = h->d_gnorm; n.B = h->B;
+        n.norm_mode = c.message_norm_mode; n.norm_value = c.message_norm_value;
+        for (int nt = 0; nt < 2; ++nt) {
+            const size_t* lo = &h->ln_off[(size_t)(l * 2 + nt) * 4];
+            n.w[nt].ln1_w = h->d_w + lo[0]; n.w[nt].ln1_b = h->d_w + lo[1];
+            n.w[nt].ln2_w = h->d_w + lo[2]; n.w[nt].ln2_b = h->d_w + lo[3];
+            n.w[nt].upd = h->d_gvp + h->upd_base(l, nt);
+        }
+        n.n_upd = c.n_update_gvps;
+        pfk_node_update(&n, l == 0, s);
+        cur ^= 1;
+    }
+    HeadParams hp{};
+    hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
+    hp.h = h->d_h[cur]; hp.v = h->d_v[cur];
+    hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
+    hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
+    hp.eps_h = eps_h; hp.eps_x = eps_x;
+    pfk_noise_head(&hp, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return PF_OK;
+}
+
+static int check_ready(pf_handle* h, bool need_batch) {
+    if (!h) return PF_ERR_ARG;
+    if (!h->committed) PF_FAIL(h, PF_ERR_STATE, "weights not committed (pf_commit_weights)");
+    if (need_batch && !h->have_batch) PF_FAIL(h, PF_ERR_STATE, "no pocket batch set (pf_set_pocket_batch)");
+    return PF_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* pf_version(void) { return "libpfdyn 0.1 (gfx950, fp32 MFMA)"; }
+
+const char* pf_last_error(const pf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pf_create(const pf_config* cfg, pf_handle** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return PF_ERR_ARG; }
+    *out = nullptr;
+    auto bad = [&](const char* m) { g_create_error = m; return PF_ERR_ARG; };
+    if (cfg->abi_version != PF_ABI_VERSION) return bad("abi_version mismatch");
+    if (cfg->vector_size != PF_V) return bad("vector_size must be 16 (kernels are specialised)");
+    if (cfg->n_hidden_scalars != PF_S) return bad("n_hidden_scalars must be 128 (kernels are specialised)");
+    if (cfg->rbf_dim != PF_R) return bad("rbf_dim must be 16");
+    if (cfg->pharm_nf < 1 || cfg->pharm_nf > 16 || cfg->rec_nf < 1) return bad("pharm_nf must be in 1..16, rec_nf >= 1");
+    if (cfg->n_convs < 1 || cfg->n_message_gvps < 1 || cfg->n_message_gvps > PF_MAX_GVPS || cfg->n_update_gvps < 1 ||
+        cfg->n_update_gvps > PF_MAX_GVPS || cfg->n_noise_gvps < 1 || cfg->n_noise_gvps > PF_MAX_GVPS)
+        return bad("layer counts out of range");
+    if (cfg->ff_k < 0 || cfg->ff_k > PF_MAXK || cfg->pf_k < 0 || cfg->pf_k > PF_MAXK) return bad("ff_k / pf_k must be in 0..16");
+    if (cfg->message_norm_mode < 0 || cfg->message_norm_mode > 2) return bad("bad message_norm_mode");
+    if (cfg->message_norm_mode == PF_NORM_VALUE && !(cfg->message_norm_value > 0)) return bad("message_norm_value must be > 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_create_error = "no HIP device available (libpfdyn has no CPU fallback)";
+        return PF_ERR_HIP;
+    }
+    pf_handle* h = new pf_handle();
+    h->cfg = *cfg;
+    *out = h;
+    return PF_OK;
+}
+
+void pf_destroy(pf_handle* h) {
+    if (!h) return;
+    free_ws(h);
+    if (h->d_w) (void)hipFree(h->d_w);
+    if (h->d_gvp) (void)hipFree(h->d_gvp);
+    delete h;
+}
+
+int pf_set_weight(pf_handle* h, const char* name, const float* host_data, int32_t ndim, const int64_t* shape) {
+    if (!h || !name) return PF_ERR_ARG;
+    int64_t n = 1;
+    RawTensor t;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= shape[i]; }
+    if (n == 0 || std::string(name) == "gamma.gamma") return PF_OK;     // dropout dummy_param / schedule table
+    if (!host_data) PF_FAIL(h, PF_ERR_ARG, "null data for %s", name);
+    t.data.assign(host_data, host_data + n);
+    h->raw[name] = std::move(t);
+    h->committed = false;
+    return PF_OK;
+}
+
+int pf_commit_weights(pf_handle* h) {
+    if (!h) return PF_ERR_ARG;
+    const pf_config& c = h->cfg;
+    const auto exp = expected_tensors(c);
+    for (const auto& kv : exp) {
+        auto it = h->raw.find(kv.first);
+        if (it == h->raw.end()) PF_FAIL(h, PF_ERR_WEIGHT, "missing weight tensor %s", kv.first.c_str());
+        if (it->second.shape != kv.second) PF_FAIL(h, PF_ERR_WEIGHT, "wrong shape for %s", kv.first.c_str());
+    }
+    if (h->raw.size() != exp.size()) {
+        for (const auto& kv : h->raw) {
+            bool found = false;
+            for (const auto& e : exp) if (e.first == kv.first) { found = true; break; }
+            if (!found) PF_FAIL(h, PF_ERR_WEIGHT, "unexpected weight tensor %s", kv.first.c_str());
+        }
+    }
+    h->h_w.clear();
+    h->h_gvp.clear();
+    std::vector<GvpOff> offs;
+    for (int l = 0; l < c.n_convs; ++l)
+        for (int et = 0; et < 4; ++et)
+            for (int j = 0; j < c.n_message_gvps; ++j) offs.push_back(pack_gvp(h, msg_spec(c, l, et, j)));
+    h->n_msg_tot = (int)offs.size();
+    for (int l = 0; l < c.n_convs; ++l)
+        for (int nt = 0; nt < 2; ++nt)
+            for (int j = 0; j < c.n_update_gvps; ++j) offs.push_back(pack_gvp(h, upd_spec(c, l, nt, j)));
+    h->n_upd_tot = (int)offs.size() - h->n_msg_tot;
+    for (int k = 0; k < c.n_noise_gvps; ++k) offs.push_back(pack_gvp(h, head_spec(c, k)));
+    for (int nt = 0; nt < 2; ++nt) {
+        const std::string p = std::string("dynamics.") + kNtKey[nt] + "_encoder.";
+        h->enc_w[nt] = push(h->h_w, h->raw[p + "0.weight"].data);
+        h->enc_b[nt] = push(h->h_w, h->raw[p + "0.bias"].data);
+        h->enc_lw[nt] = push(h->h_w, h->raw[p + "2.weight"].data);
+        h->enc_lb[nt] = push(h->h_w, h->raw[p + "2.bias"].data);
+    }
+    h->ln_off.assign((size_t)c.n_convs * 2 * 4, 0);
+    for (int l = 0; l < c.n_convs; ++l)
+        for (int nt = 0; nt < 2; ++nt) {
+            size_t* lo = &h->ln_off[(size_t)(l * 2 + nt) * 4];
+            const std::string p1 = conv_prefix(l) + "message_layer_norms." + kNtKey[nt] + ".feat_norm.";
+            const std::string p2 = conv_prefix(l) + "update_layer_norms." + kNtKey[nt] + ".feat_norm.";
+            lo[0] = push(h->h_w, h->raw[p1 + "weight"].data);
+            lo[1] = push(h->h_w, h->raw[p1 + "bias"].data);
+            lo[2] = push(h->h_w, h->raw[p2 + "weight"].data);
+            lo[3] = push(h->h_w, h->raw[p2 + "bias"].data);
+        }
+    {   // to_scalar_output as A fragments: K = 64 (32 k-steps), rows = outputs
+        const RawTensor& W = h->raw["dynamics.noise_predictor.noise_predictor.to_scalar_output.weight"];
+        std::vector<float> a((size_t)32 * 64, 0.f);
+        for (int ks = 0; ks < 32; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, hl = lane >> 5;
+                const int k = 32 * (ks / 16) + rho(ks % 16, hl);
+                a[(size_t)ks * 64 + lane] = i < c.pharm_nf ? W.data[(size_t)i * 64 + k] : 0.f;
+            }
+        h->out_a = push(h->h_w, a);
+        h->out_b = push(h->h_w, h->raw["dynamics.noise_predictor.noise_predictor.to_scalar_output.bias"].data);
+    }
+    while (h->h_w.size() % 64) h->h_w.push_back(0.f);
+    if (h->d_w) { (void)hipFree(h->d_w); h->d_w = nullptr; }
+    if (h->d_gvp) { (void)hipFree(h->d_gvp); h->d_gvp = nullptr; }
+    PF_HIP(h, hipMalloc((void**)&h->d_w, h->h_w.size() * sizeof(float)));
+    PF_HIP(h, hipMemcpy(h->d_w, h->h_w.data(), h->h_w.size() * sizeof(float), hipMemcpyHostToDevice));
+    for (const GvpOff& o : offs) {
+        GvpW g;
+        g.wh = h->d_w + o.wh; g.wu = h->d_w + o.wu; g.a_main = h->d_w + o.a_main; g.b_main = h->d_w + o.b_main;
+        g.a_gate = h->d_w + o.a_gate; g.b_gate = h->d_w + o.b_gate;
+        h->h_gvp.push_back(g);
+    }
+    PF_HIP(h, hipMalloc((void**)&h->d_gvp, h->h_gvp.size() * sizeof(GvpW)));
+    PF_HIP(h, hipMemcpy(h->d_gvp, h->h_gvp.data(), h->h_gvp.size() * sizeof(GvpW), hipMemcpyHostToDevice));
+    h->h_w.clear();
+    h->h_w.shrink_to_fit();
+    h->committed = true;
+    return PF_OK;
+}
+
+int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const int32_t* pharm_ptr,
+                        const float* dev_prot_x, const float* dev_prot_h, int64_t n_pp, const int32_t* pp_src,
+                        const int32_t* pp_dst, pf_stream stream) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (B < 1 || !prot_ptr || !pharm_ptr || !dev_prot_x || !dev_prot_h || n_pp < 0 || (n_pp && (!pp_src || !pp_dst)))
+        PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_batch: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const pf_config& c = h->cfg;
+    if (prot_ptr[0] != 0 || pharm_ptr[0] != 0) PF_FAIL(h, PF_ERR_ARG, "ptr arrays must start at 0");
+    for (int g = 0; g < B; ++g) {
+        if (prot_ptr[g + 1] < prot_ptr[g] || pharm_ptr[g + 1] < pharm_ptr[g]) PF_FAIL(h, PF_ERR_ARG, "ptr arrays must be non-decreasing");
+        if (pharm_ptr[g + 1] - pharm_ptr[g] > PF_MAXF)
+            PF_FAIL(h, PF_ERR_ARG, "graph %d has %d pharmacophore centers (limit %d)", g, pharm_ptr[g + 1] - pharm_ptr[g], PF_MAXF);
+    }
+    free_ws(h);
+    h->B = B; h->Np = prot_ptr[B]; h->Nf = pharm_ptr[B]; h->N = h->Np + h->Nf; h->Epp = n_pp;
+    h->h_prot_ptr.assign(prot_ptr, prot_ptr + B + 1);
+    h->h_pharm_ptr.assign(pharm_ptr, pharm_ptr + B + 1);
+    const int Np = h->Np, Nf = h->Nf, N = h->N;
+    // ---- host-side tables
+    std::vector<int> gid(N);
+    for (int g = 0; g < B; ++g) {
+        for (int i = prot_ptr[g]; i < prot_ptr[g + 1]; ++i) gid[i] = g;
+        for (int i = pharm_ptr[g]; i < pharm_ptr[g + 1]; ++i) gid[Np + i] = g;
+    }
+    // pp edges sorted by destination (stable counting sort): CSR-by-dst
+    std::vector<int> in_start((size_t)2 * N, 0), in_cnt((size_t)2 * N, 0);
+    std::vector<int> deg(Np + 1, 0);
+    for (int64_t e = 0; e < n_pp; ++e) {
+        if (pp_src[e] < 0 || pp_src[e] >= Np || pp_dst[e] < 0 || pp_dst[e] >= Np) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld out of range", (long long)e);
+        if (gid[pp_src[e]] != gid[pp_dst[e]]) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld crosses graphs", (long long)e);
+        deg[pp_dst[e] + 1]++;
+    }
+    for (int i = 0; i < Np; ++i) deg[i + 1] += deg[i];
+    std::vector<int> pp_cnt(B, 0);
+    // capacity of dynamic regions
+    h->h_reg.assign((size_t)3 * B, 0);
+    h->h_cap.assign((size_t)3 * B, 0);
+    int64_t cursor = n_pp;
+    for (int et = 0; et < 3; ++et)
+        for (int g = 0; g < B; ++g) {
+            const int np = prot_ptr[g + 1] - prot_ptr[g], nf = pharm_ptr[g + 1] - pharm_ptr[g];
+            int cap;
+            if (et == ET_FF) cap = c.ff_k > 0 ? nf * std::min(c.ff_k, std::max(nf - 1, 0)) : nf * std::max(nf - 1, 0);
+            else cap = c.pf_k > 0 ? nf * std::min(c.pf_k, np) : nf * np;
+            h->h_reg[(size_t)et * B + g] = (int)cursor;
+            h->h_cap[(size_t)et * B + g] = cap;
+            cursor += cap;
+        }
+    if (cursor > 0x7fffffffLL / 128) PF_FAIL(h, PF_ERR_ARG, "edge capacity too large");
+    h->Ecap = cursor;
+    const int64_t Ecap = std::max<int64_t>(cursor, 1);
+    std::vector<int> esrc(Ecap, 0), edst(Ecap, 0);
+    {
+        std::vector<int> fill(deg.begin(), deg.end() - 1);
+        for (int64_t e = 0; e < n_pp; ++e) {
+            const int pos = fill[pp_dst[e]]++;
+            esrc[pos] = pp_src[e];
+            edst[pos] = pp_dst[e];
+            pp_cnt[gid[pp_dst[e]]]++;
+        }
+        for (int i = 0; i < Np; ++i) { in_start[(size_t)N + i] = deg[i]; in_cnt[(size_t)N + i] = deg[i + 1] - deg[i]; }
+    }
+    // tiles: dynamic etypes first (they feed the short pharm-side chain), then pp
+    std::vector<EdgeTile> et_tiles;
+    for (int et = 0; et < 3; ++et)
+        for (int g = 0; g < B; ++g) {
+            const int cap = h->h_cap[(size_t)et * B + g], reg = h->h_reg[(size_t)et * B + g];
+            for (int o = 0; o < cap; o += 32) et_tiles.push_back({reg + o, std::min(32, cap - o), et, et * B + g, o});
+        }
+    for (int64_t o = 0; o < n_pp; o += 32) et_tiles.push_back({(int)o, (int)std::min<int64_t>(32, n_pp - o), ET_PP, -1, 0});
+    std::vector<NodeTile> n_tiles, h_tiles;
+    for (int o = 0; o < Nf; o += 32) {
+        n_tiles.push_back({Np + o, std::min(32, Nf - o), 1});
+        h_tiles.push_back({Np + o, std::min(32, Nf - o), 1});
+    }
+    for (int o = 0; o < Np; o += 32) n_tiles.push_back({o, std::min(32, Np - o), 0});
+    h->n_edge_tiles = (int)et_tiles.size();
+    h->n_node_tiles = (int)n_tiles.size();
+    h->n_head_tiles = (int)h_tiles.size();
+    // ---- one workspace allocation
+    size_t bytes = 0;
+    auto need = [&](size_t b) { bytes += (b + 255) & ~size_t(255); };
+    need((B + 1) * 4); need((B + 1) * 4); need((size_t)N * 4); need((size_t)3 * B * 4); need((size_t)3 * B * 4);
+    need(Ecap * 4); need(Ecap * 4); need((size_t)2 * N * 4); need((size_t)2 * N * 4); need((size_t)B * 4);
+    need(et_tiles.size() * sizeof(EdgeTile) + 256); need(n_tiles.size() * sizeof(NodeTile) + 256); need(h_tiles.size() * sizeof(NodeTile) + 256);
+    need((size_t)N * 16); need((size_t)Np * 3 * 4 + 16); need((size_t)Np * c.rec_nf * 4 + 16); need((size_t)Nf * c.pharm_nf * 4 + 16); need((size_t)B * 4);
+    need((size_t)N * PF_S * 4); need((size_t)N * PF_S * 4); need((size_t)N * 48 * 4); need((size_t)N * 48 * 4);
+    need((size_t)Ecap * PF_S * 4); need((size_t)Ecap * 48 * 4);
+    need((size_t)Nf * c.pharm_nf * 4 + 16); need((size_t)Nf * 3 * 4 + 16); need((size_t)B * 3 * 4); need((size_t)B * 3 * 4); need((size_t)2 * B * 4);
+    PF_HIP(h, hipMalloc(&h->d_ws, bytes + 4096));
+    char* cur = reinterpret_cast<char*>(h->d_ws);
+    h->d_prot_ptr = carve<int>(cur, B + 1); h->d_pharm_ptr = carve<int>(cur, B + 1); h->d_gid = carve<int>(cur, N);
+    h->d_reg = carve<int>(cur, (size_t)3 * B); h->d_dyn_cnt = carve<int>(cur, (size_t)3 * B);
+    h->d_esrc = carve<int>(cur, Ecap); h->d_edst = carve<int>(cur, Ecap);
+    h->d_in_start = carve<int>(cur, (size_t)2 * N); h->d_in_cnt = carve<int>(cur, (size_t)2 * N); h->d_pp_cnt = carve<int>(cur, B);
+    h->d_edge_tiles = carve<EdgeTile>(cur, et_tiles.size() + 16); h->d_node_tiles = carve<NodeTile>(cur, n_tiles.size() + 16);
+    h->d_head_tiles = carve<NodeTile>(cur, h_tiles.size() + 16);
+    h->d_xn = carve<float4>(cur, N); h->d_prot_x0 = carve<float>(cur, (size_t)Np * 3 + 4); h->d_prot_h0 = carve<float>(cur, (size_t)Np * c.rec_nf + 4);
+    h->d_pharm_h = carve<float>(cur, (size_t)Nf * c.pharm_nf + 4); h->d_t = carve<float>(cur, B);
+    h->d_h[0] = carve<float>(cur, (size_t)N * PF_S); h->d_h[1] = carve<float>(cur, (size_t)N * PF_S);
+    h->d_v[0] = carve<float>(cur, (size_t)N * 48); h->d_v[1] = carve<float>(cur, (size_t)N * 48);
+    h->d_msg_s = carve<float>(cur, (size_t)Ecap * PF_S); h->d_msg_v = carve<float>(cur, (size_t)Ecap * 48);
+    h->d_eps_h = carve<float>(cur, (size_t)Nf * c.pharm_nf + 4); h->d_eps_x = carve<float>(cur, (size_t)Nf * 3 + 4);
+    h->d_com_init = carve<float>(cur, (size_t)B * 3); h->d_com_tmp = carve<float>(cur, (size_t)B * 3); h->d_gnorm = carve<float>(cur, (size_t)2 * B);
+    // ---- uploads (synchronous: these are small tables; pageable host memory)
+    PF_HIP(h, hipMemcpy(h->d_prot_ptr, prot_ptr, (B + 1) * 4, hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemcpy(h->d_pharm_ptr, pharm_ptr, (B + 1) * 4, hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemcpy(h->d_gid, gid.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemcpy(h->d_reg, h->h_reg.data(), (size_t)3 * B * 4, hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemset(h->d_dyn_cnt, 0, (size_t)3 * B * 4));
+    PF_HIP(h, hipMemcpy(h->d_esrc, esrc.data(), (size_t)Ecap * 4, hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemcpy(h->d_edst, edst.data(), (size_t)Ecap * 4, hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemcpy(h->d_in_start, in_start.data(), (size_t)2 * N * 4, hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemcpy(h->d_in_cnt, in_cnt.data(), (size_t)2 * N * 4, hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemcpy(h->d_pp_cnt, pp_cnt.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+    if (!et_tiles.empty()) PF_HIP(h, hipMemcpy(h->d_edge_tiles, et_tiles.data(), et_tiles.size() * sizeof(EdgeTile), hipMemcpyHostToDevice));
+    if (!n_tiles.empty()) PF_HIP(h, hipMemcpy(h->d_node_tiles, n_tiles.data(), n_tiles.size() * sizeof(NodeTile), hipMemcpyHostToDevice));
+    if (!h_tiles.empty()) PF_HIP(h, hipMemcpy(h->d_head_tiles, h_tiles.data(), h_tiles.size() * sizeof(NodeTile), hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemsetAsync(h->d_v[0], 0, (size_t)N * 48 * 4, s));
+    PF_HIP(h, hipMemsetAsync(h->d_gnorm, 0, (size_t)2 * B * 4, s));
+    pfk_copy(dev_prot_x, h->d_prot_x0, (size_t)Np * 3, s);
+    pfk_copy(dev_prot_h, h->d_prot_h0, (size_t)Np * c.rec_nf, s);
+    pfk_load_coords(h->d_prot_x0, h->d_xn, Np, h->d_gid, nullptr, 0.f, s);
+    PF_HIP(h, hipStreamSynchronize(s));
+    h->have_batch = true;
+    h->sampling = false;
+    return PF_OK;
+}
+
+int64_t pf_build_pp_edges(pf_handle* h, int32_t B, const int32_t* prot_ptr, const float* dev_prot_x, int32_t max_nb,
+                          int32_t* host_src, int32_t* host_dst, int64_t capacity, pf_stream stream) {
+    if (!h || B < 1 || !prot_ptr || !dev_prot_x) return PF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int Np = prot_ptr[B];
+    float4* xn = nullptr; int *dptr = nullptr, *ddeg = nullptr, *doff = nullptr, *dsrc = nullptr, *ddst = nullptr;
+    std::vector<int> deg(std::max(Np, 1)), off(std::max(Np, 1) + 1, 0);
+    int64_t total = 0;
+    int rc = PF_OK;
+    auto cleanup = [&]() {
+        if (xn) (void)hipFree(xn); if (dptr) (void)hipFree(dptr); if (ddeg) (void)hipFree(ddeg);
+        if (doff) (void)hipFree(doff); if (dsrc) (void)hipFree(dsrc); if (ddst) (void)hipFree(ddst);
+    };
+#define PF_HIP2(call) do { hipError_t _e = (call); if (_e != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(_e); cleanup(); return PF_ERR_HIP; } } while (0)
+    PF_HIP2(hipMalloc((void**)&xn, (size_t)std::max(Np, 1) * 16));
+    PF_HIP2(hipMalloc((void**)&dptr, (size_t)(B + 1) * 4));
+    PF_HIP2(hipMalloc((void**)&ddeg, (size_t)std::max(Np, 1) * 4));
+    PF_HIP2(hipMalloc((void**)&doff, (size_t)std::max(Np, 1) * 4));
+    PF_HIP2(hipMemcpy(dptr, prot_ptr, (size_t)(B + 1) * 4, hipMemcpyHostToDevice));
+    pfk_load_coords(dev_prot_x, xn, Np, nullptr, nullptr, 0.f, s);
+    const float r2 = h->cfg.cutoff_pp * h->cfg.cutoff_pp;
+    pfk_pp_radius(xn, dptr, B, r2, max_nb, ddeg, nullptr, nullptr, nullptr, 0, s);
+    PF_HIP2(hipStreamSynchronize(s));
+    PF_HIP2(hipMemcpy(deg.data(), ddeg, (size_t)Np * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < Np; ++i) { off[i] = (int)total; total += deg[i]; }
+    if (host_src && host_dst) {
+        if (capacity < total) { cleanup(); h->err = "pf_build_pp_edges: capacity too small"; return PF_ERR_ARG; }
+        if (total > 0) {
+            PF_HIP2(hipMalloc((void**)&dsrc, (size_t)total * 4));
+            PF_HIP2(hipMalloc((void**)&ddst, (size_t)total * 4));
+            PF_HIP2(hipMemcpy(doff, off.data(), (size_t)Np * 4, hipMemcpyHostToDevice));
+            pfk_pp_radius(xn, dptr, B, r2, max_nb, ddeg, doff, dsrc, ddst, 1, s);
+            PF_HIP2(hipStreamSynchronize(s));
+            PF_HIP2(hipMemcpy(host_src, dsrc, (size_t)total * 4, hipMemcpyDeviceToHost));
+            PF_HIP2(hipMemcpy(host_dst, ddst, (size_t)total * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    (void)rc;
+    cleanup();
+    return total;
+}
+
+static int load_state(pf_handle* h, const float* dev_prot_x, const float* dev_pharm_x, const float* dev_pharm_h, hipStream_t s) {
+    if (dev_prot_x) pfk_load_coords(dev_prot_x, h->d_xn, h->Np, h->d_gid, nullptr, 0.f, s);
+    if (dev_pharm_x) pfk_load_coords(dev_pharm_x, h->d_xn + h->Np, h->Nf, h->d_gid, nullptr, 0.f, s);
+    if (dev_pharm_h) pfk_copy(dev_pharm_h, h->d_pharm_h, (size_t)h->Nf * h->cfg.pharm_nf, s);
+    return PF_OK;
+}
+
+int pf_dynamics_forward(pf_handle* h, const float* dev_prot_x, const float* dev_pharm_x, const float* dev_pharm_h,
+                        const float* dev_t, float* dev_eps_h, float* dev_eps_x, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!dev_pharm_x || !dev_pharm_h || !dev_t || !dev_eps_h || !dev_eps_x) PF_FAIL(h, PF_ERR_ARG, "pf_dynamics_forward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    load_state(h, dev_prot_x, dev_pharm_x, dev_pharm_h, s);
+    pfk_copy(dev_t, h->d_t, (size_t)h->B, s);
+    return run_dynamics(h, dev_eps_h, dev_eps_x, s);
+}
+
+int pf_sample_begin(pf_handle* h, const float* dev_init_pharm_com, const float* dev_noise0, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!dev_noise0) PF_FAIL(h, PF_ERR_ARG, "pf_sample_begin: null noise");
+    hipStream_t s = (hipStream_t)stream;
+    // init_prot_com = mean of the ORIGINAL protein coordinates (pharmacodiff.py:442)
+    pfk_load_coords(h->d_prot_x0, h->d_xn, h->Np, h->d_gid, nullptr, 0.f, s);
+    pfk_segment_mean(h->d_xn, h->d_prot_ptr, 0, h->B, h->d_com_init, s);
+    const float* shift = dev_init_pharm_com ? dev_init_pharm_com : h->d_com_init;      // :448-452
+    pfk_load_coords(h->d_prot_x0, h->d_xn, h->Np, h->d_gid, shift, -1.f, s);
+    pfk_load_noise0(dev_noise0, h->d_xn + h->Np, h->d_pharm_h, h->Nf, h->cfg.pharm_nf, s);  // :455-456
+    h->sampling = true;
+    return PF_OK;
+}
+
+int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noise, int32_t ep_coord, int32_t ep_feat,
+                    pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!coef || !dev_noise) PF_FAIL(h, PF_ERR_ARG, "pf_denoise_step: null argument");
+    if (!h->sampling) PF_FAIL(h, PF_ERR_STATE, "pf_denoise_step before pf_sample_begin");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t tbits;
+    memcpy(&tbits, &coef->t, 4);
+    PF_HIP(h, hipMemsetD32Async((hipDeviceptr_t)h->d_t, (int)tbits, (size_t)h->B, s));
+    rc = run_dynamics(h, h->d_eps_h, h->d_eps_x, s);
+    if (rc) return rc;
+    StepParams sp{};
+    sp.B = h->B; sp.Np_tot = h->Np; sp.prot_ptr = h->d_prot_ptr; sp.pharm_ptr = h->d_pharm_ptr;
+    sp.xn = h->d_xn; sp.pharm_h = h->d_pharm_h; sp.eps_h = h->d_eps_h; sp.eps_x = h->d_eps_x; sp.noise = dev_noise;
+    sp.nf = h->cfg.pharm_nf;
+    sp.a_ts = coef->alpha_t_given_s; sp.var = coef->var_terms; sp.sigma = coef->sigma;
+    sp.ep_zt = coef->ep_zt; sp.ep_pred = coef->ep_pred; sp.ep_coord = ep_coord; sp.ep_feat = ep_feat;
+    pfk_step_update(&sp, s);
+    return PF_OK;
+}
+
+int pf_sample_frame(pf_handle* h, float feat_norm_constant, float* dev_x, float* dev_h, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!h->sampling) PF_FAIL(h, PF_ERR_STATE, "no sampling run in progress");
+    hipStream_t s = (hipStream_t)stream;
+    pfk_segment_mean(h->d_xn, h->d_prot_ptr, 0, h->B, h->d_com_tmp, s);
+    if (dev_x) pfk_export_coords(h->d_xn, h->Np, h->Nf, h->d_gid, h->d_com_init, h->d_com_tmp, dev_x, s);
+    if (dev_h) pfk_scale_copy(h->d_pharm_h, dev_h, (size_t)h->Nf * h->cfg.pharm_nf, feat_norm_constant, s);
+    return PF_OK;
+}
+
+int pf_sample_end(pf_handle* h, float feat_norm_constant, float* dev_x0, float* dev_h0, pf_stream stream) {
+    // x_0 = x_t - protein COM + initial protein COM ; h_0 = h_t * norm constant  (pharmacodiff.py:480-488)
+    return pf_sample_frame(h, feat_norm_constant, dev_x0, dev_h0, stream);
+}
+
+int pf_sample(pf_handle* h, int32_t n_steps, const pf_step_coef* host_coef, const float* dev_noise,
+              const float* dev_init_pharm_com, int32_t ep_coord, int32_t ep_feat, float feat_norm_constant,
+              float* dev_x0, float* dev_h0, float* dev_traj_x, float* dev_traj_h, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (n_steps < 0 || (n_steps && !host_coef) || !dev_noise) PF_FAIL(h, PF_ERR_ARG, "pf_sample: bad argument");
+    const size_t row = (size_t)h->Nf * (3 + h->cfg.pharm_nf);
+    const size_t fx = (size_t)h->Nf * 3, fh = (size_t)h->Nf * h->cfg.pharm_nf;
+    rc = pf_sample_begin(h, dev_init_pharm_com, dev_noise, stream);
+    if (rc) return rc;
+    if (dev_traj_x || dev_traj_h) {
+        rc = pf_sample_frame(h, feat_norm_constant, dev_traj_x, dev_traj_h, stream);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < n_steps; ++i) {
+        rc = pf_denoise_step(h, host_coef + i, dev_noise + (size_t)(i + 1) * row, ep_coord, ep_feat, stream);
+        if (rc) return rc;
+        if (dev_traj_x || dev_traj_h) {
+            rc = pf_sample_frame(h, feat_norm_constant, dev_traj_x ? dev_traj_x + (size_t)(i + 1) * fx : nullptr,
+                                 dev_traj_h ? dev_traj_h + (size_t)(i + 1) * fh : nullptr, stream);
+            if (rc) return rc;
+        }
+    }
+    return pf_sample_end(h, feat_norm_constant, dev_x0, dev_h0, stream);
+}
+
+int64_t pf_debug_get_edges(pf_handle* h, int32_t etype, int32_t* host_src, int32_t* host_dst, int64_t capacity,
+                           pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (etype < 0 || etype > 3) PF_FAIL(h, PF_ERR_ARG, "bad etype");
+    hipStream_t s = (hipStream_t)stream;
+    PF_HIP(h, hipStreamSynchronize(s));
+    const int B = h->B, Np = h->Np;
+    std::vector<int> cnt((size_t)3 * B);
+    PF_HIP(h, hipMemcpy(cnt.data(), h->d_dyn_cnt, (size_t)3 * B * 4, hipMemcpyDeviceToHost));
+    int64_t total = 0;
+    if (etype == ET_PP) total = h->Epp;
+    else for (int g = 0; g < B; ++g) total += cnt[(size_t)etype * B + g];
+    if (!host_src || !host_dst) return total;
+    if (capacity < total) PF_FAIL(h, PF_ERR_ARG, "capacity too small");
+    std::vector<int> es(std::max<int64_t>(h->Ecap, 1)), ed(std::max<int64_t>(h->Ecap, 1));
+    PF_HIP(h, hipMemcpy(es.data(), h->d_esrc, (size_t)h->Ecap * 4, hipMemcpyDeviceToHost));
+    PF_HIP(h, hipMemcpy(ed.data(), h->d_edst, (size_t)h->Ecap * 4, hipMemcpyDeviceToHost));
+    const bool src_pharm = (etype == ET_FF || etype == ET_FP), dst_pharm = (etype == ET_FF || etype == ET_PF);
+    int64_t o = 0;
+    auto emit = [&](int64_t a, int64_t n) {
+        for (int64_t e = a; e < a + n; ++e, ++o) {
+            host_src[o] = es[e] - (src_pharm ? Np : 0);
+            host_dst[o] = ed[e] - (dst_pharm ? Np : 0);
+        }
+    };
+    if (etype == ET_PP) emit(0, h->Epp);
+    else for (int g = 0; g < B; ++g) emit(h->h_reg[(size_t)etype * B + g], cnt[(size_t)etype * B + g]);
+    return total;
+}
+
+int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, const float* dev_pharm_x,
+                        const float* hp_, const float* vp_, const float* hf_, const float* vf_,
+                        float* ohp, float* ovp, float* ohf, float* ovf, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    const pf_config& c = h->cfg;
+    if (layer < 0 || layer >= c.n_convs) PF_FAIL(h, PF_ERR_ARG, "bad layer");
+    hipStream_t s = (hipStream_t)stream;
+    load_state(h, dev_prot_x, dev_pharm_x, nullptr, s);
+    const size_t Np = h->Np, Nf = h->Nf;
+    pfk_copy(hp_, h->d_h[0], Np * PF_S, s);
+    pfk_copy(hf_, h->d_h[0] + Np * PF_S, Nf * PF_S, s);
+    pfk_copy(vp_, h->d_v[0], Np * 48, s);
+    pfk_copy(vf_, h->d_v[0] + Np * 48, Nf * 48, s);
+    BuildParams bp{};
+    bp.B = h->B; bp.Np_tot = h->Np; bp.prot_ptr = h->d_prot_ptr; bp.pharm_ptr = h->d_pharm_ptr; bp.xn = h->d_xn;
+    bp.reg = h->d_reg; bp.dyn_cnt = h->d_dyn_cnt; bp.esrc = h->d_esrc; bp.edst = h->d_edst;
+    bp.in_start = h->d_in_start; bp.in_cnt = h->d_in_cnt; bp.N = h->N; bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
+    bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
+    bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
+    pfk_build_edges(&bp, s);
+    EdgeParams e{};
+    e.tiles = h->d_edge_tiles; e.ntiles = h->n_edge_tiles; e.dyn_cnt = h->d_dyn_cnt; e.esrc = h->d_esrc; e.edst = h->d_edst;
+    e.xn = h->d_xn; e.h = h->d_h[0]; e.v = h->d_v[0]; e.msg_s = h->d_msg_s; e.msg_v = h->d_msg_v;
+    e.w = h->d_gvp + h->msg_base(layer, 0); e.n_gvps = c.n_message_gvps;
+    linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
+    e.rbf_sigma = c.rbf_dmax / (float)c.rbf_dim;
+    pfk_edge_msg(&e, 0, s);
+    NodeParams n{};
+    n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles; n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
+    n.msg_s = h->d_msg_s; n.msg_v = h->d_msg_v; n.h_in = h->d_h[0]; n.v_in = h->d_v[0]; n.h_out = h->d_h[1]; n.v_out = h->d_v[1];
+    n.gid = h->d_gid; n.gnorm = h->d_gnorm; n.B = h->B; n.norm_mode = c.message_norm_mode; n.norm_value = c.message_norm_value;
+    for (int nt = 0; nt < 2; ++nt) {
+        const size_t* lo = &h->ln_off[(size_t)(layer * 2 + nt) * 4];
+        n.w[nt].ln1_w = h->d_w + lo[0]; n.w[nt].ln1_b = h->d_w + lo[1]; n.w[nt].ln2_w = h->d_w + lo[2]; n.w[nt].ln2_b = h->d_w + lo[3];
+        n.w[nt].upd = h->d_gvp + h->upd_base(layer, nt);
+    }
+    n.n_upd = c.n_update_gvps;
+    pfk_node_update(&n, 0, s);
+    pfk_copy(h->d_h[1], ohp, Np * PF_S, s);
+    pfk_copy(h->d_h[1] + Np * PF_S, ohf, Nf * PF_S, s);
+    pfk_copy(h->d_v[1], ovp, Np * 48, s);
+    pfk_copy(h->d_v[1] + Np * 48, ovf, Nf * 48, s);
+    // the zero-vector invariant of buffer 0 (layer-0 kernels never read it, later layers overwrite it)
+    PF_HIP(h, hipMemsetAsync(h->d_v[0], 0, (size_t)h->N * 48 * 4, s));
+    hipError_t er = hipGetLastError();
+    if (er != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(er));
+    return PF_OK;
+}
+
+int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    PF_HIP(h, hipStreamSynchronize(s));
+    const pf_config& c = h->cfg;
+    std::vector<int> cnt((size_t)3 * h->B);
+    PF_HIP(h, hipMemcpy(cnt.data(), h->d_dyn_cnt, cnt.size() * 4, hipMemcpyDeviceToHost));
+    int64_t ne[4] = {0, 0, 0, h->Epp};
+    for (int et = 0; et < 3; ++et) for (int g = 0; g < h->B; ++g) ne[et] += cnt[(size_t)et * h->B + g];
+    const double E = (double)(ne[0] + ne[1] + ne[2] + ne[3]);
+    // FLOPs at 2/MAC
+    auto gvp_flops = [](int vi, int vo, int si, int so) {
+        const int hd = std::max(vi, vo);
+        return 2.0 * (vi * hd * 3 + hd * vo * 3 + (double)(hd + si) * so + (double)so * vo);
+    };
+    const double g0 = gvp_flops(17, 16, 144, 128), gg = gvp_flops(16, 16, 128, 128), gl = gvp_flops(16, 1, 128, 64);
+    const double per_edge = g0 + (c.n_message_gvps - 1) * gg;
+    const double per_node = c.n_update_gvps * gg;
+    const double head = (c.n_noise_gvps - 1) * gg + gl + 2.0 * 64 * c.pharm_nf;
+    const double enc = 2.0 * 128 * ((double)h->Np * (c.rec_nf + 1) + (double)h->Nf * (c.pharm_nf + 1));
+    if (flops) *flops = c.n_convs * (E * per_edge + (double)h->N * per_node) + (double)h->Nf * head + enc;
+    if (bytes) *bytes = c.n_convs * (E * 736.0 + (double)h->N * 1420.0);
+    if (n_edges) for (int i = 0; i < 4; ++i) n_edges[i] = ne[i];
+    return PF_OK;
+}
+
+}  // extern "C"

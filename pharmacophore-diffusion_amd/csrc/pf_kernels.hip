@@ -1,0 +1,878 @@
+// pf_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the PharmacoForge denoising path.
+//
+// Reference being restated (paths relative to the reference root):
+//   GVP.forward                      pharmacoforge/models/gvp.py:89-116
+//   GVPLayerNorm.forward             pharmacoforge/models/gvp.py:159-166
+//   GVPMultiEdgeConv.forward/message pharmacoforge/models/gvp.py:459-551
+//   PharmRecDynamicsGVP.forward      pharmacoforge/models/dynamics_gvp.py:131-185
+//   add_pharm_edges                  pharmacoforge/models/dynamics_gvp.py:187-227
+//   NoisePredictionBlock.forward     pharmacoforge/models/dynamics_gvp.py:37-42
+//   sample_p_zs_given_zt/com_removal pharmacoforge/models/pharmacodiff.py:380-431, 88-108
+//
+// Every dense layer runs on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32) with the
+// row (edge / node) on the lane, see pf_device.h "F-layout".  No LDS is needed for activations;
+// weights stream from L2 in pre-packed fragment order.
+#include <hip/hip_runtime.h>
+#include "pf_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------
+// One GVP (gvp.py:89-116) on a 32-row tile, row-on-lane.
+//   VI     input vector channels (17 for the first message GVP, else 16); H = VI (= max(VI,VO))
+//   NEXTRA extra scalar inputs that follow the 128 features (16 rbf values for the first message GVP)
+//   VO     output vector channels (16, or 1 for the last noise-head GVP)
+//   NMO    output scalar tiles of 32 (4 -> 128 outputs, 2 -> 64 outputs)
+//   SIG    sigmoid vector activation (identity for the last noise-head GVP)
+//   VROW0  only vector row 0 of the input is non-zero (conv layer 0: node vectors are zero,
+//          dynamics_gvp.py:162-173)
+// Both lanes of a row hold the full vector state (redundantly); scalars are split (F-layout).
+// ---------------------------------------------------------------------------------------------
+template <int VI, int NEXTRA, int VO, int NMO, bool SIG, bool VROW0>
+__device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64], const float* ext,
+                                          const float (&V)[VI * 3], float (&s_out)[NMO * 16],
+                                          float (&V_out)[VO * 3], const int lane) {
+    constexpr int H = VI;
+    constexpr int NSH = (H + 1) / 2;                 // k-steps that carry sh
+    constexpr int NKS = 64 + NEXTRA / 2 + NSH;       // k-steps of to_feats_out
+    constexpr int CH = 8;                            // k-steps per software-pipeline chunk
+    constexpr int NCH = (NKS + CH - 1) / CH;
+    const int hl = lane >> 5;
+    // ---- vector channel: Vh = Wh^T V, sh = |Vh|, Vu = Wu^T Vh        (gvp.py:96-99)
+    float Vh[H * 3];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int vi = 0; vi < (VROW0 ? 1 : VI); ++vi) {
+            const float wv = w.wh[vi * H + hh];
+            a0 = fmaf(wv, V[vi * 3 + 0], a0);
+            a1 = fmaf(wv, V[vi * 3 + 1], a1);
+            a2 = fmaf(wv, V[vi * 3 + 2], a2);
+        }
+        Vh[hh * 3 + 0] = a0; Vh[hh * 3 + 1] = a1; Vh[hh * 3 + 2] = a2;
+    }
+    // this lane feeds sh[2t + hl] into k-step t of the sh block (select at production so that
+    // no register array is ever indexed by a runtime value)
+    float shsel[NSH];
+#pragma unroll
+    for (int t = 0; t < NSH; ++t) {
+        const int e = 2 * t, o = 2 * t + 1;
+        const float ne = sqrtf(fmaxf(Vh[e * 3] * Vh[e * 3] + Vh[e * 3 + 1] * Vh[e * 3 + 1] + Vh[e * 3 + 2] * Vh[e * 3 + 2], 1e-8f));
+        float no = 0.f;
+        if (o < H) no = sqrtf(fmaxf(Vh[o * 3] * Vh[o * 3] + Vh[o * 3 + 1] * Vh[o * 3 + 1] + Vh[o * 3 + 2] * Vh[o * 3 + 2], 1e-8f));
+        shsel[t] = hl ? no : ne;
+    }
+    float Vu[VO * 3];
+#pragma unroll
+    for (int u = 0; u < VO; ++u) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) {
+            const float wv = w.wu[hh * VO + u];
+            a0 = fmaf(wv, Vh[hh * 3 + 0], a0);
+            a1 = fmaf(wv, Vh[hh * 3 + 1], a1);
+            a2 = fmaf(wv, Vh[hh * 3 + 2], a2);
+        }
+        Vu[u * 3 + 0] = a0; Vu[u * 3 + 1] = a1; Vu[u * 3 + 2] = a2;
+    }
+    // ---- scalar channel: feats_out = SiLU(W [s, sh] + b) on the matrix cores  (gvp.py:101-103)
+    f32x16 acc[NMO];
+    {
+        const f32x4 PF_AS1* bp = reinterpret_cast<const f32x4 PF_AS1*>(w.b_main + hl * (NMO * 16));
+#pragma unroll
+        for (int mo = 0; mo < NMO; ++mo)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = bp[mo * 4 + q];
+                acc[mo][4 * q + 0] = b4[0]; acc[mo][4 * q + 1] = b4[1];
+                acc[mo][4 * q + 2] = b4[2]; acc[mo][4 * q + 3] = b4[3];
+            }
+    }
+    typedef float fragA __attribute__((ext_vector_type(NMO)));
+    const fragA PF_AS1* ap = reinterpret_cast<const fragA PF_AS1*>(w.a_main) + lane;
+    fragA abuf[2][CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+        if (i < NKS) abuf[0][i] = ap[i * 64];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if ((c + 1) * CH + i < NKS) abuf[(c + 1) & 1][i] = ap[((c + 1) * CH + i) * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int ks = c * CH + i;
+            if (ks < NKS) {
+                float b;
+                if (ks < 64) b = s_in[ks < 64 ? ks : 0];
+                else if (ks < 64 + NEXTRA / 2) b = ext[ks - 64];
+                else b = shsel[(ks - 64 - NEXTRA / 2) < NSH ? (ks - 64 - NEXTRA / 2) : 0];
+                const fragA a = abuf[c & 1][i];
+#pragma unroll
+                for (int mo = 0; mo < NMO; ++mo) acc[mo] = MFMA(a[mo], b, acc[mo]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mo = 0; mo < NMO; ++mo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_out[mo * 16 + r] = siluf_(acc[mo][r]);
+    // ---- gates: gate = Wg feats_out + bg ; V_out = act(gate) * Vu              (gvp.py:105-111)
+    f32x16 g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = 0.f;
+    {
+        constexpr int NG = NMO * 16;
+        pf_gcf gp = w.a_gate + lane;
+        float gbuf[2][CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) gbuf[0][i] = gp[i * 64];
+#pragma unroll
+        for (int c = 0; c < NG / CH; ++c) {
+            if (c + 1 < NG / CH) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) gbuf[(c + 1) & 1][i] = gp[((c + 1) * CH + i) * 64];
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) g = MFMA(gbuf[c & 1][i], s_out[c * CH + i], g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < VO; ++u) {
+        // rows 16..31 of the packed gate matrix duplicate rows 0..15 with bit 2 flipped, so
+        // each lane of the pair receives all 16 gates (pf_host.cpp: pack_gate)
+        const int r = (u & 3) + 4 * (u >> 3);
+        float gv = (((u >> 2) & 1) == hl) ? g[r] : g[r + 8];
+        gv += w.b_gate[u];
+        if constexpr (SIG) gv = sigmoidf_(gv);
+        V_out[u * 3 + 0] = gv * Vu[u * 3 + 0];
+        V_out[u * 3 + 1] = gv * Vu[u * 3 + 1];
+        V_out[u * 3 + 2] = gv * Vu[u * 3 + 2];
+    }
+}
+
+// load / store a 128-float row in F-layout (this lane's 64 features)
+template <typename P>
+__device__ __forceinline__ void load_row_f(P row, const int hl, float (&s)[64]) {
+    auto p = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)row + 4 * hl);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 x = p[mt * 8 + q * 2];
+            s[mt * 16 + 4 * q + 0] = x[0]; s[mt * 16 + 4 * q + 1] = x[1];
+            s[mt * 16 + 4 * q + 2] = x[2]; s[mt * 16 + 4 * q + 3] = x[3];
+        }
+}
+__device__ __forceinline__ void store_row_f(float* row, const int hl, const float (&s)[64]) {
+    f32x4* p = reinterpret_cast<f32x4*>(row + 4 * hl);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 x;
+            x[0] = s[mt * 16 + 4 * q + 0]; x[1] = s[mt * 16 + 4 * q + 1];
+            x[2] = s[mt * 16 + 4 * q + 2]; x[3] = s[mt * 16 + 4 * q + 3];
+            p[mt * 8 + q * 2] = x;
+        }
+}
+template <typename P>
+__device__ __forceinline__ void load_vec48(P row, float* V) {
+    auto p = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)row);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        const f32x4 x = p[q];
+        V[4 * q + 0] = x[0]; V[4 * q + 1] = x[1]; V[4 * q + 2] = x[2]; V[4 * q + 3] = x[3];
+    }
+}
+// each lane of the pair stores one half (24 floats) of the 48-float vector row
+__device__ __forceinline__ void store_vec48_half(float* row, const int hl, const float (&V)[48]) {
+    f32x4* p = reinterpret_cast<f32x4*>(row + 24 * hl);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        f32x4 x;
+        if (hl) { x[0] = V[24 + 4 * q]; x[1] = V[25 + 4 * q]; x[2] = V[26 + 4 * q]; x[3] = V[27 + 4 * q]; }
+        else    { x[0] = V[4 * q];      x[1] = V[1 + 4 * q];  x[2] = V[2 + 4 * q];  x[3] = V[3 + 4 * q]; }
+        p[q] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Edge messages: gather source rows -> x_diff / distance / RBF -> message GVP chain -> per-edge
+// message rows (gvp.py:472-485, 540-551).  One wave per tile of 32 edge slots, all etypes in one
+// launch.  L0: conv layer 0, node vectors are identically zero.
+// ---------------------------------------------------------------------------------------------
+template <bool L0>
+__global__ __launch_bounds__(256, 1) void k_edge_msg(const EdgeParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+    if (wid >= p.ntiles) return;
+    const EdgeTile t = p.tiles[wid];
+    int nvalid = t.n;
+    if (t.cnt_idx >= 0) {
+        const int c = p.dyn_cnt[t.cnt_idx] - t.rel;
+        nvalid = min(nvalid, max(c, 0));
+    }
+    nvalid = __builtin_amdgcn_readfirstlane(nvalid);
+    if (nvalid <= 0) return;
+    const int et = __builtin_amdgcn_readfirstlane(t.et);
+    const int j = lane & 31, hl = lane >> 5;
+    const int e = t.e0 + min(j, nvalid - 1);          // idle lanes shadow the last valid edge
+    const int src = p.esrc[e], dst = p.edst[e];
+    const float4 xs = p.xn[src], xd = p.xn[dst];
+    // x_diff = x_src - x_dst ; d = sqrt(max(|x_diff|^2, 1e-8)) + 1e-8 ; unit vector ; rbf
+    const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
+    const float d = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+    float V[17 * 3];
+    V[0] = dx / d; V[1] = dy / d; V[2] = dz / d;
+    // this lane feeds rbf[2t + hl] into k-step t of the rbf block
+    float rb[PF_R / 2];
+#pragma unroll
+    for (int k = 0; k < PF_R / 2; ++k) {
+        const float ze = (d - p.rbf_mu[2 * k]) / p.rbf_sigma;
+        const float zo = (d - p.rbf_mu[2 * k + 1]) / p.rbf_sigma;
+        const float re = __expf(-(ze * ze)), ro = __expf(-(zo * zo));
+        rb[k] = hl ? ro : re;
+    }
+    float s[64];
+    load_row_f(p.h + (size_t)src * PF_S, hl, s);
+    if constexpr (!L0) load_vec48(p.v + (size_t)src * 48, V + 3);
+    else {
+#pragma unroll
+        for (int q = 3; q < 51; ++q) V[q] = 0.f;
+    }
+    const GvpW PF_AS1* wt = (const GvpW PF_AS1*)p.w + et * p.n_gvps;
+    float s1[64], V1[48];
+    gvp_apply<17, PF_R, 16, 4, true, L0>(wt[0], s, rb, V, s1, V1, lane);
+    for (int gi = 1; gi < p.n_gvps; ++gi) {
+        float s2[64], V2[48];
+        gvp_apply<16, 0, 16, 4, true, false>(wt[gi], s1, nullptr, V1, s2, V2, lane);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) s1[q] = s2[q];
+#pragma unroll
+        for (int q = 0; q < 48; ++q) V1[q] = V2[q];
+    }
+    if (j < nvalid) {
+        store_row_f(p.msg_s + (size_t)e * PF_S, hl, s1);
+        store_vec48_half(p.msg_v + (size_t)e * 48, hl, V1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Node update: deterministic segmented reduction of the in-edge messages (mean / sum per etype,
+// summed over etypes), residual, GVPLayerNorm, update GVP chain, residual, GVPLayerNorm
+// (gvp.py:488-536).  One wave per tile of 32 nodes of one type.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gvp_layernorm(pf_gcf lw, pf_gcf lb, const int hl, float (&s)[64],
+                                              float (&V)[48]) {
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) sum += s[q];
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / 128.0f);
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) { const float c = s[q] - mean; var = fmaf(c, c, var); }
+    var += __shfl_xor(var, 32);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / 128.0f) + 1e-5f);
+    float w[64], b[64];
+    load_row_f(lw, hl, w);
+    load_row_f(lb, hl, b);
+#pragma unroll
+    for (int q = 0; q < 64; ++q) s[q] = (s[q] - mean) * rstd * w[q] + b[q];
+    float vn = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        vn += fmaxf(V[3 * u] * V[3 * u] + V[3 * u + 1] * V[3 * u + 1] + V[3 * u + 2] * V[3 * u + 2], 1e-8f);
+    const float den = sqrtf(vn * (1.0f / 16.0f) + 1e-5f) + 1e-5f;
+#pragma unroll
+    for (int q = 0; q < 48; ++q) V[q] = V[q] / den;
+}
+
+template <bool L0>
+__global__ __launch_bounds__(256, 1) void k_node_update(const NodeParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+    if (wid >= p.ntiles) return;
+    const NodeTile t = p.tiles[wid];
+    const int nt = __builtin_amdgcn_readfirstlane(t.ntype);
+    const int j = lane & 31, hl = lane >> 5;
+    const bool live = j < t.n;
+    const int n = t.n0 + min(j, t.n - 1);
+    float ms[64], mv[48];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) ms[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 48; ++q) mv[q] = 0.f;
+    for (int slot = 0; slot < 2; ++slot) {
+        const int st = p.in_start[slot * p.N + n];
+        const int c = live ? p.in_cnt[slot * p.N + n] : 0;
+        int cmax = c;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+        cmax = __builtin_amdgcn_readfirstlane(cmax);
+        float as[64], av[48];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) as[q] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 48; ++q) av[q] = 0.f;
+        for (int i = 0; i < cmax; ++i) {
+            if (i < c) {
+                float r[64], rv[48];
+                load_row_f(p.msg_s + (size_t)(st + i) * PF_S, hl, r);
+                load_vec48(p.msg_v + (size_t)(st + i) * 48, rv);
+#pragma unroll
+                for (int q = 0; q < 64; ++q) as[q] += r[q];
+#pragma unroll
+                for (int q = 0; q < 48; ++q) av[q] += rv[q];
+            }
+        }
+        const float sc = (p.norm_mode == 0 && c > 0) ? 1.0f / (float)c : 1.0f;   // fn.mean, zero in-degree -> 0
+#pragma unroll
+        for (int q = 0; q < 64; ++q) ms[q] = fmaf(as[q], sc, ms[q]);
+#pragma unroll
+        for (int q = 0; q < 48; ++q) mv[q] = fmaf(av[q], sc, mv[q]);
+    }
+    float inv_norm = 1.0f;
+    if (p.norm_mode == 1) inv_norm = 1.0f / p.norm_value;
+    else if (p.norm_mode == 2) inv_norm = 1.0f / p.gnorm[nt * p.B + p.gid[n]];
+    float s[64], V[48];
+    load_row_f(p.h_in + (size_t)n * PF_S, hl, s);
+    if constexpr (!L0) load_vec48(p.v_in + (size_t)n * 48, V);
+    else {
+#pragma unroll
+        for (int q = 0; q < 48; ++q) V[q] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 64; ++q) s[q] = fmaf(ms[q], inv_norm, s[q]);
+#pragma unroll
+    for (int q = 0; q < 48; ++q) V[q] = fmaf(mv[q], inv_norm, V[q]);
+    const NodeW nw = p.w[nt];
+    gvp_layernorm(nw.ln1_w, nw.ln1_b, hl, s, V);
+    float s1[64], V1[48];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) s1[q] = s[q];
+#pragma unroll
+    for (int q = 0; q < 48; ++q) V1[q] = V[q];
+    for (int gi = 0; gi < p.n_upd; ++gi) {
+        float s2[64], V2[48];
+        gvp_apply<16, 0, 16, 4, true, false>(nw.upd[gi], s1, nullptr, V1, s2, V2, lane);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) s1[q] = s2[q];
+#pragma unroll
+        for (int q = 0; q < 48; ++q) V1[q] = V2[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 64; ++q) s[q] += s1[q];
+#pragma unroll
+    for (int q = 0; q < 48; ++q) V[q] += V1[q];
+    gvp_layernorm(nw.ln2_w, nw.ln2_b, hl, s, V);
+    if (live) {
+        store_row_f(p.h_out + (size_t)n * PF_S, hl, s);
+        store_vec48_half(p.v_out + (size_t)n * 48, hl, V);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Noise head on the pharmacophore nodes (dynamics_gvp.py:37-42).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void k_noise_head(const HeadParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+    if (wid >= p.ntiles) return;
+    const NodeTile t = p.tiles[wid];
+    const int j = lane & 31, hl = lane >> 5;
+    const bool live = j < t.n;
+    const int n = t.n0 + min(j, t.n - 1);
+    float s1[64], V1[48];
+    load_row_f(p.h + (size_t)n * PF_S, hl, s1);
+    load_vec48(p.v + (size_t)n * 48, V1);
+    for (int gi = 0; gi + 1 < p.n_gvps; ++gi) {
+        float s2[64], V2[48];
+        gvp_apply<16, 0, 16, 4, true, false>(p.gvps[gi], s1, nullptr, V1, s2, V2, lane);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) s1[q] = s2[q];
+#pragma unroll
+        for (int q = 0; q < 48; ++q) V1[q] = V2[q];
+    }
+    float so[32], Vo[3];
+    gvp_apply<16, 0, 1, 2, false, false>(p.gvps[p.n_gvps - 1], s1, nullptr, V1, so, Vo, lane);
+    // to_scalar_output: Linear(64 -> pharm_nf), rows 0..5 of a 32-row tile
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) o = MFMA(p.a_out[ks * 64 + lane], so[ks], o);
+    if (live) {
+        const int f = n - p.node_base;
+        // lane half 0 holds output rows 0-3 (regs 0-3) and 8-11 (regs 4-7); half 1 rows 4-7, 12-15
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int u = (r & 3) + 8 * (r >> 2) + 4 * hl;
+            if (u < p.pharm_nf) p.eps_h[(size_t)f * p.pharm_nf + u] = o[r] + p.b_out[u];
+        }
+        if (hl == 0) {
+            p.eps_x[(size_t)f * 3 + 0] = Vo[0];
+            p.eps_x[(size_t)f * 3 + 1] = Vo[1];
+            p.eps_x[(size_t)f * 3 + 2] = Vo[2];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scalar encoders: h = LayerNorm(SiLU(W [feat, t] + b))   (dynamics_gvp.py:107-117,143-151)
+// one wave per node, two features per lane.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_encode(const EncodeParams p) {
+    const int lane = threadIdx.x & 63;
+    const int n = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+    if (n >= p.Np + p.Nf) return;
+    const int nt = n >= p.Np ? 1 : 0;
+    const int nf = nt ? p.pharm_nf : p.rec_nf;
+    const float* in = nt ? p.pharm_h + (size_t)(n - p.Np) * nf : p.prot_h0 + (size_t)n * nf;
+    const float tt = p.t[p.gid[n]];
+    const float* W = p.w[nt];
+    const int K = nf + 1;
+    float a0 = p.b[nt][lane], a1 = p.b[nt][lane + 64];
+    for (int k = 0; k < nf; ++k) {
+        const float x = in[k];
+        a0 = fmaf(W[lane * K + k], x, a0);
+        a1 = fmaf(W[(lane + 64) * K + k], x, a1);
+    }
+    a0 = fmaf(W[lane * K + nf], tt, a0);
+    a1 = fmaf(W[(lane + 64) * K + nf], tt, a1);
+    a0 = siluf_(a0); a1 = siluf_(a1);
+    float sum = a0 + a1;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * (1.0f / 128.0f);
+    const float c0 = a0 - mean, c1 = a1 - mean;
+    float var = c0 * c0 + c1 * c1;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / 128.0f) + 1e-5f);
+    p.h_out[(size_t)n * PF_S + lane] = c0 * rstd * p.ln_w[nt][lane] + p.ln_b[nt][lane];
+    p.h_out[(size_t)n * PF_S + lane + 64] = c1 * rstd * p.ln_w[nt][lane + 64] + p.ln_b[nt][lane + 64];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dynamic edges (add_pharm_edges, dynamics_gvp.py:187-215) -- one workgroup per graph, emitted
+// destination-major into the graph's fixed-capacity regions; torch_cluster semantics as fixed in
+// oracle/pf_oracle.py (strict d^2 < r^2; kNN ordered by (d^2, index)).
+// d^2 is evaluated as (dx*dx + dy*dy) + dz*dz with one rounding per operation.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sqdist_rn(const float4 a, const float4 b) {
+    const float dx = __fsub_rn(a.x, b.x), dy = __fsub_rn(a.y, b.y), dz = __fsub_rn(a.z, b.z);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+__device__ __forceinline__ unsigned long long dkey(const float d2, const int idx) {
+    return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)idx;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long other = __shfl_xor(k, o);
+        k = other < k ? other : k;
+    }
+    return k;
+}
+// exclusive scan of one value per thread over a 256-thread block; returns this thread's offset,
+// *total receives the block total.  scratch: 256 ints of LDS.
+__device__ __forceinline__ int block_excl_scan(const int val, int* scratch, int* total) {
+    const int tid = threadIdx.x;
+    scratch[tid] = val;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int add = tid >= o ? scratch[tid - o] : 0;
+        __syncthreads();
+        scratch[tid] += add;
+        __syncthreads();
+    }
+    const int incl = scratch[tid];
+    *total = scratch[255];
+    __syncthreads();
+    return incl - val;
+}
+
+__global__ __launch_bounds__(256) void k_build_edges(const BuildParams p) {
+    __shared__ float4 fx[PF_MAXF];
+    __shared__ int cnt[PF_MAXF];
+    __shared__ int off[PF_MAXF + 1];
+    __shared__ int knn_idx[PF_MAXF * PF_MAXK];
+    __shared__ int scratch[256];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p0 = p.prot_ptr[g], p1 = p.prot_ptr[g + 1];
+    const int f0 = p.pharm_ptr[g], f1 = p.pharm_ptr[g + 1];
+    const int Np = p1 - p0, Nf = f1 - f0;
+    const int GF = p.Np_tot + f0;                     // global id of this graph's pharm node 0
+    int* in_start0 = p.in_start;          int* in_cnt0 = p.in_cnt;            // slot 0: ff (pharm) / fp (prot)
+    int* in_start1 = p.in_start + p.N;    int* in_cnt1 = p.in_cnt + p.N;      // slot 1: pf (pharm) / pp (prot)
+    if (tid < Nf) fx[tid] = p.xn[GF + tid];
+    __syncthreads();
+    // ------------------------------------------------------------------ ff (pharm -> pharm)
+    const int reg_ff = p.reg[0 * p.B + g];
+    const int kff = p.ff_k > 0 ? min(p.ff_k, Nf - 1) : 0;
+    if (tid < Nf) {
+        int c = 0;
+        if (p.ff_k > 0) c = max(kff, 0);
+        else
+            for (int jn = 0; jn < Nf; ++jn)
+                if (jn != tid && sqdist_rn(fx[jn], fx[tid]) < p.r2_ff) ++c;
+        cnt[tid] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < Nf; ++i) { off[i] = run; run += cnt[i]; }
+        off[Nf] = run;
+        p.dyn_cnt[0 * p.B + g] = run;
+    }
+    __syncthreads();
+    if (tid < Nf) {
+        int e = reg_ff + off[tid];
+        in_start0[GF + tid] = e;
+        in_cnt0[GF + tid] = cnt[tid];
+        if (p.ff_k > 0) {
+            unsigned long long prev = 0ull;
+            bool first = true;
+            for (int q = 0; q < kff; ++q) {
+                unsigned long long best = ~0ull;
+                for (int jn = 0; jn < Nf; ++jn) {
+                    if (jn == tid) continue;
+                    const unsigned long long k = dkey(sqdist_rn(fx[jn], fx[tid]), jn);
+                    if ((first || k > prev) && k < best) best = k;
+                }
+                prev = best; first = false;
+                p.esrc[e] = GF + (int)(best & 0xffffffffu);
+                p.edst[e] = GF + tid;
+                ++e;
+            }
+        } else {
+            for (int jn = 0; jn < Nf; ++jn)
+                if (jn != tid && sqdist_rn(fx[jn], fx[tid]) < p.r2_ff) {
+                    p.esrc[e] = GF + jn; p.edst[e] = GF + tid; ++e;
+                }
+        }
+    }
+    __syncthreads();   // cnt/off are reused below
+    // ------------------------------------------------------------------ pf (prot -> pharm)
+    const int reg_pf = p.reg[1 * p.B + g];
+    const int reg_fp = p.reg[2 * p.B + g];
+    if (p.pf_k > 0) {
+        const int kk = min(p.pf_k, Np);
+        for (int fl = wave; fl < Nf; fl += 4) {
+            const float4 q = fx[fl];
+            unsigned long long prev = 0ull;
+            for (int r = 0; r < kk; ++r) {
+                unsigned long long best = ~0ull;
+                for (int c = lane; c < Np; c += 64) {
+                    const unsigned long long k = dkey(sqdist_rn(p.xn[p0 + c], q), c);
+                    if ((r == 0 || k > prev) && k < best) best = k;
+                }
+                best = wave_min_u64(best);
+                prev = best;
+                if (lane == 0) {
+                    const int pc = (int)(best & 0xffffffffu);
+                    knn_idx[fl * PF_MAXK + r] = pc;
+                    p.esrc[reg_pf + fl * kk + r] = p0 + pc;
+                    p.edst[reg_pf + fl * kk + r] = GF + fl;
+                }
+            }
+            if (lane == 0) { in_start1[GF + fl] = reg_pf + fl * kk; in_cnt1[GF + fl] = kk; }
+        }
+        if (tid == 0) { p.dyn_cnt[1 * p.B + g] = Nf * kk; p.dyn_cnt[2 * p.B + g] = Nf * kk; }
+        __syncthreads();
+        // fp = pf reversed, destination-major over the protein atoms of this graph
+        int base = 0;
+        for (int c0 = 0; c0 < Np; c0 += 256) {
+            const int c = c0 + tid;
+            int my = 0;
+            if (c < Np)
+                for (int fl = 0; fl < Nf; ++fl)
+                    for (int r = 0; r < kk; ++r) my += (knn_idx[fl * PF_MAXK + r] == c) ? 1 : 0;
+            int tot;
+            const int o = block_excl_scan(my, scratch, &tot);
+            if (c < Np) {
+                int e = reg_fp + base + o;
+                in_start0[p0 + c] = e;
+                in_cnt0[p0 + c] = my;
+                if (my)
+                    for (int fl = 0; fl < Nf; ++fl)
+                        for (int r = 0; r < kk; ++r)
+                            if (knn_idx[fl * PF_MAXK + r] == c) { p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
+            }
+            base += tot;
+        }
+    } else {
+        // radius(x=pharm, y=prot, r): pf = {prot -> pharm}, fp = reverse
+        for (int fl = wave; fl < Nf; fl += 4) {
+            const float4 q = fx[fl];
+            int c = 0;
+            for (int c0 = 0; c0 < Np; c0 += 64) {
+                const int pc = c0 + lane;
+                const bool in = pc < Np && sqdist_rn(q, p.xn[p0 + pc]) < p.r2_pf;
+                c += __popcll(__ballot(in));
+            }
+            if (lane == 0) cnt[fl] = c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int i = 0; i < Nf; ++i) { off[i] = run; run += cnt[i]; }
+            off[Nf] = run;
+            p.dyn_cnt[1 * p.B + g] = run;
+            p.dyn_cnt[2 * p.B + g] = run;
+        }
+        __syncthreads();
+        for (int fl = wave; fl < Nf; fl += 4) {
+            const float4 q = fx[fl];
+            int e = reg_pf + off[fl];
+            if (lane == 0) { in_start1[GF + fl] = e; in_cnt1[GF + fl] = cnt[fl]; }
+            for (int c0 = 0; c0 < Np; c0 += 64) {
+                const int pc = c0 + lane;
+                const bool in = pc < Np && sqdist_rn(q, p.xn[p0 + pc]) < p.r2_pf;
+                const unsigned long long m = __ballot(in);
+                if (in) {
+                    const int pos = e + __popcll(m & ((1ull << lane) - 1ull));
+                    p.esrc[pos] = p0 + pc; p.edst[pos] = GF + fl;
+                }
+                e += __popcll(m);
+            }
+        }
+        int base = 0;
+        for (int c0 = 0; c0 < Np; c0 += 256) {
+            const int c = c0 + tid;
+            int my = 0;
+            float4 xc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < Np) {
+                xc = p.xn[p0 + c];
+                for (int fl = 0; fl < Nf; ++fl) my += (sqdist_rn(fx[fl], xc) < p.r2_pf) ? 1 : 0;
+            }
+            int tot;
+            const int o = block_excl_scan(my, scratch, &tot);
+            if (c < Np) {
+                int e = reg_fp + base + o;
+                in_start0[p0 + c] = e;
+                in_cnt0[p0 + c] = my;
+                for (int fl = 0; fl < Nf; ++fl)
+                    if (sqdist_rn(fx[fl], xc) < p.r2_pf) { p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
+            }
+            base += tot;
+        }
+    }
+    // per-graph normalisers for message_norm == 0 (gvp.py:504-507)
+    __syncthreads();
+    if (tid == 0 && p.norm_mode == 2) {
+        const int cff = p.dyn_cnt[0 * p.B + g], cpf = p.dyn_cnt[1 * p.B + g], cfp = p.dyn_cnt[2 * p.B + g];
+        p.gnorm[1 * p.B + g] = (float)(cff + cpf) / (float)Nf + 1.0f;
+        p.gnorm[0 * p.B + g] = (float)(cfp + p.pp_cnt[g]) / (float)Np + 1.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small state kernels
+// ---------------------------------------------------------------------------------------------
+// copy [n,3] coordinates into the float4 node array (optionally subtracting a per-graph shift)
+__global__ void k_load_coords(const float* src, float4* xn, const int n, const int* gid, const float* shift,
+                              const float sign) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
+    if (shift) {
+        const int g = gid[i];
+        x += sign * shift[3 * g]; y += sign * shift[3 * g + 1]; z += sign * shift[3 * g + 2];
+    }
+    xn[i] = make_float4(x, y, z, 0.f);
+}
+// split [n, 3+nf] noise rows into coordinates (float4 array) and features
+__global__ void k_load_noise0(const float* nz, float4* xn, float* hf, const int n, const int nf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = nz + (size_t)i * (3 + nf);
+    xn[i] = make_float4(r[0], r[1], r[2], 0.f);
+    for (int k = 0; k < nf; ++k) hf[(size_t)i * nf + k] = r[3 + k];
+}
+__global__ void k_copy(const float* src, float* dst, const size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+// per-graph mean of coordinates (dgl.readout_nodes op='mean'); one wave per graph, fixed order
+__global__ __launch_bounds__(64) void k_segment_mean(const float4* xn, const int* ptr, const int base, float* out) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int a = ptr[g], b = ptr[g + 1];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int i = a + lane; i < b; i += 64) { const float4 x = xn[base + i]; sx += x.x; sy += x.y; sz += x.z; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+    if (lane == 0) {
+        const float n = (float)max(b - a, 1);
+        out[3 * g] = sx / n; out[3 * g + 1] = sy / n; out[3 * g + 2] = sz / n;
+    }
+}
+
+// z_s = mu + sigma * noise ; remove the pharmacophore COM from pharm and prot coordinates
+// (pharmacodiff.py:413-429).  One workgroup per graph.
+__global__ __launch_bounds__(256) void k_step_update(const StepParams p) {
+    __shared__ float com[3];
+    __shared__ float red[4][3];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f0 = p.pharm_ptr[g], f1 = p.pharm_ptr[g + 1];
+    const int p0 = p.prot_ptr[g], p1 = p.prot_ptr[g + 1];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int f = f0 + tid; f < f1; f += 256) {
+        const float4 x = p.xn[p.Np_tot + f];
+        const float* nz = p.noise + (size_t)f * (3 + p.nf);
+        float m[3];
+        const float xi[3] = {x.x, x.y, x.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float e = p.eps_x[(size_t)f * 3 + c];
+            const float mu = p.ep_coord ? (p.ep_zt * xi[c] + p.ep_pred * e) : (xi[c] / p.a_ts - p.var * e);
+            m[c] = mu + p.sigma * nz[c];
+        }
+        p.xn[p.Np_tot + f] = make_float4(m[0], m[1], m[2], 0.f);
+        sx += m[0]; sy += m[1]; sz += m[2];
+        for (int k = 0; k < p.nf; ++k) {
+            const float hv = p.pharm_h[(size_t)f * p.nf + k];
+            const float e = p.eps_h[(size_t)f * p.nf + k];
+            const float mu = p.ep_feat ? (p.ep_zt * hv + p.ep_pred * e) : (hv / p.a_ts - p.var * e);
+            p.pharm_h[(size_t)f * p.nf + k] = mu + p.sigma * nz[3 + k];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+    if (lane == 0) { red[wave][0] = sx; red[wave][1] = sy; red[wave][2] = sz; }
+    __syncthreads();
+    if (tid == 0) {
+        const float n = (float)max(f1 - f0, 1);
+        for (int c = 0; c < 3; ++c) com[c] = (f1 > f0) ? (((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) / n) : 0.f;
+    }
+    __syncthreads();
+    const float cx = com[0], cy = com[1], cz = com[2];
+    for (int f = f0 + tid; f < f1; f += 256) {
+        float4 x = p.xn[p.Np_tot + f];
+        x.x -= cx; x.y -= cy; x.z -= cz;
+        p.xn[p.Np_tot + f] = x;
+    }
+    for (int i = p0 + tid; i < p1; i += 256) {
+        float4 x = p.xn[i];
+        x.x -= cx; x.y -= cy; x.z -= cz;
+        p.xn[i] = x;
+    }
+}
+// out[i] = xn[base+i] + (add[g] - sub[g]) ; used for the final frame of reference
+__global__ void k_export_coords(const float4* xn, const int base, const int n, const int* gid, const float* add,
+                                const float* sub, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = gid[base + i];
+    const float4 x = xn[base + i];
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (add) { dx += add[3 * g]; dy += add[3 * g + 1]; dz += add[3 * g + 2]; }
+    out[3 * i] = (sub ? x.x - sub[3 * g] : x.x) + dx;
+    out[3 * i + 1] = (sub ? x.y - sub[3 * g + 1] : x.y) + dy;
+    out[3 * i + 2] = (sub ? x.z - sub[3 * g + 2] : x.z) + dz;
+}
+__global__ void k_scale_copy(const float* src, float* dst, const size_t n, const float s) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] * s;
+}
+
+// static pp radius graph (dataset/protein_pharm_dataset.py:234-236): one workgroup per graph;
+// pass 0 counts per-target neighbours, pass 1 writes (source, target) target-major.
+__global__ __launch_bounds__(256) void k_pp_radius(const float4* xn, const int* prot_ptr, const float r2, const int maxn,
+                                                   int* deg, const int* row_off, int* src, int* dst, const int pass) {
+    const int g = blockIdx.x;
+    const int a = prot_ptr[g], b = prot_ptr[g + 1];
+    for (int i = a + threadIdx.x; i < b; i += 256) {
+        const float4 xi = xn[i];
+        int c = 0;
+        int e = pass ? row_off[i] : 0;
+        for (int jn = a; jn < b && c < maxn; ++jn) {
+            if (jn == i) continue;
+            if (sqdist_rn(xn[jn], xi) < r2) {
+                if (pass) { src[e] = jn; dst[e] = i; ++e; }
+                ++c;
+            }
+        }
+        if (!pass) deg[i] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers (called from pf_host.cpp)
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+void pfk_edge_msg(const EdgeParams* p, int layer0, hipStream_t s) {
+    const int blocks = (p->ntiles + 3) / 4;
+    if (blocks == 0) return;
+    if (layer0) hipLaunchKernelGGL(k_edge_msg<true>, dim3(blocks), dim3(256), 0, s, *p);
+    else hipLaunchKernelGGL(k_edge_msg<false>, dim3(blocks), dim3(256), 0, s, *p);
+}
+void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s) {
+    const int blocks = (p->ntiles + 3) / 4;
+    if (blocks == 0) return;
+    if (layer0) hipLaunchKernelGGL(k_node_update<true>, dim3(blocks), dim3(256), 0, s, *p);
+    else hipLaunchKernelGGL(k_node_update<false>, dim3(blocks), dim3(256), 0, s, *p);
+}
+void pfk_noise_head(const HeadParams* p, hipStream_t s) {
+    const int blocks = (p->ntiles + 3) / 4;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_noise_head, dim3(blocks), dim3(256), 0, s, *p);
+}
+void pfk_encode(const EncodeParams* p, hipStream_t s) {
+    const int n = p->Np + p->Nf;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_encode, dim3((n + 3) / 4), dim3(256), 0, s, *p);
+}
+void pfk_build_edges(const BuildParams* p, hipStream_t s) {
+    if (p->B == 0) return;
+    hipLaunchKernelGGL(k_build_edges, dim3(p->B), dim3(256), 0, s, *p);
+}
+void pfk_load_coords(const float* src, float4* xn, int n, const int* gid, const float* shift, float sign, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_load_coords, dim3((n + 255) / 256), dim3(256), 0, s, src, xn, n, gid, shift, sign);
+}
+void pfk_load_noise0(const float* nz, float4* xn, float* hf, int n, int nf, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_load_noise0, dim3((n + 255) / 256), dim3(256), 0, s, nz, xn, hf, n, nf);
+}
+void pfk_copy(const float* src, float* dst, size_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+}
+void pfk_scale_copy(const float* src, float* dst, size_t n, float sc, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n, sc);
+}
+void pfk_segment_mean(const float4* xn, const int* ptr, int base, int B, float* out, hipStream_t s) {
+    if (B == 0) return;
+    hipLaunchKernelGGL(k_segment_mean, dim3(B), dim3(64), 0, s, xn, ptr, base, out);
+}
+void pfk_step_update(const StepParams* p, hipStream_t s) {
+    if (p->B == 0) return;
+    hipLaunchKernelGGL(k_step_update, dim3(p->B), dim3(256), 0, s, *p);
+}
+void pfk_export_coords(const float4* xn, int base, int n, const int* gid, const float* add, const float* sub,
+                       float* out, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_export_coords, dim3((n + 255) / 256), dim3(256), 0, s, xn, base, n, gid, add, sub, out);
+}
+void pfk_pp_radius(const float4* xn, const int* prot_ptr, int B, float r2, int maxn, int* deg, const int* row_off,
+                   int* src, int* dst, int pass, hipStream_t s) {
+    if (B == 0) return;
+    hipLaunchKernelGGL(k_pp_radius, dim3(B), dim3(256), 0, s, xn, prot_ptr, r2, maxn, deg, row_off, src, dst, pass);
+}
+}

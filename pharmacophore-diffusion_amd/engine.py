@@ -1,0 +1,195 @@
+"""PfEngine: one libpfdyn handle per (process, GPU).  Marshals torch tensors (device memory owned
+by PyTorch) and the current torch HIP stream into the C ABI of include/pfdyn.h."""
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous CUDA/HIP tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class PfEngine:
+    def __init__(self, *, pharm_nf=6, rec_nf=11, vector_size=16, n_hidden_scalars=128, n_convs=2,
+                 n_message_gvps=3, n_update_gvps=2, n_noise_gvps=4, message_norm="mean", ff_k=0, pf_k=5,
+                 graph_cutoffs=None, rbf_dmax=15.0, rbf_dim=16, device=None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.PfError("no HIP device visible to PyTorch: libpfdyn has no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        cut = {"pp": 3.5, "pf": 8.0, "fp": 8.0, "ff": 9.0}
+        cut.update(graph_cutoffs or {})
+        if isinstance(message_norm, dict):
+            raise L.PfError("dict-valued message_norm is unusable in the reference too (gvp.py:453)")
+        if message_norm == "mean":
+            mode, val = L.PF_NORM_MEAN, 1.0
+        elif float(message_norm) == 0.0:
+            mode, val = L.PF_NORM_GRAPH, 0.0
+        else:
+            mode, val = L.PF_NORM_VALUE, float(message_norm)
+        self.cfg = L.PfConfig(L.PF_ABI_VERSION, pharm_nf, rec_nf, vector_size, n_hidden_scalars, n_convs,
+                              n_message_gvps, n_update_gvps, n_noise_gvps, mode, val, int(ff_k), int(pf_k),
+                              float(cut["pp"]), float(cut["pf"]), float(cut["fp"]), float(cut["ff"]),
+                              float(rbf_dmax), int(rbf_dim))
+        self.pharm_nf, self.rec_nf = pharm_nf, rec_nf
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.pf_create(ctypes.byref(self.cfg), ctypes.byref(self._h))
+        if rc < 0:
+            msg = self.lib.pf_last_error(None)
+            raise L.PfError(f"pf_create failed ({rc}): {msg.decode() if msg else ''}")
+        self.Nf = self.Np = self.B = 0
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self.lib.pf_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        return L.check(self.lib, self._h, rc, what)
+
+    # -- weights (reference state_dict key layout) -------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "dynamics."):
+        """sd: reference keys (``dynamics.*``); ``prefix`` is what the given keys start with
+        relative to the reference layout (pass prefix='' for a bare PharmRecDynamicsGVP dict)."""
+        with torch.cuda.device(self.device):
+            for k, v in sd.items():
+                name = k if prefix == "dynamics." else "dynamics." + k
+                if not name.startswith("dynamics."):
+                    continue           # e.g. gamma.gamma
+                t = v.detach().to("cpu", torch.float32).contiguous()
+                shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
+                self._ck(self.lib.pf_set_weight(self._h, name.encode(), ctypes.c_void_p(t.data_ptr()) if t.numel() else None,
+                                                t.dim(), shape), f"pf_set_weight({name})")
+            self._ck(self.lib.pf_commit_weights(self._h), "pf_commit_weights")
+
+    # -- static batch --------------------------------------------------------------------------
+    def set_batch(self, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst):
+        px, ph = _f32(prot_x, self.device), _f32(prot_h, self.device)
+        pptr = prot_ptr.to("cpu", torch.int32).contiguous()
+        fptr = pharm_ptr.to("cpu", torch.int32).contiguous()
+        src = pp_src.to("cpu", torch.int32).contiguous()
+        dst = pp_dst.to("cpu", torch.int32).contiguous()
+        self.B = int(pptr.numel() - 1)
+        self.Np, self.Nf = int(pptr[-1]), int(fptr[-1])
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_set_pocket_batch(self._h, self.B, pptr.data_ptr(), fptr.data_ptr(), _dptr(px), _dptr(ph),
+                                                  int(src.numel()), src.data_ptr() if src.numel() else None,
+                                                  dst.data_ptr() if dst.numel() else None, _stream_ptr()),
+                     "pf_set_pocket_batch")
+
+    def build_pp_edges(self, prot_x, prot_ptr, max_num_neighbors=100):
+        px = _f32(prot_x, self.device)
+        pptr = prot_ptr.to("cpu", torch.int32).contiguous()
+        B = int(pptr.numel() - 1)
+        with torch.cuda.device(self.device):
+            n = self._ck(self.lib.pf_build_pp_edges(self._h, B, pptr.data_ptr(), _dptr(px), max_num_neighbors,
+                                                    None, None, 0, _stream_ptr()), "pf_build_pp_edges")
+            src = torch.zeros(max(n, 1), dtype=torch.int32)
+            dst = torch.zeros(max(n, 1), dtype=torch.int32)
+            self._ck(self.lib.pf_build_pp_edges(self._h, B, pptr.data_ptr(), _dptr(px), max_num_neighbors,
+                                                src.data_ptr(), dst.data_ptr(), n, _stream_ptr()), "pf_build_pp_edges")
+        return src[:n].long(), dst[:n].long()
+
+    # -- the boundary function -----------------------------------------------------------------
+    def dynamics(self, pharm_x, pharm_h, t, prot_x=None):
+        x, hh, tt = _f32(pharm_x, self.device), _f32(pharm_h, self.device), _f32(t, self.device)
+        px = _f32(prot_x, self.device) if prot_x is not None else None
+        eps_h = torch.empty(self.Nf, self.pharm_nf, device=self.device)
+        eps_x = torch.empty(self.Nf, 3, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_dynamics_forward(self._h, _dptr(px), _dptr(x), _dptr(hh), _dptr(tt), _dptr(eps_h),
+                                                  _dptr(eps_x), _stream_ptr()), "pf_dynamics_forward")
+        return eps_h, eps_x
+
+    # -- sampling ------------------------------------------------------------------------------
+    @staticmethod
+    def coef_array(coef: Dict[str, torch.Tensor], order):
+        """coef: per-s tensors (host logic of the diffusion wrapper); order: iterable of s."""
+        order = list(order)
+        arr = (L.PfStepCoef * max(len(order), 1))()
+        for i, s in enumerate(order):
+            arr[i] = L.PfStepCoef(float(coef["t"][s]), float(coef["alpha_t_given_s"][s]), float(coef["var_terms"][s]),
+                                  float(coef["sigma"][s]), float(coef["ep_zt"][s]), float(coef["ep_pred"][s]))
+        return arr
+
+    def sample_begin(self, noise0, init_pharm_com=None):
+        nz = _f32(noise0, self.device)
+        com = _f32(init_pharm_com, self.device) if init_pharm_com is not None else None
+        self._keep = [nz, com]
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_sample_begin(self._h, _dptr(com), _dptr(nz), _stream_ptr()), "pf_sample_begin")
+
+    def denoise_step(self, coef_struct, noise, ep_coord=False, ep_feat=False):
+        nz = _f32(noise, self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_denoise_step(self._h, ctypes.byref(coef_struct), _dptr(nz), int(ep_coord), int(ep_feat),
+                                              _stream_ptr()), "pf_denoise_step")
+
+    def sample_frame(self, feat_norm_constant=1.0):
+        x = torch.empty(self.Nf, 3, device=self.device)
+        hh = torch.empty(self.Nf, self.pharm_nf, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_sample_frame(self._h, float(feat_norm_constant), _dptr(x), _dptr(hh), _stream_ptr()),
+                     "pf_sample_frame")
+        return x, hh
+
+    def sample(self, coef_arr, n_steps, noise, init_pharm_com=None, ep_coord=False, ep_feat=False,
+               feat_norm_constant=1.0, trajectory=False):
+        nz = _f32(noise, self.device)
+        assert nz.shape[0] >= n_steps + 1 and nz.shape[1] == self.Nf and nz.shape[2] == 3 + self.pharm_nf
+        com = _f32(init_pharm_com, self.device) if init_pharm_com is not None else None
+        x0 = torch.empty(self.Nf, 3, device=self.device)
+        h0 = torch.empty(self.Nf, self.pharm_nf, device=self.device)
+        tx = th = None
+        if trajectory:
+            tx = torch.empty(n_steps + 1, self.Nf, 3, device=self.device)
+            th = torch.empty(n_steps + 1, self.Nf, self.pharm_nf, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_sample(self._h, n_steps, coef_arr, _dptr(nz), _dptr(com), int(ep_coord), int(ep_feat),
+                                        float(feat_norm_constant), _dptr(x0), _dptr(h0), _dptr(tx), _dptr(th),
+                                        _stream_ptr()), "pf_sample")
+        return (x0, h0, tx, th) if trajectory else (x0, h0)
+
+    # -- introspection -------------------------------------------------------------------------
+    def get_edges(self, etype: int):
+        with torch.cuda.device(self.device):
+            n = self._ck(self.lib.pf_debug_get_edges(self._h, etype, None, None, 0, _stream_ptr()), "pf_debug_get_edges")
+            src = torch.zeros(max(n, 1), dtype=torch.int32)
+            dst = torch.zeros(max(n, 1), dtype=torch.int32)
+            self._ck(self.lib.pf_debug_get_edges(self._h, etype, src.data_ptr(), dst.data_ptr(), n, _stream_ptr()),
+                     "pf_debug_get_edges")
+        return src[:n].long(), dst[:n].long()
+
+    def conv_layer(self, layer, prot_x, pharm_x, h_prot, v_prot, h_pharm, v_pharm):
+        a = [_f32(t, self.device) for t in (prot_x, pharm_x, h_prot, v_prot, h_pharm, v_pharm)]
+        outs = [torch.empty_like(a[2]), torch.empty_like(a[3]), torch.empty_like(a[4]), torch.empty_like(a[5])]
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_debug_conv_layer(self._h, layer, *[_dptr(t) for t in a], *[_dptr(t) for t in outs],
+                                                  _stream_ptr()), "pf_debug_conv_layer")
+        return outs
+
+    def work(self):
+        fl, by = ctypes.c_double(), ctypes.c_double()
+        ne = (ctypes.c_int64 * 4)()
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_debug_work(self._h, ctypes.byref(fl), ctypes.byref(by), ne, _stream_ptr()), "pf_debug_work")
+        return fl.value, by.value, list(ne)

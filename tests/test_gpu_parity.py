@@ -1,0 +1,167 @@
+"""GPU parity tests proper: the HIP path (through the C ABI of include/pfdyn.h) against the CPU
+oracle on the same seeded inputs and against the golden vectors recorded from the reference.
+
+Tolerances (fp32 arithmetic on both sides; the HIP kernels accumulate dot products in MFMA
+k-order, the oracle in BLAS order):
+    single dynamics call / conv layer :  |err| <= 2e-4 + 2e-4*|ref|
+    T-step stochastic trajectory       :  |err| <= 5e-3 + 5e-3*|ref|   (rounding compounds over T steps)
+Edge sets must match exactly (bit-exact integer work)."""
+import pytest
+import torch
+
+from oracle import pf_oracle as O
+from helpers import DYN_CASES, batch_from, edge_set, load
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 2e-4, 2e-4
+
+
+def engine_for(cfg: O.DynamicsConfig, sd):
+    import pharmacoforge_amd as pfa
+    eng = pfa.PfEngine(pharm_nf=cfg.pharm_nf, rec_nf=cfg.rec_nf, n_convs=cfg.n_convs,
+                       n_message_gvps=cfg.n_message_gvps, n_update_gvps=cfg.n_update_gvps,
+                       n_noise_gvps=cfg.n_noise_gvps, message_norm=cfg.message_norm, ff_k=cfg.ff_k, pf_k=cfg.pf_k,
+                       graph_cutoffs={"pp": cfg.cutoff_pp, "pf": cfg.cutoff_pf, "fp": cfg.cutoff_fp, "ff": cfg.cutoff_ff})
+    eng.load_state_dict(sd)
+    return eng
+
+
+def set_batch(eng, batch: O.PocketBatch, prot_x=None):
+    eng.set_batch(batch.prot_x if prot_x is None else prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr,
+                  batch.pp_src, batch.pp_dst)
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    torch.testing.assert_close(a.cpu(), b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name", list(DYN_CASES))
+def test_dynamics_vs_golden_and_oracle(name):
+    z, cfg = load(name), DYN_CASES[name]
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch, z["prot_x"])
+    eps_h, eps_x = eng.dynamics(z["x_t"], z["h_t"], z["t"])
+    # edge sets of that call == the reference's (golden) == the oracle's
+    for i, et in enumerate(O.ETYPES):
+        s, d = eng.get_edges(i)
+        assert edge_set(s, d) == edge_set(z[f"e_{et}_src"].long(), z[f"e_{et}_dst"].long()), et
+        assert s.numel() == z[f"e_{et}_src"].numel()
+    close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
+    oh, ox = O.dynamics_forward(sd, cfg, batch, z["prot_x"], z["x_t"], z["h_t"], z["t"])
+    close(eps_h, oh); close(eps_x, ox)
+
+
+@pytest.mark.parametrize("name", list(DYN_CASES))
+def test_conv_layer_nonzero_vectors(name):
+    z, cfg = load(name), DYN_CASES[name]
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch, z["prot_x"])
+    li = int(z["conv_layer_index"])
+    hp, vp, hf, vf = eng.conv_layer(li, z["prot_x"], z["x_t"], z["conv_in_h_prot"], z["conv_in_v_prot"],
+                                    z["conv_in_h_pharm"], z["conv_in_v_pharm"])
+    close(hp, z["conv_out_h_prot"]); close(vp, z["conv_out_v_prot"])
+    close(hf, z["conv_out_h_pharm"]); close(vf, z["conv_out_v_pharm"])
+
+
+@pytest.mark.parametrize("name", ["traj_c1.npz", "traj_ragged.npz"])
+def test_trajectory_vs_golden(name):
+    z = load(name)
+    cfg = O.DynamicsConfig()
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    T = int(z["T"])
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+    arr = eng.coef_array(coef, reversed(range(T)))
+    traj = "pos_frames" in z
+    res = eng.sample(arr, T, z["noise"], trajectory=traj)
+    close(res[0], z["x0"], 5e-3, 5e-3); close(res[1], z["h0"], 5e-3, 5e-3)
+    if traj:
+        close(res[2], z["pos_frames"], 5e-3, 5e-3); close(res[3], z["feat_frames"], 5e-3, 5e-3)
+
+
+def test_single_steps_vs_oracle_config2_shape():
+    """One denoising step at BASELINE config-2 graph sizes (256-atom pockets, 6 centers) for a
+    small batch, against the oracle with shared noise."""
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    batch = O.synthetic_batch([100, 101, 102], 256, 6, cfg)
+    T = 500
+    gen = torch.Generator().manual_seed(42)
+    Nf = int(batch.pharm_ptr[-1])
+    noise = torch.randn(4, Nf, 9, generator=gen)
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+    arr = eng.coef_array(coef, reversed(range(T)))
+    x0, h0 = eng.sample(arr, 3, noise)
+    ox, oh = O.sample_given_receptor(sd, cfg, batch, T, 1e-5, noise, n_steps=3)
+    close(x0, ox, 1e-3, 1e-3); close(h0, oh, 1e-3, 1e-3)
+
+
+def test_pp_edge_builder_matches_oracle():
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    batch = O.synthetic_batch([5, 6], 200, [3, 4], cfg)
+    eng = engine_for(cfg, sd)
+    s, d = eng.build_pp_edges(batch.prot_x, batch.prot_ptr)
+    assert torch.equal(s, batch.pp_src) and torch.equal(d, batch.pp_dst)      # same order too
+
+
+def test_properties_translation_rotation_batch_independence():
+    """Size-independent properties at config-2 sizes: SE(3) equivariance of the dynamics, batch
+    independence (graph i unchanged by the rest of the batch), permutation of pocket atoms."""
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    batch = O.synthetic_batch([200, 201, 202, 203], 256, [6, 3, 8, 5], cfg)
+    gen = torch.Generator().manual_seed(1)
+    Nf = int(batch.pharm_ptr[-1])
+    x_t = 3.0 * torch.randn(Nf, 3, generator=gen)
+    h_t = torch.randn(Nf, 6, generator=gen)
+    t = torch.tensor([0.9, 0.5, 0.1, 1.0])
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    eh, ex = eng.dynamics(x_t, h_t, t, prot_x=batch.prot_x)
+    eh, ex = eh.cpu(), ex.cpu()
+    # rotation + translation
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=gen))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    shift = torch.tensor([1.5, -2.0, 0.7])
+    eh2, ex2 = eng.dynamics(x_t @ q.T + shift, h_t, t, prot_x=batch.prot_x @ q.T + shift)
+    close(eh2, eh, 1e-3, 1e-3); close(ex2, ex @ q.T, 1e-3, 1e-3)
+    # batch independence: graph 2 alone
+    sub = O.PocketBatch(batch.prot_x[512:768], batch.prot_h[512:768], torch.tensor([0, 256]), torch.tensor([0, 8]),
+                        *[e - 512 for e in (batch.pp_src[(batch.pp_dst >= 512) & (batch.pp_dst < 768)],
+                                            batch.pp_dst[(batch.pp_dst >= 512) & (batch.pp_dst < 768)])])
+    eng2 = engine_for(cfg, sd)
+    set_batch(eng2, sub)
+    f0, f1 = int(batch.pharm_ptr[2]), int(batch.pharm_ptr[3])
+    sh, sx = eng2.dynamics(x_t[f0:f1], h_t[f0:f1], t[2:3])
+    close(sh, eh[f0:f1], 1e-4, 1e-4); close(sx, ex[f0:f1], 1e-4, 1e-4)
+
+
+def test_empty_and_degenerate_graphs():
+    """A graph with a single pharmacophore center (no ff edges) and one with fewer protein atoms
+    than pf_k."""
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    b1 = O.synthetic_batch([300], 3, 1, cfg)
+    b2 = O.synthetic_batch([301], 40, 4, cfg)
+    batch = O.PocketBatch(torch.cat([b1.prot_x, b2.prot_x]), torch.cat([b1.prot_h, b2.prot_h]),
+                          torch.tensor([0, 3, 43]), torch.tensor([0, 1, 5]),
+                          torch.cat([b1.pp_src, b2.pp_src + 3]), torch.cat([b1.pp_dst, b2.pp_dst + 3]))
+    gen = torch.Generator().manual_seed(2)
+    x_t = torch.randn(5, 3, generator=gen); h_t = torch.randn(5, 6, generator=gen)
+    t = torch.tensor([0.3, 0.8])
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    eh, ex = eng.dynamics(x_t, h_t, t)
+    oh, ox = O.dynamics_forward(sd, cfg, batch, batch.prot_x, x_t, h_t, t)
+    close(eh, oh); close(ex, ox)
