@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- denoising sample-steps/s of the HIP path at BASELINE.json config 2
+(256-atom pocket, 6 centers, T=500 schedule, batch=32 per GPU), one process per GPU.
+
+A "step" is one pass of the hot path over one batch: one sample_p_zs_given_zt
+(dynamics forward + p(z_s|z_t) update + COM removal) for the B graphs of this rank.  Inputs
+(pockets, weights) are resident in HBM before the timed region; the per-step noise is drawn on
+the device inside it.  Rank 0 prints ONE JSON line (see the task contract) with two extra
+objects: "roofline" (dominant kernel, HIP-event timed on the launch stream inside the timed
+region) and "cpu_baseline" (the CPU oracle timed on this box's host cores on a bounded sample;
+N=1 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_TFLOPS = 157.3          # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_EDGE = 136742.0         # message chain, 2 FLOP / MAC
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--n-prot", type=int, default=256)
+    ap.add_argument("--n-pharm", type=int, default=6)
+    ap.add_argument("--timesteps", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel device time to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import pharmacoforge_amd as pfa
+    from pharmacoforge_amd import synthetic, schedule
+
+    B, T, K, W = args.batch, args.timesteps, args.steps, args.warmup
+    # ---- inputs: B distinct pockets per rank (weak scaling: per-GPU work fixed), resident in HBM
+    eng = pfa.PfEngine(device=dev)
+    eng.load_state_dict(synthetic.make_state_dict(0))
+    xs, hs = zip(*[synthetic.synthetic_pocket(1000 * rank + i, args.n_prot) for i in range(B)])
+    prot_x, prot_h = torch.cat(xs).to(dev), torch.cat(hs).to(dev)
+    prot_ptr = torch.arange(B + 1, dtype=torch.int64) * args.n_prot
+    pharm_ptr = torch.arange(B + 1, dtype=torch.int64) * args.n_pharm
+    pp_src, pp_dst = eng.build_pp_edges(prot_x, prot_ptr)
+    eng.set_batch(prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst)
+    Nf = B * args.n_pharm
+    sched = schedule.PredefinedNoiseSchedule('polynomial_2', T, 1e-5)
+    coef = schedule.step_coefficients(sched.gamma, T)
+    order = [(W + K - 1 - i) % T for i in range(W + K)]        # the last W+K steps of the T-step schedule (s = W+K-1 ... 0):
+    # with random-init weights the early, high-noise steps (1/alpha_t|s = 1.6) blow the coordinates up; the tail keeps
+    # a realistic geometry (all ff edges present).  Work per step does not depend on s.
+    carr = eng.coef_array(coef, order)
+    gen = torch.Generator(device=dev).manual_seed(42 + rank)
+
+    def run(n, first):
+        noise = torch.randn(n + 1, Nf, 9, device=dev, generator=gen)   # x columns first, then h
+        if first:
+            eng.sample_begin(noise[0])
+        for i in range(n):
+            eng.denoise_step(carr[(0 if first else W) + i], noise[i + 1])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(W, True) if W > 0 else eng.sample_begin(torch.randn(Nf, 9, device=dev, generator=gen))
+    barrier()
+    eng.profile_enable(1 << 2)                                 # HIP events around every edge_msg launch
+    t0 = time.perf_counter()
+    run(K, False)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(0)
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    flops, bytes_, ne = eng.work()                              # algorithmic work of the last call (actual edge counts)
+    edge_ms, edge_n = prof["edge_msg"]
+    edge_avg_s = edge_ms / max(edge_n, 1) * 1e-3
+    edge_flops = FLOP_PER_EDGE * sum(ne)
+    achieved_tf = edge_flops / edge_avg_s / 1e12 if edge_avg_s > 0 else 0.0
+
+    out = {
+        "metric": "denoising steps/sec (batch x T) at 256-atom pocket, 6 centers",
+        "value": world * B * K / dt, "unit": "sample-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: 256-atom pocket, 6 centers, T=500 schedule, batch=32 per GPU, dev.yml network",
+                   "batch_per_gpu": B, "n_prot": args.n_prot, "n_pharm": args.n_pharm, "T": T,
+                   "edges_per_step": {"ff": ne[0], "pf": ne[1], "fp": ne[2], "pp": ne[3]},
+                   "parallelism": f"graphs sharded over {world} GPU(s), no data-path collective"},
+        "roofline": {"bound": "mfma", "kernel": "k_edge_msg", "achieved": achieved_tf, "peak": PEAK_F32_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_TFLOPS, "traffic": None,
+                     "kernel_avg_us": edge_avg_s * 1e6, "launches_timed": edge_n,
+                     "flop_per_launch": edge_flops,
+                     "whole_step": {"algorithmic_flop": flops, "algorithmic_bytes": bytes_,
+                                    "tflops": flops / (dt / K) / 1e12, "frac_f32_peak": flops / (dt / K) / 1e12 / PEAK_F32_TFLOPS,
+                                    "gbs": bytes_ / (dt / K) / 1e9, "frac_hbm_peak": bytes_ / (dt / K) / 1e9 / PEAK_HBM_GBS}},
+    }
+
+    if args.breakdown and rank == 0:
+        eng.profile_enable(0x3f)
+        run(min(K, 20), False)
+        torch.cuda.synchronize()
+        for k, (ms, n) in eng.profile_read().items():
+            print(f"[breakdown] {k:12s} {ms / max(n, 1) * 1e3:9.1f} us/launch  x{n}", file=sys.stderr)
+        eng.profile_enable(0)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, prot_x.cpu(), prot_h.cpu(), prot_ptr, pharm_ptr, pp_src, pp_dst, T)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, T):
+    """The CPU oracle (a PyTorch fp32 restatement of the reference path, oracle/pf_oracle.py) on the
+    same workload, bounded to ~args.cpu_seconds of host time.  Reported baseline, not the target."""
+    from oracle import pf_oracle as O
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    batch = O.PocketBatch(prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst)
+    coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+    Nf = int(pharm_ptr[-1])
+    g = torch.Generator().manual_seed(42)
+    x_t, h_t = torch.randn(Nf, 3, generator=g), torch.randn(Nf, 6, generator=g)
+    px = prot_x - O.segment_mean(prot_x, prot_ptr)[batch.batch_idxs()["prot"]]
+    with torch.no_grad():
+        nz = torch.randn(Nf, 9, generator=g)
+        px, x_t, h_t = O.sample_step(sd, cfg, batch, coef, T - 1, px, x_t, h_t, nz[:, :3], nz[:, 3:])   # warm-up
+        n, t0 = 0, time.perf_counter()
+        while n < 3 or time.perf_counter() - t0 < args.cpu_seconds:
+            nz = torch.randn(Nf, 9, generator=g)
+            px, x_t, h_t = O.sample_step(sd, cfg, batch, coef, T - 2 - n, px, x_t, h_t, nz[:, :3], nz[:, 3:])
+            n += 1
+            if n >= 200:
+                break
+        dt = time.perf_counter() - t0
+    B = int(prot_ptr.numel() - 1)
+    return {"value": B * n / dt, "unit": "sample-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} denoising steps of the same B={B} batch (after 1 warm-up step), CPU oracle (PyTorch fp32, "
+                      f"{torch.get_num_threads()} threads), {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpfdyn.so")
+# PFDYN_LIB selects an alternative build of the same library (A/B kernel experiments)
+LIB_PATH = os.environ.get("PFDYN_LIB") or os.path.join(_HERE, "csrc", "libpfdyn.so")
 
 PF_ABI_VERSION = 1
 PF_NORM_MEAN, PF_NORM_VALUE, PF_NORM_GRAPH = 0, 1, 2
@@ -48,6 +49,8 @@ SYMBOLS = {
     "pf_sample": (ctypes.c_int, [_P, _I32, ctypes.POINTER(PfStepCoef), _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P]),
     "pf_debug_get_edges": (_I64, [_P, _I32, _P, _P, _I64, _P]),
     "pf_debug_conv_layer": (ctypes.c_int, [_P, _I32] + [_P] * 11),
+    "pf_profile_enable": (ctypes.c_int, [_P, ctypes.c_uint32]),
+    "pf_profile_read": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), _P]),
     "pf_debug_work": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(_I64), _P]),
 }

@@ -95,6 +95,12 @@ struct pf_handle {
           *d_v[2] = {nullptr, nullptr}, *d_msg_s = nullptr, *d_msg_v = nullptr, *d_eps_h = nullptr, *d_eps_x = nullptr,
           *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr;
     bool sampling = false;
+
+    // ---- optional per-kernel timing with HIP events on the caller's stream (pf_profile_*)
+    enum { K_ENCODE = 0, K_BUILD, K_EDGE, K_NODE, K_HEAD, K_STEP, K_NUM };
+    unsigned prof_mask = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[K_NUM];
+    size_t prof_used[K_NUM] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -262,6 +268,24 @@ static T* carve(char*& cur, size_t count) {
     return p;
 }
 
+struct ProfScope {
+    pf_handle* h; int k; hipStream_t s; bool on;
+    ProfScope(pf_handle* h_, int k_, hipStream_t s_) : h(h_), k(k_), s(s_), on((h_->prof_mask >> k_) & 1u) {
+        if (!on) return;
+        if (h->prof_used[k] == h->prof_ev[k].size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            h->prof_ev[k].push_back({a, b});
+        }
+        (void)hipEventRecord(h->prof_ev[k][h->prof_used[k]].first, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(h->prof_ev[k][h->prof_used[k]].second, s);
+        h->prof_used[k]++;
+    }
+};
+
 // sequence one dynamics call on the handle's state (xn, pharm_h, d_t)
 static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s) {
     const pf_config& c = h->cfg;
@@ -274,7 +298,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s)
         ep.ln_w[nt] = h->d_w + h->enc_lw[nt]; ep.ln_b[nt] = h->d_w + h->enc_lb[nt];
     }
     ep.h_out = h->d_h[0];
-    pfk_encode(&ep, s);
+    { ProfScope ps(h, pf_handle::K_ENCODE, s); pfk_encode(&ep, s); }
 
     BuildParams bp{};
     bp.B = h->B; bp.Np_tot = h->Np;
@@ -284,7 +308,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s)
     bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
     bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
     bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
-    pfk_build_edges(&bp, s);
+    { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); }
 
     int cur = 0;
     for (int l = 0; l < c.n_convs; ++l) {
@@ -296,7 +320,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s)
         e.w = h->d_gvp + h->msg_base(l, 0); e.n_gvps = c.n_message_gvps;
         linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
         e.rbf_sigma = (c.rbf_dmax - 0.f) / (float)c.rbf_dim;
-        pfk_edge_msg(&e, l == 0, s);
+        { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
 
         NodeParams n{};
         n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles;
@@ -312,7 +336,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s)
             n.w[nt].upd = h->d_gvp + h->upd_base(l, nt);
         }
         n.n_upd = c.n_update_gvps;
-        pfk_node_update(&n, l == 0, s);
+        { ProfScope ps(h, pf_handle::K_NODE, s); pfk_node_update(&n, l == 0, s); }
         cur ^= 1;
     }
     HeadParams hp{};
@@ -321,7 +345,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s)
     hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
     hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
     hp.eps_h = eps_h; hp.eps_x = eps_x;
-    pfk_noise_head(&hp, s);
+    { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_noise_head(&hp, s); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return PF_OK;
@@ -374,6 +398,8 @@ void pf_destroy(pf_handle* h) {
     free_ws(h);
     if (h->d_w) (void)hipFree(h->d_w);
     if (h->d_gvp) (void)hipFree(h->d_gvp);
+    for (int k = 0; k < pf_handle::K_NUM; ++k)
+        for (auto& ev : h->prof_ev[k]) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete h;
 }
 
@@ -691,7 +717,7 @@ int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noi
     sp.nf = h->cfg.pharm_nf;
     sp.a_ts = coef->alpha_t_given_s; sp.var = coef->var_terms; sp.sigma = coef->sigma;
     sp.ep_zt = coef->ep_zt; sp.ep_pred = coef->ep_pred; sp.ep_coord = ep_coord; sp.ep_feat = ep_feat;
-    pfk_step_update(&sp, s);
+    { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_update(&sp, s); }
     return PF_OK;
 }
 
@@ -815,6 +841,30 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     PF_HIP(h, hipMemsetAsync(h->d_v[0], 0, (size_t)h->N * 48 * 4, s));
     hipError_t er = hipGetLastError();
     if (er != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(er));
+    return PF_OK;
+}
+
+int pf_profile_enable(pf_handle* h, uint32_t kernel_mask) {
+    if (!h) return PF_ERR_ARG;
+    h->prof_mask = kernel_mask;
+    for (int k = 0; k < pf_handle::K_NUM; ++k) h->prof_used[k] = 0;
+    return PF_OK;
+}
+
+int pf_profile_read(pf_handle* h, double* total_ms, int64_t* launches, pf_stream stream) {
+    if (!h || !total_ms || !launches) return PF_ERR_ARG;
+    PF_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+    for (int k = 0; k < pf_handle::K_NUM; ++k) {
+        double tot = 0.0;
+        for (size_t i = 0; i < h->prof_used[k]; ++i) {
+            float ms = 0.f;
+            PF_HIP(h, hipEventElapsedTime(&ms, h->prof_ev[k][i].first, h->prof_ev[k][i].second));
+            tot += ms;
+        }
+        total_ms[k] = tot;
+        launches[k] = (int64_t)h->prof_used[k];
+        h->prof_used[k] = 0;
+    }
     return PF_OK;
 }
 

@@ -19,6 +19,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef PF_CH
+#define PF_CH 4
+#endif
+#ifndef PF_WPS_EDGE
+#define PF_WPS_EDGE 2
+#endif
+#ifndef PF_WPS_NODE
+#define PF_WPS_NODE 1
+#endif
+#ifndef PF_WPS_HEAD
+#define PF_WPS_HEAD 1
+#endif
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -42,7 +54,7 @@ __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64],
     constexpr int H = VI;
     constexpr int NSH = (H + 1) / 2;                 // k-steps that carry sh
     constexpr int NKS = 64 + NEXTRA / 2 + NSH;       // k-steps of to_feats_out
-    constexpr int CH = 8;                            // k-steps per software-pipeline chunk
+    constexpr int CH = PF_CH;                          // k-steps per software-pipeline chunk
     constexpr int NCH = (NKS + CH - 1) / CH;
     const int hl = lane >> 5;
     // ---- vector channel: Vh = Wh^T V, sh = |Vh|, Vu = Wu^T Vh        (gvp.py:96-99)
@@ -215,7 +227,7 @@ __device__ __forceinline__ void store_vec48_half(float* row, const int hl, const
 // launch.  L0: conv layer 0, node vectors are identically zero.
 // ---------------------------------------------------------------------------------------------
 template <bool L0>
-__global__ __launch_bounds__(256, 1) void k_edge_msg(const EdgeParams p) {
+__global__ __launch_bounds__(256, PF_WPS_EDGE) void k_edge_msg(const EdgeParams p) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
     if (wid >= p.ntiles) return;
@@ -302,7 +314,7 @@ __device__ __forceinline__ void gvp_layernorm(pf_gcf lw, pf_gcf lb, const int hl
 }
 
 template <bool L0>
-__global__ __launch_bounds__(256, 1) void k_node_update(const NodeParams p) {
+__global__ __launch_bounds__(256, PF_WPS_NODE) void k_node_update(const NodeParams p) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
     if (wid >= p.ntiles) return;
@@ -323,27 +335,24 @@ __global__ __launch_bounds__(256, 1) void k_node_update(const NodeParams p) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
         cmax = __builtin_amdgcn_readfirstlane(cmax);
-        float as[64], av[48];
-#pragma unroll
-        for (int q = 0; q < 64; ++q) as[q] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 48; ++q) av[q] = 0.f;
+        // fn.mean: each row is scaled by 1/in-degree as it is added (zero in-degree -> 0); fn.sum: scale 1
+        const float sc = (p.norm_mode == 0 && c > 0) ? 1.0f / (float)c : 1.0f;
         for (int i = 0; i < cmax; ++i) {
             if (i < c) {
-                float r[64], rv[48];
-                load_row_f(p.msg_s + (size_t)(st + i) * PF_S, hl, r);
-                load_vec48(p.msg_v + (size_t)(st + i) * 48, rv);
+                {
+                    float r[64];
+                    load_row_f(p.msg_s + (size_t)(st + i) * PF_S, hl, r);
 #pragma unroll
-                for (int q = 0; q < 64; ++q) as[q] += r[q];
+                    for (int q = 0; q < 64; ++q) ms[q] = fmaf(r[q], sc, ms[q]);
+                }
+                {
+                    float rv[48];
+                    load_vec48(p.msg_v + (size_t)(st + i) * 48, rv);
 #pragma unroll
-                for (int q = 0; q < 48; ++q) av[q] += rv[q];
+                    for (int q = 0; q < 48; ++q) mv[q] = fmaf(rv[q], sc, mv[q]);
+                }
             }
         }
-        const float sc = (p.norm_mode == 0 && c > 0) ? 1.0f / (float)c : 1.0f;   // fn.mean, zero in-degree -> 0
-#pragma unroll
-        for (int q = 0; q < 64; ++q) ms[q] = fmaf(as[q], sc, ms[q]);
-#pragma unroll
-        for (int q = 0; q < 48; ++q) mv[q] = fmaf(av[q], sc, mv[q]);
     }
     float inv_norm = 1.0f;
     if (p.norm_mode == 1) inv_norm = 1.0f / p.norm_value;
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void k_node_update(const NodeParams p) {
 // ---------------------------------------------------------------------------------------------
 // Noise head on the pharmacophore nodes (dynamics_gvp.py:37-42).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void k_noise_head(const HeadParams p) {
+__global__ __launch_bounds__(256, PF_WPS_HEAD) void k_noise_head(const HeadParams p) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
     if (wid >= p.ntiles) return;
