@@ -6,7 +6,7 @@ alias module at the repository root) or via ``importlib.import_module('pharmacop
 Contents: csrc/ (HIP kernels + the C ABI of include/pfdyn.h), a ctypes binding, and the host-side
 mirror of the reference's Python interface for this path (PharmRecDynamicsGVP, PharmacophoreDiff,
 sample_given_receptor / sample, SampledPharmacophore)."""
-from . import _lib
+from . import _lib, schedule, synthetic
 from .engine import PfEngine
 from ._lib import PfError
 

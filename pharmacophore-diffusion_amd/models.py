@@ -1,0 +1,461 @@
+"""Host-side mirror of the reference's model classes for the denoising path.
+
+The nn.Module tree below reproduces the reference's *parameter layout* (so ``state_dict()`` /
+``load_state_dict()`` / Lightning ``.ckpt`` files use exactly the reference key set, SURVEY.md
+section 5) and its *call surface*:
+
+    PharmRecDynamicsGVP.forward(g, timestep, batch_idxs)      pharmacoforge/models/dynamics_gvp.py:131
+    PharmacophoreDiff.sample_given_receptor / sample / forward  pharmacoforge/models/pharmacodiff.py:433,516,162
+
+but none of these modules computes anything in PyTorch: every forward goes through libpfdyn.so
+(csrc/, C ABI in include/pfdyn.h).  There is no eager / CPU fallback -- without the HIP library and
+a GPU the calls raise.
+"""
+from __future__ import annotations
+
+import math
+from math import ceil
+from pathlib import Path
+from typing import Dict, List, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .analysis import SampleAnalyzer, SampledPharmacophore
+from .engine import PfEngine
+from .graph import PocketGraph, as_pocket_graph, batch as batch_graphs, copy_graph, get_batch_idxs, unbatch
+from .schedule import PredefinedNoiseSchedule, alpha as _alpha, sigma as _sigma, sigma_and_alpha_t_given_s, step_coefficients
+
+try:  # subclass LightningModule when Lightning is importable (drop-in for train.py / load_from_checkpoint)
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # Lightning absent (this image): same surface on top of nn.Module
+    pl = None
+    _Base = nn.Module
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers with the reference's names (gvp.py:43-166, 343-437; dynamics_gvp.py:10-129)
+# ---------------------------------------------------------------------------------------------
+class GVP(nn.Module):
+    def __init__(self, dim_vectors_in, dim_vectors_out, dim_feats_in, dim_feats_out, hidden_vectors=None,
+                 feats_activation=None, vectors_activation=None, vector_gating=True, xavier_init=False):
+        super().__init__()
+        if not vector_gating:
+            raise NotImplementedError("only vector-gated GVPs are on the hot path (gvp.py:79-80)")
+        self.dim_vectors_in, self.dim_feats_in, self.dim_vectors_out = dim_vectors_in, dim_feats_in, dim_vectors_out
+        dim_h = max(dim_vectors_in, dim_vectors_out) if hidden_vectors is None else hidden_vectors
+        wh_k, wu_k = 1 / math.sqrt(dim_vectors_in), 1 / math.sqrt(dim_h)
+        self.Wh = nn.Parameter(torch.zeros(dim_vectors_in, dim_h).uniform_(-wh_k, wh_k))
+        self.Wu = nn.Parameter(torch.zeros(dim_h, dim_vectors_out).uniform_(-wu_k, wu_k))
+        self.to_feats_out = nn.Sequential(nn.Linear(dim_h + dim_feats_in, dim_feats_out), nn.SiLU())
+        self.scalar_to_vector_gates = nn.Linear(dim_feats_out, dim_vectors_out)
+        if xavier_init:
+            nn.init.xavier_uniform_(self.scalar_to_vector_gates.weight, gain=1)
+            nn.init.constant_(self.scalar_to_vector_gates.bias, 0)
+
+
+class _VDropout(nn.Module):
+    def __init__(self, drop_rate):
+        super().__init__()
+        self.drop_rate = drop_rate
+        self.dummy_param = nn.Parameter(torch.empty(0))      # the reference's empty tensor, kept for key parity
+
+
+class GVPDropout(nn.Module):
+    def __init__(self, rate):
+        super().__init__()
+        self.vector_dropout = _VDropout(rate)
+        self.feat_dropout = nn.Dropout(rate)
+
+
+class GVPLayerNorm(nn.Module):
+    def __init__(self, feats_h_size, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.feat_norm = nn.LayerNorm(feats_h_size)
+
+
+class GVPMultiEdgeConv(nn.Module):
+    def __init__(self, etypes, scalar_size=128, vector_size=16, n_message_gvps=1, n_update_gvps=1, rbf_dmax=15,
+                 rbf_dim=16, message_norm: Union[float, str, Dict] = 10, dropout=0.0):
+        super().__init__()
+        self.etypes = etypes
+        self.dst_ntypes = sorted(set(e[2] for e in etypes))
+        if isinstance(message_norm, str) and message_norm != 'mean':
+            raise ValueError(f"message_norm values must be 'mean' or a positive number, got {message_norm}")
+        if isinstance(message_norm, (int, float)) and message_norm < 0:
+            raise ValueError(f"message_norm values must be 'mean' or a positive number, got {message_norm}")
+        self.edge_message_fns = nn.ModuleDict()
+        for etype in etypes:
+            gvps = []
+            for i in range(n_message_gvps):
+                vi = vector_size + 1 if i == 0 else vector_size
+                si = scalar_size + rbf_dim if i == 0 else scalar_size
+                gvps.append(GVP(vi, vector_size, si, scalar_size))
+            self.edge_message_fns['_'.join(etype)] = nn.Sequential(*gvps)
+        self.node_update_fns = nn.ModuleDict()
+        self.update_layer_norms = nn.ModuleDict()
+        self.message_layer_norms = nn.ModuleDict()
+        for ntype in self.dst_ntypes:
+            self.node_update_fns[ntype] = nn.Sequential(*[GVP(vector_size, vector_size, scalar_size, scalar_size)
+                                                          for _ in range(n_update_gvps)])
+            self.message_layer_norms[ntype] = GVPLayerNorm(scalar_size)
+            self.update_layer_norms[ntype] = GVPLayerNorm(scalar_size)
+        self.dropout = GVPDropout(dropout)
+
+
+class NoisePredictionBlock(nn.Module):
+    def __init__(self, in_scalar_dim, out_scalar_dim, vector_size, n_gvps=3, intermediate_scalar_dim=64):
+        super().__init__()
+        gvps = []
+        for i in range(n_gvps):
+            last = i == n_gvps - 1
+            gvps.append(GVP(vector_size, 1 if last else vector_size, in_scalar_dim,
+                            intermediate_scalar_dim if last else in_scalar_dim))
+        self.gvps = nn.Sequential(*gvps)
+        self.to_scalar_output = nn.Linear(intermediate_scalar_dim, out_scalar_dim)
+
+
+class PharmRecGVP(nn.Module):
+    pharmacophore_edges = [('pharm', 'ff', 'pharm'), ('prot', 'pf', 'pharm')]
+    protein_edges = [('pharm', 'fp', 'prot'), ('prot', 'pp', 'prot')]
+    all_edges = pharmacophore_edges + protein_edges
+
+    def __init__(self, in_scalar_dim, in_vector_dim, out_scalar_dim, n_convs=4, n_message_gvps=3, n_update_gvps=2,
+                 message_norm=10, n_noise_gvps=3, dropout=0.0):
+        super().__init__()
+        self.conv_layers = nn.ModuleList([
+            GVPMultiEdgeConv(self.all_edges, in_scalar_dim, in_vector_dim, n_message_gvps, n_update_gvps,
+                             message_norm=message_norm, dropout=dropout) for _ in range(n_convs)])
+        self.noise_predictor = NoisePredictionBlock(in_scalar_dim, out_scalar_dim, in_vector_dim, n_noise_gvps)
+
+
+class PharmRecDynamicsGVP(nn.Module):
+    """Drop-in for pharmacoforge.models.dynamics_gvp.PharmRecDynamicsGVP (same constructor, same
+    state-dict keys, same forward signature); forward runs on the MI355X through libpfdyn."""
+
+    def __init__(self, n_pharm_scalars, n_prot_scalars, vector_size: int = 16, n_convs=4, n_hidden_scalars=128,
+                 act_fn=nn.SiLU, message_norm=1, graph_cutoffs: dict = {}, n_message_gvps: int = 3,
+                 n_update_gvps: int = 2, n_noise_gvps: int = 3, dropout: float = 0.0, ff_k: int = 0, pf_k: int = 0):
+        super().__init__()
+        self.graph_cutoffs = graph_cutoffs
+        self.n_pharm_scalars, self.n_prot_scalars = n_pharm_scalars, n_prot_scalars
+        self.vector_size, self.ff_k, self.pf_k = vector_size, ff_k, pf_k
+        self._arch = dict(pharm_nf=n_pharm_scalars, rec_nf=n_prot_scalars, vector_size=vector_size,
+                          n_hidden_scalars=n_hidden_scalars, n_convs=n_convs, n_message_gvps=n_message_gvps,
+                          n_update_gvps=n_update_gvps, n_noise_gvps=n_noise_gvps, message_norm=message_norm,
+                          ff_k=ff_k, pf_k=pf_k, graph_cutoffs=dict(graph_cutoffs))
+        self.dropout_rate = dropout
+        self.pharm_encoder = nn.Sequential(nn.Linear(n_pharm_scalars + 1, n_hidden_scalars), act_fn(),
+                                           nn.LayerNorm(n_hidden_scalars))
+        self.prot_encoder = nn.Sequential(nn.Linear(n_prot_scalars + 1, n_hidden_scalars), act_fn(),
+                                          nn.LayerNorm(n_hidden_scalars))
+        self.noise_predictor = PharmRecGVP(n_hidden_scalars, vector_size, n_pharm_scalars, n_convs, n_message_gvps,
+                                           n_update_gvps, message_norm, n_noise_gvps, dropout)
+        self._engine: Optional[PfEngine] = None
+        self._weights_stamp = None
+        self._batch_key = None
+
+    # -- engine plumbing ------------------------------------------------------------------
+    def _device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def engine(self) -> PfEngine:
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("PharmRecDynamicsGVP runs only on an MI355X (move the model to 'cuda'); "
+                               "there is no CPU fallback")
+        if self._engine is None or self._engine.device != dev:
+            self._engine = PfEngine(device=dev, **self._arch)
+            self._weights_stamp = None
+            self._batch_key = None
+        stamp = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if stamp != self._weights_stamp:       # parameters were (re)loaded or updated: re-pack on the device
+            self._engine.load_state_dict({k: v for k, v in self.state_dict().items()}, prefix="")
+            self._weights_stamp = stamp
+        return self._engine
+
+    def bind_graph(self, g: PocketGraph, prot_x: Optional[torch.Tensor] = None) -> PfEngine:
+        """Upload the static part of a batch (pocket atoms, pp edges, graph boundaries) once."""
+        eng = self.engine()
+        key = (id(g), g.prot_x.data_ptr(), int(g.prot_ptr[-1]), int(g.pharm_ptr[-1]), g.batch_size, int(g.pp_src.numel()))
+        if key != self._batch_key:
+            eng.set_batch(g.prot_x if prot_x is None else prot_x, g.prot_h, g.prot_ptr, g.pharm_ptr, g.pp_src, g.pp_dst)
+            self._batch_key = key
+        return eng
+
+    def forward(self, g, timestep: torch.Tensor, batch_idxs: Dict[str, torch.Tensor] = None):
+        """(eps_h, eps_x) = dynamics(g, t): reads g.x_t, g.h_t (pharm) and g.prot_x, like the reference
+        reads g.nodes['pharm'].data['x_t'/'h_t'] and g.nodes['prot'].data['x_0'] (dynamics_gvp.py:139-170)."""
+        if self.training and self.dropout_rate > 0:
+            raise NotImplementedError("training-mode dropout / backward kernels are not built yet (DESIGN.md, next)")
+        g = as_pocket_graph(g)
+        eng = self.bind_graph(g)
+        return eng.dynamics(g.x_t, g.h_t, timestep, prot_x=g.prot_x)
+
+
+class PharmSizeDistribution:
+    """pharmacoforge/models/n_nodes_dist.py:7-14 (sample_uniformly only; sample_variety is broken upstream)."""
+
+    def __init__(self, dataset_dir=None):
+        pass
+
+    def sample_uniformly(self, n_replicates) -> torch.Tensor:
+        return torch.from_numpy(np.random.randint(3, 9, n_replicates))
+
+
+# ---------------------------------------------------------------------------------------------
+class PharmacophoreDiff(_Base):
+    """Drop-in for pharmacoforge.models.pharmacodiff.PharmacophoreDiff on the sampling / evaluation
+    path.  Constructor arguments, attribute names, state-dict keys ('gamma.gamma', 'dynamics.*') and
+    the metric names follow the reference (pharmacodiff.py:27-78, 231-239)."""
+
+    def __init__(self, pharm_nf, rec_nf, ph_type_map: List[str], processed_data_dir: Path = None,
+                 n_timesteps: int = 1000, graph_config={}, dynamics_config={}, lr_scheduler_config={},
+                 sample_interval: float = 1, val_loss_interval: float = 1, batch_size: int = 64,
+                 pharms_per_pocket: int = 8, n_pockets_to_sample: int = 8, precision=1e-4,
+                 pharm_feat_norm_constant=1, endpoint_param_feat: bool = False, endpoint_param_coord: bool = False,
+                 weighted_loss: bool = False, remove_com: bool = True, **kwargs):
+        super().__init__()
+        self.n_pharm_feats, self.n_prot_feats = pharm_nf, rec_nf
+        self.batch_size = batch_size
+        self.ph_type_map = ph_type_map
+        self.n_timesteps = n_timesteps
+        self.remove_com = remove_com
+        self.pharm_feat_norm_constant = pharm_feat_norm_constant
+        self.endpoint_param_feat, self.endpoint_param_coord = endpoint_param_feat, endpoint_param_coord
+        self.weighted_loss = weighted_loss
+        self.pharm_size_dist = PharmSizeDistribution(processed_data_dir)
+        self.gamma = PredefinedNoiseSchedule(noise_schedule='polynomial_2', timesteps=n_timesteps, precision=precision)
+        self.dynamics = PharmRecDynamicsGVP(pharm_nf, rec_nf, **graph_config, **dynamics_config)
+        self.lr_scheduler_config = lr_scheduler_config
+        self.sample_interval, self.pharms_per_pocket = sample_interval, pharms_per_pocket
+        self.n_pockets_to_sample = n_pockets_to_sample
+        self.last_sample_marker = 0
+        self.last_epoch_exact = 0
+        self.val_loss_interval = val_loss_interval
+        self._hparams_dict = dict(pharm_nf=pharm_nf, rec_nf=rec_nf, ph_type_map=ph_type_map,
+                                  processed_data_dir=processed_data_dir, n_timesteps=n_timesteps,
+                                  graph_config=graph_config, dynamics_config=dynamics_config,
+                                  lr_scheduler_config=lr_scheduler_config, sample_interval=sample_interval,
+                                  val_loss_interval=val_loss_interval, batch_size=batch_size,
+                                  pharms_per_pocket=pharms_per_pocket, n_pockets_to_sample=n_pockets_to_sample,
+                                  precision=precision, pharm_feat_norm_constant=pharm_feat_norm_constant,
+                                  endpoint_param_feat=endpoint_param_feat, endpoint_param_coord=endpoint_param_coord,
+                                  weighted_loss=weighted_loss, remove_com=remove_com, **kwargs)
+        if pl is not None:
+            self.save_hyperparameters()
+        self._coef = None
+
+    # -- Lightning-free conveniences ----------------------------------------------------------
+    if pl is None:
+        @property
+        def device(self) -> torch.device:
+            return next(self.parameters()).device
+
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, map_location="cpu", **overrides):
+            """A Lightning .ckpt is a torch-loadable dict with 'state_dict' and 'hyper_parameters'."""
+            ckpt = torch.load(str(checkpoint_path), map_location=map_location, weights_only=False)
+            hp = dict(ckpt.get("hyper_parameters", {}))
+            hp.update(overrides)
+            model = cls(**hp)
+            model.load_state_dict(ckpt["state_dict"], strict=True)
+            return model
+
+        def log_dict(self, *a, **k):
+            pass
+
+    def save_checkpoint(self, path):
+        """Write a file ``load_from_checkpoint`` (ours or Lightning's) can read."""
+        torch.save({"state_dict": self.state_dict(), "hyper_parameters": self._hparams_dict}, str(path))
+
+    # -- small algebra (pharmacodiff.py:80-86, 140-160) ----------------------------------------
+    def sigma(self, gamma):
+        return _sigma(gamma)
+
+    def alpha(self, gamma):
+        return _alpha(gamma)
+
+    def sigma_and_alpha_t_given_s(self, gamma_t, gamma_s):
+        return sigma_and_alpha_t_given_s(gamma_t, gamma_s)
+
+    def step_coefficients(self):
+        if self._coef is None:
+            self._coef = step_coefficients(self.gamma.gamma, self.n_timesteps)
+        return self._coef
+
+    # -- sampling (pharmacodiff.py:433-514) ------------------------------------------------------
+    @torch.no_grad()
+    def sample_given_receptor(self, g, init_pharm_com: torch.Tensor = None, visualize_trajectory: bool = False,
+                              noise: torch.Tensor = None) -> List[SampledPharmacophore]:
+        """Reverse diffusion for a batch of pocket graphs; the whole T-step loop is enqueued on the
+        current HIP stream by pf_sample (no host synchronisation inside the loop).
+
+        ``noise`` ([T+1, Nf, 3+pharm_nf], optional) injects the Gaussian draws (initial draw first; x
+        columns before h columns -- the reference's draw order, pharmacodiff.py:455-456, 423-424).
+        When omitted they are drawn with torch.randn on the model's device in that same order."""
+        g = as_pocket_graph(g)
+        dev = self.device
+        T, Nf, nf = self.n_timesteps, g.num_nodes("pharm"), self.n_pharm_feats
+        if noise is None:
+            noise = torch.empty(T + 1, Nf, 3 + nf, device=dev)
+            for i in range(T + 1):          # same call order / shapes as the reference's torch.randn calls
+                noise[i, :, :3] = torch.randn(Nf, 3, device=dev)
+                noise[i, :, 3:] = torch.randn(Nf, nf, device=dev)
+        eng = self.dynamics.bind_graph(g)
+        coef = self.step_coefficients()
+        arr = eng.coef_array(coef, reversed(range(T)))
+        com = None if init_pharm_com is None else init_pharm_com.to(dev)
+        res = eng.sample(arr, T, noise.to(dev), init_pharm_com=com, ep_coord=self.endpoint_param_coord,
+                         ep_feat=self.endpoint_param_feat, feat_norm_constant=float(self.pharm_feat_norm_constant),
+                         trajectory=visualize_trajectory)
+        x0, h0 = res[0].cpu(), res[1].cpu()
+        traj_x = res[2].cpu() if visualize_trajectory else None
+        traj_h = res[3].cpu() if visualize_trajectory else None
+        out: List[SampledPharmacophore] = []
+        g_cpu = g.to("cpu")
+        for gi, g_i in enumerate(unbatch(g_cpu)):
+            f0, f1 = int(g.pharm_ptr[gi]), int(g.pharm_ptr[gi + 1])
+            g_i.pharm_x0, g_i.pharm_h0 = x0[f0:f1], h0[f0:f1]
+            kwargs = {"g": g_i, "pharm_type_map": self.ph_type_map}
+            if visualize_trajectory:
+                kwargs["traj_frames"] = (traj_x[:, f0:f1], traj_h[:, f0:f1])
+            out.append(SampledPharmacophore(**kwargs))
+        return out
+
+    def sample(self, ref_graphs: List[PocketGraph], n_pharms: List[List[int]], max_batch_size: int = 32,
+               init_pharm_com: torch.Tensor = None, visualize_trajectory: bool = False,
+               rank: int = 0, world_size: int = 1) -> List[List[SampledPharmacophore]]:
+        """pharmacodiff.py:516-578.  With world_size > 1 the flattened (pocket, sample) graphs are dealt
+        round-robin over the ranks (independent units: no data-path collective); each rank returns only
+        its own samples, still grouped per pocket (empty lists for pockets it did not touch)."""
+        ref_graphs = [as_pocket_graph(g) for g in ref_graphs]
+        n_receptors = len(ref_graphs)
+        if init_pharm_com is None:
+            init_pharm_com = torch.stack([g.prot_x.mean(dim=0) for g in ref_graphs], dim=0)
+        graphs, graph_ref_idx = [], []
+        for rec_idx, ref_graph in enumerate(ref_graphs):
+            n_rec = n_pharms[rec_idx]
+            graphs.extend(copy_graph(ref_graph, n_copies=len(n_rec), pharm_feats_per_copy=torch.tensor(n_rec)))
+            graph_ref_idx.extend([rec_idx] * len(n_rec))
+        mine = list(range(rank, len(graphs), world_size))
+        sampled = {}
+        for start in range(0, len(mine), max_batch_size):
+            idx = mine[start:start + max_batch_size]
+            batch_g = batch_graphs([graphs[i] for i in idx]).to(self.device)
+            init_coms = init_pharm_com[[graph_ref_idx[i] for i in idx]].to(self.device)
+            pharms = self.sample_given_receptor(batch_g, init_pharm_com=init_coms, visualize_trajectory=visualize_trajectory)
+            for i, p in zip(idx, pharms):
+                sampled[i] = p
+        per_pocket, end = [], 0
+        for rec_idx in range(n_receptors):
+            start, end = end, end + len(n_pharms[rec_idx])
+            per_pocket.append([sampled[i] for i in range(start, end) if i in sampled])
+        return per_pocket
+
+    # -- training-loss forward (pharmacodiff.py:162-243), evaluation only ---------------------------
+    def forward(self, g, phase: str = 'train', t_int: torch.Tensor = None, eps: Dict[str, torch.Tensor] = None):
+        """Losses and metrics of one batch with the dynamics evaluated by the HIP kernels.  The network
+        output carries no autograd graph (backward kernels are the next milestone), so this serves
+        validation / monitoring; ``training_step`` raises.  ``t_int`` / ``eps`` inject the random draws."""
+        g = as_pocket_graph(g)
+        dev = self.device
+        bidx = get_batch_idxs(g)
+        bp, br = bidx['pharm'].to(dev), bidx['prot'].to(dev)
+        B = g.batch_size
+        ptr_f = g.pharm_ptr.to(dev)
+
+        def seg_mean(x):
+            out = torch.zeros(B, 3, device=dev).index_add_(0, bp, x)
+            return out / (ptr_f[1:] - ptr_f[:-1]).clamp(min=1).unsqueeze(1)
+
+        h0 = g.pharm_h0.to(dev) / self.pharm_feat_norm_constant
+        com = seg_mean(g.pharm_x0.to(dev))
+        x0 = g.pharm_x0.to(dev) - com[bp]
+        prot_x = g.prot_x.to(dev) - com[br]
+        if t_int is None:
+            t_int = torch.randint(0, self.n_timesteps, size=(B,), device=dev)
+        t = t_int.to(dev).float() / self.n_timesteps
+        if eps is None:
+            eps = {'h': torch.randn(h0.shape, device=dev), 'x': torch.randn(x0.shape, device=dev)}
+        eps = {k: v.to(dev) for k, v in eps.items()}
+        gamma_t = self.gamma(t)
+        alpha_t = self.alpha(gamma_t)[bp][:, None]
+        sigma_t = self.sigma(gamma_t)[bp][:, None]
+        x_t = alpha_t * x0 + sigma_t * eps['x']
+        h_t = alpha_t * h0 + sigma_t * eps['h']
+        if self.remove_com:
+            c = seg_mean(x_t)
+            x_t = x_t - c[bp]
+            prot_x = prot_x - c[br]
+            sampled_com = c[bp]
+        eng = self.dynamics.bind_graph(g)
+        with torch.no_grad():
+            h_dyn, x_dyn = eng.dynamics(x_t, h_t, t, prot_x=prot_x)
+        if self.endpoint_param_feat:
+            h_0_pred = h_dyn
+            h_loss = F.cross_entropy(h_0_pred, h0.argmax(dim=1), reduction='none')
+        else:
+            h_loss = (eps['h'] - h_dyn).square().sum(dim=1)
+            h_0_pred = (h_t - sigma_t * h_dyn) / alpha_t
+        if self.endpoint_param_coord:
+            if self.remove_com:
+                x_dyn = x_dyn + sampled_com
+            x_0_pred = x_dyn
+            x_loss = (x_0_pred - x0).square().sum(dim=1)
+        else:
+            x_loss = (eps['x'] - x_dyn).square().sum(dim=1)
+            x_0_pred = (x_t - sigma_t * x_dyn) / alpha_t
+        weight_metric = 1 - t[bp]
+        weight_loss = weight_metric if self.weighted_loss else torch.ones_like(weight_metric)
+        losses = {phase + ' pos loss': (x_loss * weight_loss).sum() / eps['x'].numel(),
+                  phase + ' feat loss': (h_loss * weight_loss).sum() / eps['h'].numel()}
+        err = (x_0_pred - x0).square().sum(dim=1)
+        hit = (h_0_pred.argmax(dim=1) == h0.argmax(dim=1)).float()
+        metrics = {phase + ' position error': err.mean(), phase + ' weighted position error': (weight_metric * err).mean(),
+                   phase + ' accuracy': hit.mean(), phase + ' weighted accuracy': (weight_metric * hit).mean()}
+        return losses, metrics
+
+    def training_step(self, batch, batch_idx):
+        raise NotImplementedError("backward kernels for the HIP dynamics are not built yet (DESIGN.md 'next'); "
+                                  "use forward(g, 'val') for loss/metric evaluation")
+
+    def validation_step(self, batch, batch_idx):
+        phase = 'val'
+        loss_dict, metrics_dict = self.forward(batch, phase=phase)
+        loss_dict[phase + ' total loss'] = sum(list(loss_dict.values()))
+        metrics_dict[phase + ' total error'] = metrics_dict[phase + ' position error'] + 1 - metrics_dict[phase + ' accuracy']
+        metrics_dict[phase + ' weighted total error'] = (metrics_dict[phase + ' weighted position error'] + 1
+                                                         - metrics_dict[phase + ' weighted accuracy'])
+        loss_dict['epoch_exact'] = self.last_epoch_exact
+        self.log_dict(loss_dict, on_step=False, on_epoch=True, prog_bar=True, logger=True, batch_size=batch.batch_size)
+        self.log_dict(metrics_dict, on_step=False, on_epoch=True, prog_bar=True, logger=True, batch_size=batch.batch_size)
+        return loss_dict[phase + ' total loss']
+
+    def sample_and_analyze_graphs(self, pockets: List[PocketGraph], rank=0, world_size=1, process_group=None):
+        """sample_and_analyze (pharmacodiff.py:320-357) on explicit pockets; with a process group the
+        validity numerator/denominator are summed over ranks with one all-reduce (RCCL on GPUs)."""
+        n_pharms = [[g.num_nodes('pharm')] * self.pharms_per_pocket for g in pockets]
+        coms = torch.stack([g.pharm_x0.mean(dim=0) for g in pockets], dim=0)
+        was_training = self.training
+        self.eval()
+        sampled = self.sample(pockets, n_pharms, max_batch_size=64, init_pharm_com=coms, rank=rank, world_size=world_size)
+        self.train(was_training)
+        flat = [p for pocket in sampled for p in pocket]
+        return SampleAnalyzer().analyze(flat, process_group=process_group, device=self.device)
+
+
+def model_from_config(config: dict, ckpt=None) -> PharmacophoreDiff:
+    """pharmacoforge/config_utils/load_from_config.py:6-32 (same yaml -> constructor mapping)."""
+    ev = config['training']['evaluation']
+    return PharmacophoreDiff(
+        pharm_nf=len(config['dataset']['ph_type_map']), rec_nf=len(config['dataset']['prot_elements']),
+        ph_type_map=config['dataset']['ph_type_map'], processed_data_dir=config['dataset']['processed_data_dir'],
+        n_pockets_to_sample=ev['n_pockets'], pharms_per_pocket=ev['pharms_per_pocket'],
+        sample_interval=ev['sample_interval'], val_loss_interval=ev['val_loss_interval'],
+        batch_size=config['training']['batch_size'], graph_config=config['graph'], dynamics_config=config['dynamics'],
+        lr_scheduler_config=config['lr_scheduler'], **config['diffusion'])

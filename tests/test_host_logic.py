@@ -1,0 +1,176 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol of include/pfdyn.h
+(no compute calls), schedule algebra, synthetic generators, batch bookkeeping, state-dict /
+checkpoint layout, xyz writer, metrics and the 2-rank (gloo) reduction path."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import pharmacoforge_amd as pfa
+from oracle import pf_oracle as O
+from helpers import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV_DYN = dict(vector_size=16, n_convs=2, n_hidden_scalars=128, message_norm='mean', dropout=0.1, ff_k=0, pf_k=5,
+               n_message_gvps=3, n_update_gvps=2, n_noise_gvps=4)
+DEV_GRAPH = {'graph_cutoffs': {'pp': 3.5, 'pf': 8, 'fp': 8, 'ff': 9}}
+
+
+def make_model(T=100):
+    return pfa.PharmacophoreDiff(6, 11, pfa.analysis.ph_idx_to_type, None, n_timesteps=T, graph_config=DEV_GRAPH,
+                                 dynamics_config=DEV_DYN, precision=1e-5)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "pfdyn.h")).read()
+    declared = set(re.findall(r"\b(pf_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"pf_status"}
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(pfa._lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libpfdyn.so does not export {name}"
+    assert declared == set(pfa._lib.SYMBOLS), declared ^ set(pfa._lib.SYMBOLS)
+    assert pfa._lib.load().pf_version().startswith(b"libpfdyn")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback():
+    lib = pfa._lib.load()
+    cfg = pfa._lib.PfConfig(pfa._lib.PF_ABI_VERSION, 6, 11, 16, 128, 2, 3, 2, 4, 0, 1.0, 0, 5, 3.5, 8, 8, 9, 15.0, 16)
+    h = ctypes.c_void_p()
+    rc = lib.pf_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert rc == -2 and b"no HIP device" in lib.pf_last_error(None)        # PF_ERR_HIP, loudly
+    with pytest.raises(pfa.PfError):
+        pfa.PfEngine()
+    m = make_model()
+    with pytest.raises(RuntimeError):
+        m.dynamics.engine()
+
+
+def test_bad_config_rejected():
+    lib = pfa._lib.load()
+    cfg = pfa._lib.PfConfig(pfa._lib.PF_ABI_VERSION, 6, 11, 8, 128, 2, 3, 2, 4, 0, 1.0, 0, 5, 3.5, 8, 8, 9, 15.0, 16)
+    h = ctypes.c_void_p()
+    assert lib.pf_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and b"vector_size" in lib.pf_last_error(None)
+
+
+@pytest.mark.parametrize("T", [50, 500])
+def test_schedule_module_matches_reference_tables(T):
+    z = load("schedule.npz")
+    tag = f"T{T}_p1e-05"
+    sched = pfa.PredefinedNoiseSchedule('polynomial_2', T, 1e-5)
+    assert torch.equal(sched.gamma.detach(), z["gamma_" + tag])
+    c = pfa.schedule.step_coefficients(sched.gamma, T)
+    assert torch.equal(c["alpha_t_given_s"], z["a_ts_" + tag])
+    assert torch.equal(c["var_terms"], z["var_" + tag])
+    assert torch.equal(c["sigma"], z["sigma_" + tag])
+    t = torch.tensor([0.0, 0.5, 1.0])
+    assert torch.equal(sched(t), sched.gamma[torch.tensor([0, T // 2, T])])
+
+
+def test_synthetic_generators_agree_with_oracle_copies():
+    x1, h1 = pfa.synthetic.synthetic_pocket(7, 64)
+    x2, h2 = O.synthetic_pocket(7, 64)
+    assert torch.equal(x1, x2) and torch.equal(h1, h2)
+    a, b = pfa.synthetic.make_state_dict(3), O.make_state_dict(O.DynamicsConfig(), 3)
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_state_dict_layout_and_checkpoint_roundtrip(tmp_path):
+    m = make_model()
+    sd = m.state_dict()
+    assert len(sd) == 245 and "gamma.gamma" in sd
+    assert sd["dynamics.noise_predictor.conv_layers.0.dropout.vector_dropout.dummy_param"].shape == (0,)
+    ref = O.make_state_dict(O.DynamicsConfig(), 0)
+    full = dict(ref); full["gamma.gamma"] = sd["gamma.gamma"]
+    m.load_state_dict(full, strict=True)                               # reference key set loads 1:1
+    p = tmp_path / "last.ckpt"
+    m.save_checkpoint(p)
+    m2 = pfa.PharmacophoreDiff.load_from_checkpoint(p)
+    assert all(torch.equal(v, m2.state_dict()[k]) for k, v in m.state_dict().items())
+    assert m2.n_timesteps == 100 and m2.dynamics.pf_k == 5
+
+
+def test_model_from_config_dev_yml():
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "tests", "golden", "dev_config_subset.yml")))
+    m = pfa.model_from_config(cfg)
+    assert m.n_timesteps == 100 and m.n_pharm_feats == 6 and m.n_prot_feats == 11
+    assert len(m.dynamics.noise_predictor.conv_layers) == 2
+
+
+def pocket(seed, n_prot, n_pharm):
+    cfg = O.DynamicsConfig()
+    b = O.synthetic_batch([seed], n_prot, n_pharm, cfg)
+    return pfa.PocketGraph(b.prot_x, b.prot_h, b.prot_ptr, b.pharm_ptr, b.pp_src, b.pp_dst,
+                           torch.zeros(n_pharm, 3), torch.zeros(n_pharm, 6))
+
+
+def test_batch_unbatch_copy_graph():
+    g1, g2 = pocket(1, 20, 3), pocket(2, 30, 5)
+    g = pfa.batch([g1, g2])
+    assert g.batch_size == 2 and g.num_nodes("prot") == 50 and g.batch_num_nodes("pharm").tolist() == [3, 5]
+    bi = g.batch_idxs()
+    assert bi["prot"].tolist() == [0] * 20 + [1] * 30 and bi["pharm"].tolist() == [0] * 3 + [1] * 5
+    u = pfa.unbatch(g)
+    assert torch.equal(u[1].prot_x, g2.prot_x) and torch.equal(u[1].pp_src, g2.pp_src) and torch.equal(u[1].pp_dst, g2.pp_dst)
+    copies = pfa.copy_graph(g1, 3, pharm_feats_per_copy=torch.tensor([4, 8, 3]))
+    assert [c.num_nodes("pharm") for c in copies] == [4, 8, 3] and all(c.pharm_h0.abs().sum() == 0 for c in copies)
+    assert copies[0].prot_x.data_ptr() != g1.prot_x.data_ptr() and torch.equal(copies[2].prot_x, g1.prot_x)
+
+
+def test_xyz_writer_matches_reference_output():
+    z = load("traj_c1.npz")
+    g = pocket(0, 64, 4)
+    g.pharm_x0, g.pharm_h0 = z["x0"], z["h0"]
+    ph = pfa.SampledPharmacophore(g, pfa.analysis.ph_idx_to_type, traj_frames=(z["pos_frames"], z["feat_frames"]))
+    assert ph.to_xyz_file() == str(z["xyz"])
+    assert ph.traj_to_xyz().count("\n") == 51 * 5
+    txt = pfa.write_pharmacophore_file([z["x0"]], [z["h0"].argmax(dim=1).tolist()], pfa.analysis.ph_idx_to_type)
+    assert txt == str(z["xyz"])
+
+
+def test_validity_metric():
+    g = pocket(3, 10, 2)
+    g.pharm_x0 = torch.tensor([[0., 0, 0], [10., 0, 0]])
+    g.pharm_h0 = torch.eye(6)[[1, 5]]                       # HydrogenDonor, Hydrophobic
+    g.prot_ph_x = torch.tensor([[3.9, 0, 0], [10., 5.1, 0]])
+    g.prot_ph_h = torch.eye(6)[[2, 5]]                      # acceptor within 4 A; hydrophobic just outside 5 A
+    ph = pfa.SampledPharmacophore(g, pfa.analysis.ph_idx_to_type)
+    assert pfa.SampleAnalyzer().analyze([ph]) == {'validity': 0.5}
+    assert pfa.SampleAnalyzer().pharm_feat_freq([ph]).tolist() == [0, 1, 0, 0, 0, 1]
+
+
+def _rank_fn(rank, world, port, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = pocket(3, 10, 2)
+    g.pharm_x0 = torch.tensor([[0., 0, 0], [10., 0, 0]])
+    g.pharm_h0 = torch.eye(6)[[1, 5]]
+    g.prot_ph_x = torch.tensor([[3.9, 0, 0], [10., 4.9 if rank else 5.1, 0]])
+    g.prot_ph_h = torch.eye(6)[[2, 5]]
+    ph = pfa.SampledPharmacophore(g, pfa.analysis.ph_idx_to_type)
+    res = pfa.SampleAnalyzer().analyze([ph], process_group=dist.group.WORLD)
+    freq = pfa.SampleAnalyzer().pharm_feat_freq([ph], process_group=dist.group.WORLD)
+    q.put((rank, res['validity'], freq.tolist()))
+    dist.destroy_process_group()
+
+
+def test_metrics_allreduce_two_ranks_gloo():
+    """The N>1 path: graphs are dealt round-robin over ranks (no data-path collective) and only the
+    validity numerator/denominator + type counts are all-reduced."""
+    import torch.multiprocessing as mp
+    idx = [list(range(r, 7, 2)) for r in range(2)]
+    assert sorted(idx[0] + idx[1]) == list(range(7))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_rank_fn, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(30) for p in procs]
+    assert out[0][1] == out[1][1] == 0.75            # (1 + 2) valid of (2 + 2) centers over both ranks
+    assert out[0][2] == [0, 2, 0, 0, 0, 2]
