@@ -17,6 +17,10 @@
 //   which is exactly the C/D layout of v_mfma_f32_32x32x2_f32 with the row on the lane
 //   (Out^T[feature][row] = W[feature][k] * In^T[k][row]); an output tile is therefore directly
 //   the B operand of the next layer's k-steps and no activation ever goes through LDS.
+//   A 16-channel vector feature [16][3] is split the same way ("R-layout"): channel
+//   u(t,hl) = (t&3) + 8*(t>>2) + 4*hl sits in register t (0..7) of lane half hl, one register
+//   array per coordinate -- rows 0..15 of a C/D fragment -- so the vector channel (Wh, Wu) runs
+//   on the matrix cores too and the two lanes of a row never exchange data explicitly.
 //   Weights are pre-packed on the host in A-operand fragment order (pf_host.cpp: pack_linear).
 #pragma once
 #include <stdint.h>
@@ -41,12 +45,12 @@ enum { ET_FF = 0, ET_PF = 1, ET_FP = 2, ET_PP = 3 };
 typedef const float PF_AS1* pf_gcf;
 
 struct GvpW {              // packed weights of one GVP (device pointers)
-    pf_gcf wh;             // [VI][H] row-major
-    pf_gcf wu;             // [H][VO] row-major
+    pf_gcf a_wh;           // [8(+1)][64 lanes]      A fragments of Wh^T (vector channel, R-layout k order)
+    pf_gcf a_wu;           // [8(+1)][64 lanes]      A fragments of Wu^T
     pf_gcf a_main;         // [NKS][64 lanes][NMO]   A fragments of to_feats_out
     pf_gcf b_main;         // [2 halves][NMO*16]     bias in F-layout
-    pf_gcf a_gate;         // [NMO*16][64 lanes]     A fragments of scalar_to_vector_gates (rows duplicated)
-    pf_gcf b_gate;         // [VO]
+    pf_gcf a_gate;         // [NMO*16][64 lanes]     A fragments of scalar_to_vector_gates (rows 0..VO-1)
+    pf_gcf b_gate;         // [2 halves][8]          gate bias in R-layout
 };
 
 struct EdgeTile {          // one wave = 32 edge slots
@@ -77,7 +81,7 @@ struct EdgeParams {
     const GvpW* w;         // [4 etypes][n_gvps]
     int n_gvps;
     float rbf_mu[PF_R];
-    float rbf_sigma;
+    float rbf_inv_sigma;
 };
 
 struct NodeW {             // per node type

@@ -84,6 +84,7 @@ struct pf_handle {
     std::vector<int> h_reg;                 // [3][B]
     std::vector<int> h_cap;                 // [3][B]
     int n_edge_tiles = 0, n_node_tiles = 0, n_head_tiles = 0;
+    int n_edge_tiles_last = 0, n_node_tiles_last = 0;   // last conv layer: only what feeds the pharm nodes
     void* d_ws = nullptr;                   // one allocation, carved below
     int *d_prot_ptr = nullptr, *d_pharm_ptr = nullptr, *d_gid = nullptr, *d_reg = nullptr, *d_dyn_cnt = nullptr,
         *d_esrc = nullptr, *d_edst = nullptr, *d_in_start = nullptr, *d_in_cnt = nullptr, *d_pp_cnt = nullptr;
@@ -209,15 +210,32 @@ static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
     const int H = std::max(g.vi, g.vo);
     const int nextra = g.si - h->cfg.n_hidden_scalars;     // 16 (rbf) for the first message GVP
     const int NMO = g.so / 32;
-    const int NSH = (H + 1) / 2;
+    const int NSH = 8 + (g.vi == 17 ? 1 : 0);
     const int NKS = 64 + nextra / 2 + NSH;
     const int Kin = H + g.si;
     const RawTensor& W = h->raw[g.prefix + "to_feats_out.0.weight"];   // [so][si + H]
     const RawTensor& Bv = h->raw[g.prefix + "to_feats_out.0.bias"];
     const RawTensor& G = h->raw[g.prefix + "scalar_to_vector_gates.weight"];   // [vo][so]
     GvpOff o;
-    o.wh = push(h->h_w, h->raw[g.prefix + "Wh"].data);
-    o.wu = push(h->h_w, h->raw[g.prefix + "Wu"].data);
+    {   // vector channel as A fragments.  k-step t < 8: lane half hl carries input channel u(t,hl) = rho(t,hl)
+        // (for a 17-channel input that is Wh row 1 + u: row 0 is the unit x_diff, fed at k-step 8 by half 0).
+        const std::vector<float>& wh = h->raw[g.prefix + "Wh"].data;      // [vi][H]
+        const std::vector<float>& wu = h->raw[g.prefix + "Wu"].data;      // [H][vo]
+        const bool X = g.vi == 17;
+        const int NVK = 8 + (X ? 1 : 0);
+        std::vector<float> awh((size_t)NVK * 64, 0.f), awu((size_t)NVK * 64, 0.f);
+        for (int t = 0; t < NVK; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, hl = lane >> 5;
+                int vin, hin;                      // input channel of Wh / of Wu at this k-step for this half
+                if (t < 8) { vin = (X ? 1 : 0) + rho(t, hl); hin = rho(t, hl); }
+                else { vin = hl == 0 ? 0 : -1; hin = hl == 0 ? 16 : -1; }
+                awh[(size_t)t * 64 + lane] = (i < H && vin >= 0) ? wh[(size_t)vin * H + i] : 0.f;
+                awu[(size_t)t * 64 + lane] = (i < g.vo && hin >= 0 && hin < H) ? wu[(size_t)hin * g.vo + i] : 0.f;
+            }
+        o.wh = push(h->h_w, awh);
+        o.wu = push(h->h_w, awu);
+    }
     std::vector<float> a((size_t)NKS * 64 * NMO, 0.f);
     for (int ks = 0; ks < NKS; ++ks)
         for (int lane = 0; lane < 64; ++lane) {
@@ -225,9 +243,10 @@ static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
             int col;
             if (ks < 64) col = 32 * (ks / 16) + rho(ks % 16, hl);
             else if (ks < 64 + nextra / 2) col = 128 + 2 * (ks - 64) + hl;
-            else {
-                const int idx = 2 * (ks - 64 - nextra / 2) + hl;
-                col = idx < H ? 128 + nextra + idx : -1;
+            else {                                   // sh block: k-step t carries sh[u(t,hl)]; t == 8: sh[16] on half 0
+                const int t = ks - 64 - nextra / 2;
+                const int idx = t < 8 ? rho(t, hl) : (hl == 0 ? 16 : -1);
+                col = (idx >= 0 && idx < H) ? 128 + nextra + idx : -1;
             }
             for (int mo = 0; mo < NMO; ++mo) {
                 const int row = 32 * mo + i;
@@ -245,11 +264,16 @@ static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
         for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 31, hl = lane >> 5;
             const int k = 32 * (ks / 16) + rho(ks % 16, hl);
-            const int u = i < 16 ? i : ((i - 16) ^ 4);      // rows 16..31 duplicate rows 0..15, bit 2 flipped
-            ag[(size_t)ks * 64 + lane] = u < g.vo ? G.data[(size_t)u * g.so + k] : 0.f;
+            ag[(size_t)ks * 64 + lane] = i < g.vo ? G.data[(size_t)i * g.so + k] : 0.f;      // rows 0..vo-1 = gates
         }
     o.a_gate = push(h->h_w, ag);
-    o.b_gate = push(h->h_w, h->raw[g.prefix + "scalar_to_vector_gates.bias"].data);
+    {   // gate bias in R-layout: half hl, register t <-> gate rho(t,hl)
+        const std::vector<float>& bgv = h->raw[g.prefix + "scalar_to_vector_gates.bias"].data;
+        std::vector<float> bg(16, 0.f);
+        for (int hl = 0; hl < 2; ++hl)
+            for (int t = 0; t < 8; ++t) bg[(size_t)hl * 8 + t] = rho(t, hl) < g.vo ? bgv[rho(t, hl)] : 0.f;
+        o.b_gate = push(h->h_w, bg);
+    }
     return o;
 }
 
@@ -313,17 +337,18 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s)
     int cur = 0;
     for (int l = 0; l < c.n_convs; ++l) {
         EdgeParams e{};
-        e.tiles = h->d_edge_tiles; e.ntiles = h->n_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
+        const bool last = (l == c.n_convs - 1);
+        e.tiles = h->d_edge_tiles; e.ntiles = last ? h->n_edge_tiles_last : h->n_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
         e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;
         e.h = h->d_h[cur]; e.v = h->d_v[cur];
         e.msg_s = h->d_msg_s; e.msg_v = h->d_msg_v;
         e.w = h->d_gvp + h->msg_base(l, 0); e.n_gvps = c.n_message_gvps;
         linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
-        e.rbf_sigma = (c.rbf_dmax - 0.f) / (float)c.rbf_dim;
+        e.rbf_inv_sigma = 1.0f / ((c.rbf_dmax - 0.f) / (float)c.rbf_dim);
         { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
 
         NodeParams n{};
-        n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles;
+        n.tiles = h->d_node_tiles; n.ntiles = last ? h->n_node_tiles_last : h->n_node_tiles;
         n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
         n.msg_s = h->d_msg_s; n.msg_v = h->d_msg_v;
         n.h_in = h->d_h[cur]; n.v_in = h->d_v[cur]; n.h_out = h->d_h[cur ^ 1]; n.v_out = h->d_v[cur ^ 1];
@@ -481,7 +506,7 @@ int pf_commit_weights(pf_handle* h) {
     PF_HIP(h, hipMemcpy(h->d_w, h->h_w.data(), h->h_w.size() * sizeof(float), hipMemcpyHostToDevice));
     for (const GvpOff& o : offs) {
         GvpW g;
-        g.wh = h->d_w + o.wh; g.wu = h->d_w + o.wu; g.a_main = h->d_w + o.a_main; g.b_main = h->d_w + o.b_main;
+        g.a_wh = h->d_w + o.wh; g.a_wu = h->d_w + o.wu; g.a_main = h->d_w + o.a_main; g.b_main = h->d_w + o.b_main;
         g.a_gate = h->d_w + o.a_gate; g.b_gate = h->d_w + o.b_gate;
         h->h_gvp.push_back(g);
     }
@@ -559,11 +584,16 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     }
     // tiles: dynamic etypes first (they feed the short pharm-side chain), then pp
     std::vector<EdgeTile> et_tiles;
-    for (int et = 0; et < 3; ++et)
+    for (int et = 0; et < 3; ++et) {
         for (int g = 0; g < B; ++g) {
             const int cap = h->h_cap[(size_t)et * B + g], reg = h->h_reg[(size_t)et * B + g];
             for (int o = 0; o < cap; o += 32) et_tiles.push_back({reg + o, std::min(32, cap - o), et, et * B + g, o});
         }
+        // The output of the last conv layer is consumed only on the pharm nodes (dynamics_gvp.py:91), so in
+        // that layer only the etypes with a pharm destination (ff, pf: the first tiles) and only the pharm node
+        // tiles are computed; the reference computes and discards the protein side.
+        if (et == ET_PF) h->n_edge_tiles_last = (int)et_tiles.size();
+    }
     for (int64_t o = 0; o < n_pp; o += 32) et_tiles.push_back({(int)o, (int)std::min<int64_t>(32, n_pp - o), ET_PP, -1, 0});
     std::vector<NodeTile> n_tiles, h_tiles;
     for (int o = 0; o < Nf; o += 32) {
@@ -574,6 +604,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     h->n_edge_tiles = (int)et_tiles.size();
     h->n_node_tiles = (int)n_tiles.size();
     h->n_head_tiles = (int)h_tiles.size();
+    h->n_node_tiles_last = (int)h_tiles.size();          // pharm tiles come first in n_tiles
     // ---- one workspace allocation
     size_t bytes = 0;
     auto need = [&](size_t b) { bytes += (b + 255) & ~size_t(255); };
@@ -820,7 +851,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     e.xn = h->d_xn; e.h = h->d_h[0]; e.v = h->d_v[0]; e.msg_s = h->d_msg_s; e.msg_v = h->d_msg_v;
     e.w = h->d_gvp + h->msg_base(layer, 0); e.n_gvps = c.n_message_gvps;
     linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
-    e.rbf_sigma = c.rbf_dmax / (float)c.rbf_dim;
+    e.rbf_inv_sigma = 1.0f / (c.rbf_dmax / (float)c.rbf_dim);
     pfk_edge_msg(&e, 0, s);
     NodeParams n{};
     n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles; n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;

@@ -22,6 +22,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef PF_CH
 #define PF_CH 4
 #endif
+#ifndef PF_SGB
+#define PF_SGB 0
+#endif
 #ifndef PF_WPS_EDGE
 #define PF_WPS_EDGE 2
 #endif
@@ -33,68 +36,78 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float siluf_(float x) { return x / (1.0f + __expf(-x)); }
+// 1-ulp hardware reciprocal / sqrt / rsqrt (v_rcp_f32, v_sqrt_f32, v_rsq_f32): the IEEE-exact
+// expansions cost 10-15 VALU instructions each and parity is judged at 2e-4, not at 1 ulp.
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrtf_(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float rsqf_(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * rcpf_(1.0f + __expf(-x)); }
 
 // ---------------------------------------------------------------------------------------------
-// One GVP (gvp.py:89-116) on a 32-row tile, row-on-lane.
-//   VI     input vector channels (17 for the first message GVP, else 16); H = VI (= max(VI,VO))
-//   NEXTRA extra scalar inputs that follow the 128 features (16 rbf values for the first message GVP)
-//   VO     output vector channels (16, or 1 for the last noise-head GVP)
-//   NMO    output scalar tiles of 32 (4 -> 128 outputs, 2 -> 64 outputs)
+// One GVP (gvp.py:89-116) on a 32-row tile, row-on-lane, scalar AND vector channel on the matrix
+// cores.
+//   Scalars: F-layout (pf_device.h): 64 registers per lane, reg 16*mt+r <-> feature 32*mt+rho(r,hl).
+//   Vectors: "R-layout": channel u(t,hl) = (t&3) + 8*(t>>2) + 4*hl lives in register t (t = 0..7) of
+//   lane half hl, one register array per coordinate c -- i.e. rows 0..15 of a 32x32 C/D fragment.
+//   The two lanes of a row hold DISJOINT halves of both channels; all cross-lane mixing is done by
+//   the MFMAs themselves (no shuffles, no redundant VALU work):
+//       Vh^T[hh][row,c] = Wh^T[hh][v] V^T[v][row,c]     8 (+1) k-steps x 3 coordinates
+//       Vu^T[u][row,c]  = Wu^T[u][hh] Vh^T[hh][row,c]   B operand = the Vh accumulator registers
+//       sh[hh] = |Vh[hh]| enters the scalar Linear as extra k-steps, gates come out of a 16-row tile
+//   VI     input vector channels (17 for the first message GVP: channel 0 = unit x_diff; else 16)
+//   NEXTRA extra scalar inputs after the 128 features (16 rbf values for the first message GVP)
+//   VO     output vector channels (16, or 1 for the last noise-head GVP);  NMO output tiles of 32
 //   SIG    sigmoid vector activation (identity for the last noise-head GVP)
-//   VROW0  only vector row 0 of the input is non-zero (conv layer 0: node vectors are zero,
+//   VROW0  only the extra channel (x_diff) is non-zero (conv layer 0: node vectors are zero,
 //          dynamics_gvp.py:162-173)
-// Both lanes of a row hold the full vector state (redundantly); scalars are split (F-layout).
 // ---------------------------------------------------------------------------------------------
 template <int VI, int NEXTRA, int VO, int NMO, bool SIG, bool VROW0>
 __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64], const float* ext,
-                                          const float (&V)[VI * 3], float (&s_out)[NMO * 16],
-                                          float (&V_out)[VO * 3], const int lane) {
-    constexpr int H = VI;
-    constexpr int NSH = (H + 1) / 2;                 // k-steps that carry sh
-    constexpr int NKS = 64 + NEXTRA / 2 + NSH;       // k-steps of to_feats_out
-    constexpr int CH = PF_CH;                          // k-steps per software-pipeline chunk
+                                          const float (&Vr)[3][8], const float* xhat,
+                                          float (&s_out)[NMO * 16], float (&V_out)[3][8], const int lane) {
+    constexpr bool X = (VI == 17);                   // extra (17th) channel present
+    constexpr int NVK = 8 + (X ? 1 : 0);             // k-steps of the Vh / Vu products and of the sh block
+    constexpr int NKS = 64 + NEXTRA / 2 + NVK;       // k-steps of to_feats_out
+    constexpr int CH = PF_CH;                        // k-steps per software-pipeline chunk
     constexpr int NCH = (NKS + CH - 1) / CH;
     const int hl = lane >> 5;
-    // ---- vector channel: Vh = Wh^T V, sh = |Vh|, Vu = Wu^T Vh        (gvp.py:96-99)
-    float Vh[H * 3];
+    // ---- vector channel on the matrix cores                                     (gvp.py:96-99)
+    f32x16 vh[3], vu[3];
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int vi = 0; vi < (VROW0 ? 1 : VI); ++vi) {
-            const float wv = w.wh[vi * H + hh];
-            a0 = fmaf(wv, V[vi * 3 + 0], a0);
-            a1 = fmaf(wv, V[vi * 3 + 1], a1);
-            a2 = fmaf(wv, V[vi * 3 + 2], a2);
-        }
-        Vh[hh * 3 + 0] = a0; Vh[hh * 3 + 1] = a1; Vh[hh * 3 + 2] = a2;
+        for (int r = 0; r < 16; ++r) { vh[c][r] = 0.f; vu[c][r] = 0.f; }
+    {
+        pf_gcf ap = w.a_wh + lane;
+        float a[NVK];
+#pragma unroll
+        for (int t = 0; t < NVK; ++t) a[t] = ap[t * 64];
+#pragma unroll
+        for (int t = VROW0 ? 8 : 0; t < NVK; ++t)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vh[c] = MFMA(a[t], t < 8 ? Vr[c][t < 8 ? t : 0] : xhat[c], vh[c]);
     }
-    // this lane feeds sh[2t + hl] into k-step t of the sh block (select at production so that
-    // no register array is ever indexed by a runtime value)
-    float shsel[NSH];
+    {
+        pf_gcf ap = w.a_wu + lane;
+        float a[NVK];
 #pragma unroll
-    for (int t = 0; t < NSH; ++t) {
-        const int e = 2 * t, o = 2 * t + 1;
-        const float ne = sqrtf(fmaxf(Vh[e * 3] * Vh[e * 3] + Vh[e * 3 + 1] * Vh[e * 3 + 1] + Vh[e * 3 + 2] * Vh[e * 3 + 2], 1e-8f));
-        float no = 0.f;
-        if (o < H) no = sqrtf(fmaxf(Vh[o * 3] * Vh[o * 3] + Vh[o * 3 + 1] * Vh[o * 3 + 1] + Vh[o * 3 + 2] * Vh[o * 3 + 2], 1e-8f));
-        shsel[t] = hl ? no : ne;
+        for (int t = 0; t < NVK; ++t) a[t] = ap[t * 64];
+#pragma unroll
+        for (int t = 0; t < NVK; ++t)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vu[c] = MFMA(a[t], vh[c][t], vu[c]);
     }
-    float Vu[VO * 3];
+    // sh[u(t,hl)] = |Vh| for this lane's channels (k-step t of the sh block)
+    float shsel[NVK];
 #pragma unroll
-    for (int u = 0; u < VO; ++u) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int t = 0; t < NVK; ++t)
+        shsel[t] = sqrtf_(fmaxf(vh[0][t] * vh[0][t] + vh[1][t] * vh[1][t] + vh[2][t] * vh[2][t], 1e-8f));
+    float Vu[3][8];
 #pragma unroll
-        for (int hh = 0; hh < H; ++hh) {
-            const float wv = w.wu[hh * VO + u];
-            a0 = fmaf(wv, Vh[hh * 3 + 0], a0);
-            a1 = fmaf(wv, Vh[hh * 3 + 1], a1);
-            a2 = fmaf(wv, Vh[hh * 3 + 2], a2);
-        }
-        Vu[u * 3 + 0] = a0; Vu[u * 3 + 1] = a1; Vu[u * 3 + 2] = a2;
-    }
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) Vu[c][t] = vu[c][t];
     // ---- scalar channel: feats_out = SiLU(W [s, sh] + b) on the matrix cores  (gvp.py:101-103)
     f32x16 acc[NMO];
     {
@@ -128,7 +141,7 @@ __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64],
                 float b;
                 if (ks < 64) b = s_in[ks < 64 ? ks : 0];
                 else if (ks < 64 + NEXTRA / 2) b = ext[ks - 64];
-                else b = shsel[(ks - 64 - NEXTRA / 2) < NSH ? (ks - 64 - NEXTRA / 2) : 0];
+                else b = shsel[(ks - 64 - NEXTRA / 2) < NVK ? (ks - 64 - NEXTRA / 2) : 0];
                 const fragA a = abuf[c & 1][i];
 #pragma unroll
                 for (int mo = 0; mo < NMO; ++mo) acc[mo] = MFMA(a[mo], b, acc[mo]);
@@ -136,16 +149,15 @@ __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64],
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    // ---- SiLU feeds the gate MFMAs just in time:  gate = Wg feats_out + bg      (gvp.py:105-111)
+    constexpr int NG = NMO * 16;
+    constexpr int LOOK = 4;
 #pragma unroll
-    for (int mo = 0; mo < NMO; ++mo)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s_out[mo * 16 + r] = siluf_(acc[mo][r]);
-    // ---- gates: gate = Wg feats_out + bg ; V_out = act(gate) * Vu              (gvp.py:105-111)
+    for (int q = 0; q < LOOK; ++q) s_out[q] = siluf_(acc[q / 16][q % 16]);
     f32x16 g;
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = 0.f;
     {
-        constexpr int NG = NMO * 16;
         pf_gcf gp = w.a_gate + lane;
         float gbuf[2][CH];
 #pragma unroll
@@ -157,21 +169,30 @@ __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64],
                 for (int i = 0; i < CH; ++i) gbuf[(c + 1) & 1][i] = gp[((c + 1) * CH + i) * 64];
             }
 #pragma unroll
-            for (int i = 0; i < CH; ++i) g = MFMA(gbuf[c & 1][i], s_out[c * CH + i], g);
+            for (int i = 0; i < CH; ++i) {
+                const int ks = c * CH + i;
+                g = MFMA(gbuf[c & 1][i], s_out[ks], g);
+                if (ks + LOOK < NG) s_out[ks + LOOK] = siluf_(acc[(ks + LOOK) / 16][(ks + LOOK) % 16]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // V_out = act(gate) * Vu on this lane's channels (gate rows 0..15 of the tile = registers 0..7)
+    {
+        const f32x4 PF_AS1* bg = reinterpret_cast<const f32x4 PF_AS1*>(w.b_gate + hl * 8);
+        const f32x4 b0 = bg[0], b1 = bg[1];
 #pragma unroll
-    for (int u = 0; u < VO; ++u) {
-        // rows 16..31 of the packed gate matrix duplicate rows 0..15 with bit 2 flipped, so
-        // each lane of the pair receives all 16 gates (pf_host.cpp: pack_gate)
-        const int r = (u & 3) + 4 * (u >> 3);
-        float gv = (((u >> 2) & 1) == hl) ? g[r] : g[r + 8];
-        gv += w.b_gate[u];
-        if constexpr (SIG) gv = sigmoidf_(gv);
-        V_out[u * 3 + 0] = gv * Vu[u * 3 + 0];
-        V_out[u * 3 + 1] = gv * Vu[u * 3 + 1];
-        V_out[u * 3 + 2] = gv * Vu[u * 3 + 2];
+        for (int t = 0; t < 8; ++t) {
+            if (VO == 1 && t > 0) {
+                V_out[0][t] = 0.f; V_out[1][t] = 0.f; V_out[2][t] = 0.f;
+                continue;
+            }
+            float gv = g[t] + (t < 4 ? b0[t & 3] : b1[t & 3]);
+            if constexpr (SIG) gv = sigmoidf_(gv);
+            V_out[0][t] = gv * Vu[0][t];
+            V_out[1][t] = gv * Vu[1][t];
+            V_out[2][t] = gv * Vu[2][t];
+        }
     }
 }
 
@@ -200,24 +221,35 @@ __device__ __forceinline__ void store_row_f(float* row, const int hl, const floa
             p[mt * 8 + q * 2] = x;
         }
 }
+// load / store this lane's 8 channels (R-layout) of a [16][3] vector row: channels 8q+4hl .. +3 are
+// 12 contiguous floats at offset 24q + 12hl
 template <typename P>
-__device__ __forceinline__ void load_vec48(P row, float* V) {
-    auto p = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)row);
+__device__ __forceinline__ void load_vec_r(P row, const int hl, float (&V)[3][8]) {
+    auto p = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)row + 12 * hl);
 #pragma unroll
-    for (int q = 0; q < 12; ++q) {
-        const f32x4 x = p[q];
-        V[4 * q + 0] = x[0]; V[4 * q + 1] = x[1]; V[4 * q + 2] = x[2]; V[4 * q + 3] = x[3];
+    for (int q = 0; q < 2; ++q) {
+        const f32x4 a = p[6 * q], b = p[6 * q + 1], d = p[6 * q + 2];
+        const float f[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], d[0], d[1], d[2], d[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) V[c][4 * q + i] = f[3 * i + c];
     }
 }
-// each lane of the pair stores one half (24 floats) of the 48-float vector row
-__device__ __forceinline__ void store_vec48_half(float* row, const int hl, const float (&V)[48]) {
-    f32x4* p = reinterpret_cast<f32x4*>(row + 24 * hl);
+__device__ __forceinline__ void store_vec_r(float* row, const int hl, const float (&V)[3][8]) {
+    f32x4* p = reinterpret_cast<f32x4*>(row + 12 * hl);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        f32x4 x;
-        if (hl) { x[0] = V[24 + 4 * q]; x[1] = V[25 + 4 * q]; x[2] = V[26 + 4 * q]; x[3] = V[27 + 4 * q]; }
-        else    { x[0] = V[4 * q];      x[1] = V[1 + 4 * q];  x[2] = V[2 + 4 * q];  x[3] = V[3 + 4 * q]; }
-        p[q] = x;
+    for (int q = 0; q < 2; ++q) {
+        float f[12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) f[3 * i + c] = V[c][4 * q + i];
+        f32x4 a, b, d;
+        a[0] = f[0]; a[1] = f[1]; a[2] = f[2]; a[3] = f[3];
+        b[0] = f[4]; b[1] = f[5]; b[2] = f[6]; b[3] = f[7];
+        d[0] = f[8]; d[1] = f[9]; d[2] = f[10]; d[3] = f[11];
+        p[6 * q] = a; p[6 * q + 1] = b; p[6 * q + 2] = d;
     }
 }
 
@@ -246,39 +278,43 @@ __global__ __launch_bounds__(256, PF_WPS_EDGE) void k_edge_msg(const EdgeParams 
     const float4 xs = p.xn[src], xd = p.xn[dst];
     // x_diff = x_src - x_dst ; d = sqrt(max(|x_diff|^2, 1e-8)) + 1e-8 ; unit vector ; rbf
     const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
-    const float d = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
-    float V[17 * 3];
-    V[0] = dx / d; V[1] = dy / d; V[2] = dz / d;
+    const float d = sqrtf_(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+    const float rd = rcpf_(d);
+    const float xhat[3] = {dx * rd, dy * rd, dz * rd};
     // this lane feeds rbf[2t + hl] into k-step t of the rbf block
     float rb[PF_R / 2];
 #pragma unroll
     for (int k = 0; k < PF_R / 2; ++k) {
-        const float ze = (d - p.rbf_mu[2 * k]) / p.rbf_sigma;
-        const float zo = (d - p.rbf_mu[2 * k + 1]) / p.rbf_sigma;
+        const float ze = (d - p.rbf_mu[2 * k]) * p.rbf_inv_sigma;
+        const float zo = (d - p.rbf_mu[2 * k + 1]) * p.rbf_inv_sigma;
         const float re = __expf(-(ze * ze)), ro = __expf(-(zo * zo));
         rb[k] = hl ? ro : re;
     }
-    float s[64];
+    float s[64], V[3][8];
     load_row_f(p.h + (size_t)src * PF_S, hl, s);
-    if constexpr (!L0) load_vec48(p.v + (size_t)src * 48, V + 3);
+    if constexpr (!L0) load_vec_r(p.v + (size_t)src * 48, hl, V);
     else {
 #pragma unroll
-        for (int q = 3; q < 51; ++q) V[q] = 0.f;
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) V[c][q] = 0.f;
     }
     const GvpW PF_AS1* wt = (const GvpW PF_AS1*)p.w + et * p.n_gvps;
-    float s1[64], V1[48];
-    gvp_apply<17, PF_R, 16, 4, true, L0>(wt[0], s, rb, V, s1, V1, lane);
+    float s1[64], V1[3][8];
+    gvp_apply<17, PF_R, 16, 4, true, L0>(wt[0], s, rb, V, xhat, s1, V1, lane);
     for (int gi = 1; gi < p.n_gvps; ++gi) {
-        float s2[64], V2[48];
-        gvp_apply<16, 0, 16, 4, true, false>(wt[gi], s1, nullptr, V1, s2, V2, lane);
+        float s2[64], V2[3][8];
+        gvp_apply<16, 0, 16, 4, true, false>(wt[gi], s1, nullptr, V1, nullptr, s2, V2, lane);
 #pragma unroll
         for (int q = 0; q < 64; ++q) s1[q] = s2[q];
 #pragma unroll
-        for (int q = 0; q < 48; ++q) V1[q] = V2[q];
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) V1[c][q] = V2[c][q];
     }
     if (j < nvalid) {
         store_row_f(p.msg_s + (size_t)e * PF_S, hl, s1);
-        store_vec48_half(p.msg_v + (size_t)e * 48, hl, V1);
+        store_vec_r(p.msg_v + (size_t)e * 48, hl, V1);
     }
 }
 
@@ -288,7 +324,7 @@ __global__ __launch_bounds__(256, PF_WPS_EDGE) void k_edge_msg(const EdgeParams 
 // (gvp.py:488-536).  One wave per tile of 32 nodes of one type.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gvp_layernorm(pf_gcf lw, pf_gcf lb, const int hl, float (&s)[64],
-                                              float (&V)[48]) {
+                                              float (&V)[3][8]) {
     float sum = 0.f;
 #pragma unroll
     for (int q = 0; q < 64; ++q) sum += s[q];
@@ -298,7 +334,7 @@ __device__ __forceinline__ void gvp_layernorm(pf_gcf lw, pf_gcf lb, const int hl
 #pragma unroll
     for (int q = 0; q < 64; ++q) { const float c = s[q] - mean; var = fmaf(c, c, var); }
     var += __shfl_xor(var, 32);
-    const float rstd = 1.0f / sqrtf(var * (1.0f / 128.0f) + 1e-5f);
+    const float rstd = rsqf_(var * (1.0f / 128.0f) + 1e-5f);
     float w[64], b[64];
     load_row_f(lw, hl, w);
     load_row_f(lb, hl, b);
@@ -306,28 +342,32 @@ __device__ __forceinline__ void gvp_layernorm(pf_gcf lw, pf_gcf lb, const int hl
     for (int q = 0; q < 64; ++q) s[q] = (s[q] - mean) * rstd * w[q] + b[q];
     float vn = 0.f;
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
-        vn += fmaxf(V[3 * u] * V[3 * u] + V[3 * u + 1] * V[3 * u + 1] + V[3 * u + 2] * V[3 * u + 2], 1e-8f);
-    const float den = sqrtf(vn * (1.0f / 16.0f) + 1e-5f) + 1e-5f;
+    for (int t = 0; t < 8; ++t) vn += fmaxf(V[0][t] * V[0][t] + V[1][t] * V[1][t] + V[2][t] * V[2][t], 1e-8f);
+    vn += __shfl_xor(vn, 32);
+    const float rden = rcpf_(sqrtf_(vn * (1.0f / 16.0f) + 1e-5f) + 1e-5f);
 #pragma unroll
-    for (int q = 0; q < 48; ++q) V[q] = V[q] / den;
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) V[c][t] = V[c][t] * rden;
 }
 
 template <bool L0>
-__global__ __launch_bounds__(256, PF_WPS_NODE) void k_node_update(const NodeParams p) {
+__global__ __launch_bounds__(64, PF_WPS_NODE) void k_node_update(const NodeParams p) {
     const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+    const int wid = blockIdx.x;                       // one wave per block: the few tiles spread over all CUs
     if (wid >= p.ntiles) return;
     const NodeTile t = p.tiles[wid];
     const int nt = __builtin_amdgcn_readfirstlane(t.ntype);
     const int j = lane & 31, hl = lane >> 5;
     const bool live = j < t.n;
     const int n = t.n0 + min(j, t.n - 1);
-    float ms[64], mv[48];
+    float ms[64], mv[3][8];
 #pragma unroll
     for (int q = 0; q < 64; ++q) ms[q] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 48; ++q) mv[q] = 0.f;
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) mv[c][q] = 0.f;
     for (int slot = 0; slot < 2; ++slot) {
         const int st = p.in_start[slot * p.N + n];
         const int c = live ? p.in_cnt[slot * p.N + n] : 0;
@@ -339,85 +379,94 @@ __global__ __launch_bounds__(256, PF_WPS_NODE) void k_node_update(const NodePara
         const float sc = (p.norm_mode == 0 && c > 0) ? 1.0f / (float)c : 1.0f;
         for (int i = 0; i < cmax; ++i) {
             if (i < c) {
-                {
-                    float r[64];
-                    load_row_f(p.msg_s + (size_t)(st + i) * PF_S, hl, r);
+                float r[64], rv[3][8];
+                load_row_f(p.msg_s + (size_t)(st + i) * PF_S, hl, r);
+                load_vec_r(p.msg_v + (size_t)(st + i) * 48, hl, rv);
 #pragma unroll
-                    for (int q = 0; q < 64; ++q) ms[q] = fmaf(r[q], sc, ms[q]);
-                }
-                {
-                    float rv[48];
-                    load_vec48(p.msg_v + (size_t)(st + i) * 48, rv);
+                for (int q = 0; q < 64; ++q) ms[q] = fmaf(r[q], sc, ms[q]);
 #pragma unroll
-                    for (int q = 0; q < 48; ++q) mv[q] = fmaf(rv[q], sc, mv[q]);
-                }
+                for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) mv[cc][q] = fmaf(rv[cc][q], sc, mv[cc][q]);
             }
         }
     }
     float inv_norm = 1.0f;
     if (p.norm_mode == 1) inv_norm = 1.0f / p.norm_value;
     else if (p.norm_mode == 2) inv_norm = 1.0f / p.gnorm[nt * p.B + p.gid[n]];
-    float s[64], V[48];
+    float s[64], V[3][8];
     load_row_f(p.h_in + (size_t)n * PF_S, hl, s);
-    if constexpr (!L0) load_vec48(p.v_in + (size_t)n * 48, V);
+    if constexpr (!L0) load_vec_r(p.v_in + (size_t)n * 48, hl, V);
     else {
 #pragma unroll
-        for (int q = 0; q < 48; ++q) V[q] = 0.f;
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) V[c][q] = 0.f;
     }
 #pragma unroll
     for (int q = 0; q < 64; ++q) s[q] = fmaf(ms[q], inv_norm, s[q]);
 #pragma unroll
-    for (int q = 0; q < 48; ++q) V[q] = fmaf(mv[q], inv_norm, V[q]);
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) V[c][q] = fmaf(mv[c][q], inv_norm, V[c][q]);
     const NodeW nw = p.w[nt];
     gvp_layernorm(nw.ln1_w, nw.ln1_b, hl, s, V);
-    float s1[64], V1[48];
+    float s1[64], V1[3][8];
 #pragma unroll
     for (int q = 0; q < 64; ++q) s1[q] = s[q];
 #pragma unroll
-    for (int q = 0; q < 48; ++q) V1[q] = V[q];
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) V1[c][q] = V[c][q];
     for (int gi = 0; gi < p.n_upd; ++gi) {
-        float s2[64], V2[48];
-        gvp_apply<16, 0, 16, 4, true, false>(nw.upd[gi], s1, nullptr, V1, s2, V2, lane);
+        float s2[64], V2[3][8];
+        gvp_apply<16, 0, 16, 4, true, false>(nw.upd[gi], s1, nullptr, V1, nullptr, s2, V2, lane);
 #pragma unroll
         for (int q = 0; q < 64; ++q) s1[q] = s2[q];
 #pragma unroll
-        for (int q = 0; q < 48; ++q) V1[q] = V2[q];
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) V1[c][q] = V2[c][q];
     }
 #pragma unroll
     for (int q = 0; q < 64; ++q) s[q] += s1[q];
 #pragma unroll
-    for (int q = 0; q < 48; ++q) V[q] += V1[q];
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) V[c][q] += V1[c][q];
     gvp_layernorm(nw.ln2_w, nw.ln2_b, hl, s, V);
     if (live) {
         store_row_f(p.h_out + (size_t)n * PF_S, hl, s);
-        store_vec48_half(p.v_out + (size_t)n * 48, hl, V);
+        store_vec_r(p.v_out + (size_t)n * 48, hl, V);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Noise head on the pharmacophore nodes (dynamics_gvp.py:37-42).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, PF_WPS_HEAD) void k_noise_head(const HeadParams p) {
+__global__ __launch_bounds__(64, PF_WPS_HEAD) void k_noise_head(const HeadParams p) {
     const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+    const int wid = blockIdx.x;
     if (wid >= p.ntiles) return;
     const NodeTile t = p.tiles[wid];
     const int j = lane & 31, hl = lane >> 5;
     const bool live = j < t.n;
     const int n = t.n0 + min(j, t.n - 1);
-    float s1[64], V1[48];
+    float s1[64], V1[3][8];
     load_row_f(p.h + (size_t)n * PF_S, hl, s1);
-    load_vec48(p.v + (size_t)n * 48, V1);
+    load_vec_r(p.v + (size_t)n * 48, hl, V1);
     for (int gi = 0; gi + 1 < p.n_gvps; ++gi) {
-        float s2[64], V2[48];
-        gvp_apply<16, 0, 16, 4, true, false>(p.gvps[gi], s1, nullptr, V1, s2, V2, lane);
+        float s2[64], V2[3][8];
+        gvp_apply<16, 0, 16, 4, true, false>(p.gvps[gi], s1, nullptr, V1, nullptr, s2, V2, lane);
 #pragma unroll
         for (int q = 0; q < 64; ++q) s1[q] = s2[q];
 #pragma unroll
-        for (int q = 0; q < 48; ++q) V1[q] = V2[q];
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) V1[c][q] = V2[c][q];
     }
-    float so[32], Vo[3];
-    gvp_apply<16, 0, 1, 2, false, false>(p.gvps[p.n_gvps - 1], s1, nullptr, V1, so, Vo, lane);
+    float so[32], Vo[3][8];
+    gvp_apply<16, 0, 1, 2, false, false>(p.gvps[p.n_gvps - 1], s1, nullptr, V1, nullptr, so, Vo, lane);
     // to_scalar_output: Linear(64 -> pharm_nf), rows 0..5 of a 32-row tile
     f32x16 o;
 #pragma unroll
@@ -432,10 +481,10 @@ __global__ __launch_bounds__(256, PF_WPS_HEAD) void k_noise_head(const HeadParam
             const int u = (r & 3) + 8 * (r >> 2) + 4 * hl;
             if (u < p.pharm_nf) p.eps_h[(size_t)f * p.pharm_nf + u] = o[r] + p.b_out[u];
         }
-        if (hl == 0) {
-            p.eps_x[(size_t)f * 3 + 0] = Vo[0];
-            p.eps_x[(size_t)f * 3 + 1] = Vo[1];
-            p.eps_x[(size_t)f * 3 + 2] = Vo[2];
+        if (hl == 0) {                                  // output vector channel 0 = register 0 of lane half 0
+            p.eps_x[(size_t)f * 3 + 0] = Vo[0][0];
+            p.eps_x[(size_t)f * 3 + 1] = Vo[1][0];
+            p.eps_x[(size_t)f * 3 + 2] = Vo[2][0];
         }
     }
 }
@@ -831,15 +880,15 @@ void pfk_edge_msg(const EdgeParams* p, int layer0, hipStream_t s) {
     else hipLaunchKernelGGL(k_edge_msg<false>, dim3(blocks), dim3(256), 0, s, *p);
 }
 void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s) {
-    const int blocks = (p->ntiles + 3) / 4;
+    const int blocks = p->ntiles;
     if (blocks == 0) return;
-    if (layer0) hipLaunchKernelGGL(k_node_update<true>, dim3(blocks), dim3(256), 0, s, *p);
-    else hipLaunchKernelGGL(k_node_update<false>, dim3(blocks), dim3(256), 0, s, *p);
+    if (layer0) hipLaunchKernelGGL(k_node_update<true>, dim3(blocks), dim3(64), 0, s, *p);
+    else hipLaunchKernelGGL(k_node_update<false>, dim3(blocks), dim3(64), 0, s, *p);
 }
 void pfk_noise_head(const HeadParams* p, hipStream_t s) {
-    const int blocks = (p->ntiles + 3) / 4;
+    const int blocks = p->ntiles;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_noise_head, dim3(blocks), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(k_noise_head, dim3(blocks), dim3(64), 0, s, *p);
 }
 void pfk_encode(const EncodeParams* p, hipStream_t s) {
     const int n = p->Np + p->Nf;
