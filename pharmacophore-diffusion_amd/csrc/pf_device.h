@@ -48,6 +48,7 @@ struct GvpW {              // packed weights of one GVP (device pointers)
     pf_gcf a_wh;           // [8(+1)][64 lanes]      A fragments of Wh^T (vector channel, R-layout k order)
     pf_gcf a_wu;           // [8(+1)][64 lanes]      A fragments of Wu^T
     pf_gcf a_main;         // [NKS][64 lanes][NMO]   A fragments of to_feats_out
+    pf_gcf a_main_c;       // [NMO][NKS][64 lanes]   the same fragments, one output tile contiguous (4-wave kernels)
     pf_gcf b_main;         // [2 halves][NMO*16]     bias in F-layout
     pf_gcf a_gate;         // [NMO*16][64 lanes]     A fragments of scalar_to_vector_gates (rows 0..VO-1)
     pf_gcf b_gate;         // [2 halves][8]          gate bias in R-layout

@@ -16,6 +16,9 @@
 
 extern "C" {
 void pfk_edge_msg(const EdgeParams* p, int layer0, hipStream_t s);
+void pfk_edge_msg_coop(const EdgeParams* p, int layer0, hipStream_t s);
+void pfk_node_update_coop(const NodeParams* p, int layer0, hipStream_t s);
+void pfk_noise_head_coop(const HeadParams* p, hipStream_t s);
 void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s);
 void pfk_noise_head(const HeadParams* p, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
@@ -96,6 +99,8 @@ struct pf_handle {
           *d_v[2] = {nullptr, nullptr}, *d_msg_s = nullptr, *d_msg_v = nullptr, *d_eps_h = nullptr, *d_eps_x = nullptr,
           *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr;
     bool sampling = false;
+    // launches with at most this many tiles use the 4-wave cooperative kernels (latency-bound regime)
+    int coop_edge_max = 512, coop_node_max = 1024;
 
     // ---- optional per-kernel timing with HIP events on the caller's stream (pf_profile_*)
     enum { K_ENCODE = 0, K_BUILD, K_EDGE, K_NODE, K_HEAD, K_STEP, K_NUM };
@@ -204,7 +209,7 @@ static size_t push(std::vector<float>& w, const std::vector<float>& v) {
     return off;
 }
 
-struct GvpOff { size_t wh, wu, a_main, b_main, a_gate, b_gate; };
+struct GvpOff { size_t wh, wu, a_main, a_main_c, b_main, a_gate, b_gate; };
 
 static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
     const int H = std::max(g.vi, g.vo);
@@ -254,6 +259,14 @@ static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
             }
         }
     o.a_main = push(h->h_w, a);
+    {   // the same fragments with one output tile contiguous: [mo][ks][lane]
+        std::vector<float> ac(a.size());
+        for (int ks = 0; ks < NKS; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int mo = 0; mo < NMO; ++mo)
+                    ac[((size_t)mo * NKS + ks) * 64 + lane] = a[((size_t)ks * 64 + lane) * NMO + mo];
+        o.a_main_c = push(h->h_w, ac);
+    }
     std::vector<float> b((size_t)2 * NMO * 16);
     for (int hl = 0; hl < 2; ++hl)
         for (int mo = 0; mo < NMO; ++mo)
@@ -345,7 +358,8 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s)
         e.w = h->d_gvp + h->msg_base(l, 0); e.n_gvps = c.n_message_gvps;
         linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
         e.rbf_inv_sigma = 1.0f / ((c.rbf_dmax - 0.f) / (float)c.rbf_dim);
-        { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
+        // few tiles (last layer): 4 waves per tile to cut the serial latency; otherwise one wave per tile
+        { ProfScope ps(h, pf_handle::K_EDGE, s); if (e.ntiles <= h->coop_edge_max) pfk_edge_msg_coop(&e, l == 0, s); else pfk_edge_msg(&e, l == 0, s); }
 
         NodeParams n{};
         n.tiles = h->d_node_tiles; n.ntiles = last ? h->n_node_tiles_last : h->n_node_tiles;
@@ -361,7 +375,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s)
             n.w[nt].upd = h->d_gvp + h->upd_base(l, nt);
         }
         n.n_upd = c.n_update_gvps;
-        { ProfScope ps(h, pf_handle::K_NODE, s); pfk_node_update(&n, l == 0, s); }
+        { ProfScope ps(h, pf_handle::K_NODE, s); if (n.ntiles <= h->coop_node_max) pfk_node_update_coop(&n, l == 0, s); else pfk_node_update(&n, l == 0, s); }
         cur ^= 1;
     }
     HeadParams hp{};
@@ -370,7 +384,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s)
     hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
     hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
     hp.eps_h = eps_h; hp.eps_x = eps_x;
-    { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_noise_head(&hp, s); }
+    { ProfScope ps(h, pf_handle::K_HEAD, s); if (hp.ntiles <= h->coop_node_max) pfk_noise_head_coop(&hp, s); else pfk_noise_head(&hp, s); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return PF_OK;
@@ -506,7 +520,7 @@ int pf_commit_weights(pf_handle* h) {
     PF_HIP(h, hipMemcpy(h->d_w, h->h_w.data(), h->h_w.size() * sizeof(float), hipMemcpyHostToDevice));
     for (const GvpOff& o : offs) {
         GvpW g;
-        g.a_wh = h->d_w + o.wh; g.a_wu = h->d_w + o.wu; g.a_main = h->d_w + o.a_main; g.b_main = h->d_w + o.b_main;
+        g.a_wh = h->d_w + o.wh; g.a_wu = h->d_w + o.wu; g.a_main = h->d_w + o.a_main; g.a_main_c = h->d_w + o.a_main_c; g.b_main = h->d_w + o.b_main;
         g.a_gate = h->d_w + o.a_gate; g.b_gate = h->d_w + o.b_gate;
         h->h_gvp.push_back(g);
     }

@@ -490,6 +490,394 @@ __global__ __launch_bounds__(64, PF_WPS_HEAD) void k_noise_head(const HeadParams
 }
 
 // ---------------------------------------------------------------------------------------------
+// Cooperative (4-wave) form of the same GVP for launches with few tiles (last-layer edges, node
+// update, noise head): one 256-thread block per 32-row tile.  The 128 outputs of the scalar Linear
+// are split over the waves (wave w owns output tile w), the three coordinates of the vector channel
+// over waves 0..2, the K dimension of the gate Linear over the waves; partial results meet in LDS
+// (two barriers per GVP).  Per wave a generic GVP is 104 MFMAs instead of 400, so the serial latency
+// of a chain -- what these launches are bound by -- drops ~3.5x, and each wave streams only a quarter
+// of the weights.  All waves keep a full copy of the scalar state (F-layout); wave c keeps
+// coordinate c of the vector state (R-layout, 8 registers).
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) CoopLds {
+    float vh[3][9][64];     // Vh of coordinate c, k-step t          (for sh = |Vh|)
+    float so[4][16][64];    // SiLU output tile of wave w             (next layer's input)
+    float pg[4][8][64];     // partial gates of wave w
+    float vx[3][8][64];     // vector output of coordinate c          (stores / norms)
+};
+
+template <int VI, int NEXTRA, int VO, int NMO, bool SIG, bool VROW0>
+__device__ __forceinline__ void gvp_apply_coop(const GvpW w, const float (&s_in)[64], const float* ext,
+                                               const float (&Vc)[8], const float xhat_c, float (&s_out)[NMO * 16],
+                                               float (&Vc_out)[8], const int lane, const int wv, CoopLds& L) {
+    constexpr bool X = (VI == 17);
+    constexpr int NVK = 8 + (X ? 1 : 0);
+    constexpr int KS_A = 64 + NEXTRA / 2;            // k-steps that do not need sh
+    constexpr int NKS = KS_A + NVK;
+    constexpr int CH = 16;                           // deep prefetch: these launches are latency-bound
+    constexpr int NCH = (KS_A + CH - 1) / CH;
+    const int hl = lane >> 5;
+    // (1) vector products of coordinate wv on the matrix cores
+    float Vu[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) Vu[t] = 0.f;
+    if (wv < 3) {
+        f32x16 vh, vu;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { vh[r] = 0.f; vu[r] = 0.f; }
+        float a[NVK], b[NVK];
+#pragma unroll
+        for (int t = 0; t < NVK; ++t) { a[t] = w.a_wh[t * 64 + lane]; b[t] = w.a_wu[t * 64 + lane]; }
+#pragma unroll
+        for (int t = VROW0 ? 8 : 0; t < NVK; ++t) vh = MFMA(a[t], t < 8 ? Vc[t < 8 ? t : 0] : xhat_c, vh);
+#pragma unroll
+        for (int t = 0; t < NVK; ++t) L.vh[wv][t][lane] = vh[t];
+#pragma unroll
+        for (int t = 0; t < NVK; ++t) vu = MFMA(b[t], vh[t], vu);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) Vu[t] = vu[t];
+    }
+    // (2) this wave's output tile of the scalar Linear: the k-steps that do not depend on sh
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    pf_gcf ap = w.a_main_c + (size_t)(wv < NMO ? wv : 0) * NKS * 64 + lane;
+    if (wv < NMO) {
+        const f32x4 PF_AS1* bp = reinterpret_cast<const f32x4 PF_AS1*>(w.b_main + hl * (NMO * 16) + wv * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = bp[q];
+            acc[4 * q + 0] = b4[0]; acc[4 * q + 1] = b4[1]; acc[4 * q + 2] = b4[2]; acc[4 * q + 3] = b4[3];
+        }
+        float abuf[2][CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (i < KS_A) abuf[0][i] = ap[i * 64];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+                    if ((c + 1) * CH + i < KS_A) abuf[(c + 1) & 1][i] = ap[((c + 1) * CH + i) * 64];
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int ks = c * CH + i;
+                if (ks < KS_A) acc = MFMA(abuf[c & 1][i], ks < 64 ? s_in[ks < 64 ? ks : 0] : ext[ks >= 64 ? ks - 64 : 0], acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float ash[NVK], ag[16];
+    if (wv < NMO) {
+#pragma unroll
+        for (int t = 0; t < NVK; ++t) ash[t] = ap[(KS_A + t) * 64];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ag[r] = w.a_gate[(wv * 16 + r) * 64 + lane];
+    }
+    __syncthreads();                                  // B1: every Vh is in LDS
+    // (3) sh = |Vh| for this lane's channels, (4) the sh k-steps, SiLU, partial gates
+    if (wv < NMO) {
+#pragma unroll
+        for (int t = 0; t < NVK; ++t) {
+            const float x = L.vh[0][t][lane], y = L.vh[1][t][lane], z = L.vh[2][t][lane];
+            acc = MFMA(ash[t], sqrtf_(fmaxf(x * x + y * y + z * z, 1e-8f)), acc);
+        }
+        f32x16 g;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float so = siluf_(acc[r]);
+            L.so[wv][r][lane] = so;
+            g = MFMA(ag[r], so, g);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) L.pg[wv][t][lane] = g[t];
+    }
+    __syncthreads();                                  // B2: output tiles and partial gates are in LDS
+    // (5) assemble the full scalar output; gate this wave's coordinate
+#pragma unroll
+    for (int mt = 0; mt < NMO; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_out[mt * 16 + r] = L.so[mt][r][lane];
+    {
+        const f32x4 PF_AS1* bg = reinterpret_cast<const f32x4 PF_AS1*>(w.b_gate + hl * 8);
+        const f32x4 b0 = bg[0], b1 = bg[1];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (VO == 1 && t > 0) { Vc_out[t] = 0.f; continue; }
+            float gv = (t < 4 ? b0[t & 3] : b1[t & 3]);
+#pragma unroll
+            for (int ww = 0; ww < NMO; ++ww) gv += L.pg[ww][t][lane];
+            if constexpr (SIG) gv = sigmoidf_(gv);
+            Vc_out[t] = gv * Vu[t];
+        }
+    }
+}
+
+// this wave's coordinate (wv = 0..2) of the lane's 8 channels of a [16][3] vector row
+template <typename P>
+__device__ __forceinline__ void load_vec_rc(P row, const int hl, const int wv, float (&Vc)[8]) {
+    float V[3][8];
+    load_vec_r(row, hl, V);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) Vc[t] = wv == 0 ? V[0][t] : (wv == 1 ? V[1][t] : V[2][t]);
+}
+
+template <bool L0>
+__global__ __launch_bounds__(256, 1) void k_edge_msg_coop(const EdgeParams p) {
+    __shared__ CoopLds L;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const EdgeTile t = p.tiles[blockIdx.x];
+    int nvalid = t.n;
+    if (t.cnt_idx >= 0) {
+        const int c = p.dyn_cnt[t.cnt_idx] - t.rel;
+        nvalid = min(nvalid, max(c, 0));
+    }
+    nvalid = __builtin_amdgcn_readfirstlane(nvalid);
+    if (nvalid <= 0) return;                           // block-uniform
+    const int et = __builtin_amdgcn_readfirstlane(t.et);
+    const int j = lane & 31, hl = lane >> 5;
+    const int e = t.e0 + min(j, nvalid - 1);
+    const int src = p.esrc[e], dst = p.edst[e];
+    const float4 xs = p.xn[src], xd = p.xn[dst];
+    const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
+    const float d = sqrtf_(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+    const float rd = rcpf_(d);
+    const float xhat_c = (wv == 0 ? dx : (wv == 1 ? dy : dz)) * rd;
+    float rb[PF_R / 2];
+#pragma unroll
+    for (int k = 0; k < PF_R / 2; ++k) {
+        const float ze = (d - p.rbf_mu[2 * k]) * p.rbf_inv_sigma;
+        const float zo = (d - p.rbf_mu[2 * k + 1]) * p.rbf_inv_sigma;
+        const float re = __expf(-(ze * ze)), ro = __expf(-(zo * zo));
+        rb[k] = hl ? ro : re;
+    }
+    float s[64], Vc[8];
+    load_row_f(p.h + (size_t)src * PF_S, hl, s);
+    if constexpr (!L0) load_vec_rc(p.v + (size_t)src * 48, hl, wv, Vc);
+    else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) Vc[q] = 0.f;
+    }
+    const GvpW PF_AS1* wt = (const GvpW PF_AS1*)p.w + et * p.n_gvps;
+    float s1[64], V1[8];
+    gvp_apply_coop<17, PF_R, 16, 4, true, L0>(wt[0], s, rb, Vc, xhat_c, s1, V1, lane, wv, L);
+    for (int gi = 1; gi < p.n_gvps; ++gi) {
+        float s2[64], V2[8];
+        gvp_apply_coop<16, 0, 16, 4, true, false>(wt[gi], s1, nullptr, V1, 0.f, s2, V2, lane, wv, L);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) s1[q] = s2[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) V1[q] = V2[q];
+    }
+    if (wv < 3) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) L.vx[wv][q][lane] = V1[q];
+    }
+    __syncthreads();
+    if (j < nvalid) {
+        if (wv == 3) store_row_f(p.msg_s + (size_t)e * PF_S, hl, s1);
+        if (wv == 0) {
+            float V[3][8];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) V[c][q] = L.vx[c][q][lane];
+            store_vec_r(p.msg_v + (size_t)e * 48, hl, V);
+        }
+    }
+}
+
+// GVPLayerNorm with the vector state spread over waves 0..2 (coordinate c in wave c)
+__device__ __forceinline__ void gvp_layernorm_coop(pf_gcf lw, pf_gcf lb, const int hl, const int lane, const int wv,
+                                                   float (&s)[64], float (&Vc)[8], CoopLds& L) {
+    if (wv < 3) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) L.vx[wv][t][lane] = Vc[t] * Vc[t];
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) sum += s[q];
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / 128.0f);
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) { const float c = s[q] - mean; var = fmaf(c, c, var); }
+    var += __shfl_xor(var, 32);
+    const float rstd = rsqf_(var * (1.0f / 128.0f) + 1e-5f);
+    float w[64], b[64];
+    load_row_f(lw, hl, w);
+    load_row_f(lb, hl, b);
+#pragma unroll
+    for (int q = 0; q < 64; ++q) s[q] = (s[q] - mean) * rstd * w[q] + b[q];
+    __syncthreads();
+    float vn = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) vn += fmaxf(L.vx[0][t][lane] + L.vx[1][t][lane] + L.vx[2][t][lane], 1e-8f);
+    vn += __shfl_xor(vn, 32);
+    const float rden = rcpf_(sqrtf_(vn * (1.0f / 16.0f) + 1e-5f) + 1e-5f);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) Vc[t] = Vc[t] * rden;
+    __syncthreads();                                   // vx is reused by the caller
+}
+
+template <bool L0>
+__global__ __launch_bounds__(256, 1) void k_node_update_coop(const NodeParams p) {
+    __shared__ CoopLds L;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const NodeTile t = p.tiles[blockIdx.x];
+    const int nt = __builtin_amdgcn_readfirstlane(t.ntype);
+    const int j = lane & 31, hl = lane >> 5;
+    const bool live = j < t.n;
+    const int n = t.n0 + min(j, t.n - 1);
+    // segmented reduction of the in-edge messages: wave w sums scalar tile w (features 32w..32w+31) and,
+    // for w < 3, coordinate w of the vector message
+    float ms16[16], mvc[8];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ms16[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mvc[q] = 0.f;
+    for (int slot = 0; slot < 2; ++slot) {
+        const int st = p.in_start[slot * p.N + n];
+        const int c = live ? p.in_cnt[slot * p.N + n] : 0;
+        int cmax = c;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+        cmax = __builtin_amdgcn_readfirstlane(cmax);
+        const float sc = (p.norm_mode == 0 && c > 0) ? 1.0f / (float)c : 1.0f;
+        for (int i = 0; i < cmax; ++i) {
+            if (i < c) {
+                auto rp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.msg_s + (size_t)(st + i) * PF_S + 32 * wv + 4 * hl);
+                const f32x4 r0 = rp[0], r1 = rp[2], r2 = rp[4], r3 = rp[6];
+                float rv[8];
+                if (wv < 3) load_vec_rc(p.msg_v + (size_t)(st + i) * 48, hl, wv, rv);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ms16[q] = fmaf(r0[q], sc, ms16[q]);
+                    ms16[4 + q] = fmaf(r1[q], sc, ms16[4 + q]);
+                    ms16[8 + q] = fmaf(r2[q], sc, ms16[8 + q]);
+                    ms16[12 + q] = fmaf(r3[q], sc, ms16[12 + q]);
+                }
+                if (wv < 3) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) mvc[q] = fmaf(rv[q], sc, mvc[q]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) L.so[wv][r][lane] = ms16[r];
+    float inv_norm = 1.0f;
+    if (p.norm_mode == 1) inv_norm = 1.0f / p.norm_value;
+    else if (p.norm_mode == 2) inv_norm = 1.0f / p.gnorm[nt * p.B + p.gid[n]];
+    float s[64], Vc[8];
+    load_row_f(p.h_in + (size_t)n * PF_S, hl, s);
+    if constexpr (!L0) {
+        if (wv < 3) load_vec_rc(p.v_in + (size_t)n * 48, hl, wv, Vc);
+        else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) Vc[q] = 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) Vc[q] = 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[mt * 16 + r] = fmaf(L.so[mt][r][lane], inv_norm, s[mt * 16 + r]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) Vc[q] = fmaf(mvc[q], inv_norm, Vc[q]);
+    __syncthreads();                                   // so is reused by the GVP chain
+    const NodeW nw = p.w[nt];
+    gvp_layernorm_coop(nw.ln1_w, nw.ln1_b, hl, lane, wv, s, Vc, L);
+    float s1[64], V1[8];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) s1[q] = s[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) V1[q] = Vc[q];
+    for (int gi = 0; gi < p.n_upd; ++gi) {
+        float s2[64], V2[8];
+        gvp_apply_coop<16, 0, 16, 4, true, false>(nw.upd[gi], s1, nullptr, V1, 0.f, s2, V2, lane, wv, L);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) s1[q] = s2[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) V1[q] = V2[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 64; ++q) s[q] += s1[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) Vc[q] += V1[q];
+    gvp_layernorm_coop(nw.ln2_w, nw.ln2_b, hl, lane, wv, s, Vc, L);
+    if (wv < 3) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) L.vx[wv][q][lane] = Vc[q];
+    }
+    __syncthreads();
+    if (live) {
+        if (wv == 3) store_row_f(p.h_out + (size_t)n * PF_S, hl, s);
+        if (wv == 0) {
+            float V[3][8];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) V[c][q] = L.vx[c][q][lane];
+            store_vec_r(p.v_out + (size_t)n * 48, hl, V);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void k_noise_head_coop(const HeadParams p) {
+    __shared__ CoopLds L;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const NodeTile t = p.tiles[blockIdx.x];
+    const int j = lane & 31, hl = lane >> 5;
+    const bool live = j < t.n;
+    const int n = t.n0 + min(j, t.n - 1);
+    float s1[64], V1[8];
+    load_row_f(p.h + (size_t)n * PF_S, hl, s1);
+    if (wv < 3) load_vec_rc(p.v + (size_t)n * 48, hl, wv, V1);
+    else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) V1[q] = 0.f;
+    }
+    for (int gi = 0; gi + 1 < p.n_gvps; ++gi) {
+        float s2[64], V2[8];
+        gvp_apply_coop<16, 0, 16, 4, true, false>(p.gvps[gi], s1, nullptr, V1, 0.f, s2, V2, lane, wv, L);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) s1[q] = s2[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) V1[q] = V2[q];
+    }
+    float so[32], Vo[8];
+    gvp_apply_coop<16, 0, 1, 2, false, false>(p.gvps[p.n_gvps - 1], s1, nullptr, V1, 0.f, so, Vo, lane, wv, L);
+    const int f = n - p.node_base;
+    if (wv == 3) {
+        // to_scalar_output: Linear(64 -> pharm_nf), rows 0..5 of a 32-row tile
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) o = MFMA(p.a_out[ks * 64 + lane], so[ks], o);
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int u = (r & 3) + 8 * (r >> 2) + 4 * hl;
+                if (u < p.pharm_nf) p.eps_h[(size_t)f * p.pharm_nf + u] = o[r] + p.b_out[u];
+            }
+        }
+    } else if (live && hl == 0) {
+        p.eps_x[(size_t)f * 3 + wv] = Vo[0];           // output vector channel 0, coordinate wv
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Scalar encoders: h = LayerNorm(SiLU(W [feat, t] + b))   (dynamics_gvp.py:107-117,143-151)
 // one wave per node, two features per lane.
 // ---------------------------------------------------------------------------------------------
@@ -873,6 +1261,20 @@ __global__ __launch_bounds__(256) void k_pp_radius(const float4* xn, const int* 
 // launch helpers (called from pf_host.cpp)
 // ---------------------------------------------------------------------------------------------
 extern "C" {
+void pfk_edge_msg_coop(const EdgeParams* p, int layer0, hipStream_t s) {
+    if (p->ntiles == 0) return;
+    if (layer0) hipLaunchKernelGGL(k_edge_msg_coop<true>, dim3(p->ntiles), dim3(256), 0, s, *p);
+    else hipLaunchKernelGGL(k_edge_msg_coop<false>, dim3(p->ntiles), dim3(256), 0, s, *p);
+}
+void pfk_node_update_coop(const NodeParams* p, int layer0, hipStream_t s) {
+    if (p->ntiles == 0) return;
+    if (layer0) hipLaunchKernelGGL(k_node_update_coop<true>, dim3(p->ntiles), dim3(256), 0, s, *p);
+    else hipLaunchKernelGGL(k_node_update_coop<false>, dim3(p->ntiles), dim3(256), 0, s, *p);
+}
+void pfk_noise_head_coop(const HeadParams* p, hipStream_t s) {
+    if (p->ntiles == 0) return;
+    hipLaunchKernelGGL(k_noise_head_coop, dim3(p->ntiles), dim3(256), 0, s, *p);
+}
 void pfk_edge_msg(const EdgeParams* p, int layer0, hipStream_t s) {
     const int blocks = (p->ntiles + 3) / 4;
     if (blocks == 0) return;
