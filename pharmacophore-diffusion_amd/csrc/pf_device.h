@@ -99,6 +99,7 @@ struct NodeParams {
     int N;
     const float* msg_s;
     const float* msg_v;
+    int zero_row;          // index of an all-zero message row (lanes without in-edges)
     const float* h_in; const float* v_in;
     float* h_out; float* v_out;
     const int* gid;        // graph of each node
@@ -127,7 +128,8 @@ struct EncodeParams {
     int Np, Nf;
     const float* prot_h0;  // [Np][rec_nf]
     const float* pharm_h;  // [Nf][pharm_nf]
-    const float* t;        // [B]
+    const float* t;        // [B], or NULL: every graph is at t_scalar
+    float t_scalar;
     const int* gid;
     int rec_nf, pharm_nf;
     const float* w[2]; const float* b[2]; const float* ln_w[2]; const float* ln_b[2];  // 0 prot, 1 pharm

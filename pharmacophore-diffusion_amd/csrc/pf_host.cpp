@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -22,6 +23,7 @@ void pfk_noise_head_coop(const HeadParams* p, hipStream_t s);
 void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s);
 void pfk_noise_head(const HeadParams* p, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
+void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
 void pfk_build_edges(const BuildParams* p, hipStream_t s);
 void pfk_load_coords(const float* src, float4* xn, int n, const int* gid, const float* shift, float sign, hipStream_t s);
 void pfk_load_noise0(const float* nz, float4* xn, float* hf, int n, int nf, hipStream_t s);
@@ -87,6 +89,7 @@ struct pf_handle {
     std::vector<int> h_reg;                 // [3][B]
     std::vector<int> h_cap;                 // [3][B]
     int n_edge_tiles = 0, n_node_tiles = 0, n_head_tiles = 0;
+    int zero_row = 0;
     int n_edge_tiles_last = 0, n_node_tiles_last = 0;   // last conv layer: only what feeds the pharm nodes
     void* d_ws = nullptr;                   // one allocation, carved below
     int *d_prot_ptr = nullptr, *d_pharm_ptr = nullptr, *d_gid = nullptr, *d_reg = nullptr, *d_dyn_cnt = nullptr,
@@ -101,6 +104,10 @@ struct pf_handle {
     bool sampling = false;
     // launches with at most this many tiles use the 4-wave cooperative kernels (latency-bound regime)
     int coop_edge_max = 512, coop_node_max = 1024;
+    void init_tuning() {
+        if (const char* e = getenv("PFDYN_COOP_EDGE_MAX")) coop_edge_max = atoi(e);
+        if (const char* e = getenv("PFDYN_COOP_NODE_MAX")) coop_node_max = atoi(e);
+    }
 
     // ---- optional per-kernel timing with HIP events on the caller's stream (pf_profile_*)
     enum { K_ENCODE = 0, K_BUILD, K_EDGE, K_NODE, K_HEAD, K_STEP, K_NUM };
@@ -324,18 +331,18 @@ struct ProfScope {
 };
 
 // sequence one dynamics call on the handle's state (xn, pharm_h, d_t)
-static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s) {
+static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s, const float* t_scalar = nullptr) {
     const pf_config& c = h->cfg;
     EncodeParams ep{};
     ep.Np = h->Np; ep.Nf = h->Nf;
-    ep.prot_h0 = h->d_prot_h0; ep.pharm_h = h->d_pharm_h; ep.t = h->d_t; ep.gid = h->d_gid;
+    ep.prot_h0 = h->d_prot_h0; ep.pharm_h = h->d_pharm_h; ep.t = t_scalar ? nullptr : h->d_t; ep.gid = h->d_gid;
+    ep.t_scalar = t_scalar ? *t_scalar : 0.f;
     ep.rec_nf = c.rec_nf; ep.pharm_nf = c.pharm_nf;
     for (int nt = 0; nt < 2; ++nt) {
         ep.w[nt] = h->d_w + h->enc_w[nt]; ep.b[nt] = h->d_w + h->enc_b[nt];
         ep.ln_w[nt] = h->d_w + h->enc_lw[nt]; ep.ln_b[nt] = h->d_w + h->enc_lb[nt];
     }
     ep.h_out = h->d_h[0];
-    { ProfScope ps(h, pf_handle::K_ENCODE, s); pfk_encode(&ep, s); }
 
     BuildParams bp{};
     bp.B = h->B; bp.Np_tot = h->Np;
@@ -345,7 +352,10 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s)
     bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
     bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
     bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
-    { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); }
+    if (h->prof_mask & 3u) {     // timing the two halves separately needs separate launches
+        { ProfScope ps(h, pf_handle::K_ENCODE, s); pfk_encode(&ep, s); }
+        { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); }
+    } else pfk_encode_build(&ep, &bp, s);
 
     int cur = 0;
     for (int l = 0; l < c.n_convs; ++l) {
@@ -364,7 +374,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s)
         NodeParams n{};
         n.tiles = h->d_node_tiles; n.ntiles = last ? h->n_node_tiles_last : h->n_node_tiles;
         n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
-        n.msg_s = h->d_msg_s; n.msg_v = h->d_msg_v;
+        n.msg_s = h->d_msg_s; n.msg_v = h->d_msg_v; n.zero_row = h->zero_row;
         n.h_in = h->d_h[cur]; n.v_in = h->d_v[cur]; n.h_out = h->d_h[cur ^ 1]; n.v_out = h->d_v[cur ^ 1];
         n.gid = h->d_gid; n.gnorm = h->d_gnorm; n.B = h->B;
         n.norm_mode = c.message_norm_mode; n.norm_value = c.message_norm_value;
@@ -428,6 +438,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     }
     pf_handle* h = new pf_handle();
     h->cfg = *cfg;
+    h->init_tuning();
     *out = h;
     return PF_OK;
 }
@@ -578,6 +589,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
             int cap;
             if (et == ET_FF) cap = c.ff_k > 0 ? nf * std::min(c.ff_k, std::max(nf - 1, 0)) : nf * std::max(nf - 1, 0);
             else cap = c.pf_k > 0 ? nf * std::min(c.pf_k, np) : nf * np;
+            cursor = (cursor + 31) & ~int64_t(31);     // tiles are aligned to multiples of 32 slots (seg_tail in the kernels)
             h->h_reg[(size_t)et * B + g] = (int)cursor;
             h->h_cap[(size_t)et * B + g] = cap;
             cursor += cap;
@@ -627,7 +639,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     need(et_tiles.size() * sizeof(EdgeTile) + 256); need(n_tiles.size() * sizeof(NodeTile) + 256); need(h_tiles.size() * sizeof(NodeTile) + 256);
     need((size_t)N * 16); need((size_t)Np * 3 * 4 + 16); need((size_t)Np * c.rec_nf * 4 + 16); need((size_t)Nf * c.pharm_nf * 4 + 16); need((size_t)B * 4);
     need((size_t)N * PF_S * 4); need((size_t)N * PF_S * 4); need((size_t)N * 48 * 4); need((size_t)N * 48 * 4);
-    need((size_t)Ecap * PF_S * 4); need((size_t)Ecap * 48 * 4);
+    need((size_t)(Ecap + 1) * PF_S * 4); need((size_t)(Ecap + 1) * 48 * 4);
     need((size_t)Nf * c.pharm_nf * 4 + 16); need((size_t)Nf * 3 * 4 + 16); need((size_t)B * 3 * 4); need((size_t)B * 3 * 4); need((size_t)2 * B * 4);
     PF_HIP(h, hipMalloc(&h->d_ws, bytes + 4096));
     char* cur = reinterpret_cast<char*>(h->d_ws);
@@ -641,7 +653,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     h->d_pharm_h = carve<float>(cur, (size_t)Nf * c.pharm_nf + 4); h->d_t = carve<float>(cur, B);
     h->d_h[0] = carve<float>(cur, (size_t)N * PF_S); h->d_h[1] = carve<float>(cur, (size_t)N * PF_S);
     h->d_v[0] = carve<float>(cur, (size_t)N * 48); h->d_v[1] = carve<float>(cur, (size_t)N * 48);
-    h->d_msg_s = carve<float>(cur, (size_t)Ecap * PF_S); h->d_msg_v = carve<float>(cur, (size_t)Ecap * 48);
+    h->d_msg_s = carve<float>(cur, (size_t)(Ecap + 1) * PF_S); h->d_msg_v = carve<float>(cur, (size_t)(Ecap + 1) * 48);
     h->d_eps_h = carve<float>(cur, (size_t)Nf * c.pharm_nf + 4); h->d_eps_x = carve<float>(cur, (size_t)Nf * 3 + 4);
     h->d_com_init = carve<float>(cur, (size_t)B * 3); h->d_com_tmp = carve<float>(cur, (size_t)B * 3); h->d_gnorm = carve<float>(cur, (size_t)2 * B);
     // ---- uploads (synchronous: these are small tables; pageable host memory)
@@ -660,6 +672,9 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     if (!h_tiles.empty()) PF_HIP(h, hipMemcpy(h->d_head_tiles, h_tiles.data(), h_tiles.size() * sizeof(NodeTile), hipMemcpyHostToDevice));
     PF_HIP(h, hipMemsetAsync(h->d_v[0], 0, (size_t)N * 48 * 4, s));
     PF_HIP(h, hipMemsetAsync(h->d_gnorm, 0, (size_t)2 * B * 4, s));
+    PF_HIP(h, hipMemsetAsync(h->d_msg_s, 0, (size_t)(Ecap + 1) * PF_S * 4, s));     // incl. the zero row (index Ecap)
+    PF_HIP(h, hipMemsetAsync(h->d_msg_v, 0, (size_t)(Ecap + 1) * 48 * 4, s));
+    h->zero_row = (int)Ecap;
     pfk_copy(dev_prot_x, h->d_prot_x0, (size_t)Np * 3, s);
     pfk_copy(dev_prot_h, h->d_prot_h0, (size_t)Np * c.rec_nf, s);
     pfk_load_coords(h->d_prot_x0, h->d_xn, Np, h->d_gid, nullptr, 0.f, s);
@@ -751,10 +766,7 @@ int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noi
     if (!coef || !dev_noise) PF_FAIL(h, PF_ERR_ARG, "pf_denoise_step: null argument");
     if (!h->sampling) PF_FAIL(h, PF_ERR_STATE, "pf_denoise_step before pf_sample_begin");
     hipStream_t s = (hipStream_t)stream;
-    uint32_t tbits;
-    memcpy(&tbits, &coef->t, 4);
-    PF_HIP(h, hipMemsetD32Async((hipDeviceptr_t)h->d_t, (int)tbits, (size_t)h->B, s));
-    rc = run_dynamics(h, h->d_eps_h, h->d_eps_x, s);
+    rc = run_dynamics(h, h->d_eps_h, h->d_eps_x, s, &coef->t);      // every graph of the batch is at the same t
     if (rc) return rc;
     StepParams sp{};
     sp.B = h->B; sp.Np_tot = h->Np; sp.prot_ptr = h->d_prot_ptr; sp.pharm_ptr = h->d_pharm_ptr;
@@ -869,7 +881,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     pfk_edge_msg(&e, 0, s);
     NodeParams n{};
     n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles; n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
-    n.msg_s = h->d_msg_s; n.msg_v = h->d_msg_v; n.h_in = h->d_h[0]; n.v_in = h->d_v[0]; n.h_out = h->d_h[1]; n.v_out = h->d_v[1];
+    n.msg_s = h->d_msg_s; n.msg_v = h->d_msg_v; n.zero_row = h->zero_row; n.h_in = h->d_h[0]; n.v_in = h->d_v[0]; n.h_out = h->d_h[1]; n.v_out = h->d_v[1];
     n.gid = h->d_gid; n.gnorm = h->d_gnorm; n.B = h->B; n.norm_mode = c.message_norm_mode; n.norm_value = c.message_norm_value;
     for (int nt = 0; nt < 2; ++nt) {
         const size_t* lo = &h->ln_off[(size_t)(layer * 2 + nt) * 4];
