@@ -496,7 +496,13 @@ int pf_commit_weights(pf_handle* h) {
     for (int k = 0; k < c.n_noise_gvps; ++k) offs.push_back(pack_gvp(h, head_spec(c, k)));
     for (int nt = 0; nt < 2; ++nt) {
         const std::string p = std::string("dynamics.") + kNtKey[nt] + "_encoder.";
-        h->enc_w[nt] = push(h->h_w, h->raw[p + "0.weight"].data);
+        {   // encoder weight transposed to [nf+1][128]: coalesced loads of one input's column
+            const RawTensor& W = h->raw[p + "0.weight"];
+            const int K = (int)W.shape[1], S = (int)W.shape[0];
+            std::vector<float> wt((size_t)K * S);
+            for (int f = 0; f < S; ++f) for (int k = 0; k < K; ++k) wt[(size_t)k * S + f] = W.data[(size_t)f * K + k];
+            h->enc_w[nt] = push(h->h_w, wt);
+        }
         h->enc_b[nt] = push(h->h_w, h->raw[p + "0.bias"].data);
         h->enc_lw[nt] = push(h->h_w, h->raw[p + "2.weight"].data);
         h->enc_lb[nt] = push(h->h_w, h->raw[p + "2.bias"].data);

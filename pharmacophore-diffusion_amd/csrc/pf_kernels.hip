@@ -572,21 +572,42 @@ struct __attribute__((aligned(16))) CoopLds {
     float agg[32][177];     // aggregated messages per node (stride 177: conflict-free column reads)
 };
 
-template <int VI, int NEXTRA, int VO, int NMO, bool SIG, bool VROW0>
-__device__ __forceinline__ void gvp_apply_coop(const GvpW w, const float (&s_in)[64], const float* ext,
-                                               const float (&Vc)[8], const float xhat_c, float (&s_out)[NMO * 16],
-                                               float (&Vc_out)[8], const int lane, const int wv, CoopLds& L) {
-    constexpr bool X = (VI == 17);
-    constexpr int NVK = 8 + (X ? 1 : 0);
-    constexpr int KS_A = 64 + NEXTRA / 2;            // k-steps that do not need sh
-    constexpr int NKS = KS_A + NVK;
-#ifndef PF_CCH
-#define PF_CCH 96
-#endif
-    constexpr int CH = PF_CCH;                       // >= NKS: one burst loads every A fragment of this wave up front
-                                                     // (a wave's share is small; these launches are latency-bound)
-    constexpr int NCH = (KS_A + CH - 1) / CH;
+// One wave's share of a GVP's weights, held in registers: 9+9 vector fragments, <=81 fragments of its output
+// tile, 16 gate fragments and the biases (~130 VGPRs).  Loading is separated from computing so that a chain
+// can fetch GVP g+1 (or overlap the first fetch with the message aggregation) while GVP g runs: these launches
+// are bound by the serial latency of the chain, and the fetch comes from the Infinity Cache / HBM.
+template <int VI, int NEXTRA>
+struct CoopW {
+    static constexpr int NVK = 8 + (VI == 17 ? 1 : 0);
+    static constexpr int NKS = 64 + NEXTRA / 2 + NVK;
+    float awh[NVK], awu[NVK], am[NKS], ag[16];
+    f32x4 bm[4], bg[2];
+};
+template <int VI, int NEXTRA, int NMO>
+__device__ __forceinline__ void gvp_coop_load(const GvpW w, const int lane, const int wv, CoopW<VI, NEXTRA>& W) {
+    constexpr int NVK = CoopW<VI, NEXTRA>::NVK, NKS = CoopW<VI, NEXTRA>::NKS;
     const int hl = lane >> 5;
+    const int wm = wv < NMO ? wv : 0;
+#pragma unroll
+    for (int t = 0; t < NVK; ++t) { W.awh[t] = w.a_wh[t * 64 + lane]; W.awu[t] = w.a_wu[t * 64 + lane]; }
+    pf_gcf ap = w.a_main_c + (size_t)wm * NKS * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) W.am[ks] = ap[ks * 64];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) W.ag[r] = w.a_gate[(wm * 16 + r) * 64 + lane];
+    const f32x4 PF_AS1* bp = reinterpret_cast<const f32x4 PF_AS1*>(w.b_main + hl * (NMO * 16) + wm * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) W.bm[q] = bp[q];
+    const f32x4 PF_AS1* bg = reinterpret_cast<const f32x4 PF_AS1*>(w.b_gate + hl * 8);
+    W.bg[0] = bg[0]; W.bg[1] = bg[1];
+}
+
+template <int VI, int NEXTRA, int VO, int NMO, bool SIG, bool VROW0>
+__device__ __forceinline__ void gvp_coop_compute(const CoopW<VI, NEXTRA>& W, const float (&s_in)[64], const float* ext,
+                                                 const float (&Vc)[8], const float xhat_c, float (&s_out)[NMO * 16],
+                                                 float (&Vc_out)[8], const int lane, const int wv, CoopLds& L) {
+    constexpr int NVK = CoopW<VI, NEXTRA>::NVK;
+    constexpr int KS_A = 64 + NEXTRA / 2;            // k-steps that do not need sh
     // (1) vector products of coordinate wv on the matrix cores
     float Vu[8];
 #pragma unroll
@@ -595,55 +616,25 @@ __device__ __forceinline__ void gvp_apply_coop(const GvpW w, const float (&s_in)
         f32x16 vh, vu;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { vh[r] = 0.f; vu[r] = 0.f; }
-        float a[NVK], b[NVK];
 #pragma unroll
-        for (int t = 0; t < NVK; ++t) { a[t] = w.a_wh[t * 64 + lane]; b[t] = w.a_wu[t * 64 + lane]; }
-#pragma unroll
-        for (int t = VROW0 ? 8 : 0; t < NVK; ++t) vh = MFMA(a[t], t < 8 ? Vc[t < 8 ? t : 0] : xhat_c, vh);
+        for (int t = VROW0 ? 8 : 0; t < NVK; ++t) vh = MFMA(W.awh[t], t < 8 ? Vc[t < 8 ? t : 0] : xhat_c, vh);
 #pragma unroll
         for (int t = 0; t < NVK; ++t) L.vh[wv][t][lane] = vh[t];
 #pragma unroll
-        for (int t = 0; t < NVK; ++t) vu = MFMA(b[t], vh[t], vu);
+        for (int t = 0; t < NVK; ++t) vu = MFMA(W.awu[t], vh[t], vu);
 #pragma unroll
         for (int t = 0; t < 8; ++t) Vu[t] = vu[t];
     }
     // (2) this wave's output tile of the scalar Linear: the k-steps that do not depend on sh
     f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    pf_gcf ap = w.a_main_c + (size_t)(wv < NMO ? wv : 0) * NKS * 64 + lane;
-    if (wv < NMO) {
-        const f32x4 PF_AS1* bp = reinterpret_cast<const f32x4 PF_AS1*>(w.b_main + hl * (NMO * 16) + wv * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b4 = bp[q];
-            acc[4 * q + 0] = b4[0]; acc[4 * q + 1] = b4[1]; acc[4 * q + 2] = b4[2]; acc[4 * q + 3] = b4[3];
-        }
-        float abuf[2][CH];
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (i < KS_A) abuf[0][i] = ap[i * 64];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c + 1 < NCH) {
-#pragma unroll
-                for (int i = 0; i < CH; ++i)
-                    if ((c + 1) * CH + i < KS_A) abuf[(c + 1) & 1][i] = ap[((c + 1) * CH + i) * 64];
-            }
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int ks = c * CH + i;
-                if (ks < KS_A) acc = MFMA(abuf[c & 1][i], ks < 64 ? s_in[ks < 64 ? ks : 0] : ext[ks >= 64 ? ks - 64 : 0], acc);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    for (int q = 0; q < 4; ++q) {
+        acc[4 * q + 0] = W.bm[q][0]; acc[4 * q + 1] = W.bm[q][1]; acc[4 * q + 2] = W.bm[q][2]; acc[4 * q + 3] = W.bm[q][3];
     }
-    float ash[NVK], ag[16];
     if (wv < NMO) {
 #pragma unroll
-        for (int t = 0; t < NVK; ++t) ash[t] = ap[(KS_A + t) * 64];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ag[r] = w.a_gate[(wv * 16 + r) * 64 + lane];
+        for (int ks = 0; ks < KS_A; ++ks)
+            acc = MFMA(W.am[ks], ks < 64 ? s_in[ks < 64 ? ks : 0] : ext[ks >= 64 ? ks - 64 : 0], acc);
     }
     __syncthreads();                                  // B1: every Vh is in LDS
     // (3) sh = |Vh| for this lane's channels, (4) the sh k-steps, SiLU, partial gates
@@ -651,7 +642,7 @@ __device__ __forceinline__ void gvp_apply_coop(const GvpW w, const float (&s_in)
 #pragma unroll
         for (int t = 0; t < NVK; ++t) {
             const float x = L.vh[0][t][lane], y = L.vh[1][t][lane], z = L.vh[2][t][lane];
-            acc = MFMA(ash[t], sqrtf_(fmaxf(x * x + y * y + z * z, 1e-8f)), acc);
+            acc = MFMA(W.am[KS_A + t], sqrtf_(fmaxf(x * x + y * y + z * z, 1e-8f)), acc);
         }
         f32x16 g;
 #pragma unroll
@@ -660,7 +651,7 @@ __device__ __forceinline__ void gvp_apply_coop(const GvpW w, const float (&s_in)
         for (int r = 0; r < 16; ++r) {
             const float so = siluf_(acc[r]);
             L.so[wv][r][lane] = so;
-            g = MFMA(ag[r], so, g);
+            g = MFMA(W.ag[r], so, g);
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) L.pg[wv][t][lane] = g[t];
@@ -671,17 +662,34 @@ __device__ __forceinline__ void gvp_apply_coop(const GvpW w, const float (&s_in)
     for (int mt = 0; mt < NMO; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_out[mt * 16 + r] = L.so[mt][r][lane];
-    {
-        const f32x4 PF_AS1* bg = reinterpret_cast<const f32x4 PF_AS1*>(w.b_gate + hl * 8);
-        const f32x4 b0 = bg[0], b1 = bg[1];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            if (VO == 1 && t > 0) { Vc_out[t] = 0.f; continue; }
-            float gv = (t < 4 ? b0[t & 3] : b1[t & 3]);
+    for (int t = 0; t < 8; ++t) {
+        if (VO == 1 && t > 0) { Vc_out[t] = 0.f; continue; }
+        float gv = (t < 4 ? W.bg[0][t & 3] : W.bg[1][t & 3]);
 #pragma unroll
-            for (int ww = 0; ww < NMO; ++ww) gv += L.pg[ww][t][lane];
-            if constexpr (SIG) gv = sigmoidf_(gv);
-            Vc_out[t] = gv * Vu[t];
+        for (int ww = 0; ww < NMO; ++ww) gv += L.pg[ww][t][lane];
+        if constexpr (SIG) gv = sigmoidf_(gv);
+        Vc_out[t] = gv * Vu[t];
+    }
+}
+
+// a chain of n generic GVPs (16 -> 16 channels, 128 -> 128 scalars) with the next GVP's weights in flight;
+// W0 must already hold (or be loading) the weights of gvps[0]
+__device__ __forceinline__ void gvp_coop_chain(const GvpW PF_AS1* gvps, const int n, CoopW<16, 0>& W0, float (&s1)[64],
+                                               float (&V1)[8], const int lane, const int wv, CoopLds& L) {
+    CoopW<16, 0> W1;
+    for (int gi = 0; gi < n; gi += 2) {
+        if (gi + 1 < n) gvp_coop_load<16, 0, 4>(gvps[gi + 1], lane, wv, W1);
+        float s2[64], V2[8];
+        gvp_coop_compute<16, 0, 16, 4, true, false>(W0, s1, nullptr, V1, 0.f, s2, V2, lane, wv, L);
+        if (gi + 1 < n) {
+            if (gi + 2 < n) gvp_coop_load<16, 0, 4>(gvps[gi + 2], lane, wv, W0);
+            gvp_coop_compute<16, 0, 16, 4, true, false>(W1, s2, nullptr, V2, 0.f, s1, V1, lane, wv, L);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 64; ++q) s1[q] = s2[q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) V1[q] = V2[q];
         }
     }
 }
@@ -709,6 +717,9 @@ __global__ __launch_bounds__(256, 1) void k_edge_msg_coop(const EdgeParams p) {
     nvalid = __builtin_amdgcn_readfirstlane(nvalid);
     if (nvalid <= 0) return;                           // block-uniform
     const int et = __builtin_amdgcn_readfirstlane(t.et);
+    const GvpW PF_AS1* wt = (const GvpW PF_AS1*)p.w + et * p.n_gvps;
+    CoopW<17, PF_R> Wfirst;
+    gvp_coop_load<17, PF_R, 4>(wt[0], lane, wv, Wfirst);      // in flight under the gather below
     const int j = lane & 31, hl = lane >> 5;
     const int e = t.e0 + min(j, nvalid - 1);
     const int src = p.esrc[e], dst = p.edst[e];
@@ -732,16 +743,12 @@ __global__ __launch_bounds__(256, 1) void k_edge_msg_coop(const EdgeParams p) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) Vc[q] = 0.f;
     }
-    const GvpW PF_AS1* wt = (const GvpW PF_AS1*)p.w + et * p.n_gvps;
     float s1[64], V1[8];
-    gvp_apply_coop<17, PF_R, 16, 4, true, L0>(wt[0], s, rb, Vc, xhat_c, s1, V1, lane, wv, L);
-    for (int gi = 1; gi < p.n_gvps; ++gi) {
-        float s2[64], V2[8];
-        gvp_apply_coop<16, 0, 16, 4, true, false>(wt[gi], s1, nullptr, V1, 0.f, s2, V2, lane, wv, L);
-#pragma unroll
-        for (int q = 0; q < 64; ++q) s1[q] = s2[q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) V1[q] = V2[q];
+    {
+        CoopW<16, 0> Wn;
+        if (p.n_gvps > 1) gvp_coop_load<16, 0, 4>(wt[1], lane, wv, Wn);
+        gvp_coop_compute<17, PF_R, 16, 4, true, L0>(Wfirst, s, rb, Vc, xhat_c, s1, V1, lane, wv, L);
+        if (p.n_gvps > 1) gvp_coop_chain(wt + 1, p.n_gvps - 1, Wn, s1, V1, lane, wv, L);
     }
     const bool valid = j < nvalid;
     const int key = valid ? dst : -1 - j;
@@ -811,6 +818,9 @@ __global__ __launch_bounds__(256, 1) void k_node_update_coop(const NodeParams p)
     const int j = lane & 31, hl = lane >> 5;
     const bool live = j < t.n;
     const int n = t.n0 + min(j, t.n - 1);
+    const NodeW nw = p.w[nt];
+    CoopW<16, 0> Wupd;
+    gvp_coop_load<16, 0, 4>(nw.upd[0], lane, wv, Wupd);      // in flight under the aggregation below
     // Deterministic segmented reduction of the in-edge messages, row-parallel: wave w owns nodes 8w..8w+7 of the
     // tile; for each node the 64 lanes stream its contiguous message rows (128 scalars as float2 + 48 vector
     // floats per row, coalesced, eight rows in flight) and sum them in index order; fn.mean scales by 1/in-degree
@@ -904,25 +914,15 @@ __global__ __launch_bounds__(256, 1) void k_node_update_coop(const NodeParams p)
         for (int q = 0; q < 8; ++q)
             Vc[q] = fmaf(L.agg[j][128 + 3 * ((q & 3) + 8 * (q >> 2) + 4 * hl) + wv], inv_norm, Vc[q]);
     }
-    const NodeW nw = p.w[nt];
     gvp_layernorm_coop(nw.ln1_w, nw.ln1_b, hl, lane, wv, s, Vc, L);
     float s1[64], V1[8];
 #pragma unroll
     for (int q = 0; q < 64; ++q) s1[q] = s[q];
 #pragma unroll
     for (int q = 0; q < 8; ++q) V1[q] = Vc[q];
-#ifdef PF_ABL_NOGVP
-    for (int gi = 0; gi < 0; ++gi) {
-#else
-    for (int gi = 0; gi < p.n_upd; ++gi) {
+#ifndef PF_ABL_NOGVP
+    gvp_coop_chain(nw.upd, p.n_upd, Wupd, s1, V1, lane, wv, L);
 #endif
-        float s2[64], V2[8];
-        gvp_apply_coop<16, 0, 16, 4, true, false>(nw.upd[gi], s1, nullptr, V1, 0.f, s2, V2, lane, wv, L);
-#pragma unroll
-        for (int q = 0; q < 64; ++q) s1[q] = s2[q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) V1[q] = V2[q];
-    }
 #pragma unroll
     for (int q = 0; q < 64; ++q) s[q] += s1[q];
 #pragma unroll
@@ -954,6 +954,9 @@ __global__ __launch_bounds__(256, 1) void k_noise_head_coop(const HeadParams p) 
     const int j = lane & 31, hl = lane >> 5;
     const bool live = j < t.n;
     const int n = t.n0 + min(j, t.n - 1);
+    const GvpW PF_AS1* gv = (const GvpW PF_AS1*)p.gvps;
+    CoopW<16, 0> Wh0;
+    if (p.n_gvps > 1) gvp_coop_load<16, 0, 4>(gv[0], lane, wv, Wh0);
     float s1[64], V1[8];
     load_row_f(p.h + (size_t)n * PF_S, hl, s1);
     if (wv < 3) load_vec_rc(p.v + (size_t)n * 48, hl, wv, V1);
@@ -961,16 +964,11 @@ __global__ __launch_bounds__(256, 1) void k_noise_head_coop(const HeadParams p) 
 #pragma unroll
         for (int q = 0; q < 8; ++q) V1[q] = 0.f;
     }
-    for (int gi = 0; gi + 1 < p.n_gvps; ++gi) {
-        float s2[64], V2[8];
-        gvp_apply_coop<16, 0, 16, 4, true, false>(p.gvps[gi], s1, nullptr, V1, 0.f, s2, V2, lane, wv, L);
-#pragma unroll
-        for (int q = 0; q < 64; ++q) s1[q] = s2[q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) V1[q] = V2[q];
-    }
+    CoopW<16, 0> Wlast;
+    gvp_coop_load<16, 0, 2>(gv[p.n_gvps - 1], lane, wv, Wlast);
+    if (p.n_gvps > 1) gvp_coop_chain(gv, p.n_gvps - 1, Wh0, s1, V1, lane, wv, L);
     float so[32], Vo[8];
-    gvp_apply_coop<16, 0, 1, 2, false, false>(p.gvps[p.n_gvps - 1], s1, nullptr, V1, 0.f, so, Vo, lane, wv, L);
+    gvp_coop_compute<16, 0, 1, 2, false, false>(Wlast, s1, nullptr, V1, 0.f, so, Vo, lane, wv, L);
     const int f = n - p.node_base;
     if (wv == 3) {
         // to_scalar_output: Linear(64 -> pharm_nf), rows 0..5 of a 32-row tile
@@ -993,38 +991,62 @@ __global__ __launch_bounds__(256, 1) void k_noise_head_coop(const HeadParams p) 
 
 // ---------------------------------------------------------------------------------------------
 // Scalar encoders: h = LayerNorm(SiLU(W [feat, t] + b))   (dynamics_gvp.py:107-117,143-151)
-// one wave per node, two features per lane.
 // ---------------------------------------------------------------------------------------------
+// Eight nodes of one type per wave: the (transposed, coalesced) weight column of input k is loaded once and
+// applied to the 8 nodes; two output features per lane; LayerNorm statistics by wave reduction.
 __device__ __forceinline__ void encode_body(const EncodeParams& p, const int blk) {
     const int lane = threadIdx.x & 63;
-    const int n = __builtin_amdgcn_readfirstlane((int)((blk * 256 + threadIdx.x) >> 6));
-    if (n >= p.Np + p.Nf) return;
-    const int nt = n >= p.Np ? 1 : 0;
+    const int grp = __builtin_amdgcn_readfirstlane((int)((blk * 256 + threadIdx.x) >> 6));
+    const int gprot = (p.Np + 7) >> 3;
+    const int nt = grp >= gprot ? 1 : 0;
+    const int first = nt ? (grp - gprot) * 8 : grp * 8;            // type-local index of the first node
+    const int ntot = nt ? p.Nf : p.Np;
+    if (first >= ntot) return;
+    const int cnt = min(8, ntot - first);
     const int nf = nt ? p.pharm_nf : p.rec_nf;
-    const float* in = nt ? p.pharm_h + (size_t)(n - p.Np) * nf : p.prot_h0 + (size_t)n * nf;
-    const float tt = p.t ? p.t[p.gid[n]] : p.t_scalar;
-    const float* W = p.w[nt];
-    const int K = nf + 1;
-    float a0 = p.b[nt][lane], a1 = p.b[nt][lane + 64];
+    const float* in = (nt ? p.pharm_h : p.prot_h0) + (size_t)first * nf;
+    const int nbase = (nt ? p.Np : 0) + first;                     // global node id
+    const float* Wt = p.w[nt];                                     // [nf+1][128]
+    float a0[8], a1[8];
+    const float b0 = p.b[nt][lane], b1 = p.b[nt][lane + 64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a0[i] = b0; a1[i] = b1; }
     for (int k = 0; k < nf; ++k) {
-        const float x = in[k];
-        a0 = fmaf(W[lane * K + k], x, a0);
-        a1 = fmaf(W[(lane + 64) * K + k], x, a1);
+        const float w0 = Wt[k * PF_S + lane], w1 = Wt[k * PF_S + lane + 64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = in[(size_t)min(i, cnt - 1) * nf + k];
+            a0[i] = fmaf(w0, x, a0[i]);
+            a1[i] = fmaf(w1, x, a1[i]);
+        }
     }
-    a0 = fmaf(W[lane * K + nf], tt, a0);
-    a1 = fmaf(W[(lane + 64) * K + nf], tt, a1);
-    a0 = siluf_(a0); a1 = siluf_(a1);
-    float sum = a0 + a1;
+    {
+        const float w0 = Wt[nf * PF_S + lane], w1 = Wt[nf * PF_S + lane + 64];
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-    const float mean = sum * (1.0f / 128.0f);
-    const float c0 = a0 - mean, c1 = a1 - mean;
-    float var = c0 * c0 + c1 * c1;
+        for (int i = 0; i < 8; ++i) {
+            const float tt = p.t ? p.t[p.gid[nbase + min(i, cnt - 1)]] : p.t_scalar;
+            a0[i] = fmaf(w0, tt, a0[i]);
+            a1[i] = fmaf(w1, tt, a1[i]);
+        }
+    }
+    const float lw0 = p.ln_w[nt][lane], lw1 = p.ln_w[nt][lane + 64], lb0 = p.ln_b[nt][lane], lb1 = p.ln_b[nt][lane + 64];
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) var += __shfl_xor(var, o);
-    const float rstd = 1.0f / sqrtf(var * (1.0f / 128.0f) + 1e-5f);
-    p.h_out[(size_t)n * PF_S + lane] = c0 * rstd * p.ln_w[nt][lane] + p.ln_b[nt][lane];
-    p.h_out[(size_t)n * PF_S + lane + 64] = c1 * rstd * p.ln_w[nt][lane + 64] + p.ln_b[nt][lane + 64];
+    for (int i = 0; i < 8; ++i) {
+        const float s0 = siluf_(a0[i]), s1 = siluf_(a1[i]);
+        float sum = s0 + s1;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum * (1.0f / 128.0f);
+        const float c0 = s0 - mean, c1 = s1 - mean;
+        float var = c0 * c0 + c1 * c1;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) var += __shfl_xor(var, o);
+        const float rstd = rsqf_(var * (1.0f / 128.0f) + 1e-5f);
+        if (i < cnt) {
+            p.h_out[(size_t)(nbase + i) * PF_S + lane] = c0 * rstd * lw0 + lb0;
+            p.h_out[(size_t)(nbase + i) * PF_S + lane + 64] = c1 * rstd * lw1 + lb1;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1134,12 +1156,29 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
         const int kk = min(p.pf_k, Np);
         for (int fl = wave; fl < Nf; fl += 4) {
             const float4 q = fx[fl];
+            // up to 8 candidates per lane (Np <= 512) stay in registers as (d^2, index) keys; larger pockets
+            // re-read the coordinates every round
+            unsigned long long kc[8];
+            const bool cached = Np <= 512;
+            if (cached) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = lane + 64 * i;
+                    kc[i] = c < Np ? dkey(sqdist_rn(p.xn[p0 + min(c, Np - 1)], q), c) : ~0ull;
+                }
+            }
             unsigned long long prev = 0ull;
             for (int r = 0; r < kk; ++r) {
                 unsigned long long best = ~0ull;
-                for (int c = lane; c < Np; c += 64) {
-                    const unsigned long long k = dkey(sqdist_rn(p.xn[p0 + c], q), c);
-                    if ((r == 0 || k > prev) && k < best) best = k;
+                if (cached) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if ((r == 0 || kc[i] > prev) && kc[i] < best) best = kc[i];
+                } else {
+                    for (int c = lane; c < Np; c += 64) {
+                        const unsigned long long k = dkey(sqdist_rn(p.xn[p0 + c], q), c);
+                        if ((r == 0 || k > prev) && k < best) best = k;
+                    }
                 }
                 best = wave_min_u64(best);
                 prev = best;
@@ -1416,13 +1455,13 @@ void pfk_noise_head(const HeadParams* p, hipStream_t s) {
     hipLaunchKernelGGL(k_noise_head, dim3(blocks), dim3(64), 0, s, *p);
 }
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s) {
-    const int n = e->Np + e->Nf;
-    hipLaunchKernelGGL(k_encode_build, dim3(b->B + (n + 3) / 4), dim3(256), 0, s, *e, *b);
+    const int groups = (e->Np + 7) / 8 + (e->Nf + 7) / 8;
+    hipLaunchKernelGGL(k_encode_build, dim3(b->B + (groups + 3) / 4), dim3(256), 0, s, *e, *b);
 }
 void pfk_encode(const EncodeParams* p, hipStream_t s) {
-    const int n = p->Np + p->Nf;
-    if (n == 0) return;
-    hipLaunchKernelGGL(k_encode, dim3((n + 3) / 4), dim3(256), 0, s, *p);
+    const int groups = (p->Np + 7) / 8 + (p->Nf + 7) / 8;
+    if (groups == 0) return;
+    hipLaunchKernelGGL(k_encode, dim3((groups + 3) / 4), dim3(256), 0, s, *p);
 }
 void pfk_build_edges(const BuildParams* p, hipStream_t s) {
     if (p->B == 0) return;
