@@ -161,3 +161,4 @@ struct StepParams {
     float a_ts, var, sigma, ep_zt, ep_pred;
     int ep_coord, ep_feat;
 };
+

@@ -694,6 +694,21 @@ __device__ __forceinline__ void gvp_coop_chain(const GvpW PF_AS1* gvps, const in
     }
 }
 
+// the same chain with ONE weight buffer (no prefetch): half the registers, for kernels that must fit two
+// workgroups per CU
+__device__ __forceinline__ void gvp_coop_chain1(const GvpW PF_AS1* gvps, const int n, CoopW<16, 0>& W0, float (&s1)[64],
+                                                float (&V1)[8], const int lane, const int wv, CoopLds& L) {
+    for (int gi = 0; gi < n; ++gi) {
+        if (gi > 0) gvp_coop_load<16, 0, 4>(gvps[gi], lane, wv, W0);
+        float s2[64], V2[8];
+        gvp_coop_compute<16, 0, 16, 4, true, false>(W0, s1, nullptr, V1, 0.f, s2, V2, lane, wv, L);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) s1[q] = s2[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) V1[q] = V2[q];
+    }
+}
+
 // this wave's coordinate (wv = 0..2) of the lane's 8 channels of a [16][3] vector row
 template <typename P>
 __device__ __forceinline__ void load_vec_rc(P row, const int hl, const int wv, float (&Vc)[8]) {
@@ -704,11 +719,7 @@ __device__ __forceinline__ void load_vec_rc(P row, const int hl, const int wv, f
 }
 
 template <bool L0>
-__global__ __launch_bounds__(256, 1) void k_edge_msg_coop(const EdgeParams p) {
-    __shared__ CoopLds L;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const EdgeTile t = p.tiles[blockIdx.x];
+__device__ __forceinline__ void edge_tile_coop(const EdgeParams& p, const EdgeTile t, CoopLds& L, const int lane, const int wv) {
     int nvalid = t.n;
     if (t.cnt_idx >= 0) {
         const int c = p.dyn_cnt[t.cnt_idx] - t.rel;
@@ -775,6 +786,14 @@ __global__ __launch_bounds__(256, 1) void k_edge_msg_coop(const EdgeParams p) {
     }
 }
 
+template <bool L0>
+__global__ __launch_bounds__(256, 1) void k_edge_msg_coop(const EdgeParams p) {
+    __shared__ CoopLds L;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    edge_tile_coop<L0>(p, p.tiles[blockIdx.x], L, lane, wv);
+}
+
 // GVPLayerNorm with the vector state spread over waves 0..2 (coordinate c in wave c)
 __device__ __forceinline__ void gvp_layernorm_coop(pf_gcf lw, pf_gcf lb, const int hl, const int lane, const int wv,
                                                    float (&s)[64], float (&Vc)[8], CoopLds& L) {
@@ -792,11 +811,18 @@ __device__ __forceinline__ void gvp_layernorm_coop(pf_gcf lw, pf_gcf lb, const i
     for (int q = 0; q < 64; ++q) { const float c = s[q] - mean; var = fmaf(c, c, var); }
     var += __shfl_xor(var, 32);
     const float rstd = rsqf_(var * (1.0f / 128.0f) + 1e-5f);
-    float w[64], b[64];
-    load_row_f(lw, hl, w);
-    load_row_f(lb, hl, b);
+    {   // affine parameters in F-layout, one 32-feature block at a time (keeps the live set small)
+        auto pw = reinterpret_cast<const f32x4 PF_AS1*>(lw + 4 * hl);
+        auto pb = reinterpret_cast<const f32x4 PF_AS1*>(lb + 4 * hl);
 #pragma unroll
-    for (int q = 0; q < 64; ++q) s[q] = (s[q] - mean) * rstd * w[q] + b[q];
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w4 = pw[mt * 8 + q * 2], b4 = pb[mt * 8 + q * 2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[mt * 16 + 4 * q + i] = (s[mt * 16 + 4 * q + i] - mean) * rstd * w4[i] + b4[i];
+            }
+    }
     __syncthreads();
     float vn = 0.f;
 #pragma unroll
@@ -809,18 +835,12 @@ __device__ __forceinline__ void gvp_layernorm_coop(pf_gcf lw, pf_gcf lb, const i
 }
 
 template <bool L0>
-__global__ __launch_bounds__(256, 1) void k_node_update_coop(const NodeParams p) {
-    __shared__ CoopLds L;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const NodeTile t = p.tiles[blockIdx.x];
+__device__ __forceinline__ void node_tile_coop(const NodeParams& p, const NodeTile t, CoopLds& L, const int lane, const int wv) {
     const int nt = __builtin_amdgcn_readfirstlane(t.ntype);
     const int j = lane & 31, hl = lane >> 5;
     const bool live = j < t.n;
     const int n = t.n0 + min(j, t.n - 1);
     const NodeW nw = p.w[nt];
-    CoopW<16, 0> Wupd;
-    gvp_coop_load<16, 0, 4>(nw.upd[0], lane, wv, Wupd);      // in flight under the aggregation below
     // Deterministic segmented reduction of the in-edge messages, row-parallel: wave w owns nodes 8w..8w+7 of the
     // tile; for each node the 64 lanes stream its contiguous message rows (128 scalars as float2 + 48 vector
     // floats per row, coalesced, eight rows in flight) and sum them in index order; fn.mean scales by 1/in-degree
@@ -915,16 +935,26 @@ __global__ __launch_bounds__(256, 1) void k_node_update_coop(const NodeParams p)
             Vc[q] = fmaf(L.agg[j][128 + 3 * ((q & 3) + 8 * (q >> 2) + 4 * hl) + wv], inv_norm, Vc[q]);
     }
     gvp_layernorm_coop(nw.ln1_w, nw.ln1_b, hl, lane, wv, s, Vc, L);
-    float s1[64], V1[8];
+    CoopW<16, 0> Wupd;
+    gvp_coop_load<16, 0, 4>(nw.upd[0], lane, wv, Wupd);
+    // the residual copy of the scalar state waits in LDS (the aggregation buffer is free now) so that the chain
+    // fits 256 registers: two workgroups per CU, i.e. every tile of a 262-tile launch is resident at once
+    float (*res)[64] = reinterpret_cast<float (*)[64]>(&L.agg[0][0]);
+    __syncthreads();                                   // all reads of agg are done
+    if (wv == 0) {
 #pragma unroll
-    for (int q = 0; q < 64; ++q) s1[q] = s[q];
+        for (int q = 0; q < 64; ++q) res[q][lane] = s[q];
+    }
+    float V1[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) V1[q] = Vc[q];
 #ifndef PF_ABL_NOGVP
-    gvp_coop_chain(nw.upd, p.n_upd, Wupd, s1, V1, lane, wv, L);
+    gvp_coop_chain1(nw.upd, p.n_upd, Wupd, s, V1, lane, wv, L);     // its barriers also publish res
+#else
+    __syncthreads();
 #endif
 #pragma unroll
-    for (int q = 0; q < 64; ++q) s[q] += s1[q];
+    for (int q = 0; q < 64; ++q) s[q] += res[q][lane];
 #pragma unroll
     for (int q = 0; q < 8; ++q) Vc[q] += V1[q];
     gvp_layernorm_coop(nw.ln2_w, nw.ln2_b, hl, lane, wv, s, Vc, L);
@@ -946,11 +976,15 @@ __global__ __launch_bounds__(256, 1) void k_node_update_coop(const NodeParams p)
     }
 }
 
-__global__ __launch_bounds__(256, 1) void k_noise_head_coop(const HeadParams p) {
+template <bool L0>
+__global__ __launch_bounds__(256, 2) void k_node_update_coop(const NodeParams p) {
     __shared__ CoopLds L;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const NodeTile t = p.tiles[blockIdx.x];
+    node_tile_coop<L0>(p, p.tiles[blockIdx.x], L, lane, wv);
+}
+
+__device__ __forceinline__ void head_tile_coop(const HeadParams& p, const NodeTile t, CoopLds& L, const int lane, const int wv) {
     const int j = lane & 31, hl = lane >> 5;
     const bool live = j < t.n;
     const int n = t.n0 + min(j, t.n - 1);
@@ -989,11 +1023,19 @@ __global__ __launch_bounds__(256, 1) void k_noise_head_coop(const HeadParams p) 
     }
 }
 
+__global__ __launch_bounds__(256, 1) void k_noise_head_coop(const HeadParams p) {
+    __shared__ CoopLds L;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    head_tile_coop(p, p.tiles[blockIdx.x], L, lane, wv);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Scalar encoders: h = LayerNorm(SiLU(W [feat, t] + b))   (dynamics_gvp.py:107-117,143-151)
 // ---------------------------------------------------------------------------------------------
 // Eight nodes of one type per wave: the (transposed, coalesced) weight column of input k is loaded once and
 // applied to the 8 nodes; two output features per lane; LayerNorm statistics by wave reduction.
+__device__ __forceinline__ void encode_group(const EncodeParams& p, const int nt, const int first, const int cnt, const int lane);
 __device__ __forceinline__ void encode_body(const EncodeParams& p, const int blk) {
     const int lane = threadIdx.x & 63;
     const int grp = __builtin_amdgcn_readfirstlane((int)((blk * 256 + threadIdx.x) >> 6));
@@ -1002,7 +1044,10 @@ __device__ __forceinline__ void encode_body(const EncodeParams& p, const int blk
     const int first = nt ? (grp - gprot) * 8 : grp * 8;            // type-local index of the first node
     const int ntot = nt ? p.Nf : p.Np;
     if (first >= ntot) return;
-    const int cnt = min(8, ntot - first);
+    encode_group(p, nt, first, min(8, ntot - first), lane);
+}
+// up to 8 nodes [first, first+cnt) of node type nt
+__device__ __forceinline__ void encode_group(const EncodeParams& p, const int nt, const int first, const int cnt, const int lane) {
     const int nf = nt ? p.pharm_nf : p.rec_nf;
     const float* in = (nt ? p.pharm_h : p.prot_h0) + (size_t)first * nf;
     const int nbase = (nt ? p.Np : 0) + first;                     // global node id
@@ -1332,10 +1377,10 @@ __global__ __launch_bounds__(64) void k_segment_mean(const float4* xn, const int
 
 // z_s = mu + sigma * noise ; remove the pharmacophore COM from pharm and prot coordinates
 // (pharmacodiff.py:413-429).  One workgroup per graph.
-__global__ __launch_bounds__(256) void k_step_update(const StepParams p) {
+__device__ __forceinline__ void step_update_body(const StepParams& p, const int g) {
     __shared__ float com[3];
     __shared__ float red[4][3];
-    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = p.pharm_ptr[g], f1 = p.pharm_ptr[g + 1];
     const int p0 = p.prot_ptr[g], p1 = p.prot_ptr[g + 1];
     float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -1380,6 +1425,8 @@ __global__ __launch_bounds__(256) void k_step_update(const StepParams p) {
         p.xn[i] = x;
     }
 }
+__global__ __launch_bounds__(256) void k_step_update(const StepParams p) { step_update_body(p, blockIdx.x); }
+
 // out[i] = xn[base+i] + (add[g] - sub[g]) ; used for the final frame of reference
 __global__ void k_export_coords(const float4* xn, const int base, const int n, const int* gid, const float* add,
                                 const float* sub, float* out) {
