@@ -104,6 +104,8 @@ def main():
     edge_flops = FLOP_PER_EDGE * sum(ne)
     achieved_tf = edge_flops / edge_avg_s / 1e12 if edge_avg_s > 0 else 0.0
 
+    n_convs = 2
+    exec_flops = flops - (n_convs > 1) * (FLOP_PER_EDGE * (ne[2] + ne[3]) + 88064.0 * B * args.n_prot)   # last layer: pharm side only
     out = {
         "metric": "denoising steps/sec (batch x T) at 256-atom pocket, 6 centers",
         "value": world * B * K / dt, "unit": "sample-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -117,13 +119,16 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_TFLOPS, "traffic": None,
                      "kernel_avg_us": edge_avg_s * 1e6, "launches_timed": edge_n,
                      "flop_per_launch": edge_flops,
-                     "whole_step": {"algorithmic_flop": flops, "algorithmic_bytes": bytes_,
+                     "note": "k_edge_msg = the launch that computes every edge message of a conv layer (all 4 etypes, "
+                             "one wave per 32 edges); algorithmic FLOP = 136,742 per edge (SURVEY 8d) x edges of the launch",
+                     "whole_step": {"algorithmic_flop": flops, "executed_flop_after_dead_work_elimination": exec_flops,
+                                    "algorithmic_bytes": bytes_,
                                     "tflops": flops / (dt / K) / 1e12, "frac_f32_peak": flops / (dt / K) / 1e12 / PEAK_F32_TFLOPS,
                                     "gbs": bytes_ / (dt / K) / 1e9, "frac_hbm_peak": bytes_ / (dt / K) / 1e9 / PEAK_HBM_GBS}},
     }
 
     if args.breakdown and rank == 0:
-        eng.profile_enable(0x3f)
+        eng.profile_enable(0xff)
         run(min(K, 20), False)
         torch.cuda.synchronize()
         for k, (ms, n) in eng.profile_read().items():

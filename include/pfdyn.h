@@ -154,12 +154,13 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
                         float* dev_out_h_prot, float* dev_out_v_prot, float* dev_out_h_pharm, float* dev_out_v_pharm,
                         pf_stream stream);
 /* per-kernel timing with HIP events recorded on the caller's stream around every launch of the
- * selected kernel classes (bit k of kernel_mask): 0 encode, 1 build_edges, 2 edge_msg, 3 node_update,
- * 4 noise_head, 5 step_update.  pf_profile_read synchronises `stream`, returns the summed device
+ * selected kernel classes (bit k of kernel_mask): 0 encode, 1 build_edges (0 and 1 share one launch unless
+ * either is being timed), 2 edge_msg (one wave per tile), 3 node_update (one wave per tile), 4 noise_head,
+ * 5 step_update, 6 edge_msg_coop, 7 node_update_coop (four waves per tile: launches with few tiles).  pf_profile_read synchronises `stream`, returns the summed device
  * time [ms] and launch count per class since the last enable/read, and resets the counters. */
-#define PF_NUM_KERNEL_CLASSES 6
+#define PF_NUM_KERNEL_CLASSES 8
 int pf_profile_enable(pf_handle* h, uint32_t kernel_mask);
-int pf_profile_read(pf_handle* h, double* total_ms /*[6]*/, int64_t* launches /*[6]*/, pf_stream stream);
+int pf_profile_read(pf_handle* h, double* total_ms /*[8]*/, int64_t* launches /*[8]*/, pf_stream stream);
 /* algorithmic work of the last dynamics call (SURVEY.md 8(d) formulas on the actual edge counts) */
 int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges /*[4]*/, pf_stream stream);
 

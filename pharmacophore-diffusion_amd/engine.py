@@ -194,15 +194,16 @@ class PfEngine:
             self._ck(self.lib.pf_debug_work(self._h, ctypes.byref(fl), ctypes.byref(by), ne, _stream_ptr()), "pf_debug_work")
         return fl.value, by.value, list(ne)
 
-    KERNEL_CLASSES = ("encode", "build_edges", "edge_msg", "node_update", "noise_head", "step_update")
+    KERNEL_CLASSES = ("encode", "build_edges", "edge_msg", "node_update", "noise_head", "step_update", "edge_msg_coop",
+                      "node_update_coop")
 
     def profile_enable(self, mask: int):
         self._ck(self.lib.pf_profile_enable(self._h, mask), "pf_profile_enable")
 
     def profile_read(self):
         """{kernel class: (total device ms, launches)} since the last enable/read (synchronises)."""
-        ms = (ctypes.c_double * 6)()
-        n = (ctypes.c_int64 * 6)()
+        ms = (ctypes.c_double * 8)()
+        n = (ctypes.c_int64 * 8)()
         with torch.cuda.device(self.device):
             self._ck(self.lib.pf_profile_read(self._h, ms, n, _stream_ptr()), "pf_profile_read")
         return {k: (ms[i], n[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
