@@ -43,11 +43,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs at least one MI355X (no CPU fallback)")
+    dev_index = local_rank % ndev                    # normally local_rank; ranks share a GPU only in the 1-GPU dry run
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = "nccl" if world <= ndev else "gloo"    # RCCL needs one GPU per rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import pharmacoforge_amd as pfa
     from pharmacoforge_amd import synthetic, schedule
@@ -93,7 +102,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_enable(0)
-    tmax = torch.tensor([dt], device=dev)
+    tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

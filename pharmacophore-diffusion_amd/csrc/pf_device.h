@@ -80,6 +80,7 @@ struct EdgeParams {
     float* msg_s;
     float* msg_v;
     const GvpW* w;         // [4 etypes][n_gvps]
+    const float* pre;      // [Np][128] P = W_msg0[:, :128] h + b for the pp etype of this layer, or NULL
     int n_gvps;
     float rbf_mu[PF_R];
     float rbf_inv_sigma;
@@ -162,3 +163,16 @@ struct StepParams {
     int ep_coord, ep_feat;
 };
 
+
+struct PreParams {         // protein encoder + pp precompute (encode_pre_tile)
+    int Np, rec_nf, nke;   // nke = k-steps of the encoder Linear = (rec_nf + 2) / 2
+    const float* prot_h0;
+    const float* t; float t_scalar; const int* gid;
+    pf_gcf a_enc;          // [4 tiles][nke][64]   A fragments of the protein encoder Linear
+    pf_gcf b_enc;          // [2 halves][64]       its bias in F-layout
+    pf_gcf ln_w, ln_b;     // [128]
+    GvpW pre_w;            // first pp message GVP of conv layer 0
+    int pre_nks;           // its k-step count (81)
+    float* h_out;          // [N][128]
+    float* pre_out;        // [Np][128]
+};

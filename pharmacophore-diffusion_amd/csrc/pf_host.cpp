@@ -24,6 +24,7 @@ void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s);
 void pfk_noise_head(const HeadParams* p, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
+void pfk_encode_build_pre(const EncodeParams* e, const BuildParams* b, const PreParams* pp, hipStream_t s);
 void pfk_build_edges(const BuildParams* p, hipStream_t s);
 void pfk_load_coords(const float* src, float4* xn, int n, const int* gid, const float* shift, float sign, hipStream_t s);
 void pfk_load_noise0(const float* nz, float4* xn, float* hf, int n, int nf, hipStream_t s);
@@ -80,6 +81,8 @@ struct pf_handle {
     size_t enc_w[2]{}, enc_b[2]{}, enc_lw[2]{}, enc_lb[2]{};
     std::vector<size_t> ln_off;             // [layer][nt][4]: ln1_w ln1_b ln2_w ln2_b
     size_t out_a = 0, out_b = 0;
+    size_t enc_a = 0, enc_bf = 0;           // protein encoder as A fragments / F-layout bias (encode_pre_tile)
+    bool use_pre = true;
 
     // ---- batch / workspace
     bool have_batch = false;
@@ -100,13 +103,14 @@ struct pf_handle {
     float4* d_xn = nullptr;
     float *d_prot_x0 = nullptr, *d_prot_h0 = nullptr, *d_pharm_h = nullptr, *d_t = nullptr, *d_h[2] = {nullptr, nullptr},
           *d_v[2] = {nullptr, nullptr}, *d_msg_s = nullptr, *d_msg_v = nullptr, *d_eps_h = nullptr, *d_eps_x = nullptr,
-          *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr;
+          *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr, *d_pre = nullptr;
     bool sampling = false;
     // launches with at most this many tiles use the 4-wave cooperative kernels (latency-bound regime)
     int coop_edge_max = 512, coop_node_max = 1024;
     void init_tuning() {
         if (const char* e = getenv("PFDYN_COOP_EDGE_MAX")) coop_edge_max = atoi(e);
         if (const char* e = getenv("PFDYN_COOP_NODE_MAX")) coop_node_max = atoi(e);
+        if (const char* e = getenv("PFDYN_NO_PRE")) use_pre = atoi(e) == 0;
     }
 
     // ---- optional per-kernel timing with HIP events on the caller's stream (pf_profile_*)
@@ -352,9 +356,20 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
     bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
     bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
+    bool pre_ready = false;
     if (h->prof_mask & 3u) {     // timing the two halves separately needs separate launches
         { ProfScope ps(h, pf_handle::K_ENCODE, s); pfk_encode(&ep, s); }
         { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); }
+    } else if (h->use_pre && h->Np > 0) {
+        PreParams pp{};
+        pp.Np = h->Np; pp.rec_nf = c.rec_nf; pp.nke = (c.rec_nf + 2) / 2;
+        pp.prot_h0 = h->d_prot_h0; pp.t = ep.t; pp.t_scalar = ep.t_scalar; pp.gid = h->d_gid;
+        pp.a_enc = h->d_w + h->enc_a; pp.b_enc = h->d_w + h->enc_bf;
+        pp.ln_w = h->d_w + h->enc_lw[0]; pp.ln_b = h->d_w + h->enc_lb[0];
+        pp.pre_w = h->h_gvp[h->msg_base(0, ET_PP)]; pp.pre_nks = 64 + c.rbf_dim / 2 + 9;
+        pp.h_out = h->d_h[0]; pp.pre_out = h->d_pre;
+        pfk_encode_build_pre(&ep, &bp, &pp, s);
+        pre_ready = true;
     } else pfk_encode_build(&ep, &bp, s);
 
     int cur = 0;
@@ -366,6 +381,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         e.h = h->d_h[cur]; e.v = h->d_v[cur];
         e.msg_s = h->d_msg_s; e.msg_v = h->d_msg_v;
         e.w = h->d_gvp + h->msg_base(l, 0); e.n_gvps = c.n_message_gvps;
+        e.pre = (l == 0 && pre_ready) ? h->d_pre : nullptr;
         linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
         e.rbf_inv_sigma = 1.0f / ((c.rbf_dmax - 0.f) / (float)c.rbf_dim);
         // few tiles (last layer): 4 waves per tile to cut the serial latency; otherwise one wave per tile
@@ -509,6 +525,23 @@ int pf_commit_weights(pf_handle* h) {
         h->enc_lw[nt] = push(h->h_w, h->raw[p + "2.weight"].data);
         h->enc_lb[nt] = push(h->h_w, h->raw[p + "2.bias"].data);
     }
+    {   // protein encoder Linear [128][rec_nf+1] as A fragments [tile][k-step][lane]; k-step t, half hl <-> input 2t+hl
+        const RawTensor& W = h->raw["dynamics.prot_encoder.0.weight"];
+        const RawTensor& Bv = h->raw["dynamics.prot_encoder.0.bias"];
+        const int K = c.rec_nf + 1, nke = (K + 1) / 2;
+        std::vector<float> a((size_t)4 * nke * 64, 0.f), bf(128);
+        for (int mo = 0; mo < 4; ++mo)
+            for (int t = 0; t < nke; ++t)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, hl = lane >> 5, k = 2 * t + hl;
+                    a[((size_t)mo * nke + t) * 64 + lane] = k < K ? W.data[(size_t)(32 * mo + i) * K + k] : 0.f;
+                }
+        for (int hl = 0; hl < 2; ++hl)
+            for (int mo = 0; mo < 4; ++mo)
+                for (int r = 0; r < 16; ++r) bf[(size_t)hl * 64 + mo * 16 + r] = Bv.data[32 * mo + rho(r, hl)];
+        h->enc_a = push(h->h_w, a);
+        h->enc_bf = push(h->h_w, bf);
+    }
     h->ln_off.assign((size_t)c.n_convs * 2 * 4, 0);
     for (int l = 0; l < c.n_convs; ++l)
         for (int nt = 0; nt < 2; ++nt) {
@@ -649,6 +682,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     need((size_t)N * PF_S * 4); need((size_t)N * PF_S * 4); need((size_t)N * 48 * 4); need((size_t)N * 48 * 4);
     need((size_t)(Ecap + 1) * PF_S * 4); need((size_t)(Ecap + 1) * 48 * 4);
     need((size_t)Nf * c.pharm_nf * 4 + 16); need((size_t)Nf * 3 * 4 + 16); need((size_t)B * 3 * 4); need((size_t)B * 3 * 4); need((size_t)2 * B * 4);
+    need((size_t)std::max(Np, 1) * PF_S * 4);
     PF_HIP(h, hipMalloc(&h->d_ws, bytes + 4096));
     char* cur = reinterpret_cast<char*>(h->d_ws);
     h->d_prot_ptr = carve<int>(cur, B + 1); h->d_pharm_ptr = carve<int>(cur, B + 1); h->d_gid = carve<int>(cur, N);
@@ -664,6 +698,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     h->d_msg_s = carve<float>(cur, (size_t)(Ecap + 1) * PF_S); h->d_msg_v = carve<float>(cur, (size_t)(Ecap + 1) * 48);
     h->d_eps_h = carve<float>(cur, (size_t)Nf * c.pharm_nf + 4); h->d_eps_x = carve<float>(cur, (size_t)Nf * 3 + 4);
     h->d_com_init = carve<float>(cur, (size_t)B * 3); h->d_com_tmp = carve<float>(cur, (size_t)B * 3); h->d_gnorm = carve<float>(cur, (size_t)2 * B);
+    h->d_pre = carve<float>(cur, (size_t)std::max(Np, 1) * PF_S);
     // ---- uploads (synchronous: these are small tables; pageable host memory)
     PF_HIP(h, hipMemcpy(h->d_prot_ptr, prot_ptr, (B + 1) * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_pharm_ptr, pharm_ptr, (B + 1) * 4, hipMemcpyHostToDevice));

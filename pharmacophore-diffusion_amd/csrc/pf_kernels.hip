@@ -22,6 +22,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef PF_CH
 #define PF_CH 4
 #endif
+#ifdef PF_ABL_WSAME
+#define PF_WIDX(x) ((x) & 3)
+#else
+#define PF_WIDX(x) (x)
+#endif
 #ifndef PF_SGB
 #define PF_SGB 0
 #endif
@@ -62,15 +67,20 @@ __device__ __forceinline__ float siluf_(float x) { return x * rcpf_(1.0f + __exp
 //   VROW0  only the extra channel (x_diff) is non-zero (conv layer 0: node vectors are zero,
 //          dynamics_gvp.py:162-173)
 // ---------------------------------------------------------------------------------------------
-template <int VI, int NEXTRA, int VO, int NMO, bool SIG, bool VROW0>
+//   PRE    the 128-feature block of the scalar Linear (+ bias) was already applied per SOURCE NODE
+//          (k_encode_build: P = W[:, :128] h + b); the accumulators start from the gathered row of P and
+//          only the rbf / sh k-steps remain  (E/N ~ 7x fewer MFMAs for that block on pp edges)
+template <int VI, int NEXTRA, int VO, int NMO, bool SIG, bool VROW0, bool PRE = false>
 __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64], const float* ext,
                                           const float (&Vr)[3][8], const float* xhat,
-                                          float (&s_out)[NMO * 16], float (&V_out)[3][8], const int lane) {
+                                          float (&s_out)[NMO * 16], float (&V_out)[3][8], const int lane,
+                                          pf_gcf pre_row = nullptr) {
     constexpr bool X = (VI == 17);                   // extra (17th) channel present
     constexpr int NVK = 8 + (X ? 1 : 0);             // k-steps of the Vh / Vu products and of the sh block
     constexpr int NKS = 64 + NEXTRA / 2 + NVK;       // k-steps of to_feats_out
+    constexpr int KS0 = PRE ? 64 : 0;                // first k-step still to do
     constexpr int CH = PF_CH;                        // k-steps per software-pipeline chunk
-    constexpr int NCH = (NKS + CH - 1) / CH;
+    constexpr int NCH = (NKS - KS0 + CH - 1) / CH;
     const int hl = lane >> 5;
     // ---- vector channel on the matrix cores                                     (gvp.py:96-99)
     f32x16 vh[3], vu[3];
@@ -111,32 +121,34 @@ __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64],
     // ---- scalar channel: feats_out = SiLU(W [s, sh] + b) on the matrix cores  (gvp.py:101-103)
     f32x16 acc[NMO];
     {
-        const f32x4 PF_AS1* bp = reinterpret_cast<const f32x4 PF_AS1*>(w.b_main + hl * (NMO * 16));
+        // bias in F-layout -- or, with PRE, the gathered row of P (row-major, so the F-layout pattern applies)
+        const f32x4 PF_AS1* bp = PRE ? reinterpret_cast<const f32x4 PF_AS1*>(pre_row + 4 * hl)
+                                     : reinterpret_cast<const f32x4 PF_AS1*>(w.b_main + hl * (NMO * 16));
 #pragma unroll
         for (int mo = 0; mo < NMO; ++mo)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 b4 = bp[mo * 4 + q];
+                const f32x4 b4 = PRE ? bp[mo * 8 + q * 2] : bp[mo * 4 + q];
                 acc[mo][4 * q + 0] = b4[0]; acc[mo][4 * q + 1] = b4[1];
                 acc[mo][4 * q + 2] = b4[2]; acc[mo][4 * q + 3] = b4[3];
             }
     }
     typedef float fragA __attribute__((ext_vector_type(NMO)));
-    const fragA PF_AS1* ap = reinterpret_cast<const fragA PF_AS1*>(w.a_main) + lane;
+    const fragA PF_AS1* ap = reinterpret_cast<const fragA PF_AS1*>(w.a_main) + KS0 * 64 + lane;
     fragA abuf[2][CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i)
-        if (i < NKS) abuf[0][i] = ap[i * 64];
+        if (KS0 + i < NKS) abuf[0][i] = ap[PF_WIDX(i) * 64];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         if (c + 1 < NCH) {
 #pragma unroll
             for (int i = 0; i < CH; ++i)
-                if ((c + 1) * CH + i < NKS) abuf[(c + 1) & 1][i] = ap[((c + 1) * CH + i) * 64];
+                if (KS0 + (c + 1) * CH + i < NKS) abuf[(c + 1) & 1][i] = ap[PF_WIDX((c + 1) * CH + i) * 64];
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const int ks = c * CH + i;
+            const int ks = KS0 + c * CH + i;
             if (ks < NKS) {
                 float b;
                 if (ks < 64) b = s_in[ks < 64 ? ks : 0];
@@ -335,8 +347,7 @@ __global__ __launch_bounds__(256, PF_WPS_EDGE) void k_edge_msg(const EdgeParams 
         const float re = __expf(-(ze * ze)), ro = __expf(-(zo * zo));
         rb[k] = hl ? ro : re;
     }
-    float s[64], V[3][8];
-    load_row_f(p.h + (size_t)src * PF_S, hl, s);
+    float V[3][8];
     if constexpr (!L0) load_vec_r(p.v + (size_t)src * 48, hl, V);
     else {
 #pragma unroll
@@ -346,7 +357,17 @@ __global__ __launch_bounds__(256, PF_WPS_EDGE) void k_edge_msg(const EdgeParams 
     }
     const GvpW PF_AS1* wt = (const GvpW PF_AS1*)p.w + et * p.n_gvps;
     float s1[64], V1[3][8];
-    gvp_apply<17, PF_R, 16, 4, true, L0>(wt[0], s, rb, V, xhat, s1, V1, lane);
+    if (et == ET_PP && p.pre != nullptr) {
+        // pp edges: W[:, :128] h_src + b was applied once per source node; gather that row into the accumulators
+        float s[64];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) s[q] = 0.f;
+        gvp_apply<17, PF_R, 16, 4, true, L0, true>(wt[0], s, rb, V, xhat, s1, V1, lane, (pf_gcf)p.pre + (size_t)src * PF_S);
+    } else {
+        float s[64];
+        load_row_f(p.h + (size_t)src * PF_S, hl, s);
+        gvp_apply<17, PF_R, 16, 4, true, L0>(wt[0], s, rb, V, xhat, s1, V1, lane);
+    }
     for (int gi = 1; gi < p.n_gvps; ++gi) {
         float s2[64], V2[3][8];
         gvp_apply<16, 0, 16, 4, true, false>(wt[gi], s1, nullptr, V1, nullptr, s2, V2, lane);
@@ -1325,11 +1346,106 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
     }
 }
 
+// Protein encoder + per-source-node precompute for the pp messages of conv layer 0, one 256-thread block per 32
+// atoms (4-wave cooperative form): h0 = LN(SiLU(W_enc [feat, t] + b)) on the matrix cores (wave w owns output
+// tile w), LayerNorm statistics on the full row after an LDS exchange, then P = W_msg0[:, :128] h0 + b_msg0
+// (64 MFMAs per wave).  Both rows are stored; the edge kernel gathers P straight into its accumulators.
+__device__ __forceinline__ void encode_pre_tile(const PreParams& p, const int tile, CoopLds& L) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 31, hl = lane >> 5;
+    const int n0 = tile * 32, cnt = min(32, p.Np - n0);
+    const bool live = j < cnt;
+    const int n = n0 + min(j, cnt - 1);
+    const float tt = p.t ? p.t[p.gid[n]] : p.t_scalar;
+    pf_gcf in = (pf_gcf)p.prot_h0 + (size_t)n * p.rec_nf;
+    f32x16 acc;
+    {
+        const f32x4 PF_AS1* bp = reinterpret_cast<const f32x4 PF_AS1*>(p.b_enc + hl * 64 + wv * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const f32x4 b4 = bp[q]; acc[4 * q] = b4[0]; acc[4 * q + 1] = b4[1]; acc[4 * q + 2] = b4[2]; acc[4 * q + 3] = b4[3]; }
+    }
+    for (int t = 0; t < p.nke; ++t) {                 // k-step t: this half feeds input 2t + hl ([features, t])
+        const int k = 2 * t + hl;
+        const float b = k < p.rec_nf ? in[k] : (k == p.rec_nf ? tt : 0.f);
+        acc = MFMA(p.a_enc[((size_t)wv * p.nke + t) * 64 + lane], b, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) L.so[wv][r][lane] = siluf_(acc[r]);
+    __syncthreads();
+    float s[64];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[mt * 16 + r] = L.so[mt][r][lane];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) sum += s[q];
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / 128.0f);
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) { const float c = s[q] - mean; var = fmaf(c, c, var); }
+    var += __shfl_xor(var, 32);
+    const float rstd = rsqf_(var * (1.0f / 128.0f) + 1e-5f);
+    {
+        auto pw = reinterpret_cast<const f32x4 PF_AS1*>(p.ln_w + 4 * hl);
+        auto pb = reinterpret_cast<const f32x4 PF_AS1*>(p.ln_b + 4 * hl);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w4 = pw[mt * 8 + q * 2], b4 = pb[mt * 8 + q * 2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[mt * 16 + 4 * q + i] = (s[mt * 16 + 4 * q + i] - mean) * rstd * w4[i] + b4[i];
+            }
+    }
+    // P tile wv = b + sum_k W[32wv.., k] h0[k]  over the 64 feature k-steps of the first pp message GVP
+    f32x16 pa;
+    {
+        const f32x4 PF_AS1* bp = reinterpret_cast<const f32x4 PF_AS1*>(p.pre_w.b_main + hl * 64 + wv * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const f32x4 b4 = bp[q]; pa[4 * q] = b4[0]; pa[4 * q + 1] = b4[1]; pa[4 * q + 2] = b4[2]; pa[4 * q + 3] = b4[3]; }
+    }
+    pf_gcf ap = p.pre_w.a_main_c + (size_t)wv * p.pre_nks * 64 + lane;
+    float a[64];
+#pragma unroll
+    for (int ks = 0; ks < 64; ++ks) a[ks] = ap[ks * 64];
+#pragma unroll
+    for (int ks = 0; ks < 64; ++ks) pa = MFMA(a[ks], s[ks], pa);
+    if (live) {
+        // wave w stores tile w (features 32w .. 32w+31) of both rows
+        f32x4* ph = reinterpret_cast<f32x4*>(p.h_out + (size_t)n * PF_S + 32 * wv + 4 * hl);
+        f32x4* pp = reinterpret_cast<f32x4*>(p.pre_out + (size_t)n * PF_S + 32 * wv + 4 * hl);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 x, y;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i] = s[wv * 16 + 4 * q + i]; y[i] = pa[4 * q + i]; }
+            ph[q * 2] = x; pp[q * 2] = y;
+        }
+    }
+}
+
 // encoders and dynamic edge build are independent (one reads h/t, the other coordinates): one launch,
 // the first B blocks build edges, the rest encode
 __global__ __launch_bounds__(256) void k_encode_build(const EncodeParams ep, const BuildParams bp) {
     if ((int)blockIdx.x < bp.B) build_body(bp, blockIdx.x);
     else encode_body(ep, blockIdx.x - bp.B);
+}
+// the same launch with the protein side done by encode_pre_tile: blocks [0,B) build edges, [B, B+gp) encode the
+// pharmacophore nodes (8 per wave), the rest encode 32 protein atoms each and precompute P
+__global__ __launch_bounds__(256) void k_encode_build_pre(const EncodeParams ep, const BuildParams bp, const PreParams pp) {
+    __shared__ CoopLds L;
+    const int gp = ((ep.Nf + 7) / 8 + 3) / 4;
+    const int b = blockIdx.x;
+    if (b < bp.B) build_body(bp, b);
+    else if (b < bp.B + gp) {
+        const int lane = threadIdx.x & 63;
+        const int grp = __builtin_amdgcn_readfirstlane((int)(((b - bp.B) * 256 + threadIdx.x) >> 6));
+        const int first = grp * 8;
+        if (first < ep.Nf) encode_group(ep, 1, first, min(8, ep.Nf - first), lane);
+    } else encode_pre_tile(pp, b - bp.B - gp, L);
 }
 __global__ __launch_bounds__(256) void k_build_edges(const BuildParams p) { build_body(p, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_encode(const EncodeParams p) { encode_body(p, blockIdx.x); }
@@ -1504,6 +1620,10 @@ void pfk_noise_head(const HeadParams* p, hipStream_t s) {
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s) {
     const int groups = (e->Np + 7) / 8 + (e->Nf + 7) / 8;
     hipLaunchKernelGGL(k_encode_build, dim3(b->B + (groups + 3) / 4), dim3(256), 0, s, *e, *b);
+}
+void pfk_encode_build_pre(const EncodeParams* e, const BuildParams* b, const PreParams* pp, hipStream_t s) {
+    const int gp = ((e->Nf + 7) / 8 + 3) / 4;
+    hipLaunchKernelGGL(k_encode_build_pre, dim3(b->B + gp + (pp->Np + 31) / 32), dim3(256), 0, s, *e, *b, *pp);
 }
 void pfk_encode(const EncodeParams* p, hipStream_t s) {
     const int groups = (p->Np + 7) / 8 + (p->Nf + 7) / 8;
