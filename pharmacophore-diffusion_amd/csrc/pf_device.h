@@ -62,10 +62,13 @@ struct EdgeTile {          // one wave = 32 edge slots
     int rel;               // e0 - region start (dynamic tiles)
 };
 
-struct NodeTile {          // one wave = 32 nodes of one type
-    int n0;                // first global node id
-    int n;                 // nodes in this tile (<= 32)
+struct NodeTile {          // 32 nodes of one type
+    int n0;                // first global node id -- or first position in the active-atom list (ids != 0)
+    int n;                 // rows in this tile (<= 32)
     int ntype;             // 0 prot, 1 pharm
+    int cnt_idx;           // index into dyn_cnt of the list length, or -1 for static tiles
+    int rel;               // position of the tile inside its list
+    int ids;               // rows are positions in row_ids (active-atom list) instead of node ids
 };
 
 struct EdgeParams {
@@ -95,9 +98,12 @@ struct NodeW {             // per node type
 struct NodeParams {
     const NodeTile* tiles;
     int ntiles;
-    const int* in_start;   // [2][N]
-    const int* in_cnt;     // [2][N]
+    const int* in_start;   // [3][N]
+    const int* in_cnt;     // [3][N]
     int N;
+    int pp_slot;           // which slot holds the prot nodes' pp in-edges: 1 all, 2 compact copy for active atoms
+    const int* row_ids;    // active-atom lists (tiles with ids != 0)
+    const int* dyn_cnt;
     const float* msg_s;
     const float* msg_v;
     int zero_row;          // index of an all-zero message row (lanes without in-edges)
@@ -141,10 +147,12 @@ struct BuildParams {
     int B, Np_tot;
     const int* prot_ptr; const int* pharm_ptr;   // device [B+1]
     const float4* xn;
-    const int* reg;        // [3][B] region start (absolute edge slot) of ff, pf, fp
-    int* dyn_cnt;          // [3][B]
+    const int* reg;        // [4][B] region start (absolute edge slot) of ff, pf, fp, pa (pp edges into active atoms)
+    int* dyn_cnt;          // [5][B] edges of ff, pf, fp, pa; number of active atoms
+    int* act_ids;          // active-atom lists (global node ids), or NULL: no receptive-field pruning
+    const int* reg_act;    // [B] start of each graph's list in act_ids
     int* esrc; int* edst;
-    int* in_start; int* in_cnt; int N;
+    int* in_start; int* in_cnt; int N;   // [3][N]: slot 0 ff|fp, slot 1 pf|pp(all), slot 2 pp into active atoms
     int ff_k, pf_k;
     float r2_ff, r2_pf;
     float* gnorm;          // [2][B]

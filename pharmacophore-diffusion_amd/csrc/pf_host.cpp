@@ -93,7 +93,14 @@ struct pf_handle {
     std::vector<int> h_cap;                 // [3][B]
     int n_edge_tiles = 0, n_node_tiles = 0, n_head_tiles = 0;
     int zero_row = 0;
-    int n_edge_tiles_last = 0, n_node_tiles_last = 0;   // last conv layer: only what feeds the pharm nodes
+    int n_edge_tiles_last = 0, n_node_tiles_last = 0;
+    // receptive-field pruning of the second-to-last conv layer: only the protein atoms that are the source of a
+    // pf edge (the only protein rows the last layer reads) are updated, and only the edges into them are computed
+    bool prune = true;
+    int n_edge_tiles_act = 0, n_node_tiles_act = 0;
+    EdgeTile* d_edge_tiles_act = nullptr;
+    NodeTile* d_node_tiles_act = nullptr;
+    int *d_act_ids = nullptr, *d_reg_act = nullptr;   // last conv layer: only what feeds the pharm nodes
     void* d_ws = nullptr;                   // one allocation, carved below
     int *d_prot_ptr = nullptr, *d_pharm_ptr = nullptr, *d_gid = nullptr, *d_reg = nullptr, *d_dyn_cnt = nullptr,
         *d_esrc = nullptr, *d_edst = nullptr, *d_in_start = nullptr, *d_in_cnt = nullptr, *d_pp_cnt = nullptr;
@@ -106,11 +113,12 @@ struct pf_handle {
           *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr, *d_pre = nullptr;
     bool sampling = false;
     // launches with at most this many tiles use the 4-wave cooperative kernels (latency-bound regime)
-    int coop_edge_max = 512, coop_node_max = 1024;
+    int coop_edge_max = 2048, coop_node_max = 1024;
     void init_tuning() {
         if (const char* e = getenv("PFDYN_COOP_EDGE_MAX")) coop_edge_max = atoi(e);
         if (const char* e = getenv("PFDYN_COOP_NODE_MAX")) coop_node_max = atoi(e);
         if (const char* e = getenv("PFDYN_NO_PRE")) use_pre = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_NO_PRUNE")) prune = atoi(e) == 0;
     }
 
     // ---- optional per-kernel timing with HIP events on the caller's stream (pf_profile_*)
@@ -356,11 +364,13 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
     bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
     bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
+    const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;    // the layer restricted to active atoms
+    bp.act_ids = prune_layer >= 0 ? h->d_act_ids : nullptr; bp.reg_act = h->d_reg_act;
     bool pre_ready = false;
     if (h->prof_mask & 3u) {     // timing the two halves separately needs separate launches
         { ProfScope ps(h, pf_handle::K_ENCODE, s); pfk_encode(&ep, s); }
         { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); }
-    } else if (h->use_pre && h->Np > 0) {
+    } else if (h->use_pre && h->Np > 0 && prune_layer != 0) {      // layer 0 is dense: precompute P for its pp messages
         PreParams pp{};
         pp.Np = h->Np; pp.rec_nf = c.rec_nf; pp.nke = (c.rec_nf + 2) / 2;
         pp.prot_h0 = h->d_prot_h0; pp.t = ep.t; pp.t_scalar = ep.t_scalar; pp.gid = h->d_gid;
@@ -375,8 +385,9 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     int cur = 0;
     for (int l = 0; l < c.n_convs; ++l) {
         EdgeParams e{};
-        const bool last = (l == c.n_convs - 1);
-        e.tiles = h->d_edge_tiles; e.ntiles = last ? h->n_edge_tiles_last : h->n_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
+        const bool last = (l == c.n_convs - 1), pruned = (l == prune_layer);
+        e.tiles = pruned ? h->d_edge_tiles_act : h->d_edge_tiles;
+        e.ntiles = last ? h->n_edge_tiles_last : (pruned ? h->n_edge_tiles_act : h->n_edge_tiles); e.dyn_cnt = h->d_dyn_cnt;
         e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;
         e.h = h->d_h[cur]; e.v = h->d_v[cur];
         e.msg_s = h->d_msg_s; e.msg_v = h->d_msg_v;
@@ -389,8 +400,10 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         else { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
 
         NodeParams n{};
-        n.tiles = h->d_node_tiles; n.ntiles = last ? h->n_node_tiles_last : h->n_node_tiles;
+        n.tiles = pruned ? h->d_node_tiles_act : h->d_node_tiles;
+        n.ntiles = last ? h->n_node_tiles_last : (pruned ? h->n_node_tiles_act : h->n_node_tiles);
         n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
+        n.pp_slot = pruned ? 2 : 1; n.row_ids = h->d_act_ids; n.dyn_cnt = h->d_dyn_cnt;
         n.msg_s = h->d_msg_s; n.msg_v = h->d_msg_v; n.zero_row = h->zero_row;
         n.h_in = h->d_h[cur]; n.v_in = h->d_v[cur]; n.h_out = h->d_h[cur ^ 1]; n.v_out = h->d_v[cur ^ 1];
         n.gid = h->d_gid; n.gnorm = h->d_gnorm; n.B = h->B;
@@ -611,7 +624,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
         for (int i = pharm_ptr[g]; i < pharm_ptr[g + 1]; ++i) gid[Np + i] = g;
     }
     // pp edges sorted by destination (stable counting sort): CSR-by-dst
-    std::vector<int> in_start((size_t)2 * N, 0), in_cnt((size_t)2 * N, 0);
+    std::vector<int> in_start((size_t)3 * N, 0), in_cnt((size_t)3 * N, 0);
     std::vector<int> deg(Np + 1, 0);
     for (int64_t e = 0; e < n_pp; ++e) {
         if (pp_src[e] < 0 || pp_src[e] >= Np || pp_dst[e] < 0 || pp_dst[e] >= Np) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld out of range", (long long)e);
@@ -620,16 +633,27 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     }
     for (int i = 0; i < Np; ++i) deg[i + 1] += deg[i];
     std::vector<int> pp_cnt(B, 0);
-    // capacity of dynamic regions
-    h->h_reg.assign((size_t)3 * B, 0);
-    h->h_cap.assign((size_t)3 * B, 0);
+    // capacity of dynamic regions: ff, pf, fp and "pa" = compact copy of the pp edges into the active atoms
+    h->h_reg.assign((size_t)4 * B, 0);
+    h->h_cap.assign((size_t)4 * B, 0);
+    std::vector<int> reg_act(B, 0), cap_act(B, 0), maxdeg(B, 0), epp_g(B, 0);
+    for (int i = 0; i < Np; ++i) {
+        maxdeg[gid[i]] = std::max(maxdeg[gid[i]], deg[i + 1] - deg[i]);
+        epp_g[gid[i]] += deg[i + 1] - deg[i];
+    }
     int64_t cursor = n_pp;
-    for (int et = 0; et < 3; ++et)
+    int act_total = 0;
+    for (int et = 0; et < 4; ++et)
         for (int g = 0; g < B; ++g) {
             const int np = prot_ptr[g + 1] - prot_ptr[g], nf = pharm_ptr[g + 1] - pharm_ptr[g];
+            const int nact = c.pf_k > 0 ? std::min(np, nf * std::min(c.pf_k, np)) : (nf > 0 ? np : 0);
             int cap;
             if (et == ET_FF) cap = c.ff_k > 0 ? nf * std::min(c.ff_k, std::max(nf - 1, 0)) : nf * std::max(nf - 1, 0);
-            else cap = c.pf_k > 0 ? nf * std::min(c.pf_k, np) : nf * np;
+            else if (et < 3) cap = c.pf_k > 0 ? nf * std::min(c.pf_k, np) : nf * np;
+            else {
+                cap = (int)std::min<int64_t>(epp_g[g], (int64_t)nact * maxdeg[g]);
+                reg_act[g] = act_total; cap_act[g] = nact; act_total += nact;
+            }
             cursor = (cursor + 31) & ~int64_t(31);     // tiles are aligned to multiples of 32 slots (seg_tail in the kernels)
             h->h_reg[(size_t)et * B + g] = (int)cursor;
             h->h_cap[(size_t)et * B + g] = cap;
@@ -664,19 +688,32 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     for (int64_t o = 0; o < n_pp; o += 32) et_tiles.push_back({(int)o, (int)std::min<int64_t>(32, n_pp - o), ET_PP, -1, 0});
     std::vector<NodeTile> n_tiles, h_tiles;
     for (int o = 0; o < Nf; o += 32) {
-        n_tiles.push_back({Np + o, std::min(32, Nf - o), 1});
-        h_tiles.push_back({Np + o, std::min(32, Nf - o), 1});
+        n_tiles.push_back({Np + o, std::min(32, Nf - o), 1, -1, 0, 0});
+        h_tiles.push_back({Np + o, std::min(32, Nf - o), 1, -1, 0, 0});
     }
-    for (int o = 0; o < Np; o += 32) n_tiles.push_back({o, std::min(32, Np - o), 0});
+    for (int o = 0; o < Np; o += 32) n_tiles.push_back({o, std::min(32, Np - o), 0, -1, 0, 0});
     h->n_edge_tiles = (int)et_tiles.size();
     h->n_node_tiles = (int)n_tiles.size();
     h->n_head_tiles = (int)h_tiles.size();
     h->n_node_tiles_last = (int)h_tiles.size();          // pharm tiles come first in n_tiles
+    // pruned layer: ff, pf, fp tiles + pa tiles; pharm node tiles + tiles over the active-atom lists
+    std::vector<EdgeTile> et_act;
+    for (int et = 0; et < 4; ++et)
+        for (int g = 0; g < B; ++g) {
+            const int cap = h->h_cap[(size_t)et * B + g], reg = h->h_reg[(size_t)et * B + g];
+            for (int o = 0; o < cap; o += 32) et_act.push_back({reg + o, std::min(32, cap - o), et == 3 ? (int)ET_PP : et, et * B + g, o});
+        }
+    std::vector<NodeTile> n_act(h_tiles);
+    for (int g = 0; g < B; ++g)
+        for (int o = 0; o < cap_act[g]; o += 32) n_act.push_back({reg_act[g] + o, std::min(32, cap_act[g] - o), 0, 4 * B + g, o, 1});
+    h->n_edge_tiles_act = (int)et_act.size();
+    h->n_node_tiles_act = (int)n_act.size();
     // ---- one workspace allocation
     size_t bytes = 0;
     auto need = [&](size_t b) { bytes += (b + 255) & ~size_t(255); };
-    need((B + 1) * 4); need((B + 1) * 4); need((size_t)N * 4); need((size_t)3 * B * 4); need((size_t)3 * B * 4);
-    need(Ecap * 4); need(Ecap * 4); need((size_t)2 * N * 4); need((size_t)2 * N * 4); need((size_t)B * 4);
+    need((B + 1) * 4); need((B + 1) * 4); need((size_t)N * 4); need((size_t)4 * B * 4); need((size_t)5 * B * 4);
+    need(et_act.size() * sizeof(EdgeTile) + 256); need(n_act.size() * sizeof(NodeTile) + 256); need((size_t)(act_total + 1) * 4); need((size_t)B * 4);
+    need(Ecap * 4); need(Ecap * 4); need((size_t)3 * N * 4); need((size_t)3 * N * 4); need((size_t)B * 4);
     need(et_tiles.size() * sizeof(EdgeTile) + 256); need(n_tiles.size() * sizeof(NodeTile) + 256); need(h_tiles.size() * sizeof(NodeTile) + 256);
     need((size_t)N * 16); need((size_t)Np * 3 * 4 + 16); need((size_t)Np * c.rec_nf * 4 + 16); need((size_t)Nf * c.pharm_nf * 4 + 16); need((size_t)B * 4);
     need((size_t)N * PF_S * 4); need((size_t)N * PF_S * 4); need((size_t)N * 48 * 4); need((size_t)N * 48 * 4);
@@ -686,9 +723,11 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     PF_HIP(h, hipMalloc(&h->d_ws, bytes + 4096));
     char* cur = reinterpret_cast<char*>(h->d_ws);
     h->d_prot_ptr = carve<int>(cur, B + 1); h->d_pharm_ptr = carve<int>(cur, B + 1); h->d_gid = carve<int>(cur, N);
-    h->d_reg = carve<int>(cur, (size_t)3 * B); h->d_dyn_cnt = carve<int>(cur, (size_t)3 * B);
+    h->d_reg = carve<int>(cur, (size_t)4 * B); h->d_dyn_cnt = carve<int>(cur, (size_t)5 * B);
+    h->d_edge_tiles_act = carve<EdgeTile>(cur, et_act.size() + 16); h->d_node_tiles_act = carve<NodeTile>(cur, n_act.size() + 16);
+    h->d_act_ids = carve<int>(cur, (size_t)act_total + 1); h->d_reg_act = carve<int>(cur, B);
     h->d_esrc = carve<int>(cur, Ecap); h->d_edst = carve<int>(cur, Ecap);
-    h->d_in_start = carve<int>(cur, (size_t)2 * N); h->d_in_cnt = carve<int>(cur, (size_t)2 * N); h->d_pp_cnt = carve<int>(cur, B);
+    h->d_in_start = carve<int>(cur, (size_t)3 * N); h->d_in_cnt = carve<int>(cur, (size_t)3 * N); h->d_pp_cnt = carve<int>(cur, B);
     h->d_edge_tiles = carve<EdgeTile>(cur, et_tiles.size() + 16); h->d_node_tiles = carve<NodeTile>(cur, n_tiles.size() + 16);
     h->d_head_tiles = carve<NodeTile>(cur, h_tiles.size() + 16);
     h->d_xn = carve<float4>(cur, N); h->d_prot_x0 = carve<float>(cur, (size_t)Np * 3 + 4); h->d_prot_h0 = carve<float>(cur, (size_t)Np * c.rec_nf + 4);
@@ -703,12 +742,16 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     PF_HIP(h, hipMemcpy(h->d_prot_ptr, prot_ptr, (B + 1) * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_pharm_ptr, pharm_ptr, (B + 1) * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_gid, gid.data(), (size_t)N * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemcpy(h->d_reg, h->h_reg.data(), (size_t)3 * B * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemset(h->d_dyn_cnt, 0, (size_t)3 * B * 4));
+    PF_HIP(h, hipMemcpy(h->d_reg, h->h_reg.data(), (size_t)4 * B * 4, hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemset(h->d_dyn_cnt, 0, (size_t)5 * B * 4));
+    PF_HIP(h, hipMemcpy(h->d_reg_act, reg_act.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemset(h->d_act_ids, 0, (size_t)(act_total + 1) * 4));
+    if (!et_act.empty()) PF_HIP(h, hipMemcpy(h->d_edge_tiles_act, et_act.data(), et_act.size() * sizeof(EdgeTile), hipMemcpyHostToDevice));
+    if (!n_act.empty()) PF_HIP(h, hipMemcpy(h->d_node_tiles_act, n_act.data(), n_act.size() * sizeof(NodeTile), hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_esrc, esrc.data(), (size_t)Ecap * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_edst, edst.data(), (size_t)Ecap * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemcpy(h->d_in_start, in_start.data(), (size_t)2 * N * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemcpy(h->d_in_cnt, in_cnt.data(), (size_t)2 * N * 4, hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemcpy(h->d_in_start, in_start.data(), (size_t)3 * N * 4, hipMemcpyHostToDevice));
+    PF_HIP(h, hipMemcpy(h->d_in_cnt, in_cnt.data(), (size_t)3 * N * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_pp_cnt, pp_cnt.data(), (size_t)B * 4, hipMemcpyHostToDevice));
     if (!et_tiles.empty()) PF_HIP(h, hipMemcpy(h->d_edge_tiles, et_tiles.data(), et_tiles.size() * sizeof(EdgeTile), hipMemcpyHostToDevice));
     if (!n_tiles.empty()) PF_HIP(h, hipMemcpy(h->d_node_tiles, n_tiles.data(), n_tiles.size() * sizeof(NodeTile), hipMemcpyHostToDevice));
@@ -914,6 +957,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     bp.in_start = h->d_in_start; bp.in_cnt = h->d_in_cnt; bp.N = h->N; bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
     bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
     bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
+    bp.act_ids = nullptr; bp.reg_act = h->d_reg_act;
     pfk_build_edges(&bp, s);
     EdgeParams e{};
     e.tiles = h->d_edge_tiles; e.ntiles = h->n_edge_tiles; e.dyn_cnt = h->d_dyn_cnt; e.esrc = h->d_esrc; e.edst = h->d_edst;
@@ -924,6 +968,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     pfk_edge_msg(&e, 0, s);
     NodeParams n{};
     n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles; n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
+    n.pp_slot = 1; n.row_ids = h->d_act_ids; n.dyn_cnt = h->d_dyn_cnt;
     n.msg_s = h->d_msg_s; n.msg_v = h->d_msg_v; n.zero_row = h->zero_row; n.h_in = h->d_h[0]; n.v_in = h->d_v[0]; n.h_out = h->d_h[1]; n.v_out = h->d_v[1];
     n.gid = h->d_gid; n.gnorm = h->d_gnorm; n.B = h->B; n.norm_mode = c.message_norm_mode; n.norm_value = c.message_norm_value;
     for (int nt = 0; nt < 2; ++nt) {

@@ -859,8 +859,14 @@ template <bool L0>
 __device__ __forceinline__ void node_tile_coop(const NodeParams& p, const NodeTile t, CoopLds& L, const int lane, const int wv) {
     const int nt = __builtin_amdgcn_readfirstlane(t.ntype);
     const int j = lane & 31, hl = lane >> 5;
-    const bool live = j < t.n;
-    const int n = t.n0 + min(j, t.n - 1);
+    int tn = t.n;
+    if (t.cnt_idx >= 0) tn = min(tn, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
+    tn = __builtin_amdgcn_readfirstlane(tn);
+    if (tn <= 0) return;                               // block-uniform
+    const bool live = j < tn;
+    // rows are node ids, or (pruned layer) positions in the list of active protein atoms
+    auto node_of = [&](const int row) { return t.ids ? p.row_ids[t.n0 + row] : t.n0 + row; };
+    const int n = node_of(min(j, tn - 1));
     const NodeW nw = p.w[nt];
     // Deterministic segmented reduction of the in-edge messages, row-parallel: wave w owns nodes 8w..8w+7 of the
     // tile; for each node the 64 lanes stream its contiguous message rows (128 scalars as float2 + 48 vector
@@ -871,9 +877,10 @@ __device__ __forceinline__ void node_tile_coop(const NodeParams& p, const NodeTi
         int my_st = 0, my_c = 0;
         if (lane < 16) {
             const int jj = 8 * wv + (lane & 7);
-            if (jj < t.n) {
-                my_st = p.in_start[(lane >> 3) * p.N + t.n0 + jj];
-                my_c = p.in_cnt[(lane >> 3) * p.N + t.n0 + jj];
+            if (jj < tn) {
+                const int slot = (lane >> 3) == 0 ? 0 : (nt == 0 ? p.pp_slot : 1);
+                my_st = p.in_start[slot * p.N + node_of(jj)];
+                my_c = p.in_cnt[slot * p.N + node_of(jj)];
             }
         }
 #ifdef PF_ABL_NOAGG
@@ -1137,21 +1144,67 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
     return k;
 }
 // exclusive scan of one value per thread over a 256-thread block; returns this thread's offset,
-// *total receives the block total.  scratch: 256 ints of LDS.
-__device__ __forceinline__ int block_excl_scan(const int val, int* scratch, int* total) {
+// *total receives the block total.  scratch: 256 x 8 B of LDS.  The value packs three counters
+// (bits 0-15, 16-27, 28-63) so that one scan serves the fp edges, the active-atom list and its pp in-edges.
+__device__ __forceinline__ unsigned long long block_excl_scan(const unsigned long long val, unsigned long long* scratch,
+                                                              unsigned long long* total) {
     const int tid = threadIdx.x;
     scratch[tid] = val;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
-        const int add = tid >= o ? scratch[tid - o] : 0;
+        const unsigned long long add = tid >= o ? scratch[tid - o] : 0ull;
         __syncthreads();
         scratch[tid] += add;
         __syncthreads();
     }
-    const int incl = scratch[tid];
+    const unsigned long long incl = scratch[tid];
     *total = scratch[255];
     __syncthreads();
     return incl - val;
+}
+
+// Protein side of the dynamic edges of one graph, destination-major: the fp edges (sources = the pharm nodes
+// that reference atom c, ascending) and -- receptive-field pruning, see DESIGN.md -- the list of ACTIVE atoms
+// (atoms that are the source of a pf edge, the only protein rows the last conv layer reads) together with a
+// compact copy of their static pp in-edges.  `refs(c, visit)` calls visit(fl) for every referencing pharm node.
+template <typename Refs>
+__device__ __forceinline__ void emit_prot_side(const BuildParams& p, const int g, const int p0, const int Np, const int GF,
+                                               unsigned long long* scratch, Refs refs) {
+    const int tid = threadIdx.x;
+    int* in_start0 = p.in_start;             int* in_cnt0 = p.in_cnt;
+    const int* in_start1 = p.in_start + p.N; const int* in_cnt1 = p.in_cnt + p.N;
+    int* in_start2 = p.in_start + 2 * p.N;   int* in_cnt2 = p.in_cnt + 2 * p.N;
+    const int reg_fp = p.reg[2 * p.B + g], reg_pa = p.reg[3 * p.B + g];
+    const int reg_act = p.act_ids ? p.reg_act[g] : 0;
+    unsigned long long base = 0ull;
+    for (int c0 = 0; c0 < Np; c0 += 256) {
+        const int c = c0 + tid;
+        int my = 0;
+        if (c < Np) refs(c, [&](int) { ++my; });
+        const int act = (my > 0 && p.act_ids) ? 1 : 0;
+        const int deg = act ? in_cnt1[p0 + c] : 0;
+        unsigned long long tot;
+        const unsigned long long o = base + block_excl_scan((unsigned long long)my | ((unsigned long long)act << 16) |
+                                                            ((unsigned long long)deg << 28), scratch, &tot);
+        if (c < Np) {
+            int e = reg_fp + (int)(o & 0xffffu);
+            in_start0[p0 + c] = e;
+            in_cnt0[p0 + c] = my;
+            if (my) refs(c, [&](int fl) { p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; });
+            if (act) {
+                p.act_ids[reg_act + (int)((o >> 16) & 0xfffu)] = p0 + c;
+                const int d0 = reg_pa + (int)(o >> 28), s0 = in_start1[p0 + c];
+                in_start2[p0 + c] = d0;
+                in_cnt2[p0 + c] = deg;
+                for (int i = 0; i < deg; ++i) { p.esrc[d0 + i] = p.esrc[s0 + i]; p.edst[d0 + i] = p0 + c; }
+            }
+        }
+        base += tot;
+    }
+    if (tid == 0 && p.act_ids) {
+        p.dyn_cnt[3 * p.B + g] = (int)(base >> 28);
+        p.dyn_cnt[4 * p.B + g] = (int)((base >> 16) & 0xfffu);
+    }
 }
 
 __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
@@ -1159,7 +1212,7 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
     __shared__ int cnt[PF_MAXF];
     __shared__ int off[PF_MAXF + 1];
     __shared__ int knn_idx[PF_MAXF * PF_MAXK];
-    __shared__ int scratch[256];
+    __shared__ unsigned long long scratch[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p0 = p.prot_ptr[g], p1 = p.prot_ptr[g + 1];
     const int f0 = p.pharm_ptr[g], f1 = p.pharm_ptr[g + 1];
@@ -1259,27 +1312,12 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
         }
         if (tid == 0) { p.dyn_cnt[1 * p.B + g] = Nf * kk; p.dyn_cnt[2 * p.B + g] = Nf * kk; }
         __syncthreads();
-        // fp = pf reversed, destination-major over the protein atoms of this graph
-        int base = 0;
-        for (int c0 = 0; c0 < Np; c0 += 256) {
-            const int c = c0 + tid;
-            int my = 0;
-            if (c < Np)
-                for (int fl = 0; fl < Nf; ++fl)
-                    for (int r = 0; r < kk; ++r) my += (knn_idx[fl * PF_MAXK + r] == c) ? 1 : 0;
-            int tot;
-            const int o = block_excl_scan(my, scratch, &tot);
-            if (c < Np) {
-                int e = reg_fp + base + o;
-                in_start0[p0 + c] = e;
-                in_cnt0[p0 + c] = my;
-                if (my)
-                    for (int fl = 0; fl < Nf; ++fl)
-                        for (int r = 0; r < kk; ++r)
-                            if (knn_idx[fl * PF_MAXK + r] == c) { p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
-            }
-            base += tot;
-        }
+        // fp = pf reversed, destination-major over the protein atoms of this graph (+ active atoms, their pp edges)
+        emit_prot_side(p, g, p0, Np, GF, scratch, [&](const int c, auto visit) {
+            for (int fl = 0; fl < Nf; ++fl)
+                for (int r = 0; r < kk; ++r)
+                    if (knn_idx[fl * PF_MAXK + r] == c) visit(fl);
+        });
     } else {
         // radius(x=pharm, y=prot, r): pf = {prot -> pharm}, fp = reverse
         for (int fl = wave; fl < Nf; fl += 4) {
@@ -1316,26 +1354,11 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
                 e += __popcll(m);
             }
         }
-        int base = 0;
-        for (int c0 = 0; c0 < Np; c0 += 256) {
-            const int c = c0 + tid;
-            int my = 0;
-            float4 xc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < Np) {
-                xc = p.xn[p0 + c];
-                for (int fl = 0; fl < Nf; ++fl) my += (sqdist_rn(fx[fl], xc) < p.r2_pf) ? 1 : 0;
-            }
-            int tot;
-            const int o = block_excl_scan(my, scratch, &tot);
-            if (c < Np) {
-                int e = reg_fp + base + o;
-                in_start0[p0 + c] = e;
-                in_cnt0[p0 + c] = my;
-                for (int fl = 0; fl < Nf; ++fl)
-                    if (sqdist_rn(fx[fl], xc) < p.r2_pf) { p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
-            }
-            base += tot;
-        }
+        emit_prot_side(p, g, p0, Np, GF, scratch, [&](const int c, auto visit) {
+            const float4 xc = p.xn[p0 + c];
+            for (int fl = 0; fl < Nf; ++fl)
+                if (sqdist_rn(fx[fl], xc) < p.r2_pf) visit(fl);
+        });
     }
     // per-graph normalisers for message_norm == 0 (gvp.py:504-507)
     __syncthreads();
