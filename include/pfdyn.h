@@ -161,8 +161,11 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
 #define PF_NUM_KERNEL_CLASSES 8
 int pf_profile_enable(pf_handle* h, uint32_t kernel_mask);
 int pf_profile_read(pf_handle* h, double* total_ms /*[8]*/, int64_t* launches /*[8]*/, pf_stream stream);
-/* algorithmic work of the last dynamics call (SURVEY.md 8(d) formulas on the actual edge counts) */
-int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges /*[4]*/, pf_stream stream);
+/* work of the last dynamics call: `flops` / `bytes` = reference-equivalent (SURVEY.md 8(d) formulas on the actual
+ * edge counts n_edges[4] = ff, pf, fp, pp, every layer dense); `executed_flops` / `executed_edges[n_convs]` = what the
+ * kernels compute after dead-work elimination (last layer: pharm side only; layer before it: active atoms only). */
+int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges /*[4]*/, double* executed_flops,
+                  int64_t* executed_edges /*[n_convs]*/, pf_stream stream);
 
 #ifdef __cplusplus
 }

@@ -52,7 +52,7 @@ SYMBOLS = {
     "pf_profile_enable": (ctypes.c_int, [_P, ctypes.c_uint32]),
     "pf_profile_read": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), _P]),
     "pf_debug_work": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
-                                     ctypes.POINTER(_I64), _P]),
+                                     ctypes.POINTER(_I64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), _P]),
 }
 
 _lib = None

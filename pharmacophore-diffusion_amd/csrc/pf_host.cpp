@@ -113,7 +113,7 @@ struct pf_handle {
           *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr, *d_pre = nullptr;
     bool sampling = false;
     // launches with at most this many tiles use the 4-wave cooperative kernels (latency-bound regime)
-    int coop_edge_max = 2048, coop_node_max = 1024;
+    int coop_edge_max = 1024, coop_node_max = 1024;
     void init_tuning() {
         if (const char* e = getenv("PFDYN_COOP_EDGE_MAX")) coop_edge_max = atoi(e);
         if (const char* e = getenv("PFDYN_COOP_NODE_MAX")) coop_node_max = atoi(e);
@@ -1013,16 +1013,21 @@ int pf_profile_read(pf_handle* h, double* total_ms, int64_t* launches, pf_stream
     return PF_OK;
 }
 
-int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges, pf_stream stream) {
+int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges, double* executed_flops,
+                  int64_t* executed_edges, pf_stream stream) {
     int rc = check_ready(h, true);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     PF_HIP(h, hipStreamSynchronize(s));
     const pf_config& c = h->cfg;
-    std::vector<int> cnt((size_t)3 * h->B);
+    std::vector<int> cnt((size_t)5 * h->B);
     PF_HIP(h, hipMemcpy(cnt.data(), h->d_dyn_cnt, cnt.size() * 4, hipMemcpyDeviceToHost));
-    int64_t ne[4] = {0, 0, 0, h->Epp};
-    for (int et = 0; et < 3; ++et) for (int g = 0; g < h->B; ++g) ne[et] += cnt[(size_t)et * h->B + g];
+    int64_t ne[4] = {0, 0, 0, h->Epp}, n_pa = 0, n_act = 0;
+    for (int g = 0; g < h->B; ++g) {
+        for (int et = 0; et < 3; ++et) ne[et] += cnt[(size_t)et * h->B + g];
+        n_pa += cnt[(size_t)3 * h->B + g];
+        n_act += cnt[(size_t)4 * h->B + g];
+    }
     const double E = (double)(ne[0] + ne[1] + ne[2] + ne[3]);
     // FLOPs at 2/MAC
     auto gvp_flops = [](int vi, int vo, int si, int so) {
@@ -1037,6 +1042,19 @@ int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges, 
     if (flops) *flops = c.n_convs * (E * per_edge + (double)h->N * per_node) + (double)h->Nf * head + enc;
     if (bytes) *bytes = c.n_convs * (E * 736.0 + (double)h->N * 1420.0);
     if (n_edges) for (int i = 0; i < 4; ++i) n_edges[i] = ne[i];
+    // what the kernels actually compute: the last layer only feeds pharm nodes; the layer before it (when pruning
+    // is on) only the active atoms
+    const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;
+    double ex = (double)h->Nf * head + enc;
+    for (int l = 0; l < c.n_convs; ++l) {
+        double el, nl;
+        if (l == c.n_convs - 1) { el = (double)(ne[0] + ne[1]); nl = (double)h->Nf; }
+        else if (l == prune_layer) { el = (double)(ne[0] + ne[1] + ne[2] + n_pa); nl = (double)(h->Nf + n_act); }
+        else { el = E; nl = (double)h->N; }
+        ex += el * per_edge + nl * per_node;
+        if (executed_edges) executed_edges[l] = (int64_t)el;
+    }
+    if (executed_flops) *executed_flops = ex;
     return PF_OK;
 }
 

@@ -188,11 +188,19 @@ class PfEngine:
         return outs
 
     def work(self):
-        fl, by = ctypes.c_double(), ctypes.c_double()
+        """(reference-equivalent flops, bytes, [ff, pf, fp, pp] edge counts) of the last dynamics call."""
+        w = self.work_detail()
+        return w["flops"], w["bytes"], w["edges"]
+
+    def work_detail(self):
+        fl, by, ex = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         ne = (ctypes.c_int64 * 4)()
+        el = (ctypes.c_int64 * max(int(self.cfg.n_convs), 1))()
         with torch.cuda.device(self.device):
-            self._ck(self.lib.pf_debug_work(self._h, ctypes.byref(fl), ctypes.byref(by), ne, _stream_ptr()), "pf_debug_work")
-        return fl.value, by.value, list(ne)
+            self._ck(self.lib.pf_debug_work(self._h, ctypes.byref(fl), ctypes.byref(by), ne, ctypes.byref(ex), el,
+                                            _stream_ptr()), "pf_debug_work")
+        return {"flops": fl.value, "bytes": by.value, "edges": list(ne), "executed_flops": ex.value,
+                "executed_edges_per_layer": list(el)}
 
     KERNEL_CLASSES = ("encode", "build_edges", "edge_msg", "node_update", "noise_head", "step_update", "edge_msg_coop",
                       "node_update_coop")

@@ -165,3 +165,29 @@ def test_empty_and_degenerate_graphs():
     eh, ex = eng.dynamics(x_t, h_t, t)
     oh, ox = O.dynamics_forward(sd, cfg, batch, batch.prot_x, x_t, h_t, t)
     close(eh, oh); close(ex, ox)
+
+
+@pytest.mark.parametrize("name", ["dynamics_ragged.npz", "dynamics_radius.npz"])
+def test_dead_work_elimination_matches_dense_computation(name, monkeypatch):
+    """Receptive-field pruning + per-source precompute are exact: the same call with both disabled (every
+    layer dense, like the reference) gives the same outputs up to summation order."""
+    z, cfg = load(name), DYN_CASES[name]
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    outs = []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("PFDYN_NO_PRUNE", "1")
+            monkeypatch.setenv("PFDYN_NO_PRE", "1")
+        eng = engine_for(cfg, sd)
+        set_batch(eng, batch, z["prot_x"])
+        eh, ex = eng.dynamics(z["x_t"], z["h_t"], z["t"])
+        w = eng.work_detail()
+        outs.append((eh.cpu(), ex.cpu(), w))
+    (eh0, ex0, w0), (eh1, ex1, w1) = outs
+    torch.testing.assert_close(eh0, eh1, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(ex0, ex1, rtol=2e-5, atol=2e-5)
+    assert w0["flops"] == w1["flops"] and w0["executed_flops"] <= w1["executed_flops"] <= w1["flops"]
+    if cfg.pf_k > 0:                      # kNN pf edges: few active atoms, so pruning must remove work
+        assert w0["executed_flops"] < 0.8 * w1["executed_flops"]
+    assert w1["executed_edges_per_layer"][0] == sum(w1["edges"])           # dense: every edge of layer 0
