@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--timesteps", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra dense-mode kernel measurement")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel device time to stderr")
     args = ap.parse_args()
 
@@ -114,11 +115,7 @@ def main():
     # 4-wave kernel when it is pruned to the active atoms); FLOP = 136,742 per edge it actually processes
     dom = "edge_msg" if prof["edge_msg"][1] > 0 else "edge_msg_coop"
     edge_ms, edge_n = prof[dom]
-    per_step = edge_n // max(K, 1)
     l0_edges = wk["executed_edges_per_layer"][0]
-    if dom == "edge_msg_coop" and per_step > 1:
-        # both coop edge launches of a step were timed together: report the mean launch and the mean edges per launch
-        l0_edges = sum(wk["executed_edges_per_layer"]) / per_step
     edge_avg_s = edge_ms / max(edge_n, 1) * 1e-3
     edge_flops = FLOP_PER_EDGE * l0_edges
     achieved_tf = edge_flops / edge_avg_s / 1e12 if edge_avg_s > 0 else 0.0
@@ -137,7 +134,7 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_TFLOPS, "traffic": None,
                      "kernel_avg_us": edge_avg_s * 1e6, "launches_timed": edge_n, "flop_per_launch": edge_flops,
                      "note": "edge-message launches timed by HIP events inside the timed region; FLOP = 136,742 per edge "
-                             "(SURVEY 8d) x edges the launch computes (mean over the launches of a step). Outputs equal the "
+                             "(SURVEY 8d) x edges the launch computes (conv layer 0). Outputs equal the "
                              "dense reference computation; rows/edges that cannot reach the output are not computed.",
                      "whole_step": {"reference_equivalent_flop": flops, "executed_flop": wk["executed_flops"],
                                     "algorithmic_bytes": bytes_,
@@ -148,19 +145,57 @@ def main():
     }
 
     if args.breakdown and rank == 0:
-        eng.profile_enable(0xff)
+        eng.profile_enable(0x1ff)
         run(min(K, 20), False)
         torch.cuda.synchronize()
         for k, (ms, n) in eng.profile_read().items():
             print(f"[breakdown] {k:12s} {ms / max(n, 1) * 1e3:9.1f} us/launch  x{n}", file=sys.stderr)
         eng.profile_enable(0)
 
+    if rank == 0 and world == 1 and not args.no_dense_leg:
+        out["roofline"]["dense_kernel"] = dense_leg(pfa, synthetic, dev, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst,
+                                                    carr, W, min(K, 50), Nf)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, prot_x.cpu(), prot_h.cpu(), prot_ptr, pharm_ptr, pp_src, pp_dst, T)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def dense_leg(pfa, synthetic, dev, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, carr, W, K, Nf):
+    """The same steps with dead-work elimination switched off (every conv layer computed densely, like the
+    reference does): times k_edge_msg -- one wave per 32 edges over ALL edges of conv layer 0 -- the kernel that
+    dominates whenever a layer cannot be pruned (deeper nets, radius pf edges).  Extra information, outside the
+    timed region of `value`."""
+    os.environ["PFDYN_NO_PRUNE"] = "1"
+    os.environ["PFDYN_NO_PRE"] = "1"
+    try:
+        eng = pfa.PfEngine(device=dev)
+    finally:
+        del os.environ["PFDYN_NO_PRUNE"], os.environ["PFDYN_NO_PRE"]
+    eng.load_state_dict(synthetic.make_state_dict(0))
+    eng.set_batch(prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    noise = torch.randn(K + 1, Nf, 9, device=dev, generator=gen)
+    eng.sample_begin(noise[0])
+    for i in range(5):
+        eng.denoise_step(carr[W + i], noise[i + 1])
+    torch.cuda.synchronize()
+    eng.profile_enable(1 << 2)
+    t0 = time.perf_counter()
+    for i in range(K):
+        eng.denoise_step(carr[W + i], noise[i + 1])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, n = eng.profile_read()["edge_msg"]
+    wk = eng.work_detail()
+    fl = FLOP_PER_EDGE * wk["executed_edges_per_layer"][0]
+    avg = ms / max(n, 1) * 1e-3
+    B = int(prot_ptr.numel() - 1)
+    return {"kernel": "k_edge_msg", "edges_per_launch": wk["executed_edges_per_layer"][0], "kernel_avg_us": avg * 1e6,
+            "achieved": fl / avg / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg / 1e12 / PEAK_F32_TFLOPS,
+            "dense_mode_sample_steps_per_s": B * K / dt}
 
 
 def cpu_baseline(args, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, T):

@@ -156,11 +156,12 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
 /* per-kernel timing with HIP events recorded on the caller's stream around every launch of the
  * selected kernel classes (bit k of kernel_mask): 0 encode, 1 build_edges (0 and 1 share one launch unless
  * either is being timed), 2 edge_msg (one wave per tile), 3 node_update (one wave per tile), 4 noise_head,
- * 5 step_update, 6 edge_msg_coop, 7 node_update_coop (four waves per tile: launches with few tiles).  pf_profile_read synchronises `stream`, returns the summed device
+ * 5 step_update, 6 edge_msg_coop, 7 node_update_coop (four waves per tile: launches with few tiles),
+ * 8 edge_msg_coop of the last conv layer (when n_convs > 1).  pf_profile_read synchronises `stream`, returns the summed device
  * time [ms] and launch count per class since the last enable/read, and resets the counters. */
-#define PF_NUM_KERNEL_CLASSES 8
+#define PF_NUM_KERNEL_CLASSES 9
 int pf_profile_enable(pf_handle* h, uint32_t kernel_mask);
-int pf_profile_read(pf_handle* h, double* total_ms /*[8]*/, int64_t* launches /*[8]*/, pf_stream stream);
+int pf_profile_read(pf_handle* h, double* total_ms /*[9]*/, int64_t* launches /*[9]*/, pf_stream stream);
 /* work of the last dynamics call: `flops` / `bytes` = reference-equivalent (SURVEY.md 8(d) formulas on the actual
  * edge counts n_edges[4] = ff, pf, fp, pp, every layer dense); `executed_flops` / `executed_edges[n_convs]` = what the
  * kernels compute after dead-work elimination (last layer: pharm side only; layer before it: active atoms only). */

@@ -122,10 +122,10 @@ struct pf_handle {
     }
 
     // ---- optional per-kernel timing with HIP events on the caller's stream (pf_profile_*)
-    enum { K_ENCODE = 0, K_BUILD, K_EDGE, K_NODE, K_HEAD, K_STEP, K_EDGE_COOP, K_NODE_COOP, K_NUM };
+    enum { K_ENCODE = 0, K_BUILD, K_EDGE, K_NODE, K_HEAD, K_STEP, K_EDGE_COOP, K_NODE_COOP, K_EDGE_LAST, K_NUM };
     unsigned prof_mask = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[K_NUM];
-    size_t prof_used[K_NUM] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t prof_used[K_NUM] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -396,7 +396,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
         e.rbf_inv_sigma = 1.0f / ((c.rbf_dmax - 0.f) / (float)c.rbf_dim);
         // few tiles (last layer): 4 waves per tile to cut the serial latency; otherwise one wave per tile
-        if (e.ntiles <= h->coop_edge_max) { ProfScope ps(h, pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
+        if (e.ntiles <= h->coop_edge_max) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
 
         NodeParams n{};

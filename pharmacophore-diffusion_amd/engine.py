@@ -203,15 +203,15 @@ class PfEngine:
                 "executed_edges_per_layer": list(el)}
 
     KERNEL_CLASSES = ("encode", "build_edges", "edge_msg", "node_update", "noise_head", "step_update", "edge_msg_coop",
-                      "node_update_coop")
+                      "node_update_coop", "edge_msg_last")
 
     def profile_enable(self, mask: int):
         self._ck(self.lib.pf_profile_enable(self._h, mask), "pf_profile_enable")
 
     def profile_read(self):
         """{kernel class: (total device ms, launches)} since the last enable/read (synchronises)."""
-        ms = (ctypes.c_double * 8)()
-        n = (ctypes.c_int64 * 8)()
+        ms = (ctypes.c_double * 9)()
+        n = (ctypes.c_int64 * 9)()
         with torch.cuda.device(self.device):
             self._ck(self.lib.pf_profile_read(self._h, ms, n, _stream_ptr()), "pf_profile_read")
         return {k: (ms[i], n[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
