@@ -965,7 +965,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     e.w = h->d_gvp + h->msg_base(layer, 0); e.n_gvps = c.n_message_gvps;
     linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
     e.rbf_inv_sigma = 1.0f / (c.rbf_dmax / (float)c.rbf_dim);
-    pfk_edge_msg(&e, 0, s);
+    if (e.ntiles <= h->coop_edge_max) pfk_edge_msg_coop(&e, 0, s); else pfk_edge_msg(&e, 0, s);     // same choice as run_dynamics
     NodeParams n{};
     n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles; n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
     n.pp_slot = 1; n.row_ids = h->d_act_ids; n.dyn_cnt = h->d_dyn_cnt;
@@ -977,7 +977,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
         n.w[nt].upd = h->d_gvp + h->upd_base(layer, nt);
     }
     n.n_upd = c.n_update_gvps;
-    pfk_node_update(&n, 0, s);
+    if (n.ntiles <= h->coop_node_max) pfk_node_update_coop(&n, 0, s); else pfk_node_update(&n, 0, s);
     pfk_copy(h->d_h[1], ohp, Np * PF_S, s);
     pfk_copy(h->d_h[1] + Np * PF_S, ohf, Nf * PF_S, s);
     pfk_copy(h->d_v[1], ovp, Np * 48, s);

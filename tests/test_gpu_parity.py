@@ -191,3 +191,25 @@ def test_dead_work_elimination_matches_dense_computation(name, monkeypatch):
     if cfg.pf_k > 0:                      # kNN pf edges: few active atoms, so pruning must remove work
         assert w0["executed_flops"] < 0.8 * w1["executed_flops"]
     assert w1["executed_edges_per_layer"][0] == sum(w1["edges"])           # dense: every edge of layer 0
+
+
+@pytest.mark.parametrize("name", ["dynamics_ragged.npz", "dynamics_radius.npz", "dynamics_knnff.npz"])
+def test_one_wave_per_tile_kernels(name, monkeypatch):
+    """The kernels used for launches with MANY tiles (k_edge_msg / k_node_update / k_noise_head: one wave per
+    32 rows, dense layers, per-source precompute) are forced here on the small golden cases, so that both
+    kernel families are checked against the reference goldens."""
+    monkeypatch.setenv("PFDYN_COOP_EDGE_MAX", "0")
+    monkeypatch.setenv("PFDYN_COOP_NODE_MAX", "0")
+    monkeypatch.setenv("PFDYN_NO_PRUNE", "1")
+    z, cfg = load(name), DYN_CASES[name]
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch, z["prot_x"])
+    eps_h, eps_x = eng.dynamics(z["x_t"], z["h_t"], z["t"])
+    close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
+    li = int(z["conv_layer_index"])
+    hp, vp, hf, vf = eng.conv_layer(li, z["prot_x"], z["x_t"], z["conv_in_h_prot"], z["conv_in_v_prot"],
+                                    z["conv_in_h_pharm"], z["conv_in_v_pharm"])
+    close(hp, z["conv_out_h_prot"]); close(vp, z["conv_out_v_prot"])
+    close(hf, z["conv_out_h_pharm"]); close(vf, z["conv_out_v_pharm"])
