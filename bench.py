@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--n-prot", type=int, default=256)
     ap.add_argument("--n-pharm", type=int, default=6)
     ap.add_argument("--timesteps", type=int, default=500)
+    ap.add_argument("--pharm-sizes", type=str, default="", help="e.g. 3-8: ragged graphs, sizes cycling through the range (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra dense-mode kernel measurement")
@@ -69,10 +70,15 @@ def main():
     xs, hs = zip(*[synthetic.synthetic_pocket(1000 * rank + i, args.n_prot) for i in range(B)])
     prot_x, prot_h = torch.cat(xs).to(dev), torch.cat(hs).to(dev)
     prot_ptr = torch.arange(B + 1, dtype=torch.int64) * args.n_prot
-    pharm_ptr = torch.arange(B + 1, dtype=torch.int64) * args.n_pharm
+    if args.pharm_sizes:
+        lo, hi = (int(v) for v in args.pharm_sizes.split("-"))
+        sizes = [lo + (i % (hi - lo + 1)) for i in range(B)]
+    else:
+        sizes = [args.n_pharm] * B
+    pharm_ptr = torch.tensor([0] + list(__import__("itertools").accumulate(sizes)), dtype=torch.int64)
     pp_src, pp_dst = eng.build_pp_edges(prot_x, prot_ptr)
     eng.set_batch(prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst)
-    Nf = B * args.n_pharm
+    Nf = int(pharm_ptr[-1])
     sched = schedule.PredefinedNoiseSchedule('polynomial_2', T, 1e-5)
     coef = schedule.step_coefficients(sched.gamma, T)
     order = [(W + K - 1 - i) % T for i in range(W + K)]        # the last W+K steps of the T-step schedule (s = W+K-1 ... 0):
@@ -125,8 +131,10 @@ def main():
         "value": world * B * K / dt, "unit": "sample-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE config 2: 256-atom pocket, 6 centers, T=500 schedule, batch=32 per GPU, dev.yml network",
-                   "batch_per_gpu": B, "n_prot": args.n_prot, "n_pharm": args.n_pharm, "T": T,
+        "config": {"workload": ("BASELINE config 2: 256-atom pocket, 6 centers, T=500 schedule, batch=32 per GPU, dev.yml network"
+                                if (B, args.n_prot, args.n_pharm, args.pharm_sizes) == (32, 256, 6, "") else
+                                f"custom: {args.n_prot}-atom pockets, centers {args.pharm_sizes or args.n_pharm}, batch={B} per GPU, dev.yml network"),
+                   "batch_per_gpu": B, "n_prot": args.n_prot, "n_pharm": args.pharm_sizes or args.n_pharm, "T": T,
                    "edges_per_step": {"ff": ne[0], "pf": ne[1], "fp": ne[2], "pp": ne[3]},
                    "edges_computed_per_layer": wk["executed_edges_per_layer"],
                    "parallelism": f"graphs sharded over {world} GPU(s), no data-path collective"},

@@ -22,14 +22,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef PF_CH
 #define PF_CH 4
 #endif
-#ifdef PF_ABL_WSAME
-#define PF_WIDX(x) ((x) & 3)
-#else
-#define PF_WIDX(x) (x)
-#endif
-#ifndef PF_SGB
-#define PF_SGB 0
-#endif
 #ifndef PF_WPS_EDGE
 #define PF_WPS_EDGE 2
 #endif
@@ -138,13 +130,13 @@ __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64],
     fragA abuf[2][CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i)
-        if (KS0 + i < NKS) abuf[0][i] = ap[PF_WIDX(i) * 64];
+        if (KS0 + i < NKS) abuf[0][i] = ap[i * 64];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         if (c + 1 < NCH) {
 #pragma unroll
             for (int i = 0; i < CH; ++i)
-                if (KS0 + (c + 1) * CH + i < NKS) abuf[(c + 1) & 1][i] = ap[PF_WIDX((c + 1) * CH + i) * 64];
+                if (KS0 + (c + 1) * CH + i < NKS) abuf[(c + 1) & 1][i] = ap[((c + 1) * CH + i) * 64];
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
@@ -1196,7 +1188,16 @@ __device__ __forceinline__ void emit_prot_side(const BuildParams& p, const int g
                 const int d0 = reg_pa + (int)(o >> 28), s0 = in_start1[p0 + c];
                 in_start2[p0 + c] = d0;
                 in_cnt2[p0 + c] = deg;
-                for (int i = 0; i < deg; ++i) { p.esrc[d0 + i] = p.esrc[s0 + i]; p.edst[d0 + i] = p0 + c; }
+                // eight loads in flight, then eight stores (source and destination alias the same array, so a
+                // plain copy loop would serialise on memory latency)
+                for (int i = 0; i < deg; i += 8) {
+                    int tmp[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) tmp[k] = p.esrc[s0 + min(i + k, deg - 1)];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (i + k < deg) { p.esrc[d0 + i + k] = tmp[k]; p.edst[d0 + i + k] = p0 + c; }
+                }
             }
         }
         base += tot;
