@@ -875,9 +875,6 @@ __device__ __forceinline__ void node_tile_coop(const NodeParams& p, const NodeTi
                 my_c = p.in_cnt[slot * p.N + node_of(jj)];
             }
         }
-#ifdef PF_ABL_NOAGG
-        my_c = 0;
-#endif
         // software pipeline over the segments: the partial rows of segment g+1 are in flight while segment g is
         // summed.  A segment's rows are the tails of the (tile, destination) runs inside [st, st+c): slot
         // min(e|31, st+c-1), then the next tile ... ; two rows cover an in-degree of up to 33.
@@ -968,11 +965,7 @@ __device__ __forceinline__ void node_tile_coop(const NodeParams& p, const NodeTi
     float V1[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) V1[q] = Vc[q];
-#ifndef PF_ABL_NOGVP
     gvp_coop_chain1(nw.upd, p.n_upd, Wupd, s, V1, lane, wv, L);     // its barriers also publish res
-#else
-    __syncthreads();
-#endif
 #pragma unroll
     for (int q = 0; q < 64; ++q) s[q] += res[q][lane];
 #pragma unroll

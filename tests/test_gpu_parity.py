@@ -213,3 +213,63 @@ def test_one_wave_per_tile_kernels(name, monkeypatch):
                                     z["conv_in_h_pharm"], z["conv_in_v_pharm"])
     close(hp, z["conv_out_h_prot"]); close(vp, z["conv_out_v_prot"])
     close(hf, z["conv_out_h_pharm"]); close(vf, z["conv_out_v_pharm"])
+
+
+def _rand_inputs(batch, seed, pharm_nf=6, scale=3.0):
+    gen = torch.Generator().manual_seed(seed)
+    nf = int(batch.pharm_ptr[-1])
+    return (scale * torch.randn(nf, 3, generator=gen), torch.randn(nf, pharm_nf, generator=gen),
+            torch.rand(batch.batch_size, generator=gen))
+
+
+def test_large_graphs_high_degree_many_centers():
+    """Edge cases of the tile machinery: 600-atom pockets (kNN candidates not register-cached), a 6 A pp cutoff
+    (in-degree > 33: a destination's messages span more than two tiles), 40 centers in one graph (two pharm tiles,
+    ff edges over many tiles), against the oracle."""
+    cfg = O.DynamicsConfig(cutoff_pp=6.0)
+    sd = O.make_state_dict(cfg, 3)
+    batch = O.synthetic_batch([31, 32], 600, [40, 7], cfg)
+    deg = torch.bincount(batch.pp_dst, minlength=1200)
+    assert int(deg.max()) > 33
+    x_t, h_t, t = _rand_inputs(batch, 5, scale=5.0)
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    eh, ex = eng.dynamics(x_t, h_t, t)
+    oh, ox, edges = O.dynamics_forward(sd, cfg, batch, batch.prot_x, x_t, h_t, t, return_edges=True)
+    for i, et in enumerate(O.ETYPES):
+        s, d = eng.get_edges(i)
+        assert edge_set(s, d) == edge_set(*edges[et]), et
+    close(eh, oh, 5e-4, 5e-4); close(ex, ox, 5e-4, 5e-4)
+
+
+@pytest.mark.parametrize("pf_k", [5, 0])
+def test_per_graph_message_norm(pf_k):
+    """message_norm = 0: sum reducer divided by (edges into the node type)/(nodes of the type) + 1 per graph
+    (gvp.py:504-507), counted by the true graph of each edge."""
+    cfg = O.DynamicsConfig(message_norm=0, pf_k=pf_k)
+    sd = O.make_state_dict(cfg, 4)
+    batch = O.synthetic_batch([41, 42, 43], 64, [4, 6, 3], cfg)
+    x_t, h_t, t = _rand_inputs(batch, 6)
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    eh, ex = eng.dynamics(x_t, h_t, t)
+    oh, ox = O.dynamics_forward(sd, cfg, batch, batch.prot_x, x_t, h_t, t)
+    close(eh, oh); close(ex, ox)
+
+
+def test_endpoint_parameterisation_step():
+    """sample_p_zs_given_zt with endpoint_param_coord / endpoint_param_feat (pharmacodiff.py:413-420)."""
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    batch = O.synthetic_batch([51, 52], 64, [4, 5], cfg)
+    T = 50
+    gen = torch.Generator().manual_seed(8)
+    noise = torch.randn(3, int(batch.pharm_ptr[-1]), 9, generator=gen)
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+    arr = eng.coef_array(coef, reversed(range(T)))
+    x0, h0 = eng.sample(arr, 2, noise, ep_coord=True, ep_feat=True)
+    ox, oh = O.sample_given_receptor(sd, cfg, batch, T, 1e-5, noise, n_steps=2, endpoint_param_coord=True,
+                                     endpoint_param_feat=True)
+    close(x0, ox, 1e-3, 1e-3); close(h0, oh, 1e-3, 1e-3)
