@@ -139,7 +139,11 @@ def main():
                    "edges_computed_per_layer": wk["executed_edges_per_layer"],
                    "parallelism": f"graphs sharded over {world} GPU(s), no data-path collective"},
         "roofline": {"bound": "mfma", "kernel": "k_" + dom, "achieved": achieved_tf, "peak": PEAK_F32_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_TFLOPS,
+                     # HBM-side bytes per launch of that kernel from the committed rocprofv3 PMC passes
+                     # (profiles/r01/c_pruned_pmc_hbm.csv: 2 x FETCH_SIZE [gfx950 wide-read correction] + WRITE_SIZE);
+                     # PMC counters cannot be collected from inside this process
+                     "traffic": (2 * 5812.7 + 940.5) * 1024 if dom == "edge_msg_coop" else (2 * 15028.2 + 7258.8) * 1024,
                      "kernel_avg_us": edge_avg_s * 1e6, "launches_timed": edge_n, "flop_per_launch": edge_flops,
                      "note": "edge-message launches timed by HIP events inside the timed region; FLOP = 136,742 per edge "
                              "(SURVEY 8d) x edges the launch computes (conv layer 0). Outputs equal the "

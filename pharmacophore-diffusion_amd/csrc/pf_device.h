@@ -48,7 +48,10 @@ struct GvpW {              // packed weights of one GVP (device pointers)
     pf_gcf a_wh;           // [8(+1)][64 lanes]      A fragments of Wh^T (vector channel, R-layout k order)
     pf_gcf a_wu;           // [8(+1)][64 lanes]      A fragments of Wu^T
     pf_gcf a_main;         // [NKS][64 lanes][NMO]   A fragments of to_feats_out
-    pf_gcf a_main_c;       // [NMO][NKS][64 lanes]   the same fragments, one output tile contiguous (4-wave kernels)
+    pf_gcf a_main_c;       // [NMO][NKS/4][64 lanes][4]  the same fragments per output tile, four k-steps per lane (4-wave kernels)
+    pf_gcf a_gate_c;       // [NMO][4][64 lanes][4]      gate fragments of the wave that owns output tile mo
+    pf_gcf a_wh_c;         // [3][64 lanes][4]           a_wh / a_wu, four k-steps per lane (zero padded to 12)
+    pf_gcf a_wu_c;
     pf_gcf b_main;         // [2 halves][NMO*16]     bias in F-layout
     pf_gcf a_gate;         // [NMO*16][64 lanes]     A fragments of scalar_to_vector_gates (rows 0..VO-1)
     pf_gcf b_gate;         // [2 halves][8]          gate bias in R-layout

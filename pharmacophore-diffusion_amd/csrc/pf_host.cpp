@@ -228,7 +228,7 @@ static size_t push(std::vector<float>& w, const std::vector<float>& v) {
     return off;
 }
 
-struct GvpOff { size_t wh, wu, a_main, a_main_c, b_main, a_gate, b_gate; };
+struct GvpOff { size_t wh, wu, wh_c, wu_c, a_main, a_main_c, b_main, a_gate, a_gate_c, b_gate; };
 
 static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
     const int H = std::max(g.vi, g.vo);
@@ -259,6 +259,15 @@ static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
             }
         o.wh = push(h->h_w, awh);
         o.wu = push(h->h_w, awu);
+        // four k-steps per lane for the 4-wave kernels: [t/4][lane][t%4]
+        std::vector<float> c1((size_t)3 * 64 * 4, 0.f), c2((size_t)3 * 64 * 4, 0.f);
+        for (int t = 0; t < NVK; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+                c1[((size_t)(t / 4) * 64 + lane) * 4 + t % 4] = awh[(size_t)t * 64 + lane];
+                c2[((size_t)(t / 4) * 64 + lane) * 4 + t % 4] = awu[(size_t)t * 64 + lane];
+            }
+        o.wh_c = push(h->h_w, c1);
+        o.wu_c = push(h->h_w, c2);
     }
     std::vector<float> a((size_t)NKS * 64 * NMO, 0.f);
     for (int ks = 0; ks < NKS; ++ks)
@@ -278,12 +287,13 @@ static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
             }
         }
     o.a_main = push(h->h_w, a);
-    {   // the same fragments with one output tile contiguous: [mo][ks][lane]
-        std::vector<float> ac(a.size());
+    {   // the same fragments per output tile, four k-steps per lane: [mo][ks/4][lane][ks%4]
+        const int NKS4 = (NKS + 3) / 4;
+        std::vector<float> ac((size_t)NMO * NKS4 * 64 * 4, 0.f);
         for (int ks = 0; ks < NKS; ++ks)
             for (int lane = 0; lane < 64; ++lane)
                 for (int mo = 0; mo < NMO; ++mo)
-                    ac[((size_t)mo * NKS + ks) * 64 + lane] = a[((size_t)ks * 64 + lane) * NMO + mo];
+                    ac[(((size_t)mo * NKS4 + ks / 4) * 64 + lane) * 4 + ks % 4] = a[((size_t)ks * 64 + lane) * NMO + mo];
         o.a_main_c = push(h->h_w, ac);
     }
     std::vector<float> b((size_t)2 * NMO * 16);
@@ -299,6 +309,14 @@ static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
             ag[(size_t)ks * 64 + lane] = i < g.vo ? G.data[(size_t)i * g.so + k] : 0.f;      // rows 0..vo-1 = gates
         }
     o.a_gate = push(h->h_w, ag);
+    {   // gate fragments of the wave owning output tile mo: k-steps 16*mo .. 16*mo+15 as [mo][r/4][lane][r%4]
+        std::vector<float> agc((size_t)NMO * 4 * 64 * 4, 0.f);
+        for (int mo = 0; mo < NMO; ++mo)
+            for (int r = 0; r < 16; ++r)
+                for (int lane = 0; lane < 64; ++lane)
+                    agc[(((size_t)mo * 4 + r / 4) * 64 + lane) * 4 + r % 4] = ag[(size_t)(mo * 16 + r) * 64 + lane];
+        o.a_gate_c = push(h->h_w, agc);
+    }
     {   // gate bias in R-layout: half hl, register t <-> gate rho(t,hl)
         const std::vector<float>& bgv = h->raw[g.prefix + "scalar_to_vector_gates.bias"].data;
         std::vector<float> bg(16, 0.f);
@@ -586,6 +604,7 @@ int pf_commit_weights(pf_handle* h) {
     for (const GvpOff& o : offs) {
         GvpW g;
         g.a_wh = h->d_w + o.wh; g.a_wu = h->d_w + o.wu; g.a_main = h->d_w + o.a_main; g.a_main_c = h->d_w + o.a_main_c; g.b_main = h->d_w + o.b_main;
+        g.a_gate_c = h->d_w + o.a_gate_c; g.a_wh_c = h->d_w + o.wh_c; g.a_wu_c = h->d_w + o.wu_c;
         g.a_gate = h->d_w + o.a_gate; g.b_gate = h->d_w + o.b_gate;
         h->h_gvp.push_back(g);
     }

@@ -577,13 +577,32 @@ __global__ __launch_bounds__(64, PF_WPS_HEAD) void k_noise_head(const HeadParams
 // of the weights.  All waves keep a full copy of the scalar state (F-layout); wave c keeps
 // coordinate c of the vector state (R-layout, 8 registers).
 // ---------------------------------------------------------------------------------------------
+// In-kernel cycle stamps (diagnostic builds only: -DPF_STAMPS; no stamp executes in the product build).
+#ifdef PF_STAMPS
+__device__ unsigned long long* g_pf_stamps = nullptr;
+#define PF_STAMP(L) pf_stamp(L, lane, wv)
+#else
+#define PF_STAMP(L)
+#endif
 struct __attribute__((aligned(16))) CoopLds {
     float vh[3][9][64];     // Vh of coordinate c, k-step t          (for sh = |Vh|)
     float so[4][16][64];    // SiLU output tile of wave w             (next layer's input)
     float pg[4][8][64];     // partial gates of wave w
     float vx[3][8][64];     // vector output of coordinate c          (stores / norms)
     float agg[32][177];     // aggregated messages per node (stride 177: conflict-free column reads)
+#ifdef PF_STAMPS
+    int scnt[4];
+#endif
 };
+#ifdef PF_STAMPS
+__device__ __forceinline__ void pf_stamp(CoopLds& L, const int lane, const int wv) {
+    if (lane == 0 && g_pf_stamps) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        const int k = L.scnt[wv]++;
+        if (k < 64) g_pf_stamps[((size_t)blockIdx.x * 4 + wv) * 64 + k] = t;
+    }
+}
+#endif
 
 // One wave's share of a GVP's weights, held in registers: 9+9 vector fragments, <=81 fragments of its output
 // tile, 16 gate fragments and the biases (~130 VGPRs).  Loading is separated from computing so that a chain
@@ -593,21 +612,26 @@ template <int VI, int NEXTRA>
 struct CoopW {
     static constexpr int NVK = 8 + (VI == 17 ? 1 : 0);
     static constexpr int NKS = 64 + NEXTRA / 2 + NVK;
-    float awh[NVK], awu[NVK], am[NKS], ag[16];
+    static constexpr int NKS4 = (NKS + 3) / 4;
+    // fragments are packed four k-steps per lane ([k/4][lane][4]): one coalesced 16-byte load per lane and group
+    f32x4 awh[3], awu[3], am[NKS4], ag[4];
     f32x4 bm[4], bg[2];
 };
 template <int VI, int NEXTRA, int NMO>
 __device__ __forceinline__ void gvp_coop_load(const GvpW w, const int lane, const int wv, CoopW<VI, NEXTRA>& W) {
-    constexpr int NVK = CoopW<VI, NEXTRA>::NVK, NKS = CoopW<VI, NEXTRA>::NKS;
+    constexpr int NKS4 = CoopW<VI, NEXTRA>::NKS4;
     const int hl = lane >> 5;
     const int wm = wv < NMO ? wv : 0;
+    const f32x4 PF_AS1* pwh = reinterpret_cast<const f32x4 PF_AS1*>(w.a_wh_c) + lane;
+    const f32x4 PF_AS1* pwu = reinterpret_cast<const f32x4 PF_AS1*>(w.a_wu_c) + lane;
 #pragma unroll
-    for (int t = 0; t < NVK; ++t) { W.awh[t] = w.a_wh[t * 64 + lane]; W.awu[t] = w.a_wu[t * 64 + lane]; }
-    pf_gcf ap = w.a_main_c + (size_t)wm * NKS * 64 + lane;
+    for (int q = 0; q < 3; ++q) { W.awh[q] = pwh[q * 64]; W.awu[q] = pwu[q * 64]; }
+    const f32x4 PF_AS1* ap = reinterpret_cast<const f32x4 PF_AS1*>(w.a_main_c) + (size_t)wm * NKS4 * 64 + lane;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) W.am[ks] = ap[ks * 64];
+    for (int q = 0; q < NKS4; ++q) W.am[q] = ap[q * 64];
+    const f32x4 PF_AS1* gp = reinterpret_cast<const f32x4 PF_AS1*>(w.a_gate_c) + (size_t)wm * 4 * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) W.ag[r] = w.a_gate[(wm * 16 + r) * 64 + lane];
+    for (int q = 0; q < 4; ++q) W.ag[q] = gp[q * 64];
     const f32x4 PF_AS1* bp = reinterpret_cast<const f32x4 PF_AS1*>(w.b_main + hl * (NMO * 16) + wm * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) W.bm[q] = bp[q];
@@ -621,6 +645,7 @@ __device__ __forceinline__ void gvp_coop_compute(const CoopW<VI, NEXTRA>& W, con
                                                  float (&Vc_out)[8], const int lane, const int wv, CoopLds& L) {
     constexpr int NVK = CoopW<VI, NEXTRA>::NVK;
     constexpr int KS_A = 64 + NEXTRA / 2;            // k-steps that do not need sh
+    PF_STAMP(L);      // 0: GVP start
     // (1) vector products of coordinate wv on the matrix cores
     float Vu[8];
 #pragma unroll
@@ -630,14 +655,15 @@ __device__ __forceinline__ void gvp_coop_compute(const CoopW<VI, NEXTRA>& W, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) { vh[r] = 0.f; vu[r] = 0.f; }
 #pragma unroll
-        for (int t = VROW0 ? 8 : 0; t < NVK; ++t) vh = MFMA(W.awh[t], t < 8 ? Vc[t < 8 ? t : 0] : xhat_c, vh);
+        for (int t = VROW0 ? 8 : 0; t < NVK; ++t) vh = MFMA(W.awh[t >> 2][t & 3], t < 8 ? Vc[t < 8 ? t : 0] : xhat_c, vh);
 #pragma unroll
         for (int t = 0; t < NVK; ++t) L.vh[wv][t][lane] = vh[t];
 #pragma unroll
-        for (int t = 0; t < NVK; ++t) vu = MFMA(W.awu[t], vh[t], vu);
+        for (int t = 0; t < NVK; ++t) vu = MFMA(W.awu[t >> 2][t & 3], vh[t], vu);
 #pragma unroll
         for (int t = 0; t < 8; ++t) Vu[t] = vu[t];
     }
+    PF_STAMP(L);      // 1: vector products issued
     // (2) this wave's output tile of the scalar Linear: the k-steps that do not depend on sh
     f32x16 acc;
 #pragma unroll
@@ -647,29 +673,33 @@ __device__ __forceinline__ void gvp_coop_compute(const CoopW<VI, NEXTRA>& W, con
     if (wv < NMO) {
 #pragma unroll
         for (int ks = 0; ks < KS_A; ++ks)
-            acc = MFMA(W.am[ks], ks < 64 ? s_in[ks < 64 ? ks : 0] : ext[ks >= 64 ? ks - 64 : 0], acc);
+            acc = MFMA(W.am[ks >> 2][ks & 3], ks < 64 ? s_in[ks < 64 ? ks : 0] : ext[ks >= 64 ? ks - 64 : 0], acc);
     }
+    PF_STAMP(L);      // 2: main k-steps issued
     __syncthreads();                                  // B1: every Vh is in LDS
+    PF_STAMP(L);      // 3: past B1
     // (3) sh = |Vh| for this lane's channels, (4) the sh k-steps, SiLU, partial gates
     if (wv < NMO) {
 #pragma unroll
         for (int t = 0; t < NVK; ++t) {
             const float x = L.vh[0][t][lane], y = L.vh[1][t][lane], z = L.vh[2][t][lane];
-            acc = MFMA(W.am[KS_A + t], sqrtf_(fmaxf(x * x + y * y + z * z, 1e-8f)), acc);
+            acc = MFMA(W.am[(KS_A + t) >> 2][(KS_A + t) & 3], sqrtf_(fmaxf(x * x + y * y + z * z, 1e-8f)), acc);
         }
         f32x16 g;
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] = 0.f;
+        // all 16 activations first (VALU + one LDS store each), then the 16 gate MFMAs back to back
+        float so[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float so = siluf_(acc[r]);
-            L.so[wv][r][lane] = so;
-            g = MFMA(W.ag[r], so, g);
-        }
+        for (int r = 0; r < 16; ++r) { so[r] = siluf_(acc[r]); L.so[wv][r][lane] = so[r]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g = MFMA(W.ag[r >> 2][r & 3], so[r], g);
 #pragma unroll
         for (int t = 0; t < 8; ++t) L.pg[wv][t][lane] = g[t];
     }
+    PF_STAMP(L);      // 4: sh + SiLU + gates issued
     __syncthreads();                                  // B2: output tiles and partial gates are in LDS
+    PF_STAMP(L);      // 5: past B2
     // (5) assemble the full scalar output; gate this wave's coordinate
 #pragma unroll
     for (int mt = 0; mt < NMO; ++mt)
@@ -1001,6 +1031,10 @@ __device__ __forceinline__ void head_tile_coop(const HeadParams& p, const NodeTi
     const int j = lane & 31, hl = lane >> 5;
     const bool live = j < t.n;
     const int n = t.n0 + min(j, t.n - 1);
+#ifdef PF_STAMPS
+    if (lane == 0) L.scnt[wv] = 0;
+#endif
+    PF_STAMP(L);      // kernel start
     const GvpW PF_AS1* gv = (const GvpW PF_AS1*)p.gvps;
     CoopW<16, 0> Wh0;
     if (p.n_gvps > 1) gvp_coop_load<16, 0, 4>(gv[0], lane, wv, Wh0);
@@ -1016,6 +1050,7 @@ __device__ __forceinline__ void head_tile_coop(const HeadParams& p, const NodeTi
     if (p.n_gvps > 1) gvp_coop_chain(gv, p.n_gvps - 1, Wh0, s1, V1, lane, wv, L);
     float so[32], Vo[8];
     gvp_coop_compute<16, 0, 1, 2, false, false>(Wlast, s1, nullptr, V1, 0.f, so, Vo, lane, wv, L);
+    PF_STAMP(L);      // chain done
     const int f = n - p.node_base;
     if (wv == 3) {
         // to_scalar_output: Linear(64 -> pharm_nf), rows 0..5 of a 32-row tile
@@ -1424,12 +1459,12 @@ __device__ __forceinline__ void encode_pre_tile(const PreParams& p, const int ti
 #pragma unroll
         for (int q = 0; q < 4; ++q) { const f32x4 b4 = bp[q]; pa[4 * q] = b4[0]; pa[4 * q + 1] = b4[1]; pa[4 * q + 2] = b4[2]; pa[4 * q + 3] = b4[3]; }
     }
-    pf_gcf ap = p.pre_w.a_main_c + (size_t)wv * p.pre_nks * 64 + lane;
-    float a[64];
+    const f32x4 PF_AS1* ap = reinterpret_cast<const f32x4 PF_AS1*>(p.pre_w.a_main_c) + (size_t)wv * ((p.pre_nks + 3) / 4) * 64 + lane;
+    f32x4 a[16];
 #pragma unroll
-    for (int ks = 0; ks < 64; ++ks) a[ks] = ap[ks * 64];
+    for (int q = 0; q < 16; ++q) a[q] = ap[q * 64];
 #pragma unroll
-    for (int ks = 0; ks < 64; ++ks) pa = MFMA(a[ks], s[ks], pa);
+    for (int ks = 0; ks < 64; ++ks) pa = MFMA(a[ks >> 2][ks & 3], s[ks], pa);
     if (live) {
         // wave w stores tile w (features 32w .. 32w+31) of both rows
         f32x4* ph = reinterpret_cast<f32x4*>(p.h_out + (size_t)n * PF_S + 32 * wv + 4 * hl);
@@ -1603,6 +1638,9 @@ __global__ __launch_bounds__(256) void k_pp_radius(const float4* xn, const int* 
 // launch helpers (called from pf_host.cpp)
 // ---------------------------------------------------------------------------------------------
 extern "C" {
+#ifdef PF_STAMPS
+int pfk_set_stamp_buffer(unsigned long long* dev) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pf_stamps), &dev, sizeof(dev)); }
+#endif
 void pfk_edge_msg_coop(const EdgeParams* p, int layer0, hipStream_t s) {
     if (p->ntiles == 0) return;
     if (layer0) hipLaunchKernelGGL(k_edge_msg_coop<true>, dim3(p->ntiles), dim3(256), 0, s, *p);
