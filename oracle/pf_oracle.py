@@ -289,10 +289,13 @@ def _aggregate(msg, dst, n_dst: int, mean: bool):
 
 
 def conv_layer(sd, prefix: str, cfg: DynamicsConfig, node_feats, edges, batch: PocketBatch,
-               edge_counts=None):
-    """GVPMultiEdgeConv.forward, gvp.py:459-538 (eval mode: dropout = identity).
+               edge_counts=None, dropout=None):
+    """GVPMultiEdgeConv.forward, gvp.py:459-538.
 
-    node_feats: {ntype: (h [N,S], x [N,3], v [N,V,3])};  edges: {etype: (src, dst)}."""
+    node_feats: {ntype: (h [N,S], x [N,3], v [N,V,3])};  edges: {etype: (src, dst)}.
+    dropout: None (eval mode: identity) or {ntype: (msg_s [N,S], msg_v [N,V], res_s [N,S],
+    res_v [N,V])} multiplicative masks with entries in {0, 1/(1-p)} -- the draws of GVPDropout
+    (gvp.py:118-149) at its two call sites (gvp.py:518,529), injected."""
     mean = cfg.message_norm == "mean"
     agg_s = {nt: None for nt in ("pharm", "prot")}
     agg_v = {nt: None for nt in ("pharm", "prot")}
@@ -333,10 +336,16 @@ def conv_layer(sd, prefix: str, cfg: DynamicsConfig, node_feats, edges, batch: P
         sm = agg_s[nt] / norm_value                         # gvp.py:512
         nv = norm_value.unsqueeze(-1) if isinstance(norm_value, torch.Tensor) else norm_value
         vm = agg_v[nt] / nv                                 # gvp.py:517
+        if dropout is not None:                             # gvp.py:518
+            sm = sm * dropout[nt][0]
+            vm = vm * dropout[nt][1].unsqueeze(-1)
         h1 = h + sm
         v1 = v + vm
         h1, v1 = gvp_layernorm(sd, f"{prefix}message_layer_norms.{nt}.", h1, v1)   # gvp.py:521
         rs, rv = gvp_chain(sd, f"{prefix}node_update_fns.{nt}.", cfg.n_update_gvps, h1, v1)  # :524
+        if dropout is not None:                             # gvp.py:529
+            rs = rs * dropout[nt][2]
+            rv = rv * dropout[nt][3].unsqueeze(-1)
         h2 = h1 + rs
         v2 = v1 + rv
         h2, v2 = gvp_layernorm(sd, f"{prefix}update_layer_norms.{nt}.", h2, v2)    # gvp.py:532
@@ -367,11 +376,12 @@ def _edges_per_graph(node_idx, ptr):
 
 
 def dynamics_forward(sd, cfg: DynamicsConfig, batch: PocketBatch, prot_x, pharm_x, pharm_h, t,
-                     prefix: str = "dynamics.", return_edges: bool = False):
+                     prefix: str = "dynamics.", return_edges: bool = False, dropout=None):
     """PharmRecDynamicsGVP.forward, dynamics_gvp.py:131-185.
 
     prot_x: current (COM-shifted) protein coordinates [Np,3]; pharm_x/pharm_h: x_t, h_t;
-    t: [B] fp32.  Returns (eps_h [Nf,pharm_nf], eps_x [Nf,3])."""
+    t: [B] fp32.  Returns (eps_h [Nf,pharm_nf], eps_x [Nf,3]).  dropout: None or one
+    conv_layer mask dict per layer (training mode)."""
     bidx = batch.batch_idxs()
     hp = encode(sd, prefix + "pharm_encoder.", pharm_h, t[bidx["pharm"]])
     hr = encode(sd, prefix + "prot_encoder.", batch.prot_h, t[bidx["prot"]])
@@ -394,7 +404,7 @@ def dynamics_forward(sd, cfg: DynamicsConfig, batch: PocketBatch, prot_x, pharm_
         }
     for i in range(cfg.n_convs):
         node = conv_layer(sd, f"{prefix}noise_predictor.conv_layers.{i}.", cfg, node, edges, batch,
-                          edge_counts)
+                          edge_counts, None if dropout is None else dropout[i])
     hp, _, vp = node["pharm"]
     eps_h, eps_x = noise_head(sd, prefix + "noise_predictor.noise_predictor.", cfg, hp, vp)
     if return_edges:
@@ -562,7 +572,7 @@ def sample_given_receptor(sd, cfg, batch: PocketBatch, n_timesteps: int, precisi
 def training_forward(sd, cfg, batch: PocketBatch, pharm_x0, pharm_h0, n_timesteps: int,
                      precision: float, t_int: torch.Tensor, eps_h: torch.Tensor, eps_x: torch.Tensor,
                      phase: str = "train", pharm_feat_norm_constant: float = 1.0,
-                     weighted_loss: bool = False, remove_com: bool = True):
+                     weighted_loss: bool = False, remove_com: bool = True, dropout=None):
     """PharmacophoreDiff.forward, pharmacodiff.py:162-243 (epsilon parameterisation), with the
     random draws (t_int: :185, eps_h then eps_x: :189-192) injected."""
     bidx = batch.batch_idxs()
@@ -581,7 +591,7 @@ def training_forward(sd, cfg, batch: PocketBatch, pharm_x0, pharm_h0, n_timestep
         c = segment_mean(x_t, batch.pharm_ptr)
         x_t = x_t - c[bidx["pharm"]]
         prot_x = prot_x - c[bidx["prot"]]
-    h_dyn, x_dyn = dynamics_forward(sd, cfg, batch, prot_x, x_t, h_t, t)        # :199
+    h_dyn, x_dyn = dynamics_forward(sd, cfg, batch, prot_x, x_t, h_t, t, dropout=dropout)   # :199
     h_loss = (eps_h - h_dyn).square().sum(dim=1)                                # :208
     h_0_pred = (h_t - sigma_t * h_dyn) / alpha_t                                # :209
     x_loss = (eps_x - x_dyn).square().sum(dim=1)                                # :217
@@ -604,6 +614,34 @@ def training_forward(sd, cfg, batch: PocketBatch, pharm_x0, pharm_h0, n_timestep
         phase + " weighted accuracy": (weight_metric * hit).mean(),
     }
     return losses, metrics
+
+
+def training_grads(sd, cfg, batch: PocketBatch, pharm_x0, pharm_h0, n_timesteps: int, precision: float,
+                   t_int, eps_h, eps_x, dropout=None, weighted_loss: bool = False):
+    """One training_step's loss and gradients (pharmacodiff.py:265-276: total loss = pos loss +
+    feat loss; backward through PharmacophoreDiff.forward), by torch autograd over the
+    restatement above.  Returns (losses, metrics, {key: dLoss/dparam})."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    with torch.enable_grad():
+        losses, metrics = training_forward(leaf, cfg, batch, pharm_x0, pharm_h0, n_timesteps, precision,
+                                           t_int, eps_h, eps_x, weighted_loss=weighted_loss, dropout=dropout)
+        total = losses["train pos loss"] + losses["train feat loss"]
+        total.backward()
+    grads = {k: (torch.zeros_like(v) if v.grad is None else v.grad.detach()) for k, v in leaf.items()}
+    return ({k: v.detach() for k, v in losses.items()}, {k: v.detach() for k, v in metrics.items()}, grads)
+
+
+def dropout_masks(cfg: DynamicsConfig, n_pharm: int, n_prot: int, p: float, seed: int):
+    """Seeded {0, 1/(1-p)} masks in the layout conv_layer takes (one dict per layer)."""
+    g = torch.Generator().manual_seed(seed)
+    S, V = cfg.n_hidden_scalars, cfg.vector_size
+    out = []
+    for _ in range(cfg.n_convs):
+        d = {}
+        for nt, n in (("pharm", n_pharm), ("prot", n_prot)):
+            d[nt] = tuple((torch.rand(n, w, generator=g) >= p).float() / (1.0 - p) for w in (S, V, S, V))
+        out.append(d)
+    return out
 
 
 # --------------------------------------------------------------------------------------

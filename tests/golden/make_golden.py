@@ -266,6 +266,71 @@ def golden_train_forward(cfg, name, seeds, n_prot, n_pharm, T=100, wseed=0, rsee
     npz(name, **out)
 
 
+def golden_train_grads(cfg, name, seeds, n_prot, n_pharm, T=100, wseed=0, rseed=7, p_drop=0.1,
+                       weighted_loss=False):
+    """Reference training_step in train() mode: losses and d(total loss)/d(param) for every
+    dynamics parameter, with the GVPDropout draws recovered through forward hooks (mask =
+    output != 0; entries whose input is exactly 0 carry no information and are recorded as kept)."""
+    m, sd = ref_model(cfg, T, 1e-5, seed=wseed)
+    m.weighted_loss = weighted_loss
+    m.train()
+    batch = O.synthetic_batch(seeds, n_prot, n_pharm, cfg)
+    Nf = int(batch.pharm_ptr[-1])
+    Np = int(batch.prot_ptr[-1])
+    B = batch.batch_size
+    gen = torch.Generator().manual_seed(4)
+    x0 = 3.0 * torch.randn(Nf, 3, generator=gen)
+    types = torch.randint(0, cfg.pharm_nf, (Nf,), generator=gen)
+    h0 = torch.nn.functional.one_hot(types, cfg.pharm_nf).float()
+    g = ref_graph(batch, x0, h0, cfg.pharm_nf)
+    torch.manual_seed(rseed)
+    t_int = torch.randint(0, T, size=(B,))
+    eps_h = torch.randn(Nf, cfg.pharm_nf)
+    eps_x = torch.randn(Nf, 3)
+
+    calls = []          # (layer index, mask_s, mask_v) in call order
+
+    def mk_hook(layer):
+        def hook(mod, inputs, output):
+            fi, vi = inputs
+            fo, vo = output
+            ms = torch.where(fi != 0, (fo != 0).float(), torch.ones_like(fi)) / (1.0 - p_drop)
+            vin = vi.abs().sum(-1)
+            mv = torch.where(vin != 0, (vo.abs().sum(-1) != 0).float(), torch.ones_like(vin)) / (1.0 - p_drop)
+            calls.append((layer, ms.detach().clone(), mv.detach().clone()))
+        return hook
+
+    handles = []
+    for i, conv in enumerate(m.dynamics.noise_predictor.conv_layers):
+        handles.append(conv.dropout.register_forward_hook(mk_hook(i)))
+    torch.manual_seed(rseed)
+    losses, metrics = m.forward(g, 'train')
+    total = torch.sum(torch.stack(list(losses.values()), dim=0))       # pharmacodiff.py:276
+    total.backward()
+    for h in handles:
+        h.remove()
+    out = dict(batch_arrays(batch), x0=x0, h0=h0, t_int=t_int, eps_h=eps_h, eps_x=eps_x, T=T, wseed=wseed,
+               p_drop=p_drop, weighted_loss=int(weighted_loss))
+    # per layer: two calls per destination ntype (message dropout, residual dropout); the node
+    # count tells the ntypes apart (Nf != Np in every case generated here)
+    assert Nf != Np
+    seen = {}
+    for layer, ms, mv in calls:
+        nt = "pharm" if ms.shape[0] == Nf else "prot"
+        k = seen.get((layer, nt), 0)
+        seen[(layer, nt)] = k + 1
+        which = "msg" if k == 0 else "res"
+        out[f"drop_{layer}_{nt}_{which}_s"] = ms
+        out[f"drop_{layer}_{nt}_{which}_v"] = mv
+    assert all(v == 2 for v in seen.values()) and len(seen) == 2 * cfg.n_convs, seen
+    for k, v in {**losses, **metrics}.items():
+        out["out_" + k.replace(" ", "_")] = v.detach()
+    for k, prm in m.named_parameters():
+        if k.startswith("dynamics.") and prm.numel() > 0:
+            out["grad_" + k] = torch.zeros_like(prm) if prm.grad is None else prm.grad.detach()
+    npz(name, **out)
+
+
 def main():
     cfg = O.DynamicsConfig()                       # dev.yml
     golden_units(cfg)
@@ -284,6 +349,9 @@ def main():
     golden_trajectory(cfg, "traj_c1.npz", seeds=[0], n_prot=64, n_pharm=4, T=50)
     golden_trajectory(cfg, "traj_ragged.npz", seeds=[8, 9], n_prot=40, n_pharm=[3, 5], T=20, traj=False)
     golden_train_forward(cfg, "train_fwd.npz", seeds=[10, 11, 12], n_prot=40, n_pharm=[4, 6, 5])
+    golden_train_grads(cfg, "train_grads.npz", seeds=[13, 14, 15], n_prot=40, n_pharm=[4, 7, 5])
+    golden_train_grads(cfg2, "train_grads_radius.npz", seeds=[16, 17], n_prot=36, n_pharm=[5, 3], wseed=1,
+                       p_drop=0.1, weighted_loss=True)
 
 
 if __name__ == "__main__":

@@ -30,3 +30,16 @@ DYN_CASES = {
     "dynamics_radius.npz": O.DynamicsConfig(n_convs=3, n_noise_gvps=3, message_norm=10, pf_k=0, ff_k=0),
     "dynamics_knnff.npz": O.DynamicsConfig(ff_k=2, pf_k=3, message_norm=1),
 }
+
+
+# training goldens (reference in train() mode, with the dropout draws recorded)
+GRAD_CASES = {
+    "train_grads.npz": O.DynamicsConfig(),
+    "train_grads_radius.npz": O.DynamicsConfig(n_convs=3, n_noise_gvps=3, message_norm=10, pf_k=0, ff_k=0),
+}
+
+
+def dropout_from(z, cfg):
+    """conv_layer-style mask dicts (one per layer) from a train_grads golden."""
+    return [{nt: tuple(z[f"drop_{i}_{nt}_{w}_{c}"] for w in ("msg", "res") for c in ("s", "v"))
+             for nt in ("pharm", "prot")} for i in range(cfg.n_convs)]

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import pf_oracle as O
-from helpers import DYN_CASES, batch_from, edge_set, load
+from helpers import DYN_CASES, GRAD_CASES, batch_from, dropout_from, edge_set, load
 
 RTOL, ATOL = 1e-5, 1e-5
 
@@ -135,6 +135,30 @@ def test_training_forward():
     for k, v in {**losses, **metrics}.items():
         ref = float(z["out_" + k.replace(" ", "_")])
         assert abs(float(v) - ref) <= 1e-4 * max(1.0, abs(ref)), (k, float(v), ref)
+
+
+@pytest.mark.parametrize("name", sorted(GRAD_CASES))
+def test_training_gradients(name):
+    """Loss and every parameter gradient of one reference training_step (train() mode, dropout 0.1)."""
+    z = load(name)
+    cfg = GRAD_CASES[name]
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    losses, metrics, grads = O.training_grads(sd, cfg, batch, z["x0"], z["h0"], int(z["T"]), 1e-5,
+                                              z["t_int"].long(), z["eps_h"], z["eps_x"],
+                                              dropout=dropout_from(z, cfg), weighted_loss=bool(z["weighted_loss"]))
+    for k, v in {**losses, **metrics}.items():
+        ref = float(z["out_" + k.replace(" ", "_")])
+        assert abs(float(v) - ref) <= 1e-5 * max(1.0, abs(ref)), (k, float(v), ref)
+    live = 0
+    for k, g in grads.items():
+        if g.numel() == 0:
+            continue
+        ref = z["grad_" + k]
+        scale = float(ref.abs().max())
+        live += scale > 0
+        assert float((g - ref).abs().max()) <= 2e-5 * scale + 1e-9, k
+    assert live >= 150          # the last layer's prot-side parameters get exactly zero gradient
 
 
 def test_neighbour_edge_cases():
