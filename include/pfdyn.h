@@ -141,6 +141,30 @@ int pf_sample(pf_handle* h, int32_t n_steps, const pf_step_coef* host_coef, cons
               float feat_norm_constant, float* dev_x0, float* dev_h0, float* dev_traj_x, float* dev_traj_h,
               pf_stream stream);
 
+/* -- training step: gradients of the dynamics (autograd through PharmRecDynamicsGVP.forward, ------
+ *    dynamics_gvp.py:131-185, as used by PharmacophoreDiff.forward / training_step, pharmacodiff.py:162-276)
+ * Parameters and gradients are exchanged as ONE flat fp32 vector in the reference's state-dict order
+ * (pf_param_layout enumerates name / offset / numel; a tensor's gradient sits at the offset of the tensor).
+ * pf_train_forward  = the boundary function in train() mode: same outputs as pf_dynamics_forward plus GVPDropout
+ *                     (gvp.py:118-149, rate dropout_p, counter-based masks from `seed`) at the two call sites of every
+ *                     conv layer; keeps each layer's input state for the backward pass.
+ * pf_train_backward = d(loss)/d(parameters) given d(loss)/d(eps_h), d(loss)/d(eps_x) of that forward.  The loss itself
+ *                     (pharmacodiff.py:208-232) is elementwise on eps and is the caller's.
+ * The optimiser is the caller's too (optim.Adam, pharmacodiff.py:253): after a step, push the new values with
+ * pf_set_weight + pf_commit_weights. */
+int pf_param_count(pf_handle* h, int64_t* n_params, int32_t* n_tensors);
+int pf_param_layout(pf_handle* h, int32_t index, const char** name, int64_t* offset, int64_t* numel);
+int pf_train_forward(pf_handle* h, const float* dev_prot_x /*[Np,3] or NULL*/, const float* dev_pharm_x /*[Nf,3]*/,
+                     const float* dev_pharm_h /*[Nf,pharm_nf]*/, const float* dev_t /*[B]*/, float dropout_p, uint32_t seed,
+                     float* dev_eps_h, float* dev_eps_x, pf_stream stream);
+int pf_train_backward(pf_handle* h, const float* dev_g_eps_h /*[Nf,pharm_nf]*/, const float* dev_g_eps_x /*[Nf,3]*/,
+                      float* dev_grad /*[n_params]*/, pf_stream stream);
+/* the {0, 1/(1-p)} multipliers pf_train_forward applies in conv layer `layer` (which: 0 message dropout, gvp.py:518;
+ * 1 residual dropout, gvp.py:529): dev_out[node][144] = 128 scalar features then 16 vector channels, global node ids
+ * (protein atoms first). */
+int pf_debug_dropout_mask(pf_handle* h, int32_t layer, int32_t which, float dropout_p, uint32_t seed,
+                          float* dev_out /*[N,144]*/, pf_stream stream);
+
 /* -- introspection for tests / profiling ----------------------------------------------------- */
 /* edges of the last dynamics call; etype: 0 ff, 1 pf, 2 fp, 3 pp; ids are ntype-local (reference
  * convention).  host_src == NULL returns the count.  Synchronises `stream`. */

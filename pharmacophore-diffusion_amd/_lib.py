@@ -47,6 +47,11 @@ SYMBOLS = {
     "pf_sample_end": (ctypes.c_int, [_P, _F, _P, _P, _P]),
     "pf_sample_frame": (ctypes.c_int, [_P, _F, _P, _P, _P]),
     "pf_sample": (ctypes.c_int, [_P, _I32, ctypes.POINTER(PfStepCoef), _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P]),
+    "pf_param_count": (ctypes.c_int, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I32)]),
+    "pf_param_layout": (ctypes.c_int, [_P, _I32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
+    "pf_train_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _F, ctypes.c_uint32, _P, _P, _P]),
+    "pf_train_backward": (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    "pf_debug_dropout_mask": (ctypes.c_int, [_P, _I32, _I32, _F, ctypes.c_uint32, _P, _P]),
     "pf_debug_get_edges": (_I64, [_P, _I32, _P, _P, _I64, _P]),
     "pf_debug_conv_layer": (ctypes.c_int, [_P, _I32] + [_P] * 11),
     "pf_profile_enable": (ctypes.c_int, [_P, ctypes.c_uint32]),

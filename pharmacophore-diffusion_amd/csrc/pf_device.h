@@ -118,6 +118,9 @@ struct NodeParams {
     int norm_mode; float norm_value;
     NodeW w[2];
     int n_upd;
+    // training forward only (one-wave kernel): GVPDropout of the aggregated message and of the update residual
+    // (gvp.py:518,529); drop_thr == 0: inference
+    uint32_t drop_thr; float drop_scale; uint32_t seed; int layer;
 };
 
 struct HeadParams {

@@ -14,6 +14,7 @@
 
 #include "../../include/pfdyn.h"
 #include "pf_device.h"
+#include "pf_train.h"
 
 extern "C" {
 void pfk_edge_msg(const EdgeParams* p, int layer0, hipStream_t s);
@@ -34,6 +35,12 @@ void pfk_segment_mean(const float4* xn, const int* ptr, int base, int B, float* 
 void pfk_step_update(const StepParams* p, hipStream_t s);
 void pfk_export_coords(const float4* xn, int base, int n, const int* gid, const float* add, const float* sub,
                        float* out, hipStream_t s);
+void pfk_bwd_head(const BwdHeadParams* p, int nblocks, hipStream_t s);
+void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s);
+void pfk_bwd_edge(const BwdEdgeParams* p, int nblocks, hipStream_t s);
+void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
+void pfk_train_reduce(const float* gpart, int nblocks, int nparams, float* grad, hipStream_t s);
+void pfk_drop_masks(const TrainCommon* c, uint32_t stream, int n_elems, float* out, hipStream_t s);
 void pfk_pp_radius(const float4* xn, const int* prot_ptr, int B, float r2, int maxn, int* deg, const int* row_off,
                    int* src, int* dst, int pass, hipStream_t s);
 }
@@ -119,6 +126,23 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_COOP_NODE_MAX")) coop_node_max = atoi(e);
         if (const char* e = getenv("PFDYN_NO_PRE")) use_pre = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_PRUNE")) prune = atoi(e) == 0;
+    }
+
+    // ---- gradient path (pf_train_*): flat parameter vector in state-dict order, GvpT tables, per-layer activations
+    float* d_flat = nullptr;
+    size_t nparams = 0;
+    std::vector<std::pair<std::string, std::pair<size_t, size_t>>> flat_layout;   // name -> (offset, numel), state-dict order
+    GvpT* d_gvpt = nullptr;                 // same indexing as the GvpW table
+    void* d_tws = nullptr;                  // training workspace of the current batch (allocated on first use)
+    std::vector<float*> t_H, t_V, t_msg_s, t_msg_v;
+    float *t_G_h[2] = {nullptr, nullptr}, *t_G_v[2] = {nullptr, nullptr}, *t_gagg_s = nullptr, *t_gagg_v = nullptr,
+          *t_gpart = nullptr, *t_geps_h = nullptr, *t_geps_x = nullptr;
+    int t_nblk = 0;
+    bool t_have_fwd = false;
+    TrainCommon t_common{};
+    size_t flat_offset(const std::string& name) const {
+        for (const auto& kv : flat_layout) if (kv.first == name) return kv.second.first;
+        return (size_t)-1;
     }
 
     // ---- optional per-kernel timing with HIP events on the caller's stream (pf_profile_*)
@@ -330,6 +354,9 @@ static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
 static void free_ws(pf_handle* h) {
     if (h->d_ws) (void)hipFree(h->d_ws);
     h->d_ws = nullptr;
+    if (h->d_tws) (void)hipFree(h->d_tws);
+    h->d_tws = nullptr;
+    h->t_have_fwd = false;
     h->have_batch = false;
 }
 
@@ -360,8 +387,11 @@ struct ProfScope {
     }
 };
 
-// sequence one dynamics call on the handle's state (xn, pharm_h, d_t)
-static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s, const float* t_scalar = nullptr) {
+// sequence one dynamics call on the handle's state (xn, pharm_h, d_t).  train: keep every layer's input and message
+// rows (h->t_*), compute every tile (gradients need the full graph only where they are non-zero, but the first
+// version of the backward pass walks the dense tile lists) and apply dropout in the node update.
+static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s, const float* t_scalar = nullptr,
+                        bool train = false) {
     const pf_config& c = h->cfg;
     EncodeParams ep{};
     ep.Np = h->Np; ep.Nf = h->Nf;
@@ -372,7 +402,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         ep.w[nt] = h->d_w + h->enc_w[nt]; ep.b[nt] = h->d_w + h->enc_b[nt];
         ep.ln_w[nt] = h->d_w + h->enc_lw[nt]; ep.ln_b[nt] = h->d_w + h->enc_lb[nt];
     }
-    ep.h_out = h->d_h[0];
+    ep.h_out = train ? h->t_H[0] : h->d_h[0];
 
     BuildParams bp{};
     bp.B = h->B; bp.Np_tot = h->Np;
@@ -382,7 +412,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
     bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
     bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
-    const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;    // the layer restricted to active atoms
+    const int prune_layer = (h->prune && !train && c.n_convs >= 2) ? c.n_convs - 2 : -1;    // the layer restricted to active atoms
     bp.act_ids = prune_layer >= 0 ? h->d_act_ids : nullptr; bp.reg_act = h->d_reg_act;
     bool pre_ready = false;
     if (h->prof_mask & 3u) {     // timing the two halves separately needs separate launches
@@ -395,7 +425,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         pp.a_enc = h->d_w + h->enc_a; pp.b_enc = h->d_w + h->enc_bf;
         pp.ln_w = h->d_w + h->enc_lw[0]; pp.ln_b = h->d_w + h->enc_lb[0];
         pp.pre_w = h->h_gvp[h->msg_base(0, ET_PP)]; pp.pre_nks = 64 + c.rbf_dim / 2 + 9;
-        pp.h_out = h->d_h[0]; pp.pre_out = h->d_pre;
+        pp.h_out = ep.h_out; pp.pre_out = h->d_pre;
         pfk_encode_build_pre(&ep, &bp, &pp, s);
         pre_ready = true;
     } else pfk_encode_build(&ep, &bp, s);
@@ -403,12 +433,12 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     int cur = 0;
     for (int l = 0; l < c.n_convs; ++l) {
         EdgeParams e{};
-        const bool last = (l == c.n_convs - 1), pruned = (l == prune_layer);
+        const bool last = (l == c.n_convs - 1) && !train, pruned = (l == prune_layer);
         e.tiles = pruned ? h->d_edge_tiles_act : h->d_edge_tiles;
         e.ntiles = last ? h->n_edge_tiles_last : (pruned ? h->n_edge_tiles_act : h->n_edge_tiles); e.dyn_cnt = h->d_dyn_cnt;
         e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;
-        e.h = h->d_h[cur]; e.v = h->d_v[cur];
-        e.msg_s = h->d_msg_s; e.msg_v = h->d_msg_v;
+        e.h = train ? h->t_H[l] : h->d_h[cur]; e.v = train ? h->t_V[l] : h->d_v[cur];
+        e.msg_s = train ? h->t_msg_s[l] : h->d_msg_s; e.msg_v = train ? h->t_msg_v[l] : h->d_msg_v;
         e.w = h->d_gvp + h->msg_base(l, 0); e.n_gvps = c.n_message_gvps;
         e.pre = (l == 0 && pre_ready) ? h->d_pre : nullptr;
         linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
@@ -422,8 +452,10 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         n.ntiles = last ? h->n_node_tiles_last : (pruned ? h->n_node_tiles_act : h->n_node_tiles);
         n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
         n.pp_slot = pruned ? 2 : 1; n.row_ids = h->d_act_ids; n.dyn_cnt = h->d_dyn_cnt;
-        n.msg_s = h->d_msg_s; n.msg_v = h->d_msg_v; n.zero_row = h->zero_row;
-        n.h_in = h->d_h[cur]; n.v_in = h->d_v[cur]; n.h_out = h->d_h[cur ^ 1]; n.v_out = h->d_v[cur ^ 1];
+        n.msg_s = e.msg_s; n.msg_v = e.msg_v; n.zero_row = h->zero_row;
+        n.h_in = e.h; n.v_in = e.v;
+        n.h_out = train ? h->t_H[l + 1] : h->d_h[cur ^ 1]; n.v_out = train ? h->t_V[l + 1] : h->d_v[cur ^ 1];
+        if (train) { n.drop_thr = h->t_common.drop_thr; n.drop_scale = h->t_common.drop_scale; n.seed = h->t_common.seed; n.layer = l; }
         n.gid = h->d_gid; n.gnorm = h->d_gnorm; n.B = h->B;
         n.norm_mode = c.message_norm_mode; n.norm_value = c.message_norm_value;
         for (int nt = 0; nt < 2; ++nt) {
@@ -433,13 +465,13 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             n.w[nt].upd = h->d_gvp + h->upd_base(l, nt);
         }
         n.n_upd = c.n_update_gvps;
-        if (n.ntiles <= h->coop_node_max) { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_node_update_coop(&n, l == 0, s); }
+        if (n.ntiles <= h->coop_node_max && !train) { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_node_update_coop(&n, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_NODE, s); pfk_node_update(&n, l == 0, s); }
         cur ^= 1;
     }
     HeadParams hp{};
     hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
-    hp.h = h->d_h[cur]; hp.v = h->d_v[cur];
+    hp.h = train ? h->t_H[c.n_convs] : h->d_h[cur]; hp.v = train ? h->t_V[c.n_convs] : h->d_v[cur];
     hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
     hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
     hp.eps_h = eps_h; hp.eps_x = eps_x;
@@ -497,6 +529,8 @@ void pf_destroy(pf_handle* h) {
     free_ws(h);
     if (h->d_w) (void)hipFree(h->d_w);
     if (h->d_gvp) (void)hipFree(h->d_gvp);
+    if (h->d_flat) (void)hipFree(h->d_flat);
+    if (h->d_gvpt) (void)hipFree(h->d_gvpt);
     for (int k = 0; k < pf_handle::K_NUM; ++k)
         for (auto& ev : h->prof_ev[k]) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete h;
@@ -612,6 +646,39 @@ int pf_commit_weights(pf_handle* h) {
     PF_HIP(h, hipMemcpy(h->d_gvp, h->h_gvp.data(), h->h_gvp.size() * sizeof(GvpW), hipMemcpyHostToDevice));
     h->h_w.clear();
     h->h_w.shrink_to_fit();
+    {   // gradient path: the parameters once more as one flat vector in state-dict order, and where each GVP's tensors sit
+        std::vector<float> flat;
+        h->flat_layout.clear();
+        for (const auto& kv : exp) {
+            const RawTensor& t = h->raw[kv.first];
+            h->flat_layout.push_back({kv.first, {flat.size(), t.data.size()}});
+            flat.insert(flat.end(), t.data.begin(), t.data.end());
+        }
+        h->nparams = flat.size();
+        auto mk = [&](const GvpSpec& g, bool sig) {
+            GvpT t;
+            t.o_Wh = (int)h->flat_offset(g.prefix + "Wh"); t.o_Wu = (int)h->flat_offset(g.prefix + "Wu");
+            t.o_Wm = (int)h->flat_offset(g.prefix + "to_feats_out.0.weight"); t.o_bm = (int)h->flat_offset(g.prefix + "to_feats_out.0.bias");
+            t.o_Wg = (int)h->flat_offset(g.prefix + "scalar_to_vector_gates.weight"); t.o_bg = (int)h->flat_offset(g.prefix + "scalar_to_vector_gates.bias");
+            t.vi = g.vi; t.vo = g.vo; t.h = std::max(g.vi, g.vo); t.si = g.si; t.so = g.so; t.sig = sig ? 1 : 0;
+            return t;
+        };
+        std::vector<GvpT> tab;
+        for (int l = 0; l < c.n_convs; ++l)
+            for (int et = 0; et < 4; ++et)
+                for (int j = 0; j < c.n_message_gvps; ++j) tab.push_back(mk(msg_spec(c, l, et, j), true));
+        for (int l = 0; l < c.n_convs; ++l)
+            for (int nt = 0; nt < 2; ++nt)
+                for (int j = 0; j < c.n_update_gvps; ++j) tab.push_back(mk(upd_spec(c, l, nt, j), true));
+        for (int k = 0; k < c.n_noise_gvps; ++k) tab.push_back(mk(head_spec(c, k), k != c.n_noise_gvps - 1));
+        if (h->d_flat) { (void)hipFree(h->d_flat); h->d_flat = nullptr; }
+        if (h->d_gvpt) { (void)hipFree(h->d_gvpt); h->d_gvpt = nullptr; }
+        PF_HIP(h, hipMalloc((void**)&h->d_flat, std::max<size_t>(flat.size(), 1) * sizeof(float)));
+        PF_HIP(h, hipMemcpy(h->d_flat, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice));
+        PF_HIP(h, hipMalloc((void**)&h->d_gvpt, tab.size() * sizeof(GvpT)));
+        PF_HIP(h, hipMemcpy(h->d_gvpt, tab.data(), tab.size() * sizeof(GvpT), hipMemcpyHostToDevice));
+    }
+    h->t_have_fwd = false;
     h->committed = true;
     return PF_OK;
 }
@@ -1005,6 +1072,172 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     PF_HIP(h, hipMemsetAsync(h->d_v[0], 0, (size_t)h->N * 48 * 4, s));
     hipError_t er = hipGetLastError();
     if (er != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(er));
+    return PF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradient path (training step): forward that keeps the per-layer state, backward, parameter layout
+// ------------------------------------------------------------------------------------------------
+static int ensure_train_ws(pf_handle* h, hipStream_t s) {
+    if (h->d_tws) return PF_OK;
+    const pf_config& c = h->cfg;
+    if (c.n_message_gvps > PFT_MAX_CHAIN || c.n_noise_gvps > PFT_MAX_CHAIN || c.n_update_gvps > 3)
+        PF_FAIL(h, PF_ERR_ARG, "training supports at most %d message / noise GVPs and 3 update GVPs per chain", PFT_MAX_CHAIN);
+    if (c.pharm_nf > 8 || c.rec_nf + 1 > 17 || c.pharm_nf + 1 > 17)
+        PF_FAIL(h, PF_ERR_ARG, "training supports pharm_nf <= 8 and rec_nf <= 16");
+    const int L = c.n_convs, N = h->N;
+    const size_t E1 = (size_t)h->Ecap + 1;
+    h->t_nblk = std::max(1, std::min(256, h->n_edge_tiles));
+    size_t bytes = 0;
+    auto need = [&](size_t n_floats) { bytes += (n_floats * 4 + 255) & ~size_t(255); };
+    for (int l = 0; l <= L; ++l) { need((size_t)N * PF_S); need((size_t)N * 48); }
+    for (int l = 0; l < L; ++l) { need(E1 * PF_S); need(E1 * 48); }
+    for (int a = 0; a < 2; ++a) { need((size_t)N * PF_S); need((size_t)N * 48); }
+    need((size_t)N * PF_S); need((size_t)N * 48);
+    need((size_t)h->t_nblk * h->nparams);
+    PF_HIP(h, hipMalloc(&h->d_tws, bytes + 4096));
+    char* cur = reinterpret_cast<char*>(h->d_tws);
+    h->t_H.assign(L + 1, nullptr); h->t_V.assign(L + 1, nullptr); h->t_msg_s.assign(L, nullptr); h->t_msg_v.assign(L, nullptr);
+    for (int l = 0; l <= L; ++l) { h->t_H[l] = carve<float>(cur, (size_t)N * PF_S); h->t_V[l] = carve<float>(cur, (size_t)N * 48); }
+    for (int l = 0; l < L; ++l) { h->t_msg_s[l] = carve<float>(cur, E1 * PF_S); h->t_msg_v[l] = carve<float>(cur, E1 * 48); }
+    for (int a = 0; a < 2; ++a) { h->t_G_h[a] = carve<float>(cur, (size_t)N * PF_S); h->t_G_v[a] = carve<float>(cur, (size_t)N * 48); }
+    h->t_gagg_s = carve<float>(cur, (size_t)N * PF_S); h->t_gagg_v = carve<float>(cur, (size_t)N * 48);
+    h->t_gpart = carve<float>(cur, (size_t)h->t_nblk * h->nparams);
+    // message buffers: the zero row (index Ecap) must read as zeros; V[0] is the all-zero initial vector state
+    for (int l = 0; l < L; ++l) {
+        PF_HIP(h, hipMemsetAsync(h->t_msg_s[l], 0, E1 * PF_S * 4, s));
+        PF_HIP(h, hipMemsetAsync(h->t_msg_v[l], 0, E1 * 48 * 4, s));
+    }
+    PF_HIP(h, hipMemsetAsync(h->t_V[0], 0, (size_t)N * 48 * 4, s));
+    return PF_OK;
+}
+
+int pf_param_count(pf_handle* h, int64_t* n_params, int32_t* n_tensors) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (n_params) *n_params = (int64_t)h->nparams;
+    if (n_tensors) *n_tensors = (int32_t)h->flat_layout.size();
+    return PF_OK;
+}
+
+int pf_param_layout(pf_handle* h, int32_t index, const char** name, int64_t* offset, int64_t* numel) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (index < 0 || index >= (int32_t)h->flat_layout.size()) PF_FAIL(h, PF_ERR_ARG, "pf_param_layout: index out of range");
+    const auto& kv = h->flat_layout[index];
+    if (name) *name = kv.first.c_str();
+    if (offset) *offset = (int64_t)kv.second.first;
+    if (numel) *numel = (int64_t)kv.second.second;
+    return PF_OK;
+}
+
+int pf_train_forward(pf_handle* h, const float* dev_prot_x, const float* dev_pharm_x, const float* dev_pharm_h,
+                     const float* dev_t, float dropout_p, uint32_t seed, float* dev_eps_h, float* dev_eps_x, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!dev_pharm_x || !dev_pharm_h || !dev_t || !dev_eps_h || !dev_eps_x) PF_FAIL(h, PF_ERR_ARG, "pf_train_forward: null argument");
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) PF_FAIL(h, PF_ERR_ARG, "pf_train_forward: dropout must be in [0, 1)");
+    hipStream_t s = (hipStream_t)stream;
+    rc = ensure_train_ws(h, s);
+    if (rc) return rc;
+    h->t_common = TrainCommon{};
+    h->t_common.W = h->d_flat; h->t_common.gpart = h->t_gpart; h->t_common.nparams = (int)h->nparams;
+    h->t_common.drop_thr = dropout_p > 0.f ? (uint32_t)std::min(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
+    h->t_common.drop_scale = 1.0f / (1.0f - dropout_p);
+    h->t_common.seed = seed;
+    load_state(h, dev_prot_x, dev_pharm_x, dev_pharm_h, s);
+    pfk_copy(dev_t, h->d_t, (size_t)h->B, s);
+    rc = run_dynamics(h, dev_eps_h, dev_eps_x, s, nullptr, true);
+    h->t_have_fwd = rc == PF_OK;
+    return rc;
+}
+
+int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g_eps_x, float* dev_grad, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!h->t_have_fwd) PF_FAIL(h, PF_ERR_STATE, "pf_train_backward: no pf_train_forward on this batch");
+    if (!dev_g_eps_h || !dev_g_eps_x || !dev_grad) PF_FAIL(h, PF_ERR_ARG, "pf_train_backward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const pf_config& c = h->cfg;
+    const int L = c.n_convs, N = h->N, nb = h->t_nblk;
+    const TrainCommon tc = h->t_common;
+    PF_HIP(h, hipMemsetAsync(h->t_gpart, 0, (size_t)nb * h->nparams * 4, s));
+    PF_HIP(h, hipMemsetAsync(h->t_G_h[0], 0, (size_t)N * PF_S * 4, s));
+    PF_HIP(h, hipMemsetAsync(h->t_G_v[0], 0, (size_t)N * 48 * 4, s));
+    {
+        BwdHeadParams p{};
+        p.c = tc; p.tiles = h->d_head_tiles; p.ntiles = h->n_head_tiles; p.node_base = h->Np;
+        p.h = h->t_H[L]; p.v = h->t_V[L];
+        p.g = h->d_gvpt + h->head_base(); p.n_gvps = c.n_noise_gvps;
+        p.o_Wout = (int)h->flat_offset("dynamics.noise_predictor.noise_predictor.to_scalar_output.weight");
+        p.o_bout = (int)h->flat_offset("dynamics.noise_predictor.noise_predictor.to_scalar_output.bias");
+        p.pharm_nf = c.pharm_nf; p.g_eps_h = dev_g_eps_h; p.g_eps_x = dev_g_eps_x;
+        p.G_h = h->t_G_h[0]; p.G_v = h->t_G_v[0];
+        pfk_bwd_head(&p, std::max(1, std::min(nb, p.ntiles)), s);
+    }
+    int a = 0;
+    for (int l = L - 1; l >= 0; --l) {
+        BwdNodeParams n{};
+        n.c = tc; n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles;
+        n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = N;
+        n.msg_s = h->t_msg_s[l]; n.msg_v = h->t_msg_v[l]; n.zero_row = h->zero_row;
+        n.h_in = h->t_H[l]; n.v_in = h->t_V[l];
+        n.G_h_out = h->t_G_h[a]; n.G_v_out = h->t_G_v[a]; n.G_h_in = h->t_G_h[a ^ 1]; n.G_v_in = h->t_G_v[a ^ 1];
+        n.gagg_s = h->t_gagg_s; n.gagg_v = h->t_gagg_v;
+        n.gid = h->d_gid; n.gnorm = h->d_gnorm; n.B = h->B;
+        n.norm_mode = c.message_norm_mode; n.norm_value = c.message_norm_value;
+        n.upd = h->d_gvpt + h->upd_base(l, 0); n.n_upd = c.n_update_gvps;
+        for (int nt = 0; nt < 2; ++nt) {
+            const std::string p1 = conv_prefix(l) + "message_layer_norms." + kNtKey[nt] + ".feat_norm.";
+            const std::string p2 = conv_prefix(l) + "update_layer_norms." + kNtKey[nt] + ".feat_norm.";
+            n.o_ln[nt][0] = (int)h->flat_offset(p1 + "weight"); n.o_ln[nt][1] = (int)h->flat_offset(p1 + "bias");
+            n.o_ln[nt][2] = (int)h->flat_offset(p2 + "weight"); n.o_ln[nt][3] = (int)h->flat_offset(p2 + "bias");
+        }
+        n.layer = l; n.l0 = l == 0;
+        pfk_bwd_node(&n, std::max(1, std::min(nb, n.ntiles)), s);
+        BwdEdgeParams e{};
+        e.c = tc; e.tiles = h->d_edge_tiles; e.ntiles = h->n_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
+        e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;
+        e.h = h->t_H[l]; e.v = h->t_V[l];
+        e.gagg_s = h->t_gagg_s; e.gagg_v = h->t_gagg_v; e.in_cnt = h->d_in_cnt; e.N = N;
+        e.norm_mode = c.message_norm_mode;
+        e.G_h_in = h->t_G_h[a ^ 1]; e.G_v_in = h->t_G_v[a ^ 1];
+        e.g = h->d_gvpt + h->msg_base(l, 0); e.n_gvps = c.n_message_gvps;
+        linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
+        e.rbf_inv_sigma = 1.0f / ((c.rbf_dmax - 0.f) / (float)c.rbf_dim);
+        e.l0 = l == 0;
+        pfk_bwd_edge(&e, std::max(1, std::min(nb, e.ntiles)), s);
+        a ^= 1;
+    }
+    {
+        BwdEncodeParams p{};
+        p.c = tc; p.Np = h->Np; p.Nf = h->Nf;
+        p.prot_h0 = h->d_prot_h0; p.pharm_h = h->d_pharm_h; p.t = h->d_t; p.gid = h->d_gid;
+        p.rec_nf = c.rec_nf; p.pharm_nf = c.pharm_nf;
+        for (int nt = 0; nt < 2; ++nt) {
+            const std::string pre = std::string("dynamics.") + kNtKey[nt] + "_encoder.";
+            p.o_w[nt] = (int)h->flat_offset(pre + "0.weight"); p.o_b[nt] = (int)h->flat_offset(pre + "0.bias");
+            p.o_lw[nt] = (int)h->flat_offset(pre + "2.weight"); p.o_lb[nt] = (int)h->flat_offset(pre + "2.bias");
+        }
+        p.G_h = h->t_G_h[a];
+        const int tiles = (h->Np + PFT_ROWS - 1) / PFT_ROWS + (h->Nf + PFT_ROWS - 1) / PFT_ROWS;
+        pfk_bwd_encode(&p, std::max(1, std::min(nb, tiles)), s);
+    }
+    pfk_train_reduce(h->t_gpart, nb, (int)h->nparams, dev_grad, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return PF_OK;
+}
+
+int pf_debug_dropout_mask(pf_handle* h, int32_t layer, int32_t which, float dropout_p, uint32_t seed, float* dev_out, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!dev_out || layer < 0 || layer >= h->cfg.n_convs || which < 0 || which > 1) PF_FAIL(h, PF_ERR_ARG, "pf_debug_dropout_mask: bad argument");
+    TrainCommon tc{};
+    tc.drop_thr = dropout_p > 0.f ? (uint32_t)std::min(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
+    tc.drop_scale = 1.0f / (1.0f - dropout_p);
+    tc.seed = seed;
+    pfk_drop_masks(&tc, (uint32_t)layer * 2u + (uint32_t)which, h->N * 144, dev_out, (hipStream_t)stream);
     return PF_OK;
 }
 

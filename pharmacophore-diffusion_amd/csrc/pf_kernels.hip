@@ -14,6 +14,7 @@
 // weights stream from L2 in pre-packed fragment order.
 #include <hip/hip_runtime.h>
 #include "pf_device.h"
+#include "pf_train.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -420,6 +421,24 @@ __device__ __forceinline__ void gvp_layernorm(pf_gcf lw, pf_gcf lb, const int hl
         for (int t = 0; t < 8; ++t) V[c][t] = V[c][t] * rden;
 }
 
+// GVPDropout (gvp.py:118-149) of one node's scalar row (F-layout) and vector channels (R-layout): the keep mask is a
+// counter-based hash of (step seed, stream, node, element) that the backward pass regenerates (pf_train.h)
+__device__ __forceinline__ void node_dropout(const NodeParams& p, const uint32_t stream, const int n, const int hl,
+                                             float (&s)[64], float (&V)[3][8]) {
+    const uint32_t base = (uint32_t)n * 144u;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) {
+        const uint32_t f = 32u * (q >> 4) + ((q & 3) + 8 * ((q & 15) >> 2) + 4 * hl);
+        s[q] *= pf_drop_hash(p.seed, stream, base + f) < p.drop_thr ? 0.0f : p.drop_scale;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const uint32_t ch = (t & 3) + 8 * (t >> 2) + 4 * hl;
+        const float m = pf_drop_hash(p.seed, stream, base + 128u + ch) < p.drop_thr ? 0.0f : p.drop_scale;
+        V[0][t] *= m; V[1][t] *= m; V[2][t] *= m;
+    }
+}
+
 template <bool L0>
 __global__ __launch_bounds__(64, PF_WPS_NODE) void k_node_update(const NodeParams p) {
     const int lane = threadIdx.x & 63;
@@ -481,6 +500,7 @@ __global__ __launch_bounds__(64, PF_WPS_NODE) void k_node_update(const NodeParam
 #pragma unroll
             for (int q = 0; q < 8; ++q) V[c][q] = 0.f;
     }
+    if (p.drop_thr != 0u) node_dropout(p, (uint32_t)p.layer * 2u, n, hl, ms, mv);      // gvp.py:518 (training forward)
 #pragma unroll
     for (int q = 0; q < 64; ++q) s[q] = fmaf(ms[q], inv_norm, s[q]);
 #pragma unroll
@@ -506,6 +526,7 @@ __global__ __launch_bounds__(64, PF_WPS_NODE) void k_node_update(const NodeParam
 #pragma unroll
             for (int q = 0; q < 8; ++q) V1[c][q] = V2[c][q];
     }
+    if (p.drop_thr != 0u) node_dropout(p, (uint32_t)p.layer * 2u + 1u, n, hl, s1, V1);      // gvp.py:529
 #pragma unroll
     for (int q = 0; q < 64; ++q) s[q] += s1[q];
 #pragma unroll

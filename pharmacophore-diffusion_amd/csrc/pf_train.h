@@ -1,0 +1,99 @@
+// pf_train.h -- host/device structures of the gradient path of libpfdyn (gfx950 only).
+//
+// The training step keeps, per conv layer, the node state that entered the layer (h [N][128], v [N][48]) and the
+// per-(tile, destination) message partial rows the forward edge kernel wrote; every other activation is
+// recomputed inside the backward kernels (reference: PharmacophoreDiff.forward, pharmacodiff.py:162-243; autograd
+// through PharmRecDynamicsGVP.forward, dynamics_gvp.py:131-185, and GVPMultiEdgeConv, gvp.py:459-551).
+//
+// Parameters and gradients live in ONE flat fp32 vector in the reference's state-dict order
+// (pf_host.cpp: expected_tensors); a GvpT addresses one GVP's six tensors by offset into that vector, so the
+// gradient of a tensor sits at the same offset of the gradient vector.  Every thread block of a backward kernel
+// accumulates into its own private copy of the gradient vector (gpart[block][nparams], plain read-modify-write by
+// the owning lane, no atomics); pfk_train_reduce sums the copies in a fixed order, so gradients are bit-reproducible.
+#pragma once
+#include <stdint.h>
+#include "pf_device.h"
+
+#define PFT_MAX_CHAIN 4      // GVPs per chain the backward tiles hold in LDS
+#define PFT_ROWS 16          // rows (edges / nodes) per backward sub-tile = N of v_mfma_f32_16x16x4_f32
+
+struct GvpT {
+    int o_Wh, o_Wu, o_Wm, o_bm, o_Wg, o_bg;   // offsets of Wh [vi][h], Wu [h][vo], to_feats_out.0.{weight [so][si+h], bias},
+                                              // scalar_to_vector_gates.{weight [vo][so], bias}
+    int vi, h, vo, si, so, sig;               // sig: vector activation is a sigmoid (0: identity, last head GVP)
+};
+
+struct TrainCommon {
+    const float* W;          // flat parameters
+    float* gpart;            // [gridDim.x][nparams]
+    int nparams;
+    uint32_t drop_thr;       // an element is dropped iff pf_drop_hash(...) < drop_thr  (= p * 2^32; 0: no dropout)
+    float drop_scale;        // 1 / (1 - p)
+    uint32_t seed;           // dropout stream of this step
+};
+
+struct BwdHeadParams {
+    TrainCommon c;
+    const NodeTile* tiles; int ntiles;       // pharm tiles (32 rows each)
+    int node_base;
+    const float* h; const float* v;          // output of the last conv layer
+    const GvpT* g; int n_gvps;               // device table [n_gvps]
+    int o_Wout, o_bout, pharm_nf;
+    const float* g_eps_h; const float* g_eps_x;   // upstream gradients [Nf][pharm_nf], [Nf][3]
+    float* G_h; float* G_v;                  // gradient w.r.t. the last layer's output (rows of the pharm nodes are stored)
+};
+
+struct BwdNodeParams {
+    TrainCommon c;
+    const NodeTile* tiles; int ntiles;
+    const int* in_start; const int* in_cnt; int N;
+    const float* msg_s; const float* msg_v; int zero_row;
+    const float* h_in; const float* v_in;    // layer input (v_in unused when l0)
+    const float* G_h_out; const float* G_v_out;   // gradient w.r.t. the layer output
+    float* G_h_in; float* G_v_in;            // gradient w.r.t. the layer input: the residual path is STORED here (edge kernel adds)
+    float* gagg_s; float* gagg_v;            // gradient w.r.t. the aggregated message before normalisation [N][128], [N][48]
+    const int* gid; const float* gnorm; int B;
+    int norm_mode; float norm_value;
+    const GvpT* upd; int n_upd;              // device table [2 ntypes][n_upd]
+    int o_ln[2][4];                          // ln1_w ln1_b ln2_w ln2_b per node type
+    int layer, l0;
+};
+
+struct BwdEdgeParams {
+    TrainCommon c;
+    const EdgeTile* tiles; int ntiles;
+    const int* dyn_cnt;
+    const int* esrc; const int* edst;
+    const float4* xn;
+    const float* h; const float* v;          // layer input
+    const float* gagg_s; const float* gagg_v;
+    const int* in_cnt; int N;
+    int norm_mode;
+    float* G_h_in; float* G_v_in;            // atomically accumulated
+    const GvpT* g; int n_gvps;               // device table [4 etypes][n_gvps]
+    float rbf_mu[PF_R]; float rbf_inv_sigma;
+    int l0;
+};
+
+struct BwdEncodeParams {
+    TrainCommon c;
+    int Np, Nf;
+    const float* prot_h0; const float* pharm_h; const float* t; const int* gid;
+    int rec_nf, pharm_nf;
+    int o_w[2], o_b[2], o_lw[2], o_lb[2];    // 0 prot, 1 pharm
+    const float* G_h;                        // gradient w.r.t. the encoder output [N][128]
+};
+
+// dropout keep-mask of (step seed, stream, element): identical in the forward node kernel and the backward pass.
+// stream = layer * 2 + (0: message dropout, 1: residual dropout); element = node * 144 + (feature | 128 + channel).
+#if defined(__HIPCC__)
+__device__ __forceinline__
+#else
+static inline
+#endif
+uint32_t pf_drop_hash(uint32_t seed, uint32_t stream, uint32_t elem) {
+    uint32_t x = seed ^ (stream * 0x9E3779B1u) ^ (elem * 0x85EBCA77u);
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    x += elem; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+    return x;
+}

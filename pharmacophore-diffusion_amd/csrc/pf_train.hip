@@ -1,0 +1,776 @@
+// pf_train.hip -- gradient kernels of libpfdyn (gfx950): backward of the noise head, of a conv layer's node update
+// and edge messages, and of the encoders.  See pf_train.h for the data model.
+//
+// Reference semantics: autograd through NoisePredictionBlock.forward (dynamics_gvp.py:37-42), GVPMultiEdgeConv
+// (gvp.py:459-551), GVP.forward (gvp.py:89-116), GVPLayerNorm (gvp.py:152-166), GVPDropout (gvp.py:118-149) and the
+// encoders (dynamics_gvp.py:107-117).
+//
+// A backward tile is 16 rows (edges or nodes).  Its activations sit in LDS as [row][feature] with odd row strides;
+// every GEMM-shaped step -- forward recompute, input gradients and weight gradients -- goes through mm16, a block
+// cooperative v_mfma_f32_16x16x4_f32 loop whose operands are fetched by accessor lambdas (weights from the flat
+// parameter vector, activations from LDS), with the 16 rows (or 16 rows x 3 coordinates) as the N dimension of the
+// data products and as the K dimension of the weight-gradient products.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pf_train.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TR PFT_ROWS
+#define NT 256            // threads per block
+#define SWS 165           // LDS row stride of scalar rows [si + h] (<= 161)
+#define VWS 53            // ... of vector rows [vi * 3] (<= 51)
+#define ZS 129            // ... of pre-activation / activation rows [so]
+#define GTS 17            // ... of gate rows [vo]
+#define LVL_FLOATS (TR * (SWS + VWS + ZS + GTS))
+#define WORK_FLOATS (TR * (SWS * 2 + VWS * 5 + GTS))
+#define CHAIN_FLOATS(nlv) ((nlv) * LVL_FLOATS + TR * ZS + WORK_FLOATS)
+
+__device__ __forceinline__ float t_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float t_silu(float x) { return x * t_sigmoid(x); }
+__device__ __forceinline__ float t_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+__device__ __forceinline__ float drop_mul(const TrainCommon& c, const uint32_t stream, const uint32_t elem) {
+    if (c.drop_thr == 0u) return 1.0f;
+    return pf_drop_hash(c.seed, stream, elem) < c.drop_thr ? 0.0f : c.drop_scale;
+}
+
+// C[M x N] = A[M x K] B[K x N] on v_mfma_f32_16x16x4_f32 (lane l: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// C[i = 4 (l>>4) + r][j = l&15]).  Output tiles are dealt round-robin to the 4 waves; c(i, j, value) consumes them.
+template <typename FA, typename FB, typename FC>
+__device__ __forceinline__ void mm16(const int M, const int N, const int K, FA a, FB b, FC c, const int lane, const int wv) {
+    const int mts = (M + 15) >> 4, nts = (N + 15) >> 4;
+    const int li = lane & 15, kq = lane >> 4;
+    for (int t = wv; t < mts * nts; t += NT / 64) {
+        const int mt = t / nts, nt = t - mt * nts;
+        const int ai = mt * 16 + li, bj = nt * 16 + li;
+        const bool aok = ai < M, bok = bj < N;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + kq;
+            const float av = (aok && k < K) ? a(ai, k) : 0.f;
+            const float bv = (bok && k < K) ? b(k, bj) : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = mt * 16 + kq * 4 + r;
+            if (ci < M && bok) c(ci, bj, acc[r]);
+        }
+    }
+}
+
+struct ChainLds {
+    float* base; int nlv;
+    float *actl, *gX, *gY, *gVX, *gVY, *Vh, *Vu, *gVh, *ggate;
+    __device__ __forceinline__ void init(float* b, const int n) {
+        base = b; nlv = n;
+        actl = b + n * LVL_FLOATS;
+        gX = actl + TR * ZS; gY = gX + TR * SWS;
+        gVX = gY + TR * SWS; gVY = gVX + TR * VWS; Vh = gVY + TR * VWS; Vu = Vh + TR * VWS; gVh = Vu + TR * VWS;
+        ggate = gVh + TR * VWS;
+    }
+    __device__ __forceinline__ float* Sin(const int l) const { return base + l * LVL_FLOATS; }
+    __device__ __forceinline__ float* Vin(const int l) const { return Sin(l) + TR * SWS; }
+    __device__ __forceinline__ float* Z(const int l) const { return Vin(l) + TR * VWS; }
+    __device__ __forceinline__ float* gate(const int l) const { return Z(l) + TR * ZS; }
+};
+
+// Vh = Wh^T V and Vu = Wu^T Vh of one GVP for the 16 rows (gvp.py:97-101); sh goes to Sin[:, si:] when want_sh
+__device__ __forceinline__ void gvp_vec(const GvpT& g, const float* W, float* Sin, const float* Vin, float* Vh, float* Vu,
+                                        const bool want_sh, const int tid, const int lane, const int wv) {
+    const int KH = g.h, VI = g.vi, VO = g.vo;
+    mm16(KH, 3 * TR, VI,
+         [&](int i, int k) { return W[g.o_Wh + k * KH + i]; },
+         [&](int k, int j) { return Vin[(j & 15) * VWS + k * 3 + (j >> 4)]; },
+         [&](int i, int j, float x) { Vh[(j & 15) * VWS + i * 3 + (j >> 4)] = x; }, lane, wv);
+    __syncthreads();
+    if (want_sh)
+        for (int idx = tid; idx < TR * KH; idx += NT) {
+            const int row = idx & 15, hh = idx >> 4;
+            const float* q = Vh + row * VWS + hh * 3;
+            Sin[row * SWS + g.si + hh] = t_sqrt(fmaxf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2], 1e-8f));
+        }
+    mm16(VO, 3 * TR, KH,
+         [&](int i, int k) { return W[g.o_Wu + k * VO + i]; },
+         [&](int k, int j) { return Vh[(j & 15) * VWS + k * 3 + (j >> 4)]; },
+         [&](int i, int j, float x) { Vu[(j & 15) * VWS + i * 3 + (j >> 4)] = x; }, lane, wv);
+    __syncthreads();
+}
+
+// forward of one GVP on the tile: reads Sin[:, :si], Vin; fills Sin[:, si:], Z, gate, act (= SiLU(Z)) and, when
+// Vout != nullptr, the gated vectors (gvp.py:89-116)
+__device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, float* Sin, const float* Vin, float* Z, float* gate,
+                                        float* act, const int act_stride, float* Vout, float* Vh, float* Vu,
+                                        const int tid, const int lane, const int wv) {
+    const int VO = g.vo, SO = g.so, KM = g.si + g.h;
+    gvp_vec(g, W, Sin, Vin, Vh, Vu, true, tid, lane, wv);
+    mm16(SO, TR, KM,
+         [&](int i, int k) { return W[g.o_Wm + i * KM + k]; },
+         [&](int k, int j) { return Sin[j * SWS + k]; },
+         [&](int i, int j, float x) {
+             const float z = x + W[g.o_bm + i];
+             Z[j * ZS + i] = z;
+             act[j * act_stride + i] = t_silu(z);
+         }, lane, wv);
+    __syncthreads();
+    mm16(VO, TR, SO,
+         [&](int i, int k) { return W[g.o_Wg + i * SO + k]; },
+         [&](int k, int j) { return act[j * act_stride + k]; },
+         [&](int i, int j, float x) { gate[j * GTS + i] = x + W[g.o_bg + i]; }, lane, wv);
+    __syncthreads();
+    if (Vout != nullptr) {
+        for (int idx = tid; idx < TR * VO; idx += NT) {
+            const int row = idx & 15, u = idx >> 4;
+            const float gt = gate[row * GTS + u];
+            const float f = g.sig ? t_sigmoid(gt) : gt;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) Vout[row * VWS + u * 3 + cc] = f * Vu[row * VWS + u * 3 + cc];
+        }
+        __syncthreads();
+    }
+}
+
+// backward of one GVP on the tile.  In: gA = dL/d act [row][so] (stride SWS), gVo = dL/d Vout [row][vo*3].
+// Out: gS = dL/d Sin[:, :si+h] (the first si entries are the input-scalar gradient), gVi = dL/d Vin.  gA and gVo are
+// overwritten (they become dL/dZ and dL/dVu).  Weight gradients are accumulated into gp (this block's copy).
+__device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, float* gp, const float* Sin, const float* Vin,
+                                        const float* Z, const float* gate, const float* act, const int act_stride,
+                                        float* gA, float* gS, float* gVo, float* gVi, float* Vh, float* Vu, float* gVh,
+                                        float* ggate, const int tid, const int lane, const int wv) {
+    const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;
+    gvp_vec(g, W, nullptr, Vin, Vh, Vu, false, tid, lane, wv);
+    // gate: V' = f(gate) Vu
+    for (int idx = tid; idx < TR * VO; idx += NT) {
+        const int row = idx & 15, u = idx >> 4;
+        const float gt = gate[row * GTS + u];
+        float* go = gVo + row * VWS + u * 3;
+        const float* vu = Vu + row * VWS + u * 3;
+        const float dot = go[0] * vu[0] + go[1] * vu[1] + go[2] * vu[2];
+        float f, df;
+        if (g.sig) { f = t_sigmoid(gt); df = f * (1.0f - f); } else { f = gt; df = 1.0f; }
+        ggate[row * GTS + u] = dot * df;
+        go[0] *= f; go[1] *= f; go[2] *= f;
+    }
+    __syncthreads();
+    mm16(SO, TR, VO,
+         [&](int i, int k) { return W[g.o_Wg + k * SO + i]; },
+         [&](int k, int j) { return ggate[j * GTS + k]; },
+         [&](int i, int j, float x) { gA[j * SWS + i] += x; }, lane, wv);
+    mm16(VO, SO, TR,
+         [&](int i, int k) { return ggate[k * GTS + i]; },
+         [&](int k, int j) { return act[k * act_stride + j]; },
+         [&](int i, int j, float x) { gp[g.o_Wg + i * SO + j] += x; }, lane, wv);
+    if (tid < VO) {
+        float s = 0.f;
+        for (int r = 0; r < TR; ++r) s += ggate[r * GTS + tid];
+        gp[g.o_bg + tid] += s;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < TR * SO; idx += NT) {
+        const int row = idx & 15, o = idx >> 4;
+        const float z = Z[row * ZS + o];
+        const float s = t_sigmoid(z);
+        gA[row * SWS + o] *= s * (1.0f + z * (1.0f - s));
+    }
+    __syncthreads();
+    mm16(KM, TR, SO,
+         [&](int i, int k) { return W[g.o_Wm + k * KM + i]; },
+         [&](int k, int j) { return gA[j * SWS + k]; },
+         [&](int i, int j, float x) { gS[j * SWS + i] = x; }, lane, wv);
+    mm16(SO, KM, TR,
+         [&](int i, int k) { return gA[k * SWS + i]; },
+         [&](int k, int j) { return Sin[k * SWS + j]; },
+         [&](int i, int j, float x) { gp[g.o_Wm + i * KM + j] += x; }, lane, wv);
+    if (tid < SO) {
+        float s = 0.f;
+        for (int r = 0; r < TR; ++r) s += gA[r * SWS + tid];
+        gp[g.o_bm + tid] += s;
+    }
+    __syncthreads();
+    mm16(KH, 3 * TR, VO,
+         [&](int i, int k) { return W[g.o_Wu + i * VO + k]; },
+         [&](int k, int j) { return gVo[(j & 15) * VWS + k * 3 + (j >> 4)]; },
+         [&](int i, int j, float x) {
+             const int row = j & 15, cc = j >> 4;
+             const float* q = Vh + row * VWS + i * 3;
+             const float ss = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+             const float extra = ss > 1e-8f ? gS[row * SWS + SI + i] * q[cc] / Sin[row * SWS + SI + i] : 0.f;
+             gVh[row * VWS + i * 3 + cc] = x + extra;
+         }, lane, wv);
+    mm16(KH, VO, 3 * TR,
+         [&](int i, int k) { return Vh[(k & 15) * VWS + i * 3 + (k >> 4)]; },
+         [&](int k, int j) { return gVo[(k & 15) * VWS + j * 3 + (k >> 4)]; },
+         [&](int i, int j, float x) { gp[g.o_Wu + i * VO + j] += x; }, lane, wv);
+    __syncthreads();
+    mm16(VI, 3 * TR, KH,
+         [&](int i, int k) { return W[g.o_Wh + i * KH + k]; },
+         [&](int k, int j) { return gVh[(j & 15) * VWS + k * 3 + (j >> 4)]; },
+         [&](int i, int j, float x) { gVi[(j & 15) * VWS + i * 3 + (j >> 4)] = x; }, lane, wv);
+    mm16(VI, KH, 3 * TR,
+         [&](int i, int k) { return Vin[(k & 15) * VWS + i * 3 + (k >> 4)]; },
+         [&](int k, int j) { return gVh[(k & 15) * VWS + j * 3 + (k >> 4)]; },
+         [&](int i, int j, float x) { gp[g.o_Wh + i * KH + j] += x; }, lane, wv);
+    __syncthreads();
+}
+
+// forward recompute of a chain whose first-level inputs (Sin(0)[:, :si], Vin(0)) are in place.  The last level's gated
+// vectors go to vout_last when it is not null.
+__device__ __forceinline__ void chain_fwd(const ChainLds& L, const GvpT* g, const float* W, float* vout_last,
+                                          const int tid, const int lane, const int wv) {
+    for (int l = 0; l < L.nlv; ++l) {
+        const bool last = l == L.nlv - 1;
+        gvp_fwd(g[l], W, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+                last ? vout_last : L.Vin(l + 1), L.Vh, L.Vu, tid, lane, wv);
+    }
+}
+// backward through the chain: upstream gradients in L.gX ([row][so_last], stride SWS) and L.gVX; returns through
+// gs_out / gv_out the buffers that hold dL/d Sin(0) and dL/d Vin(0)
+__device__ __forceinline__ void chain_bwd(const ChainLds& L, const GvpT* g, const float* W, float* gp, float*& gs_out,
+                                          float*& gv_out, const int tid, const int lane, const int wv) {
+    float *ga = L.gX, *gs = L.gY, *gvo = L.gVX, *gvi = L.gVY;
+    for (int l = L.nlv - 1; l >= 0; --l) {
+        const bool last = l == L.nlv - 1;
+        gvp_bwd(g[l], W, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+                ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv);
+        float* t0 = ga; ga = gs; gs = t0;
+        float* t1 = gvo; gvo = gvi; gvi = t1;
+    }
+    gs_out = ga; gv_out = gvo;
+}
+
+// per-row mean over 128 features of f(row, feature); red: [16 parts][16 rows] LDS scratch.  All threads get the result
+// of their row (row = tid & 15).
+template <typename F>
+__device__ __forceinline__ float row_mean128(F f, float* red, const int tid) {
+    const int row = tid & 15, part = tid >> 4;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += f(row, part * 8 + q);
+    __syncthreads();
+    red[part * 16 + row] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q * 16 + row];
+    return tot * (1.0f / 128.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// noise head backward (dynamics_gvp.py:37-42)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
+    __shared__ float lds[CHAIN_FLOATS(PFT_MAX_CHAIN)];
+    __shared__ float s_ge[TR * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ChainLds L; L.init(lds, p.n_gvps);
+    const float* W = p.c.W;
+    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
+    const int NF = p.pharm_nf;
+    const int SOL = p.g[p.n_gvps - 1].so;            // 64
+    for (int ti = blockIdx.x; ti < p.ntiles; ti += gridDim.x) {
+        const NodeTile t = p.tiles[ti];
+        for (int sub = 0; sub * TR < t.n; ++sub) {
+            const int nv = min(TR, t.n - sub * TR);
+            const int n0 = t.n0 + sub * TR;
+            float* S0 = L.Sin(0); float* V0 = L.Vin(0);
+            for (int idx = tid; idx < TR * 32; idx += NT) {
+                const int row = idx >> 5, q = idx & 31;
+                const int n = n0 + min(row, nv - 1);
+                const float4 x = reinterpret_cast<const float4*>(p.h + (size_t)n * PF_S)[q];
+                float* d = S0 + row * SWS + 4 * q;
+                d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+            }
+            for (int idx = tid; idx < TR * 12; idx += NT) {
+                const int row = idx / 12, q = idx - row * 12;
+                const int n = n0 + min(row, nv - 1);
+                const float4 x = reinterpret_cast<const float4*>(p.v + (size_t)n * 48)[q];
+                float* d = V0 + row * VWS + 4 * q;
+                d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+            }
+            for (int idx = tid; idx < TR * NF; idx += NT) {
+                const int row = idx / NF, o = idx - row * NF;
+                s_ge[row * 8 + o] = row < nv ? p.g_eps_h[(size_t)(n0 - p.node_base + row) * NF + o] : 0.f;
+            }
+            __syncthreads();
+            chain_fwd(L, p.g, W, nullptr, tid, lane, wv);
+            // to_scalar_output: eps_h = Wout act + b ; eps_x = the single output vector channel
+            for (int idx = tid; idx < TR * SOL; idx += NT) {
+                const int row = idx & 15, k = idx >> 4;
+                float s = 0.f;
+                for (int o = 0; o < NF; ++o) s += W[p.o_Wout + o * SOL + k] * s_ge[row * 8 + o];
+                L.gX[row * SWS + k] = s;
+            }
+            for (int idx = tid; idx < NF * SOL; idx += NT) {
+                const int o = idx / SOL, k = idx - o * SOL;
+                float s = 0.f;
+                for (int r = 0; r < TR; ++r) s += s_ge[r * 8 + o] * L.actl[r * ZS + k];
+                gp[p.o_Wout + idx] += s;
+            }
+            if (tid < NF) {
+                float s = 0.f;
+                for (int r = 0; r < TR; ++r) s += s_ge[r * 8 + tid];
+                gp[p.o_bout + tid] += s;
+            }
+            for (int idx = tid; idx < TR * 3; idx += NT) {
+                const int row = idx / 3, cc = idx - row * 3;
+                L.gVX[row * VWS + cc] = row < nv ? p.g_eps_x[(size_t)(n0 - p.node_base + row) * 3 + cc] : 0.f;
+            }
+            __syncthreads();
+            float *gs, *gv;
+            chain_bwd(L, p.g, W, gp, gs, gv, tid, lane, wv);
+            for (int idx = tid; idx < TR * 128; idx += NT) {
+                const int row = idx >> 7, f = idx & 127;
+                if (row < nv) p.G_h[(size_t)(n0 + row) * PF_S + f] = gs[row * SWS + f];
+            }
+            for (int idx = tid; idx < TR * 48; idx += NT) {
+                const int row = idx / 48, q = idx - row * 48;
+                if (row < nv) p.G_v[(size_t)(n0 + row) * 48 + q] = gv[row * VWS + q];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// node update backward (gvp.py:499-536): recompute aggregate -> dropout -> residual -> LN -> update chain -> dropout
+// -> residual -> LN, then walk it backwards
+// ---------------------------------------------------------------------------------------------
+#define NODE_LVLS 3
+struct VecLn { float den, sq; };
+// GVPLayerNorm vector statistics of one row: den = sqrt(mean_ch max(|v_ch|^2, 1e-8) + 1e-5) + 1e-5 (gvp.py:163-165)
+__device__ __forceinline__ VecLn vec_ln_stats(const float* v) {
+    float m = 0.f;
+    for (int ch = 0; ch < PF_V; ++ch) m += fmaxf(v[ch * 3] * v[ch * 3] + v[ch * 3 + 1] * v[ch * 3 + 1] + v[ch * 3 + 2] * v[ch * 3 + 2], 1e-8f);
+    VecLn r;
+    r.sq = t_sqrt(m * (1.0f / PF_V) + 1e-5f);
+    r.den = r.sq + 1e-5f;
+    return r;
+}
+// gradient of out = v / den w.r.t. v for one row, in place on g (48 floats)
+__device__ __forceinline__ void vec_ln_bwd_row(const float* v, const VecLn st, float* g) {
+    float D = 0.f;
+    for (int q = 0; q < 48; ++q) D += g[q] * v[q];
+    const float coef = D / (st.den * st.den) / (PF_V * st.sq);
+    const float rden = 1.0f / st.den;
+    for (int ch = 0; ch < PF_V; ++ch) {
+        const float* q = v + ch * 3;
+        const float ind = (q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) > 1e-8f ? 1.0f : 0.0f;
+        for (int cc = 0; cc < 3; ++cc) g[ch * 3 + cc] = g[ch * 3 + cc] * rden - coef * ind * q[cc];
+    }
+}
+
+__global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
+    __shared__ float lds[CHAIN_FLOATS(NODE_LVLS)];
+    __shared__ float xh1[TR * ZS], xh2[TR * ZS], gu[TR * ZS];
+    __shared__ float vy[TR * VWS], vz[TR * VWS], gvu[TR * VWS], rvl[TR * VWS];
+    __shared__ float red[256];
+    __shared__ float s_rstd1[TR], s_rstd2[TR], s_inv[TR];
+    __shared__ VecLn s_vl1[TR], s_vl2[TR];
+    __shared__ int s_n[TR];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ChainLds L; L.init(lds, p.n_upd);
+    const float* W = p.c.W;
+    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
+    const uint32_t st_msg = (uint32_t)p.layer * 2u, st_res = st_msg + 1u;
+    for (int ti = blockIdx.x; ti < p.ntiles; ti += gridDim.x) {
+        const NodeTile t = p.tiles[ti];
+        const int nt = t.ntype;
+        const GvpT* g = p.upd + nt * p.n_upd;
+        const int o_l1w = p.o_ln[nt][0], o_l1b = p.o_ln[nt][1], o_l2w = p.o_ln[nt][2], o_l2b = p.o_ln[nt][3];
+        for (int sub = 0; sub * TR < t.n; ++sub) {
+            const int nv = min(TR, t.n - sub * TR);
+            const int n0 = t.n0 + sub * TR;
+            if (tid < TR) {
+                const int n = n0 + min(tid, nv - 1);
+                s_n[tid] = n;
+                float inv = 1.0f;
+                if (p.norm_mode == 1) inv = 1.0f / p.norm_value;
+                else if (p.norm_mode == 2) inv = 1.0f / p.gnorm[nt * p.B + p.gid[n]];
+                s_inv[tid] = inv;
+            }
+            __syncthreads();
+            // ---- aggregate the message partial rows (as k_node_update), dropout, residual
+            {
+                const int row = tid >> 4, part = tid & 15;
+                const int n = s_n[row];
+                float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mv[3] = {0, 0, 0};
+                for (int slot = 0; slot < 2; ++slot) {
+                    const int st = p.in_start[slot * p.N + n];
+                    const int c = p.in_cnt[slot * p.N + n];
+                    const float sc = (p.norm_mode == 0 && c > 0) ? 1.0f / (float)c : 1.0f;
+                    int e = st;
+                    while (e < st + c) {
+                        const int r = min(e | 31, st + c - 1);
+                        const float4 a = reinterpret_cast<const float4*>(p.msg_s + (size_t)r * PF_S)[part * 2];
+                        const float4 b = reinterpret_cast<const float4*>(p.msg_s + (size_t)r * PF_S)[part * 2 + 1];
+                        ms[0] = fmaf(a.x, sc, ms[0]); ms[1] = fmaf(a.y, sc, ms[1]); ms[2] = fmaf(a.z, sc, ms[2]); ms[3] = fmaf(a.w, sc, ms[3]);
+                        ms[4] = fmaf(b.x, sc, ms[4]); ms[5] = fmaf(b.y, sc, ms[5]); ms[6] = fmaf(b.z, sc, ms[6]); ms[7] = fmaf(b.w, sc, ms[7]);
+                        const float* vr = p.msg_v + (size_t)r * 48 + part * 3;
+                        mv[0] = fmaf(vr[0], sc, mv[0]); mv[1] = fmaf(vr[1], sc, mv[1]); mv[2] = fmaf(vr[2], sc, mv[2]);
+                        e = r + 1;
+                    }
+                }
+                const float inv = s_inv[row];
+                const float* hin = p.h_in + (size_t)n * PF_S + part * 8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float dm = drop_mul(p.c, st_msg, (uint32_t)n * 144u + (uint32_t)(part * 8 + q));
+                    xh1[row * ZS + part * 8 + q] = hin[q] + ms[q] * inv * dm;
+                }
+                const float dmv = drop_mul(p.c, st_msg, (uint32_t)n * 144u + 128u + (uint32_t)part);
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const float v0 = p.l0 ? 0.f : p.v_in[(size_t)n * 48 + part * 3 + cc];
+                    vy[row * VWS + part * 3 + cc] = v0 + mv[cc] * inv * dmv;
+                }
+            }
+            __syncthreads();
+            // ---- LN1: u -> Sin(0), vu -> Vin(0)
+            {
+                const float mean = row_mean128([&](int r, int f) { return xh1[r * ZS + f]; }, red, tid);
+                const float var = row_mean128([&](int r, int f) { const float d = xh1[r * ZS + f] - mean; return d * d; }, red, tid);
+                const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+                const int row = tid & 15, part = tid >> 4;
+                if (part == 0) { s_rstd1[row] = rstd; s_vl1[row] = vec_ln_stats(vy + row * VWS); }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int f = part * 8 + q;
+                    const float xh = (xh1[row * ZS + f] - mean) * rstd;
+                    xh1[row * ZS + f] = xh;
+                    L.Sin(0)[row * SWS + f] = xh * W[o_l1w + f] + W[o_l1b + f];
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < TR * 48; idx += NT) {
+                const int row = idx & 15, q = idx >> 4;
+                L.Vin(0)[row * VWS + q] = vy[row * VWS + q] / s_vl1[row].den;
+            }
+            __syncthreads();
+            chain_fwd(L, g, W, rvl, tid, lane, wv);
+            // ---- residual dropout, residual, LN2 statistics
+            for (int idx = tid; idx < TR * 128; idx += NT) {
+                const int row = idx & 15, f = idx >> 4;
+                const float dm = drop_mul(p.c, st_res, (uint32_t)s_n[row] * 144u + (uint32_t)f);
+                xh2[row * ZS + f] = L.Sin(0)[row * SWS + f] + L.actl[row * ZS + f] * dm;
+            }
+            for (int idx = tid; idx < TR * 48; idx += NT) {
+                const int row = idx & 15, q = idx >> 4;
+                const float dm = drop_mul(p.c, st_res, (uint32_t)s_n[row] * 144u + 128u + (uint32_t)(q / 3));
+                vz[row * VWS + q] = L.Vin(0)[row * VWS + q] + rvl[row * VWS + q] * dm;
+            }
+            __syncthreads();
+            {
+                const float mean = row_mean128([&](int r, int f) { return xh2[r * ZS + f]; }, red, tid);
+                const float var = row_mean128([&](int r, int f) { const float d = xh2[r * ZS + f] - mean; return d * d; }, red, tid);
+                const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+                const int row = tid & 15, part = tid >> 4;
+                if (part == 0) { s_rstd2[row] = rstd; s_vl2[row] = vec_ln_stats(vz + row * VWS); }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int f = part * 8 + q;
+                    xh2[row * ZS + f] = (xh2[row * ZS + f] - mean) * rstd;
+                }
+            }
+            __syncthreads();
+            // ---- backward: LN2
+            for (int idx = tid; idx < TR * 128; idx += NT) {
+                const int row = idx >> 7, f = idx & 127;
+                gu[row * ZS + f] = row < nv ? p.G_h_out[(size_t)s_n[row] * PF_S + f] : 0.f;
+            }
+            for (int idx = tid; idx < TR * 48; idx += NT) {
+                const int row = idx / 48, q = idx - row * 48;
+                gvu[row * VWS + q] = row < nv ? p.G_v_out[(size_t)s_n[row] * 48 + q] : 0.f;
+            }
+            __syncthreads();
+            if (tid < 128) {
+                float sw = 0.f, sb = 0.f;
+                for (int r = 0; r < TR; ++r) { const float go = gu[r * ZS + tid]; sw += go * xh2[r * ZS + tid]; sb += go; }
+                gp[o_l2w + tid] += sw;
+                gp[o_l2b + tid] += sb;
+            }
+            {
+                const float m1 = row_mean128([&](int r, int f) { return gu[r * ZS + f] * W[o_l2w + f]; }, red, tid);
+                const float m2 = row_mean128([&](int r, int f) { return gu[r * ZS + f] * W[o_l2w + f] * xh2[r * ZS + f]; }, red, tid);
+                const int row = tid & 15, part = tid >> 4;
+                const float rstd = s_rstd2[row];
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int f = part * 8 + q;
+                    const float gz = rstd * (gu[row * ZS + f] * W[o_l2w + f] - m1 - xh2[row * ZS + f] * m2);
+                    gu[row * ZS + f] = gz;                                     // dL/du (residual path)
+                    L.gX[row * SWS + f] = gz * drop_mul(p.c, st_res, (uint32_t)s_n[row] * 144u + (uint32_t)f);
+                }
+                if (tid < TR) vec_ln_bwd_row(vz + tid * VWS, s_vl2[tid], gvu + tid * VWS);
+            }
+            __syncthreads();
+            for (int idx = tid; idx < TR * 48; idx += NT) {
+                const int row = idx & 15, q = idx >> 4;
+                L.gVX[row * VWS + q] = gvu[row * VWS + q] * drop_mul(p.c, st_res, (uint32_t)s_n[row] * 144u + 128u + (uint32_t)(q / 3));
+            }
+            __syncthreads();
+            float *gs, *gv;
+            chain_bwd(L, g, W, gp, gs, gv, tid, lane, wv);
+            // ---- LN1 backward
+            for (int idx = tid; idx < TR * 128; idx += NT) {
+                const int row = idx & 15, f = idx >> 4;
+                gu[row * ZS + f] += gs[row * SWS + f];
+            }
+            for (int idx = tid; idx < TR * 48; idx += NT) {
+                const int row = idx & 15, q = idx >> 4;
+                gvu[row * VWS + q] = (gvu[row * VWS + q] + gv[row * VWS + q]) ;
+            }
+            __syncthreads();
+            if (tid < 128) {
+                float sw = 0.f, sb = 0.f;
+                for (int r = 0; r < TR; ++r) { const float go = gu[r * ZS + tid]; sw += go * xh1[r * ZS + tid]; sb += go; }
+                gp[o_l1w + tid] += sw;
+                gp[o_l1b + tid] += sb;
+            }
+            {
+                const float m1 = row_mean128([&](int r, int f) { return gu[r * ZS + f] * W[o_l1w + f]; }, red, tid);
+                const float m2 = row_mean128([&](int r, int f) { return gu[r * ZS + f] * W[o_l1w + f] * xh1[r * ZS + f]; }, red, tid);
+                const int row = tid & 15, part = tid >> 4;
+                const float rstd = s_rstd1[row];
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int f = part * 8 + q;
+                    gu[row * ZS + f] = rstd * (gu[row * ZS + f] * W[o_l1w + f] - m1 - xh1[row * ZS + f] * m2);   // dL/dy
+                }
+                if (tid < TR) {
+                    // the LN divides vy by den: gvu currently holds dL/d vu
+                    vec_ln_bwd_row(vy + tid * VWS, s_vl1[tid], gvu + tid * VWS);
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < TR * 128; idx += NT) {
+                const int row = idx >> 7, f = idx & 127;
+                if (row < nv) {
+                    const int n = s_n[row];
+                    const float gy = gu[row * ZS + f];
+                    p.G_h_in[(size_t)n * PF_S + f] = gy;
+                    p.gagg_s[(size_t)n * PF_S + f] = gy * s_inv[row] * drop_mul(p.c, st_msg, (uint32_t)n * 144u + (uint32_t)f);
+                }
+            }
+            for (int idx = tid; idx < TR * 48; idx += NT) {
+                const int row = idx / 48, q = idx - row * 48;
+                if (row < nv) {
+                    const int n = s_n[row];
+                    const float gy = gvu[row * VWS + q];
+                    if (!p.l0) p.G_v_in[(size_t)n * 48 + q] = gy;
+                    p.gagg_v[(size_t)n * 48 + q] = gy * s_inv[row] * drop_mul(p.c, st_msg, (uint32_t)n * 144u + 128u + (uint32_t)(q / 3));
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// edge message backward (gvp.py:472-485, 540-551): recompute the message chain of 16 edges, push the destination's
+// aggregate gradient through it, accumulate weight gradients and scatter the source-row gradients
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 1) void k_bwd_edge(const BwdEdgeParams p) {
+    __shared__ float lds[CHAIN_FLOATS(PFT_MAX_CHAIN)];
+    __shared__ int s_src[TR], s_dst[TR];
+    __shared__ float s_sc[TR];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ChainLds L; L.init(lds, p.n_gvps);
+    const float* W = p.c.W;
+    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
+    for (int ti = blockIdx.x; ti < p.ntiles; ti += gridDim.x) {
+        const EdgeTile t = p.tiles[ti];
+        int nvalid = t.n;
+        if (t.cnt_idx >= 0) nvalid = min(nvalid, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
+        const GvpT* g = p.g + t.et * p.n_gvps;
+        const int slot = (t.et == ET_FF || t.et == ET_FP) ? 0 : 1;
+        for (int sub = 0; sub * TR < nvalid; ++sub) {
+            const int nv = min(TR, nvalid - sub * TR);
+            const int e0 = t.e0 + sub * TR;
+            float* S0 = L.Sin(0); float* V0 = L.Vin(0);
+            if (tid < TR) {
+                const int e = e0 + min(tid, nv - 1);
+                const int src = p.esrc[e], dst = p.edst[e];
+                s_src[tid] = src; s_dst[tid] = dst;
+                const float4 xs = p.xn[src], xd = p.xn[dst];
+                const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
+                const float d = t_sqrt(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+                const float rd = __builtin_amdgcn_rcpf(d);
+                V0[tid * VWS + 0] = dx * rd; V0[tid * VWS + 1] = dy * rd; V0[tid * VWS + 2] = dz * rd;
+                for (int k = 0; k < PF_R; ++k) {
+                    const float z = (d - p.rbf_mu[k]) * p.rbf_inv_sigma;
+                    S0[tid * SWS + PF_S + k] = __expf(-(z * z));
+                }
+                float sc = 1.0f;
+                if (p.norm_mode == 0) sc = 1.0f / (float)p.in_cnt[slot * p.N + dst];
+                s_sc[tid] = tid < nv ? sc : 0.f;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < TR * 32; idx += NT) {
+                const int row = idx >> 5, q = idx & 31;
+                const float4 x = reinterpret_cast<const float4*>(p.h + (size_t)s_src[row] * PF_S)[q];
+                float* d = S0 + row * SWS + 4 * q;
+                d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+            }
+            for (int idx = tid; idx < TR * 12; idx += NT) {
+                const int row = idx / 12, q = idx - row * 12;
+                float4 x = {0.f, 0.f, 0.f, 0.f};
+                if (!p.l0) x = reinterpret_cast<const float4*>(p.v + (size_t)s_src[row] * 48)[q];
+                float* d = V0 + row * VWS + 3 + 4 * q;
+                d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+            }
+            __syncthreads();
+            chain_fwd(L, g, W, nullptr, tid, lane, wv);
+            for (int idx = tid; idx < TR * 128; idx += NT) {
+                const int row = idx >> 7, f = idx & 127;
+                L.gX[row * SWS + f] = p.gagg_s[(size_t)s_dst[row] * PF_S + f] * s_sc[row];
+            }
+            for (int idx = tid; idx < TR * 48; idx += NT) {
+                const int row = idx / 48, q = idx - row * 48;
+                L.gVX[row * VWS + q] = p.gagg_v[(size_t)s_dst[row] * 48 + q] * s_sc[row];
+            }
+            __syncthreads();
+            float *gs, *gv;
+            chain_bwd(L, g, W, gp, gs, gv, tid, lane, wv);
+            for (int idx = tid; idx < TR * 128; idx += NT) {
+                const int row = idx >> 7, f = idx & 127;
+                if (row < nv) unsafeAtomicAdd(p.G_h_in + (size_t)s_src[row] * PF_S + f, gs[row * SWS + f]);
+            }
+            if (!p.l0)
+                for (int idx = tid; idx < TR * 48; idx += NT) {
+                    const int row = idx / 48, q = idx - row * 48;
+                    if (row < nv) unsafeAtomicAdd(p.G_v_in + (size_t)s_src[row] * 48 + q, gv[row * VWS + 3 + q]);
+                }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// encoders backward: LayerNorm(SiLU(Linear([h, t])))  (dynamics_gvp.py:107-117,143-151)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 1) void k_bwd_encode(const BwdEncodeParams p) {
+    __shared__ float sin_[TR * 17], z[TR * ZS], xh[TR * ZS], gq[TR * ZS];
+    __shared__ float red[256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* W = p.c.W;
+    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
+    const int N = p.Np + p.Nf;
+    const int tiles_prot = (p.Np + TR - 1) / TR, tiles_pharm = (p.Nf + TR - 1) / TR;
+    for (int ti = blockIdx.x; ti < tiles_prot + tiles_pharm; ti += gridDim.x) {
+        const int nt = ti < tiles_prot ? 0 : 1;
+        const int first = nt ? p.Np + (ti - tiles_prot) * TR : ti * TR;
+        const int end = nt ? N : p.Np;
+        const int nv = min(TR, end - first);
+        const int nf = nt ? p.pharm_nf : p.rec_nf;
+        const int K = nf + 1;
+        const int ow = p.o_w[nt], ob = p.o_b[nt], olw = p.o_lw[nt], olb = p.o_lb[nt];
+        for (int idx = tid; idx < TR * K; idx += NT) {
+            const int row = idx / K, k = idx - row * K;
+            const int n = first + min(row, nv - 1);
+            float x;
+            if (k < nf) x = nt ? p.pharm_h[(size_t)(n - p.Np) * nf + k] : p.prot_h0[(size_t)n * nf + k];
+            else x = p.t[p.gid[n]];
+            sin_[row * 17 + k] = x;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < TR * 128; idx += NT) {
+            const int row = idx & 15, o = idx >> 4;
+            float s = W[ob + o];
+            for (int k = 0; k < K; ++k) s = fmaf(W[ow + o * K + k], sin_[row * 17 + k], s);
+            z[row * ZS + o] = s;
+            xh[row * ZS + o] = t_silu(s);
+        }
+        __syncthreads();
+        {
+            const float mean = row_mean128([&](int r, int f) { return xh[r * ZS + f]; }, red, tid);
+            const float var = row_mean128([&](int r, int f) { const float d = xh[r * ZS + f] - mean; return d * d; }, red, tid);
+            const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+            const int row = tid & 15, part = tid >> 4;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int f = part * 8 + q;
+                xh[row * ZS + f] = (xh[row * ZS + f] - mean) * rstd;
+            }
+            for (int idx = tid; idx < TR * 128; idx += NT) {
+                const int r = idx >> 7, f = idx & 127;
+                gq[r * ZS + f] = r < nv ? p.G_h[(size_t)(first + r) * PF_S + f] : 0.f;
+            }
+            __syncthreads();
+            if (tid < 128) {
+                float sw = 0.f, sb = 0.f;
+                for (int r = 0; r < TR; ++r) { const float go = gq[r * ZS + tid]; sw += go * xh[r * ZS + tid]; sb += go; }
+                gp[olw + tid] += sw;
+                gp[olb + tid] += sb;
+            }
+            const float m1 = row_mean128([&](int r, int f) { return gq[r * ZS + f] * W[olw + f]; }, red, tid);
+            const float m2 = row_mean128([&](int r, int f) { return gq[r * ZS + f] * W[olw + f] * xh[r * ZS + f]; }, red, tid);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int f = part * 8 + q;
+                const float ga = rstd * (gq[row * ZS + f] * W[olw + f] - m1 - xh[row * ZS + f] * m2);
+                const float zz = z[row * ZS + f];
+                const float s = t_sigmoid(zz);
+                gq[row * ZS + f] = ga * s * (1.0f + zz * (1.0f - s));            // dL/dz
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 128 * K; idx += NT) {
+            const int o = idx / K, k = idx - o * K;
+            float s = 0.f;
+            for (int r = 0; r < TR; ++r) s += gq[r * ZS + o] * sin_[r * 17 + k];
+            gp[ow + idx] += s;
+        }
+        if (tid < 128) {
+            float s = 0.f;
+            for (int r = 0; r < TR; ++r) s += gq[r * ZS + tid];
+            gp[ob + tid] += s;
+        }
+        __syncthreads();
+    }
+    (void)lane; (void)wv;
+}
+
+// grad[i] = sum over the per-block copies, in block order
+__global__ void k_train_reduce(const float* gpart, const int nblocks, const int nparams, float* grad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nparams) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += gpart[(size_t)b * nparams + i];
+    grad[i] = s;
+}
+
+// dropout masks as the forward applies them, for tests: out[(node * 144 + elem)] in {0, 1/(1-p)}
+__global__ void k_drop_masks(const TrainCommon c, const uint32_t stream, const int n_elems, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_elems) out[i] = drop_mul(c, stream, (uint32_t)i);
+}
+
+extern "C" {
+void pfk_bwd_head(const BwdHeadParams* p, int nblocks, hipStream_t s) {
+    if (p->ntiles == 0) return;
+    hipLaunchKernelGGL(k_bwd_head, dim3(nblocks), dim3(NT), 0, s, *p);
+}
+void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s) {
+    if (p->ntiles == 0) return;
+    hipLaunchKernelGGL(k_bwd_node, dim3(nblocks), dim3(NT), 0, s, *p);
+}
+void pfk_bwd_edge(const BwdEdgeParams* p, int nblocks, hipStream_t s) {
+    if (p->ntiles == 0) return;
+    hipLaunchKernelGGL(k_bwd_edge, dim3(nblocks), dim3(NT), 0, s, *p);
+}
+void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_bwd_encode, dim3(nblocks), dim3(NT), 0, s, *p);
+}
+void pfk_train_reduce(const float* gpart, int nblocks, int nparams, float* grad, hipStream_t s) {
+    hipLaunchKernelGGL(k_train_reduce, dim3((nparams + 255) / 256), dim3(256), 0, s, gpart, nblocks, nparams, grad);
+}
+void pfk_drop_masks(const TrainCommon* c, uint32_t stream, int n_elems, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_drop_masks, dim3((n_elems + 255) / 256), dim3(256), 0, s, *c, stream, n_elems, out);
+}
+}

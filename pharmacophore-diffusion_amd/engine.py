@@ -120,6 +120,53 @@ class PfEngine:
                                                   _dptr(eps_x), _stream_ptr()), "pf_dynamics_forward")
         return eps_h, eps_x
 
+    # -- training step (gradients of the boundary function) -------------------------------------
+    def param_layout(self):
+        """[(reference key, offset, numel)] of the flat parameter / gradient vector (state-dict order)."""
+        n = ctypes.c_int64()
+        nt = ctypes.c_int32()
+        self._ck(self.lib.pf_param_count(self._h, ctypes.byref(n), ctypes.byref(nt)), "pf_param_count")
+        out = []
+        for i in range(nt.value):
+            name = ctypes.c_char_p()
+            off = ctypes.c_int64()
+            cnt = ctypes.c_int64()
+            self._ck(self.lib.pf_param_layout(self._h, i, ctypes.byref(name), ctypes.byref(off), ctypes.byref(cnt)), "pf_param_layout")
+            out.append((name.value.decode(), off.value, cnt.value))
+        self.n_params = n.value
+        return out
+
+    def train_forward(self, pharm_x, pharm_h, t, prot_x=None, dropout=0.0, seed=0):
+        """PharmRecDynamicsGVP.forward in train() mode; keeps the per-layer state for train_backward."""
+        x, hh, tt = _f32(pharm_x, self.device), _f32(pharm_h, self.device), _f32(t, self.device)
+        px = _f32(prot_x, self.device) if prot_x is not None else None
+        eps_h = torch.empty(self.Nf, self.pharm_nf, device=self.device)
+        eps_x = torch.empty(self.Nf, 3, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_train_forward(self._h, _dptr(px), _dptr(x), _dptr(hh), _dptr(tt), float(dropout),
+                                               int(seed) & 0xFFFFFFFF, _dptr(eps_h), _dptr(eps_x), _stream_ptr()),
+                     "pf_train_forward")
+        return eps_h, eps_x
+
+    def train_backward(self, g_eps_h, g_eps_x):
+        """d(loss)/d(parameters) as one flat vector (see param_layout) given d(loss)/d(eps)."""
+        gh, gx = _f32(g_eps_h, self.device), _f32(g_eps_x, self.device)
+        if not hasattr(self, "n_params"):
+            self.param_layout()
+        grad = torch.empty(self.n_params, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_train_backward(self._h, _dptr(gh), _dptr(gx), _dptr(grad), _stream_ptr()), "pf_train_backward")
+        return grad
+
+    def dropout_mask(self, layer, which, dropout, seed):
+        """[N, 144] multipliers of conv layer ``layer`` (which: 0 message, 1 residual dropout); rows are global node
+        ids (protein atoms first), columns 128 scalar features then 16 vector channels."""
+        out = torch.empty(self.Np + self.Nf, 144, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_debug_dropout_mask(self._h, layer, which, float(dropout), int(seed) & 0xFFFFFFFF,
+                                                    _dptr(out), _stream_ptr()), "pf_debug_dropout_mask")
+        return out
+
     # -- sampling ------------------------------------------------------------------------------
     @staticmethod
     def coef_array(coef: Dict[str, torch.Tensor], order):

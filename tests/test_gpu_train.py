@@ -1,0 +1,102 @@
+"""Gradient parity of the HIP training path (pf_train_forward / pf_train_backward) against the oracle's autograd
+and the reference's own gradients (tests/golden/train_grads*.npz)."""
+import pytest
+import torch
+
+from oracle import pf_oracle as O
+from helpers import GRAD_CASES, batch_from, load
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(cfg, sd, batch):
+    import pharmacoforge_amd as pfa
+    eng = pfa.PfEngine(pharm_nf=cfg.pharm_nf, rec_nf=cfg.rec_nf, n_convs=cfg.n_convs,
+                       n_message_gvps=cfg.n_message_gvps, n_update_gvps=cfg.n_update_gvps,
+                       n_noise_gvps=cfg.n_noise_gvps, message_norm=cfg.message_norm, ff_k=cfg.ff_k, pf_k=cfg.pf_k,
+                       graph_cutoffs={"pp": cfg.cutoff_pp, "pf": cfg.cutoff_pf, "fp": cfg.cutoff_fp, "ff": cfg.cutoff_ff})
+    eng.load_state_dict(sd)
+    eng.set_batch(batch.prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst)
+    return eng
+
+
+def noised_inputs(cfg, batch, z, T):
+    """x_t, h_t, prot_x, t of PharmacophoreDiff.forward (pharmacodiff.py:179-199), via the oracle's algebra."""
+    bidx = batch.batch_idxs()
+    com = O.segment_mean(z["x0"], batch.pharm_ptr)
+    x0 = z["x0"] - com[bidx["pharm"]]
+    prot_x = batch.prot_x - com[bidx["prot"]]
+    t = z["t_int"].float() / T
+    gamma = O.gamma_table(T, 1e-5)
+    gt = O.gamma_lookup(gamma, t, T)
+    a = O.alpha(gt)[bidx["pharm"]][:, None]
+    s = O.sigma(gt)[bidx["pharm"]][:, None]
+    x_t = a * x0 + s * z["eps_x"]
+    h_t = a * z["h0"] + s * z["eps_h"]
+    c = O.segment_mean(x_t, batch.pharm_ptr)
+    return x_t - c[bidx["pharm"]], h_t, prot_x - c[bidx["prot"]], t
+
+
+def masks_from_engine(eng, cfg, p, seed, Np, Nf):
+    out = []
+    for layer in range(cfg.n_convs):
+        m0 = eng.dropout_mask(layer, 0, p, seed).cpu()
+        m1 = eng.dropout_mask(layer, 1, p, seed).cpu()
+        d = {}
+        for nt, sl in (("prot", slice(0, Np)), ("pharm", slice(Np, Np + Nf))):
+            d[nt] = (m0[sl, :128], m0[sl, 128:], m1[sl, :128], m1[sl, 128:])
+        out.append(d)
+    return out
+
+
+def flat_to_dict(eng, grad):
+    g = grad.cpu()
+    return {name: g[off:off + n] for name, off, n in eng.param_layout()}
+
+
+def compare(got, ref, tol, what):
+    bad = []
+    for k, r in ref.items():
+        if r.numel() == 0:
+            continue
+        g = got[k].reshape(r.shape)
+        scale = float(r.abs().max())
+        err = float((g - r).abs().max())
+        if err > tol * scale + 1e-7:
+            bad.append((k, err, scale))
+    assert not bad, (what, bad[:8], len(bad))
+
+
+@pytest.mark.parametrize("name", sorted(GRAD_CASES))
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_gradients_vs_oracle(name, p_drop):
+    z = load(name)
+    cfg = GRAD_CASES[name]
+    batch = batch_from(z)
+    T = int(z["T"])
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    eng = make_engine(cfg, sd, batch)
+    x_t, h_t, prot_x, t = noised_inputs(cfg, batch, z, T)
+    Np, Nf = int(batch.prot_ptr[-1]), int(batch.pharm_ptr[-1])
+    seed = 1234
+    eps_h, eps_x = eng.train_forward(x_t, h_t, t, prot_x=prot_x, dropout=p_drop, seed=seed)
+    drop = masks_from_engine(eng, cfg, p_drop, seed, Np, Nf) if p_drop > 0 else None
+    if drop is not None:
+        keep = torch.cat([m.reshape(-1) for d in drop for nt in d for m in d[nt]])
+        assert set(keep.unique().tolist()) <= {0.0, float(torch.tensor(1.0 / (1.0 - p_drop), dtype=torch.float32))}
+        frac = float((keep == 0).float().mean())
+        assert abs(frac - p_drop) < 0.02, frac
+    # oracle: same inputs, same masks; loss = sum of the two MSE-style terms of pharmacodiff.py:208-232
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    with torch.enable_grad():
+        oh, ox = O.dynamics_forward(leaf, cfg, batch, prot_x, x_t, h_t, t, dropout=drop)
+        loss = (z["eps_x"] - ox).square().sum() / z["eps_x"].numel() + (z["eps_h"] - oh).square().sum() / z["eps_h"].numel()
+        loss.backward()
+    assert float((eps_h.cpu() - oh.detach()).abs().max()) < 2e-4
+    assert float((eps_x.cpu() - ox.detach()).abs().max()) < 2e-4
+    g_h = (-2.0 / z["eps_h"].numel()) * (z["eps_h"] - eps_h.cpu())
+    g_x = (-2.0 / z["eps_x"].numel()) * (z["eps_x"] - eps_x.cpu())
+    grad = eng.train_backward(g_h, g_x)
+    got = flat_to_dict(eng, grad)
+    ref = {k: (torch.zeros_like(v) if v.grad is None else v.grad) for k, v in leaf.items()}
+    compare(got, ref, 2e-3, name)
