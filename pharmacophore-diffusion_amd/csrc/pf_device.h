@@ -90,6 +90,9 @@ struct EdgeParams {
     int n_gvps;
     float rbf_mu[PF_R];
     float rbf_inv_sigma;
+    // training forward (one-wave kernel only): per message-GVP level l and edge slot e, Z (pre-activation scalars),
+    // the gate pre-activations and the gated output vectors go to sv_*[(l * sv_stride + e)]; NULL: inference
+    float* sv_z; float* sv_g; float* sv_v; size_t sv_stride;
 };
 
 struct NodeW {             // per node type

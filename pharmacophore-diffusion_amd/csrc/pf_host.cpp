@@ -38,6 +38,7 @@ void pfk_export_coords(const float4* xn, int base, int n, const int* gid, const 
 void pfk_bwd_head(const BwdHeadParams* p, int nblocks, hipStream_t s);
 void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s);
 void pfk_bwd_edge(const BwdEdgeParams* p, int nblocks, hipStream_t s);
+void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, hipStream_t s);
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
 void pfk_train_reduce(const float* gpart, int nblocks, int nparams, float* grad, hipStream_t s);
 void pfk_drop_masks(const TrainCommon* c, uint32_t stream, int n_elems, float* out, hipStream_t s);
@@ -135,6 +136,9 @@ struct pf_handle {
     GvpT* d_gvpt = nullptr;                 // same indexing as the GvpW table
     void* d_tws = nullptr;                  // training workspace of the current batch (allocated on first use)
     std::vector<float*> t_H, t_V, t_msg_s, t_msg_v;
+    std::vector<float*> t_sv_z, t_sv_g, t_sv_v;     // per layer: [n_message_gvps][Ecap] rows saved by the forward
+    float *t_gs_buf = nullptr, *t_gv_buf = nullptr;
+    int et_tile0[5] = {0, 0, 0, 0, 0};      // tile ranges of ff, pf, fp, pp in d_edge_tiles
     float *t_G_h[2] = {nullptr, nullptr}, *t_G_v[2] = {nullptr, nullptr}, *t_gagg_s = nullptr, *t_gagg_v = nullptr,
           *t_gpart = nullptr, *t_geps_h = nullptr, *t_geps_x = nullptr;
     int t_nblk = 0;
@@ -444,7 +448,11 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
         e.rbf_inv_sigma = 1.0f / ((c.rbf_dmax - 0.f) / (float)c.rbf_dim);
         // few tiles (last layer): 4 waves per tile to cut the serial latency; otherwise one wave per tile
-        if (e.ntiles <= h->coop_edge_max) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
+        if (train) {
+            e.sv_z = h->t_sv_z[l]; e.sv_g = h->t_sv_g[l]; e.sv_v = h->t_sv_v[l];
+            e.sv_stride = (size_t)std::max<int64_t>(h->Ecap, 1);
+        }
+        if (e.ntiles <= h->coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
 
         NodeParams n{};
@@ -762,6 +770,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     // tiles: dynamic etypes first (they feed the short pharm-side chain), then pp
     std::vector<EdgeTile> et_tiles;
     for (int et = 0; et < 3; ++et) {
+        h->et_tile0[et] = (int)et_tiles.size();
         for (int g = 0; g < B; ++g) {
             const int cap = h->h_cap[(size_t)et * B + g], reg = h->h_reg[(size_t)et * B + g];
             for (int o = 0; o < cap; o += 32) et_tiles.push_back({reg + o, std::min(32, cap - o), et, et * B + g, o});
@@ -771,7 +780,9 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
         // tiles are computed; the reference computes and discards the protein side.
         if (et == ET_PF) h->n_edge_tiles_last = (int)et_tiles.size();
     }
+    h->et_tile0[3] = (int)et_tiles.size();
     for (int64_t o = 0; o < n_pp; o += 32) et_tiles.push_back({(int)o, (int)std::min<int64_t>(32, n_pp - o), ET_PP, -1, 0});
+    h->et_tile0[4] = (int)et_tiles.size();
     std::vector<NodeTile> n_tiles, h_tiles;
     for (int o = 0; o < Nf; o += 32) {
         n_tiles.push_back({Np + o, std::min(32, Nf - o), 1, -1, 0, 0});
@@ -1087,7 +1098,7 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
         PF_FAIL(h, PF_ERR_ARG, "training supports pharm_nf <= 8 and rec_nf <= 16");
     const int L = c.n_convs, N = h->N;
     const size_t E1 = (size_t)h->Ecap + 1;
-    h->t_nblk = std::max(1, std::min(256, h->n_edge_tiles));
+    h->t_nblk = std::max(8, std::min(256, h->n_edge_tiles));
     size_t bytes = 0;
     auto need = [&](size_t n_floats) { bytes += (n_floats * 4 + 255) & ~size_t(255); };
     for (int l = 0; l <= L; ++l) { need((size_t)N * PF_S); need((size_t)N * 48); }
@@ -1095,6 +1106,9 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     for (int a = 0; a < 2; ++a) { need((size_t)N * PF_S); need((size_t)N * 48); }
     need((size_t)N * PF_S); need((size_t)N * 48);
     need((size_t)h->t_nblk * h->nparams);
+    const size_t Es = (size_t)std::max<int64_t>(h->Ecap, 1), ng = (size_t)c.n_message_gvps;
+    for (int l = 0; l < L; ++l) { need(ng * Es * PF_S); need(ng * Es * 16); need(ng * Es * 48); }
+    need(Es * PF_S); need(Es * 48);
     PF_HIP(h, hipMalloc(&h->d_tws, bytes + 4096));
     char* cur = reinterpret_cast<char*>(h->d_tws);
     h->t_H.assign(L + 1, nullptr); h->t_V.assign(L + 1, nullptr); h->t_msg_s.assign(L, nullptr); h->t_msg_v.assign(L, nullptr);
@@ -1103,6 +1117,12 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     for (int a = 0; a < 2; ++a) { h->t_G_h[a] = carve<float>(cur, (size_t)N * PF_S); h->t_G_v[a] = carve<float>(cur, (size_t)N * 48); }
     h->t_gagg_s = carve<float>(cur, (size_t)N * PF_S); h->t_gagg_v = carve<float>(cur, (size_t)N * 48);
     h->t_gpart = carve<float>(cur, (size_t)h->t_nblk * h->nparams);
+    h->t_sv_z.assign(L, nullptr); h->t_sv_g.assign(L, nullptr); h->t_sv_v.assign(L, nullptr);
+    for (int l = 0; l < L; ++l) {
+        h->t_sv_z[l] = carve<float>(cur, ng * Es * PF_S); h->t_sv_g[l] = carve<float>(cur, ng * Es * 16);
+        h->t_sv_v[l] = carve<float>(cur, ng * Es * 48);
+    }
+    h->t_gs_buf = carve<float>(cur, Es * PF_S); h->t_gv_buf = carve<float>(cur, Es * 48);
     // message buffers: the zero row (index Ecap) must read as zeros; V[0] is the all-zero initial vector state
     for (int l = 0; l < L; ++l) {
         PF_HIP(h, hipMemsetAsync(h->t_msg_s[l], 0, E1 * PF_S * 4, s));
@@ -1195,18 +1215,36 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         }
         n.layer = l; n.l0 = l == 0;
         pfk_bwd_node(&n, std::max(1, std::min(nb, n.ntiles)), s);
-        BwdEdgeParams e{};
-        e.c = tc; e.tiles = h->d_edge_tiles; e.ntiles = h->n_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
+        BwdEdgeLevelParams e{};
+        e.c = tc; e.tiles = h->d_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
+        // blocks per etype in proportion to its tiles (at least one where there are tiles)
+        {
+            const int tot = std::max(1, h->et_tile0[4]);
+            int b0 = 0;
+            for (int et = 0; et < 4; ++et) {
+                e.et_tile0[et] = h->et_tile0[et];
+                e.et_blk0[et] = b0;
+                const int nt_et = h->et_tile0[et + 1] - h->et_tile0[et];
+                int nbk = nt_et > 0 ? std::max(1, (int)((int64_t)(nb - 3) * nt_et / tot)) : 0;
+                nbk = std::min(nbk, nt_et);
+                b0 += nbk;
+            }
+            e.et_tile0[4] = h->et_tile0[4]; e.et_blk0[4] = b0;
+            if (b0 > nb) PF_FAIL(h, PF_ERR_STATE, "internal: block partition exceeds the gradient copies");
+        }
         e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;
         e.h = h->t_H[l]; e.v = h->t_V[l];
         e.gagg_s = h->t_gagg_s; e.gagg_v = h->t_gagg_v; e.in_cnt = h->d_in_cnt; e.N = N;
         e.norm_mode = c.message_norm_mode;
         e.G_h_in = h->t_G_h[a ^ 1]; e.G_v_in = h->t_G_v[a ^ 1];
+        e.sv_z = h->t_sv_z[l]; e.sv_g = h->t_sv_g[l]; e.sv_v = h->t_sv_v[l];
+        e.sv_stride = (size_t)std::max<int64_t>(h->Ecap, 1);
+        e.gs_buf = h->t_gs_buf; e.gv_buf = h->t_gv_buf;
         e.g = h->d_gvpt + h->msg_base(l, 0); e.n_gvps = c.n_message_gvps;
         linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
         e.rbf_inv_sigma = 1.0f / ((c.rbf_dmax - 0.f) / (float)c.rbf_dim);
         e.l0 = l == 0;
-        pfk_bwd_edge(&e, std::max(1, std::min(nb, e.ntiles)), s);
+        for (int lv = c.n_message_gvps - 1; lv >= 0; --lv) { e.level = lv; pfk_bwd_edge_level(&e, s); }
         a ^= 1;
     }
     {

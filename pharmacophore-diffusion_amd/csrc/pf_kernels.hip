@@ -63,11 +63,15 @@ __device__ __forceinline__ float siluf_(float x) { return x * rcpf_(1.0f + __exp
 //   PRE    the 128-feature block of the scalar Linear (+ bias) was already applied per SOURCE NODE
 //          (k_encode_build: P = W[:, :128] h + b); the accumulators start from the gathered row of P and
 //          only the rbf / sh k-steps remain  (E/N ~ 7x fewer MFMAs for that block on pp edges)
-template <int VI, int NEXTRA, int VO, int NMO, bool SIG, bool VROW0, bool PRE = false>
+__device__ __forceinline__ void store_vec_r(float* row, const int hl, const float (&V)[3][8]);
+//   SAVE   training forward: the pre-activation scalars Z, the gate pre-activations and the gated output vectors of
+//          this row are also written to sv_z [128] / sv_g [16] / sv_v [48] (what the level-by-level backward reads)
+template <int VI, int NEXTRA, int VO, int NMO, bool SIG, bool VROW0, bool PRE = false, bool SAVE = false>
 __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64], const float* ext,
                                           const float (&Vr)[3][8], const float* xhat,
                                           float (&s_out)[NMO * 16], float (&V_out)[3][8], const int lane,
-                                          pf_gcf pre_row = nullptr) {
+                                          pf_gcf pre_row = nullptr, float* sv_z = nullptr, float* sv_g = nullptr,
+                                          float* sv_v = nullptr) {
     constexpr bool X = (VI == 17);                   // extra (17th) channel present
     constexpr int NVK = 8 + (X ? 1 : 0);             // k-steps of the Vh / Vu products and of the sh block
     constexpr int NKS = 64 + NEXTRA / 2 + NVK;       // k-steps of to_feats_out
@@ -154,6 +158,18 @@ __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64],
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (SAVE) {
+        static_assert(NMO == 4, "SAVE stores full 128-feature rows");
+        f32x4* zp = reinterpret_cast<f32x4*>(sv_z + 4 * hl);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 x;
+                x[0] = acc[mt][4 * q + 0]; x[1] = acc[mt][4 * q + 1]; x[2] = acc[mt][4 * q + 2]; x[3] = acc[mt][4 * q + 3];
+                zp[mt * 8 + q * 2] = x;
+            }
+    }
     // ---- SiLU feeds the gate MFMAs just in time:  gate = Wg feats_out + bg      (gvp.py:105-111)
     constexpr int NG = NMO * 16;
     constexpr int LOOK = 4;
@@ -193,12 +209,14 @@ __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64],
                 continue;
             }
             float gv = g[t] + (t < 4 ? b0[t & 3] : b1[t & 3]);
+            if constexpr (SAVE) sv_g[(t & 3) + 8 * (t >> 2) + 4 * hl] = gv;
             if constexpr (SIG) gv = sigmoidf_(gv);
             V_out[0][t] = gv * Vu[0][t];
             V_out[1][t] = gv * Vu[1][t];
             V_out[2][t] = gv * Vu[2][t];
         }
     }
+    if constexpr (SAVE) store_vec_r(sv_v, hl, V_out);
 }
 
 // load / store a 128-float row in F-layout (this lane's 64 features)
@@ -308,7 +326,7 @@ __device__ __forceinline__ int seg_tail(const int e, const int end) { return min
 // message rows (gvp.py:472-485, 540-551).  One wave per tile of 32 edge slots, all etypes in one
 // launch.  L0: conv layer 0, node vectors are identically zero.
 // ---------------------------------------------------------------------------------------------
-template <bool L0>
+template <bool L0, bool SAVE = false>
 __global__ __launch_bounds__(256, PF_WPS_EDGE) void k_edge_msg(const EdgeParams p) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
@@ -350,20 +368,25 @@ __global__ __launch_bounds__(256, PF_WPS_EDGE) void k_edge_msg(const EdgeParams 
     }
     const GvpW PF_AS1* wt = (const GvpW PF_AS1*)p.w + et * p.n_gvps;
     float s1[64], V1[3][8];
+    // SAVE: per-level rows of this edge slot (level-major: [level][slot])
+    float* svz = SAVE ? p.sv_z + (size_t)e * PF_S : nullptr;
+    float* svg = SAVE ? p.sv_g + (size_t)e * 16 : nullptr;
+    float* svv = SAVE ? p.sv_v + (size_t)e * 48 : nullptr;
     if (et == ET_PP && p.pre != nullptr) {
         // pp edges: W[:, :128] h_src + b was applied once per source node; gather that row into the accumulators
         float s[64];
 #pragma unroll
         for (int q = 0; q < 64; ++q) s[q] = 0.f;
-        gvp_apply<17, PF_R, 16, 4, true, L0, true>(wt[0], s, rb, V, xhat, s1, V1, lane, (pf_gcf)p.pre + (size_t)src * PF_S);
+        gvp_apply<17, PF_R, 16, 4, true, L0, true, SAVE>(wt[0], s, rb, V, xhat, s1, V1, lane, (pf_gcf)p.pre + (size_t)src * PF_S, svz, svg, svv);
     } else {
         float s[64];
         load_row_f(p.h + (size_t)src * PF_S, hl, s);
-        gvp_apply<17, PF_R, 16, 4, true, L0>(wt[0], s, rb, V, xhat, s1, V1, lane);
+        gvp_apply<17, PF_R, 16, 4, true, L0, false, SAVE>(wt[0], s, rb, V, xhat, s1, V1, lane, nullptr, svz, svg, svv);
     }
     for (int gi = 1; gi < p.n_gvps; ++gi) {
         float s2[64], V2[3][8];
-        gvp_apply<16, 0, 16, 4, true, false>(wt[gi], s1, nullptr, V1, nullptr, s2, V2, lane);
+        if constexpr (SAVE) { svz += p.sv_stride * PF_S; svg += p.sv_stride * 16; svv += p.sv_stride * 48; }
+        gvp_apply<16, 0, 16, 4, true, false, false, SAVE>(wt[gi], s1, nullptr, V1, nullptr, s2, V2, lane, nullptr, svz, svg, svv);
 #pragma unroll
         for (int q = 0; q < 64; ++q) s1[q] = s2[q];
 #pragma unroll
@@ -1679,6 +1702,11 @@ void pfk_noise_head_coop(const HeadParams* p, hipStream_t s) {
 void pfk_edge_msg(const EdgeParams* p, int layer0, hipStream_t s) {
     const int blocks = (p->ntiles + 3) / 4;
     if (blocks == 0) return;
+    if (p->sv_z != nullptr) {      // training forward: also write the per-level rows the backward pass reads
+        if (layer0) hipLaunchKernelGGL((k_edge_msg<true, true>), dim3(blocks), dim3(256), 0, s, *p);
+        else hipLaunchKernelGGL((k_edge_msg<false, true>), dim3(blocks), dim3(256), 0, s, *p);
+        return;
+    }
     if (layer0) hipLaunchKernelGGL(k_edge_msg<true>, dim3(blocks), dim3(256), 0, s, *p);
     else hipLaunchKernelGGL(k_edge_msg<false>, dim3(blocks), dim3(256), 0, s, *p);
 }

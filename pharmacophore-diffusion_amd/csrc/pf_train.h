@@ -75,6 +75,31 @@ struct BwdEdgeParams {
     int l0;
 };
 
+// level-by-level backward of the message chains (k_bwd_edge_level): one launch per GVP level, last level first.
+// The training forward (k_edge_msg<.., SAVE>) left per (level, edge slot) the pre-activation scalars Z, the gate
+// pre-activations and the gated output vectors, so nothing of the chain is recomputed but the small vector products.
+// A block serves ONE etype (blocks [et_blk0[et], et_blk0[et+1]) take the tiles [et_tile0[et], et_tile0[et+1]) of the
+// etype-ordered tile table): its to_feats_out weight sits in LDS for the whole launch and the weight gradients of
+// to_feats_out and of the gates accumulate in registers across all its tiles.
+struct BwdEdgeLevelParams {
+    TrainCommon c;
+    const EdgeTile* tiles;
+    int et_tile0[5], et_blk0[5];
+    const int* dyn_cnt;
+    const int* esrc; const int* edst;
+    const float4* xn;
+    const float* h; const float* v;          // layer input (level 0 gathers the source rows)
+    const float* gagg_s; const float* gagg_v;   // upstream of the last level
+    const int* in_cnt; int N;
+    int norm_mode;
+    float* G_h_in; float* G_v_in;            // level 0: atomically accumulated
+    const float* sv_z; const float* sv_g; const float* sv_v; size_t sv_stride;
+    float* gs_buf; float* gv_buf;            // dL/d(input scalars / vectors of the level above), per edge slot
+    const GvpT* g; int n_gvps; int level;
+    float rbf_mu[PF_R]; float rbf_inv_sigma;
+    int l0;
+};
+
 struct BwdEncodeParams {
     TrainCommon c;
     int Np, Nf;

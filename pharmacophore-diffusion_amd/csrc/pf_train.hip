@@ -17,7 +17,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define TR PFT_ROWS
-#define NT 256            // threads per block
+#define NT 512            // threads per block (8 waves: two per SIMD hide the operand-fetch latency of mm16)
+#define FPP (128 / (NT / 16))   // features per thread in the per-row passes (thread = (row = tid & 15, part = tid >> 4))
 #define SWS 165           // LDS row stride of scalar rows [si + h] (<= 161)
 #define VWS 53            // ... of vector rows [vi * 3] (<= 51)
 #define ZS 129            // ... of pre-activation / activation rows [so]
@@ -36,8 +37,9 @@ __device__ __forceinline__ float drop_mul(const TrainCommon& c, const uint32_t s
 }
 
 // C[M x N] = A[M x K] B[K x N] on v_mfma_f32_16x16x4_f32 (lane l: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
-// C[i = 4 (l>>4) + r][j = l&15]).  Output tiles are dealt round-robin to the 4 waves; c(i, j, value) consumes them.
-template <typename FA, typename FB, typename FC>
+// C[i = 4 (l>>4) + r][j = l&15]).  Output tiles are dealt round-robin to the waves; c(i, j, value) consumes them.
+// UNR k-steps are fetched before their MFMAs are issued, so the operand loads of a tile overlap.
+template <int UNR, typename FA, typename FB, typename FC>
 __device__ __forceinline__ void mm16(const int M, const int N, const int K, FA a, FB b, FC c, const int lane, const int wv) {
     const int mts = (M + 15) >> 4, nts = (N + 15) >> 4;
     const int li = lane & 15, kq = lane >> 4;
@@ -46,12 +48,16 @@ __device__ __forceinline__ void mm16(const int M, const int N, const int K, FA a
         const int ai = mt * 16 + li, bj = nt * 16 + li;
         const bool aok = ai < M, bok = bj < N;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int k0 = 0; k0 < K; k0 += 4) {
-            const int k = k0 + kq;
-            const float av = (aok && k < K) ? a(ai, k) : 0.f;
-            const float bv = (bok && k < K) ? b(k, bj) : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        for (int k0 = 0; k0 < K; k0 += 4 * UNR) {
+            float av[UNR], bv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int k = k0 + 4 * u + kq;
+                av[u] = (aok && k < K) ? a(ai, k) : 0.f;
+                bv[u] = (bok && k < K) ? b(k, bj) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -60,6 +66,66 @@ __device__ __forceinline__ void mm16(const int M, const int N, const int K, FA a
         }
     }
 }
+// G[M x N] += A[M x K] B[K x N] into this block's gradient copy (row stride ld): two output tiles per pass, their old
+// values fetched before the MFMAs so that the read-modify-write latency overlaps the products
+template <int UNR, typename FA, typename FB>
+__device__ __forceinline__ void mm16_acc(const int M, const int N, const int K, FA a, FB b, float* G, const int ld,
+                                         const int lane, const int wv) {
+    const int mts = (M + 15) >> 4, nts = (N + 15) >> 4;
+    const int li = lane & 15, kq = lane >> 4;
+    const int ntile = mts * nts;
+    for (int t0 = wv; t0 < ntile; t0 += 2 * (NT / 64)) {
+        float old[2][4];
+        f32x4 acc[2];
+        int mtv[2], bjv[2];
+        bool live[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int t = t0 + x * (NT / 64);
+            live[x] = t < ntile;
+            const int mt = live[x] ? t / nts : 0, nt = live[x] ? t - mt * nts : 0;
+            mtv[x] = mt; bjv[x] = nt * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = mt * 16 + kq * 4 + r;
+                old[x][r] = (live[x] && ci < M && bjv[x] < N) ? G[ci * ld + bjv[x]] : 0.f;
+            }
+            acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int ai = mtv[x] * 16 + li;
+            const bool aok = live[x] && ai < M, bok = live[x] && bjv[x] < N;
+            for (int k0 = 0; k0 < K; k0 += 4 * UNR) {
+                float av[UNR], bv[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int k = k0 + 4 * u + kq;
+                    av[u] = (aok && k < K) ? a(ai, k) : 0.f;
+                    bv[u] = (bok && k < K) ? b(k, bjv[x]) : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc[x], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = mtv[x] * 16 + kq * 4 + r;
+                if (live[x] && ci < M && bjv[x] < N) G[ci * ld + bjv[x]] = old[x][r] + acc[x][r];
+            }
+    }
+}
+
+// diagnostic builds (-DPFT_STAMPS): cycle stamps of block 0's first sub-tile at phase boundaries
+#ifdef PFT_STAMPS
+__device__ unsigned long long g_pft_stamps[128];
+__device__ int g_pft_nstamp;
+#define PFT_STAMP(id) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_pft_nstamp < 126) { g_pft_stamps[g_pft_nstamp] = ((unsigned long long)(id) << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull); g_pft_nstamp++; } } while (0)
+#else
+#define PFT_STAMP(id) do { } while (0)
+#endif
 
 struct ChainLds {
     float* base; int nlv;
@@ -81,7 +147,7 @@ struct ChainLds {
 __device__ __forceinline__ void gvp_vec(const GvpT& g, const float* W, float* Sin, const float* Vin, float* Vh, float* Vu,
                                         const bool want_sh, const int tid, const int lane, const int wv) {
     const int KH = g.h, VI = g.vi, VO = g.vo;
-    mm16(KH, 3 * TR, VI,
+    mm16<5>(KH, 3 * TR, VI,
          [&](int i, int k) { return W[g.o_Wh + k * KH + i]; },
          [&](int k, int j) { return Vin[(j & 15) * VWS + k * 3 + (j >> 4)]; },
          [&](int i, int j, float x) { Vh[(j & 15) * VWS + i * 3 + (j >> 4)] = x; }, lane, wv);
@@ -92,7 +158,7 @@ __device__ __forceinline__ void gvp_vec(const GvpT& g, const float* W, float* Si
             const float* q = Vh + row * VWS + hh * 3;
             Sin[row * SWS + g.si + hh] = t_sqrt(fmaxf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2], 1e-8f));
         }
-    mm16(VO, 3 * TR, KH,
+    mm16<5>(VO, 3 * TR, KH,
          [&](int i, int k) { return W[g.o_Wu + k * VO + i]; },
          [&](int k, int j) { return Vh[(j & 15) * VWS + k * 3 + (j >> 4)]; },
          [&](int i, int j, float x) { Vu[(j & 15) * VWS + i * 3 + (j >> 4)] = x; }, lane, wv);
@@ -105,8 +171,10 @@ __device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, float* Si
                                         float* act, const int act_stride, float* Vout, float* Vh, float* Vu,
                                         const int tid, const int lane, const int wv) {
     const int VO = g.vo, SO = g.so, KM = g.si + g.h;
+    PFT_STAMP(1);
     gvp_vec(g, W, Sin, Vin, Vh, Vu, true, tid, lane, wv);
-    mm16(SO, TR, KM,
+    PFT_STAMP(2);
+    mm16<14>(SO, TR, KM,
          [&](int i, int k) { return W[g.o_Wm + i * KM + k]; },
          [&](int k, int j) { return Sin[j * SWS + k]; },
          [&](int i, int j, float x) {
@@ -115,11 +183,13 @@ __device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, float* Si
              act[j * act_stride + i] = t_silu(z);
          }, lane, wv);
     __syncthreads();
-    mm16(VO, TR, SO,
+    PFT_STAMP(3);
+    mm16<16>(VO, TR, SO,
          [&](int i, int k) { return W[g.o_Wg + i * SO + k]; },
          [&](int k, int j) { return act[j * act_stride + k]; },
          [&](int i, int j, float x) { gate[j * GTS + i] = x + W[g.o_bg + i]; }, lane, wv);
     __syncthreads();
+    PFT_STAMP(4);
     if (Vout != nullptr) {
         for (int idx = tid; idx < TR * VO; idx += NT) {
             const int row = idx & 15, u = idx >> 4;
@@ -140,7 +210,9 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, float* gp
                                         float* gA, float* gS, float* gVo, float* gVi, float* Vh, float* Vu, float* gVh,
                                         float* ggate, const int tid, const int lane, const int wv) {
     const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;
+    PFT_STAMP(10);
     gvp_vec(g, W, nullptr, Vin, Vh, Vu, false, tid, lane, wv);
+    PFT_STAMP(11);
     // gate: V' = f(gate) Vu
     for (int idx = tid; idx < TR * VO; idx += NT) {
         const int row = idx & 15, u = idx >> 4;
@@ -154,20 +226,21 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, float* gp
         go[0] *= f; go[1] *= f; go[2] *= f;
     }
     __syncthreads();
-    mm16(SO, TR, VO,
+    PFT_STAMP(12);
+    mm16<4>(SO, TR, VO,
          [&](int i, int k) { return W[g.o_Wg + k * SO + i]; },
          [&](int k, int j) { return ggate[j * GTS + k]; },
          [&](int i, int j, float x) { gA[j * SWS + i] += x; }, lane, wv);
-    mm16(VO, SO, TR,
+    mm16_acc<4>(VO, SO, TR,
          [&](int i, int k) { return ggate[k * GTS + i]; },
-         [&](int k, int j) { return act[k * act_stride + j]; },
-         [&](int i, int j, float x) { gp[g.o_Wg + i * SO + j] += x; }, lane, wv);
+         [&](int k, int j) { return act[k * act_stride + j]; }, gp + g.o_Wg, SO, lane, wv);
     if (tid < VO) {
         float s = 0.f;
         for (int r = 0; r < TR; ++r) s += ggate[r * GTS + tid];
         gp[g.o_bg + tid] += s;
     }
     __syncthreads();
+    PFT_STAMP(13);
     for (int idx = tid; idx < TR * SO; idx += NT) {
         const int row = idx & 15, o = idx >> 4;
         const float z = Z[row * ZS + o];
@@ -175,21 +248,23 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, float* gp
         gA[row * SWS + o] *= s * (1.0f + z * (1.0f - s));
     }
     __syncthreads();
-    mm16(KM, TR, SO,
+    PFT_STAMP(14);
+    mm16<16>(KM, TR, SO,
          [&](int i, int k) { return W[g.o_Wm + k * KM + i]; },
          [&](int k, int j) { return gA[j * SWS + k]; },
          [&](int i, int j, float x) { gS[j * SWS + i] = x; }, lane, wv);
-    mm16(SO, KM, TR,
+    PFT_STAMP(15);
+    mm16_acc<4>(SO, KM, TR,
          [&](int i, int k) { return gA[k * SWS + i]; },
-         [&](int k, int j) { return Sin[k * SWS + j]; },
-         [&](int i, int j, float x) { gp[g.o_Wm + i * KM + j] += x; }, lane, wv);
+         [&](int k, int j) { return Sin[k * SWS + j]; }, gp + g.o_Wm, KM, lane, wv);
     if (tid < SO) {
         float s = 0.f;
         for (int r = 0; r < TR; ++r) s += gA[r * SWS + tid];
         gp[g.o_bm + tid] += s;
     }
     __syncthreads();
-    mm16(KH, 3 * TR, VO,
+    PFT_STAMP(16);
+    mm16<4>(KH, 3 * TR, VO,
          [&](int i, int k) { return W[g.o_Wu + i * VO + k]; },
          [&](int k, int j) { return gVo[(j & 15) * VWS + k * 3 + (j >> 4)]; },
          [&](int i, int j, float x) {
@@ -199,19 +274,18 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, float* gp
              const float extra = ss > 1e-8f ? gS[row * SWS + SI + i] * q[cc] / Sin[row * SWS + SI + i] : 0.f;
              gVh[row * VWS + i * 3 + cc] = x + extra;
          }, lane, wv);
-    mm16(KH, VO, 3 * TR,
+    mm16_acc<4>(KH, VO, 3 * TR,
          [&](int i, int k) { return Vh[(k & 15) * VWS + i * 3 + (k >> 4)]; },
-         [&](int k, int j) { return gVo[(k & 15) * VWS + j * 3 + (k >> 4)]; },
-         [&](int i, int j, float x) { gp[g.o_Wu + i * VO + j] += x; }, lane, wv);
+         [&](int k, int j) { return gVo[(k & 15) * VWS + j * 3 + (k >> 4)]; }, gp + g.o_Wu, VO, lane, wv);
     __syncthreads();
-    mm16(VI, 3 * TR, KH,
+    PFT_STAMP(17);
+    mm16<5>(VI, 3 * TR, KH,
          [&](int i, int k) { return W[g.o_Wh + i * KH + k]; },
          [&](int k, int j) { return gVh[(j & 15) * VWS + k * 3 + (j >> 4)]; },
          [&](int i, int j, float x) { gVi[(j & 15) * VWS + i * 3 + (j >> 4)] = x; }, lane, wv);
-    mm16(VI, KH, 3 * TR,
+    mm16_acc<4>(VI, KH, 3 * TR,
          [&](int i, int k) { return Vin[(k & 15) * VWS + i * 3 + (k >> 4)]; },
-         [&](int k, int j) { return gVh[(k & 15) * VWS + j * 3 + (k >> 4)]; },
-         [&](int i, int j, float x) { gp[g.o_Wh + i * KH + j] += x; }, lane, wv);
+         [&](int k, int j) { return gVh[(k & 15) * VWS + j * 3 + (k >> 4)]; }, gp + g.o_Wh, KH, lane, wv);
     __syncthreads();
 }
 
@@ -247,13 +321,13 @@ __device__ __forceinline__ float row_mean128(F f, float* red, const int tid) {
     const int row = tid & 15, part = tid >> 4;
     float s = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s += f(row, part * 8 + q);
+    for (int q = 0; q < FPP; ++q) s += f(row, part * FPP + q);
     __syncthreads();
     red[part * 16 + row] = s;
     __syncthreads();
     float tot = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) tot += red[q * 16 + row];
+    for (int q = 0; q < NT / 16; ++q) tot += red[q * 16 + row];
     return tot * (1.0f / 128.0f);
 }
 
@@ -365,7 +439,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
     __shared__ float lds[CHAIN_FLOATS(NODE_LVLS)];
     __shared__ float xh1[TR * ZS], xh2[TR * ZS], gu[TR * ZS];
     __shared__ float vy[TR * VWS], vz[TR * VWS], gvu[TR * VWS], rvl[TR * VWS];
-    __shared__ float red[256];
+    __shared__ float red[NT];
     __shared__ float s_rstd1[TR], s_rstd2[TR], s_inv[TR];
     __shared__ VecLn s_vl1[TR], s_vl2[TR];
     __shared__ int s_n[TR];
@@ -392,7 +466,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
             }
             __syncthreads();
             // ---- aggregate the message partial rows (as k_node_update), dropout, residual
-            {
+            if (tid < 256) {
                 const int row = tid >> 4, part = tid & 15;
                 const int n = s_n[row];
                 float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mv[3] = {0, 0, 0};
@@ -435,8 +509,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 const int row = tid & 15, part = tid >> 4;
                 if (part == 0) { s_rstd1[row] = rstd; s_vl1[row] = vec_ln_stats(vy + row * VWS); }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int f = part * 8 + q;
+                for (int q = 0; q < FPP; ++q) {
+                    const int f = part * FPP + q;
                     const float xh = (xh1[row * ZS + f] - mean) * rstd;
                     xh1[row * ZS + f] = xh;
                     L.Sin(0)[row * SWS + f] = xh * W[o_l1w + f] + W[o_l1b + f];
@@ -468,8 +542,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 const int row = tid & 15, part = tid >> 4;
                 if (part == 0) { s_rstd2[row] = rstd; s_vl2[row] = vec_ln_stats(vz + row * VWS); }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int f = part * 8 + q;
+                for (int q = 0; q < FPP; ++q) {
+                    const int f = part * FPP + q;
                     xh2[row * ZS + f] = (xh2[row * ZS + f] - mean) * rstd;
                 }
             }
@@ -497,8 +571,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 const float rstd = s_rstd2[row];
                 __syncthreads();
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int f = part * 8 + q;
+                for (int q = 0; q < FPP; ++q) {
+                    const int f = part * FPP + q;
                     const float gz = rstd * (gu[row * ZS + f] * W[o_l2w + f] - m1 - xh2[row * ZS + f] * m2);
                     gu[row * ZS + f] = gz;                                     // dL/du (residual path)
                     L.gX[row * SWS + f] = gz * drop_mul(p.c, st_res, (uint32_t)s_n[row] * 144u + (uint32_t)f);
@@ -536,8 +610,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 const float rstd = s_rstd1[row];
                 __syncthreads();
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int f = part * 8 + q;
+                for (int q = 0; q < FPP; ++q) {
+                    const int f = part * FPP + q;
                     gu[row * ZS + f] = rstd * (gu[row * ZS + f] * W[o_l1w + f] - m1 - xh1[row * ZS + f] * m2);   // dL/dy
                 }
                 if (tid < TR) {
@@ -623,7 +697,9 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge(const BwdEdgeParams p) {
                 d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
             }
             __syncthreads();
+            PFT_STAMP(20);
             chain_fwd(L, g, W, nullptr, tid, lane, wv);
+            PFT_STAMP(21);
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx >> 7, f = idx & 127;
                 L.gX[row * SWS + f] = p.gagg_s[(size_t)s_dst[row] * PF_S + f] * s_sc[row];
@@ -634,7 +710,9 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge(const BwdEdgeParams p) {
             }
             __syncthreads();
             float *gs, *gv;
+            PFT_STAMP(22);
             chain_bwd(L, g, W, gp, gs, gv, tid, lane, wv);
+            PFT_STAMP(23);
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx >> 7, f = idx & 127;
                 if (row < nv) unsafeAtomicAdd(p.G_h_in + (size_t)s_src[row] * PF_S + f, gs[row * SWS + f]);
@@ -645,8 +723,242 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge(const BwdEdgeParams p) {
                     if (row < nv) unsafeAtomicAdd(p.G_v_in + (size_t)s_src[row] * 48 + q, gv[row * VWS + 3 + q]);
                 }
             __syncthreads();
+            PFT_STAMP(24);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// edge message backward, one GVP level per launch (see BwdEdgeLevelParams)
+// ---------------------------------------------------------------------------------------------
+#define KMS 168           // LDS row stride of the staged to_feats_out weight [so][si + h]
+__global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelParams p) {
+    __shared__ float Wl[PF_S * KMS];
+    __shared__ float Zb[TR * ZS], Sin[TR * SWS], gA[TR * SWS], gS[TR * SWS];
+    __shared__ float gate[TR * GTS], ggate[TR * GTS];
+    __shared__ float Vin[TR * VWS], Vh[TR * VWS], Vu[TR * VWS], gVo[TR * VWS], gVh[TR * VWS], gVi[TR * VWS];
+    __shared__ int s_src[TR], s_dst[TR], s_e[TR];
+    __shared__ float s_sc[TR];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    int et = 0;
+    while (et < 3 && (int)blockIdx.x >= p.et_blk0[et + 1]) ++et;
+    const int nb = p.et_blk0[et + 1] - p.et_blk0[et], my = blockIdx.x - p.et_blk0[et];
+    const GvpT g = p.g[et * p.n_gvps + p.level];
+    const float* W = p.c.W;
+    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
+    const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;   // SO == 128, VO == 16 (host checks)
+    const int nts = (KM + 15) >> 4;                  // <= 11
+    const bool lastl = p.level == p.n_gvps - 1, firstl = p.level == 0;
+    const int slot = (et == ET_FF || et == ET_FP) ? 0 : 1;
+    for (int idx = tid; idx < SO * KM; idx += NT) {
+        const int o = idx / KM, k = idx - o * KM;
+        Wl[o * KMS + k] = W[g.o_Wm + idx];
+    }
+    f32x4 accWm[11], accWg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < 11; ++x) accWm[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float acc_bm = 0.f, acc_bg = 0.f;                // bias gradients of feature tid (< SO) / gate tid (< VO)
+    __syncthreads();
+    const float* zl = p.sv_z + (size_t)p.level * p.sv_stride * PF_S;
+    const float* gl = p.sv_g + (size_t)p.level * p.sv_stride * 16;
+    const float* zprev = firstl ? nullptr : p.sv_z + (size_t)(p.level - 1) * p.sv_stride * PF_S;
+    const float* vprev = firstl ? nullptr : p.sv_v + (size_t)(p.level - 1) * p.sv_stride * 48;
+    for (int ti = p.et_tile0[et] + my; ti < p.et_tile0[et + 1]; ti += nb) {
+        const EdgeTile t = p.tiles[ti];
+        int nvalid = t.n;
+        if (t.cnt_idx >= 0) nvalid = min(nvalid, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
+        for (int sub = 0; sub * TR < nvalid; ++sub) {
+            const int nv = min(TR, nvalid - sub * TR);
+            const int e0 = t.e0 + sub * TR;
+            if (tid < TR) {
+                const int e = e0 + min(tid, nv - 1);
+                s_e[tid] = e;
+                if (firstl || lastl) {
+                    const int src = p.esrc[e], dst = p.edst[e];
+                    s_src[tid] = src; s_dst[tid] = dst;
+                    if (firstl) {
+                        const float4 xs = p.xn[src], xd = p.xn[dst];
+                        const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
+                        const float d = t_sqrt(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+                        const float rd = __builtin_amdgcn_rcpf(d);
+                        Vin[tid * VWS + 0] = dx * rd; Vin[tid * VWS + 1] = dy * rd; Vin[tid * VWS + 2] = dz * rd;
+                        for (int k = 0; k < PF_R; ++k) {
+                            const float z = (d - p.rbf_mu[k]) * p.rbf_inv_sigma;
+                            Sin[tid * SWS + PF_S + k] = __expf(-(z * z));
+                        }
+                    }
+                    float sc = 1.0f;
+                    if (lastl && p.norm_mode == 0) sc = 1.0f / (float)p.in_cnt[slot * p.N + dst];
+                    s_sc[tid] = sc;
+                }
+            }
+            __syncthreads();
+            // ---- rows of this level from the forward, inputs of the level, upstream gradients
+            for (int idx = tid; idx < TR * 32; idx += NT) {
+                const int row = idx >> 5, q = idx & 31;
+                const int e = s_e[row];
+                const float4 z = reinterpret_cast<const float4*>(zl + (size_t)e * PF_S)[q];
+                float* d = Zb + row * ZS + 4 * q;
+                d[0] = z.x; d[1] = z.y; d[2] = z.z; d[3] = z.w;
+                float4 x;
+                if (firstl) x = reinterpret_cast<const float4*>(p.h + (size_t)s_src[row] * PF_S)[q];
+                else {
+                    x = reinterpret_cast<const float4*>(zprev + (size_t)e * PF_S)[q];
+                    x.x = t_silu(x.x); x.y = t_silu(x.y); x.z = t_silu(x.z); x.w = t_silu(x.w);
+                }
+                float* s = Sin + row * SWS + 4 * q;
+                s[0] = x.x; s[1] = x.y; s[2] = x.z; s[3] = x.w;
+                float4 u;
+                if (lastl) {
+                    u = reinterpret_cast<const float4*>(p.gagg_s + (size_t)s_dst[row] * PF_S)[q];
+                    const float sc = row < nv ? s_sc[row] : 0.f;
+                    u.x *= sc; u.y *= sc; u.z *= sc; u.w *= sc;
+                } else {
+                    u = reinterpret_cast<const float4*>(p.gs_buf + (size_t)e * PF_S)[q];
+                    if (row >= nv) u = float4{0.f, 0.f, 0.f, 0.f};
+                }
+                float* ga = gA + row * SWS + 4 * q;
+                ga[0] = u.x; ga[1] = u.y; ga[2] = u.z; ga[3] = u.w;
+            }
+            for (int idx = tid; idx < TR * 12; idx += NT) {
+                const int row = idx / 12, q = idx - row * 12;
+                const int e = s_e[row];
+                float4 x = {0.f, 0.f, 0.f, 0.f};
+                if (firstl) { if (!p.l0) x = reinterpret_cast<const float4*>(p.v + (size_t)s_src[row] * 48)[q]; }
+                else x = reinterpret_cast<const float4*>(vprev + (size_t)e * 48)[q];
+                float* d = Vin + row * VWS + (firstl ? 3 : 0) + 4 * q;
+                d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+                float4 u;
+                if (lastl) {
+                    u = reinterpret_cast<const float4*>(p.gagg_v + (size_t)s_dst[row] * 48)[q];
+                    const float sc = row < nv ? s_sc[row] : 0.f;
+                    u.x *= sc; u.y *= sc; u.z *= sc; u.w *= sc;
+                } else {
+                    u = reinterpret_cast<const float4*>(p.gv_buf + (size_t)e * 48)[q];
+                    if (row >= nv) u = float4{0.f, 0.f, 0.f, 0.f};
+                }
+                float* go = gVo + row * VWS + 4 * q;
+                go[0] = u.x; go[1] = u.y; go[2] = u.z; go[3] = u.w;
+            }
+            for (int idx = tid; idx < TR * 16; idx += NT) {
+                const int row = idx >> 4, u = idx & 15;
+                gate[row * GTS + u] = gl[(size_t)s_e[row] * 16 + u];
+            }
+            __syncthreads();
+            gvp_vec(g, W, Sin, Vin, Vh, Vu, true, tid, lane, wv);
+            // ---- gate: V' = sigmoid(gate) Vu
+            for (int idx = tid; idx < TR * VO; idx += NT) {
+                const int row = idx & 15, u = idx >> 4;
+                const float gt = gate[row * GTS + u];
+                float* go = gVo + row * VWS + u * 3;
+                const float* vu = Vu + row * VWS + u * 3;
+                const float dot = go[0] * vu[0] + go[1] * vu[1] + go[2] * vu[2];
+                const float f = t_sigmoid(gt);
+                ggate[row * GTS + u] = dot * f * (1.0f - f);
+                go[0] *= f; go[1] *= f; go[2] *= f;
+            }
+            __syncthreads();
+            mm16<4>(SO, TR, VO,
+                 [&](int i, int k) { return W[g.o_Wg + k * SO + i]; },
+                 [&](int k, int j) { return ggate[j * GTS + k]; },
+                 [&](int i, int j, float x) { gA[j * SWS + i] += x; }, lane, wv);
+            {   // dWg tile (gates x features 16 wv .. 16 wv + 15) += ggate^T SiLU(Z)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 4 * u + kq;
+                    accWg = __builtin_amdgcn_mfma_f32_16x16x4f32(ggate[k * GTS + li], t_silu(Zb[k * ZS + wv * 16 + li]), accWg, 0, 0, 0);
+                }
+                if (tid < VO) { float s = 0.f; for (int r = 0; r < TR; ++r) s += ggate[r * GTS + tid]; acc_bg += s; }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < TR * SO; idx += NT) {
+                const int row = idx & 15, o = idx >> 4;
+                const float z = Zb[row * ZS + o];
+                const float s = t_sigmoid(z);
+                gA[row * SWS + o] *= s * (1.0f + z * (1.0f - s));
+            }
+            __syncthreads();
+            mm16<8>(KM, TR, SO,
+                 [&](int i, int k) { return Wl[k * KMS + i]; },
+                 [&](int k, int j) { return gA[j * SWS + k]; },
+                 [&](int i, int j, float x) { gS[j * SWS + i] = x; }, lane, wv);
+            {   // dWm tiles (features 16 wv .., inputs 16 x ..) += gZ^T [s, sh]
+                float av[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) av[u] = gA[(4 * u + kq) * SWS + wv * 16 + li];
+#pragma unroll
+                for (int x = 0; x < 11; ++x)
+                    if (x < nts) {
+                        const int cj = x * 16 + li;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            accWm[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], cj < KM ? Sin[(4 * u + kq) * SWS + cj] : 0.f, accWm[x], 0, 0, 0);
+                    }
+                if (tid < SO) { float s = 0.f; for (int r = 0; r < TR; ++r) s += gA[r * SWS + tid]; acc_bm += s; }
+            }
+            __syncthreads();
+            mm16<4>(KH, 3 * TR, VO,
+                 [&](int i, int k) { return W[g.o_Wu + i * VO + k]; },
+                 [&](int k, int j) { return gVo[(j & 15) * VWS + k * 3 + (j >> 4)]; },
+                 [&](int i, int j, float x) {
+                     const int row = j & 15, cc = j >> 4;
+                     const float* q = Vh + row * VWS + i * 3;
+                     const float ss = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+                     const float extra = ss > 1e-8f ? gS[row * SWS + SI + i] * q[cc] / Sin[row * SWS + SI + i] : 0.f;
+                     gVh[row * VWS + i * 3 + cc] = x + extra;
+                 }, lane, wv);
+            mm16_acc<4>(KH, VO, 3 * TR,
+                 [&](int i, int k) { return Vh[(k & 15) * VWS + i * 3 + (k >> 4)]; },
+                 [&](int k, int j) { return gVo[(k & 15) * VWS + j * 3 + (k >> 4)]; }, gp + g.o_Wu, VO, lane, wv);
+            __syncthreads();
+            mm16<5>(VI, 3 * TR, KH,
+                 [&](int i, int k) { return W[g.o_Wh + i * KH + k]; },
+                 [&](int k, int j) { return gVh[(j & 15) * VWS + k * 3 + (j >> 4)]; },
+                 [&](int i, int j, float x) { gVi[(j & 15) * VWS + i * 3 + (j >> 4)] = x; }, lane, wv);
+            mm16_acc<4>(VI, KH, 3 * TR,
+                 [&](int i, int k) { return Vin[(k & 15) * VWS + i * 3 + (k >> 4)]; },
+                 [&](int k, int j) { return gVh[(k & 15) * VWS + j * 3 + (k >> 4)]; }, gp + g.o_Wh, KH, lane, wv);
+            __syncthreads();
+            // ---- hand the input gradients down: to the level below, or (level 0) to the source nodes
+            if (!firstl) {
+                for (int idx = tid; idx < TR * 128; idx += NT) {
+                    const int row = idx >> 7, f = idx & 127;
+                    if (row < nv) p.gs_buf[(size_t)s_e[row] * PF_S + f] = gS[row * SWS + f];
+                }
+                for (int idx = tid; idx < TR * 48; idx += NT) {
+                    const int row = idx / 48, q = idx - row * 48;
+                    if (row < nv) p.gv_buf[(size_t)s_e[row] * 48 + q] = gVi[row * VWS + q];
+                }
+            } else {
+                for (int idx = tid; idx < TR * 128; idx += NT) {
+                    const int row = idx >> 7, f = idx & 127;
+                    if (row < nv) unsafeAtomicAdd(p.G_h_in + (size_t)s_src[row] * PF_S + f, gS[row * SWS + f]);
+                }
+                if (!p.l0)
+                    for (int idx = tid; idx < TR * 48; idx += NT) {
+                        const int row = idx / 48, q = idx - row * 48;
+                        if (row < nv) unsafeAtomicAdd(p.G_v_in + (size_t)s_src[row] * 48 + q, gVi[row * VWS + 3 + q]);
+                    }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- flush the register accumulators into this block's gradient copy
+#pragma unroll
+    for (int x = 0; x < 11; ++x)
+        if (x < nts) {
+            const int cj = x * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = wv * 16 + kq * 4 + r;
+                if (cj < KM) gp[g.o_Wm + ci * KM + cj] += accWm[x][r];
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gp[g.o_Wg + (kq * 4 + r) * SO + wv * 16 + li] += accWg[r];
+    if (tid < SO) gp[g.o_bm + tid] += acc_bm;
+    if (tid < VO) gp[g.o_bg + tid] += acc_bg;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -654,7 +966,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge(const BwdEdgeParams p) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT, 1) void k_bwd_encode(const BwdEncodeParams p) {
     __shared__ float sin_[TR * 17], z[TR * ZS], xh[TR * ZS], gq[TR * ZS];
-    __shared__ float red[256];
+    __shared__ float red[NT];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* W = p.c.W;
     float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
@@ -692,8 +1004,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_encode(const BwdEncodeParams p) {
             const int row = tid & 15, part = tid >> 4;
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int f = part * 8 + q;
+            for (int q = 0; q < FPP; ++q) {
+                const int f = part * FPP + q;
                 xh[row * ZS + f] = (xh[row * ZS + f] - mean) * rstd;
             }
             for (int idx = tid; idx < TR * 128; idx += NT) {
@@ -711,8 +1023,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_encode(const BwdEncodeParams p) {
             const float m2 = row_mean128([&](int r, int f) { return gq[r * ZS + f] * W[olw + f] * xh[r * ZS + f]; }, red, tid);
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int f = part * 8 + q;
+            for (int q = 0; q < FPP; ++q) {
+                const int f = part * FPP + q;
                 const float ga = rstd * (gq[row * ZS + f] * W[olw + f] - m1 - xh[row * ZS + f] * m2);
                 const float zz = z[row * ZS + f];
                 const float s = t_sigmoid(zz);
@@ -752,6 +1064,15 @@ __global__ void k_drop_masks(const TrainCommon c, const uint32_t stream, const i
 }
 
 extern "C" {
+#ifdef PFT_STAMPS
+int pft_read_stamps(unsigned long long* host, int reset) {
+    int n = 0;
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_pft_nstamp), sizeof(int));
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pft_stamps), sizeof(unsigned long long) * 128);
+    if (reset) { int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pft_nstamp), &z, sizeof(int)); }
+    return n;
+}
+#endif
 void pfk_bwd_head(const BwdHeadParams* p, int nblocks, hipStream_t s) {
     if (p->ntiles == 0) return;
     hipLaunchKernelGGL(k_bwd_head, dim3(nblocks), dim3(NT), 0, s, *p);
@@ -763,6 +1084,11 @@ void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s) {
 void pfk_bwd_edge(const BwdEdgeParams* p, int nblocks, hipStream_t s) {
     if (p->ntiles == 0) return;
     hipLaunchKernelGGL(k_bwd_edge, dim3(nblocks), dim3(NT), 0, s, *p);
+}
+void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, hipStream_t s) {
+    const int nblocks = p->et_blk0[4];
+    if (nblocks == 0) return;
+    hipLaunchKernelGGL(k_bwd_edge_level, dim3(nblocks), dim3(NT), 0, s, *p);
 }
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s) {
     hipLaunchKernelGGL(k_bwd_encode, dim3(nblocks), dim3(NT), 0, s, *p);
