@@ -159,6 +159,14 @@ int pf_train_forward(pf_handle* h, const float* dev_prot_x /*[Np,3] or NULL*/, c
                      float* dev_eps_h, float* dev_eps_x, pf_stream stream);
 int pf_train_backward(pf_handle* h, const float* dev_g_eps_h /*[Nf,pharm_nf]*/, const float* dev_g_eps_x /*[Nf,3]*/,
                       float* dev_grad /*[n_params]*/, pf_stream stream);
+/* the flat parameter vector on the device: set = copy in + refresh the packed MFMA-fragment weights by a device gather
+ * (what an optimiser step calls instead of 245 x pf_set_weight + pf_commit_weights); get = copy out */
+int pf_set_flat_params(pf_handle* h, const float* dev_flat /*[n_params]*/, pf_stream stream);
+int pf_get_flat_params(pf_handle* h, float* dev_flat /*[n_params]*/, pf_stream stream);
+/* tests: make the following pf_train_forward / pf_train_backward calls on this batch use the given multipliers
+ * [n_convs][2][N][144] (layout of pf_debug_dropout_mask) instead of the built-in generator; NULL restores it.  The
+ * buffer must stay alive until the backward call has finished. */
+int pf_debug_set_dropout_masks(pf_handle* h, const float* dev_masks);
 /* the {0, 1/(1-p)} multipliers pf_train_forward applies in conv layer `layer` (which: 0 message dropout, gvp.py:518;
  * 1 residual dropout, gvp.py:529): dev_out[node][144] = 128 scalar features then 16 vector channels, global node ids
  * (protein atoms first). */

@@ -51,6 +51,9 @@ SYMBOLS = {
     "pf_param_layout": (ctypes.c_int, [_P, _I32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "pf_train_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _F, ctypes.c_uint32, _P, _P, _P]),
     "pf_train_backward": (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    "pf_set_flat_params": (ctypes.c_int, [_P, _P, _P]),
+    "pf_get_flat_params": (ctypes.c_int, [_P, _P, _P]),
+    "pf_debug_set_dropout_masks": (ctypes.c_int, [_P, _P]),
     "pf_debug_dropout_mask": (ctypes.c_int, [_P, _I32, _I32, _F, ctypes.c_uint32, _P, _P]),
     "pf_debug_get_edges": (_I64, [_P, _I32, _P, _P, _I64, _P]),
     "pf_debug_conv_layer": (ctypes.c_int, [_P, _I32] + [_P] * 11),

@@ -124,6 +124,7 @@ struct NodeParams {
     // training forward only (one-wave kernel): GVPDropout of the aggregated message and of the update residual
     // (gvp.py:518,529); drop_thr == 0: inference
     uint32_t drop_thr; float drop_scale; uint32_t seed; int layer;
+    const float* mask_override;   // tests: externally supplied multipliers [n_convs * 2][N * 144] instead of the hash
 };
 
 struct HeadParams {

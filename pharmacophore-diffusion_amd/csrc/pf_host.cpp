@@ -37,10 +37,10 @@ void pfk_export_coords(const float4* xn, int base, int n, const int* gid, const 
                        float* out, hipStream_t s);
 void pfk_bwd_head(const BwdHeadParams* p, int nblocks, hipStream_t s);
 void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s);
-void pfk_bwd_edge(const BwdEdgeParams* p, int nblocks, hipStream_t s);
 void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, hipStream_t s);
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
 void pfk_train_reduce(const float* gpart, int nblocks, int nparams, float* grad, hipStream_t s);
+void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s);
 void pfk_drop_masks(const TrainCommon* c, uint32_t stream, int n_elems, float* out, hipStream_t s);
 void pfk_pp_radius(const float4* xn, const int* prot_ptr, int B, float r2, int maxn, int* deg, const int* row_off,
                    int* src, int* dst, int pass, hipStream_t s);
@@ -134,6 +134,9 @@ struct pf_handle {
     size_t nparams = 0;
     std::vector<std::pair<std::string, std::pair<size_t, size_t>>> flat_layout;   // name -> (offset, numel), state-dict order
     GvpT* d_gvpt = nullptr;                 // same indexing as the GvpW table
+    std::vector<int> h_map;                 // packed element -> flat parameter index (-1: zero), see pf_commit_weights
+    int* d_map = nullptr;
+    size_t n_packed = 0;
     void* d_tws = nullptr;                  // training workspace of the current batch (allocated on first use)
     std::vector<float*> t_H, t_V, t_msg_s, t_msg_v;
     std::vector<float*> t_sv_z, t_sv_g, t_sv_v;     // per layer: [n_message_gvps][Ecap] rows saved by the forward
@@ -142,6 +145,7 @@ struct pf_handle {
     float *t_G_h[2] = {nullptr, nullptr}, *t_G_v[2] = {nullptr, nullptr}, *t_gagg_s = nullptr, *t_gagg_v = nullptr,
           *t_gpart = nullptr, *t_geps_h = nullptr, *t_geps_x = nullptr;
     int t_nblk = 0;
+    const float* t_mask_override = nullptr; // pf_debug_set_dropout_masks
     bool t_have_fwd = false;
     TrainCommon t_common{};
     size_t flat_offset(const std::string& name) const {
@@ -361,6 +365,7 @@ static void free_ws(pf_handle* h) {
     if (h->d_tws) (void)hipFree(h->d_tws);
     h->d_tws = nullptr;
     h->t_have_fwd = false;
+    h->t_mask_override = nullptr;
     h->have_batch = false;
 }
 
@@ -463,7 +468,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         n.msg_s = e.msg_s; n.msg_v = e.msg_v; n.zero_row = h->zero_row;
         n.h_in = e.h; n.v_in = e.v;
         n.h_out = train ? h->t_H[l + 1] : h->d_h[cur ^ 1]; n.v_out = train ? h->t_V[l + 1] : h->d_v[cur ^ 1];
-        if (train) { n.drop_thr = h->t_common.drop_thr; n.drop_scale = h->t_common.drop_scale; n.seed = h->t_common.seed; n.layer = l; }
+        if (train) { n.drop_thr = h->t_common.drop_thr; n.drop_scale = h->t_common.drop_scale; n.seed = h->t_common.seed; n.layer = l; n.mask_override = h->t_common.mask_override; }
         n.gid = h->d_gid; n.gnorm = h->d_gnorm; n.B = h->B;
         n.norm_mode = c.message_norm_mode; n.norm_value = c.message_norm_value;
         for (int nt = 0; nt < 2; ++nt) {
@@ -539,6 +544,7 @@ void pf_destroy(pf_handle* h) {
     if (h->d_gvp) (void)hipFree(h->d_gvp);
     if (h->d_flat) (void)hipFree(h->d_flat);
     if (h->d_gvpt) (void)hipFree(h->d_gvpt);
+    if (h->d_map) (void)hipFree(h->d_map);
     for (int k = 0; k < pf_handle::K_NUM; ++k)
         for (auto& ev : h->prof_ev[k]) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete h;
@@ -573,76 +579,112 @@ int pf_commit_weights(pf_handle* h) {
             if (!found) PF_FAIL(h, PF_ERR_WEIGHT, "unexpected weight tensor %s", kv.first.c_str());
         }
     }
-    h->h_w.clear();
     h->h_gvp.clear();
     std::vector<GvpOff> offs;
-    for (int l = 0; l < c.n_convs; ++l)
-        for (int et = 0; et < 4; ++et)
-            for (int j = 0; j < c.n_message_gvps; ++j) offs.push_back(pack_gvp(h, msg_spec(c, l, et, j)));
-    h->n_msg_tot = (int)offs.size();
-    for (int l = 0; l < c.n_convs; ++l)
-        for (int nt = 0; nt < 2; ++nt)
-            for (int j = 0; j < c.n_update_gvps; ++j) offs.push_back(pack_gvp(h, upd_spec(c, l, nt, j)));
-    h->n_upd_tot = (int)offs.size() - h->n_msg_tot;
-    for (int k = 0; k < c.n_noise_gvps; ++k) offs.push_back(pack_gvp(h, head_spec(c, k)));
-    for (int nt = 0; nt < 2; ++nt) {
-        const std::string p = std::string("dynamics.") + kNtKey[nt] + "_encoder.";
-        {   // encoder weight transposed to [nf+1][128]: coalesced loads of one input's column
-            const RawTensor& W = h->raw[p + "0.weight"];
-            const int K = (int)W.shape[1], S = (int)W.shape[0];
-            std::vector<float> wt((size_t)K * S);
-            for (int f = 0; f < S; ++f) for (int k = 0; k < K; ++k) wt[(size_t)k * S + f] = W.data[(size_t)f * K + k];
-            h->enc_w[nt] = push(h->h_w, wt);
-        }
-        h->enc_b[nt] = push(h->h_w, h->raw[p + "0.bias"].data);
-        h->enc_lw[nt] = push(h->h_w, h->raw[p + "2.weight"].data);
-        h->enc_lb[nt] = push(h->h_w, h->raw[p + "2.bias"].data);
-    }
-    {   // protein encoder Linear [128][rec_nf+1] as A fragments [tile][k-step][lane]; k-step t, half hl <-> input 2t+hl
-        const RawTensor& W = h->raw["dynamics.prot_encoder.0.weight"];
-        const RawTensor& Bv = h->raw["dynamics.prot_encoder.0.bias"];
-        const int K = c.rec_nf + 1, nke = (K + 1) / 2;
-        std::vector<float> a((size_t)4 * nke * 64, 0.f), bf(128);
-        for (int mo = 0; mo < 4; ++mo)
-            for (int t = 0; t < nke; ++t)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int i = lane & 31, hl = lane >> 5, k = 2 * t + hl;
-                    a[((size_t)mo * nke + t) * 64 + lane] = k < K ? W.data[(size_t)(32 * mo + i) * K + k] : 0.f;
-                }
-        for (int hl = 0; hl < 2; ++hl)
-            for (int mo = 0; mo < 4; ++mo)
-                for (int r = 0; r < 16; ++r) bf[(size_t)hl * 64 + mo * 16 + r] = Bv.data[32 * mo + rho(r, hl)];
-        h->enc_a = push(h->h_w, a);
-        h->enc_bf = push(h->h_w, bf);
-    }
-    h->ln_off.assign((size_t)c.n_convs * 2 * 4, 0);
-    for (int l = 0; l < c.n_convs; ++l)
+    // the packing is pure data movement (copies and zero padding), so running it a second time on tensors whose VALUES
+    // are their own flat index + 1 yields, per packed element, where it comes from: the gather map that lets
+    // pf_set_flat_params refresh the packed weights on the device after an optimiser step
+    auto pack_all = [&]() {
+        h->h_w.clear();
+        offs.clear();
+        for (int l = 0; l < c.n_convs; ++l)
+            for (int et = 0; et < 4; ++et)
+                for (int j = 0; j < c.n_message_gvps; ++j) offs.push_back(pack_gvp(h, msg_spec(c, l, et, j)));
+        h->n_msg_tot = (int)offs.size();
+        for (int l = 0; l < c.n_convs; ++l)
+            for (int nt = 0; nt < 2; ++nt)
+                for (int j = 0; j < c.n_update_gvps; ++j) offs.push_back(pack_gvp(h, upd_spec(c, l, nt, j)));
+        h->n_upd_tot = (int)offs.size() - h->n_msg_tot;
+        for (int k = 0; k < c.n_noise_gvps; ++k) offs.push_back(pack_gvp(h, head_spec(c, k)));
         for (int nt = 0; nt < 2; ++nt) {
-            size_t* lo = &h->ln_off[(size_t)(l * 2 + nt) * 4];
-            const std::string p1 = conv_prefix(l) + "message_layer_norms." + kNtKey[nt] + ".feat_norm.";
-            const std::string p2 = conv_prefix(l) + "update_layer_norms." + kNtKey[nt] + ".feat_norm.";
-            lo[0] = push(h->h_w, h->raw[p1 + "weight"].data);
-            lo[1] = push(h->h_w, h->raw[p1 + "bias"].data);
-            lo[2] = push(h->h_w, h->raw[p2 + "weight"].data);
-            lo[3] = push(h->h_w, h->raw[p2 + "bias"].data);
-        }
-    {   // to_scalar_output as A fragments: K = 64 (32 k-steps), rows = outputs
-        const RawTensor& W = h->raw["dynamics.noise_predictor.noise_predictor.to_scalar_output.weight"];
-        std::vector<float> a((size_t)32 * 64, 0.f);
-        for (int ks = 0; ks < 32; ++ks)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int i = lane & 31, hl = lane >> 5;
-                const int k = 32 * (ks / 16) + rho(ks % 16, hl);
-                a[(size_t)ks * 64 + lane] = i < c.pharm_nf ? W.data[(size_t)i * 64 + k] : 0.f;
+            const std::string p = std::string("dynamics.") + kNtKey[nt] + "_encoder.";
+            {   // encoder weight transposed to [nf+1][128]: coalesced loads of one input's column
+                const RawTensor& W = h->raw[p + "0.weight"];
+                const int K = (int)W.shape[1], S = (int)W.shape[0];
+                std::vector<float> wt((size_t)K * S);
+                for (int f = 0; f < S; ++f) for (int k = 0; k < K; ++k) wt[(size_t)k * S + f] = W.data[(size_t)f * K + k];
+                h->enc_w[nt] = push(h->h_w, wt);
             }
-        h->out_a = push(h->h_w, a);
-        h->out_b = push(h->h_w, h->raw["dynamics.noise_predictor.noise_predictor.to_scalar_output.bias"].data);
+            h->enc_b[nt] = push(h->h_w, h->raw[p + "0.bias"].data);
+            h->enc_lw[nt] = push(h->h_w, h->raw[p + "2.weight"].data);
+            h->enc_lb[nt] = push(h->h_w, h->raw[p + "2.bias"].data);
+        }
+        {   // protein encoder Linear [128][rec_nf+1] as A fragments [tile][k-step][lane]; k-step t, half hl <-> input 2t+hl
+            const RawTensor& W = h->raw["dynamics.prot_encoder.0.weight"];
+            const RawTensor& Bv = h->raw["dynamics.prot_encoder.0.bias"];
+            const int K = c.rec_nf + 1, nke = (K + 1) / 2;
+            std::vector<float> a((size_t)4 * nke * 64, 0.f), bf(128);
+            for (int mo = 0; mo < 4; ++mo)
+                for (int t = 0; t < nke; ++t)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 31, hl = lane >> 5, k = 2 * t + hl;
+                        a[((size_t)mo * nke + t) * 64 + lane] = k < K ? W.data[(size_t)(32 * mo + i) * K + k] : 0.f;
+                    }
+            for (int hl = 0; hl < 2; ++hl)
+                for (int mo = 0; mo < 4; ++mo)
+                    for (int r = 0; r < 16; ++r) bf[(size_t)hl * 64 + mo * 16 + r] = Bv.data[32 * mo + rho(r, hl)];
+            h->enc_a = push(h->h_w, a);
+            h->enc_bf = push(h->h_w, bf);
+        }
+        h->ln_off.assign((size_t)c.n_convs * 2 * 4, 0);
+        for (int l = 0; l < c.n_convs; ++l)
+            for (int nt = 0; nt < 2; ++nt) {
+                size_t* lo = &h->ln_off[(size_t)(l * 2 + nt) * 4];
+                const std::string p1 = conv_prefix(l) + "message_layer_norms." + kNtKey[nt] + ".feat_norm.";
+                const std::string p2 = conv_prefix(l) + "update_layer_norms." + kNtKey[nt] + ".feat_norm.";
+                lo[0] = push(h->h_w, h->raw[p1 + "weight"].data);
+                lo[1] = push(h->h_w, h->raw[p1 + "bias"].data);
+                lo[2] = push(h->h_w, h->raw[p2 + "weight"].data);
+                lo[3] = push(h->h_w, h->raw[p2 + "bias"].data);
+            }
+        {   // to_scalar_output as A fragments: K = 64 (32 k-steps), rows = outputs
+            const RawTensor& W = h->raw["dynamics.noise_predictor.noise_predictor.to_scalar_output.weight"];
+            std::vector<float> a((size_t)32 * 64, 0.f);
+            for (int ks = 0; ks < 32; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, hl = lane >> 5;
+                    const int k = 32 * (ks / 16) + rho(ks % 16, hl);
+                    a[(size_t)ks * 64 + lane] = i < c.pharm_nf ? W.data[(size_t)i * 64 + k] : 0.f;
+                }
+            h->out_a = push(h->h_w, a);
+            h->out_b = push(h->h_w, h->raw["dynamics.noise_predictor.noise_predictor.to_scalar_output.bias"].data);
+        }
+        while (h->h_w.size() % 64) h->h_w.push_back(0.f);
+    };
+    {
+        std::map<std::string, RawTensor> keep;
+        keep.swap(h->raw);
+        size_t off = 0;
+        for (const auto& kv : exp) {
+            RawTensor t;
+            t.shape = keep[kv.first].shape;
+            t.data.resize(keep[kv.first].data.size());
+            for (size_t i = 0; i < t.data.size(); ++i) t.data[i] = (float)(off + i + 1);
+            off += t.data.size();
+            h->raw[kv.first] = std::move(t);
+        }
+        h->h_map.clear();
+        if (off < (size_t(1) << 24)) {           // indices are exact in fp32
+            pack_all();
+            h->h_map.resize(h->h_w.size());
+            for (size_t i = 0; i < h->h_w.size(); ++i) h->h_map[i] = (int)h->h_w[i] - 1;      // -1: zero padding
+        }
+        h->raw.swap(keep);
     }
-    while (h->h_w.size() % 64) h->h_w.push_back(0.f);
+    pack_all();
     if (h->d_w) { (void)hipFree(h->d_w); h->d_w = nullptr; }
     if (h->d_gvp) { (void)hipFree(h->d_gvp); h->d_gvp = nullptr; }
     PF_HIP(h, hipMalloc((void**)&h->d_w, h->h_w.size() * sizeof(float)));
     PF_HIP(h, hipMemcpy(h->d_w, h->h_w.data(), h->h_w.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->n_packed = h->h_w.size();
+    if (h->d_map) { (void)hipFree(h->d_map); h->d_map = nullptr; }
+    if (!h->h_map.empty()) {
+        if (h->h_map.size() != h->h_w.size()) PF_FAIL(h, PF_ERR_STATE, "internal: gather map does not match the packed weights");
+        PF_HIP(h, hipMalloc((void**)&h->d_map, h->h_map.size() * sizeof(int)));
+        PF_HIP(h, hipMemcpy(h->d_map, h->h_map.data(), h->h_map.size() * sizeof(int), hipMemcpyHostToDevice));
+        h->h_map.clear();
+        h->h_map.shrink_to_fit();
+    }
     for (const GvpOff& o : offs) {
         GvpW g;
         g.a_wh = h->d_w + o.wh; g.a_wu = h->d_w + o.wu; g.a_main = h->d_w + o.a_main; g.a_main_c = h->d_w + o.a_main_c; g.b_main = h->d_w + o.b_main;
@@ -1151,6 +1193,26 @@ int pf_param_layout(pf_handle* h, int32_t index, const char** name, int64_t* off
     return PF_OK;
 }
 
+int pf_set_flat_params(pf_handle* h, const float* dev_flat, pf_stream stream) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!dev_flat) PF_FAIL(h, PF_ERR_ARG, "pf_set_flat_params: null argument");
+    if (!h->d_map) PF_FAIL(h, PF_ERR_STATE, "pf_set_flat_params: no gather map (more than 2^24 parameters)");
+    hipStream_t s = (hipStream_t)stream;
+    PF_HIP(h, hipMemcpyAsync(h->d_flat, dev_flat, h->nparams * sizeof(float), hipMemcpyDeviceToDevice, s));
+    pfk_gather_weights(h->d_flat, h->d_map, h->n_packed, h->d_w, s);
+    h->t_have_fwd = false;
+    return PF_OK;
+}
+
+int pf_get_flat_params(pf_handle* h, float* dev_flat, pf_stream stream) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!dev_flat) PF_FAIL(h, PF_ERR_ARG, "pf_get_flat_params: null argument");
+    PF_HIP(h, hipMemcpyAsync(dev_flat, h->d_flat, h->nparams * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PF_OK;
+}
+
 int pf_train_forward(pf_handle* h, const float* dev_prot_x, const float* dev_pharm_x, const float* dev_pharm_h,
                      const float* dev_t, float dropout_p, uint32_t seed, float* dev_eps_h, float* dev_eps_x, pf_stream stream) {
     int rc = check_ready(h, true);
@@ -1165,6 +1227,7 @@ int pf_train_forward(pf_handle* h, const float* dev_prot_x, const float* dev_pha
     h->t_common.drop_thr = dropout_p > 0.f ? (uint32_t)std::min(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
     h->t_common.drop_scale = 1.0f / (1.0f - dropout_p);
     h->t_common.seed = seed;
+    h->t_common.mask_override = h->t_mask_override; h->t_common.mask_N = h->N;
     load_state(h, dev_prot_x, dev_pharm_x, dev_pharm_h, s);
     pfk_copy(dev_t, h->d_t, (size_t)h->B, s);
     rc = run_dynamics(h, dev_eps_h, dev_eps_x, s, nullptr, true);
@@ -1264,6 +1327,12 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     pfk_train_reduce(h->t_gpart, nb, (int)h->nparams, dev_grad, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return PF_OK;
+}
+
+int pf_debug_set_dropout_masks(pf_handle* h, const float* dev_masks) {
+    if (!h) return PF_ERR_ARG;
+    h->t_mask_override = dev_masks;
     return PF_OK;
 }
 

@@ -449,15 +449,16 @@ __device__ __forceinline__ void gvp_layernorm(pf_gcf lw, pf_gcf lb, const int hl
 __device__ __forceinline__ void node_dropout(const NodeParams& p, const uint32_t stream, const int n, const int hl,
                                              float (&s)[64], float (&V)[3][8]) {
     const uint32_t base = (uint32_t)n * 144u;
+    const float* ov = p.mask_override ? p.mask_override + (size_t)stream * p.N * 144u : nullptr;
 #pragma unroll
     for (int q = 0; q < 64; ++q) {
         const uint32_t f = 32u * (q >> 4) + ((q & 3) + 8 * ((q & 15) >> 2) + 4 * hl);
-        s[q] *= pf_drop_hash(p.seed, stream, base + f) < p.drop_thr ? 0.0f : p.drop_scale;
+        s[q] *= ov ? ov[base + f] : (pf_drop_hash(p.seed, stream, base + f) < p.drop_thr ? 0.0f : p.drop_scale);
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const uint32_t ch = (t & 3) + 8 * (t >> 2) + 4 * hl;
-        const float m = pf_drop_hash(p.seed, stream, base + 128u + ch) < p.drop_thr ? 0.0f : p.drop_scale;
+        const float m = ov ? ov[base + 128u + ch] : (pf_drop_hash(p.seed, stream, base + 128u + ch) < p.drop_thr ? 0.0f : p.drop_scale);
         V[0][t] *= m; V[1][t] *= m; V[2][t] *= m;
     }
 }
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(64, PF_WPS_NODE) void k_node_update(const NodeParam
 #pragma unroll
             for (int q = 0; q < 8; ++q) V[c][q] = 0.f;
     }
-    if (p.drop_thr != 0u) node_dropout(p, (uint32_t)p.layer * 2u, n, hl, ms, mv);      // gvp.py:518 (training forward)
+    if (p.drop_thr != 0u || p.mask_override != nullptr) node_dropout(p, (uint32_t)p.layer * 2u, n, hl, ms, mv);      // gvp.py:518 (training forward)
 #pragma unroll
     for (int q = 0; q < 64; ++q) s[q] = fmaf(ms[q], inv_norm, s[q]);
 #pragma unroll
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(64, PF_WPS_NODE) void k_node_update(const NodeParam
 #pragma unroll
             for (int q = 0; q < 8; ++q) V1[c][q] = V2[c][q];
     }
-    if (p.drop_thr != 0u) node_dropout(p, (uint32_t)p.layer * 2u + 1u, n, hl, s1, V1);      // gvp.py:529
+    if (p.drop_thr != 0u || p.mask_override != nullptr) node_dropout(p, (uint32_t)p.layer * 2u + 1u, n, hl, s1, V1);      // gvp.py:529
 #pragma unroll
     for (int q = 0; q < 64; ++q) s[q] += s1[q];
 #pragma unroll

@@ -30,6 +30,8 @@ struct TrainCommon {
     uint32_t drop_thr;       // an element is dropped iff pf_drop_hash(...) < drop_thr  (= p * 2^32; 0: no dropout)
     float drop_scale;        // 1 / (1 - p)
     uint32_t seed;           // dropout stream of this step
+    const float* mask_override;   // tests: multipliers [n_convs * 2 streams][N * 144] used instead of the hash, or NULL
+    int mask_N;
 };
 
 struct BwdHeadParams {

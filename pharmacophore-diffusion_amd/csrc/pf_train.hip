@@ -32,6 +32,7 @@ __device__ __forceinline__ float t_silu(float x) { return x * t_sigmoid(x); }
 __device__ __forceinline__ float t_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 __device__ __forceinline__ float drop_mul(const TrainCommon& c, const uint32_t stream, const uint32_t elem) {
+    if (c.mask_override != nullptr) return c.mask_override[(size_t)stream * c.mask_N * 144u + elem];
     if (c.drop_thr == 0u) return 1.0f;
     return pf_drop_hash(c.seed, stream, elem) < c.drop_thr ? 0.0f : c.drop_scale;
 }
@@ -120,9 +121,15 @@ __device__ __forceinline__ void mm16_acc(const int M, const int N, const int K, 
 
 // diagnostic builds (-DPFT_STAMPS): cycle stamps of block 0's first sub-tile at phase boundaries
 #ifdef PFT_STAMPS
+#ifndef PFT_STAMP_BLOCK
+#define PFT_STAMP_BLOCK 0
+#endif
 __device__ unsigned long long g_pft_stamps[128];
 __device__ int g_pft_nstamp;
-#define PFT_STAMP(id) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_pft_nstamp < 126) { g_pft_stamps[g_pft_nstamp] = ((unsigned long long)(id) << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull); g_pft_nstamp++; } } while (0)
+#ifndef PFT_STAMP_MIN
+#define PFT_STAMP_MIN 0
+#endif
+#define PFT_STAMP(id) do { if ((id) >= PFT_STAMP_MIN && blockIdx.x == PFT_STAMP_BLOCK && threadIdx.x == 0 && g_pft_nstamp < 126) { g_pft_stamps[g_pft_nstamp] = ((unsigned long long)(id) << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull); g_pft_nstamp++; } } while (0)
 #else
 #define PFT_STAMP(id) do { } while (0)
 #endif
@@ -644,101 +651,53 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// edge message backward (gvp.py:472-485, 540-551): recompute the message chain of 16 edges, push the destination's
-// aggregate gradient through it, accumulate weight gradients and scatter the source-row gradients
+// edge message backward, one GVP level per launch (see BwdEdgeLevelParams).  A pass is one tile of 32 edge slots = two
+// column tiles of the data products (the weight fragment of a k-step is fetched once for both) and eight k-steps of
+// the weight-gradient products.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT, 1) void k_bwd_edge(const BwdEdgeParams p) {
-    __shared__ float lds[CHAIN_FLOATS(PFT_MAX_CHAIN)];
-    __shared__ int s_src[TR], s_dst[TR];
-    __shared__ float s_sc[TR];
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    ChainLds L; L.init(lds, p.n_gvps);
-    const float* W = p.c.W;
-    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
-    for (int ti = blockIdx.x; ti < p.ntiles; ti += gridDim.x) {
-        const EdgeTile t = p.tiles[ti];
-        int nvalid = t.n;
-        if (t.cnt_idx >= 0) nvalid = min(nvalid, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
-        const GvpT* g = p.g + t.et * p.n_gvps;
-        const int slot = (t.et == ET_FF || t.et == ET_FP) ? 0 : 1;
-        for (int sub = 0; sub * TR < nvalid; ++sub) {
-            const int nv = min(TR, nvalid - sub * TR);
-            const int e0 = t.e0 + sub * TR;
-            float* S0 = L.Sin(0); float* V0 = L.Vin(0);
-            if (tid < TR) {
-                const int e = e0 + min(tid, nv - 1);
-                const int src = p.esrc[e], dst = p.edst[e];
-                s_src[tid] = src; s_dst[tid] = dst;
-                const float4 xs = p.xn[src], xd = p.xn[dst];
-                const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
-                const float d = t_sqrt(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
-                const float rd = __builtin_amdgcn_rcpf(d);
-                V0[tid * VWS + 0] = dx * rd; V0[tid * VWS + 1] = dy * rd; V0[tid * VWS + 2] = dz * rd;
-                for (int k = 0; k < PF_R; ++k) {
-                    const float z = (d - p.rbf_mu[k]) * p.rbf_inv_sigma;
-                    S0[tid * SWS + PF_S + k] = __expf(-(z * z));
-                }
-                float sc = 1.0f;
-                if (p.norm_mode == 0) sc = 1.0f / (float)p.in_cnt[slot * p.N + dst];
-                s_sc[tid] = tid < nv ? sc : 0.f;
+#define ER 32             // rows per pass
+// C[M x 16 NTN] = A[M x K] B[K x 16 NTN]: a wave owns whole 16-row blocks of C, so one A fragment serves NTN MFMAs
+template <int UNR, int NTN, typename FA, typename FB, typename FC>
+__device__ __forceinline__ void mmR(const int M, const int K, FA a, FB b, FC c, const int lane, const int wv) {
+    const int mts = (M + 15) >> 4;
+    const int li = lane & 15, kq = lane >> 4;
+    for (int mt = wv; mt < mts; mt += NT / 64) {
+        const int ai = mt * 16 + li;
+        const bool aok = ai < M;
+        f32x4 acc[NTN];
+#pragma unroll
+        for (int n = 0; n < NTN; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += 4 * UNR) {
+            float av[UNR], bv[NTN][UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int k = k0 + 4 * u + kq;
+                const bool kok = k < K;
+                av[u] = (aok && kok) ? a(ai, k) : 0.f;
+#pragma unroll
+                for (int n = 0; n < NTN; ++n) bv[n][u] = kok ? b(k, n * 16 + li) : 0.f;
             }
-            __syncthreads();
-            for (int idx = tid; idx < TR * 32; idx += NT) {
-                const int row = idx >> 5, q = idx & 31;
-                const float4 x = reinterpret_cast<const float4*>(p.h + (size_t)s_src[row] * PF_S)[q];
-                float* d = S0 + row * SWS + 4 * q;
-                d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
-            }
-            for (int idx = tid; idx < TR * 12; idx += NT) {
-                const int row = idx / 12, q = idx - row * 12;
-                float4 x = {0.f, 0.f, 0.f, 0.f};
-                if (!p.l0) x = reinterpret_cast<const float4*>(p.v + (size_t)s_src[row] * 48)[q];
-                float* d = V0 + row * VWS + 3 + 4 * q;
-                d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
-            }
-            __syncthreads();
-            PFT_STAMP(20);
-            chain_fwd(L, g, W, nullptr, tid, lane, wv);
-            PFT_STAMP(21);
-            for (int idx = tid; idx < TR * 128; idx += NT) {
-                const int row = idx >> 7, f = idx & 127;
-                L.gX[row * SWS + f] = p.gagg_s[(size_t)s_dst[row] * PF_S + f] * s_sc[row];
-            }
-            for (int idx = tid; idx < TR * 48; idx += NT) {
-                const int row = idx / 48, q = idx - row * 48;
-                L.gVX[row * VWS + q] = p.gagg_v[(size_t)s_dst[row] * 48 + q] * s_sc[row];
-            }
-            __syncthreads();
-            float *gs, *gv;
-            PFT_STAMP(22);
-            chain_bwd(L, g, W, gp, gs, gv, tid, lane, wv);
-            PFT_STAMP(23);
-            for (int idx = tid; idx < TR * 128; idx += NT) {
-                const int row = idx >> 7, f = idx & 127;
-                if (row < nv) unsafeAtomicAdd(p.G_h_in + (size_t)s_src[row] * PF_S + f, gs[row * SWS + f]);
-            }
-            if (!p.l0)
-                for (int idx = tid; idx < TR * 48; idx += NT) {
-                    const int row = idx / 48, q = idx - row * 48;
-                    if (row < nv) unsafeAtomicAdd(p.G_v_in + (size_t)s_src[row] * 48 + q, gv[row * VWS + 3 + q]);
-                }
-            __syncthreads();
-            PFT_STAMP(24);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int n = 0; n < NTN; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[n][u], acc[n], 0, 0, 0);
         }
+#pragma unroll
+        for (int n = 0; n < NTN; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = mt * 16 + kq * 4 + r;
+                if (ci < M) c(ci, n * 16 + li, acc[n][r]);
+            }
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// edge message backward, one GVP level per launch (see BwdEdgeLevelParams)
-// ---------------------------------------------------------------------------------------------
-#define KMS 168           // LDS row stride of the staged to_feats_out weight [so][si + h]
 __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelParams p) {
-    __shared__ float Wl[PF_S * KMS];
-    __shared__ float Zb[TR * ZS], Sin[TR * SWS], gA[TR * SWS], gS[TR * SWS];
-    __shared__ float gate[TR * GTS], ggate[TR * GTS];
-    __shared__ float Vin[TR * VWS], Vh[TR * VWS], Vu[TR * VWS], gVo[TR * VWS], gVh[TR * VWS], gVi[TR * VWS];
-    __shared__ int s_src[TR], s_dst[TR], s_e[TR];
-    __shared__ float s_sc[TR];
+    __shared__ float Zb[ER * ZS], Sin[ER * SWS], gA[ER * SWS], gS[ER * SWS];
+    __shared__ float gate[ER * GTS], ggate[ER * GTS];
+    __shared__ float Vin[ER * VWS], Vh[ER * VWS], Vu[ER * VWS], gVo[ER * VWS], gVh[ER * VWS], gVi[ER * VWS];
+    __shared__ int s_src[ER], s_dst[ER], s_e[ER];
+    __shared__ float s_sc[ER];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
     int et = 0;
@@ -747,202 +706,238 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
     const GvpT g = p.g[et * p.n_gvps + p.level];
     const float* W = p.c.W;
     float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
-    const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;   // SO == 128, VO == 16 (host checks)
+    const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;   // SO == 128, VO == 16 (message GVPs)
     const int nts = (KM + 15) >> 4;                  // <= 11
     const bool lastl = p.level == p.n_gvps - 1, firstl = p.level == 0;
     const int slot = (et == ET_FF || et == ET_FP) ? 0 : 1;
-    for (int idx = tid; idx < SO * KM; idx += NT) {
-        const int o = idx / KM, k = idx - o * KM;
-        Wl[o * KMS + k] = W[g.o_Wm + idx];
-    }
-    f32x4 accWm[11], accWg = {0.f, 0.f, 0.f, 0.f};
+    // weight-gradient accumulators, kept in registers over all the tiles of this block:
+    //   to_feats_out: wave wv owns output features 16 wv .. +15, tile x = inputs 16 x .. +15
+    //   gates: wave wv owns features 16 wv .. +15 of all 16 gates
+    //   Wu (waves 0, 1: hidden channels 16 wv ..) and Wh (waves 2..5: tile (vi block (wv-2)>>1, hidden block (wv-2)&1))
+    f32x4 accWm[11], accWg = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int x = 0; x < 11; ++x) accWm[x] = f32x4{0.f, 0.f, 0.f, 0.f};
     float acc_bm = 0.f, acc_bg = 0.f;                // bias gradients of feature tid (< SO) / gate tid (< VO)
-    __syncthreads();
     const float* zl = p.sv_z + (size_t)p.level * p.sv_stride * PF_S;
     const float* gl = p.sv_g + (size_t)p.level * p.sv_stride * 16;
     const float* zprev = firstl ? nullptr : p.sv_z + (size_t)(p.level - 1) * p.sv_stride * PF_S;
     const float* vprev = firstl ? nullptr : p.sv_v + (size_t)(p.level - 1) * p.sv_stride * 48;
     for (int ti = p.et_tile0[et] + my; ti < p.et_tile0[et + 1]; ti += nb) {
         const EdgeTile t = p.tiles[ti];
-        int nvalid = t.n;
-        if (t.cnt_idx >= 0) nvalid = min(nvalid, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
-        for (int sub = 0; sub * TR < nvalid; ++sub) {
-            const int nv = min(TR, nvalid - sub * TR);
-            const int e0 = t.e0 + sub * TR;
-            if (tid < TR) {
-                const int e = e0 + min(tid, nv - 1);
-                s_e[tid] = e;
-                if (firstl || lastl) {
-                    const int src = p.esrc[e], dst = p.edst[e];
-                    s_src[tid] = src; s_dst[tid] = dst;
-                    if (firstl) {
-                        const float4 xs = p.xn[src], xd = p.xn[dst];
-                        const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
-                        const float d = t_sqrt(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
-                        const float rd = __builtin_amdgcn_rcpf(d);
-                        Vin[tid * VWS + 0] = dx * rd; Vin[tid * VWS + 1] = dy * rd; Vin[tid * VWS + 2] = dz * rd;
-                        for (int k = 0; k < PF_R; ++k) {
-                            const float z = (d - p.rbf_mu[k]) * p.rbf_inv_sigma;
-                            Sin[tid * SWS + PF_S + k] = __expf(-(z * z));
-                        }
+        int nv = t.n;
+        if (t.cnt_idx >= 0) nv = min(nv, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
+        if (nv <= 0) continue;
+        PFT_STAMP(30);
+        if (tid < ER) {
+            const int e = t.e0 + min(tid, nv - 1);
+            s_e[tid] = e;
+            if (firstl || lastl) {
+                const int src = p.esrc[e], dst = p.edst[e];
+                s_src[tid] = src; s_dst[tid] = dst;
+                if (firstl) {
+                    const float4 xs = p.xn[src], xd = p.xn[dst];
+                    const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
+                    const float d = t_sqrt(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+                    const float rd = __builtin_amdgcn_rcpf(d);
+                    Vin[tid * VWS + 0] = dx * rd; Vin[tid * VWS + 1] = dy * rd; Vin[tid * VWS + 2] = dz * rd;
+                    for (int k = 0; k < PF_R; ++k) {
+                        const float z = (d - p.rbf_mu[k]) * p.rbf_inv_sigma;
+                        Sin[tid * SWS + PF_S + k] = __expf(-(z * z));
                     }
-                    float sc = 1.0f;
-                    if (lastl && p.norm_mode == 0) sc = 1.0f / (float)p.in_cnt[slot * p.N + dst];
-                    s_sc[tid] = sc;
                 }
+                float sc = 1.0f;
+                if (lastl && p.norm_mode == 0) sc = 1.0f / (float)p.in_cnt[slot * p.N + dst];
+                s_sc[tid] = tid < nv ? sc : 0.f;
             }
-            __syncthreads();
-            // ---- rows of this level from the forward, inputs of the level, upstream gradients
-            for (int idx = tid; idx < TR * 32; idx += NT) {
-                const int row = idx >> 5, q = idx & 31;
-                const int e = s_e[row];
-                const float4 z = reinterpret_cast<const float4*>(zl + (size_t)e * PF_S)[q];
-                float* d = Zb + row * ZS + 4 * q;
-                d[0] = z.x; d[1] = z.y; d[2] = z.z; d[3] = z.w;
-                float4 x;
-                if (firstl) x = reinterpret_cast<const float4*>(p.h + (size_t)s_src[row] * PF_S)[q];
-                else {
-                    x = reinterpret_cast<const float4*>(zprev + (size_t)e * PF_S)[q];
-                    x.x = t_silu(x.x); x.y = t_silu(x.y); x.z = t_silu(x.z); x.w = t_silu(x.w);
-                }
-                float* s = Sin + row * SWS + 4 * q;
-                s[0] = x.x; s[1] = x.y; s[2] = x.z; s[3] = x.w;
-                float4 u;
-                if (lastl) {
-                    u = reinterpret_cast<const float4*>(p.gagg_s + (size_t)s_dst[row] * PF_S)[q];
-                    const float sc = row < nv ? s_sc[row] : 0.f;
-                    u.x *= sc; u.y *= sc; u.z *= sc; u.w *= sc;
-                } else {
-                    u = reinterpret_cast<const float4*>(p.gs_buf + (size_t)e * PF_S)[q];
-                    if (row >= nv) u = float4{0.f, 0.f, 0.f, 0.f};
-                }
-                float* ga = gA + row * SWS + 4 * q;
-                ga[0] = u.x; ga[1] = u.y; ga[2] = u.z; ga[3] = u.w;
-            }
-            for (int idx = tid; idx < TR * 12; idx += NT) {
-                const int row = idx / 12, q = idx - row * 12;
-                const int e = s_e[row];
-                float4 x = {0.f, 0.f, 0.f, 0.f};
-                if (firstl) { if (!p.l0) x = reinterpret_cast<const float4*>(p.v + (size_t)s_src[row] * 48)[q]; }
-                else x = reinterpret_cast<const float4*>(vprev + (size_t)e * 48)[q];
-                float* d = Vin + row * VWS + (firstl ? 3 : 0) + 4 * q;
-                d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
-                float4 u;
-                if (lastl) {
-                    u = reinterpret_cast<const float4*>(p.gagg_v + (size_t)s_dst[row] * 48)[q];
-                    const float sc = row < nv ? s_sc[row] : 0.f;
-                    u.x *= sc; u.y *= sc; u.z *= sc; u.w *= sc;
-                } else {
-                    u = reinterpret_cast<const float4*>(p.gv_buf + (size_t)e * 48)[q];
-                    if (row >= nv) u = float4{0.f, 0.f, 0.f, 0.f};
-                }
-                float* go = gVo + row * VWS + 4 * q;
-                go[0] = u.x; go[1] = u.y; go[2] = u.z; go[3] = u.w;
-            }
-            for (int idx = tid; idx < TR * 16; idx += NT) {
-                const int row = idx >> 4, u = idx & 15;
-                gate[row * GTS + u] = gl[(size_t)s_e[row] * 16 + u];
-            }
-            __syncthreads();
-            gvp_vec(g, W, Sin, Vin, Vh, Vu, true, tid, lane, wv);
-            // ---- gate: V' = sigmoid(gate) Vu
-            for (int idx = tid; idx < TR * VO; idx += NT) {
-                const int row = idx & 15, u = idx >> 4;
-                const float gt = gate[row * GTS + u];
-                float* go = gVo + row * VWS + u * 3;
-                const float* vu = Vu + row * VWS + u * 3;
-                const float dot = go[0] * vu[0] + go[1] * vu[1] + go[2] * vu[2];
-                const float f = t_sigmoid(gt);
-                ggate[row * GTS + u] = dot * f * (1.0f - f);
-                go[0] *= f; go[1] *= f; go[2] *= f;
-            }
-            __syncthreads();
-            mm16<4>(SO, TR, VO,
-                 [&](int i, int k) { return W[g.o_Wg + k * SO + i]; },
-                 [&](int k, int j) { return ggate[j * GTS + k]; },
-                 [&](int i, int j, float x) { gA[j * SWS + i] += x; }, lane, wv);
-            {   // dWg tile (gates x features 16 wv .. 16 wv + 15) += ggate^T SiLU(Z)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = 4 * u + kq;
-                    accWg = __builtin_amdgcn_mfma_f32_16x16x4f32(ggate[k * GTS + li], t_silu(Zb[k * ZS + wv * 16 + li]), accWg, 0, 0, 0);
-                }
-                if (tid < VO) { float s = 0.f; for (int r = 0; r < TR; ++r) s += ggate[r * GTS + tid]; acc_bg += s; }
-            }
-            __syncthreads();
-            for (int idx = tid; idx < TR * SO; idx += NT) {
-                const int row = idx & 15, o = idx >> 4;
-                const float z = Zb[row * ZS + o];
-                const float s = t_sigmoid(z);
-                gA[row * SWS + o] *= s * (1.0f + z * (1.0f - s));
-            }
-            __syncthreads();
-            mm16<8>(KM, TR, SO,
-                 [&](int i, int k) { return Wl[k * KMS + i]; },
-                 [&](int k, int j) { return gA[j * SWS + k]; },
-                 [&](int i, int j, float x) { gS[j * SWS + i] = x; }, lane, wv);
-            {   // dWm tiles (features 16 wv .., inputs 16 x ..) += gZ^T [s, sh]
-                float av[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) av[u] = gA[(4 * u + kq) * SWS + wv * 16 + li];
-#pragma unroll
-                for (int x = 0; x < 11; ++x)
-                    if (x < nts) {
-                        const int cj = x * 16 + li;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            accWm[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], cj < KM ? Sin[(4 * u + kq) * SWS + cj] : 0.f, accWm[x], 0, 0, 0);
-                    }
-                if (tid < SO) { float s = 0.f; for (int r = 0; r < TR; ++r) s += gA[r * SWS + tid]; acc_bm += s; }
-            }
-            __syncthreads();
-            mm16<4>(KH, 3 * TR, VO,
-                 [&](int i, int k) { return W[g.o_Wu + i * VO + k]; },
-                 [&](int k, int j) { return gVo[(j & 15) * VWS + k * 3 + (j >> 4)]; },
-                 [&](int i, int j, float x) {
-                     const int row = j & 15, cc = j >> 4;
-                     const float* q = Vh + row * VWS + i * 3;
-                     const float ss = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
-                     const float extra = ss > 1e-8f ? gS[row * SWS + SI + i] * q[cc] / Sin[row * SWS + SI + i] : 0.f;
-                     gVh[row * VWS + i * 3 + cc] = x + extra;
-                 }, lane, wv);
-            mm16_acc<4>(KH, VO, 3 * TR,
-                 [&](int i, int k) { return Vh[(k & 15) * VWS + i * 3 + (k >> 4)]; },
-                 [&](int k, int j) { return gVo[(k & 15) * VWS + j * 3 + (k >> 4)]; }, gp + g.o_Wu, VO, lane, wv);
-            __syncthreads();
-            mm16<5>(VI, 3 * TR, KH,
-                 [&](int i, int k) { return W[g.o_Wh + i * KH + k]; },
-                 [&](int k, int j) { return gVh[(j & 15) * VWS + k * 3 + (j >> 4)]; },
-                 [&](int i, int j, float x) { gVi[(j & 15) * VWS + i * 3 + (j >> 4)] = x; }, lane, wv);
-            mm16_acc<4>(VI, KH, 3 * TR,
-                 [&](int i, int k) { return Vin[(k & 15) * VWS + i * 3 + (k >> 4)]; },
-                 [&](int k, int j) { return gVh[(k & 15) * VWS + j * 3 + (k >> 4)]; }, gp + g.o_Wh, KH, lane, wv);
-            __syncthreads();
-            // ---- hand the input gradients down: to the level below, or (level 0) to the source nodes
-            if (!firstl) {
-                for (int idx = tid; idx < TR * 128; idx += NT) {
-                    const int row = idx >> 7, f = idx & 127;
-                    if (row < nv) p.gs_buf[(size_t)s_e[row] * PF_S + f] = gS[row * SWS + f];
-                }
-                for (int idx = tid; idx < TR * 48; idx += NT) {
-                    const int row = idx / 48, q = idx - row * 48;
-                    if (row < nv) p.gv_buf[(size_t)s_e[row] * 48 + q] = gVi[row * VWS + q];
-                }
-            } else {
-                for (int idx = tid; idx < TR * 128; idx += NT) {
-                    const int row = idx >> 7, f = idx & 127;
-                    if (row < nv) unsafeAtomicAdd(p.G_h_in + (size_t)s_src[row] * PF_S + f, gS[row * SWS + f]);
-                }
-                if (!p.l0)
-                    for (int idx = tid; idx < TR * 48; idx += NT) {
-                        const int row = idx / 48, q = idx - row * 48;
-                        if (row < nv) unsafeAtomicAdd(p.G_v_in + (size_t)s_src[row] * 48 + q, gVi[row * VWS + 3 + q]);
-                    }
-            }
-            __syncthreads();
         }
+        __syncthreads();
+        // ---- rows of this level from the forward, inputs of the level, upstream gradients
+        for (int idx = tid; idx < ER * 32; idx += NT) {
+            const int row = idx >> 5, q = idx & 31;
+            const int e = s_e[row];
+            const float4 z = reinterpret_cast<const float4*>(zl + (size_t)e * PF_S)[q];
+            float* d = Zb + row * ZS + 4 * q;
+            d[0] = z.x; d[1] = z.y; d[2] = z.z; d[3] = z.w;
+            float4 x;
+            if (firstl) x = reinterpret_cast<const float4*>(p.h + (size_t)s_src[row] * PF_S)[q];
+            else {
+                x = reinterpret_cast<const float4*>(zprev + (size_t)e * PF_S)[q];
+                x.x = t_silu(x.x); x.y = t_silu(x.y); x.z = t_silu(x.z); x.w = t_silu(x.w);
+            }
+            float* sp = Sin + row * SWS + 4 * q;
+            sp[0] = x.x; sp[1] = x.y; sp[2] = x.z; sp[3] = x.w;
+            float4 u;
+            if (lastl) {
+                u = reinterpret_cast<const float4*>(p.gagg_s + (size_t)s_dst[row] * PF_S)[q];
+                const float sc = s_sc[row];
+                u.x *= sc; u.y *= sc; u.z *= sc; u.w *= sc;
+            } else {
+                u = reinterpret_cast<const float4*>(p.gs_buf + (size_t)e * PF_S)[q];
+                if (row >= nv) u = float4{0.f, 0.f, 0.f, 0.f};
+            }
+            float* ga = gA + row * SWS + 4 * q;
+            ga[0] = u.x; ga[1] = u.y; ga[2] = u.z; ga[3] = u.w;
+        }
+        for (int idx = tid; idx < ER * 12; idx += NT) {
+            const int row = idx / 12, q = idx - row * 12;
+            const int e = s_e[row];
+            float4 x = {0.f, 0.f, 0.f, 0.f};
+            if (firstl) { if (!p.l0) x = reinterpret_cast<const float4*>(p.v + (size_t)s_src[row] * 48)[q]; }
+            else x = reinterpret_cast<const float4*>(vprev + (size_t)e * 48)[q];
+            float* d = Vin + row * VWS + (firstl ? 3 : 0) + 4 * q;
+            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+            float4 u;
+            if (lastl) {
+                u = reinterpret_cast<const float4*>(p.gagg_v + (size_t)s_dst[row] * 48)[q];
+                const float sc = s_sc[row];
+                u.x *= sc; u.y *= sc; u.z *= sc; u.w *= sc;
+            } else {
+                u = reinterpret_cast<const float4*>(p.gv_buf + (size_t)e * 48)[q];
+                if (row >= nv) u = float4{0.f, 0.f, 0.f, 0.f};
+            }
+            float* go = gVo + row * VWS + 4 * q;
+            go[0] = u.x; go[1] = u.y; go[2] = u.z; go[3] = u.w;
+        }
+        for (int idx = tid; idx < ER * 16; idx += NT) {
+            const int row = idx >> 4, u = idx & 15;
+            gate[row * GTS + u] = gl[(size_t)s_e[row] * 16 + u];
+        }
+        __syncthreads();
+        PFT_STAMP(31);
+        // ---- Vh = Wh^T V, sh, Vu = Wu^T Vh (columns: coordinate c = j >> 5 of row j & 31)
+        mmR<5, 6>(KH, VI,
+             [&](int i, int k) { return W[g.o_Wh + k * KH + i]; },
+             [&](int k, int j) { return Vin[(j & 31) * VWS + k * 3 + (j >> 5)]; },
+             [&](int i, int j, float x) { Vh[(j & 31) * VWS + i * 3 + (j >> 5)] = x; }, lane, wv);
+        __syncthreads();
+        for (int idx = tid; idx < ER * KH; idx += NT) {
+            const int row = idx & 31, hh = idx >> 5;
+            const float* q = Vh + row * VWS + hh * 3;
+            Sin[row * SWS + SI + hh] = t_sqrt(fmaxf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2], 1e-8f));
+        }
+        mmR<5, 6>(VO, KH,
+             [&](int i, int k) { return W[g.o_Wu + k * VO + i]; },
+             [&](int k, int j) { return Vh[(j & 31) * VWS + k * 3 + (j >> 5)]; },
+             [&](int i, int j, float x) { Vu[(j & 31) * VWS + i * 3 + (j >> 5)] = x; }, lane, wv);
+        __syncthreads();
+        PFT_STAMP(32);
+        // ---- gate: V' = sigmoid(gate) Vu
+        for (int idx = tid; idx < ER * VO; idx += NT) {
+            const int row = idx & 31, u = idx >> 5;
+            const float gt = gate[row * GTS + u];
+            float* go = gVo + row * VWS + u * 3;
+            const float* vu = Vu + row * VWS + u * 3;
+            const float dot = go[0] * vu[0] + go[1] * vu[1] + go[2] * vu[2];
+            const float f = t_sigmoid(gt);
+            ggate[row * GTS + u] = dot * f * (1.0f - f);
+            go[0] *= f; go[1] *= f; go[2] *= f;
+        }
+        __syncthreads();
+        PFT_STAMP(33);
+        mmR<4, 2>(SO, VO,
+             [&](int i, int k) { return W[g.o_Wg + k * SO + i]; },
+             [&](int k, int j) { return ggate[j * GTS + k]; },
+             [&](int i, int j, float x) { gA[j * SWS + i] += x; }, lane, wv);
+        {   // dWg tile (16 gates x features 16 wv .. +15) += ggate^T SiLU(Z)
+#pragma unroll
+            for (int u = 0; u < ER / 4; ++u) {
+                const int k = 4 * u + kq;
+                accWg = __builtin_amdgcn_mfma_f32_16x16x4f32(ggate[k * GTS + li], t_silu(Zb[k * ZS + wv * 16 + li]), accWg, 0, 0, 0);
+            }
+            if (tid < VO) { float sm = 0.f; for (int r = 0; r < ER; ++r) sm += ggate[r * GTS + tid]; acc_bg += sm; }
+        }
+        __syncthreads();
+        PFT_STAMP(34);
+        for (int idx = tid; idx < ER * SO; idx += NT) {
+            const int row = idx & 31, o = idx >> 5;
+            const float z = Zb[row * ZS + o];
+            const float sg = t_sigmoid(z);
+            gA[row * SWS + o] *= sg * (1.0f + z * (1.0f - sg));
+        }
+        __syncthreads();
+        PFT_STAMP(35);
+        mmR<8, 2>(KM, SO,
+             [&](int i, int k) { return W[g.o_Wm + k * KM + i]; },
+             [&](int k, int j) { return gA[j * SWS + k]; },
+             [&](int i, int j, float x) { gS[j * SWS + i] = x; }, lane, wv);
+        PFT_STAMP(39);
+        {   // dWm tiles (features 16 wv .., inputs 16 x ..) += gZ^T [s, sh]
+            float av[ER / 4];
+#pragma unroll
+            for (int u = 0; u < ER / 4; ++u) av[u] = gA[(4 * u + kq) * SWS + wv * 16 + li];
+#pragma unroll
+            for (int x = 0; x < 11; ++x)
+                if (x < nts) {
+                    const int cj = min(x * 16 + li, KM - 1);
+                    float bv[ER / 4];
+#pragma unroll
+                    for (int u = 0; u < ER / 4; ++u) bv[u] = Sin[(4 * u + kq) * SWS + cj];
+#pragma unroll
+                    for (int u = 0; u < ER / 4; ++u) accWm[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], accWm[x], 0, 0, 0);
+                }
+            if (tid < SO) { float sm = 0.f; for (int r = 0; r < ER; ++r) sm += gA[r * SWS + tid]; acc_bm += sm; }
+        }
+        __syncthreads();
+        PFT_STAMP(36);
+        mmR<4, 6>(KH, VO,
+             [&](int i, int k) { return W[g.o_Wu + i * VO + k]; },
+             [&](int k, int j) { return gVo[(j & 31) * VWS + k * 3 + (j >> 5)]; },
+             [&](int i, int j, float x) {
+                 const int row = j & 31, cc = j >> 5;
+                 const float* q = Vh + row * VWS + i * 3;
+                 const float ss = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+                 const float extra = ss > 1e-8f ? gS[row * SWS + SI + i] * q[cc] / Sin[row * SWS + SI + i] : 0.f;
+                 gVh[row * VWS + i * 3 + cc] = x + extra;
+             }, lane, wv);
+        if (wv < 2) {       // dWu tile (hidden channels 16 wv .., 16 outputs) += sum over rows and coordinates of Vh gVu
+            const int hh = min(wv * 16 + li, KH - 1);
+#pragma unroll
+            for (int u = 0; u < 3 * ER / 4; ++u) {
+                const int k = 4 * u + kq;
+                accV = __builtin_amdgcn_mfma_f32_16x16x4f32(Vh[(k & 31) * VWS + hh * 3 + (k >> 5)],
+                                                            gVo[(k & 31) * VWS + li * 3 + (k >> 5)], accV, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        PFT_STAMP(37);
+        mmR<5, 6>(VI, KH,
+             [&](int i, int k) { return W[g.o_Wh + i * KH + k]; },
+             [&](int k, int j) { return gVh[(j & 31) * VWS + k * 3 + (j >> 5)]; },
+             [&](int i, int j, float x) { gVi[(j & 31) * VWS + i * 3 + (j >> 5)] = x; }, lane, wv);
+        if (wv >= 2 && wv < 6) {   // dWh tile (input channels 16 a .., hidden channels 16 b ..) += V gVh
+            const int ta = (wv - 2) >> 1, tb = (wv - 2) & 1;
+            const int vi = min(ta * 16 + li, VI - 1), hh = min(tb * 16 + li, KH - 1);
+#pragma unroll
+            for (int u = 0; u < 3 * ER / 4; ++u) {
+                const int k = 4 * u + kq;
+                accV = __builtin_amdgcn_mfma_f32_16x16x4f32(Vin[(k & 31) * VWS + vi * 3 + (k >> 5)],
+                                                            gVh[(k & 31) * VWS + hh * 3 + (k >> 5)], accV, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        PFT_STAMP(38);
+        // ---- hand the input gradients down: to the level below, or (level 0) to the source nodes
+        if (!firstl) {
+            for (int idx = tid; idx < ER * 128; idx += NT) {
+                const int row = idx >> 7, f = idx & 127;
+                if (row < nv) p.gs_buf[(size_t)s_e[row] * PF_S + f] = gS[row * SWS + f];
+            }
+            for (int idx = tid; idx < ER * 48; idx += NT) {
+                const int row = idx / 48, q = idx - row * 48;
+                if (row < nv) p.gv_buf[(size_t)s_e[row] * 48 + q] = gVi[row * VWS + q];
+            }
+        } else {
+            for (int idx = tid; idx < ER * 128; idx += NT) {
+                const int row = idx >> 7, f = idx & 127;
+                if (row < nv) unsafeAtomicAdd(p.G_h_in + (size_t)s_src[row] * PF_S + f, gS[row * SWS + f]);
+            }
+            if (!p.l0)
+                for (int idx = tid; idx < ER * 48; idx += NT) {
+                    const int row = idx / 48, q = idx - row * 48;
+                    if (row < nv) unsafeAtomicAdd(p.G_v_in + (size_t)s_src[row] * 48 + q, gVi[row * VWS + 3 + q]);
+                }
+        }
+        __syncthreads();
     }
     // ---- flush the register accumulators into this block's gradient copy
 #pragma unroll
@@ -957,6 +952,20 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
         }
 #pragma unroll
     for (int r = 0; r < 4; ++r) gp[g.o_Wg + (kq * 4 + r) * SO + wv * 16 + li] += accWg[r];
+    if (wv < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hh = wv * 16 + kq * 4 + r;
+            if (hh < KH) gp[g.o_Wu + hh * VO + li] += accV[r];
+        }
+    } else if (wv < 6) {
+        const int ta = (wv - 2) >> 1, tb = (wv - 2) & 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int vi = ta * 16 + kq * 4 + r, hh = tb * 16 + li;
+            if (vi < VI && hh < KH) gp[g.o_Wh + vi * KH + hh] += accV[r];
+        }
+    }
     if (tid < SO) gp[g.o_bm + tid] += acc_bm;
     if (tid < VO) gp[g.o_bg + tid] += acc_bg;
 }
@@ -1057,6 +1066,12 @@ __global__ void k_train_reduce(const float* gpart, const int nblocks, const int 
     grad[i] = s;
 }
 
+// packed[i] = flat[map[i]] (map[i] < 0: zero padding): re-pack the MFMA-fragment weights after the parameters changed
+__global__ void k_gather_weights(const float* flat, const int* map, const size_t n, float* packed) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int m = map[i]; packed[i] = m >= 0 ? flat[m] : 0.f; }
+}
+
 // dropout masks as the forward applies them, for tests: out[(node * 144 + elem)] in {0, 1/(1-p)}
 __global__ void k_drop_masks(const TrainCommon c, const uint32_t stream, const int n_elems, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1081,10 +1096,6 @@ void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s) {
     if (p->ntiles == 0) return;
     hipLaunchKernelGGL(k_bwd_node, dim3(nblocks), dim3(NT), 0, s, *p);
 }
-void pfk_bwd_edge(const BwdEdgeParams* p, int nblocks, hipStream_t s) {
-    if (p->ntiles == 0) return;
-    hipLaunchKernelGGL(k_bwd_edge, dim3(nblocks), dim3(NT), 0, s, *p);
-}
 void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, hipStream_t s) {
     const int nblocks = p->et_blk0[4];
     if (nblocks == 0) return;
@@ -1095,6 +1106,10 @@ void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s) {
 }
 void pfk_train_reduce(const float* gpart, int nblocks, int nparams, float* grad, hipStream_t s) {
     hipLaunchKernelGGL(k_train_reduce, dim3((nparams + 255) / 256), dim3(256), 0, s, gpart, nblocks, nparams, grad);
+}
+void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_gather_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flat, map, n, packed);
 }
 void pfk_drop_masks(const TrainCommon* c, uint32_t stream, int n_elems, float* out, hipStream_t s) {
     hipLaunchKernelGGL(k_drop_masks, dim3((n_elems + 255) / 256), dim3(256), 0, s, *c, stream, n_elems, out);

@@ -158,6 +158,26 @@ class PfEngine:
             self._ck(self.lib.pf_train_backward(self._h, _dptr(gh), _dptr(gx), _dptr(grad), _stream_ptr()), "pf_train_backward")
         return grad
 
+    def set_flat_params(self, flat):
+        """Replace every parameter from one flat device vector (param_layout order); the packed kernel weights are
+        refreshed by a device-side gather."""
+        f = _f32(flat, self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_set_flat_params(self._h, _dptr(f), _stream_ptr()), "pf_set_flat_params")
+
+    def get_flat_params(self):
+        if not hasattr(self, "n_params"):
+            self.param_layout()
+        out = torch.empty(self.n_params, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_get_flat_params(self._h, _dptr(out), _stream_ptr()), "pf_get_flat_params")
+        return out
+
+    def set_dropout_masks(self, masks):
+        """tests: [n_convs, 2, N, 144] multipliers used instead of the built-in generator (None restores it)."""
+        self._mask_keepalive = None if masks is None else _f32(masks, self.device)
+        self._ck(self.lib.pf_debug_set_dropout_masks(self._h, _dptr(self._mask_keepalive)), "pf_debug_set_dropout_masks")
+
     def dropout_mask(self, layer, which, dropout, seed):
         """[N, 144] multipliers of conv layer ``layer`` (which: 0 message, 1 residual dropout); rows are global node
         ids (protein atoms first), columns 128 scalar features then 16 vector channels."""

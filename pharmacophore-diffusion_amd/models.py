@@ -7,9 +7,10 @@ section 5) and its *call surface*:
     PharmRecDynamicsGVP.forward(g, timestep, batch_idxs)      pharmacoforge/models/dynamics_gvp.py:131
     PharmacophoreDiff.sample_given_receptor / sample / forward  pharmacoforge/models/pharmacodiff.py:433,516,162
 
-but none of these modules computes anything in PyTorch: every forward goes through libpfdyn.so
-(csrc/, C ABI in include/pfdyn.h).  There is no eager / CPU fallback -- without the HIP library and
-a GPU the calls raise.
+but none of these modules computes anything in PyTorch: every forward -- and, in training, the
+backward of the dynamics -- goes through libpfdyn.so (csrc/, C ABI in include/pfdyn.h); PyTorch
+supplies the autograd plumbing around it, the elementwise loss and the optimiser.  There is no
+eager / CPU fallback -- without the HIP library and a GPU the calls raise.
 """
 from __future__ import annotations
 
@@ -133,6 +134,32 @@ class PharmRecGVP(nn.Module):
         self.noise_predictor = NoisePredictionBlock(in_scalar_dim, out_scalar_dim, in_vector_dim, n_noise_gvps)
 
 
+class _DynamicsFn(torch.autograd.Function):
+    """PharmRecDynamicsGVP.forward as one autograd node: forward = pf_train_forward (train-mode dropout inside the
+    kernels), backward = pf_train_backward, which returns d(loss)/d(parameter) for every parameter as one flat vector.
+    The inputs (x_t, h_t, t, coordinates) get no gradient: nothing upstream of them is trainable
+    (pharmacodiff.py:162-243)."""
+
+    @staticmethod
+    def forward(ctx, mod, eng, x_t, h_t, t, prot_x, dropout, seed, *params):
+        eps_h, eps_x = eng.train_forward(x_t, h_t, t, prot_x=prot_x, dropout=dropout, seed=seed)
+        mod._fwd_token += 1
+        ctx.mod, ctx.eng, ctx.token = mod, eng, mod._fwd_token
+        return eps_h, eps_x
+
+    @staticmethod
+    def backward(ctx, g_h, g_x):
+        mod, eng = ctx.mod, ctx.eng
+        if ctx.token != mod._fwd_token:
+            raise RuntimeError("backward of a PharmRecDynamicsGVP call that is not the most recent training forward: "
+                               "the engine keeps the activations of one forward at a time")
+        g_h = torch.zeros(eng.Nf, eng.pharm_nf, device=eng.device) if g_h is None else g_h.contiguous()
+        g_x = torch.zeros(eng.Nf, 3, device=eng.device) if g_x is None else g_x.contiguous()
+        flat = eng.train_backward(g_h, g_x)
+        grads = tuple(flat[off:off + n].view(p.shape) for p, off, n in mod._flat_views)
+        return (None,) * 8 + grads
+
+
 class PharmRecDynamicsGVP(nn.Module):
     """Drop-in for pharmacoforge.models.dynamics_gvp.PharmRecDynamicsGVP (same constructor, same
     state-dict keys, same forward signature); forward runs on the MI355X through libpfdyn."""
@@ -158,6 +185,9 @@ class PharmRecDynamicsGVP(nn.Module):
         self._engine: Optional[PfEngine] = None
         self._weights_stamp = None
         self._batch_key = None
+        self._flat: Optional[torch.Tensor] = None       # all parameters as one device vector (engine layout)
+        self._flat_views = []                           # [(parameter, offset, numel)] in that layout
+        self._fwd_token = 0
 
     # -- engine plumbing ------------------------------------------------------------------
     def _device(self) -> torch.device:
@@ -172,11 +202,39 @@ class PharmRecDynamicsGVP(nn.Module):
             self._engine = PfEngine(device=dev, **self._arch)
             self._weights_stamp = None
             self._batch_key = None
-        stamp = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if stamp != self._weights_stamp:       # parameters were (re)loaded or updated: re-pack on the device
+            self._flat = None
+        if self._flat is None or not self._views_intact():
+            # first use on this device (or the parameters were re-allocated, e.g. by .to()): push the tensors through
+            # the C ABI once, then re-home every parameter as a view of one flat device vector in the engine's
+            # layout, so that an optimiser step is visible to the engine as a single device-to-device refresh
             self._engine.load_state_dict({k: v for k, v in self.state_dict().items()}, prefix="")
+            self._flatten_parameters()
+            self._weights_stamp = self._stamp()
+        stamp = self._stamp()
+        if stamp != self._weights_stamp:       # parameters were updated in place (optimiser step, load_state_dict)
+            self._engine.set_flat_params(self._flat)
             self._weights_stamp = stamp
         return self._engine
+
+    def _stamp(self):
+        return tuple(p._version for p, _, _ in self._flat_views)
+
+    def _views_intact(self) -> bool:
+        base = self._flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * off and p.device == self._flat.device for p, off, _ in self._flat_views)
+
+    def _flatten_parameters(self):
+        eng = self._engine
+        layout = eng.param_layout()
+        flat = torch.empty(eng.n_params, device=eng.device)
+        named = dict(self.named_parameters())
+        views = []
+        for name, off, n in layout:
+            p = named[name[len("dynamics."):]]
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            views.append((p, off, n))
+        self._flat, self._flat_views = flat, views
 
     def bind_graph(self, g: PocketGraph, prot_x: Optional[torch.Tensor] = None) -> PfEngine:
         """Upload the static part of a batch (pocket atoms, pp edges, graph boundaries) once."""
@@ -190,11 +248,24 @@ class PharmRecDynamicsGVP(nn.Module):
     def forward(self, g, timestep: torch.Tensor, batch_idxs: Dict[str, torch.Tensor] = None):
         """(eps_h, eps_x) = dynamics(g, t): reads g.x_t, g.h_t (pharm) and g.prot_x, like the reference
         reads g.nodes['pharm'].data['x_t'/'h_t'] and g.nodes['prot'].data['x_0'] (dynamics_gvp.py:139-170)."""
-        if self.training and self.dropout_rate > 0:
-            raise NotImplementedError("training-mode dropout / backward kernels are not built yet (DESIGN.md, next)")
         g = as_pocket_graph(g)
+        return self.run(g, g.x_t, g.h_t, timestep, g.prot_x)
+
+    def run(self, g: PocketGraph, x_t, h_t, timestep, prot_x):
+        """The boundary call on explicit state tensors.  With autograd enabled and trainable parameters the result
+        carries a graph whose backward runs the HIP gradient kernels; in train() mode GVPDropout is applied inside the
+        kernels (its seed is drawn from torch's generator, so torch.manual_seed reproduces a step).  Otherwise
+        (torch.no_grad() / frozen parameters) the pruned inference path runs."""
         eng = self.bind_graph(g)
-        return eng.dynamics(g.x_t, g.h_t, timestep, prot_x=g.prot_x)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p, _, _ in self._flat_views)
+        if not need_grad and not (self.training and self.dropout_rate > 0):
+            return eng.dynamics(x_t, h_t, timestep, prot_x=prot_x)
+        p_drop = float(self.dropout_rate) if self.training else 0.0
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
+        if not need_grad:
+            return eng.train_forward(x_t, h_t, timestep, prot_x=prot_x, dropout=p_drop, seed=seed)
+        params = [p for p, _, _ in self._flat_views]
+        return _DynamicsFn.apply(self, eng, x_t, h_t, timestep, prot_x, p_drop, seed, *params)
 
 
 class PharmSizeDistribution:
@@ -359,9 +430,8 @@ class PharmacophoreDiff(_Base):
 
     # -- training-loss forward (pharmacodiff.py:162-243), evaluation only ---------------------------
     def forward(self, g, phase: str = 'train', t_int: torch.Tensor = None, eps: Dict[str, torch.Tensor] = None):
-        """Losses and metrics of one batch with the dynamics evaluated by the HIP kernels.  The network
-        output carries no autograd graph (backward kernels are the next milestone), so this serves
-        validation / monitoring; ``training_step`` raises.  ``t_int`` / ``eps`` inject the random draws."""
+        """Losses and metrics of one batch (pharmacodiff.py:162-243) with the dynamics -- and, when autograd is on,
+        its backward -- evaluated by the HIP kernels.  ``t_int`` / ``eps`` inject the random draws."""
         g = as_pocket_graph(g)
         dev = self.device
         bidx = get_batch_idxs(g)
@@ -393,9 +463,7 @@ class PharmacophoreDiff(_Base):
             x_t = x_t - c[bp]
             prot_x = prot_x - c[br]
             sampled_com = c[bp]
-        eng = self.dynamics.bind_graph(g)
-        with torch.no_grad():
-            h_dyn, x_dyn = eng.dynamics(x_t, h_t, t, prot_x=prot_x)
+        h_dyn, x_dyn = self.dynamics.run(g, x_t, h_t, t, prot_x)
         if self.endpoint_param_feat:
             h_0_pred = h_dyn
             h_loss = F.cross_entropy(h_0_pred, h0.argmax(dim=1), reduction='none')
@@ -414,15 +482,37 @@ class PharmacophoreDiff(_Base):
         weight_loss = weight_metric if self.weighted_loss else torch.ones_like(weight_metric)
         losses = {phase + ' pos loss': (x_loss * weight_loss).sum() / eps['x'].numel(),
                   phase + ' feat loss': (h_loss * weight_loss).sum() / eps['h'].numel()}
-        err = (x_0_pred - x0).square().sum(dim=1)
-        hit = (h_0_pred.argmax(dim=1) == h0.argmax(dim=1)).float()
-        metrics = {phase + ' position error': err.mean(), phase + ' weighted position error': (weight_metric * err).mean(),
-                   phase + ' accuracy': hit.mean(), phase + ' weighted accuracy': (weight_metric * hit).mean()}
+        with torch.no_grad():
+            err = (x_0_pred - x0).square().sum(dim=1)
+            hit = (h_0_pred.argmax(dim=1) == h0.argmax(dim=1)).float()
+            metrics = {phase + ' position error': err.mean(), phase + ' weighted position error': (weight_metric * err).mean(),
+                       phase + ' accuracy': hit.mean(), phase + ' weighted accuracy': (weight_metric * hit).mean()}
         return losses, metrics
 
-    def training_step(self, batch, batch_idx):
-        raise NotImplementedError("backward kernels for the HIP dynamics are not built yet (DESIGN.md 'next'); "
-                                  "use forward(g, 'val') for loss/metric evaluation")
+    def configure_optimizers(self):
+        """pharmacodiff.py:253-263: Adam + ReduceLROnPlateau from lr_scheduler_config."""
+        cfg = self.lr_scheduler_config
+        optimizer = torch.optim.Adam(self.parameters(), lr=cfg.get('base_lr', 1e-4), weight_decay=cfg.get('weight_decay', 0.0))
+        scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, **cfg.get('reducelronplateau', {}))
+        return {'optimizer': optimizer,
+                'lr_scheduler': {"scheduler": scheduler, "monitor": cfg.get('monitor', 'val total loss'),
+                                 "interval": cfg.get('interval', 'step'), "frequency": cfg.get('frequency', 1)}}
+
+    def training_step(self, batch, batch_idx, t_int: torch.Tensor = None, eps: Dict[str, torch.Tensor] = None):
+        """pharmacodiff.py:265-296: total loss = pos loss + feat loss (the caller -- Lightning or a plain loop --
+        runs .backward() and the optimiser step).  Periodic sample_and_analyze needs a trainer's datamodule and is
+        left to the caller (sample_and_analyze_graphs)."""
+        phase = 'train'
+        loss_dict, metrics_dict = self.forward(batch, phase=phase, t_int=t_int, eps=eps)
+        loss_dict[phase + ' total loss'] = torch.sum(torch.stack(list(loss_dict.values()), dim=0))
+        metrics_dict[phase + ' total error'] = metrics_dict[phase + ' position error'] + 1 - metrics_dict[phase + ' accuracy']
+        metrics_dict[phase + ' weighted total error'] = (metrics_dict[phase + ' weighted position error'] + 1
+                                                         - metrics_dict[phase + ' weighted accuracy'])
+        bs = as_pocket_graph(batch).batch_size
+        self.log_dict(loss_dict, on_step=True, on_epoch=True, prog_bar=True, logger=True, batch_size=bs)
+        self.log_dict(metrics_dict, on_step=True, on_epoch=True, prog_bar=True, logger=True, batch_size=bs)
+        self.last_metrics = {k: v.detach() for k, v in {**loss_dict, **metrics_dict}.items()}
+        return loss_dict[phase + ' total loss']
 
     def validation_step(self, batch, batch_idx):
         phase = 'val'

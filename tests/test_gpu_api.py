@@ -62,12 +62,95 @@ def test_training_loss_forward_matches_reference_golden():
     z = load("train_fwd.npz")
     m = make_model(int(z["T"]))
     g = graph_from(batch_from(z), z["x0"], z["h0"]).to("cuda")
-    losses, metrics = m.forward(g, 'train', t_int=z["t_int"].long(), eps={'h': z["eps_h"], 'x': z["eps_x"]})
+    inj = dict(t_int=z["t_int"].long(), eps={'h': z["eps_h"], 'x': z["eps_x"]})
+    with torch.no_grad():                      # pruned inference kernels
+        losses, metrics = m.forward(g, 'train', **inj)
+    losses_g, _ = m.forward(g, 'train', **inj)  # autograd on: dense training forward (eval mode: no dropout)
     for k, v in {**losses, **metrics}.items():
         ref = float(z["out_" + k.replace(" ", "_")])
         assert abs(float(v) - ref) <= 2e-4 * max(1.0, abs(ref)), (k, float(v), ref)
-    with pytest.raises(NotImplementedError):
-        m.training_step(g, 0)
+    for k, v in losses_g.items():
+        assert v.requires_grad
+        assert abs(float(v.detach()) - float(losses[k])) <= 2e-5 * max(1.0, abs(float(losses[k])))
+
+
+def _golden_masks(z, cfg, Np, Nf):
+    """[n_convs, 2, N, 144] multipliers in the engine's layout (global node ids: protein atoms first) from the
+    GVPDropout draws the reference made (tests/golden/make_golden.py:golden_train_grads)."""
+    out = torch.ones(cfg.n_convs, 2, Np + Nf, 144)
+    for layer in range(cfg.n_convs):
+        for w, which in enumerate(("msg", "res")):
+            for nt, sl in (("prot", slice(0, Np)), ("pharm", slice(Np, Np + Nf))):
+                out[layer, w, sl, :128] = z[f"drop_{layer}_{nt}_{which}_s"]
+                out[layer, w, sl, 128:] = z[f"drop_{layer}_{nt}_{which}_v"]
+    return out
+
+
+def test_training_step_gradients_match_reference_golden():
+    """One reference training_step in train() mode (dropout 0.1): loss.backward() through the HIP backward kernels
+    gives the reference's own parameter gradients (its GVPDropout draws injected as masks)."""
+    z = load("train_grads.npz")
+    cfg = O.DynamicsConfig()
+    m = make_model(int(z["T"]))
+    m.train()
+    b = batch_from(z)
+    g = graph_from(b, z["x0"], z["h0"]).to("cuda")
+    Np, Nf = int(b.prot_ptr[-1]), int(b.pharm_ptr[-1])
+    eng = m.dynamics.bind_graph(g)
+    eng.set_dropout_masks(_golden_masks(z, cfg, Np, Nf))
+    loss = m.training_step(g, 0, t_int=z["t_int"].long(), eps={'h': z["eps_h"], 'x': z["eps_x"]})
+    ref_total = float(z["out_train_pos_loss"]) + float(z["out_train_feat_loss"])
+    assert abs(float(loss.detach()) - ref_total) <= 2e-4 * max(1.0, abs(ref_total))
+    loss.backward()
+    eng.set_dropout_masks(None)
+    bad, live = [], 0
+    for k, p in m.named_parameters():
+        if p.numel() == 0 or not k.startswith("dynamics."):
+            continue
+        ref = z["grad_" + k]
+        got = torch.zeros_like(ref) if p.grad is None else p.grad.cpu()
+        scale = float(ref.abs().max())
+        live += scale > 0
+        if float((got - ref).abs().max()) > 2e-3 * scale + 1e-7:
+            bad.append((k, float((got - ref).abs().max()), scale))
+    assert not bad, (bad[:6], len(bad))
+    assert live >= 150
+
+
+def test_optimizer_steps_refresh_the_engine_and_reduce_the_loss():
+    """Adam on the module's parameters (views of one flat device vector): after every step the engine sees the new
+    values (device-side gather into the packed weights), the inference path agrees with the oracle on the updated
+    state dict, and the loss of a fixed batch goes down."""
+    z = load("train_grads.npz")
+    cfg = O.DynamicsConfig()
+    m = make_model(int(z["T"]))
+    m.train()
+    m.dynamics.dropout_rate = 0.0
+    b = batch_from(z)
+    g = graph_from(b, z["x0"], z["h0"]).to("cuda")
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3)
+    inj = dict(t_int=z["t_int"].long(), eps={'h': z["eps_h"], 'x': z["eps_x"]})
+    losses = []
+    for _ in range(12):
+        opt.zero_grad(set_to_none=True)
+        loss = m.training_step(g, 0, **inj)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.95 * losses[0] and all(torch.isfinite(torch.tensor(losses))), losses
+    # engine state == module state == what the oracle computes with those weights
+    eng = m.dynamics.engine()
+    flat = eng.get_flat_params().cpu()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    for name, off, n in eng.param_layout():
+        assert torch.equal(flat[off:off + n], sd[name].reshape(-1)), name
+    m.eval()
+    with torch.no_grad():
+        l_eng, _ = m.forward(g, 'val', **inj)
+    l_ref, _ = O.training_forward(sd, cfg, b, z["x0"], z["h0"], int(z["T"]), 1e-5, z["t_int"].long(), z["eps_h"], z["eps_x"],
+                                  phase="val")
+    for k in l_ref:
+        assert abs(float(l_eng[k]) - float(l_ref[k])) <= 5e-4 * max(1.0, abs(float(l_ref[k]))), (k, float(l_eng[k]), float(l_ref[k]))
 
 
 def test_multi_pocket_ragged_sampling_and_checkpoint(tmp_path):
