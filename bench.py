@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra dense-mode kernel measurement")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel device time to stderr")
+    ap.add_argument("--train", action="store_true",
+                    help="secondary benchmark (BASELINE config 5): training steps (forward, backward kernels, Adam) at "
+                         "batch 256 per GPU instead of the sampling metric")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -63,6 +66,11 @@ def main():
     import pharmacoforge_amd as pfa
     from pharmacoforge_amd import synthetic, schedule
 
+    if args.train:
+        train_leg(args, pfa, synthetic, dev, rank, world, backend, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     B, T, K, W = args.batch, args.timesteps, args.steps, args.warmup
     # ---- inputs: B distinct pockets per rank (weak scaling: per-GPU work fixed), resident in HBM
     eng = pfa.PfEngine(device=dev)
@@ -173,6 +181,75 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
+    """BASELINE config 5: one training step = PharmacophoreDiff.training_step (noising, dynamics forward with dropout,
+    loss) + backward (HIP gradient kernels) + gradient all-reduce over the ranks + Adam.  B graphs per GPU (weak)."""
+    B = args.batch if args.batch != 32 else 256
+    K, W = args.steps, args.warmup
+    lo, hi = (int(v) for v in (args.pharm_sizes or "4-8").split("-"))
+    sizes = [lo + (i % (hi - lo + 1)) for i in range(B)]
+    T = 100                                                     # dev.yml diffusion.n_timesteps
+    dyn = dict(vector_size=16, n_convs=2, n_hidden_scalars=128, message_norm='mean', dropout=0.1, ff_k=0, pf_k=5,
+               n_message_gvps=3, n_update_gvps=2, n_noise_gvps=4)
+    m = pfa.PharmacophoreDiff(6, 11, pfa.analysis.ph_idx_to_type, None, n_timesteps=T,
+                              graph_config={'graph_cutoffs': {'pp': 3.5, 'pf': 8, 'fp': 8, 'ff': 9}}, dynamics_config=dyn,
+                              precision=1e-5, lr_scheduler_config={'base_lr': 1e-4, 'weight_decay': 1e-12})
+    sd = dict(synthetic.make_state_dict(0))
+    sd["gamma.gamma"] = m.state_dict()["gamma.gamma"]
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).train()
+    xs, hs = zip(*[synthetic.synthetic_pocket(1000 * rank + i, args.n_prot) for i in range(B)])
+    prot_x, prot_h = torch.cat(xs), torch.cat(hs)
+    prot_ptr = torch.arange(B + 1, dtype=torch.int64) * args.n_prot
+    pharm_ptr = torch.tensor([0] + list(__import__("itertools").accumulate(sizes)), dtype=torch.int64)
+    eng = m.dynamics.engine()
+    pp_src, pp_dst = eng.build_pp_edges(prot_x.to(dev), prot_ptr)
+    Nf = int(pharm_ptr[-1])
+    gen = torch.Generator().manual_seed(7 + rank)
+    x0 = torch.cat([xs[i].mean(0, keepdim=True) + 2.0 * torch.randn(sizes[i], 3, generator=gen) for i in range(B)])
+    h0 = torch.nn.functional.one_hot(torch.randint(0, 6, (Nf,), generator=gen), 6).float()
+    g = pfa.PocketGraph(prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, pharm_x0=x0, pharm_h0=h0).to(dev)
+    # optim.Adam(lr, weight_decay) of pharmacodiff.py:253 as one fused kernel on the flat parameter vector
+    opt = pfa.FlatAdam(m.dynamics, lr=1e-4, weight_decay=1e-12)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = m.training_step(g, 0)
+        loss.backward()
+        if world > 1:
+            m.dynamics.allreduce_gradients()
+        opt.step()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(W):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training graphs/sec (forward + backward + Adam), 256-atom pockets, 4-8 centers", "value": world * B * K / dt,
+            "unit": "graphs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 5: training step, batch={B} per GPU, {args.n_prot}-atom pockets, centers {lo}-{hi}, "
+                                   "dropout 0.1, dev.yml network", "batch_per_gpu": B, "n_prot": args.n_prot,
+                       "parallelism": f"data parallel over {world} GPU(s): one all-reduce of the flat gradient per step"},
+            "final_loss": float(loss.detach())}))
 
 
 def dense_leg(pfa, synthetic, dev, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, carr, W, K, Nf):

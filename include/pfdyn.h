@@ -163,6 +163,11 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h /*[Nf,pharm_nf]*/, 
  * (what an optimiser step calls instead of 245 x pf_set_weight + pf_commit_weights); get = copy out */
 int pf_set_flat_params(pf_handle* h, const float* dev_flat /*[n_params]*/, pf_stream stream);
 int pf_get_flat_params(pf_handle* h, float* dev_flat /*[n_params]*/, pf_stream stream);
+/* one fused Adam step (torch.optim.Adam semantics: L2 weight decay into the gradient, bias correction, no amsgrad;
+ * pharmacodiff.py:253) on the caller's flat vectors [n_params], followed by pf_set_flat_params(dev_params).
+ * step counts from 1. */
+int pf_adam_step(pf_handle* h, float* dev_params, const float* dev_grad, float* dev_exp_avg, float* dev_exp_avg_sq,
+                 int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay, pf_stream stream);
 /* tests: make the following pf_train_forward / pf_train_backward calls on this batch use the given multipliers
  * [n_convs][2][N][144] (layout of pf_debug_dropout_mask) instead of the built-in generator; NULL restores it.  The
  * buffer must stay alive until the backward call has finished. */

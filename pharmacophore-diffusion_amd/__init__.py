@@ -16,10 +16,10 @@ try:  # host-side mirror of the reference API (needs only torch)
     from .graph import PocketGraph, batch, unbatch, build_initial_complex_graph, copy_graph  # noqa: F401
     from .models import (GVP, GVPLayerNorm, GVPMultiEdgeConv, NoisePredictionBlock, PharmRecGVP,  # noqa: F401
                          PharmRecDynamicsGVP, PharmacophoreDiff, PredefinedNoiseSchedule, PharmSizeDistribution,
-                         model_from_config)
+                         FlatAdam, model_from_config)
     from .analysis import SampledPharmacophore, SampleAnalyzer, write_pharmacophore_file  # noqa: F401
     __all__ += ["PocketGraph", "batch", "unbatch", "build_initial_complex_graph", "copy_graph", "PharmRecDynamicsGVP",
-                "PharmacophoreDiff", "PredefinedNoiseSchedule", "SampledPharmacophore", "SampleAnalyzer",
+                "PharmacophoreDiff", "FlatAdam", "PredefinedNoiseSchedule", "SampledPharmacophore", "SampleAnalyzer",
                 "model_from_config"]
 except ImportError as _e:   # pragma: no cover  (only while the package is being bootstrapped)
     _host_api_error = _e

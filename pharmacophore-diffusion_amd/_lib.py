@@ -53,6 +53,7 @@ SYMBOLS = {
     "pf_train_backward": (ctypes.c_int, [_P, _P, _P, _P, _P]),
     "pf_set_flat_params": (ctypes.c_int, [_P, _P, _P]),
     "pf_get_flat_params": (ctypes.c_int, [_P, _P, _P]),
+    "pf_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _P]),
     "pf_debug_set_dropout_masks": (ctypes.c_int, [_P, _P]),
     "pf_debug_dropout_mask": (ctypes.c_int, [_P, _I32, _I32, _F, ctypes.c_uint32, _P, _P]),
     "pf_debug_get_edges": (_I64, [_P, _I32, _P, _P, _I64, _P]),

@@ -41,6 +41,8 @@ void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, hipStream_t s);
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
 void pfk_train_reduce(const float* gpart, int nblocks, int nparams, float* grad, hipStream_t s);
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s);
+void pfk_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
+              float bc1, float bc2_sqrt, hipStream_t s);
 void pfk_drop_masks(const TrainCommon* c, uint32_t stream, int n_elems, float* out, hipStream_t s);
 void pfk_pp_radius(const float4* xn, const int* prot_ptr, int B, float r2, int maxn, int* deg, const int* row_off,
                    int* src, int* dst, int pass, hipStream_t s);
@@ -1203,6 +1205,18 @@ int pf_set_flat_params(pf_handle* h, const float* dev_flat, pf_stream stream) {
     pfk_gather_weights(h->d_flat, h->d_map, h->n_packed, h->d_w, s);
     h->t_have_fwd = false;
     return PF_OK;
+}
+
+int pf_adam_step(pf_handle* h, float* dev_params, const float* dev_grad, float* dev_exp_avg, float* dev_exp_avg_sq,
+                 int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay, pf_stream stream) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if (!dev_params || !dev_grad || !dev_exp_avg || !dev_exp_avg_sq || step < 1) PF_FAIL(h, PF_ERR_ARG, "pf_adam_step: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    pfk_adam(dev_params, dev_grad, dev_exp_avg, dev_exp_avg_sq, h->nparams, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+             (float)std::sqrt(bc2), s);
+    return pf_set_flat_params(h, dev_params, stream);
 }
 
 int pf_get_flat_params(pf_handle* h, float* dev_flat, pf_stream stream) {

@@ -1072,6 +1072,22 @@ __global__ void k_gather_weights(const float* flat, const int* map, const size_t
     if (i < n) { const int m = map[i]; packed[i] = m >= 0 ? flat[m] : 0.f; }
 }
 
+// one Adam step (torch.optim.Adam semantics, pharmacodiff.py:253: L2 weight decay added to the gradient, bias-corrected
+// moments, no amsgrad) on flat vectors
+__global__ void k_adam(float* p, const float* g, float* m, float* v, const size_t n, const float lr, const float b1,
+                       const float b2, const float eps, const float wd, const float bc1, const float bc2_sqrt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    const float mi = m[i] + (1.0f - b1) * (gi - m[i]);           // lerp, as torch
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
 // dropout masks as the forward applies them, for tests: out[(node * 144 + elem)] in {0, 1/(1-p)}
 __global__ void k_drop_masks(const TrainCommon c, const uint32_t stream, const int n_elems, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1110,6 +1126,11 @@ void pfk_train_reduce(const float* gpart, int nblocks, int nparams, float* grad,
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_gather_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flat, map, n, packed);
+}
+void pfk_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
+              float bc1, float bc2_sqrt, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
 }
 void pfk_drop_masks(const TrainCommon* c, uint32_t stream, int n_elems, float* out, hipStream_t s) {
     hipLaunchKernelGGL(k_drop_masks, dim3((n_elems + 255) / 256), dim3(256), 0, s, *c, stream, n_elems, out);

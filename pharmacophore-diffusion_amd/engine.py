@@ -173,6 +173,15 @@ class PfEngine:
             self._ck(self.lib.pf_get_flat_params(self._h, _dptr(out), _stream_ptr()), "pf_get_flat_params")
         return out
 
+    def adam_step(self, params, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        """Fused Adam on flat device vectors (in place) + refresh of the engine's weights from ``params``."""
+        for t in (params, grad, exp_avg, exp_avg_sq):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == self.n_params
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_adam_step(self._h, _dptr(params), _dptr(grad), _dptr(exp_avg), _dptr(exp_avg_sq), int(step),
+                                           float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                           _stream_ptr()), "pf_adam_step")
+
     def set_dropout_masks(self, masks):
         """tests: [n_convs, 2, N, 144] multipliers used instead of the built-in generator (None restores it)."""
         self._mask_keepalive = None if masks is None else _f32(masks, self.device)

@@ -72,12 +72,18 @@ class PocketGraph:
 
 
 def get_batch_idxs(g: PocketGraph) -> Dict[str, torch.Tensor]:
-    """utils/unorganized_utils.py:83-95: graph id of every node, per node type (on g.device)."""
+    """utils/unorganized_utils.py:83-95: graph id of every node, per node type (on g.device).  Cached on the graph
+    object (the ptr arrays of a PocketGraph are immutable): a training loop asks for it every step."""
+    key = (str(g.device), g.prot_ptr.data_ptr(), g.pharm_ptr.data_ptr(), int(g.prot_ptr[-1]), int(g.pharm_ptr[-1]))
+    cached = g.__dict__.get("_bidx_cache")
+    if cached is not None and cached[0] == key:
+        return dict(cached[1])
     ar = torch.arange(g.batch_size)
     out = {}
     for nt in ("prot", "pharm", "prot_ph"):
         out[nt] = ar.repeat_interleave(g.batch_num_nodes(nt)).to(g.device)
-    return out
+    g.__dict__["_bidx_cache"] = (key, out)
+    return dict(out)
 
 
 def get_batch_info(g: PocketGraph):

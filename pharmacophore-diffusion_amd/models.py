@@ -156,6 +156,7 @@ class _DynamicsFn(torch.autograd.Function):
         g_h = torch.zeros(eng.Nf, eng.pharm_nf, device=eng.device) if g_h is None else g_h.contiguous()
         g_x = torch.zeros(eng.Nf, 3, device=eng.device) if g_x is None else g_x.contiguous()
         flat = eng.train_backward(g_h, g_x)
+        mod._last_flat_grad = flat
         grads = tuple(flat[off:off + n].view(p.shape) for p, off, n in mod._flat_views)
         return (None,) * 8 + grads
 
@@ -236,6 +237,23 @@ class PharmRecDynamicsGVP(nn.Module):
             views.append((p, off, n))
         self._flat, self._flat_views = flat, views
 
+    def allreduce_gradients(self, group=None, average: bool = True):
+        """Data-parallel training (one process per GPU): sum the gradients of all ranks with ONE all-reduce of the
+        flat gradient vector (3.1 MB at dev.yml; RCCL when the tensors are on the GPU), then re-bind every
+        parameter's .grad to its slice.  SURVEY.md 8(e)."""
+        import torch.distributed as dist
+        params = [p for p, _, _ in self._flat_views] or [p for p in self.parameters() if p.numel() > 0]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+        dist.all_reduce(flat, group=group)
+        if average:
+            flat /= dist.get_world_size(group)
+        off = 0
+        for p in params:
+            p.grad = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        self._last_flat_grad = flat
+        return flat
+
     def bind_graph(self, g: PocketGraph, prot_x: Optional[torch.Tensor] = None) -> PfEngine:
         """Upload the static part of a batch (pocket atoms, pp edges, graph boundaries) once."""
         eng = self.engine()
@@ -266,6 +284,36 @@ class PharmRecDynamicsGVP(nn.Module):
             return eng.train_forward(x_t, h_t, timestep, prot_x=prot_x, dropout=p_drop, seed=seed)
         params = [p for p, _, _ in self._flat_views]
         return _DynamicsFn.apply(self, eng, x_t, h_t, timestep, prot_x, p_drop, seed, *params)
+
+
+class FlatAdam:
+    """Adam over a PharmRecDynamicsGVP as ONE fused HIP kernel on the flat parameter vector (pf_adam_step) instead of
+    a multi-tensor update over 244 tensors: same update rule as torch.optim.Adam(lr, betas, eps, weight_decay)
+    (pharmacodiff.py:253).  Uses the flat gradient of the last backward (or of allreduce_gradients)."""
+
+    def __init__(self, dynamics: "PharmRecDynamicsGVP", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.dyn, self.lr, self.betas, self.eps, self.weight_decay = dynamics, lr, betas, eps, weight_decay
+        self.t = 0
+        self.exp_avg = self.exp_avg_sq = None
+        self.param_groups = [{'lr': lr}]            # what LR schedulers / loggers look at
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.dyn.parameters():
+            p.grad = None
+        self.dyn._last_flat_grad = None
+
+    def step(self):
+        dyn = self.dyn
+        eng = dyn.engine()
+        g = getattr(dyn, "_last_flat_grad", None)
+        if g is None:
+            raise RuntimeError("FlatAdam.step(): no gradient (run loss.backward() on a training forward first)")
+        if self.exp_avg is None:
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(dyn._flat), torch.zeros_like(dyn._flat)
+        self.t += 1
+        eng.adam_step(dyn._flat, g, self.exp_avg, self.exp_avg_sq, self.t, self.param_groups[0]['lr'], self.betas, self.eps,
+                      self.weight_decay)
+        dyn._weights_stamp = dyn._stamp()            # the engine already holds these values (parameter views share _flat)
 
 
 class PharmSizeDistribution:

@@ -209,3 +209,31 @@ def test_full_size_config2_batch_properties():
     x3, h3 = eng2.sample(arr, 25, noise_r)
     torch.testing.assert_close(x3.cpu(), x1.cpu() @ q.T + 3.0, rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(h3.cpu(), h1.cpu(), rtol=2e-2, atol=2e-2)
+
+
+def test_flat_adam_matches_torch_adam():
+    """pf_adam_step (one fused kernel on the flat vector) == torch.optim.Adam on the 244 tensors, three steps."""
+    z = load("train_grads.npz")
+    b = batch_from(z)
+    inj = dict(t_int=z["t_int"].long(), eps={'h': z["eps_h"], 'x': z["eps_x"]})
+    outs = []
+    for use_flat in (False, True):
+        m = make_model(int(z["T"]))
+        m.train()
+        m.dynamics.dropout_rate = 0.0
+        g = graph_from(b, z["x0"], z["h0"]).to("cuda")
+        opt = (pfa.FlatAdam(m.dynamics, lr=1e-3, weight_decay=1e-2) if use_flat
+               else torch.optim.Adam(m.dynamics.parameters(), lr=1e-3, weight_decay=1e-2))
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            m.training_step(g, 0, **inj).backward()
+            opt.step()
+        outs.append({k: v.detach().cpu().clone() for k, v in m.dynamics.state_dict().items()})
+        with torch.no_grad():
+            outs.append(m.eval().forward(g, 'val', **inj)[0])
+    sd_t, l_t, sd_f, l_f = outs
+    for k in sd_t:
+        if sd_t[k].numel():
+            torch.testing.assert_close(sd_f[k], sd_t[k], rtol=2e-4, atol=2e-6, msg=k)
+    for k in l_t:
+        assert abs(float(l_t[k]) - float(l_f[k])) <= 1e-4 * max(1.0, abs(float(l_t[k])))

@@ -174,3 +174,34 @@ def test_metrics_allreduce_two_ranks_gloo():
     [p.join(30) for p in procs]
     assert out[0][1] == out[1][1] == 0.75            # (1 + 2) valid of (2 + 2) centers over both ranks
     assert out[0][2] == [0, 2, 0, 0, 0, 2]
+
+
+def _grad_rank_fn(rank, world, port, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    m = make_model()                                  # CPU parameters: only the gradient bookkeeping is exercised
+    for i, p in enumerate(m.dynamics.parameters()):
+        if p.numel():
+            p.grad = torch.full_like(p, float(rank + 1) * (1 + i % 3))
+    flat = m.dynamics.allreduce_gradients(average=True)
+    got = [float(p.grad.reshape(-1)[0]) for p in m.dynamics.parameters() if p.numel()][:6]
+    n = sum(p.numel() for p in m.dynamics.parameters())
+    q.put((rank, got, flat.numel() == n))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks_gloo():
+    """Data-parallel training path: one all-reduce of the flat gradient vector; every parameter's .grad becomes the
+    rank average."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_grad_rank_fn, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(30) for p in procs]
+    expect = [1.5 * (1 + i % 3) for i in range(6)]
+    assert out[0][1] == out[1][1] == expect
+    assert out[0][2] and out[1][2]
