@@ -100,3 +100,47 @@ def test_gradients_vs_oracle(name, p_drop):
     got = flat_to_dict(eng, grad)
     ref = {k: (torch.zeros_like(v) if v.grad is None else v.grad) for k, v in leaf.items()}
     compare(got, ref, 2e-3, name)
+
+
+EXTRA_CASES = {
+    # per-graph message normalisation (gvp.py:504-507), kNN ff edges
+    "per_graph_norm_knn": (O.DynamicsConfig(ff_k=2, pf_k=3, message_norm=0), [31, 32, 33], 40, [5, 4, 6]),
+    # larger pockets: destination segments that span 32-slot tiles, several node tiles, radius pf edges
+    "large_radius": (O.DynamicsConfig(pf_k=0, message_norm=10), [41, 42], 150, [8, 7]),
+    # single GVP per chain, three conv layers
+    "shallow_chains": (O.DynamicsConfig(n_convs=3, n_message_gvps=1, n_update_gvps=1, n_noise_gvps=2), [51], 64, [6]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(EXTRA_CASES))
+def test_gradients_vs_oracle_more_configs(name):
+    cfg, seeds, n_prot, n_pharm = EXTRA_CASES[name]
+    batch = O.synthetic_batch(seeds, n_prot, n_pharm, cfg)
+    sd = O.make_state_dict(cfg, 3)
+    eng = make_engine(cfg, sd, batch)
+    Np, Nf, B = int(batch.prot_ptr[-1]), int(batch.pharm_ptr[-1]), batch.batch_size
+    gen = torch.Generator().manual_seed(11)
+    bidx = batch.batch_idxs()
+    com = O.segment_mean(batch.prot_x, batch.prot_ptr)
+    prot_x = batch.prot_x - com[bidx["prot"]]
+    x_t = 2.5 * torch.randn(Nf, 3, generator=gen)
+    h_t = torch.randn(Nf, cfg.pharm_nf, generator=gen)
+    t = torch.rand(B, generator=gen)
+    w_h, w_x = torch.randn(Nf, cfg.pharm_nf, generator=gen), torch.randn(Nf, 3, generator=gen)
+    p_drop, seed = 0.2, 99
+    eps_h, eps_x = eng.train_forward(x_t, h_t, t, prot_x=prot_x, dropout=p_drop, seed=seed)
+    drop = masks_from_engine(eng, cfg, p_drop, seed, Np, Nf)
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    with torch.enable_grad():
+        oh, ox = O.dynamics_forward(leaf, cfg, batch, prot_x, x_t, h_t, t, dropout=drop)
+        ((oh * w_h).sum() + (ox * w_x).sum()).backward()
+    assert float((eps_h.cpu() - oh.detach()).abs().max()) < 5e-4 * max(1.0, float(oh.detach().abs().max()))
+    assert float((eps_x.cpu() - ox.detach()).abs().max()) < 5e-4 * max(1.0, float(ox.detach().abs().max()))
+    got = flat_to_dict(eng, eng.train_backward(w_h, w_x))
+    ref = {k: (torch.zeros_like(v) if v.grad is None else v.grad) for k, v in leaf.items()}
+    compare(got, ref, 3e-3, name)
+    # a second backward of the same forward reproduces the gradient (deterministic except for the scatter atomics)
+    again = flat_to_dict(eng, eng.train_backward(w_h, w_x))
+    for k in got:
+        if got[k].numel():
+            assert float((again[k] - got[k]).abs().max()) <= 1e-4 * float(got[k].abs().max()) + 1e-9, k
