@@ -444,7 +444,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     int cur = 0;
     for (int l = 0; l < c.n_convs; ++l) {
         EdgeParams e{};
-        const bool last = (l == c.n_convs - 1) && !train, pruned = (l == prune_layer);
+        const bool last = (l == c.n_convs - 1), pruned = (l == prune_layer);
         e.tiles = pruned ? h->d_edge_tiles_act : h->d_edge_tiles;
         e.ntiles = last ? h->n_edge_tiles_last : (pruned ? h->n_edge_tiles_act : h->n_edge_tiles); e.dyn_cnt = h->d_dyn_cnt;
         e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;
@@ -1274,8 +1274,14 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     }
     int a = 0;
     for (int l = L - 1; l >= 0; --l) {
+        // The last conv layer's output is read on the pharm nodes only (dynamics_gvp.py:91): its protein rows have a
+        // zero gradient, so -- as in the forward -- only the pharm node tiles and the ff / pf edge tiles do any work
+        // there.  The node kernel stores dL/d(layer input) for the rows it walks, the edge kernels add to it: clear first.
+        const bool last = l == L - 1;
+        PF_HIP(h, hipMemsetAsync(h->t_G_h[a ^ 1], 0, (size_t)N * PF_S * 4, s));
+        PF_HIP(h, hipMemsetAsync(h->t_G_v[a ^ 1], 0, (size_t)N * 48 * 4, s));
         BwdNodeParams n{};
-        n.c = tc; n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles;
+        n.c = tc; n.tiles = h->d_node_tiles; n.ntiles = last ? h->n_node_tiles_last : h->n_node_tiles;
         n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = N;
         n.msg_s = h->t_msg_s[l]; n.msg_v = h->t_msg_v[l]; n.zero_row = h->zero_row;
         n.h_in = h->t_H[l]; n.v_in = h->t_V[l];
@@ -1296,12 +1302,12 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         e.c = tc; e.tiles = h->d_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
         // blocks per etype in proportion to its tiles (at least one where there are tiles)
         {
-            const int tot = std::max(1, h->et_tile0[4]);
+            const int tot = std::max(1, last ? h->et_tile0[2] : h->et_tile0[4]);
             int b0 = 0;
             for (int et = 0; et < 4; ++et) {
                 e.et_tile0[et] = h->et_tile0[et];
                 e.et_blk0[et] = b0;
-                const int nt_et = h->et_tile0[et + 1] - h->et_tile0[et];
+                const int nt_et = (last && et >= ET_FP) ? 0 : h->et_tile0[et + 1] - h->et_tile0[et];
                 int nbk = nt_et > 0 ? std::max(1, (int)((int64_t)(nb - 3) * nt_et / tot)) : 0;
                 nbk = std::min(nbk, nt_et);
                 b0 += nbk;
