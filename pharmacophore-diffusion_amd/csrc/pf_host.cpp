@@ -144,6 +144,7 @@ struct pf_handle {
     std::vector<float*> t_sv_z, t_sv_g, t_sv_v;     // per layer: [n_message_gvps][Ecap] rows saved by the forward
     float *t_gs_buf = nullptr, *t_gv_buf = nullptr;
     int et_tile0[5] = {0, 0, 0, 0, 0};      // tile ranges of ff, pf, fp, pp in d_edge_tiles
+    int et_tile0_act[5] = {0, 0, 0, 0, 0};  // ... of ff, pf, fp, pa in d_edge_tiles_act
     float *t_G_h[2] = {nullptr, nullptr}, *t_G_v[2] = {nullptr, nullptr}, *t_gagg_s = nullptr, *t_gagg_v = nullptr,
           *t_gpart = nullptr, *t_geps_h = nullptr, *t_geps_x = nullptr;
     int t_nblk = 0;
@@ -423,7 +424,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
     bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
     bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
-    const int prune_layer = (h->prune && !train && c.n_convs >= 2) ? c.n_convs - 2 : -1;    // the layer restricted to active atoms
+    const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;    // the layer restricted to active atoms
     bp.act_ids = prune_layer >= 0 ? h->d_act_ids : nullptr; bp.reg_act = h->d_reg_act;
     bool pre_ready = false;
     if (h->prof_mask & 3u) {     // timing the two halves separately needs separate launches
@@ -839,11 +840,14 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     h->n_node_tiles_last = (int)h_tiles.size();          // pharm tiles come first in n_tiles
     // pruned layer: ff, pf, fp tiles + pa tiles; pharm node tiles + tiles over the active-atom lists
     std::vector<EdgeTile> et_act;
-    for (int et = 0; et < 4; ++et)
+    for (int et = 0; et < 4; ++et) {
+        h->et_tile0_act[et] = (int)et_act.size();
         for (int g = 0; g < B; ++g) {
             const int cap = h->h_cap[(size_t)et * B + g], reg = h->h_reg[(size_t)et * B + g];
             for (int o = 0; o < cap; o += 32) et_act.push_back({reg + o, std::min(32, cap - o), et == 3 ? (int)ET_PP : et, et * B + g, o});
         }
+    }
+    h->et_tile0_act[4] = (int)et_act.size();
     std::vector<NodeTile> n_act(h_tiles);
     for (int g = 0; g < B; ++g)
         for (int o = 0; o < cap_act[g]; o += 32) n_act.push_back({reg_act[g] + o, std::min(32, cap_act[g] - o), 0, 4 * B + g, o, 1});
@@ -1278,10 +1282,16 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         // zero gradient, so -- as in the forward -- only the pharm node tiles and the ff / pf edge tiles do any work
         // there.  The node kernel stores dL/d(layer input) for the rows it walks, the edge kernels add to it: clear first.
         const bool last = l == L - 1;
+        // The layer before it is needed only where the last layer reads it: the pharm nodes and the protein atoms that
+        // are the source of a pf edge (the active atoms); every other row of its output has a zero gradient.  Same
+        // tile lists as the pruned forward.
+        const bool pruned = h->prune && L >= 2 && l == L - 2;
         PF_HIP(h, hipMemsetAsync(h->t_G_h[a ^ 1], 0, (size_t)N * PF_S * 4, s));
         PF_HIP(h, hipMemsetAsync(h->t_G_v[a ^ 1], 0, (size_t)N * 48 * 4, s));
         BwdNodeParams n{};
-        n.c = tc; n.tiles = h->d_node_tiles; n.ntiles = last ? h->n_node_tiles_last : h->n_node_tiles;
+        n.c = tc; n.tiles = pruned ? h->d_node_tiles_act : h->d_node_tiles;
+        n.ntiles = last ? h->n_node_tiles_last : (pruned ? h->n_node_tiles_act : h->n_node_tiles);
+        n.pp_slot = pruned ? 2 : 1; n.row_ids = h->d_act_ids; n.dyn_cnt = h->d_dyn_cnt;
         n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = N;
         n.msg_s = h->t_msg_s[l]; n.msg_v = h->t_msg_v[l]; n.zero_row = h->zero_row;
         n.h_in = h->t_H[l]; n.v_in = h->t_V[l];
@@ -1299,20 +1309,22 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         n.layer = l; n.l0 = l == 0;
         pfk_bwd_node(&n, std::max(1, std::min(nb, n.ntiles)), s);
         BwdEdgeLevelParams e{};
-        e.c = tc; e.tiles = h->d_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
+        e.c = tc; e.tiles = pruned ? h->d_edge_tiles_act : h->d_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
+        e.pp_slot = pruned ? 2 : 1;
+        const int* et0 = pruned ? h->et_tile0_act : h->et_tile0;
         // blocks per etype in proportion to its tiles (at least one where there are tiles)
         {
-            const int tot = std::max(1, last ? h->et_tile0[2] : h->et_tile0[4]);
+            const int tot = std::max(1, last ? et0[2] : et0[4]);
             int b0 = 0;
             for (int et = 0; et < 4; ++et) {
-                e.et_tile0[et] = h->et_tile0[et];
+                e.et_tile0[et] = et0[et];
                 e.et_blk0[et] = b0;
-                const int nt_et = (last && et >= ET_FP) ? 0 : h->et_tile0[et + 1] - h->et_tile0[et];
+                const int nt_et = (last && et >= ET_FP) ? 0 : et0[et + 1] - et0[et];
                 int nbk = nt_et > 0 ? std::max(1, (int)((int64_t)(nb - 3) * nt_et / tot)) : 0;
                 nbk = std::min(nbk, nt_et);
                 b0 += nbk;
             }
-            e.et_tile0[4] = h->et_tile0[4]; e.et_blk0[4] = b0;
+            e.et_tile0[4] = et0[4]; e.et_blk0[4] = b0;
             if (b0 > nb) PF_FAIL(h, PF_ERR_STATE, "internal: block partition exceeds the gradient copies");
         }
         e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;

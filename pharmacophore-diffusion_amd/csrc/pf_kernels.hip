@@ -471,8 +471,12 @@ __global__ __launch_bounds__(64, PF_WPS_NODE) void k_node_update(const NodeParam
     const NodeTile t = p.tiles[wid];
     const int nt = __builtin_amdgcn_readfirstlane(t.ntype);
     const int j = lane & 31, hl = lane >> 5;
-    const bool live = j < t.n;
-    const int n = t.n0 + min(j, t.n - 1);
+    int tn = t.n;                                     // rows of a list tile (active atoms): what the build kernel counted
+    if (t.cnt_idx >= 0) tn = min(tn, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
+    tn = __builtin_amdgcn_readfirstlane(tn);
+    if (tn <= 0) return;
+    const bool live = j < tn;
+    const int n = t.ids ? p.row_ids[t.n0 + min(j, tn - 1)] : t.n0 + min(j, tn - 1);
     float ms[64], mv[3][8];
 #pragma unroll
     for (int q = 0; q < 64; ++q) ms[q] = 0.f;
@@ -480,7 +484,8 @@ __global__ __launch_bounds__(64, PF_WPS_NODE) void k_node_update(const NodeParam
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int q = 0; q < 8; ++q) mv[c][q] = 0.f;
-    for (int slot = 0; slot < 2; ++slot) {
+    for (int si = 0; si < 2; ++si) {
+        const int slot = si == 0 ? 0 : (nt == 0 ? p.pp_slot : 1);
         const int st = p.in_start[slot * p.N + n];
         const int c = live ? p.in_cnt[slot * p.N + n] : 0;
         int cmax = c;

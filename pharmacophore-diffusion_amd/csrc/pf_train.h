@@ -49,6 +49,8 @@ struct BwdNodeParams {
     TrainCommon c;
     const NodeTile* tiles; int ntiles;
     const int* in_start; const int* in_cnt; int N;
+    int pp_slot;                             // 1: all pp in-edges; 2: compact copy for the active atoms (pruned layer)
+    const int* row_ids; const int* dyn_cnt;  // active-atom lists (tiles with ids != 0) and their lengths
     const float* msg_s; const float* msg_v; int zero_row;
     const float* h_in; const float* v_in;    // layer input (v_in unused when l0)
     const float* G_h_out; const float* G_v_out;   // gradient w.r.t. the layer output
@@ -93,6 +95,7 @@ struct BwdEdgeLevelParams {
     const float* h; const float* v;          // layer input (level 0 gathers the source rows)
     const float* gagg_s; const float* gagg_v;   // upstream of the last level
     const int* in_cnt; int N;
+    int pp_slot;                             // in_cnt slot of the pp tiles (2 in the pruned layer)
     int norm_mode;
     float* G_h_in; float* G_v_in;            // level 0: atomically accumulated
     const float* sv_z; const float* sv_g; const float* sv_v; size_t sv_stride;

@@ -460,11 +460,14 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
         const int nt = t.ntype;
         const GvpT* g = p.upd + nt * p.n_upd;
         const int o_l1w = p.o_ln[nt][0], o_l1b = p.o_ln[nt][1], o_l2w = p.o_ln[nt][2], o_l2b = p.o_ln[nt][3];
-        for (int sub = 0; sub * TR < t.n; ++sub) {
-            const int nv = min(TR, t.n - sub * TR);
+        int tn = t.n;
+        if (t.cnt_idx >= 0) tn = min(tn, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
+        for (int sub = 0; sub * TR < tn; ++sub) {
+            const int nv = min(TR, tn - sub * TR);
             const int n0 = t.n0 + sub * TR;
             if (tid < TR) {
-                const int n = n0 + min(tid, nv - 1);
+                const int pos = n0 + min(tid, nv - 1);
+                const int n = t.ids ? p.row_ids[pos] : pos;      // pruned layer: rows are positions in the active-atom list
                 s_n[tid] = n;
                 float inv = 1.0f;
                 if (p.norm_mode == 1) inv = 1.0f / p.norm_value;
@@ -477,7 +480,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 const int row = tid >> 4, part = tid & 15;
                 const int n = s_n[row];
                 float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mv[3] = {0, 0, 0};
-                for (int slot = 0; slot < 2; ++slot) {
+                for (int si = 0; si < 2; ++si) {
+                    const int slot = si == 0 ? 0 : (nt == 0 ? p.pp_slot : 1);
                     const int st = p.in_start[slot * p.N + n];
                     const int c = p.in_cnt[slot * p.N + n];
                     const float sc = (p.norm_mode == 0 && c > 0) ? 1.0f / (float)c : 1.0f;
@@ -709,7 +713,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
     const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;   // SO == 128, VO == 16 (message GVPs)
     const int nts = (KM + 15) >> 4;                  // <= 11
     const bool lastl = p.level == p.n_gvps - 1, firstl = p.level == 0;
-    const int slot = (et == ET_FF || et == ET_FP) ? 0 : 1;
+    const int slot = (et == ET_FF || et == ET_FP) ? 0 : (et == ET_PP ? p.pp_slot : 1);
     // weight-gradient accumulators, kept in registers over all the tiles of this block:
     //   to_feats_out: wave wv owns output features 16 wv .. +15, tile x = inputs 16 x .. +15
     //   gates: wave wv owns features 16 wv .. +15 of all 16 gates

@@ -144,3 +144,27 @@ def test_gradients_vs_oracle_more_configs(name):
     for k in got:
         if got[k].numel():
             assert float((again[k] - got[k]).abs().max()) <= 1e-4 * float(got[k].abs().max()) + 1e-9, k
+
+
+@pytest.mark.parametrize("name", sorted(GRAD_CASES))
+def test_pruned_and_dense_training_agree(name, monkeypatch):
+    """Walking only the rows whose gradient can be non-zero (last layer: pharm side; layer before: active atoms) is
+    exact: with PFDYN_NO_PRUNE every tile of every layer is walked and the gradients are the same up to rounding."""
+    z = load(name)
+    cfg = GRAD_CASES[name]
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    x_t, h_t, prot_x, t = noised_inputs(cfg, batch, z, int(z["T"]))
+    gen = torch.Generator().manual_seed(5)
+    w_h, w_x = torch.randn(h_t.shape, generator=gen), torch.randn(x_t.shape, generator=gen)
+    res = []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("PFDYN_NO_PRUNE", "1")
+            monkeypatch.setenv("PFDYN_NO_PRE", "1")
+        eng = make_engine(cfg, sd, batch)
+        eh, ex = eng.train_forward(x_t, h_t, t, prot_x=prot_x, dropout=0.1, seed=77)
+        res.append((eh.cpu(), ex.cpu(), flat_to_dict(eng, eng.train_backward(w_h, w_x))))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-5, atol=2e-5)
+    compare(res[0][2], {k: v for k, v in res[1][2].items()}, 1e-3, name)
