@@ -1274,7 +1274,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         p.o_bout = (int)h->flat_offset("dynamics.noise_predictor.noise_predictor.to_scalar_output.bias");
         p.pharm_nf = c.pharm_nf; p.g_eps_h = dev_g_eps_h; p.g_eps_x = dev_g_eps_x;
         p.G_h = h->t_G_h[0]; p.G_v = h->t_G_v[0];
-        pfk_bwd_head(&p, std::max(1, std::min(nb, p.ntiles)), s);
+        pfk_bwd_head(&p, std::max(1, std::min(nb, 2 * p.ntiles)), s);
     }
     int a = 0;
     for (int l = L - 1; l >= 0; --l) {
@@ -1307,7 +1307,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
             n.o_ln[nt][2] = (int)h->flat_offset(p2 + "weight"); n.o_ln[nt][3] = (int)h->flat_offset(p2 + "bias");
         }
         n.layer = l; n.l0 = l == 0;
-        pfk_bwd_node(&n, std::max(1, std::min(nb, n.ntiles)), s);
+        pfk_bwd_node(&n, std::max(1, std::min(nb, 2 * n.ntiles)), s);
         BwdEdgeLevelParams e{};
         e.c = tc; e.tiles = pruned ? h->d_edge_tiles_act : h->d_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
         e.pp_slot = pruned ? 2 : 1;

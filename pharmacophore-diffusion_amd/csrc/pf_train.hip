@@ -350,9 +350,10 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
     float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
     const int NF = p.pharm_nf;
     const int SOL = p.g[p.n_gvps - 1].so;            // 64
-    for (int ti = blockIdx.x; ti < p.ntiles; ti += gridDim.x) {
-        const NodeTile t = p.tiles[ti];
-        for (int sub = 0; sub * TR < t.n; ++sub) {
+    // work unit = one 16-row half of a 32-row tile, dealt over the blocks
+    for (int unit = blockIdx.x; unit < 2 * p.ntiles; unit += gridDim.x) {
+        const NodeTile t = p.tiles[unit >> 1];
+        for (int sub = unit & 1; sub == (unit & 1) && sub * TR < t.n; sub += 2) {
             const int nv = min(TR, t.n - sub * TR);
             const int n0 = t.n0 + sub * TR;
             float* S0 = L.Sin(0); float* V0 = L.Vin(0);
@@ -455,14 +456,14 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
     const float* W = p.c.W;
     float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
     const uint32_t st_msg = (uint32_t)p.layer * 2u, st_res = st_msg + 1u;
-    for (int ti = blockIdx.x; ti < p.ntiles; ti += gridDim.x) {
-        const NodeTile t = p.tiles[ti];
+    for (int unit = blockIdx.x; unit < 2 * p.ntiles; unit += gridDim.x) {
+        const NodeTile t = p.tiles[unit >> 1];
         const int nt = t.ntype;
         const GvpT* g = p.upd + nt * p.n_upd;
         const int o_l1w = p.o_ln[nt][0], o_l1b = p.o_ln[nt][1], o_l2w = p.o_ln[nt][2], o_l2b = p.o_ln[nt][3];
         int tn = t.n;
         if (t.cnt_idx >= 0) tn = min(tn, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
-        for (int sub = 0; sub * TR < tn; ++sub) {
+        for (int sub = unit & 1; sub == (unit & 1) && sub * TR < tn; sub += 2) {
             const int nv = min(TR, tn - sub * TR);
             const int n0 = t.n0 + sub * TR;
             if (tid < TR) {
