@@ -237,3 +237,108 @@ def test_flat_adam_matches_torch_adam():
             torch.testing.assert_close(sd_f[k], sd_t[k], rtol=2e-4, atol=2e-6, msg=k)
     for k in l_t:
         assert abs(float(l_t[k]) - float(l_f[k])) <= 1e-4 * max(1.0, abs(float(l_t[k])))
+
+
+def _write_pocket_files(tmp_path, n_res=24, seed=3):
+    """A small synthetic receptor (standard residues around the origin + far ones) and a ligand at the origin."""
+    rng = torch.Generator().manual_seed(seed)
+    lines, serial = [], 1
+    names = [("N", "N"), ("CA", "C"), ("C", "C"), ("O", "O"), ("CB", "C")]
+    for r in range(n_res):
+        centre = (6.0 if r < n_res - 4 else 40.0) * torch.nn.functional.normalize(torch.randn(3, generator=rng), dim=0)
+        for name, el in names:
+            x, y, z = (centre + 1.2 * torch.randn(3, generator=rng)).tolist()
+            lines.append(f"ATOM  {serial:>5}  {name:<3} ALA A{r + 1:>4}    {x:8.3f}{y:8.3f}{z:8.3f}  1.00 20.00          {el:>2}")
+            serial += 1
+    (tmp_path / "rec.pdb").write_text("\n".join(lines) + "\nEND\n")
+    sdf = ["lig", "  t", "", "  3  2  0  0  0  0  0  0  0  0999 V2000"]
+    for x, el in ((-0.7, "C"), (0.0, "N"), (0.7, "O")):
+        sdf.append(f"{x:10.4f}{0.0:10.4f}{0.0:10.4f} {el:<3} 0  0  0  0  0  0  0  0  0  0  0  0")
+    sdf += ["  1  2  1  0", "  2  3  1  0", "M  END", "$$$$"]
+    (tmp_path / "lig.sdf").write_text("\n".join(sdf) + "\n")
+
+
+def test_generate_pharmacophores_cli_end_to_end(tmp_path):
+    """The reference's CLI surface (generate_pharmacophores.py:29-66, 236-392): run dir with config.yaml + checkpoints/
+    last.ckpt, PDB receptor + SDF ligand -> <out>/<receptor>/pharms.xyz, pocket.pdb, sample_time.txt, reference_files/."""
+    import subprocess
+    import sys
+    import yaml
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _write_pocket_files(tmp_path)
+    cfg = yaml.safe_load(open(os.path.join(root, "tests", "golden", "dev_config_subset.yml")))
+    cfg['diffusion']['n_timesteps'] = 12
+    cfg['dataset']['pocket_cutoff'] = 8
+    run = tmp_path / "run"
+    (run / "checkpoints").mkdir(parents=True)
+    yaml.dump(cfg, open(run / "config.yaml", "w"))
+    m = pfa.model_from_config(cfg)
+    sd = dict(O.make_state_dict(O.DynamicsConfig(), 0))
+    sd["gamma.gamma"] = m.state_dict()["gamma.gamma"]
+    m.load_state_dict(sd, strict=True)
+    m.save_checkpoint(run / "checkpoints" / "last.ckpt")
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(root, "generate_pharmacophores.py"), str(tmp_path / "rec.pdb"), "--ref_ligand_file",
+           str(tmp_path / "lig.sdf"), "--model_dir", str(run), "--samples_per_pocket", "5", "--pharm_sizes", "3", "4", "5", "6", "8",
+           "--max_batch_size", "3", "--output_dir", str(out), "--seed", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    pdir = out / "rec"
+    xyz = (pdir / "pharms.xyz").read_text().splitlines()
+    counts, i = [], 0
+    while i < len(xyz):
+        n = int(xyz[i]); counts.append(n)
+        for l in xyz[i + 1:i + 1 + n]:
+            el, x, y, z = l.split()
+            assert el in "PSFNOC" and all(abs(float(v)) < 1e4 for v in (x, y, z))
+        i += n + 1
+    # copy_graph always indexes pharm_sizes from 0 (the reference's quirk): chunks of 3 and 2 samples
+    assert counts == [3, 4, 5, 3, 4]
+    assert (pdir / "pocket.pdb").exists() and (pdir / "sample_time.txt").exists()
+    assert (pdir / "reference_files" / "rec.pdb").exists() and (pdir / "reference_files" / "lig.sdf").exists()
+    # 20 residues within 8 A of the ligand, 5 heavy atoms each
+    assert sum(l.startswith("ATOM") for l in (pdir / "pocket.pdb").read_text().splitlines()) == 100
+
+
+def test_train_driver_smoke(tmp_path):
+    """train.py on a tiny processed dataset in the reference's on-disk layout: a few optimiser steps, a validation
+    pass and a checkpoint that load_from_checkpoint reads back."""
+    import subprocess
+    import sys
+    import yaml
+    import os
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(0)
+    proc = tmp_path / "processed"
+    for split in range(3):
+        d = proc / f"split_{split}"
+        d.mkdir(parents=True)
+        n_g = 6
+        np_, nf_ = np.full(n_g, 40), rng.integers(3, 8, n_g)
+        pos = np.concatenate([O.synthetic_pocket(100 * split + i, 40)[0].numpy() for i in range(n_g)]).astype(np.float32)
+
+        def idx(c):
+            e = np.cumsum(c)
+            return np.stack([e - c, e], 1)
+        np.savez(d / 'prot_pharm_tensors.npz', prot_pos=pos, prot_feat=rng.integers(0, 4, np_.sum()), prot_idx=idx(np_),
+                 pharm_pos=(rng.normal(size=(nf_.sum(), 3)) * 3).astype(np.float32), pharm_feat=rng.integers(0, 6, nf_.sum()),
+                 pharm_idx=idx(nf_), prot_ph_pos=np.zeros((0, 3), np.float32), prot_ph_feat=np.zeros((0,), np.int64),
+                 prot_ph_idx=np.zeros((n_g, 2), np.int64))
+    cfg = yaml.safe_load(open(os.path.join(root, "tests", "golden", "dev_config_subset.yml")))
+    cfg['dataset'].update(processed_data_dir=str(proc), raw_data_dir=str(tmp_path), pocket_cutoff=8)
+    cfg['training'].update(output_dir=str(tmp_path / "runs"), batch_size=4, num_workers=0, validation_splits=[2])
+    cfg['training'].setdefault('trainer_args', {})['max_epochs'] = 1
+    cfg.setdefault('wandb', {})['name'] = 'smoke'
+    yaml.dump(cfg, open(tmp_path / "cfg.yml", "w"))
+    r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--config", str(tmp_path / "cfg.yml"), "--seed", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "val total loss" in r.stdout
+    ck = list((tmp_path / "runs").glob("*/checkpoints/last.ckpt"))
+    assert len(ck) == 1 and (ck[0].parent.parent / "config.yaml").exists()
+    m = pfa.PharmacophoreDiff.load_from_checkpoint(ck[0])
+    ref = O.make_state_dict(O.DynamicsConfig(), 0)
+    k = "dynamics.noise_predictor.noise_predictor.to_scalar_output.bias"
+    assert m.state_dict()[k].shape == ref[k].shape and torch.isfinite(m.state_dict()[k]).all()

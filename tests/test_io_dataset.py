@@ -1,0 +1,159 @@
+"""CPU tests of the receptor / ligand ingestion (pocket_io) and the processed-dataset loader (dataset): the semantics of
+generate_pharmacophores.py:68-233 and protein_pharm_dataset.py:19-179 on hand-written files."""
+import gzip
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import pharmacoforge_amd as pfa
+from pharmacoforge_amd import pocket_io as P
+from pharmacoforge_amd import dataset as D
+from oracle import pf_oracle as O
+
+PROT_ELEMENTS = ['C', 'N', 'O', 'S', 'P', 'F', 'Cl', 'Br', 'I', 'B', 'D']
+CUTOFFS = {'pp': 3.5, 'pf': 8, 'fp': 8, 'ff': 9}
+
+
+def pdb_line(rec, serial, name, alt, resn, chain, resi, x, y, z, occ, elem):
+    name_f = name if len(name) == 4 else " " + name.ljust(3)
+    return f"{rec:<6}{serial:>5} {name_f}{alt}{resn:>3} {chain}{resi:>4}    {x:8.3f}{y:8.3f}{z:8.3f}{occ:6.2f}{20.0:6.2f}          {elem:>2}"
+
+
+def make_pdb(path):
+    L = []
+    s = 1
+    # residue A:1 ALA near the ligand; one hydrogen; CB has two alternate locations (B more occupied)
+    for name, xyz, elem, alt, occ in [("N", (0, 0, 0), "N", " ", 1.0), ("CA", (1.4, 0, 0), "C", " ", 1.0), ("C", (2.0, 1.3, 0), "C", " ", 1.0),
+                                      ("O", (1.4, 2.3, 0), "O", " ", 1.0), ("CB", (2.0, -1.2, 0.5), "C", "A", 0.3),
+                                      ("CB", (2.1, -1.1, 0.6), "C", "B", 0.7), ("HA", (1.5, 0.1, 1.0), "H", " ", 1.0)]:
+        L.append(pdb_line("ATOM", s, name, alt, "ALA", "A", 1, *xyz, occ, elem)); s += 1
+    # residue A:2 MET with a selenium (not in prot_elements -> 'other' -> dropped), 6 A away: still inside the 8 A pocket
+    for name, xyz, elem in [("N", (6, 0, 0), "N"), ("CA", (7.4, 0, 0), "C"), ("SE", (7.5, 1.5, 0), "SE")]:
+        L.append(pdb_line("ATOM", s, name, " ", "MET", "A", 2, *xyz, 1.0, elem)); s += 1
+    # residue A:3 GLY far away (30 A): outside
+    for name, xyz, elem in [("N", (30, 0, 0), "N"), ("CA", (31.4, 0, 0), "C")]:
+        L.append(pdb_line("ATOM", s, name, " ", "GLY", "A", 3, *xyz, 1.0, elem)); s += 1
+    # a water and a non-standard residue right next to the ligand: never pocket residues (is_aa(standard=True))
+    L.append(pdb_line("HETATM", s, "O", " ", "HOH", "A", 101, 0.5, 0.5, 0.5, 1.0, "O")); s += 1
+    L.append(pdb_line("HETATM", s, "CA", " ", "MSE", "A", 4, 0.2, 0.2, 0.2, 1.0, "C")); s += 1
+    L.append("ENDMDL")
+    L.append(pdb_line("ATOM", s, "N", " ", "ALA", "B", 9, 0.1, 0.1, 0.1, 1.0, "N"))      # second model: ignored
+    path.write_text("\n".join(L) + "\nEND\n")
+
+
+SDF = """lig
+  test
+
+  4  3  0  0  0  0  0  0  0  0999 V2000
+    0.5000    0.5000    0.0000 C   0  0  0  0  0  0  0  0  0  0  0  0
+    1.5000    0.5000    0.0000 O   0  0  0  0  0  0  0  0  0  0  0  0
+    0.5000    1.5000    0.0000 N   0  0  0  0  0  0  0  0  0  0  0  0
+    0.5000    0.5000    1.0000 H   0  0  0  0  0  0  0  0  0  0  0  0
+  1  2  1  0
+  1  3  1  0
+  1  4  1  0
+M  END
+$$$$
+"""
+
+
+def oracle_pp(pos):
+    e = O.radius_graph(pos, 3.5, torch.tensor([0, pos.shape[0]]), 100)
+    return e[0], e[1]
+
+
+def test_pdb_sdf_pocket(tmp_path):
+    pdb, sdf = tmp_path / "rec.pdb", tmp_path / "lig.sdf"
+    make_pdb(pdb)
+    sdf.write_text(SDF)
+    res = P.read_pdb(pdb)
+    assert [(r.resname, r.chain, r.resseq, r.hetero) for r in res] == [("ALA", "A", 1, False), ("MET", "A", 2, False),
+                                                                         ("GLY", "A", 3, False), ("HOH", "A", 101, True), ("MSE", "A", 4, True)]
+    cb = [a for a in res[0].atoms if a.name == "CB"]
+    assert len(cb) == 1 and cb[0].altloc == "B" and np.allclose(cb[0].coord, [2.1, -1.1, 0.6])
+    elems, pos = P.parse_ligand(sdf, remove_hydrogen=True)
+    assert elems == ["C", "O", "N"] and pos.shape == (3, 3)
+    assert P.parse_ligand(sdf)[1].shape == (4, 3)
+    emap, tmap = P.get_prot_atom_ph_type_maps({'prot_elements': PROT_ELEMENTS, 'ph_type_map': pfa.analysis.ph_idx_to_type})
+    assert emap['other'] == 11 and tmap['Hydrophobic'] == 5
+    # the radius graph needs the GPU library; here the oracle's radius graph is injected
+    all_pos = torch.tensor(np.array([a.coord for r in res[:2] for a in r.atoms if a.element not in ("H", "SE")]))
+    g = P.process_ligand_and_pocket(pdb, tmp_path, emap, CUTOFFS, 8.0, lig_file=sdf, pp_edges=oracle_pp(all_pos))
+    assert g.num_nodes('prot') == 7                        # ALA: N CA C O CB (no H), MET: N CA (SE dropped); GLY / HOH / MSE out
+    assert torch.allclose(g.prot_x, all_pos)
+    assert g.prot_h.shape == (7, 11) and g.prot_h.sum(1).eq(1).all()
+    assert g.prot_h[:, :3].sum(0).tolist() == [4.0, 2.0, 1.0]            # 4 C, 2 N, 1 O
+    assert torch.allclose(g.pharm_x0, pos.mean(0, keepdim=True)) and g.pharm_h0.shape == (1, 6)
+    out = (tmp_path / "pocket.pdb").read_text().splitlines()
+    assert sum(l.startswith("ATOM") for l in out) == 9 and not any("HOH" in l or "GLY" in l for l in out)
+    # residue-list variant: centre = mean of ALL atoms of the listed residues (hydrogens included), :170-173
+    g2 = P.process_ligand_and_pocket(pdb, None, emap, CUTOFFS, 8.0, residue_list=["A:1"],
+                                     pp_edges=oracle_pp(all_pos[:5]))
+    ala = np.array([a.coord for a in res[0].atoms])
+    assert g2.num_nodes('prot') == 5 and torch.allclose(g2.pharm_x0, torch.tensor(ala.mean(0, keepdims=True)))
+    with pytest.raises(ValueError):
+        P.process_ligand_and_pocket(pdb, None, emap, CUTOFFS, 8.0)
+    two = tmp_path / "two.sdf"
+    two.write_text(SDF + SDF)
+    with pytest.raises(NotImplementedError):
+        P.parse_ligand(two)
+
+
+def make_split(d, seed, n_graphs):
+    rng = np.random.default_rng(seed)
+    d.mkdir(parents=True)
+    np_, nf_, nh_ = rng.integers(8, 14, n_graphs), rng.integers(3, 12, n_graphs), rng.integers(0, 5, n_graphs)
+
+    def idx(c):
+        e = np.cumsum(c)
+        return np.stack([e - c, e], 1)
+    np.savez(d / 'prot_pharm_tensors.npz',
+             prot_pos=rng.normal(size=(np_.sum(), 3)).astype(np.float32) * 4, prot_feat=rng.integers(0, 11, np_.sum()),
+             prot_idx=idx(np_), pharm_pos=rng.normal(size=(nf_.sum(), 3)).astype(np.float32), pharm_feat=rng.integers(0, 6, nf_.sum()),
+             pharm_idx=idx(nf_), prot_ph_pos=rng.normal(size=(nh_.sum(), 3)).astype(np.float32),
+             prot_ph_feat=rng.integers(0, 6, nh_.sum()), prot_ph_idx=idx(nh_))
+    with gzip.open(d / 'prot_file_names.pkl.gz', 'wb') as f:
+        pickle.dump([f"{d.name}_{i}.pdb" for i in range(n_graphs)], f)
+    return np_, nf_, nh_
+
+
+def test_processed_dataset_and_collate(tmp_path):
+    root = tmp_path / "processed"
+    a = make_split(root / "split_0", 0, 3)
+    b = make_split(root / "split_1", 1, 2)
+    make_split(root / "split_2", 2, 4)
+    cfg = dict(raw_data_dir=str(tmp_path), processed_data_dir=str(root), graph_cutoffs=CUTOFFS, prot_elements=PROT_ELEMENTS,
+               ph_type_map=pfa.analysis.ph_idx_to_type, pp_edges_fn=oracle_pp)
+    ds = D.ProteinPharmacophoreDataset('train', [0, 1], **cfg)
+    assert len(ds) == 5 and len(ds.prot_file_names) == 5
+    np_all, nf_all = np.concatenate([a[0], b[0]]), np.concatenate([a[1], b[1]])
+    raw1 = np.load(root / "split_1" / "prot_pharm_tensors.npz")
+    for i in range(5):
+        g = ds[i]
+        assert g.num_nodes('prot') == np_all[i] and g.num_nodes('pharm') == nf_all[i]
+        assert g.prot_h.shape[1] == 11 and g.pharm_h0.shape[1] == 6 and g.prot_h.sum(1).eq(1).all()
+        src, dst = oracle_pp(g.prot_x)
+        assert torch.equal(g.pp_src, src) and torch.equal(g.pp_dst, dst)
+    # graph 3 = first graph of the second file: its rows start where the first file ended (global index fix-up)
+    g3 = ds[3]
+    assert np.allclose(g3.prot_x.numpy(), raw1['prot_pos'][:b[0][0]])
+    assert np.allclose(g3.pharm_x0.numpy(), raw1['pharm_pos'][:b[1][0]])
+    gb = D.collate_fn([ds[0], ds[3], ds[4]])
+    assert gb.batch_size == 3 and gb.num_nodes('prot') == np_all[[0, 3, 4]].sum()
+    assert gb.prot_ptr.tolist() == [0] + np.cumsum(np_all[[0, 3, 4]]).tolist()
+    # subsampling keeps between subsample_min and min(subsample_max, n) centers
+    import random
+    random.seed(0)
+    ds_s = D.ProteinPharmacophoreDataset('train', [0, 1], subsample_pharms=True, subsample_min=3, subsample_max=5, **cfg)
+    for i in range(5):
+        n = ds_s[i].num_nodes('pharm')
+        assert (3 <= n <= min(5, nf_all[i])) if nf_all[i] >= 3 else n == nf_all[i]
+    dm = D.CrossdockedDataModule(dataset_config=cfg, batch_size=2, num_workers=0, validation_splits=[2])
+    dm.setup('fit')
+    assert len(dm.train_dataset) == 5 and len(dm.val_dataset) == 4
+    sizes = [g.batch_size for g in dm.val_dataloader()]
+    assert sizes == [2, 2]
+    with pytest.raises(NotImplementedError):
+        D.CrossdockedDataModule(cfg, 2, 0, [])
