@@ -123,7 +123,7 @@ struct pf_handle {
           *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr, *d_pre = nullptr;
     bool sampling = false;
     // launches with at most this many tiles use the 4-wave cooperative kernels (latency-bound regime)
-    int coop_edge_max = 1024, coop_node_max = 1024;
+    int coop_edge_max = 2000, coop_node_max = 1024;   // measured crossover: 1,728 capacity tiles (batch 96) still favour the 4-wave kernel, 2,304 (batch 128) do not
     void init_tuning() {
         if (const char* e = getenv("PFDYN_COOP_EDGE_MAX")) coop_edge_max = atoi(e);
         if (const char* e = getenv("PFDYN_COOP_NODE_MAX")) coop_node_max = atoi(e);
