@@ -205,3 +205,21 @@ def test_gradient_allreduce_two_ranks_gloo():
     expect = [1.5 * (1 + i % 3) for i in range(6)]
     assert out[0][1] == out[1][1] == expect
     assert out[0][2] and out[1][2]
+
+
+def test_product_code_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it."""
+    offenders = []
+    targets = [os.path.join(ROOT, f) for f in ("generate_pharmacophores.py", "train.py", "pharmacoforge_amd.py")]
+    for base in ("pharmacophore-diffusion_amd", "tools", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            targets += [os.path.join(dp, f) for f in files if f.endswith((".py", ".cpp", ".hip", ".h"))]
+    for path in targets:
+        text = open(path, errors="ignore").read()
+        if re.search(r"^\s*(from|import)\s+oracle\b", text, re.M) or re.search(r"^[^#/\n]*\bpf_oracle\b", text, re.M):
+            offenders.append(os.path.relpath(path, ROOT))
+    assert not offenders, offenders
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"\boracle\b", bench)]
+    start = bench.index("def cpu_baseline")
+    assert all(u > start or "import" not in bench[max(0, u - 40):u] for u in uses)
