@@ -19,6 +19,7 @@
 extern "C" {
 void pfk_edge_msg(const EdgeParams* p, int layer0, hipStream_t s);
 void pfk_edge_msg_coop(const EdgeParams* p, int layer0, hipStream_t s);
+void pfk_edge_msg_coop2(const EdgeParams* p, int layer0, hipStream_t s);
 void pfk_node_update_coop(const NodeParams* p, int layer0, hipStream_t s);
 void pfk_noise_head_coop(const HeadParams* p, hipStream_t s);
 void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s);
@@ -123,8 +124,15 @@ struct pf_handle {
           *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr, *d_pre = nullptr;
     bool sampling = false;
     // launches with at most this many tiles use the 4-wave cooperative kernels (latency-bound regime)
-    int coop_edge_max = 2000, coop_node_max = 1024;   // measured crossover: 1,728 capacity tiles (batch 96) still favour the 4-wave kernel, 2,304 (batch 128) do not
+    // Edge-message launches: up to coop_edge_max tiles (one per CU) the 4-wave kernel with next-GVP weight prefetch;
+    // up to coop2_edge_max (pruned / last-layer tile lists) or coop2_dense_max (dense layers, where the one-wave kernel
+    // has the per-source precompute) the same kernel without the prefetch at two workgroups per CU; beyond that one wave
+    // per tile.  Measured (config 3 pockets): batch 64 / 128 / 256 = 318 k / 526-560 k / 755 k sample-steps/s with the
+    // two-workgroup kernel against 236 k / 456 k / 692 k with one wave per tile; batch 1024 prefers one wave per tile.
+    int coop_edge_max = 256, coop_node_max = 1024;
+    int coop2_edge_max = 12000, coop2_dense_max = 1024;
     void init_tuning() {
+        if (const char* e = getenv("PFDYN_COOP2_EDGE_MAX")) coop2_edge_max = coop2_dense_max = atoi(e);
         if (const char* e = getenv("PFDYN_COOP_EDGE_MAX")) coop_edge_max = atoi(e);
         if (const char* e = getenv("PFDYN_COOP_NODE_MAX")) coop_node_max = atoi(e);
         if (const char* e = getenv("PFDYN_NO_PRE")) use_pre = atoi(e) == 0;
@@ -461,6 +469,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             e.sv_stride = (size_t)std::max<int64_t>(h->Ecap, 1);
         }
         if (e.ntiles <= h->coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
+        else if (e.ntiles <= ((last || pruned) ? h->coop2_edge_max : h->coop2_dense_max) && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop2(&e, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
 
         NodeParams n{};

@@ -811,7 +811,10 @@ __device__ __forceinline__ void load_vec_rc(P row, const int hl, const int wv, f
     for (int t = 0; t < 8; ++t) Vc[t] = wv == 0 ? V[0][t] : (wv == 1 ? V[1][t] : V[2][t]);
 }
 
-template <bool L0>
+// LOWREG: one weight buffer instead of two (no prefetch of the next GVP while the current one computes) so that the
+// kernel fits 256 registers and two workgroups share a CU: for launches with several times more tiles than CUs the
+// second workgroup hides the first one's barriers and weight loads.
+template <bool L0, bool LOWREG = false>
 __device__ __forceinline__ void edge_tile_coop(const EdgeParams& p, const EdgeTile t, CoopLds& L, const int lane, const int wv) {
     int nvalid = t.n;
     if (t.cnt_idx >= 0) {
@@ -848,7 +851,14 @@ __device__ __forceinline__ void edge_tile_coop(const EdgeParams& p, const EdgeTi
         for (int q = 0; q < 8; ++q) Vc[q] = 0.f;
     }
     float s1[64], V1[8];
-    {
+    if constexpr (LOWREG) {
+        gvp_coop_compute<17, PF_R, 16, 4, true, L0>(Wfirst, s, rb, Vc, xhat_c, s1, V1, lane, wv, L);
+        if (p.n_gvps > 1) {
+            CoopW<16, 0> Wn;
+            gvp_coop_load<16, 0, 4>(wt[1], lane, wv, Wn);
+            gvp_coop_chain1(wt + 1, p.n_gvps - 1, Wn, s1, V1, lane, wv, L);
+        }
+    } else {
         CoopW<16, 0> Wn;
         if (p.n_gvps > 1) gvp_coop_load<16, 0, 4>(wt[1], lane, wv, Wn);
         gvp_coop_compute<17, PF_R, 16, 4, true, L0>(Wfirst, s, rb, Vc, xhat_c, s1, V1, lane, wv, L);
@@ -885,6 +895,14 @@ __global__ __launch_bounds__(256, 1) void k_edge_msg_coop(const EdgeParams p) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     edge_tile_coop<L0>(p, p.tiles[blockIdx.x], L, lane, wv);
+}
+// two workgroups per CU (<= 256 registers): launches with many more tiles than CUs
+template <bool L0>
+__global__ __launch_bounds__(256, 2) void k_edge_msg_coop2(const EdgeParams p) {
+    __shared__ CoopLds L;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    edge_tile_coop<L0, true>(p, p.tiles[blockIdx.x], L, lane, wv);
 }
 
 // GVPLayerNorm with the vector state spread over waves 0..2 (coordinate c in wave c)
@@ -1691,6 +1709,11 @@ extern "C" {
 #ifdef PF_STAMPS
 int pfk_set_stamp_buffer(unsigned long long* dev) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pf_stamps), &dev, sizeof(dev)); }
 #endif
+void pfk_edge_msg_coop2(const EdgeParams* p, int layer0, hipStream_t s) {
+    if (p->ntiles == 0) return;
+    if (layer0) hipLaunchKernelGGL(k_edge_msg_coop2<true>, dim3(p->ntiles), dim3(256), 0, s, *p);
+    else hipLaunchKernelGGL(k_edge_msg_coop2<false>, dim3(p->ntiles), dim3(256), 0, s, *p);
+}
 void pfk_edge_msg_coop(const EdgeParams* p, int layer0, hipStream_t s) {
     if (p->ntiles == 0) return;
     if (layer0) hipLaunchKernelGGL(k_edge_msg_coop<true>, dim3(p->ntiles), dim3(256), 0, s, *p);

@@ -199,6 +199,7 @@ def test_one_wave_per_tile_kernels(name, monkeypatch):
     32 rows, dense layers, per-source precompute) are forced here on the small golden cases, so that both
     kernel families are checked against the reference goldens."""
     monkeypatch.setenv("PFDYN_COOP_EDGE_MAX", "0")
+    monkeypatch.setenv("PFDYN_COOP2_EDGE_MAX", "0")
     monkeypatch.setenv("PFDYN_COOP_NODE_MAX", "0")
     monkeypatch.setenv("PFDYN_NO_PRUNE", "1")
     z, cfg = load(name), DYN_CASES[name]
@@ -213,6 +214,24 @@ def test_one_wave_per_tile_kernels(name, monkeypatch):
                                     z["conv_in_h_pharm"], z["conv_in_v_pharm"])
     close(hp, z["conv_out_h_prot"]); close(vp, z["conv_out_v_prot"])
     close(hf, z["conv_out_h_pharm"]); close(vf, z["conv_out_v_pharm"])
+
+
+@pytest.mark.parametrize("name", ["dynamics_ragged.npz", "dynamics_radius.npz"])
+@pytest.mark.parametrize("dense", [False, True])
+def test_two_workgroups_per_cu_edge_kernel(name, dense, monkeypatch):
+    """k_edge_msg_coop2 (the 4-wave kernel without weight prefetch, two workgroups per CU: launches with more tiles
+    than CUs) forced on the small golden cases, on the pruned and on the dense tile lists."""
+    monkeypatch.setenv("PFDYN_COOP_EDGE_MAX", "0")
+    monkeypatch.setenv("PFDYN_COOP2_EDGE_MAX", "1000000")
+    if dense:
+        monkeypatch.setenv("PFDYN_NO_PRUNE", "1")
+    z, cfg = load(name), DYN_CASES[name]
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch, z["prot_x"])
+    eps_h, eps_x = eng.dynamics(z["x_t"], z["h_t"], z["t"])
+    close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
 
 
 def _rand_inputs(batch, seed, pharm_nf=6, scale=3.0):
