@@ -9,7 +9,9 @@
 // (pf_host.cpp: expected_tensors); a GvpT addresses one GVP's six tensors by offset into that vector, so the
 // gradient of a tensor sits at the same offset of the gradient vector.  Every thread block of a backward kernel
 // accumulates into its own private copy of the gradient vector (gpart[block][nparams], plain read-modify-write by
-// the owning lane, no atomics); pfk_train_reduce sums the copies in a fixed order, so gradients are bit-reproducible.
+// the owning lane, no atomics) and pfk_train_reduce sums the copies in a fixed order.  The one place where the summation
+// order is not fixed is the scatter of dL/d(h_src, v_src) from the edges of level 0 to their source nodes (fp32 atomics:
+// a node's out-edges live in many tiles); repeated backward passes agree to ~1e-7 relative, not bit for bit.
 #pragma once
 #include <stdint.h>
 #include "pf_device.h"
