@@ -342,3 +342,72 @@ def test_train_driver_smoke(tmp_path):
     ref = O.make_state_dict(O.DynamicsConfig(), 0)
     k = "dynamics.noise_predictor.noise_predictor.to_scalar_output.bias"
     assert m.state_dict()[k].shape == ref[k].shape and torch.isfinite(m.state_dict()[k]).all()
+
+
+def _tiny_run_dir(tmp_path, T=10):
+    """processed dataset in the reference layout (3 splits x 5 pockets of 40 atoms, 2-3 receptor pharmacophore points
+    each) + a run directory (config.yaml, checkpoints/last.ckpt) with seeded weights."""
+    import os
+    import numpy as np
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(1)
+    proc = tmp_path / "processed"
+    for split in range(3):
+        d = proc / f"split_{split}"
+        d.mkdir(parents=True)
+        n_g = 5
+        np_, nf_, nh_ = np.full(n_g, 40), rng.integers(3, 8, n_g), rng.integers(2, 4, n_g)
+        pos = np.concatenate([O.synthetic_pocket(200 * split + i, 40)[0].numpy() for i in range(n_g)]).astype(np.float32)
+
+        def idx(c):
+            e = np.cumsum(c)
+            return np.stack([e - c, e], 1)
+        np.savez(d / 'prot_pharm_tensors.npz', prot_pos=pos, prot_feat=rng.integers(0, 4, np_.sum()), prot_idx=idx(np_),
+                 pharm_pos=(rng.normal(size=(nf_.sum(), 3)) * 3).astype(np.float32), pharm_feat=rng.integers(0, 6, nf_.sum()),
+                 pharm_idx=idx(nf_), prot_ph_pos=(rng.normal(size=(nh_.sum(), 3)) * 4).astype(np.float32),
+                 prot_ph_feat=rng.integers(0, 6, nh_.sum()), prot_ph_idx=idx(nh_))
+    cfg = yaml.safe_load(open(os.path.join(root, "tests", "golden", "dev_config_subset.yml")))
+    cfg['diffusion']['n_timesteps'] = T
+    cfg['dataset'].update(processed_data_dir=str(proc), raw_data_dir=str(tmp_path), pocket_cutoff=8)
+    cfg['training'].update(output_dir=str(tmp_path / "runs"), batch_size=4, num_workers=0, validation_splits=[2])
+    run = tmp_path / "run"
+    (run / "checkpoints").mkdir(parents=True)
+    yaml.dump(cfg, open(run / "config.yaml", "w"))
+    m = pfa.model_from_config(cfg)
+    sd = dict(O.make_state_dict(O.DynamicsConfig(), 0))
+    sd["gamma.gamma"] = m.state_dict()["gamma.gamma"]
+    m.load_state_dict(sd, strict=True)
+    m.save_checkpoint(run / "checkpoints" / "last.ckpt")
+    return root, run
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_dataset_sampling_driver(tmp_path, world):
+    """test.py (the reference's dataset-scale sampling driver, config 4's workflow): every validation pocket gets
+    samples_per_pocket pharmacophores; with 2 ranks the pockets are dealt over the ranks and the metric counters are
+    all-reduced."""
+    import subprocess
+    import sys
+    import os
+    root, run = _tiny_run_dir(tmp_path)
+    out = tmp_path / "samples"
+    base = [os.path.join(root, "test.py"), "--model_dir", str(run), "--samples_per_pocket", "3", "--pharm_sizes", "3", "5", "4",
+            "--max_batch_size", "4", "--output_dir", str(out), "--metrics", "--pockets_per_call", "2"]
+    if world == 1:
+        cmd = [sys.executable] + base
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29677"] + base
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for i in range(5):
+        xyz = (out / f"pocket_{i}" / "pharms.xyz").read_text().splitlines()
+        counts, j = [], 0
+        while j < len(xyz):
+            counts.append(int(xyz[j])); j += counts[-1] + 1
+        assert counts == [3, 5, 4], (i, counts)
+        assert (out / f"pocket_{i}" / "sample_time.txt").exists()
+    metrics = dict(l.split(": ") for l in (out / "metrics.txt").read_text().splitlines())
+    assert 0.0 <= float(metrics["validity"]) <= 1.0
+    assert sum(eval((out / "pharm_counts_None.txt").read_text())) == 5 * 12
