@@ -115,21 +115,32 @@ def batch(graphs: List[PocketGraph]) -> PocketGraph:
 
 
 def unbatch(g: PocketGraph) -> List[PocketGraph]:
+    """dgl.unbatch: per-graph views.  The pp edges of a batched graph are grouped by graph (batch() concatenates them
+    in graph order), so each graph's edges are one slice; an arbitrary edge order falls back to masks."""
     out = []
+    B = g.batch_size
     gid = torch.searchsorted(g.prot_ptr[1:].contiguous(), g.pp_dst, right=True)
-    for b in range(g.batch_size):
-        p0, p1 = int(g.prot_ptr[b]), int(g.prot_ptr[b + 1])
-        f0, f1 = int(g.pharm_ptr[b]), int(g.pharm_ptr[b + 1])
-        m = gid == b
+    grouped = bool((gid[1:] >= gid[:-1]).all()) if gid.numel() > 1 else True
+    if grouped:
+        e_ptr = torch.zeros(B + 1, dtype=torch.int64)
+        e_ptr[1:] = torch.cumsum(torch.bincount(gid, minlength=B)[:B], 0)
+        e_ptr = e_ptr.tolist()
+    pp, fp = g.prot_ptr.tolist(), g.pharm_ptr.tolist()
+    have_ph = g.prot_ph_ptr is not None and g.prot_ph_x is not None
+    qp = g.prot_ph_ptr.tolist() if have_ph else None
 
-        def sl(t, a, e):
-            return None if t is None else t[a:e]
-        if g.prot_ph_ptr is not None and g.prot_ph_x is not None:
-            q0, q1 = int(g.prot_ph_ptr[b]), int(g.prot_ph_ptr[b + 1])
+    def sl(t, a, e):
+        return None if t is None else t[a:e]
+    for b in range(B):
+        p0, p1, f0, f1 = pp[b], pp[b + 1], fp[b], fp[b + 1]
+        if grouped:
+            src, dst = g.pp_src[e_ptr[b]:e_ptr[b + 1]] - p0, g.pp_dst[e_ptr[b]:e_ptr[b + 1]] - p0
         else:
-            q0 = q1 = 0
-        out.append(PocketGraph(g.prot_x[p0:p1], g.prot_h[p0:p1], _ptr([p1 - p0]), _ptr([f1 - f0]),
-                               g.pp_src[m] - p0, g.pp_dst[m] - p0, sl(g.pharm_x0, f0, f1), sl(g.pharm_h0, f0, f1),
+            m = gid == b
+            src, dst = g.pp_src[m] - p0, g.pp_dst[m] - p0
+        q0, q1 = (qp[b], qp[b + 1]) if have_ph else (0, 0)
+        out.append(PocketGraph(g.prot_x[p0:p1], g.prot_h[p0:p1], _ptr([p1 - p0]), _ptr([f1 - f0]), src, dst,
+                               sl(g.pharm_x0, f0, f1), sl(g.pharm_h0, f0, f1),
                                sl(g.prot_ph_x, q0, q1), sl(g.prot_ph_h, q0, q1), _ptr([q1 - q0]),
                                sl(g.x_t, f0, f1), sl(g.h_t, f0, f1)))
     return out

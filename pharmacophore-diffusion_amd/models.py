@@ -415,16 +415,15 @@ class PharmacophoreDiff(_Base):
         current HIP stream by pf_sample (no host synchronisation inside the loop).
 
         ``noise`` ([T+1, Nf, 3+pharm_nf], optional) injects the Gaussian draws (initial draw first; x
-        columns before h columns -- the reference's draw order, pharmacodiff.py:455-456, 423-424).
-        When omitted they are drawn with torch.randn on the model's device in that same order."""
+        columns before h columns -- the reference's draw order, pharmacodiff.py:455-456, 423-424): replaying a
+        reference run means passing its draws here.  When omitted all T+1 draws come from ONE torch.randn call on the
+        model's device (same distribution, reproducible under torch.manual_seed; the reference's 2(T+1) separate calls
+        would cost a thousand launches per batch and cannot reproduce a CUDA generator's stream on ROCm anyway)."""
         g = as_pocket_graph(g)
         dev = self.device
         T, Nf, nf = self.n_timesteps, g.num_nodes("pharm"), self.n_pharm_feats
         if noise is None:
-            noise = torch.empty(T + 1, Nf, 3 + nf, device=dev)
-            for i in range(T + 1):          # same call order / shapes as the reference's torch.randn calls
-                noise[i, :, :3] = torch.randn(Nf, 3, device=dev)
-                noise[i, :, 3:] = torch.randn(Nf, nf, device=dev)
+            noise = torch.randn(T + 1, Nf, 3 + nf, device=dev)
         eng = self.dynamics.bind_graph(g)
         coef = self.step_coefficients()
         arr = eng.coef_array(coef, reversed(range(T)))
