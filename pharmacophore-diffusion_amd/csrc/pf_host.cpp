@@ -21,6 +21,7 @@ void pfk_edge_msg(const EdgeParams* p, int layer0, hipStream_t s);
 void pfk_edge_msg_coop(const EdgeParams* p, int layer0, hipStream_t s);
 void pfk_edge_msg_coop2(const EdgeParams* p, int layer0, hipStream_t s);
 void pfk_node_update_coop(const NodeParams* p, int layer0, hipStream_t s);
+void pfk_node_head_coop(const NodeParams* p, const HeadParams* hp, int layer0, hipStream_t s);
 void pfk_noise_head_coop(const HeadParams* p, hipStream_t s);
 void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s);
 void pfk_noise_head(const HeadParams* p, hipStream_t s);
@@ -131,11 +132,13 @@ struct pf_handle {
     // two-workgroup kernel against 236 k / 456 k / 692 k with one wave per tile; batch 1024 prefers one wave per tile.
     int coop_edge_max = 256, coop_node_max = 1024;
     int coop2_edge_max = 12000, coop2_dense_max = 1024;
+    bool fuse_head = true;                  // last conv layer's node update + noise head in one launch (PFDYN_NO_FUSE_HEAD=1: separate)
     void init_tuning() {
         if (const char* e = getenv("PFDYN_COOP2_EDGE_MAX")) coop2_edge_max = coop2_dense_max = atoi(e);
         if (const char* e = getenv("PFDYN_COOP_EDGE_MAX")) coop_edge_max = atoi(e);
         if (const char* e = getenv("PFDYN_COOP_NODE_MAX")) coop_node_max = atoi(e);
         if (const char* e = getenv("PFDYN_NO_PRE")) use_pre = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_NO_FUSE_HEAD")) fuse_head = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_PRUNE")) prune = atoi(e) == 0;
     }
 
@@ -451,6 +454,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     } else pfk_encode_build(&ep, &bp, s);
 
     int cur = 0;
+    bool head_done = false;
     for (int l = 0; l < c.n_convs; ++l) {
         EdgeParams e{};
         const bool last = (l == c.n_convs - 1), pruned = (l == prune_layer);
@@ -490,7 +494,17 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             n.w[nt].upd = h->d_gvp + h->upd_base(l, nt);
         }
         n.n_upd = c.n_update_gvps;
-        if (n.ntiles <= h->coop_node_max && !train) { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_node_update_coop(&n, l == 0, s); }
+        if (last && !train && h->fuse_head && n.ntiles <= h->coop_node_max && h->n_head_tiles == n.ntiles) {
+            // last layer (pharm tiles only) + noise head in one launch: the layer output stays in registers
+            HeadParams hp{};
+            hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
+            hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
+            hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
+            hp.eps_h = eps_h; hp.eps_x = eps_x;
+            { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_node_head_coop(&n, &hp, l == 0, s); }
+            head_done = true;
+        }
+        else if (n.ntiles <= h->coop_node_max && !train) { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_node_update_coop(&n, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_NODE, s); pfk_node_update(&n, l == 0, s); }
         cur ^= 1;
     }
@@ -500,7 +514,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
     hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
     hp.eps_h = eps_h; hp.eps_x = eps_x;
-    { ProfScope ps(h, pf_handle::K_HEAD, s); if (hp.ntiles <= h->coop_node_max) pfk_noise_head_coop(&hp, s); else pfk_noise_head(&hp, s); }
+    if (!head_done) { ProfScope ps(h, pf_handle::K_HEAD, s); if (hp.ntiles <= h->coop_node_max) pfk_noise_head_coop(&hp, s); else pfk_noise_head(&hp, s); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return PF_OK;

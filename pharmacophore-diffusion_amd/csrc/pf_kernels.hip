@@ -945,8 +945,13 @@ __device__ __forceinline__ void gvp_layernorm_coop(pf_gcf lw, pf_gcf lb, const i
     __syncthreads();                                   // vx is reused by the caller
 }
 
-template <bool L0>
-__device__ __forceinline__ void node_tile_coop(const NodeParams& p, const NodeTile t, CoopLds& L, const int lane, const int wv) {
+__device__ __forceinline__ void head_chain_coop(const HeadParams& p, CoopW<16, 0>& Wh0, float (&s1)[64], float (&V1)[8],
+                                                const int n, const bool live, CoopLds& L, const int lane, const int wv);
+// HEAD: last conv layer of the inference path -- the tile's output never leaves the registers: the noise head runs on it
+// right away (dynamics_gvp.py:91 reads the last layer only on the pharm nodes), saving a launch and the head's start-up
+template <bool L0, bool HEAD = false>
+__device__ __forceinline__ void node_tile_coop(const NodeParams& p, const NodeTile t, CoopLds& L, const int lane, const int wv,
+                                               const HeadParams* hp = nullptr) {
     const int nt = __builtin_amdgcn_readfirstlane(t.ntype);
     const int j = lane & 31, hl = lane >> 5;
     int tn = t.n;
@@ -1068,6 +1073,17 @@ __device__ __forceinline__ void node_tile_coop(const NodeParams& p, const NodeTi
     for (int q = 0; q < 64; ++q) s[q] += res[q][lane];
 #pragma unroll
     for (int q = 0; q < 8; ++q) Vc[q] += V1[q];
+    if constexpr (HEAD) {
+        CoopW<16, 0> Wh0;                              // head GVP 0 weights travel while the LayerNorm runs
+        if (hp->n_gvps > 1) gvp_coop_load<16, 0, 4>(((const GvpW PF_AS1*)hp->gvps)[0], lane, wv, Wh0);
+        gvp_layernorm_coop(nw.ln2_w, nw.ln2_b, hl, lane, wv, s, Vc, L);
+        if (wv == 3) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) Vc[q] = 0.f;
+        }
+        head_chain_coop(*hp, Wh0, s, Vc, n, live, L, lane, wv);
+        return;
+    }
     gvp_layernorm_coop(nw.ln2_w, nw.ln2_b, hl, lane, wv, s, Vc, L);
     if (wv < 3) {
 #pragma unroll
@@ -1094,25 +1110,22 @@ __global__ __launch_bounds__(256, 2) void k_node_update_coop(const NodeParams p)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     node_tile_coop<L0>(p, p.tiles[blockIdx.x], L, lane, wv);
 }
+// last conv layer + noise head in one launch (pharm tiles only)
+template <bool L0>
+__global__ __launch_bounds__(256, 1) void k_node_head_coop(const NodeParams p, const HeadParams hp) {
+    __shared__ CoopLds L;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    node_tile_coop<L0, true>(p, p.tiles[blockIdx.x], L, lane, wv, &hp);
+}
 
-__device__ __forceinline__ void head_tile_coop(const HeadParams& p, const NodeTile t, CoopLds& L, const int lane, const int wv) {
-    const int j = lane & 31, hl = lane >> 5;
-    const bool live = j < t.n;
-    const int n = t.n0 + min(j, t.n - 1);
-#ifdef PF_STAMPS
-    if (lane == 0) L.scnt[wv] = 0;
-#endif
-    PF_STAMP(L);      // kernel start
+// noise head on a tile whose state is already in registers (s1: the full scalar row of this lane's node, replicated in
+// the four waves; V1: coordinate wv of its vector channels, zeros in wave 3).  Wh0 must hold the weights of head GVP 0
+// when n_gvps > 1.
+__device__ __forceinline__ void head_chain_coop(const HeadParams& p, CoopW<16, 0>& Wh0, float (&s1)[64], float (&V1)[8],
+                                                const int n, const bool live, CoopLds& L, const int lane, const int wv) {
+    const int hl = lane >> 5;
     const GvpW PF_AS1* gv = (const GvpW PF_AS1*)p.gvps;
-    CoopW<16, 0> Wh0;
-    if (p.n_gvps > 1) gvp_coop_load<16, 0, 4>(gv[0], lane, wv, Wh0);
-    float s1[64], V1[8];
-    load_row_f(p.h + (size_t)n * PF_S, hl, s1);
-    if (wv < 3) load_vec_rc(p.v + (size_t)n * 48, hl, wv, V1);
-    else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) V1[q] = 0.f;
-    }
     CoopW<16, 0> Wlast;
     gvp_coop_load<16, 0, 2>(gv[p.n_gvps - 1], lane, wv, Wlast);
     if (p.n_gvps > 1) gvp_coop_chain(gv, p.n_gvps - 1, Wh0, s1, V1, lane, wv, L);
@@ -1137,6 +1150,27 @@ __device__ __forceinline__ void head_tile_coop(const HeadParams& p, const NodeTi
     } else if (live && hl == 0) {
         p.eps_x[(size_t)f * 3 + wv] = Vo[0];           // output vector channel 0, coordinate wv
     }
+}
+
+__device__ __forceinline__ void head_tile_coop(const HeadParams& p, const NodeTile t, CoopLds& L, const int lane, const int wv) {
+    const int j = lane & 31, hl = lane >> 5;
+    const bool live = j < t.n;
+    const int n = t.n0 + min(j, t.n - 1);
+#ifdef PF_STAMPS
+    if (lane == 0) L.scnt[wv] = 0;
+#endif
+    PF_STAMP(L);      // kernel start
+    const GvpW PF_AS1* gv = (const GvpW PF_AS1*)p.gvps;
+    CoopW<16, 0> Wh0;
+    if (p.n_gvps > 1) gvp_coop_load<16, 0, 4>(gv[0], lane, wv, Wh0);
+    float s1[64], V1[8];
+    load_row_f(p.h + (size_t)n * PF_S, hl, s1);
+    if (wv < 3) load_vec_rc(p.v + (size_t)n * 48, hl, wv, V1);
+    else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) V1[q] = 0.f;
+    }
+    head_chain_coop(p, Wh0, s1, V1, n, live, L, lane, wv);
 }
 
 __global__ __launch_bounds__(256, 1) void k_noise_head_coop(const HeadParams p) {
@@ -1718,6 +1752,11 @@ void pfk_edge_msg_coop(const EdgeParams* p, int layer0, hipStream_t s) {
     if (p->ntiles == 0) return;
     if (layer0) hipLaunchKernelGGL(k_edge_msg_coop<true>, dim3(p->ntiles), dim3(256), 0, s, *p);
     else hipLaunchKernelGGL(k_edge_msg_coop<false>, dim3(p->ntiles), dim3(256), 0, s, *p);
+}
+void pfk_node_head_coop(const NodeParams* p, const HeadParams* hp, int layer0, hipStream_t s) {
+    if (p->ntiles == 0) return;
+    if (layer0) hipLaunchKernelGGL(k_node_head_coop<true>, dim3(p->ntiles), dim3(256), 0, s, *p, *hp);
+    else hipLaunchKernelGGL(k_node_head_coop<false>, dim3(p->ntiles), dim3(256), 0, s, *p, *hp);
 }
 void pfk_node_update_coop(const NodeParams* p, int layer0, hipStream_t s) {
     if (p->ntiles == 0) return;

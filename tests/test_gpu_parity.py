@@ -234,6 +234,19 @@ def test_two_workgroups_per_cu_edge_kernel(name, dense, monkeypatch):
     close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
 
 
+@pytest.mark.parametrize("name", ["dynamics_c1.npz", "dynamics_radius.npz"])
+def test_separate_head_launch(name, monkeypatch):
+    """By default the last layer's node update and the noise head share one launch (k_node_head_coop); with
+    PFDYN_NO_FUSE_HEAD=1 the head runs as its own kernel -- same goldens."""
+    monkeypatch.setenv("PFDYN_NO_FUSE_HEAD", "1")
+    z, cfg = load(name), DYN_CASES[name]
+    batch = batch_from(z)
+    eng = engine_for(cfg, O.make_state_dict(cfg, int(z["wseed"])))
+    set_batch(eng, batch, z["prot_x"])
+    eps_h, eps_x = eng.dynamics(z["x_t"], z["h_t"], z["t"])
+    close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
+
+
 def _rand_inputs(batch, seed, pharm_nf=6, scale=3.0):
     gen = torch.Generator().manual_seed(seed)
     nf = int(batch.pharm_ptr[-1])
