@@ -109,6 +109,10 @@ EXTRA_CASES = {
     "large_radius": (O.DynamicsConfig(pf_k=0, message_norm=10), [41, 42], 150, [8, 7]),
     # single GVP per chain, three conv layers
     "shallow_chains": (O.DynamicsConfig(n_convs=3, n_message_gvps=1, n_update_gvps=1, n_noise_gvps=2), [51], 64, [6]),
+    # one conv layer (it is first and last at once); graphs with a single center (no ff edges at all)
+    "single_layer_single_center": (O.DynamicsConfig(n_convs=1), [61, 62, 63], 33, [1, 1, 2]),
+    # four conv layers (class default depth): two dense layers below the pruned one, sum aggregation
+    "deep": (O.DynamicsConfig(n_convs=4, n_noise_gvps=3, message_norm=1, pf_k=0), [71, 72], 48, [4, 5]),
 }
 
 
