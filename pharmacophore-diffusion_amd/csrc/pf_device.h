@@ -57,6 +57,34 @@ struct GvpW {              // packed weights of one GVP (device pointers)
     pf_gcf b_gate;         // [2 halves][8]          gate bias in R-layout
 };
 
+// ---- row-group ("rg") kernels: 4 rows per v_mfma_f32_4x4x1_16b_f32, weights streamed as "quads" (pf_rg.hip) ----
+// A GVP's weights are one contiguous stream of quads ([quad][64 lanes][4 floats] = 1 KiB, one b128 load per lane) in
+// the exact order the kernel consumes them; the GVPs of a chain follow each other, so the register prefetch ring
+// (16-32 quads deep) runs across GVP boundaries.  Quad schedule of one GVP (vi, nextra, nh = output halves of 64):
+//   [const] [xhat, w16 when vi == 17] [Vh x4] [main 32*nh] [rbf 4*nh when nextra] [Vu x4] [sh 4*nh] [gate x8] [pad]
+#define RG_GEN_NQ 96        // the generic GVP (16 vectors, 128 + 16 scalars in and out) is padded to this many quads
+#define RG_TAIL_PAD 48      // quads of read-ahead padding behind the last stream (>= the deepest prefetch ring)
+struct RgSched {
+    int q_c, q_xh, q_vh, q_main, q_rbf, q_vu, q_sh, q_gate, nq_raw, nq;
+};
+constexpr RgSched rg_sched(const int vi, const int nextra, const int nh) {
+    RgSched s{};
+    s.q_c = 0;
+    s.q_xh = 1;
+    s.q_vh = 1 + (vi == 17 ? 2 : 0);
+    s.q_main = s.q_vh + 4;
+    s.q_rbf = s.q_main + 32 * nh;
+    s.q_vu = s.q_rbf + (nextra ? 4 * nh : 0);
+    s.q_sh = s.q_vu + 4;
+    s.q_gate = s.q_sh + 4 * nh;
+    s.nq_raw = s.q_gate + 8;
+    // only the generic GVP repeats inside a chain: padded so that the ring phase does not change across repetitions
+    s.nq = (vi == 16 && nextra == 0 && nh == 2) ? RG_GEN_NQ : s.nq_raw;
+    return s;
+}
+#define PF_WARM_BLOCKS 256  // helper blocks per launch: 32 per XCD (workgroups are dealt round-robin over the 8 XCDs)
+#define RG_NQ_OUT 9        // to_scalar_output: [const] [8 gate-like quads]
+
 struct EdgeTile {          // one wave = 32 edge slots
     int e0;                // first edge slot
     int n;                 // slots in this tile (<= 32)
@@ -93,6 +121,8 @@ struct EdgeParams {
     // training forward (one-wave kernel only): per message-GVP level l and edge slot e, Z (pre-activation scalars),
     // the gate pre-activations and the gated output vectors go to sv_*[(l * sv_stride + e)]; NULL: inference
     float* sv_z; float* sv_g; float* sv_v; size_t sv_stride;
+    pf_gcf rg[4];          // row-group kernels: quad stream of each etype's message chain (this layer)
+    pf_gcf warm; int warm_bytes;   // weights of the NEXT launch, pulled into every XCD's L2 by helper blocks (or null)
 };
 
 struct NodeW {             // per node type
@@ -125,6 +155,10 @@ struct NodeParams {
     // (gvp.py:518,529); drop_thr == 0: inference
     uint32_t drop_thr; float drop_scale; uint32_t seed; int layer;
     const float* mask_override;   // tests: externally supplied multipliers [n_convs * 2][N * 144] instead of the hash
+    int grp;               // edge slots per message partial row group: 32 (tile kernels) or 4*RG (row-group edge kernel)
+    pf_gcf rg_upd[2];      // row-group kernels: quad stream of each node type's update chain (pharm of the last layer:
+                           // followed by the noise head's chain and to_scalar_output)
+    pf_gcf warm; int warm_bytes;   // weights of the NEXT launch, pulled into every XCD's L2 by helper blocks (or null)
 };
 
 struct HeadParams {
@@ -168,6 +202,7 @@ struct BuildParams {
     float* gnorm;          // [2][B]
     const int* pp_cnt;     // [B] static pp edges per graph
     int norm_mode;
+    pf_gcf warm; int warm_bytes;   // weights of the NEXT launch, pulled into every XCD's L2 by helper blocks (or null)
 };
 
 struct StepParams {

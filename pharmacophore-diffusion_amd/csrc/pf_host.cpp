@@ -25,6 +25,8 @@ void pfk_node_head_coop(const NodeParams* p, const HeadParams* hp, int layer0, h
 void pfk_noise_head_coop(const HeadParams* p, hipStream_t s);
 void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s);
 void pfk_noise_head(const HeadParams* p, hipStream_t s);
+void pfk_rg_edge(const EdgeParams* p, int layer0, int rg, hipStream_t s);
+void pfk_rg_node(const NodeParams* p, const HeadParams* hp, int layer0, int rg, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
 void pfk_encode_build_pre(const EncodeParams* e, const BuildParams* b, const PreParams* pp, hipStream_t s);
@@ -132,6 +134,22 @@ struct pf_handle {
     // two-workgroup kernel against 236 k / 456 k / 692 k with one wave per tile; batch 1024 prefers one wave per tile.
     int coop_edge_max = 256, coop_node_max = 1024;
     int coop2_edge_max = 12000, coop2_dense_max = 1024;
+    // row-group kernels (pf_rg.hip): quad streams of the message chains [layer][etype] and update chains [layer][ntype]
+    // (offsets into d_w); used while a layer's launches have at most rg_rows_max rows (edge slots of the tile list)
+    std::vector<size_t> rg_msg, rg_upd;
+    // bytes of a message chain / an update chain / the last pharm update chain + noise head + to_scalar_output
+    size_t rg_msg_bytes() const { return (size_t)(rg_sched(17, PF_R, 2).nq + (cfg.n_message_gvps - 1) * RG_GEN_NQ) * 1024; }
+    size_t rg_upd_bytes() const { return (size_t)cfg.n_update_gvps * RG_GEN_NQ * 1024; }
+    size_t rg_tail_bytes() const { return rg_upd_bytes() + (size_t)((cfg.n_noise_gvps - 1) * RG_GEN_NQ + rg_sched(16, 0, 1).nq + RG_NQ_OUT) * 1024; }
+    bool l2_warm = true;                    // PFDYN_NO_WARM=1: no helper workgroups
+    int warm_mask = 7;                      // PFDYN_WARM_MASK: 1 encode/build launch, 2 edge launches, 4 node launches
+    int rg_rows_max = 16384, rg2_rows_min = 4096;
+    // 0: tile kernels; 1 / 2: row-group kernels with 4 / 8 rows per wave
+    int rg_mode(int ntiles) const {
+        const long rows = (long)ntiles * 32;
+        if (rows > rg_rows_max) return 0;
+        return rows >= rg2_rows_min ? 2 : 1;
+    }
     bool fuse_head = true;                  // last conv layer's node update + noise head in one launch (PFDYN_NO_FUSE_HEAD=1: separate)
     void init_tuning() {
         if (const char* e = getenv("PFDYN_COOP2_EDGE_MAX")) coop2_edge_max = coop2_dense_max = atoi(e);
@@ -140,6 +158,10 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_NO_PRE")) use_pre = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_FUSE_HEAD")) fuse_head = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_PRUNE")) prune = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_NO_WARM")) l2_warm = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_WARM_MASK")) warm_mask = atoi(e);
+        if (const char* e = getenv("PFDYN_RG_ROWS_MAX")) rg_rows_max = atoi(e);
+        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = atoi(e);
     }
 
     // ---- gradient path (pf_train_*): flat parameter vector in state-dict order, GvpT tables, per-layer activations
@@ -373,6 +395,86 @@ static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
     return o;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Quad stream of one GVP for the row-group kernels (pf_rg.hip; schedule: rg_sched in pf_device.h).  A quad is
+// [64 lanes][4 images]; an image is what one lane holds of a B operand: lane f <-> output feature f (scalar Linear),
+// lane 16g + u <-> output channel u of coordinate group g (vector products, gates; g = 3 unused -> 0).
+// ------------------------------------------------------------------------------------------------
+static void pack_gvp_rg(pf_handle* h, const GvpSpec& g, std::vector<float>& out) {
+    const int S = h->cfg.n_hidden_scalars;
+    const int H = std::max(g.vi, g.vo);
+    const int nextra = g.si - S;
+    const int NH = g.so / 64;
+    const bool X17 = g.vi == 17;
+    const RgSched q = rg_sched(g.vi, nextra, NH);
+    const int Kin = H + g.si;
+    const std::vector<float>& W = h->raw[g.prefix + "to_feats_out.0.weight"].data;            // [so][si + H]
+    const std::vector<float>& Bv = h->raw[g.prefix + "to_feats_out.0.bias"].data;
+    const std::vector<float>& Wg = h->raw[g.prefix + "scalar_to_vector_gates.weight"].data;   // [vo][so]
+    const std::vector<float>& bg = h->raw[g.prefix + "scalar_to_vector_gates.bias"].data;
+    const std::vector<float>& wh = h->raw[g.prefix + "Wh"].data;                              // [vi][H]
+    const std::vector<float>& wu = h->raw[g.prefix + "Wu"].data;                              // [H][vo]
+    const size_t base = out.size();
+    out.resize(base + (size_t)q.nq * 256, 0.f);
+    auto at = [&](int quad, int lane, int j) -> float& { return out[base + ((size_t)quad * 64 + lane) * 4 + j]; };
+    const int v0 = X17 ? 1 : 0;                      // Wh row of node-vector channel 0 (row 0 is the unit x_diff)
+    for (int lane = 0; lane < 64; ++lane) {
+        const int gq = lane >> 4, u = lane & 15, qq = (lane >> 2) & 3;
+        // constants: scalar bias (two halves), gate bias, Wh[0][16] on the lanes that carry xhat
+        at(q.q_c, lane, 0) = lane < g.so ? Bv[lane] : 0.f;
+        at(q.q_c, lane, 1) = 64 + lane < g.so ? Bv[64 + lane] : 0.f;
+        at(q.q_c, lane, 2) = u < g.vo ? bg[u] : 0.f;
+        at(q.q_c, lane, 3) = (X17 && qq == 0 && gq < 3) ? wh[(size_t)0 * H + 16] : 0.f;
+        if (X17) {
+            at(q.q_xh, lane, 0) = gq < 3 ? wh[(size_t)0 * H + u] : 0.f;                              // xhat k-step of Vh
+            at(q.q_xh, lane, 1) = (gq < 3 && u < g.vo) ? wu[(size_t)16 * g.vo + u] : 0.f;           // Vh[16] k-step of Vu
+            at(q.q_xh, lane, 2) = lane < g.so ? W[(size_t)lane * Kin + g.si + 16] : 0.f;           // sh[16] column
+            at(q.q_xh, lane, 3) = 64 + lane < g.so ? W[(size_t)(64 + lane) * Kin + g.si + 16] : 0.f;
+            for (int t = 0; t < 4; ++t) at(q.q_xh + 1, lane, t) = gq < 3 ? wh[(size_t)(1 + 4 * t + qq) * H + 16] : 0.f;
+        }
+        for (int t = 0; t < 4; ++t)
+            for (int j = 0; j < 4; ++j) {
+                at(q.q_vh + t, lane, j) = gq < 3 ? wh[(size_t)(v0 + 4 * t + j) * H + u] : 0.f;
+                at(q.q_vu + t, lane, j) = (gq < 3 && u < g.vo) ? wu[(size_t)(4 * t + j) * g.vo + u] : 0.f;
+            }
+        for (int half = 0; half < NH; ++half) {
+            const int f = half * 64 + lane;
+            for (int m = 0; m < 8; ++m)
+                for (int aq = 0; aq < 4; ++aq)
+                    for (int j = 0; j < 4; ++j)
+                        at(q.q_main + (m * 4 + aq) * NH + half, lane, j) = W[(size_t)f * Kin + 8 * (4 * aq + j) + m];
+            for (int aq = 0; aq < 4; ++aq)
+                for (int j = 0; j < 4; ++j) {
+                    if (nextra) at(q.q_rbf + aq * NH + half, lane, j) = W[(size_t)f * Kin + S + 4 * aq + j];
+                    at(q.q_sh + aq * NH + half, lane, j) = W[(size_t)f * Kin + g.si + 4 * aq + j];
+                }
+        }
+        for (int m = 0; m < 8; ++m)
+            for (int j = 0; j < 4; ++j) {
+                const int feat = 8 * (4 * gq + j) + m;      // A block (g, j) holds features 8 (4g + j) .. + 7
+                at(q.q_gate + m, lane, j) = (u < g.vo && feat < g.so) ? Wg[(size_t)u * g.so + feat] : 0.f;
+            }
+    }
+}
+// to_scalar_output (Linear 64 -> pharm_nf) as a gate-like product: [const] [8 quads] [pad]
+static void pack_out_rg(pf_handle* h, std::vector<float>& out) {
+    const RawTensor& W = h->raw["dynamics.noise_predictor.noise_predictor.to_scalar_output.weight"];   // [pharm_nf][64]
+    const RawTensor& Bv = h->raw["dynamics.noise_predictor.noise_predictor.to_scalar_output.bias"];
+    const int nf = h->cfg.pharm_nf;
+    const size_t base = out.size();
+    out.resize(base + (size_t)RG_NQ_OUT * 256, 0.f);
+    auto at = [&](int quad, int lane, int j) -> float& { return out[base + ((size_t)quad * 64 + lane) * 4 + j]; };
+    for (int lane = 0; lane < 64; ++lane) {
+        const int gq = lane >> 4, u = lane & 15;
+        at(0, lane, 0) = u < nf ? Bv.data[u] : 0.f;
+        for (int m = 0; m < 8; ++m)
+            for (int j = 0; j < 4; ++j) {
+                const int feat = 8 * (4 * gq + j) + m;
+                at(1 + m, lane, j) = (u < nf && feat < 64) ? W.data[(size_t)u * 64 + feat] : 0.f;
+            }
+    }
+}
+
 static void free_ws(pf_handle* h) {
     if (h->d_ws) (void)hipFree(h->d_ws);
     h->d_ws = nullptr;
@@ -438,6 +540,14 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;    // the layer restricted to active atoms
     bp.act_ids = prune_layer >= 0 ? h->d_act_ids : nullptr; bp.reg_act = h->d_reg_act;
     bool pre_ready = false;
+    {   // the first edge launch's weights travel to L2 while this launch runs (row-group path only)
+        const bool last0 = c.n_convs == 1;
+        const int nt0 = last0 ? h->n_edge_tiles_last : (prune_layer == 0 ? h->n_edge_tiles_act : h->n_edge_tiles);
+        if (!train && h->l2_warm && (h->warm_mask & 1) && h->rg_mode(nt0)) {
+            bp.warm = h->d_w + h->rg_msg[0];
+            bp.warm_bytes = (int)((last0 ? 2 : 4) * h->rg_msg_bytes());
+        }
+    }
     if (h->prof_mask & 3u) {     // timing the two halves separately needs separate launches
         { ProfScope ps(h, pf_handle::K_ENCODE, s); pfk_encode(&ep, s); }
         { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); }
@@ -472,7 +582,14 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             e.sv_z = h->t_sv_z[l]; e.sv_g = h->t_sv_g[l]; e.sv_v = h->t_sv_v[l];
             e.sv_stride = (size_t)std::max<int64_t>(h->Ecap, 1);
         }
-        if (e.ntiles <= h->coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
+        for (int et = 0; et < 4; ++et) e.rg[et] = h->d_w + h->rg_msg[(size_t)l * 4 + et];
+        const int rg = train ? 0 : h->rg_mode(e.ntiles);     // the node launch of this layer follows (partial-row grouping)
+        if (rg && h->l2_warm && (h->warm_mask & 2)) {         // this launch's helpers fetch the node launch's weights
+            e.warm = h->d_w + h->rg_upd[(size_t)l * 2 + (last ? 1 : 0)];
+            e.warm_bytes = (int)(last ? h->rg_tail_bytes() : 2 * h->rg_upd_bytes());
+        }
+        if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, l == 0, rg, s); }
+        else if (e.ntiles <= h->coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
         else if (e.ntiles <= ((last || pruned) ? h->coop2_edge_max : h->coop2_dense_max) && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop2(&e, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
 
@@ -494,7 +611,26 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             n.w[nt].upd = h->d_gvp + h->upd_base(l, nt);
         }
         n.n_upd = c.n_update_gvps;
-        if (last && !train && h->fuse_head && n.ntiles <= h->coop_node_max && h->n_head_tiles == n.ntiles) {
+        n.grp = rg ? 4 * rg : 32;
+        for (int nt = 0; nt < 2; ++nt) n.rg_upd[nt] = h->d_w + h->rg_upd[(size_t)l * 2 + nt];
+        if (rg && h->l2_warm && (h->warm_mask & 4) && !last) { // ... and the node launch's helpers the next edge launch's
+            const bool nlast = l + 1 == c.n_convs - 1;
+            n.warm = h->d_w + h->rg_msg[(size_t)(l + 1) * 4];
+            n.warm_bytes = (int)((nlast ? 2 : 4) * h->rg_msg_bytes());
+        }
+        if (rg) {
+            const int rgn = std::max(1, h->rg_mode(n.ntiles));
+            if (last && h->fuse_head && h->n_head_tiles == n.ntiles) {
+                HeadParams hp{};
+                hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
+                hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
+                hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
+                hp.eps_h = eps_h; hp.eps_x = eps_x;
+                { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node(&n, &hp, l == 0, rgn, s); }
+                head_done = true;
+            } else { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_rg_node(&n, nullptr, l == 0, rgn, s); }
+        }
+        else if (last && !train && h->fuse_head && n.ntiles <= h->coop_node_max && h->n_head_tiles == n.ntiles) {
             // last layer (pharm tiles only) + noise head in one launch: the layer output stays in registers
             HeadParams hp{};
             hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
@@ -674,6 +810,30 @@ int pf_commit_weights(pf_handle* h) {
                 }
             h->out_a = push(h->h_w, a);
             h->out_b = push(h->h_w, h->raw["dynamics.noise_predictor.noise_predictor.to_scalar_output.bias"].data);
+        }
+        {   // row-group quad streams, one contiguous stream per chain.  The pharm update chain of the last conv layer
+            // comes last and is followed by the noise head's chain and to_scalar_output: the fused node + head kernel
+            // streams straight through.  RG_TAIL_PAD quads of padding: the prefetch ring reads ahead of the last quad used.
+            h->rg_msg.assign((size_t)c.n_convs * 4, 0);
+            h->rg_upd.assign((size_t)c.n_convs * 2, 0);
+            std::vector<float> st;
+            auto flush = [&]() { const size_t off = push(h->h_w, st); st.clear(); return off; };
+            for (int l = 0; l < c.n_convs; ++l)
+                for (int et = 0; et < 4; ++et) {
+                    for (int j = 0; j < c.n_message_gvps; ++j) pack_gvp_rg(h, msg_spec(c, l, et, j), st);
+                    h->rg_msg[(size_t)l * 4 + et] = flush();
+                }
+            for (int l = 0; l < c.n_convs; ++l)
+                for (int nt = 0; nt < 2; ++nt) {
+                    if (l == c.n_convs - 1 && nt == 1) continue;
+                    for (int j = 0; j < c.n_update_gvps; ++j) pack_gvp_rg(h, upd_spec(c, l, nt, j), st);
+                    h->rg_upd[(size_t)l * 2 + nt] = flush();
+                }
+            for (int j = 0; j < c.n_update_gvps; ++j) pack_gvp_rg(h, upd_spec(c, c.n_convs - 1, 1, j), st);
+            for (int k = 0; k < c.n_noise_gvps; ++k) pack_gvp_rg(h, head_spec(c, k), st);
+            pack_out_rg(h, st);
+            st.resize(st.size() + (size_t)RG_TAIL_PAD * 256, 0.f);
+            h->rg_upd[(size_t)(c.n_convs - 1) * 2 + 1] = flush();
         }
         while (h->h_w.size() % 64) h->h_w.push_back(0.f);
     };
@@ -1133,7 +1293,10 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     e.w = h->d_gvp + h->msg_base(layer, 0); e.n_gvps = c.n_message_gvps;
     linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
     e.rbf_inv_sigma = 1.0f / (c.rbf_dmax / (float)c.rbf_dim);
-    if (e.ntiles <= h->coop_edge_max) pfk_edge_msg_coop(&e, 0, s); else pfk_edge_msg(&e, 0, s);     // same choice as run_dynamics
+    for (int et = 0; et < 4; ++et) e.rg[et] = h->d_w + h->rg_msg[(size_t)layer * 4 + et];
+    const int rg = h->rg_mode(e.ntiles);                  // same choice as run_dynamics
+    if (rg) pfk_rg_edge(&e, 0, rg, s);
+    else if (e.ntiles <= h->coop_edge_max) pfk_edge_msg_coop(&e, 0, s); else pfk_edge_msg(&e, 0, s);
     NodeParams n{};
     n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles; n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
     n.pp_slot = 1; n.row_ids = h->d_act_ids; n.dyn_cnt = h->d_dyn_cnt;
@@ -1145,7 +1308,10 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
         n.w[nt].upd = h->d_gvp + h->upd_base(layer, nt);
     }
     n.n_upd = c.n_update_gvps;
-    if (n.ntiles <= h->coop_node_max) pfk_node_update_coop(&n, 0, s); else pfk_node_update(&n, 0, s);
+    n.grp = rg ? 4 * rg : 32;
+    for (int nt = 0; nt < 2; ++nt) n.rg_upd[nt] = h->d_w + h->rg_upd[(size_t)layer * 2 + nt];
+    if (rg) pfk_rg_node(&n, nullptr, 0, std::max(1, h->rg_mode(n.ntiles)), s);
+    else if (n.ntiles <= h->coop_node_max) pfk_node_update_coop(&n, 0, s); else pfk_node_update(&n, 0, s);
     pfk_copy(h->d_h[1], ohp, Np * PF_S, s);
     pfk_copy(h->d_h[1] + Np * PF_S, ohf, Nf * PF_S, s);
     pfk_copy(h->d_v[1], ovp, Np * 48, s);

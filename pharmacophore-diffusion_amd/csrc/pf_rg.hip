@@ -1,0 +1,727 @@
+// pf_rg.hip -- "row-group" kernels of the denoising path for launches with few rows (gfx950 only).
+//
+// Same mathematics as pf_kernels.hip (GVP.forward gvp.py:89-116, GVPMultiEdgeConv gvp.py:459-551, GVPLayerNorm
+// gvp.py:159-166, NoisePredictionBlock dynamics_gvp.py:37-42), different mapping onto the matrix cores: at the
+// headline batch (32 graphs) a launch has a few hundred to a few thousand rows, and a 32-row MFMA tile per CU leaves
+// most of the chip idle while every tile pays the latency of a whole GVP chain.  Here a wave owns RG groups of FOUR
+// rows and all 128 output features, on v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4x4, exact fp32, 64 FLOP/clk/SIMD like
+// the big shapes, 8 cycles per instruction):
+//
+//   D_b[i][j] += A_sel[i] * B_b[j]        b = 0..15 blocks, i = row, lane 4b+j = output feature
+//
+//   * weights are the B operand, one VGPR image per k-step and half of 64 outputs: lane f holds W[f][k];
+//   * activations are the A operand; the CBSZ/ABID broadcast controls pick which 4-lane block of the A register feeds
+//     all (cbsz=4) or each group of four (cbsz=2) blocks, so ONE register holds 16 k-steps:
+//       "SA layout": lane 4a+i holds features 8a..8a+7 of row i in 8 registers   (k-step (m, a) <-> feature 8a+m)
+//       "VA layout": lane 16g+4q+i holds V[row i][channel 4t+q][coordinate g], t = 0..3 (4 registers; g = 3 unused)
+//   * results come out with the feature on the lane ("SD" / "VD": register i = row i, lane f / lane 16g+u), and go
+//     back to the A layouts through a few hundred bytes of wave-private LDS (no barriers: one wave, in-order DS);
+//   * the scalar->vector gates and to_scalar_output split K over the four lane groups (cbsz=2) and are summed with
+//     v_permlane32_swap / v_permlane16_swap.
+//
+// A wave therefore needs no partner: no workgroup barriers, 4-row granularity (ragged regions waste at most 3 rows),
+// and a GVP level costs ~350 MFMAs x 8 cycles per group.  All weights of a chain are one contiguous stream of 1-KiB
+// "quads" in consumption order (pf_host.cpp: pack_gvp_rg), prefetched 16-32 quads ahead into registers across GVP
+// boundaries.  Per row the weight traffic is 8x that of a 32-row tile, so pf_host.cpp uses these kernels only while the
+// launch is small enough for L2 to feed them (rg_rows_max).
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "pf_device.h"
+#include "pf_warm.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrtf_(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float rsqf_(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * rcpf_(1.0f + __expf(-x)); }
+
+// all 16 blocks read their A rows from block ABID (cbsz = 4) / each group of 4 blocks from its block ABID (cbsz = 2)
+template <int ABID>
+__device__ __forceinline__ f32x4 mfma_b4(const float a, const float b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0);
+}
+template <int ABID>
+__device__ __forceinline__ f32x4 mfma_b2(const float a, const float b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 2, ABID, 0);
+}
+
+// x[l] + x[l ^ 32], x[l] + x[l ^ 16]: the swap instructions exchange register halves / odd-even rows of two
+// registers (the compiler's builtin mis-assigns the second result in ROCm 7.2, hence the asm; the s_nop covers the
+// VALU-write -> permlane-swap-read hazard the assembler cannot see)
+__device__ __forceinline__ float xsum32(const float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float xsum16(const float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+// sum over the four lane groups g (lanes l, l^16, l^32, l^48)
+__device__ __forceinline__ float gsum(const float v) { return xsum16(xsum32(v)); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(const float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over q (lanes l, l^4, l^8, l^12 of a 16-lane row): row_ror 4 and 8
+__device__ __forceinline__ float qsum(float v) {
+    v += dpp_f<0x124>(v);
+    v += dpp_f<0x128>(v);
+    return v;
+}
+// sum over all 16 blocks a (every lane with the same row i)
+__device__ __forceinline__ float asum(const float v) { return gsum(qsum(v)); }
+
+// In-kernel cycle stamps (diagnostic builds only: -DPF_STAMPS; no stamp executes in the product build): lane 0 of the
+// first 64 waves writes s_memtime at the phase boundaries of the chain (tools/stamps_rg.py)
+#ifdef PF_STAMPS
+__device__ unsigned long long* g_rg_stamps = nullptr;
+struct RgStamp {
+    int k = 0;
+    __device__ __forceinline__ void operator()(const int lane) {
+        if (lane == 0 && g_rg_stamps && blockIdx.x < 64 && k < 64) g_rg_stamps[blockIdx.x * 64 + k] = __builtin_amdgcn_s_memtime();
+        ++k;
+    }
+};
+static int g_rg_stamp_which = -1, g_rg_stamp_seen = 0;      // host: which rg launch since the selector was set stamps
+static unsigned long long* g_rg_stamp_host_buf = nullptr;
+static void rg_stamp_arm(hipStream_t s) {
+    unsigned long long* on = (g_rg_stamp_seen++ == g_rg_stamp_which) ? g_rg_stamp_host_buf : nullptr;
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rg_stamps), &on, sizeof(on), 0, hipMemcpyHostToDevice, s);
+}
+#else
+struct RgStamp {
+    __device__ __forceinline__ void operator()(const int) {}
+};
+#endif
+
+// wave-private LDS scratch of one row group
+#define RG_T1_STRIDE 132                      // SD -> SA transposition: [4 rows][128 (+4 pad)]
+#define RG_TV_STRIDE 52                       // VD -> VA transposition: [4 rows][3 coordinates][16] + 3 (channel 16) + pad
+struct __attribute__((aligned(16))) RgLds {
+    float t1[4 * RG_T1_STRIDE];
+    float tv[4 * RG_TV_STRIDE];
+};
+__device__ __forceinline__ int pperm(const int u) { return (u & 3) * 4 + (u >> 2); }
+
+// register prefetch ring over the quad stream
+// (D quads deep; the slot of quad qi of a GVP is (PHASE + qi) % D with PHASE = quads consumed before it, mod D: the
+// generic GVP -- the only one that repeats inside a chain -- has a multiple of every D used, so PHASE is static)
+template <int D>
+struct RgRing {
+    f32x4 q[D];
+    const f32x4 PF_AS1* p;                    // quad 0 of the current GVP, + lane
+};
+template <int D>
+__device__ __forceinline__ void ring_start(RgRing<D>& r, pf_gcf stream, const int lane) {
+    r.p = reinterpret_cast<const f32x4 PF_AS1*>(stream) + lane;
+    static_for<0, D>([&](auto I) { r.q[decltype(I)::value] = r.p[decltype(I)::value * 64]; });
+}
+#ifndef RG_D1
+#define RG_D1 24                              // ring depth at 4 rows per wave (one quad per 4 MFMAs)
+#endif
+#ifndef RG_D2
+#define RG_D2 16                              // ... at 8 rows per wave (one quad per 8 MFMAs)
+#endif
+template <int RG> struct RgDepth { static constexpr int D = RG == 1 ? RG_D1 : RG_D2; };
+
+template <int VI_, int NEXTRA_, int NH_, int VO_, bool SIG_>
+struct RgSpec {
+    static constexpr int VI = VI_, NEXTRA = NEXTRA_, NH = NH_, VO = VO_;
+    static constexpr bool SIG = SIG_, H17 = VI_ == 17;
+    static constexpr RgSched S = rg_sched(VI_, NEXTRA_, NH_);
+};
+
+// ---------------------------------------------------------------------------------------------
+// One GVP on RG groups of four rows.
+//   X  [RG][8]  in: scalar input, SA layout          out: SiLU output, SA layout (next GVP's input)
+//   Va [RG][4]  in: vector input, VA layout          out: gated vector output, VA layout (when NEEDVA)
+//   R, XH       first message GVP only: rbf image (lane 4a+i: rbf_a(d_i)) and unit x_diff (lane 16g+i: xhat_i[g])
+//   slo, shi    SiLU output, SD layout (register i: row i; lane f: feature f / 64+f)
+//   Vd          gated vector output, VD layout (lane 16g+u: channel u, coordinate g)
+//   VZERO       the 16 node-vector channels are identically zero (conv layer 0): only xhat feeds Vh
+// ---------------------------------------------------------------------------------------------
+template <class S, int RG, int D, int PHASE, bool VZERO, bool NEEDVA>
+__device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float (&Va)[RG][4], const float (&R)[RG],
+                                       const float (&XH)[RG], f32x4 (&slo)[RG], f32x4 (&shi)[RG], f32x4 (&Vd)[RG],
+                                       RgLds* lds, const int lane, RgStamp& stamp) {
+    constexpr int NH = S::NH;
+    stamp(lane);                                      // 0: GVP start
+    const int a = lane >> 2, i = lane & 3, g = lane >> 4, q = a & 3, u = lane & 15;
+    const int gg = g < 3 ? g : 2;
+    // with one row group per wave every accumulator is split in two (even / odd image of a quad): back-to-back MFMAs on
+    // one accumulator issue every ~13 cycles instead of 8
+    constexpr int NA = RG == 1 ? 2 : 1;
+    f32x4 lo[RG * NA], hi[RG * NA], vh[RG * NA], vu[RG * NA], gd[RG * NA];
+#pragma unroll
+    for (int r = 0; r < RG * NA; ++r) {
+        lo[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        hi[r] = lo[r]; vh[r] = lo[r]; vu[r] = lo[r]; gd[r] = lo[r];
+    }
+    // index of the accumulator of row group r for image j of a quad; fold() adds the halves together
+    auto acc = [](const int r, const int j) { return RG == 1 ? (j & 1) : r; };
+    auto fold = [&](f32x4 (&x)[RG * NA]) {
+        if constexpr (RG == 1) { x[0] += x[1]; x[1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    };
+    f32x4 cq = {0.f, 0.f, 0.f, 0.f}, xhq = cq, w16 = cq;
+    f32x4 VhA[RG];
+    float SH[RG], SH16[RG], Vh16[RG];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) { VhA[r] = cq; SH[r] = 0.f; SH16[r] = 0.f; Vh16[r] = 0.f; }
+
+    static_for<0, S::S.nq>([&](auto QI) {
+        constexpr int qi = decltype(QI)::value;
+        constexpr RgSched Q = S::S;
+        const f32x4 w = ring.q[(PHASE + qi) % D];
+        ring.q[(PHASE + qi) % D] = ring.p[(qi + D) * 64];
+        if constexpr (qi == Q.q_c) {
+            cq = w;                                   // [bias lo, bias hi, gate bias, Wh[0][16] on the xhat lanes]
+        } else if constexpr (S::H17 && qi == Q.q_xh) {
+            xhq = w;                                  // [Wh[0][:] image, Wu[16][:] image, sh16 column lo, hi]
+#pragma unroll
+            for (int r = 0; r < RG; ++r) vh[r] = mfma_b2<0>(XH[r], w[0], vh[r]);
+        } else if constexpr (S::H17 && qi == Q.q_xh + 1) {
+            w16 = w;                                  // Wh[1 + 4t + q][16], t = 0..3
+        } else if constexpr (qi >= Q.q_vh && qi < Q.q_vh + 4) {
+            constexpr int t = qi - Q.q_vh;
+            if constexpr (!VZERO) {
+                static_for<0, 4>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+#pragma unroll
+                    for (int r = 0; r < RG; ++r) vh[acc(r, j)] = mfma_b2<j>(Va[r][t], w[j], vh[acc(r, j)]);
+                });
+            }
+            if constexpr (t == 3) {                   // Vh complete: hidden channel 16 on the VALU, publish Vh
+                stamp(lane);                          // 1: Vh issued
+                fold(vh);
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    if constexpr (S::H17) {
+                        float p = XH[r] * cq[3];
+                        if constexpr (!VZERO) {
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) p = fmaf(Va[r][tt], w16[tt], p);
+                        }
+                        Vh16[r] = qsum(p);
+                    }
+                    float* tv = lds[r].tv;
+                    if (lane < 48) {
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) tv[ii * RG_TV_STRIDE + g * 16 + pperm(u)] = vh[r][ii];
+                    }
+                    if constexpr (S::H17) {
+                        if (q == 0 && g < 3) tv[i * RG_TV_STRIDE + 48 + g] = Vh16[r];
+                    }
+                }
+            }
+        } else if constexpr (qi >= Q.q_main && qi < Q.q_main + 32 * NH) {
+            constexpr int k = qi - Q.q_main, half = k % NH, mq = k / NH, m = mq / 4, aq = mq % 4;
+            static_for<0, 4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    if constexpr (half == 0) lo[acc(r, j)] = mfma_b4<4 * aq + j>(X[r][m], w[j], lo[acc(r, j)]);
+                    else hi[acc(r, j)] = mfma_b4<4 * aq + j>(X[r][m], w[j], hi[acc(r, j)]);
+                }
+            });
+            if constexpr (k == 8 * NH) {              // Vh is back from LDS: A images of the Vu product, sh = |Vh|
+                stamp(lane);                          // 2: first quarter of the main k-steps issued
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const float* tv = lds[r].tv;
+                    VhA[r] = *reinterpret_cast<const f32x4*>(&tv[i * RG_TV_STRIDE + gg * 16 + 4 * q]);
+                    const float x = tv[i * RG_TV_STRIDE + pperm(a)], y = tv[i * RG_TV_STRIDE + 16 + pperm(a)],
+                                z = tv[i * RG_TV_STRIDE + 32 + pperm(a)];
+                    SH[r] = sqrtf_(fmaxf(x * x + y * y + z * z, 1e-8f));
+                    if constexpr (S::H17) {
+                        const float x6 = tv[i * RG_TV_STRIDE + 48], y6 = tv[i * RG_TV_STRIDE + 49], z6 = tv[i * RG_TV_STRIDE + 50];
+                        SH16[r] = sqrtf_(fmaxf(x6 * x6 + y6 * y6 + z6 * z6, 1e-8f));
+                    }
+                }
+            }
+        } else if constexpr (S::NEXTRA > 0 && qi >= Q.q_rbf && qi < Q.q_rbf + 4 * NH) {
+            constexpr int k = qi - Q.q_rbf, half = k % NH, aq = k / NH;
+            static_for<0, 4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    if constexpr (half == 0) lo[acc(r, j)] = mfma_b4<4 * aq + j>(R[r], w[j], lo[acc(r, j)]);
+                    else hi[acc(r, j)] = mfma_b4<4 * aq + j>(R[r], w[j], hi[acc(r, j)]);
+                }
+            });
+        } else if constexpr (qi >= Q.q_vu && qi < Q.q_vu + 4) {
+            constexpr int t = qi - Q.q_vu;
+            if constexpr (t == 0) stamp(lane);        // 3: main (+ rbf) k-steps issued
+            static_for<0, 4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+#pragma unroll
+                for (int r = 0; r < RG; ++r) vu[acc(r, j)] = mfma_b2<j>(VhA[r][t], w[j], vu[acc(r, j)]);
+            });
+            if constexpr (t == 3) {
+                fold(vu);
+                if constexpr (S::H17) {
+#pragma unroll
+                    for (int r = 0; r < RG; ++r) vu[r] = mfma_b2<0>(Vh16[r], xhq[1], vu[r]);
+                }
+            }
+        } else if constexpr (qi >= Q.q_sh && qi < Q.q_sh + 4 * NH) {
+            constexpr int k = qi - Q.q_sh, half = k % NH, aq = k / NH;
+            static_for<0, 4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    if constexpr (half == 0) lo[acc(r, j)] = mfma_b4<4 * aq + j>(SH[r], w[j], lo[acc(r, j)]);
+                    else hi[acc(r, j)] = mfma_b4<4 * aq + j>(SH[r], w[j], hi[acc(r, j)]);
+                }
+            });
+            if constexpr (k == 4 * NH - 1) {          // scalar Linear complete: bias, SiLU, SD -> SA through LDS
+                stamp(lane);                          // 4: Vu + sh k-steps issued
+                fold(lo);
+                fold(hi);
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    if constexpr (S::H17) {
+                        lo[r] = mfma_b4<0>(SH16[r], xhq[2], lo[r]);
+                        if constexpr (NH == 2) hi[r] = mfma_b4<0>(SH16[r], xhq[3], hi[r]);
+                    }
+                    float* t1 = lds[r].t1;
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        slo[r][ii] = siluf_(lo[r][ii] + cq[0]);
+                        t1[ii * RG_T1_STRIDE + lane] = slo[r][ii];
+                        if constexpr (NH == 2) {
+                            shi[r][ii] = siluf_(hi[r][ii] + cq[1]);
+                            t1[ii * RG_T1_STRIDE + 64 + lane] = shi[r][ii];
+                        } else shi[r][ii] = 0.f;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const float* t1 = lds[r].t1;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(&t1[i * RG_T1_STRIDE + 8 * a]);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(&t1[i * RG_T1_STRIDE + 8 * a + 4]);
+                    const bool on = NH == 2 || a < 8;  // 64 outputs: features live in blocks 0..7 only
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { X[r][m] = on ? x0[m] : 0.f; X[r][4 + m] = on ? x1[m] : 0.f; }
+                }
+                stamp(lane);                          // 5: SiLU output back in the SA layout
+            }
+        } else if constexpr (qi >= Q.q_gate && qi < Q.q_gate + 8) {
+            constexpr int m = qi - Q.q_gate;
+            static_for<0, 4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+#pragma unroll
+                for (int r = 0; r < RG; ++r) gd[acc(r, j)] = mfma_b2<j>(X[r][m], w[j], gd[acc(r, j)]);
+            });
+            if constexpr (m == 7) {                   // gates: sum the K quarters, activation, gate the vectors
+                stamp(lane);                          // 6: gate k-steps issued
+                fold(gd);
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        float gv = gsum(gd[r][ii]) + cq[2];
+                        if constexpr (S::SIG) gv = sigmoidf_(gv);
+                        Vd[r][ii] = gv * vu[r][ii];
+                    }
+                    if constexpr (NEEDVA) {
+                        float* tv = lds[r].tv;
+                        if (lane < 48) {
+#pragma unroll
+                            for (int ii = 0; ii < 4; ++ii) tv[ii * RG_TV_STRIDE + g * 16 + pperm(u)] = Vd[r][ii];
+                        }
+                    }
+                }
+                if constexpr (NEEDVA) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int r = 0; r < RG; ++r) {
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(&lds[r].tv[i * RG_TV_STRIDE + gg * 16 + 4 * q]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) Va[r][t] = g < 3 ? v4[t] : 0.f;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    ring.p += S::S.nq * 64;
+    stamp(lane);                                      // 7: GVP done
+}
+
+typedef RgSpec<17, PF_R, 2, 16, true> SpecMsg0;     // first message GVP: [h_src, rbf] / [xhat, v_src]
+typedef RgSpec<16, 0, 2, 16, true> SpecGen;         // 128 + 16 -> 128 + 16
+typedef RgSpec<16, 0, 1, 1, false> SpecHeadLast;    // last noise-head GVP: 64 scalars, 1 vector, identity gate
+
+// GVPLayerNorm (gvp.py:159-166) on the SA / VA layouts: lane 4a+i holds 8 of the 128 scalars of row i, the row's
+// statistics are a sum over the 16 blocks; vector norms need the three coordinates of a channel (lane groups g)
+template <int RG>
+__device__ __forceinline__ void rg_layernorm(pf_gcf lw, pf_gcf lb, float (&X)[RG][8], float (&Va)[RG][4], const int lane) {
+    const int a = lane >> 2, g = lane >> 4;
+    const f32x4 w0 = reinterpret_cast<const f32x4 PF_AS1*>(lw)[2 * a], w1 = reinterpret_cast<const f32x4 PF_AS1*>(lw)[2 * a + 1];
+    const f32x4 b0 = reinterpret_cast<const f32x4 PF_AS1*>(lb)[2 * a], b1 = reinterpret_cast<const f32x4 PF_AS1*>(lb)[2 * a + 1];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) sum += X[r][m];
+        const float mean = asum(sum) * (1.0f / 128.0f);
+        float var = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { const float c = X[r][m] - mean; var = fmaf(c, c, var); }
+        const float rstd = rsqf_(asum(var) * (1.0f / 128.0f) + 1e-5f);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            X[r][m] = (X[r][m] - mean) * rstd * w0[m] + b0[m];
+            X[r][4 + m] = (X[r][4 + m] - mean) * rstd * w1[m] + b1[m];
+        }
+        float vn = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vn += fmaxf(gsum(Va[r][t] * Va[r][t]), 1e-8f);
+        vn = qsum(vn);
+        const float rden = rcpf_(sqrtf_(vn * (1.0f / 16.0f) + 1e-5f) + 1e-5f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Va[r][t] = g < 3 ? Va[r][t] * rden : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Edge messages (gvp.py:472-485, 540-551): a wave = 4*RG consecutive edge slots of one tile of the list.  Slots are
+// sorted by destination, so the rows of one destination are consecutive: the wave adds them up in slot order (the
+// destination ids are wave-uniform, the test is scalar) and stores one partial row per (wave, destination) run at the
+// run's last slot -- what the node kernels read (NodeParams::grp = 4*RG).
+// ---------------------------------------------------------------------------------------------
+template <bool L0, int RG>
+__global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p) {
+    constexpr int D = RgDepth<RG>::D, PH1 = SpecMsg0::S.nq % D;      // ring phase after the first message GVP
+    __shared__ RgLds lds[RG];
+    constexpr int G = 4 * RG, PER = 32 / G;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= p.ntiles * PER) {           // helper workgroup
+        l2_warm(p.warm, p.warm_bytes, (blockIdx.x - p.ntiles * PER) >> 3, PF_WARM_BLOCKS / 8, lane);
+        return;
+    }
+    const EdgeTile t = p.tiles[blockIdx.x / PER];
+    int nvalid = t.n;
+    if (t.cnt_idx >= 0) nvalid = min(nvalid, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
+    const int base = (blockIdx.x % PER) * G;
+    const int nv = __builtin_amdgcn_readfirstlane(min(G, nvalid - base));
+    if (nv <= 0) return;                               // wave-uniform
+    const int et = __builtin_amdgcn_readfirstlane(t.et);
+    RgStamp stamp;
+    stamp(lane);                                       // kernel start
+    RgRing<D> ring;
+    ring_start(ring, p.rg[et], lane);                  // in flight under the gather
+    const int a = lane >> 2, i = lane & 3, g = lane >> 4, q = a & 3, u = lane & 15;
+    const int e0 = t.e0 + base;
+    float X[RG][8], Va[RG][4], R[RG], XH[RG];
+    int dstv[RG];
+    const float mu_step = (p.rbf_mu[PF_R - 1] - p.rbf_mu[0]) * (1.0f / (float)(PF_R - 1));
+    const float mu_a = fmaf((float)a, mu_step, p.rbf_mu[0]);
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        const int e = e0 + min(4 * r + i, nv - 1);
+        const int src = p.esrc[e], dst = p.edst[e];
+        dstv[r] = dst;
+        const float4 xs = p.xn[src], xd = p.xn[dst];
+        const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
+        const float d = sqrtf_(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+        const float ze = (d - mu_a) * p.rbf_inv_sigma;
+        R[r] = __expf(-(ze * ze));
+        XH[r] = (g == 0 ? dx : (g == 1 ? dy : (g == 2 ? dz : 0.f))) * rcpf_(d);
+        const f32x4 PF_AS1* hp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.h + (size_t)src * PF_S) + 2 * a;
+        const f32x4 x0 = hp[0], x1 = hp[1];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { X[r][m] = x0[m]; X[r][4 + m] = x1[m]; }
+        if constexpr (!L0) {
+            pf_gcf vp = (pf_gcf)p.v + (size_t)src * 48 + (g < 3 ? g : 0) + 3 * q;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) { const float x = vp[12 * tt]; Va[r][tt] = g < 3 ? x : 0.f; }
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) Va[r][tt] = 0.f;
+        }
+    }
+    f32x4 slo[RG], shi[RG], Vd[RG];
+    if (p.n_gvps == 1) rg_gvp<SpecMsg0, RG, D, 0, L0, false>(ring, X, Va, R, XH, slo, shi, Vd, lds, lane, stamp);
+    else {
+        rg_gvp<SpecMsg0, RG, D, 0, L0, true>(ring, X, Va, R, XH, slo, shi, Vd, lds, lane, stamp);
+        for (int gi = 1; gi + 1 < p.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, PH1, false, true>(ring, X, Va, R, XH, slo, shi, Vd, lds, lane, stamp);
+        rg_gvp<SpecGen, RG, D, PH1, false, false>(ring, X, Va, R, XH, slo, shi, Vd, lds, lane, stamp);
+    }
+    // in-wave segmented sum in slot order; one partial row per (wave, destination) run
+    float al = 0.f, ah = 0.f, av = 0.f;
+    int prev = -1;
+    auto put = [&](const int slot) {
+        p.msg_s[(size_t)slot * PF_S + lane] = al;
+        p.msg_s[(size_t)slot * PF_S + 64 + lane] = ah;
+        if (lane < 48) p.msg_v[(size_t)slot * 48 + 3 * u + g] = av;
+    };
+    static_for<0, G>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        if (k < nv) {
+            const int dk = __builtin_amdgcn_readlane(dstv[k / 4], k % 4);
+            if (k > 0 && dk == prev) {
+                al += slo[k / 4][k % 4]; ah += shi[k / 4][k % 4]; av += Vd[k / 4][k % 4];
+            } else {
+                if (k > 0) put(e0 + k - 1);
+                al = slo[k / 4][k % 4]; ah = shi[k / 4][k % 4]; av = Vd[k / 4][k % 4];
+            }
+            prev = dk;
+        }
+    });
+    put(e0 + nv - 1);
+    stamp(lane);                                       // stores issued
+}
+
+// ---------------------------------------------------------------------------------------------
+// Node update (gvp.py:488-536): aggregate the message partial rows (mean per etype or sum, then the norm), residual,
+// GVPLayerNorm, update chain, residual, GVPLayerNorm.  A wave = 4*RG nodes of one tile.  HEAD: last conv layer of
+// the inference path (pharm tiles): the noise head (dynamics_gvp.py:37-42) runs on the registers right away.
+// ---------------------------------------------------------------------------------------------
+template <bool L0, int RG, bool HEAD>
+__global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadParams hp) {
+    constexpr int D = RgDepth<RG>::D, PHO = SpecHeadLast::S.nq % D;  // ring phase after the last head GVP
+    static_assert(SpecGen::S.nq % D == 0, "the generic GVP must keep the ring phase");
+    __shared__ RgLds lds[RG];
+    constexpr int G = 4 * RG, PER = 32 / G;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= p.ntiles * PER) {           // helper workgroup
+        l2_warm(p.warm, p.warm_bytes, (blockIdx.x - p.ntiles * PER) >> 3, PF_WARM_BLOCKS / 8, lane);
+        return;
+    }
+    const NodeTile t = p.tiles[blockIdx.x / PER];
+    int tn = t.n;
+    if (t.cnt_idx >= 0) tn = min(tn, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
+    const int base = (blockIdx.x % PER) * G;
+    const int nv = __builtin_amdgcn_readfirstlane(min(G, tn - base));
+    if (nv <= 0) return;                               // wave-uniform
+    const int nt = __builtin_amdgcn_readfirstlane(t.ntype);
+    RgStamp stamp;
+    stamp(lane);                                       // kernel start
+    RgRing<D> ring;
+    ring_start(ring, p.rg_upd[nt], lane);
+    const int a = lane >> 2, i = lane & 3, g = lane >> 4, q = a & 3, u = lane & 15;
+    const int gc = g < 3 ? g : 0;
+    const NodeW nw = p.w[nt];
+    float X[RG][8], Va[RG][4];
+    int nid[RG];
+    const int gm = p.grp - 1;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        const int row = base + min(4 * r + i, nv - 1);
+        const int n = t.ids ? p.row_ids[t.n0 + row] : t.n0 + row;
+        nid[r] = n;
+        float as[8], avv[4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) as[m] = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) avv[tt] = 0.f;
+        // The partial rows of a segment [st, end) are the last slots of the aligned groups of grp slots it touches.  Both
+        // segments' descriptors are fetched together, then the first three partial rows of each (absent: the all-zero
+        // row) in one batch of loads; longer segments (in-degree beyond ~3 groups) finish in a loop.
+        int st[2], cn[2];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int slot = sl == 0 ? 0 : (nt == 0 ? p.pp_slot : 1);
+            st[sl] = p.in_start[slot * p.N + n];
+            cn[sl] = p.in_cnt[slot * p.N + n];
+        }
+        f32x4 x0[2][3], x1[2][3];
+        float vv[2][3][4];
+        int nxt[2];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int end = st[sl] + cn[sl];
+            int e = st[sl];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const bool has = e < end;
+                const int rw = has ? min(e | gm, end - 1) : p.zero_row;
+                const f32x4 PF_AS1* mp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.msg_s + (size_t)rw * PF_S) + 2 * a;
+                x0[sl][k] = mp[0]; x1[sl][k] = mp[1];
+                pf_gcf vp = (pf_gcf)p.msg_v + (size_t)rw * 48 + gc + 3 * q;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) vv[sl][k][tt] = vp[12 * tt];
+                e = has ? rw + 1 : e;
+            }
+            nxt[sl] = e;
+        }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int end = st[sl] + cn[sl];
+            float ps[8], pv[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                ps[m] = (x0[sl][0][m] + x0[sl][1][m]) + x0[sl][2][m];
+                ps[4 + m] = (x1[sl][0][m] + x1[sl][1][m]) + x1[sl][2][m];
+            }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) pv[tt] = (vv[sl][0][tt] + vv[sl][1][tt]) + vv[sl][2][tt];
+            for (int e = nxt[sl]; e < end;) {
+                const int rw = min(e | gm, end - 1);
+                const f32x4 PF_AS1* mp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.msg_s + (size_t)rw * PF_S) + 2 * a;
+                const f32x4 y0 = mp[0], y1 = mp[1];
+                pf_gcf vp = (pf_gcf)p.msg_v + (size_t)rw * 48 + gc + 3 * q;
+                const float v0 = vp[0], v1 = vp[12], v2 = vp[24], v3 = vp[36];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { ps[m] += y0[m]; ps[4 + m] += y1[m]; }
+                pv[0] += v0; pv[1] += v1; pv[2] += v2; pv[3] += v3;
+                e = rw + 1;
+            }
+            const float sc = (p.norm_mode == 0 && cn[sl] > 0) ? 1.0f / (float)cn[sl] : 1.0f;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) as[m] = fmaf(ps[m], sc, as[m]);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) avv[tt] = fmaf(pv[tt], sc, avv[tt]);
+        }
+        float inv_norm = 1.0f;
+        if (p.norm_mode == 1) inv_norm = 1.0f / p.norm_value;
+        else if (p.norm_mode == 2) inv_norm = 1.0f / p.gnorm[nt * p.B + p.gid[n]];
+        const f32x4 PF_AS1* hpn = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.h_in + (size_t)n * PF_S) + 2 * a;
+        const f32x4 h0 = hpn[0], h1 = hpn[1];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { X[r][m] = fmaf(as[m], inv_norm, h0[m]); X[r][4 + m] = fmaf(as[4 + m], inv_norm, h1[m]); }
+        if constexpr (!L0) {
+            pf_gcf vp = (pf_gcf)p.v_in + (size_t)n * 48 + gc + 3 * q;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) Va[r][tt] = fmaf(avv[tt], inv_norm, vp[12 * tt]);
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) Va[r][tt] = avv[tt] * inv_norm;
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) Va[r][tt] = g < 3 ? Va[r][tt] : 0.f;
+    }
+    stamp(lane);                                       // aggregation done
+    rg_layernorm<RG>(nw.ln1_w, nw.ln1_b, X, Va, lane);
+    float Xr[RG][8], Vr[RG][4];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) Xr[r][m] = X[r][m];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) Vr[r][tt] = Va[r][tt];
+    }
+    f32x4 slo[RG], shi[RG], Vd[RG];
+    const float zero[RG] = {};
+    for (int gi = 0; gi < p.n_upd; ++gi) rg_gvp<SpecGen, RG, D, 0, false, true>(ring, X, Va, zero, zero, slo, shi, Vd, lds, lane, stamp);
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) X[r][m] += Xr[r][m];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) Va[r][tt] += Vr[r][tt];
+    }
+    rg_layernorm<RG>(nw.ln2_w, nw.ln2_b, X, Va, lane);
+    stamp(lane);                                       // second LayerNorm done
+    if constexpr (!HEAD) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            if (4 * r + i < nv) {
+                f32x4* op = reinterpret_cast<f32x4*>(p.h_out + (size_t)nid[r] * PF_S) + 2 * a;
+                op[0] = (f32x4){X[r][0], X[r][1], X[r][2], X[r][3]};
+                op[1] = (f32x4){X[r][4], X[r][5], X[r][6], X[r][7]};
+                if (g < 3) {
+                    float* vp = p.v_out + (size_t)nid[r] * 48 + g + 3 * q;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) vp[12 * tt] = Va[r][tt];
+                }
+            }
+        }
+    } else {
+        // noise head: its chain and to_scalar_output follow the update chain in the quad stream
+        for (int gi = 0; gi + 1 < hp.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, 0, false, true>(ring, X, Va, zero, zero, slo, shi, Vd, lds, lane, stamp);
+        rg_gvp<SpecHeadLast, RG, D, 0, false, false>(ring, X, Va, zero, zero, slo, shi, Vd, lds, lane, stamp);
+        // to_scalar_output: Linear(64 -> pharm_nf), K split over the lane groups like the gates
+        f32x4 od[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) od[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 oc = {0.f, 0.f, 0.f, 0.f};
+        static_for<0, RG_NQ_OUT>([&](auto QI) {
+            constexpr int qi = decltype(QI)::value;
+            const f32x4 w = ring.q[(PHO + qi) % D];
+            ring.q[(PHO + qi) % D] = ring.p[(qi + D) * 64];
+            if constexpr (qi == 0) oc = w;
+            else if constexpr (qi <= 8) {
+                static_for<0, 4>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+#pragma unroll
+                    for (int r = 0; r < RG; ++r) od[r] = mfma_b2<j>(X[r][qi - 1], w[j], od[r]);
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const float o = gsum(od[r][ii]) + oc[0];
+                if (4 * r + ii < nv) {
+                    const int f = __builtin_amdgcn_readlane(nid[r], ii) - hp.node_base;
+                    if (g == 0 && u < hp.pharm_nf) hp.eps_h[(size_t)f * hp.pharm_nf + u] = o;
+                    if (u == 0 && g < 3) hp.eps_x[(size_t)f * 3 + g] = Vd[r][ii];     // output channel 0, coordinate g
+                }
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+#ifdef PF_STAMPS
+int pfk_rg_set_stamp_buffer(unsigned long long* dev) { g_rg_stamp_host_buf = dev; unsigned long long* z = nullptr; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rg_stamps), &z, sizeof(z)); }
+void pfk_rg_set_stamp_which(int which) { g_rg_stamp_which = which; g_rg_stamp_seen = 0; }
+#endif
+// rows per wave: 8 (RG = 2) once there are enough groups to fill the chip, else 4
+void pfk_rg_edge(const EdgeParams* p, int layer0, int rg, hipStream_t s) {
+    if (p->ntiles == 0) return;
+#ifdef PF_STAMPS
+    rg_stamp_arm(s);
+#endif
+    const int per = 32 / (4 * rg);
+    const int grid = p->ntiles * per + (p->warm ? PF_WARM_BLOCKS : 0);
+    if (rg == 1) {
+        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 1>), dim3(grid), dim3(64), 0, s, *p);
+        else hipLaunchKernelGGL((k_rg_edge<false, 1>), dim3(grid), dim3(64), 0, s, *p);
+    } else {
+        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 2>), dim3(grid), dim3(64), 0, s, *p);
+        else hipLaunchKernelGGL((k_rg_edge<false, 2>), dim3(grid), dim3(64), 0, s, *p);
+    }
+}
+void pfk_rg_node(const NodeParams* p, const HeadParams* hp, int layer0, int rg, hipStream_t s) {
+    if (p->ntiles == 0) return;
+#ifdef PF_STAMPS
+    rg_stamp_arm(s);
+#endif
+    const int per = 32 / (4 * rg);
+    const HeadParams none{};
+    const bool head = hp != nullptr;
+    const HeadParams& h = head ? *hp : none;
+    const int grid = p->ntiles * per + (p->warm ? PF_WARM_BLOCKS : 0);
+#define PF_RG_NODE(L0_, RG_, HEAD_) hipLaunchKernelGGL((k_rg_node<L0_, RG_, HEAD_>), dim3(grid), dim3(64), 0, s, *p, h)
+    if (rg == 1) {
+        if (head) { if (layer0) PF_RG_NODE(true, 1, true); else PF_RG_NODE(false, 1, true); }
+        else { if (layer0) PF_RG_NODE(true, 1, false); else PF_RG_NODE(false, 1, false); }
+    } else {
+        if (head) { if (layer0) PF_RG_NODE(true, 2, true); else PF_RG_NODE(false, 2, true); }
+        else { if (layer0) PF_RG_NODE(true, 2, false); else PF_RG_NODE(false, 2, false); }
+    }
+#undef PF_RG_NODE
+}
+}

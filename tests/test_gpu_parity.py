@@ -198,6 +198,7 @@ def test_one_wave_per_tile_kernels(name, monkeypatch):
     """The kernels used for launches with MANY tiles (k_edge_msg / k_node_update / k_noise_head: one wave per
     32 rows, dense layers, per-source precompute) are forced here on the small golden cases, so that both
     kernel families are checked against the reference goldens."""
+    monkeypatch.setenv("PFDYN_RG_ROWS_MAX", "0")
     monkeypatch.setenv("PFDYN_COOP_EDGE_MAX", "0")
     monkeypatch.setenv("PFDYN_COOP2_EDGE_MAX", "0")
     monkeypatch.setenv("PFDYN_COOP_NODE_MAX", "0")
@@ -221,6 +222,7 @@ def test_one_wave_per_tile_kernels(name, monkeypatch):
 def test_two_workgroups_per_cu_edge_kernel(name, dense, monkeypatch):
     """k_edge_msg_coop2 (the 4-wave kernel without weight prefetch, two workgroups per CU: launches with more tiles
     than CUs) forced on the small golden cases, on the pruned and on the dense tile lists."""
+    monkeypatch.setenv("PFDYN_RG_ROWS_MAX", "0")
     monkeypatch.setenv("PFDYN_COOP_EDGE_MAX", "0")
     monkeypatch.setenv("PFDYN_COOP2_EDGE_MAX", "1000000")
     if dense:
@@ -232,6 +234,52 @@ def test_two_workgroups_per_cu_edge_kernel(name, dense, monkeypatch):
     set_batch(eng, batch, z["prot_x"])
     eps_h, eps_x = eng.dynamics(z["x_t"], z["h_t"], z["t"])
     close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
+
+
+@pytest.mark.parametrize("name", ["dynamics_c1.npz", "dynamics_ragged.npz", "dynamics_radius.npz", "dynamics_knnff.npz"])
+@pytest.mark.parametrize("dense", [False, True])
+def test_four_waves_per_tile_kernels(name, dense, monkeypatch):
+    """The 4-wave cooperative kernels (k_edge_msg_coop / k_node_update_coop / k_node_head_coop: one 32-row tile per
+    workgroup; launches between the row-group and the one-wave regimes) forced on the golden cases."""
+    monkeypatch.setenv("PFDYN_RG_ROWS_MAX", "0")
+    if dense:
+        monkeypatch.setenv("PFDYN_NO_PRUNE", "1")
+    z, cfg = load(name), DYN_CASES[name]
+    batch = batch_from(z)
+    eng = engine_for(cfg, O.make_state_dict(cfg, int(z["wseed"])))
+    set_batch(eng, batch, z["prot_x"])
+    eps_h, eps_x = eng.dynamics(z["x_t"], z["h_t"], z["t"])
+    close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
+    li = int(z["conv_layer_index"])
+    hp, vp, hf, vf = eng.conv_layer(li, z["prot_x"], z["x_t"], z["conv_in_h_prot"], z["conv_in_v_prot"],
+                                    z["conv_in_h_pharm"], z["conv_in_v_pharm"])
+    close(hp, z["conv_out_h_prot"]); close(vp, z["conv_out_v_prot"])
+    close(hf, z["conv_out_h_pharm"]); close(vf, z["conv_out_v_pharm"])
+
+
+@pytest.mark.parametrize("name", ["dynamics_c1.npz", "dynamics_ragged.npz", "dynamics_radius.npz", "dynamics_knnff.npz"])
+@pytest.mark.parametrize("rows_per_wave", [4, 8])
+@pytest.mark.parametrize("dense", [False, True])
+def test_row_group_kernels(name, rows_per_wave, dense, monkeypatch):
+    """The row-group kernels (pf_rg.hip: k_rg_edge / k_rg_node, 4 or 8 rows per wave on the 4x4x1 MFMA) forced on
+    the golden cases at both widths, on the pruned and on the dense tile lists, fused and separate head, plus one
+    whole conv layer with non-zero node vectors."""
+    monkeypatch.setenv("PFDYN_RG_ROWS_MAX", "100000000")
+    monkeypatch.setenv("PFDYN_RG2_ROWS_MIN", "0" if rows_per_wave == 8 else "100000000")
+    if dense:
+        monkeypatch.setenv("PFDYN_NO_PRUNE", "1")
+        monkeypatch.setenv("PFDYN_NO_FUSE_HEAD", "1")
+    z, cfg = load(name), DYN_CASES[name]
+    batch = batch_from(z)
+    eng = engine_for(cfg, O.make_state_dict(cfg, int(z["wseed"])))
+    set_batch(eng, batch, z["prot_x"])
+    eps_h, eps_x = eng.dynamics(z["x_t"], z["h_t"], z["t"])
+    close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
+    li = int(z["conv_layer_index"])
+    hp, vp, hf, vf = eng.conv_layer(li, z["prot_x"], z["x_t"], z["conv_in_h_prot"], z["conv_in_v_prot"],
+                                    z["conv_in_h_pharm"], z["conv_in_v_pharm"])
+    close(hp, z["conv_out_h_prot"]); close(vp, z["conv_out_v_prot"])
+    close(hf, z["conv_out_h_pharm"]); close(vf, z["conv_out_v_pharm"])
 
 
 @pytest.mark.parametrize("name", ["dynamics_c1.npz", "dynamics_radius.npz"])

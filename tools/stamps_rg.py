@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Diagnostic: in-kernel cycle stamps (s_memtime) of the row-group kernels (pf_rg.hip) at BASELINE config 2.
+
+Needs a diagnostic build of the kernels (never the product build):
+    pharmacophore-diffusion_amd/csrc/build_variant.sh stamps "-DPF_STAMPS"
+    PFDYN_LIB=$PWD/pharmacophore-diffusion_amd/csrc/variants/libpfdyn_stamps.so python tools/stamps_rg.py
+The stamp buffer keeps what the LAST launch of a step wrote per wave slot, so the step is run with one kernel of
+interest last: by default the fused node + head launch (k_rg_node<.., HEAD>); `--layer` stops after a debug conv layer
+(edge + node launches; the node kernel's stamps overwrite the edge kernel's for the first 64 waves -- use --edge to
+keep the edge kernel's by giving the node kernel an empty tile list is not possible, so the edge kernel is stamped
+through PFDYN_STAMP_EDGE=1 which makes the node kernels skip stamping)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pharmacoforge_amd as pfa  # noqa: E402
+from pharmacoforge_amd import schedule, synthetic  # noqa: E402
+
+dev = torch.device('cuda', 0)
+B, T = int(os.environ.get("B", "32")), 500
+eng = pfa.PfEngine(device=dev)
+eng.load_state_dict(synthetic.make_state_dict(0))
+xs, hs = zip(*[synthetic.synthetic_pocket(1000 + i, 256) for i in range(B)])
+px, ph = torch.cat(xs).to(dev), torch.cat(hs).to(dev)
+pptr = torch.arange(B + 1) * 256
+fptr = torch.arange(B + 1) * 6
+s, d = eng.build_pp_edges(px, pptr)
+eng.set_batch(px, ph, pptr, fptr, s, d)
+coef = schedule.step_coefficients(schedule.PredefinedNoiseSchedule('polynomial_2', T, 1e-5).gamma, T)
+carr = eng.coef_array(coef, list(range(39, -1, -1)))
+noise = torch.randn(41, B * 6, 9, device=dev)
+buf = torch.zeros(64 * 64, dtype=torch.int64, device=dev)
+lib = eng.lib
+lib.pfk_rg_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+lib.pfk_rg_set_stamp_which.argtypes = [ctypes.c_int]
+eng.sample_begin(noise[0])
+for i in range(30):
+    eng.denoise_step(carr[i], noise[i + 1])
+torch.cuda.synchronize()
+names = {0: "k_rg_edge (conv layer 0)", 1: "k_rg_node (conv layer 0)", 2: "k_rg_edge (last layer)", 3: "k_rg_node + head (last layer)"}
+for which in range(4):
+    buf.zero_()
+    assert lib.pfk_rg_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
+    lib.pfk_rg_set_stamp_which(which)
+    eng.denoise_step(carr[30], noise[31])
+    torch.cuda.synchronize()
+    lib.pfk_rg_set_stamp_buffer(None)
+    st = buf.cpu().view(64, 64)
+    print(f"== launch {which}: {names[which]}  (cycles between consecutive stamps; waves that ran)")
+    shown = 0
+    for w in range(64):
+        row = st[w]
+        n = int((row != 0).sum())
+        if n < 2:
+            continue
+        dl = [int(row[i + 1] - row[i]) for i in range(n - 1)]
+        print(f"  wave {w:2d}: total {int(row[n - 1] - row[0])}  " + " ".join(str(x) for x in dl))
+        shown += 1
+        if shown >= 6:
+            break
