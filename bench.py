@@ -23,6 +23,8 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3          # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_EDGE = 136742.0         # message chain, 2 FLOP / MAC
+# bytes per launch of the layer-0 edge kernel at config 2, by kernel family (rows per wave), from profiles/r01
+PMC_TRAFFIC = {4: (2 * 6513.8 + 1781.7) * 1024, 128: (2 * 5812.7 + 940.5) * 1024, 32: (2 * 15028.2 + 7258.8) * 1024}
 
 
 def main():
@@ -125,9 +127,12 @@ def main():
     wk = eng.work_detail()                                      # work of the last call (actual edge counts)
     flops, bytes_, ne = wk["flops"], wk["bytes"], wk["edges"]
     prof = {k: v for k, v in prof.items()}
-    # dominant kernel = the edge-message launch of conv layer 0 (one wave per tile when the layer is dense, the
-    # 4-wave kernel when it is pruned to the active atoms); FLOP = 136,742 per edge it actually processes
+    # dominant kernel = the edge-message launch of conv layer 0; which kernel family runs it depends on the batch
+    # (pf_debug_kernel_family): row-group kernel k_rg_edge (4 / 8 rows per wave), or the 32-row tile kernels;
+    # FLOP = 136,742 per edge it actually processes
     dom = "edge_msg" if prof["edge_msg"][1] > 0 else "edge_msg_coop"
+    fam = eng.kernel_family(0)
+    dom_name = {4: "k_rg_edge<rows_per_wave=4>", 8: "k_rg_edge<rows_per_wave=8>", 32: "k_edge_msg", 128: "k_edge_msg_coop"}[fam]
     edge_ms, edge_n = prof[dom]
     l0_edges = wk["executed_edges_per_layer"][0]
     edge_avg_s = edge_ms / max(edge_n, 1) * 1e-3
@@ -146,12 +151,12 @@ def main():
                    "edges_per_step": {"ff": ne[0], "pf": ne[1], "fp": ne[2], "pp": ne[3]},
                    "edges_computed_per_layer": wk["executed_edges_per_layer"],
                    "parallelism": f"graphs sharded over {world} GPU(s), no data-path collective"},
-        "roofline": {"bound": "mfma", "kernel": "k_" + dom, "achieved": achieved_tf, "peak": PEAK_F32_TFLOPS,
+        "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved_tf, "peak": PEAK_F32_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_TFLOPS,
                      # HBM-side bytes per launch of that kernel from the committed rocprofv3 PMC passes
-                     # (profiles/r01/c_pruned_pmc_hbm.csv: 2 x FETCH_SIZE [gfx950 wide-read correction] + WRITE_SIZE);
+                     # (profiles/r01/*_pmc_hbm.csv: 2 x FETCH_SIZE [gfx950 wide-read correction] + WRITE_SIZE);
                      # PMC counters cannot be collected from inside this process
-                     "traffic": (2 * 5812.7 + 940.5) * 1024 if dom == "edge_msg_coop" else (2 * 15028.2 + 7258.8) * 1024,
+                     "traffic": PMC_TRAFFIC.get(fam) if (B, args.n_prot, args.n_pharm, args.pharm_sizes) == (32, 256, 6, "") else None,
                      "kernel_avg_us": edge_avg_s * 1e6, "launches_timed": edge_n, "flop_per_launch": edge_flops,
                      "note": "edge-message launches timed by HIP events inside the timed region; FLOP = 136,742 per edge "
                              "(SURVEY 8d) x edges the launch computes (conv layer 0). Outputs equal the "
@@ -259,10 +264,11 @@ def dense_leg(pfa, synthetic, dev, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, 
     timed region of `value`."""
     os.environ["PFDYN_NO_PRUNE"] = "1"
     os.environ["PFDYN_NO_PRE"] = "1"
+    os.environ["PFDYN_RG_ROWS_MAX"] = "0"          # the 32-row tile kernels (what large dense launches and training use)
     try:
         eng = pfa.PfEngine(device=dev)
     finally:
-        del os.environ["PFDYN_NO_PRUNE"], os.environ["PFDYN_NO_PRE"]
+        del os.environ["PFDYN_NO_PRUNE"], os.environ["PFDYN_NO_PRE"], os.environ["PFDYN_RG_ROWS_MAX"]
     eng.load_state_dict(synthetic.make_state_dict(0))
     eng.set_batch(prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst)
     gen = torch.Generator(device=dev).manual_seed(7)

@@ -204,6 +204,10 @@ int pf_profile_read(pf_handle* h, double* total_ms /*[9]*/, int64_t* launches /*
  * kernels compute after dead-work elimination (last layer: pharm side only; layer before it: active atoms only). */
 int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges /*[4]*/, double* executed_flops,
                   int64_t* executed_edges /*[n_convs]*/, pf_stream stream);
+/* kernel family of the edge-message launch of conv layer `layer` in the last dynamics call (the launch policy depends
+ * on the batch: pf_host.cpp rg_mode / coop*_max): *rows_per_wave = 4 or 8 (row-group kernels, pf_rg.hip: k_rg_edge),
+ * 32 (one wave per 32-row tile: k_edge_msg) or 128 (four waves per 32-row tile: k_edge_msg_coop / coop2) */
+int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave);
 
 #ifdef __cplusplus
 }

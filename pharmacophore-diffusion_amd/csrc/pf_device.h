@@ -58,32 +58,43 @@ struct GvpW {              // packed weights of one GVP (device pointers)
 };
 
 // ---- row-group ("rg") kernels: 4 rows per v_mfma_f32_4x4x1_16b_f32, weights streamed as "quads" (pf_rg.hip) ----
-// A GVP's weights are one contiguous stream of quads ([quad][64 lanes][4 floats] = 1 KiB, one b128 load per lane) in
-// the exact order the kernel consumes them; the GVPs of a chain follow each other, so the register prefetch ring
-// (16-32 quads deep) runs across GVP boundaries.  Quad schedule of one GVP (vi, nextra, nh = output halves of 64):
-//   [const] [xhat, w16 when vi == 17] [Vh x4] [main 32*nh] [rbf 4*nh when nextra] [Vu x4] [sh 4*nh] [gate x8] [pad]
-#define RG_GEN_NQ 96        // the generic GVP (16 vectors, 128 + 16 scalars in and out) is padded to this many quads
+// A chain's weights are one contiguous stream of quads ([quad][64 lanes][4 floats] = 1 KiB, one b128 load per lane) in
+// the exact order the kernel consumes them, so the register prefetch ring (12-24 quads deep) runs across GVP
+// boundaries.  The chain is software-pipelined: the scalar->vector gates of GVP n-1 (which need only its SiLU output)
+// and the vector products of GVP n are threaded through the 128 main k-steps of GVP n, whose MFMAs hide the LDS
+// round trips in between.  Block of GVP n (vi, nextra, nh = output halves of 64, prev = a gate is pending):
+//   [const] [xhat, w16 when vi == 17] [main m=0] [gate of GVP n-1, 8 quads, when prev] [main m=1,2] [Vh x4]
+//   [main m=3..5] [Vu x4] [main m=6,7] [rbf when nextra] [sh] [pad]
+// and a chain ends with a flush block [gate of the last GVP x8] [pad].  Every block is padded to a multiple of RG_PAD
+// quads, a multiple of every ring depth used, so a quad's ring slot is a compile-time constant.
+#define RG_PAD 24
 #define RG_TAIL_PAD 48      // quads of read-ahead padding behind the last stream (>= the deepest prefetch ring)
+#define RG_NQ_FLUSH 24      // [8 gate quads] [pad]
+#define RG_NQ_OUT 24        // to_scalar_output: [const] [8 gate-like quads] [pad]
 struct RgSched {
-    int q_c, q_xh, q_vh, q_main, q_rbf, q_vu, q_sh, q_gate, nq_raw, nq;
+    int q_c, q_xh, q_a, q_gate, q_b, q_vh, q_cc, q_vu, q_d, q_rbf, q_sh, nq_raw, nq;
 };
-constexpr RgSched rg_sched(const int vi, const int nextra, const int nh) {
+constexpr RgSched rg_sched(const int vi, const int nextra, const int nh, const bool prev) {
     RgSched s{};
     s.q_c = 0;
     s.q_xh = 1;
-    s.q_vh = 1 + (vi == 17 ? 2 : 0);
-    s.q_main = s.q_vh + 4;
-    s.q_rbf = s.q_main + 32 * nh;
-    s.q_vu = s.q_rbf + (nextra ? 4 * nh : 0);
-    s.q_sh = s.q_vu + 4;
-    s.q_gate = s.q_sh + 4 * nh;
-    s.nq_raw = s.q_gate + 8;
-    // only the generic GVP repeats inside a chain: padded so that the ring phase does not change across repetitions
-    s.nq = (vi == 16 && nextra == 0 && nh == 2) ? RG_GEN_NQ : s.nq_raw;
+    s.q_a = 1 + (vi == 17 ? 2 : 0);
+    s.q_gate = s.q_a + 4 * nh;
+    s.q_b = s.q_gate + (prev ? 8 : 0);
+    s.q_vh = s.q_b + 8 * nh;
+    s.q_cc = s.q_vh + 4;
+    s.q_vu = s.q_cc + 12 * nh;
+    s.q_d = s.q_vu + 4;
+    s.q_rbf = s.q_d + 8 * nh;
+    s.q_sh = s.q_rbf + (nextra ? 4 * nh : 0);
+    s.nq_raw = s.q_sh + 4 * nh;
+    s.nq = (s.nq_raw + RG_PAD - 1) / RG_PAD * RG_PAD;
     return s;
 }
-#define PF_WARM_BLOCKS 256  // helper blocks per launch: 32 per XCD (workgroups are dealt round-robin over the 8 XCDs)
-#define RG_NQ_OUT 9        // to_scalar_output: [const] [8 gate-like quads]
+// quad of main k-step group k (k = (m * 4 + aq) * nh + half: image j of it is k-step (m, a = 4 aq + j))
+constexpr int rg_main_quad(const RgSched& s, const int nh, const int k) {
+    return k < 4 * nh ? s.q_a + k : (k < 12 * nh ? s.q_b + k - 4 * nh : (k < 24 * nh ? s.q_cc + k - 12 * nh : s.q_d + k - 24 * nh));
+}
 
 struct EdgeTile {          // one wave = 32 edge slots
     int e0;                // first edge slot
@@ -122,7 +133,6 @@ struct EdgeParams {
     // the gate pre-activations and the gated output vectors go to sv_*[(l * sv_stride + e)]; NULL: inference
     float* sv_z; float* sv_g; float* sv_v; size_t sv_stride;
     pf_gcf rg[4];          // row-group kernels: quad stream of each etype's message chain (this layer)
-    pf_gcf warm; int warm_bytes;   // weights of the NEXT launch, pulled into every XCD's L2 by helper blocks (or null)
 };
 
 struct NodeW {             // per node type
@@ -158,7 +168,6 @@ struct NodeParams {
     int grp;               // edge slots per message partial row group: 32 (tile kernels) or 4*RG (row-group edge kernel)
     pf_gcf rg_upd[2];      // row-group kernels: quad stream of each node type's update chain (pharm of the last layer:
                            // followed by the noise head's chain and to_scalar_output)
-    pf_gcf warm; int warm_bytes;   // weights of the NEXT launch, pulled into every XCD's L2 by helper blocks (or null)
 };
 
 struct HeadParams {
@@ -202,7 +211,6 @@ struct BuildParams {
     float* gnorm;          // [2][B]
     const int* pp_cnt;     // [B] static pp edges per graph
     int norm_mode;
-    pf_gcf warm; int warm_bytes;   // weights of the NEXT launch, pulled into every XCD's L2 by helper blocks (or null)
 };
 
 struct StepParams {

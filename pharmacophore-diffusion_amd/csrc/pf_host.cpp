@@ -135,15 +135,12 @@ struct pf_handle {
     int coop_edge_max = 256, coop_node_max = 1024;
     int coop2_edge_max = 12000, coop2_dense_max = 1024;
     // row-group kernels (pf_rg.hip): quad streams of the message chains [layer][etype] and update chains [layer][ntype]
-    // (offsets into d_w); used while a layer's launches have at most rg_rows_max rows (edge slots of the tile list)
+    // (offsets into d_w).  Inference launches use them up to rg_rows_max rows (edge slots of the tile list): 4 rows per
+    // wave below rg2_rows_min rows, 8 above (measured: batch 32-128 prefer 4, batch 256-1024 prefer 8 and beat the
+    // 32-row tile kernels at every batch size); the tile kernels remain for training and PFDYN_RG_ROWS_MAX=0
     std::vector<size_t> rg_msg, rg_upd;
-    // bytes of a message chain / an update chain / the last pharm update chain + noise head + to_scalar_output
-    size_t rg_msg_bytes() const { return (size_t)(rg_sched(17, PF_R, 2).nq + (cfg.n_message_gvps - 1) * RG_GEN_NQ) * 1024; }
-    size_t rg_upd_bytes() const { return (size_t)cfg.n_update_gvps * RG_GEN_NQ * 1024; }
-    size_t rg_tail_bytes() const { return rg_upd_bytes() + (size_t)((cfg.n_noise_gvps - 1) * RG_GEN_NQ + rg_sched(16, 0, 1).nq + RG_NQ_OUT) * 1024; }
-    bool l2_warm = true;                    // PFDYN_NO_WARM=1: no helper workgroups
-    int warm_mask = 7;                      // PFDYN_WARM_MASK: 1 encode/build launch, 2 edge launches, 4 node launches
-    int rg_rows_max = 16384, rg2_rows_min = 4096;
+    std::vector<int> last_family;           // per conv layer: pf_debug_kernel_family
+    int rg_rows_max = 1 << 30, rg2_rows_min = 100000;
     // 0: tile kernels; 1 / 2: row-group kernels with 4 / 8 rows per wave
     int rg_mode(int ntiles) const {
         const long rows = (long)ntiles * 32;
@@ -158,8 +155,6 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_NO_PRE")) use_pre = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_FUSE_HEAD")) fuse_head = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_PRUNE")) prune = atoi(e) == 0;
-        if (const char* e = getenv("PFDYN_NO_WARM")) l2_warm = atoi(e) == 0;
-        if (const char* e = getenv("PFDYN_WARM_MASK")) warm_mask = atoi(e);
         if (const char* e = getenv("PFDYN_RG_ROWS_MAX")) rg_rows_max = atoi(e);
         if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = atoi(e);
     }
@@ -400,17 +395,29 @@ static GvpOff pack_gvp(pf_handle* h, const GvpSpec& g) {
 // [64 lanes][4 images]; an image is what one lane holds of a B operand: lane f <-> output feature f (scalar Linear),
 // lane 16g + u <-> output channel u of coordinate group g (vector products, gates; g = 3 unused -> 0).
 // ------------------------------------------------------------------------------------------------
-static void pack_gvp_rg(pf_handle* h, const GvpSpec& g, std::vector<float>& out) {
+// the 8 gate quads of a GVP (or to_scalar_output): K split over the lane groups, quad m, image j <-> features
+// 8 (4g + j) + m of lane group g (the A block (g, j) of the SA layout)
+static void pack_gate_quads_rg(const std::vector<float>& Wg, int vo, int so, std::vector<float>& out, size_t base, int q0) {
+    for (int lane = 0; lane < 64; ++lane) {
+        const int gq = lane >> 4, u = lane & 15;
+        for (int m = 0; m < 8; ++m)
+            for (int j = 0; j < 4; ++j) {
+                const int feat = 8 * (4 * gq + j) + m;
+                out[base + ((size_t)(q0 + m) * 64 + lane) * 4 + j] = (u < vo && feat < so) ? Wg[(size_t)u * so + feat] : 0.f;
+            }
+    }
+}
+// one block of a chain: GVP g, plus the gate quads of the GVP before it (prev) when there is one
+static void pack_gvp_rg(pf_handle* h, const GvpSpec& g, const GvpSpec* prev, std::vector<float>& out) {
     const int S = h->cfg.n_hidden_scalars;
     const int H = std::max(g.vi, g.vo);
     const int nextra = g.si - S;
     const int NH = g.so / 64;
     const bool X17 = g.vi == 17;
-    const RgSched q = rg_sched(g.vi, nextra, NH);
+    const RgSched q = rg_sched(g.vi, nextra, NH, prev != nullptr);
     const int Kin = H + g.si;
     const std::vector<float>& W = h->raw[g.prefix + "to_feats_out.0.weight"].data;            // [so][si + H]
     const std::vector<float>& Bv = h->raw[g.prefix + "to_feats_out.0.bias"].data;
-    const std::vector<float>& Wg = h->raw[g.prefix + "scalar_to_vector_gates.weight"].data;   // [vo][so]
     const std::vector<float>& bg = h->raw[g.prefix + "scalar_to_vector_gates.bias"].data;
     const std::vector<float>& wh = h->raw[g.prefix + "Wh"].data;                              // [vi][H]
     const std::vector<float>& wu = h->raw[g.prefix + "Wu"].data;                              // [H][vo]
@@ -442,19 +449,21 @@ static void pack_gvp_rg(pf_handle* h, const GvpSpec& g, std::vector<float>& out)
             for (int m = 0; m < 8; ++m)
                 for (int aq = 0; aq < 4; ++aq)
                     for (int j = 0; j < 4; ++j)
-                        at(q.q_main + (m * 4 + aq) * NH + half, lane, j) = W[(size_t)f * Kin + 8 * (4 * aq + j) + m];
+                        at(rg_main_quad(q, NH, (m * 4 + aq) * NH + half), lane, j) = W[(size_t)f * Kin + 8 * (4 * aq + j) + m];
             for (int aq = 0; aq < 4; ++aq)
                 for (int j = 0; j < 4; ++j) {
                     if (nextra) at(q.q_rbf + aq * NH + half, lane, j) = W[(size_t)f * Kin + S + 4 * aq + j];
                     at(q.q_sh + aq * NH + half, lane, j) = W[(size_t)f * Kin + g.si + 4 * aq + j];
                 }
         }
-        for (int m = 0; m < 8; ++m)
-            for (int j = 0; j < 4; ++j) {
-                const int feat = 8 * (4 * gq + j) + m;      // A block (g, j) holds features 8 (4g + j) .. + 7
-                at(q.q_gate + m, lane, j) = (u < g.vo && feat < g.so) ? Wg[(size_t)u * g.so + feat] : 0.f;
-            }
     }
+    if (prev) pack_gate_quads_rg(h->raw[prev->prefix + "scalar_to_vector_gates.weight"].data, prev->vo, prev->so, out, base, q.q_gate);
+}
+// end of a chain: the gate quads of its last GVP
+static void pack_flush_rg(pf_handle* h, const GvpSpec& g, std::vector<float>& out) {
+    const size_t base = out.size();
+    out.resize(base + (size_t)RG_NQ_FLUSH * 256, 0.f);
+    pack_gate_quads_rg(h->raw[g.prefix + "scalar_to_vector_gates.weight"].data, g.vo, g.so, out, base, 0);
 }
 // to_scalar_output (Linear 64 -> pharm_nf) as a gate-like product: [const] [8 quads] [pad]
 static void pack_out_rg(pf_handle* h, std::vector<float>& out) {
@@ -540,14 +549,6 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;    // the layer restricted to active atoms
     bp.act_ids = prune_layer >= 0 ? h->d_act_ids : nullptr; bp.reg_act = h->d_reg_act;
     bool pre_ready = false;
-    {   // the first edge launch's weights travel to L2 while this launch runs (row-group path only)
-        const bool last0 = c.n_convs == 1;
-        const int nt0 = last0 ? h->n_edge_tiles_last : (prune_layer == 0 ? h->n_edge_tiles_act : h->n_edge_tiles);
-        if (!train && h->l2_warm && (h->warm_mask & 1) && h->rg_mode(nt0)) {
-            bp.warm = h->d_w + h->rg_msg[0];
-            bp.warm_bytes = (int)((last0 ? 2 : 4) * h->rg_msg_bytes());
-        }
-    }
     if (h->prof_mask & 3u) {     // timing the two halves separately needs separate launches
         { ProfScope ps(h, pf_handle::K_ENCODE, s); pfk_encode(&ep, s); }
         { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); }
@@ -584,10 +585,8 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         }
         for (int et = 0; et < 4; ++et) e.rg[et] = h->d_w + h->rg_msg[(size_t)l * 4 + et];
         const int rg = train ? 0 : h->rg_mode(e.ntiles);     // the node launch of this layer follows (partial-row grouping)
-        if (rg && h->l2_warm && (h->warm_mask & 2)) {         // this launch's helpers fetch the node launch's weights
-            e.warm = h->d_w + h->rg_upd[(size_t)l * 2 + (last ? 1 : 0)];
-            e.warm_bytes = (int)(last ? h->rg_tail_bytes() : 2 * h->rg_upd_bytes());
-        }
+        h->last_family.resize(c.n_convs);
+        h->last_family[l] = rg ? 4 * rg : ((!train && e.ntiles <= ((last || pruned) ? std::max(h->coop_edge_max, h->coop2_edge_max) : std::max(h->coop_edge_max, h->coop2_dense_max))) ? 128 : 32);
         if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, l == 0, rg, s); }
         else if (e.ntiles <= h->coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
         else if (e.ntiles <= ((last || pruned) ? h->coop2_edge_max : h->coop2_dense_max) && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop2(&e, l == 0, s); }
@@ -613,11 +612,6 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         n.n_upd = c.n_update_gvps;
         n.grp = rg ? 4 * rg : 32;
         for (int nt = 0; nt < 2; ++nt) n.rg_upd[nt] = h->d_w + h->rg_upd[(size_t)l * 2 + nt];
-        if (rg && h->l2_warm && (h->warm_mask & 4) && !last) { // ... and the node launch's helpers the next edge launch's
-            const bool nlast = l + 1 == c.n_convs - 1;
-            n.warm = h->d_w + h->rg_msg[(size_t)(l + 1) * 4];
-            n.warm_bytes = (int)((nlast ? 2 : 4) * h->rg_msg_bytes());
-        }
         if (rg) {
             const int rgn = std::max(1, h->rg_mode(n.ntiles));
             if (last && h->fuse_head && h->n_head_tiles == n.ntiles) {
@@ -818,19 +812,28 @@ int pf_commit_weights(pf_handle* h) {
             h->rg_upd.assign((size_t)c.n_convs * 2, 0);
             std::vector<float> st;
             auto flush = [&]() { const size_t off = push(h->h_w, st); st.clear(); return off; };
+            auto chain = [&](auto spec_of, int n) {          // blocks of a chain: GVP j carries the gates of GVP j - 1
+                GvpSpec prev;
+                for (int j = 0; j < n; ++j) {
+                    const GvpSpec g = spec_of(j);
+                    pack_gvp_rg(h, g, j ? &prev : nullptr, st);
+                    prev = g;
+                }
+                pack_flush_rg(h, prev, st);
+            };
             for (int l = 0; l < c.n_convs; ++l)
                 for (int et = 0; et < 4; ++et) {
-                    for (int j = 0; j < c.n_message_gvps; ++j) pack_gvp_rg(h, msg_spec(c, l, et, j), st);
+                    chain([&](int j) { return msg_spec(c, l, et, j); }, c.n_message_gvps);
                     h->rg_msg[(size_t)l * 4 + et] = flush();
                 }
             for (int l = 0; l < c.n_convs; ++l)
                 for (int nt = 0; nt < 2; ++nt) {
                     if (l == c.n_convs - 1 && nt == 1) continue;
-                    for (int j = 0; j < c.n_update_gvps; ++j) pack_gvp_rg(h, upd_spec(c, l, nt, j), st);
+                    chain([&](int j) { return upd_spec(c, l, nt, j); }, c.n_update_gvps);
                     h->rg_upd[(size_t)l * 2 + nt] = flush();
                 }
-            for (int j = 0; j < c.n_update_gvps; ++j) pack_gvp_rg(h, upd_spec(c, c.n_convs - 1, 1, j), st);
-            for (int k = 0; k < c.n_noise_gvps; ++k) pack_gvp_rg(h, head_spec(c, k), st);
+            chain([&](int j) { return upd_spec(c, c.n_convs - 1, 1, j); }, c.n_update_gvps);
+            chain([&](int k) { return head_spec(c, k); }, c.n_noise_gvps);
             pack_out_rg(h, st);
             st.resize(st.size() + (size_t)RG_TAIL_PAD * 256, 0.f);
             h->rg_upd[(size_t)(c.n_convs - 1) * 2 + 1] = flush();
@@ -1566,6 +1569,13 @@ int pf_debug_dropout_mask(pf_handle* h, int32_t layer, int32_t which, float drop
     tc.drop_scale = 1.0f / (1.0f - dropout_p);
     tc.seed = seed;
     pfk_drop_masks(&tc, (uint32_t)layer * 2u + (uint32_t)which, h->N * 144, dev_out, (hipStream_t)stream);
+    return PF_OK;
+}
+
+int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave) {
+    if (!h || !rows_per_wave) return PF_ERR_ARG;
+    if (layer < 0 || layer >= (int)h->last_family.size()) PF_FAIL(h, PF_ERR_STATE, "pf_debug_kernel_family: no dynamics call yet, or bad layer");
+    *rows_per_wave = h->last_family[layer];
     return PF_OK;
 }
 

@@ -15,7 +15,6 @@
 #include <hip/hip_runtime.h>
 #include "pf_device.h"
 #include "pf_train.h"
-#include "pf_warm.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1584,23 +1583,17 @@ __device__ __forceinline__ void encode_pre_tile(const PreParams& p, const int ti
 
 // encoders and dynamic edge build are independent (one reads h/t, the other coordinates): one launch,
 // the first B blocks build edges, the rest encode
-// helper workgroups behind the nc working ones (pf_warm.h): workgroup j sits on XCD j % 8, its four waves take four slices
-__device__ __forceinline__ void warm_block(const BuildParams& bp, const int j) {
-    l2_warm(bp.warm, bp.warm_bytes, (j >> 3) * 4 + (int)(threadIdx.x >> 6), PF_WARM_BLOCKS / 8, threadIdx.x & 63);
-}
-__global__ __launch_bounds__(256) void k_encode_build(const EncodeParams ep, const BuildParams bp, const int nc) {
+__global__ __launch_bounds__(256) void k_encode_build(const EncodeParams ep, const BuildParams bp) {
     if ((int)blockIdx.x < bp.B) build_body(bp, blockIdx.x);
-    else if ((int)blockIdx.x < nc) encode_body(ep, blockIdx.x - bp.B);
-    else warm_block(bp, blockIdx.x - nc);
+    else encode_body(ep, blockIdx.x - bp.B);
 }
 // the same launch with the protein side done by encode_pre_tile: blocks [0,B) build edges, [B, B+gp) encode the
 // pharmacophore nodes (8 per wave), the rest encode 32 protein atoms each and precompute P
-__global__ __launch_bounds__(256) void k_encode_build_pre(const EncodeParams ep, const BuildParams bp, const PreParams pp, const int nc) {
+__global__ __launch_bounds__(256) void k_encode_build_pre(const EncodeParams ep, const BuildParams bp, const PreParams pp) {
     __shared__ CoopLds L;
     const int gp = ((ep.Nf + 7) / 8 + 3) / 4;
     const int b = blockIdx.x;
-    if (b >= nc) warm_block(bp, b - nc);
-    else if (b < bp.B) build_body(bp, b);
+    if (b < bp.B) build_body(bp, b);
     else if (b < bp.B + gp) {
         const int lane = threadIdx.x & 63;
         const int grp = __builtin_amdgcn_readfirstlane((int)(((b - bp.B) * 256 + threadIdx.x) >> 6));
@@ -1798,13 +1791,11 @@ void pfk_noise_head(const HeadParams* p, hipStream_t s) {
 }
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s) {
     const int groups = (e->Np + 7) / 8 + (e->Nf + 7) / 8;
-    const int nc = b->B + (groups + 3) / 4;
-    hipLaunchKernelGGL(k_encode_build, dim3(nc + (b->warm ? PF_WARM_BLOCKS / 4 : 0)), dim3(256), 0, s, *e, *b, nc);
+    hipLaunchKernelGGL(k_encode_build, dim3(b->B + (groups + 3) / 4), dim3(256), 0, s, *e, *b);
 }
 void pfk_encode_build_pre(const EncodeParams* e, const BuildParams* b, const PreParams* pp, hipStream_t s) {
     const int gp = ((e->Nf + 7) / 8 + 3) / 4;
-    const int nc = b->B + gp + (pp->Np + 31) / 32;
-    hipLaunchKernelGGL(k_encode_build_pre, dim3(nc + (b->warm ? PF_WARM_BLOCKS / 4 : 0)), dim3(256), 0, s, *e, *b, *pp, nc);
+    hipLaunchKernelGGL(k_encode_build_pre, dim3(b->B + gp + (pp->Np + 31) / 32), dim3(256), 0, s, *e, *b, *pp);
 }
 void pfk_encode(const EncodeParams* p, hipStream_t s) {
     const int groups = (p->Np + 7) / 8 + (p->Nf + 7) / 8;

@@ -27,7 +27,6 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "pf_device.h"
-#include "pf_warm.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -118,48 +117,66 @@ struct __attribute__((aligned(16))) RgLds {
 __device__ __forceinline__ int pperm(const int u) { return (u & 3) * 4 + (u >> 2); }
 
 // register prefetch ring over the quad stream
-// (D quads deep; the slot of quad qi of a GVP is (PHASE + qi) % D with PHASE = quads consumed before it, mod D: the
-// generic GVP -- the only one that repeats inside a chain -- has a multiple of every D used, so PHASE is static)
+// (D quads deep; every block of the stream is a multiple of RG_PAD quads and D divides RG_PAD, so quad qi of a block
+// always sits in slot qi % D)
 template <int D>
 struct RgRing {
     f32x4 q[D];
-    const f32x4 PF_AS1* p;                    // quad 0 of the current GVP, + lane
+    const f32x4 PF_AS1* p;                    // quad 0 of the current block, + lane
 };
 template <int D>
 __device__ __forceinline__ void ring_start(RgRing<D>& r, pf_gcf stream, const int lane) {
     r.p = reinterpret_cast<const f32x4 PF_AS1*>(stream) + lane;
     static_for<0, D>([&](auto I) { r.q[decltype(I)::value] = r.p[decltype(I)::value * 64]; });
 }
+#ifndef RG_SB
+#define RG_SB 1                               // quads between scheduling barriers (keeps the ring loads where they are issued)
+#endif
 #ifndef RG_D1
 #define RG_D1 24                              // ring depth at 4 rows per wave (one quad per 4 MFMAs)
 #endif
 #ifndef RG_D2
-#define RG_D2 16                              // ... at 8 rows per wave (one quad per 8 MFMAs)
+#define RG_D2 12                              // ... at 8 rows per wave (one quad per 8 MFMAs)
 #endif
-template <int RG> struct RgDepth { static constexpr int D = RG == 1 ? RG_D1 : RG_D2; };
+template <int RG> struct RgDepth {
+    static constexpr int D = RG == 1 ? RG_D1 : RG_D2;
+    static_assert(RG_PAD % D == 0, "ring depth must divide the block padding");
+};
 
-template <int VI_, int NEXTRA_, int NH_, int VO_, bool SIG_>
+template <int VI_, int NEXTRA_, int NH_, bool SIG_>
 struct RgSpec {
-    static constexpr int VI = VI_, NEXTRA = NEXTRA_, NH = NH_, VO = VO_;
+    static constexpr int VI = VI_, NEXTRA = NEXTRA_, NH = NH_;
     static constexpr bool SIG = SIG_, H17 = VI_ == 17;
-    static constexpr RgSched S = rg_sched(VI_, NEXTRA_, NH_);
+};
+typedef RgSpec<17, PF_R, 2, true> SpecMsg0;         // first message GVP: [h_src, rbf] / [xhat, v_src]
+typedef RgSpec<16, 0, 2, true> SpecGen;             // 128 + 16 -> 128 + 16
+typedef RgSpec<16, 0, 1, false> SpecHeadLast;       // last noise-head GVP: 64 scalars, 1 vector, identity gate
+
+// what a GVP leaves pending for the next block: its Vu (VD layout) and gate bias -- the gates themselves are computed
+// from its SiLU output inside the next block (or the flush block)
+template <int RG>
+struct RgCarry {
+    f32x4 vu[RG];
+    float bg;
 };
 
 // ---------------------------------------------------------------------------------------------
-// One GVP on RG groups of four rows.
+// One block of the pipelined chain = one GVP on RG groups of four rows (+ the pending gates of the previous one).
 //   X  [RG][8]  in: scalar input, SA layout          out: SiLU output, SA layout (next GVP's input)
-//   Va [RG][4]  in: vector input, VA layout          out: gated vector output, VA layout (when NEEDVA)
+//   Va [RG][4]  in (PREV == 0): vector input, VA layout; with a pending gate it is produced here
 //   R, XH       first message GVP only: rbf image (lane 4a+i: rbf_a(d_i)) and unit x_diff (lane 16g+i: xhat_i[g])
 //   slo, shi    SiLU output, SD layout (register i: row i; lane f: feature f / 64+f)
-//   Vd          gated vector output, VD layout (lane 16g+u: channel u, coordinate g)
-//   VZERO       the 16 node-vector channels are identically zero (conv layer 0): only xhat feeds Vh
+//   carry       in: pending Vu / gate bias of the previous GVP (PREV != 0); out: this GVP's
+//   PREV        0: first GVP of a chain; 1: previous GVP gates with a sigmoid; 2: identity
+//   VZERO       the 16 node-vector channels are identically zero (conv layer 0, first GVP): only xhat feeds Vh
 // ---------------------------------------------------------------------------------------------
-template <class S, int RG, int D, int PHASE, bool VZERO, bool NEEDVA>
+template <class S, int RG, int D, int PREV, bool VZERO>
 __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float (&Va)[RG][4], const float (&R)[RG],
-                                       const float (&XH)[RG], f32x4 (&slo)[RG], f32x4 (&shi)[RG], f32x4 (&Vd)[RG],
+                                       const float (&XH)[RG], f32x4 (&slo)[RG], f32x4 (&shi)[RG], RgCarry<RG>& carry,
                                        RgLds* lds, const int lane, RgStamp& stamp) {
     constexpr int NH = S::NH;
-    stamp(lane);                                      // 0: GVP start
+    static_assert(!(VZERO && PREV != 0), "VZERO is a property of a chain's first GVP");
+    stamp(lane);                                      // 0: block start
     const int a = lane >> 2, i = lane & 3, g = lane >> 4, q = a & 3, u = lane & 15;
     const int gg = g < 3 ? g : 2;
     // with one row group per wave every accumulator is split in two (even / odd image of a quad): back-to-back MFMAs on
@@ -182,11 +199,17 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
 #pragma unroll
     for (int r = 0; r < RG; ++r) { VhA[r] = cq; SH[r] = 0.f; SH16[r] = 0.f; Vh16[r] = 0.f; }
 
-    static_for<0, S::S.nq>([&](auto QI) {
+    constexpr RgSched QQ = rg_sched(S::VI, S::NEXTRA, NH, PREV != 0);
+    static_for<0, QQ.nq>([&](auto QI) {
         constexpr int qi = decltype(QI)::value;
-        constexpr RgSched Q = S::S;
-        const f32x4 w = ring.q[(PHASE + qi) % D];
-        ring.q[(PHASE + qi) % D] = ring.p[(qi + D) * 64];
+        constexpr RgSched Q = rg_sched(S::VI, S::NEXTRA, NH, PREV != 0);
+        const f32x4 w = ring.q[qi % D];
+        ring.q[qi % D] = ring.p[(qi + D) * 64];
+        // main k-step group of this quad, or -1
+        constexpr int kmain = (qi >= Q.q_a && qi < Q.q_a + 4 * NH) ? qi - Q.q_a
+                            : (qi >= Q.q_b && qi < Q.q_b + 8 * NH) ? 4 * NH + qi - Q.q_b
+                            : (qi >= Q.q_cc && qi < Q.q_cc + 12 * NH) ? 12 * NH + qi - Q.q_cc
+                            : (qi >= Q.q_d && qi < Q.q_d + 8 * NH) ? 24 * NH + qi - Q.q_d : -1;
         if constexpr (qi == Q.q_c) {
             cq = w;                                   // [bias lo, bias hi, gate bias, Wh[0][16] on the xhat lanes]
         } else if constexpr (S::H17 && qi == Q.q_xh) {
@@ -195,8 +218,49 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
             for (int r = 0; r < RG; ++r) vh[r] = mfma_b2<0>(XH[r], w[0], vh[r]);
         } else if constexpr (S::H17 && qi == Q.q_xh + 1) {
             w16 = w;                                  // Wh[1 + 4t + q][16], t = 0..3
+        } else if constexpr (kmain >= 0) {
+            constexpr int half = kmain % NH, mq = kmain / NH, m = mq / 4, aq = mq % 4;
+            static_for<0, 4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    if constexpr (half == 0) lo[acc(r, j)] = mfma_b4<4 * aq + j>(X[r][m], w[j], lo[acc(r, j)]);
+                    else hi[acc(r, j)] = mfma_b4<4 * aq + j>(X[r][m], w[j], hi[acc(r, j)]);
+                }
+            });
+        } else if constexpr (PREV != 0 && qi >= Q.q_gate && qi < Q.q_gate + 8) {
+            constexpr int m = qi - Q.q_gate;          // pending gates of the previous GVP, K split over the lane groups
+            static_for<0, 4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+#pragma unroll
+                for (int r = 0; r < RG; ++r) gd[acc(r, j)] = mfma_b2<j>(X[r][m], w[j], gd[acc(r, j)]);
+            });
+            if constexpr (m == 7) {                   // sum the K quarters, activation, gate the pending Vu, publish
+                stamp(lane);                          // 1: first main k-steps + pending gates issued
+                fold(gd);
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    float* tv = lds[r].tv;
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        float gv = gsum(gd[r][ii]) + carry.bg;
+                        if constexpr (PREV == 1) gv = sigmoidf_(gv);
+                        const float vd = gv * carry.vu[r][ii];
+                        if (lane < 48) tv[ii * RG_TV_STRIDE + g * 16 + pperm(u)] = vd;
+                    }
+                }
+            }
         } else if constexpr (qi >= Q.q_vh && qi < Q.q_vh + 4) {
             constexpr int t = qi - Q.q_vh;
+            if constexpr (t == 0 && PREV != 0) {      // the gated vectors of the previous GVP are back: VA layout
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(&lds[r].tv[i * RG_TV_STRIDE + gg * 16 + 4 * q]);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) Va[r][tt] = g < 3 ? v4[tt] : 0.f;
+                }
+            }
             if constexpr (!VZERO) {
                 static_for<0, 4>([&](auto J) {
                     constexpr int j = decltype(J)::value;
@@ -205,7 +269,7 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
                 });
             }
             if constexpr (t == 3) {                   // Vh complete: hidden channel 16 on the VALU, publish Vh
-                stamp(lane);                          // 1: Vh issued
+                stamp(lane);                          // 2: Vh issued
                 fold(vh);
 #pragma unroll
                 for (int r = 0; r < RG; ++r) {
@@ -227,18 +291,10 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
                     }
                 }
             }
-        } else if constexpr (qi >= Q.q_main && qi < Q.q_main + 32 * NH) {
-            constexpr int k = qi - Q.q_main, half = k % NH, mq = k / NH, m = mq / 4, aq = mq % 4;
-            static_for<0, 4>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-#pragma unroll
-                for (int r = 0; r < RG; ++r) {
-                    if constexpr (half == 0) lo[acc(r, j)] = mfma_b4<4 * aq + j>(X[r][m], w[j], lo[acc(r, j)]);
-                    else hi[acc(r, j)] = mfma_b4<4 * aq + j>(X[r][m], w[j], hi[acc(r, j)]);
-                }
-            });
-            if constexpr (k == 8 * NH) {              // Vh is back from LDS: A images of the Vu product, sh = |Vh|
-                stamp(lane);                          // 2: first quarter of the main k-steps issued
+        } else if constexpr (qi >= Q.q_vu && qi < Q.q_vu + 4) {
+            constexpr int t = qi - Q.q_vu;
+            if constexpr (t == 0) {                   // Vh is back from LDS: A images of the Vu product, sh = |Vh|
+                stamp(lane);                          // 3: three quarters of the main k-steps issued
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int r = 0; r < RG; ++r) {
@@ -253,19 +309,6 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
                     }
                 }
             }
-        } else if constexpr (S::NEXTRA > 0 && qi >= Q.q_rbf && qi < Q.q_rbf + 4 * NH) {
-            constexpr int k = qi - Q.q_rbf, half = k % NH, aq = k / NH;
-            static_for<0, 4>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-#pragma unroll
-                for (int r = 0; r < RG; ++r) {
-                    if constexpr (half == 0) lo[acc(r, j)] = mfma_b4<4 * aq + j>(R[r], w[j], lo[acc(r, j)]);
-                    else hi[acc(r, j)] = mfma_b4<4 * aq + j>(R[r], w[j], hi[acc(r, j)]);
-                }
-            });
-        } else if constexpr (qi >= Q.q_vu && qi < Q.q_vu + 4) {
-            constexpr int t = qi - Q.q_vu;
-            if constexpr (t == 0) stamp(lane);        // 3: main (+ rbf) k-steps issued
             static_for<0, 4>([&](auto J) {
                 constexpr int j = decltype(J)::value;
 #pragma unroll
@@ -278,8 +321,19 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
                     for (int r = 0; r < RG; ++r) vu[r] = mfma_b2<0>(Vh16[r], xhq[1], vu[r]);
                 }
             }
+        } else if constexpr (S::NEXTRA > 0 && qi >= Q.q_rbf && qi < Q.q_rbf + 4 * NH) {
+            constexpr int k = qi - Q.q_rbf, half = k % NH, aq = k / NH;
+            static_for<0, 4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    if constexpr (half == 0) lo[acc(r, j)] = mfma_b4<4 * aq + j>(R[r], w[j], lo[acc(r, j)]);
+                    else hi[acc(r, j)] = mfma_b4<4 * aq + j>(R[r], w[j], hi[acc(r, j)]);
+                }
+            });
         } else if constexpr (qi >= Q.q_sh && qi < Q.q_sh + 4 * NH) {
             constexpr int k = qi - Q.q_sh, half = k % NH, aq = k / NH;
+            if constexpr (k == 0) stamp(lane);        // 4: all main k-steps issued
             static_for<0, 4>([&](auto J) {
                 constexpr int j = decltype(J)::value;
 #pragma unroll
@@ -289,7 +343,7 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
                 }
             });
             if constexpr (k == 4 * NH - 1) {          // scalar Linear complete: bias, SiLU, SD -> SA through LDS
-                stamp(lane);                          // 4: Vu + sh k-steps issued
+                stamp(lane);                          // 5: sh k-steps issued
                 fold(lo);
                 fold(hi);
 #pragma unroll
@@ -319,54 +373,71 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
 #pragma unroll
                     for (int m = 0; m < 4; ++m) { X[r][m] = on ? x0[m] : 0.f; X[r][4 + m] = on ? x1[m] : 0.f; }
                 }
-                stamp(lane);                          // 5: SiLU output back in the SA layout
+                stamp(lane);                          // 6: SiLU output back in the SA layout
             }
-        } else if constexpr (qi >= Q.q_gate && qi < Q.q_gate + 8) {
-            constexpr int m = qi - Q.q_gate;
+        }
+        if constexpr (qi % RG_SB == RG_SB - 1) __builtin_amdgcn_sched_barrier(0);
+    });
+    ring.p += QQ.nq * 64;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) carry.vu[r] = vu[r];
+    carry.bg = cq[2];
+}
+
+// end of a chain: the pending gates of its last GVP.  Vd: gated vector output, VD layout (lane 16g+u: channel u,
+// coordinate g); Va: the same in the VA layout (when NEEDVA)
+template <int RG, int D, bool SIG, bool NEEDVA>
+__device__ __forceinline__ void rg_flush(RgRing<D>& ring, const float (&X)[RG][8], float (&Va)[RG][4], f32x4 (&Vd)[RG],
+                                         const RgCarry<RG>& carry, RgLds* lds, const int lane, RgStamp& stamp) {
+    const int i = lane & 3, g = lane >> 4, q = (lane >> 2) & 3, u = lane & 15;
+    const int gg = g < 3 ? g : 2;
+    constexpr int NA = RG == 1 ? 2 : 1;
+    f32x4 gd[RG * NA];
+#pragma unroll
+    for (int r = 0; r < RG * NA; ++r) gd[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto acc = [](const int r, const int j) { return RG == 1 ? (j & 1) : r; };
+    static_for<0, RG_NQ_FLUSH>([&](auto QI) {
+        constexpr int qi = decltype(QI)::value;
+        const f32x4 w = ring.q[qi % D];
+        ring.q[qi % D] = ring.p[(qi + D) * 64];
+        if constexpr (qi < 8) {
             static_for<0, 4>([&](auto J) {
                 constexpr int j = decltype(J)::value;
 #pragma unroll
-                for (int r = 0; r < RG; ++r) gd[acc(r, j)] = mfma_b2<j>(X[r][m], w[j], gd[acc(r, j)]);
+                for (int r = 0; r < RG; ++r) gd[acc(r, j)] = mfma_b2<j>(X[r][qi], w[j], gd[acc(r, j)]);
             });
-            if constexpr (m == 7) {                   // gates: sum the K quarters, activation, gate the vectors
-                stamp(lane);                          // 6: gate k-steps issued
-                fold(gd);
-#pragma unroll
-                for (int r = 0; r < RG; ++r) {
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        float gv = gsum(gd[r][ii]) + cq[2];
-                        if constexpr (S::SIG) gv = sigmoidf_(gv);
-                        Vd[r][ii] = gv * vu[r][ii];
-                    }
-                    if constexpr (NEEDVA) {
-                        float* tv = lds[r].tv;
-                        if (lane < 48) {
-#pragma unroll
-                            for (int ii = 0; ii < 4; ++ii) tv[ii * RG_TV_STRIDE + g * 16 + pperm(u)] = Vd[r][ii];
-                        }
-                    }
-                }
-                if constexpr (NEEDVA) {
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int r = 0; r < RG; ++r) {
-                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(&lds[r].tv[i * RG_TV_STRIDE + gg * 16 + 4 * q]);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) Va[r][t] = g < 3 ? v4[t] : 0.f;
-                    }
-                }
-            }
         }
         __builtin_amdgcn_sched_barrier(0);
     });
-    ring.p += S::S.nq * 64;
-    stamp(lane);                                      // 7: GVP done
+    ring.p += RG_NQ_FLUSH * 64;
+    if constexpr (RG == 1) gd[0] += gd[1];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            float gv = gsum(gd[r][ii]) + carry.bg;
+            if constexpr (SIG) gv = sigmoidf_(gv);
+            Vd[r][ii] = gv * carry.vu[r][ii];
+        }
+        if constexpr (NEEDVA) {
+            float* tv = lds[r].tv;
+            if (lane < 48) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) tv[ii * RG_TV_STRIDE + g * 16 + pperm(u)] = Vd[r][ii];
+            }
+        }
+    }
+    if constexpr (NEEDVA) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(&lds[r].tv[i * RG_TV_STRIDE + gg * 16 + 4 * q]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Va[r][t] = g < 3 ? v4[t] : 0.f;
+        }
+    }
+    stamp(lane);                                      // chain flushed
 }
-
-typedef RgSpec<17, PF_R, 2, 16, true> SpecMsg0;     // first message GVP: [h_src, rbf] / [xhat, v_src]
-typedef RgSpec<16, 0, 2, 16, true> SpecGen;         // 128 + 16 -> 128 + 16
-typedef RgSpec<16, 0, 1, 1, false> SpecHeadLast;    // last noise-head GVP: 64 scalars, 1 vector, identity gate
 
 // GVPLayerNorm (gvp.py:159-166) on the SA / VA layouts: lane 4a+i holds 8 of the 128 scalars of row i, the row's
 // statistics are a sum over the 16 blocks; vector norms need the three coordinates of a channel (lane groups g)
@@ -408,18 +479,15 @@ __device__ __forceinline__ void rg_layernorm(pf_gcf lw, pf_gcf lb, float (&X)[RG
 // ---------------------------------------------------------------------------------------------
 template <bool L0, int RG>
 __global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p) {
-    constexpr int D = RgDepth<RG>::D, PH1 = SpecMsg0::S.nq % D;      // ring phase after the first message GVP
+    constexpr int D = RgDepth<RG>::D;
     __shared__ RgLds lds[RG];
     constexpr int G = 4 * RG, PER = 32 / G;
     const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= p.ntiles * PER) {           // helper workgroup
-        l2_warm(p.warm, p.warm_bytes, (blockIdx.x - p.ntiles * PER) >> 3, PF_WARM_BLOCKS / 8, lane);
-        return;
-    }
-    const EdgeTile t = p.tiles[blockIdx.x / PER];
+    const int bid = blockIdx.x;
+    const EdgeTile t = p.tiles[bid / PER];
     int nvalid = t.n;
     if (t.cnt_idx >= 0) nvalid = min(nvalid, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
-    const int base = (blockIdx.x % PER) * G;
+    const int base = (bid % PER) * G;
     const int nv = __builtin_amdgcn_readfirstlane(min(G, nvalid - base));
     if (nv <= 0) return;                               // wave-uniform
     const int et = __builtin_amdgcn_readfirstlane(t.et);
@@ -458,12 +526,10 @@ __global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p) {
         }
     }
     f32x4 slo[RG], shi[RG], Vd[RG];
-    if (p.n_gvps == 1) rg_gvp<SpecMsg0, RG, D, 0, L0, false>(ring, X, Va, R, XH, slo, shi, Vd, lds, lane, stamp);
-    else {
-        rg_gvp<SpecMsg0, RG, D, 0, L0, true>(ring, X, Va, R, XH, slo, shi, Vd, lds, lane, stamp);
-        for (int gi = 1; gi + 1 < p.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, PH1, false, true>(ring, X, Va, R, XH, slo, shi, Vd, lds, lane, stamp);
-        rg_gvp<SpecGen, RG, D, PH1, false, false>(ring, X, Va, R, XH, slo, shi, Vd, lds, lane, stamp);
-    }
+    RgCarry<RG> carry;
+    rg_gvp<SpecMsg0, RG, D, 0, L0>(ring, X, Va, R, XH, slo, shi, carry, lds, lane, stamp);
+    for (int gi = 1; gi < p.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, 1, false>(ring, X, Va, R, XH, slo, shi, carry, lds, lane, stamp);
+    rg_flush<RG, D, true, false>(ring, X, Va, Vd, carry, lds, lane, stamp);
     // in-wave segmented sum in slot order; one partial row per (wave, destination) run
     float al = 0.f, ah = 0.f, av = 0.f;
     int prev = -1;
@@ -496,19 +562,15 @@ __global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p) {
 // ---------------------------------------------------------------------------------------------
 template <bool L0, int RG, bool HEAD>
 __global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadParams hp) {
-    constexpr int D = RgDepth<RG>::D, PHO = SpecHeadLast::S.nq % D;  // ring phase after the last head GVP
-    static_assert(SpecGen::S.nq % D == 0, "the generic GVP must keep the ring phase");
+    constexpr int D = RgDepth<RG>::D;
     __shared__ RgLds lds[RG];
     constexpr int G = 4 * RG, PER = 32 / G;
     const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= p.ntiles * PER) {           // helper workgroup
-        l2_warm(p.warm, p.warm_bytes, (blockIdx.x - p.ntiles * PER) >> 3, PF_WARM_BLOCKS / 8, lane);
-        return;
-    }
-    const NodeTile t = p.tiles[blockIdx.x / PER];
+    const int bid = blockIdx.x;
+    const NodeTile t = p.tiles[bid / PER];
     int tn = t.n;
     if (t.cnt_idx >= 0) tn = min(tn, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
-    const int base = (blockIdx.x % PER) * G;
+    const int base = (bid % PER) * G;
     const int nv = __builtin_amdgcn_readfirstlane(min(G, tn - base));
     if (nv <= 0) return;                               // wave-uniform
     const int nt = __builtin_amdgcn_readfirstlane(t.ntype);
@@ -620,7 +682,10 @@ __global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadPa
     }
     f32x4 slo[RG], shi[RG], Vd[RG];
     const float zero[RG] = {};
-    for (int gi = 0; gi < p.n_upd; ++gi) rg_gvp<SpecGen, RG, D, 0, false, true>(ring, X, Va, zero, zero, slo, shi, Vd, lds, lane, stamp);
+    RgCarry<RG> carry;
+    rg_gvp<SpecGen, RG, D, 0, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
+    for (int gi = 1; gi < p.n_upd; ++gi) rg_gvp<SpecGen, RG, D, 1, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
+    rg_flush<RG, D, true, true>(ring, X, Va, Vd, carry, lds, lane, stamp);
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
 #pragma unroll
@@ -646,8 +711,13 @@ __global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadPa
         }
     } else {
         // noise head: its chain and to_scalar_output follow the update chain in the quad stream
-        for (int gi = 0; gi + 1 < hp.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, 0, false, true>(ring, X, Va, zero, zero, slo, shi, Vd, lds, lane, stamp);
-        rg_gvp<SpecHeadLast, RG, D, 0, false, false>(ring, X, Va, zero, zero, slo, shi, Vd, lds, lane, stamp);
+        if (hp.n_gvps == 1) rg_gvp<SpecHeadLast, RG, D, 0, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
+        else {
+            rg_gvp<SpecGen, RG, D, 0, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
+            for (int gi = 1; gi + 1 < hp.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, 1, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
+            rg_gvp<SpecHeadLast, RG, D, 1, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
+        }
+        rg_flush<RG, D, false, false>(ring, X, Va, Vd, carry, lds, lane, stamp);
         // to_scalar_output: Linear(64 -> pharm_nf), K split over the lane groups like the gates
         f32x4 od[RG];
 #pragma unroll
@@ -655,8 +725,8 @@ __global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadPa
         f32x4 oc = {0.f, 0.f, 0.f, 0.f};
         static_for<0, RG_NQ_OUT>([&](auto QI) {
             constexpr int qi = decltype(QI)::value;
-            const f32x4 w = ring.q[(PHO + qi) % D];
-            ring.q[(PHO + qi) % D] = ring.p[(qi + D) * 64];
+            const f32x4 w = ring.q[qi % D];
+            ring.q[qi % D] = ring.p[(qi + D) * 64];
             if constexpr (qi == 0) oc = w;
             else if constexpr (qi <= 8) {
                 static_for<0, 4>([&](auto J) {
@@ -695,7 +765,7 @@ void pfk_rg_edge(const EdgeParams* p, int layer0, int rg, hipStream_t s) {
     rg_stamp_arm(s);
 #endif
     const int per = 32 / (4 * rg);
-    const int grid = p->ntiles * per + (p->warm ? PF_WARM_BLOCKS : 0);
+    const int grid = p->ntiles * per;
     if (rg == 1) {
         if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 1>), dim3(grid), dim3(64), 0, s, *p);
         else hipLaunchKernelGGL((k_rg_edge<false, 1>), dim3(grid), dim3(64), 0, s, *p);
@@ -713,7 +783,7 @@ void pfk_rg_node(const NodeParams* p, const HeadParams* hp, int layer0, int rg, 
     const HeadParams none{};
     const bool head = hp != nullptr;
     const HeadParams& h = head ? *hp : none;
-    const int grid = p->ntiles * per + (p->warm ? PF_WARM_BLOCKS : 0);
+    const int grid = p->ntiles * per;
 #define PF_RG_NODE(L0_, RG_, HEAD_) hipLaunchKernelGGL((k_rg_node<L0_, RG_, HEAD_>), dim3(grid), dim3(64), 0, s, *p, h)
     if (rg == 1) {
         if (head) { if (layer0) PF_RG_NODE(true, 1, true); else PF_RG_NODE(false, 1, true); }

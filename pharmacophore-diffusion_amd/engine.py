@@ -278,6 +278,13 @@ class PfEngine:
         return {"flops": fl.value, "bytes": by.value, "edges": list(ne), "executed_flops": ex.value,
                 "executed_edges_per_layer": list(el)}
 
+    def kernel_family(self, layer: int = 0) -> int:
+        """Rows per wave of the edge-message launch of `layer` in the last dynamics call: 4 / 8 = row-group kernels
+        (k_rg_edge), 32 = one wave per tile (k_edge_msg), 128 = four waves per tile (k_edge_msg_coop)."""
+        r = ctypes.c_int32()
+        self._ck(self.lib.pf_debug_kernel_family(self._h, int(layer), ctypes.byref(r)), "pf_debug_kernel_family")
+        return int(r.value)
+
     KERNEL_CLASSES = ("encode", "build_edges", "edge_msg", "node_update", "noise_head", "step_update", "edge_msg_coop",
                       "node_update_coop", "edge_msg_last")
 

@@ -4,11 +4,9 @@
 Needs a diagnostic build of the kernels (never the product build):
     pharmacophore-diffusion_amd/csrc/build_variant.sh stamps "-DPF_STAMPS"
     PFDYN_LIB=$PWD/pharmacophore-diffusion_amd/csrc/variants/libpfdyn_stamps.so python tools/stamps_rg.py
-The stamp buffer keeps what the LAST launch of a step wrote per wave slot, so the step is run with one kernel of
-interest last: by default the fused node + head launch (k_rg_node<.., HEAD>); `--layer` stops after a debug conv layer
-(edge + node launches; the node kernel's stamps overwrite the edge kernel's for the first 64 waves -- use --edge to
-keep the edge kernel's by giving the node kernel an empty tile list is not possible, so the edge kernel is stamped
-through PFDYN_STAMP_EDGE=1 which makes the node kernels skip stamping)."""
+Every row-group launch of a step is stamped in turn (pfk_rg_set_stamp_which selects the launch); lane 0 of the first
+64 waves writes s_memtime at the phase boundaries of rg_gvp / rg_flush (see the stamp(lane) comments in pf_rg.hip).
+s_memtime ticks are shader cycles; the stamps themselves cost ~100-200 cycles each."""
 import ctypes
 import os
 import sys
