@@ -133,6 +133,9 @@ struct EdgeParams {
     // the gate pre-activations and the gated output vectors go to sv_*[(l * sv_stride + e)]; NULL: inference
     float* sv_z; float* sv_g; float* sv_v; size_t sv_stride;
     pf_gcf rg[4];          // row-group kernels: quad stream of each etype's message chain (this layer)
+    // row-group kernels, compact work list (nreg > 0): the launch covers regions [0, nreg) of reg / dyn_cnt (region
+    // r = kind * regB + graph; kinds ff, pf, fp, pa); ngroups4 / ngroups8 = capacity in groups of 4 / 8 slots (the grid)
+    const int* reg; int nreg, regB, ngroups4, ngroups8;
 };
 
 struct NodeW {             // per node type

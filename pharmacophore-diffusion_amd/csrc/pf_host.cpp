@@ -25,8 +25,8 @@ void pfk_node_head_coop(const NodeParams* p, const HeadParams* hp, int layer0, h
 void pfk_noise_head_coop(const HeadParams* p, hipStream_t s);
 void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s);
 void pfk_noise_head(const HeadParams* p, hipStream_t s);
-void pfk_rg_edge(const EdgeParams* p, int layer0, int rg, hipStream_t s);
-void pfk_rg_node(const NodeParams* p, const HeadParams* hp, int layer0, int rg, hipStream_t s);
+void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int rg, hipStream_t s);
+void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
 void pfk_encode_build_pre(const EncodeParams* e, const BuildParams* b, const PreParams* pp, hipStream_t s);
@@ -37,6 +37,7 @@ void pfk_copy(const float* src, float* dst, size_t n, hipStream_t s);
 void pfk_scale_copy(const float* src, float* dst, size_t n, float sc, hipStream_t s);
 void pfk_segment_mean(const float4* xn, const int* ptr, int base, int B, float* out, hipStream_t s);
 void pfk_step_update(const StepParams* p, hipStream_t s);
+void pfk_step_build(const StepParams* sp, const BuildParams* bp, hipStream_t s);
 void pfk_export_coords(const float4* xn, int base, int n, const int* gid, const float* add, const float* sub,
                        float* out, hipStream_t s);
 void pfk_bwd_head(const BwdHeadParams* p, int nblocks, hipStream_t s);
@@ -126,6 +127,7 @@ struct pf_handle {
           *d_v[2] = {nullptr, nullptr}, *d_msg_s = nullptr, *d_msg_v = nullptr, *d_eps_h = nullptr, *d_eps_x = nullptr,
           *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr, *d_pre = nullptr;
     bool sampling = false;
+    bool edges_built = false;               // the dynamic edges of the current coordinates exist (built by k_step_build)
     // launches with at most this many tiles use the 4-wave cooperative kernels (latency-bound regime)
     // Edge-message launches: up to coop_edge_max tiles (one per CU) the 4-wave kernel with next-GVP weight prefetch;
     // up to coop2_edge_max (pruned / last-layer tile lists) or coop2_dense_max (dense layers, where the one-wave kernel
@@ -136,17 +138,19 @@ struct pf_handle {
     int coop2_edge_max = 12000, coop2_dense_max = 1024;
     // row-group kernels (pf_rg.hip): quad streams of the message chains [layer][etype] and update chains [layer][ntype]
     // (offsets into d_w).  Inference launches use them up to rg_rows_max rows (edge slots of the tile list): 4 rows per
-    // wave below rg2_rows_min rows, 8 above (measured: batch 32-128 prefer 4, batch 256-1024 prefer 8 and beat the
-    // 32-row tile kernels at every batch size); the tile kernels remain for training and PFDYN_RG_ROWS_MAX=0
+    // wave below rg2_rows_min slots (launches with fewer groups than SIMDs are latency-bound), 8 above; they beat the
+    // 32-row tile kernels at every batch size measured (32-1024); those remain for training and PFDYN_RG_ROWS_MAX=0
     std::vector<size_t> rg_msg, rg_upd;
     std::vector<int> last_family;           // per conv layer: pf_debug_kernel_family
-    int rg_rows_max = 1 << 30, rg2_rows_min = 100000;
+    int rg_rows_max = 1 << 30, rg2_rows_min = 12000;
     // 0: tile kernels; 1 / 2: row-group kernels with 4 / 8 rows per wave
     int rg_mode(int ntiles) const {
         const long rows = (long)ntiles * 32;
         if (rows > rg_rows_max) return 0;
         return rows >= rg2_rows_min ? 2 : 1;
     }
+    bool enc_on_the_fly = true;             // PFDYN_NO_ENC_FLY=1: always launch the encoders
+    bool rg_compact = true;                 // PFDYN_NO_COMPACT=1: row-group edge launches walk the tile lists
     bool fuse_head = true;                  // last conv layer's node update + noise head in one launch (PFDYN_NO_FUSE_HEAD=1: separate)
     void init_tuning() {
         if (const char* e = getenv("PFDYN_COOP2_EDGE_MAX")) coop2_edge_max = coop2_dense_max = atoi(e);
@@ -155,6 +159,8 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_NO_PRE")) use_pre = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_FUSE_HEAD")) fuse_head = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_PRUNE")) prune = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_NO_ENC_FLY")) enc_on_the_fly = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_NO_COMPACT")) rg_compact = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_RG_ROWS_MAX")) rg_rows_max = atoi(e);
         if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = atoi(e);
     }
@@ -521,6 +527,29 @@ struct ProfScope {
     }
 };
 
+static BuildParams build_params(pf_handle* h) {
+    const pf_config& c = h->cfg;
+    BuildParams bp{};
+    bp.B = h->B; bp.Np_tot = h->Np;
+    bp.prot_ptr = h->d_prot_ptr; bp.pharm_ptr = h->d_pharm_ptr; bp.xn = h->d_xn;
+    bp.reg = h->d_reg; bp.dyn_cnt = h->d_dyn_cnt; bp.esrc = h->d_esrc; bp.edst = h->d_edst;
+    bp.in_start = h->d_in_start; bp.in_cnt = h->d_in_cnt; bp.N = h->N;
+    bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
+    bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
+    bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
+    const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;
+    bp.act_ids = prune_layer >= 0 ? h->d_act_ids : nullptr; bp.reg_act = h->d_reg_act;
+    return bp;
+}
+// conv layer 0 of an inference call runs on the row-group kernels: they encode the rows they read on the fly, so the
+// call's first launch is the edge build alone -- which the previous denoising step's update launch can do as well
+static bool encoders_on_the_fly(const pf_handle* h) {
+    const pf_config& c = h->cfg;
+    const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;
+    const int nt0 = c.n_convs == 1 ? h->n_edge_tiles_last : (prune_layer == 0 ? h->n_edge_tiles_act : h->n_edge_tiles);
+    return h->enc_on_the_fly && h->rg_mode(nt0) != 0;
+}
+
 // sequence one dynamics call on the handle's state (xn, pharm_h, d_t).  train: keep every layer's input and message
 // rows (h->t_*), compute every tile (gradients need the full graph only where they are non-zero, but the first
 // version of the backward pass walks the dense tile lists) and apply dropout in the node update.
@@ -538,18 +567,16 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     }
     ep.h_out = train ? h->t_H[0] : h->d_h[0];
 
-    BuildParams bp{};
-    bp.B = h->B; bp.Np_tot = h->Np;
-    bp.prot_ptr = h->d_prot_ptr; bp.pharm_ptr = h->d_pharm_ptr; bp.xn = h->d_xn;
-    bp.reg = h->d_reg; bp.dyn_cnt = h->d_dyn_cnt; bp.esrc = h->d_esrc; bp.edst = h->d_edst;
-    bp.in_start = h->d_in_start; bp.in_cnt = h->d_in_cnt; bp.N = h->N;
-    bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
-    bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
-    bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
     const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;    // the layer restricted to active atoms
-    bp.act_ids = prune_layer >= 0 ? h->d_act_ids : nullptr; bp.reg_act = h->d_reg_act;
+    BuildParams bp = build_params(h);
     bool pre_ready = false;
-    if (h->prof_mask & 3u) {     // timing the two halves separately needs separate launches
+    // conv layer 0 on the row-group kernels: they encode the rows they read on the fly, only the edge build is launched
+    // -- unless the previous denoising step's update launch has built the edges of these coordinates already
+    const bool enc_fly = !train && encoders_on_the_fly(h);
+    if (enc_fly) {
+        if (!h->edges_built) { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); }
+    }
+    else if (h->prof_mask & 3u) {     // timing the two halves separately needs separate launches
         { ProfScope ps(h, pf_handle::K_ENCODE, s); pfk_encode(&ep, s); }
         { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); }
     } else if (h->use_pre && h->Np > 0 && prune_layer != 0) {      // layer 0 is dense: precompute P for its pp messages
@@ -584,10 +611,15 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             e.sv_stride = (size_t)std::max<int64_t>(h->Ecap, 1);
         }
         for (int et = 0; et < 4; ++et) e.rg[et] = h->d_w + h->rg_msg[(size_t)l * 4 + et];
+        // every edge of this launch lives in a dynamic region (each wave scans the region lengths: up to 2048 regions)
+        if ((last || pruned) && h->rg_compact && (last ? 2 : 4) * h->B <= 2048) {
+            e.reg = h->d_reg; e.regB = h->B; e.nreg = (last ? 2 : 4) * h->B;
+            for (int r = 0; r < e.nreg; ++r) { e.ngroups4 += (h->h_cap[r] + 3) / 4; e.ngroups8 += (h->h_cap[r] + 7) / 8; }
+        }
         const int rg = train ? 0 : h->rg_mode(e.ntiles);     // the node launch of this layer follows (partial-row grouping)
         h->last_family.resize(c.n_convs);
         h->last_family[l] = rg ? 4 * rg : ((!train && e.ntiles <= ((last || pruned) ? std::max(h->coop_edge_max, h->coop2_edge_max) : std::max(h->coop_edge_max, h->coop2_dense_max))) ? 128 : 32);
-        if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, l == 0, rg, s); }
+        if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, s); }
         else if (e.ntiles <= h->coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
         else if (e.ntiles <= ((last || pruned) ? h->coop2_edge_max : h->coop2_dense_max) && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop2(&e, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
@@ -620,9 +652,9 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
                 hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
                 hp.eps_h = eps_h; hp.eps_x = eps_x;
-                { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node(&n, &hp, l == 0, rgn, s); }
+                { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node(&n, &hp, enc_fly ? &ep : nullptr, l == 0, rgn, s); }
                 head_done = true;
-            } else { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_rg_node(&n, nullptr, l == 0, rgn, s); }
+            } else { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_rg_node(&n, nullptr, enc_fly ? &ep : nullptr, l == 0, rgn, s); }
         }
         else if (last && !train && h->fuse_head && n.ntiles <= h->coop_node_max && h->n_head_tiles == n.ntiles) {
             // last layer (pharm tiles only) + noise head in one launch: the layer output stays in registers
@@ -645,6 +677,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
     hp.eps_h = eps_h; hp.eps_x = eps_x;
     if (!head_done) { ProfScope ps(h, pf_handle::K_HEAD, s); if (hp.ntiles <= h->coop_node_max) pfk_noise_head_coop(&hp, s); else pfk_noise_head(&hp, s); }
+    h->edges_built = false;                 // whoever moves the coordinates next decides (pf_denoise_step rebuilds)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return PF_OK;
@@ -1098,6 +1131,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     PF_HIP(h, hipStreamSynchronize(s));
     h->have_batch = true;
     h->sampling = false;
+    h->edges_built = false;
     return PF_OK;
 }
 
@@ -1144,6 +1178,7 @@ int64_t pf_build_pp_edges(pf_handle* h, int32_t B, const int32_t* prot_ptr, cons
 }
 
 static int load_state(pf_handle* h, const float* dev_prot_x, const float* dev_pharm_x, const float* dev_pharm_h, hipStream_t s) {
+    h->edges_built = false;
     if (dev_prot_x) pfk_load_coords(dev_prot_x, h->d_xn, h->Np, h->d_gid, nullptr, 0.f, s);
     if (dev_pharm_x) pfk_load_coords(dev_pharm_x, h->d_xn + h->Np, h->Nf, h->d_gid, nullptr, 0.f, s);
     if (dev_pharm_h) pfk_copy(dev_pharm_h, h->d_pharm_h, (size_t)h->Nf * h->cfg.pharm_nf, s);
@@ -1173,6 +1208,7 @@ int pf_sample_begin(pf_handle* h, const float* dev_init_pharm_com, const float* 
     pfk_load_coords(h->d_prot_x0, h->d_xn, h->Np, h->d_gid, shift, -1.f, s);
     pfk_load_noise0(dev_noise0, h->d_xn + h->Np, h->d_pharm_h, h->Nf, h->cfg.pharm_nf, s);  // :455-456
     h->sampling = true;
+    h->edges_built = false;
     return PF_OK;
 }
 
@@ -1191,7 +1227,11 @@ int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noi
     sp.nf = h->cfg.pharm_nf;
     sp.a_ts = coef->alpha_t_given_s; sp.var = coef->var_terms; sp.sigma = coef->sigma;
     sp.ep_zt = coef->ep_zt; sp.ep_pred = coef->ep_pred; sp.ep_coord = ep_coord; sp.ep_feat = ep_feat;
-    { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_update(&sp, s); }
+    if (encoders_on_the_fly(h)) {           // update + the edges of the next dynamics call in one launch
+        const BuildParams bp = build_params(h);
+        { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_build(&sp, &bp, s); }
+        h->edges_built = true;
+    } else { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_update(&sp, s); }
     return PF_OK;
 }
 
@@ -1298,7 +1338,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     e.rbf_inv_sigma = 1.0f / (c.rbf_dmax / (float)c.rbf_dim);
     for (int et = 0; et < 4; ++et) e.rg[et] = h->d_w + h->rg_msg[(size_t)layer * 4 + et];
     const int rg = h->rg_mode(e.ntiles);                  // same choice as run_dynamics
-    if (rg) pfk_rg_edge(&e, 0, rg, s);
+    if (rg) pfk_rg_edge(&e, nullptr, 0, rg, s);
     else if (e.ntiles <= h->coop_edge_max) pfk_edge_msg_coop(&e, 0, s); else pfk_edge_msg(&e, 0, s);
     NodeParams n{};
     n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles; n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
@@ -1313,7 +1353,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     n.n_upd = c.n_update_gvps;
     n.grp = rg ? 4 * rg : 32;
     for (int nt = 0; nt < 2; ++nt) n.rg_upd[nt] = h->d_w + h->rg_upd[(size_t)layer * 2 + nt];
-    if (rg) pfk_rg_node(&n, nullptr, 0, std::max(1, h->rg_mode(n.ntiles)), s);
+    if (rg) pfk_rg_node(&n, nullptr, nullptr, 0, std::max(1, h->rg_mode(n.ntiles)), s);
     else if (n.ntiles <= h->coop_node_max) pfk_node_update_coop(&n, 0, s); else pfk_node_update(&n, 0, s);
     pfk_copy(h->d_h[1], ohp, Np * PF_S, s);
     pfk_copy(h->d_h[1] + Np * PF_S, ohf, Nf * PF_S, s);

@@ -1257,41 +1257,90 @@ __device__ __forceinline__ float sqdist_rn(const float4 a, const float4 b) {
 __device__ __forceinline__ unsigned long long dkey(const float d2, const int idx) {
     return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)idx;
 }
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const unsigned long long other = __shfl_xor(k, o);
-        k = other < k ? other : k;
-    }
-    return k;
+// wave-wide minimum of 64-bit keys on the DPP network (no LDS round trips): inclusive min-scan inside each row of 16
+// lanes (row_shr 1, 2, 4, 8), then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast15) and lane 31 into the upper
+// half (row_bcast31); lane 63 holds the result.  Lanes without a source keep `old` = all ones, the identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_min_u64(const unsigned long long k) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)(unsigned int)k, CTRL, ROW_MASK, 0xf, false);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)(unsigned int)(k >> 32), CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return o < k ? o : k;
 }
-// exclusive scan of one value per thread over a 256-thread block; returns this thread's offset,
-// *total receives the block total.  scratch: 256 x 8 B of LDS.  The value packs three counters
-// (bits 0-15, 16-27, 28-63) so that one scan serves the fp edges, the active-atom list and its pp in-edges.
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k) {
+    k = dpp_min_u64<0x111, 0xf>(k);
+    k = dpp_min_u64<0x112, 0xf>(k);
+    k = dpp_min_u64<0x114, 0xf>(k);
+    k = dpp_min_u64<0x118, 0xf>(k);
+    k = dpp_min_u64<0x142, 0xa>(k);
+    k = dpp_min_u64<0x143, 0xc>(k);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)k, 63);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(k >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// inclusive wave scan (sum) of a 32-bit value on the DPP network, same pattern
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned int dpp_add_u32(const unsigned int v) {
+    return v + (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned int wave_incl_scan_u32(unsigned int v) {
+    v = dpp_add_u32<0x111, 0xf>(v);
+    v = dpp_add_u32<0x112, 0xf>(v);
+    v = dpp_add_u32<0x114, 0xf>(v);
+    v = dpp_add_u32<0x118, 0xf>(v);
+    v = dpp_add_u32<0x142, 0xa>(v);
+    v = dpp_add_u32<0x143, 0xc>(v);
+    return v;
+}
+// exclusive scan of one value per thread over a 256-thread block; returns this thread's offset, *total receives the
+// block total.  The value packs three counters (bits 0-15, 16-27, 28-63: the fp edges, the active-atom list and its pp
+// in-edges), scanned as two 32-bit halves (low: two 16/12-bit counters that cannot carry into each other at these
+// sizes; high part: bits 28-63 shifted down) by wave-level DPP scans and one exchange of the four wave totals in LDS
+// (scratch: >= 8 x 8 B).
 __device__ __forceinline__ unsigned long long block_excl_scan(const unsigned long long val, unsigned long long* scratch,
                                                               unsigned long long* total) {
-    const int tid = threadIdx.x;
-    scratch[tid] = val;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned int lo = (unsigned int)(val & 0xfffffffull), hi = (unsigned int)(val >> 28);
+    const unsigned int slo = wave_incl_scan_u32(lo), shi = wave_incl_scan_u32(hi);
+    if (lane == 63) scratch[wave] = (unsigned long long)slo | ((unsigned long long)shi << 28);
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const unsigned long long add = tid >= o ? scratch[tid - o] : 0ull;
-        __syncthreads();
-        scratch[tid] += add;
-        __syncthreads();
+    unsigned long long before = 0ull, all = 0ull;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned long long t = scratch[w];
+        if (w < wave) before += t;
+        all += t;
     }
-    const unsigned long long incl = scratch[tid];
-    *total = scratch[255];
+    *total = all;
     __syncthreads();
-    return incl - val;
+    return before + ((unsigned long long)slo | ((unsigned long long)shi << 28)) - val;
 }
 
 // Protein side of the dynamic edges of one graph, destination-major: the fp edges (sources = the pharm nodes
 // that reference atom c, ascending) and -- receptive-field pruning, see DESIGN.md -- the list of ACTIVE atoms
 // (atoms that are the source of a pf edge, the only protein rows the last conv layer reads) together with a
 // compact copy of their static pp in-edges.  `refs(c, visit)` calls visit(fl) for every referencing pharm node.
+// static pp in-edges of this thread's atom of the first 256-atom chunk, fetched BEFORE the neighbour search (the
+// loads depend only on the static graph): emit_prot_side then only stores.  Atoms with more than 16 in-edges and
+// later chunks take the load-and-store path.
+struct PpPrefetch {
+    int st, deg;
+    int src[16];
+};
+__device__ __forceinline__ void pp_prefetch(const BuildParams& p, const int p0, const int Np, PpPrefetch& f) {
+    f.st = 0; f.deg = 0;
+    const int c = threadIdx.x;
+    if (p.act_ids && c < Np) {
+        f.st = p.in_start[p.N + p0 + c];
+        f.deg = p.in_cnt[p.N + p0 + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) f.src[k] = (p.act_ids && c < Np) ? p.esrc[f.st + min(k, max(f.deg - 1, 0))] : 0;
+}
+
 template <typename Refs>
 __device__ __forceinline__ void emit_prot_side(const BuildParams& p, const int g, const int p0, const int Np, const int GF,
-                                               unsigned long long* scratch, Refs refs) {
+                                               unsigned long long* scratch, const PpPrefetch& pre, Refs refs) {
     const int tid = threadIdx.x;
     int* in_start0 = p.in_start;             int* in_cnt0 = p.in_cnt;
     const int* in_start1 = p.in_start + p.N; const int* in_cnt1 = p.in_cnt + p.N;
@@ -1304,7 +1353,7 @@ __device__ __forceinline__ void emit_prot_side(const BuildParams& p, const int g
         int my = 0;
         if (c < Np) refs(c, [&](int) { ++my; });
         const int act = (my > 0 && p.act_ids) ? 1 : 0;
-        const int deg = act ? in_cnt1[p0 + c] : 0;
+        const int deg = act ? (c0 == 0 ? pre.deg : in_cnt1[p0 + c]) : 0;
         unsigned long long tot;
         const unsigned long long o = base + block_excl_scan((unsigned long long)my | ((unsigned long long)act << 16) |
                                                             ((unsigned long long)deg << 28), scratch, &tot);
@@ -1315,12 +1364,19 @@ __device__ __forceinline__ void emit_prot_side(const BuildParams& p, const int g
             if (my) refs(c, [&](int fl) { p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; });
             if (act) {
                 p.act_ids[reg_act + (int)((o >> 16) & 0xfffu)] = p0 + c;
-                const int d0 = reg_pa + (int)(o >> 28), s0 = in_start1[p0 + c];
+                const int d0 = reg_pa + (int)(o >> 28), s0 = c0 == 0 ? pre.st : in_start1[p0 + c];
                 in_start2[p0 + c] = d0;
                 in_cnt2[p0 + c] = deg;
+                int i0 = 0;
+                if (c0 == 0) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (k < deg) { p.esrc[d0 + k] = pre.src[k]; p.edst[d0 + k] = p0 + c; }
+                    i0 = 16;
+                }
                 // eight loads in flight, then eight stores (source and destination alias the same array, so a
                 // plain copy loop would serialise on memory latency)
-                for (int i = 0; i < deg; i += 8) {
+                for (int i = i0; i < deg; i += 8) {
                     int tmp[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) tmp[k] = p.esrc[s0 + min(i + k, deg - 1)];
@@ -1352,6 +1408,8 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
     int* in_start0 = p.in_start;          int* in_cnt0 = p.in_cnt;            // slot 0: ff (pharm) / fp (prot)
     int* in_start1 = p.in_start + p.N;    int* in_cnt1 = p.in_cnt + p.N;      // slot 1: pf (pharm) / pp (prot)
     if (tid < Nf) fx[tid] = p.xn[GF + tid];
+    PpPrefetch pre;
+    pp_prefetch(p, p0, Np, pre);                      // in flight under the neighbour searches
     __syncthreads();
     // ------------------------------------------------------------------ ff (pharm -> pharm)
     const int reg_ff = p.reg[0 * p.B + g];
@@ -1444,7 +1502,7 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
         if (tid == 0) { p.dyn_cnt[1 * p.B + g] = Nf * kk; p.dyn_cnt[2 * p.B + g] = Nf * kk; }
         __syncthreads();
         // fp = pf reversed, destination-major over the protein atoms of this graph (+ active atoms, their pp edges)
-        emit_prot_side(p, g, p0, Np, GF, scratch, [&](const int c, auto visit) {
+        emit_prot_side(p, g, p0, Np, GF, scratch, pre, [&](const int c, auto visit) {
             for (int fl = 0; fl < Nf; ++fl)
                 for (int r = 0; r < kk; ++r)
                     if (knn_idx[fl * PF_MAXK + r] == c) visit(fl);
@@ -1485,7 +1543,7 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
                 e += __popcll(m);
             }
         }
-        emit_prot_side(p, g, p0, Np, GF, scratch, [&](const int c, auto visit) {
+        emit_prot_side(p, g, p0, Np, GF, scratch, pre, [&](const int c, auto visit) {
             const float4 xc = p.xn[p0 + c];
             for (int fl = 0; fl < Nf; ++fl)
                 if (sqdist_rn(fx[fl], xc) < p.r2_pf) visit(fl);
@@ -1696,6 +1754,14 @@ __device__ __forceinline__ void step_update_body(const StepParams& p, const int 
     }
 }
 __global__ __launch_bounds__(256) void k_step_update(const StepParams p) { step_update_body(p, blockIdx.x); }
+// p(z_s | z_t) update of graph g and, on the new coordinates, the dynamic edges of the NEXT dynamics call: both are
+// one-workgroup-per-graph kernels, and with the encoders computed on the fly by the row-group kernels the edge build is
+// all that a step's first launch would do -- one launch less per denoising step.
+__global__ __launch_bounds__(256) void k_step_build(const StepParams sp, const BuildParams bp) {
+    step_update_body(sp, blockIdx.x);
+    __syncthreads();                                   // this workgroup's coordinate writes are visible to all its waves
+    build_body(bp, blockIdx.x);
+}
 
 // out[i] = xn[base+i] + (add[g] - sub[g]) ; used for the final frame of reference
 __global__ void k_export_coords(const float4* xn, const int base, const int n, const int* gid, const float* add,
@@ -1825,6 +1891,10 @@ void pfk_scale_copy(const float* src, float* dst, size_t n, float sc, hipStream_
 void pfk_segment_mean(const float4* xn, const int* ptr, int base, int B, float* out, hipStream_t s) {
     if (B == 0) return;
     hipLaunchKernelGGL(k_segment_mean, dim3(B), dim3(64), 0, s, xn, ptr, base, out);
+}
+void pfk_step_build(const StepParams* sp, const BuildParams* bp, hipStream_t s) {
+    if (sp->B == 0) return;
+    hipLaunchKernelGGL(k_step_build, dim3(sp->B), dim3(256), 0, s, *sp, *bp);
 }
 void pfk_step_update(const StepParams* p, hipStream_t s) {
     if (p->B == 0) return;

@@ -75,6 +75,11 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f(const float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
+// integer DPP moves for wave scans: lanes without a source (or rows outside ROW_MASK) read 0
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(const int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_ir(const int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
 // sum over q (lanes l, l^4, l^8, l^12 of a 16-lane row): row_ror 4 and 8
 __device__ __forceinline__ float qsum(float v) {
     v += dpp_f<0x124>(v);
@@ -471,6 +476,54 @@ __device__ __forceinline__ void rg_layernorm(pf_gcf lw, pf_gcf lb, float (&X)[RG
     }
 }
 
+// Scalar encoders on the fly (dynamics_gvp.py:107-117, 143-151): h = LayerNorm(SiLU(W [feat, t] + b)) of the rows' nodes,
+// straight into the SA layout (lane 4a+i: features 8a..8a+7 of row i).  With layer 0 on the row-group kernels only the
+// rows that layer actually reads are ever encoded -- a few thousand of the 8 k nodes of a pruned config-2 step -- and the
+// [N][128] encoder output is neither written nor gathered.  nt (0 prot, 1 pharm) is wave-uniform.
+template <int RG>
+__device__ __forceinline__ void rg_encode(const EncodeParams& ep, const int nt, const int (&node)[RG], float (&X)[RG][8], const int lane) {
+    const int a = lane >> 2;
+    const int nf = nt ? ep.pharm_nf : ep.rec_nf;
+    pf_gcf Wt = (pf_gcf)ep.w[nt] + 8 * a;                            // [nf + 1][128], input-major
+    const f32x4 b0 = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.b[nt])[2 * a], b1 = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.b[nt])[2 * a + 1];
+    pf_gcf in[RG];
+    float tt[RG];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        in[r] = nt ? (pf_gcf)ep.pharm_h + (size_t)(node[r] - ep.Np) * nf : (pf_gcf)ep.prot_h0 + (size_t)node[r] * nf;
+        tt[r] = ep.t ? ((pf_gcf)ep.t)[((const int PF_AS1*)ep.gid)[node[r]]] : ep.t_scalar;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { X[r][m] = b0[m]; X[r][4 + m] = b1[m]; }
+    }
+    for (int k = 0; k <= nf; ++k) {
+        const f32x4 w0 = reinterpret_cast<const f32x4 PF_AS1*>(Wt + k * PF_S)[0], w1 = reinterpret_cast<const f32x4 PF_AS1*>(Wt + k * PF_S)[1];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const float x = k < nf ? in[r][k] : tt[r];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { X[r][m] = fmaf(w0[m], x, X[r][m]); X[r][4 + m] = fmaf(w1[m], x, X[r][4 + m]); }
+        }
+    }
+    const f32x4 lw0 = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.ln_w[nt])[2 * a], lw1 = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.ln_w[nt])[2 * a + 1];
+    const f32x4 lb0 = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.ln_b[nt])[2 * a], lb1 = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.ln_b[nt])[2 * a + 1];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { X[r][m] = siluf_(X[r][m]); sum += X[r][m]; }
+        const float mean = asum(sum) * (1.0f / 128.0f);
+        float var = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { const float c = X[r][m] - mean; var = fmaf(c, c, var); }
+        const float rstd = rsqf_(asum(var) * (1.0f / 128.0f) + 1e-5f);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            X[r][m] = (X[r][m] - mean) * rstd * lw0[m] + lb0[m];
+            X[r][4 + m] = (X[r][4 + m] - mean) * rstd * lw1[m] + lb1[m];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Edge messages (gvp.py:472-485, 540-551): a wave = 4*RG consecutive edge slots of one tile of the list.  Slots are
 // sorted by destination, so the rows of one destination are consecutive: the wave adds them up in slot order (the
@@ -478,44 +531,78 @@ __device__ __forceinline__ void rg_layernorm(pf_gcf lw, pf_gcf lb, float (&X)[RG
 // run's last slot -- what the node kernels read (NodeParams::grp = 4*RG).
 // ---------------------------------------------------------------------------------------------
 template <bool L0, int RG>
-__global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p) {
+__global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p, const EncodeParams ep) {
     constexpr int D = RgDepth<RG>::D;
     __shared__ RgLds lds[RG];
     constexpr int G = 4 * RG, PER = 32 / G;
     const int lane = threadIdx.x;
-    const int bid = blockIdx.x;
-    const EdgeTile t = p.tiles[bid / PER];
-    int nvalid = t.n;
-    if (t.cnt_idx >= 0) nvalid = min(nvalid, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
-    const int base = (bid % PER) * G;
-    const int nv = __builtin_amdgcn_readfirstlane(min(G, nvalid - base));
-    if (nv <= 0) return;                               // wave-uniform
-    const int et = __builtin_amdgcn_readfirstlane(t.et);
+    int e0, nv, et;
+    if (p.nreg > 0) {
+        // Compact work list (launches whose edges all live in per-(etype, graph) regions of run-time length): wave w
+        // takes the w-th group of G slots, counting only the groups that hold edges -- the busy waves are the first
+        // ones of the grid and spread evenly over the chip, instead of sitting wherever a region's tiles fall.  The
+        // region of group w is found by a wave scan over the region lengths (64 regions per pass).
+        const int w = blockIdx.x;
+        int first = 0, rsel = -1, cnt = 0;
+        for (int r0 = 0; r0 < p.nreg && rsel < 0; r0 += 64) {
+            const int r = r0 + lane;
+            const int c = r < p.nreg ? p.dyn_cnt[r] : 0;
+            const int ng = (c + G - 1) / G;
+            int incl = ng;
+            incl += dpp_i<0x111>(incl); incl += dpp_i<0x112>(incl); incl += dpp_i<0x114>(incl); incl += dpp_i<0x118>(incl);
+            incl += dpp_ir<0x142, 0xa>(incl); incl += dpp_ir<0x143, 0xc>(incl);
+            incl += first;
+            const unsigned long long m = __ballot(incl > w);
+            if (m) {
+                const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                rsel = r0 + l;
+                first = __builtin_amdgcn_readlane(incl - ng, l);
+                cnt = __builtin_amdgcn_readlane(c, l);
+            } else first = __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (rsel < 0) return;                          // wave-uniform: beyond the last group
+        const int loc = (w - first) * G;
+        e0 = p.reg[rsel] + loc;
+        nv = __builtin_amdgcn_readfirstlane(min(G, cnt - loc));
+        et = rsel / p.regB;
+        et = et == 3 ? (int)ET_PP : et;                // fourth region kind: pp edges into the active atoms
+    } else {
+        const int bid = blockIdx.x;
+        const EdgeTile t = p.tiles[bid / PER];
+        int nvalid = t.n;
+        if (t.cnt_idx >= 0) nvalid = min(nvalid, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
+        const int base = (bid % PER) * G;
+        nv = __builtin_amdgcn_readfirstlane(min(G, nvalid - base));
+        if (nv <= 0) return;                           // wave-uniform
+        et = __builtin_amdgcn_readfirstlane(t.et);
+        e0 = t.e0 + base;
+    }
     RgStamp stamp;
     stamp(lane);                                       // kernel start
     RgRing<D> ring;
     ring_start(ring, p.rg[et], lane);                  // in flight under the gather
     const int a = lane >> 2, i = lane & 3, g = lane >> 4, q = a & 3, u = lane & 15;
-    const int e0 = t.e0 + base;
     float X[RG][8], Va[RG][4], R[RG], XH[RG];
-    int dstv[RG];
+    int dstv[RG], srcv[RG];
     const float mu_step = (p.rbf_mu[PF_R - 1] - p.rbf_mu[0]) * (1.0f / (float)(PF_R - 1));
     const float mu_a = fmaf((float)a, mu_step, p.rbf_mu[0]);
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
         const int e = e0 + min(4 * r + i, nv - 1);
         const int src = p.esrc[e], dst = p.edst[e];
-        dstv[r] = dst;
+        dstv[r] = dst; srcv[r] = src;
         const float4 xs = p.xn[src], xd = p.xn[dst];
         const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
         const float d = sqrtf_(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
         const float ze = (d - mu_a) * p.rbf_inv_sigma;
         R[r] = __expf(-(ze * ze));
         XH[r] = (g == 0 ? dx : (g == 1 ? dy : (g == 2 ? dz : 0.f))) * rcpf_(d);
-        const f32x4 PF_AS1* hp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.h + (size_t)src * PF_S) + 2 * a;
-        const f32x4 x0 = hp[0], x1 = hp[1];
+        if (!(L0 && ep.w[0])) {
+            const f32x4 PF_AS1* hp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.h + (size_t)src * PF_S) + 2 * a;
+            const f32x4 x0 = hp[0], x1 = hp[1];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { X[r][m] = x0[m]; X[r][4 + m] = x1[m]; }
+            for (int m = 0; m < 4; ++m) { X[r][m] = x0[m]; X[r][4 + m] = x1[m]; }
+        }
         if constexpr (!L0) {
             pf_gcf vp = (pf_gcf)p.v + (size_t)src * 48 + (g < 3 ? g : 0) + 3 * q;
 #pragma unroll
@@ -525,6 +612,7 @@ __global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p) {
             for (int tt = 0; tt < 4; ++tt) Va[r][tt] = 0.f;
         }
     }
+    if (L0 && ep.w[0]) rg_encode<RG>(ep, (et == ET_FF || et == ET_FP) ? 1 : 0, srcv, X, lane);   // sources: pharm for ff / fp
     f32x4 slo[RG], shi[RG], Vd[RG];
     RgCarry<RG> carry;
     rg_gvp<SpecMsg0, RG, D, 0, L0>(ring, X, Va, R, XH, slo, shi, carry, lds, lane, stamp);
@@ -561,7 +649,7 @@ __global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p) {
 // the inference path (pharm tiles): the noise head (dynamics_gvp.py:37-42) runs on the registers right away.
 // ---------------------------------------------------------------------------------------------
 template <bool L0, int RG, bool HEAD>
-__global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadParams hp) {
+__global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadParams hp, const EncodeParams ep) {
     constexpr int D = RgDepth<RG>::D;
     __shared__ RgLds lds[RG];
     constexpr int G = 4 * RG, PER = 32 / G;
@@ -655,10 +743,15 @@ __global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadPa
         float inv_norm = 1.0f;
         if (p.norm_mode == 1) inv_norm = 1.0f / p.norm_value;
         else if (p.norm_mode == 2) inv_norm = 1.0f / p.gnorm[nt * p.B + p.gid[n]];
-        const f32x4 PF_AS1* hpn = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.h_in + (size_t)n * PF_S) + 2 * a;
-        const f32x4 h0 = hpn[0], h1 = hpn[1];
+        if (L0 && ep.w[0]) {                           // residual input encoded below; keep the scaled aggregate
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { X[r][m] = fmaf(as[m], inv_norm, h0[m]); X[r][4 + m] = fmaf(as[4 + m], inv_norm, h1[m]); }
+            for (int m = 0; m < 8; ++m) X[r][m] = as[m] * inv_norm;
+        } else {
+            const f32x4 PF_AS1* hpn = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.h_in + (size_t)n * PF_S) + 2 * a;
+            const f32x4 h0 = hpn[0], h1 = hpn[1];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { X[r][m] = fmaf(as[m], inv_norm, h0[m]); X[r][4 + m] = fmaf(as[4 + m], inv_norm, h1[m]); }
+        }
         if constexpr (!L0) {
             pf_gcf vp = (pf_gcf)p.v_in + (size_t)n * 48 + gc + 3 * q;
 #pragma unroll
@@ -669,6 +762,14 @@ __global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadPa
         }
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) Va[r][tt] = g < 3 ? Va[r][tt] : 0.f;
+    }
+    if (L0 && ep.w[0]) {
+        float H[RG][8];
+        rg_encode<RG>(ep, nt, nid, H, lane);
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) X[r][m] += H[r][m];
     }
     stamp(lane);                                       // aggregation done
     rg_layernorm<RG>(nw.ln1_w, nw.ln1_b, X, Va, lane);
@@ -759,22 +860,25 @@ int pfk_rg_set_stamp_buffer(unsigned long long* dev) { g_rg_stamp_host_buf = dev
 void pfk_rg_set_stamp_which(int which) { g_rg_stamp_which = which; g_rg_stamp_seen = 0; }
 #endif
 // rows per wave: 8 (RG = 2) once there are enough groups to fill the chip, else 4
-void pfk_rg_edge(const EdgeParams* p, int layer0, int rg, hipStream_t s) {
+void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int rg, hipStream_t s) {
     if (p->ntiles == 0) return;
 #ifdef PF_STAMPS
     rg_stamp_arm(s);
 #endif
     const int per = 32 / (4 * rg);
-    const int grid = p->ntiles * per;
+    const int grid = p->nreg > 0 ? (rg == 1 ? p->ngroups4 : p->ngroups8) : p->ntiles * per;
+    if (grid == 0) return;
+    const EncodeParams noenc{};
+    const EncodeParams& ep = (layer0 && enc) ? *enc : noenc;      // layer 0: encode the gathered rows on the fly
     if (rg == 1) {
-        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 1>), dim3(grid), dim3(64), 0, s, *p);
-        else hipLaunchKernelGGL((k_rg_edge<false, 1>), dim3(grid), dim3(64), 0, s, *p);
+        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 1>), dim3(grid), dim3(64), 0, s, *p, ep);
+        else hipLaunchKernelGGL((k_rg_edge<false, 1>), dim3(grid), dim3(64), 0, s, *p, ep);
     } else {
-        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 2>), dim3(grid), dim3(64), 0, s, *p);
-        else hipLaunchKernelGGL((k_rg_edge<false, 2>), dim3(grid), dim3(64), 0, s, *p);
+        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 2>), dim3(grid), dim3(64), 0, s, *p, ep);
+        else hipLaunchKernelGGL((k_rg_edge<false, 2>), dim3(grid), dim3(64), 0, s, *p, ep);
     }
 }
-void pfk_rg_node(const NodeParams* p, const HeadParams* hp, int layer0, int rg, hipStream_t s) {
+void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, hipStream_t s) {
     if (p->ntiles == 0) return;
 #ifdef PF_STAMPS
     rg_stamp_arm(s);
@@ -784,7 +888,9 @@ void pfk_rg_node(const NodeParams* p, const HeadParams* hp, int layer0, int rg, 
     const bool head = hp != nullptr;
     const HeadParams& h = head ? *hp : none;
     const int grid = p->ntiles * per;
-#define PF_RG_NODE(L0_, RG_, HEAD_) hipLaunchKernelGGL((k_rg_node<L0_, RG_, HEAD_>), dim3(grid), dim3(64), 0, s, *p, h)
+    const EncodeParams noenc{};
+    const EncodeParams& ep = (layer0 && enc) ? *enc : noenc;
+#define PF_RG_NODE(L0_, RG_, HEAD_) hipLaunchKernelGGL((k_rg_node<L0_, RG_, HEAD_>), dim3(grid), dim3(64), 0, s, *p, h, ep)
     if (rg == 1) {
         if (head) { if (layer0) PF_RG_NODE(true, 1, true); else PF_RG_NODE(false, 1, true); }
         else { if (layer0) PF_RG_NODE(true, 1, false); else PF_RG_NODE(false, 1, false); }
