@@ -37,7 +37,7 @@ void pfk_copy(const float* src, float* dst, size_t n, hipStream_t s);
 void pfk_scale_copy(const float* src, float* dst, size_t n, float sc, hipStream_t s);
 void pfk_segment_mean(const float4* xn, const int* ptr, int base, int B, float* out, hipStream_t s);
 void pfk_step_update(const StepParams* p, hipStream_t s);
-void pfk_step_build(const StepParams* sp, const BuildParams* bp, hipStream_t s);
+void pfk_step_build(const StepParams* sp, const BuildParams* bp, int fast, hipStream_t s);
 void pfk_export_coords(const float4* xn, int base, int n, const int* gid, const float* add, const float* sub,
                        float* out, hipStream_t s);
 void pfk_bwd_head(const BwdHeadParams* p, int nblocks, hipStream_t s);
@@ -127,6 +127,7 @@ struct pf_handle {
           *d_v[2] = {nullptr, nullptr}, *d_msg_s = nullptr, *d_msg_v = nullptr, *d_eps_h = nullptr, *d_eps_x = nullptr,
           *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr, *d_pre = nullptr;
     bool sampling = false;
+    int max_np = 0;                         // largest pocket of the batch
     bool edges_built = false;               // the dynamic edges of the current coordinates exist (built by k_step_build)
     // launches with at most this many tiles use the 4-wave cooperative kernels (latency-bound regime)
     // Edge-message launches: up to coop_edge_max tiles (one per CU) the 4-wave kernel with next-GVP weight prefetch;
@@ -150,6 +151,7 @@ struct pf_handle {
         return rows >= rg2_rows_min ? 2 : 1;
     }
     bool enc_on_the_fly = true;             // PFDYN_NO_ENC_FLY=1: always launch the encoders
+    bool step_build_fast = true;            // PFDYN_NO_FAST_BUILD=1: the generic update + build bodies
     bool rg_compact = true;                 // PFDYN_NO_COMPACT=1: row-group edge launches walk the tile lists
     bool fuse_head = true;                  // last conv layer's node update + noise head in one launch (PFDYN_NO_FUSE_HEAD=1: separate)
     void init_tuning() {
@@ -161,6 +163,7 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_NO_PRUNE")) prune = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_ENC_FLY")) enc_on_the_fly = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_COMPACT")) rg_compact = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_NO_FAST_BUILD")) step_build_fast = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_RG_ROWS_MAX")) rg_rows_max = atoi(e);
         if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = atoi(e);
     }
@@ -977,7 +980,9 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     const int Np = h->Np, Nf = h->Nf, N = h->N;
     // ---- host-side tables
     std::vector<int> gid(N);
+    h->max_np = 0;
     for (int g = 0; g < B; ++g) {
+        h->max_np = std::max(h->max_np, prot_ptr[g + 1] - prot_ptr[g]);
         for (int i = prot_ptr[g]; i < prot_ptr[g + 1]; ++i) gid[i] = g;
         for (int i = pharm_ptr[g]; i < pharm_ptr[g + 1]; ++i) gid[Np + i] = g;
     }
@@ -1229,7 +1234,9 @@ int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noi
     sp.ep_zt = coef->ep_zt; sp.ep_pred = coef->ep_pred; sp.ep_coord = ep_coord; sp.ep_feat = ep_feat;
     if (encoders_on_the_fly(h)) {           // update + the edges of the next dynamics call in one launch
         const BuildParams bp = build_params(h);
-        { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_build(&sp, &bp, s); }
+        // kNN pf edges and pockets of at most 512 atoms: the latency-optimised kernel (one atom per thread)
+        const int fast = (h->cfg.pf_k > 0 && h->max_np <= 512 && h->step_build_fast) ? 1 : 0;
+        { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_build(&sp, &bp, fast, s); }
         h->edges_built = true;
     } else { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_update(&sp, s); }
     return PF_OK;

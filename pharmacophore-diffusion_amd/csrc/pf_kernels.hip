@@ -1250,6 +1250,12 @@ __device__ __forceinline__ void encode_group(const EncodeParams& p, const int nt
 // oracle/pf_oracle.py (strict d^2 < r^2; kNN ordered by (d^2, index)).
 // d^2 is evaluated as (dx*dx + dy*dy) + dz*dz with one rounding per operation.
 // ---------------------------------------------------------------------------------------------
+#ifdef PF_STAMPS
+__device__ unsigned long long* g_build_stamps = nullptr;      // [B][32]
+#define BSTAMP(k) do { if (threadIdx.x == 0 && g_build_stamps) g_build_stamps[blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BSTAMP(k)
+#endif
 __device__ __forceinline__ float sqdist_rn(const float4 a, const float4 b) {
     const float dx = __fsub_rn(a.x, b.x), dy = __fsub_rn(a.y, b.y), dz = __fsub_rn(a.z, b.z);
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
@@ -1407,6 +1413,7 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
     const int GF = p.Np_tot + f0;                     // global id of this graph's pharm node 0
     int* in_start0 = p.in_start;          int* in_cnt0 = p.in_cnt;            // slot 0: ff (pharm) / fp (prot)
     int* in_start1 = p.in_start + p.N;    int* in_cnt1 = p.in_cnt + p.N;      // slot 1: pf (pharm) / pp (prot)
+    BSTAMP(8);                                        // build start
     if (tid < Nf) fx[tid] = p.xn[GF + tid];
     PpPrefetch pre;
     pp_prefetch(p, p0, Np, pre);                      // in flight under the neighbour searches
@@ -1457,6 +1464,7 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
         }
     }
     __syncthreads();   // cnt/off are reused below
+    BSTAMP(9);                                        // ff done
     // ------------------------------------------------------------------ pf (prot -> pharm)
     const int reg_pf = p.reg[1 * p.B + g];
     const int reg_fp = p.reg[2 * p.B + g];
@@ -1501,6 +1509,7 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
         }
         if (tid == 0) { p.dyn_cnt[1 * p.B + g] = Nf * kk; p.dyn_cnt[2 * p.B + g] = Nf * kk; }
         __syncthreads();
+        BSTAMP(10);                                   // kNN done
         // fp = pf reversed, destination-major over the protein atoms of this graph (+ active atoms, their pp edges)
         emit_prot_side(p, g, p0, Np, GF, scratch, pre, [&](const int c, auto visit) {
             for (int fl = 0; fl < Nf; ++fl)
@@ -1551,6 +1560,7 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
     }
     // per-graph normalisers for message_norm == 0 (gvp.py:504-507)
     __syncthreads();
+    BSTAMP(11);                                       // protein side emitted
     if (tid == 0 && p.norm_mode == 2) {
         const int cff = p.dyn_cnt[0 * p.B + g], cpf = p.dyn_cnt[1 * p.B + g], cfp = p.dyn_cnt[2 * p.B + g];
         p.gnorm[1 * p.B + g] = (float)(cff + cpf) / (float)Nf + 1.0f;
@@ -1757,7 +1767,269 @@ __global__ __launch_bounds__(256) void k_step_update(const StepParams p) { step_
 // p(z_s | z_t) update of graph g and, on the new coordinates, the dynamic edges of the NEXT dynamics call: both are
 // one-workgroup-per-graph kernels, and with the encoders computed on the fly by the row-group kernels the edge build is
 // all that a step's first launch would do -- one launch less per denoising step.
+// ---------------------------------------------------------------------------------------------
+// k_step_build_fast: the same update + edge build for the common shape (kNN pf edges, pockets of at most 512 atoms, one
+// atom per thread), organised around what a launch actually pays for here: every launch starts with cold caches (each
+// XCD's L2 is invalidated at kernel boundaries), a dependent global round trip costs ~2,000 cycles, and __syncthreads
+// drains every outstanding load.  The generic bodies above make ~10 dependent trips per graph (44 k cycles); this
+// kernel makes three: (A) the graph's pointers and regions, (B) every input row -- pharm state, eps, noise, protein
+// coordinates, the static in-edge descriptors -- (C) the static pp sources of the thread's atom.  The updated
+// coordinates stay in LDS for the neighbour searches (8 waves: one pharmacophore center each), and nothing is read back
+// from global memory.  Results are identical to k_step_build (same arithmetic, same orderings).
+// ---------------------------------------------------------------------------------------------
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for every global store
+// issued so far to be acknowledged (~2,000 cycles here), and nothing in this kernel reads its global stores back
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, const BuildParams p) {
+    constexpr int NT = 512, NW = NT / 64;
+    __shared__ float4 fx[PF_MAXF];                  // updated pharm coordinates (COM removed)
+    __shared__ float4 px[NT];                       // updated protein coordinates
+    __shared__ float red[NW][3];
+    __shared__ __attribute__((aligned(16))) int knn_idx[PF_MAXF * PF_MAXK];
+    __shared__ unsigned long long scratch[NW];
+    // active atoms in list order: first slot of their pp in-edges in the "pa" region, node id, static
+    // in-edge start, and the first 16 static sources (prefetched) -- the copy into the region is then done by ALL
+    // threads, one output slot each, with coalesced stores
+    __shared__ int a_d0[NT], a_node[NT], a_pst[NT];
+    __shared__ __attribute__((aligned(16))) int a_src[NT][16];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    BSTAMP(0);
+    // ---- (A) pointers and regions
+    const int p0 = p.prot_ptr[g], p1 = p.prot_ptr[g + 1];
+    const int f0 = p.pharm_ptr[g], f1 = p.pharm_ptr[g + 1];
+    const int Np = p1 - p0, Nf = f1 - f0;
+    const int GF = p.Np_tot + f0;
+    const int reg_ff = p.reg[0 * p.B + g], reg_pf = p.reg[1 * p.B + g], reg_fp = p.reg[2 * p.B + g], reg_pa = p.reg[3 * p.B + g];
+    const int reg_act = p.act_ids ? p.reg_act[g] : 0;
+    int* in_start0 = p.in_start;          int* in_cnt0 = p.in_cnt;
+    int* in_start1 = p.in_start + p.N;    int* in_cnt1 = p.in_cnt + p.N;
+    int* in_start2 = p.in_start + 2 * p.N; int* in_cnt2 = p.in_cnt + 2 * p.N;
+    // ---- (B) every input row of this thread
+    const bool isf = tid < Nf, isp = tid < Np;
+    float4 xf = make_float4(0.f, 0.f, 0.f, 0.f), xp = xf;
+    float ex[3] = {0.f, 0.f, 0.f}, nzx[3] = {0.f, 0.f, 0.f};
+    if (isf) {
+        xf = sp.xn[GF + tid];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { ex[c] = sp.eps_x[(size_t)(f0 + tid) * 3 + c]; nzx[c] = sp.noise[(size_t)(f0 + tid) * (3 + sp.nf) + c]; }
+    }
+    int pst = 0, pdeg = 0;
+    if (isp) {
+        xp = sp.xn[p0 + tid];
+        if (p.act_ids) { pst = in_start1[p0 + tid]; pdeg = in_cnt1[p0 + tid]; }
+    }
+    // feature update of the pharm nodes (independent of everything else): load, update, store
+    if (isf) {
+        for (int k = 0; k < sp.nf; ++k) {
+            const size_t o = (size_t)(f0 + tid) * sp.nf + k;
+            const float hv = sp.pharm_h[o], e = sp.eps_h[o];
+            const float mu = sp.ep_feat ? (sp.ep_zt * hv + sp.ep_pred * e) : (hv / sp.a_ts - sp.var * e);
+            sp.pharm_h[o] = mu + sp.sigma * sp.noise[(size_t)(f0 + tid) * (3 + sp.nf) + 3 + k];
+        }
+    }
+    // ---- (C) static pp sources of this thread's atom (used only if the atom turns out to be active)
+    int psrc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) psrc[k] = (isp && p.act_ids) ? p.esrc[pst + min(k, max(pdeg - 1, 0))] : 0;
+    // ---- coordinate update (pharmacodiff.py:397-426) and COM removal of pharm AND prot coordinates (:429)
+    float m[3] = {0.f, 0.f, 0.f};
+    if (isf) {
+        const float xi[3] = {xf.x, xf.y, xf.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float mu = sp.ep_coord ? (sp.ep_zt * xi[c] + sp.ep_pred * ex[c]) : (xi[c] / sp.a_ts - sp.var * ex[c]);
+            m[c] = mu + sp.sigma * nzx[c];
+        }
+    }
+    {   // per-graph mean in the summation order of step_update_body (thread-strided partial sums, xor butterfly, 4+4 waves)
+        float sx = m[0], sy = m[1], sz = m[2];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+        if (lane == 0) { red[wave][0] = sx; red[wave][1] = sy; red[wave][2] = sz; }
+    }
+    lds_barrier();
+    BSTAMP(8);
+    float com[3];
+    {
+        const float n = (float)max(Nf, 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) com[c] = Nf > 0 ? (((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) / n) : 0.f;
+    }
+    if (isf) {
+        const float4 v = make_float4(m[0] - com[0], m[1] - com[1], m[2] - com[2], 0.f);
+        fx[tid] = v;
+        sp.xn[GF + tid] = v;
+    }
+    if (isp) { xp.x -= com[0]; xp.y -= com[1]; xp.z -= com[2]; sp.xn[p0 + tid] = xp; }
+    px[tid] = xp;
+    lds_barrier();
+    // ---- ff (pharm -> pharm) on wave 0: counts, wave scan for the offsets, emission
+    const int kff = p.ff_k > 0 ? max(min(p.ff_k, Nf - 1), 0) : 0;
+    int ff_total = 0;                                 // valid in wave 0
+    if (wave == 0) {
+        int c = 0;
+        if (lane < Nf) {
+            if (p.ff_k > 0) c = kff;
+            else
+                for (int jn = 0; jn < Nf; ++jn)
+                    if (jn != lane && sqdist_rn(fx[jn], fx[lane]) < p.r2_ff) ++c;
+        }
+        const int incl = (int)wave_incl_scan_u32((unsigned int)c);
+        ff_total = __builtin_amdgcn_readlane(incl, 63);
+        if (lane == 0) p.dyn_cnt[0 * p.B + g] = ff_total;
+        if (lane < Nf) {
+            int e = reg_ff + incl - c;
+            in_start0[GF + lane] = e;
+            in_cnt0[GF + lane] = c;
+            if (p.ff_k > 0) {
+                unsigned long long prev = 0ull;
+                bool first = true;
+                for (int q = 0; q < kff; ++q) {
+                    unsigned long long best = ~0ull;
+                    for (int jn = 0; jn < Nf; ++jn) {
+                        if (jn == lane) continue;
+                        const unsigned long long k = dkey(sqdist_rn(fx[jn], fx[lane]), jn);
+                        if ((first || k > prev) && k < best) best = k;
+                    }
+                    prev = best; first = false;
+                    p.esrc[e] = GF + (int)(best & 0xffffffffu);
+                    p.edst[e] = GF + lane;
+                    ++e;
+                }
+            } else {
+                for (int jn = 0; jn < Nf; ++jn)
+                    if (jn != lane && sqdist_rn(fx[jn], fx[lane]) < p.r2_ff) { p.esrc[e] = GF + jn; p.edst[e] = GF + lane; ++e; }
+            }
+        }
+    }
+    BSTAMP(9);
+    // ---- pf (prot -> pharm): kNN, one center per wave, candidates (d^2, index) from LDS
+    const int kk = min(p.pf_k, Np);
+    for (int fl = wave; fl < Nf; fl += NW) {
+        const float4 q = fx[fl];
+        unsigned long long kc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            kc[i] = c < Np ? dkey(sqdist_rn(px[c], q), c) : ~0ull;
+        }
+        unsigned long long prev = 0ull;
+        for (int r = 0; r < kk; ++r) {
+            unsigned long long best = ~0ull;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if ((r == 0 || kc[i] > prev) && kc[i] < best) best = kc[i];
+            best = wave_min_u64(best);
+            prev = best;
+            if (lane == 0) {
+                const int pc = (int)(best & 0xffffffffu);
+                knn_idx[fl * PF_MAXK + r] = pc;
+                p.esrc[reg_pf + fl * kk + r] = p0 + pc;
+                p.edst[reg_pf + fl * kk + r] = GF + fl;
+            }
+        }
+        if (lane == 0) { in_start1[GF + fl] = reg_pf + fl * kk; in_cnt1[GF + fl] = kk; }
+    }
+    if (tid == 0) { p.dyn_cnt[1 * p.B + g] = Nf * kk; p.dyn_cnt[2 * p.B + g] = Nf * kk; }
+    lds_barrier();
+    BSTAMP(10);
+    // ---- fp = pf reversed, destination-major over the atoms; active atoms and the compact copy of their pp in-edges
+    {
+        const int c = tid;
+        int my = 0;
+        int rf[4] = {0, 0, 0, 0};                     // the first referencing centers (ascending): usually all of them
+        // a center references an atom at most once (its k neighbours are distinct): per center one 16-entry row of
+        // knn_idx, read as four b128 loads that do not depend on each other across centers
+        for (int fl = 0; fl < Nf; ++fl) {
+            const int4* row = reinterpret_cast<const int4*>(&knn_idx[fl * PF_MAXK]);
+            bool hit = false;
+#pragma unroll
+            for (int q4 = 0; q4 < PF_MAXK / 4; ++q4) {
+                if (4 * q4 < kk) {
+                    const int4 v = row[q4];
+                    hit |= (v.x == c) | ((4 * q4 + 1 < kk) & (v.y == c)) | ((4 * q4 + 2 < kk) & (v.z == c)) | ((4 * q4 + 3 < kk) & (v.w == c));
+                }
+            }
+            hit &= isp;
+            rf[0] = (hit && my == 0) ? fl : rf[0];
+            rf[1] = (hit && my == 1) ? fl : rf[1];
+            rf[2] = (hit && my == 2) ? fl : rf[2];
+            rf[3] = (hit && my == 3) ? fl : rf[3];
+            my += hit ? 1 : 0;
+        }
+        BSTAMP(12);                                   // references counted
+        const int act = (my > 0 && p.act_ids) ? 1 : 0;
+        const int deg = act ? pdeg : 0;
+        const unsigned long long val = (unsigned long long)my | ((unsigned long long)act << 16) | ((unsigned long long)deg << 28);
+        // block scan over 8 waves (same packing as block_excl_scan)
+        const unsigned int lo = (unsigned int)(val & 0xfffffffull), hi = (unsigned int)(val >> 28);
+        const unsigned int slo = wave_incl_scan_u32(lo), shi = wave_incl_scan_u32(hi);
+        if (lane == 63) scratch[wave] = (unsigned long long)slo | ((unsigned long long)shi << 28);
+        lds_barrier();
+        unsigned long long before = 0ull, all = 0ull;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const unsigned long long t = scratch[w];
+            if (w < wave) before += t;
+            all += t;
+        }
+        const unsigned long long o = before + ((unsigned long long)slo | ((unsigned long long)shi << 28)) - val;
+        BSTAMP(13);                                   // offsets known
+        if (isp) {
+            int e = reg_fp + (int)(o & 0xffffu);
+            in_start0[p0 + c] = e;
+            in_cnt0[p0 + c] = my;
+            if (my > 0 && my <= 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < my) { p.esrc[e + k] = GF + rf[k]; p.edst[e + k] = p0 + c; }
+            } else if (my > 4) {
+                for (int fl = 0; fl < Nf; ++fl)
+                    for (int r = 0; r < kk; ++r)
+                        if (knn_idx[fl * PF_MAXK + r] == c) { p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
+            }
+            if (act) {
+                const int j = (int)((o >> 16) & 0xfffu);
+                p.act_ids[reg_act + j] = p0 + c;
+                in_start2[p0 + c] = reg_pa + (int)(o >> 28);
+                in_cnt2[p0 + c] = deg;
+                a_d0[j] = (int)(o >> 28); a_node[j] = p0 + c; a_pst[j] = pst;
+                int4* st = reinterpret_cast<int4*>(&a_src[j][0]);
+                st[0] = make_int4(psrc[0], psrc[1], psrc[2], psrc[3]);
+                st[1] = make_int4(psrc[4], psrc[5], psrc[6], psrc[7]);
+                st[2] = make_int4(psrc[8], psrc[9], psrc[10], psrc[11]);
+                st[3] = make_int4(psrc[12], psrc[13], psrc[14], psrc[15]);
+            }
+        }
+        lds_barrier();
+        {   // the "pa" region: slot t belongs to the last active atom whose first slot is <= t (binary search in LDS)
+            const int n_pa = (int)(all >> 28), n_act = (int)((all >> 16) & 0xfffu);
+            for (int t = tid; t < n_pa; t += NT) {
+                int lo = 0, hi = n_act - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (a_d0[mid] <= t) lo = mid; else hi = mid - 1;
+                }
+                const int k = t - a_d0[lo];
+                const int src = k < 16 ? a_src[lo][k] : p.esrc[a_pst[lo] + k];
+                p.esrc[reg_pa + t] = src;
+                p.edst[reg_pa + t] = a_node[lo];
+            }
+        }
+        if (tid == 0 && p.act_ids) {
+            p.dyn_cnt[3 * p.B + g] = (int)(all >> 28);
+            p.dyn_cnt[4 * p.B + g] = (int)((all >> 16) & 0xfffu);
+        }
+        if (tid == 0 && p.norm_mode == 2) {           // per-graph normalisers for message_norm == 0 (gvp.py:504-507)
+            p.gnorm[1 * p.B + g] = (float)(ff_total + Nf * kk) / (float)Nf + 1.0f;
+            p.gnorm[0 * p.B + g] = (float)(Nf * kk + p.pp_cnt[g]) / (float)Np + 1.0f;
+        }
+    }
+    BSTAMP(11);
+}
+
 __global__ __launch_bounds__(256) void k_step_build(const StepParams sp, const BuildParams bp) {
+    BSTAMP(0);                                         // kernel start
     step_update_body(sp, blockIdx.x);
     __syncthreads();                                   // this workgroup's coordinate writes are visible to all its waves
     build_body(bp, blockIdx.x);
@@ -1807,6 +2079,7 @@ __global__ __launch_bounds__(256) void k_pp_radius(const float4* xn, const int* 
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 #ifdef PF_STAMPS
+int pfk_build_set_stamp_buffer(unsigned long long* dev) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_build_stamps), &dev, sizeof(dev)); }
 int pfk_set_stamp_buffer(unsigned long long* dev) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pf_stamps), &dev, sizeof(dev)); }
 #endif
 void pfk_edge_msg_coop2(const EdgeParams* p, int layer0, hipStream_t s) {
@@ -1892,9 +2165,10 @@ void pfk_segment_mean(const float4* xn, const int* ptr, int base, int B, float* 
     if (B == 0) return;
     hipLaunchKernelGGL(k_segment_mean, dim3(B), dim3(64), 0, s, xn, ptr, base, out);
 }
-void pfk_step_build(const StepParams* sp, const BuildParams* bp, hipStream_t s) {
+void pfk_step_build(const StepParams* sp, const BuildParams* bp, int fast, hipStream_t s) {
     if (sp->B == 0) return;
-    hipLaunchKernelGGL(k_step_build, dim3(sp->B), dim3(256), 0, s, *sp, *bp);
+    if (fast) hipLaunchKernelGGL(k_step_build_fast, dim3(sp->B), dim3(512), 0, s, *sp, *bp);
+    else hipLaunchKernelGGL(k_step_build, dim3(sp->B), dim3(256), 0, s, *sp, *bp);
 }
 void pfk_step_update(const StepParams* p, hipStream_t s) {
     if (p->B == 0) return;

@@ -543,10 +543,11 @@ __global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p, const Encode
         // ones of the grid and spread evenly over the chip, instead of sitting wherever a region's tiles fall.  The
         // region of group w is found by a wave scan over the region lengths (64 regions per pass).
         const int w = blockIdx.x;
-        int first = 0, rsel = -1, cnt = 0;
+        int first = 0, rsel = -1, cnt = 0, start = 0;
         for (int r0 = 0; r0 < p.nreg && rsel < 0; r0 += 64) {
             const int r = r0 + lane;
             const int c = r < p.nreg ? p.dyn_cnt[r] : 0;
+            const int rst = r < p.nreg ? p.reg[r] : 0;  // fetched with the length: one round trip less for the winner
             const int ng = (c + G - 1) / G;
             int incl = ng;
             incl += dpp_i<0x111>(incl); incl += dpp_i<0x112>(incl); incl += dpp_i<0x114>(incl); incl += dpp_i<0x118>(incl);
@@ -558,11 +559,12 @@ __global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p, const Encode
                 rsel = r0 + l;
                 first = __builtin_amdgcn_readlane(incl - ng, l);
                 cnt = __builtin_amdgcn_readlane(c, l);
+                start = __builtin_amdgcn_readlane(rst, l);
             } else first = __builtin_amdgcn_readlane(incl, 63);
         }
         if (rsel < 0) return;                          // wave-uniform: beyond the last group
         const int loc = (w - first) * G;
-        e0 = p.reg[rsel] + loc;
+        e0 = start + loc;
         nv = __builtin_amdgcn_readfirstlane(min(G, cnt - loc));
         et = rsel / p.regB;
         et = et == 3 ? (int)ET_PP : et;                // fourth region kind: pp edges into the active atoms

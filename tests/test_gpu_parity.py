@@ -353,3 +353,37 @@ def test_endpoint_parameterisation_step():
     ox, oh = O.sample_given_receptor(sd, cfg, batch, T, 1e-5, noise, n_steps=2, endpoint_param_coord=True,
                                      endpoint_param_feat=True)
     close(x0, ox, 1e-3, 1e-3); close(h0, oh, 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("case", ["knn_pf", "knn_ff", "graph_norm", "endpoint"])
+def test_fused_update_and_edge_build_variants_agree(case, monkeypatch):
+    """A denoising step ends with k_step_build_fast (sampler update + the next call's edge build, one atom per
+    thread, three dependent global round trips) when pf edges are kNN and pockets have at most 512 atoms.  It must
+    reproduce the generic bodies (PFDYN_NO_FAST_BUILD=1: k_step_build) and the separate launches of the tile-kernel
+    path bit for bit: same edge sets, same orderings, same arithmetic -- ragged batch, several steps."""
+    kw = dict(ff_k=3) if case == "knn_ff" else (dict(message_norm=0) if case == "graph_norm" else {})
+    cfg = O.DynamicsConfig(**kw)
+    sd = O.make_state_dict(cfg, 3)
+    batch = O.synthetic_batch([61, 62, 63, 64], 300, [3, 8, 5, 6], cfg)
+    T = 50
+    gen = torch.Generator().manual_seed(9)
+    noise = torch.randn(6, int(batch.pharm_ptr[-1]), 9, generator=gen)
+    ep = case == "endpoint"
+    res = []
+    for env in ({}, {"PFDYN_NO_FAST_BUILD": "1"}, {"PFDYN_NO_ENC_FLY": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = engine_for(cfg, sd)
+        for k in env:
+            monkeypatch.delenv(k)
+        set_batch(eng, batch)
+        coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+        arr = eng.coef_array(coef, reversed(range(T)))
+        x0, h0 = eng.sample(arr, 5, noise, ep_coord=ep, ep_feat=ep)
+        res.append((x0.cpu(), h0.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])      # fast == generic fused
+    # separate encode / build / update launches feed the same row-group kernels through h[N][128]: same values
+    torch.testing.assert_close(res[0][0], res[2][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res[0][1], res[2][1], rtol=1e-5, atol=1e-5)
+    ox, oh = O.sample_given_receptor(sd, cfg, batch, T, 1e-5, noise, n_steps=5, endpoint_param_coord=ep, endpoint_param_feat=ep)
+    close(res[0][0], ox, 5e-3, 5e-3); close(res[0][1], oh, 5e-3, 5e-3)

@@ -39,6 +39,18 @@ for i in range(30):
     eng.denoise_step(carr[i], noise[i + 1])
 torch.cuda.synchronize()
 names = {0: "k_rg_edge (conv layer 0)", 1: "k_rg_node (conv layer 0)", 2: "k_rg_edge (last layer)", 3: "k_rg_node + head (last layer)"}
+if hasattr(lib, "pfk_build_set_stamp_buffer"):
+    bb = torch.zeros(B * 32, dtype=torch.int64, device=dev)
+    lib.pfk_build_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+    assert lib.pfk_build_set_stamp_buffer(ctypes.c_void_p(bb.data_ptr())) == 0
+    eng.denoise_step(carr[30], noise[31])
+    torch.cuda.synchronize()
+    lib.pfk_build_set_stamp_buffer(None)
+    st = bb.cpu().view(B, 32)
+    print("== k_step_build: cycles [start -> build start (update) -> ff done -> kNN done -> protein side emitted]")
+    for g in range(3):
+        r = st[g]
+        print(f"  graph {g}: update {int(r[8] - r[0])}  ff {int(r[9] - r[8])}  kNN {int(r[10] - r[9])}  emit {int(r[11] - r[10])} (count {int(r[12] - r[10])}, scan {int(r[13] - r[12])}, stores {int(r[11] - r[13])})  total {int(r[11] - r[0])}")
 for which in range(4):
     buf.zero_()
     assert lib.pfk_rg_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
