@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra dense-mode kernel measurement")
+    ap.add_argument("--event-every", type=int, default=10,
+                    help="HIP events around the roofline kernel on every N-th timed step (0: never)")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel device time to stderr")
     ap.add_argument("--train", action="store_true",
                     help="secondary benchmark (BASELINE config 5): training steps (forward, backward kernels, Adam) at "
@@ -97,11 +99,19 @@ def main():
     carr = eng.coef_array(coef, order)
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
 
-    def run(n, first):
+    EV_MASK = (1 << 2) | (1 << 6)                               # edge-message launches of conv layer 0
+
+    def run(n, first, event_every=0):
+        """n denoising steps.  event_every > 0: every event_every-th step has HIP events around its layer-0 edge-message
+        launch (the roofline kernel): a pair of event records costs ~11 us of stream time on this stack, so bracketing
+        every launch would inflate a 75 us step by 15 %; one step in event_every keeps the measurement live inside the
+        timed region at ~1 us per step."""
         noise = torch.randn(n + 1, Nf, 9, device=dev, generator=gen)   # x columns first, then h
         if first:
             eng.sample_begin(noise[0])
         for i in range(n):
+            if event_every:
+                eng.profile_enable(EV_MASK if i % event_every == 0 else 0)
             eng.denoise_step(carr[(0 if first else W) + i], noise[i + 1])
 
     def barrier():
@@ -112,9 +122,8 @@ def main():
 
     run(W, True) if W > 0 else eng.sample_begin(torch.randn(Nf, 9, device=dev, generator=gen))
     barrier()
-    eng.profile_enable((1 << 2) | (1 << 6))                    # HIP events around every edge-message launch
     t0 = time.perf_counter()
-    run(K, False)
+    run(K, False, event_every=args.event_every)
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.profile_read()

@@ -195,7 +195,8 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
  * either is being timed), 2 edge_msg (one wave per tile), 3 node_update (one wave per tile), 4 noise_head,
  * 5 step_update, 6 edge_msg_coop, 7 node_update_coop (four waves per tile: launches with few tiles),
  * 8 edge_msg_coop of the last conv layer (when n_convs > 1).  pf_profile_read synchronises `stream`, returns the summed device
- * time [ms] and launch count per class since the last enable/read, and resets the counters. */
+ * time [ms] and launch count per class since the last read, and resets the counters; pf_profile_enable only changes the
+ * mask, so a caller can bracket a subset of its calls (a pair of event records costs ~10 us of stream time). */
 #define PF_NUM_KERNEL_CLASSES 9
 int pf_profile_enable(pf_handle* h, uint32_t kernel_mask);
 int pf_profile_read(pf_handle* h, double* total_ms /*[9]*/, int64_t* launches /*[9]*/, pf_stream stream);

@@ -136,6 +136,7 @@ struct EdgeParams {
     // row-group kernels, compact work list (nreg > 0): the launch covers regions [0, nreg) of reg / dyn_cnt (region
     // r = kind * regB + graph; kinds ff, pf, fp, pa); ngroups4 / ngroups8 = capacity in groups of 4 / 8 slots (the grid)
     const int* reg; int nreg, regB, ngroups4, ngroups8;
+    pf_gcf rgs[4]; int rgs_stride;   // two-wave form: wave 0's stream of each chain; wave 1's follows rgs_stride floats later
 };
 
 struct NodeW {             // per node type
@@ -171,6 +172,7 @@ struct NodeParams {
     int grp;               // edge slots per message partial row group: 32 (tile kernels) or 4*RG (row-group edge kernel)
     pf_gcf rg_upd[2];      // row-group kernels: quad stream of each node type's update chain (pharm of the last layer:
                            // followed by the noise head's chain and to_scalar_output)
+    pf_gcf rgs_upd[2]; int rgs_stride[2];   // two-wave form of the same (wave 1's stream rgs_stride floats after wave 0's)
 };
 
 struct HeadParams {

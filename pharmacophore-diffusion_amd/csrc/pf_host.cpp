@@ -25,8 +25,8 @@ void pfk_node_head_coop(const NodeParams* p, const HeadParams* hp, int layer0, h
 void pfk_noise_head_coop(const HeadParams* p, hipStream_t s);
 void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s);
 void pfk_noise_head(const HeadParams* p, hipStream_t s);
-void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int rg, hipStream_t s);
-void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, hipStream_t s);
+void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s);
+void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
 void pfk_encode_build_pre(const EncodeParams* e, const BuildParams* b, const PreParams* pp, hipStream_t s);
@@ -142,6 +142,13 @@ struct pf_handle {
     // wave below rg2_rows_min slots (launches with fewer groups than SIMDs are latency-bound), 8 above; they beat the
     // 32-row tile kernels at every batch size measured (32-1024); those remain for training and PFDYN_RG_ROWS_MAX=0
     std::vector<size_t> rg_msg, rg_upd;
+    std::vector<size_t> rgs_msg, rgs_upd, rgs_upd_stride;   // two-wave form: wave 0's stream; wave 1's follows *_stride floats later
+    size_t rgs_msg_stride = 0;
+    // launches with at most this many 4-row groups run each group on TWO waves (pf_rg.hip: SPLIT).  Off by default: at
+    // config 2 it shortens the node + head launch by 3 us (19.0 -> 15.8), is neutral for launches with ~500 groups, and the
+    // layer-0 edge launch that follows two launches later then takes 30 us instead of 21 (same wave cycles, longer kernel:
+    // DESIGN.md section 4.1, open question) -- PFDYN_RG_SPLIT_MAX=128 switches it on for the head
+    int rg_split_max = 0;
     std::vector<int> last_family;           // per conv layer: pf_debug_kernel_family
     int rg_rows_max = 1 << 30, rg2_rows_min = 12000;
     // 0: tile kernels; 1 / 2: row-group kernels with 4 / 8 rows per wave
@@ -163,6 +170,7 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_NO_PRUNE")) prune = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_ENC_FLY")) enc_on_the_fly = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_COMPACT")) rg_compact = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_RG_SPLIT_MAX")) rg_split_max = atoi(e);
         if (const char* e = getenv("PFDYN_NO_FAST_BUILD")) step_build_fast = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_RG_ROWS_MAX")) rg_rows_max = atoi(e);
         if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = atoi(e);
@@ -417,11 +425,16 @@ static void pack_gate_quads_rg(const std::vector<float>& Wg, int vo, int so, std
     }
 }
 // one block of a chain: GVP g, plus the gate quads of the GVP before it (prev) when there is one
-static void pack_gvp_rg(pf_handle* h, const GvpSpec& g, const GvpSpec* prev, std::vector<float>& out) {
+// half >= 0: the block of wave `half` of the two-wave form (outputs 64 half .. 64 half + 63 of a 128-output scalar
+// Linear; a 64-output GVP is the same block for both waves)
+static void pack_gvp_rg(pf_handle* h, const GvpSpec& g, const GvpSpec* prev, std::vector<float>& out, int half = -1) {
     const int S = h->cfg.n_hidden_scalars;
     const int H = std::max(g.vi, g.vo);
     const int nextra = g.si - S;
-    const int NH = g.so / 64;
+    const bool split = half >= 0 && g.so == 128;
+    const int NH = split ? 1 : g.so / 64;             // halves of 64 outputs in this block
+    const int f0 = split ? 64 * half : 0;             // first output feature of the block
+    const int so_end = split ? f0 + 64 : g.so;
     const bool X17 = g.vi == 17;
     const RgSched q = rg_sched(g.vi, nextra, NH, prev != nullptr);
     const int Kin = H + g.si;
@@ -437,15 +450,15 @@ static void pack_gvp_rg(pf_handle* h, const GvpSpec& g, const GvpSpec* prev, std
     for (int lane = 0; lane < 64; ++lane) {
         const int gq = lane >> 4, u = lane & 15, qq = (lane >> 2) & 3;
         // constants: scalar bias (two halves), gate bias, Wh[0][16] on the lanes that carry xhat
-        at(q.q_c, lane, 0) = lane < g.so ? Bv[lane] : 0.f;
-        at(q.q_c, lane, 1) = 64 + lane < g.so ? Bv[64 + lane] : 0.f;
+        at(q.q_c, lane, 0) = f0 + lane < so_end ? Bv[f0 + lane] : 0.f;
+        at(q.q_c, lane, 1) = f0 + 64 + lane < so_end ? Bv[f0 + 64 + lane] : 0.f;
         at(q.q_c, lane, 2) = u < g.vo ? bg[u] : 0.f;
         at(q.q_c, lane, 3) = (X17 && qq == 0 && gq < 3) ? wh[(size_t)0 * H + 16] : 0.f;
         if (X17) {
             at(q.q_xh, lane, 0) = gq < 3 ? wh[(size_t)0 * H + u] : 0.f;                              // xhat k-step of Vh
             at(q.q_xh, lane, 1) = (gq < 3 && u < g.vo) ? wu[(size_t)16 * g.vo + u] : 0.f;           // Vh[16] k-step of Vu
-            at(q.q_xh, lane, 2) = lane < g.so ? W[(size_t)lane * Kin + g.si + 16] : 0.f;           // sh[16] column
-            at(q.q_xh, lane, 3) = 64 + lane < g.so ? W[(size_t)(64 + lane) * Kin + g.si + 16] : 0.f;
+            at(q.q_xh, lane, 2) = f0 + lane < so_end ? W[(size_t)(f0 + lane) * Kin + g.si + 16] : 0.f;           // sh[16] column
+            at(q.q_xh, lane, 3) = f0 + 64 + lane < so_end ? W[(size_t)(f0 + 64 + lane) * Kin + g.si + 16] : 0.f;
             for (int t = 0; t < 4; ++t) at(q.q_xh + 1, lane, t) = gq < 3 ? wh[(size_t)(1 + 4 * t + qq) * H + 16] : 0.f;
         }
         for (int t = 0; t < 4; ++t)
@@ -453,16 +466,16 @@ static void pack_gvp_rg(pf_handle* h, const GvpSpec& g, const GvpSpec* prev, std
                 at(q.q_vh + t, lane, j) = gq < 3 ? wh[(size_t)(v0 + 4 * t + j) * H + u] : 0.f;
                 at(q.q_vu + t, lane, j) = (gq < 3 && u < g.vo) ? wu[(size_t)(4 * t + j) * g.vo + u] : 0.f;
             }
-        for (int half = 0; half < NH; ++half) {
-            const int f = half * 64 + lane;
+        for (int hh = 0; hh < NH; ++hh) {
+            const int f = f0 + hh * 64 + lane;
             for (int m = 0; m < 8; ++m)
                 for (int aq = 0; aq < 4; ++aq)
                     for (int j = 0; j < 4; ++j)
-                        at(rg_main_quad(q, NH, (m * 4 + aq) * NH + half), lane, j) = W[(size_t)f * Kin + 8 * (4 * aq + j) + m];
+                        at(rg_main_quad(q, NH, (m * 4 + aq) * NH + hh), lane, j) = W[(size_t)f * Kin + 8 * (4 * aq + j) + m];
             for (int aq = 0; aq < 4; ++aq)
                 for (int j = 0; j < 4; ++j) {
-                    if (nextra) at(q.q_rbf + aq * NH + half, lane, j) = W[(size_t)f * Kin + S + 4 * aq + j];
-                    at(q.q_sh + aq * NH + half, lane, j) = W[(size_t)f * Kin + g.si + 4 * aq + j];
+                    if (nextra) at(q.q_rbf + aq * NH + hh, lane, j) = W[(size_t)f * Kin + S + 4 * aq + j];
+                    at(q.q_sh + aq * NH + hh, lane, j) = W[(size_t)f * Kin + g.si + 4 * aq + j];
                 }
         }
     }
@@ -614,15 +627,18 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             e.sv_stride = (size_t)std::max<int64_t>(h->Ecap, 1);
         }
         for (int et = 0; et < 4; ++et) e.rg[et] = h->d_w + h->rg_msg[(size_t)l * 4 + et];
-        // every edge of this launch lives in a dynamic region (each wave scans the region lengths: up to 2048 regions)
-        if ((last || pruned) && h->rg_compact && (last ? 2 : 4) * h->B <= 2048) {
+        // every edge of this launch lives in a dynamic region (each wave scans the region lengths: up to 1024 regions = 64 * RG_CPASS)
+        if ((last || pruned) && h->rg_compact && (last ? 2 : 4) * h->B <= 1024) {
             e.reg = h->d_reg; e.regB = h->B; e.nreg = (last ? 2 : 4) * h->B;
             for (int r = 0; r < e.nreg; ++r) { e.ngroups4 += (h->h_cap[r] + 3) / 4; e.ngroups8 += (h->h_cap[r] + 7) / 8; }
         }
         const int rg = train ? 0 : h->rg_mode(e.ntiles);     // the node launch of this layer follows (partial-row grouping)
         h->last_family.resize(c.n_convs);
         h->last_family[l] = rg ? 4 * rg : ((!train && e.ntiles <= ((last || pruned) ? std::max(h->coop_edge_max, h->coop2_edge_max) : std::max(h->coop_edge_max, h->coop2_dense_max))) ? 128 : 32);
-        if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, s); }
+        for (int et = 0; et < 4; ++et) e.rgs[et] = h->d_w + h->rgs_msg[(size_t)l * 4 + et];
+        e.rgs_stride = (int)h->rgs_msg_stride;
+        const int esplit = (rg == 1 && e.ntiles * 8 <= h->rg_split_max) ? 1 : 0;    // fewer groups than SIMDs: latency-bound
+        if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, esplit, s); }
         else if (e.ntiles <= h->coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
         else if (e.ntiles <= ((last || pruned) ? h->coop2_edge_max : h->coop2_dense_max) && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop2(&e, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
@@ -647,17 +663,22 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         n.n_upd = c.n_update_gvps;
         n.grp = rg ? 4 * rg : 32;
         for (int nt = 0; nt < 2; ++nt) n.rg_upd[nt] = h->d_w + h->rg_upd[(size_t)l * 2 + nt];
+        for (int nt = 0; nt < 2; ++nt) {
+            n.rgs_upd[nt] = h->d_w + h->rgs_upd[(size_t)l * 2 + nt];
+            n.rgs_stride[nt] = (int)h->rgs_upd_stride[(size_t)l * 2 + nt];
+        }
         if (rg) {
             const int rgn = std::max(1, h->rg_mode(n.ntiles));
+            const int nsplit = (rgn == 1 && n.ntiles * 8 <= h->rg_split_max) ? 1 : 0;
             if (last && h->fuse_head && h->n_head_tiles == n.ntiles) {
                 HeadParams hp{};
                 hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
                 hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
                 hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
                 hp.eps_h = eps_h; hp.eps_x = eps_x;
-                { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node(&n, &hp, enc_fly ? &ep : nullptr, l == 0, rgn, s); }
+                { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node(&n, &hp, enc_fly ? &ep : nullptr, l == 0, rgn, nsplit, s); }
                 head_done = true;
-            } else { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_rg_node(&n, nullptr, enc_fly ? &ep : nullptr, l == 0, rgn, s); }
+            } else { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_rg_node(&n, nullptr, enc_fly ? &ep : nullptr, l == 0, rgn, nsplit, s); }
         }
         else if (last && !train && h->fuse_head && n.ntiles <= h->coop_node_max && h->n_head_tiles == n.ntiles) {
             // last layer (pharm tiles only) + noise head in one launch: the layer output stays in registers
@@ -848,11 +869,11 @@ int pf_commit_weights(pf_handle* h) {
             h->rg_upd.assign((size_t)c.n_convs * 2, 0);
             std::vector<float> st;
             auto flush = [&]() { const size_t off = push(h->h_w, st); st.clear(); return off; };
-            auto chain = [&](auto spec_of, int n) {          // blocks of a chain: GVP j carries the gates of GVP j - 1
+            auto chain = [&](auto spec_of, int n, int half = -1) {   // blocks of a chain: GVP j carries the gates of GVP j - 1
                 GvpSpec prev;
                 for (int j = 0; j < n; ++j) {
                     const GvpSpec g = spec_of(j);
-                    pack_gvp_rg(h, g, j ? &prev : nullptr, st);
+                    pack_gvp_rg(h, g, j ? &prev : nullptr, st, half);
                     prev = g;
                 }
                 pack_flush_rg(h, prev, st);
@@ -873,6 +894,33 @@ int pf_commit_weights(pf_handle* h) {
             pack_out_rg(h, st);
             st.resize(st.size() + (size_t)RG_TAIL_PAD * 256, 0.f);
             h->rg_upd[(size_t)(c.n_convs - 1) * 2 + 1] = flush();
+            // the same chains for the two-wave form: per chain wave 0's stream, then wave 1's
+            h->rgs_msg.assign((size_t)c.n_convs * 4, 0);
+            h->rgs_upd.assign((size_t)c.n_convs * 2, 0);
+            h->rgs_upd_stride.assign((size_t)c.n_convs * 2, 0);
+            for (int l = 0; l < c.n_convs; ++l)
+                for (int et = 0; et < 4; ++et) {
+                    for (int half = 0; half < 2; ++half) {
+                        chain([&](int j) { return msg_spec(c, l, et, j); }, c.n_message_gvps, half);
+                        if (half == 0) h->rgs_msg_stride = st.size();
+                    }
+                    h->rgs_msg[(size_t)l * 4 + et] = flush();
+                }
+            for (int l = 0; l < c.n_convs; ++l)
+                for (int nt = 0; nt < 2; ++nt) {
+                    const bool tail = l == c.n_convs - 1 && nt == 1;
+                    for (int half = 0; half < 2; ++half) {
+                        chain([&](int j) { return upd_spec(c, l, nt, j); }, c.n_update_gvps, half);
+                        if (tail) {
+                            chain([&](int k) { return head_spec(c, k); }, c.n_noise_gvps, half);
+                            pack_out_rg(h, st);
+                        }
+                        if (half == 0) h->rgs_upd_stride[(size_t)l * 2 + nt] = st.size();
+                    }
+                    if (!tail) h->rgs_upd[(size_t)l * 2 + nt] = flush();
+                }
+            st.resize(st.size() + (size_t)RG_TAIL_PAD * 256, 0.f);
+            h->rgs_upd[(size_t)(c.n_convs - 1) * 2 + 1] = flush();
         }
         while (h->h_w.size() % 64) h->h_w.push_back(0.f);
     };
@@ -1345,7 +1393,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     e.rbf_inv_sigma = 1.0f / (c.rbf_dmax / (float)c.rbf_dim);
     for (int et = 0; et < 4; ++et) e.rg[et] = h->d_w + h->rg_msg[(size_t)layer * 4 + et];
     const int rg = h->rg_mode(e.ntiles);                  // same choice as run_dynamics
-    if (rg) pfk_rg_edge(&e, nullptr, 0, rg, s);
+    if (rg) pfk_rg_edge(&e, nullptr, 0, rg, 0, s);
     else if (e.ntiles <= h->coop_edge_max) pfk_edge_msg_coop(&e, 0, s); else pfk_edge_msg(&e, 0, s);
     NodeParams n{};
     n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles; n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
@@ -1360,7 +1408,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     n.n_upd = c.n_update_gvps;
     n.grp = rg ? 4 * rg : 32;
     for (int nt = 0; nt < 2; ++nt) n.rg_upd[nt] = h->d_w + h->rg_upd[(size_t)layer * 2 + nt];
-    if (rg) pfk_rg_node(&n, nullptr, nullptr, 0, std::max(1, h->rg_mode(n.ntiles)), s);
+    if (rg) pfk_rg_node(&n, nullptr, nullptr, 0, std::max(1, h->rg_mode(n.ntiles)), 0, s);
     else if (n.ntiles <= h->coop_node_max) pfk_node_update_coop(&n, 0, s); else pfk_node_update(&n, 0, s);
     pfk_copy(h->d_h[1], ohp, Np * PF_S, s);
     pfk_copy(h->d_h[1] + Np * PF_S, ohf, Nf * PF_S, s);
@@ -1628,8 +1676,7 @@ int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave) 
 
 int pf_profile_enable(pf_handle* h, uint32_t kernel_mask) {
     if (!h) return PF_ERR_ARG;
-    h->prof_mask = kernel_mask;
-    for (int k = 0; k < pf_handle::K_NUM; ++k) h->prof_used[k] = 0;
+    h->prof_mask = kernel_mask;             // recorded events accumulate until pf_profile_read
     return PF_OK;
 }
 

@@ -75,6 +75,7 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f(const float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
+#define RG_CPASS 16                            // compact work lists: up to 64 * RG_CPASS regions per launch
 // integer DPP moves for wave scans: lanes without a source (or rows outside ROW_MASK) read 0
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(const int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
@@ -115,9 +116,19 @@ struct RgStamp {
 // wave-private LDS scratch of one row group
 #define RG_T1_STRIDE 132                      // SD -> SA transposition: [4 rows][128 (+4 pad)]
 #define RG_TV_STRIDE 52                       // VD -> VA transposition: [4 rows][3 coordinates][16] + 3 (channel 16) + pad
+// (t1 double-buffered and tv per wave for the two-wave form, where the SiLU output is exchanged between the waves)
 struct __attribute__((aligned(16))) RgLds {
-    float t1[4 * RG_T1_STRIDE];
-    float tv[4 * RG_TV_STRIDE];
+    float t1[2][4 * RG_T1_STRIDE];
+    float tv[2][4 * RG_TV_STRIDE];
+};
+// position of a wave in its workgroup's chain: SPLIT kernels run a 4-row group on TWO waves (two SIMDs), wave h owning
+// outputs 64h..64h+63 of every 128-output scalar Linear (its own quad stream: half the main / rbf / sh quads) while the
+// cheap vector channel and the gates are computed by both; the halves meet in the T1 buffer (one workgroup barrier per
+// GVP).  A launch with fewer groups than SIMDs is bound by the latency of the chain, and a wave cannot stream its
+// weights faster than ~16 B/clk.
+struct RgWave {
+    int half;      // 0 / 1 (0 when not split)
+    int par;       // T1 buffer of the next exchange (alternates)
 };
 __device__ __forceinline__ int pperm(const int u) { return (u & 3) * 4 + (u >> 2); }
 
@@ -175,11 +186,13 @@ struct RgCarry {
 //   PREV        0: first GVP of a chain; 1: previous GVP gates with a sigmoid; 2: identity
 //   VZERO       the 16 node-vector channels are identically zero (conv layer 0, first GVP): only xhat feeds Vh
 // ---------------------------------------------------------------------------------------------
-template <class S, int RG, int D, int PREV, bool VZERO>
+template <class S, int RG, int D, int PREV, bool VZERO, bool SPLIT = false>
 __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float (&Va)[RG][4], const float (&R)[RG],
                                        const float (&XH)[RG], f32x4 (&slo)[RG], f32x4 (&shi)[RG], RgCarry<RG>& carry,
-                                       RgLds* lds, const int lane, RgStamp& stamp) {
-    constexpr int NH = S::NH;
+                                       RgLds* lds, const int lane, RgStamp& stamp, RgWave& wv) {
+    constexpr int NH = SPLIT ? 1 : S::NH;             // halves of 64 outputs computed by this wave
+    const int hcol = (SPLIT && S::NH == 2) ? 64 * wv.half : 0;
+    const int tvw = SPLIT ? wv.half : 0;
     static_assert(!(VZERO && PREV != 0), "VZERO is a property of a chain's first GVP");
     stamp(lane);                                      // 0: block start
     const int a = lane >> 2, i = lane & 3, g = lane >> 4, q = a & 3, u = lane & 15;
@@ -245,7 +258,7 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
                 fold(gd);
 #pragma unroll
                 for (int r = 0; r < RG; ++r) {
-                    float* tv = lds[r].tv;
+                    float* tv = lds[r].tv[tvw];
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
                         float gv = gsum(gd[r][ii]) + carry.bg;
@@ -261,7 +274,7 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int r = 0; r < RG; ++r) {
-                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(&lds[r].tv[i * RG_TV_STRIDE + gg * 16 + 4 * q]);
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(&lds[r].tv[tvw][i * RG_TV_STRIDE + gg * 16 + 4 * q]);
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) Va[r][tt] = g < 3 ? v4[tt] : 0.f;
                 }
@@ -286,7 +299,7 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
                         }
                         Vh16[r] = qsum(p);
                     }
-                    float* tv = lds[r].tv;
+                    float* tv = lds[r].tv[tvw];
                     if (lane < 48) {
 #pragma unroll
                         for (int ii = 0; ii < 4; ++ii) tv[ii * RG_TV_STRIDE + g * 16 + pperm(u)] = vh[r][ii];
@@ -303,7 +316,7 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int r = 0; r < RG; ++r) {
-                    const float* tv = lds[r].tv;
+                    const float* tv = lds[r].tv[tvw];
                     VhA[r] = *reinterpret_cast<const f32x4*>(&tv[i * RG_TV_STRIDE + gg * 16 + 4 * q]);
                     const float x = tv[i * RG_TV_STRIDE + pperm(a)], y = tv[i * RG_TV_STRIDE + 16 + pperm(a)],
                                 z = tv[i * RG_TV_STRIDE + 32 + pperm(a)];
@@ -357,24 +370,25 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
                         lo[r] = mfma_b4<0>(SH16[r], xhq[2], lo[r]);
                         if constexpr (NH == 2) hi[r] = mfma_b4<0>(SH16[r], xhq[3], hi[r]);
                     }
-                    float* t1 = lds[r].t1;
+                    float* t1 = lds[r].t1[wv.par];
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
                         slo[r][ii] = siluf_(lo[r][ii] + cq[0]);
-                        t1[ii * RG_T1_STRIDE + lane] = slo[r][ii];
+                        t1[ii * RG_T1_STRIDE + hcol + lane] = slo[r][ii];
                         if constexpr (NH == 2) {
                             shi[r][ii] = siluf_(hi[r][ii] + cq[1]);
                             t1[ii * RG_T1_STRIDE + 64 + lane] = shi[r][ii];
                         } else shi[r][ii] = 0.f;
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
+                if constexpr (SPLIT) __syncthreads();  // both halves of the SiLU output are in T1
+                else __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int r = 0; r < RG; ++r) {
-                    const float* t1 = lds[r].t1;
+                    const float* t1 = lds[r].t1[wv.par];
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(&t1[i * RG_T1_STRIDE + 8 * a]);
                     const f32x4 x1 = *reinterpret_cast<const f32x4*>(&t1[i * RG_T1_STRIDE + 8 * a + 4]);
-                    const bool on = NH == 2 || a < 8;  // 64 outputs: features live in blocks 0..7 only
+                    const bool on = S::NH == 2 || a < 8;   // 64 outputs: features live in blocks 0..7 only
 #pragma unroll
                     for (int m = 0; m < 4; ++m) { X[r][m] = on ? x0[m] : 0.f; X[r][4 + m] = on ? x1[m] : 0.f; }
                 }
@@ -384,6 +398,7 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
         if constexpr (qi % RG_SB == RG_SB - 1) __builtin_amdgcn_sched_barrier(0);
     });
     ring.p += QQ.nq * 64;
+    if constexpr (SPLIT) wv.par ^= 1;                 // the partner may still be reading this block's T1
 #pragma unroll
     for (int r = 0; r < RG; ++r) carry.vu[r] = vu[r];
     carry.bg = cq[2];
@@ -393,7 +408,7 @@ __device__ __forceinline__ void rg_gvp(RgRing<D>& ring, float (&X)[RG][8], float
 // coordinate g); Va: the same in the VA layout (when NEEDVA)
 template <int RG, int D, bool SIG, bool NEEDVA>
 __device__ __forceinline__ void rg_flush(RgRing<D>& ring, const float (&X)[RG][8], float (&Va)[RG][4], f32x4 (&Vd)[RG],
-                                         const RgCarry<RG>& carry, RgLds* lds, const int lane, RgStamp& stamp) {
+                                         const RgCarry<RG>& carry, RgLds* lds, const int lane, RgStamp& stamp, const int tvw = 0) {
     const int i = lane & 3, g = lane >> 4, q = (lane >> 2) & 3, u = lane & 15;
     const int gg = g < 3 ? g : 2;
     constexpr int NA = RG == 1 ? 2 : 1;
@@ -425,7 +440,7 @@ __device__ __forceinline__ void rg_flush(RgRing<D>& ring, const float (&X)[RG][8
             Vd[r][ii] = gv * carry.vu[r][ii];
         }
         if constexpr (NEEDVA) {
-            float* tv = lds[r].tv;
+            float* tv = lds[r].tv[tvw];
             if (lane < 48) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) tv[ii * RG_TV_STRIDE + g * 16 + pperm(u)] = Vd[r][ii];
@@ -436,7 +451,7 @@ __device__ __forceinline__ void rg_flush(RgRing<D>& ring, const float (&X)[RG][8
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
-            const f32x4 v4 = *reinterpret_cast<const f32x4*>(&lds[r].tv[i * RG_TV_STRIDE + gg * 16 + 4 * q]);
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(&lds[r].tv[tvw][i * RG_TV_STRIDE + gg * 16 + 4 * q]);
 #pragma unroll
             for (int t = 0; t < 4; ++t) Va[r][t] = g < 3 ? v4[t] : 0.f;
         }
@@ -530,12 +545,15 @@ __device__ __forceinline__ void rg_encode(const EncodeParams& ep, const int nt, 
 // destination ids are wave-uniform, the test is scalar) and stores one partial row per (wave, destination) run at the
 // run's last slot -- what the node kernels read (NodeParams::grp = 4*RG).
 // ---------------------------------------------------------------------------------------------
-template <bool L0, int RG>
-__global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p, const EncodeParams ep) {
+template <bool L0, int RG, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 128 : 64) void k_rg_edge(const EdgeParams p, const EncodeParams ep) {
     constexpr int D = RgDepth<RG>::D;
     __shared__ RgLds lds[RG];
     constexpr int G = 4 * RG, PER = 32 / G;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    RgWave wv;
+    wv.half = SPLIT ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    wv.par = 0;
     int e0, nv, et;
     if (p.nreg > 0) {
         // Compact work list (launches whose edges all live in per-(etype, graph) regions of run-time length): wave w
@@ -544,23 +562,33 @@ __global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p, const Encode
         // region of group w is found by a wave scan over the region lengths (64 regions per pass).
         const int w = blockIdx.x;
         int first = 0, rsel = -1, cnt = 0, start = 0;
-        for (int r0 = 0; r0 < p.nreg && rsel < 0; r0 += 64) {
-            const int r = r0 + lane;
-            const int c = r < p.nreg ? p.dyn_cnt[r] : 0;
-            const int rst = r < p.nreg ? p.reg[r] : 0;  // fetched with the length: one round trip less for the winner
-            const int ng = (c + G - 1) / G;
-            int incl = ng;
-            incl += dpp_i<0x111>(incl); incl += dpp_i<0x112>(incl); incl += dpp_i<0x114>(incl); incl += dpp_i<0x118>(incl);
-            incl += dpp_ir<0x142, 0xa>(incl); incl += dpp_ir<0x143, 0xc>(incl);
-            incl += first;
-            const unsigned long long m = __ballot(incl > w);
-            if (m) {
-                const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
-                rsel = r0 + l;
-                first = __builtin_amdgcn_readlane(incl - ng, l);
-                cnt = __builtin_amdgcn_readlane(c, l);
-                start = __builtin_amdgcn_readlane(rst, l);
-            } else first = __builtin_amdgcn_readlane(incl, 63);
+        // every pass's lengths and starts are fetched before the first scan: one global round trip whatever the number
+        // of regions (up to 64 * RG_CPASS); the scans themselves run on registers
+        int cs[RG_CPASS], rs[RG_CPASS];
+#pragma unroll
+        for (int k = 0; k < RG_CPASS; ++k) {
+            const int r = 64 * k + lane;
+            cs[k] = r < p.nreg ? p.dyn_cnt[r] : 0;
+            rs[k] = r < p.nreg ? p.reg[r] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < RG_CPASS; ++k) {
+            if (64 * k < p.nreg && rsel < 0) {           // wave-uniform
+                const int c = cs[k];
+                const int ng = (c + G - 1) / G;
+                int incl = ng;
+                incl += dpp_i<0x111>(incl); incl += dpp_i<0x112>(incl); incl += dpp_i<0x114>(incl); incl += dpp_i<0x118>(incl);
+                incl += dpp_ir<0x142, 0xa>(incl); incl += dpp_ir<0x143, 0xc>(incl);
+                incl += first;
+                const unsigned long long m = __ballot(incl > w);
+                if (m) {
+                    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                    rsel = 64 * k + l;
+                    first = __builtin_amdgcn_readlane(incl - ng, l);
+                    cnt = __builtin_amdgcn_readlane(c, l);
+                    start = __builtin_amdgcn_readlane(rs[k], l);
+                } else first = __builtin_amdgcn_readlane(incl, 63);
+            }
         }
         if (rsel < 0) return;                          // wave-uniform: beyond the last group
         const int loc = (w - first) * G;
@@ -582,7 +610,7 @@ __global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p, const Encode
     RgStamp stamp;
     stamp(lane);                                       // kernel start
     RgRing<D> ring;
-    ring_start(ring, p.rg[et], lane);                  // in flight under the gather
+    ring_start(ring, SPLIT ? p.rgs[et] + (size_t)wv.half * p.rgs_stride : p.rg[et], lane);   // in flight under the gather
     const int a = lane >> 2, i = lane & 3, g = lane >> 4, q = a & 3, u = lane & 15;
     float X[RG][8], Va[RG][4], R[RG], XH[RG];
     int dstv[RG], srcv[RG];
@@ -617,16 +645,16 @@ __global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p, const Encode
     if (L0 && ep.w[0]) rg_encode<RG>(ep, (et == ET_FF || et == ET_FP) ? 1 : 0, srcv, X, lane);   // sources: pharm for ff / fp
     f32x4 slo[RG], shi[RG], Vd[RG];
     RgCarry<RG> carry;
-    rg_gvp<SpecMsg0, RG, D, 0, L0>(ring, X, Va, R, XH, slo, shi, carry, lds, lane, stamp);
-    for (int gi = 1; gi < p.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, 1, false>(ring, X, Va, R, XH, slo, shi, carry, lds, lane, stamp);
-    rg_flush<RG, D, true, false>(ring, X, Va, Vd, carry, lds, lane, stamp);
+    rg_gvp<SpecMsg0, RG, D, 0, L0, SPLIT>(ring, X, Va, R, XH, slo, shi, carry, lds, lane, stamp, wv);
+    for (int gi = 1; gi < p.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, 1, false, SPLIT>(ring, X, Va, R, XH, slo, shi, carry, lds, lane, stamp, wv);
+    rg_flush<RG, D, true, false>(ring, X, Va, Vd, carry, lds, lane, stamp, wv.half);
     // in-wave segmented sum in slot order; one partial row per (wave, destination) run
     float al = 0.f, ah = 0.f, av = 0.f;
     int prev = -1;
-    auto put = [&](const int slot) {
-        p.msg_s[(size_t)slot * PF_S + lane] = al;
-        p.msg_s[(size_t)slot * PF_S + 64 + lane] = ah;
-        if (lane < 48) p.msg_v[(size_t)slot * 48 + 3 * u + g] = av;
+    auto put = [&](const int slot) {                   // two-wave form: wave h holds (and stores) features 64h..64h+63
+        p.msg_s[(size_t)slot * PF_S + 64 * wv.half + lane] = al;
+        if constexpr (!SPLIT) p.msg_s[(size_t)slot * PF_S + 64 + lane] = ah;
+        if (lane < 48 && wv.half == 0) p.msg_v[(size_t)slot * 48 + 3 * u + g] = av;
     };
     static_for<0, G>([&](auto K) {
         constexpr int k = decltype(K)::value;
@@ -650,12 +678,15 @@ __global__ __launch_bounds__(64) void k_rg_edge(const EdgeParams p, const Encode
 // GVPLayerNorm, update chain, residual, GVPLayerNorm.  A wave = 4*RG nodes of one tile.  HEAD: last conv layer of
 // the inference path (pharm tiles): the noise head (dynamics_gvp.py:37-42) runs on the registers right away.
 // ---------------------------------------------------------------------------------------------
-template <bool L0, int RG, bool HEAD>
-__global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadParams hp, const EncodeParams ep) {
+template <bool L0, int RG, bool HEAD, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 128 : 64) void k_rg_node(const NodeParams p, const HeadParams hp, const EncodeParams ep) {
     constexpr int D = RgDepth<RG>::D;
     __shared__ RgLds lds[RG];
     constexpr int G = 4 * RG, PER = 32 / G;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    RgWave wv;
+    wv.half = SPLIT ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    wv.par = 0;
     const int bid = blockIdx.x;
     const NodeTile t = p.tiles[bid / PER];
     int tn = t.n;
@@ -667,7 +698,7 @@ __global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadPa
     RgStamp stamp;
     stamp(lane);                                       // kernel start
     RgRing<D> ring;
-    ring_start(ring, p.rg_upd[nt], lane);
+    ring_start(ring, SPLIT ? p.rgs_upd[nt] + (size_t)wv.half * p.rgs_stride[nt] : p.rg_upd[nt], lane);
     const int a = lane >> 2, i = lane & 3, g = lane >> 4, q = a & 3, u = lane & 15;
     const int gc = g < 3 ? g : 0;
     const NodeW nw = p.w[nt];
@@ -786,9 +817,9 @@ __global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadPa
     f32x4 slo[RG], shi[RG], Vd[RG];
     const float zero[RG] = {};
     RgCarry<RG> carry;
-    rg_gvp<SpecGen, RG, D, 0, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
-    for (int gi = 1; gi < p.n_upd; ++gi) rg_gvp<SpecGen, RG, D, 1, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
-    rg_flush<RG, D, true, true>(ring, X, Va, Vd, carry, lds, lane, stamp);
+    rg_gvp<SpecGen, RG, D, 0, false, SPLIT>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp, wv);
+    for (int gi = 1; gi < p.n_upd; ++gi) rg_gvp<SpecGen, RG, D, 1, false, SPLIT>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp, wv);
+    rg_flush<RG, D, true, true>(ring, X, Va, Vd, carry, lds, lane, stamp, wv.half);
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
 #pragma unroll
@@ -801,7 +832,7 @@ __global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadPa
     if constexpr (!HEAD) {
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
-            if (4 * r + i < nv) {
+            if (4 * r + i < nv && wv.half == 0) {      // (both waves of the two-wave form hold the same result)
                 f32x4* op = reinterpret_cast<f32x4*>(p.h_out + (size_t)nid[r] * PF_S) + 2 * a;
                 op[0] = (f32x4){X[r][0], X[r][1], X[r][2], X[r][3]};
                 op[1] = (f32x4){X[r][4], X[r][5], X[r][6], X[r][7]};
@@ -814,13 +845,13 @@ __global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadPa
         }
     } else {
         // noise head: its chain and to_scalar_output follow the update chain in the quad stream
-        if (hp.n_gvps == 1) rg_gvp<SpecHeadLast, RG, D, 0, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
+        if (hp.n_gvps == 1) rg_gvp<SpecHeadLast, RG, D, 0, false, SPLIT>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp, wv);
         else {
-            rg_gvp<SpecGen, RG, D, 0, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
-            for (int gi = 1; gi + 1 < hp.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, 1, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
-            rg_gvp<SpecHeadLast, RG, D, 1, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
+            rg_gvp<SpecGen, RG, D, 0, false, SPLIT>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp, wv);
+            for (int gi = 1; gi + 1 < hp.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, 1, false, SPLIT>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp, wv);
+            rg_gvp<SpecHeadLast, RG, D, 1, false, SPLIT>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp, wv);
         }
-        rg_flush<RG, D, false, false>(ring, X, Va, Vd, carry, lds, lane, stamp);
+        rg_flush<RG, D, false, false>(ring, X, Va, Vd, carry, lds, lane, stamp, wv.half);
         // to_scalar_output: Linear(64 -> pharm_nf), K split over the lane groups like the gates
         f32x4 od[RG];
 #pragma unroll
@@ -845,7 +876,7 @@ __global__ __launch_bounds__(64) void k_rg_node(const NodeParams p, const HeadPa
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const float o = gsum(od[r][ii]) + oc[0];
-                if (4 * r + ii < nv) {
+                if (4 * r + ii < nv && wv.half == 0) {
                     const int f = __builtin_amdgcn_readlane(nid[r], ii) - hp.node_base;
                     if (g == 0 && u < hp.pharm_nf) hp.eps_h[(size_t)f * hp.pharm_nf + u] = o;
                     if (u == 0 && g < 3) hp.eps_x[(size_t)f * 3 + g] = Vd[r][ii];     // output channel 0, coordinate g
@@ -862,7 +893,7 @@ int pfk_rg_set_stamp_buffer(unsigned long long* dev) { g_rg_stamp_host_buf = dev
 void pfk_rg_set_stamp_which(int which) { g_rg_stamp_which = which; g_rg_stamp_seen = 0; }
 #endif
 // rows per wave: 8 (RG = 2) once there are enough groups to fill the chip, else 4
-void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int rg, hipStream_t s) {
+void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s) {
     if (p->ntiles == 0) return;
 #ifdef PF_STAMPS
     rg_stamp_arm(s);
@@ -872,15 +903,18 @@ void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int r
     if (grid == 0) return;
     const EncodeParams noenc{};
     const EncodeParams& ep = (layer0 && enc) ? *enc : noenc;      // layer 0: encode the gathered rows on the fly
-    if (rg == 1) {
-        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 1>), dim3(grid), dim3(64), 0, s, *p, ep);
-        else hipLaunchKernelGGL((k_rg_edge<false, 1>), dim3(grid), dim3(64), 0, s, *p, ep);
+    if (rg == 1 && split) {
+        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 1, true>), dim3(grid), dim3(128), 0, s, *p, ep);
+        else hipLaunchKernelGGL((k_rg_edge<false, 1, true>), dim3(grid), dim3(128), 0, s, *p, ep);
+    } else if (rg == 1) {
+        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 1, false>), dim3(grid), dim3(64), 0, s, *p, ep);
+        else hipLaunchKernelGGL((k_rg_edge<false, 1, false>), dim3(grid), dim3(64), 0, s, *p, ep);
     } else {
-        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 2>), dim3(grid), dim3(64), 0, s, *p, ep);
-        else hipLaunchKernelGGL((k_rg_edge<false, 2>), dim3(grid), dim3(64), 0, s, *p, ep);
+        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 2, false>), dim3(grid), dim3(64), 0, s, *p, ep);
+        else hipLaunchKernelGGL((k_rg_edge<false, 2, false>), dim3(grid), dim3(64), 0, s, *p, ep);
     }
 }
-void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, hipStream_t s) {
+void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s) {
     if (p->ntiles == 0) return;
 #ifdef PF_STAMPS
     rg_stamp_arm(s);
@@ -892,13 +926,16 @@ void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* 
     const int grid = p->ntiles * per;
     const EncodeParams noenc{};
     const EncodeParams& ep = (layer0 && enc) ? *enc : noenc;
-#define PF_RG_NODE(L0_, RG_, HEAD_) hipLaunchKernelGGL((k_rg_node<L0_, RG_, HEAD_>), dim3(grid), dim3(64), 0, s, *p, h, ep)
-    if (rg == 1) {
-        if (head) { if (layer0) PF_RG_NODE(true, 1, true); else PF_RG_NODE(false, 1, true); }
-        else { if (layer0) PF_RG_NODE(true, 1, false); else PF_RG_NODE(false, 1, false); }
+#define PF_RG_NODE(L0_, RG_, HEAD_, SP_) hipLaunchKernelGGL((k_rg_node<L0_, RG_, HEAD_, SP_>), dim3(grid), dim3(SP_ ? 128 : 64), 0, s, *p, h, ep)
+    if (rg == 1 && split) {
+        if (head) { if (layer0) PF_RG_NODE(true, 1, true, true); else PF_RG_NODE(false, 1, true, true); }
+        else { if (layer0) PF_RG_NODE(true, 1, false, true); else PF_RG_NODE(false, 1, false, true); }
+    } else if (rg == 1) {
+        if (head) { if (layer0) PF_RG_NODE(true, 1, true, false); else PF_RG_NODE(false, 1, true, false); }
+        else { if (layer0) PF_RG_NODE(true, 1, false, false); else PF_RG_NODE(false, 1, false, false); }
     } else {
-        if (head) { if (layer0) PF_RG_NODE(true, 2, true); else PF_RG_NODE(false, 2, true); }
-        else { if (layer0) PF_RG_NODE(true, 2, false); else PF_RG_NODE(false, 2, false); }
+        if (head) { if (layer0) PF_RG_NODE(true, 2, true, false); else PF_RG_NODE(false, 2, true, false); }
+        else { if (layer0) PF_RG_NODE(true, 2, false, false); else PF_RG_NODE(false, 2, false, false); }
     }
 #undef PF_RG_NODE
 }

@@ -258,14 +258,16 @@ def test_four_waves_per_tile_kernels(name, dense, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["dynamics_c1.npz", "dynamics_ragged.npz", "dynamics_radius.npz", "dynamics_knnff.npz"])
-@pytest.mark.parametrize("rows_per_wave", [4, 8])
+@pytest.mark.parametrize("rows_per_wave", [4, 8, "4 on two waves"])
 @pytest.mark.parametrize("dense", [False, True])
 def test_row_group_kernels(name, rows_per_wave, dense, monkeypatch):
     """The row-group kernels (pf_rg.hip: k_rg_edge / k_rg_node, 4 or 8 rows per wave on the 4x4x1 MFMA) forced on
-    the golden cases at both widths, on the pruned and on the dense tile lists, fused and separate head, plus one
-    whole conv layer with non-zero node vectors."""
+    the golden cases at both widths and in the two-wave form (a 4-row group on two waves, each owning 64 of the 128
+    outputs), on the pruned and on the dense tile lists, fused and separate head, plus one whole conv layer with
+    non-zero node vectors."""
     monkeypatch.setenv("PFDYN_RG_ROWS_MAX", "100000000")
     monkeypatch.setenv("PFDYN_RG2_ROWS_MIN", "0" if rows_per_wave == 8 else "100000000")
+    monkeypatch.setenv("PFDYN_RG_SPLIT_MAX", "100000000" if rows_per_wave == "4 on two waves" else "0")
     if dense:
         monkeypatch.setenv("PFDYN_NO_PRUNE", "1")
         monkeypatch.setenv("PFDYN_NO_FUSE_HEAD", "1")

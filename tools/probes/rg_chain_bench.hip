@@ -22,8 +22,9 @@ __global__ __launch_bounds__(64) void k_chain(const float* w, float* out, int nb
     }
     f32x4 slo[RG], shi[RG], Vd[RG];
     RgCarry<RG> carry;
-    rg_gvp<SpecGen, RG, D, 0, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
-    for (int b = 1; b < nblk; ++b) rg_gvp<SpecGen, RG, D, 1, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp);
+    RgWave wv{0, 0};
+    rg_gvp<SpecGen, RG, D, 0, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp, wv);
+    for (int b = 1; b < nblk; ++b) rg_gvp<SpecGen, RG, D, 1, false>(ring, X, Va, zero, zero, slo, shi, carry, lds, lane, stamp, wv);
     rg_flush<RG, D, true, true>(ring, X, Va, Vd, carry, lds, lane, stamp);
     float s = 0.f;
     for (int r = 0; r < RG; ++r) s += X[r][0] + Va[r][1] + Vd[r][2] + slo[r][0] + shi[r][1];
