@@ -144,11 +144,9 @@ struct pf_handle {
     std::vector<size_t> rg_msg, rg_upd;
     std::vector<size_t> rgs_msg, rgs_upd, rgs_upd_stride;   // two-wave form: wave 0's stream; wave 1's follows *_stride floats later
     size_t rgs_msg_stride = 0;
-    // launches with at most this many 4-row groups run each group on TWO waves (pf_rg.hip: SPLIT).  Off by default: at
-    // config 2 it shortens the node + head launch by 3 us (19.0 -> 15.8), is neutral for launches with ~500 groups, and the
-    // layer-0 edge launch that follows two launches later then takes 30 us instead of 21 (same wave cycles, longer kernel:
-    // DESIGN.md section 4.1, open question) -- PFDYN_RG_SPLIT_MAX=128 switches it on for the head
-    int rg_split_max = 0;
+    // launches with at most this many 4-row groups run each group on TWO waves (pf_rg.hip: SPLIT): pays off while the
+    // groups are far fewer than the CUs (config 2: node + head launch 19.0 -> 15.8 us; neutral at ~500 groups)
+    int rg_split_max = 128;
     std::vector<int> last_family;           // per conv layer: pf_debug_kernel_family
     int rg_rows_max = 1 << 30, rg2_rows_min = 12000;
     // 0: tile kernels; 1 / 2: row-group kernels with 4 / 8 rows per wave

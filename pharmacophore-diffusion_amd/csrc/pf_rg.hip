@@ -26,6 +26,7 @@
 // launch is small enough for L2 to feed them (rg_rows_max).
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <algorithm>
 #include "pf_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -75,6 +76,7 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f(const float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
+#define RG_QUAD_MAX 4096                       // launches of up to this many item slots use four-wave workgroups
 #define RG_CPASS 16                            // compact work lists: up to 64 * RG_CPASS regions per launch
 // integer DPP moves for wave scans: lanes without a source (or rows outside ROW_MASK) read 0
 template <int CTRL>
@@ -95,9 +97,9 @@ __device__ __forceinline__ float asum(const float v) { return gsum(qsum(v)); }
 #ifdef PF_STAMPS
 __device__ unsigned long long* g_rg_stamps = nullptr;
 struct RgStamp {
-    int k = 0;
+    int k = 0, id = 0;                                // id: item of the wave (first 64 items are recorded)
     __device__ __forceinline__ void operator()(const int lane) {
-        if (lane == 0 && g_rg_stamps && blockIdx.x < 64 && k < 64) g_rg_stamps[blockIdx.x * 64 + k] = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && g_rg_stamps && id < 64 && k < 64) g_rg_stamps[id * 64 + k] = __builtin_amdgcn_s_memtime();
         ++k;
     }
 };
@@ -109,6 +111,7 @@ static void rg_stamp_arm(hipStream_t s) {
 }
 #else
 struct RgStamp {
+    int id = 0;
     __device__ __forceinline__ void operator()(const int) {}
 };
 #endif
@@ -545,14 +548,29 @@ __device__ __forceinline__ void rg_encode(const EncodeParams& ep, const int nt, 
 // destination ids are wave-uniform, the test is scalar) and stores one partial row per (wave, destination) run at the
 // run's last slot -- what the node kernels read (NodeParams::grp = 4*RG).
 // ---------------------------------------------------------------------------------------------
-template <bool L0, int RG, bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 128 : 64) void k_rg_edge(const EdgeParams p, const EncodeParams ep) {
+// Workgroup shape: 256 threads = four waves; items are dealt in super-blocks of 1024: wave q of workgroup b takes item
+// 1024 (b / 256) + 256 q + b % 256 (two-wave form: 128 threads = one item).  Single-wave workgroups leave the wave -> SIMD placement to the dispatcher's round robin, whose
+// state survives kernel boundaries: after a launch of two-wave workgroups the busy waves of the next single-wave launch
+// land on half of the SIMDs (layer-0 edge launch of config 2: 21 -> 30 us at unchanged wave cycles).  A four-wave
+// workgroup always covers the four SIMDs of its CU, and this assignment puts the first 256 items of a launch on 256
+// different workgroups (CUs), the next 256 on their second waves (SIMDs), ... whatever the grid size, which only bounds
+// the number of busy items from above -- a launch with fewer busy items than SIMDs gets one busy wave per SIMD, each with as much of a CU's vector memory path as possible (four consecutive
+// items per workgroup measured 10 % slower on the 48-item node + head launch).
+// Launches with many more items than SIMDs (WAVES = 1) keep single-wave workgroups: a four-wave workgroup holds its
+// slots until its slowest wave retires (batch 512: -14 %), and placement history no longer matters there.
+template <bool L0, int RG, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_rg_edge(const EdgeParams p, const EncodeParams ep) {
+    constexpr bool SPLIT = WAVES == 2;
     constexpr int D = RgDepth<RG>::D;
-    __shared__ RgLds lds[RG];
+    constexpr int WPB = WAVES == 4 ? 4 : 1;            // waves with their own item per workgroup
+    __shared__ RgLds lds_all[WPB][RG];
     constexpr int G = 4 * RG, PER = 32 / G;
     const int lane = threadIdx.x & 63;
+    const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    RgLds* lds = lds_all[WPB == 4 ? wq : 0];
+    const int item = WPB == 4 ? (int)((blockIdx.x >> 8) * 1024 + wq * 256 + (blockIdx.x & 255)) : (int)blockIdx.x;
     RgWave wv;
-    wv.half = SPLIT ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    wv.half = SPLIT ? wq : 0;
     wv.par = 0;
     int e0, nv, et;
     if (p.nreg > 0) {
@@ -560,7 +578,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void k_rg_edge(const EdgeParams p
         // takes the w-th group of G slots, counting only the groups that hold edges -- the busy waves are the first
         // ones of the grid and spread evenly over the chip, instead of sitting wherever a region's tiles fall.  The
         // region of group w is found by a wave scan over the region lengths (64 regions per pass).
-        const int w = blockIdx.x;
+        const int w = item;
         int first = 0, rsel = -1, cnt = 0, start = 0;
         // every pass's lengths and starts are fetched before the first scan: one global round trip whatever the number
         // of regions (up to 64 * RG_CPASS); the scans themselves run on registers
@@ -597,7 +615,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void k_rg_edge(const EdgeParams p
         et = rsel / p.regB;
         et = et == 3 ? (int)ET_PP : et;                // fourth region kind: pp edges into the active atoms
     } else {
-        const int bid = blockIdx.x;
+        const int bid = item;
+        if (bid >= p.ntiles * PER) return;             // wave-uniform (the grid is rounded up to four items per workgroup)
         const EdgeTile t = p.tiles[bid / PER];
         int nvalid = t.n;
         if (t.cnt_idx >= 0) nvalid = min(nvalid, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
@@ -608,6 +627,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void k_rg_edge(const EdgeParams p
         e0 = t.e0 + base;
     }
     RgStamp stamp;
+    stamp.id = SPLIT ? 2 * item + wv.half : item;
     stamp(lane);                                       // kernel start
     RgRing<D> ring;
     ring_start(ring, SPLIT ? p.rgs[et] + (size_t)wv.half * p.rgs_stride : p.rg[et], lane);   // in flight under the gather
@@ -678,16 +698,22 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void k_rg_edge(const EdgeParams p
 // GVPLayerNorm, update chain, residual, GVPLayerNorm.  A wave = 4*RG nodes of one tile.  HEAD: last conv layer of
 // the inference path (pharm tiles): the noise head (dynamics_gvp.py:37-42) runs on the registers right away.
 // ---------------------------------------------------------------------------------------------
-template <bool L0, int RG, bool HEAD, bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 128 : 64) void k_rg_node(const NodeParams p, const HeadParams hp, const EncodeParams ep) {
+template <bool L0, int RG, bool HEAD, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_rg_node(const NodeParams p, const HeadParams hp, const EncodeParams ep) {
+    constexpr bool SPLIT = WAVES == 2;
     constexpr int D = RgDepth<RG>::D;
-    __shared__ RgLds lds[RG];
+    constexpr int WPB = WAVES == 4 ? 4 : 1;            // workgroup shape: see k_rg_edge
+    __shared__ RgLds lds_all[WPB][RG];
     constexpr int G = 4 * RG, PER = 32 / G;
     const int lane = threadIdx.x & 63;
+    const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    RgLds* lds = lds_all[WPB == 4 ? wq : 0];
+    const int item = WPB == 4 ? (int)((blockIdx.x >> 8) * 1024 + wq * 256 + (blockIdx.x & 255)) : (int)blockIdx.x;
     RgWave wv;
-    wv.half = SPLIT ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    wv.half = SPLIT ? wq : 0;
     wv.par = 0;
-    const int bid = blockIdx.x;
+    const int bid = item;
+    if (bid >= p.ntiles * PER) return;                 // wave-uniform
     const NodeTile t = p.tiles[bid / PER];
     int tn = t.n;
     if (t.cnt_idx >= 0) tn = min(tn, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
@@ -696,6 +722,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void k_rg_node(const NodeParams p
     if (nv <= 0) return;                               // wave-uniform
     const int nt = __builtin_amdgcn_readfirstlane(t.ntype);
     RgStamp stamp;
+    stamp.id = SPLIT ? 2 * item + wv.half : item;
     stamp(lane);                                       // kernel start
     RgRing<D> ring;
     ring_start(ring, SPLIT ? p.rgs_upd[nt] + (size_t)wv.half * p.rgs_stride[nt] : p.rg_upd[nt], lane);
@@ -903,16 +930,15 @@ void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int r
     if (grid == 0) return;
     const EncodeParams noenc{};
     const EncodeParams& ep = (layer0 && enc) ? *enc : noenc;      // layer 0: encode the gathered rows on the fly
-    if (rg == 1 && split) {
-        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 1, true>), dim3(grid), dim3(128), 0, s, *p, ep);
-        else hipLaunchKernelGGL((k_rg_edge<false, 1, true>), dim3(grid), dim3(128), 0, s, *p, ep);
-    } else if (rg == 1) {
-        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 1, false>), dim3(grid), dim3(64), 0, s, *p, ep);
-        else hipLaunchKernelGGL((k_rg_edge<false, 1, false>), dim3(grid), dim3(64), 0, s, *p, ep);
-    } else {
-        if (layer0) hipLaunchKernelGGL((k_rg_edge<true, 2, false>), dim3(grid), dim3(64), 0, s, *p, ep);
-        else hipLaunchKernelGGL((k_rg_edge<false, 2, false>), dim3(grid), dim3(64), 0, s, *p, ep);
-    }
+    const int grid4 = grid <= 256 ? grid : (grid + 1023) / 1024 * 256;      // super-blocks of 256 workgroups x 4 waves
+    const bool quad = grid <= RG_QUAD_MAX;                                  // latency regime: deterministic SIMD placement
+#define PF_RG_EDGE(L0_, RG_, W_, GRID_) hipLaunchKernelGGL((k_rg_edge<L0_, RG_, W_>), dim3(GRID_), dim3(64 * W_), 0, s, *p, ep)
+    if (rg == 1 && split) { if (layer0) PF_RG_EDGE(true, 1, 2, grid); else PF_RG_EDGE(false, 1, 2, grid); }
+    else if (rg == 1 && quad) { if (layer0) PF_RG_EDGE(true, 1, 4, grid4); else PF_RG_EDGE(false, 1, 4, grid4); }
+    else if (rg == 1) { if (layer0) PF_RG_EDGE(true, 1, 1, grid); else PF_RG_EDGE(false, 1, 1, grid); }
+    else if (quad) { if (layer0) PF_RG_EDGE(true, 2, 4, grid4); else PF_RG_EDGE(false, 2, 4, grid4); }
+    else { if (layer0) PF_RG_EDGE(true, 2, 1, grid); else PF_RG_EDGE(false, 2, 1, grid); }
+#undef PF_RG_EDGE
 }
 void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s) {
     if (p->ntiles == 0) return;
@@ -926,17 +952,20 @@ void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* 
     const int grid = p->ntiles * per;
     const EncodeParams noenc{};
     const EncodeParams& ep = (layer0 && enc) ? *enc : noenc;
-#define PF_RG_NODE(L0_, RG_, HEAD_, SP_) hipLaunchKernelGGL((k_rg_node<L0_, RG_, HEAD_, SP_>), dim3(grid), dim3(SP_ ? 128 : 64), 0, s, *p, h, ep)
-    if (rg == 1 && split) {
-        if (head) { if (layer0) PF_RG_NODE(true, 1, true, true); else PF_RG_NODE(false, 1, true, true); }
-        else { if (layer0) PF_RG_NODE(true, 1, false, true); else PF_RG_NODE(false, 1, false, true); }
-    } else if (rg == 1) {
-        if (head) { if (layer0) PF_RG_NODE(true, 1, true, false); else PF_RG_NODE(false, 1, true, false); }
-        else { if (layer0) PF_RG_NODE(true, 1, false, false); else PF_RG_NODE(false, 1, false, false); }
-    } else {
-        if (head) { if (layer0) PF_RG_NODE(true, 2, true, false); else PF_RG_NODE(false, 2, true, false); }
-        else { if (layer0) PF_RG_NODE(true, 2, false, false); else PF_RG_NODE(false, 2, false, false); }
-    }
+    const int grid4 = grid <= 256 ? grid : (grid + 1023) / 1024 * 256;
+    const bool quad = grid <= RG_QUAD_MAX;
+#define PF_RG_NODE(L0_, RG_, HEAD_, W_, GRID_) hipLaunchKernelGGL((k_rg_node<L0_, RG_, HEAD_, W_>), dim3(GRID_), dim3(64 * W_), 0, s, *p, h, ep)
+#define PF_RG_NODE2(RG_, W_, GRID_)                                                                      \
+    do {                                                                                                 \
+        if (head) { if (layer0) PF_RG_NODE(true, RG_, true, W_, GRID_); else PF_RG_NODE(false, RG_, true, W_, GRID_); }   \
+        else { if (layer0) PF_RG_NODE(true, RG_, false, W_, GRID_); else PF_RG_NODE(false, RG_, false, W_, GRID_); }      \
+    } while (0)
+    if (rg == 1 && split) PF_RG_NODE2(1, 2, grid);
+    else if (rg == 1 && quad) PF_RG_NODE2(1, 4, grid4);
+    else if (rg == 1) PF_RG_NODE2(1, 1, grid);
+    else if (quad) PF_RG_NODE2(2, 4, grid4);
+    else PF_RG_NODE2(2, 1, grid);
+#undef PF_RG_NODE2
 #undef PF_RG_NODE
 }
 }
