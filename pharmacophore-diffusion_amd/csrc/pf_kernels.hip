@@ -1467,7 +1467,6 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
     BSTAMP(9);                                        // ff done
     // ------------------------------------------------------------------ pf (prot -> pharm)
     const int reg_pf = p.reg[1 * p.B + g];
-    const int reg_fp = p.reg[2 * p.B + g];
     if (p.pf_k > 0) {
         const int kk = min(p.pf_k, Np);
         for (int fl = wave; fl < Nf; fl += 4) {
@@ -1785,11 +1784,11 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
     __shared__ float4 fx[PF_MAXF];                  // updated pharm coordinates (COM removed)
     __shared__ float4 px[NT];                       // updated protein coordinates
     __shared__ float red[NW][3];
-    __shared__ __attribute__((aligned(16))) int knn_idx[PF_MAXF * PF_MAXK];
     __shared__ unsigned long long scratch[NW];
-    // active atoms in list order: first slot of their pp in-edges in the "pa" region, node id, static
-    // in-edge start, and the first 16 static sources (prefetched) -- the copy into the region is then done by ALL
-    // threads, one output slot each, with coalesced stores
+    __shared__ unsigned int refm[NT][2];            // per atom: bit fl set <=> center fl has the atom among its k neighbours
+    // active atoms in list order: first slot of their pp in-edges in the "pa" region, node id, static in-edge start;
+    // a_src: the first 16 static sources of EVERY atom (prefetched, indexed by atom) -- the copy into the region is
+    // then done by ALL threads, one output slot each, with coalesced stores
     __shared__ int a_d0[NT], a_node[NT], a_pst[NT];
     __shared__ __attribute__((aligned(16))) int a_src[NT][16];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1862,11 +1861,12 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
     }
     if (isp) { xp.x -= com[0]; xp.y -= com[1]; xp.z -= com[2]; sp.xn[p0 + tid] = xp; }
     px[tid] = xp;
+    refm[tid][0] = 0u; refm[tid][1] = 0u;
     lds_barrier();
     // ---- ff (pharm -> pharm) on wave 0: counts, wave scan for the offsets, emission
     const int kff = p.ff_k > 0 ? max(min(p.ff_k, Nf - 1), 0) : 0;
-    int ff_total = 0;                                 // valid in wave 0
-    if (wave == 0) {
+    int ff_total = 0;                                 // valid in the last wave (it has no center to search while Nf < 8)
+    if (wave == NW - 1) {
         int c = 0;
         if (lane < Nf) {
             if (p.ff_k > 0) c = kff;
@@ -1911,19 +1911,20 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = lane + 64 * i;
-            kc[i] = c < Np ? dkey(sqdist_rn(px[c], q), c) : ~0ull;
+            kc[i] = ~0ull;
+            if (64 * i < Np) kc[i] = c < Np ? dkey(sqdist_rn(px[c], q), c) : ~0ull;    // wave-uniform bound
         }
         unsigned long long prev = 0ull;
         for (int r = 0; r < kk; ++r) {
             unsigned long long best = ~0ull;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if ((r == 0 || kc[i] > prev) && kc[i] < best) best = kc[i];
+                if (64 * i < Np && (r == 0 || kc[i] > prev) && kc[i] < best) best = kc[i];
             best = wave_min_u64(best);
             prev = best;
             if (lane == 0) {
                 const int pc = (int)(best & 0xffffffffu);
-                knn_idx[fl * PF_MAXK + r] = pc;
+                atomicOr(&refm[pc][fl >> 5], 1u << (fl & 31));
                 p.esrc[reg_pf + fl * kk + r] = p0 + pc;
                 p.edst[reg_pf + fl * kk + r] = GF + fl;
             }
@@ -1931,32 +1932,22 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
         if (lane == 0) { in_start1[GF + fl] = reg_pf + fl * kk; in_cnt1[GF + fl] = kk; }
     }
     if (tid == 0) { p.dyn_cnt[1 * p.B + g] = Nf * kk; p.dyn_cnt[2 * p.B + g] = Nf * kk; }
+    {   // the prefetched pp sources go to LDS here, unconditionally: left to their only use (active atoms, below) the
+        // compiler sinks the loads into that branch and the round trip (C) is paid there, late and exposed
+        int4* st = reinterpret_cast<int4*>(&a_src[tid][0]);
+        st[0] = make_int4(psrc[0], psrc[1], psrc[2], psrc[3]);
+        st[1] = make_int4(psrc[4], psrc[5], psrc[6], psrc[7]);
+        st[2] = make_int4(psrc[8], psrc[9], psrc[10], psrc[11]);
+        st[3] = make_int4(psrc[12], psrc[13], psrc[14], psrc[15]);
+    }
     lds_barrier();
     BSTAMP(10);
     // ---- fp = pf reversed, destination-major over the atoms; active atoms and the compact copy of their pp in-edges
     {
         const int c = tid;
-        int my = 0;
-        int rf[4] = {0, 0, 0, 0};                     // the first referencing centers (ascending): usually all of them
-        // a center references an atom at most once (its k neighbours are distinct): per center one 16-entry row of
-        // knn_idx, read as four b128 loads that do not depend on each other across centers
-        for (int fl = 0; fl < Nf; ++fl) {
-            const int4* row = reinterpret_cast<const int4*>(&knn_idx[fl * PF_MAXK]);
-            bool hit = false;
-#pragma unroll
-            for (int q4 = 0; q4 < PF_MAXK / 4; ++q4) {
-                if (4 * q4 < kk) {
-                    const int4 v = row[q4];
-                    hit |= (v.x == c) | ((4 * q4 + 1 < kk) & (v.y == c)) | ((4 * q4 + 2 < kk) & (v.z == c)) | ((4 * q4 + 3 < kk) & (v.w == c));
-                }
-            }
-            hit &= isp;
-            rf[0] = (hit && my == 0) ? fl : rf[0];
-            rf[1] = (hit && my == 1) ? fl : rf[1];
-            rf[2] = (hit && my == 2) ? fl : rf[2];
-            rf[3] = (hit && my == 3) ? fl : rf[3];
-            my += hit ? 1 : 0;
-        }
+        // the centers that reference this atom, ascending: the bits of its mask (set by the kNN waves above)
+        const unsigned int m0 = isp ? refm[c][0] : 0u, m1 = isp ? refm[c][1] : 0u;
+        const int my = __popc(m0) + __popc(m1);
         BSTAMP(12);                                   // references counted
         const int act = (my > 0 && p.act_ids) ? 1 : 0;
         const int deg = act ? pdeg : 0;
@@ -1979,14 +1970,11 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
             int e = reg_fp + (int)(o & 0xffffu);
             in_start0[p0 + c] = e;
             in_cnt0[p0 + c] = my;
-            if (my > 0 && my <= 4) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < my) { p.esrc[e + k] = GF + rf[k]; p.edst[e + k] = p0 + c; }
-            } else if (my > 4) {
-                for (int fl = 0; fl < Nf; ++fl)
-                    for (int r = 0; r < kk; ++r)
-                        if (knn_idx[fl * PF_MAXK + r] == c) { p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
+            {
+                unsigned int mm = m0;
+                while (mm) { const int fl = __ffs(mm) - 1; mm &= mm - 1; p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
+                mm = m1;
+                while (mm) { const int fl = 32 + __ffs(mm) - 1; mm &= mm - 1; p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
             }
             if (act) {
                 const int j = (int)((o >> 16) & 0xfffu);
@@ -1994,14 +1982,11 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
                 in_start2[p0 + c] = reg_pa + (int)(o >> 28);
                 in_cnt2[p0 + c] = deg;
                 a_d0[j] = (int)(o >> 28); a_node[j] = p0 + c; a_pst[j] = pst;
-                int4* st = reinterpret_cast<int4*>(&a_src[j][0]);
-                st[0] = make_int4(psrc[0], psrc[1], psrc[2], psrc[3]);
-                st[1] = make_int4(psrc[4], psrc[5], psrc[6], psrc[7]);
-                st[2] = make_int4(psrc[8], psrc[9], psrc[10], psrc[11]);
-                st[3] = make_int4(psrc[12], psrc[13], psrc[14], psrc[15]);
             }
         }
+        BSTAMP(14);                                   // fp edges / descriptors stored, active atoms staged
         lds_barrier();
+        BSTAMP(15);
         {   // the "pa" region: slot t belongs to the last active atom whose first slot is <= t (binary search in LDS)
             const int n_pa = (int)(all >> 28), n_act = (int)((all >> 16) & 0xfffu);
             for (int t = tid; t < n_pa; t += NT) {
@@ -2011,7 +1996,7 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
                     if (a_d0[mid] <= t) lo = mid; else hi = mid - 1;
                 }
                 const int k = t - a_d0[lo];
-                const int src = k < 16 ? a_src[lo][k] : p.esrc[a_pst[lo] + k];
+                const int src = k < 16 ? a_src[a_node[lo] - p0][k] : p.esrc[a_pst[lo] + k];
                 p.esrc[reg_pa + t] = src;
                 p.edst[reg_pa + t] = a_node[lo];
             }
@@ -2020,7 +2005,7 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
             p.dyn_cnt[3 * p.B + g] = (int)(all >> 28);
             p.dyn_cnt[4 * p.B + g] = (int)((all >> 16) & 0xfffu);
         }
-        if (tid == 0 && p.norm_mode == 2) {           // per-graph normalisers for message_norm == 0 (gvp.py:504-507)
+        if (tid == NT - 64 && p.norm_mode == 2) {     // per-graph normalisers for message_norm == 0 (gvp.py:504-507)
             p.gnorm[1 * p.B + g] = (float)(ff_total + Nf * kk) / (float)Nf + 1.0f;
             p.gnorm[0 * p.B + g] = (float)(Nf * kk + p.pp_cnt[g]) / (float)Np + 1.0f;
         }

@@ -50,7 +50,7 @@ if hasattr(lib, "pfk_build_set_stamp_buffer"):
     print("== k_step_build: cycles [start -> build start (update) -> ff done -> kNN done -> protein side emitted]")
     for g in range(3):
         r = st[g]
-        print(f"  graph {g}: update {int(r[8] - r[0])}  ff {int(r[9] - r[8])}  kNN {int(r[10] - r[9])}  emit {int(r[11] - r[10])} (count {int(r[12] - r[10])}, scan {int(r[13] - r[12])}, stores {int(r[11] - r[13])})  total {int(r[11] - r[0])}")
+        print(f"  graph {g}: update {int(r[8] - r[0])}  ff {int(r[9] - r[8])}  kNN {int(r[10] - r[9])}  emit {int(r[11] - r[10])} (count {int(r[12] - r[10])}, scan {int(r[13] - r[12])}, stores {int(r[14] - r[13])}, barrier {int(r[15] - r[14])}, pa copy {int(r[11] - r[15])})  total {int(r[11] - r[0])}")
 for which in range(4):
     buf.zero_()
     assert lib.pfk_rg_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
