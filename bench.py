@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra dense-mode kernel measurement")
+    ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed device activity before the W warm-up steps")
     ap.add_argument("--event-every", type=int, default=10,
                     help="HIP events around the roofline kernel on every N-th timed step (0: never)")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel device time to stderr")
@@ -100,13 +101,16 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
 
     EV_MASK = (1 << 2) | (1 << 6)                               # edge-message launches of conv layer 0
+    noise_buf = torch.empty(max(K, W) + 1, Nf, 9, device=dev)
 
     def run(n, first, event_every=0):
         """n denoising steps.  event_every > 0: every event_every-th step has HIP events around its layer-0 edge-message
         launch (the roofline kernel): a pair of event records costs ~11 us of stream time on this stack, so bracketing
         every launch would inflate a 75 us step by 15 %; one step in event_every keeps the measurement live inside the
         timed region at ~1 us per step."""
-        noise = torch.randn(n + 1, Nf, 9, device=dev, generator=gen)   # x columns first, then h
+        # x columns first, then h; drawn on the device inside the timed region, into a buffer allocated once outside it
+        # (a fresh allocation in the timed region occasionally costs tens of milliseconds of host time)
+        noise = noise_buf[:n + 1].normal_(generator=gen)
         if first:
             eng.sample_begin(noise[0])
         for i in range(n):
@@ -120,7 +124,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(W, True) if W > 0 else eng.sample_begin(torch.randn(Nf, 9, device=dev, generator=gen))
+    # GPU clocks: the first tens of milliseconds after an idle period run below the sustained clock (the first 100
+    # steps after set-up measured 1.1-2.3x slower than the following ones at batch 128-256); the W warm-up steps
+    # (0.8 ms at config 2) do not cover that, so the device is kept busy for --prewarm-ms first, on the same pockets
+    # (the reverse process is restarted by the warm-up below)
+    if args.prewarm_ms > 0:
+        tp = time.perf_counter()
+        while (time.perf_counter() - tp) * 1e3 < args.prewarm_ms:
+            run(min(max(K, W), 50), True)
+            torch.cuda.synchronize()
+    # the warm-up steps run with the events on: the library creates its event pairs on first use, and creating them
+    # inside the timed region occasionally stalls the host for tens of milliseconds (observed at batch 128-256)
+    run(W, True, event_every=1) if W > 0 else eng.sample_begin(torch.randn(Nf, 9, device=dev, generator=gen))
+    eng.profile_read()
+    eng.profile_enable(0)
     barrier()
     t0 = time.perf_counter()
     run(K, False, event_every=args.event_every)
@@ -243,6 +260,10 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    tp = time.perf_counter()
+    while (time.perf_counter() - tp) * 1e3 < args.prewarm_ms:      # sustained clocks before the warm-up (see main)
+        step()
+        torch.cuda.synchronize()
     for _ in range(W):
         step()
     barrier()
