@@ -1,4 +1,5 @@
-// pf_rg.hip -- "row-group" kernels of the denoising path for launches with few rows (gfx950 only).
+// pf_rg.hip -- "row-group" kernels of the denoising path: the inference form of the conv layers and the noise head
+// (gfx950 only).
 //
 // Same mathematics as pf_kernels.hip (GVP.forward gvp.py:89-116, GVPMultiEdgeConv gvp.py:459-551, GVPLayerNorm
 // gvp.py:159-166, NoisePredictionBlock dynamics_gvp.py:37-42), different mapping onto the matrix cores: at the
@@ -21,9 +22,11 @@
 //
 // A wave therefore needs no partner: no workgroup barriers, 4-row granularity (ragged regions waste at most 3 rows),
 // and a GVP level costs ~350 MFMAs x 8 cycles per group.  All weights of a chain are one contiguous stream of 1-KiB
-// "quads" in consumption order (pf_host.cpp: pack_gvp_rg), prefetched 16-32 quads ahead into registers across GVP
-// boundaries.  Per row the weight traffic is 8x that of a 32-row tile, so pf_host.cpp uses these kernels only while the
-// launch is small enough for L2 to feed them (rg_rows_max).
+// "quads" in consumption order (pf_host.cpp: pack_gvp_rg), prefetched 12-24 quads ahead into registers across GVP
+// boundaries; the chain is software-pipelined (rg_gvp).  Per row the weight traffic is 4-8x that of a 32-row tile, yet
+// these kernels won at every batch size measured (32-1024 graphs): 4-row granularity, no barriers, no padding of the
+// ragged regions.  The 32-row tile kernels of pf_kernels.hip remain for training.  Launch policy: pf_host.cpp rg_mode;
+// measurements and the cycle accounting: DESIGN.md section 4.1, profiles/README.md.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <algorithm>
