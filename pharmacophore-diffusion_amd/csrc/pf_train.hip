@@ -994,6 +994,15 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_encode(const BwdEncodeParams p) {
         const int nf = nt ? p.pharm_nf : p.rec_nf;
         const int K = nf + 1;
         const int ow = p.o_w[nt], ob = p.o_b[nt], olw = p.o_lw[nt], olb = p.o_lb[nt];
+        {   // rows outside the receptive field of the output (most protein atoms of a pruned layer) have an exactly zero
+            // incoming gradient: their tile contributes nothing to any parameter gradient and is skipped
+            int nz = 0;
+            for (int idx = tid; idx < TR * 128; idx += NT) {
+                const int r = idx >> 7, f = idx & 127;
+                if (r < nv && p.G_h[(size_t)(first + r) * PF_S + f] != 0.f) nz = 1;
+            }
+            if (!__syncthreads_or(nz)) continue;       // block-uniform
+        }
         for (int idx = tid; idx < TR * K; idx += NT) {
             const int row = idx / K, k = idx - row * K;
             const int n = first + min(row, nv - 1);
