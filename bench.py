@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra dense-mode kernel measurement")
+    ap.add_argument("--arch", choices=["dev", "class-default"], default="dev",
+                    help="dev = configs/dev.yml dynamics block (the headline); class-default = the depth the reference's "
+                         "class defaults give (SURVEY 8d secondary run): n_convs=4, n_noise_gvps=3, message_norm=1, radius pf edges")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed device activity before the W warm-up steps")
     ap.add_argument("--event-every", type=int, default=10,
                     help="HIP events around the roofline kernel on every N-th timed step (0: never)")
@@ -78,8 +81,12 @@ def main():
         return
     B, T, K, W = args.batch, args.timesteps, args.steps, args.warmup
     # ---- inputs: B distinct pockets per rank (weak scaling: per-GPU work fixed), resident in HBM
-    eng = pfa.PfEngine(device=dev)
-    eng.load_state_dict(synthetic.make_state_dict(0))
+    arch_eng, arch_sd = {}, {}
+    if args.arch == "class-default":
+        arch_eng = dict(n_convs=4, n_noise_gvps=3, message_norm=1, pf_k=0)
+        arch_sd = dict(n_convs=4, n_noise_gvps=3)
+    eng = pfa.PfEngine(device=dev, **arch_eng)
+    eng.load_state_dict(synthetic.make_state_dict(0, **arch_sd))
     xs, hs = zip(*[synthetic.synthetic_pocket(1000 * rank + i, args.n_prot) for i in range(B)])
     prot_x, prot_h = torch.cat(xs).to(dev), torch.cat(hs).to(dev)
     prot_ptr = torch.arange(B + 1, dtype=torch.int64) * args.n_prot
@@ -171,8 +178,9 @@ def main():
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("BASELINE config 2: 256-atom pocket, 6 centers, T=500 schedule, batch=32 per GPU, dev.yml network"
-                                if (B, args.n_prot, args.n_pharm, args.pharm_sizes) == (32, 256, 6, "") else
-                                f"custom: {args.n_prot}-atom pockets, centers {args.pharm_sizes or args.n_pharm}, batch={B} per GPU, dev.yml network"),
+                                if (B, args.n_prot, args.n_pharm, args.pharm_sizes, args.arch) == (32, 256, 6, "", "dev") else
+                                f"custom: {args.n_prot}-atom pockets, centers {args.pharm_sizes or args.n_pharm}, batch={B} per GPU, "
+                                + ("dev.yml network" if args.arch == "dev" else "class-default network (n_convs=4, n_noise_gvps=3, message_norm=1, radius pf)")),
                    "batch_per_gpu": B, "n_prot": args.n_prot, "n_pharm": args.pharm_sizes or args.n_pharm, "T": T,
                    "edges_per_step": {"ff": ne[0], "pf": ne[1], "fp": ne[2], "pp": ne[3]},
                    "edges_computed_per_layer": wk["executed_edges_per_layer"],
@@ -182,7 +190,7 @@ def main():
                      # HBM-side bytes per launch of that kernel from the committed rocprofv3 PMC passes
                      # (profiles/r01/*_pmc_hbm.csv: 2 x FETCH_SIZE [gfx950 wide-read correction] + WRITE_SIZE);
                      # PMC counters cannot be collected from inside this process
-                     "traffic": PMC_TRAFFIC.get(fam) if (B, args.n_prot, args.n_pharm, args.pharm_sizes) == (32, 256, 6, "") else None,
+                     "traffic": PMC_TRAFFIC.get(fam) if (B, args.n_prot, args.n_pharm, args.pharm_sizes, args.arch) == (32, 256, 6, "", "dev") else None,
                      "kernel_avg_us": edge_avg_s * 1e6, "launches_timed": edge_n, "flop_per_launch": edge_flops,
                      "note": "edge-message launches timed by HIP events inside the timed region; FLOP = 136,742 per edge "
                              "(SURVEY 8d) x edges the launch computes (conv layer 0). Outputs equal the "
