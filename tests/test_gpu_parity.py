@@ -389,3 +389,26 @@ def test_fused_update_and_edge_build_variants_agree(case, monkeypatch):
     torch.testing.assert_close(res[0][1], res[2][1], rtol=1e-5, atol=1e-5)
     ox, oh = O.sample_given_receptor(sd, cfg, batch, T, 1e-5, noise, n_steps=5, endpoint_param_coord=ep, endpoint_param_feat=ep)
     close(res[0][0], ox, 5e-3, 5e-3); close(res[0][1], oh, 5e-3, 5e-3)
+
+
+def test_kernel_family_reporting(monkeypatch):
+    """pf_debug_kernel_family reports what the launch policy chose for a layer's edge messages: the row-group kernels by
+    default (4 rows per wave for small launches), the 32-row tile kernels when they are switched off."""
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    batch = O.synthetic_batch([71, 72], 64, [4, 5], cfg)
+    x_t, h_t, t = _rand_inputs(batch, 5)
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    eng.dynamics(x_t, h_t, t)
+    assert eng.kernel_family(0) == 4 and eng.kernel_family(1) == 4
+    monkeypatch.setenv("PFDYN_RG2_ROWS_MIN", "0")
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    eng.dynamics(x_t, h_t, t)
+    assert eng.kernel_family(0) == 8
+    monkeypatch.setenv("PFDYN_RG_ROWS_MAX", "0")
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    eng.dynamics(x_t, h_t, t)
+    assert eng.kernel_family(0) in (32, 128)
