@@ -105,6 +105,9 @@ def main():
     # with random-init weights the early, high-noise steps (1/alpha_t|s = 1.6) blow the coordinates up; the tail keeps
     # a realistic geometry (all ff edges present).  Work per step does not depend on s.
     carr = eng.coef_array(coef, order)
+    # the trajectory's timesteps, as pf_sample announces them itself (layer-0 type tables: one launch per 64 timesteps
+    # at set-up instead of one small launch in front of every step)
+    eng.prepare_timesteps(carr, W + K)
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
 
     EV_MASK = (1 << 2) | (1 << 6)                               # edge-message launches of conv layer 0

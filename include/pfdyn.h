@@ -133,6 +133,11 @@ int pf_sample_end(pf_handle* h, float feat_norm_constant, float* dev_x0 /*[Nf,3]
 /* current frame in the caller's frame of reference (get_pos_feat_for_visual, pharmacodiff.py:360-378) */
 int pf_sample_frame(pf_handle* h, float feat_norm_constant, float* dev_x /*[Nf,3]*/, float* dev_h /*[Nf,pharm_nf]*/,
                     pf_stream stream);
+/* Optional, before a loop of pf_denoise_step calls: the timesteps (pf_step_coef::t) the loop will visit.  The first
+ * conv layer's protein-side messages depend on t only through one encoder output per element type
+ * (dynamics_gvp.py:107-117 feeding gvp.py:545-549); their tables are computed here in one launch per 64 timesteps
+ * instead of one small launch in front of every step.  pf_sample does this itself; results never depend on it. */
+int pf_prepare_timesteps(pf_handle* h, const float* host_t, int32_t n, pf_stream stream);
 /* whole loop: begin + n_steps x step + end, all enqueued on `stream` without host synchronisation.
  * host_coef[i] is the i-th iteration's coefficients (s = T-1-i); dev_noise is [n_steps+1, Nf, 3+pharm_nf].
  * dev_traj_x / dev_traj_h (optional) receive n_steps+1 frames. */
@@ -209,6 +214,9 @@ int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges /
  * on the batch: pf_host.cpp rg_mode / coop*_max): *rows_per_wave = 4 or 8 (row-group kernels, pf_rg.hip: k_rg_edge),
  * 32 (one wave per 32-row tile: k_edge_msg) or 128 (four waves per 32-row tile: k_edge_msg_coop / coop2) */
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave);
+/* static hoist of conv layer 0's protein-protein messages in the last dynamics call: *rows_per_wave = 0 (not used: training,
+ * tile kernels, protein features that are not element one-hots, PFDYN_NO_L0_HOIST=1) or 4 / 8 rows per hoisted wave */
+int pf_debug_l0_hoist(pf_handle* h, int32_t* rows_per_wave);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,7 @@ SYMBOLS = {
     "pf_sample_begin": (ctypes.c_int, [_P, _P, _P, _P]),
     "pf_denoise_step": (ctypes.c_int, [_P, ctypes.POINTER(PfStepCoef), _P, _I32, _I32, _P]),
     "pf_sample_end": (ctypes.c_int, [_P, _F, _P, _P, _P]),
+    "pf_prepare_timesteps": (ctypes.c_int, [_P, _P, _I32, _P]),
     "pf_sample_frame": (ctypes.c_int, [_P, _F, _P, _P, _P]),
     "pf_sample": (ctypes.c_int, [_P, _I32, ctypes.POINTER(PfStepCoef), _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P]),
     "pf_param_count": (ctypes.c_int, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I32)]),
@@ -63,6 +64,7 @@ SYMBOLS = {
     "pf_debug_work": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(_I64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), _P]),
     "pf_debug_kernel_family": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
+    "pf_debug_l0_hoist": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int32)]),
 }
 
 _lib = None

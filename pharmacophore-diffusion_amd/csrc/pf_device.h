@@ -137,6 +137,46 @@ struct EdgeParams {
     // r = kind * regB + graph; kinds ff, pf, fp, pa); ngroups4 / ngroups8 = capacity in groups of 4 / 8 slots (the grid)
     const int* reg; int nreg, regB, ngroups4, ngroups8;
     pf_gcf rgs[4]; int rgs_stride;   // two-wave form: wave 0's stream of each chain; wave 1's follows rgs_stride floats later
+    // conv layer 0, static pp edges (row-group kernels, "static hoist"): the first message GVP of a pp edge
+    // reads h_src = encoder(element one-hot, t) and v_src = 0, and the protein moves rigidly, so its scalar
+    // pre-activation is zs[eo] (bias + rbf + sh terms: constant over the trajectory) + ptab[type(src)] (the h_src block
+    // of the Linear applied to the encoder output of each element type at this t), and its Vu is xhat (x) weff.
+    // zs == NULL: off.  eorig[e]: static pp slot of edge slot e (identity below Epp; set by the edge build for "pa").
+    const float* zs;       // [Epp][128]
+    const float* ptab;     // [graph or 1][ntypes][128]
+    int ptab_gstride;      // floats between the tables of consecutive graphs (0: every graph is at the same t)
+    const int* ptype;      // [Np] element type of each protein atom
+    const int* eorig;      // [Ecap]
+    const int* l0_gid;     // graph of each node (ptab_gstride != 0)
+    const float* l0c;      // [16 weff][16 gate bias]
+    int ngroups_sel;       // compact work list: grid in groups when the regions' group sizes differ by kind (0: ngroups4/8)
+};
+
+// static-hoist source block in the packed weights (pure copies of the first pp message GVP of conv layer 0 and of the
+// protein encoder's consumers: the gather map of pf_set_flat_params covers it); offsets in floats
+#define L0H_WR 0           // [16 rbf][128]     to_feats_out columns 128..143, k-major
+#define L0H_WSH 2048       // [17][128]         to_feats_out columns 144..160 (sh), k-major
+#define L0H_B 4224         // [128]             to_feats_out bias
+#define L0H_WH0 4352       // [17] (+pad)       Wh row 0 (the unit x_diff channel)
+#define L0H_WU 4384        // [17][16]          Wu
+#define L0H_BG 4672        // [16]              gate bias
+#define L0H_WHT 4736       // [128 k][128 f]    to_feats_out columns 0..127 (h_src), k-major
+#define L0H_SIZE (4736 + 16384)
+struct L0HoistParams {
+    const float* src;      // the block above
+    float* l0c;            // out: [16 weff][16 gate bias]
+    // zs
+    const int* esrc; const int* edst; const float4* xn; int Epp;
+    float rbf_mu0, rbf_mu_step, rbf_inv_sigma;
+    float* zs;
+    // ptab
+    const float* enc_w; const float* enc_b; const float* enc_lw; const float* enc_lb;   // protein encoder (w: [rec_nf+1][128])
+    int rec_nf, nt;        // rows = nt * rec_nf
+    const float* t_dev;    // [nt] or NULL: t_host
+    float t_host[64];
+    float* ptab;
+    // types
+    const float* prot_h0; int Np; int* ptype; int* flag;
 };
 
 struct NodeW {             // per node type
@@ -170,6 +210,7 @@ struct NodeParams {
     uint32_t drop_thr; float drop_scale; uint32_t seed; int layer;
     const float* mask_override;   // tests: externally supplied multipliers [n_convs * 2][N * 144] instead of the hash
     int grp;               // edge slots per message partial row group: 32 (tile kernels) or 4*RG (row-group edge kernel)
+    int grp_pa;            // ... of the pp / "pa" segment of the protein nodes (differs from grp under the static hoist)
     pf_gcf rg_upd[2];      // row-group kernels: quad stream of each node type's update chain (pharm of the last layer:
                            // followed by the noise head's chain and to_scalar_output)
     pf_gcf rgs_upd[2]; int rgs_stride[2];   // two-wave form of the same (wave 1's stream rgs_stride floats after wave 0's)
@@ -210,6 +251,7 @@ struct BuildParams {
     int* act_ids;          // active-atom lists (global node ids), or NULL: no receptive-field pruning
     const int* reg_act;    // [B] start of each graph's list in act_ids
     int* esrc; int* edst;
+    int* eorig;            // [Ecap] static pp slot of each "pa" slot (EdgeParams::eorig), or NULL
     int* in_start; int* in_cnt; int N;   // [3][N]: slot 0 ff|fp, slot 1 pf|pp(all), slot 2 pp into active atoms
     int ff_k, pf_k;
     float r2_ff, r2_pf;

@@ -10,11 +10,14 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/pfdyn.h"
 #include "pf_device.h"
 #include "pf_train.h"
+
+#define L0_PTAB_SLOTS 1024        // timesteps whose layer-0 type tables stay resident (pf_prepare_timesteps)
 
 extern "C" {
 void pfk_edge_msg(const EdgeParams* p, int layer0, hipStream_t s);
@@ -25,7 +28,8 @@ void pfk_node_head_coop(const NodeParams* p, const HeadParams* hp, int layer0, h
 void pfk_noise_head_coop(const HeadParams* p, hipStream_t s);
 void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s);
 void pfk_noise_head(const HeadParams* p, hipStream_t s);
-void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s);
+void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int rg, int split, int rgp, hipStream_t s);
+void pfk_l0_hoist(const L0HoistParams* p, int what, hipStream_t s);
 void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
@@ -148,13 +152,32 @@ struct pf_handle {
     // groups are far fewer than the CUs (config 2: node + head launch 19.0 -> 15.8 us; neutral at ~500 groups)
     int rg_split_max = 128;
     std::vector<int> last_family;           // per conv layer: pf_debug_kernel_family
+    int last_hoist = 0;                     // pf_debug_l0_hoist
     int rg_rows_max = 1 << 30, rg2_rows_min = 12000;
+    // compact pruned layer-0 launch under the static hoist: more than half of its items run a two-block chain, so 4 rows
+    // per wave stay ahead up to a larger launch (config 2, 18.4 k slots: 437 k -> 444 k sample-steps/s; batch 64, 36.8 k slots: 701 k -> 714 k; batch 128 prefers 8)
+    int rg2_rows_min_hoist = 48000;
     // 0: tile kernels; 1 / 2: row-group kernels with 4 / 8 rows per wave
     int rg_mode(int ntiles) const {
         const long rows = (long)ntiles * 32;
         if (rows > rg_rows_max) return 0;
         return rows >= rg2_rows_min ? 2 : 1;
     }
+    // ---- static hoist of conv layer 0's pp messages (pf_rg.hip, EdgeParams::zs).  Everything derived from the weights
+    // carries the version of the weights it was computed from (commit / pf_set_flat_params bump w_version).
+    bool l0_hoist = true;                   // PFDYN_NO_L0_HOIST=1: off
+    int l0_rgp = 0;                         // PFDYN_L0_RGP: rows-per-wave factor of the hoisted items (0: policy)
+    int l0_rga = 0;                         // PFDYN_L0_RGA: ... of the other items of a compact pruned layer-0 launch (0: policy)
+    size_t l0h_off = 0;                     // L0H_* block in d_w
+    uint64_t w_version = 1, zs_version = 0, ptab_version = 0;
+    bool l0_onehot = false;                 // every protein feature row of the batch is an element one-hot
+    bool coords_custom = false;             // protein coordinates came from the caller of this call (not the batch's own)
+    bool zs_batch_coords = false;           // d_zs was computed from (a rigid translate of) the batch's coordinates
+    float* d_l0c = nullptr;                 // [32]
+    float* d_ptab = nullptr;                // [L0_PTAB_SLOTS][rec_nf][128] tables of the timesteps seen (scalar-t calls)
+    std::unordered_map<uint32_t, int> ptab_slot;
+    int *d_eorig = nullptr, *d_ptype = nullptr, *d_l0flag = nullptr;
+    float *d_zs = nullptr, *d_ptab_pg = nullptr;
     bool enc_on_the_fly = true;             // PFDYN_NO_ENC_FLY=1: always launch the encoders
     bool step_build_fast = true;            // PFDYN_NO_FAST_BUILD=1: the generic update + build bodies
     bool rg_compact = true;                 // PFDYN_NO_COMPACT=1: row-group edge launches walk the tile lists
@@ -171,7 +194,11 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_RG_SPLIT_MAX")) rg_split_max = atoi(e);
         if (const char* e = getenv("PFDYN_NO_FAST_BUILD")) step_build_fast = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_RG_ROWS_MAX")) rg_rows_max = atoi(e);
-        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = atoi(e);
+        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = rg2_rows_min_hoist = atoi(e);
+        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN_HOIST")) rg2_rows_min_hoist = atoi(e);
+        if (const char* e = getenv("PFDYN_NO_L0_HOIST")) l0_hoist = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_L0_RGP")) l0_rgp = atoi(e);
+        if (const char* e = getenv("PFDYN_L0_RGA")) l0_rga = atoi(e);
     }
 
     // ---- gradient path (pf_train_*): flat parameter vector in state-dict order, GvpT tables, per-layer activations
@@ -553,6 +580,7 @@ static BuildParams build_params(pf_handle* h) {
     bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
     const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;
     bp.act_ids = prune_layer >= 0 ? h->d_act_ids : nullptr; bp.reg_act = h->d_reg_act;
+    bp.eorig = h->d_eorig;
     return bp;
 }
 // conv layer 0 of an inference call runs on the row-group kernels: they encode the rows they read on the fly, so the
@@ -562,6 +590,57 @@ static bool encoders_on_the_fly(const pf_handle* h) {
     const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;
     const int nt0 = c.n_convs == 1 ? h->n_edge_tiles_last : (prune_layer == 0 ? h->n_edge_tiles_act : h->n_edge_tiles);
     return h->enc_on_the_fly && h->rg_mode(nt0) != 0;
+}
+
+// ---- static hoist of conv layer 0 (pf_rg.hip: EdgeParams::zs) ----------------------------------------------------
+// usable for this handle / batch at all (inference, row-group kernels with encoders on the fly)
+static bool l0_hoist_ok(const pf_handle* h) {
+    const pf_config& c = h->cfg;
+    return h->l0_hoist && h->l0_onehot && h->Epp > 0 && c.n_message_gvps >= 2 && c.rbf_dim == PF_R && c.rec_nf < 128 &&
+           encoders_on_the_fly(h);
+}
+static L0HoistParams l0_params(pf_handle* h) {
+    const pf_config& c = h->cfg;
+    L0HoistParams lp{};
+    lp.src = h->d_w + h->l0h_off; lp.l0c = h->d_l0c;
+    lp.esrc = h->d_esrc; lp.edst = h->d_edst; lp.xn = h->d_xn; lp.Epp = (int)h->Epp; lp.zs = h->d_zs;
+    float mu[PF_R];
+    linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, mu);
+    lp.rbf_mu0 = mu[0]; lp.rbf_mu_step = (mu[PF_R - 1] - mu[0]) * (1.0f / (float)(PF_R - 1));
+    lp.rbf_inv_sigma = 1.0f / ((c.rbf_dmax - 0.f) / (float)c.rbf_dim);
+    lp.enc_w = h->d_w + h->enc_w[0]; lp.enc_b = h->d_w + h->enc_b[0];
+    lp.enc_lw = h->d_w + h->enc_lw[0]; lp.enc_lb = h->d_w + h->enc_lb[0];
+    lp.rec_nf = c.rec_nf;
+    return lp;
+}
+// the trajectory constants (zs, weff) of the current protein coordinates and weights
+static void l0_ensure_static(pf_handle* h, hipStream_t s) {
+    if (!h->coords_custom && h->zs_batch_coords && h->zs_version == h->w_version) return;
+    const L0HoistParams lp = l0_params(h);
+    pfk_l0_hoist(&lp, 0, s);
+    h->zs_version = h->w_version;
+    h->zs_batch_coords = !h->coords_custom;
+}
+// type tables of n timesteps (scalar-t calls): slots of the resident cache, computed on a miss
+static void l0_prepare_t(pf_handle* h, const float* tv, int n, hipStream_t s) {
+    if (h->ptab_version != h->w_version) { h->ptab_slot.clear(); h->ptab_version = h->w_version; }
+    const size_t slot_floats = (size_t)h->cfg.rec_nf * PF_S;
+    int i = 0;
+    while (i < n) {
+        L0HoistParams lp = l0_params(h);
+        if (h->ptab_slot.size() + 64 > L0_PTAB_SLOTS) h->ptab_slot.clear();     // stream order keeps earlier launches valid
+        const int slot0 = (int)h->ptab_slot.size();
+        int m = 0;
+        for (; i < n && m < 64; ++i) {
+            uint32_t bits; memcpy(&bits, &tv[i], 4);
+            if (h->ptab_slot.count(bits)) continue;
+            h->ptab_slot[bits] = slot0 + m;
+            lp.t_host[m++] = tv[i];
+        }
+        if (m == 0) continue;
+        lp.nt = m; lp.t_dev = nullptr; lp.ptab = h->d_ptab + (size_t)slot0 * slot_floats;
+        pfk_l0_hoist(&lp, 1, s);
+    }
 }
 
 // sequence one dynamics call on the handle's state (xn, pharm_h, d_t).  train: keep every layer's input and message
@@ -605,6 +684,24 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         pre_ready = true;
     } else pfk_encode_build(&ep, &bp, s);
 
+    // conv layer 0: static hoist of the pp messages (trajectory constants + per-timestep type table)
+    const bool hoist = !train && enc_fly && l0_hoist_ok(h);
+    const float* l0_ptab = nullptr;
+    int l0_gstride = 0;
+    if (hoist) {
+        l0_ensure_static(h, s);
+        if (t_scalar) {
+            l0_prepare_t(h, t_scalar, 1, s);
+            uint32_t bits; memcpy(&bits, t_scalar, 4);
+            l0_ptab = h->d_ptab + (size_t)h->ptab_slot[bits] * c.rec_nf * PF_S;
+        } else {
+            L0HoistParams lp = l0_params(h);
+            lp.nt = h->B; lp.t_dev = h->d_t; lp.ptab = h->d_ptab_pg;
+            pfk_l0_hoist(&lp, 1, s);
+            l0_ptab = h->d_ptab_pg; l0_gstride = c.rec_nf * PF_S;
+        }
+    }
+    h->last_hoist = 0;
     int cur = 0;
     bool head_done = false;
     for (int l = 0; l < c.n_convs; ++l) {
@@ -630,13 +727,29 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             e.reg = h->d_reg; e.regB = h->B; e.nreg = (last ? 2 : 4) * h->B;
             for (int r = 0; r < e.nreg; ++r) { e.ngroups4 += (h->h_cap[r] + 3) / 4; e.ngroups8 += (h->h_cap[r] + 7) / 8; }
         }
-        const int rg = train ? 0 : h->rg_mode(e.ntiles);     // the node launch of this layer follows (partial-row grouping)
+        int rg = train ? 0 : h->rg_mode(e.ntiles);           // the node launch of this layer follows (partial-row grouping)
+        // static hoist: the hoisted ("pa") items of a compact layer-0 launch run a two-block chain and may take 8 rows
+        // per wave while the full-chain items (ff, pf, fp) take 4
+        int rgp = 0;
+        if (hoist && l == 0 && rg) {
+            e.zs = h->d_zs; e.ptab = l0_ptab; e.ptab_gstride = l0_gstride; e.ptype = h->d_ptype; e.eorig = h->d_eorig;
+            e.l0_gid = h->d_gid; e.l0c = h->d_l0c;
+            rgp = rg;
+            if (e.nreg > 0 && pruned) {
+                rg = (long)e.ntiles * 32 >= h->rg2_rows_min_hoist ? 2 : 1;
+                if (h->l0_rga) rg = h->l0_rga;
+                rgp = h->l0_rgp ? h->l0_rgp : rg;
+                if (rg == 2) rgp = 2;
+                for (int r = 0; r < e.nreg; ++r) e.ngroups_sel += (h->h_cap[r] + 4 * (r >= 3 * h->B ? rgp : rg) - 1) / (4 * (r >= 3 * h->B ? rgp : rg));
+            }
+            h->last_hoist = 4 * rgp;
+        }
         h->last_family.resize(c.n_convs);
         h->last_family[l] = rg ? 4 * rg : ((!train && e.ntiles <= ((last || pruned) ? std::max(h->coop_edge_max, h->coop2_edge_max) : std::max(h->coop_edge_max, h->coop2_dense_max))) ? 128 : 32);
         for (int et = 0; et < 4; ++et) e.rgs[et] = h->d_w + h->rgs_msg[(size_t)l * 4 + et];
         e.rgs_stride = (int)h->rgs_msg_stride;
-        const int esplit = (rg == 1 && e.ntiles * 8 <= h->rg_split_max) ? 1 : 0;    // fewer groups than SIMDs: latency-bound
-        if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, esplit, s); }
+        const int esplit = (rg == 1 && e.ntiles * 8 <= h->rg_split_max && !e.zs) ? 1 : 0;    // fewer groups than SIMDs: latency-bound
+        if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, esplit, rgp, s); }
         else if (e.ntiles <= h->coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
         else if (e.ntiles <= ((last || pruned) ? h->coop2_edge_max : h->coop2_dense_max) && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop2(&e, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
@@ -660,6 +773,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         }
         n.n_upd = c.n_update_gvps;
         n.grp = rg ? 4 * rg : 32;
+        n.grp_pa = rgp ? 4 * rgp : n.grp;
         for (int nt = 0; nt < 2; ++nt) n.rg_upd[nt] = h->d_w + h->rg_upd[(size_t)l * 2 + nt];
         for (int nt = 0; nt < 2; ++nt) {
             n.rgs_upd[nt] = h->d_w + h->rgs_upd[(size_t)l * 2 + nt];
@@ -756,6 +870,8 @@ void pf_destroy(pf_handle* h) {
     if (h->d_flat) (void)hipFree(h->d_flat);
     if (h->d_gvpt) (void)hipFree(h->d_gvpt);
     if (h->d_map) (void)hipFree(h->d_map);
+    if (h->d_l0c) (void)hipFree(h->d_l0c);
+    if (h->d_ptab) (void)hipFree(h->d_ptab);
     for (int k = 0; k < pf_handle::K_NUM; ++k)
         for (auto& ev : h->prof_ev[k]) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete h;
@@ -859,6 +975,26 @@ int pf_commit_weights(pf_handle* h) {
                 }
             h->out_a = push(h->h_w, a);
             h->out_b = push(h->h_w, h->raw["dynamics.noise_predictor.noise_predictor.to_scalar_output.bias"].data);
+        }
+        {   // static hoist of conv layer 0 (pf_device.h L0H_*): pure copies of the first pp message GVP's pieces
+            const GvpSpec g = msg_spec(c, 0, ET_PP, 0);
+            const std::vector<float>& W = h->raw[g.prefix + "to_feats_out.0.weight"].data;        // [128][144 + 17]
+            const std::vector<float>& wh = h->raw[g.prefix + "Wh"].data;                          // [17][17]
+            const std::vector<float>& wu = h->raw[g.prefix + "Wu"].data;                          // [17][16]
+            std::vector<float> blk(L0H_SIZE, 0.f);
+            if (g.vi == 17 && g.so == PF_S && g.si == PF_S + PF_R && g.vo == 16) {
+                const int Kin = g.si + 17;
+                for (int f = 0; f < PF_S; ++f) {
+                    for (int k = 0; k < PF_R; ++k) blk[L0H_WR + (size_t)k * PF_S + f] = W[(size_t)f * Kin + PF_S + k];
+                    for (int k = 0; k < 17; ++k) blk[L0H_WSH + (size_t)k * PF_S + f] = W[(size_t)f * Kin + g.si + k];
+                    for (int k = 0; k < PF_S; ++k) blk[L0H_WHT + (size_t)k * PF_S + f] = W[(size_t)f * Kin + k];
+                    blk[L0H_B + f] = h->raw[g.prefix + "to_feats_out.0.bias"].data[f];
+                }
+                for (int k = 0; k < 17; ++k) blk[L0H_WH0 + k] = wh[(size_t)0 * 17 + k];
+                for (int k = 0; k < 17 * 16; ++k) blk[L0H_WU + k] = wu[k];
+                for (int k = 0; k < 16; ++k) blk[L0H_BG + k] = h->raw[g.prefix + "scalar_to_vector_gates.bias"].data[k];
+            }
+            h->l0h_off = push(h->h_w, blk);
         }
         {   // row-group quad streams, one contiguous stream per chain.  The pharm update chain of the last conv layer
             // comes last and is followed by the noise head's chain and to_scalar_output: the fused node + head kernel
@@ -1001,6 +1137,10 @@ int pf_commit_weights(pf_handle* h) {
     }
     h->t_have_fwd = false;
     h->committed = true;
+    ++h->w_version;
+    if (!h->d_l0c) PF_HIP(h, hipMalloc((void**)&h->d_l0c, 32 * sizeof(float)));
+    if (h->d_ptab) { (void)hipFree(h->d_ptab); h->d_ptab = nullptr; }
+    PF_HIP(h, hipMalloc((void**)&h->d_ptab, (size_t)L0_PTAB_SLOTS * c.rec_nf * PF_S * sizeof(float)));
     return PF_OK;
 }
 
@@ -1135,6 +1275,8 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     need((size_t)(Ecap + 1) * PF_S * 4); need((size_t)(Ecap + 1) * 48 * 4);
     need((size_t)Nf * c.pharm_nf * 4 + 16); need((size_t)Nf * 3 * 4 + 16); need((size_t)B * 3 * 4); need((size_t)B * 3 * 4); need((size_t)2 * B * 4);
     need((size_t)std::max(Np, 1) * PF_S * 4);
+    need(Ecap * 4); need((size_t)std::max(Np, 1) * 4); need(256); need((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4);
+    need((size_t)B * c.rec_nf * PF_S * 4);
     PF_HIP(h, hipMalloc(&h->d_ws, bytes + 4096));
     char* cur = reinterpret_cast<char*>(h->d_ws);
     h->d_prot_ptr = carve<int>(cur, B + 1); h->d_pharm_ptr = carve<int>(cur, B + 1); h->d_gid = carve<int>(cur, N);
@@ -1153,6 +1295,9 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     h->d_eps_h = carve<float>(cur, (size_t)Nf * c.pharm_nf + 4); h->d_eps_x = carve<float>(cur, (size_t)Nf * 3 + 4);
     h->d_com_init = carve<float>(cur, (size_t)B * 3); h->d_com_tmp = carve<float>(cur, (size_t)B * 3); h->d_gnorm = carve<float>(cur, (size_t)2 * B);
     h->d_pre = carve<float>(cur, (size_t)std::max(Np, 1) * PF_S);
+    h->d_eorig = carve<int>(cur, Ecap); h->d_ptype = carve<int>(cur, std::max(Np, 1)); h->d_l0flag = carve<int>(cur, 64);
+    h->d_zs = carve<float>(cur, (size_t)std::max<int64_t>(n_pp, 1) * PF_S);
+    h->d_ptab_pg = carve<float>(cur, (size_t)B * c.rec_nf * PF_S);
     // ---- uploads (synchronous: these are small tables; pageable host memory)
     PF_HIP(h, hipMemcpy(h->d_prot_ptr, prot_ptr, (B + 1) * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_pharm_ptr, pharm_ptr, (B + 1) * 4, hipMemcpyHostToDevice));
@@ -1165,6 +1310,12 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     if (!n_act.empty()) PF_HIP(h, hipMemcpy(h->d_node_tiles_act, n_act.data(), n_act.size() * sizeof(NodeTile), hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_esrc, esrc.data(), (size_t)Ecap * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_edst, edst.data(), (size_t)Ecap * 4, hipMemcpyHostToDevice));
+    {   // static pp slot of every edge slot: the identity (the edge build overwrites the "pa" regions)
+        std::vector<int> eo(Ecap);
+        for (int64_t e = 0; e < Ecap; ++e) eo[e] = (int)e;
+        PF_HIP(h, hipMemcpy(h->d_eorig, eo.data(), (size_t)Ecap * 4, hipMemcpyHostToDevice));
+        PF_HIP(h, hipMemset(h->d_l0flag, 0, 256));
+    }
     PF_HIP(h, hipMemcpy(h->d_in_start, in_start.data(), (size_t)3 * N * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_in_cnt, in_cnt.data(), (size_t)3 * N * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_pp_cnt, pp_cnt.data(), (size_t)B * 4, hipMemcpyHostToDevice));
@@ -1179,7 +1330,18 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     pfk_copy(dev_prot_x, h->d_prot_x0, (size_t)Np * 3, s);
     pfk_copy(dev_prot_h, h->d_prot_h0, (size_t)Np * c.rec_nf, s);
     pfk_load_coords(h->d_prot_x0, h->d_xn, Np, h->d_gid, nullptr, 0.f, s);
+    {
+        L0HoistParams lp{};
+        lp.prot_h0 = h->d_prot_h0; lp.Np = Np; lp.rec_nf = c.rec_nf; lp.ptype = h->d_ptype; lp.flag = h->d_l0flag;
+        pfk_l0_hoist(&lp, 2, s);
+    }
     PF_HIP(h, hipStreamSynchronize(s));
+    {
+        int flag = 1;
+        PF_HIP(h, hipMemcpy(&flag, h->d_l0flag, 4, hipMemcpyDeviceToHost));
+        h->l0_onehot = Np > 0 && flag == 0;
+    }
+    h->zs_version = 0; h->zs_batch_coords = false; h->coords_custom = false;
     h->have_batch = true;
     h->sampling = false;
     h->edges_built = false;
@@ -1230,7 +1392,7 @@ int64_t pf_build_pp_edges(pf_handle* h, int32_t B, const int32_t* prot_ptr, cons
 
 static int load_state(pf_handle* h, const float* dev_prot_x, const float* dev_pharm_x, const float* dev_pharm_h, hipStream_t s) {
     h->edges_built = false;
-    if (dev_prot_x) pfk_load_coords(dev_prot_x, h->d_xn, h->Np, h->d_gid, nullptr, 0.f, s);
+    if (dev_prot_x) { pfk_load_coords(dev_prot_x, h->d_xn, h->Np, h->d_gid, nullptr, 0.f, s); h->coords_custom = true; }
     if (dev_pharm_x) pfk_load_coords(dev_pharm_x, h->d_xn + h->Np, h->Nf, h->d_gid, nullptr, 0.f, s);
     if (dev_pharm_h) pfk_copy(dev_pharm_h, h->d_pharm_h, (size_t)h->Nf * h->cfg.pharm_nf, s);
     return PF_OK;
@@ -1258,6 +1420,7 @@ int pf_sample_begin(pf_handle* h, const float* dev_init_pharm_com, const float* 
     const float* shift = dev_init_pharm_com ? dev_init_pharm_com : h->d_com_init;      // :448-452
     pfk_load_coords(h->d_prot_x0, h->d_xn, h->Np, h->d_gid, shift, -1.f, s);
     pfk_load_noise0(dev_noise0, h->d_xn + h->Np, h->d_pharm_h, h->Nf, h->cfg.pharm_nf, s);  // :455-456
+    h->coords_custom = false;               // a rigid translate of the batch's own coordinates from here on
     h->sampling = true;
     h->edges_built = false;
     return PF_OK;
@@ -1285,6 +1448,15 @@ int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noi
         { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_build(&sp, &bp, fast, s); }
         h->edges_built = true;
     } else { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_update(&sp, s); }
+    return PF_OK;
+}
+
+int pf_prepare_timesteps(pf_handle* h, const float* host_t, int32_t n, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (n < 0 || (n && !host_t)) PF_FAIL(h, PF_ERR_ARG, "pf_prepare_timesteps: bad argument");
+    if (n > L0_PTAB_SLOTS - 64) n = L0_PTAB_SLOTS - 64;      // the rest are computed when their steps arrive
+    if (l0_hoist_ok(h)) l0_prepare_t(h, host_t, n, (hipStream_t)stream);
     return PF_OK;
 }
 
@@ -1316,6 +1488,12 @@ int pf_sample(pf_handle* h, int32_t n_steps, const pf_step_coef* host_coef, cons
     if (rc) return rc;
     if (dev_traj_x || dev_traj_h) {
         rc = pf_sample_frame(h, feat_norm_constant, dev_traj_x, dev_traj_h, stream);
+        if (rc) return rc;
+    }
+    {
+        std::vector<float> tv(n_steps);
+        for (int i = 0; i < n_steps; ++i) tv[i] = host_coef[i].t;
+        rc = pf_prepare_timesteps(h, tv.data(), n_steps, stream);
         if (rc) return rc;
     }
     for (int i = 0; i < n_steps; ++i) {
@@ -1391,7 +1569,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     e.rbf_inv_sigma = 1.0f / (c.rbf_dmax / (float)c.rbf_dim);
     for (int et = 0; et < 4; ++et) e.rg[et] = h->d_w + h->rg_msg[(size_t)layer * 4 + et];
     const int rg = h->rg_mode(e.ntiles);                  // same choice as run_dynamics
-    if (rg) pfk_rg_edge(&e, nullptr, 0, rg, 0, s);
+    if (rg) pfk_rg_edge(&e, nullptr, 0, rg, 0, 0, s);
     else if (e.ntiles <= h->coop_edge_max) pfk_edge_msg_coop(&e, 0, s); else pfk_edge_msg(&e, 0, s);
     NodeParams n{};
     n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles; n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
@@ -1405,6 +1583,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     }
     n.n_upd = c.n_update_gvps;
     n.grp = rg ? 4 * rg : 32;
+    n.grp_pa = n.grp;
     for (int nt = 0; nt < 2; ++nt) n.rg_upd[nt] = h->d_w + h->rg_upd[(size_t)layer * 2 + nt];
     if (rg) pfk_rg_node(&n, nullptr, nullptr, 0, std::max(1, h->rg_mode(n.ntiles)), 0, s);
     else if (n.ntiles <= h->coop_node_max) pfk_node_update_coop(&n, 0, s); else pfk_node_update(&n, 0, s);
@@ -1492,6 +1671,7 @@ int pf_set_flat_params(pf_handle* h, const float* dev_flat, pf_stream stream) {
     hipStream_t s = (hipStream_t)stream;
     PF_HIP(h, hipMemcpyAsync(h->d_flat, dev_flat, h->nparams * sizeof(float), hipMemcpyDeviceToDevice, s));
     pfk_gather_weights(h->d_flat, h->d_map, h->n_packed, h->d_w, s);
+    ++h->w_version;
     h->t_have_fwd = false;
     return PF_OK;
 }
@@ -1672,6 +1852,12 @@ int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave) 
     return PF_OK;
 }
 
+int pf_debug_l0_hoist(pf_handle* h, int32_t* rows_per_wave) {
+    if (!h || !rows_per_wave) return PF_ERR_ARG;
+    *rows_per_wave = h->last_hoist;
+    return PF_OK;
+}
+
 int pf_profile_enable(pf_handle* h, uint32_t kernel_mask) {
     if (!h) return PF_ERR_ARG;
     h->prof_mask = kernel_mask;             // recorded events accumulate until pf_profile_read
@@ -1734,6 +1920,8 @@ int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges, 
         else if (l == prune_layer) { el = (double)(ne[0] + ne[1] + ne[2] + n_pa); nl = (double)(h->Nf + n_act); }
         else { el = E; nl = (double)h->N; }
         ex += el * per_edge + nl * per_node;
+        // static hoist (last call): the pp edges of layer 0 skip their first message GVP but for its gates
+        if (l == 0 && h->last_hoist) ex -= (double)(l == prune_layer ? n_pa : (l == c.n_convs - 1 ? 0 : ne[3])) * (g0 - 2.0 * 128 * 16);
         if (executed_edges) executed_edges[l] = (int64_t)el;
     }
     if (executed_flops) *executed_flops = ex;

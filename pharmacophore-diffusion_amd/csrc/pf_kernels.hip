@@ -1377,7 +1377,7 @@ __device__ __forceinline__ void emit_prot_side(const BuildParams& p, const int g
                 if (c0 == 0) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
-                        if (k < deg) { p.esrc[d0 + k] = pre.src[k]; p.edst[d0 + k] = p0 + c; }
+                        if (k < deg) { p.esrc[d0 + k] = pre.src[k]; p.edst[d0 + k] = p0 + c; if (p.eorig) p.eorig[d0 + k] = s0 + k; }
                     i0 = 16;
                 }
                 // eight loads in flight, then eight stores (source and destination alias the same array, so a
@@ -1388,7 +1388,7 @@ __device__ __forceinline__ void emit_prot_side(const BuildParams& p, const int g
                     for (int k = 0; k < 8; ++k) tmp[k] = p.esrc[s0 + min(i + k, deg - 1)];
 #pragma unroll
                     for (int k = 0; k < 8; ++k)
-                        if (i + k < deg) { p.esrc[d0 + i + k] = tmp[k]; p.edst[d0 + i + k] = p0 + c; }
+                        if (i + k < deg) { p.esrc[d0 + i + k] = tmp[k]; p.edst[d0 + i + k] = p0 + c; if (p.eorig) p.eorig[d0 + i + k] = s0 + i + k; }
                 }
             }
         }
@@ -1999,6 +1999,7 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
                 const int src = k < 16 ? a_src[a_node[lo] - p0][k] : p.esrc[a_pst[lo] + k];
                 p.esrc[reg_pa + t] = src;
                 p.edst[reg_pa + t] = a_node[lo];
+                if (p.eorig) p.eorig[reg_pa + t] = a_pst[lo] + k;
             }
         }
         if (tid == 0 && p.act_ids) {

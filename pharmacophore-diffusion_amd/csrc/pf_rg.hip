@@ -99,10 +99,12 @@ __device__ __forceinline__ float asum(const float v) { return gsum(qsum(v)); }
 // first 64 waves writes s_memtime at the phase boundaries of the chain (tools/stamps_rg.py)
 #ifdef PF_STAMPS
 __device__ unsigned long long* g_rg_stamps = nullptr;
+__device__ int g_rg_stamp_off = 0;                    // first recorded item (pfk_rg_set_stamp_offset)
 struct RgStamp {
-    int k = 0, id = 0;                                // id: item of the wave (first 64 items are recorded)
+    int k = 0, id = 0;                                // id: item of the wave (64 items from g_rg_stamp_off are recorded)
     __device__ __forceinline__ void operator()(const int lane) {
-        if (lane == 0 && g_rg_stamps && id < 64 && k < 64) g_rg_stamps[id * 64 + k] = __builtin_amdgcn_s_memtime();
+        const int rid = id - g_rg_stamp_off;
+        if (lane == 0 && g_rg_stamps && rid >= 0 && rid < 64 && k < 64) g_rg_stamps[rid * 64 + k] = __builtin_amdgcn_s_memtime();
         ++k;
     }
 };
@@ -561,115 +563,102 @@ __device__ __forceinline__ void rg_encode(const EncodeParams& ep, const int nt, 
 // items per workgroup measured 10 % slower on the 48-item node + head launch).
 // Launches with many more items than SIMDs (WAVES = 1) keep single-wave workgroups: a four-wave workgroup holds its
 // slots until its slowest wave retires (batch 512: -14 %), and placement history no longer matters there.
-template <bool L0, int RG, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_rg_edge(const EdgeParams p, const EncodeParams ep) {
+// quad_perm broadcast of lane II of every group of four lanes
+template <int II>
+__device__ __forceinline__ float quad_bcast(const float v) { return dpp_f<II * 0x55>(v); }
+
+// One item of an edge launch: the G = 4 RG slots [e0, e0 + nv) of etype et.
+// PRE (conv layer 0, static pp edges; EdgeParams::zs): the first message GVP is not computed -- its SiLU input is
+// zs[static slot] + ptab[type of the source] (two row gathers in the SA layout), its Vu is xhat (x) weff -- and the
+// chain starts at the second block of the quad stream, with the first GVP's gates pending as usual.
+template <bool L0, int RG, int WAVES, bool PRE>
+__device__ __forceinline__ void rg_edge_item(const EdgeParams& p, const EncodeParams& ep, RgLds* lds, const int item,
+                                             const int wq, const int e0, const int nv, const int et, const int lane) {
     constexpr bool SPLIT = WAVES == 2;
     constexpr int D = RgDepth<RG>::D;
-    constexpr int WPB = WAVES == 4 ? 4 : 1;            // waves with their own item per workgroup
-    __shared__ RgLds lds_all[WPB][RG];
-    constexpr int G = 4 * RG, PER = 32 / G;
-    const int lane = threadIdx.x & 63;
-    const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    RgLds* lds = lds_all[WPB == 4 ? wq : 0];
-    const int item = WPB == 4 ? (int)((blockIdx.x >> 8) * 1024 + wq * 256 + (blockIdx.x & 255)) : (int)blockIdx.x;
+    constexpr int G = 4 * RG;
+    static_assert(!(PRE && (SPLIT || !L0)), "the static hoist is a conv-layer-0 path of the one-wave forms");
     RgWave wv;
     wv.half = SPLIT ? wq : 0;
     wv.par = 0;
-    int e0, nv, et;
-    if (p.nreg > 0) {
-        // Compact work list (launches whose edges all live in per-(etype, graph) regions of run-time length): wave w
-        // takes the w-th group of G slots, counting only the groups that hold edges -- the busy waves are the first
-        // ones of the grid and spread evenly over the chip, instead of sitting wherever a region's tiles fall.  The
-        // region of group w is found by a wave scan over the region lengths (64 regions per pass).
-        const int w = item;
-        int first = 0, rsel = -1, cnt = 0, start = 0;
-        // every pass's lengths and starts are fetched before the first scan: one global round trip whatever the number
-        // of regions (up to 64 * RG_CPASS); the scans themselves run on registers
-        int cs[RG_CPASS], rs[RG_CPASS];
-#pragma unroll
-        for (int k = 0; k < RG_CPASS; ++k) {
-            const int r = 64 * k + lane;
-            cs[k] = r < p.nreg ? p.dyn_cnt[r] : 0;
-            rs[k] = r < p.nreg ? p.reg[r] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < RG_CPASS; ++k) {
-            if (64 * k < p.nreg && rsel < 0) {           // wave-uniform
-                const int c = cs[k];
-                const int ng = (c + G - 1) / G;
-                int incl = ng;
-                incl += dpp_i<0x111>(incl); incl += dpp_i<0x112>(incl); incl += dpp_i<0x114>(incl); incl += dpp_i<0x118>(incl);
-                incl += dpp_ir<0x142, 0xa>(incl); incl += dpp_ir<0x143, 0xc>(incl);
-                incl += first;
-                const unsigned long long m = __ballot(incl > w);
-                if (m) {
-                    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
-                    rsel = 64 * k + l;
-                    first = __builtin_amdgcn_readlane(incl - ng, l);
-                    cnt = __builtin_amdgcn_readlane(c, l);
-                    start = __builtin_amdgcn_readlane(rs[k], l);
-                } else first = __builtin_amdgcn_readlane(incl, 63);
-            }
-        }
-        if (rsel < 0) return;                          // wave-uniform: beyond the last group
-        const int loc = (w - first) * G;
-        e0 = start + loc;
-        nv = __builtin_amdgcn_readfirstlane(min(G, cnt - loc));
-        et = rsel / p.regB;
-        et = et == 3 ? (int)ET_PP : et;                // fourth region kind: pp edges into the active atoms
-    } else {
-        const int bid = item;
-        if (bid >= p.ntiles * PER) return;             // wave-uniform (the grid is rounded up to four items per workgroup)
-        const EdgeTile t = p.tiles[bid / PER];
-        int nvalid = t.n;
-        if (t.cnt_idx >= 0) nvalid = min(nvalid, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
-        const int base = (bid % PER) * G;
-        nv = __builtin_amdgcn_readfirstlane(min(G, nvalid - base));
-        if (nv <= 0) return;                           // wave-uniform
-        et = __builtin_amdgcn_readfirstlane(t.et);
-        e0 = t.e0 + base;
-    }
     RgStamp stamp;
     stamp.id = SPLIT ? 2 * item + wv.half : item;
     stamp(lane);                                       // kernel start
     RgRing<D> ring;
-    ring_start(ring, SPLIT ? p.rgs[et] + (size_t)wv.half * p.rgs_stride : p.rg[et], lane);   // in flight under the gather
+    constexpr int NQ0 = rg_sched(SpecMsg0::VI, SpecMsg0::NEXTRA, 2, false).nq;          // quads of the chain's first block
+    ring_start(ring, SPLIT ? p.rgs[et] + (size_t)wv.half * p.rgs_stride : p.rg[et] + (PRE ? (size_t)NQ0 * 256 : 0), lane);   // in flight under the gather
     const int a = lane >> 2, i = lane & 3, g = lane >> 4, q = a & 3, u = lane & 15;
     float X[RG][8], Va[RG][4], R[RG], XH[RG];
     int dstv[RG], srcv[RG];
-    const float mu_step = (p.rbf_mu[PF_R - 1] - p.rbf_mu[0]) * (1.0f / (float)(PF_R - 1));
-    const float mu_a = fmaf((float)a, mu_step, p.rbf_mu[0]);
+    f32x4 slo[RG], shi[RG], Vd[RG];
+    RgCarry<RG> carry;
+    if constexpr (PRE) {
+        const float weff = g < 3 ? p.l0c[u] : 0.f;
+        carry.bg = p.l0c[16 + u];
+        int eo[RG];
 #pragma unroll
-    for (int r = 0; r < RG; ++r) {
-        const int e = e0 + min(4 * r + i, nv - 1);
-        const int src = p.esrc[e], dst = p.edst[e];
-        dstv[r] = dst; srcv[r] = src;
-        const float4 xs = p.xn[src], xd = p.xn[dst];
-        const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
-        const float d = sqrtf_(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
-        const float ze = (d - mu_a) * p.rbf_inv_sigma;
-        R[r] = __expf(-(ze * ze));
-        XH[r] = (g == 0 ? dx : (g == 1 ? dy : (g == 2 ? dz : 0.f))) * rcpf_(d);
-        if (!(L0 && ep.w[0])) {
-            const f32x4 PF_AS1* hp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.h + (size_t)src * PF_S) + 2 * a;
-            const f32x4 x0 = hp[0], x1 = hp[1];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) { X[r][m] = x0[m]; X[r][4 + m] = x1[m]; }
+        for (int r = 0; r < RG; ++r) {
+            const int e = e0 + min(4 * r + i, nv - 1);
+            srcv[r] = p.esrc[e]; dstv[r] = p.edst[e]; eo[r] = p.eorig[e];
         }
-        if constexpr (!L0) {
-            pf_gcf vp = (pf_gcf)p.v + (size_t)src * 48 + (g < 3 ? g : 0) + 3 * q;
+        f32x4 z0[RG], z1[RG];
+        int ty[RG];
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) { const float x = vp[12 * tt]; Va[r][tt] = g < 3 ? x : 0.f; }
-        } else {
+        for (int r = 0; r < RG; ++r) {
+            const float4 xs = p.xn[srcv[r]], xd = p.xn[dstv[r]];
+            ty[r] = p.ptype[srcv[r]];
+            if (p.ptab_gstride) ty[r] = ty[r] * PF_S + p.l0_gid[srcv[r]] * p.ptab_gstride; else ty[r] *= PF_S;
+            const f32x4 PF_AS1* zp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.zs + (size_t)eo[r] * PF_S) + 2 * a;
+            z0[r] = zp[0]; z1[r] = zp[1];
+            const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
+            const float d = sqrtf_(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+            XH[r] = (g == 0 ? dx : (g == 1 ? dy : (g == 2 ? dz : 0.f))) * rcpf_(d);
+            R[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const f32x4 PF_AS1* pp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.ptab + ty[r]) + 2 * a;
+            const f32x4 p0 = pp[0], p1 = pp[1];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { X[r][m] = siluf_(z0[r][m] + p0[m]); X[r][4 + m] = siluf_(z1[r][m] + p1[m]); }
+            carry.vu[r] = (f32x4){quad_bcast<0>(XH[r]) * weff, quad_bcast<1>(XH[r]) * weff, quad_bcast<2>(XH[r]) * weff, quad_bcast<3>(XH[r]) * weff};
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) Va[r][tt] = 0.f;
         }
+        for (int gi = 1; gi < p.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, 1, false, false>(ring, X, Va, R, XH, slo, shi, carry, lds, lane, stamp, wv);
+    } else {
+        const float mu_step = (p.rbf_mu[PF_R - 1] - p.rbf_mu[0]) * (1.0f / (float)(PF_R - 1));
+        const float mu_a = fmaf((float)a, mu_step, p.rbf_mu[0]);
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const int e = e0 + min(4 * r + i, nv - 1);
+            const int src = p.esrc[e], dst = p.edst[e];
+            dstv[r] = dst; srcv[r] = src;
+            const float4 xs = p.xn[src], xd = p.xn[dst];
+            const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
+            const float d = sqrtf_(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+            const float ze = (d - mu_a) * p.rbf_inv_sigma;
+            R[r] = __expf(-(ze * ze));
+            XH[r] = (g == 0 ? dx : (g == 1 ? dy : (g == 2 ? dz : 0.f))) * rcpf_(d);
+            if (!(L0 && ep.w[0])) {
+                const f32x4 PF_AS1* hp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.h + (size_t)src * PF_S) + 2 * a;
+                const f32x4 x0 = hp[0], x1 = hp[1];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { X[r][m] = x0[m]; X[r][4 + m] = x1[m]; }
+            }
+            if constexpr (!L0) {
+                pf_gcf vp = (pf_gcf)p.v + (size_t)src * 48 + (g < 3 ? g : 0) + 3 * q;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) { const float x = vp[12 * tt]; Va[r][tt] = g < 3 ? x : 0.f; }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) Va[r][tt] = 0.f;
+            }
+        }
+        if (L0 && ep.w[0]) rg_encode<RG>(ep, (et == ET_FF || et == ET_FP) ? 1 : 0, srcv, X, lane);   // sources: pharm for ff / fp
+        rg_gvp<SpecMsg0, RG, D, 0, L0, SPLIT>(ring, X, Va, R, XH, slo, shi, carry, lds, lane, stamp, wv);
+        for (int gi = 1; gi < p.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, 1, false, SPLIT>(ring, X, Va, R, XH, slo, shi, carry, lds, lane, stamp, wv);
     }
-    if (L0 && ep.w[0]) rg_encode<RG>(ep, (et == ET_FF || et == ET_FP) ? 1 : 0, srcv, X, lane);   // sources: pharm for ff / fp
-    f32x4 slo[RG], shi[RG], Vd[RG];
-    RgCarry<RG> carry;
-    rg_gvp<SpecMsg0, RG, D, 0, L0, SPLIT>(ring, X, Va, R, XH, slo, shi, carry, lds, lane, stamp, wv);
-    for (int gi = 1; gi < p.n_gvps; ++gi) rg_gvp<SpecGen, RG, D, 1, false, SPLIT>(ring, X, Va, R, XH, slo, shi, carry, lds, lane, stamp, wv);
     rg_flush<RG, D, true, false>(ring, X, Va, Vd, carry, lds, lane, stamp, wv.half);
     // in-wave segmented sum in slot order; one partial row per (wave, destination) run
     float al = 0.f, ah = 0.f, av = 0.f;
@@ -694,6 +683,86 @@ __global__ __launch_bounds__(64 * WAVES) void k_rg_edge(const EdgeParams p, cons
     });
     put(e0 + nv - 1);
     stamp(lane);                                       // stores issued
+}
+
+// RGP: rows-per-wave factor of the static-hoist items (0: that path is not compiled; conv layer 0 only).  With the
+// compact work list the "pa" regions (kind 3) are cut into groups of 4 RGP slots and every other region into groups of
+// 4 RG; tile lists need RGP == RG.
+template <bool L0, int RG, int WAVES, int RGP>
+__global__ __launch_bounds__(64 * WAVES) void k_rg_edge(const EdgeParams p, const EncodeParams ep) {
+    constexpr int WPB = WAVES == 4 ? 4 : 1;            // waves with their own item per workgroup
+    constexpr int RGM = RGP > RG ? RGP : RG;
+    __shared__ RgLds lds_all[WPB][RGM];
+    constexpr int G = 4 * RG, PER = 32 / G;
+    const int lane = threadIdx.x & 63;
+    const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    RgLds* lds = lds_all[WPB == 4 ? wq : 0];
+    const int item = WPB == 4 ? (int)((blockIdx.x >> 8) * 1024 + wq * 256 + (blockIdx.x & 255)) : (int)blockIdx.x;
+    const bool hoist = RGP > 0 && p.zs != nullptr;     // wave-uniform (kernel argument)
+    int e0, nv, et;
+    bool pre = false;
+    if (p.nreg > 0) {
+        // Compact work list (launches whose edges all live in per-(etype, graph) regions of run-time length): wave w
+        // takes the w-th group of G slots, counting only the groups that hold edges -- the busy waves are the first
+        // ones of the grid and spread evenly over the chip, instead of sitting wherever a region's tiles fall.  The
+        // region of group w is found by a wave scan over the region lengths (64 regions per pass).
+        const int w = item;
+        int first = 0, rsel = -1, cnt = 0, start = 0;
+        // every pass's lengths and starts are fetched before the first scan: one global round trip whatever the number
+        // of regions (up to 64 * RG_CPASS); the scans themselves run on registers
+        int cs[RG_CPASS], rs[RG_CPASS];
+#pragma unroll
+        for (int k = 0; k < RG_CPASS; ++k) {
+            const int r = 64 * k + lane;
+            cs[k] = r < p.nreg ? p.dyn_cnt[r] : 0;
+            rs[k] = r < p.nreg ? p.reg[r] : 0;
+        }
+        constexpr int SH = RG == 2 ? 3 : 2, SHP = RGP == 2 ? 3 : 2;
+        const int pa0 = (hoist && RGP != RG) ? 3 * p.regB : 0x7fffffff;      // first region cut into groups of 4 RGP
+#pragma unroll
+        for (int k = 0; k < RG_CPASS; ++k) {
+            if (64 * k < p.nreg && rsel < 0) {           // wave-uniform
+                const int c = cs[k];
+                const int ng = (64 * k + lane >= pa0) ? (c + (1 << SHP) - 1) >> SHP : (c + G - 1) >> SH;
+                int incl = ng;
+                incl += dpp_i<0x111>(incl); incl += dpp_i<0x112>(incl); incl += dpp_i<0x114>(incl); incl += dpp_i<0x118>(incl);
+                incl += dpp_ir<0x142, 0xa>(incl); incl += dpp_ir<0x143, 0xc>(incl);
+                incl += first;
+                const unsigned long long m = __ballot(incl > w);
+                if (m) {
+                    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                    rsel = 64 * k + l;
+                    first = __builtin_amdgcn_readlane(incl - ng, l);
+                    cnt = __builtin_amdgcn_readlane(c, l);
+                    start = __builtin_amdgcn_readlane(rs[k], l);
+                } else first = __builtin_amdgcn_readlane(incl, 63);
+            }
+        }
+        if (rsel < 0) return;                          // wave-uniform: beyond the last group
+        const int kind = rsel / p.regB;
+        pre = hoist && kind == 3;
+        const int Gs = (pre && RGP != RG) ? 4 * RGP : G;
+        const int loc = (w - first) * Gs;
+        e0 = start + loc;
+        nv = __builtin_amdgcn_readfirstlane(min(Gs, cnt - loc));
+        et = kind == 3 ? (int)ET_PP : kind;            // fourth region kind: pp edges into the active atoms
+    } else {
+        const int bid = item;
+        if (bid >= p.ntiles * PER) return;             // wave-uniform (the grid is rounded up to four items per workgroup)
+        const EdgeTile t = p.tiles[bid / PER];
+        int nvalid = t.n;
+        if (t.cnt_idx >= 0) nvalid = min(nvalid, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
+        const int base = (bid % PER) * G;
+        nv = __builtin_amdgcn_readfirstlane(min(G, nvalid - base));
+        if (nv <= 0) return;                           // wave-uniform
+        et = __builtin_amdgcn_readfirstlane(t.et);
+        e0 = t.e0 + base;
+        pre = hoist && RGP == RG && et == ET_PP;
+    }
+    if constexpr (RGP > 0) {
+        if (pre) { rg_edge_item<L0, RGP, WAVES, true>(p, ep, lds, item, wq, e0, nv, et, lane); return; }
+    }
+    rg_edge_item<L0, RG, WAVES, false>(p, ep, lds, item, wq, e0, nv, et, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -734,7 +803,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rg_node(const NodeParams p, cons
     const NodeW nw = p.w[nt];
     float X[RG][8], Va[RG][4];
     int nid[RG];
-    const int gm = p.grp - 1;
+    const int gm0 = p.grp - 1, gm1 = (nt == 0 ? p.grp_pa : p.grp) - 1;
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
         const int row = base + min(4 * r + i, nv - 1);
@@ -761,6 +830,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rg_node(const NodeParams p, cons
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
             const int end = st[sl] + cn[sl];
+            const int gm = sl == 0 ? gm0 : gm1;
             int e = st[sl];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -778,6 +848,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rg_node(const NodeParams p, cons
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
             const int end = st[sl] + cn[sl];
+            const int gm = sl == 0 ? gm0 : gm1;
             float ps[8], pv[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -915,32 +986,133 @@ __global__ __launch_bounds__(64 * WAVES) void k_rg_node(const NodeParams p, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Static hoist of conv layer 0 (EdgeParams::zs): everything the first message GVP of a pp edge computes from the
+// pocket's rigid geometry is constant over a trajectory, and its h_src block sees one of rec_nf encoder outputs per t.
+//   k_l0_consts  weff[o] = sum_c Wu[c][o] Wh[0][c]  (Vu = xhat (x) weff when the node vectors are zero), gate bias
+//   k_l0_zs      zs[e][f] = b[f] + sum_k W[f][128 + k] rbf_k(d_e) + sum_c W[f][144 + c] sh_c,  sh_c = |Wh[0][c] xhat_e|
+//   k_l0_ptab    ptab[row][f] = sum_k W[f][k] LayerNorm(SiLU(W_enc [onehot(type), t] + b_enc))[k]
+//   k_l0_types   element type of every protein atom; flag != 0 if a feature row is not a one-hot
+// (gvp.py:89-116 with the message inputs of gvp.py:545-547; encoder dynamics_gvp.py:107-117)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_l0_consts(const L0HoistParams p) {
+    const int u = threadIdx.x;
+    if (u < 16) {
+        float w = 0.f;
+        for (int c = 0; c < 17; ++c) w = fmaf(p.src[L0H_WU + c * 16 + u], p.src[L0H_WH0 + c], w);
+        p.l0c[u] = w;
+        p.l0c[16 + u] = p.src[L0H_BG + u];
+    }
+}
+__global__ __launch_bounds__(128) void k_l0_zs(const L0HoistParams p) {
+    const int f = threadIdx.x;
+    const float b = p.src[L0H_B + f];
+    float wr[16], ws[17], wh0[17];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wr[k] = p.src[L0H_WR + k * PF_S + f];
+#pragma unroll
+    for (int c = 0; c < 17; ++c) { ws[c] = p.src[L0H_WSH + c * PF_S + f]; wh0[c] = p.src[L0H_WH0 + c]; }
+    for (int e = blockIdx.x; e < p.Epp; e += gridDim.x) {
+        const float4 xs = p.xn[p.esrc[e]], xd = p.xn[p.edst[e]];
+        const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
+        const float d = sqrtf_(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+        const float rd = rcpf_(d), hx = dx * rd, hy = dy * rd, hz = dz * rd;
+        float z = b;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float ze = (d - fmaf((float)k, p.rbf_mu_step, p.rbf_mu0)) * p.rbf_inv_sigma;
+            z = fmaf(wr[k], __expf(-(ze * ze)), z);
+        }
+#pragma unroll
+        for (int c = 0; c < 17; ++c) {
+            const float vx = wh0[c] * hx, vy = wh0[c] * hy, vz = wh0[c] * hz;
+            z = fmaf(ws[c], sqrtf_(fmaxf(vx * vx + vy * vy + vz * vz, 1e-8f)), z);
+        }
+        p.zs[(size_t)e * PF_S + f] = z;
+    }
+}
+__global__ __launch_bounds__(128) void k_l0_ptab(const L0HoistParams p) {
+    __shared__ float hs[PF_S];
+    __shared__ float red[4];
+    const int f = threadIdx.x, row = blockIdx.x;
+    const int it = row / p.rec_nf, ty = row % p.rec_nf;
+    const float t = p.t_dev ? p.t_dev[it] : p.t_host[it];
+    float x = p.enc_b[f];
+    x = fmaf(p.enc_w[ty * PF_S + f], 1.0f, x);
+    x = fmaf(p.enc_w[p.rec_nf * PF_S + f], t, x);
+    x = siluf_(x);
+    auto bsum = [&](float v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if ((f & 63) == 0) red[f >> 6] = v;
+        __syncthreads();
+        return red[0] + red[1];
+    };
+    const float mean = bsum(x) * (1.0f / 128.0f);
+    const float c = x - mean;
+    const float rstd = rsqf_(bsum(c * c) * (1.0f / 128.0f) + 1e-5f);
+    hs[f] = c * rstd * p.enc_lw[f] + p.enc_lb[f];
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < PF_S; ++k) acc = fmaf(p.src[L0H_WHT + k * PF_S + f], hs[k], acc);
+    p.ptab[(size_t)row * PF_S + f] = acc;
+}
+__global__ __launch_bounds__(256) void k_l0_types(const L0HoistParams p) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= p.Np) return;
+    int ty = -1, bad = 0;
+    for (int k = 0; k < p.rec_nf; ++k) {
+        const float x = p.prot_h0[(size_t)n * p.rec_nf + k];
+        if (x == 1.0f) { if (ty >= 0) bad = 1; ty = k; }
+        else if (x != 0.0f) bad = 1;
+    }
+    if (ty < 0) { bad = 1; ty = 0; }
+    p.ptype[n] = ty;
+    if (bad) atomicOr(p.flag, 1);
+}
+
 }  // namespace
 
 extern "C" {
 #ifdef PF_STAMPS
 int pfk_rg_set_stamp_buffer(unsigned long long* dev) { g_rg_stamp_host_buf = dev; unsigned long long* z = nullptr; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rg_stamps), &z, sizeof(z)); }
+int pfk_rg_set_stamp_offset(int off) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rg_stamp_off), &off, sizeof(off)); }
 void pfk_rg_set_stamp_which(int which) { g_rg_stamp_which = which; g_rg_stamp_seen = 0; }
 #endif
-// rows per wave: 8 (RG = 2) once there are enough groups to fill the chip, else 4
-void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s) {
+void pfk_l0_hoist(const L0HoistParams* p, int what, hipStream_t s) {       // what: 0 consts + zs, 1 ptab, 2 types
+    if (what == 0) {
+        hipLaunchKernelGGL(k_l0_consts, dim3(1), dim3(64), 0, s, *p);
+        if (p->Epp > 0) hipLaunchKernelGGL(k_l0_zs, dim3(std::min(p->Epp, 8192)), dim3(128), 0, s, *p);
+    } else if (what == 1) {
+        if (p->nt > 0) hipLaunchKernelGGL(k_l0_ptab, dim3(p->nt * p->rec_nf), dim3(128), 0, s, *p);
+    } else if (p->Np > 0) hipLaunchKernelGGL(k_l0_types, dim3((p->Np + 255) / 256), dim3(256), 0, s, *p);
+}
+// rows per wave: 8 (RG = 2) once there are enough groups to fill the chip, else 4; rgp: rows-per-wave factor of the
+// static-hoist items of conv layer 0 (0: off; tile lists need rgp == rg)
+void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int rg, int split, int rgp, hipStream_t s) {
     if (p->ntiles == 0) return;
 #ifdef PF_STAMPS
     rg_stamp_arm(s);
 #endif
     const int per = 32 / (4 * rg);
-    const int grid = p->nreg > 0 ? (rg == 1 ? p->ngroups4 : p->ngroups8) : p->ntiles * per;
+    const int grid = p->nreg > 0 ? (p->ngroups_sel > 0 ? p->ngroups_sel : (rg == 1 ? p->ngroups4 : p->ngroups8)) : p->ntiles * per;
     if (grid == 0) return;
     const EncodeParams noenc{};
     const EncodeParams& ep = (layer0 && enc) ? *enc : noenc;      // layer 0: encode the gathered rows on the fly
     const int grid4 = grid <= 256 ? grid : (grid + 1023) / 1024 * 256;      // super-blocks of 256 workgroups x 4 waves
     const bool quad = grid <= RG_QUAD_MAX;                                  // latency regime: deterministic SIMD placement
-#define PF_RG_EDGE(L0_, RG_, W_, GRID_) hipLaunchKernelGGL((k_rg_edge<L0_, RG_, W_>), dim3(GRID_), dim3(64 * W_), 0, s, *p, ep)
-    if (rg == 1 && split) { if (layer0) PF_RG_EDGE(true, 1, 2, grid); else PF_RG_EDGE(false, 1, 2, grid); }
-    else if (rg == 1 && quad) { if (layer0) PF_RG_EDGE(true, 1, 4, grid4); else PF_RG_EDGE(false, 1, 4, grid4); }
-    else if (rg == 1) { if (layer0) PF_RG_EDGE(true, 1, 1, grid); else PF_RG_EDGE(false, 1, 1, grid); }
-    else if (quad) { if (layer0) PF_RG_EDGE(true, 2, 4, grid4); else PF_RG_EDGE(false, 2, 4, grid4); }
-    else { if (layer0) PF_RG_EDGE(true, 2, 1, grid); else PF_RG_EDGE(false, 2, 1, grid); }
+    if (!layer0 || split || !p->zs) rgp = 0;
+#define PF_RG_EDGE(L0_, RG_, W_, P_, GRID_) hipLaunchKernelGGL((k_rg_edge<L0_, RG_, W_, P_>), dim3(GRID_), dim3(64 * W_), 0, s, *p, ep)
+    if (rg == 1 && split) { if (layer0) PF_RG_EDGE(true, 1, 2, 0, grid); else PF_RG_EDGE(false, 1, 2, 0, grid); }
+    else if (!layer0) {
+        if (rg == 1 && quad) PF_RG_EDGE(false, 1, 4, 0, grid4);
+        else if (rg == 1) PF_RG_EDGE(false, 1, 1, 0, grid);
+        else if (quad) PF_RG_EDGE(false, 2, 4, 0, grid4);
+        else PF_RG_EDGE(false, 2, 1, 0, grid);
+    } else if (rg == 1 && rgp == 2) { if (quad) PF_RG_EDGE(true, 1, 4, 2, grid4); else PF_RG_EDGE(true, 1, 1, 2, grid); }
+    else if (rg == 1) { if (quad) PF_RG_EDGE(true, 1, 4, 1, grid4); else PF_RG_EDGE(true, 1, 1, 1, grid); }      // rgp 0 / 1: p->zs decides
+    else { if (quad) PF_RG_EDGE(true, 2, 4, 2, grid4); else PF_RG_EDGE(true, 2, 1, 2, grid); }
 #undef PF_RG_EDGE
 }
 void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s) {

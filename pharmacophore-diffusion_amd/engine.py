@@ -214,6 +214,13 @@ class PfEngine:
         with torch.cuda.device(self.device):
             self._ck(self.lib.pf_sample_begin(self._h, _dptr(com), _dptr(nz), _stream_ptr()), "pf_sample_begin")
 
+    def prepare_timesteps(self, coef_arr, n=None):
+        """Optional before a loop of denoise_step calls: the timesteps the loop will visit (pf_prepare_timesteps)."""
+        n = len(coef_arr) if n is None else n
+        tv = (ctypes.c_float * max(n, 1))(*[coef_arr[i].t for i in range(n)])
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_prepare_timesteps(self._h, tv, n, _stream_ptr()), "pf_prepare_timesteps")
+
     def denoise_step(self, coef_struct, noise, ep_coord=False, ep_feat=False):
         nz = _f32(noise, self.device)
         with torch.cuda.device(self.device):
@@ -283,6 +290,12 @@ class PfEngine:
         (k_rg_edge), 32 = one wave per tile (k_edge_msg), 128 = four waves per tile (k_edge_msg_coop)."""
         r = ctypes.c_int32()
         self._ck(self.lib.pf_debug_kernel_family(self._h, int(layer), ctypes.byref(r)), "pf_debug_kernel_family")
+        return int(r.value)
+
+    def l0_hoist(self) -> int:
+        """Rows per hoisted wave of conv layer 0's pp messages in the last dynamics call (0: static hoist not used)."""
+        r = ctypes.c_int32()
+        self._ck(self.lib.pf_debug_l0_hoist(self._h, ctypes.byref(r)), "pf_debug_l0_hoist")
         return int(r.value)
 
     KERNEL_CLASSES = ("encode", "build_edges", "edge_msg", "node_update", "noise_head", "step_update", "edge_msg_coop",

@@ -412,3 +412,74 @@ def test_kernel_family_reporting(monkeypatch):
     set_batch(eng, batch)
     eng.dynamics(x_t, h_t, t)
     assert eng.kernel_family(0) in (32, 128)
+
+
+# ---- static hoist of conv layer 0's protein-protein messages (pf_rg.hip: EdgeParams::zs) -------------------------
+HOIST_VARIANTS = {
+    "default": {},
+    "rows4": {"PFDYN_L0_RGA": "1", "PFDYN_L0_RGP": "1"},
+    "rows4_hoisted8": {"PFDYN_L0_RGA": "1", "PFDYN_L0_RGP": "2"},
+    "rows8": {"PFDYN_L0_RGA": "2", "PFDYN_RG2_ROWS_MIN": "0"},
+    "tile_lists": {"PFDYN_NO_COMPACT": "1"},
+    "dense_layer0": {"PFDYN_NO_PRUNE": "1"},
+    "dense_layer0_rows8": {"PFDYN_NO_PRUNE": "1", "PFDYN_RG2_ROWS_MIN": "0"},
+}
+
+
+@pytest.mark.parametrize("variant", list(HOIST_VARIANTS))
+@pytest.mark.parametrize("name", list(DYN_CASES))
+def test_static_hoist_vs_golden_and_full_chain(name, variant, monkeypatch):
+    """Conv layer 0 with the pp messages' first GVP hoisted (trajectory constants + per-timestep type table) against
+    the reference goldens, and against the same launch shapes computing the full chain (PFDYN_NO_L0_HOIST=1).  Every
+    work-list form of the layer-0 edge launch is forced: mixed 4 / 8 rows per wave, tile lists, the dense layer."""
+    z, cfg = load(name), DYN_CASES[name]
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    for k, v in HOIST_VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch, z["prot_x"])
+    eps_h, eps_x = eng.dynamics(z["x_t"], z["h_t"], z["t"])
+    assert eng.l0_hoist() in (4, 8), "the static hoist did not run"
+    close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
+    monkeypatch.setenv("PFDYN_NO_L0_HOIST", "1")
+    ref = engine_for(cfg, sd)
+    set_batch(ref, batch, z["prot_x"])
+    rh, rx = ref.dynamics(z["x_t"], z["h_t"], z["t"])
+    assert ref.l0_hoist() == 0
+    torch.testing.assert_close(eps_h.cpu(), rh.cpu(), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(eps_x.cpu(), rx.cpu(), rtol=2e-5, atol=2e-5)
+
+
+def test_static_hoist_follows_coordinates_weights_and_features():
+    """The hoisted constants are recomputed when the caller passes other protein coordinates and when the weights
+    change; protein features that are not element one-hots switch the hoist off."""
+    name = "dynamics_ragged.npz"
+    z, cfg = load(name), DYN_CASES[name]
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch, z["prot_x"])
+    eng.dynamics(z["x_t"], z["h_t"], z["t"])
+    assert eng.l0_hoist() > 0
+    # other coordinates (not a rigid translate) with the same static edges
+    gen = torch.Generator().manual_seed(3)
+    px = z["prot_x"] + 0.3 * torch.randn(z["prot_x"].shape, generator=gen)
+    eh, ex = eng.dynamics(z["x_t"], z["h_t"], z["t"], prot_x=px)
+    oh, ox = O.dynamics_forward(sd, cfg, batch, px, z["x_t"], z["h_t"], z["t"])
+    close(eh, oh); close(ex, ox)
+    # other weights
+    sd2 = O.make_state_dict(cfg, int(z["wseed"]) + 1)
+    eng.set_flat_params(torch.cat([sd2[n].reshape(-1) for n, _, _ in eng.param_layout()]))     # as after an optimiser step
+    eh, ex = eng.dynamics(z["x_t"], z["h_t"], z["t"], prot_x=z["prot_x"])
+    assert eng.l0_hoist() > 0
+    oh, ox = O.dynamics_forward(sd2, cfg, batch, z["prot_x"], z["x_t"], z["h_t"], z["t"])
+    close(eh, oh); close(ex, ox)
+    # soft features
+    soft = batch.prot_h.clone() * 0.9 + 0.01
+    b2 = O.PocketBatch(batch.prot_x, soft, batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst)
+    set_batch(eng, b2, z["prot_x"])
+    eh, ex = eng.dynamics(z["x_t"], z["h_t"], z["t"])
+    assert eng.l0_hoist() == 0
+    oh, ox = O.dynamics_forward(sd2, cfg, b2, z["prot_x"], z["x_t"], z["h_t"], z["t"])
+    close(eh, oh); close(ex, ox)

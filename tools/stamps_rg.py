@@ -51,7 +51,10 @@ if hasattr(lib, "pfk_build_set_stamp_buffer"):
     for g in range(3):
         r = st[g]
         print(f"  graph {g}: update {int(r[8] - r[0])}  ff {int(r[9] - r[8])}  kNN {int(r[10] - r[9])}  emit {int(r[11] - r[10])} (count {int(r[12] - r[10])}, scan {int(r[13] - r[12])}, stores {int(r[14] - r[13])}, barrier {int(r[15] - r[14])}, pa copy {int(r[11] - r[15])})  total {int(r[11] - r[0])}")
-for which in range(4):
+OFFS = [int(x) for x in os.environ.get("STAMP_OFFSETS", "0").split(",")]       # first recorded item per pass
+lib.pfk_rg_set_stamp_offset.argtypes = [ctypes.c_int]
+for which, off in [(w, o) for w in range(4) for o in (OFFS if w == 0 else [0])]:
+    assert lib.pfk_rg_set_stamp_offset(off) == 0
     buf.zero_()
     assert lib.pfk_rg_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
     lib.pfk_rg_set_stamp_which(which)
@@ -59,7 +62,8 @@ for which in range(4):
     torch.cuda.synchronize()
     lib.pfk_rg_set_stamp_buffer(None)
     st = buf.cpu().view(64, 64)
-    print(f"== launch {which}: {names[which]}  (cycles between consecutive stamps; waves that ran)")
+    print(f"== launch {which}: {names[which]}  items from {off}  (cycles between consecutive stamps; waves that ran)")
+    t0 = min(int(st[w][0]) for w in range(64) if int(st[w][0]) != 0) if bool((st[:, 0] != 0).any()) else 0
     shown = 0
     for w in range(64):
         row = st[w]
@@ -67,7 +71,7 @@ for which in range(4):
         if n < 2:
             continue
         dl = [int(row[i + 1] - row[i]) for i in range(n - 1)]
-        print(f"  wave {w:2d}: total {int(row[n - 1] - row[0])}  " + " ".join(str(x) for x in dl))
+        print(f"  wave {w:2d}: start +{int(row[0]) - t0}  total {int(row[n - 1] - row[0])}  " + " ".join(str(x) for x in dl))
         shown += 1
         if shown >= 6:
             break
