@@ -17,7 +17,7 @@
 #include "pf_device.h"
 #include "pf_train.h"
 
-#define L0_PTAB_SLOTS 1024        // timesteps whose layer-0 type tables stay resident (pf_prepare_timesteps)
+#define L0_PTAB_SLOTS 2048        // timesteps whose layer-0 type tables stay resident (pf_prepare_timesteps)
 
 extern "C" {
 void pfk_edge_msg(const EdgeParams* p, int layer0, hipStream_t s);

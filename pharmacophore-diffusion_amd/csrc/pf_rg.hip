@@ -79,7 +79,9 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f(const float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
+#ifndef RG_QUAD_MAX
 #define RG_QUAD_MAX 4096                       // launches of up to this many item slots use four-wave workgroups
+#endif
 #define RG_CPASS 16                            // compact work lists: up to 64 * RG_CPASS regions per launch
 // integer DPP moves for wave scans: lanes without a source (or rows outside ROW_MASK) read 0
 template <int CTRL>
