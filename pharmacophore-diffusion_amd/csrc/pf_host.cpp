@@ -121,6 +121,7 @@ struct pf_handle {
     NodeTile* d_node_tiles_act = nullptr;
     int *d_act_ids = nullptr, *d_reg_act = nullptr;   // last conv layer: only what feeds the pharm nodes
     void* d_ws = nullptr;                   // one allocation, carved below
+    size_t ws_capacity = 0;                 // bytes behind d_ws: kept across pocket batches while it is large enough
     int *d_prot_ptr = nullptr, *d_pharm_ptr = nullptr, *d_gid = nullptr, *d_reg = nullptr, *d_dyn_cnt = nullptr,
         *d_esrc = nullptr, *d_edst = nullptr, *d_in_start = nullptr, *d_in_cnt = nullptr, *d_pp_cnt = nullptr;
     EdgeTile* d_edge_tiles = nullptr;
@@ -531,9 +532,10 @@ static void pack_out_rg(pf_handle* h, std::vector<float>& out) {
     }
 }
 
-static void free_ws(pf_handle* h) {
-    if (h->d_ws) (void)hipFree(h->d_ws);
-    h->d_ws = nullptr;
+// keep_ws: the inference workspace stays allocated (pf_set_pocket_batch re-carves it when the next batch fits: a
+// hipMalloc / hipFree pair of a few hundred MB per batch costs milliseconds)
+static void free_ws(pf_handle* h, bool keep_ws = false) {
+    if (h->d_ws && !keep_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; }
     if (h->d_tws) (void)hipFree(h->d_tws);
     h->d_tws = nullptr;
     h->t_have_fwd = false;
@@ -1159,7 +1161,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
         if (pharm_ptr[g + 1] - pharm_ptr[g] > PF_MAXF)
             PF_FAIL(h, PF_ERR_ARG, "graph %d has %d pharmacophore centers (limit %d)", g, pharm_ptr[g + 1] - pharm_ptr[g], PF_MAXF);
     }
-    free_ws(h);
+    free_ws(h, true);
     h->B = B; h->Np = prot_ptr[B]; h->Nf = pharm_ptr[B]; h->N = h->Np + h->Nf; h->Epp = n_pp;
     h->h_prot_ptr.assign(prot_ptr, prot_ptr + B + 1);
     h->h_pharm_ptr.assign(pharm_ptr, pharm_ptr + B + 1);
@@ -1277,7 +1279,13 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     need((size_t)std::max(Np, 1) * PF_S * 4);
     need(Ecap * 4); need((size_t)std::max(Np, 1) * 4); need(256); need((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4);
     need((size_t)B * c.rec_nf * PF_S * 4);
-    PF_HIP(h, hipMalloc(&h->d_ws, bytes + 4096));
+    // launches of the previous batch may still read the workspace (hipFree used to wait for them)
+    PF_HIP(h, hipDeviceSynchronize());
+    if (h->ws_capacity < bytes + 4096) {
+        if (h->d_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; }
+        PF_HIP(h, hipMalloc(&h->d_ws, bytes + 4096));
+        h->ws_capacity = bytes + 4096;
+    }
     char* cur = reinterpret_cast<char*>(h->d_ws);
     h->d_prot_ptr = carve<int>(cur, B + 1); h->d_pharm_ptr = carve<int>(cur, B + 1); h->d_gid = carve<int>(cur, N);
     h->d_reg = carve<int>(cur, (size_t)4 * B); h->d_dyn_cnt = carve<int>(cur, (size_t)5 * B);
@@ -1310,12 +1318,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     if (!n_act.empty()) PF_HIP(h, hipMemcpy(h->d_node_tiles_act, n_act.data(), n_act.size() * sizeof(NodeTile), hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_esrc, esrc.data(), (size_t)Ecap * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_edst, edst.data(), (size_t)Ecap * 4, hipMemcpyHostToDevice));
-    {   // static pp slot of every edge slot: the identity (the edge build overwrites the "pa" regions)
-        std::vector<int> eo(Ecap);
-        for (int64_t e = 0; e < Ecap; ++e) eo[e] = (int)e;
-        PF_HIP(h, hipMemcpy(h->d_eorig, eo.data(), (size_t)Ecap * 4, hipMemcpyHostToDevice));
-        PF_HIP(h, hipMemset(h->d_l0flag, 0, 256));
-    }
+    PF_HIP(h, hipMemset(h->d_l0flag, 0, 256));
     PF_HIP(h, hipMemcpy(h->d_in_start, in_start.data(), (size_t)3 * N * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_in_cnt, in_cnt.data(), (size_t)3 * N * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_pp_cnt, pp_cnt.data(), (size_t)B * 4, hipMemcpyHostToDevice));
@@ -1333,6 +1336,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     {
         L0HoistParams lp{};
         lp.prot_h0 = h->d_prot_h0; lp.Np = Np; lp.rec_nf = c.rec_nf; lp.ptype = h->d_ptype; lp.flag = h->d_l0flag;
+        lp.zs = reinterpret_cast<float*>(h->d_eorig); lp.Epp = (int)Ecap;      // static slot of every edge slot: the identity
         pfk_l0_hoist(&lp, 2, s);
     }
     PF_HIP(h, hipStreamSynchronize(s));

@@ -1062,6 +1062,8 @@ __global__ __launch_bounds__(128) void k_l0_ptab(const L0HoistParams p) {
 }
 __global__ __launch_bounds__(256) void k_l0_types(const L0HoistParams p) {
     const int n = blockIdx.x * 256 + threadIdx.x;
+    int* eorig = reinterpret_cast<int*>(p.zs);        // [Epp here = Ecap]: identity (the edge build overwrites the "pa" regions)
+    for (int e = n; e < p.Epp; e += gridDim.x * 256) eorig[e] = e;
     if (n >= p.Np) return;
     int ty = -1, bad = 0;
     for (int k = 0; k < p.rec_nf; ++k) {
@@ -1088,7 +1090,7 @@ void pfk_l0_hoist(const L0HoistParams* p, int what, hipStream_t s) {       // wh
         if (p->Epp > 0) hipLaunchKernelGGL(k_l0_zs, dim3(std::min(p->Epp, 8192)), dim3(128), 0, s, *p);
     } else if (what == 1) {
         if (p->nt > 0) hipLaunchKernelGGL(k_l0_ptab, dim3(p->nt * p->rec_nf), dim3(128), 0, s, *p);
-    } else if (p->Np > 0) hipLaunchKernelGGL(k_l0_types, dim3((p->Np + 255) / 256), dim3(256), 0, s, *p);
+    } else hipLaunchKernelGGL(k_l0_types, dim3(std::max(1, (p->Np + 255) / 256)), dim3(256), 0, s, *p);
 }
 // rows per wave: 8 (RG = 2) once there are enough groups to fill the chip, else 4; rgp: rows-per-wave factor of the
 // static-hoist items of conv layer 0 (0: off; tile lists need rgp == rg)
