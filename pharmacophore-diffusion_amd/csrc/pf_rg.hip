@@ -764,7 +764,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_rg_edge(const EdgeParams p, cons
     if constexpr (RGP > 0) {
         if (pre) { rg_edge_item<L0, RGP, WAVES, true>(p, ep, lds, item, wq, e0, nv, et, lane); return; }
     }
+#ifdef PF_TWICE                                       // diagnostic: every item twice through the SAME code (warm instruction cache the second time)
+#pragma nounroll
+    for (int it = 0; it < 2; ++it) rg_edge_item<L0, RG, WAVES, false>(p, ep, lds, item + 100000 * it, wq, e0, nv, et, lane);
+#else
     rg_edge_item<L0, RG, WAVES, false>(p, ep, lds, item, wq, e0, nv, et, lane);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
