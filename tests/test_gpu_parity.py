@@ -483,3 +483,38 @@ def test_static_hoist_follows_coordinates_weights_and_features():
     assert eng.l0_hoist() == 0
     oh, ox = O.dynamics_forward(sd2, cfg, b2, z["prot_x"], z["x_t"], z["h_t"], z["t"])
     close(eh, oh); close(ex, ox)
+
+
+def test_static_hoist_type_tables_announced_or_on_arrival():
+    """The per-timestep type tables of the static hoist: announced by pf_sample (several launches of 64 timesteps),
+    computed on arrival by un-announced pf_denoise_step calls, announced by the caller (pf_prepare_timesteps) -- the
+    three give bitwise the same trajectory, and the same as a handle that saw other timesteps before."""
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    batch = O.synthetic_batch([7, 8, 9], 96, [3, 5, 4], cfg)
+    T, n = 500, 150
+    Nf = int(batch.pharm_ptr[-1])
+    noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(1))
+    coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+
+    def fresh():
+        eng = engine_for(cfg, sd)
+        set_batch(eng, batch)
+        return eng, eng.coef_array(coef, reversed(range(n)))         # the last n steps of the schedule
+
+    eng, arr = fresh()
+    x_a, h_a = eng.sample(arr, n, noise)
+    assert eng.l0_hoist() > 0
+    results = []
+    for announce in (False, True):
+        eng, arr = fresh()
+        if announce:
+            eng.prepare_timesteps(arr, n)
+        else:                                                        # other timesteps first: the cache is not empty
+            eng.prepare_timesteps(eng.coef_array(coef, range(200, 330)), 130)
+        eng.sample_begin(noise[0])
+        for i in range(n):
+            eng.denoise_step(arr[i], noise[i + 1])
+        results.append(eng.sample_frame())
+    for x, h in results:
+        assert torch.equal(x.cpu(), x_a.cpu()) and torch.equal(h.cpu(), h_a.cpu())
