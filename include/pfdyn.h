@@ -133,7 +133,7 @@ int pf_sample_end(pf_handle* h, float feat_norm_constant, float* dev_x0 /*[Nf,3]
 /* current frame in the caller's frame of reference (get_pos_feat_for_visual, pharmacodiff.py:360-378) */
 int pf_sample_frame(pf_handle* h, float feat_norm_constant, float* dev_x /*[Nf,3]*/, float* dev_h /*[Nf,pharm_nf]*/,
                     pf_stream stream);
-/* Optional, before a loop of pf_denoise_step calls: the timesteps (pf_step_coef::t) the loop will visit.  The first
+/* Optional, after pf_set_pocket_batch and before a loop of pf_denoise_step calls: the timesteps (pf_step_coef::t) the loop will visit.  The first
  * conv layer's protein-side messages depend on t only through one encoder output per element type
  * (dynamics_gvp.py:107-117 feeding gvp.py:545-549); their tables are computed here in one launch per 64 timesteps
  * instead of one small launch in front of every step.  pf_sample does this itself; results never depend on it. */
