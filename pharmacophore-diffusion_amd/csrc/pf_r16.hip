@@ -49,17 +49,31 @@ __device__ __forceinline__ float dpp_f0(const float v) {      // lanes without a
 template <int CTRL>
 __device__ __forceinline__ int dpp_i0(const int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
 
+// scheduling barriers after every quad keep the ring loads where they are issued (without them the compiler sinks
+// every load next to its use).  The loads walk the stream strictly sequentially through a SCALAR pointer that is made
+// opaque after every step: with ordinary pointer arithmetic the compiler computes the 64-bit vector address of each of
+// the ~100 loads of a block ahead of the first barrier (372-394 registers: one wave per SIMD)
+#ifndef R16_SBM
+#define R16_SBM 0
+#endif
 #define R16_D 8                                // quads in the prefetch ring (depth 6 / 12 / 24 measured the same)
 template <int D>
 struct Ring16 {
     f32x4 q[D];
-    pf_gcf p;                                  // quad 0 of the current block (wave-uniform: scalar base + lane offset addressing)
+    pf_gcf pl;                                 // next quad to load (wave-uniform: scalar base + lane offset addressing)
 };
 static_assert(R16_PAD % R16_D == 0, "ring depth must divide the block padding");
 
 // one quad: take it from the ring, refill the slot
-#define R16_LOAD(QI) (reinterpret_cast<const f32x4 PF_AS1*>(ring.p + (size_t)(QI) * 256)[lane])
-#define R16_TAKE(W, QI) const f32x4 W = ring.q[(QI) % R16_D]; ring.q[(QI) % R16_D] = R16_LOAD((QI) + R16_D)
+__device__ __forceinline__ f32x4 r16_next(Ring16<R16_D>& ring, const int lane) {
+    const f32x4 v = reinterpret_cast<const f32x4 PF_AS1*>(ring.pl)[lane];
+    ring.pl += 256;
+    asm volatile("" : "+s"(ring.pl));
+    return v;
+}
+// quad QI of the current block (every block is a multiple of R16_D quads, so it sits in slot QI % R16_D); the slot is
+// refilled with the next quad of the stream
+#define R16_TAKE(W, QI) const f32x4 W = ring.q[(QI) % R16_D]; ring.q[(QI) % R16_D] = r16_next(ring, lane)
 
 // pending gates of the previous GVP -> its gated vectors: Vin[c][i] = act(gate[i]) * vu[c][i]   (channel 4 g + i)
 template <bool SIG, int Q0>
@@ -73,7 +87,7 @@ __device__ __forceinline__ void r16_gates(Ring16<R16_D>& ring, const float (&S)[
         constexpr int q = decltype(Q)::value;
         R16_TAKE(w, Q0 + 1 + q);
         static_for<0, 4>([&](auto J) { constexpr int j = decltype(J)::value; ga[j] = mfma16(w[j], S[4 * q + j], ga[j]); });
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(R16_SBM);
     });
     const f32x4 gd = (ga[0] + ga[1]) + (ga[2] + ga[3]);
 #pragma unroll
@@ -94,13 +108,13 @@ __device__ __forceinline__ void r16_gvp(Ring16<R16_D>& ring, float (&S)[32], f32
     { R16_TAKE(w, 9); wh = w; }
     f32x4 acc[8];
     static_for<0, 8>([&](auto T) { constexpr int t = decltype(T)::value; R16_TAKE(w, 10 + t); acc[t] = w; });
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(R16_SBM);
     // main k-steps 0..15 (the sigmoids above retire under them)
     static_for<0, 32>([&](auto Q) {
         constexpr int q = decltype(Q)::value, ks = q / 2, half = q % 2;
         R16_TAKE(w, 18 + q);
         static_for<0, 4>([&](auto J) { constexpr int j = decltype(J)::value; acc[4 * half + j] = mfma16(w[j], S[ks], acc[4 * half + j]); });
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(R16_SBM);
     });
     // Vh[c] = Wh^T Vin[c]
     f32x4 vh[3];
@@ -111,13 +125,13 @@ __device__ __forceinline__ void r16_gvp(Ring16<R16_D>& ring, float (&S)[32], f32
 #pragma unroll
         for (int c = 0; c < 3; ++c) vh[c] = mfma16(wh[k], vin[c][k], vh[c]);
     });
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(R16_SBM);
     // main k-steps 16..31
     static_for<0, 32>([&](auto Q) {
         constexpr int q = decltype(Q)::value, ks = 16 + q / 2, half = q % 2;
         R16_TAKE(w, 50 + q);
         static_for<0, 4>([&](auto J) { constexpr int j = decltype(J)::value; acc[4 * half + j] = mfma16(w[j], S[ks], acc[4 * half + j]); });
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(R16_SBM);
     });
     // Vu[c] = Wu^T Vh[c];  sh = |Vh|
     f32x4 wu;
@@ -132,15 +146,14 @@ __device__ __forceinline__ void r16_gvp(Ring16<R16_D>& ring, float (&S)[32], f32
     float sh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) sh[i] = sqrtf_(fmaxf(vh[0][i] * vh[0][i] + vh[1][i] * vh[1][i] + vh[2][i] * vh[2][i], 1e-8f));
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(R16_SBM);
     static_for<0, 8>([&](auto Q) {
         constexpr int q = decltype(Q)::value, ks = q / 2, half = q % 2;
         R16_TAKE(w, 83 + q);
         static_for<0, 4>([&](auto J) { constexpr int j = decltype(J)::value; acc[4 * half + j] = mfma16(w[j], sh[ks], acc[4 * half + j]); });
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(R16_SBM);
     });
     static_for<91, R16_NQ_GVP>([&](auto Q) { constexpr int q = decltype(Q)::value; R16_TAKE(w, q); (void)w; });   // padding quads keep the slots aligned
-    ring.p += R16_NQ_GVP * 256;
     static_for<0, 8>([&](auto T) {
         constexpr int t = decltype(T)::value;
 #pragma unroll
@@ -199,8 +212,8 @@ __global__ __launch_bounds__(64) void k_r16_pp(const EdgeParams p, const int rba
         e0 = t.e0 + base;
     }
     Ring16<R16_D> ring;
-    ring.p = p.r16;
-    static_for<0, R16_D>([&](auto I) { ring.q[decltype(I)::value] = R16_LOAD(decltype(I)::value); });
+    ring.pl = p.r16;
+    static_for<0, R16_D>([&](auto I) { ring.q[decltype(I)::value] = r16_next(ring, lane); });
     const int row = lane & 15, g = lane >> 4;
     const int e = e0 + min(row, nv - 1);
     const int src = p.esrc[e], dst = p.edst[e], eo = p.eorig[e];

@@ -3,7 +3,7 @@ run() { echo "== $1 | $2"; env $1 python bench.py --no-cpu-baseline $2 2>/dev/nu
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d['roofline']
 print('   ', round(d['value']), 'ms/step', round(d['ms_per_step'],5), 'edge_us', round(r['kernel_avg_us'],2), 'frac', round(r['frac'],3), r['kernel'])"; }
-for A in "" "--batch 64" "--batch 128 --pharm-sizes 3-8" "--batch 256 --pharm-sizes 3-8" "--batch 1024 --pharm-sizes 3-8" "--arch class-default"; do
+for A in "--batch 128 --pharm-sizes 3-8" "--batch 1024 --pharm-sizes 3-8" "--arch class-default"; do
 run "PFDYN_X=0" "$A"
 run "PFDYN_R16_ROWS_MIN=0" "$A"
 done
