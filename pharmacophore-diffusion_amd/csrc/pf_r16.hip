@@ -56,6 +56,13 @@ __device__ __forceinline__ int dpp_i0(const int v) { return __builtin_amdgcn_upd
 #ifndef R16_SBM
 #define R16_SBM 0
 #endif
+// in-kernel cycle stamps (diagnostic builds only: -DPF_STAMPS; tools/stamps_r16.py)
+#ifdef PF_STAMPS
+__device__ unsigned long long* g_r16_stamps = nullptr;
+#define R16_STAMP(K) do { if (lane == 0 && g_r16_stamps && item < 64) g_r16_stamps[item * 16 + (K)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define R16_STAMP(K) do { } while (0)
+#endif
 #define R16_D 8                                // quads in the prefetch ring (depth 6 / 12 / 24 measured the same)
 template <int D>
 struct Ring16 {
@@ -211,6 +218,7 @@ __global__ __launch_bounds__(64) void k_r16_pp(const EdgeParams p, const int rba
         if (nv <= 0) return;                           // wave-uniform
         e0 = t.e0 + base;
     }
+    R16_STAMP(0);                                                  // work item known
     Ring16<R16_D> ring;
     ring.pl = p.r16;
     static_for<0, R16_D>([&](auto I) { ring.q[decltype(I)::value] = r16_next(ring, lane); });
@@ -241,9 +249,11 @@ __global__ __launch_bounds__(64) void k_r16_pp(const EdgeParams p, const int rba
 #pragma unroll
         for (int c = 0; c < 3; ++c) vu[c] = weff * xh[c];
     }
-    for (int gi = 1; gi < p.n_gvps; ++gi) r16_gvp(ring, S, vu, lane);
+    R16_STAMP(1);                                                  // rows gathered, S / Vu of the hoisted GVP ready
+    for (int gi = 1; gi < p.n_gvps; ++gi) { r16_gvp(ring, S, vu, lane); R16_STAMP(1 + gi); }
     f32x4 vd[3];
     r16_gates<true, 0>(ring, S, vu, vd, lane);                     // flush: the last GVP's gates
+    R16_STAMP(8);
     // per-destination sums of consecutive rows (slots are sorted by destination): segmented inclusive scan inside each
     // 16-lane row of the wave, one partial row per (item, destination) run, stored at the run's last slot
     const int did = row < nv ? dst : -1 - row;                     // rows beyond the item: their own segments, never stored
@@ -280,11 +290,15 @@ __global__ __launch_bounds__(64) void k_r16_pp(const EdgeParams p, const int rba
             vp[2] = (f32x4){o[8], o[9], o[10], o[11]};
         }
     }
+    R16_STAMP(9);                                                  // stores issued
 }
 
 }  // namespace
 
 extern "C" {
+#ifdef PF_STAMPS
+int pfk_r16_set_stamp_buffer(unsigned long long* dev) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_r16_stamps), &dev, sizeof(dev)); }
+#endif
 // the hoisted pp items of conv layer 0: compact regions [rbase, rbase + p->nreg) (grid: p->ngroups_sel groups of 16), or the
 // ntiles tiles from tile0 of p->tiles
 void pfk_r16_pp(const EdgeParams* p, int rbase, int tile0, hipStream_t s) {
