@@ -72,7 +72,7 @@ struct GvpW {              // packed weights of one GVP (device pointers)
 #define RG_NQ_FLUSH 24      // [8 gate quads] [pad]
 #define RG_NQ_OUT 24        // to_scalar_output: [const] [8 gate-like quads] [pad]
 // 16-row form of the hoisted layer-0 pp items (pf_r16.hip): quads per GVP block / flush block, padding unit = ring depth
-#define R16_PAD 8
+#define R16_PAD 24
 #define R16_NQ_GVP 96       // 91 used
 #define R16_NQ_FLUSH 24     // 9 used; the ring reads 8 quads ahead
 #define RG_CPASS_R16 4      // compact work list of pf_r16.hip: up to 256 regions

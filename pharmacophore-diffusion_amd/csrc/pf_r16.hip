@@ -63,7 +63,7 @@ __device__ unsigned long long* g_r16_stamps = nullptr;
 #else
 #define R16_STAMP(K) do { } while (0)
 #endif
-#define R16_D 8                                // quads in the prefetch ring (depth 6 / 12 / 24 measured the same)
+#define R16_D 24                               // quads in the prefetch ring (a block: 17 k cycles at depth 8, 15 k at 24)
 template <int D>
 struct Ring16 {
     f32x4 q[D];
