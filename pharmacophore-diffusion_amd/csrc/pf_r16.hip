@@ -56,6 +56,17 @@ __device__ __forceinline__ int dpp_i0(const int v) { return __builtin_amdgcn_upd
 #ifndef R16_SBM
 #define R16_SBM 0
 #endif
+// R16_GROUPS: the issue order is pinned by a pipeline description instead (sched_group_barrier: one VMEM read, then the
+// MFMAs of the quad, in source order), which leaves the ALU instructions free: 182 registers, two waves per SIMD
+#ifdef R16_GROUPS
+#define R16_SG_L() __builtin_amdgcn_sched_group_barrier(0x020, 1, 0)
+#define R16_SG_M(N) __builtin_amdgcn_sched_group_barrier(0x008, N, 0)
+#define R16_SB() do { } while (0)
+#else
+#define R16_SG_L() do { } while (0)
+#define R16_SG_M(N) do { } while (0)
+#define R16_SB() __builtin_amdgcn_sched_barrier(R16_SBM)
+#endif
 // in-kernel cycle stamps (diagnostic builds only: -DPF_STAMPS; tools/stamps_r16.py)
 #ifdef PF_STAMPS
 __device__ unsigned long long* g_r16_stamps = nullptr;
@@ -63,7 +74,9 @@ __device__ unsigned long long* g_r16_stamps = nullptr;
 #else
 #define R16_STAMP(K) do { } while (0)
 #endif
+#ifndef R16_D
 #define R16_D 24                               // quads in the prefetch ring (a block: 17 k cycles at depth 8, 15 k at 24)
+#endif
 template <int D>
 struct Ring16 {
     f32x4 q[D];
@@ -87,14 +100,14 @@ template <bool SIG, int Q0>
 __device__ __forceinline__ void r16_gates(Ring16<R16_D>& ring, const float (&S)[32], const f32x4 (&vu)[3], f32x4 (&vin)[3], const int lane) {
     // four accumulators (one per image of a quad): back-to-back MFMAs on one accumulator wait for each other
     f32x4 ga[4];
-    { R16_TAKE(w, Q0); ga[0] = w; }                               // gate bias image = accumulator init
+    { R16_TAKE(w, Q0); ga[0] = w; R16_SG_L(); }                   // gate bias image = accumulator init
 #pragma unroll
     for (int j = 1; j < 4; ++j) ga[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     static_for<0, 8>([&](auto Q) {
         constexpr int q = decltype(Q)::value;
         R16_TAKE(w, Q0 + 1 + q);
         static_for<0, 4>([&](auto J) { constexpr int j = decltype(J)::value; ga[j] = mfma16(w[j], S[4 * q + j], ga[j]); });
-        __builtin_amdgcn_sched_barrier(R16_SBM);
+        R16_SG_L(); R16_SG_M(4); R16_SB();
     });
     const f32x4 gd = (ga[0] + ga[1]) + (ga[2] + ga[3]);
 #pragma unroll
@@ -112,16 +125,16 @@ __device__ __forceinline__ void r16_gvp(Ring16<R16_D>& ring, float (&S)[32], f32
     f32x4 vin[3];
     r16_gates<true, 0>(ring, S, vu, vin, lane);                    // quads 0..8
     f32x4 wh;
-    { R16_TAKE(w, 9); wh = w; }
+    { R16_TAKE(w, 9); wh = w; R16_SG_L(); }
     f32x4 acc[8];
-    static_for<0, 8>([&](auto T) { constexpr int t = decltype(T)::value; R16_TAKE(w, 10 + t); acc[t] = w; });
-    __builtin_amdgcn_sched_barrier(R16_SBM);
+    static_for<0, 8>([&](auto T) { constexpr int t = decltype(T)::value; R16_TAKE(w, 10 + t); acc[t] = w; R16_SG_L(); });
+    R16_SB();
     // main k-steps 0..15 (the sigmoids above retire under them)
     static_for<0, 32>([&](auto Q) {
         constexpr int q = decltype(Q)::value, ks = q / 2, half = q % 2;
         R16_TAKE(w, 18 + q);
         static_for<0, 4>([&](auto J) { constexpr int j = decltype(J)::value; acc[4 * half + j] = mfma16(w[j], S[ks], acc[4 * half + j]); });
-        __builtin_amdgcn_sched_barrier(R16_SBM);
+        R16_SG_L(); R16_SG_M(4); R16_SB();
     });
     // Vh[c] = Wh^T Vin[c]
     f32x4 vh[3];
@@ -132,17 +145,17 @@ __device__ __forceinline__ void r16_gvp(Ring16<R16_D>& ring, float (&S)[32], f32
 #pragma unroll
         for (int c = 0; c < 3; ++c) vh[c] = mfma16(wh[k], vin[c][k], vh[c]);
     });
-    __builtin_amdgcn_sched_barrier(R16_SBM);
+    R16_SG_M(12); R16_SB();
     // main k-steps 16..31
     static_for<0, 32>([&](auto Q) {
         constexpr int q = decltype(Q)::value, ks = 16 + q / 2, half = q % 2;
         R16_TAKE(w, 50 + q);
         static_for<0, 4>([&](auto J) { constexpr int j = decltype(J)::value; acc[4 * half + j] = mfma16(w[j], S[ks], acc[4 * half + j]); });
-        __builtin_amdgcn_sched_barrier(R16_SBM);
+        R16_SG_L(); R16_SG_M(4); R16_SB();
     });
     // Vu[c] = Wu^T Vh[c];  sh = |Vh|
     f32x4 wu;
-    { R16_TAKE(w, 82); wu = w; }
+    { R16_TAKE(w, 82); wu = w; R16_SG_L(); }
 #pragma unroll
     for (int c = 0; c < 3; ++c) vu[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     static_for<0, 4>([&](auto K) {
@@ -153,14 +166,14 @@ __device__ __forceinline__ void r16_gvp(Ring16<R16_D>& ring, float (&S)[32], f32
     float sh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) sh[i] = sqrtf_(fmaxf(vh[0][i] * vh[0][i] + vh[1][i] * vh[1][i] + vh[2][i] * vh[2][i], 1e-8f));
-    __builtin_amdgcn_sched_barrier(R16_SBM);
+    R16_SG_M(12); R16_SB();
     static_for<0, 8>([&](auto Q) {
         constexpr int q = decltype(Q)::value, ks = q / 2, half = q % 2;
         R16_TAKE(w, 83 + q);
         static_for<0, 4>([&](auto J) { constexpr int j = decltype(J)::value; acc[4 * half + j] = mfma16(w[j], sh[ks], acc[4 * half + j]); });
-        __builtin_amdgcn_sched_barrier(R16_SBM);
+        R16_SG_L(); R16_SG_M(4); R16_SB();
     });
-    static_for<91, R16_NQ_GVP>([&](auto Q) { constexpr int q = decltype(Q)::value; R16_TAKE(w, q); (void)w; });   // padding quads keep the slots aligned
+    static_for<91, R16_NQ_GVP>([&](auto Q) { constexpr int q = decltype(Q)::value; R16_TAKE(w, q); (void)w; R16_SG_L(); });   // padding quads keep the slots aligned
     static_for<0, 8>([&](auto T) {
         constexpr int t = decltype(T)::value;
 #pragma unroll
