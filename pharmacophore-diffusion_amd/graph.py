@@ -19,6 +19,10 @@ def _ptr(counts) -> torch.Tensor:
     return torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(c, 0)])
 
 
+def _ptr1(n: int) -> torch.Tensor:             # _ptr([n]) in one tensor construction (unbatch: three per graph)
+    return torch.tensor([0, int(n)], dtype=torch.int64)
+
+
 @dataclass
 class PocketGraph:
     prot_x: torch.Tensor                       # [Np,3]  'prot'.x_0
@@ -34,6 +38,8 @@ class PocketGraph:
     prot_ph_ptr: Optional[torch.Tensor] = None
     x_t: Optional[torch.Tensor] = None         # 'pharm'.x_t / h_t during sampling
     h_t: Optional[torch.Tensor] = None
+    pp_ptr: Optional[torch.Tensor] = None      # [B+1] int64 (host): graph g owns pp edges [pp_ptr[g], pp_ptr[g+1]) -- set by
+                                               # batch(); lets unbatch() skip the search for the per-graph edge ranges
 
     # -- DGL-like accessors used by the reference's drivers --------------------------------
     @property
@@ -104,14 +110,17 @@ def batch(graphs: List[PocketGraph]) -> PocketGraph:
     prot_counts = torch.cat([g.batch_num_nodes("prot") for g in graphs])
     pharm_counts = torch.cat([g.batch_num_nodes("pharm") for g in graphs])
     ph_counts = torch.cat([g.batch_num_nodes("prot_ph") for g in graphs])
-    srcs, dsts, off = [], [], 0
+    srcs, dsts, off, e_counts = [], [], 0, []
     for g in graphs:
         srcs.append(g.pp_src + off)
         dsts.append(g.pp_dst + off)
         off += g.num_nodes("prot")
+        e_counts.append(int(g.pp_src.numel()))
+    # per-graph edge ranges are known only when every input is a single graph (a batched input keeps its own grouping)
+    pp_ptr = _ptr(e_counts) if all(g.batch_size == 1 for g in graphs) else None
     return PocketGraph(cat("prot_x"), cat("prot_h"), _ptr(prot_counts), _ptr(pharm_counts), torch.cat(srcs), torch.cat(dsts),
                        cat("pharm_x0"), cat("pharm_h0"), cat("prot_ph_x"), cat("prot_ph_h"), _ptr(ph_counts),
-                       cat("x_t"), cat("h_t"))
+                       cat("x_t"), cat("h_t"), pp_ptr)
 
 
 def unbatch(g: PocketGraph) -> List[PocketGraph]:
@@ -119,12 +128,15 @@ def unbatch(g: PocketGraph) -> List[PocketGraph]:
     in graph order), so each graph's edges are one slice; an arbitrary edge order falls back to masks."""
     out = []
     B = g.batch_size
-    gid = torch.searchsorted(g.prot_ptr[1:].contiguous(), g.pp_dst, right=True)
-    grouped = bool((gid[1:] >= gid[:-1]).all()) if gid.numel() > 1 else True
-    if grouped:
-        e_ptr = torch.zeros(B + 1, dtype=torch.int64)
-        e_ptr[1:] = torch.cumsum(torch.bincount(gid, minlength=B)[:B], 0)
-        e_ptr = e_ptr.tolist()
+    if g.pp_ptr is not None and g.pp_ptr.numel() == B + 1 and int(g.pp_ptr[-1]) == g.pp_src.numel():
+        grouped, gid, e_ptr = True, None, g.pp_ptr.tolist()
+    else:
+        gid = torch.searchsorted(g.prot_ptr[1:].contiguous(), g.pp_dst, right=True)
+        grouped = bool((gid[1:] >= gid[:-1]).all()) if gid.numel() > 1 else True
+        if grouped:
+            e_ptr = torch.zeros(B + 1, dtype=torch.int64)
+            e_ptr[1:] = torch.cumsum(torch.bincount(gid, minlength=B)[:B], 0)
+            e_ptr = e_ptr.tolist()
     pp, fp = g.prot_ptr.tolist(), g.pharm_ptr.tolist()
     have_ph = g.prot_ph_ptr is not None and g.prot_ph_x is not None
     qp = g.prot_ph_ptr.tolist() if have_ph else None
@@ -139,9 +151,9 @@ def unbatch(g: PocketGraph) -> List[PocketGraph]:
             m = gid == b
             src, dst = g.pp_src[m] - p0, g.pp_dst[m] - p0
         q0, q1 = (qp[b], qp[b + 1]) if have_ph else (0, 0)
-        out.append(PocketGraph(g.prot_x[p0:p1], g.prot_h[p0:p1], _ptr([p1 - p0]), _ptr([f1 - f0]), src, dst,
+        out.append(PocketGraph(g.prot_x[p0:p1], g.prot_h[p0:p1], _ptr1(p1 - p0), _ptr1(f1 - f0), src, dst,
                                sl(g.pharm_x0, f0, f1), sl(g.pharm_h0, f0, f1),
-                               sl(g.prot_ph_x, q0, q1), sl(g.prot_ph_h, q0, q1), _ptr([q1 - q0]),
+                               sl(g.prot_ph_x, q0, q1), sl(g.prot_ph_h, q0, q1), _ptr1(q1 - q0),
                                sl(g.x_t, f0, f1), sl(g.h_t, f0, f1)))
     return out
 

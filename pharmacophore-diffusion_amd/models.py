@@ -419,6 +419,10 @@ class PharmacophoreDiff(_Base):
         reference run means passing its draws here.  When omitted all T+1 draws come from ONE torch.randn call on the
         model's device (same distribution, reproducible under torch.manual_seed; the reference's 2(T+1) separate calls
         would cost a thousand launches per batch and cannot reproduce a CUDA generator's stream on ROCm anyway)."""
+        return self._sample_finish(self._sample_enqueue(g, init_pharm_com, visualize_trajectory, noise))
+
+    def _sample_enqueue(self, g, init_pharm_com=None, visualize_trajectory=False, noise=None):
+        """First half of sample_given_receptor: upload the batch and enqueue the whole reverse process (asynchronous)."""
         g = as_pocket_graph(g)
         dev = self.device
         T, Nf, nf = self.n_timesteps, g.num_nodes("pharm"), self.n_pharm_feats
@@ -426,11 +430,23 @@ class PharmacophoreDiff(_Base):
             noise = torch.randn(T + 1, Nf, 3 + nf, device=dev)
         eng = self.dynamics.bind_graph(g)
         coef = self.step_coefficients()
-        arr = eng.coef_array(coef, reversed(range(T)))
+        if getattr(self, "_coef_arr", None) is None or self._coef_arr[0] != T:      # 500-1000 ctypes structs: built once
+            self._coef_arr = (T, eng.coef_array(coef, reversed(range(T))))
+        arr = self._coef_arr[1]
         com = None if init_pharm_com is None else init_pharm_com.to(dev)
         res = eng.sample(arr, T, noise.to(dev), init_pharm_com=com, ep_coord=self.endpoint_param_coord,
                          ep_feat=self.endpoint_param_feat, feat_norm_constant=float(self.pharm_feat_norm_constant),
                          trajectory=visualize_trajectory)
+        return g, res, visualize_trajectory
+
+    def _sample_fetch(self, pending):
+        """Results of an enqueued batch on the host (waits for the device)."""
+        g, res, traj = pending
+        return g, tuple(r.cpu() if r is not None else None for r in res), traj
+
+    def _sample_finish(self, pending) -> List[SampledPharmacophore]:
+        """Second half: per-graph SampledPharmacophores (host work only once the results are fetched)."""
+        g, res, visualize_trajectory = pending
         x0, h0 = res[0].cpu(), res[1].cpu()
         traj_x = res[2].cpu() if visualize_trajectory else None
         traj_h = res[3].cpu() if visualize_trajectory else None
@@ -462,13 +478,26 @@ class PharmacophoreDiff(_Base):
             graph_ref_idx.extend([rec_idx] * len(n_rec))
         mine = list(range(rank, len(graphs), world_size))
         sampled = {}
+        # Two-stage pipeline over the batches: the host work of a batch (collating the next one, splitting the previous
+        # one's results into SampledPharmacophores) runs while the device works on another batch; only the upload of a
+        # batch (one workspace per handle) waits for the batch before it.  The batched graph stays on the host: the engine
+        # uploads what it needs once, and the per-graph views are host tensors anyway.
+        pending = None                                  # (idx, enqueued batch)
+        def finish(done):
+            for i, p in zip(done[0], self._sample_finish(done[1])):
+                sampled[i] = p
         for start in range(0, len(mine), max_batch_size):
             idx = mine[start:start + max_batch_size]
-            batch_g = batch_graphs([graphs[i] for i in idx]).to(self.device)
+            batch_g = batch_graphs([graphs[i] for i in idx])
             init_coms = init_pharm_com[[graph_ref_idx[i] for i in idx]].to(self.device)
-            pharms = self.sample_given_receptor(batch_g, init_pharm_com=init_coms, visualize_trajectory=visualize_trajectory)
-            for i, p in zip(idx, pharms):
-                sampled[i] = p
+            done = None
+            if pending is not None:
+                done = (pending[0], self._sample_fetch(pending[1]))     # waits for the device: the workspace is free again
+            pending = (idx, self._sample_enqueue(batch_g, init_coms, visualize_trajectory))
+            if done is not None:
+                finish(done)                            # while the device runs the batch just enqueued
+        if pending is not None:
+            finish((pending[0], self._sample_fetch(pending[1])))
         per_pocket, end = [], 0
         for rec_idx in range(n_receptors):
             start, end = end, end + len(n_pharms[rec_idx])
