@@ -141,7 +141,7 @@ class _DynamicsFn(torch.autograd.Function):
     (pharmacodiff.py:162-243)."""
 
     @staticmethod
-    def forward(ctx, mod, eng, x_t, h_t, t, prot_x, dropout, seed, *params):
+    def forward(ctx, mod, eng, x_t, h_t, t, prot_x, dropout, seed, flat_leaf):
         eps_h, eps_x = eng.train_forward(x_t, h_t, t, prot_x=prot_x, dropout=dropout, seed=seed)
         mod._fwd_token += 1
         ctx.mod, ctx.eng, ctx.token = mod, eng, mod._fwd_token
@@ -155,10 +155,10 @@ class _DynamicsFn(torch.autograd.Function):
                                "the engine keeps the activations of one forward at a time")
         g_h = torch.zeros(eng.Nf, eng.pharm_nf, device=eng.device) if g_h is None else g_h.contiguous()
         g_x = torch.zeros(eng.Nf, 3, device=eng.device) if g_x is None else g_x.contiguous()
-        flat = eng.train_backward(g_h, g_x)
-        mod._last_flat_grad = flat
-        grads = tuple(flat[off:off + n].view(p.shape) for p, off, n in mod._flat_views)
-        return (None,) * 8 + grads
+        # ONE gradient for autograd: the flat vector, for the flat leaf that aliases every parameter (244 separate
+        # gradient views and AccumulateGrad nodes cost 1.4 ms of host time per step -- more than the device could hide);
+        # the hooks of the leaf re-bind each parameter's .grad to its slice (PharmRecDynamicsGVP._bind_grads)
+        return (None,) * 8 + (eng.train_backward(g_h, g_x),)
 
 
 class PharmRecDynamicsGVP(nn.Module):
@@ -236,6 +236,33 @@ class PharmRecDynamicsGVP(nn.Module):
             p.data = flat[off:off + n].view(p.shape)
             views.append((p, off, n))
         self._flat, self._flat_views = flat, views
+        # the autograd face of the parameters: one leaf over the same storage (not a registered parameter: state_dict and
+        # parameters() keep the reference's 244 tensors).  Its incoming-gradient hook notices gradients that were
+        # cleared parameter by parameter (optimizer.zero_grad(), module.zero_grad()), its post-accumulate hook points
+        # every parameter's .grad at its slice of the accumulated flat gradient.
+        leaf = flat.detach().requires_grad_(True)
+        leaf.register_hook(self._before_accumulate)
+        leaf.register_post_accumulate_grad_hook(self._bind_grads)
+        self.__dict__["_flat_leaf"] = leaf
+        self._last_flat_grad = None
+
+    def _before_accumulate(self, grad):
+        leaf = self.__dict__["_flat_leaf"]
+        if leaf.grad is not None:
+            p0 = next((p for p, _, _ in self._flat_views if p.requires_grad), None)
+            if p0 is None or p0.grad is None or p0.grad.data_ptr() != leaf.grad.data_ptr() + 4 * next(o for q, o, _ in self._flat_views if q is p0):
+                leaf.grad = None                # the per-parameter gradients were cleared or replaced: start afresh
+        return grad
+
+    def _bind_grads(self, leaf):
+        g = leaf.grad
+        self._last_flat_grad = g
+        p0, o0 = next(((p, o) for p, o, _ in self._flat_views if p.requires_grad), (None, 0))
+        if p0 is not None and p0.grad is not None and p0.grad.data_ptr() == g.data_ptr() + 4 * o0:
+            return                              # accumulated in place: the views are still the gradient
+        for p, off, n in self._flat_views:
+            if p.requires_grad:
+                p.grad = g[off:off + n].view(p.shape)
 
     def allreduce_gradients(self, group=None, average: bool = True):
         """Data-parallel training (one process per GPU): sum the gradients of all ranks with ONE all-reduce of the
@@ -243,6 +270,12 @@ class PharmRecDynamicsGVP(nn.Module):
         parameter's .grad to its slice.  SURVEY.md 8(e)."""
         import torch.distributed as dist
         params = [p for p, _, _ in self._flat_views] or [p for p in self.parameters() if p.numel() > 0]
+        flat = getattr(self, "_last_flat_grad", None)
+        if flat is not None and params and params[0].grad is not None and params[0].grad.data_ptr() == flat.data_ptr():
+            dist.all_reduce(flat, group=group)   # the parameters' .grad are views of this vector already
+            if average:
+                flat /= dist.get_world_size(group)
+            return flat
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
         dist.all_reduce(flat, group=group)
         if average:
@@ -282,8 +315,7 @@ class PharmRecDynamicsGVP(nn.Module):
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
         if not need_grad:
             return eng.train_forward(x_t, h_t, timestep, prot_x=prot_x, dropout=p_drop, seed=seed)
-        params = [p for p, _, _ in self._flat_views]
-        return _DynamicsFn.apply(self, eng, x_t, h_t, timestep, prot_x, p_drop, seed, *params)
+        return _DynamicsFn.apply(self, eng, x_t, h_t, timestep, prot_x, p_drop, seed, self.__dict__["_flat_leaf"])
 
 
 class FlatAdam:
@@ -298,8 +330,12 @@ class FlatAdam:
         self.param_groups = [{'lr': lr}]            # what LR schedulers / loggers look at
 
     def zero_grad(self, set_to_none: bool = True):
-        for p in self.dyn.parameters():
+        views = self.dyn._flat_views
+        for p in ([p for p, _, _ in views] if views else self.dyn.parameters()):
             p.grad = None
+        leaf = self.dyn.__dict__.get("_flat_leaf")
+        if leaf is not None:
+            leaf.grad = None
         self.dyn._last_flat_grad = None
 
     def step(self):
@@ -513,7 +549,13 @@ class PharmacophoreDiff(_Base):
         bidx = get_batch_idxs(g)
         bp, br = bidx['pharm'].to(dev), bidx['prot'].to(dev)
         B = g.batch_size
-        ptr_f = g.pharm_ptr.to(dev)
+        # the (host) ptr array on the device, cached on the graph object like the batch indices: a pageable host -> device
+        # copy waits for everything enqueued before it, i.e. for the previous training step
+        ck = g.__dict__.get("_ptrf_cache")
+        if ck is None or ck[0] != (str(dev), g.pharm_ptr.data_ptr(), int(g.pharm_ptr[-1])):
+            ck = ((str(dev), g.pharm_ptr.data_ptr(), int(g.pharm_ptr[-1])), g.pharm_ptr.to(dev))
+            g.__dict__["_ptrf_cache"] = ck
+        ptr_f = ck[1]
 
         def seg_mean(x):
             out = torch.zeros(B, 3, device=dev).index_add_(0, bp, x)
