@@ -271,7 +271,8 @@ class PharmRecDynamicsGVP(nn.Module):
         import torch.distributed as dist
         params = [p for p, _, _ in self._flat_views] or [p for p in self.parameters() if p.numel() > 0]
         flat = getattr(self, "_last_flat_grad", None)
-        if flat is not None and params and params[0].grad is not None and params[0].grad.data_ptr() == flat.data_ptr():
+        off0 = self._flat_views[0][1] if self._flat_views else 0
+        if flat is not None and params and params[0].grad is not None and params[0].grad.data_ptr() == flat.data_ptr() + 4 * off0:
             dist.all_reduce(flat, group=group)   # the parameters' .grad are views of this vector already
             if average:
                 flat /= dist.get_world_size(group)

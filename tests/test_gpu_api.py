@@ -411,3 +411,42 @@ def test_dataset_sampling_driver(tmp_path, world):
     metrics = dict(l.split(": ") for l in (out / "metrics.txt").read_text().splitlines())
     assert 0.0 <= float(metrics["validity"]) <= 1.0
     assert sum(eval((out / "pharm_counts_None.txt").read_text())) == 5 * 12
+
+
+def test_gradient_views_accumulate_clear_and_allreduce_in_place():
+    """The dynamics' parameters reach autograd as ONE flat leaf; every parameter's .grad is a view of the accumulated
+    flat gradient.  Gradient accumulation over two backward passes, clearing parameter by parameter (what
+    torch.optim's zero_grad does) and the single-vector all-reduce (one rank, RCCL) keep the usual semantics."""
+    import torch.distributed as dist
+    z = load("train_grads.npz")
+    m = make_model(int(z["T"]))
+    m.train()
+    b = batch_from(z)
+    g = graph_from(b, z["x0"], z["h0"]).to("cuda")
+    kw = dict(t_int=z["t_int"].long(), eps={'h': z["eps_h"], 'x': z["eps_x"]})
+    params = [p for k, p in m.named_parameters() if k.startswith("dynamics.") and p.numel() > 0]
+
+    def grads():
+        return torch.cat([p.grad.reshape(-1) for p in params]).clone()
+
+    torch.manual_seed(3)
+    m.training_step(g, 0, **kw).backward()
+    g1 = grads()
+    flat = m.dynamics._last_flat_grad
+    assert all(p.grad.data_ptr() >= flat.data_ptr() and p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel() for p in params)
+    torch.manual_seed(3)                                           # same dropout draws: the second pass adds the same gradient
+    m.training_step(g, 0, **kw).backward()
+    torch.testing.assert_close(grads(), 2 * g1, rtol=1e-5, atol=1e-7)
+    for p in m.parameters():                                       # optimizer.zero_grad(set_to_none=True)
+        p.grad = None
+    torch.manual_seed(3)
+    m.training_step(g, 0, **kw).backward()
+    torch.testing.assert_close(grads(), g1, rtol=1e-5, atol=1e-7)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        r = m.dynamics.allreduce_gradients(average=True)
+        assert r.data_ptr() == m.dynamics._last_flat_grad.data_ptr()
+        torch.testing.assert_close(grads(), g1, rtol=1e-5, atol=1e-7)
+    finally:
+        dist.destroy_process_group()
