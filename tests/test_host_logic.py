@@ -64,9 +64,11 @@ def test_schedule_module_matches_reference_tables(T):
     sched = pfa.PredefinedNoiseSchedule('polynomial_2', T, 1e-5)
     assert torch.equal(sched.gamma.detach(), z["gamma_" + tag])
     c = pfa.schedule.step_coefficients(sched.gamma, T)
-    assert torch.equal(c["alpha_t_given_s"], z["a_ts_" + tag])
-    assert torch.equal(c["var_terms"], z["var_" + tag])
-    assert torch.equal(c["sigma"], z["sigma_" + tag])
+    # the gamma table is a float64 numpy pipeline (bit-exact everywhere); the per-step coefficients are fp32 torch
+    # expm1 / softplus / exp, whose vectorised CPU kernels differ by an ulp between instruction sets (the goldens were
+    # recorded on this container's CPU; the GPU box's host gives 1-ulp differences)
+    for k, zk in (("alpha_t_given_s", "a_ts_"), ("var_terms", "var_"), ("sigma", "sigma_")):
+        torch.testing.assert_close(c[k], z[zk + tag], rtol=1e-6, atol=1e-9)
     t = torch.tensor([0.0, 0.5, 1.0])
     assert torch.equal(sched(t), sched.gamma[torch.tensor([0, T // 2, T])])
 

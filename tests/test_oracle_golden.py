@@ -64,9 +64,9 @@ def test_schedule_tables(T, prec):
     gamma = O.gamma_table(T, prec)
     assert torch.equal(gamma, z["gamma_" + tag])          # float64 numpy pipeline -> bit exact
     c = O.step_coefficients(gamma, T)
-    assert torch.equal(c["alpha_t_given_s"], z["a_ts_" + tag])
-    assert torch.equal(c["var_terms"], z["var_" + tag])
-    assert torch.equal(c["sigma"], z["sigma_" + tag])
+    # fp32 torch expm1 / softplus / exp: 1 ulp between the vectorised CPU kernels of different instruction sets
+    for k, zk in (("alpha_t_given_s", "a_ts_"), ("var_terms", "var_"), ("sigma", "sigma_")):
+        torch.testing.assert_close(c[k], z[zk + tag], rtol=1e-6, atol=1e-9)
 
 
 def test_schedule_probe_values():
