@@ -1,124 +1,134 @@
 #!/usr/bin/env python3
-"""Sampling CLI with the flags, directory layout and output files of the reference's generate_pharmacophores.py
-(:29-66, :236-392), on the MI355X library: PDB receptor + SDF reference ligand (or a residue list) -> pocket graph ->
-PharmacophoreDiff.sample_given_receptor -> <output_dir>/<receptor>/pharms.xyz (or per-sample trajectories).
-Receptor parsing needs neither Biopython nor rdkit (pharmacoforge_amd.pocket_io)."""
+"""Pharmacophore sampling for one receptor pocket on the MI355X library.
+
+Command-line contract of the reference's generate_pharmacophores.py (flag names, types and defaults of its :29-46; the
+run-directory convention <run>/config.y[a]ml + <run>/checkpoints/last.ckpt; the output tree
+<output_dir>/<receptor>/{pharms.xyz | pharm_<i>_traj.xyz, pocket.pdb, sample_time.txt, sample_time.pkl,
+reference_files/}), so scripts written against the reference keep working.  Everything behind the flags is this
+repository's: receptor parsing without Biopython / rdkit (pharmacoforge_amd.pocket_io: PDB or mmCIF receptor, SDF
+ligand), PharmacophoreDiff.sample_given_receptor -> pf_sample (the whole reverse process enqueued on the GPU)."""
 import argparse
 import pickle
 import shutil
+import sys
 import time
 from pathlib import Path
 
 import torch
 import yaml
 
-
-def parse_arguments():
-    p = argparse.ArgumentParser()
-    p.add_argument('receptor_file', type=Path, help='PDB file of the receptor')
-    p.add_argument('--ref_ligand_file', type=Path, help='sdf file of ligand used to define the pocket')
-    p.add_argument('--residue_list', nargs="+", type=str, default=[], help="Residues that define the pocket in the form chain ID:residue idx")
-    p.add_argument('--ckpt', type=Path, help='Path to checkpoint file. Must be inside model dir.', default=None)
-    p.add_argument('--model_dir', type=Path, default=None, help='Directory of output from a training run. Will use last.ckpt in this directory.')
-    p.add_argument('--samples_per_pocket', type=int, default=1, help="number of samples generated per pocket")
-    p.add_argument('--pharm_sizes', nargs="+", type=int, default=[], help="number of pharmacophore centers in each sample, must be of length samples per pocket")
-    p.add_argument('--output_dir', type=str, default='generated_pharms/')
-    p.add_argument('--receptor_name', type=str, default=None)
-    p.add_argument('--max_batch_size', type=int, default=128, help='maximum feasible batch size due to memory constraints')
-    p.add_argument('--seed', type=int, default=42, help='random seed as an integer.')
-    p.add_argument('--use_ref_lig_com', action='store_true', help="Initialize each pharmacophore's position at the reference ligand's center of mass")
-    p.add_argument('--visualize_trajectory', action='store_true', help="Visualize trajectories of generated pharmacophores")
-    p.add_argument('--metrics', action='store_true', help='compute metrics on generated pharmacophores')
-    args = p.parse_args()
-    if args.ckpt is not None and args.model_dir is not None:
-        raise ValueError('only model_file or model_dir can be specified but not both')
-    if args.ckpt is None and args.model_dir is None:
-        raise ValueError('one of model_file or model_dir must be specified')
-    if args.pharm_sizes and len(args.pharm_sizes) != args.samples_per_pocket:
-        raise ValueError("If pharm_sizes list is provided, must be of length sample per pocket")
-    if args.ref_ligand_file is None and len(args.residue_list) == 0:
-        raise ValueError('Either ref_ligand or residue_list must be specified')
-    if args.ref_ligand_file is not None and len(args.residue_list) != 0:
-        print("WARNING: Both reference ligand file and residue list specified. Reference ligand will be used to define pocket in this case.")
-    return args
+# (flag, argparse keywords): names / types / defaults are the reference's, the descriptions are ours
+_FLAGS = [
+    ('receptor_file', dict(type=Path, help='receptor structure, .pdb or .cif / .mmcif')),
+    ('--ref_ligand_file', dict(type=Path, help='SDF ligand; residues with an atom within the config\'s pocket_cutoff of it form the pocket')),
+    ('--residue_list', dict(nargs='+', type=str, default=[], help='pocket given explicitly instead: entries CHAIN:RESSEQ, e.g. A:105 A:106')),
+    ('--ckpt', dict(type=Path, default=None, help='checkpoint file at <run>/checkpoints/<name>.ckpt (the config is looked up in <run>)')),
+    ('--model_dir', dict(type=Path, default=None, help='training run directory <run>; its checkpoints/last.ckpt is loaded')),
+    ('--samples_per_pocket', dict(type=int, default=1, help='how many pharmacophores to draw')),
+    ('--pharm_sizes', dict(nargs='+', type=int, default=[], help='centers per pharmacophore, one integer per sample (default: uniform 3..8)')),
+    ('--output_dir', dict(type=str, default='generated_pharms/', help='root of the output tree')),
+    ('--receptor_name', dict(type=str, default=None, help='sub-directory name (default: receptor file stem)')),
+    ('--max_batch_size', dict(type=int, default=128, help='graphs per device batch')),
+    ('--seed', dict(type=int, default=42, help='torch seed of the run')),
+    ('--use_ref_lig_com', dict(action='store_true', help='start the centers at the ligand\'s mean position instead of the pocket\'s')),
+    ('--visualize_trajectory', dict(action='store_true', help='write every denoising frame, one xyz file per sample')),
+    ('--metrics', dict(action='store_true', help='print the validity of the samples against receptor pharmacophore features')),
+]
 
 
-def main():
+def parse_arguments(argv=None):
+    parser = argparse.ArgumentParser(description=__doc__.split('\n\n')[0])
+    for flag, kw in _FLAGS:
+        parser.add_argument(flag, **kw)
+    a = parser.parse_args(argv)
+    problems = []
+    if (a.ckpt is None) == (a.model_dir is None):
+        problems.append('give exactly one of --ckpt and --model_dir')
+    if a.pharm_sizes and len(a.pharm_sizes) != a.samples_per_pocket:
+        problems.append(f'--pharm_sizes lists {len(a.pharm_sizes)} sizes for --samples_per_pocket {a.samples_per_pocket}')
+    if a.ref_ligand_file is None and not a.residue_list:
+        problems.append('the pocket is undefined: pass --ref_ligand_file or --residue_list')
+    if problems:
+        raise ValueError('; '.join(problems))
+    if a.ref_ligand_file is not None and a.residue_list:
+        print('note: --residue_list is ignored because --ref_ligand_file defines the pocket', file=sys.stderr)
+    return a
+
+
+def locate_run(args):
+    """-> (run directory, checkpoint file, parsed config)."""
+    if args.ckpt is not None:
+        run_dir, ckpt = args.ckpt.parent.parent, args.ckpt
+    else:
+        run_dir, ckpt = args.model_dir, args.model_dir / 'checkpoints' / 'last.ckpt'
+    for name in ('config.yaml', 'config.yml'):
+        if (run_dir / name).exists():
+            with open(run_dir / name) as f:
+                return run_dir, ckpt, yaml.load(f, Loader=yaml.FullLoader)
+    raise FileNotFoundError(f'{run_dir} holds neither config.yaml nor config.yml')
+
+
+def load_model(pfa, ckpt, config, device):
+    try:
+        model = pfa.PharmacophoreDiff.load_from_checkpoint(ckpt)
+    except TypeError:              # checkpoints written before ph_type_map became a hyper-parameter
+        model = pfa.PharmacophoreDiff.load_from_checkpoint(ckpt, ph_type_map=config['dataset']['ph_type_map'])
+    return model.to(device).eval()
+
+
+def main(argv=None):
     import pharmacoforge_amd as pfa
     from pharmacoforge_amd.pocket_io import get_prot_atom_ph_type_maps, process_ligand_and_pocket
 
-    args = parse_arguments()
-    output_dir = Path(args.output_dir)
-    output_dir.mkdir(exist_ok=True)
-    if args.ckpt is not None:
-        run_dir, model_file = args.ckpt.parent.parent, args.ckpt
-    else:
-        run_dir, model_file = args.model_dir, args.model_dir / 'checkpoints' / 'last.ckpt'
-    config_file = run_dir / 'config.yaml'
-    if not config_file.exists():
-        config_file = run_dir / 'config.yml'
-        if not config_file.exists():
-            raise FileNotFoundError(f'config file not found in {run_dir}')
-    with open(config_file, 'r') as f:
-        config = yaml.load(f, Loader=yaml.FullLoader)
+    args = parse_arguments(argv)
+    for path, what in ((args.receptor_file, 'receptor'), (args.ref_ligand_file, 'ligand')):
+        if path is not None and not path.exists():
+            raise ValueError(f'{what} file {path} not found')
     if not torch.cuda.is_available():
         raise SystemExit("generate_pharmacophores.py needs an MI355X: the denoising kernels have no CPU fallback")
+    _, ckpt, config = locate_run(args)
     device = torch.device('cuda')
     print(f'{device=}', flush=True)
     torch.manual_seed(args.seed)
-    dataset_config = config['dataset']
-    prot_element_map, ph_type_map = get_prot_atom_ph_type_maps(dataset_config)
-    try:
-        model = pfa.PharmacophoreDiff.load_from_checkpoint(model_file).to(device)
-    except TypeError:
-        model = pfa.PharmacophoreDiff.load_from_checkpoint(model_file, ph_type_map=config['dataset']['ph_type_map']).to(device)
-    model.eval()
+    prot_element_map, _ = get_prot_atom_ph_type_maps(config['dataset'])
+    model = load_model(pfa, ckpt, config, device)
 
-    rec_file, ref_lig_file = args.receptor_file, args.ref_ligand_file
-    if not rec_file.exists():
-        raise ValueError('receptor file does not exist')
-    if ref_lig_file and not ref_lig_file.exists():
-        raise ValueError('ligand file does not exist')
-    rec_name = args.receptor_name or rec_file.name.split(".")[0]
-    pocket_dir = output_dir / f'{rec_name}'
-    pocket_dir.mkdir(exist_ok=True)
-    ref_graph = process_ligand_and_pocket(rec_file, pocket_dir, lig_file=ref_lig_file, residue_list=args.residue_list,
-                                          prot_element_map=prot_element_map, graph_cutoffs=config['graph']['graph_cutoffs'],
-                                          pocket_cutoff=dataset_config['pocket_cutoff'], remove_hydrogen=True).to(device)
-    ref_lig_com = ref_graph.pharm_x0 if args.use_ref_lig_com else None
+    name = args.receptor_name or args.receptor_file.name.split('.')[0]
+    pocket_dir = Path(args.output_dir) / name
+    pocket_dir.mkdir(parents=True, exist_ok=True)
+    pocket = process_ligand_and_pocket(args.receptor_file, pocket_dir, lig_file=args.ref_ligand_file,
+                                       residue_list=args.residue_list, prot_element_map=prot_element_map,
+                                       graph_cutoffs=config['graph']['graph_cutoffs'],
+                                       pocket_cutoff=config['dataset']['pocket_cutoff'], remove_hydrogen=True).to(device)
 
-    start = time.time()
-    sampled_pharms = []
-    while True:
-        batch_size = min(args.samples_per_pocket - len(sampled_pharms), args.max_batch_size)
-        pharm_sizes = args.pharm_sizes or model.pharm_size_dist.sample_uniformly(args.samples_per_pocket)
-        g_batch = pfa.batch(pfa.copy_graph(ref_graph, batch_size, pharm_feats_per_copy=pharm_sizes))
-        init_pharm_com = ref_lig_com.repeat(batch_size, 1) if args.use_ref_lig_com else None
+    t0 = time.time()
+    pharms = []
+    while len(pharms) < args.samples_per_pocket:
+        n = min(args.samples_per_pocket - len(pharms), args.max_batch_size)
+        sizes = args.pharm_sizes or model.pharm_size_dist.sample_uniformly(args.samples_per_pocket)
+        # like the reference (:329-333, utils/unorganized_utils.py:48) every chunk reads the size list from its start
+        copies = pfa.batch(pfa.copy_graph(pocket, n, pharm_feats_per_copy=sizes))
+        com = pocket.pharm_x0.repeat(n, 1) if args.use_ref_lig_com else None
         with torch.no_grad():
-            sampled_pharms.extend(model.sample_given_receptor(g_batch, init_pharm_com=init_pharm_com,
-                                                              visualize_trajectory=args.visualize_trajectory))
-        if len(sampled_pharms) >= args.samples_per_pocket:
-            break
-    pocket_sample_time = time.time() - start
-    with open(pocket_dir / 'sample_time.txt', 'w') as f:
-        f.write(f'{pocket_sample_time:.2f}')
+            pharms += model.sample_given_receptor(copies, init_pharm_com=com, visualize_trajectory=args.visualize_trajectory)
+    elapsed = time.time() - t0
+
+    (pocket_dir / 'sample_time.txt').write_text(f'{elapsed:.2f}')
     with open(pocket_dir / 'sample_time.pkl', 'wb') as f:
-        pickle.dump([pocket_sample_time], f)
-    print(f'Pocket {rec_name} sampling time: {pocket_sample_time:.2f} seconds')
-    print(f'Pocket {rec_name} sampling time per pharmacophore: {pocket_sample_time / len(sampled_pharms):.2f} seconds')
-    ref_files_dir = pocket_dir / 'reference_files'
-    ref_files_dir.mkdir(exist_ok=True)
-    shutil.copy(rec_file, ref_files_dir / rec_file.name)
-    if ref_lig_file is not None:
-        shutil.copy(ref_lig_file, ref_files_dir / ref_lig_file.name)
+        pickle.dump([elapsed], f)
+    print(f'{name}: {len(pharms)} pharmacophores in {elapsed:.2f} s ({elapsed / len(pharms):.3f} s each)')
+    ref_dir = pocket_dir / 'reference_files'
+    ref_dir.mkdir(exist_ok=True)
+    for src in (args.receptor_file, args.ref_ligand_file):
+        if src is not None:
+            shutil.copy(src, ref_dir / src.name)
     if args.visualize_trajectory:
-        for i, ph in enumerate(sampled_pharms):
+        for i, ph in enumerate(pharms):
             ph.traj_to_xyz(pocket_dir / f'pharm_{i}_traj.xyz')
     else:
-        with open(pocket_dir / 'pharms.xyz', 'w') as f:
-            f.write(''.join(ph.to_xyz_file() for ph in sampled_pharms))
+        (pocket_dir / 'pharms.xyz').write_text(''.join(ph.to_xyz_file() for ph in pharms))
     if args.metrics:
-        print(pfa.SampleAnalyzer().analyze(sampled_pharms))
+        print(pfa.SampleAnalyzer().analyze(pharms))
 
 
 if __name__ == "__main__":

@@ -368,11 +368,46 @@ def noise_head(sd, prefix: str, cfg: DynamicsConfig, h, v):
 
 
 def _edges_per_graph(node_idx, ptr):
-    """get_edges_per_batch, utils/unorganized_utils.py:17-23 (count of edges per graph by the
-    graph id of ``node_idx``)."""
+    """get_edges_per_batch, utils/unorganized_utils.py:17-23: ``node_batch_idxs[edge_node_idxs]`` run-length
+    encoded with unique_consecutive and scattered into a [B] vector (a graph that appears in two separate runs
+    keeps the LAST run's count -- plain assignment, :22; with the index rows the reference passes the runs are
+    already grouped by graph)."""
     B = ptr.numel() - 1
     gid = torch.searchsorted(ptr[1:].contiguous(), node_idx, right=True)
-    return torch.bincount(gid, minlength=B)
+    runs, counts = torch.unique_consecutive(gid, return_counts=True)
+    out = torch.zeros(B, dtype=torch.int64)
+    out[runs] = counts
+    return out
+
+
+def dynamic_edge_counts(cfg: DynamicsConfig, batch: PocketBatch, edges):
+    """The per-graph edge counts add_pharm_edges stores on the graph (dynamics_gvp.py:218-225), which gvp.py:506
+    reads back when message_norm == 0.
+
+    ff: by the graph of the edge's SOURCE center (``ff_idxs[0]`` with the pharm batch vector, :219) -- source and
+    target share a graph, so this is the true count.
+    pf: ``get_edges_per_batch(pf_idxs[0], batch_size, prot_batch_idx)`` (:220).  In the radius branch ``pf_idxs[0]``
+    holds PROTEIN indices (row 0 of torch_cluster.radius(x=pharm, y=prot) is the y index, :211): the true count.  In
+    the kNN branch ``pf_idxs[0]`` holds PHARMACOPHORE-center indices (row 0 of knn(x=prot, y=pharm), :202), which
+    the reference nevertheless looks up in the PROTEIN batch vector: center j is booked on the graph that owns
+    protein atom j.  That is what the reference computes, so it is what is reproduced here (center indices are
+    < Nf_tot <= Np_tot in every usable batch; the reference would raise an IndexError otherwise).
+    fp: the same vector as pf (:221).  pp: the static counts of the batched graph."""
+    ff_src = edges["ff"][0]
+    if cfg.pf_k > 0:
+        pf_row0 = edges["pf"][1]          # knn row 0 = pharm (y) index; pf was added as (row1 -> row0), :206
+        if pf_row0.numel() and int(pf_row0.max()) >= int(batch.prot_ptr[-1]):
+            raise IndexError("dynamics_gvp.py:220 indexes the protein batch vector with a pharmacophore index "
+                             "beyond the number of protein atoms")
+    else:
+        pf_row0 = edges["pf"][0]          # radius row 0 = prot (y) index; pf was added as (row0 -> row1), :212
+    pf_cnt = _edges_per_graph(pf_row0, batch.prot_ptr)
+    return {
+        "ff": _edges_per_graph(ff_src, batch.pharm_ptr),
+        "pf": pf_cnt,
+        "fp": pf_cnt,
+        "pp": _edges_per_graph(edges["pp"][1], batch.prot_ptr),
+    }
 
 
 def dynamics_forward(sd, cfg: DynamicsConfig, batch: PocketBatch, prot_x, pharm_x, pharm_h, t,
@@ -394,14 +429,9 @@ def dynamics_forward(sd, cfg: DynamicsConfig, batch: PocketBatch, prot_x, pharm_
     edges["pp"] = (batch.pp_src, batch.pp_dst)
     edge_counts = None
     if cfg.message_norm == 0 and cfg.message_norm != "mean":
-        # dynamics_gvp.py:219-221 (including the quirk at :220 for the kNN branch is NOT
-        # reproduced: counts are by the true graph of the edge)
-        edge_counts = {
-            "ff": _edges_per_graph(edges["ff"][1], batch.pharm_ptr),
-            "pf": _edges_per_graph(edges["pf"][1], batch.pharm_ptr),
-            "fp": _edges_per_graph(edges["fp"][1], batch.prot_ptr),
-            "pp": _edges_per_graph(edges["pp"][1], batch.prot_ptr),
-        }
+        # dynamics_gvp.py:218-225, including the kNN branch's lookup of center indices in the protein batch
+        # vector (:220), reproduced as the reference computes it
+        edge_counts = dynamic_edge_counts(cfg, batch, edges)
     for i in range(cfg.n_convs):
         node = conv_layer(sd, f"{prefix}noise_predictor.conv_layers.{i}.", cfg, node, edges, batch,
                           edge_counts, None if dropout is None else dropout[i])
@@ -569,6 +599,58 @@ def sample_given_receptor(sd, cfg, batch: PocketBatch, n_timesteps: int, precisi
     return x_0, h_0
 
 
+def copy_pocket(pocket: PocketBatch, n_centers: int) -> PocketBatch:
+    """copy_graph with pharm_feats_per_copy (utils/unorganized_utils.py:28-81) for one copy: same protein nodes and
+    pp edges, ``n_centers`` pharmacophore nodes (their features are zeros and are overwritten by the sampler)."""
+    assert pocket.batch_size == 1
+    return PocketBatch(pocket.prot_x.clone(), pocket.prot_h.clone(), pocket.prot_ptr.clone(),
+                       torch.tensor([0, int(n_centers)], dtype=torch.int64), pocket.pp_src.clone(), pocket.pp_dst.clone())
+
+
+def concat_pockets(pockets: List[PocketBatch]) -> PocketBatch:
+    """dgl.batch (pharmacodiff.py:554): node ids and edges concatenated in list order."""
+    po, fo, srcs, dsts, pp, fp = 0, 0, [], [], [0], [0]
+    for b in pockets:
+        srcs.append(b.pp_src + po)
+        dsts.append(b.pp_dst + po)
+        for g in range(b.batch_size):
+            pp.append(po + int(b.prot_ptr[g + 1]))
+            fp.append(fo + int(b.pharm_ptr[g + 1]))
+        po += int(b.prot_ptr[-1])
+        fo += int(b.pharm_ptr[-1])
+    return PocketBatch(torch.cat([b.prot_x for b in pockets]), torch.cat([b.prot_h for b in pockets]),
+                       torch.tensor(pp, dtype=torch.int64), torch.tensor(fp, dtype=torch.int64),
+                       torch.cat(srcs), torch.cat(dsts))
+
+
+def sample(sd, cfg, ref_pockets: List[PocketBatch], n_pharms: List[List[int]], max_batch_size: int, n_timesteps: int,
+           precision: float, noises: List[torch.Tensor], init_pharm_com: Optional[torch.Tensor] = None):
+    """PharmacophoreDiff.sample, pharmacodiff.py:516-578: one copy of the pocket per requested pharmacophore
+    (:541-545), flattened in pocket order, sampled in batches of ``max_batch_size`` (:551-568) with the pocket's
+    row of ``init_pharm_com`` (:556; default: the receptor COMs, :531-535), regrouped per pocket (:570-576).
+    ``noises[i]`` holds the draws of batch i.  Returns [[(x_0, h_0) per pharmacophore] per pocket]."""
+    if init_pharm_com is None:
+        init_pharm_com = torch.stack([p.prot_x.mean(dim=0) for p in ref_pockets], dim=0)
+    graphs, ref_idx = [], []
+    for r, (pocket, sizes) in enumerate(zip(ref_pockets, n_pharms)):
+        graphs.extend(copy_pocket(pocket, n) for n in sizes)
+        ref_idx.extend([r] * len(sizes))
+    flat = []
+    for bi, start in enumerate(range(0, len(graphs), max_batch_size)):
+        chunk = graphs[start:start + max_batch_size]
+        batch = concat_pockets(chunk)
+        coms = init_pharm_com[ref_idx[start:start + max_batch_size]]
+        x0, h0 = sample_given_receptor(sd, cfg, batch, n_timesteps, precision, noises[bi], init_pharm_com=coms)
+        for g in range(batch.batch_size):
+            a, b = int(batch.pharm_ptr[g]), int(batch.pharm_ptr[g + 1])
+            flat.append((x0[a:b], h0[a:b]))
+    out, end = [], 0
+    for sizes in n_pharms:
+        start, end = end, end + len(sizes)
+        out.append(flat[start:end])
+    return out
+
+
 def training_forward(sd, cfg, batch: PocketBatch, pharm_x0, pharm_h0, n_timesteps: int,
                      precision: float, t_int: torch.Tensor, eps_h: torch.Tensor, eps_x: torch.Tensor,
                      phase: str = "train", pharm_feat_norm_constant: float = 1.0,
@@ -669,14 +751,16 @@ def synthetic_pocket(seed: int, n_prot: int, rec_nf: int = 11):
     return x, h
 
 
-def synthetic_batch(seeds, n_prot: int, n_pharm, cfg: DynamicsConfig) -> PocketBatch:
-    """B graphs; ``n_pharm`` is an int or a per-graph list (ragged)."""
+def synthetic_batch(seeds, n_prot, n_pharm, cfg: DynamicsConfig) -> PocketBatch:
+    """B graphs; ``n_prot`` / ``n_pharm`` are ints or per-graph lists (ragged)."""
     seeds = list(seeds)
     if isinstance(n_pharm, int):
         n_pharm = [n_pharm] * len(seeds)
+    if isinstance(n_prot, int):
+        n_prot = [n_prot] * len(seeds)
     xs, hs = [], []
-    for sd in seeds:
-        x, h = synthetic_pocket(sd, n_prot, cfg.rec_nf)
+    for sd, npg in zip(seeds, n_prot):
+        x, h = synthetic_pocket(sd, npg, cfg.rec_nf)
         xs.append(x)
         hs.append(h)
     prot_ptr = torch.tensor([0] + list(np.cumsum([x.shape[0] for x in xs])), dtype=torch.int64)

@@ -88,6 +88,20 @@ def compute_complementarity(pharm_types, pharm_pos, prot_ph_types, prot_ph_pos, 
     return count / max(len(pharm_types), 1)          # (the reference divides by an undefined name here, metrics.py:85)
 
 
+def _allreduce_sum(counts: torch.Tensor, process_group, device=None) -> torch.Tensor:
+    """Sum a small host vector over the ranks.  The buffer lives where the group's backend needs it: RCCL ("nccl")
+    reduces device memory only, so the buffer goes to ``device`` (default: this process's current GPU); gloo reduces the
+    host tensor directly."""
+    import torch.distributed as dist
+    if dist.get_backend(process_group) == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        buf = counts.to(dev)
+    else:
+        buf = counts.clone()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
+    return buf.cpu()
+
+
 class SampleAnalyzer:
     def analyze(self, sample: List[SampledPharmacophore], process_group=None, device=None):
         """metrics.py:9-35.  With ``process_group`` the numerator / denominator are all-reduced (sum)
@@ -104,10 +118,7 @@ class SampleAnalyzer:
             den += ph.n_ph_centers
         counts = torch.tensor([float(num), float(den)], dtype=torch.float64)
         if process_group is not None:
-            import torch.distributed as dist
-            buf = counts.to(device) if device is not None and dist.get_backend(process_group) == "nccl" else counts
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
-            counts = buf.cpu()
+            counts = _allreduce_sum(counts, process_group, device)
         return {'validity': float(counts[0] / counts[1]) if counts[1] > 0 else 0.0}
 
     def pharm_feat_freq(self, sample: List[SampledPharmacophore], process_group=None, device=None):
@@ -117,8 +128,5 @@ class SampleAnalyzer:
             for val in ph.ph_feats_idxs:
                 counts[int(val)] += 1
         if process_group is not None:
-            import torch.distributed as dist
-            buf = counts.to(device) if device is not None and dist.get_backend(process_group) == "nccl" else counts
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
-            counts = buf.cpu()
+            counts = _allreduce_sum(counts, process_group, device)
         return counts

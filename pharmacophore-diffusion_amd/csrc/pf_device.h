@@ -263,6 +263,9 @@ struct BuildParams {
     float r2_ff, r2_pf;
     float* gnorm;          // [2][B]
     const int* pp_cnt;     // [B] static pp edges per graph
+    const int* pfq_cnt;    // [B] or NULL: the pf / fp edge counts the REFERENCE books per graph when pf edges are kNN
+                           // (dynamics_gvp.py:220 looks center indices up in the protein batch vector); used instead of
+                           // the true counts by the per-graph normalisers
     int norm_mode;
 };
 

@@ -132,6 +132,7 @@ struct pf_handle {
     float *d_prot_x0 = nullptr, *d_prot_h0 = nullptr, *d_pharm_h = nullptr, *d_t = nullptr, *d_h[2] = {nullptr, nullptr},
           *d_v[2] = {nullptr, nullptr}, *d_msg_s = nullptr, *d_msg_v = nullptr, *d_eps_h = nullptr, *d_eps_x = nullptr,
           *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr, *d_pre = nullptr;
+    int* d_pfq_cnt = nullptr;      // [B] reference-booked pf edge counts (message_norm 0 with kNN pf edges), else NULL
     bool sampling = false;
     int max_np = 0;                         // largest pocket of the batch
     bool edges_built = false;               // the dynamic edges of the current coordinates exist (built by k_step_build)
@@ -639,7 +640,7 @@ static BuildParams build_params(pf_handle* h) {
     bp.in_start = h->d_in_start; bp.in_cnt = h->d_in_cnt; bp.N = h->N;
     bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
     bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
-    bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
+    bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.pfq_cnt = h->d_pfq_cnt; bp.norm_mode = c.message_norm_mode;
     const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;
     bp.act_ids = prune_layer >= 0 ? h->d_act_ids : nullptr; bp.reg_act = h->d_reg_act;
     bp.eorig = h->d_eorig;
@@ -1271,6 +1272,22 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     }
     for (int i = 0; i < Np; ++i) deg[i + 1] += deg[i];
     std::vector<int> pp_cnt(B, 0);
+    // message_norm == 0 with kNN pf edges: the reference derives the per-graph pf / fp edge counts by looking the
+    // pharmacophore-CENTER index of every edge up in the PROTEIN batch vector (dynamics_gvp.py:220), i.e. the min(k, Np_g)
+    // edges of center j are booked on the graph that owns protein atom j.  gvp.py:506 normalises with those counts, so
+    // they are reproduced (a pure function of the ptr arrays); the reference raises an IndexError when j >= Np_tot.
+    std::vector<int> pfq;
+    if (c.message_norm_mode == PF_NORM_GRAPH && c.pf_k > 0) {
+        pfq.assign(B, 0);
+        for (int g = 0; g < B; ++g) {
+            const int kg = std::min(c.pf_k, prot_ptr[g + 1] - prot_ptr[g]);
+            for (int j = pharm_ptr[g]; j < pharm_ptr[g + 1] && kg > 0; ++j) {
+                if (j >= Np) PF_FAIL(h, PF_ERR_ARG, "message_norm 0 with kNN pf edges: center index %d >= %d protein atoms "
+                                     "(the reference indexes the protein batch vector with it, dynamics_gvp.py:220)", j, Np);
+                pfq[gid[j]] += kg;
+            }
+        }
+    }
     // capacity of dynamic regions: ff, pf, fp and "pa" = compact copy of the pp edges into the active atoms
     h->h_reg.assign((size_t)4 * B, 0);
     h->h_cap.assign((size_t)4 * B, 0);
@@ -1366,6 +1383,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     need((size_t)std::max(Np, 1) * PF_S * 4);
     need(Ecap * 4); need((size_t)std::max(Np, 1) * 4); need(256); need((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4);
     need((size_t)B * c.rec_nf * PF_S * 4);
+    need((size_t)B * 4);
     // launches of the previous batch may still read the workspace (hipFree used to wait for them)
     PF_HIP(h, hipDeviceSynchronize());
     if (h->ws_capacity < bytes + 4096) {
@@ -1393,6 +1411,8 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     h->d_eorig = carve<int>(cur, Ecap); h->d_ptype = carve<int>(cur, std::max(Np, 1)); h->d_l0flag = carve<int>(cur, 64);
     h->d_zs = carve<float>(cur, (size_t)std::max<int64_t>(n_pp, 1) * PF_S);
     h->d_ptab_pg = carve<float>(cur, (size_t)B * c.rec_nf * PF_S);
+    h->d_pfq_cnt = pfq.empty() ? nullptr : carve<int>(cur, B);
+    if (h->d_pfq_cnt) PF_HIP(h, hipMemcpy(h->d_pfq_cnt, pfq.data(), (size_t)B * 4, hipMemcpyHostToDevice));
     // ---- uploads (synchronous: these are small tables; pageable host memory)
     PF_HIP(h, hipMemcpy(h->d_prot_ptr, prot_ptr, (B + 1) * 4, hipMemcpyHostToDevice));
     PF_HIP(h, hipMemcpy(h->d_pharm_ptr, pharm_ptr, (B + 1) * 4, hipMemcpyHostToDevice));
@@ -1649,7 +1669,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     bp.reg = h->d_reg; bp.dyn_cnt = h->d_dyn_cnt; bp.esrc = h->d_esrc; bp.edst = h->d_edst;
     bp.in_start = h->d_in_start; bp.in_cnt = h->d_in_cnt; bp.N = h->N; bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
     bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
-    bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.norm_mode = c.message_norm_mode;
+    bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.pfq_cnt = h->d_pfq_cnt; bp.norm_mode = c.message_norm_mode;
     bp.act_ids = nullptr; bp.reg_act = h->d_reg_act;
     pfk_build_edges(&bp, s);
     EdgeParams e{};

@@ -1561,7 +1561,8 @@ __device__ __forceinline__ void build_body(const BuildParams& p, const int g) {
     __syncthreads();
     BSTAMP(11);                                       // protein side emitted
     if (tid == 0 && p.norm_mode == 2) {
-        const int cff = p.dyn_cnt[0 * p.B + g], cpf = p.dyn_cnt[1 * p.B + g], cfp = p.dyn_cnt[2 * p.B + g];
+        const int cff = p.dyn_cnt[0 * p.B + g];
+        const int cpf = p.pfq_cnt ? p.pfq_cnt[g] : p.dyn_cnt[1 * p.B + g], cfp = p.pfq_cnt ? p.pfq_cnt[g] : p.dyn_cnt[2 * p.B + g];
         p.gnorm[1 * p.B + g] = (float)(cff + cpf) / (float)Nf + 1.0f;
         p.gnorm[0 * p.B + g] = (float)(cfp + p.pp_cnt[g]) / (float)Np + 1.0f;
     }
@@ -2007,8 +2008,9 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
             p.dyn_cnt[4 * p.B + g] = (int)((all >> 16) & 0xfffu);
         }
         if (tid == NT - 64 && p.norm_mode == 2) {     // per-graph normalisers for message_norm == 0 (gvp.py:504-507)
-            p.gnorm[1 * p.B + g] = (float)(ff_total + Nf * kk) / (float)Nf + 1.0f;
-            p.gnorm[0 * p.B + g] = (float)(Nf * kk + p.pp_cnt[g]) / (float)Np + 1.0f;
+            const int cpf = p.pfq_cnt ? p.pfq_cnt[g] : Nf * kk;
+            p.gnorm[1 * p.B + g] = (float)(ff_total + cpf) / (float)Nf + 1.0f;
+            p.gnorm[0 * p.B + g] = (float)(cpf + p.pp_cnt[g]) / (float)Np + 1.0f;
         }
     }
     BSTAMP(11);

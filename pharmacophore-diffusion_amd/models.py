@@ -186,6 +186,7 @@ class PharmRecDynamicsGVP(nn.Module):
         self._engine: Optional[PfEngine] = None
         self._weights_stamp = None
         self._batch_key = None
+        self._bound_static = None                       # strong references to the tensors behind _batch_key
         self._flat: Optional[torch.Tensor] = None       # all parameters as one device vector (engine layout)
         self._flat_views = []                           # [(parameter, offset, numel)] in that layout
         self._fwd_token = 0
@@ -269,16 +270,24 @@ class PharmRecDynamicsGVP(nn.Module):
         flat gradient vector (3.1 MB at dev.yml; RCCL when the tensors are on the GPU), then re-bind every
         parameter's .grad to its slice.  SURVEY.md 8(e)."""
         import torch.distributed as dist
+
+        def reduce_(t):
+            if t.is_cuda and dist.get_backend(group) != "nccl":      # gloo dry runs (ranks sharing a card): via the host
+                c = t.cpu()
+                dist.all_reduce(c, group=group)
+                t.copy_(c)
+            else:
+                dist.all_reduce(t, group=group)
         params = [p for p, _, _ in self._flat_views] or [p for p in self.parameters() if p.numel() > 0]
         flat = getattr(self, "_last_flat_grad", None)
         off0 = self._flat_views[0][1] if self._flat_views else 0
         if flat is not None and params and params[0].grad is not None and params[0].grad.data_ptr() == flat.data_ptr() + 4 * off0:
-            dist.all_reduce(flat, group=group)   # the parameters' .grad are views of this vector already
+            reduce_(flat)                        # the parameters' .grad are views of this vector already
             if average:
                 flat /= dist.get_world_size(group)
             return flat
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-        dist.all_reduce(flat, group=group)
+        reduce_(flat)
         if average:
             flat /= dist.get_world_size(group)
         off = 0
@@ -289,12 +298,20 @@ class PharmRecDynamicsGVP(nn.Module):
         return flat
 
     def bind_graph(self, g: PocketGraph, prot_x: Optional[torch.Tensor] = None) -> PfEngine:
-        """Upload the static part of a batch (pocket atoms, pp edges, graph boundaries) once."""
+        """Upload the static part of a batch (pocket atoms, pp edges, graph boundaries) once.
+
+        The upload is skipped only when the very same tensors are bound again: the key holds the storage address and
+        version counter of every static tensor plus the ptr arrays' contents, and the module keeps a strong reference
+        to those tensors while they are bound -- so neither CPython nor the caching allocator can hand their addresses
+        to another batch (a temporary such as ``training_step(g.to(dev))`` is kept alive until the next bind)."""
         eng = self.engine()
-        key = (id(g), g.prot_x.data_ptr(), int(g.prot_ptr[-1]), int(g.pharm_ptr[-1]), g.batch_size, int(g.pp_src.numel()))
+        static = (g.prot_x if prot_x is None else prot_x, g.prot_h, g.pp_src, g.pp_dst)
+        key = (tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in static),
+               tuple(g.prot_ptr.tolist()), tuple(g.pharm_ptr.tolist()))
         if key != self._batch_key:
-            eng.set_batch(g.prot_x if prot_x is None else prot_x, g.prot_h, g.prot_ptr, g.pharm_ptr, g.pp_src, g.pp_dst)
+            eng.set_batch(static[0], g.prot_h, g.prot_ptr, g.pharm_ptr, g.pp_src, g.pp_dst)
             self._batch_key = key
+            self._bound_static = static
         return eng
 
     def forward(self, g, timestep: torch.Tensor, batch_idxs: Dict[str, torch.Tensor] = None):
@@ -338,6 +355,36 @@ class FlatAdam:
         if leaf is not None:
             leaf.grad = None
         self.dyn._last_flat_grad = None
+
+    # -- state: what torch.optim.Adam.state_dict() carries, on the flat vector (checkpoint / resume, rank-0 broadcast) --
+    def ensure_state(self, t: int = None, lr: float = None):
+        self.dyn.engine()
+        if self.exp_avg is None:
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.dyn._flat), torch.zeros_like(self.dyn._flat)
+        if t is not None:
+            self.t = int(t)
+        if lr is not None:
+            self.param_groups[0]['lr'] = float(lr)
+
+    def state_dict_meta(self):
+        return self.t, self.param_groups[0]['lr']
+
+    def state_dict(self):
+        self.ensure_state()
+        return {'state': {'step': self.t, 'exp_avg': self.exp_avg.detach().cpu(), 'exp_avg_sq': self.exp_avg_sq.detach().cpu()},
+                'param_groups': [{'lr': self.param_groups[0]['lr'], 'betas': self.betas, 'eps': self.eps,
+                                  'weight_decay': self.weight_decay}],
+                'layout': 'flat vector in pf_param_layout order'}
+
+    def load_state_dict(self, sd):
+        st, pg = sd['state'], sd['param_groups'][0]
+        self.ensure_state(st['step'], pg['lr'])
+        if st['exp_avg'].numel() != self.exp_avg.numel():
+            raise ValueError("FlatAdam.load_state_dict: moment vectors do not match this model's parameter count")
+        self.exp_avg.copy_(st['exp_avg'])
+        self.exp_avg_sq.copy_(st['exp_avg_sq'])
+        self.betas, self.eps = tuple(pg.get('betas', self.betas)), pg.get('eps', self.eps)
+        self.weight_decay = pg.get('weight_decay', self.weight_decay)
 
     def step(self):
         dyn = self.dyn
@@ -425,9 +472,10 @@ class PharmacophoreDiff(_Base):
         def log_dict(self, *a, **k):
             pass
 
-    def save_checkpoint(self, path):
-        """Write a file ``load_from_checkpoint`` (ours or Lightning's) can read."""
-        torch.save({"state_dict": self.state_dict(), "hyper_parameters": self._hparams_dict}, str(path))
+    def save_checkpoint(self, path, **extra):
+        """Write a file ``load_from_checkpoint`` (ours or Lightning's) can read.  ``extra``: further top-level entries in
+        Lightning's checkpoint vocabulary ('epoch', 'global_step', 'optimizer_states', 'lr_schedulers')."""
+        torch.save({"state_dict": self.state_dict(), "hyper_parameters": self._hparams_dict, **extra}, str(path))
 
     # -- small algebra (pharmacodiff.py:80-86, 140-160) ----------------------------------------
     def sigma(self, gamma):
@@ -500,10 +548,20 @@ class PharmacophoreDiff(_Base):
 
     def sample(self, ref_graphs: List[PocketGraph], n_pharms: List[List[int]], max_batch_size: int = 32,
                init_pharm_com: torch.Tensor = None, visualize_trajectory: bool = False,
-               rank: int = 0, world_size: int = 1) -> List[List[SampledPharmacophore]]:
-        """pharmacodiff.py:516-578.  With world_size > 1 the flattened (pocket, sample) graphs are dealt
-        round-robin over the ranks (independent units: no data-path collective); each rank returns only
-        its own samples, still grouped per pocket (empty lists for pockets it did not touch)."""
+               rank: int = 0, world_size: int = 1, noise=None) -> List[List[SampledPharmacophore]]:
+        """pharmacodiff.py:516-578: one pocket copy per requested pharmacophore, flattened in pocket order and cut into
+        batches of ``max_batch_size`` in list order.
+
+        With ``world_size`` > 1 whole BATCHES are dealt over the ranks (greedy by protein-protein edge count,
+        sharding.shard_by_work; no data-path collective): a batch holds the same graphs, in the same order, whatever the
+        number of GPUs, so every sample is bitwise the one a single GPU produces.  Each rank returns only its own
+        samples, still grouped per pocket (shorter or empty lists for the others).
+
+        ``noise``: None -- batch i draws its [T+1, Nf_i, 3+nf] Gaussians from a device generator seeded with
+        (one draw from torch's global CPU generator) + i, i.e. reproducible under torch.manual_seed and independent of
+        rank / world_size when the ranks share the seed; or a list with one such tensor per batch (replaying a
+        reference run: tests/golden/sample_multi.npz)."""
+        from .sharding import shard_by_work
         ref_graphs = [as_pocket_graph(g) for g in ref_graphs]
         n_receptors = len(ref_graphs)
         if init_pharm_com is None:
@@ -513,7 +571,15 @@ class PharmacophoreDiff(_Base):
             n_rec = n_pharms[rec_idx]
             graphs.extend(copy_graph(ref_graph, n_copies=len(n_rec), pharm_feats_per_copy=torch.tensor(n_rec)))
             graph_ref_idx.extend([rec_idx] * len(n_rec))
-        mine = list(range(rank, len(graphs), world_size))
+        batches = [list(range(s0, min(s0 + max_batch_size, len(graphs)))) for s0 in range(0, len(graphs), max_batch_size)]
+        if world_size > 1:
+            epp = [int(g.pp_src.numel()) for g in ref_graphs]
+            work = [sum(epp[graph_ref_idx[i]] + 1 for i in idx) for idx in batches]
+            mine = shard_by_work(work, world_size)[rank]
+        else:
+            mine = list(range(len(batches)))
+        T, nf = self.n_timesteps, self.n_pharm_feats
+        base_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else 0
         sampled = {}
         # Two-stage pipeline over the batches: the host work of a batch (collating the next one, splitting the previous
         # one's results into SampledPharmacophores) runs while the device works on another batch; only the upload of a
@@ -523,14 +589,19 @@ class PharmacophoreDiff(_Base):
         def finish(done):
             for i, p in zip(done[0], self._sample_finish(done[1])):
                 sampled[i] = p
-        for start in range(0, len(mine), max_batch_size):
-            idx = mine[start:start + max_batch_size]
+        for bi in mine:
+            idx = batches[bi]
             batch_g = batch_graphs([graphs[i] for i in idx])
             init_coms = init_pharm_com[[graph_ref_idx[i] for i in idx]].to(self.device)
+            if noise is None:
+                gen = torch.Generator(device=self.device).manual_seed(base_seed + bi)
+                nz = torch.randn(T + 1, batch_g.num_nodes("pharm"), 3 + nf, device=self.device, generator=gen)
+            else:
+                nz = noise[bi]
             done = None
             if pending is not None:
                 done = (pending[0], self._sample_fetch(pending[1]))     # waits for the device: the workspace is free again
-            pending = (idx, self._sample_enqueue(batch_g, init_coms, visualize_trajectory))
+            pending = (idx, self._sample_enqueue(batch_g, init_coms, visualize_trajectory, nz))
             if done is not None:
                 finish(done)                            # while the device runs the batch just enqueued
         if pending is not None:
@@ -617,21 +688,73 @@ class PharmacophoreDiff(_Base):
                 'lr_scheduler': {"scheduler": scheduler, "monitor": cfg.get('monitor', 'val total loss'),
                                  "interval": cfg.get('interval', 'step'), "frequency": cfg.get('frequency', 1)}}
 
+    # -- trainer context: Lightning's when attached, else a two-attribute stand-in (attach_trainer) -----------------
+    def attach_trainer(self, datamodule, train_dataloader=None, current_epoch: int = 0, optimizer=None):
+        """For Lightning-free drivers (train.py here): gives training_step what it reads from ``self.trainer`` in the
+        reference -- ``trainer.datamodule.val_dataset`` (pharmacodiff.py:323), ``len(trainer.train_dataloader)``
+        (:245) -- plus ``current_epoch`` and the optimiser whose learning rate is logged (:287-290)."""
+        from types import SimpleNamespace
+        self.__dict__["_pf_trainer"] = SimpleNamespace(datamodule=datamodule, train_dataloader=train_dataloader,
+                                                       current_epoch=current_epoch, optimizer=optimizer)
+
+    def _trainer_ctx(self):
+        tr = self.__dict__.get("_pf_trainer")
+        if tr is not None:
+            return tr
+        if pl is not None:
+            try:
+                tr = self.trainer
+                from types import SimpleNamespace
+                opt = None
+                try:
+                    opt = self.optimizers()
+                except Exception:
+                    pass
+                return SimpleNamespace(datamodule=tr.datamodule, train_dataloader=tr.train_dataloader,
+                                       current_epoch=self.current_epoch, optimizer=opt)
+            except Exception:
+                return None
+        return None
+
+    def num_training_batches(self):
+        return len(self._trainer_ctx().train_dataloader)                        # pharmacodiff.py:244-245
+
     def training_step(self, batch, batch_idx, t_int: torch.Tensor = None, eps: Dict[str, torch.Tensor] = None):
         """pharmacodiff.py:265-296: total loss = pos loss + feat loss (the caller -- Lightning or a plain loop --
-        runs .backward() and the optimiser step).  Periodic sample_and_analyze needs a trainer's datamodule and is
-        left to the caller (sample_and_analyze_graphs)."""
+        runs .backward() and the optimiser step).  With a trainer context (Lightning's, or attach_trainer) the
+        fractional epoch is tracked and, every ``sample_interval`` epochs, sample_and_analyze runs inside the step
+        and its metrics join the logged ones (:281-284); without one (a bare loop over tensors) that part is skipped."""
         phase = 'train'
         loss_dict, metrics_dict = self.forward(batch, phase=phase, t_int=t_int, eps=eps)
         loss_dict[phase + ' total loss'] = torch.sum(torch.stack(list(loss_dict.values()), dim=0))
         metrics_dict[phase + ' total error'] = metrics_dict[phase + ' position error'] + 1 - metrics_dict[phase + ' accuracy']
         metrics_dict[phase + ' weighted total error'] = (metrics_dict[phase + ' weighted position error'] + 1
                                                          - metrics_dict[phase + ' weighted accuracy'])
+        tr = self._trainer_ctx()
+        if tr is not None and tr.train_dataloader is not None:
+            epoch_exact = tr.current_epoch + batch_idx / max(len(tr.train_dataloader), 1)       # :270
+            if epoch_exact - self.last_sample_marker >= self.sample_interval and tr.datamodule is not None:   # :281
+                metrics_dict.update(self.sample_and_analyze())
+                self.last_sample_marker = epoch_exact
+            if tr.optimizer is not None:
+                metrics_dict['lr'] = tr.optimizer.param_groups[0]['lr']                          # :287-290
+            loss_dict['epoch_exact'] = epoch_exact
+            self.last_epoch_exact = epoch_exact
         bs = as_pocket_graph(batch).batch_size
         self.log_dict(loss_dict, on_step=True, on_epoch=True, prog_bar=True, logger=True, batch_size=bs)
         self.log_dict(metrics_dict, on_step=True, on_epoch=True, prog_bar=True, logger=True, batch_size=bs)
-        self.last_metrics = {k: v.detach() for k, v in {**loss_dict, **metrics_dict}.items()}
+        self.last_metrics = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in {**loss_dict, **metrics_dict}.items()}
         return loss_dict[phase + ' total loss']
+
+    @torch.no_grad()
+    def sample_and_analyze(self, rank: int = 0, world_size: int = 1, process_group=None):
+        """pharmacodiff.py:320-357: ``n_pockets_to_sample`` random validation pockets (with replacement, like the
+        reference's randint), ``pharms_per_pocket`` pharmacophores each with the reference pharmacophore's size and
+        center of mass, batches of 64, validity of the lot."""
+        val_dataset = self._trainer_ctx().datamodule.val_dataset
+        pocket_idxs = torch.randint(low=0, high=len(val_dataset), size=(self.n_pockets_to_sample,))
+        pockets = [val_dataset[int(i)] for i in pocket_idxs]
+        return self.sample_and_analyze_graphs(pockets, rank=rank, world_size=world_size, process_group=process_group)
 
     def validation_step(self, batch, batch_idx):
         phase = 'val'

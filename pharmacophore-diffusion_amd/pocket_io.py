@@ -11,7 +11,10 @@ Mirrors generate_pharmacophores.py:68-220 of the reference:
 
 The PDB reader follows the fixed-column PDB format (ATOM / HETATM records of the first MODEL); like Bio.PDB it keeps, for
 an atom with alternate locations, the location with the highest occupancy, and takes the element from columns 77-78
-(falling back to the atom name).  mmCIF is not supported (the reference accepts '.mmcif' through Bio.PDB.MMCIFParser).
+(falling back to the atom name).  mmCIF receptors ('.mmcif' as in the reference, generate_pharmacophores.py:11,131-132;
+'.cif' too) are read from the ``_atom_site`` loop with the column choices of Bio.PDB.MMCIFParser: author chain and
+residue numbers (auth_asym_id / auth_seq_id), label_atom_id / label_comp_id names, pdbx_PDB_ins_code, label_alt_id,
+type_symbol as the element, first pdbx_PDB_model_num only; their pocket.pdb records are formatted here.
 """
 from __future__ import annotations
 
@@ -101,6 +104,126 @@ def read_pdb(path) -> List[Residue]:
             elif altloc != " " and occ > prev.occupancy:        # disordered atom: keep the most occupied location
                 res.atoms[res.atoms.index(prev)] = atom
     return residues
+
+
+def _cif_tokens(line: str) -> List[str]:
+    """Whitespace-separated mmCIF values of one line; a value may be wrapped in single or double quotes (the closing
+    quote is the one followed by whitespace or the end of the line, so O5' and "N" both survive)."""
+    out, i, n = [], 0, len(line)
+    while i < n:
+        c = line[i]
+        if c.isspace():
+            i += 1
+        elif c in "'\"" :
+            j = i + 1
+            while j < n and not (line[j] == c and (j + 1 == n or line[j + 1].isspace())):
+                j += 1
+            out.append(line[i + 1:j])
+            i = j + 1
+        elif c == "#":
+            break
+        else:
+            j = i
+            while j < n and not line[j].isspace():
+                j += 1
+            out.append(line[i:j])
+            i = j
+    return out
+
+
+def _pdb_record(hetero: bool, serial: int, name: str, altloc: str, resname: str, chain: str, resseq: int, icode: str,
+                xyz, occ: float, bfac: float, elem: str) -> str:
+    """One fixed-column ATOM / HETATM record (atom names of fewer than four characters of a one-letter element start
+    in column 14, as in wwPDB files)."""
+    nm = name if len(name) >= 4 or len(elem) >= 2 else " " + name
+    return (f"{'HETATM' if hetero else 'ATOM  '}{serial % 100000:>5} {nm:<4}{altloc:1}{resname:>3} {chain[:1]:1}{resseq:>4}{icode:1}   "
+            f"{xyz[0]:8.3f}{xyz[1]:8.3f}{xyz[2]:8.3f}{occ:6.2f}{bfac:6.2f}          {elem:>2}")
+
+
+def read_mmcif(path) -> List[Residue]:
+    """Residues of the first model of an mmCIF file, in file order (the ``_atom_site`` loop; semantics as read_pdb)."""
+    cols: List[str] = []
+    rows: List[List[str]] = []
+    in_header = in_rows = False
+    with open(path, "r") as f:
+        for raw in f:
+            line = raw.rstrip("\n")
+            st = line.strip()
+            if not in_header and not in_rows:
+                if st == "loop_":
+                    cols, in_header = [], True
+                continue
+            if in_header:
+                if st.startswith("_atom_site."):
+                    cols.append(st.split()[0][len("_atom_site."):])
+                    continue
+                if st.startswith("_") or not cols:          # another category's loop
+                    in_header = False
+                    cols = []
+                    if st == "loop_":
+                        in_header = True
+                    continue
+                in_header, in_rows = False, True            # first data row of the _atom_site loop
+            if in_rows:
+                if not st or st.startswith("#") or st.startswith("_") or st == "loop_" or st.startswith("data_"):
+                    break
+                tok = _cif_tokens(line)
+                if len(tok) != len(cols):
+                    raise ValueError(f"{path}: _atom_site row with {len(tok)} values for {len(cols)} columns: {line!r}")
+                rows.append(tok)
+    if not rows:
+        raise ValueError(f"{path}: no _atom_site loop found")
+    ix = {c: i for i, c in enumerate(cols)}
+
+    def col(row, *names, default=None):
+        for nme in names:
+            if nme in ix and row[ix[nme]] not in (".", "?"):
+                return row[ix[nme]]
+        return default
+    residues: List[Residue] = []
+    index: Dict[tuple, Residue] = {}
+    first_model = col(rows[0], "pdbx_PDB_model_num", default="1")
+    for serial, row in enumerate(rows, 1):
+        if col(row, "pdbx_PDB_model_num", default=first_model) != first_model:
+            break
+        hetero = col(row, "group_PDB", default="ATOM") == "HETATM"
+        name = col(row, "label_atom_id", "auth_atom_id", default="X")
+        resname = col(row, "label_comp_id", "auth_comp_id", default="UNK")
+        chain = col(row, "auth_asym_id", "label_asym_id", default=" ")
+        seq = col(row, "auth_seq_id", "label_seq_id")
+        if seq is None:
+            continue                                        # Bio.PDB skips atoms without a residue number too
+        resseq = int(seq)
+        icode = col(row, "pdbx_PDB_ins_code", default=" ")
+        altloc = col(row, "label_alt_id", default=" ")
+        xyz = np.array([float(row[ix["Cartn_x"]]), float(row[ix["Cartn_y"]]), float(row[ix["Cartn_z"]])], dtype=np.float32)
+        occ = float(col(row, "occupancy", default="1.0"))
+        bfac = float(col(row, "B_iso_or_equiv", default="0.0"))
+        elem = (col(row, "type_symbol") or _guess_element(name)).upper()
+        key = (chain, resseq, icode, hetero)
+        res = index.get(key)
+        if res is None:
+            res = Residue(chain, resseq, icode, resname, hetero)
+            index[key] = res
+            residues.append(res)
+        atom = Atom(name, elem, xyz, occ, altloc, _pdb_record(hetero, serial, name, altloc, resname, chain, resseq, icode,
+                                                              xyz, occ, bfac, elem.capitalize() if len(elem) > 1 else elem))
+        prev = next((a for a in res.atoms if a.name == atom.name), None)
+        if prev is None:
+            res.atoms.append(atom)
+        elif altloc != " " and occ > prev.occupancy:
+            res.atoms[res.atoms.index(prev)] = atom
+    return residues
+
+
+def read_receptor(path) -> List[Residue]:
+    """generate_pharmacophores.py:129-136: the parser follows the file suffix."""
+    suffix = Path(path).suffix.lower()
+    if suffix == '.pdb':
+        return read_pdb(path)
+    if suffix in ('.mmcif', '.cif'):
+        return read_mmcif(path)
+    raise ValueError(f'unsupported receptor file type: {suffix}, must be .pdb or .mmcif')
 
 
 def is_aa(resname: str, standard: bool = True) -> bool:
@@ -197,10 +320,7 @@ def process_ligand_and_pocket(rec_file: Path, output_dir: Optional[Path], prot_e
     rec_file = Path(rec_file)
     if lig_file is None and len(residue_list) == 0:
         raise ValueError("Either reference ligand or pocket residue list must be provided.")
-    if rec_file.suffix != '.pdb':
-        raise ValueError(f'unsupported receptor file type: {rec_file.suffix}, must be .pdb '
-                         '(.mmcif needs Bio.PDB, which this build does not depend on)')
-    residues = read_pdb(rec_file)
+    residues = read_receptor(rec_file)
     if lig_file is not None:
         _, lig_coords = parse_ligand(lig_file, remove_hydrogen=remove_hydrogen)
         init_com = lig_coords.mean(dim=0).reshape(1, 3)

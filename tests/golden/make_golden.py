@@ -10,7 +10,8 @@ regenerate the identical state dict from the seed.  Random draws of the referenc
 (torch.randn / torch.randint with torch.manual_seed) are reproduced up front with the same
 seed, call order and shapes and stored next to the outputs.
 
-    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py                  # rewrites every tests/golden/*.npz
+    python tests/golden/make_golden.py traj_c1.npz ...  # only the named files
 """
 import os
 import sys
@@ -331,27 +332,124 @@ def golden_train_grads(cfg, name, seeds, n_prot, n_pharm, T=100, wseed=0, rseed=
     npz(name, **out)
 
 
+@torch.no_grad()
+def golden_endpoint_trajectory(cfg, name, seeds, n_prot, n_pharm, T, noise_seed=42, wseed=0):
+    """sample_given_receptor with endpoint_param_coord / endpoint_param_feat (pharmacodiff.py:413-420)."""
+    m, sd = ref_model(cfg, T, 1e-5, seed=wseed)
+    m.endpoint_param_coord = True
+    m.endpoint_param_feat = True
+    batch = O.synthetic_batch(seeds, n_prot, n_pharm, cfg)
+    g = ref_graph(batch, pharm_nf=cfg.pharm_nf)
+    Nf = int(batch.pharm_ptr[-1])
+    torch.manual_seed(noise_seed)
+    noise = torch.zeros(T + 1, Nf, 3 + cfg.pharm_nf)
+    for i in range(T + 1):
+        noise[i, :, :3] = torch.randn(Nf, 3)
+        noise[i, :, 3:] = torch.randn(Nf, cfg.pharm_nf)
+    torch.manual_seed(noise_seed)
+    pharms = m.sample_given_receptor(g, init_pharm_com=None, visualize_trajectory=True)
+    npz(name, **batch_arrays(batch), noise=noise, T=T, wseed=wseed,
+        x0=torch.cat([p.ph_coords for p in pharms]), h0=torch.cat([p.g.nodes['pharm'].data['h_0'] for p in pharms]),
+        pos_frames=torch.cat([p.pos_frames for p in pharms], dim=1),
+        feat_frames=torch.cat([p.feat_frames for p in pharms], dim=1))
+
+
+@torch.no_grad()
+def golden_sample_multi(cfg, name, pockets, n_pharms, max_batch_size, T, noise_seed=42, wseed=0, com_shift=0.5):
+    """PharmacophoreDiff.sample (pharmacodiff.py:516-578) over several pockets: copy_graph with pharm_feats_per_copy
+    (utils/unorganized_utils.py:28-81), batches of max_batch_size in list order, explicit init_pharm_com per pocket.
+    pockets: [(seed, n_prot)].  The draws of every batch (initial x, h; then x, h per step) are recorded per batch."""
+    m, sd = ref_model(cfg, T, 1e-5, seed=wseed)
+    singles = [O.synthetic_batch([s], n, 1, cfg) for s, n in pockets]
+    ref_graphs = [ref_graph(b, pharm_nf=cfg.pharm_nf) for b in singles]
+    coms = torch.stack([b.prot_x.mean(dim=0) for b in singles]) + com_shift
+    sizes = [n for per in n_pharms for n in per]
+    chunks = [sizes[i:i + max_batch_size] for i in range(0, len(sizes), max_batch_size)]
+    torch.manual_seed(noise_seed)
+    noises = []
+    for ch in chunks:
+        Nf = sum(ch)
+        nz = torch.zeros(T + 1, Nf, 3 + cfg.pharm_nf)
+        for i in range(T + 1):
+            nz[i, :, :3] = torch.randn(Nf, 3)
+            nz[i, :, 3:] = torch.randn(Nf, cfg.pharm_nf)
+        noises.append(nz)
+    torch.manual_seed(noise_seed)
+    per_pocket = m.sample(ref_graphs, n_pharms, max_batch_size=max_batch_size, init_pharm_com=coms)
+    assert [len(p) for p in per_pocket] == [len(n) for n in n_pharms]
+    flat = [p for per in per_pocket for p in per]
+    assert [p.n_ph_centers for p in flat] == sizes
+    out = dict(T=T, wseed=wseed, max_batch_size=max_batch_size, init_pharm_com=coms,
+               n_pharms_flat=torch.tensor(sizes), n_pharms_per_pocket=torch.tensor([len(n) for n in n_pharms]),
+               pocket_seeds=torch.tensor([s for s, _ in pockets]), pocket_n_prot=torch.tensor([n for _, n in pockets]),
+               x0=torch.cat([p.ph_coords for p in flat]), h0=torch.cat([p.g.nodes['pharm'].data['h_0'] for p in flat]),
+               prot_x_out=torch.cat([p.g.nodes['prot'].data['x_0'] for p in flat]),
+               xyz="".join(p.to_xyz_file() for p in flat))
+    for i, nz in enumerate(noises):
+        out[f"noise_{i}"] = nz
+    npz(name, **out)
+
+
+def golden_pp_edges(name, pockets, cutoff=3.5):
+    """The static prot->prot edges exactly as build_initial_complex_graph emits them
+    (dataset/protein_pharm_dataset.py:234-236: radius_graph(r, max_num_neighbors=100) on one pocket), in its order."""
+    from pharmacoforge.dataset.protein_pharm_dataset import build_initial_complex_graph
+    out = dict(cutoff=cutoff, pocket_seeds=torch.tensor([s for s, _ in pockets]),
+               pocket_n_prot=torch.tensor([n for _, n in pockets]))
+    for i, (seed, n) in enumerate(pockets):
+        x, h = O.synthetic_pocket(seed, n)
+        g = build_initial_complex_graph(x, h, {'pp': cutoff, 'pf': 8, 'fp': 8, 'ff': 9},
+                                        pharm_atom_positions=torch.zeros(3, 3), pharm_atom_features=torch.zeros(3, 6))
+        u, v = g.edges(form='uv', etype='pp')
+        assert g.num_nodes('prot') == n and g.num_nodes('pharm') == 3 and g.num_nodes('prot_ph') == 0
+        out[f"src_{i}"], out[f"dst_{i}"] = u, v
+    npz(name, **out)
+
+
 def main():
     cfg = O.DynamicsConfig()                       # dev.yml
-    golden_units(cfg)
-    golden_schedule()
-    # config 1: 64-atom pocket, 4 centers, B=1
-    golden_conv_and_dynamics(cfg, "dynamics_c1.npz", seeds=[0], n_prot=64, n_pharm=4)
-    # ragged batch: B=3, pharm sizes 3/8/5, 48-atom pockets
-    golden_conv_and_dynamics(cfg, "dynamics_ragged.npz", seeds=[1, 2, 3], n_prot=48, n_pharm=[3, 8, 5])
-    # class-default flavour: radius pf edges, numeric message_norm, 3 convs / 3 noise GVPs
     cfg2 = O.DynamicsConfig(n_convs=3, n_noise_gvps=3, message_norm=10, pf_k=0, ff_k=0)
-    golden_conv_and_dynamics(cfg2, "dynamics_radius.npz", seeds=[4, 5], n_prot=40, n_pharm=[4, 6], wseed=1)
-    # kNN ff edges
     cfg3 = O.DynamicsConfig(ff_k=2, pf_k=3, message_norm=1)
-    golden_conv_and_dynamics(cfg3, "dynamics_knnff.npz", seeds=[6, 7], n_prot=32, n_pharm=[5, 4], wseed=2)
-    # config 1 trajectory, T=50
-    golden_trajectory(cfg, "traj_c1.npz", seeds=[0], n_prot=64, n_pharm=4, T=50)
-    golden_trajectory(cfg, "traj_ragged.npz", seeds=[8, 9], n_prot=40, n_pharm=[3, 5], T=20, traj=False)
-    golden_train_forward(cfg, "train_fwd.npz", seeds=[10, 11, 12], n_prot=40, n_pharm=[4, 6, 5])
-    golden_train_grads(cfg, "train_grads.npz", seeds=[13, 14, 15], n_prot=40, n_pharm=[4, 7, 5])
-    golden_train_grads(cfg2, "train_grads_radius.npz", seeds=[16, 17], n_prot=36, n_pharm=[5, 3], wseed=1,
-                       p_drop=0.1, weighted_loss=True)
+    jobs = {
+        "units.npz": lambda n: golden_units(cfg),
+        "schedule.npz": lambda n: golden_schedule(),
+        # config 1: 64-atom pocket, 4 centers, B=1
+        "dynamics_c1.npz": lambda n: golden_conv_and_dynamics(cfg, n, seeds=[0], n_prot=64, n_pharm=4),
+        # ragged batch: B=3, pharm sizes 3/8/5, 48-atom pockets
+        "dynamics_ragged.npz": lambda n: golden_conv_and_dynamics(cfg, n, seeds=[1, 2, 3], n_prot=48, n_pharm=[3, 8, 5]),
+        # class-default flavour: radius pf edges, numeric message_norm, 3 convs / 3 noise GVPs
+        "dynamics_radius.npz": lambda n: golden_conv_and_dynamics(cfg2, n, seeds=[4, 5], n_prot=40, n_pharm=[4, 6], wseed=1),
+        # kNN ff edges
+        "dynamics_knnff.npz": lambda n: golden_conv_and_dynamics(cfg3, n, seeds=[6, 7], n_prot=32, n_pharm=[5, 4], wseed=2),
+        # config 1 trajectory, T=50
+        "traj_c1.npz": lambda n: golden_trajectory(cfg, n, seeds=[0], n_prot=64, n_pharm=4, T=50),
+        "traj_ragged.npz": lambda n: golden_trajectory(cfg, n, seeds=[8, 9], n_prot=40, n_pharm=[3, 5], T=20, traj=False),
+        "train_fwd.npz": lambda n: golden_train_forward(cfg, n, seeds=[10, 11, 12], n_prot=40, n_pharm=[4, 6, 5]),
+        "train_grads.npz": lambda n: golden_train_grads(cfg, n, seeds=[13, 14, 15], n_prot=40, n_pharm=[4, 7, 5]),
+        "train_grads_radius.npz": lambda n: golden_train_grads(cfg2, n, seeds=[16, 17], n_prot=36, n_pharm=[5, 3], wseed=1,
+                                                               p_drop=0.1, weighted_loss=True),
+        # ---- round 2 -------------------------------------------------------------------------------------------
+        # config 1 over the whole T=500 schedule (pharmacodiff.py:466-472), every frame
+        "traj_c1_T500.npz": lambda n: golden_trajectory(cfg, n, seeds=[0], n_prot=64, n_pharm=4, T=500),
+        # endpoint parameterisation of both coordinates and features (pharmacodiff.py:413-420)
+        "traj_endpoint.npz": lambda n: golden_endpoint_trajectory(cfg, n, seeds=[18, 19], n_prot=40, n_pharm=[4, 6], T=20),
+        # message_norm = 0 (gvp.py:504-507): per-graph normalisers from g.batch_num_edges; radius pf edges (counts by
+        # the protein index: correct) and kNN pf edges (dynamics_gvp.py:220 looks the PHARM indices up in the PROT
+        # batch vector: the reference's counts, reproduced as they are) -- ragged pockets so that the lookup crosses
+        # a graph boundary
+        "dynamics_gnorm_radius.npz": lambda n: golden_conv_and_dynamics(
+            O.DynamicsConfig(message_norm=0, pf_k=0), n, seeds=[20, 21, 22], n_prot=[30, 44, 36], n_pharm=[4, 6, 3], wseed=3),
+        "dynamics_gnorm_knn.npz": lambda n: golden_conv_and_dynamics(
+            O.DynamicsConfig(message_norm=0, pf_k=5), n, seeds=[23, 24, 25], n_prot=[5, 40, 30], n_pharm=[4, 6, 3], wseed=3),
+        # PharmacophoreDiff.sample + copy_graph over three pockets of different sizes, two batches
+        "sample_multi.npz": lambda n: golden_sample_multi(cfg, n, pockets=[(26, 40), (27, 52), (28, 33)],
+                                                          n_pharms=[[3, 4], [5], [8, 3, 6]], max_batch_size=4, T=15),
+        # static pp edges through build_initial_complex_graph
+        "pp_edges.npz": lambda n: golden_pp_edges(n, pockets=[(0, 64), (29, 256), (30, 300), (31, 2)]),
+    }
+    want = sys.argv[1:] or list(jobs)
+    for name in want:
+        jobs[name](name)
 
 
 if __name__ == "__main__":

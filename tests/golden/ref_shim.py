@@ -159,6 +159,9 @@ class HeteroGraph:
         v = torch.as_tensor(v, dtype=torch.int64).reshape(-1)
         s, d = self._edges[cet]
         self._edges[cet] = (torch.cat([s, u]), torch.cat([d, v]))
+        # documented: existing edge features are extended with zeros for the new edges
+        self._edata[cet] = {k: torch.cat([t, torch.zeros((u.numel(),) + tuple(t.shape[1:]), dtype=t.dtype)])
+                            for k, t in self._edata[cet].items()}
         # like DGL, a structure change drops batch bookkeeping for that etype to "one graph"
         self._bne[cet] = torch.tensor([self._edges[cet][0].numel()])
 

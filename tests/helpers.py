@@ -29,6 +29,10 @@ DYN_CASES = {
     "dynamics_ragged.npz": O.DynamicsConfig(),
     "dynamics_radius.npz": O.DynamicsConfig(n_convs=3, n_noise_gvps=3, message_norm=10, pf_k=0, ff_k=0),
     "dynamics_knnff.npz": O.DynamicsConfig(ff_k=2, pf_k=3, message_norm=1),
+    # message_norm = 0 (per-graph normalisers, gvp.py:504-507): radius pf edges / kNN pf edges (the reference's
+    # dynamics_gvp.py:220 bookkeeping, reproduced), ragged pockets
+    "dynamics_gnorm_radius.npz": O.DynamicsConfig(message_norm=0, pf_k=0),
+    "dynamics_gnorm_knn.npz": O.DynamicsConfig(message_norm=0, pf_k=5),
 }
 
 

@@ -212,7 +212,7 @@ def test_gradient_allreduce_two_ranks_gloo():
 def test_product_code_never_imports_the_oracle():
     """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it."""
     offenders = []
-    targets = [os.path.join(ROOT, f) for f in ("generate_pharmacophores.py", "train.py", "pharmacoforge_amd.py")]
+    targets = [os.path.join(ROOT, f) for f in ("generate_pharmacophores.py", "train.py", "test.py", "pharmacoforge_amd.py")]
     for base in ("pharmacophore-diffusion_amd", "tools", "include"):
         for dp, _, files in os.walk(os.path.join(ROOT, base)):
             targets += [os.path.join(dp, f) for f in files if f.endswith((".py", ".cpp", ".hip", ".h"))]
@@ -225,3 +225,55 @@ def test_product_code_never_imports_the_oracle():
     uses = [m.start() for m in re.finditer(r"\boracle\b", bench)]
     start = bench.index("def cpu_baseline")
     assert all(u > start or "import" not in bench[max(0, u - 40):u] for u in uses)
+
+
+def _skewed_edge_counts(n, seed=0):
+    """pp edge counts of pockets whose atom counts spread 2-3x (150..450 atoms at ~6.8 edges per atom)."""
+    rng = np.random.default_rng(seed)
+    return [int(6.8 * a) for a in rng.integers(150, 451, size=n)]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_shard_by_work_balances_skewed_pockets(world):
+    from pharmacoforge_amd.sharding import shard_by_work, shard_loads
+    w = _skewed_edge_counts(200)
+    shards = shard_by_work(w, world)
+    assert sorted(i for s in shards for i in s) == list(range(200))          # a partition
+    loads = shard_loads(w, shards)
+    assert max(loads) / min(loads) <= 1.1, loads
+    assert shards == shard_by_work(list(w), world)                            # pure function: ranks agree without talking
+    # dealing by index on the same list is what this replaces
+    naive = [sum(w[i] for i in range(r, 200, world)) for r in range(world)]
+    assert max(loads) - min(loads) <= max(naive) - min(naive)
+    assert shard_by_work([], 3) == [[], [], []] and shard_by_work([5.0], 2) == [[0], []]
+
+
+def _shard_rank_fn(rank, world, port, q):
+    import torch.distributed as dist
+    from pharmacoforge_amd.sharding import shard_by_work
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    w = _skewed_edge_counts(64, seed=3)
+    mine = shard_by_work(w, world)[rank]                       # computed locally on every rank
+    load = torch.tensor([float(sum(w[i] for i in mine))], dtype=torch.float64)
+    lo, hi = load.clone(), load.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    seen = torch.zeros(64)
+    seen[mine] = 1
+    dist.all_reduce(seen)
+    q.put((rank, float(hi / lo), seen.tolist() == [1.0] * 64))
+    dist.destroy_process_group()
+
+
+def test_shard_by_work_two_ranks_gloo():
+    """The N>1 path of the sampling drivers: every rank derives its own shard from the same weights; together the shards
+    cover every pocket exactly once and the per-rank edge sums differ by at most 10 %."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_shard_rank_fn, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(30) for p in procs]
+    assert all(ratio <= 1.1 and cover for _, ratio, cover in out), out

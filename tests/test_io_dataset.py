@@ -157,3 +157,88 @@ def test_processed_dataset_and_collate(tmp_path):
     assert sizes == [2, 2]
     with pytest.raises(NotImplementedError):
         D.CrossdockedDataModule(cfg, 2, 0, [])
+
+
+def test_dataloader_workers_slice_the_precomputed_pp_table(tmp_path):
+    """DataLoader workers are forked after the parent has initialised HIP, so they must never build a radius graph on
+    the GPU: the data module builds the pp-edge table of every pocket in setup() (main process) and __getitem__ only
+    slices it; a worker that finds no table raises instead of touching the GPU."""
+    root = tmp_path / "processed"
+    for i in range(3):
+        make_split(root / f"split_{i}", i, 3)
+    cfg = dict(raw_data_dir=str(tmp_path), processed_data_dir=str(root), graph_cutoffs=CUTOFFS, prot_elements=PROT_ELEMENTS,
+               ph_type_map=pfa.analysis.ph_idx_to_type, pp_edges_fn=oracle_pp)
+    dm = D.CrossdockedDataModule(dataset_config=cfg, batch_size=2, num_workers=2, validation_splits=[2])
+    dm.setup('fit')
+    ds = dm.train_dataset
+    assert ds._pp_ptr is not None and ds._pp_src.dtype == torch.int16 and int(ds._pp_ptr[-1]) == ds._pp_src.numel()
+    assert ds.pp_edge_counts().tolist() == [int(oracle_pp(ds[i].prot_x)[0].numel()) for i in range(len(ds))]
+    got = [g for g in dm.train_dataloader()]                       # two forked workers
+    assert sum(g.batch_size for g in got) == len(ds)
+    ref = D.collate_fn([ds[0], ds[1]])
+    assert torch.equal(got[0].pp_src, ref.pp_src) and torch.equal(got[0].prot_x, ref.prot_x)
+    cold = D.ProteinPharmacophoreDataset('val', [2], **cfg)         # no table, no setup()
+    with pytest.raises(RuntimeError, match="pp edge table"):
+        next(iter(D.get_dataloader(cold, 2, num_workers=1)))
+
+
+def make_mmcif(path):
+    """The receptor of make_pdb as an mmCIF ``_atom_site`` loop (wwPDB column set), preceded by another loop, with a
+    quoted atom name, '.' / '?' null markers, label and author numbering that differ, and a second model."""
+    rows = []
+    s = 1
+
+    def add(group, name, alt, comp, lasym, lseq, x, y, z, occ, elem, aseq, aasym, model=1):
+        nonlocal s
+        qn = f'"{name}"' if "'" in name else name
+        rows.append(f"{group} {s} {elem} {qn} {alt} {comp} {lasym} 1 {lseq} ? {x:.3f} {y:.3f} {z:.3f} {occ:.2f} 20.00 ? {aseq} {comp} {aasym} {qn} {model}")
+        s += 1
+    for name, xyz, elem, alt, occ in [("N", (0, 0, 0), "N", ".", 1.0), ("CA", (1.4, 0, 0), "C", ".", 1.0), ("C", (2.0, 1.3, 0), "C", ".", 1.0),
+                                      ("O", (1.4, 2.3, 0), "O", ".", 1.0), ("CB", (2.0, -1.2, 0.5), "C", "A", 0.3),
+                                      ("CB", (2.1, -1.1, 0.6), "C", "B", 0.7), ("HA", (1.5, 0.1, 1.0), "H", ".", 1.0)]:
+        add("ATOM", name, alt, "ALA", "X", 11, *xyz, occ, elem, 1, "A")       # label chain X / seq 11 vs author A / 1
+    for name, xyz, elem in [("N", (6, 0, 0), "N"), ("CA", (7.4, 0, 0), "C"), ("SE", (7.5, 1.5, 0), "SE")]:
+        add("ATOM", name, ".", "MET", "X", 12, *xyz, 1.0, elem, 2, "A")
+    for name, xyz, elem in [("N", (30, 0, 0), "N"), ("CA", (31.4, 0, 0), "C")]:
+        add("ATOM", name, ".", "GLY", "X", 13, *xyz, 1.0, elem, 3, "A")
+    add("HETATM", "O", ".", "HOH", "Y", ".", 0.5, 0.5, 0.5, 1.0, "O", 101, "A")
+    add("HETATM", "CA", ".", "MSE", "X", 14, 0.2, 0.2, 0.2, 1.0, "C", 4, "A")
+    add("ATOM", "N", ".", "ALA", "Z", 1, 0.1, 0.1, 0.1, 1.0, "N", 9, "B", model=2)
+    cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id", "label_entity_id",
+            "label_seq_id", "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z", "occupancy", "B_iso_or_equiv", "pdbx_formal_charge",
+            "auth_seq_id", "auth_comp_id", "auth_asym_id", "auth_atom_id", "pdbx_PDB_model_num"]
+    text = ["data_TEST", "#", "loop_", "_entity.id", "_entity.type", "1 polymer", "2 water", "#", "loop_"]
+    text += ["_atom_site." + c for c in cols] + rows + ["#", "loop_", "_atom_type.symbol", "C", "N", "#"]
+    path.write_text("\n".join(text) + "\n")
+
+
+def test_mmcif_receptor_reads_like_the_pdb(tmp_path):
+    """generate_pharmacophores.py:131-132 accepts '.mmcif' receptors (Bio.PDB.MMCIFParser): the same structure written as
+    PDB and as mmCIF gives the same residues, atoms, alternate-location choice, pocket graph and pocket.pdb atoms."""
+    pdb, cif, sdf = tmp_path / "rec.pdb", tmp_path / "rec.mmcif", tmp_path / "lig.sdf"
+    make_pdb(pdb); make_mmcif(cif); sdf.write_text(SDF)
+    a, b = P.read_pdb(pdb), P.read_mmcif(cif)
+    assert [(r.resname, r.chain, r.resseq, r.icode, r.hetero) for r in a] == [(r.resname, r.chain, r.resseq, r.icode, r.hetero) for r in b]
+    for ra, rb in zip(a, b):
+        assert [(x.name, x.element, x.altloc.strip(), x.occupancy) for x in ra.atoms] == \
+               [(x.name, x.element, x.altloc.strip(), x.occupancy) for x in rb.atoms]
+        assert np.allclose(np.array([x.coord for x in ra.atoms]), np.array([x.coord for x in rb.atoms]))
+    assert P._cif_tokens("""ATOM 1 O "O5'" . 'A B' x""") == ["ATOM", "1", "O", "O5'", ".", "A B", "x"]
+    emap, _ = P.get_prot_atom_ph_type_maps({'prot_elements': PROT_ELEMENTS, 'ph_type_map': pfa.analysis.ph_idx_to_type})
+    all_pos = torch.tensor(np.array([x.coord for r in a[:2] for x in r.atoms if x.element not in ("H", "SE")]))
+    out_a, out_b = tmp_path / "a", tmp_path / "b"
+    out_a.mkdir(); out_b.mkdir()
+    ga = P.process_ligand_and_pocket(pdb, out_a, emap, CUTOFFS, 8.0, lig_file=sdf, pp_edges=oracle_pp(all_pos))
+    gb = P.process_ligand_and_pocket(cif, out_b, emap, CUTOFFS, 8.0, lig_file=sdf, pp_edges=oracle_pp(all_pos))
+    assert torch.equal(ga.prot_x, gb.prot_x) and torch.equal(ga.prot_h, gb.prot_h) and torch.equal(ga.pharm_x0, gb.pharm_x0)
+    la = [l for l in (out_a / "pocket.pdb").read_text().splitlines() if l.startswith("ATOM")]
+    lb = [l for l in (out_b / "pocket.pdb").read_text().splitlines() if l.startswith("ATOM")]
+    assert len(la) == len(lb) == 9
+    for x, y in zip(la, lb):          # same name / residue / chain / number / coordinates / element columns
+        assert x[12:16].strip() == y[12:16].strip() and x[16:27] == y[16:27] and x[30:54] == y[30:54], (x, y)
+        assert x[76:78].strip().upper() == y[76:78].strip().upper(), (x, y)
+    assert P.read_pdb(out_b / "pocket.pdb")[0].atoms[0].name == "N"           # the written records parse back
+    gr = P.process_ligand_and_pocket(cif, None, emap, CUTOFFS, 8.0, residue_list=["A:1"], pp_edges=oracle_pp(all_pos[:5]))
+    assert gr.num_nodes('prot') == 5
+    with pytest.raises(ValueError, match="unsupported receptor file type"):
+        P.process_ligand_and_pocket(tmp_path / "rec.xyz", None, emap, CUTOFFS, 8.0, lig_file=sdf)

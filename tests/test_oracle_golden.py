@@ -96,7 +96,7 @@ def test_edges_conv_dynamics(name):
     ref_edges = {et: (z[f"e_{et}_src"].long(), z[f"e_{et}_dst"].long()) for et in O.ETYPES}
     nf = {"pharm": (z["conv_in_h_pharm"], z["x_t"], z["conv_in_v_pharm"]),
           "prot": (z["conv_in_h_prot"], z["prot_x"], z["conv_in_v_prot"])}
-    ec = None
+    ec = O.dynamic_edge_counts(cfg, batch, ref_edges) if cfg.message_norm == 0 else None
     out = O.conv_layer(sd, f"dynamics.noise_predictor.conv_layers.{li}.", cfg, nf, ref_edges, batch, ec)
     for nt in ("pharm", "prot"):
         close(out[nt][0], z[f"conv_out_h_{nt}"], rtol=1e-4, atol=2e-5)
@@ -107,14 +107,41 @@ def test_edges_conv_dynamics(name):
     close(eps_x, z["eps_x"], rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("name,traj", [("traj_c1.npz", True), ("traj_ragged.npz", False)])
-def test_trajectory(name, traj):
+def test_reference_edge_bookkeeping_for_per_graph_norm():
+    """message_norm = 0 reads the per-graph edge counts add_pharm_edges stored (dynamics_gvp.py:218-225).  With kNN pf
+    edges the reference books center j's edges on the graph that owns PROTEIN atom j (:220); the golden was produced
+    by that code, so the oracle must reproduce the same counts -- and they differ from the true per-graph counts."""
+    z, cfg = load("dynamics_gnorm_knn.npz"), DYN_CASES["dynamics_gnorm_knn.npz"]
+    batch = batch_from(z)
+    edges = {et: (z[f"e_{et}_src"].long(), z[f"e_{et}_dst"].long()) for et in O.ETYPES}
+    ec = O.dynamic_edge_counts(cfg, batch, edges)
+    # pockets of 5 / 40 / 30 atoms, 4 / 6 / 3 centers, k = 5: centers 0..4 -> graph 0, centers 5..12 -> graph 1
+    assert ec["pf"].tolist() == [25, 40, 0] and ec["fp"].tolist() == [25, 40, 0]
+    true_pf = torch.bincount(torch.searchsorted(batch.pharm_ptr[1:].contiguous(), edges["pf"][1], right=True), minlength=3)
+    assert true_pf.tolist() == [20, 30, 15]
+    assert ec["ff"].tolist() == torch.bincount(torch.searchsorted(batch.pharm_ptr[1:].contiguous(), edges["ff"][1], right=True),
+                                               minlength=3).tolist()
+    # radius pf edges: the lookup uses protein indices, the counts are the true ones
+    z, cfg = load("dynamics_gnorm_radius.npz"), DYN_CASES["dynamics_gnorm_radius.npz"]
+    batch = batch_from(z)
+    edges = {et: (z[f"e_{et}_src"].long(), z[f"e_{et}_dst"].long()) for et in O.ETYPES}
+    ec = O.dynamic_edge_counts(cfg, batch, edges)
+    true_pf = torch.bincount(torch.searchsorted(batch.pharm_ptr[1:].contiguous(), edges["pf"][1], right=True), minlength=3)
+    assert ec["pf"].tolist() == true_pf.tolist() and sum(ec["pf"].tolist()) == edges["pf"][0].numel()
+
+
+@pytest.mark.parametrize("name,traj,ep", [("traj_c1.npz", True, False), ("traj_ragged.npz", False, False),
+                                          ("traj_c1_T500.npz", True, False), ("traj_endpoint.npz", True, True)])
+def test_trajectory(name, traj, ep):
+    """sample_given_receptor against the reference's trajectories: config 1 at T=50 and over the whole T=500 schedule
+    (every frame), a ragged batch, and the endpoint parameterisation (pharmacodiff.py:413-420)."""
     z = load(name)
     cfg = O.DynamicsConfig()
     batch = batch_from(z)
     sd = O.make_state_dict(cfg, int(z["wseed"]))
     T = int(z["T"])
-    res = O.sample_given_receptor(sd, cfg, batch, T, 1e-5, z["noise"], return_traj=traj)
+    res = O.sample_given_receptor(sd, cfg, batch, T, 1e-5, z["noise"], return_traj=traj, endpoint_param_coord=ep,
+                                  endpoint_param_feat=ep)
     # T-step stochastic trajectory: rounding differences compound, tolerance is looser
     close(res[0], z["x0"], rtol=1e-3, atol=1e-3)
     close(res[1], z["h0"], rtol=1e-3, atol=1e-3)
@@ -123,6 +150,34 @@ def test_trajectory(name, traj):
         feat = torch.stack([f[1] for f in res[2]])
         close(pos, z["pos_frames"], rtol=1e-3, atol=1e-3)
         close(feat, z["feat_frames"], rtol=1e-3, atol=1e-3)
+
+
+def test_sample_multi_pocket_and_copy_graph():
+    """PharmacophoreDiff.sample (pharmacodiff.py:516-578) + copy_graph (utils/unorganized_utils.py:28-81): three pockets
+    of different sizes, ragged requests, batches of 4 in list order, explicit init_pharm_com."""
+    z = load("sample_multi.npz")
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    pockets = [O.synthetic_batch([int(s)], int(n), 1, cfg) for s, n in zip(z["pocket_seeds"], z["pocket_n_prot"])]
+    sizes, per = z["n_pharms_flat"].tolist(), z["n_pharms_per_pocket"].tolist()
+    n_pharms, k = [], 0
+    for c in per:
+        n_pharms.append(sizes[k:k + c]); k += c
+    noises = [z[f"noise_{i}"] for i in range(2)]
+    out = O.sample(sd, cfg, pockets, n_pharms, int(z["max_batch_size"]), int(z["T"]), 1e-5, noises, z["init_pharm_com"])
+    assert [len(o) for o in out] == per
+    x0 = torch.cat([x for o in out for x, _ in o]); h0 = torch.cat([h for o in out for _, h in o])
+    close(x0, z["x0"], rtol=1e-3, atol=1e-3); close(h0, z["h0"], rtol=1e-3, atol=1e-3)
+
+
+def test_static_pp_edges_as_build_initial_complex_graph_emits_them():
+    """dataset/protein_pharm_dataset.py:234-236 on single pockets (64 / 256 / 300 atoms and a 2-atom corner case):
+    the oracle's radius graph gives the same edges in the same order."""
+    z = load("pp_edges.npz")
+    for i, (seed, n) in enumerate(zip(z["pocket_seeds"].tolist(), z["pocket_n_prot"].tolist())):
+        x, _ = O.synthetic_pocket(seed, n)
+        s, d = O.build_pp_edges(x, torch.tensor([0, n]), float(z["cutoff"]), 100)
+        assert torch.equal(s, z[f"src_{i}"].long()) and torch.equal(d, z[f"dst_{i}"].long()), (seed, n)
 
 
 def test_training_forward():
