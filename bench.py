@@ -23,9 +23,33 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3          # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_EDGE = 136742.0         # message chain, 2 FLOP / MAC
-# bytes per launch of the layer-0 edge kernel at config 2, by kernel family (rows per wave), from profiles/r01
-PMC_TRAFFIC = {8: (2 * 5353.9 + 1313.4) * 1024, 4: (2 * 6112.6 + 1715.0) * 1024,      # 4: h_hoist_pmc_hbm.csv (the default)
-                128: (2 * 5812.7 + 940.5) * 1024, 32: (2 * 15028.2 + 7258.8) * 1024}
+# roofline.traffic: HBM bytes per launch need hardware counters, which cannot be read from inside this process.  They are
+# collected by separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh) and committed under
+# profiles/; the JSON line carries null plus the pointer below instead of a number copied from an earlier run.
+TRAFFIC_SOURCE = "profiles/r02/*_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; see profiles/README.md)"
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh processes, one per GPU, BEFORE this process touches
+    the GPU (counting devices does not initialise HIP), with the torchrun environment contract; rank 0 prints the JSON
+    line.  Never re-executes a process that has initialised the GPU."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs at least one MI355X (no CPU fallback)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    raise SystemExit(rc)
 
 
 def main():
@@ -45,13 +69,19 @@ def main():
                     help="dev = configs/dev.yml dynamics block (the headline); class-default = the depth the reference's "
                          "class defaults give (SURVEY 8d secondary run): n_convs=4, n_noise_gvps=3, message_norm=1, radius pf edges")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed device activity before the W warm-up steps")
-    ap.add_argument("--event-every", type=int, default=10,
-                    help="HIP events around the roofline kernel on every N-th timed step (0: never)")
+    ap.add_argument("--event-every", type=int, default=-1,
+                    help="HIP events around the roofline kernel on every N-th timed step (0: never; default: chosen so that "
+                         "at least 20 launches are timed whatever --steps is)")
+    ap.add_argument("--no-full-trajectory", action="store_true", help="skip the whole-schedule pf_sample leg")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel device time to stderr")
+    ap.add_argument("--train-batches", type=int, default=4,
+                    help="--train: number of distinct batches the steps rotate through (1: the same batch every step, no re-bind)")
     ap.add_argument("--train", action="store_true",
                     help="secondary benchmark (BASELINE config 5): training steps (forward, backward kernels, Adam) at "
                          "batch 256 per GPU instead of the sampling metric")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -81,6 +111,8 @@ def main():
             dist.destroy_process_group()
         return
     B, T, K, W = args.batch, args.timesteps, args.steps, args.warmup
+    if args.event_every < 0:
+        args.event_every = max(1, K // 20)
     # ---- inputs: B distinct pockets per rank (weak scaling: per-GPU work fixed), resident in HBM
     arch_eng, arch_sd = {}, {}
     if args.arch == "class-default":
@@ -102,17 +134,18 @@ def main():
     Nf = int(pharm_ptr[-1])
     sched = schedule.PredefinedNoiseSchedule('polynomial_2', T, 1e-5)
     coef = schedule.step_coefficients(sched.gamma, T)
-    order = [(W + K - 1 - i) % T for i in range(W + K)]        # the last W+K steps of the T-step schedule (s = W+K-1 ... 0):
+    KK = max(K, 20)                                             # room for the roofline top-up pass
+    order = [(W + KK - 1 - i) % T for i in range(W + KK)]        # the last W+K steps of the T-step schedule (s = W+K-1 ... 0):
     # with random-init weights the early, high-noise steps (1/alpha_t|s = 1.6) blow the coordinates up; the tail keeps
     # a realistic geometry (all ff edges present).  Work per step does not depend on s.
     carr = eng.coef_array(coef, order)
     # the trajectory's timesteps, as pf_sample announces them itself (layer-0 type tables: one launch per 64 timesteps
     # at set-up instead of one small launch in front of every step)
-    eng.prepare_timesteps(carr, W + K)
+    eng.prepare_timesteps(carr, W + KK)
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
 
     EV_MASK = (1 << 2) | (1 << 6)                               # edge-message launches of conv layer 0
-    noise_buf = torch.empty(max(K, W) + 1, Nf, 9, device=dev)
+    noise_buf = torch.empty(max(K, W, 20) + 1, Nf, 9, device=dev)
 
     def run(n, first, event_every=0):
         """n denoising steps.  event_every > 0: every event_every-th step has HIP events around its layer-0 edge-message
@@ -156,10 +189,21 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_enable(0)
-    tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    in_region = prof["edge_msg"][1] + prof["edge_msg_coop"][1]
+    if 0 < in_region < 20:                      # short timed regions: top the sample up to 20 launches, outside `value`
+        eng.profile_enable(EV_MASK)
+        run(20 - in_region, False)
+        torch.cuda.synchronize()
+        extra = eng.profile_read()
+        eng.profile_enable(0)
+        prof = {k: (prof[k][0] + extra[k][0], prof[k][1] + extra[k][1]) for k in prof}
+
+    def max_over_ranks(x):
+        t_ = torch.tensor([x], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        return float(t_.item())
+    dt = max_over_ranks(dt)
 
     wk = eng.work_detail()                                      # work of the last call (actual edge counts)
     flops, bytes_, ne = wk["flops"], wk["bytes"], wk["edges"]
@@ -197,10 +241,7 @@ def main():
                    "parallelism": f"graphs sharded over {world} GPU(s), no data-path collective"},
         "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved_tf, "peak": PEAK_F32_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_TFLOPS,
-                     # HBM-side bytes per launch of that kernel from the committed rocprofv3 PMC passes
-                     # (profiles/r01/*_pmc_hbm.csv: 2 x FETCH_SIZE [gfx950 wide-read correction] + WRITE_SIZE);
-                     # PMC counters cannot be collected from inside this process
-                     "traffic": PMC_TRAFFIC.get(fam) if (B, args.n_prot, args.n_pharm, args.pharm_sizes, args.arch) == (32, 256, 6, "", "dev") else None,
+                     "traffic": None, "traffic_source": TRAFFIC_SOURCE,
                      "kernel_avg_us": edge_avg_s * 1e6, "launches_timed": edge_n, "flop_per_launch": edge_flops,
                      "executed_flop_per_launch": edge_flops_exec, "hoisted_edges_per_launch": hoisted_edges,
                      "frac_executed": (edge_flops_exec / edge_avg_s / 1e12 / PEAK_F32_TFLOPS) if edge_avg_s > 0 else 0.0,
@@ -215,6 +256,10 @@ def main():
                                     "executed_tflops": wk["executed_flops"] / (dt / K) / 1e12,
                                     "gbs": bytes_ / (dt / K) / 1e9, "frac_hbm_peak": bytes_ / (dt / K) / 1e9 / PEAK_HBM_GBS}},
     }
+
+    out["roofline"]["launches_timed_in_region"] = in_region
+    if not args.no_full_trajectory:
+        out["full_trajectory"] = full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks)
 
     if args.breakdown and rank == 0:
         eng.profile_enable(0x1ff)
@@ -235,6 +280,36 @@ def main():
         dist.destroy_process_group()
 
 
+def full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks):
+    """SURVEY.md 8(d) row 1 as written: wall time of the WHOLE T-step reverse loop (pharmacodiff.py:466-472 equivalent)
+    for the rank's batch -- pf_sample: begin, T steps, final frame, enqueued without a host sync; x_T, h_T ~ N(0, I) at
+    the pocket COM, seed-0 weights, noise drawn on the device inside the timed region -- reported as B*T / wall.  With
+    untrained weights the centers drift outwards over the schedule (1/alpha_T ~ 300 x the initial spread), so late steps
+    see different neighbour sets than a trained model's would; the edge counts of the last step are reported.  Three
+    repetitions, median; max over ranks."""
+    arr = eng.coef_array(coef, reversed(range(T)))
+    gen = torch.Generator(device=dev).manual_seed(4242 + rank)
+    buf = torch.empty(T + 1, Nf, 9, device=dev)
+    times = []
+    for rep in range(4):
+        barrier()
+        t0 = time.perf_counter()
+        noise = buf.normal_(generator=gen)
+        x0, h0 = eng.sample(arr, T, noise)
+        barrier()
+        if rep:                                    # repetition 0 warms up (type tables for all T timesteps, allocations)
+            times.append(max_over_ranks(time.perf_counter() - t0))
+    times.sort()
+    dt = times[len(times) // 2]
+    wk = eng.work_detail()
+    return {"value": world * B * T / dt, "unit": "sample-steps/s", "T": T, "wall_ms": dt * 1e3, "ms_per_step": dt / T * 1e3,
+            "repetitions_ms": [round(t * 1e3, 3) for t in times], "finite": bool(torch.isfinite(x0).all() and torch.isfinite(h0).all()),
+            "max_abs_coordinate": float(x0.abs().max()),
+            "edges_last_step": dict(zip(("ff", "pf", "fp", "pp"), wk["edges"])),
+            "edges_computed_per_layer_last_step": wk["executed_edges_per_layer"],
+            "note": "whole T-step reverse process of the rank's batch through pf_sample, noise generation included"}
+
+
 def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
     """BASELINE config 5: one training step = PharmacophoreDiff.training_step (noising, dynamics forward with dropout,
     loss) + backward (HIP gradient kernels) + gradient all-reduce over the ranks + Adam.  B graphs per GPU (weak)."""
@@ -252,22 +327,32 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
     sd["gamma.gamma"] = m.state_dict()["gamma.gamma"]
     m.load_state_dict(sd, strict=True)
     m = m.to(dev).train()
-    xs, hs = zip(*[synthetic.synthetic_pocket(1000 * rank + i, args.n_prot) for i in range(B)])
-    prot_x, prot_h = torch.cat(xs), torch.cat(hs)
-    prot_ptr = torch.arange(B + 1, dtype=torch.int64) * args.n_prot
-    pharm_ptr = torch.tensor([0] + list(__import__("itertools").accumulate(sizes)), dtype=torch.int64)
+    pockets = [synthetic.synthetic_pocket(1000 * rank + i, args.n_prot) for i in range(B)]
     eng = m.dynamics.engine()
-    pp_src, pp_dst = eng.build_pp_edges(prot_x.to(dev), prot_ptr)
-    Nf = int(pharm_ptr[-1])
     gen = torch.Generator().manual_seed(7 + rank)
-    x0 = torch.cat([xs[i].mean(0, keepdim=True) + 2.0 * torch.randn(sizes[i], 3, generator=gen) for i in range(B)])
-    h0 = torch.nn.functional.one_hot(torch.randint(0, 6, (Nf,), generator=gen), 6).float()
-    g = pfa.PocketGraph(prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, pharm_x0=x0, pharm_h0=h0).to(dev)
+    # a rotating set of DISTINCT batches (other pocket order, other center counts: other ptr arrays and coordinates), as a
+    # data loader delivers them: every step pays the per-batch bind (pf_set_pocket_batch) like train.py does
+    graphs = []
+    for r in range(args.train_batches):
+        order = [(i + r * (B // max(args.train_batches, 1))) % B for i in range(B)]
+        sz = [sizes[(i + r) % B] for i in range(B)]
+        xs, hs = [pockets[i][0] for i in order], [pockets[i][1] for i in order]
+        prot_x, prot_h = torch.cat(xs), torch.cat(hs)
+        prot_ptr = torch.arange(B + 1, dtype=torch.int64) * args.n_prot
+        pharm_ptr = torch.tensor([0] + list(__import__("itertools").accumulate(sz)), dtype=torch.int64)
+        pp_src, pp_dst = eng.build_pp_edges(prot_x.to(dev), prot_ptr)
+        Nf = int(pharm_ptr[-1])
+        x0 = torch.cat([xs[i].mean(0, keepdim=True) + 2.0 * torch.randn(sz[i], 3, generator=gen) for i in range(B)])
+        h0 = torch.nn.functional.one_hot(torch.randint(0, 6, (Nf,), generator=gen), 6).float()
+        graphs.append(pfa.PocketGraph(prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, pharm_x0=x0, pharm_h0=h0).to(dev))
+    it = [0]
     # optim.Adam(lr, weight_decay) of pharmacodiff.py:253 as one fused kernel on the flat parameter vector
     opt = pfa.FlatAdam(m.dynamics, lr=1e-4, weight_decay=1e-12)
 
     def step():
         opt.zero_grad(set_to_none=True)
+        g = graphs[it[0] % len(graphs)]
+        it[0] += 1
         loss = m.training_step(g, 0)
         loss.backward()
         if world > 1:
@@ -304,6 +389,7 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config 5: training step, batch={B} per GPU, {args.n_prot}-atom pockets, centers {lo}-{hi}, "
                                    "dropout 0.1, dev.yml network", "batch_per_gpu": B, "n_prot": args.n_prot,
+                       "distinct_batches": len(graphs),
                        "parallelism": f"data parallel over {world} GPU(s): one all-reduce of the flat gradient per step"},
             "final_loss": float(loss.detach())}))
 
@@ -345,32 +431,52 @@ def dense_leg(pfa, synthetic, dev, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, 
 
 
 def cpu_baseline(args, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, T):
-    """The CPU oracle (a PyTorch fp32 restatement of the reference path, oracle/pf_oracle.py) on the
-    same workload, bounded to ~args.cpu_seconds of host time.  Reported baseline, not the target."""
+    """The CPU oracle (a PyTorch fp32 restatement of the reference path, oracle/pf_oracle.py) on the same workload on
+    this box's host cores.  torch's default thread count (every hardware thread) oversubscribes this workload, so the
+    oracle is timed at 8 (the survey container's count), 16, 32 and 64 threads -- a bounded sample each, ~args.cpu_seconds
+    in total -- and the BEST is reported with its thread count.  Reported baseline, not the target."""
     from oracle import pf_oracle as O
     cfg = O.DynamicsConfig()
     sd = O.make_state_dict(cfg, 0)
     batch = O.PocketBatch(prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst)
     coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
     Nf = int(pharm_ptr[-1])
-    g = torch.Generator().manual_seed(42)
-    x_t, h_t = torch.randn(Nf, 3, generator=g), torch.randn(Nf, 6, generator=g)
-    px = prot_x - O.segment_mean(prot_x, prot_ptr)[batch.batch_idxs()["prot"]]
-    with torch.no_grad():
-        nz = torch.randn(Nf, 9, generator=g)
-        px, x_t, h_t = O.sample_step(sd, cfg, batch, coef, T - 1, px, x_t, h_t, nz[:, :3], nz[:, 3:])   # warm-up
-        n, t0 = 0, time.perf_counter()
-        while n < 3 or time.perf_counter() - t0 < args.cpu_seconds:
-            nz = torch.randn(Nf, 9, generator=g)
-            px, x_t, h_t = O.sample_step(sd, cfg, batch, coef, T - 2 - n, px, x_t, h_t, nz[:, :3], nz[:, 3:])
-            n += 1
-            if n >= 200:
-                break
-        dt = time.perf_counter() - t0
     B = int(prot_ptr.numel() - 1)
-    return {"value": B * n / dt, "unit": "sample-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} denoising steps of the same B={B} batch (after 1 warm-up step), CPU oracle (PyTorch fp32, "
-                      f"{torch.get_num_threads()} threads), {dt:.1f} s"}
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    default_threads = torch.get_num_threads()
+    # every hardware thread of a 256-thread host oversubscribes these small GEMMs by two orders of magnitude (measured
+    # on the GPU box: 0.4 sample-steps/s at 256 threads against 150-180 at 8-32), so the sweep stops at 64
+    cands = sorted({n for n in (8, 16, 32, 64) if n <= ncpu} or {ncpu})
+    budget = max(args.cpu_seconds / len(cands), 2.0)
+    results = {}
+    for nthr in cands:
+        torch.set_num_threads(nthr)
+        g = torch.Generator().manual_seed(42)
+        x_t, h_t = torch.randn(Nf, 3, generator=g), torch.randn(Nf, 6, generator=g)
+        px = prot_x - O.segment_mean(prot_x, prot_ptr)[batch.batch_idxs()["prot"]]
+        with torch.no_grad():
+            nz = torch.randn(Nf, 9, generator=g)
+            px, x_t, h_t = O.sample_step(sd, cfg, batch, coef, T - 1, px, x_t, h_t, nz[:, :3], nz[:, 3:])   # warm-up
+            n, t0 = 0, time.perf_counter()
+            while n < 2 or time.perf_counter() - t0 < budget:
+                nz = torch.randn(Nf, 9, generator=g)
+                px, x_t, h_t = O.sample_step(sd, cfg, batch, coef, T - 2 - n, px, x_t, h_t, nz[:, :3], nz[:, 3:])
+                n += 1
+                if n >= 200:
+                    break
+            dt = time.perf_counter() - t0
+        results[nthr] = (B * n / dt, n, dt)
+    torch.set_num_threads(default_threads)
+    best = max(results, key=lambda k: results[k][0])
+    return {"value": results[best][0], "unit": "sample-steps/s", "cores": best, "kind": "port",
+            "by_threads": {str(k): round(v[0], 2) for k, v in results.items()}, "host_cpus": ncpu,
+            "sample": f"{results[best][1]} denoising steps of the same B={B} batch (after 1 warm-up step) in {results[best][2]:.1f} s "
+                      f"at {best} threads -- the best of {cands} threads, each timed for ~{budget:.0f} s; CPU oracle "
+                      "(PyTorch fp32 restatement of the reference path)"}
 
 
 if __name__ == "__main__":

@@ -102,10 +102,19 @@ int pf_commit_weights(pf_handle* h);
 /* -- static per-batch data (the DGL-free batch container) -----------------------------------
  * B graphs; graph g owns prot atoms [prot_ptr[g], prot_ptr[g+1]) and pharmacophore centers
  * [pharm_ptr[g], pharm_ptr[g+1]).  pp edges (static prot->prot, batch-local prot ids) may be in
- * any order.  prot_x / prot_h are copied into the workspace. */
+ * any order.  prot_x / prot_h are copied into the workspace.  Asynchronous: the host tables are staged in pinned
+ * memory owned by the handle and uploaded with one copy on `stream`; the host arrays may be freed on return.  The call
+ * synchronises the device only when the workspace has to grow. */
 int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* host_prot_ptr, const int32_t* host_pharm_ptr,
                         const float* dev_prot_x, const float* dev_prot_h,
                         int64_t n_pp, const int32_t* host_pp_src, const int32_t* host_pp_dst, pf_stream stream);
+
+/* Optional, right after pf_set_pocket_batch: the caller states whether every row of prot_h is an element one-hot
+ * (what the reference's dataset / CLI always produce: protein_pharm_dataset.py:129, generate_pharmacophores.py:105-118).
+ * pf_set_pocket_batch checks this on the device and the first inference call that wants the answer waits for it; a caller
+ * that already knows (it built the rows, or checked them on the host) says so here and no call ever waits: the whole
+ * bind is then asynchronous on `stream`.  Declaring 1 for rows that are not one-hots gives wrong results. */
+int pf_declare_onehot_features(pf_handle* h, int32_t is_onehot);
 
 /* radius_graph(prot, r=cutoff_pp, max_num_neighbors) per graph on the device; results on the host.
  * Call with host_src == NULL to get the edge count (return value >= 0), then again with buffers. */

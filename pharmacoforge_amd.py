@@ -9,7 +9,7 @@ if _root not in sys.path:
 _pkg = importlib.import_module("pharmacophore-diffusion_amd")
 # one module object per submodule: 'pharmacoforge_amd.x' must be THE module 'pharmacophore-diffusion_amd.x' (classes are
 # compared by identity, e.g. isinstance(g, PocketGraph)), not a second copy loaded under the alias name
-for _name in ("pocket_io", "dataset"):
+for _name in ("pocket_io", "dataset", "sharding"):
     importlib.import_module("pharmacophore-diffusion_amd." + _name)
 for _k, _m in list(sys.modules.items()):
     if _k.startswith("pharmacophore-diffusion_amd."):

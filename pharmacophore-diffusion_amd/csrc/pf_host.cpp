@@ -123,6 +123,18 @@ struct pf_handle {
     int *d_act_ids = nullptr, *d_reg_act = nullptr;   // last conv layer: only what feeds the pharm nodes
     void* d_ws = nullptr;                   // one allocation, carved below
     size_t ws_capacity = 0;                 // bytes behind d_ws: kept across pocket batches while it is large enough
+    // pf_set_pocket_batch stages every host-built table in pinned memory, in the layout of the workspace's table section,
+    // and uploads it with ONE asynchronous copy on the caller's stream (two staging buffers alternate; a buffer is reused
+    // only after the copy that read it has completed)
+    void* stage[2] = {nullptr, nullptr};
+    size_t stage_cap[2] = {0, 0};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    int stage_next = 0;
+    // one-hot check of the protein features (static hoist): 0 unknown (device flag pending), 1 one-hot, 2 not
+    int l0_state = 0;
+    int* l0flag_host = nullptr;             // pinned; written by an async copy of d_l0flag
+    hipEvent_t l0flag_ev = nullptr;
+    size_t tws_capacity = 0;                // bytes behind d_tws (kept across batches like d_ws)
     int *d_prot_ptr = nullptr, *d_pharm_ptr = nullptr, *d_gid = nullptr, *d_reg = nullptr, *d_dyn_cnt = nullptr,
         *d_esrc = nullptr, *d_edst = nullptr, *d_in_start = nullptr, *d_in_cnt = nullptr, *d_pp_cnt = nullptr;
     EdgeTile* d_edge_tiles = nullptr;
@@ -226,6 +238,7 @@ struct pf_handle {
     int t_nblk = 0;
     const float* t_mask_override = nullptr; // pf_debug_set_dropout_masks
     bool t_have_fwd = false;
+    bool t_ws_ready = false;                // d_tws is carved (and its zero rows set) for the current batch
     TrainCommon t_common{};
     size_t flat_offset(const std::string& name) const {
         for (const auto& kv : flat_layout) if (kv.first == name) return kv.second.first;
@@ -597,8 +610,8 @@ static void pack_out_rg(pf_handle* h, std::vector<float>& out) {
 // hipMalloc / hipFree pair of a few hundred MB per batch costs milliseconds)
 static void free_ws(pf_handle* h, bool keep_ws = false) {
     if (h->d_ws && !keep_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; }
-    if (h->d_tws) (void)hipFree(h->d_tws);
-    h->d_tws = nullptr;
+    if (h->d_tws && !keep_ws) { (void)hipFree(h->d_tws); h->d_tws = nullptr; h->tws_capacity = 0; }
+    h->t_ws_ready = false;
     h->t_have_fwd = false;
     h->t_mask_override = nullptr;
     h->have_batch = false;
@@ -657,7 +670,16 @@ static bool encoders_on_the_fly(const pf_handle* h) {
 
 // ---- static hoist of conv layer 0 (pf_rg.hip: EdgeParams::zs) ----------------------------------------------------
 // usable for this handle / batch at all (inference, row-group kernels with encoders on the fly)
-static bool l0_hoist_ok(const pf_handle* h) {
+// The device-side one-hot check of pf_set_pocket_batch is read back lazily: only an inference call that could use the
+// static hoist waits for it (callers that pass the element types themselves never wait).
+static void l0_resolve_onehot(pf_handle* h) {
+    if (h->l0_state != 0) return;
+    if (h->l0flag_ev) (void)hipEventSynchronize(h->l0flag_ev);
+    h->l0_state = (h->Np > 0 && h->l0flag_host && *h->l0flag_host == 0) ? 1 : 2;
+    h->l0_onehot = h->l0_state == 1;
+}
+static bool l0_hoist_ok(pf_handle* h) {
+    if (h->l0_hoist && h->l0_state == 0) l0_resolve_onehot(h);
     const pf_config& c = h->cfg;
     return h->l0_hoist && h->l0_onehot && h->Epp > 0 && c.n_message_gvps >= 2 && c.rbf_dim == PF_R && c.rec_nf < 128 &&
            encoders_on_the_fly(h);
@@ -956,6 +978,9 @@ void pf_destroy(pf_handle* h) {
     if (h->d_map) (void)hipFree(h->d_map);
     if (h->d_l0c) (void)hipFree(h->d_l0c);
     if (h->d_ptab) (void)hipFree(h->d_ptab);
+    for (int k = 0; k < 2; ++k) { if (h->stage[k]) (void)hipHostFree(h->stage[k]); if (h->stage_ev[k]) (void)hipEventDestroy(h->stage_ev[k]); }
+    if (h->l0flag_host) (void)hipHostFree(h->l0flag_host);
+    if (h->l0flag_ev) (void)hipEventDestroy(h->l0flag_ev);
     for (int k = 0; k < pf_handle::K_NUM; ++k)
         for (auto& ev : h->prof_ev[k]) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete h;
@@ -1369,73 +1394,96 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
         for (int o = 0; o < cap_act[g]; o += 32) n_act.push_back({reg_act[g] + o, std::min(32, cap_act[g] - o), 0, 4 * B + g, o, 1});
     h->n_edge_tiles_act = (int)et_act.size();
     h->n_node_tiles_act = (int)n_act.size();
-    // ---- one workspace allocation
-    size_t bytes = 0;
-    auto need = [&](size_t b) { bytes += (b + 255) & ~size_t(255); };
-    need((B + 1) * 4); need((B + 1) * 4); need((size_t)N * 4); need((size_t)4 * B * 4); need((size_t)5 * B * 4);
-    need(et_act.size() * sizeof(EdgeTile) + 256); need(n_act.size() * sizeof(NodeTile) + 256); need((size_t)(act_total + 1) * 4); need((size_t)B * 4);
-    need(Ecap * 4); need(Ecap * 4); need((size_t)3 * N * 4); need((size_t)3 * N * 4); need((size_t)B * 4);
-    need(et_tiles.size() * sizeof(EdgeTile) + 256); need(n_tiles.size() * sizeof(NodeTile) + 256); need(h_tiles.size() * sizeof(NodeTile) + 256);
-    need((size_t)N * 16); need((size_t)Np * 3 * 4 + 16); need((size_t)Np * c.rec_nf * 4 + 16); need((size_t)Nf * c.pharm_nf * 4 + 16); need((size_t)B * 4);
-    need((size_t)N * PF_S * 4); need((size_t)N * PF_S * 4); need((size_t)N * 48 * 4); need((size_t)N * 48 * 4);
-    need((size_t)(Ecap + 1) * PF_S * 4); need((size_t)(Ecap + 1) * 48 * 4);
-    need((size_t)Nf * c.pharm_nf * 4 + 16); need((size_t)Nf * 3 * 4 + 16); need((size_t)B * 3 * 4); need((size_t)B * 3 * 4); need((size_t)2 * B * 4);
-    need((size_t)std::max(Np, 1) * PF_S * 4);
-    need(Ecap * 4); need((size_t)std::max(Np, 1) * 4); need(256); need((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4);
-    need((size_t)B * c.rec_nf * PF_S * 4);
-    need((size_t)B * 4);
-    // launches of the previous batch may still read the workspace (hipFree used to wait for them)
-    PF_HIP(h, hipDeviceSynchronize());
+    // ---- workspace layout: [table section: host-built, uploaded with one copy][zero section][scratch]
+    const size_t n_eta = et_act.size() + 16, n_nta = n_act.size() + 16, n_et = et_tiles.size() + 16, n_nt = n_tiles.size() + 16,
+                 n_ht = h_tiles.size() + 16;
+    auto rnd = [](size_t b) { return (b + 255) & ~size_t(255); };
+    size_t off = 0;
+    auto place = [&](size_t b) { const size_t o = off; off += rnd(b); return o; };
+    // table section
+    const size_t o_pptr = place((B + 1) * 4), o_fptr = place((B + 1) * 4), o_gid = place((size_t)N * 4), o_reg = place((size_t)4 * B * 4),
+                 o_regact = place((size_t)B * 4), o_eta = place(n_eta * sizeof(EdgeTile)), o_nta = place(n_nta * sizeof(NodeTile)),
+                 o_esrc = place(Ecap * 4), o_edst = place(Ecap * 4), o_ins = place((size_t)3 * N * 4), o_inc = place((size_t)3 * N * 4),
+                 o_ppc = place((size_t)B * 4), o_et = place(n_et * sizeof(EdgeTile)), o_nt = place(n_nt * sizeof(NodeTile)),
+                 o_ht = place(n_ht * sizeof(NodeTile)), o_pfq = place((size_t)B * 4);
+    const size_t table_bytes = off;
+    // zero section (cleared with one memset per bind)
+    const size_t o_dyn = place((size_t)5 * B * 4), o_act = place((size_t)(act_total + 1) * 4), o_flag = place(256), o_gnorm = place((size_t)2 * B * 4);
+    const size_t zero_bytes = off - table_bytes;
+    // scratch
+    const size_t o_xn = place((size_t)N * 16), o_px0 = place((size_t)Np * 3 * 4 + 16), o_ph0 = place((size_t)Np * c.rec_nf * 4 + 16),
+                 o_fh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_t = place((size_t)B * 4),
+                 o_h0 = place((size_t)N * PF_S * 4), o_h1 = place((size_t)N * PF_S * 4), o_v0 = place((size_t)N * 48 * 4), o_v1 = place((size_t)N * 48 * 4),
+                 o_ms = place((size_t)(Ecap + 1) * PF_S * 4), o_mv = place((size_t)(Ecap + 1) * 48 * 4),
+                 o_eh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_ex = place((size_t)Nf * 3 * 4 + 16), o_c0 = place((size_t)B * 3 * 4), o_c1 = place((size_t)B * 3 * 4),
+                 o_pre = place((size_t)std::max(Np, 1) * PF_S * 4), o_eorig = place(Ecap * 4), o_ptype = place((size_t)std::max(Np, 1) * 4),
+                 o_zs = place((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4), o_ptpg = place((size_t)B * c.rec_nf * PF_S * 4);
+    const size_t bytes = off;
+    bool fresh = false;
     if (h->ws_capacity < bytes + 4096) {
+        // launches of the previous batch may still read the old workspace
+        PF_HIP(h, hipDeviceSynchronize());
         if (h->d_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; }
-        PF_HIP(h, hipMalloc(&h->d_ws, bytes + 4096));
-        h->ws_capacity = bytes + 4096;
+        const size_t want = bytes + bytes / 8 + 4096;           // head room: the next batch of similar size fits without a realloc
+        PF_HIP(h, hipMalloc(&h->d_ws, want));
+        h->ws_capacity = want;
+        fresh = true;
     }
-    char* cur = reinterpret_cast<char*>(h->d_ws);
-    h->d_prot_ptr = carve<int>(cur, B + 1); h->d_pharm_ptr = carve<int>(cur, B + 1); h->d_gid = carve<int>(cur, N);
-    h->d_reg = carve<int>(cur, (size_t)4 * B); h->d_dyn_cnt = carve<int>(cur, (size_t)5 * B);
-    h->d_edge_tiles_act = carve<EdgeTile>(cur, et_act.size() + 16); h->d_node_tiles_act = carve<NodeTile>(cur, n_act.size() + 16);
-    h->d_act_ids = carve<int>(cur, (size_t)act_total + 1); h->d_reg_act = carve<int>(cur, B);
-    h->d_esrc = carve<int>(cur, Ecap); h->d_edst = carve<int>(cur, Ecap);
-    h->d_in_start = carve<int>(cur, (size_t)3 * N); h->d_in_cnt = carve<int>(cur, (size_t)3 * N); h->d_pp_cnt = carve<int>(cur, B);
-    h->d_edge_tiles = carve<EdgeTile>(cur, et_tiles.size() + 16); h->d_node_tiles = carve<NodeTile>(cur, n_tiles.size() + 16);
-    h->d_head_tiles = carve<NodeTile>(cur, h_tiles.size() + 16);
-    h->d_xn = carve<float4>(cur, N); h->d_prot_x0 = carve<float>(cur, (size_t)Np * 3 + 4); h->d_prot_h0 = carve<float>(cur, (size_t)Np * c.rec_nf + 4);
-    h->d_pharm_h = carve<float>(cur, (size_t)Nf * c.pharm_nf + 4); h->d_t = carve<float>(cur, B);
-    h->d_h[0] = carve<float>(cur, (size_t)N * PF_S); h->d_h[1] = carve<float>(cur, (size_t)N * PF_S);
-    h->d_v[0] = carve<float>(cur, (size_t)N * 48); h->d_v[1] = carve<float>(cur, (size_t)N * 48);
-    h->d_msg_s = carve<float>(cur, (size_t)(Ecap + 1) * PF_S); h->d_msg_v = carve<float>(cur, (size_t)(Ecap + 1) * 48);
-    h->d_eps_h = carve<float>(cur, (size_t)Nf * c.pharm_nf + 4); h->d_eps_x = carve<float>(cur, (size_t)Nf * 3 + 4);
-    h->d_com_init = carve<float>(cur, (size_t)B * 3); h->d_com_tmp = carve<float>(cur, (size_t)B * 3); h->d_gnorm = carve<float>(cur, (size_t)2 * B);
-    h->d_pre = carve<float>(cur, (size_t)std::max(Np, 1) * PF_S);
-    h->d_eorig = carve<int>(cur, Ecap); h->d_ptype = carve<int>(cur, std::max(Np, 1)); h->d_l0flag = carve<int>(cur, 64);
-    h->d_zs = carve<float>(cur, (size_t)std::max<int64_t>(n_pp, 1) * PF_S);
-    h->d_ptab_pg = carve<float>(cur, (size_t)B * c.rec_nf * PF_S);
-    h->d_pfq_cnt = pfq.empty() ? nullptr : carve<int>(cur, B);
-    if (h->d_pfq_cnt) PF_HIP(h, hipMemcpy(h->d_pfq_cnt, pfq.data(), (size_t)B * 4, hipMemcpyHostToDevice));
-    // ---- uploads (synchronous: these are small tables; pageable host memory)
-    PF_HIP(h, hipMemcpy(h->d_prot_ptr, prot_ptr, (B + 1) * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemcpy(h->d_pharm_ptr, pharm_ptr, (B + 1) * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemcpy(h->d_gid, gid.data(), (size_t)N * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemcpy(h->d_reg, h->h_reg.data(), (size_t)4 * B * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemset(h->d_dyn_cnt, 0, (size_t)5 * B * 4));
-    PF_HIP(h, hipMemcpy(h->d_reg_act, reg_act.data(), (size_t)B * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemset(h->d_act_ids, 0, (size_t)(act_total + 1) * 4));
-    if (!et_act.empty()) PF_HIP(h, hipMemcpy(h->d_edge_tiles_act, et_act.data(), et_act.size() * sizeof(EdgeTile), hipMemcpyHostToDevice));
-    if (!n_act.empty()) PF_HIP(h, hipMemcpy(h->d_node_tiles_act, n_act.data(), n_act.size() * sizeof(NodeTile), hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemcpy(h->d_esrc, esrc.data(), (size_t)Ecap * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemcpy(h->d_edst, edst.data(), (size_t)Ecap * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemset(h->d_l0flag, 0, 256));
-    PF_HIP(h, hipMemcpy(h->d_in_start, in_start.data(), (size_t)3 * N * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemcpy(h->d_in_cnt, in_cnt.data(), (size_t)3 * N * 4, hipMemcpyHostToDevice));
-    PF_HIP(h, hipMemcpy(h->d_pp_cnt, pp_cnt.data(), (size_t)B * 4, hipMemcpyHostToDevice));
-    if (!et_tiles.empty()) PF_HIP(h, hipMemcpy(h->d_edge_tiles, et_tiles.data(), et_tiles.size() * sizeof(EdgeTile), hipMemcpyHostToDevice));
-    if (!n_tiles.empty()) PF_HIP(h, hipMemcpy(h->d_node_tiles, n_tiles.data(), n_tiles.size() * sizeof(NodeTile), hipMemcpyHostToDevice));
-    if (!h_tiles.empty()) PF_HIP(h, hipMemcpy(h->d_head_tiles, h_tiles.data(), h_tiles.size() * sizeof(NodeTile), hipMemcpyHostToDevice));
+    char* const base = reinterpret_cast<char*>(h->d_ws);
+    auto at = [&](size_t o) { return base + o; };
+    h->d_prot_ptr = (int*)at(o_pptr); h->d_pharm_ptr = (int*)at(o_fptr); h->d_gid = (int*)at(o_gid); h->d_reg = (int*)at(o_reg);
+    h->d_reg_act = (int*)at(o_regact); h->d_edge_tiles_act = (EdgeTile*)at(o_eta); h->d_node_tiles_act = (NodeTile*)at(o_nta);
+    h->d_esrc = (int*)at(o_esrc); h->d_edst = (int*)at(o_edst); h->d_in_start = (int*)at(o_ins); h->d_in_cnt = (int*)at(o_inc);
+    h->d_pp_cnt = (int*)at(o_ppc); h->d_edge_tiles = (EdgeTile*)at(o_et); h->d_node_tiles = (NodeTile*)at(o_nt);
+    h->d_head_tiles = (NodeTile*)at(o_ht); h->d_pfq_cnt = pfq.empty() ? nullptr : (int*)at(o_pfq);
+    h->d_dyn_cnt = (int*)at(o_dyn); h->d_act_ids = (int*)at(o_act); h->d_l0flag = (int*)at(o_flag); h->d_gnorm = (float*)at(o_gnorm);
+    h->d_xn = (float4*)at(o_xn); h->d_prot_x0 = (float*)at(o_px0); h->d_prot_h0 = (float*)at(o_ph0); h->d_pharm_h = (float*)at(o_fh);
+    h->d_t = (float*)at(o_t); h->d_h[0] = (float*)at(o_h0); h->d_h[1] = (float*)at(o_h1); h->d_v[0] = (float*)at(o_v0); h->d_v[1] = (float*)at(o_v1);
+    h->d_msg_s = (float*)at(o_ms); h->d_msg_v = (float*)at(o_mv); h->d_eps_h = (float*)at(o_eh); h->d_eps_x = (float*)at(o_ex);
+    h->d_com_init = (float*)at(o_c0); h->d_com_tmp = (float*)at(o_c1); h->d_pre = (float*)at(o_pre); h->d_eorig = (int*)at(o_eorig);
+    h->d_ptype = (int*)at(o_ptype); h->d_zs = (float*)at(o_zs); h->d_ptab_pg = (float*)at(o_ptpg);
+    // ---- stage the tables in pinned memory and upload them with one asynchronous copy
+    const int sb = h->stage_next;
+    h->stage_next ^= 1;
+    if (!h->stage_ev[sb]) PF_HIP(h, hipEventCreateWithFlags(&h->stage_ev[sb], hipEventDisableTiming));
+    else PF_HIP(h, hipEventSynchronize(h->stage_ev[sb]));       // the copy that last read this buffer (two binds ago) is done
+    if (h->stage_cap[sb] < table_bytes) {
+        if (h->stage[sb]) (void)hipHostFree(h->stage[sb]);
+        h->stage[sb] = nullptr; h->stage_cap[sb] = 0;
+        PF_HIP(h, hipHostMalloc(&h->stage[sb], table_bytes + table_bytes / 4 + 4096, hipHostMallocDefault));
+        h->stage_cap[sb] = table_bytes + table_bytes / 4 + 4096;
+    }
+    char* const st = reinterpret_cast<char*>(h->stage[sb]);
+    memcpy(st + o_pptr, prot_ptr, (size_t)(B + 1) * 4);
+    memcpy(st + o_fptr, pharm_ptr, (size_t)(B + 1) * 4);
+    memcpy(st + o_gid, gid.data(), (size_t)N * 4);
+    memcpy(st + o_reg, h->h_reg.data(), (size_t)4 * B * 4);
+    memcpy(st + o_regact, reg_act.data(), (size_t)B * 4);
+    if (!et_act.empty()) memcpy(st + o_eta, et_act.data(), et_act.size() * sizeof(EdgeTile));
+    if (!n_act.empty()) memcpy(st + o_nta, n_act.data(), n_act.size() * sizeof(NodeTile));
+    memcpy(st + o_esrc, esrc.data(), (size_t)Ecap * 4);
+    memcpy(st + o_edst, edst.data(), (size_t)Ecap * 4);
+    memcpy(st + o_ins, in_start.data(), (size_t)3 * N * 4);
+    memcpy(st + o_inc, in_cnt.data(), (size_t)3 * N * 4);
+    memcpy(st + o_ppc, pp_cnt.data(), (size_t)B * 4);
+    if (!et_tiles.empty()) memcpy(st + o_et, et_tiles.data(), et_tiles.size() * sizeof(EdgeTile));
+    if (!n_tiles.empty()) memcpy(st + o_nt, n_tiles.data(), n_tiles.size() * sizeof(NodeTile));
+    if (!h_tiles.empty()) memcpy(st + o_ht, h_tiles.data(), h_tiles.size() * sizeof(NodeTile));
+    if (!pfq.empty()) memcpy(st + o_pfq, pfq.data(), (size_t)B * 4);
+    PF_HIP(h, hipMemcpyAsync(base, st, table_bytes, hipMemcpyHostToDevice, s));
+    PF_HIP(h, hipEventRecord(h->stage_ev[sb], s));
+    PF_HIP(h, hipMemsetAsync(base + table_bytes, 0, zero_bytes, s));
     PF_HIP(h, hipMemsetAsync(h->d_v[0], 0, (size_t)N * 48 * 4, s));
-    PF_HIP(h, hipMemsetAsync(h->d_gnorm, 0, (size_t)2 * B * 4, s));
-    PF_HIP(h, hipMemsetAsync(h->d_msg_s, 0, (size_t)(Ecap + 1) * PF_S * 4, s));     // incl. the zero row (index Ecap)
-    PF_HIP(h, hipMemsetAsync(h->d_msg_v, 0, (size_t)(Ecap + 1) * 48 * 4, s));
+    // Message rows: the node kernels read only rows the edge kernels of the same layer wrote (the last slot of every
+    // aligned group a destination's segment touches) and the all-zero row Ecap, so a reused workspace needs only that row
+    // cleared; a fresh allocation is cleared once in full
+    if (fresh) {
+        PF_HIP(h, hipMemsetAsync(h->d_msg_s, 0, (size_t)(Ecap + 1) * PF_S * 4, s));
+        PF_HIP(h, hipMemsetAsync(h->d_msg_v, 0, (size_t)(Ecap + 1) * 48 * 4, s));
+    } else {
+        PF_HIP(h, hipMemsetAsync(h->d_msg_s + (size_t)Ecap * PF_S, 0, PF_S * 4, s));
+        PF_HIP(h, hipMemsetAsync(h->d_msg_v + (size_t)Ecap * 48, 0, 48 * 4, s));
+    }
     h->zero_row = (int)Ecap;
     pfk_copy(dev_prot_x, h->d_prot_x0, (size_t)Np * 3, s);
     pfk_copy(dev_prot_h, h->d_prot_h0, (size_t)Np * c.rec_nf, s);
@@ -1446,16 +1494,26 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
         lp.zs = reinterpret_cast<float*>(h->d_eorig); lp.Epp = (int)Ecap;      // static slot of every edge slot: the identity
         pfk_l0_hoist(&lp, 2, s);
     }
-    PF_HIP(h, hipStreamSynchronize(s));
-    {
-        int flag = 1;
-        PF_HIP(h, hipMemcpy(&flag, h->d_l0flag, 4, hipMemcpyDeviceToHost));
-        h->l0_onehot = Np > 0 && flag == 0;
-    }
+    // the one-hot verdict of k_l0_types comes back through pinned memory; nobody waits for it here (l0_resolve_onehot)
+    if (!h->l0flag_host) PF_HIP(h, hipHostMalloc((void**)&h->l0flag_host, 64, hipHostMallocDefault));
+    if (!h->l0flag_ev) PF_HIP(h, hipEventCreateWithFlags(&h->l0flag_ev, hipEventDisableTiming));
+    else PF_HIP(h, hipEventSynchronize(h->l0flag_ev));           // the previous bind's read-back (long done) before its target is reused
+    *h->l0flag_host = 1;
+    PF_HIP(h, hipMemcpyAsync(h->l0flag_host, h->d_l0flag, 4, hipMemcpyDeviceToHost, s));
+    PF_HIP(h, hipEventRecord(h->l0flag_ev, s));
+    h->l0_state = 0; h->l0_onehot = false;
     h->zs_version = 0; h->zs_batch_coords = false; h->coords_custom = false;
     h->have_batch = true;
     h->sampling = false;
     h->edges_built = false;
+    return PF_OK;
+}
+
+int pf_declare_onehot_features(pf_handle* h, int32_t is_onehot) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    h->l0_state = is_onehot ? 1 : 2;
+    h->l0_onehot = is_onehot != 0 && h->Np > 0;
     return PF_OK;
 }
 
@@ -1713,7 +1771,7 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
 // gradient path (training step): forward that keeps the per-layer state, backward, parameter layout
 // ------------------------------------------------------------------------------------------------
 static int ensure_train_ws(pf_handle* h, hipStream_t s) {
-    if (h->d_tws) return PF_OK;
+    if (h->d_tws && h->t_ws_ready) return PF_OK;
     const pf_config& c = h->cfg;
     if (c.n_message_gvps > PFT_MAX_CHAIN || c.n_noise_gvps > PFT_MAX_CHAIN || c.n_update_gvps > 3)
         PF_FAIL(h, PF_ERR_ARG, "training supports at most %d message / noise GVPs and 3 update GVPs per chain", PFT_MAX_CHAIN);
@@ -1732,7 +1790,17 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     const size_t Es = (size_t)std::max<int64_t>(h->Ecap, 1), ng = (size_t)c.n_message_gvps;
     for (int l = 0; l < L; ++l) { need(ng * Es * PF_S); need(ng * Es * 16); need(ng * Es * 48); }
     need(Es * PF_S); need(Es * 48);
-    PF_HIP(h, hipMalloc(&h->d_tws, bytes + 4096));
+    // like d_ws the allocation outlives the batch: a training loop binds a new batch every step, and a hipFree / hipMalloc
+    // pair of a few GB (plus clearing it) per step cost two orders of magnitude more than the step itself
+    bool fresh = false;
+    if (h->tws_capacity < bytes + 4096) {
+        PF_HIP(h, hipDeviceSynchronize());
+        if (h->d_tws) { (void)hipFree(h->d_tws); h->d_tws = nullptr; h->tws_capacity = 0; }
+        const size_t want = bytes + bytes / 8 + 4096;
+        PF_HIP(h, hipMalloc(&h->d_tws, want));
+        h->tws_capacity = want;
+        fresh = true;
+    }
     char* cur = reinterpret_cast<char*>(h->d_tws);
     h->t_H.assign(L + 1, nullptr); h->t_V.assign(L + 1, nullptr); h->t_msg_s.assign(L, nullptr); h->t_msg_v.assign(L, nullptr);
     for (int l = 0; l <= L; ++l) { h->t_H[l] = carve<float>(cur, (size_t)N * PF_S); h->t_V[l] = carve<float>(cur, (size_t)N * 48); }
@@ -1747,11 +1815,18 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     }
     h->t_gs_buf = carve<float>(cur, Es * PF_S); h->t_gv_buf = carve<float>(cur, Es * 48);
     // message buffers: the zero row (index Ecap) must read as zeros; V[0] is the all-zero initial vector state
+    // (only rows written by the same forward and the zero row are ever read: a reused allocation needs just that row)
     for (int l = 0; l < L; ++l) {
-        PF_HIP(h, hipMemsetAsync(h->t_msg_s[l], 0, E1 * PF_S * 4, s));
-        PF_HIP(h, hipMemsetAsync(h->t_msg_v[l], 0, E1 * 48 * 4, s));
+        if (fresh) {
+            PF_HIP(h, hipMemsetAsync(h->t_msg_s[l], 0, E1 * PF_S * 4, s));
+            PF_HIP(h, hipMemsetAsync(h->t_msg_v[l], 0, E1 * 48 * 4, s));
+        } else {
+            PF_HIP(h, hipMemsetAsync(h->t_msg_s[l] + (E1 - 1) * PF_S, 0, PF_S * 4, s));
+            PF_HIP(h, hipMemsetAsync(h->t_msg_v[l] + (E1 - 1) * 48, 0, 48 * 4, s));
+        }
     }
     PF_HIP(h, hipMemsetAsync(h->t_V[0], 0, (size_t)N * 48 * 4, s));
+    h->t_ws_ready = true;
     return PF_OK;
 }
 

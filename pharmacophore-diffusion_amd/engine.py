@@ -82,8 +82,22 @@ class PfEngine:
             self._ck(self.lib.pf_commit_weights(self._h), "pf_commit_weights")
 
     # -- static batch --------------------------------------------------------------------------
+    def _upload(self, t: torch.Tensor) -> torch.Tensor:
+        """fp32 device copy of a host tensor through pinned memory (a pageable host -> device copy waits for everything
+        already enqueued on the stream, i.e. for the previous batch); device tensors pass through."""
+        if t.is_cuda:
+            return _f32(t, self.device)
+        return t.detach().to(torch.float32).contiguous().pin_memory().to(self.device, non_blocking=True)
+
     def set_batch(self, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst):
-        px, ph = _f32(prot_x, self.device), _f32(prot_h, self.device)
+        """pf_set_pocket_batch: asynchronous on the current stream.  When the protein features are on the host their
+        one-hot-ness is checked here (a few hundred microseconds) and declared to the library, so that no later call
+        waits for the device-side check; device-resident features are checked on the device, lazily."""
+        onehot = None
+        if not prot_h.is_cuda:
+            ph_host = prot_h.detach()
+            onehot = bool(ph_host.numel() > 0 and ((ph_host == 0) | (ph_host == 1)).all() and (ph_host.sum(dim=1) == 1).all())
+        px, ph = self._upload(prot_x), self._upload(prot_h)
         pptr = prot_ptr.to("cpu", torch.int32).contiguous()
         fptr = pharm_ptr.to("cpu", torch.int32).contiguous()
         src = pp_src.to("cpu", torch.int32).contiguous()
@@ -95,6 +109,8 @@ class PfEngine:
                                                   int(src.numel()), src.data_ptr() if src.numel() else None,
                                                   dst.data_ptr() if dst.numel() else None, _stream_ptr()),
                      "pf_set_pocket_batch")
+            if onehot is not None:
+                self._ck(self.lib.pf_declare_onehot_features(self._h, int(onehot)), "pf_declare_onehot_features")
 
     def build_pp_edges(self, prot_x, prot_ptr, max_num_neighbors=100):
         px = _f32(prot_x, self.device)

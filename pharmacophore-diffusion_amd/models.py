@@ -504,7 +504,7 @@ class PharmacophoreDiff(_Base):
         reference run means passing its draws here.  When omitted all T+1 draws come from ONE torch.randn call on the
         model's device (same distribution, reproducible under torch.manual_seed; the reference's 2(T+1) separate calls
         would cost a thousand launches per batch and cannot reproduce a CUDA generator's stream on ROCm anyway)."""
-        return self._sample_finish(self._sample_enqueue(g, init_pharm_com, visualize_trajectory, noise))
+        return self._sample_finish(self._sample_fetch(self._sample_enqueue(g, init_pharm_com, visualize_trajectory, noise)))
 
     def _sample_enqueue(self, g, init_pharm_com=None, visualize_trajectory=False, noise=None):
         """First half of sample_given_receptor: upload the batch and enqueue the whole reverse process (asynchronous)."""
@@ -518,20 +518,30 @@ class PharmacophoreDiff(_Base):
         if getattr(self, "_coef_arr", None) is None or self._coef_arr[0] != T:      # 500-1000 ctypes structs: built once
             self._coef_arr = (T, eng.coef_array(coef, reversed(range(T))))
         arr = self._coef_arr[1]
-        com = None if init_pharm_com is None else init_pharm_com.to(dev)
-        res = eng.sample(arr, T, noise.to(dev), init_pharm_com=com, ep_coord=self.endpoint_param_coord,
+        com = None
+        if init_pharm_com is not None:
+            com = init_pharm_com if init_pharm_com.is_cuda else init_pharm_com.float().pin_memory().to(dev, non_blocking=True)
+        res = eng.sample(arr, T, noise if noise.is_cuda else noise.float().pin_memory().to(dev, non_blocking=True),
+                         init_pharm_com=com, ep_coord=self.endpoint_param_coord,
                          ep_feat=self.endpoint_param_feat, feat_norm_constant=float(self.pharm_feat_norm_constant),
                          trajectory=visualize_trajectory)
-        return g, res, visualize_trajectory
+        # results go to pinned host memory with copies enqueued right behind the batch's kernels, and an event marks their
+        # completion: whatever is enqueued afterwards (the next batch) does not delay the fetch of this one
+        host = tuple(None if r is None else torch.empty(r.shape, dtype=r.dtype, pin_memory=True).copy_(r, non_blocking=True)
+                     for r in res)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        return g, host, visualize_trajectory, done
 
     def _sample_fetch(self, pending):
-        """Results of an enqueued batch on the host (waits for the device)."""
-        g, res, traj = pending
-        return g, tuple(r.cpu() if r is not None else None for r in res), traj
+        """Results of an enqueued batch on the host (waits for that batch only)."""
+        g, host, traj, done = pending
+        done.synchronize()
+        return g, host, traj
 
     def _sample_finish(self, pending) -> List[SampledPharmacophore]:
         """Second half: per-graph SampledPharmacophores (host work only once the results are fetched)."""
-        g, res, visualize_trajectory = pending
+        g, res, visualize_trajectory = pending[:3]
         x0, h0 = res[0].cpu(), res[1].cpu()
         traj_x = res[2].cpu() if visualize_trajectory else None
         traj_h = res[3].cpu() if visualize_trajectory else None
@@ -581,9 +591,10 @@ class PharmacophoreDiff(_Base):
         T, nf = self.n_timesteps, self.n_pharm_feats
         base_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else 0
         sampled = {}
-        # Two-stage pipeline over the batches: the host work of a batch (collating the next one, splitting the previous
-        # one's results into SampledPharmacophores) runs while the device works on another batch; only the upload of a
-        # batch (one workspace per handle) waits for the batch before it.  The batched graph stays on the host: the engine
+        # Pipeline over the batches: the host work of a batch (collating the next one, splitting the previous one's results
+        # into SampledPharmacophores) runs while the device works on another batch.  Nothing in it waits for the device
+        # except the fetch of a finished batch: uploads go through pinned memory, pf_set_pocket_batch is asynchronous, and
+        # the one workspace of the handle is reused in stream order.  The batched graph stays on the host: the engine
         # uploads what it needs once, and the per-graph views are host tensors anyway.
         pending = None                                  # (idx, enqueued batch)
         def finish(done):
@@ -592,18 +603,18 @@ class PharmacophoreDiff(_Base):
         for bi in mine:
             idx = batches[bi]
             batch_g = batch_graphs([graphs[i] for i in idx])
-            init_coms = init_pharm_com[[graph_ref_idx[i] for i in idx]].to(self.device)
+            init_coms = init_pharm_com[[graph_ref_idx[i] for i in idx]]
             if noise is None:
                 gen = torch.Generator(device=self.device).manual_seed(base_seed + bi)
                 nz = torch.randn(T + 1, batch_g.num_nodes("pharm"), 3 + nf, device=self.device, generator=gen)
             else:
                 nz = noise[bi]
-            done = None
+            # the bind is asynchronous (stream-ordered behind the previous batch's kernels), so this batch is enqueued
+            # BEFORE the previous one is fetched: the device goes from one batch straight into the next
+            nxt = (idx, self._sample_enqueue(batch_g, init_coms, visualize_trajectory, nz))
             if pending is not None:
-                done = (pending[0], self._sample_fetch(pending[1]))     # waits for the device: the workspace is free again
-            pending = (idx, self._sample_enqueue(batch_g, init_coms, visualize_trajectory, nz))
-            if done is not None:
-                finish(done)                            # while the device runs the batch just enqueued
+                finish((pending[0], self._sample_fetch(pending[1])))    # while the device runs the batch just enqueued
+            pending = nxt
         if pending is not None:
             finish((pending[0], self._sample_fetch(pending[1])))
         per_pocket, end = [], 0
@@ -725,17 +736,23 @@ class PharmacophoreDiff(_Base):
         fractional epoch is tracked and, every ``sample_interval`` epochs, sample_and_analyze runs inside the step
         and its metrics join the logged ones (:281-284); without one (a bare loop over tensors) that part is skipped."""
         phase = 'train'
+        tr = self._trainer_ctx()
+        ph_quality_metrics, epoch_exact = {}, None
+        if tr is not None and tr.train_dataloader is not None:
+            epoch_exact = tr.current_epoch + batch_idx / max(len(tr.train_dataloader), 1)       # :270
+            if epoch_exact - self.last_sample_marker >= self.sample_interval and tr.datamodule is not None:   # :281
+                # sampled BEFORE this step's forward (the reference samples between its forward and the caller's
+                # backward, :273-284): the engine keeps the activations of one training forward at a time, and sampling
+                # rebinds its workspace; the losses / metrics do not depend on the order, only the RNG stream does
+                ph_quality_metrics = self.sample_and_analyze()
+                self.last_sample_marker = epoch_exact
         loss_dict, metrics_dict = self.forward(batch, phase=phase, t_int=t_int, eps=eps)
         loss_dict[phase + ' total loss'] = torch.sum(torch.stack(list(loss_dict.values()), dim=0))
         metrics_dict[phase + ' total error'] = metrics_dict[phase + ' position error'] + 1 - metrics_dict[phase + ' accuracy']
         metrics_dict[phase + ' weighted total error'] = (metrics_dict[phase + ' weighted position error'] + 1
                                                          - metrics_dict[phase + ' weighted accuracy'])
-        tr = self._trainer_ctx()
-        if tr is not None and tr.train_dataloader is not None:
-            epoch_exact = tr.current_epoch + batch_idx / max(len(tr.train_dataloader), 1)       # :270
-            if epoch_exact - self.last_sample_marker >= self.sample_interval and tr.datamodule is not None:   # :281
-                metrics_dict.update(self.sample_and_analyze())
-                self.last_sample_marker = epoch_exact
+        metrics_dict.update(ph_quality_metrics)
+        if epoch_exact is not None:
             if tr.optimizer is not None:
                 metrics_dict['lr'] = tr.optimizer.param_groups[0]['lr']                          # :287-290
             loss_dict['epoch_exact'] = epoch_exact

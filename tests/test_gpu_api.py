@@ -180,6 +180,57 @@ def test_multi_pocket_ragged_sampling_and_checkpoint(tmp_path):
     assert [len(a) + len(b) for a, b in zip(r0, r1)] == [2, 1, 3]
 
 
+def test_sample_multi_pocket_matches_reference_golden():
+    """PharmacophoreDiff.sample + copy_graph against the reference's own run (tests/golden/sample_multi.npz:
+    pharmacodiff.py:516-578 over three pockets of 40 / 52 / 33 atoms, requests [[3,4],[5],[8,3,6]], batches of 4, explicit
+    init_pharm_com, its noise draws injected per batch): per-pocket grouping, sizes, coordinates, features, xyz text, and
+    the protein frame the samples are returned in."""
+    z = load("sample_multi.npz")
+    cfg = O.DynamicsConfig()
+    m = make_model(int(z["T"]), int(z["wseed"]))
+    pockets = [graph_from(O.synthetic_batch([int(s)], int(n), 1, cfg)) for s, n in zip(z["pocket_seeds"], z["pocket_n_prot"])]
+    sizes, per = z["n_pharms_flat"].tolist(), z["n_pharms_per_pocket"].tolist()
+    n_pharms, k = [], 0
+    for c in per:
+        n_pharms.append(sizes[k:k + c]); k += c
+    out = m.sample(pockets, n_pharms, max_batch_size=int(z["max_batch_size"]), init_pharm_com=z["init_pharm_com"],
+                   noise=[z["noise_0"], z["noise_1"]])
+    assert [len(o) for o in out] == per and [[p.n_ph_centers for p in o] for o in out] == n_pharms
+    flat = [p for o in out for p in o]
+    torch.testing.assert_close(torch.cat([p.ph_coords for p in flat]), z["x0"], rtol=5e-3, atol=5e-3)
+    torch.testing.assert_close(torch.cat([p.g.pharm_h0 for p in flat]), z["h0"], rtol=5e-3, atol=5e-3)
+    ours = [l.split() for l in "".join(p.to_xyz_file() for p in flat).splitlines()]
+    ref = [l.split() for l in str(z["xyz"]).splitlines()]
+    assert len(ours) == len(ref)
+    for a, b in zip(ours, ref):
+        assert a[0] == b[0] and all(abs(float(u) - float(v)) <= 6e-3 for u, v in zip(a[1:], b[1:])), (a, b)
+
+
+def test_bind_graph_rebinds_look_alike_batches():
+    """Two batches with the same totals (same pocket, center counts [3, 5] vs [5, 3]) passed as temporaries: the second
+    call must not run on the first batch's graph boundaries (the cache key holds the ptr contents and the module keeps
+    the bound tensors alive, so addresses cannot be recycled into a false hit)."""
+    cfg = O.DynamicsConfig()
+    m = make_model(100)
+    pocket = O.synthetic_batch([77], 48, 1, cfg)
+    gen = torch.Generator().manual_seed(2)
+    x_t, h_t = torch.randn(8, 3, generator=gen), torch.randn(8, 6, generator=gen)
+    t = torch.tensor([0.3, 0.7])
+    outs = []
+    for sizes in ([3, 5], [5, 3]):
+        b = O.concat_pockets([O.copy_pocket(pocket, n) for n in sizes])
+        def call():
+            g = graph_from(b).to("cuda")           # a temporary: freed when call() returns
+            g.x_t, g.h_t = x_t.cuda(), h_t.cuda()
+            return m.dynamics(g, t.cuda(), None)
+        eh, ex = call()
+        oh, ox = O.dynamics_forward(O.make_state_dict(cfg, 0), cfg, b, b.prot_x, x_t, h_t, t)
+        torch.testing.assert_close(eh.cpu(), oh, rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(ex.cpu(), ox, rtol=2e-4, atol=2e-4)
+        outs.append(eh.cpu())
+    assert not torch.allclose(outs[0], outs[1])
+
+
 def test_full_size_config2_batch_properties():
     """BASELINE config 2 at full size (B=32 x 256 atoms x 6 centers), 25 steps of the T=500 schedule:
     finite, bitwise reproducible, and invariant to a rigid motion of the whole input (the sampler's
@@ -411,6 +462,101 @@ def test_dataset_sampling_driver(tmp_path, world):
     metrics = dict(l.split(": ") for l in (out / "metrics.txt").read_text().splitlines())
     assert 0.0 <= float(metrics["validity"]) <= 1.0
     assert sum(eval((out / "pharm_counts_None.txt").read_text())) == 5 * 12
+
+
+def test_train_driver_two_ranks_keep_identical_replicas(tmp_path):
+    """train.py under torchrun with 2 ranks (sharing this box's one GPU: gloo collectives through the host; RCCL when the
+    box has two): rank 0's weights are broadcast, gradients averaged every step, the validation loss all-reduced --
+    --check_replicas verifies bitwise-identical parameters on all ranks after every epoch; the checkpoint carries the
+    optimiser state and a resumed run continues from it."""
+    import subprocess
+    import sys
+    import yaml
+    import os
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(0)
+    proc = tmp_path / "processed"
+    for split in range(3):
+        d = proc / f"split_{split}"
+        d.mkdir(parents=True)
+        n_g = 8
+        np_, nf_ = np.full(n_g, 40), rng.integers(3, 8, n_g)
+        pos = np.concatenate([O.synthetic_pocket(100 * split + i, 40)[0].numpy() for i in range(n_g)]).astype(np.float32)
+
+        def idx(c):
+            e = np.cumsum(c)
+            return np.stack([e - c, e], 1)
+        np.savez(d / 'prot_pharm_tensors.npz', prot_pos=pos, prot_feat=rng.integers(0, 4, np_.sum()), prot_idx=idx(np_),
+                 pharm_pos=(rng.normal(size=(nf_.sum(), 3)) * 3).astype(np.float32), pharm_feat=rng.integers(0, 6, nf_.sum()),
+                 pharm_idx=idx(nf_), prot_ph_pos=np.zeros((0, 3), np.float32), prot_ph_feat=np.zeros((0,), np.int64),
+                 prot_ph_idx=np.zeros((n_g, 2), np.int64))
+    cfg = yaml.safe_load(open(os.path.join(root, "tests", "golden", "dev_config_subset.yml")))
+    cfg['dataset'].update(processed_data_dir=str(proc), raw_data_dir=str(tmp_path), pocket_cutoff=8)
+    cfg['training'].update(output_dir=str(tmp_path / "runs"), batch_size=4, num_workers=0, validation_splits=[2])
+    cfg['training'].setdefault('trainer_args', {})['max_epochs'] = 2
+    cfg['training']['evaluation']['sample_interval'] = 1000          # no sampling inside these few steps
+    cfg.setdefault('wandb', {})['name'] = 'dp'
+    yaml.dump(cfg, open(tmp_path / "cfg.yml", "w"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29687", os.path.join(root, "train.py"), "--config", str(tmp_path / "cfg.yml"), "--seed", "0",
+           "--check_replicas"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.count("replicas identical on 2 ranks") == 2, r.stdout[-2000:]
+    ck = list((tmp_path / "runs").glob("*/checkpoints/last.ckpt"))
+    assert len(ck) == 1
+    saved = torch.load(str(ck[0]), map_location="cpu", weights_only=False)
+    assert saved['epoch'] == 1 and saved['global_step'] == 4
+    st = saved['optimizer_states'][0]['state']
+    assert st['step'] == 4 and float(st['exp_avg_sq'].abs().sum()) > 0 and 'best' in saved['lr_schedulers'][0]
+    # resume: one more epoch from the saved optimiser state
+    cfg['training']['trainer_args']['max_epochs'] = 3
+    yaml.dump(cfg, open(tmp_path / "cfg.yml", "w"))
+    r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--config", str(tmp_path / "cfg.yml"), "--seed", "0",
+                        "--resume", str(ck[0])], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "epoch 2:" in r.stdout and "epoch 0:" not in r.stdout
+    newest = max((tmp_path / "runs").glob("*/checkpoints/last.ckpt"), key=lambda p: p.stat().st_mtime)
+    again = torch.load(str(newest), map_location="cpu", weights_only=False)
+    assert again['epoch'] == 2 and again['optimizer_states'][0]['state']['step'] > 4
+
+
+def _rccl_rank_fn(rank, world, port, q):
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
+    z = load("train_grads.npz")
+    m = make_model(int(z["T"])).to(dev)
+    m.train()
+    g = graph_from(batch_from(z), z["x0"], z["h0"]).to(dev)
+    torch.manual_seed(3 + rank)                                     # different dropout draws per rank
+    m.training_step(g, 0, t_int=z["t_int"].long(), eps={'h': z["eps_h"], 'x': z["eps_x"]}).backward()
+    own = m.dynamics._last_flat_grad.clone()
+    flat = m.dynamics.allreduce_gradients(average=True)             # RCCL all-reduce of the flat gradient
+    gathered = [torch.zeros_like(own) for _ in range(world)]
+    dist.all_gather(gathered, own)
+    ok = torch.allclose(flat, sum(gathered) / world, rtol=1e-6, atol=1e-9)
+    ph = pfa.SampledPharmacophore(graph_from(batch_from(load("traj_c1.npz")), load("traj_c1.npz")["x0"], load("traj_c1.npz")["h0"]),
+                                  pfa.analysis.ph_idx_to_type)
+    freq = pfa.SampleAnalyzer().pharm_feat_freq([ph], process_group=dist.group.WORLD)      # NCCL branch: device buffer
+    q.put((rank, bool(ok), float(freq.sum())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL is one rank per GPU (not substituted by gloo)")
+def test_two_rank_rccl_gradient_allreduce_and_metrics():
+    """A real 2-rank RCCL run (skipped on a one-GPU box): the flat-gradient all-reduce averages the two ranks' gradients,
+    and the metric counters are reduced through a device buffer."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_rank_fn, args=(r, 2, 29711, q)) for r in range(2)]
+    [p.start() for p in procs]
+    out = sorted(q.get(timeout=600) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(ok for _, ok, _ in out) and out[0][2] == out[1][2] == 8.0
 
 
 def test_gradient_views_accumulate_clear_and_allreduce_in_place():
