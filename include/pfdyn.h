@@ -109,6 +109,13 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* host_prot_ptr, c
                         const float* dev_prot_x, const float* dev_prot_h,
                         int64_t n_pp, const int32_t* host_pp_src, const int32_t* host_pp_dst, pf_stream stream);
 
+/* The same bind for callers whose pocket data lives on the HOST (the sampling drivers batch pockets on the host):
+ * prot_x [Np,3] / prot_h [Np,rec_nf] are host fp32 arrays; they travel in the same single staged upload as the index
+ * tables and the one-hot check runs on the host copy, so the call never waits for the device. */
+int pf_set_pocket_batch_host(pf_handle* h, int32_t B, const int32_t* host_prot_ptr, const int32_t* host_pharm_ptr,
+                             const float* host_prot_x, const float* host_prot_h,
+                             int64_t n_pp, const int32_t* host_pp_src, const int32_t* host_pp_dst, pf_stream stream);
+
 /* Optional, right after pf_set_pocket_batch: the caller states whether every row of prot_h is an element one-hot
  * (what the reference's dataset / CLI always produce: protein_pharm_dataset.py:129, generate_pharmacophores.py:105-118).
  * pf_set_pocket_batch checks this on the device and the first inference call that wants the answer waits for it; a caller

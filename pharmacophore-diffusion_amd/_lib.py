@@ -40,6 +40,7 @@ SYMBOLS = {
     "pf_set_weight": (ctypes.c_int, [_P, ctypes.c_char_p, _P, _I32, ctypes.POINTER(_I64)]),
     "pf_commit_weights": (ctypes.c_int, [_P]),
     "pf_set_pocket_batch": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "pf_set_pocket_batch_host": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "pf_declare_onehot_features": (ctypes.c_int, [_P, _I32]),
     "pf_build_pp_edges": (_I64, [_P, _I32, _P, _P, _I32, _P, _P, _I64, _P]),
     "pf_dynamics_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),

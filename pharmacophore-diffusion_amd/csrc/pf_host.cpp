@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -1259,12 +1260,15 @@ int pf_commit_weights(pf_handle* h) {
     return PF_OK;
 }
 
-int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const int32_t* pharm_ptr,
-                        const float* dev_prot_x, const float* dev_prot_h, int64_t n_pp, const int32_t* pp_src,
-                        const int32_t* pp_dst, pf_stream stream) {
+// prot_x / prot_h come either as device pointers (copied on the stream) or as host pointers (staged with the tables)
+static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_ptr, const int32_t* pharm_ptr,
+                                 const float* dev_prot_x, const float* dev_prot_h, const float* host_prot_x, const float* host_prot_h,
+                                 int64_t n_pp, const int32_t* pp_src, const int32_t* pp_dst, pf_stream stream) {
     int rc = check_ready(h, false);
     if (rc) return rc;
-    if (B < 1 || !prot_ptr || !pharm_ptr || !dev_prot_x || !dev_prot_h || n_pp < 0 || (n_pp && (!pp_src || !pp_dst)))
+    const bool from_host = host_prot_x != nullptr;
+    if (B < 1 || !prot_ptr || !pharm_ptr || (from_host ? !host_prot_h : (!dev_prot_x || !dev_prot_h)) || n_pp < 0 ||
+        (n_pp && (!pp_src || !pp_dst)))
         PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_batch: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const pf_config& c = h->cfg;
@@ -1274,6 +1278,11 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
         if (pharm_ptr[g + 1] - pharm_ptr[g] > PF_MAXF)
             PF_FAIL(h, PF_ERR_ARG, "graph %d has %d pharmacophore centers (limit %d)", g, pharm_ptr[g + 1] - pharm_ptr[g], PF_MAXF);
     }
+    static const bool timing = getenv("PFDYN_TIMING") != nullptr;
+    double tm[8] = {0}; int tmi = 0;
+    auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    auto mark = [&] { if (timing && tmi < 8) tm[tmi++] = now(); };
+    mark();
     free_ws(h, true);
     h->B = B; h->Np = prot_ptr[B]; h->Nf = pharm_ptr[B]; h->N = h->Np + h->Nf; h->Epp = n_pp;
     h->h_prot_ptr.assign(prot_ptr, prot_ptr + B + 1);
@@ -1394,6 +1403,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
         for (int o = 0; o < cap_act[g]; o += 32) n_act.push_back({reg_act[g] + o, std::min(32, cap_act[g] - o), 0, 4 * B + g, o, 1});
     h->n_edge_tiles_act = (int)et_act.size();
     h->n_node_tiles_act = (int)n_act.size();
+    mark();      // 1: host tables built
     // ---- workspace layout: [table section: host-built, uploaded with one copy][zero section][scratch]
     const size_t n_eta = et_act.size() + 16, n_nta = n_act.size() + 16, n_et = et_tiles.size() + 16, n_nt = n_tiles.size() + 16,
                  n_ht = h_tiles.size() + 16;
@@ -1406,12 +1416,15 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
                  o_esrc = place(Ecap * 4), o_edst = place(Ecap * 4), o_ins = place((size_t)3 * N * 4), o_inc = place((size_t)3 * N * 4),
                  o_ppc = place((size_t)B * 4), o_et = place(n_et * sizeof(EdgeTile)), o_nt = place(n_nt * sizeof(NodeTile)),
                  o_ht = place(n_ht * sizeof(NodeTile)), o_pfq = place((size_t)B * 4);
-    const size_t table_bytes = off;
+    const size_t index_bytes = off;
+    const size_t o_px0 = place((size_t)Np * 3 * 4 + 16), o_ph0 = place((size_t)Np * c.rec_nf * 4 + 16);
+    const size_t table_bytes = from_host ? off : index_bytes;      // what the single upload covers
+    const size_t table_end = off;
     // zero section (cleared with one memset per bind)
     const size_t o_dyn = place((size_t)5 * B * 4), o_act = place((size_t)(act_total + 1) * 4), o_flag = place(256), o_gnorm = place((size_t)2 * B * 4);
-    const size_t zero_bytes = off - table_bytes;
+    const size_t zero_bytes = off - table_end;
     // scratch
-    const size_t o_xn = place((size_t)N * 16), o_px0 = place((size_t)Np * 3 * 4 + 16), o_ph0 = place((size_t)Np * c.rec_nf * 4 + 16),
+    const size_t o_xn = place((size_t)N * 16),
                  o_fh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_t = place((size_t)B * 4),
                  o_h0 = place((size_t)N * PF_S * 4), o_h1 = place((size_t)N * PF_S * 4), o_v0 = place((size_t)N * 48 * 4), o_v1 = place((size_t)N * 48 * 4),
                  o_ms = place((size_t)(Ecap + 1) * PF_S * 4), o_mv = place((size_t)(Ecap + 1) * 48 * 4),
@@ -1442,6 +1455,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     h->d_msg_s = (float*)at(o_ms); h->d_msg_v = (float*)at(o_mv); h->d_eps_h = (float*)at(o_eh); h->d_eps_x = (float*)at(o_ex);
     h->d_com_init = (float*)at(o_c0); h->d_com_tmp = (float*)at(o_c1); h->d_pre = (float*)at(o_pre); h->d_eorig = (int*)at(o_eorig);
     h->d_ptype = (int*)at(o_ptype); h->d_zs = (float*)at(o_zs); h->d_ptab_pg = (float*)at(o_ptpg);
+    mark();      // 2: workspace ready
     // ---- stage the tables in pinned memory and upload them with one asynchronous copy
     const int sb = h->stage_next;
     h->stage_next ^= 1;
@@ -1453,6 +1467,7 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
         PF_HIP(h, hipHostMalloc(&h->stage[sb], table_bytes + table_bytes / 4 + 4096, hipHostMallocDefault));
         h->stage_cap[sb] = table_bytes + table_bytes / 4 + 4096;
     }
+    mark();      // 3: staging buffer ready
     char* const st = reinterpret_cast<char*>(h->stage[sb]);
     memcpy(st + o_pptr, prot_ptr, (size_t)(B + 1) * 4);
     memcpy(st + o_fptr, pharm_ptr, (size_t)(B + 1) * 4);
@@ -1470,9 +1485,26 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     if (!n_tiles.empty()) memcpy(st + o_nt, n_tiles.data(), n_tiles.size() * sizeof(NodeTile));
     if (!h_tiles.empty()) memcpy(st + o_ht, h_tiles.data(), h_tiles.size() * sizeof(NodeTile));
     if (!pfq.empty()) memcpy(st + o_pfq, pfq.data(), (size_t)B * 4);
+    int host_onehot = -1;
+    if (from_host) {
+        memcpy(st + o_px0, host_prot_x, (size_t)Np * 3 * 4);
+        memcpy(st + o_ph0, host_prot_h, (size_t)Np * c.rec_nf * 4);
+        // the one-hot verdict (static hoist) on the host copy: nobody will wait for the device-side check
+        host_onehot = Np > 0 ? 1 : 0;
+        for (int i = 0; i < Np && host_onehot; ++i) {
+            int ones = 0;
+            for (int k = 0; k < c.rec_nf; ++k) {
+                const float x = host_prot_h[(size_t)i * c.rec_nf + k];
+                if (x == 1.0f) ++ones; else if (x != 0.0f) host_onehot = 0;
+            }
+            if (ones != 1) host_onehot = 0;
+        }
+    }
+    mark();      // 4: staged
     PF_HIP(h, hipMemcpyAsync(base, st, table_bytes, hipMemcpyHostToDevice, s));
     PF_HIP(h, hipEventRecord(h->stage_ev[sb], s));
-    PF_HIP(h, hipMemsetAsync(base + table_bytes, 0, zero_bytes, s));
+    mark();      // 5: upload enqueued
+    PF_HIP(h, hipMemsetAsync(base + table_end, 0, zero_bytes, s));
     PF_HIP(h, hipMemsetAsync(h->d_v[0], 0, (size_t)N * 48 * 4, s));
     // Message rows: the node kernels read only rows the edge kernels of the same layer wrote (the last slot of every
     // aligned group a destination's segment touches) and the all-zero row Ecap, so a reused workspace needs only that row
@@ -1485,8 +1517,10 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
         PF_HIP(h, hipMemsetAsync(h->d_msg_v + (size_t)Ecap * 48, 0, 48 * 4, s));
     }
     h->zero_row = (int)Ecap;
-    pfk_copy(dev_prot_x, h->d_prot_x0, (size_t)Np * 3, s);
-    pfk_copy(dev_prot_h, h->d_prot_h0, (size_t)Np * c.rec_nf, s);
+    if (!from_host) {
+        pfk_copy(dev_prot_x, h->d_prot_x0, (size_t)Np * 3, s);
+        pfk_copy(dev_prot_h, h->d_prot_h0, (size_t)Np * c.rec_nf, s);
+    }
     pfk_load_coords(h->d_prot_x0, h->d_xn, Np, h->d_gid, nullptr, 0.f, s);
     {
         L0HoistParams lp{};
@@ -1501,12 +1535,30 @@ int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const 
     *h->l0flag_host = 1;
     PF_HIP(h, hipMemcpyAsync(h->l0flag_host, h->d_l0flag, 4, hipMemcpyDeviceToHost, s));
     PF_HIP(h, hipEventRecord(h->l0flag_ev, s));
+    mark();      // 6: everything enqueued
+    if (timing) fprintf(stderr, "[pf_set_pocket_batch] B=%d tables %.2f ws %.2f stage-wait %.2f memcpy %.2f upload %.2f rest %.2f ms (fresh %d, %zu MB)\n",
+                        B, tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], tm[6] - tm[5], (int)fresh, bytes >> 20);
     h->l0_state = 0; h->l0_onehot = false;
+    if (host_onehot >= 0) { h->l0_state = host_onehot ? 1 : 2; h->l0_onehot = host_onehot == 1; }
     h->zs_version = 0; h->zs_batch_coords = false; h->coords_custom = false;
     h->have_batch = true;
     h->sampling = false;
     h->edges_built = false;
     return PF_OK;
+}
+
+int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const int32_t* pharm_ptr,
+                        const float* dev_prot_x, const float* dev_prot_h, int64_t n_pp, const int32_t* pp_src,
+                        const int32_t* pp_dst, pf_stream stream) {
+    if (h && (!dev_prot_x || !dev_prot_h)) PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_batch: bad argument");
+    return set_pocket_batch_impl(h, B, prot_ptr, pharm_ptr, dev_prot_x, dev_prot_h, nullptr, nullptr, n_pp, pp_src, pp_dst, stream);
+}
+
+int pf_set_pocket_batch_host(pf_handle* h, int32_t B, const int32_t* prot_ptr, const int32_t* pharm_ptr,
+                             const float* host_prot_x, const float* host_prot_h, int64_t n_pp, const int32_t* pp_src,
+                             const int32_t* pp_dst, pf_stream stream) {
+    if (h && (!host_prot_x || !host_prot_h)) PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_batch_host: bad argument");
+    return set_pocket_batch_impl(h, B, prot_ptr, pharm_ptr, nullptr, nullptr, host_prot_x, host_prot_h, n_pp, pp_src, pp_dst, stream);
 }
 
 int pf_declare_onehot_features(pf_handle* h, int32_t is_onehot) {

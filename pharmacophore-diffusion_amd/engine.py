@@ -19,6 +19,13 @@ def _dptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _i32_host(t: torch.Tensor):
+    """contiguous int32 numpy copy of an index tensor (host)."""
+    import numpy as np
+    a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
 def _f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
@@ -90,27 +97,27 @@ class PfEngine:
         return t.detach().to(torch.float32).contiguous().pin_memory().to(self.device, non_blocking=True)
 
     def set_batch(self, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst):
-        """pf_set_pocket_batch: asynchronous on the current stream.  When the protein features are on the host their
-        one-hot-ness is checked here (a few hundred microseconds) and declared to the library, so that no later call
-        waits for the device-side check; device-resident features are checked on the device, lazily."""
-        onehot = None
-        if not prot_h.is_cuda:
-            ph_host = prot_h.detach()
-            onehot = bool(ph_host.numel() > 0 and ((ph_host == 0) | (ph_host == 1)).all() and (ph_host.sum(dim=1) == 1).all())
-        px, ph = self._upload(prot_x), self._upload(prot_h)
-        pptr = prot_ptr.to("cpu", torch.int32).contiguous()
-        fptr = pharm_ptr.to("cpu", torch.int32).contiguous()
-        src = pp_src.to("cpu", torch.int32).contiguous()
-        dst = pp_dst.to("cpu", torch.int32).contiguous()
-        self.B = int(pptr.numel() - 1)
+        """pf_set_pocket_batch / pf_set_pocket_batch_host: asynchronous on the current stream."""
+        import numpy as np
+        # index arrays: int32 host copies through numpy (single-threaded; a torch dtype conversion of half a million
+        # elements goes through the intra-op thread pool, whose wake-up stalls for tens of milliseconds now and then on
+        # hosts with hundreds of hardware threads)
+        pptr, fptr, src, dst = (_i32_host(t) for t in (prot_ptr, pharm_ptr, pp_src, pp_dst))
+        self.B = int(pptr.size - 1)
         self.Np, self.Nf = int(pptr[-1]), int(fptr[-1])
+        args = (int(src.size), src.ctypes.data if src.size else None, dst.ctypes.data if dst.size else None, _stream_ptr())
         with torch.cuda.device(self.device):
-            self._ck(self.lib.pf_set_pocket_batch(self._h, self.B, pptr.data_ptr(), fptr.data_ptr(), _dptr(px), _dptr(ph),
-                                                  int(src.numel()), src.data_ptr() if src.numel() else None,
-                                                  dst.data_ptr() if dst.numel() else None, _stream_ptr()),
-                     "pf_set_pocket_batch")
-            if onehot is not None:
-                self._ck(self.lib.pf_declare_onehot_features(self._h, int(onehot)), "pf_declare_onehot_features")
+            if not prot_x.is_cuda and not prot_h.is_cuda:
+                # host-resident pockets (the sampling drivers): the library stages them with its tables -- one upload, the
+                # one-hot check on the host copy, nothing waits for the device
+                hx = np.ascontiguousarray(prot_x.detach().numpy(), dtype=np.float32)
+                hh = np.ascontiguousarray(prot_h.detach().numpy(), dtype=np.float32)
+                self._ck(self.lib.pf_set_pocket_batch_host(self._h, self.B, pptr.ctypes.data, fptr.ctypes.data, hx.ctypes.data,
+                                                           hh.ctypes.data, *args), "pf_set_pocket_batch_host")
+            else:
+                px, ph = self._upload(prot_x), self._upload(prot_h)
+                self._ck(self.lib.pf_set_pocket_batch(self._h, self.B, pptr.ctypes.data, fptr.ctypes.data, _dptr(px), _dptr(ph),
+                                                      *args), "pf_set_pocket_batch")
 
     def build_pp_edges(self, prot_x, prot_ptr, max_num_neighbors=100):
         px = _f32(prot_x, self.device)

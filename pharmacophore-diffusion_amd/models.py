@@ -590,6 +590,9 @@ class PharmacophoreDiff(_Base):
             mine = list(range(len(batches)))
         T, nf = self.n_timesteps, self.n_pharm_feats
         base_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else 0
+        # every graph's initial center of mass on the device with ONE copy before the pipeline starts (a batch is a
+        # contiguous range of graphs); per-batch host -> device copies would each wait for the batch in flight
+        coms_dev = init_pharm_com[graph_ref_idx].to(self.device, torch.float32) if graphs else None
         sampled = {}
         # Pipeline over the batches: the host work of a batch (collating the next one, splitting the previous one's results
         # into SampledPharmacophores) runs while the device works on another batch.  Nothing in it waits for the device
@@ -603,7 +606,7 @@ class PharmacophoreDiff(_Base):
         for bi in mine:
             idx = batches[bi]
             batch_g = batch_graphs([graphs[i] for i in idx])
-            init_coms = init_pharm_com[[graph_ref_idx[i] for i in idx]]
+            init_coms = coms_dev[idx[0]:idx[-1] + 1]
             if noise is None:
                 gen = torch.Generator(device=self.device).manual_seed(base_seed + bi)
                 nz = torch.randn(T + 1, batch_g.num_nodes("pharm"), 3 + nf, device=self.device, generator=gen)
