@@ -71,11 +71,6 @@ struct GvpW {              // packed weights of one GVP (device pointers)
 #define RG_TAIL_PAD 48      // quads of read-ahead padding behind the last stream (>= the deepest prefetch ring)
 #define RG_NQ_FLUSH 24      // [8 gate quads] [pad]
 #define RG_NQ_OUT 24        // to_scalar_output: [const] [8 gate-like quads] [pad]
-// 16-row form of the hoisted layer-0 pp items (pf_r16.hip): quads per GVP block / flush block, padding unit = ring depth
-#define R16_PAD 24
-#define R16_NQ_GVP 96       // 91 used
-#define R16_NQ_FLUSH 24     // 9 used; the ring reads 8 quads ahead
-#define RG_CPASS_R16 4      // compact work list of pf_r16.hip: up to 256 regions
 struct RgSched {
     int q_c, q_xh, q_a, q_gate, q_b, q_vh, q_cc, q_vu, q_d, q_rbf, q_sh, nq_raw, nq;
 };
@@ -155,7 +150,6 @@ struct EdgeParams {
     const int* l0_gid;     // graph of each node (ptab_gstride != 0)
     const float* l0c;      // [16 weff][16 gate bias]
     int ngroups_sel;       // compact work list: grid in groups when the regions' group sizes differ by kind (0: ngroups4/8)
-    pf_gcf r16;            // pf_r16.hip: quad stream of the pp message chain of this layer from its second GVP on
 };
 
 // static-hoist source block in the packed weights (pure copies of the first pp message GVP of conv layer 0 and of the

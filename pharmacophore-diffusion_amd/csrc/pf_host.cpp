@@ -31,7 +31,6 @@ void pfk_node_update(const NodeParams* p, int layer0, hipStream_t s);
 void pfk_noise_head(const HeadParams* p, hipStream_t s);
 void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int rg, int split, int rgp, hipStream_t s);
 void pfk_l0_hoist(const L0HoistParams* p, int what, hipStream_t s);
-void pfk_r16_pp(const EdgeParams* p, int rbase, int tile0, hipStream_t s);
 void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
@@ -185,8 +184,6 @@ struct pf_handle {
     int l0_rgp = 0;                         // PFDYN_L0_RGP: rows-per-wave factor of the hoisted items (0: policy)
     int l0_rga = 0;                         // PFDYN_L0_RGA: ... of the other items of a compact pruned layer-0 launch (0: policy)
     size_t l0h_off = 0;                     // L0H_* block in d_w
-    size_t r16_off = 0;                     // pf_r16.hip: quad stream of layer 0's pp message chain from its second GVP on
-    long r16_rows_min = 1L << 40;           // PFDYN_R16_ROWS_MIN: hoisted items on 16-row groups from this many slots per launch
     uint64_t w_version = 1, zs_version = 0, ptab_version = 0;
     bool l0_onehot = false;                 // every protein feature row of the batch is an element one-hot
     bool coords_custom = false;             // protein coordinates came from the caller of this call (not the batch's own)
@@ -215,7 +212,6 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = rg2_rows_min_hoist = atoi(e);
         if (const char* e = getenv("PFDYN_RG2_ROWS_MIN_HOIST")) rg2_rows_min_hoist = atoi(e);
         if (const char* e = getenv("PFDYN_NO_L0_HOIST")) l0_hoist = atoi(e) == 0;
-        if (const char* e = getenv("PFDYN_R16_ROWS_MIN")) r16_rows_min = atol(e);
         if (const char* e = getenv("PFDYN_L0_RGP")) l0_rgp = atoi(e);
         if (const char* e = getenv("PFDYN_L0_RGA")) l0_rga = atoi(e);
     }
@@ -526,62 +522,6 @@ static void pack_gvp_rg(pf_handle* h, const GvpSpec& g, const GvpSpec* prev, std
     }
     if (prev) pack_gate_quads_rg(h->raw[prev->prefix + "scalar_to_vector_gates.weight"].data, prev->vo, prev->so, out, base, q.q_gate);
 }
-// ------------------------------------------------------------------------------------------------
-// 16-row form (pf_r16.hip): blocks of v_mfma_f32_16x16x4_f32 A operands.  Lane l of an image holds
-// A[m = l & 15][k = l >> 4]; the K order of every Linear is the order in which a D fragment presents the previous
-// GVP's outputs: k-step ks, k = g  <->  feature 16 (ks / 4) + 4 g + ks % 4 (vector channels: k-step ks, k = g <->
-// channel 4 g + ks).  Bias images are accumulator initialisers in the D layout (register i, lane l: 4 (l >> 4) + i).
-// ------------------------------------------------------------------------------------------------
-static void pack_gates_r16(pf_handle* h, const GvpSpec& prev, std::vector<float>& out, size_t base) {
-    const std::vector<float>& Wg = h->raw[prev.prefix + "scalar_to_vector_gates.weight"].data;   // [vo][so]
-    const std::vector<float>& bg = h->raw[prev.prefix + "scalar_to_vector_gates.bias"].data;
-    auto at = [&](int quad, int lane, int j) -> float& { return out[base + ((size_t)quad * 64 + lane) * 4 + j]; };
-    for (int lane = 0; lane < 64; ++lane) {
-        const int m = lane & 15, g = lane >> 4;
-        for (int i = 0; i < 4; ++i) at(0, lane, i) = 4 * g + i < prev.vo ? bg[4 * g + i] : 0.f;
-        for (int q = 0; q < 8; ++q)
-            for (int j = 0; j < 4; ++j) {
-                const int ks = 4 * q + j, f = 16 * (ks / 4) + 4 * g + ks % 4;
-                at(1 + q, lane, j) = (m < prev.vo && f < prev.so) ? Wg[(size_t)m * prev.so + f] : 0.f;
-            }
-    }
-}
-static void pack_gvp_r16(pf_handle* h, const GvpSpec& g, const GvpSpec& prev, std::vector<float>& out) {
-    const size_t base = out.size();
-    out.resize(base + (size_t)R16_NQ_GVP * 256, 0.f);
-    if (!(g.vi == 16 && g.vo == 16 && g.si == PF_S && g.so == PF_S && prev.so == PF_S)) return;      // not this form: zeros (never launched)
-    pack_gates_r16(h, prev, out, base);
-    const int H = 16, Kin = g.si + H;
-    const std::vector<float>& W = h->raw[g.prefix + "to_feats_out.0.weight"].data;            // [so][si + H]
-    const std::vector<float>& Bv = h->raw[g.prefix + "to_feats_out.0.bias"].data;
-    const std::vector<float>& wh = h->raw[g.prefix + "Wh"].data;                              // [vi][H]
-    const std::vector<float>& wu = h->raw[g.prefix + "Wu"].data;                              // [H][vo]
-    auto at = [&](int quad, int lane, int j) -> float& { return out[base + ((size_t)quad * 64 + lane) * 4 + j]; };
-    for (int lane = 0; lane < 64; ++lane) {
-        const int m = lane & 15, gq = lane >> 4;
-        for (int k = 0; k < 4; ++k) {
-            at(9, lane, k) = wh[(size_t)(4 * gq + k) * H + m];
-            at(82, lane, k) = wu[(size_t)(4 * gq + k) * g.vo + m];
-        }
-        for (int t = 0; t < 8; ++t)
-            for (int i = 0; i < 4; ++i) at(10 + t, lane, i) = Bv[16 * t + 4 * gq + i];
-        for (int ks = 0; ks < 32; ++ks)
-            for (int half = 0; half < 2; ++half)
-                for (int j = 0; j < 4; ++j) {
-                    const int t = 4 * half + j, f = 16 * (ks / 4) + 4 * gq + ks % 4;
-                    at((ks < 16 ? 18 : 50) + 2 * (ks % 16) + half, lane, j) = W[(size_t)(16 * t + m) * Kin + f];
-                }
-        for (int ks = 0; ks < 4; ++ks)
-            for (int half = 0; half < 2; ++half)
-                for (int j = 0; j < 4; ++j)
-                    at(83 + 2 * ks + half, lane, j) = W[(size_t)(16 * (4 * half + j) + m) * Kin + g.si + 4 * gq + ks];
-    }
-}
-static void pack_flush_r16(pf_handle* h, const GvpSpec& last, std::vector<float>& out) {
-    const size_t base = out.size();
-    out.resize(base + (size_t)R16_NQ_FLUSH * 256, 0.f);
-    if (last.vo == 16 && last.so == PF_S) pack_gates_r16(h, last, out, base);
-}
 // end of a chain: the gate quads of its last GVP
 static void pack_flush_rg(pf_handle* h, const GvpSpec& g, std::vector<float>& out) {
     const size_t base = out.size();
@@ -830,33 +770,12 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             }
             h->last_hoist = 4 * rgp;
         }
-        // the hoisted items on 16-row groups (pf_r16.hip) in their own launch; the row-group launch keeps ff / pf / fp
-        EdgeParams e16{};
-        int r16_rbase = 0, r16_tile0 = 0;
-        bool r16 = false;
-        if (e.zs && (long)e.ntiles * 32 >= h->r16_rows_min && c.vector_size == 16 && (e.nreg == 0 || h->B <= 64 * RG_CPASS_R16)) {
-            r16 = true;
-            const int* et0 = pruned ? h->et_tile0_act : h->et_tile0;
-            e16 = e;
-            e16.r16 = h->d_w + h->r16_off;
-            if (e.nreg > 0) {                   // compact: regions [3 B, 4 B) here, [0, 3 B) in the row-group launch
-                e16.nreg = h->B; r16_rbase = 3 * h->B; e16.ngroups_sel = 0;
-                for (int g = 0; g < h->B; ++g) e16.ngroups_sel += (h->h_cap[(size_t)3 * h->B + g] + 15) / 16;
-                e.nreg = 3 * h->B; e.ngroups_sel = 0;
-                for (int r = 0; r < e.nreg; ++r) e.ngroups_sel += (h->h_cap[r] + 4 * rg - 1) / (4 * rg);
-            } else {
-                r16_tile0 = et0[3]; e16.ntiles = et0[4] - et0[3];
-                e.ntiles = et0[3];
-            }
-            rgp = 4;                            // group size 16 of the pp segment for the node launch
-            h->last_hoist = 16;
-        }
         h->last_family.resize(c.n_convs);
         h->last_family[l] = rg ? 4 * rg : ((!train && e.ntiles <= ((last || pruned) ? std::max(h->coop_edge_max, h->coop2_edge_max) : std::max(h->coop_edge_max, h->coop2_dense_max))) ? 128 : 32);
         for (int et = 0; et < 4; ++et) e.rgs[et] = h->d_w + h->rgs_msg[(size_t)l * 4 + et];
         e.rgs_stride = (int)h->rgs_msg_stride;
         const int esplit = (rg == 1 && e.ntiles * 8 <= h->rg_split_max && !e.zs) ? 1 : 0;    // fewer groups than SIMDs: latency-bound
-        if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, esplit, r16 ? 0 : rgp, s); if (r16) pfk_r16_pp(&e16, r16_rbase, r16_tile0, s); }
+        if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, esplit, rgp, s); }
         else if (e.ntiles <= h->coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
         else if (e.ntiles <= ((last || pruned) ? h->coop2_edge_max : h->coop2_dense_max) && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop2(&e, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
@@ -1105,12 +1024,6 @@ int pf_commit_weights(pf_handle* h) {
                 for (int k = 0; k < 16; ++k) blk[L0H_BG + k] = h->raw[g.prefix + "scalar_to_vector_gates.bias"].data[k];
             }
             h->l0h_off = push(h->h_w, blk);
-            // the same chain from its second GVP on, for the 16-row form
-            std::vector<float> st;
-            for (int j = 1; j < c.n_message_gvps; ++j) pack_gvp_r16(h, msg_spec(c, 0, ET_PP, j), msg_spec(c, 0, ET_PP, j - 1), st);
-            pack_flush_r16(h, msg_spec(c, 0, ET_PP, c.n_message_gvps - 1), st);
-            st.resize(st.size() + (size_t)2 * R16_PAD * 256, 0.f);
-            h->r16_off = push(h->h_w, st);
         }
         {   // row-group quad streams, one contiguous stream per chain.  The pharm update chain of the last conv layer
             // comes last and is followed by the noise head's chain and to_scalar_output: the fused node + head kernel
