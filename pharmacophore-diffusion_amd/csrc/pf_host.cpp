@@ -48,6 +48,8 @@ void pfk_export_coords(const float4* xn, int base, int n, const int* gid, const 
 void pfk_bwd_head(const BwdHeadParams* p, int nblocks, hipStream_t s);
 void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s);
 void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, hipStream_t s);
+void pfk_fix_apply(long long* A, float* G, size_t n, const float* fix, hipStream_t s);
+void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* fix, hipStream_t s);
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
 void pfk_train_reduce(const float* gpart, int nblocks, int nparams, float* grad, hipStream_t s);
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s);
@@ -232,6 +234,8 @@ struct pf_handle {
     int et_tile0_act[5] = {0, 0, 0, 0, 0};  // ... of ff, pf, fp, pa in d_edge_tiles_act
     float *t_G_h[2] = {nullptr, nullptr}, *t_G_v[2] = {nullptr, nullptr}, *t_gagg_s = nullptr, *t_gagg_v = nullptr,
           *t_gpart = nullptr, *t_geps_h = nullptr, *t_geps_x = nullptr;
+    long long *t_A_h = nullptr, *t_A_v = nullptr;      // fixed-point accumulators of the level-0 scatter (kept clear between uses)
+    float* t_fix = nullptr;                 // [2] scale / inverse scale of the current backward call
     int t_nblk = 0;
     const float* t_mask_override = nullptr; // pf_debug_set_dropout_masks
     bool t_have_fwd = false;
@@ -1751,6 +1755,8 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     for (int l = 0; l < L; ++l) { need(E1 * PF_S); need(E1 * 48); }
     for (int a = 0; a < 2; ++a) { need((size_t)N * PF_S); need((size_t)N * 48); }
     need((size_t)N * PF_S); need((size_t)N * 48);
+    need((size_t)2 * N * PF_S); need((size_t)2 * N * 48);          // int64 accumulators (two floats per element)
+    need(64);
     need((size_t)h->t_nblk * h->nparams);
     const size_t Es = (size_t)std::max<int64_t>(h->Ecap, 1), ng = (size_t)c.n_message_gvps;
     for (int l = 0; l < L; ++l) { need(ng * Es * PF_S); need(ng * Es * 16); need(ng * Es * 48); }
@@ -1772,6 +1778,11 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     for (int l = 0; l < L; ++l) { h->t_msg_s[l] = carve<float>(cur, E1 * PF_S); h->t_msg_v[l] = carve<float>(cur, E1 * 48); }
     for (int a = 0; a < 2; ++a) { h->t_G_h[a] = carve<float>(cur, (size_t)N * PF_S); h->t_G_v[a] = carve<float>(cur, (size_t)N * 48); }
     h->t_gagg_s = carve<float>(cur, (size_t)N * PF_S); h->t_gagg_v = carve<float>(cur, (size_t)N * 48);
+    h->t_A_h = reinterpret_cast<long long*>(carve<float>(cur, (size_t)2 * N * PF_S));
+    h->t_A_v = reinterpret_cast<long long*>(carve<float>(cur, (size_t)2 * N * 48));
+    h->t_fix = carve<float>(cur, 64);
+    PF_HIP(h, hipMemsetAsync(h->t_A_h, 0, (size_t)N * PF_S * 8, s));       // pfk_fix_apply keeps them clear afterwards
+    PF_HIP(h, hipMemsetAsync(h->t_A_v, 0, (size_t)N * 48 * 8, s));
     h->t_gpart = carve<float>(cur, (size_t)h->t_nblk * h->nparams);
     h->t_sv_z.assign(L, nullptr); h->t_sv_g.assign(L, nullptr); h->t_sv_v.assign(L, nullptr);
     for (int l = 0; l < L; ++l) {
@@ -1879,6 +1890,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     const int L = c.n_convs, N = h->N, nb = h->t_nblk;
     const TrainCommon tc = h->t_common;
     PF_HIP(h, hipMemsetAsync(h->t_gpart, 0, (size_t)nb * h->nparams * 4, s));
+    pfk_fix_scale(dev_g_eps_h, h->Nf * c.pharm_nf, dev_g_eps_x, h->Nf * 3, h->t_fix, s);
     PF_HIP(h, hipMemsetAsync(h->t_G_h[0], 0, (size_t)N * PF_S * 4, s));
     PF_HIP(h, hipMemsetAsync(h->t_G_v[0], 0, (size_t)N * 48 * 4, s));
     {
@@ -1955,7 +1967,10 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
         e.rbf_inv_sigma = 1.0f / ((c.rbf_dmax - 0.f) / (float)c.rbf_dim);
         e.l0 = l == 0;
+        e.A_h = h->t_A_h; e.A_v = h->t_A_v; e.fix = h->t_fix;
         for (int lv = c.n_message_gvps - 1; lv >= 0; --lv) { e.level = lv; pfk_bwd_edge_level(&e, s); }
+        pfk_fix_apply(h->t_A_h, e.G_h_in, (size_t)N * PF_S, h->t_fix, s);
+        if (l != 0) pfk_fix_apply(h->t_A_v, e.G_v_in, (size_t)N * 48, h->t_fix, s);       // conv layer 0 has no vector input
         a ^= 1;
     }
     {

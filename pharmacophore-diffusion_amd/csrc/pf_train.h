@@ -9,15 +9,17 @@
 // (pf_host.cpp: expected_tensors); a GvpT addresses one GVP's six tensors by offset into that vector, so the
 // gradient of a tensor sits at the same offset of the gradient vector.  Every thread block of a backward kernel
 // accumulates into its own private copy of the gradient vector (gpart[block][nparams], plain read-modify-write by
-// the owning lane, no atomics) and pfk_train_reduce sums the copies in a fixed order.  The one place where the summation
-// order is not fixed is the scatter of dL/d(h_src, v_src) from the edges of level 0 to their source nodes (fp32 atomics:
-// a node's out-edges live in many tiles); repeated backward passes agree to ~1e-7 relative, not bit for bit.
+// the owning lane, no atomics) and pfk_train_reduce sums the copies in a fixed order.  The scatter of dL/d(h_src, v_src)
+// from the edges of level 0 to their source nodes (a node's out-edges live in many tiles) uses atomics on 64-bit
+// fixed-point accumulators, whose result is independent of the arrival order: repeated backward passes agree bit for bit.
 #pragma once
 #include <stdint.h>
 #include "pf_device.h"
 
 #define PFT_MAX_CHAIN 4      // GVPs per chain the backward tiles hold in LDS
 #define PFT_ROWS 16          // rows (edges / nodes) per backward sub-tile = N of v_mfma_f32_16x16x4_f32
+#define PFT_FIX_BITS 40      // fixed-point scale of the level-0 scatter RELATIVE to the largest upstream gradient of the call:
+                             // resolution 2^-40 of it, head room 2^23 times it (pfk_fix_scale picks the power of two)
 
 struct GvpT {
     int o_Wh, o_Wu, o_Wm, o_bm, o_Wg, o_bg;   // offsets of Wh [vi][h], Wu [h][vo], to_feats_out.0.{weight [so][si+h], bias},
@@ -99,7 +101,13 @@ struct BwdEdgeLevelParams {
     const int* in_cnt; int N;
     int pp_slot;                             // in_cnt slot of the pp tiles (2 in the pruned layer)
     int norm_mode;
-    float* G_h_in; float* G_v_in;            // level 0: atomically accumulated
+    float* G_h_in; float* G_v_in;            // gradient w.r.t. the layer input (the node kernel stored the residual path)
+    // level 0 scatters dL/d(h_src, v_src) of every edge to its source node.  A node's out-edges live in many tiles, so
+    // the sums are atomic -- on 64-bit FIXED-POINT accumulators (value * 2^k, rounded to nearest; k from the call's upstream gradients): integer
+    // addition is associative, so the result does not depend on the order in which the blocks arrive and the gradients
+    // are bitwise reproducible.  pfk_fix_apply adds the sums to G_h_in / G_v_in and clears the accumulators.
+    long long* A_h; long long* A_v;          // [N][128], [N][48]
+    const float* fix;                        // device: [scale = 2^k, 1 / scale] of this backward call (pfk_fix_scale)
     const float* sv_z; const float* sv_g; const float* sv_v; size_t sv_stride;
     float* gs_buf; float* gv_buf;            // dL/d(input scalars / vectors of the level above), per edge slot
     const GvpT* g; int n_gvps; int level;

@@ -12,6 +12,7 @@
 // data products and as the K dimension of the weight-gradient products.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "pf_train.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -715,6 +716,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
     const int nts = (KM + 15) >> 4;                  // <= 11
     const bool lastl = p.level == p.n_gvps - 1, firstl = p.level == 0;
     const int slot = (et == ET_FF || et == ET_FP) ? 0 : (et == ET_PP ? p.pp_slot : 1);
+    const float fix_scale = firstl ? p.fix[0] : 1.0f;
     // weight-gradient accumulators, kept in registers over all the tiles of this block:
     //   to_feats_out: wave wv owns output features 16 wv .. +15, tile x = inputs 16 x .. +15
     //   gates: wave wv owns features 16 wv .. +15 of all 16 gates
@@ -934,12 +936,14 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
         } else {
             for (int idx = tid; idx < ER * 128; idx += NT) {
                 const int row = idx >> 7, f = idx & 127;
-                if (row < nv) unsafeAtomicAdd(p.G_h_in + (size_t)s_src[row] * PF_S + f, gS[row * SWS + f]);
+                if (row < nv) atomicAdd(reinterpret_cast<unsigned long long*>(p.A_h + (size_t)s_src[row] * PF_S + f),
+                                        (unsigned long long)__float2ll_rn(gS[row * SWS + f] * fix_scale));
             }
             if (!p.l0)
                 for (int idx = tid; idx < ER * 48; idx += NT) {
                     const int row = idx / 48, q = idx - row * 48;
-                    if (row < nv) unsafeAtomicAdd(p.G_v_in + (size_t)s_src[row] * 48 + q, gVi[row * VWS + 3 + q]);
+                    if (row < nv) atomicAdd(reinterpret_cast<unsigned long long*>(p.A_v + (size_t)s_src[row] * 48 + q),
+                                            (unsigned long long)__float2ll_rn(gVi[row * VWS + 3 + q] * fix_scale));
                 }
         }
         __syncthreads();
@@ -1072,6 +1076,37 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_encode(const BwdEncodeParams p) {
 }
 
 // grad[i] = sum over the per-block copies, in block order
+// G += A / scale, A = 0: the fixed-point scatter sums of level 0 join the float gradient; the accumulators are left
+// clear for the next layer / step.  Element order is fixed, so the result is deterministic.
+__global__ void k_fix_apply(long long* A, float* G, const size_t n, const float* fix) {
+    const double inv = (double)fix[1];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const long long a = A[i];
+        if (a != 0) {
+            G[i] += (float)((double)a * inv);
+            A[i] = 0;
+        }
+    }
+}
+// scale of the fixed-point scatter for one backward call: 2^(PFT_FIX_BITS - ceil(log2(max |upstream gradient|))) -- every
+// gradient of the call is linear in the upstream ones, so this keeps ~40 bits below and 23 bits above their largest entry
+__global__ __launch_bounds__(256) void k_fix_scale(const float* g_h, const int n_h, const float* g_x, const int n_x, float* fix) {
+    __shared__ float red[256];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n_h; i += 256) m = fmaxf(m, fabsf(g_h[i]));
+    for (int i = threadIdx.x; i < n_x; i += 256) m = fmaxf(m, fabsf(g_x[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) {
+        int e = 0;
+        const float mx = red[0];
+        if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);         // mx = f * 2^e, 0.5 <= f < 1
+        const int k = max(-100, min(100, PFT_FIX_BITS - e));
+        fix[0] = ldexpf(1.0f, k);
+        fix[1] = ldexpf(1.0f, -k);
+    }
+}
 __global__ void k_train_reduce(const float* gpart, const int nblocks, const int nparams, float* grad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nparams) return;
@@ -1130,6 +1165,13 @@ void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, hipStream_t s) {
     const int nblocks = p->et_blk0[4];
     if (nblocks == 0) return;
     hipLaunchKernelGGL(k_bwd_edge_level, dim3(nblocks), dim3(NT), 0, s, *p);
+}
+void pfk_fix_apply(long long* A, float* G, size_t n, const float* fix, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_fix_apply, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, s, A, G, n, fix);
+}
+void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* fix, hipStream_t s) {
+    hipLaunchKernelGGL(k_fix_scale, dim3(1), dim3(256), 0, s, g_h, n_h, g_x, n_x, fix);
 }
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s) {
     hipLaunchKernelGGL(k_bwd_encode, dim3(nblocks), dim3(NT), 0, s, *p);
