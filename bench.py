@@ -372,16 +372,32 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
         torch.cuda.synchronize()
     for _ in range(W):
         step()
+    eng.profile_read_train()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(K):
+    ev_every = max(1, K // 8)                      # HIP events around the edge-message backward launches of every n-th step
+    for i in range(K):
+        eng.profile_enable((1 << 11) if i % ev_every == 0 else 0)
         loss = step()
+    eng.profile_enable(0)
     barrier()
     dt = time.perf_counter() - t0
+    prof = eng.profile_read_train()
     tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # dominant kernel of the step: k_bwd_edge_level (one launch per message-GVP level and conv layer).  Algorithmic work
+    # of the message chain's backward = 2 x its forward (one product for the input gradient, one for the weight
+    # gradient, per Linear): 2 x 136,742 FLOP per edge the layer computes, over its n_message_gvps launches
+    wk = eng.work_detail()
+    lvl_ms, lvl_n = prof["bwd_edge_level"]
+    edges_exec = sum(wk["executed_edges_per_layer"])
+    launches_per_step = 3 * len(wk["executed_edges_per_layer"])
+    steps_timed = lvl_n / max(launches_per_step, 1)
+    bwd_flop_per_step = 2.0 * FLOP_PER_EDGE * edges_exec
+    lvl_s_per_step = lvl_ms * 1e-3 / max(steps_timed, 1e-9)
+    ach = bwd_flop_per_step / lvl_s_per_step / 1e12 if lvl_ms > 0 else 0.0
     if rank == 0:
         print(json.dumps({
             "metric": "training graphs/sec (forward + backward + Adam), 256-atom pockets, 4-8 centers", "value": world * B * K / dt,
@@ -391,6 +407,13 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
                                    "dropout 0.1, dev.yml network", "batch_per_gpu": B, "n_prot": args.n_prot,
                        "distinct_batches": len(graphs),
                        "parallelism": f"data parallel over {world} GPU(s): one all-reduce of the flat gradient per step"},
+            "roofline": {"bound": "mfma", "kernel": "k_bwd_edge_level (all levels of a step)", "achieved": ach, "peak": PEAK_F32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS, "traffic": None, "traffic_source": TRAFFIC_SOURCE,
+                         "kernel_avg_us": lvl_ms / max(lvl_n, 1) * 1e3, "launches_timed": lvl_n, "launches_per_step": launches_per_step,
+                         "edge_backward_ms_per_step": lvl_s_per_step * 1e3, "flop_per_step": bwd_flop_per_step,
+                         "edges_computed_per_layer": wk["executed_edges_per_layer"],
+                         "note": "HIP events around the edge-message backward launches of every n-th timed step; FLOP = 2 x 136,742 "
+                                 "per edge a layer computes (backward of the message chain = two products per Linear)"},
             "final_loss": float(loss.detach())}))
 
 

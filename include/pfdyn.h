@@ -116,6 +116,16 @@ int pf_set_pocket_batch_host(pf_handle* h, int32_t B, const int32_t* host_prot_p
                              const float* host_prot_x, const float* host_prot_h,
                              int64_t n_pp, const int32_t* host_pp_src, const int32_t* host_pp_dst, pf_stream stream);
 
+/* Optional, BEFORE the next pf_set_pocket_batch / _host call: host_rep[g] = index of the graph that represents graph g's
+ * pocket (host_rep[r] == r for a representative).  The caller claims that graph g is a COPY of graph host_rep[g] -- same
+ * atoms, features, coordinates and pp edges -- which is how every sampling batch of the reference is built
+ * (copy_graph, utils/unorganized_utils.py:28-81; pharmacodiff.py:541-545; generate_pharmacophores.py:329-333).  The bind
+ * verifies the claim (everything it can see on the host) and fails with PF_ERR_ARG if it does not hold.  Effect: during
+ * sampling, copies at the same timestep share conv layer 0's protein->protein messages (computed once per pocket
+ * instead of once per copy, gvp.py:545-549 being a pure function of pocket geometry, element types and t there);
+ * outputs are the same up to fp32 summation order.  The groups apply to one bind only. */
+int pf_set_pocket_groups(pf_handle* h, int32_t B, const int32_t* host_rep);
+
 /* Optional, right after pf_set_pocket_batch: the caller states whether every row of prot_h is an element one-hot
  * (what the reference's dataset / CLI always produce: protein_pharm_dataset.py:129, generate_pharmacophores.py:105-118).
  * pf_set_pocket_batch checks this on the device and the first inference call that wants the answer waits for it; a caller
@@ -221,6 +231,9 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
 #define PF_NUM_KERNEL_CLASSES 9
 int pf_profile_enable(pf_handle* h, uint32_t kernel_mask);
 int pf_profile_read(pf_handle* h, double* total_ms /*[9]*/, int64_t* launches /*[9]*/, pf_stream stream);
+/* The same for the gradient kernels of pf_train_backward (mask bits 9..12 of pf_profile_enable): 0 noise-head backward,
+ * 1 node-update backward, 2 edge-message backward (one launch per GVP level), 3 reserved. */
+int pf_profile_read_train(pf_handle* h, double* total_ms /*[4]*/, int64_t* launches /*[4]*/, pf_stream stream);
 /* work of the last dynamics call: `flops` / `bytes` = reference-equivalent (SURVEY.md 8(d) formulas on the actual
  * edge counts n_edges[4] = ff, pf, fp, pp, every layer dense); `executed_flops` / `executed_edges[n_convs]` = what the
  * kernels compute after dead-work elimination (last layer: pharm side only; layer before it: active atoms only). */

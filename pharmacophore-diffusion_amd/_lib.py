@@ -41,6 +41,7 @@ SYMBOLS = {
     "pf_commit_weights": (ctypes.c_int, [_P]),
     "pf_set_pocket_batch": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "pf_set_pocket_batch_host": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "pf_set_pocket_groups": (ctypes.c_int, [_P, _I32, _P]),
     "pf_declare_onehot_features": (ctypes.c_int, [_P, _I32]),
     "pf_build_pp_edges": (_I64, [_P, _I32, _P, _P, _I32, _P, _P, _I64, _P]),
     "pf_dynamics_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
@@ -63,6 +64,7 @@ SYMBOLS = {
     "pf_debug_conv_layer": (ctypes.c_int, [_P, _I32] + [_P] * 11),
     "pf_profile_enable": (ctypes.c_int, [_P, ctypes.c_uint32]),
     "pf_profile_read": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), _P]),
+    "pf_profile_read_train": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), _P]),
     "pf_debug_work": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(_I64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), _P]),
     "pf_debug_kernel_family": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),

@@ -150,6 +150,8 @@ struct EdgeParams {
     const int* l0_gid;     // graph of each node (ptab_gstride != 0)
     const float* l0c;      // [16 weff][16 gate bias]
     int ngroups_sel;       // compact work list: grid in groups when the regions' group sizes differ by kind (0: ngroups4/8)
+    int pa_abs;            // pocket sharing: the kind-3 regions are ranges of STATIC slots with arbitrary starts; their
+                           // groups are cut on absolute multiples of the group size (what the node kernel's e | (grp - 1) expects)
 };
 
 // static-hoist source block in the packed weights (pure copies of the first pp message GVP of conv layer 0 and of the
@@ -188,8 +190,8 @@ struct NodeW {             // per node type
 struct NodeParams {
     const NodeTile* tiles;
     int ntiles;
-    const int* in_start;   // [3][N]
-    const int* in_cnt;     // [3][N]
+    const int* in_start;   // [4][N]
+    const int* in_cnt;     // [4][N]
     int N;
     int pp_slot;           // which slot holds the prot nodes' pp in-edges: 1 all, 2 compact copy for active atoms
     const int* row_ids;    // active-atom lists (tiles with ids != 0)
@@ -252,11 +254,17 @@ struct BuildParams {
     const int* reg_act;    // [B] start of each graph's list in act_ids
     int* esrc; int* edst;
     int* eorig;            // [Ecap] static pp slot of each "pa" slot (EdgeParams::eorig), or NULL
-    int* in_start; int* in_cnt; int N;   // [3][N]: slot 0 ff|fp, slot 1 pf|pp(all), slot 2 pp into active atoms
+    int* in_start; int* in_cnt; int N;   // [4][N]: slot 0 ff|fp, slot 1 pf|pp(all), slot 2 pp into active atoms, slot 3 static (pocket sharing)
     int ff_k, pf_k;
     float r2_ff, r2_pf;
     float* gnorm;          // [2][B]
     const int* pp_cnt;     // [B] static pp edges per graph
+    // pocket sharing (conv layer 0 under the static hoist): copies of one pocket at the same t have identical
+    // pp messages, so the "pa" region of a pocket's REPRESENTATIVE graph is re-pointed at that graph's static pp edges
+    // (EdgeParams::reg) and the copies publish an empty one.  pa_static[g] = count to publish (static pp edges of a
+    // representative, 0 for a copy); the per-step pa copy and the slot-2 descriptors are then not written (the node
+    // kernel reads slot 3: the representative's static in-edge ranges, uploaded once per batch).  NULL: off.
+    const int* pa_static;
     const int* pfq_cnt;    // [B] or NULL: the pf / fp edge counts the REFERENCE books per graph when pf edges are kNN
                            // (dynamics_gvp.py:220 looks center indices up in the protein batch vector); used instead of
                            // the true counts by the per-graph normalisers

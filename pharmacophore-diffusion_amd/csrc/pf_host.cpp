@@ -147,9 +147,19 @@ struct pf_handle {
           *d_v[2] = {nullptr, nullptr}, *d_msg_s = nullptr, *d_msg_v = nullptr, *d_eps_h = nullptr, *d_eps_x = nullptr,
           *d_com_init = nullptr, *d_com_tmp = nullptr, *d_gnorm = nullptr, *d_pre = nullptr;
     int* d_pfq_cnt = nullptr;      // [B] reference-booked pf edge counts (message_norm 0 with kNN pf edges), else NULL
+    // pocket sharing: pf_set_pocket_groups names, per graph, the representative graph of its pocket; the
+    // next bind verifies the claim and, when it pays, prepares the tables of the sharing mode
+    std::vector<int> pending_rep;           // consumed by the next pf_set_pocket_batch*
+    bool share_ok = false;                  // tables of the sharing mode exist for this batch
+    int* d_reg_share = nullptr;             // [4][B]: d_reg with the kind-3 entries of representatives at their static pp edges
+    int* d_pa_static = nullptr;             // [B]: static pp edge count of a representative, 0 for a copy
+    long share_rows = 0;                    // edge slots of a shared layer-0 launch (capacities of ff, pf, fp + the static ranges)
+    std::vector<int> h_share_start, h_share_cnt;   // host copies of d_reg_share's kind-3 entries / d_pa_static (grid sizing)
+    bool share_disable = false;             // PFDYN_NO_POCKET_SHARE=1
     bool sampling = false;
     int max_np = 0;                         // largest pocket of the batch
     bool edges_built = false;               // the dynamic edges of the current coordinates exist (built by k_step_build)
+    bool edges_share = false;               // ... in the pocket-sharing form (no pa copies)
     // launches with at most this many tiles use the 4-wave cooperative kernels (latency-bound regime)
     // Edge-message launches: up to coop_edge_max tiles (one per CU) the 4-wave kernel with next-GVP weight prefetch;
     // up to coop2_edge_max (pruned / last-layer tile lists) or coop2_dense_max (dense layers, where the one-wave kernel
@@ -214,6 +224,7 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = rg2_rows_min_hoist = atoi(e);
         if (const char* e = getenv("PFDYN_RG2_ROWS_MIN_HOIST")) rg2_rows_min_hoist = atoi(e);
         if (const char* e = getenv("PFDYN_NO_L0_HOIST")) l0_hoist = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_NO_POCKET_SHARE")) share_disable = atoi(e) != 0;
         if (const char* e = getenv("PFDYN_L0_RGP")) l0_rgp = atoi(e);
         if (const char* e = getenv("PFDYN_L0_RGA")) l0_rga = atoi(e);
     }
@@ -247,10 +258,12 @@ struct pf_handle {
     }
 
     // ---- optional per-kernel timing with HIP events on the caller's stream (pf_profile_*)
-    enum { K_ENCODE = 0, K_BUILD, K_EDGE, K_NODE, K_HEAD, K_STEP, K_EDGE_COOP, K_NODE_COOP, K_EDGE_LAST, K_NUM };
+    // classes 0..8: pf_profile_read (inference path); 9..12: pf_profile_read_train (gradient kernels)
+    enum { K_ENCODE = 0, K_BUILD, K_EDGE, K_NODE, K_HEAD, K_STEP, K_EDGE_COOP, K_NODE_COOP, K_EDGE_LAST,
+           K_BWD_HEAD, K_BWD_NODE, K_BWD_EDGE_LEVEL, K_BWD_REST, K_NUM };
     unsigned prof_mask = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[K_NUM];
-    size_t prof_used[K_NUM] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t prof_used[K_NUM] = {};
 };
 
 namespace {
@@ -589,7 +602,13 @@ struct ProfScope {
     }
 };
 
-static BuildParams build_params(pf_handle* h) {
+static bool l0_hoist_ok(pf_handle* h);
+// pocket sharing applies to inference calls at one common t whose conv layer 0 is the pruned layer under the static hoist
+static bool share_now(pf_handle* h) {
+    const pf_config& c = h->cfg;
+    return h->share_ok && !h->share_disable && h->prune && c.n_convs == 2 && h->rg_compact && l0_hoist_ok(h);
+}
+static BuildParams build_params(pf_handle* h, bool share = false) {
     const pf_config& c = h->cfg;
     BuildParams bp{};
     bp.B = h->B; bp.Np_tot = h->Np;
@@ -602,6 +621,7 @@ static BuildParams build_params(pf_handle* h) {
     const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;
     bp.act_ids = prune_layer >= 0 ? h->d_act_ids : nullptr; bp.reg_act = h->d_reg_act;
     bp.eorig = h->d_eorig;
+    bp.pa_static = share ? h->d_pa_static : nullptr;
     return bp;
 }
 // conv layer 0 of an inference call runs on the row-group kernels: they encode the rows they read on the fly, so the
@@ -691,13 +711,16 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     ep.h_out = train ? h->t_H[0] : h->d_h[0];
 
     const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;    // the layer restricted to active atoms
-    BuildParams bp = build_params(h);
-    bool pre_ready = false;
     // conv layer 0 on the row-group kernels: they encode the rows they read on the fly, only the edge build is launched
     // -- unless the previous denoising step's update launch has built the edges of these coordinates already
     const bool enc_fly = !train && encoders_on_the_fly(h);
+    // pocket sharing: copies of a pocket read one set of layer-0 pp messages (calls at one common t only)
+    const bool share = enc_fly && t_scalar != nullptr && prune_layer == 0 && share_now(h);
+    if (h->edges_built && h->edges_share != share) h->edges_built = false;       // built for the other mode: rebuild
+    BuildParams bp = build_params(h, share);
+    bool pre_ready = false;
     if (enc_fly) {
-        if (!h->edges_built) { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); }
+        if (!h->edges_built) { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); h->edges_share = share; }
     }
     else if (h->prof_mask & 3u) {     // timing the two halves separately needs separate launches
         { ProfScope ps(h, pf_handle::K_ENCODE, s); pfk_encode(&ep, s); }
@@ -753,11 +776,21 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         }
         for (int et = 0; et < 4; ++et) e.rg[et] = h->d_w + h->rg_msg[(size_t)l * 4 + et];
         // every edge of this launch lives in a dynamic region (each wave scans the region lengths: up to 1024 regions = 64 * RG_CPASS)
+        const bool shared = share && pruned && l == 0;       // pocket sharing: kind-3 regions = static ranges of the representatives
+        // capacity of region r in groups of gs slots (a shared kind-3 region is cut on absolute multiples of gs)
+        auto region_groups = [&](int r, int gs) {
+            if (shared && r >= 3 * h->B) {
+                const int st = h->h_share_start[r - 3 * h->B], cn = h->h_share_cnt[r - 3 * h->B];
+                return cn > 0 ? (st + cn - 1) / gs - st / gs + 1 : 0;
+            }
+            return (h->h_cap[r] + gs - 1) / gs;
+        };
         if ((last || pruned) && h->rg_compact && (last ? 2 : 4) * h->B <= 1024) {
-            e.reg = h->d_reg; e.regB = h->B; e.nreg = (last ? 2 : 4) * h->B;
-            for (int r = 0; r < e.nreg; ++r) { e.ngroups4 += (h->h_cap[r] + 3) / 4; e.ngroups8 += (h->h_cap[r] + 7) / 8; }
+            e.reg = shared ? h->d_reg_share : h->d_reg; e.regB = h->B; e.nreg = (last ? 2 : 4) * h->B;
+            e.pa_abs = shared ? 1 : 0;
+            for (int r = 0; r < e.nreg; ++r) { e.ngroups4 += region_groups(r, 4); e.ngroups8 += region_groups(r, 8); }
         }
-        int rg = train ? 0 : h->rg_mode(e.ntiles);           // the node launch of this layer follows (partial-row grouping)
+        int rg = train ? 0 : h->rg_mode(shared ? (int)((h->share_rows + 31) / 32) : e.ntiles);           // the node launch of this layer follows (partial-row grouping)
         // static hoist: the hoisted ("pa") items of a compact layer-0 launch run a two-block chain and may take 8 rows
         // per wave while the full-chain items (ff, pf, fp) take 4
         int rgp = 0;
@@ -766,11 +799,11 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             e.l0_gid = h->d_gid; e.l0c = h->d_l0c;
             rgp = rg;
             if (e.nreg > 0 && pruned) {
-                rg = (long)e.ntiles * 32 >= h->rg2_rows_min_hoist ? 2 : 1;
+                rg = (shared ? h->share_rows : (long)e.ntiles * 32) >= h->rg2_rows_min_hoist ? 2 : 1;
                 if (h->l0_rga) rg = h->l0_rga;
                 rgp = h->l0_rgp ? h->l0_rgp : rg;
                 if (rg == 2) rgp = 2;
-                for (int r = 0; r < e.nreg; ++r) e.ngroups_sel += (h->h_cap[r] + 4 * (r >= 3 * h->B ? rgp : rg) - 1) / (4 * (r >= 3 * h->B ? rgp : rg));
+                for (int r = 0; r < e.nreg; ++r) e.ngroups_sel += region_groups(r, 4 * (r >= 3 * h->B ? rgp : rg));
             }
             h->last_hoist = 4 * rgp;
         }
@@ -788,7 +821,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         n.tiles = pruned ? h->d_node_tiles_act : h->d_node_tiles;
         n.ntiles = last ? h->n_node_tiles_last : (pruned ? h->n_node_tiles_act : h->n_node_tiles);
         n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
-        n.pp_slot = pruned ? 2 : 1; n.row_ids = h->d_act_ids; n.dyn_cnt = h->d_dyn_cnt;
+        n.pp_slot = pruned ? (shared ? 3 : 2) : 1; n.row_ids = h->d_act_ids; n.dyn_cnt = h->d_dyn_cnt;
         n.msg_s = e.msg_s; n.msg_v = e.msg_v; n.zero_row = h->zero_row;
         n.h_in = e.h; n.v_in = e.v;
         n.h_out = train ? h->t_H[l + 1] : h->d_h[cur ^ 1]; n.v_out = train ? h->t_V[l + 1] : h->d_v[cur ^ 1];
@@ -1214,7 +1247,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
         for (int i = pharm_ptr[g]; i < pharm_ptr[g + 1]; ++i) gid[Np + i] = g;
     }
     // pp edges sorted by destination (stable counting sort): CSR-by-dst
-    std::vector<int> in_start((size_t)3 * N, 0), in_cnt((size_t)3 * N, 0);
+    std::vector<int> in_start((size_t)4 * N, 0), in_cnt((size_t)4 * N, 0);       // [4 slots][N]: BuildParams::in_start
     std::vector<int> deg(Np + 1, 0);
     for (int64_t e = 0; e < n_pp; ++e) {
         if (pp_src[e] < 0 || pp_src[e] >= Np || pp_dst[e] < 0 || pp_dst[e] >= Np) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld out of range", (long long)e);
@@ -1279,6 +1312,61 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
         }
         for (int i = 0; i < Np; ++i) { in_start[(size_t)N + i] = deg[i]; in_cnt[(size_t)N + i] = deg[i + 1] - deg[i]; }
     }
+    // ---- pocket sharing (pf_set_pocket_groups): verify the caller's claim and prepare the tables of the sharing mode
+    bool share = false;
+    h->share_ok = false; h->share_rows = 0;
+    h->h_share_start.assign(B, 0); h->h_share_cnt.assign(B, 0);
+    if (!h->pending_rep.empty()) {
+        std::vector<int> rep;
+        rep.swap(h->pending_rep);                                  // consumed by this bind, whatever happens
+        if ((int)rep.size() != B) PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_groups named %d graphs, this batch has %d", (int)rep.size(), B);
+        long dense = 0, percopy = 0;
+        int nrep = 0;
+        for (int g = 0; g < B; ++g) {
+            const int r = rep[g];
+            if (r < 0 || r >= B || rep[r] != r) PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_groups: graph %d names %d, which is not a representative", g, r);
+            const int np = prot_ptr[g + 1] - prot_ptr[g];
+            if (np != prot_ptr[r + 1] - prot_ptr[r] || epp_g[g] != epp_g[r])
+                PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_groups: graph %d is not a copy of graph %d (%d vs %d atoms, %d vs %d pp edges)",
+                        g, r, np, prot_ptr[r + 1] - prot_ptr[r], epp_g[g], epp_g[r]);
+            if (r != g) {
+                // same static graph: in-degrees and (destination-sorted) sources, pocket-local
+                const int p0g = prot_ptr[g], p0r = prot_ptr[r];
+                for (int i = 0; i < np; ++i)
+                    if (deg[p0g + i + 1] - deg[p0g + i] != deg[p0r + i + 1] - deg[p0r + i])
+                        PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_groups: graph %d is not a copy of graph %d (pp in-degree of atom %d)", g, r, i);
+                const int eg = deg[p0g], er = deg[p0r];
+                for (int k = 0; k < epp_g[g]; ++k)
+                    if (esrc[eg + k] - p0g != esrc[er + k] - p0r)
+                        PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_groups: graph %d is not a copy of graph %d (pp edge %d)", g, r, k);
+                if (from_host && (memcmp(host_prot_x + (size_t)p0g * 3, host_prot_x + (size_t)p0r * 3, (size_t)np * 12) ||
+                                  memcmp(host_prot_h + (size_t)p0g * c.rec_nf, host_prot_h + (size_t)p0r * c.rec_nf, (size_t)np * c.rec_nf * 4)))
+                    PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_groups: graph %d is not a copy of graph %d (coordinates / features differ)", g, r);
+            } else { dense += epp_g[g]; ++nrep; }
+            {   // what the per-copy form computes for this graph: the pp in-edges of its active atoms -- at most nf k
+                // of them, about 60 % of that once the centers' neighbour sets overlap -- at the pocket's mean in-degree
+                const int nf = pharm_ptr[g + 1] - pharm_ptr[g];
+                const int nact = c.pf_k > 0 ? std::min(np, nf * std::min(c.pf_k, np)) : (nf > 0 ? np : 0);
+                percopy += np > 0 ? (long)(0.6 * nact * (double)epp_g[g] / np) : 0;
+            }
+        }
+        // worth it when the representatives' static edges are clearly fewer than the per-copy edges they replace (about
+        // half of them at 30 copies of a 256-atom pocket); the compact work list must cover 4 B regions
+        share = nrep < B && 4 * B <= 1024 && dense * 4 <= percopy * 3;
+        if (share) {
+            for (int g = 0; g < B; ++g) {
+                const int r = rep[g], p0g = prot_ptr[g], p0r = prot_ptr[r], np = prot_ptr[g + 1] - p0g;
+                for (int i = 0; i < np; ++i) {         // slot 3: the representative's static in-edge range of the same atom
+                    in_start[(size_t)3 * N + p0g + i] = deg[p0r + i];
+                    in_cnt[(size_t)3 * N + p0g + i] = deg[p0r + i + 1] - deg[p0r + i];
+                }
+                if (r == g) { h->h_share_start[g] = deg[p0g]; h->h_share_cnt[g] = epp_g[g]; }
+            }
+            h->share_rows = dense;
+            for (int et = 0; et < 3; ++et) for (int g = 0; g < B; ++g) h->share_rows += h->h_cap[(size_t)et * B + g];
+            h->share_ok = true;
+        }
+    }
     // tiles: dynamic etypes first (they feed the short pharm-side chain), then pp
     std::vector<EdgeTile> et_tiles;
     for (int et = 0; et < 3; ++et) {
@@ -1330,9 +1418,10 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     // table section
     const size_t o_pptr = place((B + 1) * 4), o_fptr = place((B + 1) * 4), o_gid = place((size_t)N * 4), o_reg = place((size_t)4 * B * 4),
                  o_regact = place((size_t)B * 4), o_eta = place(n_eta * sizeof(EdgeTile)), o_nta = place(n_nta * sizeof(NodeTile)),
-                 o_esrc = place(Ecap * 4), o_edst = place(Ecap * 4), o_ins = place((size_t)3 * N * 4), o_inc = place((size_t)3 * N * 4),
+                 o_esrc = place(Ecap * 4), o_edst = place(Ecap * 4), o_ins = place((size_t)4 * N * 4), o_inc = place((size_t)4 * N * 4),
                  o_ppc = place((size_t)B * 4), o_et = place(n_et * sizeof(EdgeTile)), o_nt = place(n_nt * sizeof(NodeTile)),
-                 o_ht = place(n_ht * sizeof(NodeTile)), o_pfq = place((size_t)B * 4);
+                 o_ht = place(n_ht * sizeof(NodeTile)), o_pfq = place((size_t)B * 4),
+                 o_regs = place((size_t)4 * B * 4), o_pas = place((size_t)B * 4);
     const size_t index_bytes = off;
     const size_t o_px0 = place((size_t)Np * 3 * 4 + 16), o_ph0 = place((size_t)Np * c.rec_nf * 4 + 16);
     const size_t table_bytes = from_host ? off : index_bytes;      // what the single upload covers
@@ -1366,6 +1455,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     h->d_esrc = (int*)at(o_esrc); h->d_edst = (int*)at(o_edst); h->d_in_start = (int*)at(o_ins); h->d_in_cnt = (int*)at(o_inc);
     h->d_pp_cnt = (int*)at(o_ppc); h->d_edge_tiles = (EdgeTile*)at(o_et); h->d_node_tiles = (NodeTile*)at(o_nt);
     h->d_head_tiles = (NodeTile*)at(o_ht); h->d_pfq_cnt = pfq.empty() ? nullptr : (int*)at(o_pfq);
+    h->d_reg_share = (int*)at(o_regs); h->d_pa_static = (int*)at(o_pas);
     h->d_dyn_cnt = (int*)at(o_dyn); h->d_act_ids = (int*)at(o_act); h->d_l0flag = (int*)at(o_flag); h->d_gnorm = (float*)at(o_gnorm);
     h->d_xn = (float4*)at(o_xn); h->d_prot_x0 = (float*)at(o_px0); h->d_prot_h0 = (float*)at(o_ph0); h->d_pharm_h = (float*)at(o_fh);
     h->d_t = (float*)at(o_t); h->d_h[0] = (float*)at(o_h0); h->d_h[1] = (float*)at(o_h1); h->d_v[0] = (float*)at(o_v0); h->d_v[1] = (float*)at(o_v1);
@@ -1395,13 +1485,19 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     if (!n_act.empty()) memcpy(st + o_nta, n_act.data(), n_act.size() * sizeof(NodeTile));
     memcpy(st + o_esrc, esrc.data(), (size_t)Ecap * 4);
     memcpy(st + o_edst, edst.data(), (size_t)Ecap * 4);
-    memcpy(st + o_ins, in_start.data(), (size_t)3 * N * 4);
-    memcpy(st + o_inc, in_cnt.data(), (size_t)3 * N * 4);
+    memcpy(st + o_ins, in_start.data(), (size_t)4 * N * 4);
+    memcpy(st + o_inc, in_cnt.data(), (size_t)4 * N * 4);
     memcpy(st + o_ppc, pp_cnt.data(), (size_t)B * 4);
     if (!et_tiles.empty()) memcpy(st + o_et, et_tiles.data(), et_tiles.size() * sizeof(EdgeTile));
     if (!n_tiles.empty()) memcpy(st + o_nt, n_tiles.data(), n_tiles.size() * sizeof(NodeTile));
     if (!h_tiles.empty()) memcpy(st + o_ht, h_tiles.data(), h_tiles.size() * sizeof(NodeTile));
     if (!pfq.empty()) memcpy(st + o_pfq, pfq.data(), (size_t)B * 4);
+    {
+        std::vector<int> regs(h->h_reg);
+        for (int g = 0; g < B && share; ++g) regs[(size_t)3 * B + g] = h->h_share_start[g];
+        memcpy(st + o_regs, regs.data(), (size_t)4 * B * 4);
+        if (share) memcpy(st + o_pas, h->h_share_cnt.data(), (size_t)B * 4); else memset(st + o_pas, 0, (size_t)B * 4);
+    }
     int host_onehot = -1;
     if (from_host) {
         memcpy(st + o_px0, host_prot_x, (size_t)Np * 3 * 4);
@@ -1476,6 +1572,13 @@ int pf_set_pocket_batch_host(pf_handle* h, int32_t B, const int32_t* prot_ptr, c
                              const int32_t* pp_dst, pf_stream stream) {
     if (h && (!host_prot_x || !host_prot_h)) PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_batch_host: bad argument");
     return set_pocket_batch_impl(h, B, prot_ptr, pharm_ptr, nullptr, nullptr, host_prot_x, host_prot_h, n_pp, pp_src, pp_dst, stream);
+}
+
+int pf_set_pocket_groups(pf_handle* h, int32_t B, const int32_t* host_rep) {
+    if (!h) return PF_ERR_ARG;
+    if (B < 0 || (B > 0 && !host_rep)) PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_groups: bad argument");
+    h->pending_rep.assign(host_rep, host_rep + B);
+    return PF_OK;
 }
 
 int pf_declare_onehot_features(pf_handle* h, int32_t is_onehot) {
@@ -1580,7 +1683,10 @@ int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noi
     sp.a_ts = coef->alpha_t_given_s; sp.var = coef->var_terms; sp.sigma = coef->sigma;
     sp.ep_zt = coef->ep_zt; sp.ep_pred = coef->ep_pred; sp.ep_coord = ep_coord; sp.ep_feat = ep_feat;
     if (encoders_on_the_fly(h)) {           // update + the edges of the next dynamics call in one launch
-        const BuildParams bp = build_params(h);
+        const pf_config& cc = h->cfg;
+        const bool share = (h->prune && cc.n_convs == 2) && share_now(h);     // what the next denoising step's dynamics call will ask for
+        const BuildParams bp = build_params(h, share);
+        h->edges_share = share;
         // kNN pf edges and pockets of at most 512 atoms: the latency-optimised kernel (one atom per thread)
         const int fast = (h->cfg.pf_k > 0 && h->max_np <= 512 && h->step_build_fast) ? 1 : 0;
         { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_build(&sp, &bp, fast, s); }
@@ -1902,7 +2008,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         p.o_bout = (int)h->flat_offset("dynamics.noise_predictor.noise_predictor.to_scalar_output.bias");
         p.pharm_nf = c.pharm_nf; p.g_eps_h = dev_g_eps_h; p.g_eps_x = dev_g_eps_x;
         p.G_h = h->t_G_h[0]; p.G_v = h->t_G_v[0];
-        pfk_bwd_head(&p, std::max(1, std::min(nb, 2 * p.ntiles)), s);
+        { ProfScope ps(h, pf_handle::K_BWD_HEAD, s); pfk_bwd_head(&p, std::max(1, std::min(nb, 2 * p.ntiles)), s); }
     }
     int a = 0;
     for (int l = L - 1; l >= 0; --l) {
@@ -1935,7 +2041,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
             n.o_ln[nt][2] = (int)h->flat_offset(p2 + "weight"); n.o_ln[nt][3] = (int)h->flat_offset(p2 + "bias");
         }
         n.layer = l; n.l0 = l == 0;
-        pfk_bwd_node(&n, std::max(1, std::min(nb, 2 * n.ntiles)), s);
+        { ProfScope ps(h, pf_handle::K_BWD_NODE, s); pfk_bwd_node(&n, std::max(1, std::min(nb, 2 * n.ntiles)), s); }
         BwdEdgeLevelParams e{};
         e.c = tc; e.tiles = pruned ? h->d_edge_tiles_act : h->d_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
         e.pp_slot = pruned ? 2 : 1;
@@ -1968,7 +2074,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         e.rbf_inv_sigma = 1.0f / ((c.rbf_dmax - 0.f) / (float)c.rbf_dim);
         e.l0 = l == 0;
         e.A_h = h->t_A_h; e.A_v = h->t_A_v; e.fix = h->t_fix;
-        for (int lv = c.n_message_gvps - 1; lv >= 0; --lv) { e.level = lv; pfk_bwd_edge_level(&e, s); }
+        for (int lv = c.n_message_gvps - 1; lv >= 0; --lv) { e.level = lv; ProfScope ps(h, pf_handle::K_BWD_EDGE_LEVEL, s); pfk_bwd_edge_level(&e, s); }
         pfk_fix_apply(h->t_A_h, e.G_h_in, (size_t)N * PF_S, h->t_fix, s);
         if (l != 0) pfk_fix_apply(h->t_A_v, e.G_v_in, (size_t)N * 48, h->t_fix, s);       // conv layer 0 has no vector input
         a ^= 1;
@@ -2030,21 +2136,28 @@ int pf_profile_enable(pf_handle* h, uint32_t kernel_mask) {
     return PF_OK;
 }
 
-int pf_profile_read(pf_handle* h, double* total_ms, int64_t* launches, pf_stream stream) {
+static int profile_read_range(pf_handle* h, int k0, int k1, double* total_ms, int64_t* launches, pf_stream stream) {
     if (!h || !total_ms || !launches) return PF_ERR_ARG;
     PF_HIP(h, hipStreamSynchronize((hipStream_t)stream));
-    for (int k = 0; k < pf_handle::K_NUM; ++k) {
+    for (int k = k0; k < k1; ++k) {
         double tot = 0.0;
         for (size_t i = 0; i < h->prof_used[k]; ++i) {
             float ms = 0.f;
             PF_HIP(h, hipEventElapsedTime(&ms, h->prof_ev[k][i].first, h->prof_ev[k][i].second));
             tot += ms;
         }
-        total_ms[k] = tot;
-        launches[k] = (int64_t)h->prof_used[k];
+        total_ms[k - k0] = tot;
+        launches[k - k0] = (int64_t)h->prof_used[k];
         h->prof_used[k] = 0;
     }
     return PF_OK;
+}
+
+int pf_profile_read(pf_handle* h, double* total_ms, int64_t* launches, pf_stream stream) {
+    return profile_read_range(h, 0, pf_handle::K_BWD_HEAD, total_ms, launches, stream);
+}
+int pf_profile_read_train(pf_handle* h, double* total_ms, int64_t* launches, pf_stream stream) {
+    return profile_read_range(h, pf_handle::K_BWD_HEAD, pf_handle::K_NUM, total_ms, launches, stream);
 }
 
 int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges, double* executed_flops,

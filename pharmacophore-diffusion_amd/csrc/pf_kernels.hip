@@ -1336,12 +1336,13 @@ struct PpPrefetch {
 __device__ __forceinline__ void pp_prefetch(const BuildParams& p, const int p0, const int Np, PpPrefetch& f) {
     f.st = 0; f.deg = 0;
     const int c = threadIdx.x;
-    if (p.act_ids && c < Np) {
+    const bool want = p.act_ids && !p.pa_static && c < Np;       // (pocket sharing: no pa copy, nothing to prefetch)
+    if (want) {
         f.st = p.in_start[p.N + p0 + c];
         f.deg = p.in_cnt[p.N + p0 + c];
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) f.src[k] = (p.act_ids && c < Np) ? p.esrc[f.st + min(k, max(f.deg - 1, 0))] : 0;
+    for (int k = 0; k < 16; ++k) f.src[k] = want ? p.esrc[f.st + min(k, max(f.deg - 1, 0))] : 0;
 }
 
 template <typename Refs>
@@ -1368,8 +1369,8 @@ __device__ __forceinline__ void emit_prot_side(const BuildParams& p, const int g
             in_start0[p0 + c] = e;
             in_cnt0[p0 + c] = my;
             if (my) refs(c, [&](int fl) { p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; });
-            if (act) {
-                p.act_ids[reg_act + (int)((o >> 16) & 0xfffu)] = p0 + c;
+            if (act) p.act_ids[reg_act + (int)((o >> 16) & 0xfffu)] = p0 + c;
+            if (act && !p.pa_static) {
                 const int d0 = reg_pa + (int)(o >> 28), s0 = c0 == 0 ? pre.st : in_start1[p0 + c];
                 in_start2[p0 + c] = d0;
                 in_cnt2[p0 + c] = deg;
@@ -1395,7 +1396,7 @@ __device__ __forceinline__ void emit_prot_side(const BuildParams& p, const int g
         base += tot;
     }
     if (tid == 0 && p.act_ids) {
-        p.dyn_cnt[3 * p.B + g] = (int)(base >> 28);
+        p.dyn_cnt[3 * p.B + g] = p.pa_static ? p.pa_static[g] : (int)(base >> 28);
         p.dyn_cnt[4 * p.B + g] = (int)((base >> 16) & 0xfffu);
     }
 }
@@ -1816,7 +1817,7 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
     int pst = 0, pdeg = 0;
     if (isp) {
         xp = sp.xn[p0 + tid];
-        if (p.act_ids) { pst = in_start1[p0 + tid]; pdeg = in_cnt1[p0 + tid]; }
+        if (p.act_ids && !p.pa_static) { pst = in_start1[p0 + tid]; pdeg = in_cnt1[p0 + tid]; }
     }
     // feature update of the pharm nodes (independent of everything else): load, update, store
     if (isf) {
@@ -1830,7 +1831,7 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
     // ---- (C) static pp sources of this thread's atom (used only if the atom turns out to be active)
     int psrc[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) psrc[k] = (isp && p.act_ids) ? p.esrc[pst + min(k, max(pdeg - 1, 0))] : 0;
+    for (int k = 0; k < 16; ++k) psrc[k] = (isp && p.act_ids && !p.pa_static) ? p.esrc[pst + min(k, max(pdeg - 1, 0))] : 0;
     // ---- coordinate update (pharmacodiff.py:397-426) and COM removal of pharm AND prot coordinates (:429)
     float m[3] = {0.f, 0.f, 0.f};
     if (isf) {
@@ -1980,16 +1981,18 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
             if (act) {
                 const int j = (int)((o >> 16) & 0xfffu);
                 p.act_ids[reg_act + j] = p0 + c;
-                in_start2[p0 + c] = reg_pa + (int)(o >> 28);
-                in_cnt2[p0 + c] = deg;
-                a_d0[j] = (int)(o >> 28); a_node[j] = p0 + c; a_pst[j] = pst;
+                if (!p.pa_static) {
+                    in_start2[p0 + c] = reg_pa + (int)(o >> 28);
+                    in_cnt2[p0 + c] = deg;
+                    a_d0[j] = (int)(o >> 28); a_node[j] = p0 + c; a_pst[j] = pst;
+                }
             }
         }
         BSTAMP(14);                                   // fp edges / descriptors stored, active atoms staged
         lds_barrier();
         BSTAMP(15);
         {   // the "pa" region: slot t belongs to the last active atom whose first slot is <= t (binary search in LDS)
-            const int n_pa = (int)(all >> 28), n_act = (int)((all >> 16) & 0xfffu);
+            const int n_pa = p.pa_static ? 0 : (int)(all >> 28), n_act = (int)((all >> 16) & 0xfffu);
             for (int t = tid; t < n_pa; t += NT) {
                 int lo = 0, hi = n_act - 1;
                 while (lo < hi) {
@@ -2004,7 +2007,7 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
             }
         }
         if (tid == 0 && p.act_ids) {
-            p.dyn_cnt[3 * p.B + g] = (int)(all >> 28);
+            p.dyn_cnt[3 * p.B + g] = p.pa_static ? p.pa_static[g] : (int)(all >> 28);
             p.dyn_cnt[4 * p.B + g] = (int)((all >> 16) & 0xfffu);
         }
         if (tid == NT - 64 && p.norm_mode == 2) {     // per-graph normalisers for message_norm == 0 (gvp.py:504-507)

@@ -721,11 +721,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_rg_edge(const EdgeParams p, cons
         }
         constexpr int SH = RG == 2 ? 3 : 2, SHP = RGP == 2 ? 3 : 2;
         const int pa0 = (hoist && RGP != RG) ? 3 * p.regB : 0x7fffffff;      // first region cut into groups of 4 RGP
+        const int abs0 = p.pa_abs ? 3 * p.regB : 0x7fffffff;                 // first region whose groups sit on absolute boundaries
 #pragma unroll
         for (int k = 0; k < RG_CPASS; ++k) {
             if (64 * k < p.nreg && rsel < 0) {           // wave-uniform
                 const int c = cs[k];
-                const int ng = (64 * k + lane >= pa0) ? (c + (1 << SHP) - 1) >> SHP : (c + G - 1) >> SH;
+                const int gsh = (64 * k + lane >= pa0) ? SHP : SH;
+                const int ng = (64 * k + lane >= abs0) ? (c > 0 ? ((rs[k] + c - 1) >> gsh) - (rs[k] >> gsh) + 1 : 0)
+                                                       : (c + (1 << gsh) - 1) >> gsh;
                 int incl = ng;
                 incl += dpp_i<0x111>(incl); incl += dpp_i<0x112>(incl); incl += dpp_i<0x114>(incl); incl += dpp_i<0x118>(incl);
                 incl += dpp_ir<0x142, 0xa>(incl); incl += dpp_ir<0x143, 0xc>(incl);
@@ -744,9 +747,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_rg_edge(const EdgeParams p, cons
         const int kind = rsel / p.regB;
         pre = hoist && kind == 3;
         const int Gs = (pre && RGP != RG) ? 4 * RGP : G;
-        const int loc = (w - first) * Gs;
-        e0 = start + loc;
-        nv = __builtin_amdgcn_readfirstlane(min(Gs, cnt - loc));
+        if (p.pa_abs && kind == 3) {                   // static range: group (w - first) of the absolute grid of Gs slots
+            const int lo = ((start / Gs) + (w - first)) * Gs;
+            e0 = max(start, lo);
+            nv = __builtin_amdgcn_readfirstlane(min(start + cnt, lo + Gs) - e0);
+        } else {
+            const int loc = (w - first) * Gs;
+            e0 = start + loc;
+            nv = __builtin_amdgcn_readfirstlane(min(Gs, cnt - loc));
+        }
         et = kind == 3 ? (int)ET_PP : kind;            // fourth region kind: pp edges into the active atoms
     } else {
         const int bid = item;

@@ -96,9 +96,17 @@ class PfEngine:
             return _f32(t, self.device)
         return t.detach().to(torch.float32).contiguous().pin_memory().to(self.device, non_blocking=True)
 
-    def set_batch(self, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst):
-        """pf_set_pocket_batch / pf_set_pocket_batch_host: asynchronous on the current stream."""
+    def set_batch(self, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, pocket_uid=None):
+        """pf_set_pocket_batch / pf_set_pocket_batch_host: asynchronous on the current stream.  ``pocket_uid`` ([B]
+        integers, optional): graphs with equal values are copies of one pocket (PocketGraph.pocket_uid); the library
+        verifies that and lets the copies share conv layer 0's protein-protein messages during sampling."""
         import numpy as np
+        if pocket_uid is not None:
+            uid = np.asarray(pocket_uid.detach().cpu().numpy() if isinstance(pocket_uid, torch.Tensor) else pocket_uid).reshape(-1)
+            first = {}
+            rep = np.asarray([first.setdefault(int(u), i) for i, u in enumerate(uid)], dtype=np.int32)
+            if len(first) < rep.size:                     # at least one pocket has copies
+                self._ck(self.lib.pf_set_pocket_groups(self._h, int(rep.size), rep.ctypes.data), "pf_set_pocket_groups")
         # index arrays: int32 host copies through numpy (single-threaded; a torch dtype conversion of half a million
         # elements goes through the intra-op thread pool, whose wake-up stalls for tens of milliseconds now and then on
         # hosts with hundreds of hardware threads)
@@ -326,6 +334,16 @@ class PfEngine:
 
     def profile_enable(self, mask: int):
         self._ck(self.lib.pf_profile_enable(self._h, mask), "pf_profile_enable")
+
+    TRAIN_KERNEL_CLASSES = ("bwd_head", "bwd_node", "bwd_edge_level", "bwd_rest")
+
+    def profile_read_train(self):
+        """{gradient-kernel class: (total device ms, launches)} since the last read (profile_enable bits 9..12)."""
+        ms = (ctypes.c_double * 4)()
+        n = (ctypes.c_int64 * 4)()
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_profile_read_train(self._h, ms, n, _stream_ptr()), "pf_profile_read_train")
+        return {k: (ms[i], n[i]) for i, k in enumerate(self.TRAIN_KERNEL_CLASSES)}
 
     def profile_read(self):
         """{kernel class: (total device ms, launches)} since the last enable/read (synchronises)."""

@@ -8,10 +8,14 @@ their node type ('prot', 'pharm', 'prot_ph'); graph g owns the contiguous ranges
 prot<->pharm edges are rebuilt on the device at every denoising step (dynamics_gvp.py:187-246)."""
 from __future__ import annotations
 
+import itertools
 from dataclasses import dataclass, field, replace
 from typing import Dict, List, Optional
 
 import torch
+
+
+_pocket_uids = itertools.count(1)
 
 
 def _ptr(counts) -> torch.Tensor:
@@ -40,6 +44,9 @@ class PocketGraph:
     h_t: Optional[torch.Tensor] = None
     pp_ptr: Optional[torch.Tensor] = None      # [B+1] int64 (host): graph g owns pp edges [pp_ptr[g], pp_ptr[g+1]) -- set by
                                                # batch(); lets unbatch() skip the search for the per-graph edge ranges
+    pocket_uid: Optional[torch.Tensor] = None  # [B] int64 (host): graphs with the same value are COPIES of one pocket (same
+                                               # atoms, features, coordinates, pp edges) -- stamped by copy_graph, carried
+                                               # through batch / unbatch / to; the engine lets such copies share work
 
     # -- DGL-like accessors used by the reference's drivers --------------------------------
     @property
@@ -118,9 +125,14 @@ def batch(graphs: List[PocketGraph]) -> PocketGraph:
         e_counts.append(int(g.pp_src.numel()))
     # per-graph edge ranges are known only when every input is a single graph (a batched input keeps its own grouping)
     pp_ptr = _ptr(e_counts) if all(g.batch_size == 1 for g in graphs) else None
+    # graphs without a stamp are pockets of their own: fresh values (negative, so they never meet a copy_graph stamp)
+    uid = None
+    if any(g.pocket_uid is not None for g in graphs):
+        uid = torch.cat([g.pocket_uid if g.pocket_uid is not None else -((next(_pocket_uids) << 20) + torch.arange(g.batch_size))
+                         for g in graphs])
     return PocketGraph(cat("prot_x"), cat("prot_h"), _ptr(prot_counts), _ptr(pharm_counts), torch.cat(srcs), torch.cat(dsts),
                        cat("pharm_x0"), cat("pharm_h0"), cat("prot_ph_x"), cat("prot_ph_h"), _ptr(ph_counts),
-                       cat("x_t"), cat("h_t"), pp_ptr)
+                       cat("x_t"), cat("h_t"), pp_ptr, uid)
 
 
 def unbatch(g: PocketGraph) -> List[PocketGraph]:
@@ -154,7 +166,8 @@ def unbatch(g: PocketGraph) -> List[PocketGraph]:
         out.append(PocketGraph(g.prot_x[p0:p1], g.prot_h[p0:p1], _ptr1(p1 - p0), _ptr1(f1 - f0), src, dst,
                                sl(g.pharm_x0, f0, f1), sl(g.pharm_h0, f0, f1),
                                sl(g.prot_ph_x, q0, q1), sl(g.prot_ph_h, q0, q1), _ptr1(q1 - q0),
-                               sl(g.x_t, f0, f1), sl(g.h_t, f0, f1)))
+                               sl(g.x_t, f0, f1), sl(g.h_t, f0, f1),
+                               pocket_uid=None if g.pocket_uid is None else g.pocket_uid[b:b + 1]))
     return out
 
 
@@ -163,8 +176,10 @@ def copy_graph(g: PocketGraph, n_copies: int, pharm_feats_per_copy=None, batched
     copy i gets that many pharmacophore nodes with zeroed features (always indexed from 0, like the
     reference, SURVEY.md section 7 "quirks")."""
     copies = []
+    # the copies of a single pocket are stamped as such (a batched input keeps whatever stamps its graphs carry)
+    uid = g.pocket_uid if (g.pocket_uid is not None or g.batch_size != 1) else torch.tensor([next(_pocket_uids)], dtype=torch.int64)
     for i in range(n_copies):
-        c = replace(g, prot_x=g.prot_x.detach().clone(), prot_h=g.prot_h.detach().clone())
+        c = replace(g, prot_x=g.prot_x.detach().clone(), prot_h=g.prot_h.detach().clone(), pocket_uid=uid)
         if pharm_feats_per_copy is not None:
             if batched_graph:
                 raise ValueError("pharm_feats_per_copy needs a single (unbatched) graph")

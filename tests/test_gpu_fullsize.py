@@ -222,3 +222,60 @@ def test_workspace_reuse_leaves_no_trace_of_the_previous_batch():
     used.train_forward(x_t, h_t, t, prot_x=small.prot_x, dropout=0.1, seed=9)
     g = used.train_backward(w_h, w_x)
     assert torch.equal(g, g_ref)
+
+
+def _copies_batch(cfg, pockets, sizes_per_pocket):
+    """[(seed, n_prot)] x [[sizes]] -> (PocketBatch of the copies in pocket order, pocket uid per graph)."""
+    parts, uid = [], []
+    for k, ((seed, n), sizes) in enumerate(zip(pockets, sizes_per_pocket)):
+        pocket = O.synthetic_batch([seed], n, 1, cfg)
+        parts += [O.copy_pocket(pocket, s) for s in sizes]
+        uid += [k + 1] * len(sizes)
+    return O.concat_pockets(parts), torch.tensor(uid)
+
+
+def test_pocket_sharing_equals_the_per_copy_path():
+    """Copies of one pocket at the same timestep share conv layer 0's protein->protein messages (pf_set_pocket_groups):
+    a 40-step trajectory of 3 pockets x (24, 20, 21) ragged copies with sharing == without, against the oracle too; the
+    shared launch computes fewer edges; per-graph timesteps (pf_dynamics_forward) on the same bind fall back to the
+    per-copy path; a false claim is refused."""
+    _no_policy_overrides()
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    sizes = [3, 8, 5, 4, 6, 7, 3, 5, 4, 8, 3, 6, 6, 3, 4, 8, 5, 7, 3, 4, 6, 5, 7, 8]
+    batch, uid = _copies_batch(cfg, [(501, 120), (502, 200), (503, 150)], [sizes, sizes[:20], sizes[3:]])
+    T, n = 100, 40
+    Nf = int(batch.pharm_ptr[-1])
+    noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(3))
+    coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+    res, work = [], []
+    for shared in (False, True):
+        eng = _engine(cfg, sd)
+        eng.set_batch(batch.prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst,
+                      pocket_uid=uid if shared else None)
+        arr = eng.coef_array(coef, reversed(range(n)))
+        x, h = eng.sample(arr, n, noise)
+        res.append((x.cpu(), h.cpu()))
+        work.append(eng.work_detail())
+        if shared:                                   # per-graph t on the same bind: the per-copy path, against the oracle
+            gen = torch.Generator().manual_seed(4)
+            x_t, h_t, t = 2.0 * torch.randn(Nf, 3, generator=gen), torch.randn(Nf, 6, generator=gen), torch.rand(batch.batch_size, generator=gen)
+            eh, ex = eng.dynamics(x_t, h_t, t, prot_x=batch.prot_x)
+            oh, ox = O.dynamics_forward(sd, cfg, batch, batch.prot_x, x_t, h_t, t)
+            torch.testing.assert_close(eh.cpu(), oh, rtol=2e-4, atol=2e-4)
+            torch.testing.assert_close(ex.cpu(), ox, rtol=2e-4, atol=2e-4)
+            x2, h2 = eng.sample(arr, n, noise)       # and back to the shared form: bitwise what it gave before
+            assert torch.equal(x2.cpu(), res[1][0]) and torch.equal(h2.cpu(), res[1][1])
+    torch.testing.assert_close(res[1][0], res[0][0], rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(res[1][1], res[0][1], rtol=2e-4, atol=2e-4)
+    assert work[1]["executed_edges_per_layer"][0] < 0.8 * work[0]["executed_edges_per_layer"][0], (work[0], work[1])
+    assert work[1]["flops"] == work[0]["flops"]                    # the reference-equivalent work is the same
+    # a claim that does not hold: graph 1 named a copy of a pocket with another atom count
+    eng = _engine(cfg, sd)
+    bad = uid.clone(); bad[24] = 1
+    with pytest.raises(pfa.PfError, match="not a copy"):
+        eng.set_batch(batch.prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst, pocket_uid=bad)
+    # ... and one that the host copy of the coordinates exposes
+    px = batch.prot_x.clone(); px[130] += 0.01                     # an atom of the second copy of the first pocket
+    with pytest.raises(pfa.PfError, match="coordinates / features differ"):
+        eng.set_batch(px, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst, pocket_uid=uid)

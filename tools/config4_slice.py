@@ -2,7 +2,8 @@
 """Wall-clock of a slice of BASELINE config 4 on one GPU: P synthetic 256-atom pockets x 30 samples (sizes 3,3,3,3,3,4..8
 cycling), T=500, max_batch_size 128, through PharmacophoreDiff.sample (graph copies, batching, set_batch, the fused
 pf_sample loop, unbatching into SampledPharmacophore objects).
-    python tools/config4_slice.py [P]"""
+    python tools/config4_slice.py [P] [S]     # S samples per pocket (default 30; 128 = one pocket per batch, the shape of a
+                                              # generate_pharmacophores.py run with --samples_per_pocket 128)"""
 import os
 import sys
 import time
@@ -26,7 +27,8 @@ for i in range(P):
     x, h = synthetic.synthetic_pocket(i, 256)
     pockets.append(pfa.build_initial_complex_graph(x, h, cutoffs={'pp': 3.5, 'pf': 8, 'fp': 8, 'ff': 9},
                                                    pharm_atom_positions=torch.zeros(1, 3), pharm_atom_features=torch.zeros(1, 6)))
-sizes = ([3] * 5 + [4, 5, 6, 7, 8]) * 3
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+sizes = (([3] * 5 + [4, 5, 6, 7, 8]) * 13)[:S]
 n_pharms = [sizes for _ in range(P)]
 torch.manual_seed(0)
 with torch.no_grad():
@@ -37,5 +39,5 @@ with torch.no_grad():
     torch.cuda.synchronize()
     dt = time.time() - t0
 n = sum(len(o) for o in out)
-print(f"{P} pockets x 30 samples = {n} pharmacophores, T={T}: {dt:.2f} s  ->  {n * T / dt / 1e3:.0f} k sample-steps/s end to end, "
+print(f"{P} pockets x {S} samples = {n} pharmacophores, T={T}: {dt:.2f} s  ->  {n * T / dt / 1e3:.0f} k sample-steps/s end to end, "
       f"{dt / P * 1e3:.0f} ms per pocket")
