@@ -150,6 +150,7 @@ struct EdgeParams {
     const int* l0_gid;     // graph of each node (ptab_gstride != 0)
     const float* l0c;      // [16 weff][16 gate bias]
     int ngroups_sel;       // compact work list: grid in groups when the regions' group sizes differ by kind (0: ngroups4/8)
+    const int* need; int need_stamp;   // pocket sharing: a kind-3 item runs only if one of its destinations carries the stamp
     int pa_abs;            // pocket sharing: the kind-3 regions are ranges of STATIC slots with arbitrary starts; their
                            // groups are cut on absolute multiples of the group size (what the node kernel's e | (grp - 1) expects)
 };
@@ -265,6 +266,11 @@ struct BuildParams {
     // representative, 0 for a copy); the per-step pa copy and the slot-2 descriptors are then not written (the node
     // kernel reads slot 3: the representative's static in-edge ranges, uploaded once per batch).  NULL: off.
     const int* pa_static;
+    // ... and every graph marks its active atoms on its representative (need[rep_base[g] + atom] = need_stamp, a value
+    // that is new for every build: nothing to clear), so that the shared launch computes only the static edge groups
+    // that some copy of the pocket reads in this step
+    const int* rep_base;   // [B] node id of the first atom of graph g's representative
+    int* need; int need_stamp;
     const int* pfq_cnt;    // [B] or NULL: the pf / fp edge counts the REFERENCE books per graph when pf edges are kNN
                            // (dynamics_gvp.py:220 looks center indices up in the protein batch vector); used instead of
                            // the true counts by the per-graph normalisers

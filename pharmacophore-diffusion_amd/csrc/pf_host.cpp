@@ -153,6 +153,9 @@ struct pf_handle {
     bool share_ok = false;                  // tables of the sharing mode exist for this batch
     int* d_reg_share = nullptr;             // [4][B]: d_reg with the kind-3 entries of representatives at their static pp edges
     int* d_pa_static = nullptr;             // [B]: static pp edge count of a representative, 0 for a copy
+    int* d_rep_base = nullptr;              // [B]: node id of the first atom of each graph's representative
+    int* d_need = nullptr;                  // [Np]: stamp of the last build in which some copy had the atom active
+    int need_stamp = 0, edges_stamp = 0;    // stamp of the next build / of the build the current edges came from
     long share_rows = 0;                    // edge slots of a shared layer-0 launch (capacities of ff, pf, fp + the static ranges)
     std::vector<int> h_share_start, h_share_cnt;   // host copies of d_reg_share's kind-3 entries / d_pa_static (grid sizing)
     bool share_disable = false;             // PFDYN_NO_POCKET_SHARE=1
@@ -608,6 +611,11 @@ static bool share_now(pf_handle* h) {
     const pf_config& c = h->cfg;
     return h->share_ok && !h->share_disable && h->prune && c.n_convs == 2 && h->rg_compact && l0_hoist_ok(h);
 }
+// a build with these parameters has been enqueued: its stamp is what the next shared edge launch looks for
+static void build_done(pf_handle* h, bool share) {
+    h->edges_share = share;
+    if (share) h->edges_stamp = ++h->need_stamp;
+}
 static BuildParams build_params(pf_handle* h, bool share = false) {
     const pf_config& c = h->cfg;
     BuildParams bp{};
@@ -622,6 +630,7 @@ static BuildParams build_params(pf_handle* h, bool share = false) {
     bp.act_ids = prune_layer >= 0 ? h->d_act_ids : nullptr; bp.reg_act = h->d_reg_act;
     bp.eorig = h->d_eorig;
     bp.pa_static = share ? h->d_pa_static : nullptr;
+    if (share) { bp.rep_base = h->d_rep_base; bp.need = h->d_need; bp.need_stamp = h->need_stamp + 1; }   // committed by build_done()
     return bp;
 }
 // conv layer 0 of an inference call runs on the row-group kernels: they encode the rows they read on the fly, so the
@@ -720,7 +729,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     BuildParams bp = build_params(h, share);
     bool pre_ready = false;
     if (enc_fly) {
-        if (!h->edges_built) { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); h->edges_share = share; }
+        if (!h->edges_built) { ProfScope ps(h, pf_handle::K_BUILD, s); pfk_build_edges(&bp, s); build_done(h, share); }
     }
     else if (h->prof_mask & 3u) {     // timing the two halves separately needs separate launches
         { ProfScope ps(h, pf_handle::K_ENCODE, s); pfk_encode(&ep, s); }
@@ -788,6 +797,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         if ((last || pruned) && h->rg_compact && (last ? 2 : 4) * h->B <= 1024) {
             e.reg = shared ? h->d_reg_share : h->d_reg; e.regB = h->B; e.nreg = (last ? 2 : 4) * h->B;
             e.pa_abs = shared ? 1 : 0;
+            if (shared) { e.need = h->d_need; e.need_stamp = h->edges_stamp; }
             for (int r = 0; r < e.nreg; ++r) { e.ngroups4 += region_groups(r, 4); e.ngroups8 += region_groups(r, 8); }
         }
         int rg = train ? 0 : h->rg_mode(shared ? (int)((h->share_rows + 31) / 32) : e.ntiles);           // the node launch of this layer follows (partial-row grouping)
@@ -799,7 +809,10 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             e.l0_gid = h->d_gid; e.l0c = h->d_l0c;
             rgp = rg;
             if (e.nreg > 0 && pruned) {
-                rg = (shared ? h->share_rows : (long)e.ntiles * 32) >= h->rg2_rows_min_hoist ? 2 : 1;
+                // (a shared launch: most of the representatives' groups return at once, what runs scales with the batch
+                // like the dynamic regions do -- the general threshold applies; measured at 4-5 pockets x 30 copies:
+                // 1.21 M sample-steps/s end to end at 4 rows per wave, 1.26 M at 8)
+                rg = shared ? (h->share_rows >= h->rg2_rows_min ? 2 : 1) : ((long)e.ntiles * 32 >= h->rg2_rows_min_hoist ? 2 : 1);
                 if (h->l0_rga) rg = h->l0_rga;
                 rgp = h->l0_rgp ? h->l0_rgp : rg;
                 if (rg == 2) rgp = 2;
@@ -1314,6 +1327,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     }
     // ---- pocket sharing (pf_set_pocket_groups): verify the caller's claim and prepare the tables of the sharing mode
     bool share = false;
+    std::vector<int> rep_base(B, 0);
     h->share_ok = false; h->share_rows = 0;
     h->h_share_start.assign(B, 0); h->h_share_cnt.assign(B, 0);
     if (!h->pending_rep.empty()) {
@@ -1352,7 +1366,9 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
         }
         // worth it when the representatives' static edges are clearly fewer than the per-copy edges they replace (about
         // half of them at 30 copies of a 256-atom pocket); the compact work list must cover 4 B regions
-        share = nrep < B && 4 * B <= 1024 && dense * 4 <= percopy * 3;
+        // (with the per-step need stamps only the union of the copies' active atoms is computed, so what a
+        // representative costs beyond that is launching the idle groups of its static range)
+        share = nrep < B && 4 * B <= 1024 && (dense * 4 <= percopy * 3 || nrep * 4 <= B);
         if (share) {
             for (int g = 0; g < B; ++g) {
                 const int r = rep[g], p0g = prot_ptr[g], p0r = prot_ptr[r], np = prot_ptr[g + 1] - p0g;
@@ -1360,6 +1376,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
                     in_start[(size_t)3 * N + p0g + i] = deg[p0r + i];
                     in_cnt[(size_t)3 * N + p0g + i] = deg[p0r + i + 1] - deg[p0r + i];
                 }
+                rep_base[g] = p0r;
                 if (r == g) { h->h_share_start[g] = deg[p0g]; h->h_share_cnt[g] = epp_g[g]; }
             }
             h->share_rows = dense;
@@ -1421,13 +1438,14 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
                  o_esrc = place(Ecap * 4), o_edst = place(Ecap * 4), o_ins = place((size_t)4 * N * 4), o_inc = place((size_t)4 * N * 4),
                  o_ppc = place((size_t)B * 4), o_et = place(n_et * sizeof(EdgeTile)), o_nt = place(n_nt * sizeof(NodeTile)),
                  o_ht = place(n_ht * sizeof(NodeTile)), o_pfq = place((size_t)B * 4),
-                 o_regs = place((size_t)4 * B * 4), o_pas = place((size_t)B * 4);
+                 o_regs = place((size_t)4 * B * 4), o_pas = place((size_t)B * 4), o_repb = place((size_t)B * 4);
     const size_t index_bytes = off;
     const size_t o_px0 = place((size_t)Np * 3 * 4 + 16), o_ph0 = place((size_t)Np * c.rec_nf * 4 + 16);
     const size_t table_bytes = from_host ? off : index_bytes;      // what the single upload covers
     const size_t table_end = off;
     // zero section (cleared with one memset per bind)
-    const size_t o_dyn = place((size_t)5 * B * 4), o_act = place((size_t)(act_total + 1) * 4), o_flag = place(256), o_gnorm = place((size_t)2 * B * 4);
+    const size_t o_dyn = place((size_t)5 * B * 4), o_act = place((size_t)(act_total + 1) * 4), o_flag = place(256), o_gnorm = place((size_t)2 * B * 4),
+                 o_need = place((size_t)std::max(Np, 1) * 4);
     const size_t zero_bytes = off - table_end;
     // scratch
     const size_t o_xn = place((size_t)N * 16),
@@ -1455,7 +1473,8 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     h->d_esrc = (int*)at(o_esrc); h->d_edst = (int*)at(o_edst); h->d_in_start = (int*)at(o_ins); h->d_in_cnt = (int*)at(o_inc);
     h->d_pp_cnt = (int*)at(o_ppc); h->d_edge_tiles = (EdgeTile*)at(o_et); h->d_node_tiles = (NodeTile*)at(o_nt);
     h->d_head_tiles = (NodeTile*)at(o_ht); h->d_pfq_cnt = pfq.empty() ? nullptr : (int*)at(o_pfq);
-    h->d_reg_share = (int*)at(o_regs); h->d_pa_static = (int*)at(o_pas);
+    h->d_reg_share = (int*)at(o_regs); h->d_pa_static = (int*)at(o_pas); h->d_rep_base = (int*)at(o_repb); h->d_need = (int*)at(o_need);
+    h->need_stamp = 0; h->edges_stamp = 0;
     h->d_dyn_cnt = (int*)at(o_dyn); h->d_act_ids = (int*)at(o_act); h->d_l0flag = (int*)at(o_flag); h->d_gnorm = (float*)at(o_gnorm);
     h->d_xn = (float4*)at(o_xn); h->d_prot_x0 = (float*)at(o_px0); h->d_prot_h0 = (float*)at(o_ph0); h->d_pharm_h = (float*)at(o_fh);
     h->d_t = (float*)at(o_t); h->d_h[0] = (float*)at(o_h0); h->d_h[1] = (float*)at(o_h1); h->d_v[0] = (float*)at(o_v0); h->d_v[1] = (float*)at(o_v1);
@@ -1497,6 +1516,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
         for (int g = 0; g < B && share; ++g) regs[(size_t)3 * B + g] = h->h_share_start[g];
         memcpy(st + o_regs, regs.data(), (size_t)4 * B * 4);
         if (share) memcpy(st + o_pas, h->h_share_cnt.data(), (size_t)B * 4); else memset(st + o_pas, 0, (size_t)B * 4);
+        memcpy(st + o_repb, rep_base.data(), (size_t)B * 4);
     }
     int host_onehot = -1;
     if (from_host) {
@@ -1686,10 +1706,10 @@ int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noi
         const pf_config& cc = h->cfg;
         const bool share = (h->prune && cc.n_convs == 2) && share_now(h);     // what the next denoising step's dynamics call will ask for
         const BuildParams bp = build_params(h, share);
-        h->edges_share = share;
         // kNN pf edges and pockets of at most 512 atoms: the latency-optimised kernel (one atom per thread)
         const int fast = (h->cfg.pf_k > 0 && h->max_np <= 512 && h->step_build_fast) ? 1 : 0;
         { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_build(&sp, &bp, fast, s); }
+        build_done(h, share);
         h->edges_built = true;
     } else { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_update(&sp, s); }
     return PF_OK;

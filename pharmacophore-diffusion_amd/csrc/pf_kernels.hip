@@ -1370,6 +1370,7 @@ __device__ __forceinline__ void emit_prot_side(const BuildParams& p, const int g
             in_cnt0[p0 + c] = my;
             if (my) refs(c, [&](int fl) { p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; });
             if (act) p.act_ids[reg_act + (int)((o >> 16) & 0xfffu)] = p0 + c;
+            if (act && p.pa_static) p.need[p.rep_base[g] + c] = p.need_stamp;
             if (act && !p.pa_static) {
                 const int d0 = reg_pa + (int)(o >> 28), s0 = c0 == 0 ? pre.st : in_start1[p0 + c];
                 in_start2[p0 + c] = d0;
@@ -1981,7 +1982,8 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
             if (act) {
                 const int j = (int)((o >> 16) & 0xfffu);
                 p.act_ids[reg_act + j] = p0 + c;
-                if (!p.pa_static) {
+                if (p.pa_static) p.need[p.rep_base[g] + c] = p.need_stamp;
+                else {
                     in_start2[p0 + c] = reg_pa + (int)(o >> 28);
                     in_cnt2[p0 + c] = deg;
                     a_d0[j] = (int)(o >> 28); a_node[j] = p0 + c; a_pst[j] = pst;

@@ -771,6 +771,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_rg_edge(const EdgeParams p, cons
         pre = hoist && RGP == RG && et == ET_PP;
     }
     if constexpr (RGP > 0) {
+        if (pre && p.need) {
+            // pocket sharing: this group of a representative's static pp edges is computed only if some copy of the
+            // pocket reads one of its destinations in this step (its build stamped the atom)
+            const int e = e0 + min(lane, nv - 1);
+            const bool wanted = p.need[p.edst[e]] == p.need_stamp;
+            if (!__any(wanted)) return;                // wave-uniform
+        }
         if (pre) { rg_edge_item<L0, RGP, WAVES, true>(p, ep, lds, item, wq, e0, nv, et, lane); return; }
     }
 #ifdef PF_TWICE                                       // diagnostic: every item twice through the SAME code (warm instruction cache the second time)

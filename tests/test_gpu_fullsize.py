@@ -161,7 +161,7 @@ def test_config4_slice_sharded_equals_single_rank_bitwise():
     assert [len(o) for o in full] == [per] * n_pockets
     assert [[p.n_ph_centers for p in o] for o in full] == n_pharms
     assert all(torch.isfinite(p.ph_coords).all() for o in full for p in o)
-    assert m.dynamics.engine().kernel_family(0) == 8
+    assert m.dynamics.engine().kernel_family(0) in (4, 8)
     halves = []
     for r in range(2):
         torch.manual_seed(11)                                   # the ranks of a job share the seed
