@@ -47,12 +47,14 @@ void pfk_export_coords(const float4* xn, int base, int n, const int* gid, const 
                        float* out, hipStream_t s);
 void pfk_bwd_head(const BwdHeadParams* p, int nblocks, hipStream_t s);
 void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s);
-void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, hipStream_t s);
+void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, int nblocks, hipStream_t s);
 void pfk_fix_apply(long long* A, float* G, size_t n, const float* fix, hipStream_t s);
 void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* fix, hipStream_t s);
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
 void pfk_train_reduce(const float* gpart, int nblocks, int nparams, float* grad, hipStream_t s);
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s);
+void pfk_pack_bwd(const float* W, const GvpT* g, int n_gvps, float* out, hipStream_t s);
+void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s);
 void pfk_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
               float bc1, float bc2_sqrt, hipStream_t s);
 void pfk_drop_masks(const TrainCommon* c, uint32_t stream, int n_elems, float* out, hipStream_t s);
@@ -249,6 +251,9 @@ struct pf_handle {
     float *t_G_h[2] = {nullptr, nullptr}, *t_G_v[2] = {nullptr, nullptr}, *t_gagg_s = nullptr, *t_gagg_v = nullptr,
           *t_gpart = nullptr, *t_geps_h = nullptr, *t_geps_x = nullptr;
     long long *t_A_h = nullptr, *t_A_v = nullptr;      // fixed-point accumulators of the level-0 scatter (kept clear between uses)
+    float* d_wpack = nullptr;               // k_pack_bwd fragments of every message GVP; valid for w_version == wpack_version
+    uint64_t wpack_version = ~0ull;
+    int *t_clist = nullptr, *t_ccnt = nullptr;   // compact list of non-empty edge tiles of the layer being differentiated
     float* t_fix = nullptr;                 // [2] scale / inverse scale of the current backward call
     int t_nblk = 0;
     const float* t_mask_override = nullptr; // pf_debug_set_dropout_masks
@@ -944,6 +949,7 @@ void pf_destroy(pf_handle* h) {
     if (h->d_w) (void)hipFree(h->d_w);
     if (h->d_gvp) (void)hipFree(h->d_gvp);
     if (h->d_flat) (void)hipFree(h->d_flat);
+    if (h->d_wpack) (void)hipFree(h->d_wpack);
     if (h->d_gvpt) (void)hipFree(h->d_gvpt);
     if (h->d_map) (void)hipFree(h->d_map);
     if (h->d_l0c) (void)hipFree(h->d_l0c);
@@ -1209,6 +1215,8 @@ int pf_commit_weights(pf_handle* h) {
         for (int k = 0; k < c.n_noise_gvps; ++k) tab.push_back(mk(head_spec(c, k), k != c.n_noise_gvps - 1));
         if (h->d_flat) { (void)hipFree(h->d_flat); h->d_flat = nullptr; }
         if (h->d_gvpt) { (void)hipFree(h->d_gvpt); h->d_gvpt = nullptr; }
+        if (h->d_wpack) { (void)hipFree(h->d_wpack); h->d_wpack = nullptr; }
+        h->wpack_version = ~0ull;
         PF_HIP(h, hipMalloc((void**)&h->d_flat, std::max<size_t>(flat.size(), 1) * sizeof(float)));
         PF_HIP(h, hipMemcpy(h->d_flat, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice));
         PF_HIP(h, hipMalloc((void**)&h->d_gvpt, tab.size() * sizeof(GvpT)));
@@ -1883,6 +1891,7 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     need((size_t)N * PF_S); need((size_t)N * 48);
     need((size_t)2 * N * PF_S); need((size_t)2 * N * 48);          // int64 accumulators (two floats per element)
     need(64);
+    need(64); need((size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);      // compact tile list and its counts
     need((size_t)h->t_nblk * h->nparams);
     const size_t Es = (size_t)std::max<int64_t>(h->Ecap, 1), ng = (size_t)c.n_message_gvps;
     for (int l = 0; l < L; ++l) { need(ng * Es * PF_S); need(ng * Es * 16); need(ng * Es * 48); }
@@ -1907,6 +1916,8 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     h->t_A_h = reinterpret_cast<long long*>(carve<float>(cur, (size_t)2 * N * PF_S));
     h->t_A_v = reinterpret_cast<long long*>(carve<float>(cur, (size_t)2 * N * 48));
     h->t_fix = carve<float>(cur, 64);
+    h->t_ccnt = carve<int>(cur, 64);
+    h->t_clist = carve<int>(cur, (size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);
     PF_HIP(h, hipMemsetAsync(h->t_A_h, 0, (size_t)N * PF_S * 8, s));       // pfk_fix_apply keeps them clear afterwards
     PF_HIP(h, hipMemsetAsync(h->t_A_v, 0, (size_t)N * 48 * 8, s));
     h->t_gpart = carve<float>(cur, (size_t)h->t_nblk * h->nparams);
@@ -2015,6 +2026,11 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     const pf_config& c = h->cfg;
     const int L = c.n_convs, N = h->N, nb = h->t_nblk;
     const TrainCommon tc = h->t_common;
+    if (h->wpack_version != h->w_version) {         // packed to_feats_out fragments of the message GVPs for k_bwd_edge_level
+        if (!h->d_wpack) PF_HIP(h, hipMalloc((void**)&h->d_wpack, (size_t)std::max(h->n_msg_tot, 1) * PFT_WPACK_FLOATS * sizeof(float)));
+        pfk_pack_bwd(h->d_flat, h->d_gvpt, h->n_msg_tot, h->d_wpack, s);
+        h->wpack_version = h->w_version;
+    }
     PF_HIP(h, hipMemsetAsync(h->t_gpart, 0, (size_t)nb * h->nparams * 4, s));
     pfk_fix_scale(dev_g_eps_h, h->Nf * c.pharm_nf, dev_g_eps_x, h->Nf * 3, h->t_fix, s);
     PF_HIP(h, hipMemsetAsync(h->t_G_h[0], 0, (size_t)N * PF_S * 4, s));
@@ -2066,21 +2082,10 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         e.c = tc; e.tiles = pruned ? h->d_edge_tiles_act : h->d_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
         e.pp_slot = pruned ? 2 : 1;
         const int* et0 = pruned ? h->et_tile0_act : h->et_tile0;
-        // blocks per etype in proportion to its tiles (at least one where there are tiles)
-        {
-            const int tot = std::max(1, last ? et0[2] : et0[4]);
-            int b0 = 0;
-            for (int et = 0; et < 4; ++et) {
-                e.et_tile0[et] = et0[et];
-                e.et_blk0[et] = b0;
-                const int nt_et = (last && et >= ET_FP) ? 0 : et0[et + 1] - et0[et];
-                int nbk = nt_et > 0 ? std::max(1, (int)((int64_t)(nb - 3) * nt_et / tot)) : 0;
-                nbk = std::min(nbk, nt_et);
-                b0 += nbk;
-            }
-            e.et_tile0[4] = et0[4]; e.et_blk0[4] = b0;
-            if (b0 > nb) PF_FAIL(h, PF_ERR_STATE, "internal: block partition exceeds the gradient copies");
-        }
+        for (int et = 0; et <= 4; ++et) e.et_tile0[et] = et0[et];
+        e.n_et = last ? 2 : 4;                       // the last layer's fp / pp messages reach no output
+        e.clist = h->t_clist; e.ccnt = h->t_ccnt;
+        pfk_compact_tiles(e.tiles, e.et_tile0, e.n_et, h->d_dyn_cnt, h->t_clist, h->t_ccnt, s);
         e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;
         e.h = h->t_H[l]; e.v = h->t_V[l];
         e.gagg_s = h->t_gagg_s; e.gagg_v = h->t_gagg_v; e.in_cnt = h->d_in_cnt; e.N = N;
@@ -2094,7 +2099,8 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         e.rbf_inv_sigma = 1.0f / ((c.rbf_dmax - 0.f) / (float)c.rbf_dim);
         e.l0 = l == 0;
         e.A_h = h->t_A_h; e.A_v = h->t_A_v; e.fix = h->t_fix;
-        for (int lv = c.n_message_gvps - 1; lv >= 0; --lv) { e.level = lv; ProfScope ps(h, pf_handle::K_BWD_EDGE_LEVEL, s); pfk_bwd_edge_level(&e, s); }
+        e.wpack = h->d_wpack + (size_t)h->msg_base(l, 0) * PFT_WPACK_FLOATS;
+        for (int lv = c.n_message_gvps - 1; lv >= 0; --lv) { e.level = lv; ProfScope ps(h, pf_handle::K_BWD_EDGE_LEVEL, s); pfk_bwd_edge_level(&e, nb, s); }
         pfk_fix_apply(h->t_A_h, e.G_h_in, (size_t)N * PF_S, h->t_fix, s);
         if (l != 0) pfk_fix_apply(h->t_A_v, e.G_v_in, (size_t)N * 48, h->t_fix, s);       // conv layer 0 has no vector input
         a ^= 1;

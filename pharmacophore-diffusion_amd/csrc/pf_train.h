@@ -18,6 +18,7 @@
 
 #define PFT_MAX_CHAIN 4      // GVPs per chain the backward tiles hold in LDS
 #define PFT_ROWS 16          // rows (edges / nodes) per backward sub-tile = N of v_mfma_f32_16x16x4_f32
+#define PFT_WPACK_FLOATS (11 * 8 * 64 * 4)   // packed to_feats_out of one message GVP (k_pack_bwd)
 #define PFT_FIX_BITS 40      // fixed-point scale of the level-0 scatter RELATIVE to the largest upstream gradient of the call:
                              // resolution 2^-40 of it, head room 2^23 times it (pfk_fix_scale picks the power of two)
 
@@ -86,13 +87,14 @@ struct BwdEdgeParams {
 // level-by-level backward of the message chains (k_bwd_edge_level): one launch per GVP level, last level first.
 // The training forward (k_edge_msg<.., SAVE>) left per (level, edge slot) the pre-activation scalars Z, the gate
 // pre-activations and the gated output vectors, so nothing of the chain is recomputed but the small vector products.
-// A block serves ONE etype (blocks [et_blk0[et], et_blk0[et+1]) take the tiles [et_tile0[et], et_tile0[et+1]) of the
-// etype-ordered tile table): its to_feats_out weight sits in LDS for the whole launch and the weight gradients of
+// A block serves ONE etype (the blocks are dealt to the etypes in proportion to their non-empty tiles, which the block
+// walks with a stride): its to_feats_out weight sits in LDS for the whole launch and the weight gradients of
 // to_feats_out and of the gates accumulate in registers across all its tiles.
 struct BwdEdgeLevelParams {
     TrainCommon c;
     const EdgeTile* tiles;
-    int et_tile0[5], et_blk0[5];
+    int et_tile0[5]; int n_et;               // etype segments of the tile table; etypes [0, n_et) take part
+    const int* clist; const int* ccnt;       // k_compact_tiles: non-empty tiles per segment (same offsets) and their counts [4]
     const int* dyn_cnt;
     const int* esrc; const int* edst;
     const float4* xn;
@@ -111,6 +113,7 @@ struct BwdEdgeLevelParams {
     const float* sv_z; const float* sv_g; const float* sv_v; size_t sv_stride;
     float* gs_buf; float* gv_buf;            // dL/d(input scalars / vectors of the level above), per edge slot
     const GvpT* g; int n_gvps; int level;
+    const float* wpack;                      // k_pack_bwd fragments of this layer's message GVPs [et][level][PFT_WPACK_FLOATS]
     float rbf_mu[PF_R]; float rbf_inv_sigma;
     int l0;
 };

@@ -657,296 +657,443 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// edge message backward, one GVP level per launch (see BwdEdgeLevelParams).  A pass is one tile of 32 edge slots = two
-// column tiles of the data products (the weight fragment of a k-step is fetched once for both) and eight k-steps of
-// the weight-gradient products.
+// edge message backward, one GVP level per launch (see BwdEdgeLevelParams).  A pass is one tile of 32 edge slots.
+//
+// What a pass costs is decided by operand fetch, not by the matrix pipe (its products are ~1,900
+// v_mfma_f32_16x16x4_f32 = 15 k cycles over four SIMDs), so the pass is organised around that:
+//   * the rows of the NEXT tile (saved Z / gate / V rows, level inputs, upstream gradients: 62 KB) are fetched into
+//     registers while this tile's big products run, their indices one tile earlier still, the tile descriptors once per
+//     round of 64 tiles: no dependent global round trip is left inside a pass;
+//   * the input-gradient product gS = gZ Wm reads to_feats_out as 1-KiB fragments of a packed copy (k_pack_bwd: lane
+//     (i, kq) holds four consecutive k of input i -- one global_load_dwordx4 per four MFMAs) and keeps gZ, its other
+//     operand, in registers for all of a wave's output tiles (16 ds_read_b128 per wave and pass);
+//   * Wh, Wu and the gate weights sit in LDS for the whole launch; the small vector products are dealt over the waves by
+//     COLUMN tile (row half x coordinate: six waves) while the two remaining waves take the Wu / Wh weight gradients;
+//   * the gate contribution and SiLU' are applied on the accumulator fragments (one LDS round trip less).
+// Weight gradients accumulate in registers over all tiles of the block and are flushed once.
 // ---------------------------------------------------------------------------------------------
 #define ER 32             // rows per pass
-// C[M x 16 NTN] = A[M x K] B[K x 16 NTN]: a wave owns whole 16-row blocks of C, so one A fragment serves NTN MFMAs
-template <int UNR, int NTN, typename FA, typename FB, typename FC>
-__device__ __forceinline__ void mmR(const int M, const int K, FA a, FB b, FC c, const int lane, const int wv) {
-    const int mts = (M + 15) >> 4;
-    const int li = lane & 15, kq = lane >> 4;
-    for (int mt = wv; mt < mts; mt += NT / 64) {
-        const int ai = mt * 16 + li;
-        const bool aok = ai < M;
-        f32x4 acc[NTN];
-#pragma unroll
-        for (int n = 0; n < NTN; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < K; k0 += 4 * UNR) {
-            float av[UNR], bv[NTN][UNR];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int k = k0 + 4 * u + kq;
-                const bool kok = k < K;
-                av[u] = (aok && kok) ? a(ai, k) : 0.f;
-#pragma unroll
-                for (int n = 0; n < NTN; ++n) bv[n][u] = kok ? b(k, n * 16 + li) : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                for (int n = 0; n < NTN; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[n][u], acc[n], 0, 0, 0);
+#define E2_ZS 144         // LDS row stride of Z rows [128] (16-byte aligned rows: b128 accesses)
+#define E2_SS 176         // ... of scalar rows [si + h] (<= 161): whole 16-column tiles
+#define E2_WHS 36         // ... of the staged Wh [vi][h], zero padded to [32][36]
+#define E2_TILES 64       // tile descriptors staged per round
+
+// the non-empty tiles of each etype's segment of a tile table, in table order: clist[et_tile0[et] - et_tile0[0] + i], ccnt[et]
+// (a dynamic region's tiles cover its capacity; a backward block that is dealt tiles by table index gets whatever share
+// of the empty ones the layout gives it -- the ff blocks of config 5 walked four times the tiles of the pp blocks)
+__global__ __launch_bounds__(256) void k_compact_tiles(const EdgeTile* tiles, const int t0, const int t1, const int seg0,
+                                                       const int* dyn_cnt, int* clist, int* ccnt) {
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int base = 0;
+    for (int c = t0; c < t1; c += 256) {
+        const int ti = c + tid;
+        bool ne = false;
+        if (ti < t1) {
+            const EdgeTile t = tiles[ti];
+            int n = t.n;
+            if (t.cnt_idx >= 0) n = min(n, max(dyn_cnt[t.cnt_idx] - t.rel, 0));
+            ne = n > 0;
         }
+        const unsigned long long m = __ballot(ne);
+        if (lane == 0) s_w[wv] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; ++w) off += s_w[w];
+        if (ne) clist[seg0 + off + __popcll(m & ((1ull << lane) - 1ull))] = ti;
+        base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (tid == 0) *ccnt = base;
+}
+
+// packed to_feats_out of every message GVP for the input-gradient product: [gvp][m tile (11)][k block (8)][lane] x 4:
+// lane (li, kq) of m tile mt, block sb holds W[k = 16 sb + 4 kq + t][i = 16 mt + li], t = 0..3 (zero for i >= si + h)
+__global__ __launch_bounds__(64) void k_pack_bwd(const float* W, const GvpT* g, float* out) {
+    const int gi = blockIdx.x / 88, rem = blockIdx.x - gi * 88, mt = rem >> 3, sb = rem & 7;
+    const int lane = threadIdx.x, li = lane & 15, kq = lane >> 4;
+    const GvpT t = g[gi];
+    const int KM = t.si + t.h, i = 16 * mt + li;
+    f32x4 v;
 #pragma unroll
-        for (int n = 0; n < NTN; ++n)
+    for (int tt = 0; tt < 4; ++tt) {
+        const int k = 16 * sb + 4 * kq + tt;
+        v[tt] = (i < KM && k < t.so) ? W[t.o_Wm + k * KM + i] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(out)[(size_t)blockIdx.x * 64 + lane] = v;
+}
+
+// one column tile (16 columns, column = lane & 15) of C[M x 16] = A[M x K] B[K x 16], K <= 4 KS: b(k) is this lane's
+// column of B, a(i, k) an element of A (zero padded), c(i, value) consumes row i of the lane's column
+template <int KS, typename FA, typename FB, typename FC>
+__device__ __forceinline__ void mmcol(const int mts, FA a, FB b, FC c, const int lane) {
+    const int li = lane & 15, kq = lane >> 4;
+    float bv[KS];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ci = mt * 16 + kq * 4 + r;
-                if (ci < M) c(ci, n * 16 + li, acc[n][r]);
-            }
+    for (int u = 0; u < KS; ++u) bv[u] = b(4 * u + kq);
+    for (int mt = 0; mt < mts; ++mt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < KS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a(mt * 16 + li, 4 * u + kq), bv[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c(mt * 16 + kq * 4 + r, acc[r]);
     }
 }
 
+struct E2Idx { int eA[2], eV, eG, sA[2], sV, sT, dA[2], dV, dT; };
+struct E2Rows { float4 z[2], x[2], u[2], vx, vu, xs, xd; float gt; int cA[2], cV, sT; };
+
 __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelParams p) {
-    __shared__ float Zb[ER * ZS], Sin[ER * SWS], gA[ER * SWS], gS[ER * SWS];
+    __shared__ __attribute__((aligned(16))) float Zb[ER * E2_ZS];
+    __shared__ __attribute__((aligned(16))) float Sin[ER * E2_SS];
+    __shared__ __attribute__((aligned(16))) float gA[ER * E2_SS];
+    __shared__ __attribute__((aligned(16))) float gS[ER * E2_SS];
     __shared__ float gate[ER * GTS], ggate[ER * GTS];
     __shared__ float Vin[ER * VWS], Vh[ER * VWS], Vu[ER * VWS], gVo[ER * VWS], gVh[ER * VWS], gVi[ER * VWS];
-    __shared__ int s_src[ER], s_dst[ER], s_e[ER];
-    __shared__ float s_sc[ER];
+    __shared__ float sWh[32 * E2_WHS], sWu[32 * 16], sWg[16 * 128];
+    __shared__ int s_src[ER], s_e[ER], s_te0[E2_TILES], s_tnv[E2_TILES];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
-    int et = 0;
-    while (et < 3 && (int)blockIdx.x >= p.et_blk0[et + 1]) ++et;
-    const int nb = p.et_blk0[et + 1] - p.et_blk0[et], my = blockIdx.x - p.et_blk0[et];
+    // blocks per etype in proportion to its non-empty tiles (k_compact_tiles), at least one where there are tiles: every
+    // block derives the same partition from the four counts
+    int et = -1, nb = 0, my = 0, cnt_et = 0;
+    {
+        int cnt[4], tot = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cnt[e] = e < p.n_et ? p.ccnt[e] : 0; tot += cnt[e]; }
+        int b0 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int nbk = cnt[e] > 0 ? min(cnt[e], max(1, (int)((long long)((int)gridDim.x - 3) * cnt[e] / tot))) : 0;
+            if ((int)blockIdx.x >= b0 && (int)blockIdx.x < b0 + nbk) { et = e; nb = nbk; my = blockIdx.x - b0; cnt_et = cnt[e]; }
+            b0 += nbk;
+        }
+    }
+    if (et < 0) return;                              // block-uniform: more gradient copies than work
+    const int* clist = p.clist + (p.et_tile0[et] - p.et_tile0[0]);
     const GvpT g = p.g[et * p.n_gvps + p.level];
     const float* W = p.c.W;
+    const f32x4* Wp = reinterpret_cast<const f32x4*>(p.wpack) + (size_t)(et * p.n_gvps + p.level) * (11 * 8 * 64);
     float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
-    const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;   // SO == 128, VO == 16 (message GVPs)
+    const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;   // SO == 128, VO == 16; KH, VI <= 17 (message GVPs)
     const int nts = (KM + 15) >> 4;                  // <= 11
+    const int mth = (KH + 15) >> 4, mti = (VI + 15) >> 4;
     const bool lastl = p.level == p.n_gvps - 1, firstl = p.level == 0;
     const int slot = (et == ET_FF || et == ET_FP) ? 0 : (et == ET_PP ? p.pp_slot : 1);
     const float fix_scale = firstl ? p.fix[0] : 1.0f;
+    const bool want_sc = lastl && p.norm_mode == 0;
     // weight-gradient accumulators, kept in registers over all the tiles of this block:
     //   to_feats_out: wave wv owns output features 16 wv .. +15, tile x = inputs 16 x .. +15
     //   gates: wave wv owns features 16 wv .. +15 of all 16 gates
-    //   Wu (waves 0, 1: hidden channels 16 wv ..) and Wh (waves 2..5: tile (vi block (wv-2)>>1, hidden block (wv-2)&1))
-    f32x4 accWm[11], accWg = {0.f, 0.f, 0.f, 0.f}, accV = {0.f, 0.f, 0.f, 0.f};
+    //   waves 6, 7: Wu tile (hidden channels 16 (wv - 6) ..) and Wh tiles (vi block wv - 6, hidden blocks 0 and 1)
+    f32x4 accWm[11], accWg = {0.f, 0.f, 0.f, 0.f}, accU = {0.f, 0.f, 0.f, 0.f}, accH[2];
 #pragma unroll
     for (int x = 0; x < 11; ++x) accWm[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accH[0] = accH[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     float acc_bm = 0.f, acc_bg = 0.f;                // bias gradients of feature tid (< SO) / gate tid (< VO)
     const float* zl = p.sv_z + (size_t)p.level * p.sv_stride * PF_S;
     const float* gl = p.sv_g + (size_t)p.level * p.sv_stride * 16;
     const float* zprev = firstl ? nullptr : p.sv_z + (size_t)(p.level - 1) * p.sv_stride * PF_S;
     const float* vprev = firstl ? nullptr : p.sv_v + (size_t)(p.level - 1) * p.sv_stride * 48;
-    for (int ti = p.et_tile0[et] + my; ti < p.et_tile0[et + 1]; ti += nb) {
-        const EdgeTile t = p.tiles[ti];
-        int nv = t.n;
-        if (t.cnt_idx >= 0) nv = min(nv, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
-        if (nv <= 0) continue;
-        PFT_STAMP(30);
-        if (tid < ER) {
-            const int e = t.e0 + min(tid, nv - 1);
-            s_e[tid] = e;
-            if (firstl || lastl) {
-                const int src = p.esrc[e], dst = p.edst[e];
-                s_src[tid] = src; s_dst[tid] = dst;
-                if (firstl) {
-                    const float4 xs = p.xn[src], xd = p.xn[dst];
-                    const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
-                    const float d = t_sqrt(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
-                    const float rd = __builtin_amdgcn_rcpf(d);
-                    Vin[tid * VWS + 0] = dx * rd; Vin[tid * VWS + 1] = dy * rd; Vin[tid * VWS + 2] = dz * rd;
-                    for (int k = 0; k < PF_R; ++k) {
-                        const float z = (d - p.rbf_mu[k]) * p.rbf_inv_sigma;
-                        Sin[tid * SWS + PF_S + k] = __expf(-(z * z));
+    // ---- small weights of the level, zero padded: sWh[a][b] = Wh[vi a][hidden b], sWu[a][b] = Wu[hidden a][out b], sWg[gate][feature]
+    for (int idx = tid; idx < 32 * E2_WHS; idx += NT) {
+        const int a = idx / E2_WHS, b = idx - a * E2_WHS;
+        sWh[idx] = (a < VI && b < KH) ? W[g.o_Wh + a * KH + b] : 0.f;
+    }
+    for (int idx = tid; idx < 32 * 16; idx += NT) sWu[idx] = (idx >> 4) < KH ? W[g.o_Wu + idx] : 0.f;
+    for (int idx = tid; idx < 16 * 128; idx += NT) sWg[idx] = W[g.o_Wg + idx];
+
+    const int rA = tid >> 5, qA = tid & 31;          // scalar rows: float4 qA of rows rA and rA + 16
+    const bool hasV = tid < ER * 12;
+    const int rV = hasV ? tid / 12 : 0, qV = hasV ? tid - rV * 12 : 0;      // vector rows: float4 qV of row rV
+    const int rG = tid >> 4, uG = tid & 15;          // gate rows
+    const int cw = wv >> 1, rb = 16 * (wv & 1);      // waves 0..5: column tile (coordinate cw, rows rb .. rb + 15)
+
+    auto load_idx = [&](const int e0, const int nv) {
+        E2Idx x = {};
+        if (nv <= 0) return x;                       // block-uniform
+        const int m = nv - 1;
+        x.eA[0] = e0 + min(rA, m); x.eA[1] = e0 + min(rA + 16, m); x.eV = e0 + min(rV, m); x.eG = e0 + min(rG, m);
+        const int eT = e0 + min(tid & 31, m);
+        if (firstl) {
+            x.sA[0] = p.esrc[x.eA[0]]; x.sA[1] = p.esrc[x.eA[1]];
+            if (!p.l0) x.sV = p.esrc[x.eV];
+            x.sT = p.esrc[eT]; x.dT = p.edst[eT];
+        }
+        if (lastl) { x.dA[0] = p.edst[x.eA[0]]; x.dA[1] = p.edst[x.eA[1]]; x.dV = p.edst[x.eV]; }
+        return x;
+    };
+    auto load_rows = [&](const E2Idx& x, const int nv) {
+        E2Rows r = {};
+        if (nv <= 0) return r;                       // block-uniform
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            r.z[c] = reinterpret_cast<const float4*>(zl + (size_t)x.eA[c] * PF_S)[qA];
+            r.x[c] = firstl ? reinterpret_cast<const float4*>(p.h + (size_t)x.sA[c] * PF_S)[qA]
+                            : reinterpret_cast<const float4*>(zprev + (size_t)x.eA[c] * PF_S)[qA];
+            r.u[c] = lastl ? reinterpret_cast<const float4*>(p.gagg_s + (size_t)x.dA[c] * PF_S)[qA]
+                           : reinterpret_cast<const float4*>(p.gs_buf + (size_t)x.eA[c] * PF_S)[qA];
+            r.cA[c] = want_sc ? p.in_cnt[slot * p.N + x.dA[c]] : 1;
+        }
+        if (hasV) {
+            if (firstl) { if (!p.l0) r.vx = reinterpret_cast<const float4*>(p.v + (size_t)x.sV * 48)[qV]; }
+            else r.vx = reinterpret_cast<const float4*>(vprev + (size_t)x.eV * 48)[qV];
+            r.vu = lastl ? reinterpret_cast<const float4*>(p.gagg_v + (size_t)x.dV * 48)[qV]
+                         : reinterpret_cast<const float4*>(p.gv_buf + (size_t)x.eV * 48)[qV];
+            r.cV = want_sc ? p.in_cnt[slot * p.N + x.dV] : 1;
+        }
+        r.gt = gl[(size_t)x.eG * 16 + uG];
+        r.sT = x.sT;
+        if (firstl && tid < ER) { r.xs = p.xn[x.sT]; r.xd = p.xn[x.dT]; }
+        return r;
+    };
+
+    const int npass = my < cnt_et ? (cnt_et - my + nb - 1) / nb : 0;
+    for (int base = 0; base < npass; base += E2_TILES) {
+        __syncthreads();
+        if (tid < E2_TILES) {                        // this round's tile descriptors
+            int e0 = 0, n = 0;
+            if (base + tid < npass) {
+                const EdgeTile t = p.tiles[clist[my + (base + tid) * nb]];
+                n = t.n; e0 = t.e0;
+                if (t.cnt_idx >= 0) n = min(n, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
+            }
+            s_te0[tid] = e0; s_tnv[tid] = n;
+        }
+        __syncthreads();
+        const int cn = min(E2_TILES, npass - base);
+        E2Idx ix = load_idx(s_te0[0], s_tnv[0]);
+        E2Rows rw = load_rows(ix, s_tnv[0]);
+        ix = cn > 1 ? load_idx(s_te0[1], s_tnv[1]) : E2Idx{};
+        for (int j = 0; j < cn; ++j) {
+            const int nv = __builtin_amdgcn_readfirstlane(s_tnv[j]);
+            const int e0 = __builtin_amdgcn_readfirstlane(s_te0[j]);
+            if (nv > 0) {
+                PFT_STAMP(30);
+                // ---- this tile's rows: registers -> LDS
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int row = rA + 16 * c;
+                    *reinterpret_cast<float4*>(Zb + row * E2_ZS + 4 * qA) = rw.z[c];
+                    float4 x = rw.x[c];
+                    if (!firstl) { x.x = t_silu(x.x); x.y = t_silu(x.y); x.z = t_silu(x.z); x.w = t_silu(x.w); }
+                    *reinterpret_cast<float4*>(Sin + row * E2_SS + 4 * qA) = x;
+                    const float sc = row < nv ? (want_sc ? 1.0f / (float)rw.cA[c] : 1.0f) : 0.f;
+                    float4 u = rw.u[c];
+                    u.x *= sc; u.y *= sc; u.z *= sc; u.w *= sc;
+                    *reinterpret_cast<float4*>(gA + row * E2_SS + 4 * qA) = u;
+                }
+                if (hasV) {
+                    float* d = Vin + rV * VWS + (firstl ? 3 : 0) + 4 * qV;
+                    d[0] = rw.vx.x; d[1] = rw.vx.y; d[2] = rw.vx.z; d[3] = rw.vx.w;
+                    const float sc = rV < nv ? (want_sc ? 1.0f / (float)rw.cV : 1.0f) : 0.f;
+                    float* go = gVo + rV * VWS + 4 * qV;
+                    go[0] = rw.vu.x * sc; go[1] = rw.vu.y * sc; go[2] = rw.vu.z * sc; go[3] = rw.vu.w * sc;
+                }
+                gate[rG * GTS + uG] = rw.gt;
+                if (tid < ER) {
+                    s_e[tid] = e0 + min(tid, nv - 1);
+                    s_src[tid] = rw.sT;
+                    if (firstl) {
+                        const float dx = rw.xs.x - rw.xd.x, dy = rw.xs.y - rw.xd.y, dz = rw.xs.z - rw.xd.z;
+                        const float d = t_sqrt(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+                        const float rd = __builtin_amdgcn_rcpf(d);
+                        Vin[tid * VWS + 0] = dx * rd; Vin[tid * VWS + 1] = dy * rd; Vin[tid * VWS + 2] = dz * rd;
+                        for (int k = 0; k < PF_R; ++k) {
+                            const float z = (d - p.rbf_mu[k]) * p.rbf_inv_sigma;
+                            Sin[tid * E2_SS + PF_S + k] = __expf(-(z * z));
+                        }
                     }
                 }
-                float sc = 1.0f;
-                if (lastl && p.norm_mode == 0) sc = 1.0f / (float)p.in_cnt[slot * p.N + dst];
-                s_sc[tid] = tid < nv ? sc : 0.f;
-            }
-        }
-        __syncthreads();
-        // ---- rows of this level from the forward, inputs of the level, upstream gradients
-        for (int idx = tid; idx < ER * 32; idx += NT) {
-            const int row = idx >> 5, q = idx & 31;
-            const int e = s_e[row];
-            const float4 z = reinterpret_cast<const float4*>(zl + (size_t)e * PF_S)[q];
-            float* d = Zb + row * ZS + 4 * q;
-            d[0] = z.x; d[1] = z.y; d[2] = z.z; d[3] = z.w;
-            float4 x;
-            if (firstl) x = reinterpret_cast<const float4*>(p.h + (size_t)s_src[row] * PF_S)[q];
-            else {
-                x = reinterpret_cast<const float4*>(zprev + (size_t)e * PF_S)[q];
-                x.x = t_silu(x.x); x.y = t_silu(x.y); x.z = t_silu(x.z); x.w = t_silu(x.w);
-            }
-            float* sp = Sin + row * SWS + 4 * q;
-            sp[0] = x.x; sp[1] = x.y; sp[2] = x.z; sp[3] = x.w;
-            float4 u;
-            if (lastl) {
-                u = reinterpret_cast<const float4*>(p.gagg_s + (size_t)s_dst[row] * PF_S)[q];
-                const float sc = s_sc[row];
-                u.x *= sc; u.y *= sc; u.z *= sc; u.w *= sc;
-            } else {
-                u = reinterpret_cast<const float4*>(p.gs_buf + (size_t)e * PF_S)[q];
-                if (row >= nv) u = float4{0.f, 0.f, 0.f, 0.f};
-            }
-            float* ga = gA + row * SWS + 4 * q;
-            ga[0] = u.x; ga[1] = u.y; ga[2] = u.z; ga[3] = u.w;
-        }
-        for (int idx = tid; idx < ER * 12; idx += NT) {
-            const int row = idx / 12, q = idx - row * 12;
-            const int e = s_e[row];
-            float4 x = {0.f, 0.f, 0.f, 0.f};
-            if (firstl) { if (!p.l0) x = reinterpret_cast<const float4*>(p.v + (size_t)s_src[row] * 48)[q]; }
-            else x = reinterpret_cast<const float4*>(vprev + (size_t)e * 48)[q];
-            float* d = Vin + row * VWS + (firstl ? 3 : 0) + 4 * q;
-            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
-            float4 u;
-            if (lastl) {
-                u = reinterpret_cast<const float4*>(p.gagg_v + (size_t)s_dst[row] * 48)[q];
-                const float sc = s_sc[row];
-                u.x *= sc; u.y *= sc; u.z *= sc; u.w *= sc;
-            } else {
-                u = reinterpret_cast<const float4*>(p.gv_buf + (size_t)e * 48)[q];
-                if (row >= nv) u = float4{0.f, 0.f, 0.f, 0.f};
-            }
-            float* go = gVo + row * VWS + 4 * q;
-            go[0] = u.x; go[1] = u.y; go[2] = u.z; go[3] = u.w;
-        }
-        for (int idx = tid; idx < ER * 16; idx += NT) {
-            const int row = idx >> 4, u = idx & 15;
-            gate[row * GTS + u] = gl[(size_t)s_e[row] * 16 + u];
-        }
-        __syncthreads();
-        PFT_STAMP(31);
-        // ---- Vh = Wh^T V, sh, Vu = Wu^T Vh (columns: coordinate c = j >> 5 of row j & 31)
-        mmR<5, 6>(KH, VI,
-             [&](int i, int k) { return W[g.o_Wh + k * KH + i]; },
-             [&](int k, int j) { return Vin[(j & 31) * VWS + k * 3 + (j >> 5)]; },
-             [&](int i, int j, float x) { Vh[(j & 31) * VWS + i * 3 + (j >> 5)] = x; }, lane, wv);
-        __syncthreads();
-        for (int idx = tid; idx < ER * KH; idx += NT) {
-            const int row = idx & 31, hh = idx >> 5;
-            const float* q = Vh + row * VWS + hh * 3;
-            Sin[row * SWS + SI + hh] = t_sqrt(fmaxf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2], 1e-8f));
-        }
-        mmR<5, 6>(VO, KH,
-             [&](int i, int k) { return W[g.o_Wu + k * VO + i]; },
-             [&](int k, int j) { return Vh[(j & 31) * VWS + k * 3 + (j >> 5)]; },
-             [&](int i, int j, float x) { Vu[(j & 31) * VWS + i * 3 + (j >> 5)] = x; }, lane, wv);
-        __syncthreads();
-        PFT_STAMP(32);
-        // ---- gate: V' = sigmoid(gate) Vu
-        for (int idx = tid; idx < ER * VO; idx += NT) {
-            const int row = idx & 31, u = idx >> 5;
-            const float gt = gate[row * GTS + u];
-            float* go = gVo + row * VWS + u * 3;
-            const float* vu = Vu + row * VWS + u * 3;
-            const float dot = go[0] * vu[0] + go[1] * vu[1] + go[2] * vu[2];
-            const float f = t_sigmoid(gt);
-            ggate[row * GTS + u] = dot * f * (1.0f - f);
-            go[0] *= f; go[1] *= f; go[2] *= f;
-        }
-        __syncthreads();
-        PFT_STAMP(33);
-        mmR<4, 2>(SO, VO,
-             [&](int i, int k) { return W[g.o_Wg + k * SO + i]; },
-             [&](int k, int j) { return ggate[j * GTS + k]; },
-             [&](int i, int j, float x) { gA[j * SWS + i] += x; }, lane, wv);
-        {   // dWg tile (16 gates x features 16 wv .. +15) += ggate^T SiLU(Z)
-#pragma unroll
-            for (int u = 0; u < ER / 4; ++u) {
-                const int k = 4 * u + kq;
-                accWg = __builtin_amdgcn_mfma_f32_16x16x4f32(ggate[k * GTS + li], t_silu(Zb[k * ZS + wv * 16 + li]), accWg, 0, 0, 0);
-            }
-            if (tid < VO) { float sm = 0.f; for (int r = 0; r < ER; ++r) sm += ggate[r * GTS + tid]; acc_bg += sm; }
-        }
-        __syncthreads();
-        PFT_STAMP(34);
-        for (int idx = tid; idx < ER * SO; idx += NT) {
-            const int row = idx & 31, o = idx >> 5;
-            const float z = Zb[row * ZS + o];
-            const float sg = t_sigmoid(z);
-            gA[row * SWS + o] *= sg * (1.0f + z * (1.0f - sg));
-        }
-        __syncthreads();
-        PFT_STAMP(35);
-        mmR<8, 2>(KM, SO,
-             [&](int i, int k) { return W[g.o_Wm + k * KM + i]; },
-             [&](int k, int j) { return gA[j * SWS + k]; },
-             [&](int i, int j, float x) { gS[j * SWS + i] = x; }, lane, wv);
-        PFT_STAMP(39);
-        {   // dWm tiles (features 16 wv .., inputs 16 x ..) += gZ^T [s, sh]
-            float av[ER / 4];
-#pragma unroll
-            for (int u = 0; u < ER / 4; ++u) av[u] = gA[(4 * u + kq) * SWS + wv * 16 + li];
-#pragma unroll
-            for (int x = 0; x < 11; ++x)
-                if (x < nts) {
-                    const int cj = min(x * 16 + li, KM - 1);
-                    float bv[ER / 4];
-#pragma unroll
-                    for (int u = 0; u < ER / 4; ++u) bv[u] = Sin[(4 * u + kq) * SWS + cj];
-#pragma unroll
-                    for (int u = 0; u < ER / 4; ++u) accWm[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], accWm[x], 0, 0, 0);
+                __syncthreads();
+                PFT_STAMP(31);
+                // ---- Vh = Wh^T V (columns: coordinate cw of rows rb .. rb + 15)
+                if (wv < 6)
+                    mmcol<5>(mth,
+                        [&](int i, int k) { return sWh[k * E2_WHS + i]; },
+                        [&](int k) { return k < VI ? Vin[(rb + li) * VWS + k * 3 + cw] : 0.f; },
+                        [&](int i, float x) { if (i < KH) Vh[(rb + li) * VWS + i * 3 + cw] = x; }, lane);
+                __syncthreads();
+                // ---- sh = |Vh|, Vu = Wu^T Vh
+                for (int idx = tid; idx < ER * KH; idx += NT) {
+                    const int row = idx & 31, hh = idx >> 5;
+                    const float* q = Vh + row * VWS + hh * 3;
+                    Sin[row * E2_SS + SI + hh] = t_sqrt(fmaxf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2], 1e-8f));
                 }
-            if (tid < SO) { float sm = 0.f; for (int r = 0; r < ER; ++r) sm += gA[r * SWS + tid]; acc_bm += sm; }
-        }
-        __syncthreads();
-        PFT_STAMP(36);
-        mmR<4, 6>(KH, VO,
-             [&](int i, int k) { return W[g.o_Wu + i * VO + k]; },
-             [&](int k, int j) { return gVo[(j & 31) * VWS + k * 3 + (j >> 5)]; },
-             [&](int i, int j, float x) {
-                 const int row = j & 31, cc = j >> 5;
-                 const float* q = Vh + row * VWS + i * 3;
-                 const float ss = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
-                 const float extra = ss > 1e-8f ? gS[row * SWS + SI + i] * q[cc] / Sin[row * SWS + SI + i] : 0.f;
-                 gVh[row * VWS + i * 3 + cc] = x + extra;
-             }, lane, wv);
-        if (wv < 2) {       // dWu tile (hidden channels 16 wv .., 16 outputs) += sum over rows and coordinates of Vh gVu
-            const int hh = min(wv * 16 + li, KH - 1);
-#pragma unroll
-            for (int u = 0; u < 3 * ER / 4; ++u) {
-                const int k = 4 * u + kq;
-                accV = __builtin_amdgcn_mfma_f32_16x16x4f32(Vh[(k & 31) * VWS + hh * 3 + (k >> 5)],
-                                                            gVo[(k & 31) * VWS + li * 3 + (k >> 5)], accV, 0, 0, 0);
-            }
-        }
-        __syncthreads();
-        PFT_STAMP(37);
-        mmR<5, 6>(VI, KH,
-             [&](int i, int k) { return W[g.o_Wh + i * KH + k]; },
-             [&](int k, int j) { return gVh[(j & 31) * VWS + k * 3 + (j >> 5)]; },
-             [&](int i, int j, float x) { gVi[(j & 31) * VWS + i * 3 + (j >> 5)] = x; }, lane, wv);
-        if (wv >= 2 && wv < 6) {   // dWh tile (input channels 16 a .., hidden channels 16 b ..) += V gVh
-            const int ta = (wv - 2) >> 1, tb = (wv - 2) & 1;
-            const int vi = min(ta * 16 + li, VI - 1), hh = min(tb * 16 + li, KH - 1);
-#pragma unroll
-            for (int u = 0; u < 3 * ER / 4; ++u) {
-                const int k = 4 * u + kq;
-                accV = __builtin_amdgcn_mfma_f32_16x16x4f32(Vin[(k & 31) * VWS + vi * 3 + (k >> 5)],
-                                                            gVh[(k & 31) * VWS + hh * 3 + (k >> 5)], accV, 0, 0, 0);
-            }
-        }
-        __syncthreads();
-        PFT_STAMP(38);
-        // ---- hand the input gradients down: to the level below, or (level 0) to the source nodes
-        if (!firstl) {
-            for (int idx = tid; idx < ER * 128; idx += NT) {
-                const int row = idx >> 7, f = idx & 127;
-                if (row < nv) p.gs_buf[(size_t)s_e[row] * PF_S + f] = gS[row * SWS + f];
-            }
-            for (int idx = tid; idx < ER * 48; idx += NT) {
-                const int row = idx / 48, q = idx - row * 48;
-                if (row < nv) p.gv_buf[(size_t)s_e[row] * 48 + q] = gVi[row * VWS + q];
-            }
-        } else {
-            for (int idx = tid; idx < ER * 128; idx += NT) {
-                const int row = idx >> 7, f = idx & 127;
-                if (row < nv) atomicAdd(reinterpret_cast<unsigned long long*>(p.A_h + (size_t)s_src[row] * PF_S + f),
-                                        (unsigned long long)__float2ll_rn(gS[row * SWS + f] * fix_scale));
-            }
-            if (!p.l0)
-                for (int idx = tid; idx < ER * 48; idx += NT) {
-                    const int row = idx / 48, q = idx - row * 48;
-                    if (row < nv) atomicAdd(reinterpret_cast<unsigned long long*>(p.A_v + (size_t)s_src[row] * 48 + q),
-                                            (unsigned long long)__float2ll_rn(gVi[row * VWS + 3 + q] * fix_scale));
+                if (wv < 6)
+                    mmcol<5>(1,
+                        [&](int i, int k) { return sWu[k * 16 + i]; },
+                        [&](int k) { return k < KH ? Vh[(rb + li) * VWS + k * 3 + cw] : 0.f; },
+                        [&](int i, float x) { Vu[(rb + li) * VWS + i * 3 + cw] = x; }, lane);
+                __syncthreads();
+                PFT_STAMP(32);
+                // ---- gate: V' = sigmoid(gate) Vu
+                for (int idx = tid; idx < ER * VO; idx += NT) {
+                    const int row = idx & 31, u = idx >> 5;
+                    const float gt = gate[row * GTS + u];
+                    float* go = gVo + row * VWS + u * 3;
+                    const float* vu = Vu + row * VWS + u * 3;
+                    const float dot = go[0] * vu[0] + go[1] * vu[1] + go[2] * vu[2];
+                    const float f = t_sigmoid(gt);
+                    ggate[row * GTS + u] = dot * f * (1.0f - f);
+                    go[0] *= f; go[1] *= f; go[2] *= f;
                 }
+                __syncthreads();
+                PFT_STAMP(33);
+                {   // ---- gZ = (gA + ggate Wg) SiLU'(Z) for features 16 wv .. +15 of all rows, on the accumulator fragments
+                    float aw[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) aw[s] = sWg[(4 * s + kq) * 128 + wv * 16 + li];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s], ggate[(16 * n + li) * GTS + 4 * s + kq], acc, 0, 0, 0);
+                        const int row = 16 * n + li, f0 = wv * 16 + kq * 4;
+                        float4* gap = reinterpret_cast<float4*>(gA + row * E2_SS + f0);
+                        const float4 ga = *gap, z = *reinterpret_cast<const float4*>(Zb + row * E2_ZS + f0);
+                        const float zz[4] = {z.x, z.y, z.z, z.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w};
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float sg = t_sigmoid(zz[r]);
+                            o[r] = (gg[r] + acc[r]) * sg * (1.0f + zz[r] * (1.0f - sg));
+                        }
+                        *gap = float4{o[0], o[1], o[2], o[3]};
+                    }
+                    // dWg tile (16 gates x features 16 wv .. +15) += ggate^T SiLU(Z)
+#pragma unroll
+                    for (int u = 0; u < ER / 4; ++u) {
+                        const int k = 4 * u + kq;
+                        accWg = __builtin_amdgcn_mfma_f32_16x16x4f32(ggate[k * GTS + li], t_silu(Zb[k * E2_ZS + wv * 16 + li]), accWg, 0, 0, 0);
+                    }
+                    if (tid < VO) { float sm = 0.f; for (int r = 0; r < ER; ++r) sm += ggate[r * GTS + tid]; acc_bg += sm; }
+                }
+                __syncthreads();
+                PFT_STAMP(35);
+                {   // ---- gS = gZ Wm: gZ fragments of both row tiles in registers, packed weight fragments streamed
+                    f32x4 bf[2][8];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int sb = 0; sb < 8; ++sb)
+                            bf[n][sb] = *reinterpret_cast<const f32x4*>(gA + (16 * n + li) * E2_SS + 16 * sb + 4 * kq);
+                    for (int mt = wv; mt < nts; mt += NT / 64) {
+                        const f32x4* wp = Wp + (size_t)mt * (8 * 64) + lane;
+                        f32x4 aq[8];
+#pragma unroll
+                        for (int sb = 0; sb < 8; ++sb) aq[sb] = wp[sb * 64];
+                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int sb = 0; sb < 8; ++sb)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[sb][t], bf[0][sb][t], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[sb][t], bf[1][sb][t], acc1, 0, 0, 0);
+                            }
+                        *reinterpret_cast<f32x4*>(gS + li * E2_SS + 16 * mt + 4 * kq) = acc0;
+                        *reinterpret_cast<f32x4*>(gS + (16 + li) * E2_SS + 16 * mt + 4 * kq) = acc1;
+                    }
+                }
+                PFT_STAMP(39);
+                {   // dWm tiles (features 16 wv .., inputs 16 x ..) += gZ^T [s, sh]
+                    float av[ER / 4];
+#pragma unroll
+                    for (int u = 0; u < ER / 4; ++u) av[u] = gA[(4 * u + kq) * E2_SS + wv * 16 + li];
+#pragma unroll
+                    for (int x = 0; x < 11; ++x)
+                        if (x < nts) {
+                            float bv[ER / 4];
+#pragma unroll
+                            for (int u = 0; u < ER / 4; ++u) bv[u] = Sin[(4 * u + kq) * E2_SS + x * 16 + li];
+#pragma unroll
+                            for (int u = 0; u < ER / 4; ++u) accWm[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], accWm[x], 0, 0, 0);
+                        }
+                    if (tid < SO) { float sm = 0.f; for (int r = 0; r < ER; ++r) sm += gA[r * E2_SS + tid]; acc_bm += sm; }
+                }
+            }
+            // ---- fetch ahead: the rows of the next tile (their indices arrived during the previous pass), the indices of the
+            // tile after it.  Nothing below this point waits for a global load.
+            if (j + 1 < cn) rw = load_rows(ix, s_tnv[j + 1]);
+            if (j + 2 < cn) ix = load_idx(s_te0[j + 2], s_tnv[j + 2]);
+            if (nv > 0) {
+                __syncthreads();
+                PFT_STAMP(36);
+                // ---- gVh = Wu gVu + (gradient through sh); dWu on waves 6, 7
+                if (wv < 6)
+                    mmcol<4>(mth,
+                        [&](int i, int k) { return sWu[i * 16 + k]; },
+                        [&](int k) { return gVo[(rb + li) * VWS + k * 3 + cw]; },
+                        [&](int i, float x) {
+                            if (i < KH) {
+                                const int row = rb + li;
+                                const float* q = Vh + row * VWS + i * 3;
+                                const float ss = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+                                const float extra = ss > 1e-8f ? gS[row * E2_SS + SI + i] * q[cw] / Sin[row * E2_SS + SI + i] : 0.f;
+                                gVh[row * VWS + i * 3 + cw] = x + extra;
+                            }
+                        }, lane);
+                else if (16 * (wv - 6) < KH) {       // dWu tile (hidden channels 16 (wv - 6) .., 16 outputs) += sum over rows and coordinates of Vh gVu
+                    const int hh = min((wv - 6) * 16 + li, KH - 1);
+#pragma unroll
+                    for (int u = 0; u < 3 * ER / 4; ++u) {
+                        const int k = 4 * u + kq;
+                        accU = __builtin_amdgcn_mfma_f32_16x16x4f32(Vh[(k & 31) * VWS + hh * 3 + (k >> 5)],
+                                                                    gVo[(k & 31) * VWS + li * 3 + (k >> 5)], accU, 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+                PFT_STAMP(37);
+                // ---- gVi = Wh gVh; dWh on waves 6, 7
+                if (wv < 6) {
+                    if (!(firstl && p.l0))           // conv layer 0 has no vector input: nobody reads gVi there
+                        mmcol<5>(mti,
+                            [&](int i, int k) { return sWh[i * E2_WHS + k]; },
+                            [&](int k) { return k < KH ? gVh[(rb + li) * VWS + k * 3 + cw] : 0.f; },
+                            [&](int i, float x) { if (i < VI) gVi[(rb + li) * VWS + i * 3 + cw] = x; }, lane);
+                } else if (16 * (wv - 6) < VI) {     // dWh tiles (input channels 16 (wv - 6) .., hidden channels 16 tb ..) += V gVh
+                    const int vi = min((wv - 6) * 16 + li, VI - 1);
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb)
+                        if (16 * tb < KH) {
+                            const int hh = min(tb * 16 + li, KH - 1);
+#pragma unroll
+                            for (int u = 0; u < 3 * ER / 4; ++u) {
+                                const int k = 4 * u + kq;
+                                accH[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vin[(k & 31) * VWS + vi * 3 + (k >> 5)],
+                                                                                gVh[(k & 31) * VWS + hh * 3 + (k >> 5)], accH[tb], 0, 0, 0);
+                            }
+                        }
+                }
+                __syncthreads();
+                PFT_STAMP(38);
+                // ---- hand the input gradients down: to the level below, or (level 0) to the source nodes
+                if (!firstl) {
+                    for (int idx = tid; idx < ER * 32; idx += NT) {
+                        const int row = idx >> 5, q = idx & 31;
+                        if (row < nv) reinterpret_cast<float4*>(p.gs_buf + (size_t)s_e[row] * PF_S)[q] = *reinterpret_cast<const float4*>(gS + row * E2_SS + 4 * q);
+                    }
+                    for (int idx = tid; idx < ER * 48; idx += NT) {
+                        const int row = idx / 48, q = idx - row * 48;
+                        if (row < nv) p.gv_buf[(size_t)s_e[row] * 48 + q] = gVi[row * VWS + q];
+                    }
+                } else {
+                    for (int idx = tid; idx < ER * 128; idx += NT) {
+                        const int row = idx >> 7, f = idx & 127;
+                        if (row < nv) atomicAdd(reinterpret_cast<unsigned long long*>(p.A_h + (size_t)s_src[row] * PF_S + f),
+                                                (unsigned long long)__float2ll_rn(gS[row * E2_SS + f] * fix_scale));
+                    }
+                    if (!p.l0)
+                        for (int idx = tid; idx < ER * 48; idx += NT) {
+                            const int row = idx / 48, q = idx - row * 48;
+                            if (row < nv) atomicAdd(reinterpret_cast<unsigned long long*>(p.A_v + (size_t)s_src[row] * 48 + q),
+                                                    (unsigned long long)__float2ll_rn(gVi[row * VWS + 3 + q] * fix_scale));
+                        }
+                }
+                __syncthreads();
+            }
         }
-        __syncthreads();
     }
     // ---- flush the register accumulators into this block's gradient copy
 #pragma unroll
@@ -961,19 +1108,20 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
         }
 #pragma unroll
     for (int r = 0; r < 4; ++r) gp[g.o_Wg + (kq * 4 + r) * SO + wv * 16 + li] += accWg[r];
-    if (wv < 2) {
+    if (wv >= 6) {
+        const int tb6 = wv - 6;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int hh = wv * 16 + kq * 4 + r;
-            if (hh < KH) gp[g.o_Wu + hh * VO + li] += accV[r];
+            const int hh = tb6 * 16 + kq * 4 + r;
+            if (hh < KH) gp[g.o_Wu + hh * VO + li] += accU[r];
         }
-    } else if (wv < 6) {
-        const int ta = (wv - 2) >> 1, tb = (wv - 2) & 1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int vi = ta * 16 + kq * 4 + r, hh = tb * 16 + li;
-            if (vi < VI && hh < KH) gp[g.o_Wh + vi * KH + hh] += accV[r];
-        }
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int vi = tb6 * 16 + kq * 4 + r, hh = tb * 16 + li;
+                if (vi < VI && hh < KH) gp[g.o_Wh + vi * KH + hh] += accH[tb][r];
+            }
     }
     if (tid < SO) gp[g.o_bm + tid] += acc_bm;
     if (tid < VO) gp[g.o_bg + tid] += acc_bg;
@@ -1161,10 +1309,18 @@ void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s) {
     if (p->ntiles == 0) return;
     hipLaunchKernelGGL(k_bwd_node, dim3(nblocks), dim3(NT), 0, s, *p);
 }
-void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, hipStream_t s) {
-    const int nblocks = p->et_blk0[4];
-    if (nblocks == 0) return;
+void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, int nblocks, hipStream_t s) {
+    if (nblocks == 0 || p->et_tile0[p->n_et] == p->et_tile0[0]) return;
     hipLaunchKernelGGL(k_bwd_edge_level, dim3(nblocks), dim3(NT), 0, s, *p);
+}
+void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s) {
+    for (int et = 0; et < n_et; ++et)
+        hipLaunchKernelGGL(k_compact_tiles, dim3(1), dim3(256), 0, s, tiles, et_tile0[et], et_tile0[et + 1], et_tile0[et] - et_tile0[0],
+                           dyn_cnt, clist, ccnt + et);
+}
+void pfk_pack_bwd(const float* W, const GvpT* g, int n_gvps, float* out, hipStream_t s) {
+    if (n_gvps == 0) return;
+    hipLaunchKernelGGL(k_pack_bwd, dim3(n_gvps * 88), dim3(64), 0, s, W, g, out);
 }
 void pfk_fix_apply(long long* A, float* G, size_t n, const float* fix, hipStream_t s) {
     if (n == 0) return;
