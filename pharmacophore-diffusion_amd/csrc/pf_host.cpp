@@ -51,7 +51,7 @@ void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, int nblocks, hipStream_t s)
 void pfk_fix_apply(long long* A, float* G, size_t n, const float* fix, hipStream_t s);
 void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* fix, hipStream_t s);
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
-void pfk_train_reduce(const float* gpart, int nblocks, int nparams, float* grad, hipStream_t s);
+void pfk_train_reduce(const ReduceParams* p, hipStream_t s);
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s);
 void pfk_pack_bwd(const float* W, const GvpT* g, int n_gvps, float* out, hipStream_t s);
 void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s);
@@ -251,6 +251,7 @@ struct pf_handle {
     float *t_G_h[2] = {nullptr, nullptr}, *t_G_v[2] = {nullptr, nullptr}, *t_gagg_s = nullptr, *t_gagg_v = nullptr,
           *t_gpart = nullptr, *t_geps_h = nullptr, *t_geps_x = nullptr;
     long long *t_A_h = nullptr, *t_A_v = nullptr;      // fixed-point accumulators of the level-0 scatter (kept clear between uses)
+    TensorSeg* d_tseg = nullptr; int n_tseg = 0;   // class of every parameter tensor (pf_train.h: which gradient copies hold it)
     float* d_wpack = nullptr;               // k_pack_bwd fragments of every message GVP; valid for w_version == wpack_version
     uint64_t wpack_version = ~0ull;
     int *t_clist = nullptr, *t_ccnt = nullptr;   // compact list of non-empty edge tiles of the layer being differentiated
@@ -950,6 +951,7 @@ void pf_destroy(pf_handle* h) {
     if (h->d_gvp) (void)hipFree(h->d_gvp);
     if (h->d_flat) (void)hipFree(h->d_flat);
     if (h->d_wpack) (void)hipFree(h->d_wpack);
+    if (h->d_tseg) (void)hipFree(h->d_tseg);
     if (h->d_gvpt) (void)hipFree(h->d_gvpt);
     if (h->d_map) (void)hipFree(h->d_map);
     if (h->d_l0c) (void)hipFree(h->d_l0c);
@@ -1197,6 +1199,31 @@ int pf_commit_weights(pf_handle* h) {
             flat.insert(flat.end(), t.data.begin(), t.data.end());
         }
         h->nparams = flat.size();
+        {   // class of every tensor: the kernel that differentiates it
+            std::vector<TensorSeg> segs;
+            for (const auto& kv : h->flat_layout) {
+                const std::string& k = kv.first;
+                TensorSeg sg{(int)kv.second.first, (int)(kv.second.first + kv.second.second), PFT_CLS_NONE, 0};
+                if (kv.second.second == 0) sg.cls = PFT_CLS_NONE;
+                else if (k.find("_encoder.") != std::string::npos) sg.cls = PFT_CLS_ENC;
+                else if (k.find("noise_predictor.noise_predictor.") != std::string::npos) sg.cls = PFT_CLS_HEAD;
+                else {
+                    int layer = -1;
+                    for (int l = 0; l < c.n_convs; ++l)
+                        if (k.compare(0, conv_prefix(l).size(), conv_prefix(l)) == 0) layer = l;
+                    if (layer < 0) PF_FAIL(h, PF_ERR_STATE, "internal: parameter %s has no gradient class", k.c_str());
+                    if (layer >= 4) { h->n_tseg = -1; break; }           // the gradient path numbers its classes for n_convs <= 4
+                    sg.cls = PFT_CLS_NODE + layer;
+                    for (int et = 0; et < 4; ++et)
+                        if (k.find(std::string("edge_message_fns.") + kEtKey[et] + ".") != std::string::npos) sg.cls = PFT_CLS_MSG + layer * 4 + et;
+                }
+                segs.push_back(sg);
+            }
+            if (h->d_tseg) { (void)hipFree(h->d_tseg); h->d_tseg = nullptr; }
+            h->n_tseg = c.n_convs <= 4 ? (int)segs.size() : -1;
+            PF_HIP(h, hipMalloc((void**)&h->d_tseg, std::max<size_t>(segs.size(), 1) * sizeof(TensorSeg)));
+            PF_HIP(h, hipMemcpy(h->d_tseg, segs.data(), segs.size() * sizeof(TensorSeg), hipMemcpyHostToDevice));
+        }
         auto mk = [&](const GvpSpec& g, bool sig) {
             GvpT t;
             t.o_Wh = (int)h->flat_offset(g.prefix + "Wh"); t.o_Wu = (int)h->flat_offset(g.prefix + "Wu");
@@ -2006,6 +2033,7 @@ int pf_train_forward(pf_handle* h, const float* dev_prot_x, const float* dev_pha
     if (rc) return rc;
     h->t_common = TrainCommon{};
     h->t_common.W = h->d_flat; h->t_common.gpart = h->t_gpart; h->t_common.nparams = (int)h->nparams;
+    h->t_common.tseg = h->d_tseg; h->t_common.ntens = h->n_tseg;
     h->t_common.drop_thr = dropout_p > 0.f ? (uint32_t)std::min(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
     h->t_common.drop_scale = 1.0f / (1.0f - dropout_p);
     h->t_common.seed = seed;
@@ -2022,6 +2050,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     if (rc) return rc;
     if (!h->t_have_fwd) PF_FAIL(h, PF_ERR_STATE, "pf_train_backward: no pf_train_forward on this batch");
     if (!dev_g_eps_h || !dev_g_eps_x || !dev_grad) PF_FAIL(h, PF_ERR_ARG, "pf_train_backward: null argument");
+    if (h->n_tseg < 0) PF_FAIL(h, PF_ERR_ARG, "pf_train_backward: the gradient path supports n_convs <= 4");
     hipStream_t s = (hipStream_t)stream;
     const pf_config& c = h->cfg;
     const int L = c.n_convs, N = h->N, nb = h->t_nblk;
@@ -2031,7 +2060,9 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         pfk_pack_bwd(h->d_flat, h->d_gvpt, h->n_msg_tot, h->d_wpack, s);
         h->wpack_version = h->w_version;
     }
-    PF_HIP(h, hipMemsetAsync(h->t_gpart, 0, (size_t)nb * h->nparams * 4, s));
+    ReduceParams rp{};
+    rp.gpart = h->t_gpart; rp.nparams = (int)h->nparams; rp.grad = dev_grad; rp.tseg = h->d_tseg; rp.ntens = h->n_tseg;
+    rp.NB = nb; rp.ccnt = h->t_ccnt;
     pfk_fix_scale(dev_g_eps_h, h->Nf * c.pharm_nf, dev_g_eps_x, h->Nf * 3, h->t_fix, s);
     PF_HIP(h, hipMemsetAsync(h->t_G_h[0], 0, (size_t)N * PF_S * 4, s));
     PF_HIP(h, hipMemsetAsync(h->t_G_v[0], 0, (size_t)N * 48 * 4, s));
@@ -2044,7 +2075,8 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         p.o_bout = (int)h->flat_offset("dynamics.noise_predictor.noise_predictor.to_scalar_output.bias");
         p.pharm_nf = c.pharm_nf; p.g_eps_h = dev_g_eps_h; p.g_eps_x = dev_g_eps_x;
         p.G_h = h->t_G_h[0]; p.G_v = h->t_G_v[0];
-        { ProfScope ps(h, pf_handle::K_BWD_HEAD, s); pfk_bwd_head(&p, std::max(1, std::min(nb, 2 * p.ntiles)), s); }
+        rp.head_grid = p.ntiles > 0 ? std::max(1, std::min(nb, 2 * p.ntiles)) : 0;
+        { ProfScope ps(h, pf_handle::K_BWD_HEAD, s); pfk_bwd_head(&p, rp.head_grid, s); }
     }
     int a = 0;
     for (int l = L - 1; l >= 0; --l) {
@@ -2077,15 +2109,17 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
             n.o_ln[nt][2] = (int)h->flat_offset(p2 + "weight"); n.o_ln[nt][3] = (int)h->flat_offset(p2 + "bias");
         }
         n.layer = l; n.l0 = l == 0;
-        { ProfScope ps(h, pf_handle::K_BWD_NODE, s); pfk_bwd_node(&n, std::max(1, std::min(nb, 2 * n.ntiles)), s); }
+        rp.node_grid[l] = n.ntiles > 0 ? std::max(1, std::min(nb, 2 * n.ntiles)) : 0;
+        { ProfScope ps(h, pf_handle::K_BWD_NODE, s); pfk_bwd_node(&n, rp.node_grid[l], s); }
         BwdEdgeLevelParams e{};
         e.c = tc; e.tiles = pruned ? h->d_edge_tiles_act : h->d_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
         e.pp_slot = pruned ? 2 : 1;
         const int* et0 = pruned ? h->et_tile0_act : h->et_tile0;
         for (int et = 0; et <= 4; ++et) e.et_tile0[et] = et0[et];
         e.n_et = last ? 2 : 4;                       // the last layer's fp / pp messages reach no output
-        e.clist = h->t_clist; e.ccnt = h->t_ccnt;
-        pfk_compact_tiles(e.tiles, e.et_tile0, e.n_et, h->d_dyn_cnt, h->t_clist, h->t_ccnt, s);
+        e.clist = h->t_clist; e.ccnt = h->t_ccnt + 4 * l;
+        rp.n_et[l] = e.n_et;
+        pfk_compact_tiles(e.tiles, e.et_tile0, e.n_et, h->d_dyn_cnt, h->t_clist, h->t_ccnt + 4 * l, s);
         e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;
         e.h = h->t_H[l]; e.v = h->t_V[l];
         e.gagg_s = h->t_gagg_s; e.gagg_v = h->t_gagg_v; e.in_cnt = h->d_in_cnt; e.N = N;
@@ -2117,9 +2151,10 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         }
         p.G_h = h->t_G_h[a];
         const int tiles = (h->Np + PFT_ROWS - 1) / PFT_ROWS + (h->Nf + PFT_ROWS - 1) / PFT_ROWS;
-        pfk_bwd_encode(&p, std::max(1, std::min(nb, tiles)), s);
+        rp.enc_grid = std::max(1, std::min(nb, tiles));
+        pfk_bwd_encode(&p, rp.enc_grid, s);
     }
-    pfk_train_reduce(h->t_gpart, nb, (int)h->nparams, dev_grad, s);
+    pfk_train_reduce(&rp, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return PF_OK;

@@ -28,10 +28,30 @@ struct GvpT {
     int vi, h, vo, si, so, sig;               // sig: vector activation is a sigmoid (0: identity, last head GVP)
 };
 
+// Which blocks' gradient copies hold a tensor's gradient is a function of the kernel that differentiates it (its "class"):
+// head, encoders and node kernels use the blocks [0, grid) of their launch and clear their tensors in their own copy when they
+// start; an edge-level launch deals its blocks over the etypes (k_bwd_edge_level) and every block STORES the whole GVP it
+// served.  Nothing is cleared globally and pfk_train_reduce adds up exactly the copies that were written.
+#define PFT_CLS_HEAD 0
+#define PFT_CLS_ENC 1
+#define PFT_CLS_NODE 2       // + layer
+#define PFT_CLS_MSG 8        // + layer * 4 + etype
+#define PFT_CLS_NONE (-1)    // empty tensors
+struct TensorSeg { int begin, end, cls, pad; };
+struct ReduceParams {
+    const float* gpart; int nparams; float* grad;
+    const TensorSeg* tseg; int ntens;
+    int NB;                  // gradient copies = grid of the edge-level launches
+    int head_grid, enc_grid, node_grid[4];
+    int n_et[4];             // etypes that took part in layer l's edge-level launches
+    const int* ccnt;         // [layer][4] non-empty tiles per etype (k_compact_tiles)
+};
+
 struct TrainCommon {
     const float* W;          // flat parameters
     float* gpart;            // [gridDim.x][nparams]
     int nparams;
+    const TensorSeg* tseg; int ntens;
     uint32_t drop_thr;       // an element is dropped iff pf_drop_hash(...) < drop_thr  (= p * 2^32; 0: no dropout)
     float drop_scale;        // 1 / (1 - p)
     uint32_t seed;           // dropout stream of this step

@@ -120,6 +120,30 @@ __device__ __forceinline__ void mm16_acc(const int M, const int N, const int K, 
     }
 }
 
+// clear the tensors of class `cls` in this block's gradient copy (start of a kernel that accumulates per tile)
+__device__ __forceinline__ void zero_class(const TrainCommon& c, float* gp, const int cls, const int tid) {
+    for (int t = 0; t < c.ntens; ++t) {
+        const TensorSeg s = c.tseg[t];
+        if (s.cls == cls)
+            for (int i = s.begin + tid; i < s.end; i += NT) gp[i] = 0.f;
+    }
+    __syncthreads();
+}
+// blocks [b0, b0 + nbk) of an edge-level launch of NB blocks serve etype `et`: in proportion to the non-empty tiles, at
+// least one where there are tiles, never more than tiles
+__device__ __forceinline__ void et_blocks(const int* ccnt, const int n_et, const int NB, const int et, int& b0, int& nbk) {
+    int cnt[4], tot = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { cnt[e] = e < n_et ? ccnt[e] : 0; tot += cnt[e]; }
+    b0 = 0; nbk = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n = cnt[e] > 0 ? min(cnt[e], max(1, (int)((long long)(NB - 3) * cnt[e] / tot))) : 0;
+        if (e < et) b0 += n;
+        if (e == et) nbk = n;
+    }
+}
+
 // diagnostic builds (-DPFT_STAMPS): cycle stamps of block 0's first sub-tile at phase boundaries
 #ifdef PFT_STAMPS
 #ifndef PFT_STAMP_BLOCK
@@ -349,6 +373,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
     ChainLds L; L.init(lds, p.n_gvps);
     const float* W = p.c.W;
     float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
+    zero_class(p.c, gp, PFT_CLS_HEAD, threadIdx.x);
     const int NF = p.pharm_nf;
     const int SOL = p.g[p.n_gvps - 1].so;            // 64
     // work unit = one 16-row half of a 32-row tile, dealt over the blocks
@@ -456,6 +481,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
     ChainLds L; L.init(lds, p.n_upd);
     const float* W = p.c.W;
     float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
+    zero_class(p.c, gp, PFT_CLS_NODE + p.layer, threadIdx.x);
     const uint32_t st_msg = (uint32_t)p.layer * 2u, st_res = st_msg + 1u;
     for (int unit = blockIdx.x; unit < 2 * p.ntiles; unit += gridDim.x) {
         const NodeTile t = p.tiles[unit >> 1];
@@ -757,17 +783,11 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
     // blocks per etype in proportion to its non-empty tiles (k_compact_tiles), at least one where there are tiles: every
     // block derives the same partition from the four counts
     int et = -1, nb = 0, my = 0, cnt_et = 0;
-    {
-        int cnt[4], tot = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { cnt[e] = e < p.n_et ? p.ccnt[e] : 0; tot += cnt[e]; }
-        int b0 = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int nbk = cnt[e] > 0 ? min(cnt[e], max(1, (int)((long long)((int)gridDim.x - 3) * cnt[e] / tot))) : 0;
-            if ((int)blockIdx.x >= b0 && (int)blockIdx.x < b0 + nbk) { et = e; nb = nbk; my = blockIdx.x - b0; cnt_et = cnt[e]; }
-            b0 += nbk;
-        }
+    for (int e = 0; e < 4; ++e) {
+        int b0, nbk;
+        et_blocks(p.ccnt, p.n_et, (int)gridDim.x, e, b0, nbk);
+        if ((int)blockIdx.x >= b0 && (int)blockIdx.x < b0 + nbk) { et = e; nb = nbk; my = blockIdx.x - b0; cnt_et = p.ccnt[e]; }
     }
     if (et < 0) return;                              // block-uniform: more gradient copies than work
     const int* clist = p.clist + (p.et_tile0[et] - p.et_tile0[0]);
@@ -1095,7 +1115,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
             }
         }
     }
-    // ---- flush the register accumulators into this block's gradient copy
+    // ---- the register accumulators ARE this block's share of the GVP's gradient: stored, not added (every block of the
+    // etype's range stores every element of the GVP; waves 6 / 7 hold zeros in the Wu / Wh tiles they never touched)
 #pragma unroll
     for (int x = 0; x < 11; ++x)
         if (x < nts) {
@@ -1103,28 +1124,28 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = wv * 16 + kq * 4 + r;
-                if (cj < KM) gp[g.o_Wm + ci * KM + cj] += accWm[x][r];
+                if (cj < KM) gp[g.o_Wm + ci * KM + cj] = accWm[x][r];
             }
         }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) gp[g.o_Wg + (kq * 4 + r) * SO + wv * 16 + li] += accWg[r];
+    for (int r = 0; r < 4; ++r) gp[g.o_Wg + (kq * 4 + r) * SO + wv * 16 + li] = accWg[r];
     if (wv >= 6) {
         const int tb6 = wv - 6;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int hh = tb6 * 16 + kq * 4 + r;
-            if (hh < KH) gp[g.o_Wu + hh * VO + li] += accU[r];
+            if (hh < KH) gp[g.o_Wu + hh * VO + li] = accU[r];
         }
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int vi = tb6 * 16 + kq * 4 + r, hh = tb * 16 + li;
-                if (vi < VI && hh < KH) gp[g.o_Wh + vi * KH + hh] += accH[tb][r];
+                if (vi < VI && hh < KH) gp[g.o_Wh + vi * KH + hh] = accH[tb][r];
             }
     }
-    if (tid < SO) gp[g.o_bm + tid] += acc_bm;
-    if (tid < VO) gp[g.o_bg + tid] += acc_bg;
+    if (tid < SO) gp[g.o_bm + tid] = acc_bm;
+    if (tid < VO) gp[g.o_bg + tid] = acc_bg;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1136,6 +1157,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_encode(const BwdEncodeParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* W = p.c.W;
     float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
+    zero_class(p.c, gp, PFT_CLS_ENC, threadIdx.x);
     const int N = p.Np + p.Nf;
     const int tiles_prot = (p.Np + TR - 1) / TR, tiles_pharm = (p.Nf + TR - 1) / TR;
     for (int ti = blockIdx.x; ti < tiles_prot + tiles_pharm; ti += gridDim.x) {
@@ -1255,12 +1277,27 @@ __global__ __launch_bounds__(256) void k_fix_scale(const float* g_h, const int n
         fix[1] = ldexpf(1.0f, -k);
     }
 }
-__global__ void k_train_reduce(const float* gpart, const int nblocks, const int nparams, float* grad) {
+__global__ void k_train_reduce(const ReduceParams p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nparams) return;
+    if (i >= p.nparams) return;
+    int lo = 0, hi = p.ntens - 1;                    // last tensor that begins at or before i (empty tensors precede their successor)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (p.tseg[mid].begin <= i) lo = mid; else hi = mid - 1;
+    }
+    const int cls = p.tseg[lo].cls;
+    int b0 = 0, b1 = 0;
+    if (cls == PFT_CLS_HEAD) b1 = p.head_grid;
+    else if (cls == PFT_CLS_ENC) b1 = p.enc_grid;
+    else if (cls >= PFT_CLS_MSG) {
+        const int l = (cls - PFT_CLS_MSG) >> 2, et = (cls - PFT_CLS_MSG) & 3;
+        int nbk;
+        et_blocks(p.ccnt + 4 * l, p.n_et[l], p.NB, et, b0, nbk);
+        b1 = b0 + nbk;
+    } else if (cls >= PFT_CLS_NODE) b1 = p.node_grid[cls - PFT_CLS_NODE];
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += gpart[(size_t)b * nparams + i];
-    grad[i] = s;
+    for (int b = b0; b < b1; ++b) s += p.gpart[(size_t)b * p.nparams + i];
+    p.grad[i] = s;
 }
 
 // packed[i] = flat[map[i]] (map[i] < 0: zero padding): re-pack the MFMA-fragment weights after the parameters changed
@@ -1332,8 +1369,8 @@ void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* 
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s) {
     hipLaunchKernelGGL(k_bwd_encode, dim3(nblocks), dim3(NT), 0, s, *p);
 }
-void pfk_train_reduce(const float* gpart, int nblocks, int nparams, float* grad, hipStream_t s) {
-    hipLaunchKernelGGL(k_train_reduce, dim3((nparams + 255) / 256), dim3(256), 0, s, gpart, nblocks, nparams, grad);
+void pfk_train_reduce(const ReduceParams* p, hipStream_t s) {
+    hipLaunchKernelGGL(k_train_reduce, dim3((p->nparams + 255) / 256), dim3(256), 0, s, *p);
 }
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s) {
     if (n == 0) return;
