@@ -55,6 +55,9 @@ SYMBOLS = {
     "pf_param_layout": (ctypes.c_int, [_P, _I32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "pf_train_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _F, ctypes.c_uint32, _P, _P, _P]),
     "pf_train_backward": (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    "pf_train_loss_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_float, ctypes.c_int32,
+                                             ctypes.c_int32, ctypes.c_float, ctypes.c_uint32, _P, _P]),
+    "pf_train_loss_backward": (ctypes.c_int, [_P, _P, _P, _P, _P]),
     "pf_set_flat_params": (ctypes.c_int, [_P, _P, _P]),
     "pf_get_flat_params": (ctypes.c_int, [_P, _P, _P]),
     "pf_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _P]),

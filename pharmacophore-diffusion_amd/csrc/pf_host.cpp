@@ -54,6 +54,9 @@ void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
 void pfk_train_reduce(const ReduceParams* p, hipStream_t s);
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s);
 void pfk_pack_bwd(const float* W, const GvpT* g, int n_gvps, float* out, hipStream_t s);
+void pfk_loss_prepare(const LossParams* p, hipStream_t s);
+void pfk_loss_eval(const LossParams* p, hipStream_t s);
+void pfk_scale_by(float* g, int n, const float* scale, hipStream_t s);
 void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s);
 void pfk_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
               float bc1, float bc2_sqrt, hipStream_t s);
@@ -254,6 +257,8 @@ struct pf_handle {
     TensorSeg* d_tseg = nullptr; int n_tseg = 0;   // class of every parameter tensor (pf_train.h: which gradient copies hold it)
     float* d_wpack = nullptr;               // k_pack_bwd fragments of every message GVP; valid for w_version == wpack_version
     uint64_t wpack_version = ~0ull;
+    float *t_lx0c = nullptr, *t_lag = nullptr, *t_lsg = nullptr, *t_lgx = nullptr, *t_lgh = nullptr, *t_lout = nullptr;   // pf_train_loss_forward
+    bool t_have_loss = false;
     int *t_clist = nullptr, *t_ccnt = nullptr;   // compact list of non-empty edge tiles of the layer being differentiated
     float* t_fix = nullptr;                 // [2] scale / inverse scale of the current backward call
     int t_nblk = 0;
@@ -1919,6 +1924,7 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     need((size_t)2 * N * PF_S); need((size_t)2 * N * 48);          // int64 accumulators (two floats per element)
     need(64);
     need(64); need((size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);      // compact tile list and its counts
+    need((size_t)h->Nf * 3); need((size_t)h->B); need((size_t)h->B); need((size_t)h->Nf * 3); need((size_t)h->Nf * c.pharm_nf); need(64);   // loss buffers
     need((size_t)h->t_nblk * h->nparams);
     const size_t Es = (size_t)std::max<int64_t>(h->Ecap, 1), ng = (size_t)c.n_message_gvps;
     for (int l = 0; l < L; ++l) { need(ng * Es * PF_S); need(ng * Es * 16); need(ng * Es * 48); }
@@ -1945,6 +1951,8 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     h->t_fix = carve<float>(cur, 64);
     h->t_ccnt = carve<int>(cur, 64);
     h->t_clist = carve<int>(cur, (size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);
+    h->t_lx0c = carve<float>(cur, (size_t)h->Nf * 3); h->t_lag = carve<float>(cur, (size_t)h->B); h->t_lsg = carve<float>(cur, (size_t)h->B);
+    h->t_lgx = carve<float>(cur, (size_t)h->Nf * 3); h->t_lgh = carve<float>(cur, (size_t)h->Nf * c.pharm_nf); h->t_lout = carve<float>(cur, 64);
     PF_HIP(h, hipMemsetAsync(h->t_A_h, 0, (size_t)N * PF_S * 8, s));       // pfk_fix_apply keeps them clear afterwards
     PF_HIP(h, hipMemsetAsync(h->t_A_v, 0, (size_t)N * 48 * 8, s));
     h->t_gpart = carve<float>(cur, (size_t)h->t_nblk * h->nparams);
@@ -2038,11 +2046,67 @@ int pf_train_forward(pf_handle* h, const float* dev_prot_x, const float* dev_pha
     h->t_common.drop_scale = 1.0f / (1.0f - dropout_p);
     h->t_common.seed = seed;
     h->t_common.mask_override = h->t_mask_override; h->t_common.mask_N = h->N;
+    h->t_have_loss = false;
     load_state(h, dev_prot_x, dev_pharm_x, dev_pharm_h, s);
     pfk_copy(dev_t, h->d_t, (size_t)h->B, s);
     rc = run_dynamics(h, dev_eps_h, dev_eps_x, s, nullptr, true);
     h->t_have_fwd = rc == PF_OK;
     return rc;
+}
+
+int pf_train_loss_forward(pf_handle* h, const float* dev_pharm_x0, const float* dev_pharm_h0, const int32_t* dev_t_int,
+                          const float* dev_eps_x, const float* dev_eps_h, const float* dev_alpha, const float* dev_sigma,
+                          int32_t n_timesteps, float feat_norm, int32_t remove_com, int32_t weighted_loss, float dropout_p,
+                          uint32_t seed, float* dev_out, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!dev_pharm_x0 || !dev_pharm_h0 || !dev_t_int || !dev_eps_x || !dev_eps_h || !dev_alpha || !dev_sigma || !dev_out)
+        PF_FAIL(h, PF_ERR_ARG, "pf_train_loss_forward: null argument");
+    if (n_timesteps < 1 || !(feat_norm > 0.f)) PF_FAIL(h, PF_ERR_ARG, "pf_train_loss_forward: bad n_timesteps / feat_norm");
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) PF_FAIL(h, PF_ERR_ARG, "pf_train_loss_forward: dropout must be in [0, 1)");
+    hipStream_t s = (hipStream_t)stream;
+    rc = ensure_train_ws(h, s);
+    if (rc) return rc;
+    h->t_have_loss = false;
+    h->t_common = TrainCommon{};
+    h->t_common.W = h->d_flat; h->t_common.gpart = h->t_gpart; h->t_common.nparams = (int)h->nparams;
+    h->t_common.tseg = h->d_tseg; h->t_common.ntens = h->n_tseg;
+    h->t_common.drop_thr = dropout_p > 0.f ? (uint32_t)std::min(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
+    h->t_common.drop_scale = 1.0f / (1.0f - dropout_p);
+    h->t_common.seed = seed;
+    h->t_common.mask_override = h->t_mask_override; h->t_common.mask_N = h->N;
+    LossParams lp{};
+    lp.B = h->B; lp.Np = h->Np; lp.Nf = h->Nf; lp.nf = h->cfg.pharm_nf; lp.T = n_timesteps; lp.remove_com = remove_com; lp.weighted = weighted_loss;
+    lp.feat_norm = feat_norm;
+    lp.prot_ptr = h->d_prot_ptr; lp.pharm_ptr = h->d_pharm_ptr; lp.gid = h->d_gid; lp.prot_x0 = h->d_prot_x0;
+    lp.x0 = dev_pharm_x0; lp.h0 = dev_pharm_h0; lp.t_int = dev_t_int; lp.eps_x = dev_eps_x; lp.eps_h = dev_eps_h;
+    lp.alpha_tab = dev_alpha; lp.sigma_tab = dev_sigma;
+    lp.xn = h->d_xn; lp.pharm_h = h->d_pharm_h; lp.t = h->d_t;
+    lp.x0c = h->t_lx0c; lp.alpha_g = h->t_lag; lp.sigma_g = h->t_lsg;
+    lp.dyn_h = h->d_eps_h; lp.dyn_x = h->d_eps_x; lp.g_x = h->t_lgx; lp.g_h = h->t_lgh; lp.out = dev_out;
+    h->edges_built = false;
+    h->coords_custom = true;                     // the pocket moved with the centers' COM: trajectory constants of the bound coordinates do not apply
+    pfk_loss_prepare(&lp, s);
+    rc = run_dynamics(h, h->d_eps_h, h->d_eps_x, s, nullptr, true);
+    h->t_have_fwd = rc == PF_OK;
+    if (rc) return rc;
+    pfk_loss_eval(&lp, s);
+    h->t_have_loss = true;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return PF_OK;
+}
+
+int pf_train_loss_backward(pf_handle* h, const float* dev_g_pos, const float* dev_g_feat, float* dev_grad, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!h->t_have_fwd || !h->t_have_loss) PF_FAIL(h, PF_ERR_STATE, "pf_train_loss_backward: no pf_train_loss_forward on this batch");
+    if (!dev_g_pos || !dev_g_feat || !dev_grad) PF_FAIL(h, PF_ERR_ARG, "pf_train_loss_backward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    pfk_scale_by(h->t_lgx, h->Nf * 3, dev_g_pos, s);
+    pfk_scale_by(h->t_lgh, h->Nf * h->cfg.pharm_nf, dev_g_feat, s);
+    h->t_have_loss = false;                      // the unit gradients are consumed
+    return pf_train_backward(h, h->t_lgh, h->t_lgx, dev_grad, stream);
 }
 
 int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g_eps_x, float* dev_grad, pf_stream stream) {

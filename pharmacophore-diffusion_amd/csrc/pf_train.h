@@ -147,6 +147,21 @@ struct BwdEncodeParams {
     const float* G_h;                        // gradient w.r.t. the encoder output [N][128]
 };
 
+// the loss around the dynamics (k_loss_prepare / k_loss_eval, pf_train_loss_forward)
+struct LossParams {
+    int B, Np, Nf, nf, T, remove_com, weighted;
+    float feat_norm;
+    const int* prot_ptr; const int* pharm_ptr; const int* gid;
+    const float* prot_x0;                    // [Np][3] as bound
+    const float* x0; const float* h0;        // clean centers [Nf][3], raw feature one-hots [Nf][nf]
+    const int* t_int; const float* eps_x; const float* eps_h;
+    const float* alpha_tab; const float* sigma_tab;
+    float4* xn; float* pharm_h; float* t;    // the dynamics' input state
+    float* x0c; float* alpha_g; float* sigma_g;
+    const float* dyn_h; const float* dyn_x;  // the dynamics' outputs
+    float* g_x; float* g_h; float* out;      // unit upstream gradients, [6] losses and metrics
+};
+
 // dropout keep-mask of (step seed, stream, element): identical in the forward node kernel and the backward pass.
 // stream = layer * 2 + (0: message dropout, 1: residual dropout); element = node * 144 + (feature | 128 + channel).
 #if defined(__HIPCC__)

@@ -1322,6 +1322,108 @@ __global__ void k_adam(float* p, const float* g, float* m, float* v, const size_
     p[i] = pi - (lr / bc1) * (mi / denom);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The loss around the dynamics (PharmacophoreDiff.forward, pharmacodiff.py:162-243, noise parameterisation) as two small
+// kernels instead of ~60 framework launches per step:
+//   k_loss_prepare (one block per graph): COM of the clean centers taken off the centers and the pocket (:176-183), z_t =
+//     alpha_t x0 + sigma_t eps with alpha / sigma looked up at t_int (:186-197), second COM removal (:199-205); writes the
+//     dynamics' input state (xn, pharm_h, t) in place
+//   k_loss_eval (one block, fixed reduction order): the two losses (:208-232), the four metrics (:234-241) and the unit
+//     upstream gradients d(pos loss)/d(eps_x), d(feat loss)/d(eps_h) for pf_train_loss_backward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_loss_prepare(const LossParams p) {
+    __shared__ float s_sh[8];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int f0 = p.pharm_ptr[g], nfg = p.pharm_ptr[g + 1] - f0;          // <= 64 centers per graph
+    const int ti = p.t_int[g];
+    const float a = p.alpha_tab[ti], sg = p.sigma_tab[ti];
+    if (tid < 64) {
+        auto wsum = [](float v) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            return v;
+        };
+        const bool on = tid < nfg;
+        const int f = f0 + (on ? tid : 0);
+        float x = on ? p.x0[3 * f] : 0.f, y = on ? p.x0[3 * f + 1] : 0.f, z = on ? p.x0[3 * f + 2] : 0.f;
+        const float cnt = (float)max(nfg, 1);
+        const float cx = wsum(x) / cnt, cy = wsum(y) / cnt, cz = wsum(z) / cnt;
+        x -= cx; y -= cy; z -= cz;
+        float xt = on ? a * x + sg * p.eps_x[3 * f] : 0.f, yt = on ? a * y + sg * p.eps_x[3 * f + 1] : 0.f,
+              zt = on ? a * z + sg * p.eps_x[3 * f + 2] : 0.f;
+        float mx = 0.f, my = 0.f, mz = 0.f;
+        if (p.remove_com) { mx = wsum(xt) / cnt; my = wsum(yt) / cnt; mz = wsum(zt) / cnt; }
+        if (on) {
+            p.x0c[3 * f] = x; p.x0c[3 * f + 1] = y; p.x0c[3 * f + 2] = z;
+            p.xn[p.Np + f] = make_float4(xt - mx, yt - my, zt - mz, 0.f);
+            for (int k = 0; k < p.nf; ++k)
+                p.pharm_h[(size_t)f * p.nf + k] = a * (p.h0[(size_t)f * p.nf + k] / p.feat_norm) + sg * p.eps_h[(size_t)f * p.nf + k];
+        }
+        if (tid == 0) {
+            s_sh[0] = cx; s_sh[1] = cy; s_sh[2] = cz; s_sh[3] = mx; s_sh[4] = my; s_sh[5] = mz;
+            p.t[g] = (float)ti / (float)p.T;
+            p.alpha_g[g] = a; p.sigma_g[g] = sg;
+        }
+    }
+    __syncthreads();
+    const float cx = s_sh[0], cy = s_sh[1], cz = s_sh[2], mx = s_sh[3], my = s_sh[4], mz = s_sh[5];
+    for (int n = p.prot_ptr[g] + tid; n < p.prot_ptr[g + 1]; n += 256)
+        p.xn[n] = make_float4(p.prot_x0[3 * n] - cx - mx, p.prot_x0[3 * n + 1] - cy - my, p.prot_x0[3 * n + 2] - cz - mz, 0.f);
+}
+__global__ __launch_bounds__(1024) void k_loss_eval(const LossParams p) {
+    __shared__ float red[6][1024];
+    const int tid = threadIdx.x;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float inv_x = 1.0f / (float)(p.Nf * 3), inv_h = 1.0f / (float)(p.Nf * p.nf);
+    for (int f = tid; f < p.Nf; f += 1024) {
+        const int g = p.gid[p.Np + f];
+        const float a = p.alpha_g[g], sg = p.sigma_g[g], wm = 1.0f - p.t[g], wl = p.weighted ? wm : 1.0f;
+        const float4 xt = p.xn[p.Np + f];
+        const float xtv[3] = {xt.x, xt.y, xt.z};
+        float xl = 0.f, err = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d = p.eps_x[3 * f + c] - p.dyn_x[3 * f + c];
+            xl += d * d;
+            p.g_x[3 * f + c] = -2.0f * wl * d * inv_x;
+            const float e = (xtv[c] - sg * p.dyn_x[3 * f + c]) / a - p.x0c[3 * f + c];
+            err += e * e;
+        }
+        float hl = 0.f, bp = 0.f, bt = 0.f;
+        int ip = 0, it = 0;
+        for (int k = 0; k < p.nf; ++k) {
+            const size_t o = (size_t)f * p.nf + k;
+            const float d = p.eps_h[o] - p.dyn_h[o];
+            hl += d * d;
+            p.g_h[o] = -2.0f * wl * d * inv_h;
+            const float hp = (p.pharm_h[o] - sg * p.dyn_h[o]) / a, ht = p.h0[o];
+            if (k == 0 || hp > bp) { bp = hp; ip = k; }                  // first maximum, like argmax
+            if (k == 0 || ht > bt) { bt = ht; it = k; }
+        }
+        const float hit = ip == it ? 1.0f : 0.f;
+        acc[0] += xl * wl; acc[1] += hl * wl; acc[2] += err; acc[3] += wm * err; acc[4] += hit; acc[5] += wm * hit;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) red[q][tid] = acc[q];
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if (tid < st)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) red[q][tid] += red[q][tid + st];
+        __syncthreads();
+    }
+    if (tid < 6) {
+        const float nfl = (float)p.Nf;
+        const float den = tid == 0 ? (float)(p.Nf * 3) : (tid == 1 ? (float)(p.Nf * p.nf) : nfl);
+        p.out[tid] = red[tid][0] / den;
+    }
+}
+// g[i] *= *scale (the upstream gradient of a scalar loss)
+__global__ void k_scale_by(float* g, const int n, const float* scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) g[i] *= scale[0];
+}
+
 // dropout masks as the forward applies them, for tests: out[(node * 144 + elem)] in {0, 1/(1-p)}
 __global__ void k_drop_masks(const TrainCommon c, const uint32_t stream, const int n_elems, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1354,6 +1456,11 @@ void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, con
     for (int et = 0; et < n_et; ++et)
         hipLaunchKernelGGL(k_compact_tiles, dim3(1), dim3(256), 0, s, tiles, et_tile0[et], et_tile0[et + 1], et_tile0[et] - et_tile0[0],
                            dyn_cnt, clist, ccnt + et);
+}
+void pfk_loss_prepare(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_prepare, dim3(p->B), dim3(256), 0, s, *p); }
+void pfk_loss_eval(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_eval, dim3(1), dim3(1024), 0, s, *p); }
+void pfk_scale_by(float* g, int n, const float* scale, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_scale_by, dim3((n + 255) / 256), dim3(256), 0, s, g, n, scale);
 }
 void pfk_pack_bwd(const float* W, const GvpT* g, int n_gvps, float* out, hipStream_t s) {
     if (n_gvps == 0) return;

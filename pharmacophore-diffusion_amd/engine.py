@@ -189,6 +189,34 @@ class PfEngine:
             self._ck(self.lib.pf_train_backward(self._h, _dptr(gh), _dptr(gx), _dptr(grad), _stream_ptr()), "pf_train_backward")
         return grad
 
+    def train_loss_forward(self, pharm_x0, pharm_h0, t_int, eps_x, eps_h, alpha_tab, sigma_tab, n_timesteps, feat_norm,
+                           remove_com=True, weighted_loss=False, dropout=0.0, seed=0):
+        """PharmacophoreDiff.forward (pharmacodiff.py:162-243, noise parameterisation) around the bound batch as one call:
+        COM removal, noising, the train-mode dynamics, losses and metrics.  Returns a device tensor [6]: pos loss, feat
+        loss, position error, weighted position error, accuracy, weighted accuracy."""
+        x0, h0 = _f32(pharm_x0, self.device), _f32(pharm_h0, self.device)
+        ex, eh = _f32(eps_x, self.device), _f32(eps_h, self.device)
+        ti = t_int.to(self.device, torch.int32).contiguous()
+        al, sg = _f32(alpha_tab, self.device), _f32(sigma_tab, self.device)
+        out = torch.empty(6, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_train_loss_forward(self._h, _dptr(x0), _dptr(h0), _dptr(ti), _dptr(ex), _dptr(eh), _dptr(al),
+                                                    _dptr(sg), int(n_timesteps), float(feat_norm), int(bool(remove_com)),
+                                                    int(bool(weighted_loss)), float(dropout), int(seed) & 0xFFFFFFFF,
+                                                    _dptr(out), _stream_ptr()), "pf_train_loss_forward")
+        return out
+
+    def train_loss_backward(self, g_pos, g_feat):
+        """d(g_pos * pos loss + g_feat * feat loss)/d(parameters) of the last train_loss_forward, as one flat vector."""
+        gp, gf = _f32(g_pos, self.device).reshape(1), _f32(g_feat, self.device).reshape(1)
+        if not hasattr(self, "n_params"):
+            self.param_layout()
+        grad = torch.empty(self.n_params, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_train_loss_backward(self._h, _dptr(gp), _dptr(gf), _dptr(grad), _stream_ptr()),
+                     "pf_train_loss_backward")
+        return grad
+
     def set_flat_params(self, flat):
         """Replace every parameter from one flat device vector (param_layout order); the packed kernel weights are
         refreshed by a device-side gather."""

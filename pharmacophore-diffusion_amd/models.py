@@ -161,6 +161,29 @@ class _DynamicsFn(torch.autograd.Function):
         return (None,) * 8 + (eng.train_backward(g_h, g_x),)
 
 
+class _LossFn(torch.autograd.Function):
+    """PharmacophoreDiff.forward's loss (pharmacodiff.py:162-243, noise parameterisation) as one autograd node: forward =
+    pf_train_loss_forward (COM removal, noising, train-mode dynamics, losses and metrics on the device), backward =
+    pf_train_loss_backward with the upstream gradients of the two losses.  Output: [pos loss, feat loss, four metrics]."""
+
+    @staticmethod
+    def forward(ctx, mod, eng, x0, h0, t_int, eps_x, eps_h, tabs, T, feat_norm, remove_com, weighted, dropout, seed, flat_leaf):
+        out = eng.train_loss_forward(x0, h0, t_int, eps_x, eps_h, tabs[0], tabs[1], T, feat_norm, remove_com, weighted,
+                                     dropout=dropout, seed=seed)
+        mod._fwd_token += 1
+        ctx.mod, ctx.eng, ctx.token = mod, eng, mod._fwd_token
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        mod, eng = ctx.mod, ctx.eng
+        if ctx.token != mod._fwd_token:
+            raise RuntimeError("backward of a loss forward that is not the most recent training forward: the engine keeps "
+                               "the activations of one forward at a time")
+        g_out = g_out.contiguous()
+        return (None,) * 14 + (eng.train_loss_backward(g_out[0:1], g_out[1:2]),)
+
+
 class PharmRecDynamicsGVP(nn.Module):
     """Drop-in for pharmacoforge.models.dynamics_gvp.PharmRecDynamicsGVP (same constructor, same
     state-dict keys, same forward signature); forward runs on the MI355X through libpfdyn."""
@@ -634,6 +657,8 @@ class PharmacophoreDiff(_Base):
         its backward -- evaluated by the HIP kernels.  ``t_int`` / ``eps`` inject the random draws."""
         g = as_pocket_graph(g)
         dev = self.device
+        if self.fused_loss and dev.type == "cuda" and not self.endpoint_param_feat and not self.endpoint_param_coord:
+            return self._forward_fused(g, phase, t_int, eps)
         bidx = get_batch_idxs(g)
         bp, br = bidx['pharm'].to(dev), bidx['prot'].to(dev)
         B = g.batch_size
@@ -693,6 +718,48 @@ class PharmacophoreDiff(_Base):
             hit = (h_0_pred.argmax(dim=1) == h0.argmax(dim=1)).float()
             metrics = {phase + ' position error': err.mean(), phase + ' weighted position error': (weight_metric * err).mean(),
                        phase + ' accuracy': hit.mean(), phase + ' weighted accuracy': (weight_metric * hit).mean()}
+        return losses, metrics
+
+    fused_loss = True      # noise-parameterised losses run as one C-ABI call (pf_train_loss_forward); False: the framework-op restatement above
+
+    def _loss_tables(self):
+        """alpha(gamma(k / T)), sigma(gamma(k / T)) for k = 0..T with the reference's own fp32 expressions (pharmacodiff.py:186-190,
+        582-668), on the device: what forward() looks up at t_int."""
+        tabs = self.__dict__.get("_loss_tabs")
+        if tabs is None or tabs[0].device != self.device:
+            t = torch.arange(0, self.n_timesteps + 1, device=self.device).float() / self.n_timesteps
+            gamma_t = self.gamma(t)
+            tabs = (self.alpha(gamma_t).float().contiguous(), self.sigma(gamma_t).float().contiguous())
+            self.__dict__["_loss_tabs"] = tabs
+        return tabs
+
+    def _forward_fused(self, g, phase, t_int, eps):
+        """forward() for the noise parameterisation through pf_train_loss_forward: same draws (t_int, eps), same losses and
+        metrics; the pocket's coordinates are the ones bound to the engine (bind_graph), nothing else is uploaded but the
+        clean centers."""
+        dev = self.device
+        dyn = self.dynamics
+        eng = dyn.bind_graph(g)
+        B = g.batch_size
+        x0, h0 = g.pharm_x0.to(dev), g.pharm_h0.to(dev)
+        if t_int is None:
+            t_int = torch.randint(0, self.n_timesteps, size=(B,), device=dev)
+        if eps is None:
+            eps = {'h': torch.randn(h0.shape, device=dev), 'x': torch.randn(x0.shape, device=dev)}
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p, _, _ in dyn._flat_views)
+        p_drop = float(dyn.dropout_rate) if dyn.training else 0.0
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
+        args = (x0, h0, t_int, eps['x'], eps['h'], self._loss_tables(), self.n_timesteps, float(self.pharm_feat_norm_constant),
+                bool(self.remove_com), bool(self.weighted_loss), p_drop, seed)
+        if need_grad:
+            out = _LossFn.apply(dyn, eng, *args, dyn.__dict__["_flat_leaf"])
+        else:
+            out = eng.train_loss_forward(args[0], args[1], args[2], args[3], args[4], args[5][0], args[5][1], *args[6:10],
+                                         dropout=p_drop, seed=seed)
+        losses = {phase + ' pos loss': out[0], phase + ' feat loss': out[1]}
+        m = out.detach()
+        metrics = {phase + ' position error': m[2], phase + ' weighted position error': m[3],
+                   phase + ' accuracy': m[4], phase + ' weighted accuracy': m[5]}
         return losses, metrics
 
     def configure_optimizers(self):

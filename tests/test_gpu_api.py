@@ -74,6 +74,28 @@ def test_training_loss_forward_matches_reference_golden():
         assert abs(float(v.detach()) - float(losses[k])) <= 2e-5 * max(1.0, abs(float(losses[k])))
 
 
+@pytest.mark.parametrize("remove_com,weighted", [(True, False), (False, True)])
+def test_fused_loss_call_equals_the_framework_restatement(remove_com, weighted):
+    """pf_train_loss_forward / _backward (one C-ABI call each) against forward()'s op-by-op restatement of
+    pharmacodiff.py:162-243 around pf_train_forward / pf_train_backward: same draws, same losses, metrics and gradients."""
+    z = load("train_fwd.npz")
+    m = make_model(int(z["T"]))
+    m.remove_com, m.weighted_loss = remove_com, weighted
+    g = graph_from(batch_from(z), z["x0"], z["h0"]).to("cuda")
+    inj = dict(t_int=z["t_int"].long(), eps={'h': z["eps_h"], 'x': z["eps_x"]})
+    res = {}
+    for fused in (True, False):
+        m.fused_loss = fused
+        m.zero_grad(set_to_none=True)
+        losses, metrics = m.forward(g, 'train', **inj)
+        (losses['train pos loss'] * 0.75 + losses['train feat loss'] * 1.5).backward()
+        res[fused] = ({k: float(v.detach()) for k, v in {**losses, **metrics}.items()}, m.dynamics._last_flat_grad.clone())
+    for k, v in res[True][0].items():
+        assert abs(v - res[False][0][k]) <= 2e-5 * max(1.0, abs(v)), (k, v, res[False][0][k])
+    ga, gb = res[True][1], res[False][1]
+    assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
+
+
 def _golden_masks(z, cfg, Np, Nf):
     """[n_convs, 2, N, 144] multipliers in the engine's layout (global node ids: protein atoms first) from the
     GVPDropout draws the reference made (tests/golden/make_golden.py:golden_train_grads)."""
