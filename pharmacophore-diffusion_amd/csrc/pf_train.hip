@@ -120,13 +120,23 @@ __device__ __forceinline__ void mm16_acc(const int M, const int N, const int K, 
     }
 }
 
-// clear the tensors of class `cls` in this block's gradient copy (start of a kernel that accumulates per tile)
+// clear the tensors of class `cls` in this block's gradient copy (start of a kernel that accumulates per tile); the
+// class's ranges are collected by one pass of the block over the tensor table
 __device__ __forceinline__ void zero_class(const TrainCommon& c, float* gp, const int cls, const int tid) {
-    for (int t = 0; t < c.ntens; ++t) {
+    __shared__ int s_rng[2 * 96], s_nr;
+    if (tid == 0) s_nr = 0;
+    __syncthreads();
+    for (int t = tid; t < c.ntens; t += NT) {
         const TensorSeg s = c.tseg[t];
-        if (s.cls == cls)
-            for (int i = s.begin + tid; i < s.end; i += NT) gp[i] = 0.f;
+        if (s.cls == cls && s.end > s.begin) {
+            const int k = atomicAdd(&s_nr, 1);
+            if (k < 96) { s_rng[2 * k] = s.begin; s_rng[2 * k + 1] = s.end; }
+        }
     }
+    __syncthreads();
+    const int nr = min(s_nr, 96);
+    for (int k = 0; k < nr; ++k)
+        for (int i = s_rng[2 * k] + tid; i < s_rng[2 * k + 1]; i += NT) gp[i] = 0.f;
     __syncthreads();
 }
 // blocks [b0, b0 + nbk) of an edge-level launch of NB blocks serve etype `et`: in proportion to the non-empty tiles, at
@@ -703,6 +713,12 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
 #define E2_SS 176         // ... of scalar rows [si + h] (<= 161): whole 16-column tiles
 #define E2_WHS 36         // ... of the staged Wh [vi][h], zero padded to [32][36]
 #define E2_TILES 64       // tile descriptors staged per round
+// Every phase of a pass derives its lane coordinates from an OPAQUE copy of the thread id: otherwise the compiler hoists the
+// per-thread addresses of all ten phases out of the pass loop (~100 registers live across it, spilled in the prologue and
+// re-read from scratch at every use, and no room left for the rows fetched ahead)
+#define E2_PHASE() int zz_ = 0; asm volatile("" : "+v"(zz_)); const int tid = tid_ + zz_; const int lane = tid & 63; \
+    const int li = lane & 15, kq = lane >> 4; (void)li; (void)kq
+
 
 // the non-empty tiles of each etype's segment of a tile table, in table order: clist[et_tile0[et] - et_tile0[0] + i], ccnt[et]
 // (a dynamic region's tiles cover its capacity; a backward block that is dealt tiles by table index gets whatever share
@@ -766,9 +782,6 @@ __device__ __forceinline__ void mmcol(const int mts, FA a, FB b, FC c, const int
     }
 }
 
-struct E2Idx { int eA[2], eV, eG, sA[2], sV, sT, dA[2], dV, dT; };
-struct E2Rows { float4 z[2], x[2], u[2], vx, vu, xs, xd; float gt; int cA[2], cV, sT; };
-
 __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelParams p) {
     __shared__ __attribute__((aligned(16))) float Zb[ER * E2_ZS];
     __shared__ __attribute__((aligned(16))) float Sin[ER * E2_SS];
@@ -780,6 +793,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
     __shared__ int s_src[ER], s_e[ER], s_te0[E2_TILES], s_tnv[E2_TILES];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
+    const int tid_ = tid;
     // blocks per etype in proportion to its non-empty tiles (k_compact_tiles), at least one where there are tiles: every
     // block derives the same partition from the four counts
     int et = -1, nb = 0, my = 0, cnt_et = 0;
@@ -829,43 +843,40 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
     const int rG = tid >> 4, uG = tid & 15;          // gate rows
     const int cw = wv >> 1, rb = 16 * (wv & 1);      // waves 0..5: column tile (coordinate cw, rows rb .. rb + 15)
 
+    // fetched ahead, in plain registers (aggregates returned from a lambda end up in scratch memory, and every load is then
+    // waited for on the spot): indices of the tile after next (i*), rows of the next tile (r*)
+    int iA0 = 0, iA1 = 0, iV = 0, iG = 0, isA0 = 0, isA1 = 0, isV = 0, isT = 0, idA0 = 0, idA1 = 0, idV = 0, idT = 0;
+    float4 rz0 = {}, rz1 = {}, rx0 = {}, rx1 = {}, ru0 = {}, ru1 = {}, rvx = {}, rvu = {}, rxs = {}, rxd = {};
+    float rgt = 0.f;
+    int rcA0 = 1, rcA1 = 1, rcV = 1, rsT = 0;
+    // every load is unconditional (addresses are selected, not branched on) so that the fetches of a tile are issued back to
+    // back; lanes without a vector row (tid >= 384) fetch row 0 again
     auto load_idx = [&](const int e0, const int nv) {
-        E2Idx x = {};
-        if (nv <= 0) return x;                       // block-uniform
-        const int m = nv - 1;
-        x.eA[0] = e0 + min(rA, m); x.eA[1] = e0 + min(rA + 16, m); x.eV = e0 + min(rV, m); x.eG = e0 + min(rG, m);
+        const int m = max(nv, 1) - 1;
+        iA0 = e0 + min(rA, m); iA1 = e0 + min(rA + 16, m); iV = e0 + min(rV, m); iG = e0 + min(rG, m);
         const int eT = e0 + min(tid & 31, m);
-        if (firstl) {
-            x.sA[0] = p.esrc[x.eA[0]]; x.sA[1] = p.esrc[x.eA[1]];
-            if (!p.l0) x.sV = p.esrc[x.eV];
-            x.sT = p.esrc[eT]; x.dT = p.edst[eT];
-        }
-        if (lastl) { x.dA[0] = p.edst[x.eA[0]]; x.dA[1] = p.edst[x.eA[1]]; x.dV = p.edst[x.eV]; }
-        return x;
+        isA0 = p.esrc[iA0]; isA1 = p.esrc[iA1]; isV = p.esrc[iV]; isT = p.esrc[eT];
+        idA0 = p.edst[iA0]; idA1 = p.edst[iA1]; idV = p.edst[iV]; idT = p.edst[eT];
     };
-    auto load_rows = [&](const E2Idx& x, const int nv) {
-        E2Rows r = {};
-        if (nv <= 0) return r;                       // block-uniform
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            r.z[c] = reinterpret_cast<const float4*>(zl + (size_t)x.eA[c] * PF_S)[qA];
-            r.x[c] = firstl ? reinterpret_cast<const float4*>(p.h + (size_t)x.sA[c] * PF_S)[qA]
-                            : reinterpret_cast<const float4*>(zprev + (size_t)x.eA[c] * PF_S)[qA];
-            r.u[c] = lastl ? reinterpret_cast<const float4*>(p.gagg_s + (size_t)x.dA[c] * PF_S)[qA]
-                           : reinterpret_cast<const float4*>(p.gs_buf + (size_t)x.eA[c] * PF_S)[qA];
-            r.cA[c] = want_sc ? p.in_cnt[slot * p.N + x.dA[c]] : 1;
-        }
-        if (hasV) {
-            if (firstl) { if (!p.l0) r.vx = reinterpret_cast<const float4*>(p.v + (size_t)x.sV * 48)[qV]; }
-            else r.vx = reinterpret_cast<const float4*>(vprev + (size_t)x.eV * 48)[qV];
-            r.vu = lastl ? reinterpret_cast<const float4*>(p.gagg_v + (size_t)x.dV * 48)[qV]
-                         : reinterpret_cast<const float4*>(p.gv_buf + (size_t)x.eV * 48)[qV];
-            r.cV = want_sc ? p.in_cnt[slot * p.N + x.dV] : 1;
-        }
-        r.gt = gl[(size_t)x.eG * 16 + uG];
-        r.sT = x.sT;
-        if (firstl && tid < ER) { r.xs = p.xn[x.sT]; r.xd = p.xn[x.dT]; }
-        return r;
+    auto load_rows = [&]() {
+        const float* xb = firstl ? p.h : zprev;
+        const float* ub = lastl ? p.gagg_s : p.gs_buf;
+        rz0 = reinterpret_cast<const float4*>(zl + (size_t)iA0 * PF_S)[qA];
+        rz1 = reinterpret_cast<const float4*>(zl + (size_t)iA1 * PF_S)[qA];
+        rx0 = reinterpret_cast<const float4*>(xb + (size_t)(firstl ? isA0 : iA0) * PF_S)[qA];
+        rx1 = reinterpret_cast<const float4*>(xb + (size_t)(firstl ? isA1 : iA1) * PF_S)[qA];
+        ru0 = reinterpret_cast<const float4*>(ub + (size_t)(lastl ? idA0 : iA0) * PF_S)[qA];
+        ru1 = reinterpret_cast<const float4*>(ub + (size_t)(lastl ? idA1 : iA1) * PF_S)[qA];
+        rcA0 = p.in_cnt[want_sc ? slot * p.N + idA0 : 0];
+        rcA1 = p.in_cnt[want_sc ? slot * p.N + idA1 : 0];
+        const float* vb = firstl ? p.v : vprev;            // (conv layer 0 at level 0: the rows are fetched and not used)
+        const float* gb = lastl ? p.gagg_v : p.gv_buf;
+        rvx = reinterpret_cast<const float4*>(vb + (size_t)(firstl ? isV : iV) * 48)[qV];
+        rvu = reinterpret_cast<const float4*>(gb + (size_t)(lastl ? idV : iV) * 48)[qV];
+        rcV = p.in_cnt[want_sc ? slot * p.N + idV : 0];
+        rgt = gl[(size_t)iG * 16 + uG];
+        rsT = isT;
+        rxs = p.xn[isT]; rxd = p.xn[idT];
     };
 
     const int npass = my < cnt_et ? (cnt_et - my + nb - 1) / nb : 0;
@@ -882,40 +893,47 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
         }
         __syncthreads();
         const int cn = min(E2_TILES, npass - base);
-        E2Idx ix = load_idx(s_te0[0], s_tnv[0]);
-        E2Rows rw = load_rows(ix, s_tnv[0]);
-        ix = cn > 1 ? load_idx(s_te0[1], s_tnv[1]) : E2Idx{};
+        load_idx(s_te0[0], s_tnv[0]);
+        load_rows();
+        if (cn > 1) load_idx(s_te0[1], s_tnv[1]);
         for (int j = 0; j < cn; ++j) {
             const int nv = __builtin_amdgcn_readfirstlane(s_tnv[j]);
             const int e0 = __builtin_amdgcn_readfirstlane(s_te0[j]);
             if (nv > 0) {
                 PFT_STAMP(30);
                 // ---- this tile's rows: registers -> LDS
+                {
+                E2_PHASE();
+                const int rA = tid >> 5, qA = tid & 31;
+                const bool hasV = tid < ER * 12;
+                const int rV = hasV ? tid / 12 : 0, qV = hasV ? tid - rV * 12 : 0;
+                const int rG = tid >> 4, uG = tid & 15;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int row = rA + 16 * c;
-                    *reinterpret_cast<float4*>(Zb + row * E2_ZS + 4 * qA) = rw.z[c];
-                    float4 x = rw.x[c];
+                    *reinterpret_cast<float4*>(Zb + row * E2_ZS + 4 * qA) = c ? rz1 : rz0;
+                    float4 x = c ? rx1 : rx0;
                     if (!firstl) { x.x = t_silu(x.x); x.y = t_silu(x.y); x.z = t_silu(x.z); x.w = t_silu(x.w); }
                     *reinterpret_cast<float4*>(Sin + row * E2_SS + 4 * qA) = x;
-                    const float sc = row < nv ? (want_sc ? 1.0f / (float)rw.cA[c] : 1.0f) : 0.f;
-                    float4 u = rw.u[c];
+                    const float sc = row < nv ? (want_sc ? 1.0f / (float)(c ? rcA1 : rcA0) : 1.0f) : 0.f;
+                    float4 u = c ? ru1 : ru0;
                     u.x *= sc; u.y *= sc; u.z *= sc; u.w *= sc;
                     *reinterpret_cast<float4*>(gA + row * E2_SS + 4 * qA) = u;
                 }
                 if (hasV) {
                     float* d = Vin + rV * VWS + (firstl ? 3 : 0) + 4 * qV;
-                    d[0] = rw.vx.x; d[1] = rw.vx.y; d[2] = rw.vx.z; d[3] = rw.vx.w;
-                    const float sc = rV < nv ? (want_sc ? 1.0f / (float)rw.cV : 1.0f) : 0.f;
+                    const float vk = (firstl && p.l0) ? 0.f : 1.0f;            // conv layer 0 has no vector input
+                    d[0] = rvx.x * vk; d[1] = rvx.y * vk; d[2] = rvx.z * vk; d[3] = rvx.w * vk;
+                    const float sc = rV < nv ? (want_sc ? 1.0f / (float)rcV : 1.0f) : 0.f;
                     float* go = gVo + rV * VWS + 4 * qV;
-                    go[0] = rw.vu.x * sc; go[1] = rw.vu.y * sc; go[2] = rw.vu.z * sc; go[3] = rw.vu.w * sc;
+                    go[0] = rvu.x * sc; go[1] = rvu.y * sc; go[2] = rvu.z * sc; go[3] = rvu.w * sc;
                 }
-                gate[rG * GTS + uG] = rw.gt;
+                gate[rG * GTS + uG] = rgt;
                 if (tid < ER) {
                     s_e[tid] = e0 + min(tid, nv - 1);
-                    s_src[tid] = rw.sT;
+                    s_src[tid] = rsT;
                     if (firstl) {
-                        const float dx = rw.xs.x - rw.xd.x, dy = rw.xs.y - rw.xd.y, dz = rw.xs.z - rw.xd.z;
+                        const float dx = rxs.x - rxd.x, dy = rxs.y - rxd.y, dz = rxs.z - rxd.z;
                         const float d = t_sqrt(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
                         const float rd = __builtin_amdgcn_rcpf(d);
                         Vin[tid * VWS + 0] = dx * rd; Vin[tid * VWS + 1] = dy * rd; Vin[tid * VWS + 2] = dz * rd;
@@ -925,29 +943,43 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                         }
                     }
                 }
+                }
                 __syncthreads();
                 PFT_STAMP(31);
-                // ---- Vh = Wh^T V (columns: coordinate cw of rows rb .. rb + 15)
-                if (wv < 6)
-                    mmcol<5>(mth,
-                        [&](int i, int k) { return sWh[k * E2_WHS + i]; },
-                        [&](int k) { return k < VI ? Vin[(rb + li) * VWS + k * 3 + cw] : 0.f; },
-                        [&](int i, float x) { if (i < KH) Vh[(rb + li) * VWS + i * 3 + cw] = x; }, lane);
+                // ---- Vh = Wh^T V, then Vu = Wu^T Vh on the SAME column tile (coordinate cw of rows rb .. rb + 15): the D
+                // fragment of the first product (lane (col, kq): rows 16 mt + 4 kq + r) is the B operand of the second for
+                // the k-steps "k = 16 mt + 4 kq + r" -- no LDS round trip, no barrier in between
+                if (wv < 6) {
+                    E2_PHASE();
+                    float bv[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) { const int k = 4 * u + kq; bv[u] = k < VI ? Vin[(rb + li) * VWS + k * 3 + cw] : 0.f; }
+                    f32x4 au = {0.f, 0.f, 0.f, 0.f};
+                    for (int mt = 0; mt < mth; ++mt) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int u = 0; u < 5; ++u)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sWh[(4 * u + kq) * E2_WHS + mt * 16 + li], bv[u], acc, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = mt * 16 + kq * 4 + r;                 // hidden channel of acc[r]; rows >= KH are zero (sWh padding)
+                            if (i < KH) Vh[(rb + li) * VWS + i * 3 + cw] = acc[r];
+                            au = __builtin_amdgcn_mfma_f32_16x16x4f32(sWu[i * 16 + li], acc[r], au, 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Vu[(rb + li) * VWS + (kq * 4 + r) * 3 + cw] = au[r];
+                }
                 __syncthreads();
-                // ---- sh = |Vh|, Vu = Wu^T Vh
-                for (int idx = tid; idx < ER * KH; idx += NT) {
+                PFT_STAMP(32);
+                // ---- gate: V' = sigmoid(gate) Vu
+                {
+                E2_PHASE();
+                for (int idx = tid; idx < ER * KH; idx += NT) {                     // sh = |Vh|
                     const int row = idx & 31, hh = idx >> 5;
                     const float* q = Vh + row * VWS + hh * 3;
                     Sin[row * E2_SS + SI + hh] = t_sqrt(fmaxf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2], 1e-8f));
                 }
-                if (wv < 6)
-                    mmcol<5>(1,
-                        [&](int i, int k) { return sWu[k * 16 + i]; },
-                        [&](int k) { return k < KH ? Vh[(rb + li) * VWS + k * 3 + cw] : 0.f; },
-                        [&](int i, float x) { Vu[(rb + li) * VWS + i * 3 + cw] = x; }, lane);
-                __syncthreads();
-                PFT_STAMP(32);
-                // ---- gate: V' = sigmoid(gate) Vu
                 for (int idx = tid; idx < ER * VO; idx += NT) {
                     const int row = idx & 31, u = idx >> 5;
                     const float gt = gate[row * GTS + u];
@@ -958,9 +990,11 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                     ggate[row * GTS + u] = dot * f * (1.0f - f);
                     go[0] *= f; go[1] *= f; go[2] *= f;
                 }
+                }
                 __syncthreads();
                 PFT_STAMP(33);
                 {   // ---- gZ = (gA + ggate Wg) SiLU'(Z) for features 16 wv .. +15 of all rows, on the accumulator fragments
+                    E2_PHASE();
                     float aw[4];
 #pragma unroll
                     for (int s = 0; s < 4; ++s) aw[s] = sWg[(4 * s + kq) * 128 + wv * 16 + li];
@@ -992,32 +1026,55 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                 }
                 __syncthreads();
                 PFT_STAMP(35);
-                {   // ---- gS = gZ Wm: gZ fragments of both row tiles in registers, packed weight fragments streamed
-                    f32x4 bf[2][8];
+                {   // ---- gS = gZ Wm: a wave owns m tiles wv and wv + 8; their packed weight fragments (16 x 1 KiB) are all
+                    // requested before the first product, the gZ fragments come from LDS as they are used
+                    E2_PHASE();
+                    const bool two = wv + NT / 64 < nts;               // wave-uniform
+                    const f32x4* wp0 = Wp + (size_t)wv * (8 * 64) + lane;
+                    const f32x4* wp1 = Wp + (size_t)(two ? wv + NT / 64 : wv) * (8 * 64) + lane;
+                    f32x4 aq0[8], aq1[8];
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
+                    for (int sb = 0; sb < 8; ++sb) aq0[sb] = wp0[sb * 64];
+                    if (two) {
 #pragma unroll
-                        for (int sb = 0; sb < 8; ++sb)
-                            bf[n][sb] = *reinterpret_cast<const f32x4*>(gA + (16 * n + li) * E2_SS + 16 * sb + 4 * kq);
-                    for (int mt = wv; mt < nts; mt += NT / 64) {
-                        const f32x4* wp = Wp + (size_t)mt * (8 * 64) + lane;
-                        f32x4 aq[8];
-#pragma unroll
-                        for (int sb = 0; sb < 8; ++sb) aq[sb] = wp[sb * 64];
+                        for (int sb = 0; sb < 8; ++sb) aq1[sb] = wp1[sb * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float* b0p = gA + li * E2_SS + 4 * kq;
+                    const float* b1p = gA + (16 + li) * E2_SS + 4 * kq;
+                    if (wv < nts) {
                         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int sb = 0; sb < 8; ++sb)
+                        for (int sb = 0; sb < 8; ++sb) {
+                            const f32x4 b0 = *reinterpret_cast<const f32x4*>(b0p + 16 * sb), b1 = *reinterpret_cast<const f32x4*>(b1p + 16 * sb);
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[sb][t], bf[0][sb][t], acc0, 0, 0, 0);
-                                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[sb][t], bf[1][sb][t], acc1, 0, 0, 0);
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq0[sb][t], b0[t], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq0[sb][t], b1[t], acc1, 0, 0, 0);
                             }
+                        }
+                        *reinterpret_cast<f32x4*>(gS + li * E2_SS + 16 * wv + 4 * kq) = acc0;
+                        *reinterpret_cast<f32x4*>(gS + (16 + li) * E2_SS + 16 * wv + 4 * kq) = acc1;
+                    }
+                    if (two) {
+                        const int mt = wv + NT / 64;
+                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int sb = 0; sb < 8; ++sb) {
+                            const f32x4 b0 = *reinterpret_cast<const f32x4*>(b0p + 16 * sb), b1 = *reinterpret_cast<const f32x4*>(b1p + 16 * sb);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq1[sb][t], b0[t], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq1[sb][t], b1[t], acc1, 0, 0, 0);
+                            }
+                        }
                         *reinterpret_cast<f32x4*>(gS + li * E2_SS + 16 * mt + 4 * kq) = acc0;
                         *reinterpret_cast<f32x4*>(gS + (16 + li) * E2_SS + 16 * mt + 4 * kq) = acc1;
                     }
                 }
                 PFT_STAMP(39);
                 {   // dWm tiles (features 16 wv .., inputs 16 x ..) += gZ^T [s, sh]
+                    E2_PHASE();
                     float av[ER / 4];
 #pragma unroll
                     for (int u = 0; u < ER / 4; ++u) av[u] = gA[(4 * u + kq) * E2_SS + wv * 16 + li];
@@ -1035,26 +1092,56 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
             }
             // ---- fetch ahead: the rows of the next tile (their indices arrived during the previous pass), the indices of the
             // tile after it.  Nothing below this point waits for a global load.
-            if (j + 1 < cn) rw = load_rows(ix, s_tnv[j + 1]);
-            if (j + 2 < cn) ix = load_idx(s_te0[j + 2], s_tnv[j + 2]);
+            __builtin_amdgcn_sched_barrier(0);       // the fetches stay behind the products above (hoisted into them they spill)
+            if (j + 1 < cn) load_rows();
+            if (j + 2 < cn) load_idx(s_te0[j + 2], s_tnv[j + 2]);
             if (nv > 0) {
                 __syncthreads();
                 PFT_STAMP(36);
-                // ---- gVh = Wu gVu + (gradient through sh); dWu on waves 6, 7
-                if (wv < 6)
-                    mmcol<4>(mth,
-                        [&](int i, int k) { return sWu[i * 16 + k]; },
-                        [&](int k) { return gVo[(rb + li) * VWS + k * 3 + cw]; },
-                        [&](int i, float x) {
+                // ---- gVh = Wu gVu + (gradient through sh), then gVi = Wh gVh on the same column tile through the registers
+                // (as Vh -> Vu above); dWu on waves 6, 7
+                if (wv < 6) {
+                    E2_PHASE();
+                    const bool want_vi = !(firstl && p.l0);          // conv layer 0 has no vector input: nobody reads gVi there
+                    float bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bv[u] = gVo[(rb + li) * VWS + (4 * u + kq) * 3 + cw];
+                    f32x4 ai[2];
+                    ai[0] = ai[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int row = rb + li;
+                    for (int mt = 0; mt < mth; ++mt) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sWu[(mt * 16 + li) * 16 + 4 * u + kq], bv[u], acc, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = mt * 16 + kq * 4 + r;                 // hidden channel of acc[r]
+                            float gv = 0.f;
                             if (i < KH) {
-                                const int row = rb + li;
                                 const float* q = Vh + row * VWS + i * 3;
                                 const float ss = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
                                 const float extra = ss > 1e-8f ? gS[row * E2_SS + SI + i] * q[cw] / Sin[row * E2_SS + SI + i] : 0.f;
-                                gVh[row * VWS + i * 3 + cw] = x + extra;
+                                gv = acc[r] + extra;
+                                gVh[row * VWS + i * 3 + cw] = gv;
                             }
-                        }, lane);
-                else if (16 * (wv - 6) < KH) {       // dWu tile (hidden channels 16 (wv - 6) .., 16 outputs) += sum over rows and coordinates of Vh gVu
+                            if (want_vi) {
+#pragma unroll
+                                for (int m2 = 0; m2 < 2; ++m2)
+                                    if (m2 < mti) ai[m2] = __builtin_amdgcn_mfma_f32_16x16x4f32(sWh[(m2 * 16 + li) * E2_WHS + i], gv, ai[m2], 0, 0, 0);
+                            }
+                        }
+                    }
+                    if (want_vi)
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int vi = m2 * 16 + kq * 4 + r;
+                                if (vi < VI) gVi[row * VWS + vi * 3 + cw] = ai[m2][r];
+                            }
+                } else if (16 * (wv - 6) < KH) {     // dWu tile (hidden channels 16 (wv - 6) .., 16 outputs) += sum over rows and coordinates of Vh gVu
+                    E2_PHASE();
                     const int hh = min((wv - 6) * 16 + li, KH - 1);
 #pragma unroll
                     for (int u = 0; u < 3 * ER / 4; ++u) {
@@ -1064,15 +1151,10 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                     }
                 }
                 __syncthreads();
-                PFT_STAMP(37);
-                // ---- gVi = Wh gVh; dWh on waves 6, 7
-                if (wv < 6) {
-                    if (!(firstl && p.l0))           // conv layer 0 has no vector input: nobody reads gVi there
-                        mmcol<5>(mti,
-                            [&](int i, int k) { return sWh[i * E2_WHS + k]; },
-                            [&](int k) { return k < KH ? gVh[(rb + li) * VWS + k * 3 + cw] : 0.f; },
-                            [&](int i, float x) { if (i < VI) gVi[(rb + li) * VWS + i * 3 + cw] = x; }, lane);
-                } else if (16 * (wv - 6) < VI) {     // dWh tiles (input channels 16 (wv - 6) .., hidden channels 16 tb ..) += V gVh
+                PFT_STAMP(38);
+                // ---- dWh on waves 6, 7 (input channels 16 (wv - 6) .., hidden channels 16 tb ..) += V gVh, ahead of their share of the write-out
+                if (wv >= 6 && 16 * (wv - 6) < VI) {
+                    E2_PHASE();
                     const int vi = min((wv - 6) * 16 + li, VI - 1);
 #pragma unroll
                     for (int tb = 0; tb < 2; ++tb)
@@ -1086,9 +1168,9 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                             }
                         }
                 }
-                __syncthreads();
-                PFT_STAMP(38);
                 // ---- hand the input gradients down: to the level below, or (level 0) to the source nodes
+                {
+                E2_PHASE();
                 if (!firstl) {
                     for (int idx = tid; idx < ER * 32; idx += NT) {
                         const int row = idx >> 5, q = idx & 31;
@@ -1110,6 +1192,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                             if (row < nv) atomicAdd(reinterpret_cast<unsigned long long*>(p.A_v + (size_t)s_src[row] * 48 + q),
                                                     (unsigned long long)__float2ll_rn(gVi[row * VWS + 3 + q] * fix_scale));
                         }
+                }
                 }
                 __syncthreads();
             }
