@@ -350,7 +350,7 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
     opt = pfa.FlatAdam(m.dynamics, lr=1e-4, weight_decay=1e-12)
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad()
         g = graphs[it[0] % len(graphs)]
         it[0] += 1
         loss = m.training_step(g, 0)

@@ -372,11 +372,20 @@ class FlatAdam:
         self.exp_avg = self.exp_avg_sq = None
         self.param_groups = [{'lr': lr}]            # what LR schedulers / loggers look at
 
-    def zero_grad(self, set_to_none: bool = True):
+    def zero_grad(self, set_to_none: bool = False):
+        """Default (``set_to_none=False``): the flat gradient is zeroed IN PLACE -- one small kernel; the 244 parameters'
+        ``.grad`` stay the views of it that the last backward bound, the next backward accumulates into it.  Clearing and
+        re-creating 244 views per step costs ~0.8 ms of host time, which is what bounds a step that binds a new batch.
+        ``set_to_none=True`` drops everything, like torch.optim's default."""
         views = self.dyn._flat_views
+        leaf = self.dyn.__dict__.get("_flat_leaf")
+        if not set_to_none and leaf is not None and leaf.grad is not None and views:
+            p0, o0 = next(((p, o) for p, o, _ in views if p.requires_grad), (None, 0))
+            if p0 is not None and p0.grad is not None and p0.grad.data_ptr() == leaf.grad.data_ptr() + 4 * o0:
+                leaf.grad.zero_()
+                return
         for p in ([p for p, _, _ in views] if views else self.dyn.parameters()):
             p.grad = None
-        leaf = self.dyn.__dict__.get("_flat_leaf")
         if leaf is not None:
             leaf.grad = None
         self.dyn._last_flat_grad = None
