@@ -723,10 +723,11 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
 // the non-empty tiles of each etype's segment of a tile table, in table order: clist[et_tile0[et] - et_tile0[0] + i], ccnt[et]
 // (a dynamic region's tiles cover its capacity; a backward block that is dealt tiles by table index gets whatever share
 // of the empty ones the layout gives it -- the ff blocks of config 5 walked four times the tiles of the pp blocks)
-__global__ __launch_bounds__(256) void k_compact_tiles(const EdgeTile* tiles, const int t0, const int t1, const int seg0,
-                                                       const int* dyn_cnt, int* clist, int* ccnt) {
+struct CompactParams { int et_tile0[5]; };
+__global__ __launch_bounds__(256) void k_compact_tiles(const EdgeTile* tiles, const CompactParams cp, const int* dyn_cnt, int* clist, int* ccnt) {
     __shared__ int s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t0 = cp.et_tile0[blockIdx.x], t1 = cp.et_tile0[blockIdx.x + 1], seg0 = t0 - cp.et_tile0[0];     // one block per etype
     int base = 0;
     for (int c = t0; c < t1; c += 256) {
         const int ti = c + tid;
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(256) void k_compact_tiles(const EdgeTile* tiles, co
         base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         __syncthreads();
     }
-    if (tid == 0) *ccnt = base;
+    if (tid == 0) ccnt[blockIdx.x] = base;
 }
 
 // packed to_feats_out of every message GVP for the input-gradient product: [gvp][m tile (11)][k block (8)][lane] x 4:
@@ -1536,9 +1537,9 @@ void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, int nblocks, hipStream_t s)
     hipLaunchKernelGGL(k_bwd_edge_level, dim3(nblocks), dim3(NT), 0, s, *p);
 }
 void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s) {
-    for (int et = 0; et < n_et; ++et)
-        hipLaunchKernelGGL(k_compact_tiles, dim3(1), dim3(256), 0, s, tiles, et_tile0[et], et_tile0[et + 1], et_tile0[et] - et_tile0[0],
-                           dyn_cnt, clist, ccnt + et);
+    CompactParams cp;
+    for (int et = 0; et <= 4; ++et) cp.et_tile0[et] = et_tile0[et];
+    hipLaunchKernelGGL(k_compact_tiles, dim3(n_et), dim3(256), 0, s, tiles, cp, dyn_cnt, clist, ccnt);
 }
 void pfk_loss_prepare(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_prepare, dim3(p->B), dim3(256), 0, s, *p); }
 void pfk_loss_eval(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_eval, dim3(1), dim3(1024), 0, s, *p); }
