@@ -53,7 +53,7 @@ void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* 
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
 void pfk_train_reduce(const ReduceParams* p, hipStream_t s);
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s);
-void pfk_pack_bwd(const float* W, const GvpT* g, int n_gvps, float* out, hipStream_t s);
+void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float* out_f, hipStream_t s);
 void pfk_loss_prepare(const LossParams* p, hipStream_t s);
 void pfk_loss_eval(const LossParams* p, hipStream_t s);
 void pfk_scale_by(float* g, int n, const float* scale, hipStream_t s);
@@ -255,6 +255,7 @@ struct pf_handle {
           *t_gpart = nullptr, *t_geps_h = nullptr, *t_geps_x = nullptr;
     long long *t_A_h = nullptr, *t_A_v = nullptr;      // fixed-point accumulators of the level-0 scatter (kept clear between uses)
     TensorSeg* d_tseg = nullptr; int n_tseg = 0;   // class of every parameter tensor (pf_train.h: which gradient copies hold it)
+    int n_gvpt = 0;                         // entries of d_gvpt (message, update, head GVPs)
     float* d_wpack = nullptr;               // k_pack_bwd fragments of every message GVP; valid for w_version == wpack_version
     uint64_t wpack_version = ~0ull;
     float *t_lx0c = nullptr, *t_lag = nullptr, *t_lsg = nullptr, *t_lgx = nullptr, *t_lgh = nullptr, *t_lout = nullptr;   // pf_train_loss_forward
@@ -1229,15 +1230,16 @@ int pf_commit_weights(pf_handle* h) {
             PF_HIP(h, hipMalloc((void**)&h->d_tseg, std::max<size_t>(segs.size(), 1) * sizeof(TensorSeg)));
             PF_HIP(h, hipMemcpy(h->d_tseg, segs.data(), segs.size() * sizeof(TensorSeg), hipMemcpyHostToDevice));
         }
+        std::vector<GvpT> tab;
         auto mk = [&](const GvpSpec& g, bool sig) {
             GvpT t;
             t.o_Wh = (int)h->flat_offset(g.prefix + "Wh"); t.o_Wu = (int)h->flat_offset(g.prefix + "Wu");
             t.o_Wm = (int)h->flat_offset(g.prefix + "to_feats_out.0.weight"); t.o_bm = (int)h->flat_offset(g.prefix + "to_feats_out.0.bias");
             t.o_Wg = (int)h->flat_offset(g.prefix + "scalar_to_vector_gates.weight"); t.o_bg = (int)h->flat_offset(g.prefix + "scalar_to_vector_gates.bias");
             t.vi = g.vi; t.vo = g.vo; t.h = std::max(g.vi, g.vo); t.si = g.si; t.so = g.so; t.sig = sig ? 1 : 0;
+            t.pk = (int)tab.size();
             return t;
         };
-        std::vector<GvpT> tab;
         for (int l = 0; l < c.n_convs; ++l)
             for (int et = 0; et < 4; ++et)
                 for (int j = 0; j < c.n_message_gvps; ++j) tab.push_back(mk(msg_spec(c, l, et, j), true));
@@ -1251,6 +1253,7 @@ int pf_commit_weights(pf_handle* h) {
         h->wpack_version = ~0ull;
         PF_HIP(h, hipMalloc((void**)&h->d_flat, std::max<size_t>(flat.size(), 1) * sizeof(float)));
         PF_HIP(h, hipMemcpy(h->d_flat, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice));
+        h->n_gvpt = (int)tab.size();
         PF_HIP(h, hipMalloc((void**)&h->d_gvpt, tab.size() * sizeof(GvpT)));
         PF_HIP(h, hipMemcpy(h->d_gvpt, tab.data(), tab.size() * sizeof(GvpT), hipMemcpyHostToDevice));
     }
@@ -2118,12 +2121,14 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     hipStream_t s = (hipStream_t)stream;
     const pf_config& c = h->cfg;
     const int L = c.n_convs, N = h->N, nb = h->t_nblk;
-    const TrainCommon tc = h->t_common;
     if (h->wpack_version != h->w_version) {         // packed to_feats_out fragments of the message GVPs for k_bwd_edge_level
-        if (!h->d_wpack) PF_HIP(h, hipMalloc((void**)&h->d_wpack, (size_t)std::max(h->n_msg_tot, 1) * PFT_WPACK_FLOATS * sizeof(float)));
-        pfk_pack_bwd(h->d_flat, h->d_gvpt, h->n_msg_tot, h->d_wpack, s);
+        const int ng = h->n_gvpt;
+        if (!h->d_wpack) PF_HIP(h, hipMalloc((void**)&h->d_wpack, (size_t)2 * std::max(ng, 1) * PFT_WPACK_FLOATS * sizeof(float)));
+        pfk_pack_gvp(h->d_flat, h->d_gvpt, ng, h->d_wpack, h->d_wpack + (size_t)ng * PFT_WPACK_FLOATS, s);
         h->wpack_version = h->w_version;
     }
+    h->t_common.wpack_b = h->d_wpack; h->t_common.wpack_f = h->d_wpack + (size_t)h->n_gvpt * PFT_WPACK_FLOATS;
+    const TrainCommon tc = h->t_common;
     ReduceParams rp{};
     rp.gpart = h->t_gpart; rp.nparams = (int)h->nparams; rp.grad = dev_grad; rp.tseg = h->d_tseg; rp.ntens = h->n_tseg;
     rp.NB = nb; rp.ccnt = h->t_ccnt;

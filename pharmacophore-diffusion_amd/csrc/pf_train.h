@@ -26,6 +26,7 @@ struct GvpT {
     int o_Wh, o_Wu, o_Wm, o_bm, o_Wg, o_bg;   // offsets of Wh [vi][h], Wu [h][vo], to_feats_out.0.{weight [so][si+h], bias},
                                               // scalar_to_vector_gates.{weight [vo][so], bias}
     int vi, h, vo, si, so, sig;               // sig: vector activation is a sigmoid (0: identity, last head GVP)
+    int pk;                                   // index of this GVP in the packed fragment tables (k_pack_gvp)
 };
 
 // Which blocks' gradient copies hold a tensor's gradient is a function of the kernel that differentiates it (its "class"):
@@ -52,6 +53,7 @@ struct TrainCommon {
     float* gpart;            // [gridDim.x][nparams]
     int nparams;
     const TensorSeg* tseg; int ntens;
+    const float* wpack_b; const float* wpack_f;   // k_pack_gvp tables (PFT_WPACK_FLOATS per GVP each)
     uint32_t drop_thr;       // an element is dropped iff pf_drop_hash(...) < drop_thr  (= p * 2^32; 0: no dropout)
     float drop_scale;        // 1 / (1 - p)
     uint32_t seed;           // dropout stream of this step

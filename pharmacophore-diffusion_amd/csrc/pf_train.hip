@@ -72,7 +72,7 @@ __device__ __forceinline__ void mm16(const int M, const int N, const int K, FA a
 // values fetched before the MFMAs so that the read-modify-write latency overlaps the products
 template <int UNR, typename FA, typename FB>
 __device__ __forceinline__ void mm16_acc(const int M, const int N, const int K, FA a, FB b, float* G, const int ld,
-                                         const int lane, const int wv) {
+                                         const int lane, const int wv, const bool fresh = false) {
     const int mts = (M + 15) >> 4, nts = (N + 15) >> 4;
     const int li = lane & 15, kq = lane >> 4;
     const int ntile = mts * nts;
@@ -90,7 +90,7 @@ __device__ __forceinline__ void mm16_acc(const int M, const int N, const int K, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = mt * 16 + kq * 4 + r;
-                old[x][r] = (live[x] && ci < M && bjv[x] < N) ? G[ci * ld + bjv[x]] : 0.f;
+                old[x][r] = (!fresh && live[x] && ci < M && bjv[x] < N) ? G[ci * ld + bjv[x]] : 0.f;      // fresh: known zeros (zero_class)
             }
             acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -154,6 +154,29 @@ __device__ __forceinline__ void et_blocks(const int* ccnt, const int n_et, const
     }
 }
 
+// C[i][j] (i < 16 mts, j < 16 rows) = sum_k A[i][k] B[k][j] with A from a packed fragment table ([m tile][NSB k blocks][lane] x 4:
+// lane (li, kq) holds A[16 mt + li][16 sb + 4 kq + t], t = 0..3; k_pack_gvp) -- one 1-KiB load per four MFMAs instead of
+// four strided dword loads -- and B[k][j] = b(k, j) from LDS.  Wave wv takes m tiles wv, wv + 8, ...
+template <int NSB, typename FB, typename FC>
+__device__ __forceinline__ void mm16_packed(const f32x4* P, const int mts, const int nsb, FB b, FC c, const int lane, const int wv) {
+    const int li = lane & 15, kq = lane >> 4;
+    for (int mt = wv; mt < mts; mt += NT / 64) {
+        const f32x4* pp = P + (size_t)mt * (NSB * 64) + lane;
+        f32x4 aq[NSB];
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) aq[sb] = sb < nsb ? pp[sb * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb)
+            if (sb < nsb) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[sb][t], b(16 * sb + 4 * kq + t, li), acc, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c(mt * 16 + kq * 4 + r, li, acc[r]);
+    }
+}
+
 // diagnostic builds (-DPFT_STAMPS): cycle stamps of block 0's first sub-tile at phase boundaries
 #ifdef PFT_STAMPS
 #ifndef PFT_STAMP_BLOCK
@@ -209,20 +232,22 @@ __device__ __forceinline__ void gvp_vec(const GvpT& g, const float* W, float* Si
 
 // forward of one GVP on the tile: reads Sin[:, :si], Vin; fills Sin[:, si:], Z, gate, act (= SiLU(Z)) and, when
 // Vout != nullptr, the gated vectors (gvp.py:89-116)
-__device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, float* Sin, const float* Vin, float* Z, float* gate,
+struct PackPtr { const float* f; const float* b; };     // k_pack_gvp tables of every GVP: forward and input-gradient fragments of to_feats_out
+__device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, const PackPtr pk, float* Sin, const float* Vin, float* Z, float* gate,
                                         float* act, const int act_stride, float* Vout, float* Vh, float* Vu,
                                         const int tid, const int lane, const int wv) {
     const int VO = g.vo, SO = g.so, KM = g.si + g.h;
     PFT_STAMP(1);
     gvp_vec(g, W, Sin, Vin, Vh, Vu, true, tid, lane, wv);
     PFT_STAMP(2);
-    mm16<14>(SO, TR, KM,
-         [&](int i, int k) { return W[g.o_Wm + i * KM + k]; },
-         [&](int k, int j) { return Sin[j * SWS + k]; },
+    mm16_packed<11>(reinterpret_cast<const f32x4*>(pk.f) + (size_t)g.pk * (8 * 11 * 64), (SO + 15) >> 4, (KM + 15) >> 4,
+         [&](int k, int j) { return k < KM ? Sin[j * SWS + k] : 0.f; },
          [&](int i, int j, float x) {
-             const float z = x + W[g.o_bm + i];
-             Z[j * ZS + i] = z;
-             act[j * act_stride + i] = t_silu(z);
+             if (i < SO) {
+                 const float z = x + W[g.o_bm + i];
+                 Z[j * ZS + i] = z;
+                 act[j * act_stride + i] = t_silu(z);
+             }
          }, lane, wv);
     __syncthreads();
     PFT_STAMP(3);
@@ -247,7 +272,7 @@ __device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, float* Si
 // backward of one GVP on the tile.  In: gA = dL/d act [row][so] (stride SWS), gVo = dL/d Vout [row][vo*3].
 // Out: gS = dL/d Sin[:, :si+h] (the first si entries are the input-scalar gradient), gVi = dL/d Vin.  gA and gVo are
 // overwritten (they become dL/dZ and dL/dVu).  Weight gradients are accumulated into gp (this block's copy).
-__device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, float* gp, const float* Sin, const float* Vin,
+__device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const PackPtr pk, const bool fresh, float* gp, const float* Sin, const float* Vin,
                                         const float* Z, const float* gate, const float* act, const int act_stride,
                                         float* gA, float* gS, float* gVo, float* gVi, float* Vh, float* Vu, float* gVh,
                                         float* ggate, const int tid, const int lane, const int wv) {
@@ -275,7 +300,7 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, float* gp
          [&](int i, int j, float x) { gA[j * SWS + i] += x; }, lane, wv);
     mm16_acc<4>(VO, SO, TR,
          [&](int i, int k) { return ggate[k * GTS + i]; },
-         [&](int k, int j) { return act[k * act_stride + j]; }, gp + g.o_Wg, SO, lane, wv);
+         [&](int k, int j) { return act[k * act_stride + j]; }, gp + g.o_Wg, SO, lane, wv, fresh);
     if (tid < VO) {
         float s = 0.f;
         for (int r = 0; r < TR; ++r) s += ggate[r * GTS + tid];
@@ -291,14 +316,13 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, float* gp
     }
     __syncthreads();
     PFT_STAMP(14);
-    mm16<16>(KM, TR, SO,
-         [&](int i, int k) { return W[g.o_Wm + k * KM + i]; },
+    mm16_packed<8>(reinterpret_cast<const f32x4*>(pk.b) + (size_t)g.pk * (11 * 8 * 64), (KM + 15) >> 4, (SO + 15) >> 4,
          [&](int k, int j) { return gA[j * SWS + k]; },
-         [&](int i, int j, float x) { gS[j * SWS + i] = x; }, lane, wv);
+         [&](int i, int j, float x) { if (i < KM) gS[j * SWS + i] = x; }, lane, wv);
     PFT_STAMP(15);
     mm16_acc<4>(SO, KM, TR,
          [&](int i, int k) { return gA[k * SWS + i]; },
-         [&](int k, int j) { return Sin[k * SWS + j]; }, gp + g.o_Wm, KM, lane, wv);
+         [&](int k, int j) { return Sin[k * SWS + j]; }, gp + g.o_Wm, KM, lane, wv, fresh);
     if (tid < SO) {
         float s = 0.f;
         for (int r = 0; r < TR; ++r) s += gA[r * SWS + tid];
@@ -318,7 +342,7 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, float* gp
          }, lane, wv);
     mm16_acc<4>(KH, VO, 3 * TR,
          [&](int i, int k) { return Vh[(k & 15) * VWS + i * 3 + (k >> 4)]; },
-         [&](int k, int j) { return gVo[(k & 15) * VWS + j * 3 + (k >> 4)]; }, gp + g.o_Wu, VO, lane, wv);
+         [&](int k, int j) { return gVo[(k & 15) * VWS + j * 3 + (k >> 4)]; }, gp + g.o_Wu, VO, lane, wv, fresh);
     __syncthreads();
     PFT_STAMP(17);
     mm16<5>(VI, 3 * TR, KH,
@@ -327,28 +351,28 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, float* gp
          [&](int i, int j, float x) { gVi[(j & 15) * VWS + i * 3 + (j >> 4)] = x; }, lane, wv);
     mm16_acc<4>(VI, KH, 3 * TR,
          [&](int i, int k) { return Vin[(k & 15) * VWS + i * 3 + (k >> 4)]; },
-         [&](int k, int j) { return gVh[(k & 15) * VWS + j * 3 + (k >> 4)]; }, gp + g.o_Wh, KH, lane, wv);
+         [&](int k, int j) { return gVh[(k & 15) * VWS + j * 3 + (k >> 4)]; }, gp + g.o_Wh, KH, lane, wv, fresh);
     __syncthreads();
 }
 
 // forward recompute of a chain whose first-level inputs (Sin(0)[:, :si], Vin(0)) are in place.  The last level's gated
 // vectors go to vout_last when it is not null.
-__device__ __forceinline__ void chain_fwd(const ChainLds& L, const GvpT* g, const float* W, float* vout_last,
+__device__ __forceinline__ void chain_fwd(const ChainLds& L, const GvpT* g, const float* W, const PackPtr pk, float* vout_last,
                                           const int tid, const int lane, const int wv) {
     for (int l = 0; l < L.nlv; ++l) {
         const bool last = l == L.nlv - 1;
-        gvp_fwd(g[l], W, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+        gvp_fwd(g[l], W, pk, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
                 last ? vout_last : L.Vin(l + 1), L.Vh, L.Vu, tid, lane, wv);
     }
 }
 // backward through the chain: upstream gradients in L.gX ([row][so_last], stride SWS) and L.gVX; returns through
 // gs_out / gv_out the buffers that hold dL/d Sin(0) and dL/d Vin(0)
-__device__ __forceinline__ void chain_bwd(const ChainLds& L, const GvpT* g, const float* W, float* gp, float*& gs_out,
-                                          float*& gv_out, const int tid, const int lane, const int wv) {
+__device__ __forceinline__ void chain_bwd(const ChainLds& L, const GvpT* g, const float* W, const PackPtr pk, const bool fresh, float* gp,
+                                          float*& gs_out, float*& gv_out, const int tid, const int lane, const int wv) {
     float *ga = L.gX, *gs = L.gY, *gvo = L.gVX, *gvi = L.gVY;
     for (int l = L.nlv - 1; l >= 0; --l) {
         const bool last = l == L.nlv - 1;
-        gvp_bwd(g[l], W, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+        gvp_bwd(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
                 ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv);
         float* t0 = ga; ga = gs; gs = t0;
         float* t1 = gvo; gvo = gvi; gvi = t1;
@@ -384,6 +408,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
     const float* W = p.c.W;
     float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
     zero_class(p.c, gp, PFT_CLS_HEAD, threadIdx.x);
+    const PackPtr pk = {p.c.wpack_f, p.c.wpack_b};
     const int NF = p.pharm_nf;
     const int SOL = p.g[p.n_gvps - 1].so;            // 64
     // work unit = one 16-row half of a 32-row tile, dealt over the blocks
@@ -412,7 +437,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
                 s_ge[row * 8 + o] = row < nv ? p.g_eps_h[(size_t)(n0 - p.node_base + row) * NF + o] : 0.f;
             }
             __syncthreads();
-            chain_fwd(L, p.g, W, nullptr, tid, lane, wv);
+            chain_fwd(L, p.g, W, pk, nullptr, tid, lane, wv);
             // to_scalar_output: eps_h = Wout act + b ; eps_x = the single output vector channel
             for (int idx = tid; idx < TR * SOL; idx += NT) {
                 const int row = idx & 15, k = idx >> 4;
@@ -437,7 +462,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
             }
             __syncthreads();
             float *gs, *gv;
-            chain_bwd(L, p.g, W, gp, gs, gv, tid, lane, wv);
+            chain_bwd(L, p.g, W, pk, unit == (int)blockIdx.x, gp, gs, gv, tid, lane, wv);
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx >> 7, f = idx & 127;
                 if (row < nv) p.G_h[(size_t)(n0 + row) * PF_S + f] = gs[row * SWS + f];
@@ -492,6 +517,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
     const float* W = p.c.W;
     float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
     zero_class(p.c, gp, PFT_CLS_NODE + p.layer, threadIdx.x);
+    const PackPtr pk = {p.c.wpack_f, p.c.wpack_b};
+    bool seen[2] = {false, false};          // weight-gradient tiles of a node type: the first unit stores onto the cleared copy without reading it
     const uint32_t st_msg = (uint32_t)p.layer * 2u, st_res = st_msg + 1u;
     for (int unit = blockIdx.x; unit < 2 * p.ntiles; unit += gridDim.x) {
         const NodeTile t = p.tiles[unit >> 1];
@@ -571,7 +598,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 L.Vin(0)[row * VWS + q] = vy[row * VWS + q] / s_vl1[row].den;
             }
             __syncthreads();
-            chain_fwd(L, g, W, rvl, tid, lane, wv);
+            chain_fwd(L, g, W, pk, rvl, tid, lane, wv);
             // ---- residual dropout, residual, LN2 statistics
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx & 15, f = idx >> 4;
@@ -635,7 +662,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
             }
             __syncthreads();
             float *gs, *gv;
-            chain_bwd(L, g, W, gp, gs, gv, tid, lane, wv);
+            chain_bwd(L, g, W, pk, !seen[nt], gp, gs, gv, tid, lane, wv);
+            seen[nt] = true;
             // ---- LN1 backward
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx & 15, f = idx >> 4;
@@ -750,20 +778,33 @@ __global__ __launch_bounds__(256) void k_compact_tiles(const EdgeTile* tiles, co
     if (tid == 0) ccnt[blockIdx.x] = base;
 }
 
-// packed to_feats_out of every message GVP for the input-gradient product: [gvp][m tile (11)][k block (8)][lane] x 4:
-// lane (li, kq) of m tile mt, block sb holds W[k = 16 sb + 4 kq + t][i = 16 mt + li], t = 0..3 (zero for i >= si + h)
-__global__ __launch_bounds__(64) void k_pack_bwd(const float* W, const GvpT* g, float* out) {
-    const int gi = blockIdx.x / 88, rem = blockIdx.x - gi * 88, mt = rem >> 3, sb = rem & 7;
+// packed to_feats_out of every GVP (message, update and head GVPs in the order of the GvpT table; GvpT::pk):
+//   input-gradient product (blockIdx.y == 0): [gvp][m tile (11)][k block (8)][lane] x 4 -- lane (li, kq) of m tile mt, block sb
+//     holds W[k = 16 sb + 4 kq + t][i = 16 mt + li], t = 0..3 (zero for i >= si + h, k >= so)
+//   forward product (blockIdx.y == 1): [gvp][m tile (8)][k block (11)][lane] x 4 -- W[o = 16 mt + li][k = 16 sb + 4 kq + t]
+__global__ __launch_bounds__(64) void k_pack_gvp(const float* W, const GvpT* g, float* out_b, float* out_f) {
+    const int gi = blockIdx.x / 88, rem = blockIdx.x - gi * 88;
     const int lane = threadIdx.x, li = lane & 15, kq = lane >> 4;
     const GvpT t = g[gi];
-    const int KM = t.si + t.h, i = 16 * mt + li;
+    const int KM = t.si + t.h;
     f32x4 v;
+    if (blockIdx.y == 0) {
+        const int mt = rem >> 3, sb = rem & 7, i = 16 * mt + li;
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        const int k = 16 * sb + 4 * kq + tt;
-        v[tt] = (i < KM && k < t.so) ? W[t.o_Wm + k * KM + i] : 0.f;
+        for (int tt = 0; tt < 4; ++tt) {
+            const int k = 16 * sb + 4 * kq + tt;
+            v[tt] = (i < KM && k < t.so) ? W[t.o_Wm + k * KM + i] : 0.f;
+        }
+        reinterpret_cast<f32x4*>(out_b)[(size_t)blockIdx.x * 64 + lane] = v;
+    } else {
+        const int mt = rem / 11, sb = rem - mt * 11, o = 16 * mt + li;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int k = 16 * sb + 4 * kq + tt;
+            v[tt] = (o < t.so && k < KM) ? W[t.o_Wm + o * KM + k] : 0.f;
+        }
+        reinterpret_cast<f32x4*>(out_f)[(size_t)blockIdx.x * 64 + lane] = v;
     }
-    reinterpret_cast<f32x4*>(out)[(size_t)blockIdx.x * 64 + lane] = v;
 }
 
 // one column tile (16 columns, column = lane & 15) of C[M x 16] = A[M x K] B[K x 16], K <= 4 KS: b(k) is this lane's
@@ -1546,9 +1587,9 @@ void pfk_loss_eval(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_lo
 void pfk_scale_by(float* g, int n, const float* scale, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_scale_by, dim3((n + 255) / 256), dim3(256), 0, s, g, n, scale);
 }
-void pfk_pack_bwd(const float* W, const GvpT* g, int n_gvps, float* out, hipStream_t s) {
+void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float* out_f, hipStream_t s) {
     if (n_gvps == 0) return;
-    hipLaunchKernelGGL(k_pack_bwd, dim3(n_gvps * 88), dim3(64), 0, s, W, g, out);
+    hipLaunchKernelGGL(k_pack_gvp, dim3(n_gvps * 88, 2), dim3(64), 0, s, W, g, out_b, out_f);
 }
 void pfk_fix_apply(long long* A, float* G, size_t n, const float* fix, hipStream_t s) {
     if (n == 0) return;
