@@ -164,7 +164,7 @@ __device__ __forceinline__ void mm16_packed(const f32x4* P, const int mts, const
         const f32x4* pp = P + (size_t)mt * (NSB * 64) + lane;
         f32x4 aq[NSB];
 #pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) aq[sb] = sb < nsb ? pp[sb * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sb = 0; sb < NSB; ++sb) aq[sb] = pp[sb * 64];       // all NSB blocks exist in the table (zero padded): no branches between the loads
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb)
@@ -174,6 +174,39 @@ __device__ __forceinline__ void mm16_packed(const f32x4* P, const int mts, const
             }
 #pragma unroll
         for (int r = 0; r < 4; ++r) c(mt * 16 + kq * 4 + r, li, acc[r]);
+    }
+}
+
+// G[M x N] += A^T-style weight gradient with the wave owning m tile wv (M <= 128): A[i][k] = a(i, k) is fetched once per wave for
+// the K = 16 rows of the unit and serves every n tile; fresh: the block's copy is known to be zero there (store, no read)
+template <typename FA, typename FB>
+__device__ __forceinline__ void mm16_acc_rows(const int M, const int N, FA a, FB b, float* G, const int ld, const int lane, const int wv,
+                                              const bool fresh) {
+    const int li = lane & 15, kq = lane >> 4;
+    if (wv * 16 >= M) return;
+    const int ai = wv * 16 + li;
+    float av[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) av[u] = ai < M ? a(ai, 4 * u + kq) : 0.f;
+    const int nts = (N + 15) >> 4;
+    for (int nt = 0; nt < nts; ++nt) {
+        const int bj = nt * 16 + li;
+        float bv[4], old[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bv[u] = bj < N ? b(4 * u + kq, bj) : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = wv * 16 + kq * 4 + r;
+            old[r] = (!fresh && ci < M && bj < N) ? G[ci * ld + bj] : 0.f;
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = wv * 16 + kq * 4 + r;
+            if (ci < M && bj < N) G[ci * ld + bj] = old[r] + acc[r];
+        }
     }
 }
 
@@ -320,7 +353,7 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const Pac
          [&](int k, int j) { return gA[j * SWS + k]; },
          [&](int i, int j, float x) { if (i < KM) gS[j * SWS + i] = x; }, lane, wv);
     PFT_STAMP(15);
-    mm16_acc<4>(SO, KM, TR,
+    mm16_acc_rows(SO, KM,
          [&](int i, int k) { return gA[k * SWS + i]; },
          [&](int k, int j) { return Sin[k * SWS + j]; }, gp + g.o_Wm, KM, lane, wv, fresh);
     if (tid < SO) {
