@@ -254,6 +254,8 @@ struct pf_handle {
     float *t_G_h[2] = {nullptr, nullptr}, *t_G_v[2] = {nullptr, nullptr}, *t_gagg_s = nullptr, *t_gagg_v = nullptr,
           *t_gpart = nullptr, *t_geps_h = nullptr, *t_geps_x = nullptr;
     long long *t_A_h = nullptr, *t_A_v = nullptr;      // fixed-point accumulators of the level-0 scatter (kept clear between uses)
+    int enc_begin = 0, enc_n = 0;           // flat range of the encoders' parameters (contiguous: the first tensors of the state dict)
+    float* t_gpart_enc = nullptr;
     TensorSeg* d_tseg = nullptr; int n_tseg = 0;   // class of every parameter tensor (pf_train.h: which gradient copies hold it)
     int n_gvpt = 0;                         // entries of d_gvpt (message, update, head GVPs)
     float* d_wpack = nullptr;               // k_pack_bwd fragments of every message GVP; valid for w_version == wpack_version
@@ -1225,6 +1227,14 @@ int pf_commit_weights(pf_handle* h) {
                 }
                 segs.push_back(sg);
             }
+            {
+                int lo = 0x7fffffff, hi = 0, tot = 0;
+                for (const TensorSeg& sg : segs)
+                    if (sg.cls == PFT_CLS_ENC) { lo = std::min(lo, sg.begin); hi = std::max(hi, sg.end); tot += sg.end - sg.begin; }
+                if (tot == 0) { lo = hi = 0; }
+                if (hi - lo != tot) PF_FAIL(h, PF_ERR_STATE, "internal: the encoders' parameters are not contiguous in the flat layout");
+                h->enc_begin = lo; h->enc_n = hi - lo;
+            }
             if (h->d_tseg) { (void)hipFree(h->d_tseg); h->d_tseg = nullptr; }
             h->n_tseg = c.n_convs <= 4 ? (int)segs.size() : -1;
             PF_HIP(h, hipMalloc((void**)&h->d_tseg, std::max<size_t>(segs.size(), 1) * sizeof(TensorSeg)));
@@ -1927,6 +1937,7 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     need((size_t)2 * N * PF_S); need((size_t)2 * N * 48);          // int64 accumulators (two floats per element)
     need(64);
     need(64); need((size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);      // compact tile list and its counts
+    need((size_t)PFT_ENC_BLOCKS * std::max(h->enc_n, 1));
     need((size_t)h->Nf * 3); need((size_t)h->B); need((size_t)h->B); need((size_t)h->Nf * 3); need((size_t)h->Nf * c.pharm_nf); need(64);   // loss buffers
     need((size_t)h->t_nblk * h->nparams);
     const size_t Es = (size_t)std::max<int64_t>(h->Ecap, 1), ng = (size_t)c.n_message_gvps;
@@ -1954,6 +1965,7 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     h->t_fix = carve<float>(cur, 64);
     h->t_ccnt = carve<int>(cur, 64);
     h->t_clist = carve<int>(cur, (size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);
+    h->t_gpart_enc = carve<float>(cur, (size_t)PFT_ENC_BLOCKS * std::max(h->enc_n, 1));
     h->t_lx0c = carve<float>(cur, (size_t)h->Nf * 3); h->t_lag = carve<float>(cur, (size_t)h->B); h->t_lsg = carve<float>(cur, (size_t)h->B);
     h->t_lgx = carve<float>(cur, (size_t)h->Nf * 3); h->t_lgh = carve<float>(cur, (size_t)h->Nf * c.pharm_nf); h->t_lout = carve<float>(cur, 64);
     PF_HIP(h, hipMemsetAsync(h->t_A_h, 0, (size_t)N * PF_S * 8, s));       // pfk_fix_apply keeps them clear afterwards
@@ -2045,6 +2057,7 @@ int pf_train_forward(pf_handle* h, const float* dev_prot_x, const float* dev_pha
     h->t_common = TrainCommon{};
     h->t_common.W = h->d_flat; h->t_common.gpart = h->t_gpart; h->t_common.nparams = (int)h->nparams;
     h->t_common.tseg = h->d_tseg; h->t_common.ntens = h->n_tseg;
+    h->t_common.gpart_enc = h->t_gpart_enc; h->t_common.enc_begin = h->enc_begin; h->t_common.enc_n = h->enc_n;
     h->t_common.drop_thr = dropout_p > 0.f ? (uint32_t)std::min(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
     h->t_common.drop_scale = 1.0f / (1.0f - dropout_p);
     h->t_common.seed = seed;
@@ -2074,6 +2087,7 @@ int pf_train_loss_forward(pf_handle* h, const float* dev_pharm_x0, const float* 
     h->t_common = TrainCommon{};
     h->t_common.W = h->d_flat; h->t_common.gpart = h->t_gpart; h->t_common.nparams = (int)h->nparams;
     h->t_common.tseg = h->d_tseg; h->t_common.ntens = h->n_tseg;
+    h->t_common.gpart_enc = h->t_gpart_enc; h->t_common.enc_begin = h->enc_begin; h->t_common.enc_n = h->enc_n;
     h->t_common.drop_thr = dropout_p > 0.f ? (uint32_t)std::min(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
     h->t_common.drop_scale = 1.0f / (1.0f - dropout_p);
     h->t_common.seed = seed;
@@ -2132,6 +2146,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     ReduceParams rp{};
     rp.gpart = h->t_gpart; rp.nparams = (int)h->nparams; rp.grad = dev_grad; rp.tseg = h->d_tseg; rp.ntens = h->n_tseg;
     rp.NB = nb; rp.ccnt = h->t_ccnt;
+    rp.gpart_enc = h->t_gpart_enc; rp.enc_begin = h->enc_begin; rp.enc_n = h->enc_n;
     pfk_fix_scale(dev_g_eps_h, h->Nf * c.pharm_nf, dev_g_eps_x, h->Nf * 3, h->t_fix, s);
     PF_HIP(h, hipMemsetAsync(h->t_G_h[0], 0, (size_t)N * PF_S * 4, s));
     PF_HIP(h, hipMemsetAsync(h->t_G_v[0], 0, (size_t)N * 48 * 4, s));
@@ -2220,7 +2235,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         }
         p.G_h = h->t_G_h[a];
         const int tiles = (h->Np + PFT_ROWS - 1) / PFT_ROWS + (h->Nf + PFT_ROWS - 1) / PFT_ROWS;
-        rp.enc_grid = std::max(1, std::min(nb, tiles));
+        rp.enc_grid = std::max(1, std::min(PFT_ENC_BLOCKS, tiles));
         pfk_bwd_encode(&p, rp.enc_grid, s);
     }
     pfk_train_reduce(&rp, s);

@@ -33,6 +33,7 @@ struct GvpT {
 // head, encoders and node kernels use the blocks [0, grid) of their launch and clear their tensors in their own copy when they
 // start; an edge-level launch deals its blocks over the etypes (k_bwd_edge_level) and every block STORES the whole GVP it
 // served.  Nothing is cleared globally and pfk_train_reduce adds up exactly the copies that were written.
+#define PFT_ENC_BLOCKS 1024
 #define PFT_CLS_HEAD 0
 #define PFT_CLS_ENC 1
 #define PFT_CLS_NODE 2       // + layer
@@ -41,6 +42,7 @@ struct GvpT {
 struct TensorSeg { int begin, end, cls, pad; };
 struct ReduceParams {
     const float* gpart; int nparams; float* grad;
+    const float* gpart_enc; int enc_begin, enc_n;
     const TensorSeg* tseg; int ntens;
     int NB;                  // gradient copies = grid of the edge-level launches
     int head_grid, enc_grid, node_grid[4];
@@ -53,6 +55,8 @@ struct TrainCommon {
     float* gpart;            // [gridDim.x][nparams]
     int nparams;
     const TensorSeg* tseg; int ntens;
+    float* gpart_enc; int enc_begin, enc_n;  // the encoders' parameters [enc_begin, enc_begin + enc_n) have their own, narrow gradient copies
+                                             // [PFT_ENC_BLOCKS][enc_n]: k_bwd_encode is latency-bound per tile and runs several blocks per CU
     const float* wpack_b; const float* wpack_f;   // k_pack_gvp tables (PFT_WPACK_FLOATS per GVP each)
     uint32_t drop_thr;       // an element is dropped iff pf_drop_hash(...) < drop_thr  (= p * 2^32; 0: no dropout)
     float drop_scale;        // 1 / (1 - p)

@@ -1309,13 +1309,14 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
 // ---------------------------------------------------------------------------------------------
 // encoders backward: LayerNorm(SiLU(Linear([h, t])))  (dynamics_gvp.py:107-117,143-151)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT, 1) void k_bwd_encode(const BwdEncodeParams p) {
+__global__ __launch_bounds__(NT) void k_bwd_encode(const BwdEncodeParams p) {
     __shared__ float sin_[TR * 17], z[TR * ZS], xh[TR * ZS], gq[TR * ZS];
     __shared__ float red[NT];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* W = p.c.W;
-    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
-    zero_class(p.c, gp, PFT_CLS_ENC, threadIdx.x);
+    float* gp = p.c.gpart_enc + (size_t)blockIdx.x * p.c.enc_n - p.c.enc_begin;       // gp[flat offset] as in the other kernels
+    for (int i = threadIdx.x; i < p.c.enc_n; i += NT) gp[p.c.enc_begin + i] = 0.f;
+    __syncthreads();
     const int N = p.Np + p.Nf;
     const int tiles_prot = (p.Np + TR - 1) / TR, tiles_pharm = (p.Nf + TR - 1) / TR;
     for (int ti = blockIdx.x; ti < tiles_prot + tiles_pharm; ti += gridDim.x) {
@@ -1435,6 +1436,24 @@ __global__ __launch_bounds__(256) void k_fix_scale(const float* g_h, const int n
         fix[1] = ldexpf(1.0f, -k);
     }
 }
+// the encoders' gradient: up to PFT_ENC_BLOCKS narrow copies; 8 threads per parameter sum every 8th copy, then their partial sums are
+// added in slice order (fixed order: deterministic)
+__global__ __launch_bounds__(256) void k_reduce_enc(const ReduceParams p) {
+    __shared__ float part[8][32];
+    const int pi = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + pi;
+    float s = 0.f;
+    if (i < p.enc_n)
+        for (int b = sl; b < p.enc_grid; b += 8) s += p.gpart_enc[(size_t)b * p.enc_n + i];
+    part[sl][pi] = s;
+    __syncthreads();
+    if (sl == 0 && i < p.enc_n) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += part[q][pi];
+        p.grad[p.enc_begin + i] = t;
+    }
+}
 __global__ void k_train_reduce(const ReduceParams p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.nparams) return;
@@ -1445,8 +1464,8 @@ __global__ void k_train_reduce(const ReduceParams p) {
     }
     const int cls = p.tseg[lo].cls;
     int b0 = 0, b1 = 0;
+    if (cls == PFT_CLS_ENC) return;                  // k_reduce_enc
     if (cls == PFT_CLS_HEAD) b1 = p.head_grid;
-    else if (cls == PFT_CLS_ENC) b1 = p.enc_grid;
     else if (cls >= PFT_CLS_MSG) {
         const int l = (cls - PFT_CLS_MSG) >> 2, et = (cls - PFT_CLS_MSG) & 3;
         int nbk;
@@ -1635,6 +1654,7 @@ void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s) {
     hipLaunchKernelGGL(k_bwd_encode, dim3(nblocks), dim3(NT), 0, s, *p);
 }
 void pfk_train_reduce(const ReduceParams* p, hipStream_t s) {
+    if (p->enc_n > 0) hipLaunchKernelGGL(k_reduce_enc, dim3((p->enc_n + 31) / 32), dim3(256), 0, s, *p);
     hipLaunchKernelGGL(k_train_reduce, dim3((p->nparams + 255) / 256), dim3(256), 0, s, *p);
 }
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s) {
