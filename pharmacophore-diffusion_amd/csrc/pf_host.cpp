@@ -258,7 +258,7 @@ struct pf_handle {
     float* t_gpart_enc = nullptr;
     TensorSeg* d_tseg = nullptr; int n_tseg = 0;   // class of every parameter tensor (pf_train.h: which gradient copies hold it)
     int n_gvpt = 0;                         // entries of d_gvpt (message, update, head GVPs)
-    float* d_wpack = nullptr;               // k_pack_bwd fragments of every message GVP; valid for w_version == wpack_version
+    float* d_wpack = nullptr;               // k_pack_gvp tables of every GVP (input-gradient fragments, then forward fragments); valid for w_version == wpack_version
     uint64_t wpack_version = ~0ull;
     float *t_lx0c = nullptr, *t_lag = nullptr, *t_lsg = nullptr, *t_lgx = nullptr, *t_lgh = nullptr, *t_lout = nullptr;   // pf_train_loss_forward
     bool t_have_loss = false;

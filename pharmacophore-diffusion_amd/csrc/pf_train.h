@@ -18,7 +18,7 @@
 
 #define PFT_MAX_CHAIN 4      // GVPs per chain the backward tiles hold in LDS
 #define PFT_ROWS 16          // rows (edges / nodes) per backward sub-tile = N of v_mfma_f32_16x16x4_f32
-#define PFT_WPACK_FLOATS (11 * 8 * 64 * 4)   // packed to_feats_out of one message GVP (k_pack_bwd)
+#define PFT_WPACK_FLOATS (11 * 8 * 64 * 4)   // packed to_feats_out of one message GVP (k_pack_gvp: one table per product direction)
 #define PFT_FIX_BITS 40      // fixed-point scale of the level-0 scatter RELATIVE to the largest upstream gradient of the call:
                              // resolution 2^-40 of it, head room 2^23 times it (pfk_fix_scale picks the power of two)
 
@@ -139,7 +139,7 @@ struct BwdEdgeLevelParams {
     const float* sv_z; const float* sv_g; const float* sv_v; size_t sv_stride;
     float* gs_buf; float* gv_buf;            // dL/d(input scalars / vectors of the level above), per edge slot
     const GvpT* g; int n_gvps; int level;
-    const float* wpack;                      // k_pack_bwd fragments of this layer's message GVPs [et][level][PFT_WPACK_FLOATS]
+    const float* wpack;                      // k_pack_gvp input-gradient fragments of this layer's message GVPs [et][level][PFT_WPACK_FLOATS]
     float rbf_mu[PF_R]; float rbf_inv_sigma;
     int l0;
 };

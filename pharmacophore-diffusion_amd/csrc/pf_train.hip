@@ -761,7 +761,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
 //   * the rows of the NEXT tile (saved Z / gate / V rows, level inputs, upstream gradients: 62 KB) are fetched into
 //     registers while this tile's big products run, their indices one tile earlier still, the tile descriptors once per
 //     round of 64 tiles: no dependent global round trip is left inside a pass;
-//   * the input-gradient product gS = gZ Wm reads to_feats_out as 1-KiB fragments of a packed copy (k_pack_bwd: lane
+//   * the input-gradient product gS = gZ Wm reads to_feats_out as 1-KiB fragments of a packed copy (k_pack_gvp: lane
 //     (i, kq) holds four consecutive k of input i -- one global_load_dwordx4 per four MFMAs) and keeps gZ, its other
 //     operand, in registers for all of a wave's output tiles (16 ds_read_b128 per wave and pass);
 //   * Wh, Wu and the gate weights sit in LDS for the whole launch; the small vector products are dealt over the waves by
