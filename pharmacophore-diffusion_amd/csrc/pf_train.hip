@@ -54,9 +54,12 @@ __device__ __forceinline__ void mm16(const int M, const int N, const int K, FA a
             float av[UNR], bv[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const int k = k0 + 4 * u + kq;
-                av[u] = (aok && k < K) ? a(ai, k) : 0.f;
-                bv[u] = (bok && k < K) ? b(k, bj) : 0.f;
+                // operands are fetched unconditionally at clamped indices and masked afterwards: a guarded fetch compiles to an
+                // exec-masked branch per element, which is what these loops used to spend their time on
+                const int k = k0 + 4 * u + kq, kc = min(k, K - 1);
+                const float xa = a(min(ai, M - 1), kc), xb = b(kc, min(bj, N - 1));
+                av[u] = (aok && k < K) ? xa : 0.f;
+                bv[u] = (bok && k < K) ? xb : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
@@ -90,7 +93,11 @@ __device__ __forceinline__ void mm16_acc(const int M, const int N, const int K, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = mt * 16 + kq * 4 + r;
-                old[x][r] = (!fresh && live[x] && ci < M && bjv[x] < N) ? G[ci * ld + bjv[x]] : 0.f;      // fresh: known zeros (zero_class)
+                old[x][r] = 0.f;                                   // fresh: known zeros (zero_class)
+                if (!fresh) {                                      // block-uniform
+                    const float o = G[min(ci, M - 1) * ld + min(bjv[x], N - 1)];
+                    old[x][r] = (live[x] && ci < M && bjv[x] < N) ? o : 0.f;
+                }
             }
             acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -102,9 +109,10 @@ __device__ __forceinline__ void mm16_acc(const int M, const int N, const int K, 
                 float av[UNR], bv[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const int k = k0 + 4 * u + kq;
-                    av[u] = (aok && k < K) ? a(ai, k) : 0.f;
-                    bv[u] = (bok && k < K) ? b(k, bjv[x]) : 0.f;
+                    const int k = k0 + 4 * u + kq, kc = min(k, K - 1);
+                    const float xa = a(min(ai, M - 1), kc), xb = b(kc, min(bjv[x], N - 1));
+                    av[u] = (aok && k < K) ? xa : 0.f;
+                    bv[u] = (bok && k < K) ? xb : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc[x], 0, 0, 0);
@@ -187,17 +195,21 @@ __device__ __forceinline__ void mm16_acc_rows(const int M, const int N, FA a, FB
     const int ai = wv * 16 + li;
     float av[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) av[u] = ai < M ? a(ai, 4 * u + kq) : 0.f;
+    for (int u = 0; u < 4; ++u) { const float x = a(min(ai, M - 1), 4 * u + kq); av[u] = ai < M ? x : 0.f; }
     const int nts = (N + 15) >> 4;
     for (int nt = 0; nt < nts; ++nt) {
         const int bj = nt * 16 + li;
         float bv[4], old[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bv[u] = bj < N ? b(4 * u + kq, bj) : 0.f;
+        for (int u = 0; u < 4; ++u) { const float x = b(4 * u + kq, min(bj, N - 1)); bv[u] = bj < N ? x : 0.f; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ci = wv * 16 + kq * 4 + r;
-            old[r] = (!fresh && ci < M && bj < N) ? G[ci * ld + bj] : 0.f;
+            old[r] = 0.f;
+            if (!fresh) {                                          // block-uniform
+                const float o = G[min(ci, M - 1) * ld + min(bj, N - 1)];
+                old[r] = (ci < M && bj < N) ? o : 0.f;
+            }
         }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -274,7 +286,7 @@ __device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, const Pac
     gvp_vec(g, W, Sin, Vin, Vh, Vu, true, tid, lane, wv);
     PFT_STAMP(2);
     mm16_packed<11>(reinterpret_cast<const f32x4*>(pk.f) + (size_t)g.pk * (8 * 11 * 64), (SO + 15) >> 4, (KM + 15) >> 4,
-         [&](int k, int j) { return k < KM ? Sin[j * SWS + k] : 0.f; },
+         [&](int k, int j) { return Sin[j * SWS + min(k, KM - 1)]; },         // (the fragments are zero beyond KM)
          [&](int i, int j, float x) {
              if (i < SO) {
                  const float z = x + W[g.o_bm + i];
@@ -1028,7 +1040,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                     E2_PHASE();
                     float bv[5];
 #pragma unroll
-                    for (int u = 0; u < 5; ++u) { const int k = 4 * u + kq; bv[u] = k < VI ? Vin[(rb + li) * VWS + k * 3 + cw] : 0.f; }
+                    for (int u = 0; u < 5; ++u) { const int k = min(4 * u + kq, VI - 1); bv[u] = Vin[(rb + li) * VWS + k * 3 + cw]; }   // (sWh is zero beyond VI)
                     f32x4 au = {0.f, 0.f, 0.f, 0.f};
                     for (int mt = 0; mt < mth; ++mt) {
                         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
