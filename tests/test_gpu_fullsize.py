@@ -162,6 +162,13 @@ def test_config4_slice_sharded_equals_single_rank_bitwise():
     assert [[p.n_ph_centers for p in o] for o in full] == n_pharms
     assert all(torch.isfinite(p.ph_coords).all() for o in full for p in o)
     assert m.dynamics.engine().kernel_family(0) in (4, 8)
+    # batches in flight on several HIP streams / handles: a batch's result does not depend on the lane it ran on
+    for lanes in (1, 3):
+        torch.manual_seed(11)
+        again = m.sample(pockets, n_pharms, max_batch_size=128, lanes=lanes)
+        for i in range(n_pockets):
+            for p, q in zip(full[i], again[i]):
+                assert torch.equal(p.ph_coords, q.ph_coords) and torch.equal(p.ph_feats_idxs, q.ph_feats_idxs), (lanes, i)
     halves = []
     for r in range(2):
         torch.manual_seed(11)                                   # the ranks of a job share the seed

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Probe: does a config-2 batch finish sooner as S independent sub-batches on S HIP streams (one handle each)?
 Every launch of a B=32 step has fewer row groups than the chip has SIMDs, so concurrent sub-batches overlap.
-    python tools/two_stream_probe.py"""
+    python tools/two_stream_probe.py              # one batch of B split over S streams
+    FULL=1 B=128 python tools/two_stream_probe.py # S whole batches of B in flight at once (S handles, S streams)"""
 import os
 import sys
 import time
@@ -13,14 +14,15 @@ from pharmacoforge_amd import schedule, synthetic
 
 dev = torch.device("cuda", 0)
 B, T = int(os.environ.get("B", "32")), 500
-pockets = [synthetic.synthetic_pocket(1000 + i, 256) for i in range(B)]
+FULL = os.environ.get("FULL", "0") != "0"
+pockets = [synthetic.synthetic_pocket(1000 + i, 256) for i in range(B * (4 if FULL else 1))]
 coef = schedule.step_coefficients(schedule.PredefinedNoiseSchedule('polynomial_2', T, 1e-5).gamma, T)
 sd = synthetic.make_state_dict(0)
 
 
 def run(S):
     engs, streams, noises = [], [], []
-    per = B // S
+    per = B if FULL else B // S
     for k in range(S):
         eng = pfa.PfEngine(device=dev)
         eng.load_state_dict(sd)
@@ -46,7 +48,8 @@ def run(S):
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     best = sorted(times[1:])[1]
-    print(f"B={B} as {S} sub-batch(es) on {S} stream(s): {best * 1e3:.2f} ms for T={T} -> {B * T / best / 1e3:.0f} k sample-steps/s", flush=True)
+    tot = per * S
+    print(f"{tot} graphs as {S} batch(es) of {per} on {S} stream(s): {best * 1e3:.2f} ms for T={T} -> {tot * T / best / 1e3:.0f} k sample-steps/s", flush=True)
 
 
 for S in (1, 2, 4):
