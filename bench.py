@@ -74,6 +74,9 @@ def main():
                          "at least 20 launches are timed whatever --steps is)")
     ap.add_argument("--no-full-trajectory", action="store_true", help="skip the whole-schedule pf_sample leg")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel device time to stderr")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="full-trajectory leg: also report the throughput with this many independent batches in flight (own handle "
+                         "and HIP stream each; 1: skip)")
     ap.add_argument("--train-batches", type=int, default=4,
                     help="--train: number of distinct batches the steps rotate through (1: the same batch every step, no re-bind)")
     ap.add_argument("--train", action="store_true",
@@ -259,7 +262,15 @@ def main():
 
     out["roofline"]["launches_timed_in_region"] = in_region
     if not args.no_full_trajectory:
-        out["full_trajectory"] = full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks)
+        def eng2_factory(k):                        # lane k: its own handle, the same weights, other pockets of the same shape
+            e2 = pfa.PfEngine(device=dev, **arch_eng)
+            e2.load_state_dict(synthetic.make_state_dict(0, **arch_sd))
+            xs2, hs2 = zip(*[synthetic.synthetic_pocket(5000 + 1000 * rank + 100 * k + i, args.n_prot) for i in range(B)])
+            px2, ph2 = torch.cat(xs2).to(dev), torch.cat(hs2).to(dev)
+            s2, d2 = e2.build_pp_edges(px2, prot_ptr)
+            e2.set_batch(px2, ph2, prot_ptr, pharm_ptr, s2, d2)
+            return e2
+        out["full_trajectory"] = full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, eng2_factory)
 
     if args.breakdown and rank == 0:
         eng.profile_enable(0x1ff)
@@ -280,7 +291,7 @@ def main():
         dist.destroy_process_group()
 
 
-def full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks):
+def full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, eng2_factory=None):
     """SURVEY.md 8(d) row 1 as written: wall time of the WHOLE T-step reverse loop (pharmacodiff.py:466-472 equivalent)
     for the rank's batch -- pf_sample: begin, T steps, final frame, enqueued without a host sync; x_T, h_T ~ N(0, I) at
     the pocket COM, seed-0 weights, noise drawn on the device inside the timed region -- reported as B*T / wall.  With
@@ -302,12 +313,42 @@ def full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_ov
     times.sort()
     dt = times[len(times) // 2]
     wk = eng.work_detail()
-    return {"value": world * B * T / dt, "unit": "sample-steps/s", "T": T, "wall_ms": dt * 1e3, "ms_per_step": dt / T * 1e3,
+    lanes = None
+    if args.lanes > 1:
+        lanes = batches_in_flight(args, eng2_factory, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, arr)
+    return {"lanes": lanes, "value": world * B * T / dt, "unit": "sample-steps/s", "T": T, "wall_ms": dt * 1e3, "ms_per_step": dt / T * 1e3,
             "repetitions_ms": [round(t * 1e3, 3) for t in times], "finite": bool(torch.isfinite(x0).all() and torch.isfinite(h0).all()),
             "max_abs_coordinate": float(x0.abs().max()),
             "edges_last_step": dict(zip(("ff", "pf", "fp", "pp"), wk["edges"])),
             "edges_computed_per_layer_last_step": wk["executed_edges_per_layer"],
             "note": "whole T-step reverse process of the rank's batch through pf_sample, noise generation included"}
+
+
+def batches_in_flight(args, factory, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, arr):
+    """Throughput with args.lanes independent batches of the SAME configuration in flight at once, each on its own handle
+    and HIP stream (what PharmacophoreDiff.sample does when a job has more than one batch: four of the five launches of a
+    batched step leave part of the chip idle, so independent batches overlap).  Reported beside the single-batch numbers,
+    never as `value`: the unit of work is L batches of B graphs, T steps each."""
+    L = args.lanes
+    engs = [factory(k) for k in range(L)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(L)]
+    gens = [torch.Generator(device=dev).manual_seed(777 + 13 * rank + k) for k in range(L)]
+    bufs = [torch.empty(T + 1, Nf, 9, device=dev) for _ in range(L)]
+    times = []
+    for rep in range(4):
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(L):
+            with torch.cuda.stream(streams[k]):
+                engs[k].sample(arr, T, bufs[k].normal_(generator=gens[k]))
+        barrier()
+        if rep:
+            times.append(max_over_ranks(time.perf_counter() - t0))
+    times.sort()
+    dt = times[len(times) // 2]
+    return {"batches_in_flight": L, "value": world * L * B * T / dt, "unit": "sample-steps/s", "wall_ms": dt * 1e3,
+            "repetitions_ms": [round(t * 1e3, 3) for t in times],
+            "note": f"{L} independent batches of {B} graphs (other pockets, same shape), each through pf_sample on its own handle and stream"}
 
 
 def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):

@@ -2,8 +2,9 @@
 """Wall-clock of a slice of BASELINE config 4 on one GPU: P synthetic 256-atom pockets x 30 samples (sizes 3,3,3,3,3,4..8
 cycling), T=500, max_batch_size 128, through PharmacophoreDiff.sample (graph copies, batching, set_batch, the fused
 pf_sample loop, unbatching into SampledPharmacophore objects).
-    python tools/config4_slice.py [P] [S]     # S samples per pocket (default 30; 128 = one pocket per batch, the shape of a
-                                              # generate_pharmacophores.py run with --samples_per_pocket 128)"""
+    python tools/config4_slice.py [P] [S] [L]  # S samples per pocket (default 30; 128 = one pocket per batch, the shape of a
+                                               # generate_pharmacophores.py run with --samples_per_pocket 128); L batches in
+                                               # flight (default: PharmacophoreDiff.sample_lanes)"""
 import os
 import sys
 import time
@@ -30,14 +31,15 @@ for i in range(P):
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 sizes = (([3] * 5 + [4, 5, 6, 7, 8]) * 13)[:S]
 n_pharms = [sizes for _ in range(P)]
+LANES = int(sys.argv[3]) if len(sys.argv) > 3 else None
 torch.manual_seed(0)
 with torch.no_grad():
-    m.sample(pockets[:2], n_pharms[:2], max_batch_size=128)          # warm-up
+    m.sample(pockets[:max(2, (LANES or 2))], n_pharms[:max(2, (LANES or 2))], max_batch_size=128, lanes=LANES)          # warm-up (every lane's handle)
     torch.cuda.synchronize()
     t0 = time.time()
-    out = m.sample(pockets, n_pharms, max_batch_size=128)
+    out = m.sample(pockets, n_pharms, max_batch_size=128, lanes=LANES)
     torch.cuda.synchronize()
     dt = time.time() - t0
 n = sum(len(o) for o in out)
-print(f"{P} pockets x {S} samples = {n} pharmacophores, T={T}: {dt:.2f} s  ->  {n * T / dt / 1e3:.0f} k sample-steps/s end to end, "
+print(f"[{LANES or m.sample_lanes} lane(s)] {P} pockets x {S} samples = {n} pharmacophores, T={T}: {dt:.2f} s  ->  {n * T / dt / 1e3:.0f} k sample-steps/s end to end, "
       f"{dt / P * 1e3:.0f} ms per pocket")
