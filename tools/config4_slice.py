@@ -32,14 +32,16 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 sizes = (([3] * 5 + [4, 5, 6, 7, 8]) * 13)[:S]
 n_pharms = [sizes for _ in range(P)]
 LANES = int(sys.argv[3]) if len(sys.argv) > 3 else None
+MAXB = int(os.environ.get("MAXB", "128"))          # max_batch_size
 torch.manual_seed(0)
 with torch.no_grad():
-    m.sample(pockets[:max(2, (LANES or 2))], n_pharms[:max(2, (LANES or 2))], max_batch_size=128, lanes=LANES)          # warm-up (every lane's handle)
+    nw = min(P, max(2, 4 * ((S * 4 + MAXB - 1) // MAXB) // max(S, 1) + 4))       # enough batches to create every lane's handle outside the timed run
+    m.sample(pockets[:nw], n_pharms[:nw], max_batch_size=MAXB, lanes=LANES)
     torch.cuda.synchronize()
     t0 = time.time()
-    out = m.sample(pockets, n_pharms, max_batch_size=128, lanes=LANES)
+    out = m.sample(pockets, n_pharms, max_batch_size=MAXB, lanes=LANES)
     torch.cuda.synchronize()
     dt = time.time() - t0
 n = sum(len(o) for o in out)
-print(f"[{LANES or m.sample_lanes} lane(s)] {P} pockets x {S} samples = {n} pharmacophores, T={T}: {dt:.2f} s  ->  {n * T / dt / 1e3:.0f} k sample-steps/s end to end, "
+print(f"[{LANES or m.sample_lanes or 'auto'} lane(s), batches of {MAXB}] {P} pockets x {S} samples = {n} pharmacophores, T={T}: {dt:.2f} s  ->  {n * T / dt / 1e3:.0f} k sample-steps/s end to end, "
       f"{dt / P * 1e3:.0f} ms per pocket")
