@@ -74,6 +74,12 @@ def main():
                          "(steps / 10)-th for long runs; the sample is topped up to 20 launches after the timed region)")
     ap.add_argument("--no-full-trajectory", action="store_true", help="skip the whole-schedule pf_sample leg")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel device time to stderr")
+    ap.add_argument("--sample-slice", type=int, default=0, metavar="P",
+                    help="secondary benchmark (a slice of BASELINE config 4): P synthetic pockets per GPU x --samples pharmacophores "
+                         "each (sizes 3..8), T=500, through PharmacophoreDiff.sample end to end (copies, batching, binds, the fused "
+                         "reverse process, unbatching into SampledPharmacophore objects); pockets are dealt over the ranks by work")
+    ap.add_argument("--samples", type=int, default=30, help="--sample-slice: pharmacophores per pocket")
+    ap.add_argument("--max-batch-size", type=int, default=128, help="--sample-slice: graphs per batch")
     ap.add_argument("--lanes", type=int, default=2,
                     help="full-trajectory leg: also report the throughput with this many independent batches in flight (own handle "
                          "and HIP stream each; 1: skip)")
@@ -110,6 +116,11 @@ def main():
 
     if args.train:
         train_leg(args, pfa, synthetic, dev, rank, world, backend, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if args.sample_slice > 0:
+        slice_leg(args, pfa, synthetic, dev, rank, world, backend, dist)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -351,6 +362,60 @@ def batches_in_flight(args, factory, coef, dev, rank, world, B, T, Nf, barrier, 
     return {"batches_in_flight": L, "value": world * L * B * T / dt, "unit": "sample-steps/s", "wall_ms": dt * 1e3,
             "repetitions_ms": [round(t * 1e3, 3) for t in times],
             "note": f"{L} independent batches of {B} graphs (other pockets, same shape), each through pf_sample on its own handle and stream"}
+
+
+def slice_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
+    """A slice of BASELINE config 4 (dataset-scale sampling: every pocket x 30 pharmacophores, T = 500): wall time of
+    PharmacophoreDiff.sample over P x world synthetic pockets -- what test.py / generate_pharmacophores.py spend their time in.
+    One JSON line; value = pharmacophores x T / wall, max over ranks."""
+    P, S, T = args.sample_slice, args.samples, args.timesteps
+    dyn = dict(vector_size=16, n_convs=2, n_hidden_scalars=128, message_norm='mean', dropout=0.1, ff_k=0, pf_k=5,
+               n_message_gvps=3, n_update_gvps=2, n_noise_gvps=4)
+    cut = {'pp': 3.5, 'pf': 8, 'fp': 8, 'ff': 9}
+    m = pfa.PharmacophoreDiff(6, 11, pfa.analysis.ph_idx_to_type, None, n_timesteps=T, graph_config={'graph_cutoffs': cut},
+                              dynamics_config=dyn, precision=1e-5)
+    sd = dict(synthetic.make_state_dict(0))
+    sd["gamma.gamma"] = m.state_dict()["gamma.gamma"]
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    pockets = []
+    for i in range(P * world):                                   # every rank builds the whole list; sample() deals the batches
+        x, h = synthetic.synthetic_pocket(i, args.n_prot)
+        pockets.append(pfa.build_initial_complex_graph(x, h, cutoffs=cut, pharm_atom_positions=torch.zeros(1, 3),
+                                                       pharm_atom_features=torch.zeros(1, 6)))
+    sizes = (([3] * 5 + [4, 5, 6, 7, 8]) * (S // 10 + 1))[:S]
+    n_pharms = [sizes for _ in pockets]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    with torch.no_grad():
+        torch.manual_seed(0)
+        m.sample(pockets[:min(len(pockets), 8)], n_pharms[:min(len(pockets), 8)], max_batch_size=args.max_batch_size)   # handles, tables
+        barrier()
+        torch.manual_seed(0)
+        t0 = time.perf_counter()
+        out = m.sample(pockets, n_pharms, max_batch_size=args.max_batch_size, rank=rank, world_size=world)
+        barrier()
+        dt = time.perf_counter() - t0
+    n = sum(len(o) for o in out)
+    tt = torch.tensor([dt, float(n)], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+    if world > 1:
+        mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt, n = float(mx[0]), int(sm[1])
+    if rank == 0:
+        print(json.dumps({
+            "metric": "denoising steps/sec end to end through PharmacophoreDiff.sample (config-4 slice)", "value": n * T / dt,
+            "unit": "sample-steps/s", "n_gpus": world, "steps": T, "warmup": 0, "ms_per_step": dt / T * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 4 slice: {P} pockets per GPU x {S} pharmacophores (sizes 3-8), {args.n_prot}-atom "
+                                   f"pockets, T={T}, max_batch_size {args.max_batch_size}, dev.yml network",
+                       "pockets": P * world, "pharmacophores": n, "wall_s": dt, "ms_per_pocket": dt / max(P, 1) * 1e3,
+                       "batches_in_flight": "auto (2; 4 for batches of <= 32 graphs)" if m.sample_lanes is None else m.sample_lanes,
+                       "parallelism": f"batches dealt over {world} GPU(s) by work, no data-path collective"}}))
 
 
 def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
