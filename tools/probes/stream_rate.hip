@@ -68,13 +68,13 @@ __global__ void k_lds(const f32x4* __restrict__ tab, int nq, int reps, float* ou
 __global__ void k_evict(f32x4* buf, size_t n) {          // touch 64 MiB: nothing of the table is left in any XCD's L2
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) buf[i] += (f32x4){1.f, 1.f, 1.f, 1.f};
 }
-static f32x4* dtab; static float* dout; static unsigned long long* dcyc; static f32x4* dbig; static int g_evict = 0;
+static f32x4* dtab; static float* dout; static unsigned long long* dcyc; static f32x4* dbig; static int g_evict = 0; static size_t g_evict_bytes = (size_t)64 << 20;
 static double median(std::vector<unsigned long long>& v) { std::sort(v.begin(), v.end()); return (double)v[v.size() / 2]; }
 
 template <int D, int SPLIT, int POLICY> static void run(int G, int W, int nq, int reps, const char* tag) {
     hipLaunchKernelGGL((k_stream<D, SPLIT, POLICY>), dim3(G), dim3(64 * W), 0, 0, dtab, nq, reps, dout, dcyc);   // warm: L2, i-cache
     hipDeviceSynchronize();
-    if (g_evict) { hipLaunchKernelGGL(k_evict, dim3(2048), dim3(256), 0, 0, dbig, (size_t)(64 << 20) / 16); if (g_evict == 2) hipDeviceSynchronize(); }
+    if (g_evict) { hipLaunchKernelGGL(k_evict, dim3(2048), dim3(256), 0, 0, dbig, g_evict_bytes / 16); if (g_evict == 2) hipDeviceSynchronize(); }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
     hipLaunchKernelGGL((k_stream<D, SPLIT, POLICY>), dim3(G), dim3(64 * W), 0, 0, dtab, nq, reps, dout, dcyc);
@@ -141,6 +141,14 @@ int main(int argc, char** argv) {
                 run<12, 0, 0>(G, 4, nq2, 1, "4 waves, same order");
             }
         }
+    }
+    // how much other traffic between two uses does it take to push a 288-quad table out of the XCDs' L2s (4 MiB each; the sweep is
+    // spread over the eight of them)?
+    g_evict = 1;
+    for (size_t mib : {1, 2, 4, 8, 16, 24, 32, 48, 64}) {
+        g_evict_bytes = mib << 20;
+        printf("--- %zu MiB swept by another kernel in between (%.2f MiB per XCD): ", mib, mib / 8.0);
+        run<12, 0, 0>(256, 1, 288, 1, "one wave per workgroup");
     }
     return 0;
 }
