@@ -57,6 +57,7 @@ void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float
 void pfk_loss_prepare(const LossParams* p, hipStream_t s);
 void pfk_loss_eval(const LossParams* p, hipStream_t s);
 void pfk_scale_by(float* g, int n, const float* scale, hipStream_t s);
+void pfk_compact_units(const NodeTile* tiles, int ntiles, const int* dyn_cnt, int* ulist, int* ucnt, hipStream_t s);
 void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s);
 void pfk_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
               float bc1, float bc2_sqrt, hipStream_t s);
@@ -262,6 +263,7 @@ struct pf_handle {
     uint64_t wpack_version = ~0ull;
     float *t_lx0c = nullptr, *t_lag = nullptr, *t_lsg = nullptr, *t_lgx = nullptr, *t_lgh = nullptr, *t_lout = nullptr;   // pf_train_loss_forward
     bool t_have_loss = false;
+    int* t_ulist = nullptr;                 // compact list of non-empty node units of the layer being differentiated (count: t_ccnt[32])
     int *t_clist = nullptr, *t_ccnt = nullptr;   // compact list of non-empty edge tiles of the layer being differentiated
     float* t_fix = nullptr;                 // [2] scale / inverse scale of the current backward call
     int t_nblk = 0;
@@ -1938,6 +1940,7 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     need(64);
     need(64); need((size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);      // compact tile list and its counts
     need((size_t)PFT_ENC_BLOCKS * std::max(h->enc_n, 1));
+    need((size_t)2 * std::max(h->n_node_tiles, h->n_node_tiles_act) + 64);
     need((size_t)h->Nf * 3); need((size_t)h->B); need((size_t)h->B); need((size_t)h->Nf * 3); need((size_t)h->Nf * c.pharm_nf); need(64);   // loss buffers
     need((size_t)h->t_nblk * h->nparams);
     const size_t Es = (size_t)std::max<int64_t>(h->Ecap, 1), ng = (size_t)c.n_message_gvps;
@@ -1966,6 +1969,7 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     h->t_ccnt = carve<int>(cur, 64);
     h->t_clist = carve<int>(cur, (size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);
     h->t_gpart_enc = carve<float>(cur, (size_t)PFT_ENC_BLOCKS * std::max(h->enc_n, 1));
+    h->t_ulist = carve<int>(cur, (size_t)2 * std::max(h->n_node_tiles, h->n_node_tiles_act) + 64);
     h->t_lx0c = carve<float>(cur, (size_t)h->Nf * 3); h->t_lag = carve<float>(cur, (size_t)h->B); h->t_lsg = carve<float>(cur, (size_t)h->B);
     h->t_lgx = carve<float>(cur, (size_t)h->Nf * 3); h->t_lgh = carve<float>(cur, (size_t)h->Nf * c.pharm_nf); h->t_lout = carve<float>(cur, 64);
     PF_HIP(h, hipMemsetAsync(h->t_A_h, 0, (size_t)N * PF_S * 8, s));       // pfk_fix_apply keeps them clear afterwards
@@ -2193,6 +2197,8 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
             n.o_ln[nt][2] = (int)h->flat_offset(p2 + "weight"); n.o_ln[nt][3] = (int)h->flat_offset(p2 + "bias");
         }
         n.layer = l; n.l0 = l == 0;
+        n.ulist = h->t_ulist; n.ucnt = h->t_ccnt + 32;
+        pfk_compact_units(n.tiles, n.ntiles, h->d_dyn_cnt, h->t_ulist, h->t_ccnt + 32, s);
         rp.node_grid[l] = n.ntiles > 0 ? std::max(1, std::min(nb, 2 * n.ntiles)) : 0;
         { ProfScope ps(h, pf_handle::K_BWD_NODE, s); pfk_bwd_node(&n, rp.node_grid[l], s); }
         BwdEdgeLevelParams e{};

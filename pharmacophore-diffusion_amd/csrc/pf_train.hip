@@ -565,7 +565,11 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
     const PackPtr pk = {p.c.wpack_f, p.c.wpack_b};
     bool seen[2] = {false, false};          // weight-gradient tiles of a node type: the first unit stores onto the cleared copy without reading it
     const uint32_t st_msg = (uint32_t)p.layer * 2u, st_res = st_msg + 1u;
-    for (int unit = blockIdx.x; unit < 2 * p.ntiles; unit += gridDim.x) {
+    // the non-empty 16-row units of the launch, dealt round-robin (k_compact_units): dealt by table index, the units of the
+    // active-atom tiles (capacity 256 atoms per graph, ~60 in use) left every other block with half as much again to do
+    const int nunits = p.ucnt[0];
+    for (int ui = blockIdx.x; ui < nunits; ui += gridDim.x) {
+        const int unit = p.ulist[ui];
         const NodeTile t = p.tiles[unit >> 1];
         const int nt = t.ntype;
         const GvpT* g = p.upd + nt * p.n_upd;
@@ -796,6 +800,31 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
 // the non-empty tiles of each etype's segment of a tile table, in table order: clist[et_tile0[et] - et_tile0[0] + i], ccnt[et]
 // (a dynamic region's tiles cover its capacity; a backward block that is dealt tiles by table index gets whatever share
 // of the empty ones the layout gives it -- the ff blocks of config 5 walked four times the tiles of the pp blocks)
+// non-empty 16-row units (tile, half) of a node tile table, in table order
+__global__ __launch_bounds__(256) void k_compact_units(const NodeTile* tiles, const int ntiles, const int* dyn_cnt, int* ulist, int* ucnt) {
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int base = 0;
+    for (int c = 0; c < 2 * ntiles; c += 256) {
+        const int u = c + tid;
+        bool ne = false;
+        if (u < 2 * ntiles) {
+            const NodeTile t = tiles[u >> 1];
+            int n = t.n;
+            if (t.cnt_idx >= 0) n = min(n, max(dyn_cnt[t.cnt_idx] - t.rel, 0));
+            ne = (u & 1) * TR < n;
+        }
+        const unsigned long long m = __ballot(ne);
+        if (lane == 0) s_w[wv] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; ++w) off += s_w[w];
+        if (ne) ulist[off + __popcll(m & ((1ull << lane) - 1ull))] = u;
+        base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (tid == 0) ucnt[0] = base;
+}
 struct CompactParams { int et_tile0[5]; };
 __global__ __launch_bounds__(256) void k_compact_tiles(const EdgeTile* tiles, const CompactParams cp, const int* dyn_cnt, int* clist, int* ccnt) {
     __shared__ int s_w[4];
@@ -1640,6 +1669,9 @@ void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s) {
 void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, int nblocks, hipStream_t s) {
     if (nblocks == 0 || p->et_tile0[p->n_et] == p->et_tile0[0]) return;
     hipLaunchKernelGGL(k_bwd_edge_level, dim3(nblocks), dim3(NT), 0, s, *p);
+}
+void pfk_compact_units(const NodeTile* tiles, int ntiles, const int* dyn_cnt, int* ulist, int* ucnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_compact_units, dim3(1), dim3(256), 0, s, tiles, ntiles, dyn_cnt, ulist, ucnt);
 }
 void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s) {
     CompactParams cp;
