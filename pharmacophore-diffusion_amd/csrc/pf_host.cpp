@@ -1317,9 +1317,13 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     // pp edges sorted by destination (stable counting sort): CSR-by-dst
     std::vector<int> in_start((size_t)4 * N, 0), in_cnt((size_t)4 * N, 0);       // [4 slots][N]: BuildParams::in_start
     std::vector<int> deg(Np + 1, 0);
+    bool dst_sorted = true;                    // radius_graph and pf_build_pp_edges emit the edges grouped by destination, ascending:
+    int prev_dst = -1;                         // the stable sort below is then the identity and is skipped
     for (int64_t e = 0; e < n_pp; ++e) {
         if (pp_src[e] < 0 || pp_src[e] >= Np || pp_dst[e] < 0 || pp_dst[e] >= Np) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld out of range", (long long)e);
         if (gid[pp_src[e]] != gid[pp_dst[e]]) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld crosses graphs", (long long)e);
+        dst_sorted &= pp_dst[e] >= prev_dst;
+        prev_dst = pp_dst[e];
         deg[pp_dst[e] + 1]++;
     }
     for (int i = 0; i < Np; ++i) deg[i + 1] += deg[i];
@@ -1371,12 +1375,17 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     const int64_t Ecap = std::max<int64_t>(cursor, 1);
     std::vector<int> esrc(Ecap, 0), edst(Ecap, 0);
     {
-        std::vector<int> fill(deg.begin(), deg.end() - 1);
-        for (int64_t e = 0; e < n_pp; ++e) {
-            const int pos = fill[pp_dst[e]]++;
-            esrc[pos] = pp_src[e];
-            edst[pos] = pp_dst[e];
-            pp_cnt[gid[pp_dst[e]]]++;
+        if (dst_sorted) {
+            if (n_pp > 0) { memcpy(esrc.data(), pp_src, (size_t)n_pp * 4); memcpy(edst.data(), pp_dst, (size_t)n_pp * 4); }
+            for (int g = 0; g < B; ++g) pp_cnt[g] = deg[prot_ptr[g + 1]] - deg[prot_ptr[g]];
+        } else {
+            std::vector<int> fill(deg.begin(), deg.end() - 1);
+            for (int64_t e = 0; e < n_pp; ++e) {
+                const int pos = fill[pp_dst[e]]++;
+                esrc[pos] = pp_src[e];
+                edst[pos] = pp_dst[e];
+                pp_cnt[gid[pp_dst[e]]]++;
+            }
         }
         for (int i = 0; i < Np; ++i) { in_start[(size_t)N + i] = deg[i]; in_cnt[(size_t)N + i] = deg[i + 1] - deg[i]; }
     }

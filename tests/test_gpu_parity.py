@@ -186,6 +186,15 @@ def test_properties_translation_rotation_batch_independence():
     f0, f1 = int(batch.pharm_ptr[2]), int(batch.pharm_ptr[3])
     sh, sx = eng2.dynamics(x_t[f0:f1], h_t[f0:f1], t[2:3])
     close(sh, eh[f0:f1], 1e-4, 1e-4); close(sx, ex[f0:f1], 1e-4, 1e-4)
+    # the pp edges in any order (the bind sorts them by destination, stably; destination-sorted input skips the sort): the edges of
+    # a destination keep their relative order under a stable shuffle by source parity, so the sums are bitwise the same
+    perm = torch.cat([torch.nonzero(batch.pp_src % 2 == 0).flatten(), torch.nonzero(batch.pp_src % 2 == 1).flatten()])
+    assert not bool((batch.pp_dst[perm][1:] >= batch.pp_dst[perm][:-1]).all())
+    shuffled = O.PocketBatch(batch.prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, batch.pp_src[perm], batch.pp_dst[perm])
+    eng3 = engine_for(cfg, sd)
+    set_batch(eng3, shuffled)
+    ph, px = eng3.dynamics(x_t, h_t, t, prot_x=batch.prot_x)
+    close(ph.cpu(), eh, 1e-5, 1e-5); close(px.cpu(), ex, 1e-5, 1e-5)
 
 
 def test_empty_and_degenerate_graphs():
