@@ -639,12 +639,23 @@ class PharmacophoreDiff(_Base):
         n_receptors = len(ref_graphs)
         if init_pharm_com is None:
             init_pharm_com = torch.stack([g.prot_x.mean(dim=0) for g in ref_graphs], dim=0)
-        graphs, graph_ref_idx = [], []
-        for rec_idx, ref_graph in enumerate(ref_graphs):
-            n_rec = n_pharms[rec_idx]
-            graphs.extend(copy_graph(ref_graph, n_copies=len(n_rec), pharm_feats_per_copy=torch.tensor(n_rec)))
-            graph_ref_idx.extend([rec_idx] * len(n_rec))
-        batches = [list(range(s0, min(s0 + max_batch_size, len(graphs)))) for s0 in range(0, len(graphs), max_batch_size)]
+        # the requested graphs in pocket order: (pocket, number of centers); the copies themselves are made batch by batch
+        # inside the pipeline (30,000 graph objects up front cost a dataset-scale run most of a second before the device starts)
+        graph_ref_idx = [rec_idx for rec_idx in range(n_receptors) for _ in n_pharms[rec_idx]]
+        graph_size = [int(n) for rec_idx in range(n_receptors) for n in n_pharms[rec_idx]]
+        n_graphs = len(graph_ref_idx)
+
+        def make_batch(idx):
+            gs, a = [], 0
+            while a < len(idx):                         # runs of one pocket: one copy_graph call each (its copies share a pocket_uid)
+                b = a
+                while b < len(idx) and graph_ref_idx[idx[b]] == graph_ref_idx[idx[a]]:
+                    b += 1
+                gs.extend(copy_graph(ref_graphs[graph_ref_idx[idx[a]]], n_copies=b - a,
+                                     pharm_feats_per_copy=torch.tensor([graph_size[i] for i in idx[a:b]])))
+                a = b
+            return batch_graphs(gs)
+        batches = [list(range(s0, min(s0 + max_batch_size, n_graphs))) for s0 in range(0, n_graphs, max_batch_size)]
         if world_size > 1:
             epp = [int(g.pp_src.numel()) for g in ref_graphs]
             work = [sum(epp[graph_ref_idx[i]] + 1 for i in idx) for idx in batches]
@@ -655,7 +666,7 @@ class PharmacophoreDiff(_Base):
         base_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else 0
         # every graph's initial center of mass on the device with ONE copy before the pipeline starts (a batch is a
         # contiguous range of graphs); per-batch host -> device copies would each wait for the batch in flight
-        coms_dev = init_pharm_com[graph_ref_idx].to(self.device, torch.float32) if graphs else None
+        coms_dev = init_pharm_com[graph_ref_idx].to(self.device, torch.float32) if n_graphs else None
         sampled = {}
         # Pipeline over the batches: the host work of a batch (collating the next one, splitting the previous one's results
         # into SampledPharmacophores) runs while the device works on another batch.  Nothing in it waits for the device
@@ -676,7 +687,7 @@ class PharmacophoreDiff(_Base):
         pending = []                                    # enqueued batches, oldest first: at most n_lanes
         for k, bi in enumerate(mine):
             idx = batches[bi]
-            batch_g = batch_graphs([graphs[i] for i in idx])
+            batch_g = make_batch(idx)
             init_coms = coms_dev[idx[0]:idx[-1] + 1]
             lane = k % n_lanes
             with torch.cuda.stream(streams[lane]):
