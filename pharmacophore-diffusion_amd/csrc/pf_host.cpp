@@ -51,6 +51,7 @@ void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, int nblocks, hipStream_t s)
 void pfk_fix_apply(long long* A, float* G, size_t n, const float* fix, hipStream_t s);
 void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* fix, hipStream_t s);
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
+void pfk_enc_group(const float* G_h, const int* prot_ptr, const int* ptype, int B, int rec_nf, float* Gg, hipStream_t s);
 void pfk_train_reduce(const ReduceParams* p, hipStream_t s);
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s);
 void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float* out_f, hipStream_t s);
@@ -263,6 +264,7 @@ struct pf_handle {
     uint64_t wpack_version = ~0ull;
     float *t_lx0c = nullptr, *t_lag = nullptr, *t_lsg = nullptr, *t_lgx = nullptr, *t_lgh = nullptr, *t_lout = nullptr;   // pf_train_loss_forward
     bool t_have_loss = false;
+    float* t_Gg = nullptr;                  // encoder backward: upstream gradient summed per (graph, element)
     int* t_ulist = nullptr;                 // compact list of non-empty node units of the layer being differentiated (count: t_ccnt[32])
     int *t_clist = nullptr, *t_ccnt = nullptr;   // compact list of non-empty edge tiles of the layer being differentiated
     float* t_fix = nullptr;                 // [2] scale / inverse scale of the current backward call
@@ -1950,6 +1952,7 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     need(64); need((size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);      // compact tile list and its counts
     need((size_t)PFT_ENC_BLOCKS * std::max(h->enc_n, 1));
     need((size_t)2 * std::max(h->n_node_tiles, h->n_node_tiles_act) + 64);
+    need((size_t)h->B * c.rec_nf * PF_S);
     need((size_t)h->Nf * 3); need((size_t)h->B); need((size_t)h->B); need((size_t)h->Nf * 3); need((size_t)h->Nf * c.pharm_nf); need(64);   // loss buffers
     need((size_t)h->t_nblk * h->nparams);
     const size_t Es = (size_t)std::max<int64_t>(h->Ecap, 1), ng = (size_t)c.n_message_gvps;
@@ -1979,6 +1982,7 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     h->t_clist = carve<int>(cur, (size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);
     h->t_gpart_enc = carve<float>(cur, (size_t)PFT_ENC_BLOCKS * std::max(h->enc_n, 1));
     h->t_ulist = carve<int>(cur, (size_t)2 * std::max(h->n_node_tiles, h->n_node_tiles_act) + 64);
+    h->t_Gg = carve<float>(cur, (size_t)h->B * c.rec_nf * PF_S);
     h->t_lx0c = carve<float>(cur, (size_t)h->Nf * 3); h->t_lag = carve<float>(cur, (size_t)h->B); h->t_lsg = carve<float>(cur, (size_t)h->B);
     h->t_lgx = carve<float>(cur, (size_t)h->Nf * 3); h->t_lgh = carve<float>(cur, (size_t)h->Nf * c.pharm_nf); h->t_lout = carve<float>(cur, 64);
     PF_HIP(h, hipMemsetAsync(h->t_A_h, 0, (size_t)N * PF_S * 8, s));       // pfk_fix_apply keeps them clear afterwards
@@ -2249,6 +2253,9 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
             p.o_lw[nt] = (int)h->flat_offset(pre + "2.weight"); p.o_lb[nt] = (int)h->flat_offset(pre + "2.bias");
         }
         p.G_h = h->t_G_h[a];
+        p.B = h->B; p.onehot_flag = h->d_l0flag;
+        p.Gg = (c.rec_nf <= 16 && h->Np > 0) ? h->t_Gg : nullptr;
+        if (p.Gg) pfk_enc_group(p.G_h, h->d_prot_ptr, h->d_ptype, h->B, c.rec_nf, h->t_Gg, s);
         const int tiles = (h->Np + PFT_ROWS - 1) / PFT_ROWS + (h->Nf + PFT_ROWS - 1) / PFT_ROWS;
         rp.enc_grid = std::max(1, std::min(PFT_ENC_BLOCKS, tiles));
         pfk_bwd_encode(&p, rp.enc_grid, s);

@@ -152,6 +152,9 @@ struct BwdEncodeParams {
     int rec_nf, pharm_nf;
     int o_w[2], o_b[2], o_lw[2], o_lb[2];    // 0 prot, 1 pharm
     const float* G_h;                        // gradient w.r.t. the encoder output [N][128]
+    int B;
+    const float* Gg;                         // k_enc_group: G_h summed per (graph, element) [B][rec_nf][128], or NULL (rec_nf > 16)
+    const int* onehot_flag;                  // device: 0 iff every protein feature row is an element one-hot (k_l0_types at bind time)
 };
 
 // the loss around the dynamics (k_loss_prepare / k_loss_eval, pf_train_loss_forward)
