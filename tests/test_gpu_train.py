@@ -116,10 +116,17 @@ EXTRA_CASES = {
 }
 
 
-@pytest.mark.parametrize("name", sorted(EXTRA_CASES))
+@pytest.mark.parametrize("name", sorted(EXTRA_CASES) + ["soft_features"])
 def test_gradients_vs_oracle_more_configs(name):
-    cfg, seeds, n_prot, n_pharm = EXTRA_CASES[name]
+    soft = name == "soft_features"
+    cfg, seeds, n_prot, n_pharm = EXTRA_CASES["large_radius" if soft else name]
     batch = O.synthetic_batch(seeds, n_prot, n_pharm, cfg)
+    if soft:
+        # protein feature rows that are NOT element one-hots: the encoder backward then differentiates every atom on its own
+        # (with one-hots it works on per-(graph, element) sums of the upstream gradient, k_enc_group)
+        g0 = torch.Generator().manual_seed(5)
+        batch = O.PocketBatch(batch.prot_x, batch.prot_h + 0.25 * torch.rand(batch.prot_h.shape, generator=g0), batch.prot_ptr,
+                              batch.pharm_ptr, batch.pp_src, batch.pp_dst)
     sd = O.make_state_dict(cfg, 3)
     eng = make_engine(cfg, sd, batch)
     Np, Nf, B = int(batch.prot_ptr[-1]), int(batch.pharm_ptr[-1]), batch.batch_size
