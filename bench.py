@@ -327,8 +327,11 @@ def full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_ov
     dt = times[len(times) // 2]
     wk = eng.work_detail()
     lanes = None
-    if args.lanes > 1:
-        lanes = batches_in_flight(args, eng2_factory, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, arr)
+    if args.lanes > 1 and world == 1 and eng2_factory is not None:      # informational leg, single-rank runs only; never costs the line
+        try:
+            lanes = batches_in_flight(args, eng2_factory, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, arr)
+        except Exception as e:                                          # (e.g. no memory for the extra handles)
+            lanes = {"error": f"{type(e).__name__}: {e}"}
     return {"lanes": lanes, "value": world * B * T / dt, "unit": "sample-steps/s", "T": T, "wall_ms": dt * 1e3, "ms_per_step": dt / T * 1e3,
             "repetitions_ms": [round(t * 1e3, 3) for t in times], "finite": bool(torch.isfinite(x0).all() and torch.isfinite(h0).all()),
             "max_abs_coordinate": float(x0.abs().max()),
