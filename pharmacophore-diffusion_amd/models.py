@@ -637,6 +637,8 @@ class PharmacophoreDiff(_Base):
         from .sharding import shard_by_work
         ref_graphs = [as_pocket_graph(g) for g in ref_graphs]
         n_receptors = len(ref_graphs)
+        if n_receptors == 0:
+            return []
         if init_pharm_com is None:
             init_pharm_com = torch.stack([g.prot_x.mean(dim=0) for g in ref_graphs], dim=0)
         # the requested graphs in pocket order: (pocket, number of centers); the copies themselves are made batch by batch

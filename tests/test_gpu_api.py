@@ -228,6 +228,39 @@ def test_sample_multi_pocket_matches_reference_golden():
         assert a[0] == b[0] and all(abs(float(u) - float(v)) <= 6e-3 for u, v in zip(a[1:], b[1:])), (a, b)
 
 
+def test_sample_lanes_edge_cases():
+    """sample() with batches in flight on several handles: empty requests, fewer batches than lanes, trajectories -- counts,
+    sizes, and bitwise the results of one lane."""
+    m = make_model(20)
+    cfg = O.DynamicsConfig()
+    pockets = []
+    for i in range(5):
+        b = O.synthetic_batch([900 + i], 40 + 30 * i, 1, cfg)
+        pockets.append(pfa.PocketGraph(b.prot_x, b.prot_h, b.prot_ptr, b.pharm_ptr, b.pp_src, b.pp_dst, torch.zeros(1, 3), torch.zeros(1, 6)))
+    cases = [("no pockets", [], [], 8, None),
+             ("one pocket, one sample", pockets[:1], [[3]], 8, None),
+             ("one pocket, empty request", pockets[:1], [[]], 8, None),
+             ("mixed empty", pockets[:3], [[4, 5], [], [1]], 2, None),
+             ("many tiny batches, four lanes", pockets, [[3, 4, 5, 6, 7, 8, 1]] * 5, 3, 4),
+             ("more lanes than batches", pockets[:2], [[3], [4]], 1, 7),
+             ("trajectories", pockets[:2], [[3, 4], [5]], 2, 2)]
+    with torch.no_grad():
+        for desc, ps, ns, mb, lanes in cases:
+            traj = desc == "trajectories"
+            torch.manual_seed(1)
+            out = m.sample(ps, ns, max_batch_size=mb, lanes=lanes, visualize_trajectory=traj)
+            assert [len(o) for o in out] == [len(n) for n in ns], desc
+            assert all(p.n_ph_centers == k for o, n in zip(out, ns) for p, k in zip(o, n)), desc
+            assert all(torch.isfinite(p.ph_coords).all() for o in out for p in o), desc
+            torch.manual_seed(1)
+            ref = m.sample(ps, ns, max_batch_size=mb, lanes=1, visualize_trajectory=traj)
+            for o, r in zip(out, ref):
+                for p, q in zip(o, r):
+                    assert torch.equal(p.ph_coords, q.ph_coords) and torch.equal(p.ph_feats_idxs, q.ph_feats_idxs), desc
+                    if traj:
+                        assert torch.equal(p.pos_frames, q.pos_frames), desc
+
+
 def test_bind_graph_rebinds_look_alike_batches():
     """Two batches with the same totals (same pocket, center counts [3, 5] vs [5, 3]) passed as temporaries: the second
     call must not run on the first batch's graph boundaries (the cache key holds the ptr contents and the module keeps
