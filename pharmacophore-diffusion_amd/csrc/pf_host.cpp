@@ -166,6 +166,7 @@ struct pf_handle {
     long share_rows = 0;                    // edge slots of a shared layer-0 launch (capacities of ff, pf, fp + the static ranges)
     std::vector<int> h_share_start, h_share_cnt;   // host copies of d_reg_share's kind-3 entries / d_pa_static (grid sizing)
     bool share_disable = false;             // PFDYN_NO_POCKET_SHARE=1
+    bool train_rg_node = true;              // PFDYN_TRAIN_TILE_NODE=1: the training forward keeps the 32-row tile node kernel
     bool sampling = false;
     int max_np = 0;                         // largest pocket of the batch
     bool edges_built = false;               // the dynamic edges of the current coordinates exist (built by k_step_build)
@@ -235,6 +236,7 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_RG2_ROWS_MIN_HOIST")) rg2_rows_min_hoist = atoi(e);
         if (const char* e = getenv("PFDYN_NO_L0_HOIST")) l0_hoist = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_POCKET_SHARE")) share_disable = atoi(e) != 0;
+        if (const char* e = getenv("PFDYN_TRAIN_TILE_NODE")) train_rg_node = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_L0_RGP")) l0_rgp = atoi(e);
         if (const char* e = getenv("PFDYN_L0_RGA")) l0_rga = atoi(e);
     }
@@ -895,6 +897,13 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             hp.eps_h = eps_h; hp.eps_x = eps_x;
             { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_node_head_coop(&n, &hp, l == 0, s); }
             head_done = true;
+        }
+        else if (train && h->train_rg_node && h->rg_mode(n.ntiles) > 0) {
+            // training forward: the row-group node kernel (with the two GVPDropout sites) on the tile edge kernels' partial rows
+            // (one per 32-slot tile and destination: grp = 32); the layer input comes from memory, as the backward kernels read it
+            n.grp = 32; n.grp_pa = 32;
+            ProfScope ps(h, pf_handle::K_NODE_COOP, s);
+            pfk_rg_node(&n, nullptr, nullptr, l == 0, h->rg_mode(n.ntiles), 0, s);
         }
         else if (n.ntiles <= h->coop_node_max && !train) { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_node_update_coop(&n, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_NODE, s); pfk_node_update(&n, l == 0, s); }
