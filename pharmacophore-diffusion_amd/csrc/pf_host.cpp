@@ -167,6 +167,8 @@ struct pf_handle {
     std::vector<int> h_share_start, h_share_cnt;   // host copies of d_reg_share's kind-3 entries / d_pa_static (grid sizing)
     bool share_disable = false;             // PFDYN_NO_POCKET_SHARE=1
     bool train_rg_node = true;              // PFDYN_TRAIN_TILE_NODE=1: the training forward keeps the 32-row tile node kernel
+    bool train_rg_edge = true;              // PFDYN_TRAIN_TILE_EDGE=1: ... and the 32-slot tile edge kernel
+    std::vector<int> t_grp;                 // per conv layer: slots per message partial-row group of the last training forward
     bool sampling = false;
     int max_np = 0;                         // largest pocket of the batch
     bool edges_built = false;               // the dynamic edges of the current coordinates exist (built by k_step_build)
@@ -237,6 +239,7 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_NO_L0_HOIST")) l0_hoist = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_POCKET_SHARE")) share_disable = atoi(e) != 0;
         if (const char* e = getenv("PFDYN_TRAIN_TILE_NODE")) train_rg_node = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_TRAIN_TILE_EDGE")) train_rg_edge = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_L0_RGP")) l0_rgp = atoi(e);
         if (const char* e = getenv("PFDYN_L0_RGA")) l0_rga = atoi(e);
     }
@@ -820,7 +823,8 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             if (shared) { e.need = h->d_need; e.need_stamp = h->edges_stamp; }
             for (int r = 0; r < e.nreg; ++r) { e.ngroups4 += region_groups(r, 4); e.ngroups8 += region_groups(r, 8); }
         }
-        int rg = train ? 0 : h->rg_mode(shared ? (int)((h->share_rows + 31) / 32) : e.ntiles);           // the node launch of this layer follows (partial-row grouping)
+        int rg = train ? ((h->train_rg_edge && h->train_rg_node) ? h->rg_mode(e.ntiles) : 0)
+                       : h->rg_mode(shared ? (int)((h->share_rows + 31) / 32) : e.ntiles);           // the node launch of this layer follows (partial-row grouping)
         // static hoist: the hoisted ("pa") items of a compact layer-0 launch run a two-block chain and may take 8 rows
         // per wave while the full-chain items (ff, pf, fp) take 4
         int rgp = 0;
@@ -870,6 +874,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         n.n_upd = c.n_update_gvps;
         n.grp = rg ? 4 * rg : 32;
         n.grp_pa = rgp ? 4 * rgp : n.grp;
+        if (train) { h->t_grp.resize(c.n_convs); h->t_grp[l] = n.grp; }
         for (int nt = 0; nt < 2; ++nt) n.rg_upd[nt] = h->d_w + h->rg_upd[(size_t)l * 2 + nt];
         for (int nt = 0; nt < 2; ++nt) {
             n.rgs_upd[nt] = h->d_w + h->rgs_upd[(size_t)l * 2 + nt];
@@ -877,8 +882,8 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         }
         if (rg) {
             const int rgn = std::max(1, h->rg_mode(n.ntiles));
-            const int nsplit = (rgn == 1 && n.ntiles * 8 <= h->rg_split_max) ? 1 : 0;
-            if (last && h->fuse_head && h->n_head_tiles == n.ntiles) {
+            const int nsplit = (!train && rgn == 1 && n.ntiles * 8 <= h->rg_split_max) ? 1 : 0;
+            if (last && !train && h->fuse_head && h->n_head_tiles == n.ntiles) {
                 HeadParams hp{};
                 hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
                 hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
@@ -2219,6 +2224,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
             n.o_ln[nt][2] = (int)h->flat_offset(p2 + "weight"); n.o_ln[nt][3] = (int)h->flat_offset(p2 + "bias");
         }
         n.layer = l; n.l0 = l == 0;
+        n.grp = (int)h->t_grp.size() > l ? h->t_grp[l] : 32;
         n.ulist = h->t_ulist; n.ucnt = h->t_ccnt + 32;
         pfk_compact_units(n.tiles, n.ntiles, h->d_dyn_cnt, h->t_ulist, h->t_ccnt + 32, s);
         rp.node_grid[l] = n.ntiles > 0 ? std::max(1, std::min(nb, 2 * n.ntiles)) : 0;

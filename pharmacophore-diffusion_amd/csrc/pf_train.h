@@ -93,6 +93,7 @@ struct BwdNodeParams {
     const GvpT* upd; int n_upd;              // device table [2 ntypes][n_upd]
     int o_ln[2][4];                          // ln1_w ln1_b ln2_w ln2_b per node type
     int layer, l0;
+    int grp;                                 // slots per partial-row group of the forward's edge kernel (32: tile kernel; 4 / 8: row groups)
 };
 
 struct BwdEdgeParams {

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                     const float sc = (p.norm_mode == 0 && c > 0) ? 1.0f / (float)c : 1.0f;
                     int e = st;
                     while (e < st + c) {
-                        const int r = min(e | 31, st + c - 1);
+                        const int r = min(e | (p.grp - 1), st + c - 1);
                         const float4 a = reinterpret_cast<const float4*>(p.msg_s + (size_t)r * PF_S)[part * 2];
                         const float4 b = reinterpret_cast<const float4*>(p.msg_s + (size_t)r * PF_S)[part * 2 + 1];
                         ms[0] = fmaf(a.x, sc, ms[0]); ms[1] = fmaf(a.y, sc, ms[1]); ms[2] = fmaf(a.z, sc, ms[2]); ms[3] = fmaf(a.w, sc, ms[3]);

@@ -187,10 +187,11 @@ def test_pruned_and_dense_training_agree(name, monkeypatch):
 
 
 @pytest.mark.parametrize("name", sorted(GRAD_CASES))
-def test_training_forward_node_kernel_families_agree(name, monkeypatch):
-    """The training forward runs its node updates on the row-group kernel (k_rg_node with the two GVPDropout sites) by default
-    and on the 32-row tile kernel (k_node_update) when PFDYN_TRAIN_TILE_NODE=1 or the batch is beyond the row-group policy: same
-    dropout masks (one hash), outputs and gradients equal up to summation order."""
+def test_training_forward_kernel_families_agree(name, monkeypatch):
+    """The training forward runs on the row-group kernels by default (k_rg_edge<., SAVE> writing the per-level rows of the
+    backward pass, k_rg_node with the two GVPDropout sites); PFDYN_TRAIN_TILE_EDGE=1 keeps the 32-slot tile edge kernel
+    (k_edge_msg<., SAVE>) under the row-group node kernel, PFDYN_TRAIN_TILE_NODE=1 (or a batch beyond the row-group policy)
+    the tile kernels for both: same dropout masks (one hash), outputs and gradients equal up to summation order."""
     z = load(name)
     cfg = GRAD_CASES[name]
     batch = batch_from(z)
@@ -199,12 +200,15 @@ def test_training_forward_node_kernel_families_agree(name, monkeypatch):
     gen = torch.Generator().manual_seed(6)
     w_h, w_x = torch.randn(h_t.shape, generator=gen), torch.randn(x_t.shape, generator=gen)
     res = []
-    for tile in (False, True):
-        if tile:
-            monkeypatch.setenv("PFDYN_TRAIN_TILE_NODE", "1")
+    for var in (None, "PFDYN_TRAIN_TILE_EDGE", "PFDYN_TRAIN_TILE_NODE"):
+        if var:
+            monkeypatch.setenv(var, "1")
         eng = make_engine(cfg, sd, batch)
         eh, ex = eng.train_forward(x_t, h_t, t, prot_x=prot_x, dropout=0.15, seed=321)
         res.append((eh.cpu(), ex.cpu(), flat_to_dict(eng, eng.train_backward(w_h, w_x))))
-    torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-4, atol=2e-4)
-    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-4, atol=2e-4)
-    compare(res[0][2], {k: v for k, v in res[1][2].items()}, 2e-3, name)
+        if var:
+            monkeypatch.delenv(var)
+    for other in res[1:]:
+        torch.testing.assert_close(res[0][0], other[0], rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(res[0][1], other[1], rtol=2e-4, atol=2e-4)
+        compare(res[0][2], {k: v for k, v in other[2].items()}, 2e-3, name)
