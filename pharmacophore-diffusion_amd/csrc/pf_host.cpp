@@ -261,6 +261,9 @@ struct pf_handle {
     float *t_G_h[2] = {nullptr, nullptr}, *t_G_v[2] = {nullptr, nullptr}, *t_gagg_s = nullptr, *t_gagg_v = nullptr,
           *t_gpart = nullptr, *t_geps_h = nullptr, *t_geps_x = nullptr;
     long long *t_A_h = nullptr, *t_A_v = nullptr;      // fixed-point accumulators of the level-0 scatter (kept clear between uses)
+    void* d_tA = nullptr;                   // their own allocation: it outlives the batches, so "kept clear" holds across them
+    size_t tA_capacity = 0;                 // bytes
+    bool tA_dirty = false;                  // a backward pass stopped between the scatter and pfk_fix_apply
     int enc_begin = 0, enc_n = 0;           // flat range of the encoders' parameters (contiguous: the first tensors of the state dict)
     float* t_gpart_enc = nullptr;
     TensorSeg* d_tseg = nullptr; int n_tseg = 0;   // class of every parameter tensor (pf_train.h: which gradient copies hold it)
@@ -595,6 +598,7 @@ static void pack_out_rg(pf_handle* h, std::vector<float>& out) {
 static void free_ws(pf_handle* h, bool keep_ws = false) {
     if (h->d_ws && !keep_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; }
     if (h->d_tws && !keep_ws) { (void)hipFree(h->d_tws); h->d_tws = nullptr; h->tws_capacity = 0; }
+    if (h->d_tA && !keep_ws) { (void)hipFree(h->d_tA); h->d_tA = nullptr; h->tA_capacity = 0; }
     h->t_ws_ready = false;
     h->t_have_fwd = false;
     h->t_mask_override = nullptr;
@@ -1961,7 +1965,6 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     for (int l = 0; l < L; ++l) { need(E1 * PF_S); need(E1 * 48); }
     for (int a = 0; a < 2; ++a) { need((size_t)N * PF_S); need((size_t)N * 48); }
     need((size_t)N * PF_S); need((size_t)N * 48);
-    need((size_t)2 * N * PF_S); need((size_t)2 * N * 48);          // int64 accumulators (two floats per element)
     need(64);
     need(64); need((size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);      // compact tile list and its counts
     need((size_t)PFT_ENC_BLOCKS * std::max(h->enc_n, 1));
@@ -1989,8 +1992,21 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     for (int l = 0; l < L; ++l) { h->t_msg_s[l] = carve<float>(cur, E1 * PF_S); h->t_msg_v[l] = carve<float>(cur, E1 * 48); }
     for (int a = 0; a < 2; ++a) { h->t_G_h[a] = carve<float>(cur, (size_t)N * PF_S); h->t_G_v[a] = carve<float>(cur, (size_t)N * 48); }
     h->t_gagg_s = carve<float>(cur, (size_t)N * PF_S); h->t_gagg_v = carve<float>(cur, (size_t)N * 48);
-    h->t_A_h = reinterpret_cast<long long*>(carve<float>(cur, (size_t)2 * N * PF_S));
-    h->t_A_v = reinterpret_cast<long long*>(carve<float>(cur, (size_t)2 * N * 48));
+    {
+        // int64 accumulators [N][128] and [N][48]: cleared when allocated, pfk_fix_apply leaves every element it read at zero
+        const size_t a_bytes = ((size_t)N * PF_S * 8 + 255) / 256 * 256, need_a = a_bytes + (size_t)N * 48 * 8;
+        if (h->tA_capacity < need_a) {
+            PF_HIP(h, hipDeviceSynchronize());
+            if (h->d_tA) { (void)hipFree(h->d_tA); h->d_tA = nullptr; h->tA_capacity = 0; }
+            const size_t want = need_a + need_a / 8;
+            PF_HIP(h, hipMalloc(&h->d_tA, want));
+            h->tA_capacity = want;
+            h->tA_dirty = true;
+        }
+        if (h->tA_dirty) { PF_HIP(h, hipMemsetAsync(h->d_tA, 0, h->tA_capacity, s)); h->tA_dirty = false; }
+        h->t_A_h = reinterpret_cast<long long*>(h->d_tA);
+        h->t_A_v = reinterpret_cast<long long*>(reinterpret_cast<char*>(h->d_tA) + a_bytes);
+    }
     h->t_fix = carve<float>(cur, 64);
     h->t_ccnt = carve<int>(cur, 64);
     h->t_clist = carve<int>(cur, (size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);
@@ -1999,8 +2015,6 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     h->t_Gg = carve<float>(cur, (size_t)h->B * c.rec_nf * PF_S);
     h->t_lx0c = carve<float>(cur, (size_t)h->Nf * 3); h->t_lag = carve<float>(cur, (size_t)h->B); h->t_lsg = carve<float>(cur, (size_t)h->B);
     h->t_lgx = carve<float>(cur, (size_t)h->Nf * 3); h->t_lgh = carve<float>(cur, (size_t)h->Nf * c.pharm_nf); h->t_lout = carve<float>(cur, 64);
-    PF_HIP(h, hipMemsetAsync(h->t_A_h, 0, (size_t)N * PF_S * 8, s));       // pfk_fix_apply keeps them clear afterwards
-    PF_HIP(h, hipMemsetAsync(h->t_A_v, 0, (size_t)N * 48 * 8, s));
     h->t_gpart = carve<float>(cur, (size_t)h->t_nblk * h->nparams);
     h->t_sv_z.assign(L, nullptr); h->t_sv_g.assign(L, nullptr); h->t_sv_v.assign(L, nullptr);
     for (int l = 0; l < L; ++l) {
@@ -2179,8 +2193,10 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     rp.NB = nb; rp.ccnt = h->t_ccnt;
     rp.gpart_enc = h->t_gpart_enc; rp.enc_begin = h->enc_begin; rp.enc_n = h->enc_n;
     pfk_fix_scale(dev_g_eps_h, h->Nf * c.pharm_nf, dev_g_eps_x, h->Nf * 3, h->t_fix, s);
-    PF_HIP(h, hipMemsetAsync(h->t_G_h[0], 0, (size_t)N * PF_S * 4, s));
-    PF_HIP(h, hipMemsetAsync(h->t_G_v[0], 0, (size_t)N * 48 * 4, s));
+    if (h->tA_dirty) PF_HIP(h, hipMemsetAsync(h->d_tA, 0, h->tA_capacity, s));      // an earlier pass stopped half way
+    h->tA_dirty = true;
+    // (the head kernel stores dL/d(last layer output) for every pharm row, and the last layer's node kernel reads those rows
+    // only: no clearing of t_G_*[0] here)
     {
         BwdHeadParams p{};
         p.c = tc; p.tiles = h->d_head_tiles; p.ntiles = h->n_head_tiles; p.node_base = h->Np;
@@ -2278,6 +2294,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     pfk_train_reduce(&rp, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    h->tA_dirty = false;
     return PF_OK;
 }
 
