@@ -263,6 +263,16 @@ int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave);
 /* static hoist of conv layer 0's protein-protein messages in the last dynamics call: *rows_per_wave = 0 (not used: training,
  * tile kernels, protein features that are not element one-hots, PFDYN_NO_L0_HOIST=1) or 4 / 8 rows per hoisted wave */
 int pf_debug_l0_hoist(pf_handle* h, int32_t* rows_per_wave);
+/* One chain of the row-group kernels (pf_rg.hip: rg_gvp / rg_flush / rg_layernorm, 4 rows per wave) on caller-supplied rows,
+ * with the committed weights -- the unit-level checker against the reference's own module outputs (gvp.py:89-116, 152-166;
+ * dynamics_gvp.py:10-42).  All pointers are device memory; no batch needs to be bound.
+ *   kind 0  message chain of conv `layer`, edge type `sub` (0 ff, 1 pf, 2 fp, 3 pp; gvp.py:545-549):
+ *           s_in [n][144] = [h_src, rbf], v_in [n][17][3] = [x_hat, v_src]  ->  s_out [n][128], v_out [n][16][3]
+ *   kind 1  update chain of conv `layer`, node type `sub` (0 prot, 1 pharm): [n][128], [n][16][3] -> same shapes
+ *   kind 2  GVPLayerNorm of conv `layer`: sub = 2 * node type + (0 message_layer_norms, 1 update_layer_norms)
+ *   kind 3  NoisePredictionBlock: s_in [n][128], v_in [n][16][3]  ->  s_out [n][pharm_nf] (eps_h), v_out [n][3] (eps_x) */
+int pf_debug_chain(pf_handle* h, int32_t kind, int32_t layer, int32_t sub, int32_t n_rows, const float* dev_s_in,
+                   const float* dev_v_in, float* dev_s_out, float* dev_v_out, pf_stream stream);
 
 #ifdef __cplusplus
 }

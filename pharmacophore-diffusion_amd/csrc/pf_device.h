@@ -188,6 +188,17 @@ struct NodeW {             // per node type
     const GvpW PF_AS1* upd;                   // [n_upd]
 };
 
+// pf_debug_chain: one chain of the row-group kernels on caller-supplied rows (unit tests against the reference's own
+// module outputs).  kind 0: message chain (s_in [n][144] = [h_src, rbf], v_in [n][17][3] = [xhat, v_src]); 1: update chain
+// (s_in [n][128], v_in [n][16][3]); 2: GVPLayerNorm; 3: noise head (s_out [n][pharm_nf], v_out [n][3])
+struct UnitParams {
+    const float* s_in; const float* v_in; float* s_out; float* v_out;
+    int n, kind, n_gvps, pharm_nf;
+    const float* stream;                      // quad stream of the chain (kinds 0, 1, 3)
+    int skip_gvps;                            // kind 3: update-chain blocks (+ their flush) in front of the head in that stream
+    const float* ln_w; const float* ln_b;     // kind 2
+};
+
 struct NodeParams {
     const NodeTile* tiles;
     int ntiles;

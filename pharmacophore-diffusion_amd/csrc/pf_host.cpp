@@ -32,6 +32,7 @@ void pfk_noise_head(const HeadParams* p, hipStream_t s);
 void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int rg, int split, int rgp, hipStream_t s);
 void pfk_l0_hoist(const L0HoistParams* p, int what, hipStream_t s);
 void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s);
+void pfk_rg_unit(const UnitParams* p, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
 void pfk_encode_build_pre(const EncodeParams* e, const BuildParams* b, const PreParams* pp, hipStream_t s);
@@ -2320,6 +2321,34 @@ int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave) 
     if (!h || !rows_per_wave) return PF_ERR_ARG;
     if (layer < 0 || layer >= (int)h->last_family.size()) PF_FAIL(h, PF_ERR_STATE, "pf_debug_kernel_family: no dynamics call yet, or bad layer");
     *rows_per_wave = h->last_family[layer];
+    return PF_OK;
+}
+
+int pf_debug_chain(pf_handle* h, int32_t kind, int32_t layer, int32_t sub, int32_t n_rows, const float* dev_s_in, const float* dev_v_in,
+                   float* dev_s_out, float* dev_v_out, pf_stream stream) {
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    const pf_config& c = h->cfg;
+    if (kind < 0 || kind > 3 || n_rows < 0 || !dev_s_in || !dev_v_in || !dev_s_out || !dev_v_out) PF_FAIL(h, PF_ERR_ARG, "pf_debug_chain: bad argument");
+    if (kind != 3 && (layer < 0 || layer >= c.n_convs)) PF_FAIL(h, PF_ERR_ARG, "pf_debug_chain: bad layer");
+    if ((kind == 0 && (sub < 0 || sub > 3)) || ((kind == 1 || kind == 2) && (sub < 0 || sub > 3))) PF_FAIL(h, PF_ERR_ARG, "pf_debug_chain: bad sub index");
+    if (h->rg_msg.empty()) PF_FAIL(h, PF_ERR_STATE, "pf_debug_chain: no row-group streams (weights not committed)");
+    UnitParams p{};
+    p.s_in = dev_s_in; p.v_in = dev_v_in; p.s_out = dev_s_out; p.v_out = dev_v_out;
+    p.n = n_rows; p.kind = kind; p.pharm_nf = c.pharm_nf;
+    if (kind == 0) { p.stream = h->d_w + h->rg_msg[(size_t)layer * 4 + sub]; p.n_gvps = c.n_message_gvps; }
+    else if (kind == 1) {
+        if (sub > 1) PF_FAIL(h, PF_ERR_ARG, "pf_debug_chain: node type 0 (prot) or 1 (pharm)");
+        p.stream = h->d_w + h->rg_upd[(size_t)layer * 2 + sub]; p.n_gvps = c.n_update_gvps;
+    } else if (kind == 2) {           // sub: 2 * node type + (0: message_layer_norms, 1: update_layer_norms)
+        const size_t* lo = &h->ln_off[(size_t)(layer * 2 + (sub >> 1)) * 4];
+        p.ln_w = h->d_w + lo[(sub & 1) * 2]; p.ln_b = h->d_w + lo[(sub & 1) * 2 + 1];
+    } else {
+        p.stream = h->d_w + h->rg_upd[(size_t)(c.n_convs - 1) * 2 + 1]; p.n_gvps = c.n_noise_gvps; p.skip_gvps = c.n_update_gvps;
+    }
+    pfk_rg_unit(&p, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return PF_OK;
 }
 

@@ -357,6 +357,22 @@ class PfEngine:
         self._ck(self.lib.pf_debug_l0_hoist(self._h, ctypes.byref(r)), "pf_debug_l0_hoist")
         return int(r.value)
 
+    def debug_chain(self, kind: int, layer: int, sub: int, s_in: torch.Tensor, v_in: torch.Tensor):
+        """pf_debug_chain: one chain of the row-group kernels on the given rows (kinds and shapes: include/pfdyn.h)."""
+        s_in = s_in.to(self.device, torch.float32).contiguous()
+        v_in = v_in.to(self.device, torch.float32).contiguous()
+        n = s_in.shape[0]
+        if kind == 3:
+            s_out = torch.empty(n, self.cfg.pharm_nf, device=self.device)
+            v_out = torch.empty(n, 3, device=self.device)
+        else:
+            s_out = torch.empty(n, 128, device=self.device)
+            v_out = torch.empty(n, 16, 3, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_debug_chain(self._h, int(kind), int(layer), int(sub), int(n), _dptr(s_in), _dptr(v_in),
+                                             _dptr(s_out), _dptr(v_out), _stream_ptr()), "pf_debug_chain")
+        return s_out, v_out
+
     KERNEL_CLASSES = ("encode", "build_edges", "edge_msg", "node_update", "noise_head", "step_update", "edge_msg_coop",
                       "node_update_coop", "edge_msg_last")
 

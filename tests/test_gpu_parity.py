@@ -91,6 +91,63 @@ def test_trajectory_vs_golden(name, ep):
         close(res[2], z["pos_frames"], 5e-3, 5e-3); close(res[3], z["feat_frames"], 5e-3, 5e-3)
 
 
+UNIT_TOL = 5e-5
+
+
+def test_chain_units_vs_reference_modules():
+    """The chain code of the row-group kernels in isolation (pf_debug_chain: rg_gvp / rg_flush / rg_layernorm on supplied
+    rows) against the outputs of the reference's own modules on the same rows (tests/golden/units.npz, recorded by
+    make_golden.py from gvp.py:89-116 GVP chains, gvp.py:152-166 GVPLayerNorm incl. an all-zero vector row, dynamics_gvp.py:10-42
+    NoisePredictionBlock).  A single GVP of a chain cannot be cut out of the quad stream (block j carries the gates of GVP
+    j - 1), so the msg0 / msg1 vectors of the file stay with the oracle test; chains, norm and head are compared here."""
+    z = load("units.npz")
+    cfg = O.DynamicsConfig()
+    eng = engine_for(cfg, O.make_state_dict(cfg, 0))
+    so, vo = eng.debug_chain(0, 0, 1, z["chain_s"], z["chain_v"])            # edge_message_fns.prot_pf_pharm, 3 GVPs
+    close(so, z["chain_so"], UNIT_TOL, UNIT_TOL); close(vo, z["chain_vo"], UNIT_TOL, UNIT_TOL)
+    so, vo = eng.debug_chain(1, 0, 0, z["upd_s"], z["upd_v"])                # node_update_fns.prot, 2 GVPs
+    close(so, z["upd_so"], UNIT_TOL, UNIT_TOL); close(vo, z["upd_vo"], UNIT_TOL, UNIT_TOL)
+    so, vo = eng.debug_chain(2, 0, 2, z["ln_s"], z["ln_v"])                  # message_layer_norms.pharm
+    close(so, z["ln_so"], UNIT_TOL, UNIT_TOL); close(vo, z["ln_vo"], UNIT_TOL, UNIT_TOL)
+    assert torch.all(vo[5] == 0) and torch.isfinite(vo).all()
+    eh, ex = eng.debug_chain(3, 0, 0, z["head_s"], z["head_v"])              # noise_predictor: 4 GVPs + to_scalar_output
+    close(eh, z["head_eh"], UNIT_TOL, UNIT_TOL); close(ex, z["head_ex"], UNIT_TOL, UNIT_TOL)
+
+
+@pytest.mark.parametrize("arch", ["dev", "deep"])
+def test_chain_units_every_chain_vs_oracle(arch):
+    """Every message chain (layer x edge type), update chain and norm (layer x node type) and the head of a network through
+    pf_debug_chain against the oracle's restatement on random rows, ragged row counts (1..4 rows in the last wave)."""
+    cfg = O.DynamicsConfig() if arch == "dev" else O.DynamicsConfig(n_convs=3, n_message_gvps=2, n_update_gvps=3, n_noise_gvps=2)
+    sd = O.make_state_dict(cfg, 7)
+    eng = engine_for(cfg, sd)
+    gen = torch.Generator().manual_seed(3)
+    et_names = ["pharm_ff_pharm", "prot_pf_pharm", "pharm_fp_prot", "prot_pp_prot"]
+    for layer in range(cfg.n_convs):
+        p = f"dynamics.noise_predictor.conv_layers.{layer}."
+        for et in range(4):
+            n = 5 + 4 * layer + et                                            # 5..: every remainder mod 4 occurs
+            s, v = torch.randn(n, 144, generator=gen), torch.randn(n, 17, 3, generator=gen)
+            s[:, 128:] = s[:, 128:].abs().clamp(max=1.0)                      # rbf values live in (0, 1]
+            so, vo = eng.debug_chain(0, layer, et, s, v)
+            ro, rv = O.gvp_chain(sd, p + f"edge_message_fns.{et_names[et]}.", cfg.n_message_gvps, s, v)
+            close(so, ro, UNIT_TOL, UNIT_TOL); close(vo, rv, UNIT_TOL, UNIT_TOL)
+        for nt, name in enumerate(("prot", "pharm")):
+            n = 6 + nt
+            s, v = torch.randn(n, 128, generator=gen), torch.randn(n, 16, 3, generator=gen)
+            so, vo = eng.debug_chain(1, layer, nt, s, v)
+            ro, rv = O.gvp_chain(sd, p + f"node_update_fns.{name}.", cfg.n_update_gvps, s, v)
+            close(so, ro, UNIT_TOL, UNIT_TOL); close(vo, rv, UNIT_TOL, UNIT_TOL)
+            for which, ln in enumerate(("message_layer_norms", "update_layer_norms")):
+                so, vo = eng.debug_chain(2, layer, 2 * nt + which, s, v)
+                ro, rv = O.gvp_layernorm(sd, p + f"{ln}.{name}.", s, v)
+                close(so, ro, UNIT_TOL, UNIT_TOL); close(vo, rv, UNIT_TOL, UNIT_TOL)
+    s, v = torch.randn(9, 128, generator=gen), torch.randn(9, 16, 3, generator=gen)
+    eh, ex = eng.debug_chain(3, 0, 0, s, v)
+    rh, rx = O.noise_head(sd, "dynamics.noise_predictor.noise_predictor.", cfg, s, v)
+    close(eh, rh, UNIT_TOL, UNIT_TOL); close(ex, rx, UNIT_TOL, UNIT_TOL)
+
+
 def test_pp_edges_as_the_reference_dataset_code_emits_them():
     """pf_build_pp_edges against build_initial_complex_graph's edges (dataset/protein_pharm_dataset.py:234-236, golden
     from the reference's function): same edges in the same order for 64 / 256 / 300-atom pockets and a 2-atom one, one
