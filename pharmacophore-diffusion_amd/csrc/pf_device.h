@@ -197,6 +197,9 @@ struct UnitParams {
     const float* stream;                      // quad stream of the chain (kinds 0, 1, 3)
     int skip_gvps;                            // kind 3: update-chain blocks (+ their flush) in front of the head in that stream
     const float* ln_w; const float* ln_b;     // kind 2
+    // kind 3 as the training forward of the noise head: per GVP level and row the pre-activation scalars [128], gate
+    // pre-activations [16] and gated vectors [48] k_bwd_head reads instead of recomputing the chain (NULL: not saved)
+    float* sv_z; float* sv_g; float* sv_v; size_t sv_stride;
 };
 
 struct NodeParams {
@@ -228,6 +231,10 @@ struct NodeParams {
     pf_gcf rg_upd[2];      // row-group kernels: quad stream of each node type's update chain (pharm of the last layer:
                            // followed by the noise head's chain and to_scalar_output)
     pf_gcf rgs_upd[2]; int rgs_stride[2];   // two-wave form of the same (wave 1's stream rgs_stride floats after wave 0's)
+    // training forward (k_rg_node<., SAVE>): per update-GVP level and row the pre-activation scalars / gate pre-activations / gated
+    // vectors, indexed by the row's position in the tile lists (+ N for the active-atom lists): k_bwd_node reads them instead of
+    // recomputing the chain.  NULL: not saved
+    float* sv_z; float* sv_g; float* sv_v; size_t sv_stride;
 };
 
 struct HeadParams {

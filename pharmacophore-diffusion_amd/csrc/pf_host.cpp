@@ -169,6 +169,12 @@ struct pf_handle {
     bool share_disable = false;             // PFDYN_NO_POCKET_SHARE=1
     bool train_rg_node = true;              // PFDYN_TRAIN_TILE_NODE=1: the training forward keeps the 32-row tile node kernel
     bool train_rg_edge = true;              // PFDYN_TRAIN_TILE_EDGE=1: ... and the 32-slot tile edge kernel
+    bool train_rg_head = true;              // PFDYN_TRAIN_TILE_HEAD=1: the training forward's noise head on the tile kernel (the backward recomputes it)
+    float *t_hsv_z = nullptr, *t_hsv_g = nullptr, *t_hsv_v = nullptr;   // head levels saved by the training forward [n_noise_gvps][Nf][128 / 16 / 48]
+    bool t_head_saved = false;              // ... by the last pf_train_forward
+    bool train_node_save = true;            // PFDYN_TRAIN_NODE_RECOMPUTE=1: k_bwd_node recomputes the update chains instead of reading saved levels
+    std::vector<float*> t_nsv_z, t_nsv_g, t_nsv_v;  // per conv layer: update-chain levels saved by the training forward [n_update_gvps][2 N][128 / 16 / 48]
+    std::vector<char> t_node_saved;         // ... by the last pf_train_forward
     std::vector<int> t_grp;                 // per conv layer: slots per message partial-row group of the last training forward
     bool sampling = false;
     int max_np = 0;                         // largest pocket of the batch
@@ -241,6 +247,8 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_NO_POCKET_SHARE")) share_disable = atoi(e) != 0;
         if (const char* e = getenv("PFDYN_TRAIN_TILE_NODE")) train_rg_node = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_TRAIN_TILE_EDGE")) train_rg_edge = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_TRAIN_TILE_HEAD")) train_rg_head = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_TRAIN_NODE_RECOMPUTE")) train_node_save = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_L0_RGP")) l0_rgp = atoi(e);
         if (const char* e = getenv("PFDYN_L0_RGA")) l0_rga = atoi(e);
     }
@@ -879,7 +887,10 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         n.n_upd = c.n_update_gvps;
         n.grp = rg ? 4 * rg : 32;
         n.grp_pa = rgp ? 4 * rgp : n.grp;
-        if (train) { h->t_grp.resize(c.n_convs); h->t_grp[l] = n.grp; }
+        if (train) {
+            h->t_grp.resize(c.n_convs); h->t_grp[l] = n.grp;
+            h->t_node_saved.resize(c.n_convs); h->t_node_saved[l] = 0;
+        }
         for (int nt = 0; nt < 2; ++nt) n.rg_upd[nt] = h->d_w + h->rg_upd[(size_t)l * 2 + nt];
         for (int nt = 0; nt < 2; ++nt) {
             n.rgs_upd[nt] = h->d_w + h->rgs_upd[(size_t)l * 2 + nt];
@@ -896,7 +907,13 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 hp.eps_h = eps_h; hp.eps_x = eps_x;
                 { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node(&n, &hp, enc_fly ? &ep : nullptr, l == 0, rgn, nsplit, s); }
                 head_done = true;
-            } else { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_rg_node(&n, nullptr, enc_fly ? &ep : nullptr, l == 0, rgn, nsplit, s); }
+            } else {
+                if (train && h->train_node_save) {
+                    n.sv_z = h->t_nsv_z[l]; n.sv_g = h->t_nsv_g[l]; n.sv_v = h->t_nsv_v[l]; n.sv_stride = (size_t)2 * h->N;
+                    h->t_node_saved[l] = 1;
+                }
+                ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_rg_node(&n, nullptr, enc_fly ? &ep : nullptr, l == 0, rgn, nsplit, s);
+            }
         }
         else if (last && !train && h->fuse_head && n.ntiles <= h->coop_node_max && h->n_head_tiles == n.ntiles) {
             // last layer (pharm tiles only) + noise head in one launch: the layer output stays in registers
@@ -912,6 +929,10 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             // training forward: the row-group node kernel (with the two GVPDropout sites) on the tile edge kernels' partial rows
             // (one per 32-slot tile and destination: grp = 32); the layer input comes from memory, as the backward kernels read it
             n.grp = 32; n.grp_pa = 32;
+            if (h->train_node_save) {
+                n.sv_z = h->t_nsv_z[l]; n.sv_g = h->t_nsv_g[l]; n.sv_v = h->t_nsv_v[l]; n.sv_stride = (size_t)2 * h->N;
+                h->t_node_saved[l] = 1;
+            }
             ProfScope ps(h, pf_handle::K_NODE_COOP, s);
             pfk_rg_node(&n, nullptr, nullptr, l == 0, h->rg_mode(n.ntiles), 0, s);
         }
@@ -925,6 +946,19 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
     hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
     hp.eps_h = eps_h; hp.eps_x = eps_x;
+    if (train) h->t_head_saved = false;
+    if (!head_done && train && h->train_rg_head && !h->rg_msg.empty() && h->Nf > 0) {
+        // training forward: the head chain on the row-group code (4 rows per wave), which also leaves every level's pre-activations,
+        // gate pre-activations and gated vectors for k_bwd_head (pharm rows are the contiguous rows [Np, Np + Nf))
+        UnitParams up{};
+        up.s_in = hp.h + (size_t)h->Np * PF_S; up.v_in = hp.v + (size_t)h->Np * 48; up.s_out = eps_h; up.v_out = eps_x;
+        up.n = h->Nf; up.kind = 3; up.n_gvps = c.n_noise_gvps; up.pharm_nf = c.pharm_nf;
+        up.stream = h->d_w + h->rg_upd[(size_t)(c.n_convs - 1) * 2 + 1]; up.skip_gvps = c.n_update_gvps;
+        up.sv_z = h->t_hsv_z; up.sv_g = h->t_hsv_g; up.sv_v = h->t_hsv_v; up.sv_stride = (size_t)h->Nf;
+        { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_unit(&up, s); }
+        h->t_head_saved = true;
+        head_done = true;
+    }
     if (!head_done) { ProfScope ps(h, pf_handle::K_HEAD, s); if (hp.ntiles <= h->coop_node_max) pfk_noise_head_coop(&hp, s); else pfk_noise_head(&hp, s); }
     h->edges_built = false;                 // whoever moves the coordinates next decides (pf_denoise_step rebuilds)
     hipError_t e = hipGetLastError();
@@ -1972,6 +2006,9 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     need((size_t)2 * std::max(h->n_node_tiles, h->n_node_tiles_act) + 64);
     need((size_t)h->B * c.rec_nf * PF_S);
     need((size_t)h->Nf * 3); need((size_t)h->B); need((size_t)h->B); need((size_t)h->Nf * 3); need((size_t)h->Nf * c.pharm_nf); need(64);   // loss buffers
+    for (int l = 0; l < L; ++l) { need((size_t)c.n_update_gvps * 2 * N * PF_S); need((size_t)c.n_update_gvps * 2 * N * 16); need((size_t)c.n_update_gvps * 2 * N * 48); }
+    need((size_t)c.n_noise_gvps * std::max(h->Nf, 1) * PF_S); need((size_t)c.n_noise_gvps * std::max(h->Nf, 1) * 16);
+    need((size_t)c.n_noise_gvps * std::max(h->Nf, 1) * 48);
     need((size_t)h->t_nblk * h->nparams);
     const size_t Es = (size_t)std::max<int64_t>(h->Ecap, 1), ng = (size_t)c.n_message_gvps;
     for (int l = 0; l < L; ++l) { need(ng * Es * PF_S); need(ng * Es * 16); need(ng * Es * 48); }
@@ -2016,6 +2053,15 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     h->t_Gg = carve<float>(cur, (size_t)h->B * c.rec_nf * PF_S);
     h->t_lx0c = carve<float>(cur, (size_t)h->Nf * 3); h->t_lag = carve<float>(cur, (size_t)h->B); h->t_lsg = carve<float>(cur, (size_t)h->B);
     h->t_lgx = carve<float>(cur, (size_t)h->Nf * 3); h->t_lgh = carve<float>(cur, (size_t)h->Nf * c.pharm_nf); h->t_lout = carve<float>(cur, 64);
+    h->t_nsv_z.assign(L, nullptr); h->t_nsv_g.assign(L, nullptr); h->t_nsv_v.assign(L, nullptr);
+    for (int l = 0; l < L; ++l) {
+        h->t_nsv_z[l] = carve<float>(cur, (size_t)c.n_update_gvps * 2 * N * PF_S);
+        h->t_nsv_g[l] = carve<float>(cur, (size_t)c.n_update_gvps * 2 * N * 16);
+        h->t_nsv_v[l] = carve<float>(cur, (size_t)c.n_update_gvps * 2 * N * 48);
+    }
+    h->t_hsv_z = carve<float>(cur, (size_t)c.n_noise_gvps * std::max(h->Nf, 1) * PF_S);
+    h->t_hsv_g = carve<float>(cur, (size_t)c.n_noise_gvps * std::max(h->Nf, 1) * 16);
+    h->t_hsv_v = carve<float>(cur, (size_t)c.n_noise_gvps * std::max(h->Nf, 1) * 48);
     h->t_gpart = carve<float>(cur, (size_t)h->t_nblk * h->nparams);
     h->t_sv_z.assign(L, nullptr); h->t_sv_g.assign(L, nullptr); h->t_sv_v.assign(L, nullptr);
     for (int l = 0; l < L; ++l) {
@@ -2207,6 +2253,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         p.o_bout = (int)h->flat_offset("dynamics.noise_predictor.noise_predictor.to_scalar_output.bias");
         p.pharm_nf = c.pharm_nf; p.g_eps_h = dev_g_eps_h; p.g_eps_x = dev_g_eps_x;
         p.G_h = h->t_G_h[0]; p.G_v = h->t_G_v[0];
+        if (h->t_head_saved) { p.sv_z = h->t_hsv_z; p.sv_g = h->t_hsv_g; p.sv_v = h->t_hsv_v; p.sv_stride = (size_t)h->Nf; }
         rp.head_grid = p.ntiles > 0 ? std::max(1, std::min(nb, 2 * p.ntiles)) : 0;
         { ProfScope ps(h, pf_handle::K_BWD_HEAD, s); pfk_bwd_head(&p, rp.head_grid, s); }
     }
@@ -2242,6 +2289,9 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         }
         n.layer = l; n.l0 = l == 0;
         n.grp = (int)h->t_grp.size() > l ? h->t_grp[l] : 32;
+        if ((int)h->t_node_saved.size() > l && h->t_node_saved[l]) {
+            n.sv_z = h->t_nsv_z[l]; n.sv_g = h->t_nsv_g[l]; n.sv_v = h->t_nsv_v[l]; n.sv_stride = (size_t)2 * h->N;
+        }
         n.ulist = h->t_ulist; n.ucnt = h->t_ccnt + 32;
         pfk_compact_units(n.tiles, n.ntiles, h->d_dyn_cnt, h->t_ulist, h->t_ccnt + 32, s);
         rp.node_grid[l] = n.ntiles > 0 ? std::max(1, std::min(nb, 2 * n.ntiles)) : 0;

@@ -74,6 +74,9 @@ struct BwdHeadParams {
     int o_Wout, o_bout, pharm_nf;
     const float* g_eps_h; const float* g_eps_x;   // upstream gradients [Nf][pharm_nf], [Nf][3]
     float* G_h; float* G_v;                  // gradient w.r.t. the last layer's output (rows of the pharm nodes are stored)
+    // what the training forward of the head left per level and pharm row (k_rg_unit<SAVE>): [level][Nf][128 / 16 / 48]; NULL: the
+    // kernel recomputes the chain
+    const float* sv_z; const float* sv_g; const float* sv_v; size_t sv_stride;
 };
 
 struct BwdNodeParams {
@@ -94,6 +97,8 @@ struct BwdNodeParams {
     int o_ln[2][4];                          // ln1_w ln1_b ln2_w ln2_b per node type
     int layer, l0;
     int grp;                                 // slots per partial-row group of the forward's edge kernel (32: tile kernel; 4 / 8: row groups)
+    // update-chain levels left by the training forward (k_rg_node<., SAVE>; NodeParams::sv_*): [level][2 N][128 / 16 / 48]; NULL: recompute
+    const float* sv_z; const float* sv_g; const float* sv_v; size_t sv_stride;
 };
 
 struct BwdEdgeParams {

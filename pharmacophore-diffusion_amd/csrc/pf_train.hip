@@ -320,10 +320,11 @@ __device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, const Pac
 __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const PackPtr pk, const bool fresh, float* gp, const float* Sin, const float* Vin,
                                         const float* Z, const float* gate, const float* act, const int act_stride,
                                         float* gA, float* gS, float* gVo, float* gVi, float* Vh, float* Vu, float* gVh,
-                                        float* ggate, const int tid, const int lane, const int wv) {
+                                        float* ggate, const int tid, const int lane, const int wv, const bool fill_sh = false) {
     const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;
     PFT_STAMP(10);
-    gvp_vec(g, W, nullptr, Vin, Vh, Vu, false, tid, lane, wv);
+    // (fill_sh: the level's rows came from the forward's saved pre-activations, the sh columns of Sin are still to be filled)
+    gvp_vec(g, W, const_cast<float*>(Sin), Vin, Vh, Vu, fill_sh, tid, lane, wv);
     PFT_STAMP(11);
     // gate: V' = f(gate) Vu
     for (int idx = tid; idx < TR * VO; idx += NT) {
@@ -410,15 +411,48 @@ __device__ __forceinline__ void chain_fwd(const ChainLds& L, const GvpT* g, cons
                 last ? vout_last : L.Vin(l + 1), L.Vh, L.Vu, tid, lane, wv);
     }
 }
+// instead of chain_fwd: the forward left every level's pre-activations (rows i0 .. i0 + nv - 1 of [level][stride][128 / 16 / 48]):
+// fill Z, gate and the next level's inputs (act = SiLU(Z), gated vectors) with independent loads -- one round trip instead of the
+// ~30 k cycles per GVP of the recomputation.  The sh columns of every Sin are filled by gvp_bwd (fill_sh).
+__device__ __forceinline__ void chain_load(const ChainLds& L, const GvpT* g, const float* sv_z, const float* sv_g, const float* sv_v,
+                                           const size_t stride, const size_t i0, const int nv, float* vout_last, const int tid) {
+    for (int l = 0; l < L.nlv; ++l) {
+        const bool last = l == L.nlv - 1;
+        const int so = g[l].so, vo = g[l].vo;
+        const float* zl = sv_z + ((size_t)l * stride + i0) * PF_S;
+        const float* gl = sv_g + ((size_t)l * stride + i0) * 16;
+        const float* vl = sv_v + ((size_t)l * stride + i0) * 48;
+        float* Zl = L.Z(l); float* act = last ? L.actl : L.Sin(l + 1);
+        float* gt = L.gate(l);
+        float* vout = last ? vout_last : L.Vin(l + 1);
+        const int astr = last ? ZS : SWS;
+        for (int idx = tid; idx < TR * so; idx += NT) {
+            const int row = idx / so, k = idx - row * so;
+            const float z = zl[(size_t)min(row, nv - 1) * PF_S + k];
+            Zl[row * ZS + k] = z;
+            act[row * astr + k] = t_silu(z);
+        }
+        for (int idx = tid; idx < TR * vo; idx += NT) {
+            const int row = idx / vo, u = idx - row * vo;
+            gt[row * GTS + u] = gl[(size_t)min(row, nv - 1) * 16 + u];
+        }
+        if (vout != nullptr)
+            for (int idx = tid; idx < TR * vo * 3; idx += NT) {
+                const int row = idx / (vo * 3), q = idx - row * (vo * 3);
+                vout[row * VWS + q] = vl[(size_t)min(row, nv - 1) * 48 + q];
+            }
+    }
+    __syncthreads();
+}
 // backward through the chain: upstream gradients in L.gX ([row][so_last], stride SWS) and L.gVX; returns through
 // gs_out / gv_out the buffers that hold dL/d Sin(0) and dL/d Vin(0)
 __device__ __forceinline__ void chain_bwd(const ChainLds& L, const GvpT* g, const float* W, const PackPtr pk, const bool fresh, float* gp,
-                                          float*& gs_out, float*& gv_out, const int tid, const int lane, const int wv) {
+                                          float*& gs_out, float*& gv_out, const int tid, const int lane, const int wv, const bool fill_sh = false) {
     float *ga = L.gX, *gs = L.gY, *gvo = L.gVX, *gvi = L.gVY;
     for (int l = L.nlv - 1; l >= 0; --l) {
         const bool last = l == L.nlv - 1;
         gvp_bwd(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
-                ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv);
+                ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh);
         float* t0 = ga; ga = gs; gs = t0;
         float* t1 = gvo; gvo = gvi; gvi = t1;
     }
@@ -482,7 +516,9 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
                 s_ge[row * 8 + o] = row < nv ? p.g_eps_h[(size_t)(n0 - p.node_base + row) * NF + o] : 0.f;
             }
             __syncthreads();
-            chain_fwd(L, p.g, W, pk, nullptr, tid, lane, wv);
+            const bool saved = p.sv_z != nullptr;
+            if (!saved) chain_fwd(L, p.g, W, pk, nullptr, tid, lane, wv);
+            else chain_load(L, p.g, p.sv_z, p.sv_g, p.sv_v, p.sv_stride, (size_t)(n0 - p.node_base), nv, nullptr, tid);
             // to_scalar_output: eps_h = Wout act + b ; eps_x = the single output vector channel
             for (int idx = tid; idx < TR * SOL; idx += NT) {
                 const int row = idx & 15, k = idx >> 4;
@@ -507,7 +543,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
             }
             __syncthreads();
             float *gs, *gv;
-            chain_bwd(L, p.g, W, pk, unit == (int)blockIdx.x, gp, gs, gv, tid, lane, wv);
+            chain_bwd(L, p.g, W, pk, unit == (int)blockIdx.x, gp, gs, gv, tid, lane, wv, saved);
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx >> 7, f = idx & 127;
                 if (row < nv) p.G_h[(size_t)(n0 + row) * PF_S + f] = gs[row * SWS + f];
@@ -647,7 +683,9 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 L.Vin(0)[row * VWS + q] = vy[row * VWS + q] / s_vl1[row].den;
             }
             __syncthreads();
-            chain_fwd(L, g, W, pk, rvl, tid, lane, wv);
+            const bool saved = p.sv_z != nullptr;
+            if (!saved) chain_fwd(L, g, W, pk, rvl, tid, lane, wv);
+            else chain_load(L, g, p.sv_z, p.sv_g, p.sv_v, p.sv_stride, (size_t)(t.ids ? p.N : 0) + n0, nv, rvl, tid);
             // ---- residual dropout, residual, LN2 statistics
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx & 15, f = idx >> 4;
@@ -711,7 +749,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
             }
             __syncthreads();
             float *gs, *gv;
-            chain_bwd(L, g, W, pk, !seen[nt], gp, gs, gv, tid, lane, wv);
+            chain_bwd(L, g, W, pk, !seen[nt], gp, gs, gv, tid, lane, wv, saved);
             seen[nt] = true;
             // ---- LN1 backward
             for (int idx = tid; idx < TR * 128; idx += NT) {

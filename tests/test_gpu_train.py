@@ -191,7 +191,10 @@ def test_training_forward_kernel_families_agree(name, monkeypatch):
     """The training forward runs on the row-group kernels by default (k_rg_edge<., SAVE> writing the per-level rows of the
     backward pass, k_rg_node with the two GVPDropout sites); PFDYN_TRAIN_TILE_EDGE=1 keeps the 32-slot tile edge kernel
     (k_edge_msg<., SAVE>) under the row-group node kernel, PFDYN_TRAIN_TILE_NODE=1 (or a batch beyond the row-group policy)
-    the tile kernels for both: same dropout masks (one hash), outputs and gradients equal up to summation order."""
+    the tile kernels for both; PFDYN_TRAIN_TILE_HEAD=1 runs the noise head on the tile kernel and lets k_bwd_head recompute its
+    chain instead of reading the levels k_rg_unit<SAVE> left, PFDYN_TRAIN_NODE_RECOMPUTE=1 does the same for the update chains
+    of k_bwd_node (k_rg_node<., SAVE>): same dropout masks (one hash), outputs and gradients equal up to
+    summation order."""
     z = load(name)
     cfg = GRAD_CASES[name]
     batch = batch_from(z)
@@ -200,7 +203,7 @@ def test_training_forward_kernel_families_agree(name, monkeypatch):
     gen = torch.Generator().manual_seed(6)
     w_h, w_x = torch.randn(h_t.shape, generator=gen), torch.randn(x_t.shape, generator=gen)
     res = []
-    for var in (None, "PFDYN_TRAIN_TILE_EDGE", "PFDYN_TRAIN_TILE_NODE"):
+    for var in (None, "PFDYN_TRAIN_TILE_HEAD", "PFDYN_TRAIN_NODE_RECOMPUTE", "PFDYN_TRAIN_TILE_EDGE", "PFDYN_TRAIN_TILE_NODE"):
         if var:
             monkeypatch.setenv(var, "1")
         eng = make_engine(cfg, sd, batch)
