@@ -1588,7 +1588,15 @@ __global__ void k_train_reduce(const ReduceParams p) {
         b1 = b0 + nbk;
     } else if (cls >= PFT_CLS_NODE) b1 = p.node_grid[cls - PFT_CLS_NODE];
     float s = 0.f;
-    for (int b = b0; b < b1; ++b) s += p.gpart[(size_t)b * p.nparams + i];
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {                    // eight copies in flight, summed in block order
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = __builtin_nontemporal_load(p.gpart + (size_t)(b + u) * p.nparams + i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += x[u];
+    }
+    for (; b < b1; ++b) s += __builtin_nontemporal_load(p.gpart + (size_t)b * p.nparams + i);
     p.grad[i] = s;
 }
 
