@@ -198,6 +198,8 @@ struct pf_handle {
     // launches with at most this many 4-row groups run each group on TWO waves (pf_rg.hip: SPLIT): pays off while the
     // groups are far fewer than the CUs (config 2: node + head launch 19.0 -> 15.8 us; neutral at ~500 groups)
     int rg_split_max = 128;
+    int rg_split_max_node = 256;            // node launches: the two-wave form up to this many groups (PFDYN_RG_SPLIT_MAX_NODE)
+    int rg_split_max_head = 512;            // ... the fused last-layer node + noise-head launch, a 6-7 block chain (PFDYN_RG_SPLIT_MAX_HEAD)
     std::vector<int> last_family;           // per conv layer: pf_debug_kernel_family
     int last_hoist = 0;                     // pf_debug_l0_hoist
     int rg_rows_max = 1 << 30, rg2_rows_min = 12000;
@@ -238,7 +240,9 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_NO_PRUNE")) prune = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_ENC_FLY")) enc_on_the_fly = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_COMPACT")) rg_compact = atoi(e) == 0;
-        if (const char* e = getenv("PFDYN_RG_SPLIT_MAX")) rg_split_max = atoi(e);
+        if (const char* e = getenv("PFDYN_RG_SPLIT_MAX")) rg_split_max = rg_split_max_node = rg_split_max_head = atoi(e);
+        if (const char* e = getenv("PFDYN_RG_SPLIT_MAX_NODE")) rg_split_max_node = atoi(e);
+        if (const char* e = getenv("PFDYN_RG_SPLIT_MAX_HEAD")) rg_split_max_head = atoi(e);
         if (const char* e = getenv("PFDYN_NO_FAST_BUILD")) step_build_fast = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_RG_ROWS_MAX")) rg_rows_max = atoi(e);
         if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = rg2_rows_min_hoist = atoi(e);
@@ -898,8 +902,9 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         }
         if (rg) {
             const int rgn = std::max(1, h->rg_mode(n.ntiles));
-            const int nsplit = (!train && rgn == 1 && n.ntiles * 8 <= h->rg_split_max) ? 1 : 0;
-            if (last && !train && h->fuse_head && h->n_head_tiles == n.ntiles) {
+            const bool fuse = last && !train && h->fuse_head && h->n_head_tiles == n.ntiles;
+            const int nsplit = (!train && rgn == 1 && n.ntiles * 8 <= (fuse ? h->rg_split_max_head : h->rg_split_max_node)) ? 1 : 0;
+            if (fuse) {
                 HeadParams hp{};
                 hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
                 hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
