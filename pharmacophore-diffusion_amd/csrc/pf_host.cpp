@@ -205,7 +205,7 @@ struct pf_handle {
     int rg_rows_max = 1 << 30, rg2_rows_min = 12000;
     // compact pruned layer-0 launch under the static hoist: more than half of its items run a two-block chain, so 4 rows
     // per wave stay ahead up to a larger launch (config 2, 18.4 k slots: 437 k -> 444 k sample-steps/s; batch 64, 36.8 k slots: 701 k -> 714 k; batch 128 prefers 8)
-    int rg2_rows_min_hoist = 48000;
+    int rg2_rows_min_hoist = 17000;        // (48,000 until late in round 2: batches of 48-64 graphs gained 7-10 % from 8 rows per wave)
     // 0: tile kernels; 1 / 2: row-group kernels with 4 / 8 rows per wave
     int rg_mode(int ntiles) const {
         const long rows = (long)ntiles * 32;
