@@ -205,7 +205,12 @@ struct pf_handle {
     int rg_rows_max = 1 << 30, rg2_rows_min = 12000;
     // compact pruned layer-0 launch under the static hoist: more than half of its items run a two-block chain, so 4 rows
     // per wave stay ahead up to a larger launch (config 2, 18.4 k slots: 437 k -> 444 k sample-steps/s; batch 64, 36.8 k slots: 701 k -> 714 k; batch 128 prefers 8)
-    int rg2_rows_min_hoist = 17000;        // (48,000 until late in round 2: batches of 48-64 graphs gained 7-10 % from 8 rows per wave)
+    // compact pruned layer-0 launch under the hoist (slots = 32 x tiles of the launch; 256-atom pockets: ~560 per graph): from
+    // rg2p_rows_min slots the hoisted (two-block) items take 8 rows per wave, from rg2_rows_min_hoist the full-chain items too.
+    // Swept late in round 2 at batches of 8-256: all-4-rows wins up to 16 graphs, the mixed form by 3-8 % at 24-48, all-8-rows by
+    // 10 % at 64 and above (48,000 / no mixed form before)
+    int rg2_rows_min_hoist = 30000;
+    int rg2p_rows_min = 11000;
     // 0: tile kernels; 1 / 2: row-group kernels with 4 / 8 rows per wave
     int rg_mode(int ntiles) const {
         const long rows = (long)ntiles * 32;
@@ -245,7 +250,8 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_RG_SPLIT_MAX_HEAD")) rg_split_max_head = atoi(e);
         if (const char* e = getenv("PFDYN_NO_FAST_BUILD")) step_build_fast = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_RG_ROWS_MAX")) rg_rows_max = atoi(e);
-        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = rg2_rows_min_hoist = atoi(e);
+        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = rg2_rows_min_hoist = rg2p_rows_min = atoi(e);
+        if (const char* e = getenv("PFDYN_RG2P_ROWS_MIN")) rg2p_rows_min = atoi(e);
         if (const char* e = getenv("PFDYN_RG2_ROWS_MIN_HOIST")) rg2_rows_min_hoist = atoi(e);
         if (const char* e = getenv("PFDYN_NO_L0_HOIST")) l0_hoist = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_POCKET_SHARE")) share_disable = atoi(e) != 0;
@@ -854,8 +860,9 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 // like the dynamic regions do -- the general threshold applies; measured at 4-5 pockets x 30 copies:
                 // 1.21 M sample-steps/s end to end at 4 rows per wave, 1.26 M at 8)
                 rg = shared ? (h->share_rows >= h->rg2_rows_min ? 2 : 1) : ((long)e.ntiles * 32 >= h->rg2_rows_min_hoist ? 2 : 1);
+                const int rgp_pol = shared ? rg : ((long)e.ntiles * 32 >= h->rg2p_rows_min ? 2 : 1);
                 if (h->l0_rga) rg = h->l0_rga;
-                rgp = h->l0_rgp ? h->l0_rgp : rg;
+                rgp = h->l0_rgp ? h->l0_rgp : std::max(rg, rgp_pol);
                 if (rg == 2) rgp = 2;
                 for (int r = 0; r < e.nreg; ++r) e.ngroups_sel += region_groups(r, 4 * (r >= 3 * h->B ? rgp : rg));
             }
