@@ -859,7 +859,9 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 // (a shared launch: most of the representatives' groups return at once, what runs scales with the batch
                 // like the dynamic regions do -- the general threshold applies; measured at 4-5 pockets x 30 copies:
                 // 1.21 M sample-steps/s end to end at 4 rows per wave, 1.26 M at 8)
-                rg = shared ? (h->share_rows >= h->rg2_rows_min ? 2 : 1) : ((long)e.ntiles * 32 >= h->rg2_rows_min_hoist ? 2 : 1);
+                // (one pocket x 128 copies: few shared rows, but 128 graphs' worth of ff / pf / fp items -- 8 rows per wave is 8 % ahead)
+                rg = shared ? ((h->share_rows >= h->rg2_rows_min || (long)e.ntiles * 32 >= h->rg2_rows_min_hoist) ? 2 : 1)
+                            : ((long)e.ntiles * 32 >= h->rg2_rows_min_hoist ? 2 : 1);
                 const int rgp_pol = shared ? rg : ((long)e.ntiles * 32 >= h->rg2p_rows_min ? 2 : 1);
                 if (h->l0_rga) rg = h->l0_rga;
                 rgp = h->l0_rgp ? h->l0_rgp : std::max(rg, rgp_pol);
