@@ -211,6 +211,7 @@ struct pf_handle {
     // 10 % at 64 and above (48,000 / no mixed form before)
     int rg2_rows_min_hoist = 30000;
     int rg2p_rows_min = 11000;
+    int rg2_rows_min_node = 12000;         // node launches: 8 rows per wave from this many rows of their tile list (PFDYN_RG2_ROWS_MIN_NODE)
     // 0: tile kernels; 1 / 2: row-group kernels with 4 / 8 rows per wave
     int rg_mode(int ntiles) const {
         const long rows = (long)ntiles * 32;
@@ -250,8 +251,9 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_RG_SPLIT_MAX_HEAD")) rg_split_max_head = atoi(e);
         if (const char* e = getenv("PFDYN_NO_FAST_BUILD")) step_build_fast = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_RG_ROWS_MAX")) rg_rows_max = atoi(e);
-        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = rg2_rows_min_hoist = rg2p_rows_min = atoi(e);
+        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = rg2_rows_min_hoist = rg2p_rows_min = rg2_rows_min_node = atoi(e);
         if (const char* e = getenv("PFDYN_RG2P_ROWS_MIN")) rg2p_rows_min = atoi(e);
+        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN_NODE")) rg2_rows_min_node = atoi(e);
         if (const char* e = getenv("PFDYN_RG2_ROWS_MIN_HOIST")) rg2_rows_min_hoist = atoi(e);
         if (const char* e = getenv("PFDYN_NO_L0_HOIST")) l0_hoist = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_POCKET_SHARE")) share_disable = atoi(e) != 0;
@@ -910,7 +912,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             n.rgs_stride[nt] = (int)h->rgs_upd_stride[(size_t)l * 2 + nt];
         }
         if (rg) {
-            const int rgn = std::max(1, h->rg_mode(n.ntiles));
+            const int rgn = (long)n.ntiles * 32 >= h->rg2_rows_min_node ? 2 : 1;
             const bool fuse = last && !train && h->fuse_head && h->n_head_tiles == n.ntiles;
             const int nsplit = (!train && rgn == 1 && n.ntiles * 8 <= (fuse ? h->rg_split_max_head : h->rg_split_max_node)) ? 1 : 0;
             if (fuse) {
