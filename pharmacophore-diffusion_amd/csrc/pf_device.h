@@ -96,6 +96,43 @@ constexpr int rg_main_quad(const RgSched& s, const int nh, const int k) {
     return k < 4 * nh ? s.q_a + k : (k < 12 * nh ? s.q_b + k - 4 * nh : (k < 24 * nh ? s.q_cc + k - 12 * nh : s.q_d + k - 24 * nh));
 }
 
+// ---- "n16" kernels (pf_n16.hip): an item is 16 rows on the four waves of a workgroup, v_mfma_f32_16x16x4_f32 ----
+// Wave w owns output features [32 w, 32 w + 32) of every 128-output scalar Linear (two 16 x 16 tiles) and streams only
+// that quarter of its weights; waves 0..2 own one coordinate of the vector channel each.  The activations meet in LDS
+// once per GVP.  Every wave has its own quad stream per chain (wave w's stream n16_stride floats after wave w - 1's);
+// a block is one GVP, quads in consumption order (a quad = [64 lanes][4 images], image = one lane's share of an A
+// operand: lane 16 g + i <-> output row i, k = 4 ks + g of the k-step):
+//   GEN  [vh] [main x16] [sh x2] [vu] [bias x2] [gate x2]                               = 24   (128 + 16 -> 128 + 16)
+//   M0F  [x1] [vh] [w16] [main x16] [rbf x2] [sh x2] [vu] [bias x2] [gate x2]           = 28   first message GVP
+//   M0Z  [x1] [xh] [main x16] [rbf x2] [sh x2] [vu] [bias x2] [gate x2]                 = 27   ... when v_src == 0 (conv layer 0)
+//   M0H  [x1] [xh] [rbf x2] [sh x2] [vu] [gate x2]                                      = 9    ... and h_src is a row of a type table
+// Scalar k-step ks (0..31), lane group g <-> input feature 16 (ks >> 2) + 4 g + (ks & 3): the D fragment of tile T = 2 w + t
+// (lane 16 g + j, register r: feature 16 T + 4 g + r of row j) is the B operand of k-step 4 T + r without any data movement.
+#define N16_D 12            // depth of the register prefetch ring in quads (GEN blocks are a multiple of it)
+#define N16_TAIL_PAD 16     // quads of read-ahead padding behind every wave's stream
+enum { N16_GEN = 0, N16_M0F = 1, N16_M0Z = 2, N16_M0H = 3 };
+struct N16Sched { int q_x1, q_vh, q_w16, q_main, q_rbf, q_sh, q_vu, q_b, q_gate, nq; };
+constexpr N16Sched n16_sched(const int kind) {
+    N16Sched s{};
+    int q = 0;
+    const bool m0 = kind != N16_GEN;
+    s.q_x1 = m0 ? q++ : -1;
+    s.q_vh = q++;
+    s.q_w16 = kind == N16_M0F ? q++ : -1;
+    s.q_main = kind != N16_M0H ? q : -1;
+    if (kind != N16_M0H) q += 16;
+    s.q_rbf = m0 ? q : -1;
+    if (m0) q += 2;
+    s.q_sh = q; q += 2;
+    s.q_vu = q++;
+    s.q_b = kind != N16_M0H ? q : -1;
+    if (kind != N16_M0H) q += 2;
+    s.q_gate = q; q += 2;
+    s.nq = q;
+    return s;
+}
+static_assert(n16_sched(N16_GEN).nq % N16_D == 0, "GEN blocks must keep the ring phase");
+
 struct EdgeTile {          // one wave = 32 edge slots
     int e0;                // first edge slot
     int n;                 // slots in this tile (<= 32)
@@ -153,6 +190,8 @@ struct EdgeParams {
     const int* need; int need_stamp;   // pocket sharing: a kind-3 item runs only if one of its destinations carries the stamp
     int pa_abs;            // pocket sharing: the kind-3 regions are ranges of STATIC slots with arbitrary starts; their
                            // groups are cut on absolute multiples of the group size (what the node kernel's e | (grp - 1) expects)
+    // n16 kernels (pf_n16.hip): wave 0's quad stream of each etype's message chain; wave w's n16_stride[et] floats further
+    pf_gcf n16[4]; int n16_stride[4];
 };
 
 // static-hoist source block in the packed weights (pure copies of the first pp message GVP of conv layer 0 and of the
@@ -200,6 +239,7 @@ struct UnitParams {
     // kind 3 as the training forward of the noise head: per GVP level and row the pre-activation scalars [128], gate
     // pre-activations [16] and gated vectors [48] k_bwd_head reads instead of recomputing the chain (NULL: not saved)
     float* sv_z; float* sv_g; float* sv_v; size_t sv_stride;
+    int n16_stride;                           // kinds 16 / 17: the message / update chain in the n16 form (stream = wave 0's)
 };
 
 struct NodeParams {

@@ -33,6 +33,8 @@ void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int r
 void pfk_l0_hoist(const L0HoistParams* p, int what, hipStream_t s);
 void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s);
 void pfk_rg_unit(const UnitParams* p, hipStream_t s);
+void pfk_n16_edge(const EdgeParams* p, int layer0, hipStream_t s);
+void pfk_n16_unit(const UnitParams* p, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
 void pfk_encode_build_pre(const EncodeParams* e, const BuildParams* b, const PreParams* pp, hipStream_t s);
@@ -195,6 +197,12 @@ struct pf_handle {
     std::vector<size_t> rg_msg, rg_upd;
     std::vector<size_t> rgs_msg, rgs_upd, rgs_upd_stride;   // two-wave form: wave 0's stream; wave 1's follows *_stride floats later
     size_t rgs_msg_stride = 0;
+    // n16 kernels (pf_n16.hip): per chain the four waves' quad streams, wave w's *_stride floats after wave w - 1's.
+    // n16_msg: every message chain with a full first GVP (M0F: what conv layers >= 1 run, and what pf_debug_chain tests)
+    std::vector<size_t> n16_msg, n16_upd;
+    size_t n16_msg_stride = 0, n16_upd_stride = 0;
+    // which launches of the inference path take the n16 form (PFDYN_N16, bit mask): 1 edge launches of conv layers >= 1
+    int n16_mask = 0;
     // launches with at most this many 4-row groups run each group on TWO waves (pf_rg.hip: SPLIT): pays off while the
     // groups are far fewer than the CUs (config 2: node + head launch 19.0 -> 15.8 us; neutral at ~500 groups)
     int rg_split_max = 128;
@@ -263,6 +271,7 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_TRAIN_NODE_RECOMPUTE")) train_node_save = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_L0_RGP")) l0_rgp = atoi(e);
         if (const char* e = getenv("PFDYN_L0_RGA")) l0_rga = atoi(e);
+        if (const char* e = getenv("PFDYN_N16")) n16_mask = atoi(e);
     }
 
     // ---- gradient path (pf_train_*): flat parameter vector in state-dict order, GvpT tables, per-layer activations
@@ -614,6 +623,67 @@ static void pack_out_rg(pf_handle* h, std::vector<float>& out) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// n16 kernels (pf_n16.hip; schedules: n16_sched in pf_device.h): wave w's block of GVP g.  An image is one lane's share
+// of an A operand of v_mfma_f32_16x16x4_f32: lane 16 gq + i <-> output row i of the tile, k = gq of the k-step.
+// Scalar k-step ks <-> input feature 16 (ks >> 2) + 4 gq + (ks & 3); vector / rbf / sh k-step r <-> channel 4 gq + r.
+// ------------------------------------------------------------------------------------------------
+static void pack_n16(pf_handle* h, const GvpSpec& g, int kind, int w, std::vector<float>& out) {
+    const N16Sched q = n16_sched(kind);
+    const int H = std::max(g.vi, g.vo), Kin = H + g.si;
+    const bool m0 = kind != N16_GEN, vz = kind == N16_M0Z || kind == N16_M0H;
+    const int v0 = g.vi == 17 ? 1 : 0;
+    const std::vector<float>& W = h->raw[g.prefix + "to_feats_out.0.weight"].data;            // [so][si + H]
+    const std::vector<float>& Bv = h->raw[g.prefix + "to_feats_out.0.bias"].data;
+    const std::vector<float>& Wg = h->raw[g.prefix + "scalar_to_vector_gates.weight"].data;   // [vo][so]
+    const std::vector<float>& bg = h->raw[g.prefix + "scalar_to_vector_gates.bias"].data;
+    const std::vector<float>& wh = h->raw[g.prefix + "Wh"].data;                              // [vi][H]
+    const std::vector<float>& wu = h->raw[g.prefix + "Wu"].data;                              // [H][vo]
+    const size_t base = out.size();
+    out.resize(base + (size_t)q.nq * 256, 0.f);
+    auto at = [&](int quad, int lane, int j) -> float& { return out[base + ((size_t)quad * 64 + lane) * 4 + j]; };
+    for (int lane = 0; lane < 64; ++lane) {
+        const int gq = lane >> 4, i = lane & 15;
+        const int f0 = 32 * w + i, f1 = 32 * w + 16 + i;             // this lane's output rows of tile 0 / tile 1
+        if (m0) {
+            at(q.q_x1, lane, 0) = gq == 0 ? W[(size_t)f0 * Kin + g.si + 16] : 0.f;
+            at(q.q_x1, lane, 1) = gq == 0 ? W[(size_t)f1 * Kin + g.si + 16] : 0.f;
+            at(q.q_x1, lane, 2) = (gq == 0 && w < 3) ? wu[(size_t)16 * g.vo + i] : 0.f;
+            at(q.q_x1, lane, 3) = gq == 0 ? wh[(size_t)0 * H + i] : (lane == 16 ? wh[(size_t)0 * H + 16] : 0.f);
+        }
+        for (int r = 0; r < 4; ++r) {
+            if (vz) at(q.q_vh, lane, r) = wh[(size_t)0 * H + 4 * gq + r];                     // Vh = Wh[0] (x) xhat
+            else if (w < 3) at(q.q_vh, lane, r) = wh[(size_t)(v0 + 4 * gq + r) * H + i];
+            if (q.q_w16 >= 0 && w < 3) at(q.q_w16, lane, r) = wh[(size_t)(v0 + 4 * gq + r) * H + 16];
+            at(q.q_vu, lane, r) = w < 3 ? wu[(size_t)(4 * gq + r) * g.vo + i] : bg[4 * gq + r];
+        }
+        if (q.q_main >= 0)
+            for (int qm = 0; qm < 16; ++qm)
+                for (int half = 0; half < 2; ++half) {
+                    const int ks = 2 * qm + half, f = 16 * (ks >> 2) + 4 * gq + (ks & 3);
+                    at(q.q_main + qm, lane, 2 * half) = W[(size_t)f0 * Kin + f];
+                    at(q.q_main + qm, lane, 2 * half + 1) = W[(size_t)f1 * Kin + f];
+                }
+        for (int qq = 0; qq < 2; ++qq)
+            for (int half = 0; half < 2; ++half) {
+                const int r = 2 * qq + half;
+                if (m0) {
+                    at(q.q_rbf + qq, lane, 2 * half) = W[(size_t)f0 * Kin + PF_S + 4 * gq + r];
+                    at(q.q_rbf + qq, lane, 2 * half + 1) = W[(size_t)f1 * Kin + PF_S + 4 * gq + r];
+                }
+                at(q.q_sh + qq, lane, 2 * half) = W[(size_t)f0 * Kin + g.si + 4 * gq + r];
+                at(q.q_sh + qq, lane, 2 * half + 1) = W[(size_t)f1 * Kin + g.si + 4 * gq + r];
+            }
+        if (q.q_b >= 0)
+            for (int r = 0; r < 4; ++r) {
+                at(q.q_b, lane, r) = Bv[32 * w + 4 * gq + r];
+                at(q.q_b + 1, lane, r) = Bv[32 * w + 16 + 4 * gq + r];
+            }
+        for (int t = 0; t < 2; ++t)
+            for (int r = 0; r < 4; ++r) at(q.q_gate + t, lane, r) = Wg[(size_t)i * g.so + 32 * w + 16 * t + 4 * gq + r];
+    }
+}
+
 // keep_ws: the inference workspace stays allocated (pf_set_pocket_batch re-carves it when the next batch fits: a
 // hipMalloc / hipFree pair of a few hundred MB per batch costs milliseconds)
 static void free_ws(pf_handle* h, bool keep_ws = false) {
@@ -872,12 +942,21 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             }
             h->last_hoist = 4 * rgp;
         }
+        // n16 form (pf_n16.hip): 16-row items on four waves; conv layers >= 1 (their first message GVP reads h / v from memory)
+        const bool n16e = !train && rg && l > 0 && (h->n16_mask & 1) && !h->n16_msg.empty();
+        if (n16e) {
+            for (int et = 0; et < 4; ++et) { e.n16[et] = h->d_w + h->n16_msg[(size_t)l * 4 + et]; e.n16_stride[et] = (int)h->n16_msg_stride; }
+            e.ngroups_sel = 0;
+            for (int r = 0; r < e.nreg; ++r) e.ngroups_sel += region_groups(r, 16);
+            rg = 4;                                  // 16 slots per partial-row group
+        }
         h->last_family.resize(c.n_convs);
         h->last_family[l] = rg ? 4 * rg : ((!train && e.ntiles <= ((last || pruned) ? std::max(h->coop_edge_max, h->coop2_edge_max) : std::max(h->coop_edge_max, h->coop2_dense_max))) ? 128 : 32);
         for (int et = 0; et < 4; ++et) e.rgs[et] = h->d_w + h->rgs_msg[(size_t)l * 4 + et];
         e.rgs_stride = (int)h->rgs_msg_stride;
         const int esplit = (rg == 1 && e.ntiles * 8 <= h->rg_split_max && !e.zs) ? 1 : 0;    // fewer groups than SIMDs: latency-bound
-        if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, esplit, rgp, s); }
+        if (n16e) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_n16_edge(&e, 0, s); }
+        else if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, esplit, rgp, s); }
         else if (e.ntiles <= h->coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
         else if (e.ntiles <= ((last || pruned) ? h->coop2_edge_max : h->coop2_dense_max) && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop2(&e, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
@@ -1224,6 +1303,28 @@ int pf_commit_weights(pf_handle* h) {
             st.resize(st.size() + (size_t)RG_TAIL_PAD * 256, 0.f);
             h->rgs_upd[(size_t)(c.n_convs - 1) * 2 + 1] = flush();
         }
+        if (c.n_message_gvps >= 2 && c.n_update_gvps >= 1) {   // n16 quad streams: per chain wave 0's stream, then waves 1..3
+            h->n16_msg.assign((size_t)c.n_convs * 4, 0);
+            h->n16_upd.assign((size_t)c.n_convs * 2, 0);
+            std::vector<float> st;
+            auto chain16 = [&](auto spec_of, int n, int kind0, size_t& stride) {
+                for (int w = 0; w < 4; ++w) {
+                    const size_t b0 = st.size();
+                    for (int j = 0; j < n; ++j) pack_n16(h, spec_of(j), j == 0 ? kind0 : N16_GEN, w, st);
+                    st.resize(st.size() + (size_t)N16_TAIL_PAD * 256, 0.f);
+                    stride = st.size() - b0;
+                }
+                const size_t off = push(h->h_w, st);
+                st.clear();
+                return off;
+            };
+            for (int l = 0; l < c.n_convs; ++l)
+                for (int et = 0; et < 4; ++et)
+                    h->n16_msg[(size_t)l * 4 + et] = chain16([&](int j) { return msg_spec(c, l, et, j); }, c.n_message_gvps, N16_M0F, h->n16_msg_stride);
+            for (int l = 0; l < c.n_convs; ++l)
+                for (int nt = 0; nt < 2; ++nt)
+                    h->n16_upd[(size_t)l * 2 + nt] = chain16([&](int j) { return upd_spec(c, l, nt, j); }, c.n_update_gvps, N16_GEN, h->n16_upd_stride);
+        } else { h->n16_msg.clear(); h->n16_upd.clear(); }
         while (h->h_w.size() % 64) h->h_w.push_back(0.f);
     };
     {
@@ -2395,6 +2496,20 @@ int pf_debug_chain(pf_handle* h, int32_t kind, int32_t layer, int32_t sub, int32
     int rc = check_ready(h, false);
     if (rc) return rc;
     const pf_config& c = h->cfg;
+    if (kind == 16 || kind == 17) {           // the message / update chain in the n16 form (pf_n16.hip); rows as for kinds 0 / 1
+        if (n_rows < 0 || !dev_s_in || !dev_v_in || !dev_s_out || !dev_v_out) PF_FAIL(h, PF_ERR_ARG, "pf_debug_chain: bad argument");
+        if (layer < 0 || layer >= c.n_convs || sub < 0 || sub > (kind == 16 ? 3 : 1)) PF_FAIL(h, PF_ERR_ARG, "pf_debug_chain: bad layer / sub index");
+        if (h->n16_msg.empty()) PF_FAIL(h, PF_ERR_STATE, "pf_debug_chain: this architecture has no n16 streams (needs n_message_gvps >= 2)");
+        UnitParams p{};
+        p.s_in = dev_s_in; p.v_in = dev_v_in; p.s_out = dev_s_out; p.v_out = dev_v_out;
+        p.n = n_rows; p.kind = kind;
+        if (kind == 16) { p.stream = h->d_w + h->n16_msg[(size_t)layer * 4 + sub]; p.n_gvps = c.n_message_gvps; p.n16_stride = (int)h->n16_msg_stride; }
+        else { p.stream = h->d_w + h->n16_upd[(size_t)layer * 2 + sub]; p.n_gvps = c.n_update_gvps; p.n16_stride = (int)h->n16_upd_stride; }
+        pfk_n16_unit(&p, (hipStream_t)stream);
+        hipError_t e16 = hipGetLastError();
+        if (e16 != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e16));
+        return PF_OK;
+    }
     if (kind < 0 || kind > 3 || n_rows < 0 || !dev_s_in || !dev_v_in || !dev_s_out || !dev_v_out) PF_FAIL(h, PF_ERR_ARG, "pf_debug_chain: bad argument");
     if (kind != 3 && (layer < 0 || layer >= c.n_convs)) PF_FAIL(h, PF_ERR_ARG, "pf_debug_chain: bad layer");
     if ((kind == 0 && (sub < 0 || sub > 3)) || ((kind == 1 || kind == 2) && (sub < 0 || sub > 3))) PF_FAIL(h, PF_ERR_ARG, "pf_debug_chain: bad sub index");

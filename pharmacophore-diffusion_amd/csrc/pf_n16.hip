@@ -1,0 +1,496 @@
+// pf_n16.hip -- "n16" kernels of the denoising path (gfx950 only): an item is SIXTEEN rows (edge slots or nodes) on the
+// FOUR waves of a workgroup, on v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles, the same 64 FLOP/clk/SIMD as every f32
+// matrix instruction).
+//
+// Same mathematics as pf_rg.hip / pf_kernels.hip (GVP.forward gvp.py:89-116, GVPMultiEdgeConv gvp.py:459-551), third
+// mapping onto the matrix cores.  Why: a 4-row item of pf_rg.hip pulls ALL weights of a GVP (96 KiB) through one wave
+// for four rows -- ~115 cycles per 1-KiB quad where the matrix pipe needs 64, and 390 MB of L2 traffic per layer-0
+// launch of config 2.  Here
+//   * the OUTPUT features of every 128-output Linear are dealt over the four waves: wave w owns features [32 w, 32 w + 32)
+//     = two 16 x 16 tiles and streams a QUARTER of the weights, for 16 rows: 1/16 of the weight bytes per row and wave,
+//     and the four SIMDs of a CU work on one item;
+//   * weights are the A operand (lane 16 g + i: output row i of the tile, k = 4 ks + g), activations the B operand
+//     (lane 16 g + j: row j, k = 4 ks + g).  A D fragment (lane 16 g + j, register r: output 4 g + r of row j) is a valid B
+//     operand of the next Linear as it stands when that Linear's weights are packed in the matching order of K, so inside
+//     a wave nothing moves between lanes;
+//   * what a wave lacks of the next GVP's input -- the other waves' 96 SiLU outputs per row, the three coordinates of Vh
+//     for sh = |Vh|, the K-split partial sums of the 128 -> 16 gate Linear -- goes through 15 KiB of LDS behind two
+//     LDS-only barriers per GVP, placed after long stretches of matrix instructions (arrival times are even);
+//   * the vector channel is dealt by COORDINATE: wave c < 3 computes Vh, Vu and the gated output of coordinate c (wave 3
+//     contributes the gate bias), so a coordinate's chain is lane-local from GVP to GVP;
+//   * a wave's quarter of a chain is one contiguous quad stream in consumption order (pf_host.cpp: pack_n16),
+//     prefetched N16_D quads ahead in registers across GVP boundaries, read through a buffer descriptor.
+// Schedules: pf_device.h (n16_sched).  Launch policy: pf_host.cpp.  Measurements: DESIGN.md section 4.1.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <algorithm>
+#include "pf_device.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrtf_(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float rsqf_(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * rcpf_(1.0f + __expf(-x)); }
+
+__device__ __forceinline__ f32x4 mfma16(const float a, const float b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// x[l] + x[l ^ 32], x[l] + x[l ^ 16] (see pf_rg.hip: the compiler's permlane-swap builtins mis-assign their second result)
+__device__ __forceinline__ float xsum32(const float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float xsum16(const float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+// sum over the four lane groups g (lanes l, l ^ 16, l ^ 32, l ^ 48): every lane of a row ends with the row's sum
+__device__ __forceinline__ float gsum(const float v) { return xsum16(xsum32(v)); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(const float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(const int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_ir(const int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+// value of lane L in every lane (the element is copied out first: __builtin_bit_cast applied directly to an element of an
+// ext_vector_type read element 0 with this compiler)
+__device__ __forceinline__ float lane_bcast(const float v, const int L) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), L));
+}
+// orders LDS only: __syncthreads() would also drain the weight ring's outstanding global loads
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// register prefetch ring over a wave's quad stream (the stream is read through a buffer descriptor: scalar base and
+// stream position, the lane's 16 bytes in one vector register -- no per-quad vector address arithmetic)
+struct N16Ring {
+    f32x4 q[N16_D];
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned loff;                            // 16 * lane
+    unsigned blk;                             // byte offset of quad 0 of the current block (wave-uniform)
+    __device__ __forceinline__ f32x4 load(const int qi) const {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, loff, blk + (unsigned)qi * 1024u, 0));
+    }
+    __device__ __forceinline__ void advance(const int nq) { blk += (unsigned)nq * 1024u; }
+};
+__device__ __forceinline__ void ring_start(N16Ring& r, pf_gcf stream, const int lane) {
+    const unsigned long long a = (unsigned long long)stream;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    r.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+    r.loff = 16u * (unsigned)lane;
+    r.blk = 0;
+    static_for<0, N16_D>([&](auto I) { r.q[decltype(I)::value] = r.load(decltype(I)::value); });
+}
+
+// LDS of one item (one workgroup): every buffer has a barrier between a read and the next write (see n16_block)
+struct __attribute__((aligned(16))) N16Lds {
+    float s[8 * 64 * 4];                      // SiLU outputs: [tile T = 2 w + t][lane][r] = feature 16 T + 4 g + r of row j
+    float v[3 * 64 * 4];                      // Vh per coordinate: [c][lane][r] = hidden channel 4 g + r of row j
+    float g[4 * 64 * 4];                      // K-split partial sums of the gate Linear per wave: [w][lane][r] = channel 4 g + r
+    float v16[3 * 16];                        // first message GVP (17 hidden channels): Vh[16] per coordinate and row
+};
+
+// what the first message GVP of an edge needs besides the source row
+struct N16In {
+    float rb[4];                              // rbf image: lane 16 g + j holds rbf_{4 g + r}(d_j)
+    float xh[3];                              // unit x_diff of row j (every lane of the row)
+};
+
+// ---------------------------------------------------------------------------------------------
+// One GVP (gvp.py:89-116) on the 16 rows of an item, on the four waves of the workgroup (wq = wave, 0..3).
+//   XS [32]  in : scalar input as B operands (k-step ks: feature 16 (ks >> 2) + 4 g + (ks & 3) of row j); unused by M0H
+//            out: the SiLU output in the same form (!LAST)
+//   VB [4]   in : vector input of coordinate wq as B operands (register r: channel 4 g + r of row j; 0 on wave 3);
+//                 unused by the kinds whose node vectors are zero
+//            out: the gated output vectors of coordinate wq (waves 0..2)
+//   S  [2]   in : M0H only: the pre-activation so far (type-table row of the source, bias folded in), D layout
+//            out: the SiLU output of this wave's 32 features (tile t, register r: feature 32 wq + 16 t + 4 g + r)
+//   OFF      ring phase: quad qi of the block sits in ring slot (OFF + qi) % N16_D
+//   LAST     last GVP of the chain: the SiLU output is not exchanged (XS is not written)
+// Barriers: A (Vh of the three coordinates -> sh; only the kinds with a vector input) and B (SiLU outputs, gate sums).
+// ---------------------------------------------------------------------------------------------
+template <int KIND, int OFF, bool LAST>
+__device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float (&VB)[4], const N16In& in, f32x4 (&S)[2],
+                                          N16Lds* lds, const int lane, const int wq) {
+    constexpr N16Sched Q = n16_sched(KIND);
+    constexpr bool M0 = KIND != N16_GEN;                              // 17 hidden vector channels, rbf inputs
+    constexpr bool VZ = KIND == N16_M0Z || KIND == N16_M0H;           // the node vectors are zero: Vh = Wh[0] (x) xhat
+    constexpr bool HOIST = KIND == N16_M0H;
+    const int g = lane >> 4;
+    const bool vecw = wq < 3;                                         // wave-uniform
+    const bool g0 = g == 0;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, vh = acc0, vu = acc0, gp = acc0;
+    if constexpr (HOIST) { acc0 = S[0]; acc1 = S[1]; }
+    f32x4 x1 = acc0, b0 = acc0, gbias = acc0, sh = acc0;
+    float vh16 = 0.f, sh16 = 0.f;
+    const float xhc = M0 ? (wq == 0 ? in.xh[0] : (wq == 1 ? in.xh[1] : (wq == 2 ? in.xh[2] : 0.f))) : 0.f;
+    static_for<0, Q.nq>([&](auto QI) {
+        constexpr int qi = decltype(QI)::value;
+        const f32x4 w = ring.q[(OFF + qi) % N16_D];
+        ring.q[(OFF + qi) % N16_D] = ring.load(qi + N16_D);
+        if constexpr (qi == Q.q_x1) {
+            x1 = w;                                   // [sh16 column tile 0, tile 1, Wu[16][i], Wh[0][i] (lane 16: Wh[0][16])]
+        } else if constexpr (qi == Q.q_vh) {
+            if constexpr (VZ) {
+                // Vh[h][c] = Wh[0][h] xhat_c: this wave's coordinate for Vu, all three for sh (no exchange)
+                const float w016 = lane_bcast(x1[3], 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vh[r] = w[r] * xhc;
+                    const float a = w[r] * in.xh[0], b = w[r] * in.xh[1], c = w[r] * in.xh[2];
+                    sh[r] = sqrtf_(fmaxf(a * a + b * b + c * c, 1e-8f));
+                }
+                vh16 = w016 * xhc;
+                const float a = w016 * in.xh[0], b = w016 * in.xh[1], c = w016 * in.xh[2];
+                sh16 = sqrtf_(fmaxf(a * a + b * b + c * c, 1e-8f));
+            } else if (vecw) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vh = mfma16(w[r], VB[r], vh);
+                if constexpr (M0) vh = mfma16(g0 ? x1[3] : 0.f, g0 ? xhc : 0.f, vh);      // the unit x_diff channel
+                if constexpr (!M0) *reinterpret_cast<f32x4*>(&lds->v[(wq * 64 + lane) * 4]) = vh;
+            }
+        } else if constexpr (qi == Q.q_w16) {         // hidden channel 16 of Vh on the vector ALU: [Wh[v0 + 4 g + r][16]]
+            if (vecw) {
+                const float w016 = lane_bcast(x1[3], 16);
+                float pv = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv = fmaf(w[r], VB[r], pv);
+                vh16 = fmaf(w016, xhc, gsum(pv));
+                *reinterpret_cast<f32x4*>(&lds->v[(wq * 64 + lane) * 4]) = vh;
+                if (g0) lds->v16[wq * 16 + (lane & 15)] = vh16;
+            }
+        } else if constexpr (Q.q_main >= 0 && qi >= Q.q_main && qi < Q.q_main + 16) {
+            constexpr int ks = 2 * (qi - Q.q_main);
+            acc0 = mfma16(w[0], XS[ks], acc0);
+            acc1 = mfma16(w[1], XS[ks], acc1);
+            acc0 = mfma16(w[2], XS[ks + 1], acc0);
+            acc1 = mfma16(w[3], XS[ks + 1], acc1);
+        } else if constexpr (M0 && qi >= Q.q_rbf && qi < Q.q_rbf + 2) {
+            constexpr int r0 = 2 * (qi - Q.q_rbf);
+            acc0 = mfma16(w[0], in.rb[r0], acc0);
+            acc1 = mfma16(w[1], in.rb[r0], acc1);
+            acc0 = mfma16(w[2], in.rb[r0 + 1], acc0);
+            acc1 = mfma16(w[3], in.rb[r0 + 1], acc1);
+        } else if constexpr (qi >= Q.q_sh && qi < Q.q_sh + 2) {
+            constexpr int r0 = 2 * (qi - Q.q_sh);
+            if constexpr (r0 == 0 && !VZ) {           // barrier A: the three coordinates of Vh are in LDS
+                lds_barrier();
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&lds->v[(0 * 64 + lane) * 4]);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(&lds->v[(1 * 64 + lane) * 4]);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(&lds->v[(2 * 64 + lane) * 4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sh[r] = sqrtf_(fmaxf(a[r] * a[r] + b[r] * b[r] + c[r] * c[r], 1e-8f));
+                if constexpr (M0) {
+                    const float x6 = lds->v16[lane & 15], y6 = lds->v16[16 + (lane & 15)], z6 = lds->v16[32 + (lane & 15)];
+                    sh16 = sqrtf_(fmaxf(x6 * x6 + y6 * y6 + z6 * z6, 1e-8f));
+                }
+            }
+            acc0 = mfma16(w[0], sh[r0], acc0);
+            acc1 = mfma16(w[1], sh[r0], acc1);
+            acc0 = mfma16(w[2], sh[r0 + 1], acc0);
+            acc1 = mfma16(w[3], sh[r0 + 1], acc1);
+            if constexpr (M0 && r0 == 2) {            // hidden channel 16: one more k-step, k = 0 only
+                acc0 = mfma16(g0 ? x1[0] : 0.f, g0 ? sh16 : 0.f, acc0);
+                acc1 = mfma16(g0 ? x1[1] : 0.f, g0 ? sh16 : 0.f, acc1);
+            }
+        } else if constexpr (qi == Q.q_vu) {
+            if (vecw) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vu = mfma16(w[r], vh[r], vu);
+                if constexpr (M0) vu = mfma16(g0 ? x1[2] : 0.f, g0 ? vh16 : 0.f, vu);
+            } else gbias = w;                          // wave 3's stream carries the gate bias here
+            if constexpr (HOIST) { S[0] = acc0; S[1] = acc1; }
+        } else if constexpr (Q.q_b >= 0 && qi == Q.q_b) {
+            b0 = w;
+        } else if constexpr (Q.q_b >= 0 && qi == Q.q_b + 1) {
+            S[0] = acc0 + b0;
+            S[1] = acc1 + w;
+        } else if constexpr (qi >= Q.q_gate && qi < Q.q_gate + 2) {
+            constexpr int t = qi - Q.q_gate;
+            if constexpr (t == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { S[0][r] = siluf_(S[0][r]); S[1][r] = siluf_(S[1][r]); }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gp = mfma16(w[r], S[t][r], gp);
+            if constexpr (t == 1) {                   // publish; barrier B; collect
+                if (!vecw) gp += gbias;
+                *reinterpret_cast<f32x4*>(&lds->g[(wq * 64 + lane) * 4]) = gp;
+                if constexpr (!LAST) {
+                    *reinterpret_cast<f32x4*>(&lds->s[((2 * wq) * 64 + lane) * 4]) = S[0];
+                    *reinterpret_cast<f32x4*>(&lds->s[((2 * wq + 1) * 64 + lane) * 4]) = S[1];
+                }
+                lds_barrier();
+                if constexpr (!LAST) {
+#pragma unroll
+                    for (int T = 0; T < 8; ++T) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(&lds->s[(T * 64 + lane) * 4]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) XS[4 * T + r] = x[r];
+                    }
+                }
+                if (vecw) {
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(&lds->g[(0 * 64 + lane) * 4]);
+                    const f32x4 gb = *reinterpret_cast<const f32x4*>(&lds->g[(1 * 64 + lane) * 4]);
+                    const f32x4 gc = *reinterpret_cast<const f32x4*>(&lds->g[(2 * 64 + lane) * 4]);
+                    const f32x4 gd = *reinterpret_cast<const f32x4*>(&lds->g[(3 * 64 + lane) * 4]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) VB[r] = sigmoidf_((ga[r] + gb[r]) + (gc[r] + gd[r])) * vu[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) VB[r] = 0.f;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    ring.advance(Q.nq);
+}
+
+// segmented inclusive scan over the 16 rows of an item (one 16-lane DPP row per lane group): rows are sorted by key
+struct SegMask16 { float m1, m2, m4, m8; };
+__device__ __forceinline__ SegMask16 seg_masks16(const int key, const int j) {
+    const int k1 = dpp_i<0x111>(key), k2 = dpp_i<0x112>(key), k4 = dpp_i<0x114>(key), k8 = dpp_i<0x118>(key);
+    SegMask16 m;
+    m.m1 = ((j >= 1) & (k1 == key)) ? 1.f : 0.f;
+    m.m2 = ((j >= 2) & (k2 == key)) ? 1.f : 0.f;
+    m.m4 = ((j >= 4) & (k4 == key)) ? 1.f : 0.f;
+    m.m8 = ((j >= 8) & (k8 == key)) ? 1.f : 0.f;
+    return m;
+}
+__device__ __forceinline__ float seg_scan16(float v, const SegMask16& m) {
+    v = fmaf(dpp_f<0x111>(v), m.m1, v);
+    v = fmaf(dpp_f<0x112>(v), m.m2, v);
+    v = fmaf(dpp_f<0x114>(v), m.m4, v);
+    v = fmaf(dpp_f<0x118>(v), m.m8, v);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Edge messages (gvp.py:472-485, 540-551): one item = the 16 edge slots [e0, e0 + nv) of etype et.  Slots are sorted by
+// destination: the rows of one destination are consecutive lanes of a 16-lane row, a segmented scan leaves each
+// (item, destination) run's sum in its last lane, and only those lanes store a partial row (at their own slot) -- what
+// the node kernels read with NodeParams::grp = 16.
+// ---------------------------------------------------------------------------------------------
+template <int KIND0>
+__device__ __forceinline__ void n16_edge_item(const EdgeParams& p, N16Lds* lds, const int e0, const int nv, const int et,
+                                              const int lane, const int wq) {
+    constexpr int OFF1 = n16_sched(KIND0).nq % N16_D;
+    N16Ring ring;
+    ring_start(ring, p.n16[et] + (size_t)wq * p.n16_stride[et], lane);      // in flight under the gathers
+    const int g = lane >> 4, j = lane & 15;
+    const int e = e0 + min(j, nv - 1);
+    const int src = p.esrc[e], dst = p.edst[e];
+    const float4 xs = p.xn[src], xd = p.xn[dst];
+    float XS[32], VB[4];
+    f32x4 S[2];
+    if constexpr (KIND0 == N16_M0F || KIND0 == N16_M0Z) {
+        const f32x4 PF_AS1* hp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.h + (size_t)src * PF_S) + g;
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+            const f32x4 x = hp[4 * T];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) XS[4 * T + r] = x[r];
+        }
+    }
+    if constexpr (KIND0 == N16_M0F) {
+        pf_gcf vp = (pf_gcf)p.v + (size_t)src * 48 + 12 * g + (wq < 3 ? wq : 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float x = vp[3 * r]; VB[r] = wq < 3 ? x : 0.f; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) VB[r] = 0.f;
+    }
+    N16In in;
+    {
+        const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
+        const float d = sqrtf_(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+        const float rd = rcpf_(d);
+        in.xh[0] = dx * rd; in.xh[1] = dy * rd; in.xh[2] = dz * rd;
+        const float mu_step = (p.rbf_mu[PF_R - 1] - p.rbf_mu[0]) * (1.0f / (float)(PF_R - 1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ze = (d - fmaf((float)(4 * g + r), mu_step, p.rbf_mu[0])) * p.rbf_inv_sigma;
+            in.rb[r] = __expf(-(ze * ze));
+        }
+    }
+    S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
+    n16_block<KIND0, 0, false>(ring, XS, VB, in, S, lds, lane, wq);
+    for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false>(ring, XS, VB, in, S, lds, lane, wq);
+    n16_block<N16_GEN, OFF1, true>(ring, XS, VB, in, S, lds, lane, wq);
+    // per-destination sums in slot order, one partial row per (item, destination) run
+    const SegMask16 sm = seg_masks16(dst, j);
+    const int dnext = dpp_i<0x101>(dst);                 // row_shl 1: the next row's destination
+    const bool tail = (j == nv - 1) | ((j < nv - 1) & (dnext != dst));
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[t][r] = seg_scan16(S[t][r], sm);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) VB[r] = seg_scan16(VB[r], sm);
+    if (tail) {
+        float* ms = p.msg_s + (size_t)e * PF_S + 32 * wq + 4 * g;
+        *reinterpret_cast<f32x4*>(ms) = S[0];
+        *reinterpret_cast<f32x4*>(ms + 16) = S[1];
+        if (wq < 3) {
+            float* mv = p.msg_v + (size_t)e * 48 + 12 * g + wq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mv[3 * r] = VB[r];
+        }
+    }
+}
+
+// grid: one workgroup per 16-slot group (compact work list: the w-th non-empty group; tile lists: two groups per tile)
+template <bool L0>
+__global__ __launch_bounds__(256) void k_n16_edge(const EdgeParams p) {
+    __shared__ N16Lds lds;
+    const int lane = threadIdx.x & 63;
+    const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int item = (int)blockIdx.x;
+    int e0, nv, et;
+    if (p.nreg > 0) {
+        // compact work list (see k_rg_edge): every wave of the workgroup finds the item's region by the same wave scan
+        constexpr int NP = 16;                           // up to 64 * NP regions
+        const int w = item;
+        int first = 0, rsel = -1, cnt = 0, start = 0;
+        int cs[NP], rs[NP];
+        // (every pass's lengths and starts are requested before the first scan: one global round trip; the tests on the
+        // pass are scalar, the lane's index is clamped instead of branched on)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            cs[k] = 0; rs[k] = 0;
+            if (64 * k < p.nreg) {
+                const int r = min(64 * k + lane, p.nreg - 1);
+                const int c = p.dyn_cnt[r];
+                rs[k] = p.reg[r];
+                cs[k] = 64 * k + lane < p.nreg ? c : 0;
+            }
+        }
+        const int abs0 = p.pa_abs ? 3 * p.regB : 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if (64 * k < p.nreg && rsel < 0) {
+                const int c = cs[k];
+                const int ng = (64 * k + lane >= abs0) ? (c > 0 ? ((rs[k] + c - 1) >> 4) - (rs[k] >> 4) + 1 : 0) : (c + 15) >> 4;
+                int incl = ng;
+                incl += dpp_i<0x111>(incl); incl += dpp_i<0x112>(incl); incl += dpp_i<0x114>(incl); incl += dpp_i<0x118>(incl);
+                incl += dpp_ir<0x142, 0xa>(incl); incl += dpp_ir<0x143, 0xc>(incl);
+                incl += first;
+                const unsigned long long m = __ballot(incl > w);
+                if (m) {
+                    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                    rsel = 64 * k + l;
+                    first = __builtin_amdgcn_readlane(incl - ng, l);
+                    cnt = __builtin_amdgcn_readlane(c, l);
+                    start = __builtin_amdgcn_readlane(rs[k], l);
+                } else first = __builtin_amdgcn_readlane(incl, 63);
+            }
+        }
+        if (rsel < 0) return;                            // workgroup-uniform: beyond the last group
+        const int kind = rsel / p.regB;
+        if (p.pa_abs && kind == 3) {
+            const int lo = ((start >> 4) + (w - first)) << 4;
+            e0 = max(start, lo);
+            nv = __builtin_amdgcn_readfirstlane(min(start + cnt, lo + 16) - e0);
+        } else {
+            const int loc = (w - first) << 4;
+            e0 = start + loc;
+            nv = __builtin_amdgcn_readfirstlane(min(16, cnt - loc));
+        }
+        et = kind == 3 ? (int)ET_PP : kind;
+    } else {
+        if (item >= p.ntiles * 2) return;
+        const EdgeTile t = p.tiles[item >> 1];
+        int nvalid = t.n;
+        if (t.cnt_idx >= 0) nvalid = min(nvalid, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
+        const int base = (item & 1) * 16;
+        nv = __builtin_amdgcn_readfirstlane(min(16, nvalid - base));
+        if (nv <= 0) return;                             // workgroup-uniform
+        et = __builtin_amdgcn_readfirstlane(t.et);
+        e0 = t.e0 + base;
+    }
+    static_assert(!L0, "conv layer 0 in the n16 form: not built yet");
+    n16_edge_item<N16_M0F>(p, &lds, e0, nv, et, lane, wq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pf_debug_chain kinds 16 / 17: the message / update chain in the n16 form on caller-supplied rows (layouts of kinds 0 / 1)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_n16_unit(const UnitParams p) {
+    __shared__ N16Lds lds;
+    const int lane = threadIdx.x & 63;
+    const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int e0 = 16 * (int)blockIdx.x;
+    const int nv = __builtin_amdgcn_readfirstlane(min(16, p.n - e0));
+    if (nv <= 0) return;
+    const int g = lane >> 4, j = lane & 15;
+    const int row = e0 + min(j, nv - 1);
+    const bool msg = p.kind == 16;
+    const int sw = msg ? 144 : 128, vw = msg ? 51 : 48, v0 = msg ? 3 : 0;
+    N16Ring ring;
+    ring_start(ring, (pf_gcf)p.stream + (size_t)wq * p.n16_stride, lane);
+    float XS[32], VB[4];
+    f32x4 S[2];
+    S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
+#pragma unroll
+    for (int T = 0; T < 8; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) XS[4 * T + r] = p.s_in[(size_t)row * sw + 16 * T + 4 * g + r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) VB[r] = wq < 3 ? p.v_in[(size_t)row * vw + v0 + (4 * g + r) * 3 + wq] : 0.f;
+    N16In in;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) in.rb[r] = msg ? p.s_in[(size_t)row * sw + 128 + 4 * g + r] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) in.xh[c] = msg ? p.v_in[(size_t)row * vw + c] : 0.f;
+    if (msg) {
+        constexpr int OFF1 = n16_sched(N16_M0F).nq % N16_D;
+        n16_block<N16_M0F, 0, false>(ring, XS, VB, in, S, &lds, lane, wq);
+        for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false>(ring, XS, VB, in, S, &lds, lane, wq);
+        n16_block<N16_GEN, OFF1, true>(ring, XS, VB, in, S, &lds, lane, wq);
+    } else {
+        for (int gi = 0; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, 0, false>(ring, XS, VB, in, S, &lds, lane, wq);
+        n16_block<N16_GEN, 0, true>(ring, XS, VB, in, S, &lds, lane, wq);
+    }
+    if (j < nv) {
+        float* so = p.s_out + (size_t)row * 128 + 32 * wq + 4 * g;
+        *reinterpret_cast<f32x4*>(so) = S[0];
+        *reinterpret_cast<f32x4*>(so + 16) = S[1];
+        if (wq < 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p.v_out[(size_t)row * 48 + (4 * g + r) * 3 + wq] = VB[r];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+// layer0 = 0 only (so far); the grid is the launch's capacity in 16-slot groups (p->ngroups_sel) or two per tile
+void pfk_n16_edge(const EdgeParams* p, int layer0, hipStream_t s) {
+    if (p->ntiles == 0 || layer0) return;
+    const int grid = p->nreg > 0 ? p->ngroups_sel : p->ntiles * 2;
+    if (grid <= 0) return;
+    hipLaunchKernelGGL((k_n16_edge<false>), dim3(grid), dim3(256), 0, s, *p);
+}
+void pfk_n16_unit(const UnitParams* p, hipStream_t s) {
+    if (p->n <= 0) return;
+    hipLaunchKernelGGL(k_n16_unit, dim3((p->n + 15) / 16), dim3(256), 0, s, *p);
+}
+}

@@ -1,0 +1,73 @@
+"""GPU parity tests of the n16 kernels (pharmacophore-diffusion_amd/csrc/pf_n16.hip: 16-row items on the four waves of a
+workgroup, v_mfma_f32_16x16x4_f32), through the C ABI: the chain code in isolation against the reference's own module
+outputs (tests/golden/units.npz) and the oracle, and the kernels forced onto every dynamics golden.
+
+Tolerances as in test_gpu_parity.py (fp32 both sides): a chain 5e-5, a dynamics call 2e-4 + 2e-4 |ref|."""
+import pytest
+import torch
+
+from oracle import pf_oracle as O
+from helpers import DYN_CASES, batch_from, load
+from test_gpu_parity import UNIT_TOL, close, engine_for, set_batch
+
+pytestmark = pytest.mark.gpu
+
+ET_NAMES = ["pharm_ff_pharm", "prot_pf_pharm", "pharm_fp_prot", "prot_pp_prot"]
+
+
+def test_n16_chain_units_vs_reference_modules():
+    """pf_debug_chain kinds 16 / 17 (n16_block on supplied rows) against the reference's own GVP chains
+    (gvp.py:89-116; rows of tests/golden/units.npz): the 3-GVP message chain with a 17-channel first GVP and the 2-GVP
+    update chain, 37 rows = two full items and a ragged one."""
+    z = load("units.npz")
+    cfg = O.DynamicsConfig()
+    eng = engine_for(cfg, O.make_state_dict(cfg, 0))
+    so, vo = eng.debug_chain(16, 0, 1, z["chain_s"], z["chain_v"])           # edge_message_fns.prot_pf_pharm
+    close(so, z["chain_so"], UNIT_TOL, UNIT_TOL); close(vo, z["chain_vo"], UNIT_TOL, UNIT_TOL)
+    so, vo = eng.debug_chain(17, 0, 0, z["upd_s"], z["upd_v"])               # node_update_fns.prot
+    close(so, z["upd_so"], UNIT_TOL, UNIT_TOL); close(vo, z["upd_vo"], UNIT_TOL, UNIT_TOL)
+
+
+@pytest.mark.parametrize("arch", ["dev", "deep"])
+def test_n16_every_chain_vs_oracle(arch):
+    """Every message chain (layer x edge type) and update chain (layer x node type) in the n16 form against the oracle on
+    random rows; row counts 1..40 cover every remainder of the 16-row item."""
+    cfg = O.DynamicsConfig() if arch == "dev" else O.DynamicsConfig(n_convs=3, n_message_gvps=2, n_update_gvps=3, n_noise_gvps=2)
+    sd = O.make_state_dict(cfg, 7)
+    eng = engine_for(cfg, sd)
+    gen = torch.Generator().manual_seed(3)
+    counts = iter([1, 2, 3, 5, 7, 8, 9, 13, 15, 16, 17, 21, 27, 31, 32, 33, 40, 4, 6, 10, 11, 12, 14, 18] * 2)
+    for layer in range(cfg.n_convs):
+        p = f"dynamics.noise_predictor.conv_layers.{layer}."
+        for et in range(4):
+            n = next(counts)
+            s, v = torch.randn(n, 144, generator=gen), torch.randn(n, 17, 3, generator=gen)
+            s[:, 128:] = s[:, 128:].abs().clamp(max=1.0)
+            so, vo = eng.debug_chain(16, layer, et, s, v)
+            ro, rv = O.gvp_chain(sd, p + f"edge_message_fns.{ET_NAMES[et]}.", cfg.n_message_gvps, s, v)
+            close(so, ro, UNIT_TOL, UNIT_TOL); close(vo, rv, UNIT_TOL, UNIT_TOL)
+        for nt, name in enumerate(("prot", "pharm")):
+            n = next(counts)
+            s, v = torch.randn(n, 128, generator=gen), torch.randn(n, 16, 3, generator=gen)
+            so, vo = eng.debug_chain(17, layer, nt, s, v)
+            ro, rv = O.gvp_chain(sd, p + f"node_update_fns.{name}.", cfg.n_update_gvps, s, v)
+            close(so, ro, UNIT_TOL, UNIT_TOL); close(vo, rv, UNIT_TOL, UNIT_TOL)
+
+
+@pytest.mark.parametrize("variant", ["compact", "tile_lists", "dense"])
+@pytest.mark.parametrize("name", list(DYN_CASES))
+def test_n16_edge_kernels_on_goldens(name, variant, monkeypatch):
+    """The n16 edge kernel forced onto the conv layers >= 1 of every dynamics golden (PFDYN_N16 bit 0), on compact work
+    lists, on tile lists and on the dense (unpruned) lists; the node kernels read its 16-slot partial rows."""
+    monkeypatch.setenv("PFDYN_N16", "1")
+    if variant == "tile_lists":
+        monkeypatch.setenv("PFDYN_NO_COMPACT", "1")
+    if variant == "dense":
+        monkeypatch.setenv("PFDYN_NO_PRUNE", "1")
+    z, cfg = load(name), DYN_CASES[name]
+    batch = batch_from(z)
+    eng = engine_for(cfg, O.make_state_dict(cfg, int(z["wseed"])))
+    set_batch(eng, batch, z["prot_x"])
+    eps_h, eps_x = eng.dynamics(z["x_t"], z["h_t"], z["t"])
+    assert eng.kernel_family(cfg.n_convs - 1) == 16
+    close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
