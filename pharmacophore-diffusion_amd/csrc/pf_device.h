@@ -108,8 +108,10 @@ constexpr int rg_main_quad(const RgSched& s, const int nh, const int k) {
 //   M0H  [x1] [xh] [rbf x2] [sh x2] [vu] [gate x2]                                      = 9    ... and h_src is a row of a type table
 // Scalar k-step ks (0..31), lane group g <-> input feature 16 (ks >> 2) + 4 g + (ks & 3): the D fragment of tile T = 2 w + t
 // (lane 16 g + j, register r: feature 16 T + 4 g + r of row j) is the B operand of k-step 4 T + r without any data movement.
+#ifndef N16_D
 #define N16_D 12            // depth of the register prefetch ring in quads (GEN blocks are a multiple of it)
-#define N16_TAIL_PAD 16     // quads of read-ahead padding behind every wave's stream
+#endif
+#define N16_TAIL_PAD 24     // quads of read-ahead padding behind every wave's stream
 enum { N16_GEN = 0, N16_M0F = 1, N16_M0Z = 2, N16_M0H = 3 };
 struct N16Sched { int q_x1, q_vh, q_w16, q_main, q_rbf, q_sh, q_vu, q_b, q_gate, nq; };
 constexpr N16Sched n16_sched(const int kind) {
@@ -192,6 +194,7 @@ struct EdgeParams {
                            // groups are cut on absolute multiples of the group size (what the node kernel's e | (grp - 1) expects)
     // n16 kernels (pf_n16.hip): wave 0's quad stream of each etype's message chain; wave w's n16_stride[et] floats further
     pf_gcf n16[4]; int n16_stride[4];
+    int ptab16_off[4];     // conv layer 0: float offset of the etype's type table (bias folded in) inside ptab's slot, or -1
 };
 
 // static-hoist source block in the packed weights (pure copies of the first pp message GVP of conv layer 0 and of the
@@ -203,7 +206,12 @@ struct EdgeParams {
 #define L0H_WU 4384        // [17][16]          Wu
 #define L0H_BG 4672        // [16]              gate bias
 #define L0H_WHT 4736       // [128 k][128 f]    to_feats_out columns 0..127 (h_src), k-major
-#define L0H_SIZE (4736 + 16384)
+#define L0H_WHT_PF 21120   // [128 k][128 f]    the pf etype's first message GVP: to_feats_out columns 0..127, k-major
+#define L0H_B_PF 37504     // [128]             ... its bias
+#define L0H_SIZE (37504 + 128)
+// type tables of one timestep (k_l0_ptab): L0_NTAB tables of [rec_nf][128]: 0 pp without bias (row-group kernels: the bias
+// sits in zs), 1 pp with bias, 2 pf with bias (n16 kernels)
+#define L0_NTAB 3
 struct L0HoistParams {
     const float* src;      // the block above
     float* l0c;            // out: [16 weff][16 gate bias]

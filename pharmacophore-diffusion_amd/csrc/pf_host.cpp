@@ -33,7 +33,7 @@ void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int r
 void pfk_l0_hoist(const L0HoistParams* p, int what, hipStream_t s);
 void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s);
 void pfk_rg_unit(const UnitParams* p, hipStream_t s);
-void pfk_n16_edge(const EdgeParams* p, int layer0, hipStream_t s);
+void pfk_n16_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, hipStream_t s);
 void pfk_n16_unit(const UnitParams* p, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
@@ -201,7 +201,10 @@ struct pf_handle {
     // n16_msg: every message chain with a full first GVP (M0F: what conv layers >= 1 run, and what pf_debug_chain tests)
     std::vector<size_t> n16_msg, n16_upd;
     size_t n16_msg_stride = 0, n16_upd_stride = 0;
-    // which launches of the inference path take the n16 form (PFDYN_N16, bit mask): 1 edge launches of conv layers >= 1
+    // conv layer 0's message chains in their own forms: protein sources (pf, pp) start from a type-table row (M0H),
+    // centers (ff, fp) have zero node vectors (M0Z)
+    size_t n16_l0[4] = {0, 0, 0, 0}, n16_l0_stride[4] = {0, 0, 0, 0};
+    // which launches of the inference path take the n16 form (PFDYN_N16, bit mask): 1 edge launches of conv layers >= 1, 2 the edge launch of conv layer 0 (needs the static hoist's type tables)
     int n16_mask = 0;
     // launches with at most this many 4-row groups run each group on TWO waves (pf_rg.hip: SPLIT): pays off while the
     // groups are far fewer than the CUs (config 2: node + head launch 19.0 -> 15.8 us; neutral at ~500 groups)
@@ -237,7 +240,7 @@ struct pf_handle {
     bool coords_custom = false;             // protein coordinates came from the caller of this call (not the batch's own)
     bool zs_batch_coords = false;           // d_zs was computed from (a rigid translate of) the batch's coordinates
     float* d_l0c = nullptr;                 // [32]
-    float* d_ptab = nullptr;                // [L0_PTAB_SLOTS][rec_nf][128] tables of the timesteps seen (scalar-t calls)
+    float* d_ptab = nullptr;                // [L0_PTAB_SLOTS][L0_NTAB][rec_nf][128] tables of the timesteps seen (scalar-t calls)
     std::unordered_map<uint32_t, int> ptab_slot;
     int *d_eorig = nullptr, *d_ptype = nullptr, *d_l0flag = nullptr;
     float *d_zs = nullptr, *d_ptab_pg = nullptr;
@@ -801,7 +804,7 @@ static void l0_ensure_static(pf_handle* h, hipStream_t s) {
 // type tables of n timesteps (scalar-t calls): slots of the resident cache, computed on a miss
 static void l0_prepare_t(pf_handle* h, const float* tv, int n, hipStream_t s) {
     if (h->ptab_version != h->w_version) { h->ptab_slot.clear(); h->ptab_version = h->w_version; }
-    const size_t slot_floats = (size_t)h->cfg.rec_nf * PF_S;
+    const size_t slot_floats = (size_t)L0_NTAB * h->cfg.rec_nf * PF_S;
     int i = 0;
     while (i < n) {
         L0HoistParams lp = l0_params(h);
@@ -868,17 +871,18 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     const bool hoist = !train && enc_fly && l0_hoist_ok(h);
     const float* l0_ptab = nullptr;
     int l0_gstride = 0;
+    const bool n16_l0 = hoist && (h->n16_mask & 2) && !h->n16_msg.empty();      // layer 0 on the n16 kernels: no zs
     if (hoist) {
-        l0_ensure_static(h, s);
+        if (!n16_l0) l0_ensure_static(h, s);
         if (t_scalar) {
             l0_prepare_t(h, t_scalar, 1, s);
             uint32_t bits; memcpy(&bits, t_scalar, 4);
-            l0_ptab = h->d_ptab + (size_t)h->ptab_slot[bits] * c.rec_nf * PF_S;
+            l0_ptab = h->d_ptab + (size_t)h->ptab_slot[bits] * L0_NTAB * c.rec_nf * PF_S;
         } else {
             L0HoistParams lp = l0_params(h);
             lp.nt = h->B; lp.t_dev = h->d_t; lp.ptab = h->d_ptab_pg;
             pfk_l0_hoist(&lp, 1, s);
-            l0_ptab = h->d_ptab_pg; l0_gstride = c.rec_nf * PF_S;
+            l0_ptab = h->d_ptab_pg; l0_gstride = L0_NTAB * c.rec_nf * PF_S;
         }
     }
     h->last_hoist = 0;
@@ -942,10 +946,16 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             }
             h->last_hoist = 4 * rgp;
         }
-        // n16 form (pf_n16.hip): 16-row items on four waves; conv layers >= 1 (their first message GVP reads h / v from memory)
-        const bool n16e = !train && rg && l > 0 && (h->n16_mask & 1) && !h->n16_msg.empty();
+        // n16 form (pf_n16.hip): 16-row items on four waves.  Conv layers >= 1 read h / v of the sources from memory; conv
+        // layer 0 needs the static hoist's type tables (protein sources) and encodes the centers on the fly
+        const bool n16e = !train && rg && !h->n16_msg.empty() && (l > 0 ? (h->n16_mask & 1) != 0 : ((h->n16_mask & 2) != 0 && hoist));
         if (n16e) {
-            for (int et = 0; et < 4; ++et) { e.n16[et] = h->d_w + h->n16_msg[(size_t)l * 4 + et]; e.n16_stride[et] = (int)h->n16_msg_stride; }
+            for (int et = 0; et < 4; ++et) {
+                e.n16[et] = h->d_w + (l > 0 ? h->n16_msg[(size_t)l * 4 + et] : h->n16_l0[et]);
+                e.n16_stride[et] = (int)(l > 0 ? h->n16_msg_stride : h->n16_l0_stride[et]);
+                e.ptab16_off[et] = et == ET_PP ? c.rec_nf * PF_S : (et == ET_PF ? 2 * c.rec_nf * PF_S : -1);
+            }
+            if (l == 0) { e.zs = nullptr; rgp = 4; h->last_hoist = 16; }      // (ptab / ptype / l0_gid were set above)
             e.ngroups_sel = 0;
             for (int r = 0; r < e.nreg; ++r) e.ngroups_sel += region_groups(r, 16);
             rg = 4;                                  // 16 slots per partial-row group
@@ -955,7 +965,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         for (int et = 0; et < 4; ++et) e.rgs[et] = h->d_w + h->rgs_msg[(size_t)l * 4 + et];
         e.rgs_stride = (int)h->rgs_msg_stride;
         const int esplit = (rg == 1 && e.ntiles * 8 <= h->rg_split_max && !e.zs) ? 1 : 0;    // fewer groups than SIMDs: latency-bound
-        if (n16e) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_n16_edge(&e, 0, s); }
+        if (n16e) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_n16_edge(&e, &ep, l == 0, s); }
         else if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, esplit, rgp, s); }
         else if (e.ntiles <= h->coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
         else if (e.ntiles <= ((last || pruned) ? h->coop2_edge_max : h->coop2_dense_max) && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop2(&e, l == 0, s); }
@@ -1240,6 +1250,12 @@ int pf_commit_weights(pf_handle* h) {
                 for (int k = 0; k < 17; ++k) blk[L0H_WH0 + k] = wh[(size_t)0 * 17 + k];
                 for (int k = 0; k < 17 * 16; ++k) blk[L0H_WU + k] = wu[k];
                 for (int k = 0; k < 16; ++k) blk[L0H_BG + k] = h->raw[g.prefix + "scalar_to_vector_gates.bias"].data[k];
+                const GvpSpec gp = msg_spec(c, 0, ET_PF, 0);                  // the pf etype's type table (n16 kernels)
+                const std::vector<float>& Wp = h->raw[gp.prefix + "to_feats_out.0.weight"].data;
+                for (int f = 0; f < PF_S; ++f) {
+                    for (int k = 0; k < PF_S; ++k) blk[L0H_WHT_PF + (size_t)k * PF_S + f] = Wp[(size_t)f * Kin + k];
+                    blk[L0H_B_PF + f] = h->raw[gp.prefix + "to_feats_out.0.bias"].data[f];
+                }
             }
             h->l0h_off = push(h->h_w, blk);
         }
@@ -1321,6 +1337,9 @@ int pf_commit_weights(pf_handle* h) {
             for (int l = 0; l < c.n_convs; ++l)
                 for (int et = 0; et < 4; ++et)
                     h->n16_msg[(size_t)l * 4 + et] = chain16([&](int j) { return msg_spec(c, l, et, j); }, c.n_message_gvps, N16_M0F, h->n16_msg_stride);
+            for (int et = 0; et < 4; ++et)
+                h->n16_l0[et] = chain16([&](int j) { return msg_spec(c, 0, et, j); }, c.n_message_gvps,
+                                        (et == ET_PP || et == ET_PF) ? N16_M0H : N16_M0Z, h->n16_l0_stride[et]);
             for (int l = 0; l < c.n_convs; ++l)
                 for (int nt = 0; nt < 2; ++nt)
                     h->n16_upd[(size_t)l * 2 + nt] = chain16([&](int j) { return upd_spec(c, l, nt, j); }, c.n_update_gvps, N16_GEN, h->n16_upd_stride);
@@ -1446,7 +1465,7 @@ int pf_commit_weights(pf_handle* h) {
     ++h->w_version;
     if (!h->d_l0c) PF_HIP(h, hipMalloc((void**)&h->d_l0c, 32 * sizeof(float)));
     if (h->d_ptab) { (void)hipFree(h->d_ptab); h->d_ptab = nullptr; }
-    PF_HIP(h, hipMalloc((void**)&h->d_ptab, (size_t)L0_PTAB_SLOTS * c.rec_nf * PF_S * sizeof(float)));
+    PF_HIP(h, hipMalloc((void**)&h->d_ptab, (size_t)L0_PTAB_SLOTS * L0_NTAB * c.rec_nf * PF_S * sizeof(float)));
     return PF_OK;
 }
 
@@ -1690,7 +1709,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
                  o_ms = place((size_t)(Ecap + 1) * PF_S * 4), o_mv = place((size_t)(Ecap + 1) * 48 * 4),
                  o_eh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_ex = place((size_t)Nf * 3 * 4 + 16), o_c0 = place((size_t)B * 3 * 4), o_c1 = place((size_t)B * 3 * 4),
                  o_pre = place((size_t)std::max(Np, 1) * PF_S * 4), o_eorig = place(Ecap * 4), o_ptype = place((size_t)std::max(Np, 1) * 4),
-                 o_zs = place((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4), o_ptpg = place((size_t)B * c.rec_nf * PF_S * 4);
+                 o_zs = place((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4), o_ptpg = place((size_t)B * L0_NTAB * c.rec_nf * PF_S * 4);
     const size_t bytes = off;
     bool fresh = false;
     if (h->ws_capacity < bytes + 4096) {

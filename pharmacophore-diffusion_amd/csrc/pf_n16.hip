@@ -98,6 +98,20 @@ __device__ __forceinline__ void ring_start(N16Ring& r, pf_gcf stream, const int 
     static_for<0, N16_D>([&](auto I) { r.q[decltype(I)::value] = r.load(decltype(I)::value); });
 }
 
+// In-kernel cycle stamps (diagnostic builds only, -DN16_STAMPS: tools/probes/n16_chain_bench.hip): lane 0 of every wave of
+// the first 64 workgroups writes s_memtime at the phase boundaries of n16_block
+#ifdef N16_STAMPS
+__device__ unsigned long long* g_n16_stamps = nullptr;
+#define N16_STAMP(sk, lane, wq)                                                                                        \
+    do {                                                                                                               \
+        if ((lane) == 0 && g_n16_stamps && blockIdx.x < 64 && (sk) < 64)                                               \
+            g_n16_stamps[((size_t)blockIdx.x * 4 + (wq)) * 64 + (sk)] = __builtin_amdgcn_s_memtime();                  \
+        ++(sk);                                                                                                        \
+    } while (0)
+#else
+#define N16_STAMP(sk, lane, wq) do { } while (0)
+#endif
+
 // LDS of one item (one workgroup): every buffer has a barrier between a read and the next write (see n16_block)
 struct __attribute__((aligned(16))) N16Lds {
     float s[8 * 64 * 4];                      // SiLU outputs: [tile T = 2 w + t][lane][r] = feature 16 T + 4 g + r of row j
@@ -127,8 +141,9 @@ struct N16In {
 // ---------------------------------------------------------------------------------------------
 template <int KIND, int OFF, bool LAST>
 __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float (&VB)[4], const N16In& in, f32x4 (&S)[2],
-                                          N16Lds* lds, const int lane, const int wq) {
+                                          N16Lds* lds, const int lane, const int wq, int& sk) {
     constexpr N16Sched Q = n16_sched(KIND);
+    N16_STAMP(sk, lane, wq);                                          // block start
     constexpr bool M0 = KIND != N16_GEN;                              // 17 hidden vector channels, rbf inputs
     constexpr bool VZ = KIND == N16_M0Z || KIND == N16_M0H;           // the node vectors are zero: Vh = Wh[0] (x) xhat
     constexpr bool HOIST = KIND == N16_M0H;
@@ -190,7 +205,9 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
         } else if constexpr (qi >= Q.q_sh && qi < Q.q_sh + 2) {
             constexpr int r0 = 2 * (qi - Q.q_sh);
             if constexpr (r0 == 0 && !VZ) {           // barrier A: the three coordinates of Vh are in LDS
+                N16_STAMP(sk, lane, wq);              // main k-steps issued
                 lds_barrier();
+                N16_STAMP(sk, lane, wq);              // barrier A passed
                 const f32x4 a = *reinterpret_cast<const f32x4*>(&lds->v[(0 * 64 + lane) * 4]);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(&lds->v[(1 * 64 + lane) * 4]);
                 const f32x4 c = *reinterpret_cast<const f32x4*>(&lds->v[(2 * 64 + lane) * 4]);
@@ -236,7 +253,9 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
                     *reinterpret_cast<f32x4*>(&lds->s[((2 * wq) * 64 + lane) * 4]) = S[0];
                     *reinterpret_cast<f32x4*>(&lds->s[((2 * wq + 1) * 64 + lane) * 4]) = S[1];
                 }
+                N16_STAMP(sk, lane, wq);              // sh / Vu / SiLU / gate k-steps issued
                 lds_barrier();
+                N16_STAMP(sk, lane, wq);              // barrier B passed
                 if constexpr (!LAST) {
 #pragma unroll
                     for (int T = 0; T < 8; ++T) {
@@ -288,10 +307,58 @@ __device__ __forceinline__ float seg_scan16(float v, const SegMask16& m) {
 // (item, destination) run's sum in its last lane, and only those lanes store a partial row (at their own slot) -- what
 // the node kernels read with NodeParams::grp = 16.
 // ---------------------------------------------------------------------------------------------
+// Scalar encoder of the pharmacophore centers on the fly (dynamics_gvp.py:107-117, 143-151: h = LayerNorm(SiLU(W [h_t, t] + b)))
+// for the 16 source rows of a conv-layer-0 item: wave w encodes features [32 w, 32 w + 32) (SiLU is the expensive part),
+// the slices meet in LDS, and every wave normalises the features it holds as B operands (two-pass statistics over the
+// row: its 32 registers and the four lane groups).  node: global id of the row's source (a center).
+__device__ __forceinline__ void n16_encode_pharm(const EncodeParams& ep, const int node, float (&XS)[32], N16Lds* lds,
+                                                 const int lane, const int wq) {
+    const int g = lane >> 4;
+    const int nf = ep.pharm_nf;
+    pf_gcf in = (pf_gcf)ep.pharm_h + (size_t)(node - ep.Np) * nf;
+    const float tt = ep.t ? ((pf_gcf)ep.t)[((const int PF_AS1*)ep.gid)[node]] : ep.t_scalar;
+    pf_gcf Wt = (pf_gcf)ep.w[1] + 32 * wq + 4 * g;                    // [nf + 1][128], input-major
+    f32x4 z0 = *reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.b[1] + 32 * wq + 4 * g);
+    f32x4 z1 = *reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.b[1] + 32 * wq + 16 + 4 * g);
+    for (int k = 0; k <= nf; ++k) {
+        const float x = k < nf ? in[k] : tt;
+        const f32x4 w0 = *reinterpret_cast<const f32x4 PF_AS1*>(Wt + k * PF_S), w1 = *reinterpret_cast<const f32x4 PF_AS1*>(Wt + k * PF_S + 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z0[r] = fmaf(w0[r], x, z0[r]); z1[r] = fmaf(w1[r], x, z1[r]); }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { z0[r] = siluf_(z0[r]); z1[r] = siluf_(z1[r]); }
+    *reinterpret_cast<f32x4*>(&lds->s[((2 * wq) * 64 + lane) * 4]) = z0;
+    *reinterpret_cast<f32x4*>(&lds->s[((2 * wq + 1) * 64 + lane) * 4]) = z1;
+    lds_barrier();
+    float sum = 0.f;
+#pragma unroll
+    for (int T = 0; T < 8; ++T) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(&lds->s[(T * 64 + lane) * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { XS[4 * T + r] = x[r]; sum += x[r]; }
+    }
+    const float mean = gsum(sum) * (1.0f / 128.0f);
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { const float c = XS[k] - mean; var = fmaf(c, c, var); }
+    const float rstd = rsqf_(gsum(var) * (1.0f / 128.0f) + 1e-5f);
+#pragma unroll
+    for (int T = 0; T < 8; ++T) {
+        const f32x4 lw = *reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.ln_w[1] + 16 * T + 4 * g);
+        const f32x4 lb = *reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.ln_b[1] + 16 * T + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) XS[4 * T + r] = (XS[4 * T + r] - mean) * rstd * lw[r] + lb[r];
+    }
+    lds_barrier();                                       // the slices are read: the chain's first block may write lds->s
+}
+
 template <int KIND0>
-__device__ __forceinline__ void n16_edge_item(const EdgeParams& p, N16Lds* lds, const int e0, const int nv, const int et,
-                                              const int lane, const int wq) {
+__device__ __forceinline__ void n16_edge_item(const EdgeParams& p, const EncodeParams& ep, N16Lds* lds, const int e0, const int nv,
+                                              const int et, const int lane, const int wq) {
     constexpr int OFF1 = n16_sched(KIND0).nq % N16_D;
+    int sk = 0;
+    N16_STAMP(sk, lane, wq);                              // item start
     N16Ring ring;
     ring_start(ring, p.n16[et] + (size_t)wq * p.n16_stride[et], lane);      // in flight under the gathers
     const int g = lane >> 4, j = lane & 15;
@@ -300,7 +367,17 @@ __device__ __forceinline__ void n16_edge_item(const EdgeParams& p, N16Lds* lds, 
     const float4 xs = p.xn[src], xd = p.xn[dst];
     float XS[32], VB[4];
     f32x4 S[2];
-    if constexpr (KIND0 == N16_M0F || KIND0 == N16_M0Z) {
+    S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
+    if constexpr (KIND0 == N16_M0H) {
+        // the h_src block of the first message Linear (+ its bias) is a row of the etype's type table
+        int ty = p.ptype[src] * PF_S + p.ptab16_off[et];
+        if (p.ptab_gstride) ty += p.l0_gid[src] * p.ptab_gstride;
+        pf_gcf tp = (pf_gcf)p.ptab + ty + 32 * wq + 4 * g;
+        S[0] = *reinterpret_cast<const f32x4 PF_AS1*>(tp);
+        S[1] = *reinterpret_cast<const f32x4 PF_AS1*>(tp + 16);
+    }
+    if constexpr (KIND0 == N16_M0Z) n16_encode_pharm(ep, src, XS, lds, lane, wq);
+    if constexpr (KIND0 == N16_M0F) {
         const f32x4 PF_AS1* hp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.h + (size_t)src * PF_S) + g;
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
@@ -330,10 +407,10 @@ __device__ __forceinline__ void n16_edge_item(const EdgeParams& p, N16Lds* lds, 
             in.rb[r] = __expf(-(ze * ze));
         }
     }
-    S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
-    n16_block<KIND0, 0, false>(ring, XS, VB, in, S, lds, lane, wq);
-    for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false>(ring, XS, VB, in, S, lds, lane, wq);
-    n16_block<N16_GEN, OFF1, true>(ring, XS, VB, in, S, lds, lane, wq);
+    n16_block<KIND0, 0, false>(ring, XS, VB, in, S, lds, lane, wq, sk);
+    for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false>(ring, XS, VB, in, S, lds, lane, wq, sk);
+    n16_block<N16_GEN, OFF1, true>(ring, XS, VB, in, S, lds, lane, wq, sk);
+    N16_STAMP(sk, lane, wq);                              // chain done
     // per-destination sums in slot order, one partial row per (item, destination) run
     const SegMask16 sm = seg_masks16(dst, j);
     const int dnext = dpp_i<0x101>(dst);                 // row_shl 1: the next row's destination
@@ -358,7 +435,7 @@ __device__ __forceinline__ void n16_edge_item(const EdgeParams& p, N16Lds* lds, 
 
 // grid: one workgroup per 16-slot group (compact work list: the w-th non-empty group; tile lists: two groups per tile)
 template <bool L0>
-__global__ __launch_bounds__(256) void k_n16_edge(const EdgeParams p) {
+__global__ __launch_bounds__(256) void k_n16_edge(const EdgeParams p, const EncodeParams ep) {
     __shared__ N16Lds lds;
     const int lane = threadIdx.x & 63;
     const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -425,8 +502,18 @@ __global__ __launch_bounds__(256) void k_n16_edge(const EdgeParams p) {
         et = __builtin_amdgcn_readfirstlane(t.et);
         e0 = t.e0 + base;
     }
-    static_assert(!L0, "conv layer 0 in the n16 form: not built yet");
-    n16_edge_item<N16_M0F>(p, &lds, e0, nv, et, lane, wq);
+    if constexpr (L0) {
+        // conv layer 0: every node vector is zero; protein sources (pf, pp) read the type tables of the static hoist
+        // (h_src is one of rec_nf encoder outputs per t), centers (ff, fp) are encoded on the fly
+        if (et == ET_PP && p.need) {
+            // pocket sharing: this group of a representative's static pp edges runs only if some copy of the pocket reads
+            // one of its destinations in this step
+            const int e = e0 + min(lane & 15, nv - 1);
+            if (!__any(p.need[p.edst[e]] == p.need_stamp)) return;      // workgroup-uniform (every wave tests the same rows)
+        }
+        if (et == ET_PP || et == ET_PF) n16_edge_item<N16_M0H>(p, ep, &lds, e0, nv, et, lane, wq);
+        else n16_edge_item<N16_M0Z>(p, ep, &lds, e0, nv, et, lane, wq);
+    } else n16_edge_item<N16_M0F>(p, ep, &lds, e0, nv, et, lane, wq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -442,6 +529,8 @@ __global__ __launch_bounds__(256) void k_n16_unit(const UnitParams p) {
     const int g = lane >> 4, j = lane & 15;
     const int row = e0 + min(j, nv - 1);
     const bool msg = p.kind == 16;
+    int sk = 0;
+    N16_STAMP(sk, lane, wq);                              // item start
     const int sw = msg ? 144 : 128, vw = msg ? 51 : 48, v0 = msg ? 3 : 0;
     N16Ring ring;
     ring_start(ring, (pf_gcf)p.stream + (size_t)wq * p.n16_stride, lane);
@@ -461,13 +550,14 @@ __global__ __launch_bounds__(256) void k_n16_unit(const UnitParams p) {
     for (int c = 0; c < 3; ++c) in.xh[c] = msg ? p.v_in[(size_t)row * vw + c] : 0.f;
     if (msg) {
         constexpr int OFF1 = n16_sched(N16_M0F).nq % N16_D;
-        n16_block<N16_M0F, 0, false>(ring, XS, VB, in, S, &lds, lane, wq);
-        for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false>(ring, XS, VB, in, S, &lds, lane, wq);
-        n16_block<N16_GEN, OFF1, true>(ring, XS, VB, in, S, &lds, lane, wq);
+        n16_block<N16_M0F, 0, false>(ring, XS, VB, in, S, &lds, lane, wq, sk);
+        for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false>(ring, XS, VB, in, S, &lds, lane, wq, sk);
+        n16_block<N16_GEN, OFF1, true>(ring, XS, VB, in, S, &lds, lane, wq, sk);
     } else {
-        for (int gi = 0; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, 0, false>(ring, XS, VB, in, S, &lds, lane, wq);
-        n16_block<N16_GEN, 0, true>(ring, XS, VB, in, S, &lds, lane, wq);
+        for (int gi = 0; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, 0, false>(ring, XS, VB, in, S, &lds, lane, wq, sk);
+        n16_block<N16_GEN, 0, true>(ring, XS, VB, in, S, &lds, lane, wq, sk);
     }
+    N16_STAMP(sk, lane, wq);                              // chain done
     if (j < nv) {
         float* so = p.s_out + (size_t)row * 128 + 32 * wq + 4 * g;
         *reinterpret_cast<f32x4*>(so) = S[0];
@@ -482,12 +572,15 @@ __global__ __launch_bounds__(256) void k_n16_unit(const UnitParams p) {
 }  // namespace
 
 extern "C" {
-// layer0 = 0 only (so far); the grid is the launch's capacity in 16-slot groups (p->ngroups_sel) or two per tile
-void pfk_n16_edge(const EdgeParams* p, int layer0, hipStream_t s) {
-    if (p->ntiles == 0 || layer0) return;
+// the grid is the launch's capacity in 16-slot groups (p->ngroups_sel) or two per tile; layer0: the type tables of the static
+// hoist (p->ptab, p->ptab16_off) and the encoder of the centers (enc) are required
+void pfk_n16_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, hipStream_t s) {
+    if (p->ntiles == 0) return;
     const int grid = p->nreg > 0 ? p->ngroups_sel : p->ntiles * 2;
     if (grid <= 0) return;
-    hipLaunchKernelGGL((k_n16_edge<false>), dim3(grid), dim3(256), 0, s, *p);
+    const EncodeParams noenc{};
+    if (layer0) hipLaunchKernelGGL((k_n16_edge<true>), dim3(grid), dim3(256), 0, s, *p, *enc);
+    else hipLaunchKernelGGL((k_n16_edge<false>), dim3(grid), dim3(256), 0, s, *p, noenc);
 }
 void pfk_n16_unit(const UnitParams* p, hipStream_t s) {
     if (p->n <= 0) return;

@@ -54,12 +54,15 @@ def test_n16_every_chain_vs_oracle(arch):
             close(so, ro, UNIT_TOL, UNIT_TOL); close(vo, rv, UNIT_TOL, UNIT_TOL)
 
 
+@pytest.mark.parametrize("mask", [1, 2, 3])
 @pytest.mark.parametrize("variant", ["compact", "tile_lists", "dense"])
 @pytest.mark.parametrize("name", list(DYN_CASES))
-def test_n16_edge_kernels_on_goldens(name, variant, monkeypatch):
-    """The n16 edge kernel forced onto the conv layers >= 1 of every dynamics golden (PFDYN_N16 bit 0), on compact work
-    lists, on tile lists and on the dense (unpruned) lists; the node kernels read its 16-slot partial rows."""
-    monkeypatch.setenv("PFDYN_N16", "1")
+def test_n16_edge_kernels_on_goldens(name, variant, mask, monkeypatch):
+    """The n16 edge kernel forced onto every dynamics golden (PFDYN_N16 bit 0: conv layers >= 1, first message GVP reads
+    h / v from memory; bit 1: conv layer 0, protein sources from the static hoist's type tables, centers encoded on the
+    fly), on compact work lists, on tile lists and on the dense (unpruned) lists; the node kernels read its 16-slot
+    partial rows."""
+    monkeypatch.setenv("PFDYN_N16", str(mask))
     if variant == "tile_lists":
         monkeypatch.setenv("PFDYN_NO_COMPACT", "1")
     if variant == "dense":
@@ -69,5 +72,8 @@ def test_n16_edge_kernels_on_goldens(name, variant, monkeypatch):
     eng = engine_for(cfg, O.make_state_dict(cfg, int(z["wseed"])))
     set_batch(eng, batch, z["prot_x"])
     eps_h, eps_x = eng.dynamics(z["x_t"], z["h_t"], z["t"])
-    assert eng.kernel_family(cfg.n_convs - 1) == 16
+    if mask & 1:
+        assert eng.kernel_family(cfg.n_convs - 1) == 16
+    if mask & 2:
+        assert eng.kernel_family(0) == 16 and eng.l0_hoist() == 16
     close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
