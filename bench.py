@@ -229,7 +229,8 @@ def main():
     # FLOP = 136,742 per edge it actually processes
     dom = "edge_msg" if prof["edge_msg"][1] > 0 else "edge_msg_coop"
     fam = eng.kernel_family(0)
-    dom_name = {4: "k_rg_edge<rows_per_wave=4>", 8: "k_rg_edge<rows_per_wave=8>", 32: "k_edge_msg", 128: "k_edge_msg_coop"}[fam]
+    dom_name = {4: "k_rg_edge<rows_per_wave=4>", 8: "k_rg_edge<rows_per_wave=8>", 16: "k_n16_edge<layer0>: 16-row items on four waves",
+                32: "k_edge_msg", 128: "k_edge_msg_coop"}[fam]
     edge_ms, edge_n = prof[dom]
     l0_edges = wk["executed_edges_per_layer"][0]
     edge_avg_s = edge_ms / max(edge_n, 1) * 1e-3
@@ -241,6 +242,9 @@ def main():
     n_dyn = ne[0] + ne[1] + ne[2]
     hoisted_edges = (l0_edges - n_dyn if l0_edges < sum(ne) else ne[3]) if hoist_rows else 0
     edge_flops_exec = edge_flops - (48678.0 - 4096.0) * max(hoisted_edges, 0)
+    if hoist_rows == 16:                        # n16 form: pp and pf edges start from a type-table row: the h_src block of the first
+        hoisted_edges += ne[1]                  # scalar Linear (2 x 128 x 128) and the Vh matrix product (2 x 16 x 17 x 3) are not executed
+        edge_flops_exec = edge_flops - (32768.0 + 1632.0) * max(hoisted_edges, 0)
 
     out = {
         "metric": "denoising steps/sec (batch x T) at 256-atom pocket, 6 centers",

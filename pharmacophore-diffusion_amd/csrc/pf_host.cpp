@@ -2628,7 +2628,10 @@ int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges, 
         else { el = E; nl = (double)h->N; }
         ex += el * per_edge + nl * per_node;
         // static hoist (last call): the pp edges of layer 0 skip their first message GVP but for its gates
-        if (l == 0 && h->last_hoist) ex -= (double)(l == prune_layer ? n_pa : (l == c.n_convs - 1 ? 0 : ne[3])) * (g0 - 2.0 * 128 * 16);
+        // (n16 form, last_hoist == 16: the pp AND pf edges skip the h_src block of the first scalar Linear and the Vh matrix product
+        // -- a type-table row and 17 x 3 multiplications instead)
+        if (l == 0 && h->last_hoist == 16) ex -= (double)((l == prune_layer ? n_pa : (l == c.n_convs - 1 ? 0 : ne[3])) + ne[1]) * (2.0 * 128 * 128 + 2.0 * 16 * 17 * 3);
+        else if (l == 0 && h->last_hoist) ex -= (double)(l == prune_layer ? n_pa : (l == c.n_convs - 1 ? 0 : ne[3])) * (g0 - 2.0 * 128 * 16);
         if (executed_edges) executed_edges[l] = (int64_t)el;
     }
     if (executed_flops) *executed_flops = ex;

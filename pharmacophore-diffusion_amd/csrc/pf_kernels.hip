@@ -1782,7 +1782,11 @@ __global__ __launch_bounds__(256) void k_step_update(const StepParams p) { step_
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for every global store
 // issued so far to be acknowledged (~2,000 cycles here), and nothing in this kernel reads its global stores back
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, const BuildParams p) {
+// (the leading scalar arguments repeat the fields round trip (A) needs: preloaded into scalar registers with the wave,
+// -mllvm -amdgpu-kernarg-preload-count in the Makefile, so (A) does not wait for the kernel-argument segment)
+__global__ __launch_bounds__(512) void k_step_build_fast(const int* __restrict__ a_prot_ptr, const int* __restrict__ a_pharm_ptr,
+                                                         const int* __restrict__ a_reg, const int a_B, const int a_Np_tot,
+                                                         const StepParams sp, const BuildParams p) {
     constexpr int NT = 512, NW = NT / 64;
     __shared__ float4 fx[PF_MAXF];                  // updated pharm coordinates (COM removed)
     __shared__ float4 px[NT];                       // updated protein coordinates
@@ -1797,11 +1801,11 @@ __global__ __launch_bounds__(512) void k_step_build_fast(const StepParams sp, co
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     BSTAMP(0);
     // ---- (A) pointers and regions
-    const int p0 = p.prot_ptr[g], p1 = p.prot_ptr[g + 1];
-    const int f0 = p.pharm_ptr[g], f1 = p.pharm_ptr[g + 1];
+    const int p0 = a_prot_ptr[g], p1 = a_prot_ptr[g + 1];
+    const int f0 = a_pharm_ptr[g], f1 = a_pharm_ptr[g + 1];
     const int Np = p1 - p0, Nf = f1 - f0;
-    const int GF = p.Np_tot + f0;
-    const int reg_ff = p.reg[0 * p.B + g], reg_pf = p.reg[1 * p.B + g], reg_fp = p.reg[2 * p.B + g], reg_pa = p.reg[3 * p.B + g];
+    const int GF = a_Np_tot + f0;
+    const int reg_ff = a_reg[0 * a_B + g], reg_pf = a_reg[1 * a_B + g], reg_fp = a_reg[2 * a_B + g], reg_pa = a_reg[3 * a_B + g];
     const int reg_act = p.act_ids ? p.reg_act[g] : 0;
     int* in_start0 = p.in_start;          int* in_cnt0 = p.in_cnt;
     int* in_start1 = p.in_start + p.N;    int* in_cnt1 = p.in_cnt + p.N;
@@ -2160,7 +2164,7 @@ void pfk_segment_mean(const float4* xn, const int* ptr, int base, int B, float* 
 }
 void pfk_step_build(const StepParams* sp, const BuildParams* bp, int fast, hipStream_t s) {
     if (sp->B == 0) return;
-    if (fast) hipLaunchKernelGGL(k_step_build_fast, dim3(sp->B), dim3(512), 0, s, *sp, *bp);
+    if (fast) hipLaunchKernelGGL(k_step_build_fast, dim3(sp->B), dim3(512), 0, s, bp->prot_ptr, bp->pharm_ptr, bp->reg, bp->B, bp->Np_tot, *sp, *bp);
     else hipLaunchKernelGGL(k_step_build, dim3(sp->B), dim3(256), 0, s, *sp, *bp);
 }
 void pfk_step_update(const StepParams* p, hipStream_t s) {

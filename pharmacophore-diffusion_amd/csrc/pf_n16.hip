@@ -102,14 +102,21 @@ __device__ __forceinline__ void ring_start(N16Ring& r, pf_gcf stream, const int 
 // the first 64 workgroups writes s_memtime at the phase boundaries of n16_block
 #ifdef N16_STAMPS
 __device__ unsigned long long* g_n16_stamps = nullptr;
+__device__ int g_n16_stamp_off = 0;                   // first recorded workgroup
 #define N16_STAMP(sk, lane, wq)                                                                                        \
     do {                                                                                                               \
-        if ((lane) == 0 && g_n16_stamps && blockIdx.x < 64 && (sk) < 64)                                               \
-            g_n16_stamps[((size_t)blockIdx.x * 4 + (wq)) * 64 + (sk)] = __builtin_amdgcn_s_memtime();                  \
+        const int rb_ = (int)blockIdx.x - g_n16_stamp_off;                                                             \
+        if ((lane) == 0 && g_n16_stamps && rb_ >= 0 && rb_ < 64 && (sk) < 64)                                          \
+            g_n16_stamps[((size_t)rb_ * 4 + (wq)) * 64 + (sk)] = __builtin_amdgcn_s_memtime();                         \
         ++(sk);                                                                                                        \
     } while (0)
 #else
 #define N16_STAMP(sk, lane, wq) do { } while (0)
+#endif
+
+// -DN16_TRACE (diagnostic builds): wave 0 of every workgroup of k_n16_edge records [start, end, HW_ID, XCC_ID | item kind]
+#ifdef N16_TRACE
+__device__ unsigned long long* g_n16_trace = nullptr;
 #endif
 
 // LDS of one item (one workgroup): every buffer has a barrier between a read and the next write (see n16_block)
@@ -320,11 +327,25 @@ __device__ __forceinline__ void n16_encode_pharm(const EncodeParams& ep, const i
     pf_gcf Wt = (pf_gcf)ep.w[1] + 32 * wq + 4 * g;                    // [nf + 1][128], input-major
     f32x4 z0 = *reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.b[1] + 32 * wq + 4 * g);
     f32x4 z1 = *reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.b[1] + 32 * wq + 16 + 4 * g);
-    for (int k = 0; k <= nf; ++k) {
-        const float x = k < nf ? in[k] : tt;
-        const f32x4 w0 = *reinterpret_cast<const f32x4 PF_AS1*>(Wt + k * PF_S), w1 = *reinterpret_cast<const f32x4 PF_AS1*>(Wt + k * PF_S + 16);
+    // the encoder's inputs and weight rows are requested eight at a time with clamped indices (one round trip per batch: a
+    // loop over the run-time input count would wait for every row in turn)
+    for (int k0 = 0; k0 <= nf; k0 += 8) {
+        float x[8];
+        f32x4 w0[8], w1[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { z0[r] = fmaf(w0[r], x, z0[r]); z1[r] = fmaf(w1[r], x, z1[r]); }
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = min(k0 + kk, nf);
+            x[kk] = in[min(k, nf - 1)];
+            w0[kk] = *reinterpret_cast<const f32x4 PF_AS1*>(Wt + k * PF_S);
+            w1[kk] = *reinterpret_cast<const f32x4 PF_AS1*>(Wt + k * PF_S + 16);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = k0 + kk;
+            const float xv = k < nf ? x[kk] : (k == nf ? tt : 0.f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { z0[r] = fmaf(w0[kk][r], xv, z0[r]); z1[r] = fmaf(w1[kk][r], xv, z1[r]); }
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { z0[r] = siluf_(z0[r]); z1[r] = siluf_(z1[r]); }
@@ -355,10 +376,9 @@ __device__ __forceinline__ void n16_encode_pharm(const EncodeParams& ep, const i
 
 template <int KIND0>
 __device__ __forceinline__ void n16_edge_item(const EdgeParams& p, const EncodeParams& ep, N16Lds* lds, const int e0, const int nv,
-                                              const int et, const int lane, const int wq) {
+                                              const int et, const int lane, const int wq, int& sk) {
     constexpr int OFF1 = n16_sched(KIND0).nq % N16_D;
-    int sk = 0;
-    N16_STAMP(sk, lane, wq);                              // item start
+    N16_STAMP(sk, lane, wq);                              // item known (work list scanned)
     N16Ring ring;
     ring_start(ring, p.n16[et] + (size_t)wq * p.n16_stride[et], lane);      // in flight under the gathers
     const int g = lane >> 4, j = lane & 15;
@@ -407,6 +427,7 @@ __device__ __forceinline__ void n16_edge_item(const EdgeParams& p, const EncodeP
             in.rb[r] = __expf(-(ze * ze));
         }
     }
+    N16_STAMP(sk, lane, wq);                              // source rows gathered / encoded (as far as the compiler keeps the order)
     n16_block<KIND0, 0, false>(ring, XS, VB, in, S, lds, lane, wq, sk);
     for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false>(ring, XS, VB, in, S, lds, lane, wq, sk);
     n16_block<N16_GEN, OFF1, true>(ring, XS, VB, in, S, lds, lane, wq, sk);
@@ -434,14 +455,20 @@ __device__ __forceinline__ void n16_edge_item(const EdgeParams& p, const EncodeP
 }
 
 // grid: one workgroup per 16-slot group (compact work list: the w-th non-empty group; tile lists: two groups per tile)
+// The leading scalar arguments repeat the fields of p that the work-list scan needs: they are preloaded into scalar
+// registers with the wave (-mllvm -amdgpu-kernarg-preload-count, Makefile), so the scan's loads leave without waiting for
+// the kernel-argument segment (one dependent round trip of ~2,000 cycles less in front of every item).
 template <bool L0>
-__global__ __launch_bounds__(256) void k_n16_edge(const EdgeParams p, const EncodeParams ep) {
+__global__ __launch_bounds__(256) void k_n16_edge(const int* __restrict__ a_dyn_cnt, const int* __restrict__ a_reg, const int a_nreg,
+                                                  const int a_regB, const int a_pa_abs, const EdgeParams p, const EncodeParams ep) {
     __shared__ N16Lds lds;
     const int lane = threadIdx.x & 63;
     const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int item = (int)blockIdx.x;
+    int sk = 0;
+    N16_STAMP(sk, lane, wq);                              // kernel entry
     int e0, nv, et;
-    if (p.nreg > 0) {
+    if (a_nreg > 0) {
         // compact work list (see k_rg_edge): every wave of the workgroup finds the item's region by the same wave scan
         constexpr int NP = 16;                           // up to 64 * NP regions
         const int w = item;
@@ -452,17 +479,17 @@ __global__ __launch_bounds__(256) void k_n16_edge(const EdgeParams p, const Enco
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             cs[k] = 0; rs[k] = 0;
-            if (64 * k < p.nreg) {
-                const int r = min(64 * k + lane, p.nreg - 1);
-                const int c = p.dyn_cnt[r];
-                rs[k] = p.reg[r];
-                cs[k] = 64 * k + lane < p.nreg ? c : 0;
+            if (64 * k < a_nreg) {
+                const int r = min(64 * k + lane, a_nreg - 1);
+                const int c = a_dyn_cnt[r];
+                rs[k] = a_reg[r];
+                cs[k] = 64 * k + lane < a_nreg ? c : 0;
             }
         }
-        const int abs0 = p.pa_abs ? 3 * p.regB : 0x7fffffff;
+        const int abs0 = a_pa_abs ? 3 * a_regB : 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            if (64 * k < p.nreg && rsel < 0) {
+            if (64 * k < a_nreg && rsel < 0) {
                 const int c = cs[k];
                 const int ng = (64 * k + lane >= abs0) ? (c > 0 ? ((rs[k] + c - 1) >> 4) - (rs[k] >> 4) + 1 : 0) : (c + 15) >> 4;
                 int incl = ng;
@@ -480,8 +507,8 @@ __global__ __launch_bounds__(256) void k_n16_edge(const EdgeParams p, const Enco
             }
         }
         if (rsel < 0) return;                            // workgroup-uniform: beyond the last group
-        const int kind = rsel / p.regB;
-        if (p.pa_abs && kind == 3) {
+        const int kind = rsel / a_regB;
+        if (a_pa_abs && kind == 3) {
             const int lo = ((start >> 4) + (w - first)) << 4;
             e0 = max(start, lo);
             nv = __builtin_amdgcn_readfirstlane(min(start + cnt, lo + 16) - e0);
@@ -502,6 +529,13 @@ __global__ __launch_bounds__(256) void k_n16_edge(const EdgeParams p, const Enco
         et = __builtin_amdgcn_readfirstlane(t.et);
         e0 = t.e0 + base;
     }
+#ifdef N16_TRACE
+    if (g_n16_trace && threadIdx.x == 0) {
+        g_n16_trace[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+        g_n16_trace[(size_t)blockIdx.x * 4 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        g_n16_trace[(size_t)blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) | ((unsigned long long)et << 32) | ((unsigned long long)nv << 40);
+    }
+#endif
     if constexpr (L0) {
         // conv layer 0: every node vector is zero; protein sources (pf, pp) read the type tables of the static hoist
         // (h_src is one of rec_nf encoder outputs per t), centers (ff, fp) are encoded on the fly
@@ -511,9 +545,12 @@ __global__ __launch_bounds__(256) void k_n16_edge(const EdgeParams p, const Enco
             const int e = e0 + min(lane & 15, nv - 1);
             if (!__any(p.need[p.edst[e]] == p.need_stamp)) return;      // workgroup-uniform (every wave tests the same rows)
         }
-        if (et == ET_PP || et == ET_PF) n16_edge_item<N16_M0H>(p, ep, &lds, e0, nv, et, lane, wq);
-        else n16_edge_item<N16_M0Z>(p, ep, &lds, e0, nv, et, lane, wq);
-    } else n16_edge_item<N16_M0F>(p, ep, &lds, e0, nv, et, lane, wq);
+        if (et == ET_PP || et == ET_PF) n16_edge_item<N16_M0H>(p, ep, &lds, e0, nv, et, lane, wq, sk);
+        else n16_edge_item<N16_M0Z>(p, ep, &lds, e0, nv, et, lane, wq, sk);
+    } else n16_edge_item<N16_M0F>(p, ep, &lds, e0, nv, et, lane, wq, sk);
+#ifdef N16_TRACE
+    if (g_n16_trace && threadIdx.x == 0) g_n16_trace[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -579,9 +616,18 @@ void pfk_n16_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, hipS
     const int grid = p->nreg > 0 ? p->ngroups_sel : p->ntiles * 2;
     if (grid <= 0) return;
     const EncodeParams noenc{};
-    if (layer0) hipLaunchKernelGGL((k_n16_edge<true>), dim3(grid), dim3(256), 0, s, *p, *enc);
-    else hipLaunchKernelGGL((k_n16_edge<false>), dim3(grid), dim3(256), 0, s, *p, noenc);
+    if (layer0) hipLaunchKernelGGL((k_n16_edge<true>), dim3(grid), dim3(256), 0, s, p->dyn_cnt, p->reg, p->nreg, p->regB, p->pa_abs, *p, *enc);
+    else hipLaunchKernelGGL((k_n16_edge<false>), dim3(grid), dim3(256), 0, s, p->dyn_cnt, p->reg, p->nreg, p->regB, p->pa_abs, *p, noenc);
 }
+#ifdef N16_STAMPS
+int pfk_n16_set_stamp_buffer(unsigned long long* dev, int off) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_n16_stamp_off), &off, sizeof(off));
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_n16_stamps), &dev, sizeof(dev));
+}
+#endif
+#ifdef N16_TRACE
+int pfk_n16_set_trace_buffer(unsigned long long* dev) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_n16_trace), &dev, sizeof(dev)); }
+#endif
 void pfk_n16_unit(const UnitParams* p, hipStream_t s) {
     if (p->n <= 0) return;
     hipLaunchKernelGGL(k_n16_unit, dim3((p->n + 15) / 16), dim3(256), 0, s, *p);
