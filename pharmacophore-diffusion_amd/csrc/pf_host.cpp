@@ -205,7 +205,11 @@ struct pf_handle {
     // centers (ff, fp) have zero node vectors (M0Z)
     size_t n16_l0[4] = {0, 0, 0, 0}, n16_l0_stride[4] = {0, 0, 0, 0};
     // which launches of the inference path take the n16 form (PFDYN_N16, bit mask): 1 edge launches of conv layers >= 1, 2 the edge launch of conv layer 0 (needs the static hoist's type tables)
-    int n16_mask = 0;
+    int n16_mask = 3;
+    // ... up to this many edge slots in the batch's pruned conv-layer launch (PFDYN_N16_ROWS_MAX).  Measured at 256-atom
+    // pockets (575 slots per graph): +5 % at 16 graphs, +10 % at 32, -3..-5 % at 64 and -15 % at 256 against the row-group
+    // kernels: the n16 form wins while a launch has at most ~2 items per compute unit (its items are a CU wide)
+    long n16_rows_max = 24000;
     // launches with at most this many 4-row groups run each group on TWO waves (pf_rg.hip: SPLIT): pays off while the
     // groups are far fewer than the CUs (config 2: node + head launch 19.0 -> 15.8 us; neutral at ~500 groups)
     int rg_split_max = 128;
@@ -274,7 +278,12 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_TRAIN_NODE_RECOMPUTE")) train_node_save = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_L0_RGP")) l0_rgp = atoi(e);
         if (const char* e = getenv("PFDYN_L0_RGA")) l0_rga = atoi(e);
+        // forcing a row-group form (tests, sweeps) switches the n16 form off unless PFDYN_N16 says otherwise
+        for (const char* v : {"PFDYN_RG2_ROWS_MIN", "PFDYN_RG2P_ROWS_MIN", "PFDYN_RG2_ROWS_MIN_HOIST", "PFDYN_RG_SPLIT_MAX", "PFDYN_L0_RGA",
+                              "PFDYN_L0_RGP", "PFDYN_RG_ROWS_MAX"})
+            if (getenv(v)) n16_mask = 0;
         if (const char* e = getenv("PFDYN_N16")) n16_mask = atoi(e);
+        if (const char* e = getenv("PFDYN_N16_ROWS_MAX")) n16_rows_max = atol(e);
     }
 
     // ---- gradient path (pf_train_*): flat parameter vector in state-dict order, GvpT tables, per-layer activations
@@ -871,7 +880,9 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     const bool hoist = !train && enc_fly && l0_hoist_ok(h);
     const float* l0_ptab = nullptr;
     int l0_gstride = 0;
-    const bool n16_l0 = hoist && (h->n16_mask & 2) && !h->n16_msg.empty();      // layer 0 on the n16 kernels: no zs
+    // the n16 form serves the latency regime: batches whose pruned conv-layer launch has few items per compute unit
+    const bool n16_batch = (long)(prune_layer >= 0 ? h->n_edge_tiles_act : h->n_edge_tiles) * 32 <= h->n16_rows_max && !h->n16_msg.empty();
+    const bool n16_l0 = hoist && (h->n16_mask & 2) && n16_batch;      // layer 0 on the n16 kernels: no zs
     if (hoist) {
         if (!n16_l0) l0_ensure_static(h, s);
         if (t_scalar) {
@@ -948,7 +959,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         }
         // n16 form (pf_n16.hip): 16-row items on four waves.  Conv layers >= 1 read h / v of the sources from memory; conv
         // layer 0 needs the static hoist's type tables (protein sources) and encodes the centers on the fly
-        const bool n16e = !train && rg && !h->n16_msg.empty() && (l > 0 ? (h->n16_mask & 1) != 0 : ((h->n16_mask & 2) != 0 && hoist));
+        const bool n16e = !train && rg && n16_batch && (l > 0 ? (h->n16_mask & 1) != 0 : n16_l0);
         if (n16e) {
             for (int et = 0; et < 4; ++et) {
                 e.n16[et] = h->d_w + (l > 0 ? h->n16_msg[(size_t)l * 4 + et] : h->n16_l0[et]);

@@ -36,6 +36,49 @@ def _no_policy_overrides():
     assert not [k for k in os.environ if k.startswith("PFDYN_")], "these tests check the DEFAULT launch policy"
 
 
+def test_config2_batch32_steps_vs_oracle_under_the_default_policy():
+    """BASELINE config 2 at its own size (32 x (256 atoms + 6 centers), T = 500) under the DEFAULT launch policy -- the
+    configuration bench.py times: three steps at both ends of the schedule against the oracle with shared noise, and the
+    kernel forms the policy picked are the ones the bench line reports (conv layers on the n16 kernels, conv layer 0 from
+    the static hoist's type tables)."""
+    _no_policy_overrides()
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    B = 32
+    batch = O.synthetic_batch(range(1000, 1000 + B), 256, [6] * B, cfg)
+    T, n = 500, 3
+    Nf = int(batch.pharm_ptr[-1])
+    noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(42))
+    eng = _engine(cfg, sd)
+    eng.set_batch(batch.prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst)
+    coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+    x0, h0 = eng.sample(eng.coef_array(coef, reversed(range(n))), n, noise)          # s = 2, 1, 0
+    assert (eng.kernel_family(0), eng.kernel_family(1), eng.l0_hoist()) == (16, 16, 16)
+    ne = eng.work()[2]
+    assert ne[1] == 5 * Nf and ne[2] == ne[1] and ne[3] == batch.pp_src.numel()
+    bidx = batch.batch_idxs()
+    init_com = O.segment_mean(batch.prot_x, batch.prot_ptr)
+    px = batch.prot_x - init_com[bidx["prot"]]
+    x_t, h_t = noise[0][:, :3].clone(), noise[0][:, 3:].clone()
+    with torch.no_grad():
+        for i, s in enumerate(reversed(range(n))):
+            px, x_t, h_t = O.sample_step(sd, cfg, batch, coef, s, px, x_t, h_t, noise[1 + i][:, :3], noise[1 + i][:, 3:])
+    ox = x_t - O.segment_mean(px, batch.prot_ptr)[bidx["pharm"]] + init_com[bidx["pharm"]]
+    torch.testing.assert_close(x0.cpu(), ox, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(h0.cpu(), h_t, rtol=1e-3, atol=1e-3)
+    x1, h1 = eng.sample(eng.coef_array(coef, reversed(range(T))), n, noise)           # s = 499, 498, 497
+    ox1, oh1 = O.sample_given_receptor(sd, cfg, batch, T, 1e-5, noise, n_steps=n)
+    torch.testing.assert_close(x1.cpu(), ox1, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(h1.cpu(), oh1, rtol=1e-3, atol=1e-3)
+    # a single dynamics call of that batch at the tolerance of a call (2e-4), per-graph timesteps (the non-shared tables)
+    gen = torch.Generator().manual_seed(4)
+    xt, ht, t = 2.0 * torch.randn(Nf, 3, generator=gen), torch.randn(Nf, 6, generator=gen), torch.rand(B, generator=gen)
+    eh, ex = eng.dynamics(xt, ht, t, prot_x=batch.prot_x)
+    oh, oxx = O.dynamics_forward(sd, cfg, batch, batch.prot_x, xt, ht, t)
+    torch.testing.assert_close(eh.cpu(), oh, rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(ex.cpu(), oxx, rtol=2e-4, atol=2e-4)
+
+
 def test_config3_ragged_batch128_steps_vs_oracle():
     _no_policy_overrides()
     cfg = O.DynamicsConfig()

@@ -63,6 +63,7 @@ def test_n16_edge_kernels_on_goldens(name, variant, mask, monkeypatch):
     fly), on compact work lists, on tile lists and on the dense (unpruned) lists; the node kernels read its 16-slot
     partial rows."""
     monkeypatch.setenv("PFDYN_N16", str(mask))
+    monkeypatch.setenv("PFDYN_N16_ROWS_MAX", "100000000")
     if variant == "tile_lists":
         monkeypatch.setenv("PFDYN_NO_COMPACT", "1")
     if variant == "dense":
@@ -77,3 +78,32 @@ def test_n16_edge_kernels_on_goldens(name, variant, mask, monkeypatch):
     if mask & 2:
         assert eng.kernel_family(0) == 16 and eng.l0_hoist() == 16
     close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
+
+
+def test_n16_with_pocket_sharing(monkeypatch):
+    """Copies of a pocket share conv layer 0's protein -> protein messages under the n16 edge kernel too: a
+    30-step trajectory of 2 pockets x (9, 7) ragged copies, shared == per-copy == the row-group kernels, and the shared
+    launch computes fewer edges."""
+    from test_gpu_fullsize import _copies_batch, _engine
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    sizes = [3, 8, 5, 4, 6, 7, 3, 5, 4]
+    batch, uid = _copies_batch(cfg, [(511, 120), (512, 90)], [sizes, sizes[:7]])
+    T, n = 100, 30
+    Nf = int(batch.pharm_ptr[-1])
+    noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(5))
+    coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+    res, fam, work = {}, {}, {}
+    for name, env, shared in (("rg", {"PFDYN_N16": "0"}, True), ("n16", {"PFDYN_N16": "3"}, False), ("n16_shared", {"PFDYN_N16": "3"}, True)):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = _engine(cfg, sd)
+        eng.set_batch(batch.prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst,
+                      pocket_uid=uid if shared else None)
+        x, h = eng.sample(eng.coef_array(coef, reversed(range(n))), n, noise)
+        res[name], fam[name], work[name] = (x.cpu(), h.cpu()), eng.kernel_family(0), eng.work_detail()
+    assert fam == {"rg": 4, "n16": 16, "n16_shared": 16}, fam
+    for a in ("rg", "n16"):
+        torch.testing.assert_close(res["n16_shared"][0], res[a][0], rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(res["n16_shared"][1], res[a][1], rtol=2e-4, atol=2e-4)
+    assert work["n16_shared"]["executed_edges_per_layer"][0] < 0.9 * work["n16"]["executed_edges_per_layer"][0]

@@ -503,7 +503,7 @@ def test_fused_update_and_edge_build_variants_agree(case, monkeypatch):
 
 def test_kernel_family_reporting(monkeypatch):
     """pf_debug_kernel_family reports what the launch policy chose for a layer's edge messages: the row-group kernels by
-    default (4 rows per wave for small launches), the 32-row tile kernels when they are switched off."""
+    default (the n16 form for small launches; with it off, 4 rows per wave), the 32-row tile kernels when they are switched off."""
     cfg = O.DynamicsConfig()
     sd = O.make_state_dict(cfg, 0)
     batch = O.synthetic_batch([71, 72], 64, [4, 5], cfg)
@@ -511,7 +511,13 @@ def test_kernel_family_reporting(monkeypatch):
     eng = engine_for(cfg, sd)
     set_batch(eng, batch)
     eng.dynamics(x_t, h_t, t)
+    assert eng.kernel_family(0) == 16 and eng.kernel_family(1) == 16       # small launches: 16-row items on four waves (pf_n16.hip)
+    monkeypatch.setenv("PFDYN_N16", "0")
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    eng.dynamics(x_t, h_t, t)
     assert eng.kernel_family(0) == 4 and eng.kernel_family(1) == 4
+    monkeypatch.delenv("PFDYN_N16")
     monkeypatch.setenv("PFDYN_RG2_ROWS_MIN", "0")
     eng = engine_for(cfg, sd)
     set_batch(eng, batch)
@@ -550,7 +556,7 @@ def test_static_hoist_vs_golden_and_full_chain(name, variant, monkeypatch):
     eng = engine_for(cfg, sd)
     set_batch(eng, batch, z["prot_x"])
     eps_h, eps_x = eng.dynamics(z["x_t"], z["h_t"], z["t"])
-    assert eng.l0_hoist() in (4, 8), "the static hoist did not run"
+    assert eng.l0_hoist() in (4, 8, 16), "the static hoist did not run"
     close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
     monkeypatch.setenv("PFDYN_NO_L0_HOIST", "1")
     ref = engine_for(cfg, sd)
