@@ -10,60 +10,69 @@ import torch
 ph_idx_to_type = ['Aromatic', 'HydrogenDonor', 'HydrogenAcceptor', 'PositiveIon', 'NegativeIon', 'Hydrophobic']
 
 
+_XYZ_ELEMENTS = ('P', 'S', 'F', 'N', 'O', 'C')      # file format of pharms.xyz: one pseudo-element per pharmacophore type
+
+
+def _xyz_block(elements, coords) -> str:
+    """One xyz frame: the center count, then `element x y z` with three decimals per center (the text
+    pharm_builder.py:35-42 / unorganized_utils.py:111-128 emit; this is the file format)."""
+    rows = torch.as_tensor(coords, dtype=torch.float64).reshape(-1, 3).tolist()
+    if len(rows) != len(elements):
+        raise ValueError(f"{len(elements)} element symbols for {len(rows)} positions")
+    body = "".join(f"{e} {x:.3f} {y:.3f} {z:.3f}\n" for e, (x, y, z) in zip(elements, rows))
+    return f"{len(rows)}\n" + body
+
+
+def _emit(text: str, filename):
+    """Return the text, or write it when a file name is given (the reference's writers do the same)."""
+    if filename is None:
+        return text
+    Path(filename).write_text(text)
+    return None
+
+
 class SampledPharmacophore:
-    type_idx_to_elem = ['P', 'S', 'F', 'N', 'O', 'C']
+    """One generated pharmacophore: the final graph, its argmax feature types and, optionally, the frames of its
+    reverse-diffusion trajectory.  Attribute and method names follow pharmacoforge/analysis/pharm_builder.py:7-71
+    (callers and the metrics read them); the bodies are this repository's."""
+    type_idx_to_elem = list(_XYZ_ELEMENTS)
 
     def __init__(self, g, pharm_type_map: List[str], traj_frames=None, ref_prot_file: Path = None, ref_rdkit_lig=None):
-        self.g = g                                       # single-graph PocketGraph holding the final x_0 / h_0
-        self.pharm_type_map = pharm_type_map
+        if len(pharm_type_map) != len(_XYZ_ELEMENTS):
+            raise AssertionError(f"a pharmacophore type map of {len(_XYZ_ELEMENTS)} entries is required, got {len(pharm_type_map)}")
+        self.g = g                                       # single-graph PocketGraph with x_0 / h_0 of the centers
+        self.pharm_type_map = list(pharm_type_map)
+        self.ph_type_to_elem = dict(zip(self.pharm_type_map, _XYZ_ELEMENTS))
         self.ref_prot_file, self.ref_rdkit_lig = ref_prot_file, ref_rdkit_lig
         self.ph_coords = g.pharm_x0
-        self.ph_feats_idxs = g.pharm_h0.argmax(dim=1)
-        self.ph_types = [pharm_type_map[int(i)] for i in self.ph_feats_idxs]
-        self.n_ph_centers = self.ph_coords.shape[0]
-        self.pos_frames, self.feat_frames = (None, None) if traj_frames is None else traj_frames
-        assert len(pharm_type_map) == len(self.type_idx_to_elem), \
-            f"pharm_type_map must have {len(self.type_idx_to_elem)} elements"
-        self.ph_type_to_elem = {pharm_type_map[i]: self.type_idx_to_elem[i] for i in range(len(pharm_type_map))}
+        self.ph_feats_idxs = torch.argmax(g.pharm_h0, dim=1)
+        self.ph_types = self._names(self.ph_feats_idxs)
+        self.n_ph_centers = int(self.ph_coords.shape[0])
+        self.pos_frames, self.feat_frames = traj_frames if traj_frames is not None else (None, None)
 
-    def pharm_to_xyz(self, pos: torch.Tensor, types: List[str]):
-        out = f'{len(pos)}\n'
-        for i in range(len(pos)):
-            out += f"{self.ph_type_to_elem[types[i]]} {pos[i, 0]:.3f} {pos[i, 1]:.3f} {pos[i, 2]:.3f}\n"
-        return out
+    def _names(self, type_indices) -> List[str]:
+        return [self.pharm_type_map[k] for k in torch.as_tensor(type_indices).tolist()]
+
+    def pharm_to_xyz(self, pos: torch.Tensor, types: List[str]) -> str:
+        return _xyz_block([self.ph_type_to_elem[t] for t in types], pos)
 
     def to_xyz_file(self, filename: str = None):
-        out = self.pharm_to_xyz(self.ph_coords, self.ph_types)
-        if filename is None:
-            return out
-        with open(filename, 'w') as f:
-            f.write(out)
+        return _emit(self.pharm_to_xyz(self.ph_coords, self.ph_types), filename)
 
     def traj_to_xyz(self, filename: str = None):
-        if self.pos_frames is None:
-            raise ValueError("Cannot write trajectory because no trajectory frames were passed to the SampledPharmacophore object")
-        out = ""
-        frame_type_idxs = self.feat_frames.argmax(dim=2)
-        for i in range(self.pos_frames.shape[0]):
-            out += self.pharm_to_xyz(self.pos_frames[i], [self.pharm_type_map[int(j)] for j in frame_type_idxs[i]])
-        if filename is None:
-            return out
-        with open(filename, 'w') as f:
-            f.write(out)
+        if self.pos_frames is None or self.feat_frames is None:
+            raise ValueError("this SampledPharmacophore holds no trajectory: sample with visualize_trajectory=True to record one")
+        per_frame_types = torch.argmax(self.feat_frames, dim=2)
+        frames = (self.pharm_to_xyz(x, self._names(k)) for x, k in zip(self.pos_frames, per_frame_types))
+        return _emit("".join(frames), filename)
 
 
 def write_pharmacophore_file(coords_list, atom_types_list, pharm_type_map: list, filename: str = None):
-    elem = ['P', 'S', 'F', 'N', 'O', 'C']
-    out = ""
-    for coords, atom_types in zip(coords_list, atom_types_list):
-        assert len(coords) == len(atom_types)
-        out += f"{len(coords)}\n"
-        for i in range(len(coords)):
-            out += f"{elem[atom_types[i]]} {coords[i, 0]:.3f} {coords[i, 1]:.3f} {coords[i, 2]:.3f}\n"
-    if filename is None:
-        return out
-    with open(filename, 'w') as f:
-        f.write(out)
+    """Several pharmacophores, given as coordinates and type INDICES, as consecutive xyz frames (unorganized_utils.py:111-128)."""
+    frames = []
+    for coords, type_indices in zip(coords_list, atom_types_list):
+        frames.append(_xyz_block([_XYZ_ELEMENTS[int(k)] for k in type_indices], coords))
+    return _emit("".join(frames), filename)
 
 
 _MATCHING_TYPES = {'Aromatic': ['Aromatic', 'PositiveIon'], 'HydrogenDonor': ['HydrogenAcceptor'],

@@ -1484,6 +1484,10 @@ int pf_commit_weights(pf_handle* h) {
 static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_ptr, const int32_t* pharm_ptr,
                                  const float* dev_prot_x, const float* dev_prot_h, const float* host_prot_x, const float* host_prot_h,
                                  int64_t n_pp, const int32_t* pp_src, const int32_t* pp_dst, pf_stream stream) {
+    // the pocket-group claim (pf_set_pocket_groups) belongs to THIS bind: it is taken off the handle before anything can
+    // fail, so that a rejected bind never leaves it behind for the next, unrelated batch
+    std::vector<int> rep_claim;
+    if (h) rep_claim.swap(h->pending_rep);
     int rc = check_ready(h, false);
     if (rc) return rc;
     const bool from_host = host_prot_x != nullptr;
@@ -1503,19 +1507,35 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     auto mark = [&] { if (timing && tmi < 8) tm[tmi++] = now(); };
     mark();
-    free_ws(h, true);
-    h->B = B; h->Np = prot_ptr[B]; h->Nf = pharm_ptr[B]; h->N = h->Np + h->Nf; h->Epp = n_pp;
-    h->h_prot_ptr.assign(prot_ptr, prot_ptr + B + 1);
-    h->h_pharm_ptr.assign(pharm_ptr, pharm_ptr + B + 1);
-    const int Np = h->Np, Nf = h->Nf, N = h->N;
+    const int Np = prot_ptr[B], Nf = pharm_ptr[B], N = Np + Nf;
     // ---- host-side tables
     std::vector<int> gid(N);
-    h->max_np = 0;
+    int max_np = 0;
     for (int g = 0; g < B; ++g) {
-        h->max_np = std::max(h->max_np, prot_ptr[g + 1] - prot_ptr[g]);
+        max_np = std::max(max_np, prot_ptr[g + 1] - prot_ptr[g]);
         for (int i = prot_ptr[g]; i < prot_ptr[g + 1]; ++i) gid[i] = g;
         for (int i = pharm_ptr[g]; i < pharm_ptr[g + 1]; ++i) gid[Np + i] = g;
     }
+    // every argument check runs before the previous batch's state is touched: a rejected bind leaves the handle as it was
+    for (int64_t e = 0; e < n_pp; ++e) {
+        if (pp_src[e] < 0 || pp_src[e] >= Np || pp_dst[e] < 0 || pp_dst[e] >= Np) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld out of range", (long long)e);
+        if (gid[pp_src[e]] != gid[pp_dst[e]]) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld crosses graphs", (long long)e);
+    }
+    if (c.message_norm_mode == PF_NORM_GRAPH && c.pf_k > 0)
+        for (int g = 0; g < B; ++g)
+            if (std::min(c.pf_k, prot_ptr[g + 1] - prot_ptr[g]) > 0 && pharm_ptr[g + 1] > pharm_ptr[g] && pharm_ptr[g + 1] - 1 >= Np)
+                PF_FAIL(h, PF_ERR_ARG, "message_norm 0 with kNN pf edges: center index %d >= %d protein atoms "
+                        "(the reference indexes the protein batch vector with it, dynamics_gvp.py:220)", pharm_ptr[g + 1] - 1, Np);
+    if (!rep_claim.empty() && (int)rep_claim.size() != B)
+        PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_groups named %d graphs, this batch has %d", (int)rep_claim.size(), B);
+    // from here on the handle describes the new batch (a failure below -- a false pocket-group claim, a failing HIP call --
+    // leaves it without a batch: loud, never the previous one's tables under the new sizes)
+    h->have_batch = false;
+    free_ws(h, true);
+    h->B = B; h->Np = Np; h->Nf = Nf; h->N = N; h->Epp = n_pp;
+    h->h_prot_ptr.assign(prot_ptr, prot_ptr + B + 1);
+    h->h_pharm_ptr.assign(pharm_ptr, pharm_ptr + B + 1);
+    h->max_np = max_np;
     // pp edges sorted by destination (stable counting sort): CSR-by-dst
     std::vector<int> in_start((size_t)4 * N, 0), in_cnt((size_t)4 * N, 0);       // [4 slots][N]: BuildParams::in_start
     std::vector<int> deg(Np + 1, 0);
@@ -1596,9 +1616,9 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     std::vector<int> rep_base(B, 0);
     h->share_ok = false; h->share_rows = 0;
     h->h_share_start.assign(B, 0); h->h_share_cnt.assign(B, 0);
-    if (!h->pending_rep.empty()) {
+    if (!rep_claim.empty()) {
         std::vector<int> rep;
-        rep.swap(h->pending_rep);                                  // consumed by this bind, whatever happens
+        rep.swap(rep_claim);
         if ((int)rep.size() != B) PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_groups named %d graphs, this batch has %d", (int)rep.size(), B);
         long dense = 0, percopy = 0;
         int nrep = 0;
@@ -2319,6 +2339,7 @@ int pf_train_loss_forward(pf_handle* h, const float* dev_pharm_x0, const float* 
         PF_FAIL(h, PF_ERR_ARG, "pf_train_loss_forward: null argument");
     if (n_timesteps < 1 || !(feat_norm > 0.f)) PF_FAIL(h, PF_ERR_ARG, "pf_train_loss_forward: bad n_timesteps / feat_norm");
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) PF_FAIL(h, PF_ERR_ARG, "pf_train_loss_forward: dropout must be in [0, 1)");
+    if (h->Nf == 0) PF_FAIL(h, PF_ERR_ARG, "pf_train_loss_forward: the batch has no pharmacophore centers (the losses are means over them)");
     hipStream_t s = (hipStream_t)stream;
     rc = ensure_train_ws(h, s);
     if (rc) return rc;

@@ -1635,7 +1635,7 @@ __global__ __launch_bounds__(256) void k_loss_prepare(const LossParams p) {
     __shared__ float s_sh[8];
     const int g = blockIdx.x, tid = threadIdx.x;
     const int f0 = p.pharm_ptr[g], nfg = p.pharm_ptr[g + 1] - f0;          // <= 64 centers per graph
-    const int ti = p.t_int[g];
+    const int ti = min(max(p.t_int[g], 0), p.T);        // the tables hold T + 1 entries (callers validate; never read outside them)
     const float a = p.alpha_tab[ti], sg = p.sigma_tab[ti];
     if (tid < 64) {
         auto wsum = [](float v) {

@@ -98,24 +98,43 @@ class PfEngine:
 
     def set_batch(self, prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, pocket_uid=None):
         """pf_set_pocket_batch / pf_set_pocket_batch_host: asynchronous on the current stream.  ``pocket_uid`` ([B]
-        integers, optional): graphs with equal values are copies of one pocket (PocketGraph.pocket_uid); the library
-        verifies that and lets the copies share conv layer 0's protein-protein messages during sampling."""
+        integers, optional): graphs with equal values are claimed to be copies of one pocket (PocketGraph.pocket_uid), which
+        lets them share conv layer 0's protein-protein messages during sampling.  The claim is verified before it is used:
+        the library checks atom counts, pp in-degrees and pp sources of every copy, and coordinates and features byte for
+        byte when the pocket tensors are host-resident; for device-resident tensors (which the library never reads on the
+        host) the coordinate / feature comparison is done here, on the device.  A false claim raises PfError."""
         import numpy as np
-        if pocket_uid is not None:
-            uid = np.asarray(pocket_uid.detach().cpu().numpy() if isinstance(pocket_uid, torch.Tensor) else pocket_uid).reshape(-1)
-            first = {}
-            rep = np.asarray([first.setdefault(int(u), i) for i, u in enumerate(uid)], dtype=np.int32)
-            if len(first) < rep.size:                     # at least one pocket has copies
-                self._ck(self.lib.pf_set_pocket_groups(self._h, int(rep.size), rep.ctypes.data), "pf_set_pocket_groups")
         # index arrays: int32 host copies through numpy (single-threaded; a torch dtype conversion of half a million
         # elements goes through the intra-op thread pool, whose wake-up stalls for tens of milliseconds now and then on
         # hosts with hundreds of hardware threads)
         pptr, fptr, src, dst = (_i32_host(t) for t in (prot_ptr, pharm_ptr, pp_src, pp_dst))
+        on_host = not prot_x.is_cuda and not prot_h.is_cuda
+        rep = None
+        if pocket_uid is not None:
+            uid = np.asarray(pocket_uid.detach().cpu().numpy() if isinstance(pocket_uid, torch.Tensor) else pocket_uid).reshape(-1)
+            first = {}
+            rep = np.asarray([first.setdefault(int(u), i) for i, u in enumerate(uid)], dtype=np.int32)
+            if len(first) == rep.size:
+                rep = None                                # no pocket has copies
+        if rep is not None and not on_host and rep.size == pptr.size - 1:
+            cnt = np.diff(pptr)
+            if np.array_equal(cnt, cnt[rep]):             # (unequal atom counts: the library refuses the claim itself)
+                # atom i of a copy <-> the same atom of its representative: one gather and one comparison on the device
+                idx = np.concatenate([np.arange(pptr[r], pptr[r + 1]) for r in rep]) if rep.size else np.zeros(0, np.int64)
+                idx_t = torch.from_numpy(idx.astype(np.int64)).to(prot_x.device)
+                same = bool(torch.equal(prot_x, prot_x[idx_t])) and bool(torch.equal(prot_h.to(prot_x.device), prot_h.to(prot_x.device)[idx_t]))
+                if not same:
+                    raise L.PfError("pf_set_pocket_groups: a graph is not a copy of the pocket it names (coordinates / features differ)")
+        # the claim always travels with its bind (an empty one clears whatever an earlier, failed bind left behind)
+        if rep is not None:
+            self._ck(self.lib.pf_set_pocket_groups(self._h, int(rep.size), rep.ctypes.data), "pf_set_pocket_groups")
+        else:
+            self._ck(self.lib.pf_set_pocket_groups(self._h, 0, None), "pf_set_pocket_groups")
         self.B = int(pptr.size - 1)
         self.Np, self.Nf = int(pptr[-1]), int(fptr[-1])
-        args = (int(src.size), src.ctypes.data if src.size else None, dst.ctypes.data if dst.size else None, _stream_ptr())
         with torch.cuda.device(self.device):
-            if not prot_x.is_cuda and not prot_h.is_cuda:
+            args = (int(src.size), src.ctypes.data if src.size else None, dst.ctypes.data if dst.size else None, _stream_ptr())
+            if on_host:
                 # host-resident pockets (the sampling drivers): the library stages them with its tables -- one upload, the
                 # one-hot check on the host copy, nothing waits for the device
                 hx = np.ascontiguousarray(prot_x.detach().numpy(), dtype=np.float32)

@@ -430,12 +430,33 @@ class FlatAdam:
                 'layout': 'flat vector in pf_param_layout order'}
 
     def load_state_dict(self, sd):
+        """Accepts this class's own state (flat moment vectors, marked by 'layout') and the per-parameter state of
+        torch.optim.Adam -- what a checkpoint written by the reference's Lightning run holds (pharmacodiff.py:253-263:
+        Adam(self.parameters())): parameter i of that optimiser is tensor i of the flat layout (state-dict order, the
+        empty dummy_param included); parameters without an entry (never stepped) keep zero moments."""
         st, pg = sd['state'], sd['param_groups'][0]
-        self.ensure_state(st['step'], pg['lr'])
-        if st['exp_avg'].numel() != self.exp_avg.numel():
-            raise ValueError("FlatAdam.load_state_dict: moment vectors do not match this model's parameter count")
-        self.exp_avg.copy_(st['exp_avg'])
-        self.exp_avg_sq.copy_(st['exp_avg_sq'])
+        if 'layout' in sd:
+            self.ensure_state(st['step'], pg['lr'])
+            if st['exp_avg'].numel() != self.exp_avg.numel():
+                raise ValueError("FlatAdam.load_state_dict: moment vectors do not match this model's parameter count")
+            self.exp_avg.copy_(st['exp_avg'])
+            self.exp_avg_sq.copy_(st['exp_avg_sq'])
+        else:
+            layout = self.dyn.engine().param_layout()                # [(name, offset, numel)] in flat order
+            ids = list(pg.get('params', range(len(layout))))
+            if len(ids) != len(layout):
+                raise ValueError(f"FlatAdam.load_state_dict: the optimiser state names {len(ids)} parameters, this model has {len(layout)}")
+            steps = [int(torch.as_tensor(st[i]['step']).item()) for i in ids if i in st and 'step' in st[i]]
+            self.ensure_state(max(steps) if steps else 0, pg['lr'])
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+            for i, (name, off, n) in zip(ids, layout):
+                if n == 0 or i not in st:
+                    continue
+                for key, dst in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq)):
+                    src = st[i][key].reshape(-1)
+                    if src.numel() != n:
+                        raise ValueError(f"FlatAdam.load_state_dict: moment of {name} has {src.numel()} elements, expected {n}")
+                    dst[off:off + n].copy_(src)
         self.betas, self.eps = tuple(pg.get('betas', self.betas)), pg.get('eps', self.eps)
         self.weight_decay = pg.get('weight_decay', self.weight_decay)
 
@@ -715,6 +736,15 @@ class PharmacophoreDiff(_Base):
         return per_pocket
 
     # -- training-loss forward (pharmacodiff.py:162-243), evaluation only ---------------------------
+    def _check_injected_t(self, t_int, B):
+        """A caller-supplied t_int indexes tables of n_timesteps + 1 entries on the device: refuse anything else here (the
+        values the module draws itself, randint(0, T), need no check and no synchronisation)."""
+        if t_int.numel() != B:
+            raise ValueError(f"t_int has {t_int.numel()} entries for a batch of {B} graphs")
+        lo, hi = int(t_int.min()), int(t_int.max())
+        if lo < 0 or hi > self.n_timesteps:
+            raise ValueError(f"t_int must lie in [0, {self.n_timesteps}], got [{lo}, {hi}]")
+
     def forward(self, g, phase: str = 'train', t_int: torch.Tensor = None, eps: Dict[str, torch.Tensor] = None):
         """Losses and metrics of one batch (pharmacodiff.py:162-243) with the dynamics -- and, when autograd is on,
         its backward -- evaluated by the HIP kernels.  ``t_int`` / ``eps`` inject the random draws."""
@@ -743,6 +773,8 @@ class PharmacophoreDiff(_Base):
         prot_x = g.prot_x.to(dev) - com[br]
         if t_int is None:
             t_int = torch.randint(0, self.n_timesteps, size=(B,), device=dev)
+        else:
+            self._check_injected_t(t_int, B)
         t = t_int.to(dev).float() / self.n_timesteps
         if eps is None:
             eps = {'h': torch.randn(h0.shape, device=dev), 'x': torch.randn(x0.shape, device=dev)}
@@ -809,6 +841,8 @@ class PharmacophoreDiff(_Base):
         x0, h0 = g.pharm_x0.to(dev), g.pharm_h0.to(dev)
         if t_int is None:
             t_int = torch.randint(0, self.n_timesteps, size=(B,), device=dev)
+        else:
+            self._check_injected_t(t_int, B)
         if eps is None:
             eps = {'h': torch.randn(h0.shape, device=dev), 'x': torch.randn(x0.shape, device=dev)}
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p, _, _ in dyn._flat_views)

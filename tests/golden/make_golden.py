@@ -406,6 +406,75 @@ def golden_pp_edges(name, pockets, cutoff=3.5):
     npz(name, **out)
 
 
+def golden_dataset(name):
+    """The reference's ProteinPharmacophoreDataset (dataset/protein_pharm_dataset.py:19-179: per-file index arrays made
+    global, one-hot features, random pharmacophore subsampling :151-161, build_initial_complex_graph) and collate_fn
+    (:268-271 = dgl.batch) on a tiny processed directory in the process_crossdocked.py:246-252 layout.  The directory's
+    arrays are stored with the outputs, so the test rebuilds it and runs this repository's loader on the same files with
+    the same `random` seeds."""
+    import gzip
+    import pickle
+    import random
+    import tempfile
+    from pathlib import Path
+    from pharmacoforge.dataset import protein_pharm_dataset as ref_ds
+    prot_elements = ['C', 'N', 'O', 'S', 'P', 'F', 'Cl', 'Br', 'I', 'B', 'Se']
+    cutoffs = {'pp': 3.5, 'pf': 8, 'fp': 8, 'ff': 9}
+    rng = np.random.default_rng(77)
+    out = dict(cutoff_pp=3.5, subsample_min=3, subsample_max=6)
+    with tempfile.TemporaryDirectory() as tmp:
+        root = Path(tmp) / "processed"
+        splits = {"split_0": 3, "split_1": 2, "split_2": 4}
+        for sname, n_graphs in splits.items():
+            d = root / sname
+            d.mkdir(parents=True)
+            n_prot, n_pharm, n_ph = rng.integers(9, 15, n_graphs), rng.integers(2, 11, n_graphs), rng.integers(0, 4, n_graphs)
+
+            def idx(c):
+                e = np.cumsum(c)
+                return np.stack([e - c, e], 1)
+            arrs = dict(prot_pos=(rng.normal(size=(n_prot.sum(), 3)) * 3.5).astype(np.float32), prot_feat=rng.integers(0, 11, n_prot.sum()),
+                        prot_idx=idx(n_prot), pharm_pos=rng.normal(size=(n_pharm.sum(), 3)).astype(np.float32),
+                        pharm_feat=rng.integers(0, 6, n_pharm.sum()), pharm_idx=idx(n_pharm),
+                        prot_ph_pos=rng.normal(size=(n_ph.sum(), 3)).astype(np.float32), prot_ph_feat=rng.integers(0, 6, n_ph.sum()),
+                        prot_ph_idx=idx(n_ph))
+            np.savez(d / 'prot_pharm_tensors.npz', **arrs)
+            with gzip.open(d / 'prot_file_names.pkl.gz', 'wb') as f:
+                pickle.dump([f"{sname}_{i}.pdb" for i in range(n_graphs)], f)
+            with gzip.open(d / 'lig_rdmol.pkl.gz', 'wb') as f:
+                pickle.dump([None] * n_graphs, f)
+            for k, v in arrs.items():
+                out[f"in_{sname}_{k}"] = torch.from_numpy(v)
+        kw = dict(name='train', split_idxs=[0, 2], raw_data_dir=tmp, processed_data_dir=str(root), graph_cutoffs=cutoffs,
+                  prot_elements=prot_elements, ph_type_map=PH_TYPES)
+        plain = ref_ds.ProteinPharmacophoreDataset(**kw)
+        sub = ref_ds.ProteinPharmacophoreDataset(subsample_pharms=True, subsample_min=3, subsample_max=6, **kw)
+        out["n_graphs"] = len(plain)
+        out["file_names"] = "\n".join(plain.prot_file_names)          # the order in which the reference walked the split directories
+        graphs = []
+        for tag, ds in (("plain", plain), ("sub", sub)):
+            for i in range(len(ds)):
+                random.seed(1000 + i)                                  # the test seeds `random` the same way before ds[i]
+                g = ds[i]
+                u, v = g.edges(form='uv', etype='pp')
+                for nt, short in (("prot", "prot"), ("pharm", "pharm"), ("prot_ph", "ph")):
+                    out[f"{tag}_{i}_{short}_x"] = g.nodes[nt].data['x_0'] if g.num_nodes(nt) else torch.zeros(0, 3)
+                    out[f"{tag}_{i}_{short}_h"] = g.nodes[nt].data['h_0'] if g.num_nodes(nt) else torch.zeros(0, 6 if nt != "prot" else 11)
+                out[f"{tag}_{i}_pp_src"], out[f"{tag}_{i}_pp_dst"] = u, v
+                if tag == "plain":
+                    graphs.append(g)
+        pick = [0, 3, 5, 6]
+        gb = ref_ds.collate_fn([graphs[i] for i in pick])
+        out["collate_pick"] = torch.tensor(pick)
+        for nt, short in (("prot", "prot"), ("pharm", "pharm"), ("prot_ph", "ph")):
+            out[f"collate_{short}_counts"] = gb.batch_num_nodes(nt)
+            out[f"collate_{short}_x"] = gb.nodes[nt].data['x_0']
+        u, v = gb.edges(form='uv', etype='pp')
+        out["collate_pp_src"], out["collate_pp_dst"] = u, v
+        out["collate_pp_counts"] = gb.batch_num_edges('pp')
+    npz(name, **out)
+
+
 def main():
     cfg = O.DynamicsConfig()                       # dev.yml
     cfg2 = O.DynamicsConfig(n_convs=3, n_noise_gvps=3, message_norm=10, pf_k=0, ff_k=0)
@@ -446,6 +515,9 @@ def main():
                                                           n_pharms=[[3, 4], [5], [8, 3, 6]], max_batch_size=4, T=15),
         # static pp edges through build_initial_complex_graph
         "pp_edges.npz": lambda n: golden_pp_edges(n, pockets=[(0, 64), (29, 256), (30, 300), (31, 2)]),
+        # ---- round 3 -------------------------------------------------------------------------------------------
+        # the processed-dataset loader and collate_fn
+        "dataset.npz": lambda n: golden_dataset(n),
     }
     want = sys.argv[1:] or list(jobs)
     for name in want:

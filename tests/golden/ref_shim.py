@@ -402,7 +402,11 @@ def install(reference_root: str = "/root/reference"):
         return m
 
     fn = mod("dgl.function", u_sub_v=_USubV, copy_e=_CopyE, sum=_fn_sum, mean=_fn_mean)
-    data = mod("dgl.data", DGLDataset=object)
+    class DGLDataset:                 # dgl.data.DGLDataset as far as the reference's dataset class uses it: a name, nothing else
+        def __init__(self, name=None, **kwargs):
+            self._name = name
+
+    data = mod("dgl.data", DGLDataset=DGLDataset)
     dl = mod("dgl.dataloading", GraphDataLoader=object)
     mod("dgl", DGLHeteroGraph=HeteroGraph, heterograph=heterograph, batch=batch, unbatch=unbatch,
         readout_nodes=readout_nodes, function=fn, data=data, dataloading=dl)

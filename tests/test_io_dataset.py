@@ -1,6 +1,7 @@
 """CPU tests of the receptor / ligand ingestion (pocket_io) and the processed-dataset loader (dataset): the semantics of
 generate_pharmacophores.py:68-233 and protein_pharm_dataset.py:19-179 on hand-written files."""
 import gzip
+import os
 import pickle
 
 import numpy as np
@@ -242,3 +243,100 @@ def test_mmcif_receptor_reads_like_the_pdb(tmp_path):
     assert gr.num_nodes('prot') == 5
     with pytest.raises(ValueError, match="unsupported receptor file type"):
         P.process_ligand_and_pocket(tmp_path / "rec.xyz", None, emap, CUTOFFS, 8.0, lig_file=sdf)
+
+
+# ---- the reference's own dataset class as the witness (tests/golden/dataset.npz, recorded by make_golden.py from
+# ---- dataset/protein_pharm_dataset.py:19-179,268-276 run on a tiny processed directory) ---------------------------------
+def _rebuild_processed_dir(z, root):
+    names = sorted({k.split("_")[1] + "_" + k.split("_")[2] for k in z if k.startswith("in_")})
+    for sname in names:
+        d = root / sname
+        d.mkdir(parents=True)
+        arrs = {k[len(f"in_{sname}_"):]: np.asarray(z[k]) for k in z if k.startswith(f"in_{sname}_")}
+        np.savez(d / 'prot_pharm_tensors.npz', **arrs)
+        with gzip.open(d / 'prot_file_names.pkl.gz', 'wb') as f:
+            pickle.dump([f"{sname}_{i}.pdb" for i in range(len(arrs['prot_idx']))], f)
+    return names
+
+
+def test_dataset_reproduces_the_reference_dataset_class(tmp_path):
+    """`ProteinPharmacophoreDataset.__getitem__` (global index fix-up over the split files, one-hot features, the random
+    pharmacophore subsampling and its draws, the pp edges of build_initial_complex_graph) and `collate_fn` against what the
+    REFERENCE's class returned for the same files and the same `random` seeds."""
+    import random
+    from helpers import load
+    z = load("dataset.npz")
+    root = tmp_path / "processed"
+    _rebuild_processed_dir(z, root)
+    kw = dict(name='train', split_idxs=[0, 2], raw_data_dir=str(tmp_path), processed_data_dir=str(root), graph_cutoffs=CUTOFFS,
+              prot_elements=PROT_ELEMENTS, ph_type_map=pfa.analysis.ph_idx_to_type, pp_edges_fn=oracle_pp)
+    ref_names = str(z["file_names"]).split("\n")
+    n = int(z["n_graphs"])
+    assert len(ref_names) == n == 7
+    for tag, extra in (("plain", {}), ("sub", dict(subsample_pharms=True, subsample_min=int(z["subsample_min"]), subsample_max=int(z["subsample_max"])))):
+        ds = D.ProteinPharmacophoreDataset(**kw, **extra)
+        assert len(ds) == n and sorted(ds.prot_file_names) == sorted(ref_names)
+        for i, fname in enumerate(ref_names):                 # the reference walks the split directories in file-system order
+            j = ds.prot_file_names.index(fname)
+            random.seed(1000 + i)
+            g = ds[j]
+            for short, x, h in (("prot", g.prot_x, g.prot_h), ("pharm", g.pharm_x0, g.pharm_h0), ("ph", g.prot_ph_x, g.prot_ph_h)):
+                assert torch.equal(x, z[f"{tag}_{i}_{short}_x"]), (tag, i, short)
+                assert torch.equal(h, z[f"{tag}_{i}_{short}_h"]), (tag, i, short)
+            assert torch.equal(g.pp_src, z[f"{tag}_{i}_pp_src"].long()) and torch.equal(g.pp_dst, z[f"{tag}_{i}_pp_dst"].long())
+        if tag == "sub":                                      # the subsampling really drew: some pockets lost centers
+            assert any(z[f"sub_{i}_pharm_x"].shape[0] < z[f"plain_{i}_pharm_x"].shape[0] for i in range(n))
+    ds = D.ProteinPharmacophoreDataset(**kw)
+    pick = [ds.prot_file_names.index(ref_names[i]) for i in z["collate_pick"].tolist()]
+    gb = D.collate_fn([ds[j] for j in pick])
+    assert torch.equal(torch.diff(gb.prot_ptr), z["collate_prot_counts"].long())
+    assert torch.equal(torch.diff(gb.pharm_ptr), z["collate_pharm_counts"].long())
+    assert torch.equal(torch.diff(gb.prot_ph_ptr), z["collate_ph_counts"].long())
+    assert torch.equal(gb.prot_x, z["collate_prot_x"]) and torch.equal(gb.pharm_x0, z["collate_pharm_x"]) and torch.equal(gb.prot_ph_x, z["collate_ph_x"])
+    assert torch.equal(gb.pp_src, z["collate_pp_src"].long()) and torch.equal(gb.pp_dst, z["collate_pp_dst"].long())
+
+
+def test_from_dgl_adapter_on_a_heterograph_shaped_like_the_references():
+    """graph.from_dgl on DGL-style heterographs (tests/golden/ref_shim.HeteroGraph, the stand-in the goldens were recorded
+    with): graphs assembled the way build_initial_complex_graph assembles them (dataset/protein_pharm_dataset.py:226-264:
+    node types prot / pharm / prot_ph, edge types pp / pf / ff / fp, x_0 / h_0 node data) from the reference's recorded
+    outputs, single and batched with the stand-in's dgl.batch; when the reference is on this machine its own function builds
+    the graph."""
+    import sys
+    from helpers import GOLDEN, load
+    sys.path.insert(0, GOLDEN)
+    import ref_shim
+    z = load("dataset.npz")
+
+    def hetero(i):
+        no = ([], [])
+        data = {('prot', 'pp', 'prot'): (z[f"plain_{i}_pp_src"].long(), z[f"plain_{i}_pp_dst"].long()), ('prot', 'pf', 'pharm'): no,
+                ('pharm', 'ff', 'pharm'): no, ('pharm', 'fp', 'prot'): no}
+        nn = {'prot': z[f"plain_{i}_prot_x"].shape[0], 'pharm': z[f"plain_{i}_pharm_x"].shape[0], 'prot_ph': z[f"plain_{i}_ph_x"].shape[0]}
+        g = ref_shim.heterograph(data, num_nodes_dict=nn)
+        for nt, short in (("prot", "prot"), ("pharm", "pharm"), ("prot_ph", "ph")):
+            g.nodes[nt].data['x_0'] = z[f"plain_{i}_{short}_x"]
+            g.nodes[nt].data['h_0'] = z[f"plain_{i}_{short}_h"]
+        return g
+    pg = pfa.graph.from_dgl(hetero(2))
+    assert pg.batch_size == 1 and torch.equal(pg.prot_x, z["plain_2_prot_x"]) and torch.equal(pg.pharm_h0, z["plain_2_pharm_h"])
+    assert torch.equal(pg.prot_ph_x, z["plain_2_ph_x"]) and torch.equal(pg.pp_src, z["plain_2_pp_src"].long())
+    assert pg.prot_ptr.tolist() == [0, z["plain_2_prot_x"].shape[0]] and pg.pharm_ptr.tolist() == [0, z["plain_2_pharm_x"].shape[0]]
+    pick = z["collate_pick"].tolist()
+    gb = pfa.graph.from_dgl(ref_shim.batch([hetero(i) for i in pick]))
+    assert gb.batch_size == len(pick)
+    assert torch.equal(torch.diff(gb.prot_ptr), z["collate_prot_counts"].long()) and torch.equal(gb.prot_x, z["collate_prot_x"])
+    assert torch.equal(gb.pp_src, z["collate_pp_src"].long()) and torch.equal(gb.pp_dst, z["collate_pp_dst"].long())
+    # the batched adapter output is what this repository's own collate gives for the same pockets
+    own = pfa.batch([pfa.graph.from_dgl(hetero(i)) for i in pick])
+    for f in ("prot_x", "prot_h", "prot_ptr", "pharm_ptr", "pp_src", "pp_dst", "pharm_x0", "pharm_h0", "prot_ph_x", "prot_ph_ptr"):
+        assert torch.equal(getattr(gb, f), getattr(own, f)), f
+    if os.path.isdir("/root/reference/pharmacoforge"):        # build container only: the reference's own graph builder
+        ref_shim.install("/root/reference")
+        from pharmacoforge.dataset.protein_pharm_dataset import build_initial_complex_graph as ref_build
+        g = ref_build(z["plain_1_prot_x"], z["plain_1_prot_h"], {'pp': 3.5, 'pf': 8, 'fp': 8, 'ff': 9},
+                      pharm_atom_positions=z["plain_1_pharm_x"], pharm_atom_features=z["plain_1_pharm_h"],
+                      prot_ph_pos=z["plain_1_ph_x"], prot_ph_feat=z["plain_1_ph_h"])
+        pg = pfa.graph.from_dgl(g)
+        assert torch.equal(pg.pp_src, z["plain_1_pp_src"].long()) and torch.equal(pg.pp_dst, z["plain_1_pp_dst"].long())
+        assert torch.equal(pg.prot_x, z["plain_1_prot_x"]) and pg.num_nodes('pharm') == z["plain_1_pharm_x"].shape[0]
