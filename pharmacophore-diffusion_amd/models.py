@@ -442,16 +442,25 @@ class FlatAdam:
             self.exp_avg.copy_(st['exp_avg'])
             self.exp_avg_sq.copy_(st['exp_avg_sq'])
         else:
-            layout = self.dyn.engine().param_layout()                # [(name, offset, numel)] in flat order
-            ids = list(pg.get('params', range(len(layout))))
-            if len(ids) != len(layout):
-                raise ValueError(f"FlatAdam.load_state_dict: the optimiser state names {len(ids)} parameters, this model has {len(layout)}")
+            # parameter i of that optimiser = the i-th entry of the model's parameters(): PharmacophoreDiff's list is
+            # gamma.gamma (a frozen nn.Parameter upstream, pharmacodiff.py:662-664: never stepped) followed by the dynamics
+            # module's parameters in registration order, the empty dummy_param tensors included; an optimiser built on
+            # model.dynamics.parameters() lacks the leading gamma
+            where = {name: (off, n) for name, off, n in self.dyn.engine().param_layout()}
+            names = ['dynamics.' + k for k, _ in self.dyn.named_parameters()]
+            ids = list(pg.get('params', range(len(names))))
+            if len(ids) == len(names) + 1:
+                names = ['gamma.gamma'] + names
+            elif len(ids) != len(names):
+                raise ValueError(f"FlatAdam.load_state_dict: the optimiser state names {len(ids)} parameters, this model has "
+                                 f"{len(names)} (+ gamma.gamma)")
             steps = [int(torch.as_tensor(st[i]['step']).item()) for i in ids if i in st and 'step' in st[i]]
             self.ensure_state(max(steps) if steps else 0, pg['lr'])
             self.exp_avg.zero_(); self.exp_avg_sq.zero_()
-            for i, (name, off, n) in zip(ids, layout):
-                if n == 0 or i not in st:
+            for i, name in zip(ids, names):
+                if i not in st or name not in where or where[name][1] == 0:
                     continue
+                off, n = where[name]
                 for key, dst in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq)):
                     src = st[i][key].reshape(-1)
                     if src.numel() != n:

@@ -651,3 +651,86 @@ def test_gradient_views_accumulate_clear_and_allreduce_in_place():
         torch.testing.assert_close(grads(), g1, rtol=1e-5, atol=1e-7)
     finally:
         dist.destroy_process_group()
+
+
+def test_flat_adam_resumes_from_a_per_parameter_adam_state():
+    """A checkpoint written by the reference's Lightning run carries torch.optim.Adam's per-parameter state
+    (pharmacodiff.py:253-263); FlatAdam.load_state_dict maps it into the flat moment vectors (parameter i = tensor i of
+    the flat layout) and the next steps equal torch.optim.Adam's own continuation."""
+    z = load("train_grads.npz")
+    b = batch_from(z)
+    inj = dict(t_int=z["t_int"].long(), eps={'h': z["eps_h"], 'x': z["eps_x"]})
+
+    def steps(m, opt, n):
+        g = graph_from(b, z["x0"], z["h0"]).to("cuda")
+        for _ in range(n):
+            opt.zero_grad(set_to_none=True)
+            m.training_step(g, 0, **inj).backward()
+            opt.step()
+
+    def fresh():
+        m = make_model(int(z["T"]))
+        m.train()
+        m.dynamics.dropout_rate = 0.0
+        return m
+    m_t = fresh()
+    opt_t = torch.optim.Adam(m_t.parameters(), lr=1e-3)
+    steps(m_t, opt_t, 2)
+    ck_state = {k: v.detach().cpu().clone() for k, v in m_t.state_dict().items()}
+    import copy
+    ck_opt = copy.deepcopy(opt_t.state_dict())                 # {'state': {i: {step, exp_avg, exp_avg_sq}}, 'param_groups': [...]}
+    assert 'layout' not in ck_opt and isinstance(next(iter(ck_opt['state'].values())), dict)
+    steps(m_t, opt_t, 2)                                       # the uninterrupted run
+    m_f = fresh()
+    m_f.load_state_dict(ck_state, strict=True)
+    opt_f = pfa.FlatAdam(m_f.dynamics, lr=1e-3)
+    opt_f.load_state_dict(ck_opt)
+    assert opt_f.t == 2 and float(opt_f.exp_avg.abs().max()) > 0
+    steps(m_f, opt_f, 2)
+    for k, v in m_t.dynamics.state_dict().items():
+        if v.numel():
+            torch.testing.assert_close(m_f.dynamics.state_dict()[k].cpu(), v.cpu(), rtol=2e-4, atol=2e-6, msg=k)
+    own = opt_f.state_dict()                                   # and its own format still round-trips
+    opt_g = pfa.FlatAdam(m_f.dynamics, lr=1e-3)
+    opt_g.load_state_dict(own)
+    assert opt_g.t == opt_f.t and torch.equal(opt_g.exp_avg, opt_f.exp_avg)
+
+
+def test_pocket_claims_device_resident_batches_and_failed_binds():
+    """A pocket-group claim is verified for device-resident pocket tensors too (coordinates compared on the device), a
+    rejected bind neither keeps its claim for the next batch nor destroys the batch that was bound before, and an
+    injected t_int outside the schedule is refused."""
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    from test_gpu_fullsize import _copies_batch, _engine
+    batch, uid = _copies_batch(cfg, [(601, 60), (602, 48)], [[3, 5, 4], [6, 4]])
+    eng = _engine(cfg, sd)
+    dev = lambda t: t.cuda()
+    eng.set_batch(dev(batch.prot_x), dev(batch.prot_h), batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst, pocket_uid=uid)
+    gen = torch.Generator().manual_seed(1)
+    Nf = int(batch.pharm_ptr[-1])
+    x_t, h_t, t = torch.randn(Nf, 3, generator=gen), torch.randn(Nf, 6, generator=gen), torch.full((5,), 0.4)
+    ref = [v.cpu() for v in eng.dynamics(x_t, h_t, t)]
+    px = batch.prot_x.clone(); px[70] += 0.01                 # an atom of the second copy of the first pocket, on the device
+    with pytest.raises(pfa.PfError, match="coordinates / features differ"):
+        eng.set_batch(dev(px), dev(batch.prot_h), batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst, pocket_uid=uid)
+    # a bind the library rejects (a pp edge across two graphs) with a claim attached ...
+    bad_src = batch.pp_src.clone(); bad_src[0] = int(batch.prot_ptr[1]) + 1
+    with pytest.raises(pfa.PfError, match="crosses graphs"):
+        eng.set_batch(batch.prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, bad_src, batch.pp_dst, pocket_uid=uid)
+    # ... leaves the previous batch usable, bitwise
+    again = [v.cpu() for v in eng.dynamics(x_t, h_t, t)]
+    assert torch.equal(again[0], ref[0]) and torch.equal(again[1], ref[1])
+    # ... and the stale claim does not attach to the next, unrelated batch (another number of graphs)
+    other = O.synthetic_batch([603, 604], 40, [4, 3], cfg)
+    eng.set_batch(other.prot_x, other.prot_h, other.prot_ptr, other.pharm_ptr, other.pp_src, other.pp_dst)
+    Nf2 = int(other.pharm_ptr[-1])
+    eh, ex = eng.dynamics(torch.randn(Nf2, 3, generator=gen), torch.randn(Nf2, 6, generator=gen), torch.full((2,), 0.3))
+    assert torch.isfinite(eh).all() and torch.isfinite(ex).all()
+    # injected timesteps outside [0, T]
+    z = load("train_grads.npz")
+    m = make_model(int(z["T"]))
+    g = graph_from(batch_from(z), z["x0"], z["h0"]).to("cuda")
+    bad_t = z["t_int"].long().clone(); bad_t[0] = int(z["T"]) + 3
+    with pytest.raises(ValueError, match="t_int must lie"):
+        m.forward(g, 'val', t_int=bad_t, eps={'h': z["eps_h"], 'x': z["eps_x"]})
