@@ -221,8 +221,8 @@ def golden_conv_and_dynamics(cfg, name, seeds, n_prot, n_pharm, T=100, wseed=0):
 
 
 @torch.no_grad()
-def golden_trajectory(cfg, name, seeds, n_prot, n_pharm, T, noise_seed=42, wseed=0, traj=True):
-    m, sd = ref_model(cfg, T, 1e-5, seed=wseed)
+def golden_trajectory(cfg, name, seeds, n_prot, n_pharm, T, noise_seed=42, wseed=0, traj=True, precision=1e-5):
+    m, sd = ref_model(cfg, T, precision, seed=wseed)
     batch = O.synthetic_batch(seeds, n_prot, n_pharm, cfg)
     g = ref_graph(batch, pharm_nf=cfg.pharm_nf)
     Nf = int(batch.pharm_ptr[-1])
@@ -236,7 +236,7 @@ def golden_trajectory(cfg, name, seeds, n_prot, n_pharm, T, noise_seed=42, wseed
     pharms = m.sample_given_receptor(g, init_pharm_com=None, visualize_trajectory=traj)
     x0 = torch.cat([p.ph_coords for p in pharms])
     h0 = torch.cat([p.g.nodes['pharm'].data['h_0'] for p in pharms])
-    out = dict(batch_arrays(batch), noise=noise, x0=x0, h0=h0, T=T, wseed=wseed,
+    out = dict(batch_arrays(batch), noise=noise, x0=x0, h0=h0, T=T, wseed=wseed, precision=precision,
                xyz="".join(p.to_xyz_file() for p in pharms))
     if traj:
         out["pos_frames"] = torch.cat([p.pos_frames for p in pharms], dim=1)    # [T+1, Nf, 3]
@@ -518,6 +518,13 @@ def main():
         # ---- round 3 -------------------------------------------------------------------------------------------
         # the processed-dataset loader and collate_fn
         "dataset.npz": lambda n: golden_dataset(n),
+        # config 1 over the whole T = 500 schedule in the regime a trained model lives in: the centers stay inside the
+        # pocket.  With seeded random weights the noise prediction cannot cancel the sampler's 1 / alpha_{t|s} factors (their
+        # product is 1 / alpha_T = 316 at the shipped precision 1e-5: traj_c1_T500.npz ends ~480 A from the pocket, and
+        # scaling the head's output by +-300 moves that by 3 %), so the bound comes from the schedule instead: PharmacophoreDiff's
+        # own `precision` argument (pharmacodiff.py:41,64) at 0.25 gives alpha_T >= 0.5 -- same sampler code, every step with
+        # ff / pf / fp edges between centers 1-5 A apart, 3.4 A from the pocket centre at most.
+        "traj_c1_T500_bounded.npz": lambda n: golden_trajectory(cfg, n, seeds=[0], n_prot=64, n_pharm=4, T=500, precision=0.25),
     }
     want = sys.argv[1:] or list(jobs)
     for name in want:

@@ -91,6 +91,36 @@ def test_trajectory_vs_golden(name, ep):
         close(res[2], z["pos_frames"], 5e-3, 5e-3); close(res[3], z["feat_frames"], 5e-3, 5e-3)
 
 
+def test_bounded_T500_trajectory_every_frame_absolute():
+    """The whole T = 500 reverse process in the regime a trained model lives in -- every center inside the pocket at every step,
+    ff / pf / fp edges present throughout -- against the reference's own run (tests/golden/traj_c1_T500_bounded.npz: the
+    reference's sampler with its `precision` argument at 0.25, which bounds 1 / alpha_T by 2; see make_golden.py for why
+    scaled weights cannot do that): all 501 frames with an ABSOLUTE tolerance of 2e-2 A, no relative part; edge sets of the
+    last step; and the same through the oracle."""
+    z = load("traj_c1_T500_bounded.npz")
+    cfg = O.DynamicsConfig()
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    T, prec = int(z["T"]), float(z["precision"])
+    assert T == 500 and prec == 0.25
+    pos = z["pos_frames"]
+    com = O.segment_mean(batch.prot_x, batch.prot_ptr)
+    assert float((pos - com).norm(dim=-1).max()) < 4.0                       # pocket radius 6.7 A: the centers never leave it
+    pd = torch.cdist(pos[-100:], pos[-100:])
+    assert float(pd.max()) < cfg.cutoff_ff                                    # => every ordered pair is an ff edge in the last 100 steps
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    coef = O.step_coefficients(O.gamma_table(T, prec), T)
+    res = eng.sample(eng.coef_array(coef, reversed(range(T))), T, z["noise"], trajectory=True)
+    for got, ref in ((res[0], z["x0"]), (res[1], z["h0"]), (res[2], z["pos_frames"]), (res[3], z["feat_frames"])):
+        torch.testing.assert_close(got.cpu(), ref, rtol=0.0, atol=2e-2)
+    Nf = int(batch.pharm_ptr[-1])
+    ne = eng.work()[2]                                                        # edges of the last dynamics call (step s = 0)
+    assert ne[0] == Nf * (Nf - 1) and ne[1] == 5 * Nf and ne[2] == ne[1]
+    worst = float((res[2].cpu() - z["pos_frames"]).abs().max())
+    assert worst < 2e-2, worst
+
+
 UNIT_TOL = 5e-5
 
 

@@ -131,16 +131,20 @@ def test_reference_edge_bookkeeping_for_per_graph_norm():
 
 
 @pytest.mark.parametrize("name,traj,ep", [("traj_c1.npz", True, False), ("traj_ragged.npz", False, False),
-                                          ("traj_c1_T500.npz", True, False), ("traj_endpoint.npz", True, True)])
+                                          ("traj_c1_T500.npz", True, False), ("traj_endpoint.npz", True, True),
+                                          ("traj_c1_T500_bounded.npz", True, False)])
 def test_trajectory(name, traj, ep):
     """sample_given_receptor against the reference's trajectories: config 1 at T=50 and over the whole T=500 schedule
-    (every frame), a ragged batch, and the endpoint parameterisation (pharmacodiff.py:413-420)."""
+    (every frame; once at the shipped schedule precision, where random weights let the centers drift ~480 A away, once
+    at precision 0.25, where they stay inside the pocket at every step), a ragged batch, and the endpoint
+    parameterisation (pharmacodiff.py:413-420)."""
     z = load(name)
     cfg = O.DynamicsConfig()
     batch = batch_from(z)
     sd = O.make_state_dict(cfg, int(z["wseed"]))
     T = int(z["T"])
-    res = O.sample_given_receptor(sd, cfg, batch, T, 1e-5, z["noise"], return_traj=traj, endpoint_param_coord=ep,
+    prec = float(z["precision"]) if "precision" in z else 1e-5
+    res = O.sample_given_receptor(sd, cfg, batch, T, prec, z["noise"], return_traj=traj, endpoint_param_coord=ep,
                                   endpoint_param_feat=ep)
     # T-step stochastic trajectory: rounding differences compound, tolerance is looser
     close(res[0], z["x0"], rtol=1e-3, atol=1e-3)
