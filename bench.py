@@ -23,10 +23,99 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3          # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_EDGE = 136742.0         # message chain, 2 FLOP / MAC
-# roofline.traffic: HBM bytes per launch need hardware counters, which cannot be read from inside this process.  They are
-# collected by separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh) and committed under
-# profiles/; the JSON line carries null plus the pointer below instead of a number copied from an earlier run.
-TRAFFIC_SOURCE = "profiles/r02/*_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; see profiles/README.md)"
+# roofline.traffic: bytes per launch of the dominant kernel from the hardware counters FETCH_SIZE / WRITE_SIZE, collected by two
+# rocprofv3 --pmc child passes of this same script (pmc_passes) that the parent starts BEFORE it touches the GPU; corrected as
+# MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KB, FETCH_SIZE reports half of the bytes of wide (16 B per
+# lane) reads on gfx950 -- every bulk read of these kernels -- and is doubled, WRITE_SIZE is exact.  null only when rocprofv3 is
+# not available (the reason is given next to it).
+
+
+def _child_json(cmd, env=None, timeout=600):
+    """Run a child process and return the last JSON object line of its stdout (None, reason on failure)."""
+    import subprocess
+    try:
+        pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    except Exception as e:
+        return None, f"{type(e).__name__}: {e}"
+    for line in reversed(pr.stdout.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{"):
+            try:
+                return json.loads(line), None
+            except Exception:
+                pass
+    return None, f"exit code {pr.returncode}: {pr.stderr.strip().splitlines()[-1] if pr.stderr.strip() else 'no JSON line'}"
+
+
+def pmc_passes(inner_args):
+    """FETCH_SIZE and WRITE_SIZE per kernel (mean per launch, KB) from two separate rocprofv3 --pmc passes of a short inner run
+    of this script (counters are never collected together with --stats or a trace domain; the profiled program is python3
+    itself, directly after `--`).  Returns ({kernel name: {"fetch_kb", "write_kb", "launches"}}, None) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    from collections import defaultdict
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    env = dict(os.environ, TMPDIR="/tmp")
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="pfbench_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   "python3", os.path.abspath(__file__)] + inner_args
+            _, err = _child_json(cmd, env=env, timeout=600)
+            if err is not None:
+                return None, f"{counter} pass failed: {err}"
+            acc = defaultdict(lambda: [0.0, 0])
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") != counter:
+                            continue
+                        a = acc[row["Kernel_Name"]]
+                        a[0] += float(row["Counter_Value"])
+                        a[1] += 1
+            if not acc:
+                return None, f"{counter} pass wrote no counter rows"
+            for k, (tot, n) in acc.items():
+                d = res.setdefault(k, {"fetch_kb": 0.0, "write_kb": 0.0, "launches": n})
+                d["fetch_kb" if counter == "FETCH_SIZE" else "write_kb"] = tot / n
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return res, None
+
+
+def secondary_legs(args):
+    """The other BASELINE configurations as compact objects of the default line: children of this script, started before the
+    parent touches the GPU.  config 3 (batch 128, ragged sizes 3-8), a config-4 slice (64 pockets x 30 pharmacophores end to end
+    through PharmacophoreDiff.sample) and the training step of config 5 (batch 256, a new batch every step)."""
+    me = [sys.executable, os.path.abspath(__file__)]
+    light = ["--no-cpu-baseline", "--no-dense-leg", "--no-secondary", "--no-traffic", "--gpus", "1"]
+    out = {}
+    j, err = _child_json(me + light + ["--batch", "128", "--pharm-sizes", "3-8", "--steps", "50", "--warmup", "5", "--no-full-trajectory"])
+    if j:
+        r = j["roofline"]
+        out["config3"] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                          "dominant_kernel": r["kernel"], "kernel_avg_us": r["kernel_avg_us"], "frac_executed": r["frac_executed"], "frac": r["frac"]}
+    else:
+        out["config3"] = {"error": err}
+    j, err = _child_json(me + light + ["--sample-slice", "64"])
+    if j:
+        out["config4_slice"] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "wall_s": j["config"]["wall_s"],
+                                "ms_per_pocket": j["config"]["ms_per_pocket"], "ms_per_step": j["ms_per_step"], **j.get("dominant", {})}
+    else:
+        out["config4_slice"] = {"error": err}
+    j, err = _child_json(me + light + ["--train", "--steps", "20", "--warmup", "4"])
+    if j:
+        r = j["roofline"]
+        out["train_step"] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                             "dominant_kernel": r["kernel"], "kernel_avg_us": r["kernel_avg_us"], "frac_executed": r["frac"], "frac": r["frac"],
+                             "note": "a new batch every step (4 distinct batches rotate); the backward kernels execute exactly the algorithmic FLOPs"}
+    else:
+        out["train_step"] = {"error": err}
+    return out
 
 
 def launch_ranks(n):
@@ -85,6 +174,8 @@ def main():
                          "and HIP stream each; 1: skip)")
     ap.add_argument("--train-batches", type=int, default=4,
                     help="--train: number of distinct batches the steps rotate through (1: the same batch every step, no re-bind)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the compact objects of the other configurations (config 3, config-4 slice, training step)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
     ap.add_argument("--train", action="store_true",
                     help="secondary benchmark (BASELINE config 5): training steps (forward, backward kernels, Adam) at "
                          "batch 256 per GPU instead of the sampling metric")
@@ -95,6 +186,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # children first: nothing in this process has touched the GPU yet (a process that has must not start other programs)
+    headline = not args.train and args.sample_slice == 0
+    pmc, pmc_err, secondary = None, "not collected (--no-traffic, or a multi-rank run)", None
+    if rank == 0 and world == 1 and headline:
+        if not args.no_traffic:
+            inner = ["--no-cpu-baseline", "--no-dense-leg", "--no-full-trajectory", "--no-secondary", "--no-traffic", "--gpus", "1",
+                     "--steps", "20", "--warmup", "2", "--batch", str(args.batch), "--n-prot", str(args.n_prot), "--n-pharm", str(args.n_pharm),
+                     "--arch", args.arch] + (["--pharm-sizes", args.pharm_sizes] if args.pharm_sizes else [])
+            pmc, pmc_err = pmc_passes(inner)
+        default_cfg = (args.batch, args.n_prot, args.n_pharm, args.pharm_sizes, args.arch) == (32, 256, 6, "", "dev")
+        if not args.no_secondary and default_cfg:
+            secondary = secondary_legs(args)
     import torch.distributed as dist
     ndev = torch.cuda.device_count()
     if ndev == 0:
@@ -219,6 +322,11 @@ def main():
         if world > 1:
             dist.all_reduce(t_, op=dist.ReduceOp.MAX)
         return float(t_.item())
+    per_rank_ms = [dt / K * 1e3]
+    if world > 1:                                   # every rank's own time, for auditing a scaling run
+        tl = [torch.zeros(1, device=dev if backend == "nccl" else "cpu", dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([dt / K * 1e3], device=dev if backend == "nccl" else "cpu", dtype=torch.float64))
+        per_rank_ms = [float(t_.item()) for t_ in tl]
     dt = max_over_ranks(dt)
 
     wk = eng.work_detail()                                      # work of the last call (actual edge counts)
@@ -229,8 +337,18 @@ def main():
     # FLOP = 136,742 per edge it actually processes
     dom = "edge_msg" if prof["edge_msg"][1] > 0 else "edge_msg_coop"
     fam = eng.kernel_family(0)
-    dom_name = {4: "k_rg_edge<rows_per_wave=4>", 8: "k_rg_edge<rows_per_wave=8>", 16: "k_n16_edge<layer0>: 16-row items on four waves",
-                32: "k_edge_msg", 128: "k_edge_msg_coop"}[fam]
+    hoist_rows = eng.l0_hoist()
+    # the template the launch really ran (pf_host.cpp: run_dynamics): the rocprofv3 kernel name starts with it
+    if fam == 16:
+        dom_name, dom_match = "k_n16_edge<true> (conv layer 0: 16-row items on four waves, v_mfma_f32_16x16x4_f32)", "k_n16_edge<true>"
+    elif fam in (4, 8):
+        rg_a, rg_p = fam // 4, hoist_rows // 4
+        dom_name = (f"k_rg_edge<true, {rg_a}, ., {rg_p}> (conv layer 0: {fam} rows per wave" +
+                    (f", hoisted pp items {hoist_rows}" if hoist_rows and hoist_rows != fam else "") + ", v_mfma_f32_4x4x1_16b_f32)")
+        dom_match = f"k_rg_edge<true, {rg_a},"
+    else:
+        dom_name = {32: "k_edge_msg<true>", 128: "k_edge_msg_coop<true>"}[fam]
+        dom_match = dom_name[:-6]
     edge_ms, edge_n = prof[dom]
     l0_edges = wk["executed_edges_per_layer"][0]
     edge_avg_s = edge_ms / max(edge_n, 1) * 1e-3
@@ -238,7 +356,6 @@ def main():
     achieved_tf = edge_flops / edge_avg_s / 1e12 if edge_avg_s > 0 else 0.0
     # static hoist of conv layer 0: its pp edges do not execute their first message GVP (48,678 FLOP of the
     # 136,742) except its gates (4,096); reported next to the algorithmic figure
-    hoist_rows = eng.l0_hoist()
     n_dyn = ne[0] + ne[1] + ne[2]
     hoisted_edges = (l0_edges - n_dyn if l0_edges < sum(ne) else ne[3]) if hoist_rows else 0
     edge_flops_exec = edge_flops - (48678.0 - 4096.0) * max(hoisted_edges, 0)
@@ -259,23 +376,50 @@ def main():
                    "edges_per_step": {"ff": ne[0], "pf": ne[1], "fp": ne[2], "pp": ne[3]},
                    "edges_computed_per_layer": wk["executed_edges_per_layer"],
                    "parallelism": f"graphs sharded over {world} GPU(s), no data-path collective"},
-        "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved_tf, "peak": PEAK_F32_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_TFLOPS,
-                     "traffic": None, "traffic_source": TRAFFIC_SOURCE,
+        "roofline": {"bound": "mfma", "kernel": dom_name,
+                     # what the launch EXECUTES over its duration comes first; `achieved` / `frac` below are the contract's
+                     # algorithmic figures (SURVEY 8d's per-edge FLOPs x the edges the launch computes)
+                     "frac_executed": (edge_flops_exec / edge_avg_s / 1e12 / PEAK_F32_TFLOPS) if edge_avg_s > 0 else 0.0,
+                     "achieved_executed": (edge_flops_exec / edge_avg_s / 1e12) if edge_avg_s > 0 else 0.0,
+                     "achieved": achieved_tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_TFLOPS,
+                     "traffic": None, "traffic_unit": "bytes per launch", "traffic_detail": pmc_err,
                      "kernel_avg_us": edge_avg_s * 1e6, "launches_timed": edge_n, "flop_per_launch": edge_flops,
                      "executed_flop_per_launch": edge_flops_exec, "hoisted_edges_per_launch": hoisted_edges,
-                     "frac_executed": (edge_flops_exec / edge_avg_s / 1e12 / PEAK_F32_TFLOPS) if edge_avg_s > 0 else 0.0,
-                     "note": "edge-message launches timed by HIP events inside the timed region; FLOP = 136,742 per edge "
-                             "(SURVEY 8d) x edges the launch computes (conv layer 0). Outputs equal the "
-                             "dense reference computation; rows/edges that cannot reach the output are not computed, and the "
-                             "static pp edges of conv layer 0 start at their second message GVP (executed_flop_per_launch; DESIGN 4.1a).",
-                     "whole_step": {"reference_equivalent_flop": flops, "executed_flop": wk["executed_flops"],
-                                    "algorithmic_bytes": bytes_,
-                                    "reference_equivalent_tflops": flops / (dt / K) / 1e12,
-                                    "frac_f32_peak_reference_equivalent": flops / (dt / K) / 1e12 / PEAK_F32_TFLOPS,
-                                    "executed_tflops": wk["executed_flops"] / (dt / K) / 1e12,
-                                    "gbs": bytes_ / (dt / K) / 1e9, "frac_hbm_peak": bytes_ / (dt / K) / 1e9 / PEAK_HBM_GBS}},
+                     "note": "edge-message launches of conv layer 0 timed by HIP events inside the timed region (an event pair adds ~3 us to "
+                             "what it brackets: rocprofv3 durations in profiles/ are that much shorter); algorithmic FLOP = 136,742 per edge "
+                             "(SURVEY 8d) x edges the launch computes; executed FLOP leaves out what the static hoist removes (DESIGN 4.1a: the "
+                             "h_src block of the first scalar Linear and the Vh product of edges whose source is a protein atom). Outputs equal the "
+                             "dense reference computation; rows/edges that cannot reach the output are not computed.",
+                     "whole_step": {"executed_flop": wk["executed_flops"], "executed_tflops": wk["executed_flops"] / (dt / K) / 1e12,
+                                    "frac_f32_peak_executed": wk["executed_flops"] / (dt / K) / 1e12 / PEAK_F32_TFLOPS,
+                                    "dense_reference_flop": flops, "dense_reference_bytes": bytes_,
+                                    "note": "dense_reference_* = what the reference's dense computation of this step would execute / move "
+                                            "(SURVEY 8d formulas): information only -- the kernels do not execute or move it (dead-work "
+                                            "elimination is exact), so no fraction is formed from it"}},
+        "rccl_world": (dist.get_world_size() if (world > 1 and backend == "nccl") else (1 if world == 1 else 0)),
+        "per_rank_ms_per_step": per_rank_ms,
     }
+    if pmc is not None:
+        hits = {k: v for k, v in pmc.items() if dom_match in k}
+        if hits:
+            kname = max(hits, key=lambda k: hits[k]["launches"])
+            d = hits[kname]
+            fetch_b, write_b = 2.0 * d["fetch_kb"] * 1024.0, d["write_kb"] * 1024.0
+            out["roofline"]["traffic"] = fetch_b + write_b
+            out["roofline"]["traffic_detail"] = {
+                "kernel": kname[:120], "launches": d["launches"], "FETCH_SIZE_KB": d["fetch_kb"], "WRITE_SIZE_KB": d["write_kb"],
+                "fetch_bytes_corrected": fetch_b, "write_bytes": write_b,
+                "correction": "FETCH_SIZE (KB) x 2: gfx950 tallies the 128-B requests of 16-B-per-lane reads at 64 B (MI355X_MICROARCH.md, "
+                              "HBM section); WRITE_SIZE (KB) exact; memory-side requests of the L2, Infinity-Cache hits included",
+                "source": "two rocprofv3 --kernel-trace --pmc child passes of this script (--steps 20 --warmup 2), mean per launch",
+                "algorithmic_bytes_per_launch": 736.0 * l0_edges + 704.0 * l0_edges / 3.0,
+                "algorithmic_note": "gathers 736 B per edge (SURVEY 8d) + one 704-B partial message row per (item, destination) run (~1 in 3 edges)",
+                "per_step_all_kernels_bytes": sum((2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0 * v["launches"] for v in pmc.values())
+                                              / max(d["launches"], 1)}
+        else:
+            out["roofline"]["traffic_detail"] = f"no kernel matching {dom_match!r} in the counter output"
+    if secondary is not None:
+        out["secondary"] = secondary
 
     out["roofline"]["launches_timed_in_region"] = in_region
     if not args.no_full_trajectory:
@@ -287,7 +431,9 @@ def main():
             s2, d2 = e2.build_pp_edges(px2, prot_ptr)
             e2.set_batch(px2, ph2, prot_ptr, pharm_ptr, s2, d2)
             return e2
-        out["full_trajectory"] = full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, eng2_factory)
+        coef_bounded = schedule.step_coefficients(schedule.PredefinedNoiseSchedule('polynomial_2', T, 0.25).gamma, T)
+        out["full_trajectory"] = full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, eng2_factory,
+                                                 coef_bounded)
 
     if args.breakdown and rank == 0:
         eng.profile_enable(0x1ff)
@@ -308,7 +454,7 @@ def main():
         dist.destroy_process_group()
 
 
-def full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, eng2_factory=None):
+def full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, eng2_factory=None, coef_bounded=None):
     """SURVEY.md 8(d) row 1 as written: wall time of the WHOLE T-step reverse loop (pharmacodiff.py:466-472 equivalent)
     for the rank's batch -- pf_sample: begin, T steps, final frame, enqueued without a host sync; x_T, h_T ~ N(0, I) at
     the pocket COM, seed-0 weights, noise drawn on the device inside the timed region -- reported as B*T / wall.  With
@@ -330,13 +476,34 @@ def full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_ov
     times.sort()
     dt = times[len(times) // 2]
     wk = eng.work_detail()
+    bounded = None
+    if coef_bounded is not None:
+        # the same reverse process in the regime a trained model lives in: schedule precision 0.25 bounds 1 / alpha_T by 2, the
+        # centers stay inside the pocket at every step and every ff / pf / fp edge exists throughout (the configuration of
+        # tests/golden/traj_c1_T500_bounded.npz, which pins it frame by frame against the reference)
+        arr_b = eng.coef_array(coef_bounded, reversed(range(T)))
+        tb = []
+        for rep in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            xb, hb = eng.sample(arr_b, T, buf.normal_(generator=gen))
+            barrier()
+            if rep:
+                tb.append(max_over_ranks(time.perf_counter() - t0))
+        wkb = eng.work_detail()
+        dtb = min(tb)
+        bounded = {"value": world * B * T / dtb, "unit": "sample-steps/s", "wall_ms": dtb * 1e3, "schedule_precision": 0.25,
+                   "max_abs_coordinate": float(xb.abs().max()), "finite": bool(torch.isfinite(xb).all() and torch.isfinite(hb).all()),
+                   "edges_last_step": dict(zip(("ff", "pf", "fp", "pp"), wkb["edges"])),
+                   "note": "schedule precision 0.25 instead of 1e-5: random-init weights cannot cancel the sampler's 1 / alpha factors, so "
+                           "the bound on the coordinates comes from the schedule; same kernels, same launch policy"}
     lanes = None
     if args.lanes > 1 and world == 1 and eng2_factory is not None:      # informational leg, single-rank runs only; never costs the line
         try:
             lanes = batches_in_flight(args, eng2_factory, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, arr)
         except Exception as e:                                          # (e.g. no memory for the extra handles)
             lanes = {"error": f"{type(e).__name__}: {e}"}
-    return {"lanes": lanes, "value": world * B * T / dt, "unit": "sample-steps/s", "T": T, "wall_ms": dt * 1e3, "ms_per_step": dt / T * 1e3,
+    return {"lanes": lanes, "bounded": bounded, "value": world * B * T / dt, "unit": "sample-steps/s", "T": T, "wall_ms": dt * 1e3, "ms_per_step": dt / T * 1e3,
             "repetitions_ms": [round(t * 1e3, 3) for t in times], "finite": bool(torch.isfinite(x0).all() and torch.isfinite(h0).all()),
             "max_abs_coordinate": float(x0.abs().max()),
             "edges_last_step": dict(zip(("ff", "pf", "fp", "pp"), wk["edges"])),
@@ -408,6 +575,46 @@ def slice_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
         barrier()
         dt = time.perf_counter() - t0
     n = sum(len(o) for o in out)
+    dominant = {}
+    if rank == 0:
+        # the dominant kernel of such a job: conv layer 0's edge-message launch of one full batch (copies of a few pockets, pocket
+        # sharing on), timed by HIP events over 20 steps at the end of the schedule on a batch bound like sample() binds it
+        try:
+            from pharmacoforge_amd import schedule
+            eng = m.dynamics.engine()
+            per = max(args.max_batch_size // S, 1)
+            copies = [c for k in range(per) for c in pfa.copy_graph(pockets[k], S, pharm_feats_per_copy=torch.tensor(sizes))][:args.max_batch_size]
+            gb = pfa.batch(copies)
+            eng.set_batch(gb.prot_x, gb.prot_h, gb.prot_ptr, gb.pharm_ptr, gb.pp_src, gb.pp_dst, pocket_uid=gb.pocket_uid)
+            coef = schedule.step_coefficients(schedule.PredefinedNoiseSchedule('polynomial_2', T, 1e-5).gamma, T)
+            nst = 25
+            carr = eng.coef_array(coef, list(range(nst - 1, -1, -1)))
+            eng.prepare_timesteps(carr, nst)
+            Nfb = int(gb.pharm_ptr[-1])
+            nz = torch.randn(nst + 1, Nfb, 9, device=dev)
+            eng.sample_begin(nz[0])
+            for i in range(nst):
+                eng.profile_enable(((1 << 2) | (1 << 6)) if i >= 5 else 0)
+                eng.denoise_step(carr[i], nz[i + 1])
+            torch.cuda.synchronize()
+            prof = eng.profile_read()
+            eng.profile_enable(0)
+            key = "edge_msg" if prof["edge_msg"][1] > 0 else "edge_msg_coop"
+            ms, cnt = prof[key]
+            wk = eng.work_detail()
+            l0 = wk["executed_edges_per_layer"][0]
+            ne = wk["edges"]
+            fam, hoist = eng.kernel_family(0), eng.l0_hoist()
+            avg = ms / max(cnt, 1) * 1e-3
+            hoisted = max(l0 - (ne[0] + ne[1] + ne[2]), 0) if hoist else 0
+            fl = FLOP_PER_EDGE * l0
+            fl_ex = fl - ((32768.0 + 1632.0) * (hoisted + ne[1]) if hoist == 16 else (48678.0 - 4096.0) * hoisted)
+            dominant = {"dominant_kernel": ("k_n16_edge<true>" if fam == 16 else f"k_rg_edge<true, {fam // 4}, ., {hoist // 4}>") + " (conv layer 0, pocket sharing)",
+                        "kernel_avg_us": avg * 1e6, "batch_graphs": gb.batch_size, "edges_computed": l0,
+                        "frac_executed": fl_ex / avg / 1e12 / PEAK_F32_TFLOPS if avg > 0 else 0.0,
+                        "frac": fl / avg / 1e12 / PEAK_F32_TFLOPS if avg > 0 else 0.0}
+        except Exception as e:                       # informational: never costs the line
+            dominant = {"dominant_kernel": None, "error": f"{type(e).__name__}: {e}"}
     tt = torch.tensor([dt, float(n)], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -422,7 +629,8 @@ def slice_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
                                    f"pockets, T={T}, max_batch_size {args.max_batch_size}, dev.yml network",
                        "pockets": P * world, "pharmacophores": n, "wall_s": dt, "ms_per_pocket": dt / max(P, 1) * 1e3,
                        "batches_in_flight": "auto (2; 4 for batches of <= 32 graphs)" if m.sample_lanes is None else m.sample_lanes,
-                       "parallelism": f"batches dealt over {world} GPU(s) by work, no data-path collective"}}))
+                       "parallelism": f"batches dealt over {world} GPU(s) by work, no data-path collective"},
+            "dominant": dominant}))
 
 
 def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
@@ -523,7 +731,7 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
                        "distinct_batches": len(graphs),
                        "parallelism": f"data parallel over {world} GPU(s): one all-reduce of the flat gradient per step"},
             "roofline": {"bound": "mfma", "kernel": "k_bwd_edge_level (all levels of a step)", "achieved": ach, "peak": PEAK_F32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS, "traffic": None, "traffic_source": TRAFFIC_SOURCE,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS, "traffic": None, "traffic_detail": "profiles/r03/train_pmc_hbm.csv (rocprofv3 --pmc passes of this command)",
                          "kernel_avg_us": lvl_ms / max(lvl_n, 1) * 1e3, "launches_timed": lvl_n, "launches_per_step": launches_per_step,
                          "edge_backward_ms_per_step": lvl_s_per_step * 1e3, "flop_per_step": bwd_flop_per_step,
                          "edges_computed_per_layer": wk["executed_edges_per_layer"],
