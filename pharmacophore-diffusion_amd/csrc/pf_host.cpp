@@ -93,7 +93,81 @@ static void linspace_f32(float start, float end, int steps, float* out) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------------
+// Launch policy of the inference path: which kernel form a launch takes.  One place, one table.
+//
+// The chip: 256 compute units (CUs) = 1,024 SIMDs.  A launch is in the LATENCY regime while it has about as many items
+// as the chip has places to put them (its duration is one item's chain of dependent GVPs), in the THROUGHPUT regime beyond.
+// Sizes below are EDGE SLOTS (or node rows) of the launch's work list = 32 x its tiles: capacities, known on the host
+// (the dynamic edge counts are not; at 256-atom pockets with kNN pf edges about a third of the slots hold an edge).
+//
+//   launch                        | size (slots / rows)        | form
+//   ------------------------------+----------------------------+---------------------------------------------------------
+//   edge messages, any conv layer | batch <= n16_rows_max      | n16: 16-row items on the four waves of a workgroup
+//                                 |   (24,000 ~ 2 busy items   |   (pf_n16.hip; conv layer 0 needs the static hoist's type
+//                                 |   per CU)                  |   tables, else the row-group form)
+//   edge messages                 | < rg2_rows_min (12,000 ~   | row-group, 4 rows per wave (pf_rg.hip); four-wave workgroups
+//                                 |   3 four-row items / SIMD) |   up to RG_QUAD_MAX item slots (fixed SIMD placement)
+//                                 | >= rg2_rows_min            | row-group, 8 rows per wave
+//     conv layer 0 under the      | >= rg2p_rows_min (11,000)  |   hoisted (two-block) items 8 rows, full-chain items 4
+//     static hoist (compact list) | >= rg2_rows_min_hoist      |   all items 8 rows
+//                                 |   (30,000)                 |
+//   node update                   | < rg2_rows_min_node        | row-group, 4 rows per wave; on TWO waves per item while the
+//                                 |                            |   launch has <= rg_split_max_node (256) items: fewer items than CUs
+//                                 | >= rg2_rows_min_node       | row-group, 8 rows per wave
+//   last layer's nodes + head     | <= rg_split_max_head (512) | row-group, 4 rows on two waves (a 6-7 block chain: the longest of a step)
+//   everything, row-group off     | rows > rg_rows_max         | 32-row tile kernels (pf_kernels.hip): four waves per tile up to
+//   (training forward of dense    |                            |   coop_edge_max / coop_node_max tiles, two workgroups per CU up to
+//   layers; PFDYN_RG_ROWS_MAX=0)  |                            |   coop2_*_max, one wave per tile beyond
+//
+// Every threshold can be overridden from the environment (tests force every form onto the goldens; sweeps: tools/):
+//   PFDYN_N16 (bit 0: conv layers >= 1, bit 1: conv layer 0; default 3), PFDYN_N16_ROWS_MAX, PFDYN_RG_ROWS_MAX,
+//   PFDYN_RG2_ROWS_MIN (sets all four 8-row thresholds) / _NODE / _HOIST, PFDYN_RG2P_ROWS_MIN, PFDYN_L0_RGA / PFDYN_L0_RGP (rows-per-
+//   wave factor of the full-chain / hoisted items of a compact layer-0 launch), PFDYN_RG_SPLIT_MAX (all three) / _NODE / _HEAD,
+//   PFDYN_COOP_EDGE_MAX, PFDYN_COOP2_EDGE_MAX, PFDYN_COOP_NODE_MAX.  Forcing a row-group form switches the n16 form off
+//   unless PFDYN_N16 is given.  Feature switches (not thresholds) are read in pf_handle::init_tuning.
+// ------------------------------------------------------------------------------------------------------------------
+struct LaunchPolicy {
+    static constexpr int kCUs = 256, kSIMDs = 4 * kCUs;
+    int n16_mask = 3;
+    long n16_rows_max = 24000;              // measured at 256-atom pockets (575 slots per graph): +5 % at 16 graphs, +10 % at 32, -3..-5 % at 64, -15 % at 256
+    int rg_rows_max = 1 << 30;
+    int rg2_rows_min = 12000;               // ~3 four-row items per SIMD (3 x 4 x kSIMDs = 12,288)
+    int rg2_rows_min_node = 12000;
+    int rg2p_rows_min = 11000;              // mixed 4 / 8 rows: +5 % at 24 graphs, +2 % at 32, +7 % at 40, +11 % at 48 over all-4-rows (round 2 sweep)
+    int rg2_rows_min_hoist = 30000;         // all-8-rows: +10 % at 56-64 graphs
+    int l0_rga = 0, l0_rgp = 0;             // 0: by the thresholds above
+    int rg_split_max = 128;                 // edge launches: two waves per 4-row item up to this many items (kCUs / 2)
+    int rg_split_max_node = 256;            // = kCUs
+    int rg_split_max_head = 512;            // = 2 kCUs: +2-3 % at 144-384 items
+    int coop_edge_max = 256, coop_node_max = 1024;       // tile kernels: one tile per CU / per SIMD
+    int coop2_edge_max = 12000, coop2_dense_max = 1024;
+    // 0: tile kernels; 1 / 2: row-group kernels with 4 / 8 rows per wave
+    int rg_mode(int ntiles) const {
+        const long rows = (long)ntiles * 32;
+        if (rows > rg_rows_max) return 0;
+        return rows >= rg2_rows_min ? 2 : 1;
+    }
+    void from_env() {
+        auto geti = [](const char* v, int& x) { if (const char* e = getenv(v)) x = atoi(e); };
+        geti("PFDYN_COOP_EDGE_MAX", coop_edge_max); geti("PFDYN_COOP_NODE_MAX", coop_node_max);
+        if (const char* e = getenv("PFDYN_COOP2_EDGE_MAX")) coop2_edge_max = coop2_dense_max = atoi(e);
+        if (const char* e = getenv("PFDYN_RG_SPLIT_MAX")) rg_split_max = rg_split_max_node = rg_split_max_head = atoi(e);
+        geti("PFDYN_RG_SPLIT_MAX_NODE", rg_split_max_node); geti("PFDYN_RG_SPLIT_MAX_HEAD", rg_split_max_head);
+        geti("PFDYN_RG_ROWS_MAX", rg_rows_max);
+        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = rg2_rows_min_hoist = rg2p_rows_min = rg2_rows_min_node = atoi(e);
+        geti("PFDYN_RG2P_ROWS_MIN", rg2p_rows_min); geti("PFDYN_RG2_ROWS_MIN_NODE", rg2_rows_min_node); geti("PFDYN_RG2_ROWS_MIN_HOIST", rg2_rows_min_hoist);
+        geti("PFDYN_L0_RGP", l0_rgp); geti("PFDYN_L0_RGA", l0_rga);
+        for (const char* v : {"PFDYN_RG2_ROWS_MIN", "PFDYN_RG2P_ROWS_MIN", "PFDYN_RG2_ROWS_MIN_HOIST", "PFDYN_RG_SPLIT_MAX", "PFDYN_L0_RGA",
+                              "PFDYN_L0_RGP", "PFDYN_RG_ROWS_MAX"})
+            if (getenv(v)) n16_mask = 0;
+        geti("PFDYN_N16", n16_mask);
+        if (const char* e = getenv("PFDYN_N16_ROWS_MAX")) n16_rows_max = atol(e);
+    }
+};
+
 struct pf_handle {
+    LaunchPolicy pol;
     pf_config cfg{};
     std::string err;
     std::map<std::string, RawTensor> raw;
@@ -182,18 +256,8 @@ struct pf_handle {
     int max_np = 0;                         // largest pocket of the batch
     bool edges_built = false;               // the dynamic edges of the current coordinates exist (built by k_step_build)
     bool edges_share = false;               // ... in the pocket-sharing form (no pa copies)
-    // launches with at most this many tiles use the 4-wave cooperative kernels (latency-bound regime)
-    // Edge-message launches: up to coop_edge_max tiles (one per CU) the 4-wave kernel with next-GVP weight prefetch;
-    // up to coop2_edge_max (pruned / last-layer tile lists) or coop2_dense_max (dense layers, where the one-wave kernel
-    // has the per-source precompute) the same kernel without the prefetch at two workgroups per CU; beyond that one wave
-    // per tile.  Measured (config 3 pockets): batch 64 / 128 / 256 = 318 k / 526-560 k / 755 k sample-steps/s with the
-    // two-workgroup kernel against 236 k / 456 k / 692 k with one wave per tile; batch 1024 prefers one wave per tile.
-    int coop_edge_max = 256, coop_node_max = 1024;
-    int coop2_edge_max = 12000, coop2_dense_max = 1024;
     // row-group kernels (pf_rg.hip): quad streams of the message chains [layer][etype] and update chains [layer][ntype]
-    // (offsets into d_w).  Inference launches use them up to rg_rows_max rows (edge slots of the tile list): 4 rows per
-    // wave below rg2_rows_min slots (launches with fewer groups than SIMDs are latency-bound), 8 above; they beat the
-    // 32-row tile kernels at every batch size measured (32-1024); those remain for training and PFDYN_RG_ROWS_MAX=0
+    // (offsets into d_w); which form a launch takes: LaunchPolicy above
     std::vector<size_t> rg_msg, rg_upd;
     std::vector<size_t> rgs_msg, rgs_upd, rgs_upd_stride;   // two-wave form: wave 0's stream; wave 1's follows *_stride floats later
     size_t rgs_msg_stride = 0;
@@ -204,40 +268,11 @@ struct pf_handle {
     // conv layer 0's message chains in their own forms: protein sources (pf, pp) start from a type-table row (M0H),
     // centers (ff, fp) have zero node vectors (M0Z)
     size_t n16_l0[4] = {0, 0, 0, 0}, n16_l0_stride[4] = {0, 0, 0, 0};
-    // which launches of the inference path take the n16 form (PFDYN_N16, bit mask): 1 edge launches of conv layers >= 1, 2 the edge launch of conv layer 0 (needs the static hoist's type tables)
-    int n16_mask = 3;
-    // ... up to this many edge slots in the batch's pruned conv-layer launch (PFDYN_N16_ROWS_MAX).  Measured at 256-atom
-    // pockets (575 slots per graph): +5 % at 16 graphs, +10 % at 32, -3..-5 % at 64 and -15 % at 256 against the row-group
-    // kernels: the n16 form wins while a launch has at most ~2 items per compute unit (its items are a CU wide)
-    long n16_rows_max = 24000;
-    // launches with at most this many 4-row groups run each group on TWO waves (pf_rg.hip: SPLIT): pays off while the
-    // groups are far fewer than the CUs (config 2: node + head launch 19.0 -> 15.8 us; neutral at ~500 groups)
-    int rg_split_max = 128;
-    int rg_split_max_node = 256;            // node launches: the two-wave form up to this many groups (PFDYN_RG_SPLIT_MAX_NODE)
-    int rg_split_max_head = 512;            // ... the fused last-layer node + noise-head launch, a 6-7 block chain (PFDYN_RG_SPLIT_MAX_HEAD)
     std::vector<int> last_family;           // per conv layer: pf_debug_kernel_family
     int last_hoist = 0;                     // pf_debug_l0_hoist
-    int rg_rows_max = 1 << 30, rg2_rows_min = 12000;
-    // compact pruned layer-0 launch under the static hoist: more than half of its items run a two-block chain, so 4 rows
-    // per wave stay ahead up to a larger launch (config 2, 18.4 k slots: 437 k -> 444 k sample-steps/s; batch 64, 36.8 k slots: 701 k -> 714 k; batch 128 prefers 8)
-    // compact pruned layer-0 launch under the hoist (slots = 32 x tiles of the launch; 256-atom pockets: ~560 per graph): from
-    // rg2p_rows_min slots the hoisted (two-block) items take 8 rows per wave, from rg2_rows_min_hoist the full-chain items too.
-    // Swept late in round 2 at batches of 8-256: all-4-rows wins up to 16 graphs, the mixed form by 3-8 % at 24-48, all-8-rows by
-    // 10 % at 64 and above (48,000 / no mixed form before)
-    int rg2_rows_min_hoist = 30000;
-    int rg2p_rows_min = 11000;
-    int rg2_rows_min_node = 12000;         // node launches: 8 rows per wave from this many rows of their tile list (PFDYN_RG2_ROWS_MIN_NODE)
-    // 0: tile kernels; 1 / 2: row-group kernels with 4 / 8 rows per wave
-    int rg_mode(int ntiles) const {
-        const long rows = (long)ntiles * 32;
-        if (rows > rg_rows_max) return 0;
-        return rows >= rg2_rows_min ? 2 : 1;
-    }
     // ---- static hoist of conv layer 0's pp messages (pf_rg.hip, EdgeParams::zs).  Everything derived from the weights
     // carries the version of the weights it was computed from (commit / pf_set_flat_params bump w_version).
     bool l0_hoist = true;                   // PFDYN_NO_L0_HOIST=1: off
-    int l0_rgp = 0;                         // PFDYN_L0_RGP: rows-per-wave factor of the hoisted items (0: policy)
-    int l0_rga = 0;                         // PFDYN_L0_RGA: ... of the other items of a compact pruned layer-0 launch (0: policy)
     size_t l0h_off = 0;                     // L0H_* block in d_w
     uint64_t w_version = 1, zs_version = 0, ptab_version = 0;
     bool l0_onehot = false;                 // every protein feature row of the batch is an element one-hot
@@ -253,37 +288,19 @@ struct pf_handle {
     bool rg_compact = true;                 // PFDYN_NO_COMPACT=1: row-group edge launches walk the tile lists
     bool fuse_head = true;                  // last conv layer's node update + noise head in one launch (PFDYN_NO_FUSE_HEAD=1: separate)
     void init_tuning() {
-        if (const char* e = getenv("PFDYN_COOP2_EDGE_MAX")) coop2_edge_max = coop2_dense_max = atoi(e);
-        if (const char* e = getenv("PFDYN_COOP_EDGE_MAX")) coop_edge_max = atoi(e);
-        if (const char* e = getenv("PFDYN_COOP_NODE_MAX")) coop_node_max = atoi(e);
         if (const char* e = getenv("PFDYN_NO_PRE")) use_pre = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_FUSE_HEAD")) fuse_head = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_PRUNE")) prune = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_ENC_FLY")) enc_on_the_fly = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_COMPACT")) rg_compact = atoi(e) == 0;
-        if (const char* e = getenv("PFDYN_RG_SPLIT_MAX")) rg_split_max = rg_split_max_node = rg_split_max_head = atoi(e);
-        if (const char* e = getenv("PFDYN_RG_SPLIT_MAX_NODE")) rg_split_max_node = atoi(e);
-        if (const char* e = getenv("PFDYN_RG_SPLIT_MAX_HEAD")) rg_split_max_head = atoi(e);
         if (const char* e = getenv("PFDYN_NO_FAST_BUILD")) step_build_fast = atoi(e) == 0;
-        if (const char* e = getenv("PFDYN_RG_ROWS_MAX")) rg_rows_max = atoi(e);
-        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN")) rg2_rows_min = rg2_rows_min_hoist = rg2p_rows_min = rg2_rows_min_node = atoi(e);
-        if (const char* e = getenv("PFDYN_RG2P_ROWS_MIN")) rg2p_rows_min = atoi(e);
-        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN_NODE")) rg2_rows_min_node = atoi(e);
-        if (const char* e = getenv("PFDYN_RG2_ROWS_MIN_HOIST")) rg2_rows_min_hoist = atoi(e);
         if (const char* e = getenv("PFDYN_NO_L0_HOIST")) l0_hoist = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_POCKET_SHARE")) share_disable = atoi(e) != 0;
         if (const char* e = getenv("PFDYN_TRAIN_TILE_NODE")) train_rg_node = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_TRAIN_TILE_EDGE")) train_rg_edge = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_TRAIN_TILE_HEAD")) train_rg_head = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_TRAIN_NODE_RECOMPUTE")) train_node_save = atoi(e) == 0;
-        if (const char* e = getenv("PFDYN_L0_RGP")) l0_rgp = atoi(e);
-        if (const char* e = getenv("PFDYN_L0_RGA")) l0_rga = atoi(e);
-        // forcing a row-group form (tests, sweeps) switches the n16 form off unless PFDYN_N16 says otherwise
-        for (const char* v : {"PFDYN_RG2_ROWS_MIN", "PFDYN_RG2P_ROWS_MIN", "PFDYN_RG2_ROWS_MIN_HOIST", "PFDYN_RG_SPLIT_MAX", "PFDYN_L0_RGA",
-                              "PFDYN_L0_RGP", "PFDYN_RG_ROWS_MAX"})
-            if (getenv(v)) n16_mask = 0;
-        if (const char* e = getenv("PFDYN_N16")) n16_mask = atoi(e);
-        if (const char* e = getenv("PFDYN_N16_ROWS_MAX")) n16_rows_max = atol(e);
+        pol.from_env();
     }
 
     // ---- gradient path (pf_train_*): flat parameter vector in state-dict order, GvpT tables, per-layer activations
@@ -769,7 +786,7 @@ static bool encoders_on_the_fly(const pf_handle* h) {
     const pf_config& c = h->cfg;
     const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;
     const int nt0 = c.n_convs == 1 ? h->n_edge_tiles_last : (prune_layer == 0 ? h->n_edge_tiles_act : h->n_edge_tiles);
-    return h->enc_on_the_fly && h->rg_mode(nt0) != 0;
+    return h->enc_on_the_fly && h->pol.rg_mode(nt0) != 0;
 }
 
 // ---- static hoist of conv layer 0 (pf_rg.hip: EdgeParams::zs) ----------------------------------------------------
@@ -881,8 +898,8 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     const float* l0_ptab = nullptr;
     int l0_gstride = 0;
     // the n16 form serves the latency regime: batches whose pruned conv-layer launch has few items per compute unit
-    const bool n16_batch = (long)(prune_layer >= 0 ? h->n_edge_tiles_act : h->n_edge_tiles) * 32 <= h->n16_rows_max && !h->n16_msg.empty();
-    const bool n16_l0 = hoist && (h->n16_mask & 2) && n16_batch;      // layer 0 on the n16 kernels: no zs
+    const bool n16_batch = (long)(prune_layer >= 0 ? h->n_edge_tiles_act : h->n_edge_tiles) * 32 <= h->pol.n16_rows_max && !h->n16_msg.empty();
+    const bool n16_l0 = hoist && (h->pol.n16_mask & 2) && n16_batch;      // layer 0 on the n16 kernels: no zs
     if (hoist) {
         if (!n16_l0) l0_ensure_static(h, s);
         if (t_scalar) {
@@ -933,8 +950,8 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             if (shared) { e.need = h->d_need; e.need_stamp = h->edges_stamp; }
             for (int r = 0; r < e.nreg; ++r) { e.ngroups4 += region_groups(r, 4); e.ngroups8 += region_groups(r, 8); }
         }
-        int rg = train ? ((h->train_rg_edge && h->train_rg_node) ? h->rg_mode(e.ntiles) : 0)
-                       : h->rg_mode(shared ? (int)((h->share_rows + 31) / 32) : e.ntiles);           // the node launch of this layer follows (partial-row grouping)
+        int rg = train ? ((h->train_rg_edge && h->train_rg_node) ? h->pol.rg_mode(e.ntiles) : 0)
+                       : h->pol.rg_mode(shared ? (int)((h->share_rows + 31) / 32) : e.ntiles);           // the node launch of this layer follows (partial-row grouping)
         // static hoist: the hoisted ("pa") items of a compact layer-0 launch run a two-block chain and may take 8 rows
         // per wave while the full-chain items (ff, pf, fp) take 4
         int rgp = 0;
@@ -947,11 +964,11 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 // like the dynamic regions do -- the general threshold applies; measured at 4-5 pockets x 30 copies:
                 // 1.21 M sample-steps/s end to end at 4 rows per wave, 1.26 M at 8)
                 // (one pocket x 128 copies: few shared rows, but 128 graphs' worth of ff / pf / fp items -- 8 rows per wave is 8 % ahead)
-                rg = shared ? ((h->share_rows >= h->rg2_rows_min || (long)e.ntiles * 32 >= h->rg2_rows_min_hoist) ? 2 : 1)
-                            : ((long)e.ntiles * 32 >= h->rg2_rows_min_hoist ? 2 : 1);
-                const int rgp_pol = shared ? rg : ((long)e.ntiles * 32 >= h->rg2p_rows_min ? 2 : 1);
-                if (h->l0_rga) rg = h->l0_rga;
-                rgp = h->l0_rgp ? h->l0_rgp : std::max(rg, rgp_pol);
+                rg = shared ? ((h->share_rows >= h->pol.rg2_rows_min || (long)e.ntiles * 32 >= h->pol.rg2_rows_min_hoist) ? 2 : 1)
+                            : ((long)e.ntiles * 32 >= h->pol.rg2_rows_min_hoist ? 2 : 1);
+                const int rgp_pol = shared ? rg : ((long)e.ntiles * 32 >= h->pol.rg2p_rows_min ? 2 : 1);
+                if (h->pol.l0_rga) rg = h->pol.l0_rga;
+                rgp = h->pol.l0_rgp ? h->pol.l0_rgp : std::max(rg, rgp_pol);
                 if (rg == 2) rgp = 2;
                 for (int r = 0; r < e.nreg; ++r) e.ngroups_sel += region_groups(r, 4 * (r >= 3 * h->B ? rgp : rg));
             }
@@ -959,7 +976,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         }
         // n16 form (pf_n16.hip): 16-row items on four waves.  Conv layers >= 1 read h / v of the sources from memory; conv
         // layer 0 needs the static hoist's type tables (protein sources) and encodes the centers on the fly
-        const bool n16e = !train && rg && n16_batch && (l > 0 ? (h->n16_mask & 1) != 0 : n16_l0);
+        const bool n16e = !train && rg && n16_batch && (l > 0 ? (h->pol.n16_mask & 1) != 0 : n16_l0);
         if (n16e) {
             for (int et = 0; et < 4; ++et) {
                 e.n16[et] = h->d_w + (l > 0 ? h->n16_msg[(size_t)l * 4 + et] : h->n16_l0[et]);
@@ -972,14 +989,14 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             rg = 4;                                  // 16 slots per partial-row group
         }
         h->last_family.resize(c.n_convs);
-        h->last_family[l] = rg ? 4 * rg : ((!train && e.ntiles <= ((last || pruned) ? std::max(h->coop_edge_max, h->coop2_edge_max) : std::max(h->coop_edge_max, h->coop2_dense_max))) ? 128 : 32);
+        h->last_family[l] = rg ? 4 * rg : ((!train && e.ntiles <= ((last || pruned) ? std::max(h->pol.coop_edge_max, h->pol.coop2_edge_max) : std::max(h->pol.coop_edge_max, h->pol.coop2_dense_max))) ? 128 : 32);
         for (int et = 0; et < 4; ++et) e.rgs[et] = h->d_w + h->rgs_msg[(size_t)l * 4 + et];
         e.rgs_stride = (int)h->rgs_msg_stride;
-        const int esplit = (rg == 1 && e.ntiles * 8 <= h->rg_split_max && !e.zs) ? 1 : 0;    // fewer groups than SIMDs: latency-bound
+        const int esplit = (rg == 1 && e.ntiles * 8 <= h->pol.rg_split_max && !e.zs) ? 1 : 0;    // fewer groups than SIMDs: latency-bound
         if (n16e) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_n16_edge(&e, &ep, l == 0, s); }
         else if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, esplit, rgp, s); }
-        else if (e.ntiles <= h->coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
-        else if (e.ntiles <= ((last || pruned) ? h->coop2_edge_max : h->coop2_dense_max) && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop2(&e, l == 0, s); }
+        else if (e.ntiles <= h->pol.coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
+        else if (e.ntiles <= ((last || pruned) ? h->pol.coop2_edge_max : h->pol.coop2_dense_max) && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop2(&e, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_EDGE, s); pfk_edge_msg(&e, l == 0, s); }
 
         NodeParams n{};
@@ -1012,9 +1029,9 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             n.rgs_stride[nt] = (int)h->rgs_upd_stride[(size_t)l * 2 + nt];
         }
         if (rg) {
-            const int rgn = (long)n.ntiles * 32 >= h->rg2_rows_min_node ? 2 : 1;
+            const int rgn = (long)n.ntiles * 32 >= h->pol.rg2_rows_min_node ? 2 : 1;
             const bool fuse = last && !train && h->fuse_head && h->n_head_tiles == n.ntiles;
-            const int nsplit = (!train && rgn == 1 && n.ntiles * 8 <= (fuse ? h->rg_split_max_head : h->rg_split_max_node)) ? 1 : 0;
+            const int nsplit = (!train && rgn == 1 && n.ntiles * 8 <= (fuse ? h->pol.rg_split_max_head : h->pol.rg_split_max_node)) ? 1 : 0;
             if (fuse) {
                 HeadParams hp{};
                 hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
@@ -1031,7 +1048,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_rg_node(&n, nullptr, enc_fly ? &ep : nullptr, l == 0, rgn, nsplit, s);
             }
         }
-        else if (last && !train && h->fuse_head && n.ntiles <= h->coop_node_max && h->n_head_tiles == n.ntiles) {
+        else if (last && !train && h->fuse_head && n.ntiles <= h->pol.coop_node_max && h->n_head_tiles == n.ntiles) {
             // last layer (pharm tiles only) + noise head in one launch: the layer output stays in registers
             HeadParams hp{};
             hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
@@ -1041,7 +1058,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_node_head_coop(&n, &hp, l == 0, s); }
             head_done = true;
         }
-        else if (train && h->train_rg_node && h->rg_mode(n.ntiles) > 0) {
+        else if (train && h->train_rg_node && h->pol.rg_mode(n.ntiles) > 0) {
             // training forward: the row-group node kernel (with the two GVPDropout sites) on the tile edge kernels' partial rows
             // (one per 32-slot tile and destination: grp = 32); the layer input comes from memory, as the backward kernels read it
             n.grp = 32; n.grp_pa = 32;
@@ -1050,9 +1067,9 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 h->t_node_saved[l] = 1;
             }
             ProfScope ps(h, pf_handle::K_NODE_COOP, s);
-            pfk_rg_node(&n, nullptr, nullptr, l == 0, h->rg_mode(n.ntiles), 0, s);
+            pfk_rg_node(&n, nullptr, nullptr, l == 0, h->pol.rg_mode(n.ntiles), 0, s);
         }
-        else if (n.ntiles <= h->coop_node_max && !train) { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_node_update_coop(&n, l == 0, s); }
+        else if (n.ntiles <= h->pol.coop_node_max && !train) { ProfScope ps(h, pf_handle::K_NODE_COOP, s); pfk_node_update_coop(&n, l == 0, s); }
         else { ProfScope ps(h, pf_handle::K_NODE, s); pfk_node_update(&n, l == 0, s); }
         cur ^= 1;
     }
@@ -1075,7 +1092,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         h->t_head_saved = true;
         head_done = true;
     }
-    if (!head_done) { ProfScope ps(h, pf_handle::K_HEAD, s); if (hp.ntiles <= h->coop_node_max) pfk_noise_head_coop(&hp, s); else pfk_noise_head(&hp, s); }
+    if (!head_done) { ProfScope ps(h, pf_handle::K_HEAD, s); if (hp.ntiles <= h->pol.coop_node_max) pfk_noise_head_coop(&hp, s); else pfk_noise_head(&hp, s); }
     h->edges_built = false;                 // whoever moves the coordinates next decides (pf_denoise_step rebuilds)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -2118,9 +2135,9 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
     e.rbf_inv_sigma = 1.0f / (c.rbf_dmax / (float)c.rbf_dim);
     for (int et = 0; et < 4; ++et) e.rg[et] = h->d_w + h->rg_msg[(size_t)layer * 4 + et];
-    const int rg = h->rg_mode(e.ntiles);                  // same choice as run_dynamics
+    const int rg = h->pol.rg_mode(e.ntiles);                  // same choice as run_dynamics
     if (rg) pfk_rg_edge(&e, nullptr, 0, rg, 0, 0, s);
-    else if (e.ntiles <= h->coop_edge_max) pfk_edge_msg_coop(&e, 0, s); else pfk_edge_msg(&e, 0, s);
+    else if (e.ntiles <= h->pol.coop_edge_max) pfk_edge_msg_coop(&e, 0, s); else pfk_edge_msg(&e, 0, s);
     NodeParams n{};
     n.tiles = h->d_node_tiles; n.ntiles = h->n_node_tiles; n.in_start = h->d_in_start; n.in_cnt = h->d_in_cnt; n.N = h->N;
     n.pp_slot = 1; n.row_ids = h->d_act_ids; n.dyn_cnt = h->d_dyn_cnt;
@@ -2135,8 +2152,8 @@ int pf_debug_conv_layer(pf_handle* h, int32_t layer, const float* dev_prot_x, co
     n.grp = rg ? 4 * rg : 32;
     n.grp_pa = n.grp;
     for (int nt = 0; nt < 2; ++nt) n.rg_upd[nt] = h->d_w + h->rg_upd[(size_t)layer * 2 + nt];
-    if (rg) pfk_rg_node(&n, nullptr, nullptr, 0, std::max(1, h->rg_mode(n.ntiles)), 0, s);
-    else if (n.ntiles <= h->coop_node_max) pfk_node_update_coop(&n, 0, s); else pfk_node_update(&n, 0, s);
+    if (rg) pfk_rg_node(&n, nullptr, nullptr, 0, std::max(1, h->pol.rg_mode(n.ntiles)), 0, s);
+    else if (n.ntiles <= h->pol.coop_node_max) pfk_node_update_coop(&n, 0, s); else pfk_node_update(&n, 0, s);
     pfk_copy(h->d_h[1], ohp, Np * PF_S, s);
     pfk_copy(h->d_h[1] + Np * PF_S, ohf, Nf * PF_S, s);
     pfk_copy(h->d_v[1], ovp, Np * 48, s);
