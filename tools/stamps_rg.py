@@ -39,6 +39,8 @@ for i in range(30):
     eng.denoise_step(carr[i], noise[i + 1])
 torch.cuda.synchronize()
 names = {0: "k_rg_edge (conv layer 0)", 1: "k_rg_node (conv layer 0)", 2: "k_rg_edge (last layer)", 3: "k_rg_node + head (last layer)"}
+if os.environ.get("PFDYN_N16", "3") != "0":          # the edge launches run on the n16 kernels (tools/n16_stamps.py): only the node launches are row-group launches
+    names = {0: "k_rg_node (conv layer 0)", 1: "k_rg_node + head (last layer)", 2: "-", 3: "-"}
 if hasattr(lib, "pfk_build_set_stamp_buffer"):
     bb = torch.zeros(B * 32, dtype=torch.int64, device=dev)
     lib.pfk_build_set_stamp_buffer.argtypes = [ctypes.c_void_p]
