@@ -210,8 +210,9 @@ struct EdgeParams {
 #define L0H_B_PF 37504     // [128]             ... its bias
 #define L0H_SIZE (37504 + 128)
 // type tables of one timestep (k_l0_ptab): L0_NTAB tables of [rec_nf][128]: 0 pp without bias (row-group kernels: the bias
-// sits in zs), 1 pp with bias, 2 pf with bias (n16 kernels)
-#define L0_NTAB 3
+// sits in zs), 1 pp with bias, 2 pf with bias (n16 kernels), 3 the protein encoder's output itself (the residual input of
+// conv layer 0's node update: n16 fused launch)
+#define L0_NTAB 4
 struct L0HoistParams {
     const float* src;      // the block above
     float* l0c;            // out: [16 weff][16 gate bias]
@@ -283,6 +284,24 @@ struct NodeParams {
     // vectors, indexed by the row's position in the tile lists (+ N for the active-atom lists): k_bwd_node reads them instead of
     // recomputing the chain.  NULL: not saved
     float* sv_z; float* sv_g; float* sv_v; size_t sv_stride;
+};
+
+// n16 fused launch (pf_n16.hip: k_n16_fused): the LAST conv layer's edge messages with conv layer 0's node update of every
+// item's SOURCE rows computed in front of the item's message chain -- the node launch of conv layer 0 disappears (n_convs = 2,
+// receptive-field pruning, kNN pf edges: the sources of the last layer's edges are exactly the rows that launch updates).
+struct FusedParams {
+    // conv layer 0's messages and where a node finds them (NodeParams of that layer)
+    const int* in_start; const int* in_cnt; int N, pp_slot;
+    const float* msg_s; const float* msg_v; int zero_row, grp, grp_pa;
+    const int* gid; const float* gnorm; int B, norm_mode; float norm_value;
+    pf_gcf ln1_w[2], ln1_b[2], ln2_w[2], ln2_b[2];   // [node type]: message / update layer norms of conv layer 0
+    int n_upd;
+    pf_gcf chain[4]; int chain_stride[4];            // per etype (ff, pf): [update chain of the source type][message chain], wave 0's stream
+    pf_gcf upd_pharm; int upd_pharm_stride;          // the centers' update chain alone (store items)
+    const float* htab; int htab_gstride;             // protein encoder output per element type (table 3 of the timestep's slot)
+    const int* ptype;
+    float* h_out; float* v_out;                      // conv layer 1's input state: written for the centers (the node + head launch reads it)
+    const int* pharm_ptr; int Np, n_edge_items;      // store items: graph g's centers; items [0, n_edge_items) are edge items
 };
 
 struct HeadParams {

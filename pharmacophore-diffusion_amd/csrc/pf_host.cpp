@@ -35,6 +35,7 @@ void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* 
 void pfk_rg_unit(const UnitParams* p, hipStream_t s);
 void pfk_n16_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, hipStream_t s);
 void pfk_n16_unit(const UnitParams* p, hipStream_t s);
+void pfk_n16_fused(const EdgeParams* p, const FusedParams* f, const EncodeParams* enc, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
 void pfk_encode_build_pre(const EncodeParams* e, const BuildParams* b, const PreParams* pp, hipStream_t s);
@@ -103,6 +104,8 @@ static void linspace_f32(float start, float end, int steps, float* out) {
 //
 //   launch                        | size (slots / rows)        | form
 //   ------------------------------+----------------------------+---------------------------------------------------------
+//   conv layer 0's node update    | batch <= n16_fuse_rows_max | none: computed by the last layer's edge items for their own source rows
+//     (n_convs = 2, kNN pf edges) |   (20,000: <= 32 graphs)   |   (pf_n16.hip: k_n16_fused; one launch less per step)
 //   edge messages, any conv layer | batch <= n16_rows_max      | n16: 16-row items on the four waves of a workgroup
 //                                 |   (24,000 ~ 2 busy items   |   (pf_n16.hip; conv layer 0 needs the static hoist's type
 //                                 |   per CU)                  |   tables, else the row-group form)
@@ -121,7 +124,8 @@ static void linspace_f32(float start, float end, int steps, float* out) {
 //   layers; PFDYN_RG_ROWS_MAX=0)  |                            |   coop2_*_max, one wave per tile beyond
 //
 // Every threshold can be overridden from the environment (tests force every form onto the goldens; sweeps: tools/):
-//   PFDYN_N16 (bit 0: conv layers >= 1, bit 1: conv layer 0; default 3), PFDYN_N16_ROWS_MAX, PFDYN_RG_ROWS_MAX,
+//   PFDYN_N16 (bit 0: conv layers >= 1, bit 1: conv layer 0, bit 2: conv layer 0's node update fused into the last layer's edge
+//   launch when n_convs = 2; default 7), PFDYN_N16_ROWS_MAX (sets both n16 thresholds), PFDYN_N16_FUSE_ROWS_MAX, PFDYN_RG_ROWS_MAX,
 //   PFDYN_RG2_ROWS_MIN (sets all four 8-row thresholds) / _NODE / _HOIST, PFDYN_RG2P_ROWS_MIN, PFDYN_L0_RGA / PFDYN_L0_RGP (rows-per-
 //   wave factor of the full-chain / hoisted items of a compact layer-0 launch), PFDYN_RG_SPLIT_MAX (all three) / _NODE / _HEAD,
 //   PFDYN_COOP_EDGE_MAX, PFDYN_COOP2_EDGE_MAX, PFDYN_COOP_NODE_MAX.  Forcing a row-group form switches the n16 form off
@@ -129,7 +133,8 @@ static void linspace_f32(float start, float end, int steps, float* out) {
 // ------------------------------------------------------------------------------------------------------------------
 struct LaunchPolicy {
     static constexpr int kCUs = 256, kSIMDs = 4 * kCUs;
-    int n16_mask = 3;
+    int n16_mask = 7;
+    long n16_fuse_rows_max = 20000;         // the fused launch (bit 2): +2-3 % up to 32 graphs of 256 atoms, -4 % at 40 (its items carry five blocks: throughput-bound earlier)
     long n16_rows_max = 24000;              // measured at 256-atom pockets (575 slots per graph): +5 % at 16 graphs, +10 % at 32, -3..-5 % at 64, -15 % at 256
     int rg_rows_max = 1 << 30;
     int rg2_rows_min = 12000;               // ~3 four-row items per SIMD (3 x 4 x kSIMDs = 12,288)
@@ -162,7 +167,8 @@ struct LaunchPolicy {
                               "PFDYN_L0_RGP", "PFDYN_RG_ROWS_MAX"})
             if (getenv(v)) n16_mask = 0;
         geti("PFDYN_N16", n16_mask);
-        if (const char* e = getenv("PFDYN_N16_ROWS_MAX")) n16_rows_max = atol(e);
+        if (const char* e = getenv("PFDYN_N16_ROWS_MAX")) n16_rows_max = n16_fuse_rows_max = atol(e);
+        if (const char* e = getenv("PFDYN_N16_FUSE_ROWS_MAX")) n16_fuse_rows_max = atol(e);
     }
 };
 
@@ -268,6 +274,9 @@ struct pf_handle {
     // conv layer 0's message chains in their own forms: protein sources (pf, pp) start from a type-table row (M0H),
     // centers (ff, fp) have zero node vectors (M0Z)
     size_t n16_l0[4] = {0, 0, 0, 0}, n16_l0_stride[4] = {0, 0, 0, 0};
+    // fused launch (n_convs = 2): per etype of the last layer (ff, pf) [update chain of conv layer 0 for the source type][message chain]
+    size_t n16_fused[2] = {0, 0}, n16_fused_stride[2] = {0, 0};
+    float *d_msg_s2 = nullptr, *d_msg_v2 = nullptr;   // the last conv layer's message rows when conv layer 0's are still being read (fused launch)
     std::vector<int> last_family;           // per conv layer: pf_debug_kernel_family
     int last_hoist = 0;                     // pf_debug_l0_hoist
     // ---- static hoist of conv layer 0's pp messages (pf_rg.hip, EdgeParams::zs).  Everything derived from the weights
@@ -916,6 +925,12 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     h->last_hoist = 0;
     int cur = 0;
     bool head_done = false;
+    // fused launch (pf_n16.hip: k_n16_fused): with two conv layers, receptive-field pruning and kNN pf edges the rows conv
+    // layer 0's node update produces are exactly the sources of the last layer's edges (+ the centers): every edge item of
+    // the last layer updates its own source rows first, and the node launch of conv layer 0 disappears
+    const bool fuse_l0node = !train && n16_batch && (long)h->n_edge_tiles_act * 32 <= h->pol.n16_fuse_rows_max && (h->pol.n16_mask & 4) && (h->pol.n16_mask & 1) && hoist && c.n_convs == 2 && prune_layer == 0 && c.pf_k > 0 &&
+                             c.n_update_gvps >= 1 && h->rg_compact && 2 * h->B <= 1024 && h->d_msg_s2 != nullptr && h->n16_fused[0] != 0;
+    FusedParams fz{};
     for (int l = 0; l < c.n_convs; ++l) {
         EdgeParams e{};
         const bool last = (l == c.n_convs - 1), pruned = (l == prune_layer);
@@ -924,6 +939,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;
         e.h = train ? h->t_H[l] : h->d_h[cur]; e.v = train ? h->t_V[l] : h->d_v[cur];
         e.msg_s = train ? h->t_msg_s[l] : h->d_msg_s; e.msg_v = train ? h->t_msg_v[l] : h->d_msg_v;
+        if (fuse_l0node && l == 1) { e.msg_s = h->d_msg_s2; e.msg_v = h->d_msg_v2; }
         e.w = h->d_gvp + h->msg_base(l, 0); e.n_gvps = c.n_message_gvps;
         e.pre = (l == 0 && pre_ready) ? h->d_pre : nullptr;
         linspace_f32(0.f, c.rbf_dmax, c.rbf_dim, e.rbf_mu);
@@ -993,7 +1009,18 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         for (int et = 0; et < 4; ++et) e.rgs[et] = h->d_w + h->rgs_msg[(size_t)l * 4 + et];
         e.rgs_stride = (int)h->rgs_msg_stride;
         const int esplit = (rg == 1 && e.ntiles * 8 <= h->pol.rg_split_max && !e.zs) ? 1 : 0;    // fewer groups than SIMDs: latency-bound
-        if (n16e) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_n16_edge(&e, &ep, l == 0, s); }
+        if (n16e && fuse_l0node && l == 1) {
+            fz.chain[ET_FF] = h->d_w + h->n16_fused[0]; fz.chain_stride[ET_FF] = (int)h->n16_fused_stride[0];
+            fz.chain[ET_PF] = h->d_w + h->n16_fused[1]; fz.chain_stride[ET_PF] = (int)h->n16_fused_stride[1];
+            fz.upd_pharm = h->d_w + h->n16_upd[(size_t)0 * 2 + 1]; fz.upd_pharm_stride = (int)h->n16_upd_stride;
+            fz.htab = l0_ptab + (size_t)3 * c.rec_nf * PF_S; fz.htab_gstride = l0_gstride; fz.ptype = h->d_ptype;
+            fz.h_out = h->d_h[cur]; fz.v_out = h->d_v[cur];          // (cur was flipped behind conv layer 0: its output side)
+            fz.pharm_ptr = h->d_pharm_ptr; fz.Np = h->Np; fz.n_edge_items = e.ngroups_sel;
+            h->last_family[l] = 17;                      // pf_debug_kernel_family: 16-row items with conv layer 0's node update in front
+            ProfScope ps(h, pf_handle::K_EDGE_LAST, s);
+            pfk_n16_fused(&e, &fz, &ep, s);
+        }
+        else if (n16e) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_n16_edge(&e, &ep, l == 0, s); }
         else if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, esplit, rgp, s); }
         else if (e.ntiles <= h->pol.coop_edge_max && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop(&e, l == 0, s); }
         else if (e.ntiles <= ((last || pruned) ? h->pol.coop2_edge_max : h->pol.coop2_dense_max) && !train) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_edge_msg_coop2(&e, l == 0, s); }
@@ -1027,6 +1054,17 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         for (int nt = 0; nt < 2; ++nt) {
             n.rgs_upd[nt] = h->d_w + h->rgs_upd[(size_t)l * 2 + nt];
             n.rgs_stride[nt] = (int)h->rgs_upd_stride[(size_t)l * 2 + nt];
+        }
+        if (fuse_l0node && l == 0) {       // no node launch: the last layer's edge items (and its store items) compute these rows
+            fz.in_start = n.in_start; fz.in_cnt = n.in_cnt; fz.N = n.N; fz.pp_slot = n.pp_slot;
+            fz.msg_s = n.msg_s; fz.msg_v = n.msg_v; fz.zero_row = n.zero_row; fz.grp = n.grp; fz.grp_pa = n.grp_pa;
+            fz.gid = n.gid; fz.gnorm = n.gnorm; fz.B = n.B; fz.norm_mode = n.norm_mode; fz.norm_value = n.norm_value;
+            for (int nt = 0; nt < 2; ++nt) {
+                fz.ln1_w[nt] = n.w[nt].ln1_w; fz.ln1_b[nt] = n.w[nt].ln1_b; fz.ln2_w[nt] = n.w[nt].ln2_w; fz.ln2_b[nt] = n.w[nt].ln2_b;
+            }
+            fz.n_upd = n.n_upd;
+            cur ^= 1;
+            continue;
         }
         if (rg) {
             const int rgn = (long)n.ntiles * 32 >= h->pol.rg2_rows_min_node ? 2 : 1;
@@ -1351,10 +1389,11 @@ int pf_commit_weights(pf_handle* h) {
             h->n16_msg.assign((size_t)c.n_convs * 4, 0);
             h->n16_upd.assign((size_t)c.n_convs * 2, 0);
             std::vector<float> st;
-            auto chain16 = [&](auto spec_of, int n, int kind0, size_t& stride) {
+            // (m0_at: index of the block that is a first message GVP in the full form, M0F; -1: block 0 has kind0)
+            auto chain16 = [&](auto spec_of, int n, int kind0, size_t& stride, int m0_at = -1) {
                 for (int w = 0; w < 4; ++w) {
                     const size_t b0 = st.size();
-                    for (int j = 0; j < n; ++j) pack_n16(h, spec_of(j), j == 0 ? kind0 : N16_GEN, w, st);
+                    for (int j = 0; j < n; ++j) pack_n16(h, spec_of(j), j == m0_at ? N16_M0F : (j == 0 ? kind0 : N16_GEN), w, st);
                     st.resize(st.size() + (size_t)N16_TAIL_PAD * 256, 0.f);
                     stride = st.size() - b0;
                 }
@@ -1368,6 +1407,12 @@ int pf_commit_weights(pf_handle* h) {
             for (int et = 0; et < 4; ++et)
                 h->n16_l0[et] = chain16([&](int j) { return msg_spec(c, 0, et, j); }, c.n_message_gvps,
                                         (et == ET_PP || et == ET_PF) ? N16_M0H : N16_M0Z, h->n16_l0_stride[et]);
+            if (c.n_convs == 2)          // fused launch: conv layer 0's update chain of the source type, then the last layer's message chain
+                for (int k = 0; k < 2; ++k) {
+                    const int et = k == 0 ? ET_FF : ET_PF, nt = k == 0 ? 1 : 0;
+                    h->n16_fused[k] = chain16([&](int j) { return j < c.n_update_gvps ? upd_spec(c, 0, nt, j) : msg_spec(c, 1, et, j - c.n_update_gvps); },
+                                              c.n_update_gvps + c.n_message_gvps, N16_GEN, h->n16_fused_stride[k], c.n_update_gvps);
+                }
             for (int l = 0; l < c.n_convs; ++l)
                 for (int nt = 0; nt < 2; ++nt)
                     h->n16_upd[(size_t)l * 2 + nt] = chain16([&](int j) { return upd_spec(c, l, nt, j); }, c.n_update_gvps, N16_GEN, h->n16_upd_stride);
@@ -1751,10 +1796,14 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
                  o_need = place((size_t)std::max(Np, 1) * 4);
     const size_t zero_bytes = off - table_end;
     // scratch
+    // (a second set of message rows for the last conv layer: the fused launch of small n_convs = 2 batches writes them while conv
+    // layer 0's are still being read)
+    const bool msg2 = c.n_convs == 2 && (long)h->n_edge_tiles_act * 32 <= h->pol.n16_rows_max;
     const size_t o_xn = place((size_t)N * 16),
                  o_fh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_t = place((size_t)B * 4),
                  o_h0 = place((size_t)N * PF_S * 4), o_h1 = place((size_t)N * PF_S * 4), o_v0 = place((size_t)N * 48 * 4), o_v1 = place((size_t)N * 48 * 4),
                  o_ms = place((size_t)(Ecap + 1) * PF_S * 4), o_mv = place((size_t)(Ecap + 1) * 48 * 4),
+                 o_ms2 = place(msg2 ? (size_t)(Ecap + 1) * PF_S * 4 : 16), o_mv2 = place(msg2 ? (size_t)(Ecap + 1) * 48 * 4 : 16),
                  o_eh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_ex = place((size_t)Nf * 3 * 4 + 16), o_c0 = place((size_t)B * 3 * 4), o_c1 = place((size_t)B * 3 * 4),
                  o_pre = place((size_t)std::max(Np, 1) * PF_S * 4), o_eorig = place(Ecap * 4), o_ptype = place((size_t)std::max(Np, 1) * 4),
                  o_zs = place((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4), o_ptpg = place((size_t)B * L0_NTAB * c.rec_nf * PF_S * 4);
@@ -1781,6 +1830,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     h->d_dyn_cnt = (int*)at(o_dyn); h->d_act_ids = (int*)at(o_act); h->d_l0flag = (int*)at(o_flag); h->d_gnorm = (float*)at(o_gnorm);
     h->d_xn = (float4*)at(o_xn); h->d_prot_x0 = (float*)at(o_px0); h->d_prot_h0 = (float*)at(o_ph0); h->d_pharm_h = (float*)at(o_fh);
     h->d_t = (float*)at(o_t); h->d_h[0] = (float*)at(o_h0); h->d_h[1] = (float*)at(o_h1); h->d_v[0] = (float*)at(o_v0); h->d_v[1] = (float*)at(o_v1);
+    h->d_msg_s2 = msg2 ? (float*)at(o_ms2) : nullptr; h->d_msg_v2 = msg2 ? (float*)at(o_mv2) : nullptr;
     h->d_msg_s = (float*)at(o_ms); h->d_msg_v = (float*)at(o_mv); h->d_eps_h = (float*)at(o_eh); h->d_eps_x = (float*)at(o_ex);
     h->d_com_init = (float*)at(o_c0); h->d_com_tmp = (float*)at(o_c1); h->d_pre = (float*)at(o_pre); h->d_eorig = (int*)at(o_eorig);
     h->d_ptype = (int*)at(o_ptype); h->d_zs = (float*)at(o_zs); h->d_ptab_pg = (float*)at(o_ptpg);
@@ -1853,6 +1903,15 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
         PF_HIP(h, hipMemsetAsync(h->d_msg_v + (size_t)Ecap * 48, 0, 48 * 4, s));
     }
     h->zero_row = (int)Ecap;
+    if (h->d_msg_s2) {
+        if (fresh) {
+            PF_HIP(h, hipMemsetAsync(h->d_msg_s2, 0, (size_t)(Ecap + 1) * PF_S * 4, s));
+            PF_HIP(h, hipMemsetAsync(h->d_msg_v2, 0, (size_t)(Ecap + 1) * 48 * 4, s));
+        } else {
+            PF_HIP(h, hipMemsetAsync(h->d_msg_s2 + (size_t)Ecap * PF_S, 0, PF_S * 4, s));
+            PF_HIP(h, hipMemsetAsync(h->d_msg_v2 + (size_t)Ecap * 48, 0, 48 * 4, s));
+        }
+    }
     if (!from_host) {
         pfk_copy(dev_prot_x, h->d_prot_x0, (size_t)Np * 3, s);
         pfk_copy(dev_prot_h, h->d_prot_h0, (size_t)Np * c.rec_nf, s);

@@ -125,6 +125,7 @@ struct __attribute__((aligned(16))) N16Lds {
     float v[3 * 64 * 4];                      // Vh per coordinate: [c][lane][r] = hidden channel 4 g + r of row j
     float g[4 * 64 * 4];                      // K-split partial sums of the gate Linear per wave: [w][lane][r] = channel 4 g + r
     float v16[3 * 16];                        // first message GVP (17 hidden channels): Vh[16] per coordinate and row
+    float vn[3 * 64 * 4];                     // GVPLayerNorm: squared vector components per coordinate (n16_layernorm)
 };
 
 // what the first message GVP of an edge needs besides the source row
@@ -317,13 +318,11 @@ __device__ __forceinline__ float seg_scan16(float v, const SegMask16& m) {
 // Scalar encoder of the pharmacophore centers on the fly (dynamics_gvp.py:107-117, 143-151: h = LayerNorm(SiLU(W [h_t, t] + b)))
 // for the 16 source rows of a conv-layer-0 item: wave w encodes features [32 w, 32 w + 32) (SiLU is the expensive part),
 // the slices meet in LDS, and every wave normalises the features it holds as B operands (two-pass statistics over the
-// row: its 32 registers and the four lane groups).  node: global id of the row's source (a center).
-__device__ __forceinline__ void n16_encode_pharm(const EncodeParams& ep, const int node, float (&XS)[32], N16Lds* lds,
+// row: its 32 registers and the four lane groups).  in: the features of the row's center; tt: its graph's timestep.
+__device__ __forceinline__ void n16_encode_pharm(const EncodeParams& ep, pf_gcf in, const float tt, float (&XS)[32], N16Lds* lds,
                                                  const int lane, const int wq) {
     const int g = lane >> 4;
     const int nf = ep.pharm_nf;
-    pf_gcf in = (pf_gcf)ep.pharm_h + (size_t)(node - ep.Np) * nf;
-    const float tt = ep.t ? ((pf_gcf)ep.t)[((const int PF_AS1*)ep.gid)[node]] : ep.t_scalar;
     pf_gcf Wt = (pf_gcf)ep.w[1] + 32 * wq + 4 * g;                    // [nf + 1][128], input-major
     f32x4 z0 = *reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.b[1] + 32 * wq + 4 * g);
     f32x4 z1 = *reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.b[1] + 32 * wq + 16 + 4 * g);
@@ -374,49 +373,22 @@ __device__ __forceinline__ void n16_encode_pharm(const EncodeParams& ep, const i
     lds_barrier();                                       // the slices are read: the chain's first block may write lds->s
 }
 
+// what an item's prologue hands to its chain: this lane's row (edge slot, destination; rows beyond nv repeat the last one)
+// and the coordinates of its end points
+struct N16Rows {
+    int e, dst;
+    float4 xs, xd;
+};
+
+// chain + per-destination sums of one item whose first-block inputs are in registers (XS / VB / S as n16_block takes them)
 template <int KIND0>
-__device__ __forceinline__ void n16_edge_item(const EdgeParams& p, const EncodeParams& ep, N16Lds* lds, const int e0, const int nv,
-                                              const int et, const int lane, const int wq, int& sk) {
+__device__ __forceinline__ void n16_edge_chain(const EdgeParams& p, N16Ring& ring, const N16Rows& rw, float (&XS)[32], float (&VB)[4],
+                                               f32x4 (&S)[2], N16Lds* lds, const int nv, const int lane, const int wq, int& sk) {
     constexpr int OFF1 = n16_sched(KIND0).nq % N16_D;
-    N16_STAMP(sk, lane, wq);                              // item known (work list scanned)
-    N16Ring ring;
-    ring_start(ring, p.n16[et] + (size_t)wq * p.n16_stride[et], lane);      // in flight under the gathers
     const int g = lane >> 4, j = lane & 15;
-    const int e = e0 + min(j, nv - 1);
-    const int src = p.esrc[e], dst = p.edst[e];
-    const float4 xs = p.xn[src], xd = p.xn[dst];
-    float XS[32], VB[4];
-    f32x4 S[2];
-    S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
-    if constexpr (KIND0 == N16_M0H) {
-        // the h_src block of the first message Linear (+ its bias) is a row of the etype's type table
-        int ty = p.ptype[src] * PF_S + p.ptab16_off[et];
-        if (p.ptab_gstride) ty += p.l0_gid[src] * p.ptab_gstride;
-        pf_gcf tp = (pf_gcf)p.ptab + ty + 32 * wq + 4 * g;
-        S[0] = *reinterpret_cast<const f32x4 PF_AS1*>(tp);
-        S[1] = *reinterpret_cast<const f32x4 PF_AS1*>(tp + 16);
-    }
-    if constexpr (KIND0 == N16_M0Z) n16_encode_pharm(ep, src, XS, lds, lane, wq);
-    if constexpr (KIND0 == N16_M0F) {
-        const f32x4 PF_AS1* hp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.h + (size_t)src * PF_S) + g;
-#pragma unroll
-        for (int T = 0; T < 8; ++T) {
-            const f32x4 x = hp[4 * T];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) XS[4 * T + r] = x[r];
-        }
-    }
-    if constexpr (KIND0 == N16_M0F) {
-        pf_gcf vp = (pf_gcf)p.v + (size_t)src * 48 + 12 * g + (wq < 3 ? wq : 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float x = vp[3 * r]; VB[r] = wq < 3 ? x : 0.f; }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) VB[r] = 0.f;
-    }
     N16In in;
     {
-        const float dx = xs.x - xd.x, dy = xs.y - xd.y, dz = xs.z - xd.z;
+        const float dx = rw.xs.x - rw.xd.x, dy = rw.xs.y - rw.xd.y, dz = rw.xs.z - rw.xd.z;
         const float d = sqrtf_(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
         const float rd = rcpf_(d);
         in.xh[0] = dx * rd; in.xh[1] = dy * rd; in.xh[2] = dz * rd;
@@ -433,9 +405,9 @@ __device__ __forceinline__ void n16_edge_item(const EdgeParams& p, const EncodeP
     n16_block<N16_GEN, OFF1, true>(ring, XS, VB, in, S, lds, lane, wq, sk);
     N16_STAMP(sk, lane, wq);                              // chain done
     // per-destination sums in slot order, one partial row per (item, destination) run
-    const SegMask16 sm = seg_masks16(dst, j);
-    const int dnext = dpp_i<0x101>(dst);                 // row_shl 1: the next row's destination
-    const bool tail = (j == nv - 1) | ((j < nv - 1) & (dnext != dst));
+    const SegMask16 sm = seg_masks16(rw.dst, j);
+    const int dnext = dpp_i<0x101>(rw.dst);              // row_shl 1: the next row's destination
+    const bool tail = (j == nv - 1) | ((j < nv - 1) & (dnext != rw.dst));
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -443,15 +415,61 @@ __device__ __forceinline__ void n16_edge_item(const EdgeParams& p, const EncodeP
 #pragma unroll
     for (int r = 0; r < 4; ++r) VB[r] = seg_scan16(VB[r], sm);
     if (tail) {
-        float* ms = p.msg_s + (size_t)e * PF_S + 32 * wq + 4 * g;
+        float* ms = p.msg_s + (size_t)rw.e * PF_S + 32 * wq + 4 * g;
         *reinterpret_cast<f32x4*>(ms) = S[0];
         *reinterpret_cast<f32x4*>(ms + 16) = S[1];
         if (wq < 3) {
-            float* mv = p.msg_v + (size_t)e * 48 + 12 * g + wq;
+            float* mv = p.msg_v + (size_t)rw.e * 48 + 12 * g + wq;
 #pragma unroll
             for (int r = 0; r < 4; ++r) mv[3 * r] = VB[r];
         }
     }
+}
+
+// an item whose rows are gathered from global memory: slots -> (source, destination) -> coordinates / source rows -> type-table row
+template <int KIND0>
+__device__ __forceinline__ void n16_edge_item(const EdgeParams& p, const EncodeParams& ep, N16Lds* lds, const int e0, const int nv,
+                                              const int et, const int lane, const int wq, int& sk) {
+    N16_STAMP(sk, lane, wq);                              // item known (work list scanned)
+    N16Ring ring;
+    ring_start(ring, p.n16[et] + (size_t)wq * p.n16_stride[et], lane);      // in flight under the gathers
+    const int g = lane >> 4, j = lane & 15;
+    N16Rows rw;
+    rw.e = e0 + min(j, nv - 1);
+    const int src = p.esrc[rw.e];
+    rw.dst = p.edst[rw.e];
+    rw.xs = p.xn[src]; rw.xd = p.xn[rw.dst];
+    float XS[32], VB[4];
+    f32x4 S[2];
+    S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
+    if constexpr (KIND0 == N16_M0H) {
+        // the h_src block of the first message Linear (+ its bias) is a row of the etype's type table
+        int ty = p.ptype[src] * PF_S + p.ptab16_off[et];
+        if (p.ptab_gstride) ty += p.l0_gid[src] * p.ptab_gstride;
+        pf_gcf tp = (pf_gcf)p.ptab + ty + 32 * wq + 4 * g;
+        S[0] = *reinterpret_cast<const f32x4 PF_AS1*>(tp);
+        S[1] = *reinterpret_cast<const f32x4 PF_AS1*>(tp + 16);
+    }
+    if constexpr (KIND0 == N16_M0Z) {
+        const float tt = ep.t ? ((pf_gcf)ep.t)[((const int PF_AS1*)ep.gid)[src]] : ep.t_scalar;
+        n16_encode_pharm(ep, (pf_gcf)ep.pharm_h + (size_t)(src - ep.Np) * ep.pharm_nf, tt, XS, lds, lane, wq);
+    }
+    if constexpr (KIND0 == N16_M0F) {
+        const f32x4 PF_AS1* hp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)p.h + (size_t)src * PF_S) + g;
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+            const f32x4 x = hp[4 * T];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) XS[4 * T + r] = x[r];
+        }
+        pf_gcf vp = (pf_gcf)p.v + (size_t)src * 48 + 12 * g + (wq < 3 ? wq : 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float x = vp[3 * r]; VB[r] = wq < 3 ? x : 0.f; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) VB[r] = 0.f;
+    }
+    n16_edge_chain<KIND0>(p, ring, rw, XS, VB, S, lds, nv, lane, wq, sk);
 }
 
 // grid: one workgroup per 16-slot group (compact work list: the w-th non-empty group; tile lists: two groups per tile)
@@ -554,6 +572,220 @@ __global__ __launch_bounds__(256) void k_n16_edge(const int* __restrict__ a_dyn_
 }
 
 // ---------------------------------------------------------------------------------------------
+// GVPLayerNorm (gvp.py:159-166) on the n16 layouts.  Every wave holds all 128 scalars of its rows (32 registers x the four
+// lane groups): the row statistics are a register sum and one cross-group sum.  The vector norm needs the three
+// coordinates of a channel, which live on three waves: the squares meet in LDS (lds->vn; one barrier).  Called by all
+// four waves (wave 3: VB = 0).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void n16_layernorm(pf_gcf lw, pf_gcf lb, float (&XS)[32], float (&VB)[4], N16Lds* lds, const int lane, const int wq) {
+    const int g = lane >> 4;
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) sum += XS[k];
+    const float mean = gsum(sum) * (1.0f / 128.0f);
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { const float c = XS[k] - mean; var = fmaf(c, c, var); }
+    const float rstd = rsqf_(gsum(var) * (1.0f / 128.0f) + 1e-5f);
+#pragma unroll
+    for (int T = 0; T < 8; ++T) {
+        const f32x4 w = *reinterpret_cast<const f32x4 PF_AS1*>(lw + 16 * T + 4 * g), b = *reinterpret_cast<const f32x4 PF_AS1*>(lb + 16 * T + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) XS[4 * T + r] = (XS[4 * T + r] - mean) * rstd * w[r] + b[r];
+    }
+    if (wq < 3) *reinterpret_cast<f32x4*>(&lds->vn[(wq * 64 + lane) * 4]) = (f32x4){VB[0] * VB[0], VB[1] * VB[1], VB[2] * VB[2], VB[3] * VB[3]};
+    lds_barrier();
+    const f32x4 a = *reinterpret_cast<const f32x4*>(&lds->vn[(0 * 64 + lane) * 4]);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(&lds->vn[(1 * 64 + lane) * 4]);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(&lds->vn[(2 * 64 + lane) * 4]);
+    float vn = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vn += fmaxf(a[r] + b[r] + c[r], 1e-8f);
+    const float rden = rcpf_(sqrtf_(gsum(vn) * (1.0f / 16.0f) + 1e-5f) + 1e-5f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) VB[r] *= rden;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Conv layer 0's node update (gvp.py:488-536) of the 16 rows `node` (one node per lane row; type nt workgroup-uniform):
+// sum of the node's message partial rows (mean per etype or the configured norm), residual on the encoder output (the
+// node vectors of conv layer 0 are zero), GVPLayerNorm, the update chain (ring: the next blocks of the stream), residual,
+// GVPLayerNorm.  Leaves h' in XS (every wave: all 128 features) and v' in VB (wave c: coordinate c) -- exactly what the first
+// message GVP of the NEXT layer's edges takes, so nothing is written (k_n16_fused).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void n16_node_update_l0(const FusedParams& f, const EncodeParams& ep, N16Ring& ring, const int node, const int nt,
+                                                   float (&XS)[32], float (&VB)[4], N16Lds* lds, const int lane, const int wq, int& sk) {
+    const int g = lane >> 4;
+    const int cw = wq < 3 ? wq : 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) XS[k] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) VB[r] = 0.f;
+    // the two segments of the node's in-edges; their partial rows are the last slots of the aligned groups they touch
+    int st[2], cn[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int slot = sl == 0 ? 0 : (nt == 0 ? f.pp_slot : 1);
+        st[sl] = f.in_start[slot * f.N + node];
+        cn[sl] = f.in_cnt[slot * f.N + node];
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int end = st[sl] + cn[sl];
+        const int gm = (sl == 0 ? f.grp : (nt == 0 ? f.grp_pa : f.grp)) - 1;
+        const float sc = (f.norm_mode == 0 && cn[sl] > 0) ? 1.0f / (float)cn[sl] : 1.0f;
+        int e = st[sl];
+        while (__any(e < end)) {                          // (rows that are done add the all-zero row)
+            const bool has = e < end;
+            const int rw = has ? min(e | gm, end - 1) : f.zero_row;
+            const f32x4 PF_AS1* mp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)f.msg_s + (size_t)rw * PF_S) + g;
+            f32x4 x[8];
+#pragma unroll
+            for (int T = 0; T < 8; ++T) x[T] = mp[4 * T];
+            pf_gcf vp = (pf_gcf)f.msg_v + (size_t)rw * 48 + 12 * g + cw;
+            float vv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv[r] = vp[3 * r];
+#pragma unroll
+            for (int T = 0; T < 8; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) XS[4 * T + r] = fmaf(x[T][r], sc, XS[4 * T + r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) VB[r] = fmaf(vv[r], sc, VB[r]);
+            e = has ? rw + 1 : e;
+        }
+    }
+    float inv_norm = 1.0f;
+    if (f.norm_mode == 1) inv_norm = 1.0f / f.norm_value;
+    else if (f.norm_mode == 2) inv_norm = 1.0f / f.gnorm[nt * f.B + f.gid[node]];
+    // residual input: the encoder output of the node (a type-table row for protein atoms, encoded on the fly for centers)
+    float H[32];
+    if (nt == 0) {
+        pf_gcf hp = (pf_gcf)f.htab + (f.htab_gstride ? (size_t)f.gid[node] * f.htab_gstride : 0) + (size_t)f.ptype[node] * PF_S + 4 * g;
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+            const f32x4 x = *reinterpret_cast<const f32x4 PF_AS1*>(hp + 16 * T);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H[4 * T + r] = x[r];
+        }
+    } else {
+        const float tt = ep.t ? ((pf_gcf)ep.t)[f.gid[node]] : ep.t_scalar;
+        n16_encode_pharm(ep, (pf_gcf)ep.pharm_h + (size_t)(node - ep.Np) * ep.pharm_nf, tt, H, lds, lane, wq);
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) XS[k] = fmaf(XS[k], inv_norm, H[k]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) VB[r] = wq < 3 ? VB[r] * inv_norm : 0.f;
+    n16_layernorm(f.ln1_w[nt], f.ln1_b[nt], XS, VB, lds, lane, wq);
+    float Xr[32], Vr[4];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) Xr[k] = XS[k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Vr[r] = VB[r];
+    N16In none{};
+    f32x4 S[2];
+    S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
+    for (int gi = 0; gi < f.n_upd; ++gi) n16_block<N16_GEN, 0, false>(ring, XS, VB, none, S, lds, lane, wq, sk);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) XS[k] += Xr[k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) VB[r] += Vr[r];
+    n16_layernorm(f.ln2_w[nt], f.ln2_b[nt], XS, VB, lds, lane, wq);
+}
+
+// The fused launch (FusedParams): items [0, n_edge_items) are the last conv layer's 16-slot edge groups (compact work list:
+// ff and pf regions); the remaining workgroups store conv layer 0's update of the centers, 16 per item, for the node + head
+// launch.  An edge item first updates its own source rows (conv layer 0's node update, weights: the first blocks of its
+// stream), then runs its message chain on them.
+__global__ __launch_bounds__(256) void k_n16_fused(const int* __restrict__ a_dyn_cnt, const int* __restrict__ a_reg, const int a_nreg,
+                                                   const int a_regB, const EdgeParams p, const FusedParams f, const EncodeParams ep) {
+    __shared__ N16Lds lds;
+    const int lane = threadIdx.x & 63;
+    const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = lane >> 4, j = lane & 15;
+    int sk = 0;
+    N16_STAMP(sk, lane, wq);                              // kernel entry
+    float XS[32], VB[4];
+    if ((int)blockIdx.x >= f.n_edge_items) {
+        // ---- store item: the centers [16 part, 16 part + 16) of graph gq
+        const int it = (int)blockIdx.x - f.n_edge_items;
+        const int gq = it / (PF_MAXF / 16), part = it % (PF_MAXF / 16);
+        const int f0 = f.pharm_ptr[gq], nf = f.pharm_ptr[gq + 1] - f0;
+        const int nv = __builtin_amdgcn_readfirstlane(min(16, nf - 16 * part));
+        if (nv <= 0) return;                             // workgroup-uniform
+        const int node = f.Np + f0 + 16 * part + min(j, nv - 1);
+        N16Ring ring;
+        ring_start(ring, f.upd_pharm + (size_t)wq * f.upd_pharm_stride, lane);
+        n16_node_update_l0(f, ep, ring, node, 1, XS, VB, &lds, lane, wq, sk);
+        if (j < nv && wq == 0) {
+            float* hp = f.h_out + (size_t)node * PF_S + 4 * g;
+#pragma unroll
+            for (int T = 0; T < 8; ++T) *reinterpret_cast<f32x4*>(hp + 16 * T) = (f32x4){XS[4 * T], XS[4 * T + 1], XS[4 * T + 2], XS[4 * T + 3]};
+        }
+        if (j < nv && wq < 3) {
+            float* vp = f.v_out + (size_t)node * 48 + 12 * g + wq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vp[3 * r] = VB[r];
+        }
+        return;
+    }
+    // ---- edge item: the w-th non-empty 16-slot group of the launch's regions (see k_n16_edge)
+    int e0, nv, et;
+    {
+        constexpr int NP = 16;
+        const int w = (int)blockIdx.x;
+        int first = 0, rsel = -1, cnt = 0, start = 0;
+        int cs[NP], rs[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            cs[k] = 0; rs[k] = 0;
+            if (64 * k < a_nreg) {
+                const int r = min(64 * k + lane, a_nreg - 1);
+                const int c = a_dyn_cnt[r];
+                rs[k] = a_reg[r];
+                cs[k] = 64 * k + lane < a_nreg ? c : 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if (64 * k < a_nreg && rsel < 0) {
+                const int c = cs[k];
+                const int ng = (c + 15) >> 4;
+                int incl = ng;
+                incl += dpp_i<0x111>(incl); incl += dpp_i<0x112>(incl); incl += dpp_i<0x114>(incl); incl += dpp_i<0x118>(incl);
+                incl += dpp_ir<0x142, 0xa>(incl); incl += dpp_ir<0x143, 0xc>(incl);
+                incl += first;
+                const unsigned long long m = __ballot(incl > w);
+                if (m) {
+                    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                    rsel = 64 * k + l;
+                    first = __builtin_amdgcn_readlane(incl - ng, l);
+                    cnt = __builtin_amdgcn_readlane(c, l);
+                    start = __builtin_amdgcn_readlane(rs[k], l);
+                } else first = __builtin_amdgcn_readlane(incl, 63);
+            }
+        }
+        if (rsel < 0) return;                            // workgroup-uniform: beyond the last group
+        et = rsel / a_regB;                              // the last layer's regions: ff, pf
+        const int loc = (w - first) << 4;
+        e0 = start + loc;
+        nv = __builtin_amdgcn_readfirstlane(min(16, cnt - loc));
+    }
+    N16_STAMP(sk, lane, wq);                              // item known
+    N16Ring ring;
+    ring_start(ring, f.chain[et] + (size_t)wq * f.chain_stride[et], lane);
+    N16Rows rw;
+    rw.e = e0 + min(j, nv - 1);
+    const int src = p.esrc[rw.e];
+    rw.dst = p.edst[rw.e];
+    rw.xs = p.xn[src]; rw.xd = p.xn[rw.dst];
+    n16_node_update_l0(f, ep, ring, src, et == ET_FF ? 1 : 0, XS, VB, &lds, lane, wq, sk);
+    f32x4 S[2];
+    S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
+    n16_edge_chain<N16_M0F>(p, ring, rw, XS, VB, S, &lds, nv, lane, wq, sk);
+}
+
+// ---------------------------------------------------------------------------------------------
 // pf_debug_chain kinds 16 / 17: the message / update chain in the n16 form on caller-supplied rows (layouts of kinds 0 / 1)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_n16_unit(const UnitParams p) {
@@ -628,6 +860,12 @@ int pfk_n16_set_stamp_buffer(unsigned long long* dev, int off) {
 #ifdef N16_TRACE
 int pfk_n16_set_trace_buffer(unsigned long long* dev) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_n16_trace), &dev, sizeof(dev)); }
 #endif
+// grid: the edge launch's capacity in 16-slot groups (f->n_edge_items) + PF_MAXF / 16 store items per graph
+void pfk_n16_fused(const EdgeParams* p, const FusedParams* f, const EncodeParams* enc, hipStream_t s) {
+    const int grid = f->n_edge_items + f->B * (PF_MAXF / 16);
+    if (grid <= 0) return;
+    hipLaunchKernelGGL(k_n16_fused, dim3(grid), dim3(256), 0, s, p->dyn_cnt, p->reg, p->nreg, p->regB, *p, *f, *enc);
+}
 void pfk_n16_unit(const UnitParams* p, hipStream_t s) {
     if (p->n <= 0) return;
     hipLaunchKernelGGL(k_n16_unit, dim3((p->n + 15) / 16), dim3(256), 0, s, *p);

@@ -365,7 +365,8 @@ class PfEngine:
 
     def kernel_family(self, layer: int = 0) -> int:
         """Rows per wave of the edge-message launch of `layer` in the last dynamics call: 4 / 8 = row-group kernels
-        (k_rg_edge), 32 = one wave per tile (k_edge_msg), 128 = four waves per tile (k_edge_msg_coop)."""
+        (k_rg_edge), 16 = 16-row items on four waves (k_n16_edge; 17: the fused launch k_n16_fused, which also computes conv layer 0's
+        node update of its source rows), 32 = one wave per tile (k_edge_msg), 128 = four waves per tile (k_edge_msg_coop)."""
         r = ctypes.c_int32()
         self._ck(self.lib.pf_debug_kernel_family(self._h, int(layer), ctypes.byref(r)), "pf_debug_kernel_family")
         return int(r.value)

@@ -53,7 +53,7 @@ def test_config2_batch32_steps_vs_oracle_under_the_default_policy():
     eng.set_batch(batch.prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst)
     coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
     x0, h0 = eng.sample(eng.coef_array(coef, reversed(range(n))), n, noise)          # s = 2, 1, 0
-    assert (eng.kernel_family(0), eng.kernel_family(1), eng.l0_hoist()) == (16, 16, 16)
+    assert (eng.kernel_family(0), eng.kernel_family(1), eng.l0_hoist()) == (16, 17, 16)
     ne = eng.work()[2]
     assert ne[1] == 5 * Nf and ne[2] == ne[1] and ne[3] == batch.pp_src.numel()
     bidx = batch.batch_idxs()

@@ -54,13 +54,13 @@ def test_n16_every_chain_vs_oracle(arch):
             close(so, ro, UNIT_TOL, UNIT_TOL); close(vo, rv, UNIT_TOL, UNIT_TOL)
 
 
-@pytest.mark.parametrize("mask", [1, 2, 3])
+@pytest.mark.parametrize("mask", [1, 2, 3, 5, 7])
 @pytest.mark.parametrize("variant", ["compact", "tile_lists", "dense"])
 @pytest.mark.parametrize("name", list(DYN_CASES))
 def test_n16_edge_kernels_on_goldens(name, variant, mask, monkeypatch):
     """The n16 edge kernel forced onto every dynamics golden (PFDYN_N16 bit 0: conv layers >= 1, first message GVP reads
     h / v from memory; bit 1: conv layer 0, protein sources from the static hoist's type tables, centers encoded on the
-    fly), on compact work lists, on tile lists and on the dense (unpruned) lists; the node kernels read its 16-slot
+    fly; bit 2: with two conv layers, conv layer 0's node update fused into the last layer's edge launch), on compact work lists, on tile lists and on the dense (unpruned) lists; the node kernels read its 16-slot
     partial rows."""
     monkeypatch.setenv("PFDYN_N16", str(mask))
     monkeypatch.setenv("PFDYN_N16_ROWS_MAX", "100000000")
@@ -73,8 +73,9 @@ def test_n16_edge_kernels_on_goldens(name, variant, mask, monkeypatch):
     eng = engine_for(cfg, O.make_state_dict(cfg, int(z["wseed"])))
     set_batch(eng, batch, z["prot_x"])
     eps_h, eps_x = eng.dynamics(z["x_t"], z["h_t"], z["t"])
+    fusable = cfg.n_convs == 2 and cfg.pf_k > 0 and variant == "compact"      # bit 2: conv layer 0's node update inside the last layer's edge launch
     if mask & 1:
-        assert eng.kernel_family(cfg.n_convs - 1) == 16
+        assert eng.kernel_family(cfg.n_convs - 1) == (17 if (mask & 4) and fusable else 16)
     if mask & 2:
         assert eng.kernel_family(0) == 16 and eng.l0_hoist() == 16
     close(eps_h, z["eps_h"]); close(eps_x, z["eps_x"])
@@ -94,7 +95,7 @@ def test_n16_with_pocket_sharing(monkeypatch):
     noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(5))
     coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
     res, fam, work = {}, {}, {}
-    for name, env, shared in (("rg", {"PFDYN_N16": "0"}, True), ("n16", {"PFDYN_N16": "3"}, False), ("n16_shared", {"PFDYN_N16": "3"}, True)):
+    for name, env, shared in (("rg", {"PFDYN_N16": "0"}, True), ("n16", {"PFDYN_N16": "7"}, False), ("n16_shared", {"PFDYN_N16": "7"}, True)):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = _engine(cfg, sd)
@@ -102,7 +103,7 @@ def test_n16_with_pocket_sharing(monkeypatch):
                       pocket_uid=uid if shared else None)
         x, h = eng.sample(eng.coef_array(coef, reversed(range(n))), n, noise)
         res[name], fam[name], work[name] = (x.cpu(), h.cpu()), eng.kernel_family(0), eng.work_detail()
-    assert fam == {"rg": 4, "n16": 16, "n16_shared": 16}, fam
+    assert fam == {"rg": 4, "n16": 16, "n16_shared": 16}, fam          # (layer 0; the last layer runs the fused launch in both n16 cases)
     for a in ("rg", "n16"):
         torch.testing.assert_close(res["n16_shared"][0], res[a][0], rtol=2e-4, atol=2e-4)
         torch.testing.assert_close(res["n16_shared"][1], res[a][1], rtol=2e-4, atol=2e-4)

@@ -541,7 +541,7 @@ def test_kernel_family_reporting(monkeypatch):
     eng = engine_for(cfg, sd)
     set_batch(eng, batch)
     eng.dynamics(x_t, h_t, t)
-    assert eng.kernel_family(0) == 16 and eng.kernel_family(1) == 16       # small launches: 16-row items on four waves (pf_n16.hip)
+    assert eng.kernel_family(0) == 16 and eng.kernel_family(1) == 17       # small launches: 16-row items on four waves (pf_n16.hip); the last layer's launch also updates conv layer 0's nodes
     monkeypatch.setenv("PFDYN_N16", "0")
     eng = engine_for(cfg, sd)
     set_batch(eng, batch)
