@@ -370,6 +370,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("BASELINE config 2: 256-atom pocket, 6 centers, T=500 schedule, batch=32 per GPU, dev.yml network"
                                 if (B, args.n_prot, args.n_pharm, args.pharm_sizes, args.arch) == (32, 256, 6, "", "dev") else
+                                "BASELINE config 3: mixed pharm sizes 3-8 (ragged graphs), 256-atom pockets, batch=128 per GPU, dev.yml network"
+                                if (B, args.n_prot, args.pharm_sizes, args.arch) == (128, 256, "3-8", "dev") else
                                 f"custom: {args.n_prot}-atom pockets, centers {args.pharm_sizes or args.n_pharm}, batch={B} per GPU, "
                                 + ("dev.yml network" if args.arch == "dev" else "class-default network (n_convs=4, n_noise_gvps=3, message_norm=1, radius pf)")),
                    "batch_per_gpu": B, "n_prot": args.n_prot, "n_pharm": args.pharm_sizes or args.n_pharm, "T": T,

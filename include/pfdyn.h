@@ -257,11 +257,14 @@ int pf_profile_read_train(pf_handle* h, double* total_ms /*[4]*/, int64_t* launc
 int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges /*[4]*/, double* executed_flops,
                   int64_t* executed_edges /*[n_convs]*/, pf_stream stream);
 /* kernel family of the edge-message launch of conv layer `layer` in the last dynamics call (the launch policy depends
- * on the batch: pf_host.cpp rg_mode / coop*_max): *rows_per_wave = 4 or 8 (row-group kernels, pf_rg.hip: k_rg_edge),
- * 32 (one wave per 32-row tile: k_edge_msg) or 128 (four waves per 32-row tile: k_edge_msg_coop / coop2) */
+ * on the batch: pf_host.cpp LaunchPolicy): *rows_per_wave = 4 or 8 (row-group kernels, pf_rg.hip: k_rg_edge), 16 (16-row
+ * items on the four waves of a workgroup, pf_n16.hip: k_n16_edge; 17 = the fused launch k_n16_fused, whose items also
+ * compute conv layer 0's node update of their source rows), 32 (one wave per 32-row tile: k_edge_msg) or 128 (four waves per
+ * 32-row tile: k_edge_msg_coop / coop2) */
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave);
 /* static hoist of conv layer 0's protein-protein messages in the last dynamics call: *rows_per_wave = 0 (not used: training,
- * tile kernels, protein features that are not element one-hots, PFDYN_NO_L0_HOIST=1) or 4 / 8 rows per hoisted wave */
+ * tile kernels, protein features that are not element one-hots, PFDYN_NO_L0_HOIST=1), 4 / 8 rows per hoisted wave (row-group
+ * kernels: pp edges start at their second message GVP) or 16 (n16 kernels: pp AND pf edges start from a type-table row) */
 int pf_debug_l0_hoist(pf_handle* h, int32_t* rows_per_wave);
 /* One chain of the row-group kernels (pf_rg.hip: rg_gvp / rg_flush / rg_layernorm, 4 rows per wave) on caller-supplied rows,
  * with the committed weights -- the unit-level checker against the reference's own module outputs (gvp.py:89-116, 152-166;
@@ -270,7 +273,9 @@ int pf_debug_l0_hoist(pf_handle* h, int32_t* rows_per_wave);
  *           s_in [n][144] = [h_src, rbf], v_in [n][17][3] = [x_hat, v_src]  ->  s_out [n][128], v_out [n][16][3]
  *   kind 1  update chain of conv `layer`, node type `sub` (0 prot, 1 pharm): [n][128], [n][16][3] -> same shapes
  *   kind 2  GVPLayerNorm of conv `layer`: sub = 2 * node type + (0 message_layer_norms, 1 update_layer_norms)
- *   kind 3  NoisePredictionBlock: s_in [n][128], v_in [n][16][3]  ->  s_out [n][pharm_nf] (eps_h), v_out [n][3] (eps_x) */
+ *   kind 3  NoisePredictionBlock: s_in [n][128], v_in [n][16][3]  ->  s_out [n][pharm_nf] (eps_h), v_out [n][3] (eps_x)
+ *   kind 16 / 17  the message / update chain (kinds 0 / 1, same rows) on the n16 kernels' chain code (pf_n16.hip: n16_block,
+ *           16 rows per workgroup of four waves); needs n_message_gvps >= 2 */
 int pf_debug_chain(pf_handle* h, int32_t kind, int32_t layer, int32_t sub, int32_t n_rows, const float* dev_s_in,
                    const float* dev_v_in, float* dev_s_out, float* dev_v_out, pf_stream stream);
 
