@@ -108,3 +108,31 @@ def test_n16_with_pocket_sharing(monkeypatch):
         torch.testing.assert_close(res["n16_shared"][0], res[a][0], rtol=2e-4, atol=2e-4)
         torch.testing.assert_close(res["n16_shared"][1], res[a][1], rtol=2e-4, atol=2e-4)
     assert work["n16_shared"]["executed_edges_per_layer"][0] < 0.9 * work["n16"]["executed_edges_per_layer"][0]
+
+
+@pytest.mark.parametrize("norm", ["mean", 0, 4.0])
+def test_n16_default_policy_on_random_ragged_batches_vs_oracle(norm):
+    """The default launch policy (n16 edge kernels, fused launch) on seeded random ragged batches against the oracle: 1-12
+    graphs, pockets of 3-70 atoms (some smaller than k), 1-10 centers (a single center has no ff edges: its graph's store
+    item is the only writer of that center's conv-layer-0 update), both calling conventions (one common t, per-graph t),
+    centers placed inside and outside the ff cutoff."""
+    import random
+    rnd = random.Random(11)
+    cfg = O.DynamicsConfig(message_norm=norm)
+    sd = O.make_state_dict(cfg, 5)
+    eng = engine_for(cfg, sd)
+    for trial in range(6):
+        B = rnd.choice([1, 2, 3, 5, 8, 12])
+        n_prot = [rnd.choice([3, 4, 7, 12, 20, 33, 48, 70]) for _ in range(B)]
+        n_pharm = [rnd.choice([1, 1, 2, 3, 5, 8, 10]) for _ in range(B)]
+        batch = O.synthetic_batch([900 + 20 * trial + i for i in range(B)], n_prot, n_pharm, cfg)
+        gen = torch.Generator().manual_seed(100 + trial)
+        Nf = int(batch.pharm_ptr[-1])
+        spread = rnd.choice([1.0, 4.0, 12.0])                           # 12 A: most center pairs beyond the 9 A ff cutoff
+        x_t, h_t = spread * torch.randn(Nf, 3, generator=gen), torch.randn(Nf, 6, generator=gen)
+        set_batch(eng, batch)
+        for t in (torch.full((B,), 0.37), torch.rand(B, generator=gen)):
+            eps_h, eps_x = eng.dynamics(x_t, h_t, t)
+            assert eng.kernel_family(0) == 16 and eng.kernel_family(1) == 17, (trial, eng.kernel_family(0), eng.kernel_family(1))
+            oh, ox = O.dynamics_forward(sd, cfg, batch, batch.prot_x, x_t, h_t, t)
+            close(eps_h, oh); close(eps_x, ox)
