@@ -656,7 +656,9 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
     eng = m.dynamics.engine()
     gen = torch.Generator().manual_seed(7 + rank)
     # a rotating set of DISTINCT batches (other pocket order, other center counts: other ptr arrays and coordinates), as a
-    # data loader delivers them: every step pays the per-batch bind (pf_set_pocket_batch) like train.py does
+    # data loader delivers them: every step pays the per-batch bind (pf_set_pocket_batch) like train.py does.  (The int32 host
+    # form of the index arrays is made once per graph object -- PocketGraph.index_arrays_i32, which graph.batch() calls at
+    # collate time, i.e. in the data loader's workers -- so it is not part of the timed steps here either.)
     graphs = []
     for r in range(args.train_batches):
         order = [(i + r * (B // max(args.train_batches, 1))) % B for i in range(B)]

@@ -289,6 +289,12 @@ struct NodeParams {
 // n16 fused launch (pf_n16.hip: k_n16_fused): the LAST conv layer's edge messages with conv layer 0's node update of every
 // item's SOURCE rows computed in front of the item's message chain -- the node launch of conv layer 0 disappears (n_convs = 2,
 // receptive-field pruning, kNN pf edges: the sources of the last layer's edges are exactly the rows that launch updates).
+// regions cleared by one k_zero_multi launch (dword-aligned pointers, byte counts that are multiples of 4)
+struct ZeroList {
+    void* p[8];
+    unsigned long long nbytes[8];
+    int cnt;
+};
 struct FusedParams {
     // conv layer 0's messages and where a node finds them (NodeParams of that layer)
     const int* in_start; const int* in_cnt; int N, pp_slot;

@@ -43,6 +43,7 @@ void pfk_build_edges(const BuildParams* p, hipStream_t s);
 void pfk_load_coords(const float* src, float4* xn, int n, const int* gid, const float* shift, float sign, hipStream_t s);
 void pfk_load_noise0(const float* nz, float4* xn, float* hf, int n, int nf, hipStream_t s);
 void pfk_copy(const float* src, float* dst, size_t n, hipStream_t s);
+void pfk_zero_multi(const ZeroList* z, hipStream_t s);
 void pfk_scale_copy(const float* src, float* dst, size_t n, float sc, hipStream_t s);
 void pfk_segment_mean(const float4* xn, const int* ptr, int base, int B, float* out, hipStream_t s);
 void pfk_step_update(const StepParams* p, hipStream_t s);
@@ -222,6 +223,17 @@ struct pf_handle {
     size_t stage_cap[2] = {0, 0};
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     int stage_next = 0;
+    // The table section lives in two device buffers of its own that alternate between binds, and its upload runs on a
+    // copy stream: a training loop binds a new batch every step, and on the caller's stream the ~8 MB copy would sit
+    // between two steps (0.14 ms of a 2 ms step) instead of under the previous step's kernels.  tab_guard[w]: everything
+    // that read buffer w has finished (recorded on the caller's stream at the start of the bind after the one that
+    // used w); tab_up[w]: the upload into w is complete (the caller's stream waits for it).
+    void* d_tab[2] = {nullptr, nullptr};
+    size_t tab_cap[2] = {0, 0};
+    hipEvent_t tab_guard[2] = {nullptr, nullptr}, tab_up[2] = {nullptr, nullptr};
+    bool tab_guard_set[2] = {false, false};
+    int tab_next = 0;
+    hipStream_t s_copy = nullptr;
     // one-hot check of the protein features (static hoist): 0 unknown (device flag pending), 1 one-hot, 2 not
     int l0_state = 0;
     int* l0flag_host = nullptr;             // pinned; written by an async copy of d_l0flag
@@ -1137,6 +1149,19 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     return PF_OK;
 }
 
+// collects regions to clear and clears them with one launch (flush), eight at a time
+struct ZeroBatch {
+    ZeroList z{};
+    hipStream_t s;
+    explicit ZeroBatch(hipStream_t st) : s(st) {}
+    void add(void* p, size_t nbytes) {
+        if (!p || nbytes == 0) return;
+        if (z.cnt == 8) flush();
+        z.p[z.cnt] = p; z.nbytes[z.cnt] = nbytes; ++z.cnt;
+    }
+    void flush() { pfk_zero_multi(&z, s); z.cnt = 0; }
+};
+
 static int check_ready(pf_handle* h, bool need_batch) {
     if (!h) return PF_ERR_ARG;
     if (!h->committed) PF_FAIL(h, PF_ERR_STATE, "weights not committed (pf_commit_weights)");
@@ -1193,6 +1218,12 @@ void pf_destroy(pf_handle* h) {
     if (h->d_l0c) (void)hipFree(h->d_l0c);
     if (h->d_ptab) (void)hipFree(h->d_ptab);
     for (int k = 0; k < 2; ++k) { if (h->stage[k]) (void)hipHostFree(h->stage[k]); if (h->stage_ev[k]) (void)hipEventDestroy(h->stage_ev[k]); }
+    for (int k = 0; k < 2; ++k) {
+        if (h->d_tab[k]) (void)hipFree(h->d_tab[k]);
+        if (h->tab_guard[k]) (void)hipEventDestroy(h->tab_guard[k]);
+        if (h->tab_up[k]) (void)hipEventDestroy(h->tab_up[k]);
+    }
+    if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
     if (h->l0flag_host) (void)hipHostFree(h->l0flag_host);
     if (h->l0flag_ev) (void)hipEventDestroy(h->l0flag_ev);
     for (int k = 0; k < pf_handle::K_NUM; ++k)
@@ -1578,10 +1609,23 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
         for (int i = prot_ptr[g]; i < prot_ptr[g + 1]; ++i) gid[i] = g;
         for (int i = pharm_ptr[g]; i < pharm_ptr[g + 1]; ++i) gid[Np + i] = g;
     }
-    // every argument check runs before the previous batch's state is touched: a rejected bind leaves the handle as it was
-    for (int64_t e = 0; e < n_pp; ++e) {
-        if (pp_src[e] < 0 || pp_src[e] >= Np || pp_dst[e] < 0 || pp_dst[e] >= Np) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld out of range", (long long)e);
-        if (gid[pp_src[e]] != gid[pp_dst[e]]) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld crosses graphs", (long long)e);
+    // every argument check runs before the previous batch's state is touched: a rejected bind leaves the handle as it was.
+    // One pass over the pp edges checks them and counts the in-degrees (a training loop binds a new batch every step and
+    // this function is most of that step's host time): the graph of an edge is looked up only when the destination leaves
+    // the atom range of the previous edge's graph -- edge lists come grouped by destination.
+    std::vector<int> deg(Np + 1, 0);
+    bool dst_sorted = true;                    // radius_graph and pf_build_pp_edges emit the edges grouped by destination, ascending:
+    {                                          // the stable sort below is then the identity and is skipped
+        int prev_dst = -1, lo = 0, hi = 0;
+        for (int64_t e = 0; e < n_pp; ++e) {
+            const int sn = pp_src[e], dn = pp_dst[e];
+            if ((unsigned)sn >= (unsigned)Np || (unsigned)dn >= (unsigned)Np) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld out of range", (long long)e);
+            if (dn < lo || dn >= hi) { const int g = gid[dn]; lo = prot_ptr[g]; hi = prot_ptr[g + 1]; }
+            if (sn < lo || sn >= hi) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld crosses graphs", (long long)e);
+            dst_sorted &= dn >= prev_dst;
+            prev_dst = dn;
+            deg[dn + 1]++;
+        }
     }
     if (c.message_norm_mode == PF_NORM_GRAPH && c.pf_k > 0)
         for (int g = 0; g < B; ++g)
@@ -1598,18 +1642,6 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     h->h_prot_ptr.assign(prot_ptr, prot_ptr + B + 1);
     h->h_pharm_ptr.assign(pharm_ptr, pharm_ptr + B + 1);
     h->max_np = max_np;
-    // pp edges sorted by destination (stable counting sort): CSR-by-dst
-    std::vector<int> in_start((size_t)4 * N, 0), in_cnt((size_t)4 * N, 0);       // [4 slots][N]: BuildParams::in_start
-    std::vector<int> deg(Np + 1, 0);
-    bool dst_sorted = true;                    // radius_graph and pf_build_pp_edges emit the edges grouped by destination, ascending:
-    int prev_dst = -1;                         // the stable sort below is then the identity and is skipped
-    for (int64_t e = 0; e < n_pp; ++e) {
-        if (pp_src[e] < 0 || pp_src[e] >= Np || pp_dst[e] < 0 || pp_dst[e] >= Np) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld out of range", (long long)e);
-        if (gid[pp_src[e]] != gid[pp_dst[e]]) PF_FAIL(h, PF_ERR_ARG, "pp edge %lld crosses graphs", (long long)e);
-        dst_sorted &= pp_dst[e] >= prev_dst;
-        prev_dst = pp_dst[e];
-        deg[pp_dst[e] + 1]++;
-    }
     for (int i = 0; i < Np; ++i) deg[i + 1] += deg[i];
     std::vector<int> pp_cnt(B, 0);
     // message_norm == 0 with kNN pf edges: the reference derives the per-graph pf / fp edge counts by looking the
@@ -1657,10 +1689,156 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     if (cursor > 0x7fffffffLL / 128) PF_FAIL(h, PF_ERR_ARG, "edge capacity too large");
     h->Ecap = cursor;
     const int64_t Ecap = std::max<int64_t>(cursor, 1);
-    std::vector<int> esrc(Ecap, 0), edst(Ecap, 0);
+    // tiles: dynamic etypes first (they feed the short pharm-side chain), then pp
+    std::vector<EdgeTile> et_tiles;
+    et_tiles.reserve((size_t)n_pp / 32 + (size_t)(Ecap - n_pp) / 8 + 64);
+    for (int et = 0; et < 3; ++et) {
+        h->et_tile0[et] = (int)et_tiles.size();
+        for (int g = 0; g < B; ++g) {
+            const int cap = h->h_cap[(size_t)et * B + g], reg = h->h_reg[(size_t)et * B + g];
+            for (int o = 0; o < cap; o += 32) et_tiles.push_back({reg + o, std::min(32, cap - o), et, et * B + g, o});
+        }
+        // The output of the last conv layer is consumed only on the pharm nodes (dynamics_gvp.py:91), so in
+        // that layer only the etypes with a pharm destination (ff, pf: the first tiles) and only the pharm node
+        // tiles are computed; the reference computes and discards the protein side.
+        if (et == ET_PF) h->n_edge_tiles_last = (int)et_tiles.size();
+    }
+    h->et_tile0[3] = (int)et_tiles.size();
+    for (int64_t o = 0; o < n_pp; o += 32) et_tiles.push_back({(int)o, (int)std::min<int64_t>(32, n_pp - o), ET_PP, -1, 0});
+    h->et_tile0[4] = (int)et_tiles.size();
+    std::vector<NodeTile> n_tiles, h_tiles;
+    n_tiles.reserve((size_t)N / 32 + 8);
+    for (int o = 0; o < Nf; o += 32) {
+        n_tiles.push_back({Np + o, std::min(32, Nf - o), 1, -1, 0, 0});
+        h_tiles.push_back({Np + o, std::min(32, Nf - o), 1, -1, 0, 0});
+    }
+    for (int o = 0; o < Np; o += 32) n_tiles.push_back({o, std::min(32, Np - o), 0, -1, 0, 0});
+    h->n_edge_tiles = (int)et_tiles.size();
+    h->n_node_tiles = (int)n_tiles.size();
+    h->n_head_tiles = (int)h_tiles.size();
+    h->n_node_tiles_last = (int)h_tiles.size();          // pharm tiles come first in n_tiles
+    // pruned layer: ff, pf, fp tiles + pa tiles; pharm node tiles + tiles over the active-atom lists
+    std::vector<EdgeTile> et_act;
+    for (int et = 0; et < 4; ++et) {
+        h->et_tile0_act[et] = (int)et_act.size();
+        for (int g = 0; g < B; ++g) {
+            const int cap = h->h_cap[(size_t)et * B + g], reg = h->h_reg[(size_t)et * B + g];
+            for (int o = 0; o < cap; o += 32) et_act.push_back({reg + o, std::min(32, cap - o), et == 3 ? (int)ET_PP : et, et * B + g, o});
+        }
+    }
+    h->et_tile0_act[4] = (int)et_act.size();
+    std::vector<NodeTile> n_act(h_tiles);
+    for (int g = 0; g < B; ++g)
+        for (int o = 0; o < cap_act[g]; o += 32) n_act.push_back({reg_act[g] + o, std::min(32, cap_act[g] - o), 0, 4 * B + g, o, 1});
+    h->n_edge_tiles_act = (int)et_act.size();
+    h->n_node_tiles_act = (int)n_act.size();
+    mark();      // 1: host tables built
+    // ---- workspace layout: [table section: host-built, uploaded with one copy][zero section][scratch]
+    const size_t n_eta = et_act.size() + 16, n_nta = n_act.size() + 16, n_et = et_tiles.size() + 16, n_nt = n_tiles.size() + 16,
+                 n_ht = h_tiles.size() + 16;
+    auto rnd = [](size_t b) { return (b + 255) & ~size_t(255); };
+    size_t off = 0;
+    auto place = [&](size_t b) { const size_t o = off; off += rnd(b); return o; };
+    // table section (a buffer of its own: offsets relative to d_tab[w])
+    const size_t o_pptr = place((B + 1) * 4), o_fptr = place((B + 1) * 4), o_gid = place((size_t)N * 4), o_reg = place((size_t)4 * B * 4),
+                 o_regact = place((size_t)B * 4), o_eta = place(n_eta * sizeof(EdgeTile)), o_nta = place(n_nta * sizeof(NodeTile)),
+                 o_esrc = place(Ecap * 4), o_edst = place(Ecap * 4), o_ins = place((size_t)4 * N * 4), o_inc = place((size_t)4 * N * 4),
+                 o_ppc = place((size_t)B * 4), o_et = place(n_et * sizeof(EdgeTile)), o_nt = place(n_nt * sizeof(NodeTile)),
+                 o_ht = place(n_ht * sizeof(NodeTile)), o_pfq = place((size_t)B * 4),
+                 o_regs = place((size_t)4 * B * 4), o_pas = place((size_t)B * 4), o_repb = place((size_t)B * 4);
+    const size_t index_bytes = off;
+    const size_t o_px0 = place((size_t)Np * 3 * 4 + 16), o_ph0 = place((size_t)Np * c.rec_nf * 4 + 16);
+    const size_t table_bytes = from_host ? off : index_bytes;      // what the single upload covers
+    const size_t table_total = off;
+    off = 0;                                                       // the workspace proper starts with the zero section
+    // zero section (cleared with one launch per bind)
+    const size_t o_dyn = place((size_t)5 * B * 4), o_act = place((size_t)(act_total + 1) * 4), o_flag = place(256), o_gnorm = place((size_t)2 * B * 4),
+                 o_need = place((size_t)std::max(Np, 1) * 4);
+    const size_t zero_bytes = off;
+    // scratch
+    // (a second set of message rows for the last conv layer: the fused launch of small n_convs = 2 batches writes them while conv
+    // layer 0's are still being read)
+    const bool msg2 = c.n_convs == 2 && (long)h->n_edge_tiles_act * 32 <= h->pol.n16_rows_max;
+    const size_t o_xn = place((size_t)N * 16),
+                 o_fh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_t = place((size_t)B * 4),
+                 o_h0 = place((size_t)N * PF_S * 4), o_h1 = place((size_t)N * PF_S * 4), o_v0 = place((size_t)N * 48 * 4), o_v1 = place((size_t)N * 48 * 4),
+                 o_ms = place((size_t)(Ecap + 1) * PF_S * 4), o_mv = place((size_t)(Ecap + 1) * 48 * 4),
+                 o_ms2 = place(msg2 ? (size_t)(Ecap + 1) * PF_S * 4 : 16), o_mv2 = place(msg2 ? (size_t)(Ecap + 1) * 48 * 4 : 16),
+                 o_eh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_ex = place((size_t)Nf * 3 * 4 + 16), o_c0 = place((size_t)B * 3 * 4), o_c1 = place((size_t)B * 3 * 4),
+                 o_pre = place((size_t)std::max(Np, 1) * PF_S * 4), o_eorig = place(Ecap * 4), o_ptype = place((size_t)std::max(Np, 1) * 4),
+                 o_zs = place((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4), o_ptpg = place((size_t)B * L0_NTAB * c.rec_nf * PF_S * 4);
+    const size_t bytes = off;
+    bool fresh = false;
+    if (h->ws_capacity < bytes + 4096) {
+        // launches of the previous batch may still read the old workspace
+        PF_HIP(h, hipDeviceSynchronize());
+        if (h->d_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; }
+        const size_t want = bytes + bytes / 8 + 4096;           // head room: the next batch of similar size fits without a realloc
+        PF_HIP(h, hipMalloc(&h->d_ws, want));
+        h->ws_capacity = want;
+        fresh = true;
+    }
+    char* const base = reinterpret_cast<char*>(h->d_ws);
+    auto at = [&](size_t o) { return base + o; };
+    // the table buffer of this bind
+    const int tw = h->tab_next;
+    h->tab_next ^= 1;
+    if (!h->s_copy) PF_HIP(h, hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        if (!h->tab_guard[k]) PF_HIP(h, hipEventCreateWithFlags(&h->tab_guard[k], hipEventDisableTiming));
+        if (!h->tab_up[k]) PF_HIP(h, hipEventCreateWithFlags(&h->tab_up[k], hipEventDisableTiming));
+    }
+    if (h->tab_cap[tw] < table_total + 4096) {
+        PF_HIP(h, hipDeviceSynchronize());                       // launches of two binds ago may still read the old buffer
+        if (h->d_tab[tw]) { (void)hipFree(h->d_tab[tw]); h->d_tab[tw] = nullptr; h->tab_cap[tw] = 0; }
+        const size_t want = table_total + table_total / 8 + 4096;
+        PF_HIP(h, hipMalloc(&h->d_tab[tw], want));
+        h->tab_cap[tw] = want;
+        h->tab_guard_set[tw] = false;
+    }
+    char* const tbase = reinterpret_cast<char*>(h->d_tab[tw]);
+    auto tat = [&](size_t o) { return tbase + o; };
+    h->d_prot_ptr = (int*)tat(o_pptr); h->d_pharm_ptr = (int*)tat(o_fptr); h->d_gid = (int*)tat(o_gid); h->d_reg = (int*)tat(o_reg);
+    h->d_reg_act = (int*)tat(o_regact); h->d_edge_tiles_act = (EdgeTile*)tat(o_eta); h->d_node_tiles_act = (NodeTile*)tat(o_nta);
+    h->d_esrc = (int*)tat(o_esrc); h->d_edst = (int*)tat(o_edst); h->d_in_start = (int*)tat(o_ins); h->d_in_cnt = (int*)tat(o_inc);
+    h->d_pp_cnt = (int*)tat(o_ppc); h->d_edge_tiles = (EdgeTile*)tat(o_et); h->d_node_tiles = (NodeTile*)tat(o_nt);
+    h->d_head_tiles = (NodeTile*)tat(o_ht); h->d_pfq_cnt = pfq.empty() ? nullptr : (int*)tat(o_pfq);
+    h->d_reg_share = (int*)tat(o_regs); h->d_pa_static = (int*)tat(o_pas); h->d_rep_base = (int*)tat(o_repb); h->d_need = (int*)at(o_need);
+    h->need_stamp = 0; h->edges_stamp = 0;
+    h->d_dyn_cnt = (int*)at(o_dyn); h->d_act_ids = (int*)at(o_act); h->d_l0flag = (int*)at(o_flag); h->d_gnorm = (float*)at(o_gnorm);
+    h->d_xn = (float4*)at(o_xn); h->d_prot_x0 = (float*)tat(o_px0); h->d_prot_h0 = (float*)tat(o_ph0); h->d_pharm_h = (float*)at(o_fh);
+    h->d_t = (float*)at(o_t); h->d_h[0] = (float*)at(o_h0); h->d_h[1] = (float*)at(o_h1); h->d_v[0] = (float*)at(o_v0); h->d_v[1] = (float*)at(o_v1);
+    h->d_msg_s2 = msg2 ? (float*)at(o_ms2) : nullptr; h->d_msg_v2 = msg2 ? (float*)at(o_mv2) : nullptr;
+    h->d_msg_s = (float*)at(o_ms); h->d_msg_v = (float*)at(o_mv); h->d_eps_h = (float*)at(o_eh); h->d_eps_x = (float*)at(o_ex);
+    h->d_com_init = (float*)at(o_c0); h->d_com_tmp = (float*)at(o_c1); h->d_pre = (float*)at(o_pre); h->d_eorig = (int*)at(o_eorig);
+    h->d_ptype = (int*)at(o_ptype); h->d_zs = (float*)at(o_zs); h->d_ptab_pg = (float*)at(o_ptpg);
+    mark();      // 2: workspace ready
+    // ---- stage the tables in pinned memory and upload them with one asynchronous copy
+    const int sb = h->stage_next;
+    h->stage_next ^= 1;
+    if (!h->stage_ev[sb]) PF_HIP(h, hipEventCreateWithFlags(&h->stage_ev[sb], hipEventDisableTiming));
+    else PF_HIP(h, hipEventSynchronize(h->stage_ev[sb]));       // the copy that last read this buffer (two binds ago) is done
+    if (h->stage_cap[sb] < table_bytes) {
+        if (h->stage[sb]) (void)hipHostFree(h->stage[sb]);
+        h->stage[sb] = nullptr; h->stage_cap[sb] = 0;
+        PF_HIP(h, hipHostMalloc(&h->stage[sb], table_bytes + table_bytes / 4 + 4096, hipHostMallocDefault));
+        h->stage_cap[sb] = table_bytes + table_bytes / 4 + 4096;
+    }
+    mark();      // 3: staging buffer ready
+    char* const st = reinterpret_cast<char*>(h->stage[sb]);
+    // pp edges sorted by destination (stable counting sort): CSR-by-dst.  The big index arrays are built in the staging
+    // buffer itself (5 MB of edges and 2 MB of in-edge ranges at 256 pockets: no intermediate copies)
+    int* const esrc = reinterpret_cast<int*>(st + o_esrc);
+    int* const edst = reinterpret_cast<int*>(st + o_edst);
+    int* const in_start = reinterpret_cast<int*>(st + o_ins);      // [4 slots][N]: BuildParams::in_start
+    int* const in_cnt = reinterpret_cast<int*>(st + o_inc);
+    memset(esrc + n_pp, 0, (size_t)(Ecap - n_pp) * 4);
+    memset(edst + n_pp, 0, (size_t)(Ecap - n_pp) * 4);
+    memset(in_start, 0, (size_t)4 * N * 4);
+    memset(in_cnt, 0, (size_t)4 * N * 4);
     {
         if (dst_sorted) {
-            if (n_pp > 0) { memcpy(esrc.data(), pp_src, (size_t)n_pp * 4); memcpy(edst.data(), pp_dst, (size_t)n_pp * 4); }
+            if (n_pp > 0) { memcpy(esrc, pp_src, (size_t)n_pp * 4); memcpy(edst, pp_dst, (size_t)n_pp * 4); }
             for (int g = 0; g < B; ++g) pp_cnt[g] = deg[prot_ptr[g + 1]] - deg[prot_ptr[g]];
         } else {
             std::vector<int> fill(deg.begin(), deg.end() - 1);
@@ -1732,122 +1910,6 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
             h->share_ok = true;
         }
     }
-    // tiles: dynamic etypes first (they feed the short pharm-side chain), then pp
-    std::vector<EdgeTile> et_tiles;
-    for (int et = 0; et < 3; ++et) {
-        h->et_tile0[et] = (int)et_tiles.size();
-        for (int g = 0; g < B; ++g) {
-            const int cap = h->h_cap[(size_t)et * B + g], reg = h->h_reg[(size_t)et * B + g];
-            for (int o = 0; o < cap; o += 32) et_tiles.push_back({reg + o, std::min(32, cap - o), et, et * B + g, o});
-        }
-        // The output of the last conv layer is consumed only on the pharm nodes (dynamics_gvp.py:91), so in
-        // that layer only the etypes with a pharm destination (ff, pf: the first tiles) and only the pharm node
-        // tiles are computed; the reference computes and discards the protein side.
-        if (et == ET_PF) h->n_edge_tiles_last = (int)et_tiles.size();
-    }
-    h->et_tile0[3] = (int)et_tiles.size();
-    for (int64_t o = 0; o < n_pp; o += 32) et_tiles.push_back({(int)o, (int)std::min<int64_t>(32, n_pp - o), ET_PP, -1, 0});
-    h->et_tile0[4] = (int)et_tiles.size();
-    std::vector<NodeTile> n_tiles, h_tiles;
-    for (int o = 0; o < Nf; o += 32) {
-        n_tiles.push_back({Np + o, std::min(32, Nf - o), 1, -1, 0, 0});
-        h_tiles.push_back({Np + o, std::min(32, Nf - o), 1, -1, 0, 0});
-    }
-    for (int o = 0; o < Np; o += 32) n_tiles.push_back({o, std::min(32, Np - o), 0, -1, 0, 0});
-    h->n_edge_tiles = (int)et_tiles.size();
-    h->n_node_tiles = (int)n_tiles.size();
-    h->n_head_tiles = (int)h_tiles.size();
-    h->n_node_tiles_last = (int)h_tiles.size();          // pharm tiles come first in n_tiles
-    // pruned layer: ff, pf, fp tiles + pa tiles; pharm node tiles + tiles over the active-atom lists
-    std::vector<EdgeTile> et_act;
-    for (int et = 0; et < 4; ++et) {
-        h->et_tile0_act[et] = (int)et_act.size();
-        for (int g = 0; g < B; ++g) {
-            const int cap = h->h_cap[(size_t)et * B + g], reg = h->h_reg[(size_t)et * B + g];
-            for (int o = 0; o < cap; o += 32) et_act.push_back({reg + o, std::min(32, cap - o), et == 3 ? (int)ET_PP : et, et * B + g, o});
-        }
-    }
-    h->et_tile0_act[4] = (int)et_act.size();
-    std::vector<NodeTile> n_act(h_tiles);
-    for (int g = 0; g < B; ++g)
-        for (int o = 0; o < cap_act[g]; o += 32) n_act.push_back({reg_act[g] + o, std::min(32, cap_act[g] - o), 0, 4 * B + g, o, 1});
-    h->n_edge_tiles_act = (int)et_act.size();
-    h->n_node_tiles_act = (int)n_act.size();
-    mark();      // 1: host tables built
-    // ---- workspace layout: [table section: host-built, uploaded with one copy][zero section][scratch]
-    const size_t n_eta = et_act.size() + 16, n_nta = n_act.size() + 16, n_et = et_tiles.size() + 16, n_nt = n_tiles.size() + 16,
-                 n_ht = h_tiles.size() + 16;
-    auto rnd = [](size_t b) { return (b + 255) & ~size_t(255); };
-    size_t off = 0;
-    auto place = [&](size_t b) { const size_t o = off; off += rnd(b); return o; };
-    // table section
-    const size_t o_pptr = place((B + 1) * 4), o_fptr = place((B + 1) * 4), o_gid = place((size_t)N * 4), o_reg = place((size_t)4 * B * 4),
-                 o_regact = place((size_t)B * 4), o_eta = place(n_eta * sizeof(EdgeTile)), o_nta = place(n_nta * sizeof(NodeTile)),
-                 o_esrc = place(Ecap * 4), o_edst = place(Ecap * 4), o_ins = place((size_t)4 * N * 4), o_inc = place((size_t)4 * N * 4),
-                 o_ppc = place((size_t)B * 4), o_et = place(n_et * sizeof(EdgeTile)), o_nt = place(n_nt * sizeof(NodeTile)),
-                 o_ht = place(n_ht * sizeof(NodeTile)), o_pfq = place((size_t)B * 4),
-                 o_regs = place((size_t)4 * B * 4), o_pas = place((size_t)B * 4), o_repb = place((size_t)B * 4);
-    const size_t index_bytes = off;
-    const size_t o_px0 = place((size_t)Np * 3 * 4 + 16), o_ph0 = place((size_t)Np * c.rec_nf * 4 + 16);
-    const size_t table_bytes = from_host ? off : index_bytes;      // what the single upload covers
-    const size_t table_end = off;
-    // zero section (cleared with one memset per bind)
-    const size_t o_dyn = place((size_t)5 * B * 4), o_act = place((size_t)(act_total + 1) * 4), o_flag = place(256), o_gnorm = place((size_t)2 * B * 4),
-                 o_need = place((size_t)std::max(Np, 1) * 4);
-    const size_t zero_bytes = off - table_end;
-    // scratch
-    // (a second set of message rows for the last conv layer: the fused launch of small n_convs = 2 batches writes them while conv
-    // layer 0's are still being read)
-    const bool msg2 = c.n_convs == 2 && (long)h->n_edge_tiles_act * 32 <= h->pol.n16_rows_max;
-    const size_t o_xn = place((size_t)N * 16),
-                 o_fh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_t = place((size_t)B * 4),
-                 o_h0 = place((size_t)N * PF_S * 4), o_h1 = place((size_t)N * PF_S * 4), o_v0 = place((size_t)N * 48 * 4), o_v1 = place((size_t)N * 48 * 4),
-                 o_ms = place((size_t)(Ecap + 1) * PF_S * 4), o_mv = place((size_t)(Ecap + 1) * 48 * 4),
-                 o_ms2 = place(msg2 ? (size_t)(Ecap + 1) * PF_S * 4 : 16), o_mv2 = place(msg2 ? (size_t)(Ecap + 1) * 48 * 4 : 16),
-                 o_eh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_ex = place((size_t)Nf * 3 * 4 + 16), o_c0 = place((size_t)B * 3 * 4), o_c1 = place((size_t)B * 3 * 4),
-                 o_pre = place((size_t)std::max(Np, 1) * PF_S * 4), o_eorig = place(Ecap * 4), o_ptype = place((size_t)std::max(Np, 1) * 4),
-                 o_zs = place((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4), o_ptpg = place((size_t)B * L0_NTAB * c.rec_nf * PF_S * 4);
-    const size_t bytes = off;
-    bool fresh = false;
-    if (h->ws_capacity < bytes + 4096) {
-        // launches of the previous batch may still read the old workspace
-        PF_HIP(h, hipDeviceSynchronize());
-        if (h->d_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; }
-        const size_t want = bytes + bytes / 8 + 4096;           // head room: the next batch of similar size fits without a realloc
-        PF_HIP(h, hipMalloc(&h->d_ws, want));
-        h->ws_capacity = want;
-        fresh = true;
-    }
-    char* const base = reinterpret_cast<char*>(h->d_ws);
-    auto at = [&](size_t o) { return base + o; };
-    h->d_prot_ptr = (int*)at(o_pptr); h->d_pharm_ptr = (int*)at(o_fptr); h->d_gid = (int*)at(o_gid); h->d_reg = (int*)at(o_reg);
-    h->d_reg_act = (int*)at(o_regact); h->d_edge_tiles_act = (EdgeTile*)at(o_eta); h->d_node_tiles_act = (NodeTile*)at(o_nta);
-    h->d_esrc = (int*)at(o_esrc); h->d_edst = (int*)at(o_edst); h->d_in_start = (int*)at(o_ins); h->d_in_cnt = (int*)at(o_inc);
-    h->d_pp_cnt = (int*)at(o_ppc); h->d_edge_tiles = (EdgeTile*)at(o_et); h->d_node_tiles = (NodeTile*)at(o_nt);
-    h->d_head_tiles = (NodeTile*)at(o_ht); h->d_pfq_cnt = pfq.empty() ? nullptr : (int*)at(o_pfq);
-    h->d_reg_share = (int*)at(o_regs); h->d_pa_static = (int*)at(o_pas); h->d_rep_base = (int*)at(o_repb); h->d_need = (int*)at(o_need);
-    h->need_stamp = 0; h->edges_stamp = 0;
-    h->d_dyn_cnt = (int*)at(o_dyn); h->d_act_ids = (int*)at(o_act); h->d_l0flag = (int*)at(o_flag); h->d_gnorm = (float*)at(o_gnorm);
-    h->d_xn = (float4*)at(o_xn); h->d_prot_x0 = (float*)at(o_px0); h->d_prot_h0 = (float*)at(o_ph0); h->d_pharm_h = (float*)at(o_fh);
-    h->d_t = (float*)at(o_t); h->d_h[0] = (float*)at(o_h0); h->d_h[1] = (float*)at(o_h1); h->d_v[0] = (float*)at(o_v0); h->d_v[1] = (float*)at(o_v1);
-    h->d_msg_s2 = msg2 ? (float*)at(o_ms2) : nullptr; h->d_msg_v2 = msg2 ? (float*)at(o_mv2) : nullptr;
-    h->d_msg_s = (float*)at(o_ms); h->d_msg_v = (float*)at(o_mv); h->d_eps_h = (float*)at(o_eh); h->d_eps_x = (float*)at(o_ex);
-    h->d_com_init = (float*)at(o_c0); h->d_com_tmp = (float*)at(o_c1); h->d_pre = (float*)at(o_pre); h->d_eorig = (int*)at(o_eorig);
-    h->d_ptype = (int*)at(o_ptype); h->d_zs = (float*)at(o_zs); h->d_ptab_pg = (float*)at(o_ptpg);
-    mark();      // 2: workspace ready
-    // ---- stage the tables in pinned memory and upload them with one asynchronous copy
-    const int sb = h->stage_next;
-    h->stage_next ^= 1;
-    if (!h->stage_ev[sb]) PF_HIP(h, hipEventCreateWithFlags(&h->stage_ev[sb], hipEventDisableTiming));
-    else PF_HIP(h, hipEventSynchronize(h->stage_ev[sb]));       // the copy that last read this buffer (two binds ago) is done
-    if (h->stage_cap[sb] < table_bytes) {
-        if (h->stage[sb]) (void)hipHostFree(h->stage[sb]);
-        h->stage[sb] = nullptr; h->stage_cap[sb] = 0;
-        PF_HIP(h, hipHostMalloc(&h->stage[sb], table_bytes + table_bytes / 4 + 4096, hipHostMallocDefault));
-        h->stage_cap[sb] = table_bytes + table_bytes / 4 + 4096;
-    }
-    mark();      // 3: staging buffer ready
-    char* const st = reinterpret_cast<char*>(h->stage[sb]);
     memcpy(st + o_pptr, prot_ptr, (size_t)(B + 1) * 4);
     memcpy(st + o_fptr, pharm_ptr, (size_t)(B + 1) * 4);
     memcpy(st + o_gid, gid.data(), (size_t)N * 4);
@@ -1855,10 +1917,6 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     memcpy(st + o_regact, reg_act.data(), (size_t)B * 4);
     if (!et_act.empty()) memcpy(st + o_eta, et_act.data(), et_act.size() * sizeof(EdgeTile));
     if (!n_act.empty()) memcpy(st + o_nta, n_act.data(), n_act.size() * sizeof(NodeTile));
-    memcpy(st + o_esrc, esrc.data(), (size_t)Ecap * 4);
-    memcpy(st + o_edst, edst.data(), (size_t)Ecap * 4);
-    memcpy(st + o_ins, in_start.data(), (size_t)4 * N * 4);
-    memcpy(st + o_inc, in_cnt.data(), (size_t)4 * N * 4);
     memcpy(st + o_ppc, pp_cnt.data(), (size_t)B * 4);
     if (!et_tiles.empty()) memcpy(st + o_et, et_tiles.data(), et_tiles.size() * sizeof(EdgeTile));
     if (!n_tiles.empty()) memcpy(st + o_nt, n_tiles.data(), n_tiles.size() * sizeof(NodeTile));
@@ -1887,31 +1945,43 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
         }
     }
     mark();      // 4: staged
-    PF_HIP(h, hipMemcpyAsync(base, st, table_bytes, hipMemcpyHostToDevice, s));
-    PF_HIP(h, hipEventRecord(h->stage_ev[sb], s));
+    // the upload: on the copy stream, once everything that read this table buffer (the bind before the previous one and its
+    // steps) has finished; the caller's stream continues when it has arrived.  The guard of the OTHER buffer is recorded now:
+    // what is enqueued on the caller's stream at this point is everything that reads it.
+    if (h->tab_guard_set[tw]) PF_HIP(h, hipStreamWaitEvent(h->s_copy, h->tab_guard[tw], 0));
+    PF_HIP(h, hipEventRecord(h->tab_guard[tw ^ 1], s));
+    h->tab_guard_set[tw ^ 1] = true;
+    PF_HIP(h, hipMemcpyAsync(tbase, st, table_bytes, hipMemcpyHostToDevice, h->s_copy));
+    PF_HIP(h, hipEventRecord(h->stage_ev[sb], h->s_copy));
+    PF_HIP(h, hipEventRecord(h->tab_up[tw], h->s_copy));
+    PF_HIP(h, hipStreamWaitEvent(s, h->tab_up[tw], 0));
     mark();      // 5: upload enqueued
-    PF_HIP(h, hipMemsetAsync(base + table_end, 0, zero_bytes, s));
-    PF_HIP(h, hipMemsetAsync(h->d_v[0], 0, (size_t)N * 48 * 4, s));
     // Message rows: the node kernels read only rows the edge kernels of the same layer wrote (the last slot of every
     // aligned group a destination's segment touches) and the all-zero row Ecap, so a reused workspace needs only that row
     // cleared; a fresh allocation is cleared once in full
-    if (fresh) {
-        PF_HIP(h, hipMemsetAsync(h->d_msg_s, 0, (size_t)(Ecap + 1) * PF_S * 4, s));
-        PF_HIP(h, hipMemsetAsync(h->d_msg_v, 0, (size_t)(Ecap + 1) * 48 * 4, s));
-    } else {
-        PF_HIP(h, hipMemsetAsync(h->d_msg_s + (size_t)Ecap * PF_S, 0, PF_S * 4, s));
-        PF_HIP(h, hipMemsetAsync(h->d_msg_v + (size_t)Ecap * 48, 0, 48 * 4, s));
+    {
+        ZeroBatch zb(s);
+        zb.add(base, zero_bytes);
+        zb.add(h->d_v[0], (size_t)N * 48 * 4);
+        if (fresh) {
+            zb.add(h->d_msg_s, (size_t)(Ecap + 1) * PF_S * 4);
+            zb.add(h->d_msg_v, (size_t)(Ecap + 1) * 48 * 4);
+        } else {
+            zb.add(h->d_msg_s + (size_t)Ecap * PF_S, PF_S * 4);
+            zb.add(h->d_msg_v + (size_t)Ecap * 48, 48 * 4);
+        }
+        if (h->d_msg_s2) {
+            if (fresh) {
+                zb.add(h->d_msg_s2, (size_t)(Ecap + 1) * PF_S * 4);
+                zb.add(h->d_msg_v2, (size_t)(Ecap + 1) * 48 * 4);
+            } else {
+                zb.add(h->d_msg_s2 + (size_t)Ecap * PF_S, PF_S * 4);
+                zb.add(h->d_msg_v2 + (size_t)Ecap * 48, 48 * 4);
+            }
+        }
+        zb.flush();
     }
     h->zero_row = (int)Ecap;
-    if (h->d_msg_s2) {
-        if (fresh) {
-            PF_HIP(h, hipMemsetAsync(h->d_msg_s2, 0, (size_t)(Ecap + 1) * PF_S * 4, s));
-            PF_HIP(h, hipMemsetAsync(h->d_msg_v2, 0, (size_t)(Ecap + 1) * 48 * 4, s));
-        } else {
-            PF_HIP(h, hipMemsetAsync(h->d_msg_s2 + (size_t)Ecap * PF_S, 0, PF_S * 4, s));
-            PF_HIP(h, hipMemsetAsync(h->d_msg_v2 + (size_t)Ecap * 48, 0, 48 * 4, s));
-        }
-    }
     if (!from_host) {
         pfk_copy(dev_prot_x, h->d_prot_x0, (size_t)Np * 3, s);
         pfk_copy(dev_prot_h, h->d_prot_h0, (size_t)Np * c.rec_nf, s);
@@ -2314,16 +2384,20 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     h->t_gs_buf = carve<float>(cur, Es * PF_S); h->t_gv_buf = carve<float>(cur, Es * 48);
     // message buffers: the zero row (index Ecap) must read as zeros; V[0] is the all-zero initial vector state
     // (only rows written by the same forward and the zero row are ever read: a reused allocation needs just that row)
-    for (int l = 0; l < L; ++l) {
-        if (fresh) {
-            PF_HIP(h, hipMemsetAsync(h->t_msg_s[l], 0, E1 * PF_S * 4, s));
-            PF_HIP(h, hipMemsetAsync(h->t_msg_v[l], 0, E1 * 48 * 4, s));
-        } else {
-            PF_HIP(h, hipMemsetAsync(h->t_msg_s[l] + (E1 - 1) * PF_S, 0, PF_S * 4, s));
-            PF_HIP(h, hipMemsetAsync(h->t_msg_v[l] + (E1 - 1) * 48, 0, 48 * 4, s));
+    {
+        ZeroBatch zb(s);
+        for (int l = 0; l < L; ++l) {
+            if (fresh) {
+                zb.add(h->t_msg_s[l], E1 * PF_S * 4);
+                zb.add(h->t_msg_v[l], E1 * 48 * 4);
+            } else {
+                zb.add(h->t_msg_s[l] + (E1 - 1) * PF_S, PF_S * 4);
+                zb.add(h->t_msg_v[l] + (E1 - 1) * 48, 48 * 4);
+            }
         }
+        zb.add(h->t_V[0], (size_t)N * 48 * 4);
+        zb.flush();
     }
-    PF_HIP(h, hipMemsetAsync(h->t_V[0], 0, (size_t)N * 48 * 4, s));
     h->t_ws_ready = true;
     return PF_OK;
 }
@@ -2511,8 +2585,12 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         // are the source of a pf edge (the active atoms); every other row of its output has a zero gradient.  Same
         // tile lists as the pruned forward.
         const bool pruned = h->prune && L >= 2 && l == L - 2;
-        PF_HIP(h, hipMemsetAsync(h->t_G_h[a ^ 1], 0, (size_t)N * PF_S * 4, s));
-        PF_HIP(h, hipMemsetAsync(h->t_G_v[a ^ 1], 0, (size_t)N * 48 * 4, s));
+        {
+            ZeroBatch zb(s);
+            zb.add(h->t_G_h[a ^ 1], (size_t)N * PF_S * 4);
+            zb.add(h->t_G_v[a ^ 1], (size_t)N * 48 * 4);
+            zb.flush();
+        }
         BwdNodeParams n{};
         n.c = tc; n.tiles = pruned ? h->d_node_tiles_act : h->d_node_tiles;
         n.ntiles = last ? h->n_node_tiles_last : (pruned ? h->n_node_tiles_act : h->n_node_tiles);

@@ -1701,6 +1701,22 @@ __global__ void k_copy(const float* src, float* dst, const size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
 }
+// clear up to eight regions with one launch (a bind clears four small-to-medium regions, the training workspace five: one
+// launch of ~5 us each as separate memsets).  Regions are dword-aligned; 16-byte aligned ones are cleared with b128 stores.
+__global__ __launch_bounds__(256) void k_zero_multi(const ZeroList z) {
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    for (int r = 0; r < z.cnt; ++r) {
+        char* const p = reinterpret_cast<char*>(z.p[r]);
+        const size_t nb = z.nbytes[r];
+        if (((reinterpret_cast<uintptr_t>(p) | nb) & 15) == 0) {
+            float4* q = reinterpret_cast<float4*>(p);
+            for (size_t i = t0; i < (nb >> 4); i += nt) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            float* q = reinterpret_cast<float*>(p);
+            for (size_t i = t0; i < (nb >> 2); i += nt) q[i] = 0.f;
+        }
+    }
+}
 // per-graph mean of coordinates (dgl.readout_nodes op='mean'); one wave per graph, fixed order
 __global__ __launch_bounds__(64) void k_segment_mean(const float4* xn, const int* ptr, const int base, float* out) {
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -2153,6 +2169,13 @@ void pfk_load_noise0(const float* nz, float4* xn, float* hf, int n, int nf, hipS
 void pfk_copy(const float* src, float* dst, size_t n, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+}
+void pfk_zero_multi(const ZeroList* z, hipStream_t s) {
+    if (z->cnt == 0) return;
+    size_t big = 0;
+    for (int r = 0; r < z->cnt; ++r) big = std::max(big, (size_t)z->nbytes[r]);
+    const unsigned blocks = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (big / 16 + 255) / 256));
+    hipLaunchKernelGGL(k_zero_multi, dim3(blocks), dim3(256), 0, s, *z);
 }
 void pfk_scale_copy(const float* src, float* dst, size_t n, float sc, hipStream_t s) {
     if (n == 0) return;

@@ -232,7 +232,11 @@ __device__ int g_pft_nstamp;
 #ifndef PFT_STAMP_MIN
 #define PFT_STAMP_MIN 0
 #endif
-#define PFT_STAMP(id) do { if ((id) >= PFT_STAMP_MIN && blockIdx.x == PFT_STAMP_BLOCK && threadIdx.x == 0 && g_pft_nstamp < 126) { g_pft_stamps[g_pft_nstamp] = ((unsigned long long)(id) << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull); g_pft_nstamp++; } } while (0)
+#ifndef PFT_STAMP_SKIP_LO
+#define PFT_STAMP_SKIP_LO 1000
+#define PFT_STAMP_SKIP_HI 1000
+#endif
+#define PFT_STAMP(id) do { if ((id) >= PFT_STAMP_MIN && !((id) >= PFT_STAMP_SKIP_LO && (id) <= PFT_STAMP_SKIP_HI) && blockIdx.x == PFT_STAMP_BLOCK && threadIdx.x == 0 && g_pft_nstamp < 126) { g_pft_stamps[g_pft_nstamp] = ((unsigned long long)(id) << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull); g_pft_nstamp++; } } while (0)
 #else
 #define PFT_STAMP(id) do { } while (0)
 #endif
@@ -496,6 +500,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
         for (int sub = unit & 1; sub == (unit & 1) && sub * TR < t.n; sub += 2) {
             const int nv = min(TR, t.n - sub * TR);
             const int n0 = t.n0 + sub * TR;
+            PFT_STAMP(40);
             float* S0 = L.Sin(0); float* V0 = L.Vin(0);
             for (int idx = tid; idx < TR * 32; idx += NT) {
                 const int row = idx >> 5, q = idx & 31;
@@ -516,9 +521,11 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
                 s_ge[row * 8 + o] = row < nv ? p.g_eps_h[(size_t)(n0 - p.node_base + row) * NF + o] : 0.f;
             }
             __syncthreads();
+            PFT_STAMP(41);
             const bool saved = p.sv_z != nullptr;
             if (!saved) chain_fwd(L, p.g, W, pk, nullptr, tid, lane, wv);
             else chain_load(L, p.g, p.sv_z, p.sv_g, p.sv_v, p.sv_stride, (size_t)(n0 - p.node_base), nv, nullptr, tid);
+            PFT_STAMP(42);
             // to_scalar_output: eps_h = Wout act + b ; eps_x = the single output vector channel
             for (int idx = tid; idx < TR * SOL; idx += NT) {
                 const int row = idx & 15, k = idx >> 4;
@@ -542,8 +549,10 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
                 L.gVX[row * VWS + cc] = row < nv ? p.g_eps_x[(size_t)(n0 - p.node_base + row) * 3 + cc] : 0.f;
             }
             __syncthreads();
+            PFT_STAMP(43);
             float *gs, *gv;
             chain_bwd(L, p.g, W, pk, unit == (int)blockIdx.x, gp, gs, gv, tid, lane, wv, saved);
+            PFT_STAMP(44);
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx >> 7, f = idx & 127;
                 if (row < nv) p.G_h[(size_t)(n0 + row) * PF_S + f] = gs[row * SWS + f];
@@ -615,6 +624,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
         for (int sub = unit & 1; sub == (unit & 1) && sub * TR < tn; sub += 2) {
             const int nv = min(TR, tn - sub * TR);
             const int n0 = t.n0 + sub * TR;
+            PFT_STAMP(20);
             if (tid < TR) {
                 const int pos = n0 + min(tid, nv - 1);
                 const int n = t.ids ? p.row_ids[pos] : pos;      // pruned layer: rows are positions in the active-atom list
@@ -662,6 +672,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 }
             }
             __syncthreads();
+            PFT_STAMP(21);
             // ---- LN1: u -> Sin(0), vu -> Vin(0)
             {
                 const float mean = row_mean128([&](int r, int f) { return xh1[r * ZS + f]; }, red, tid);
@@ -683,9 +694,11 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 L.Vin(0)[row * VWS + q] = vy[row * VWS + q] / s_vl1[row].den;
             }
             __syncthreads();
+            PFT_STAMP(22);
             const bool saved = p.sv_z != nullptr;
             if (!saved) chain_fwd(L, g, W, pk, rvl, tid, lane, wv);
             else chain_load(L, g, p.sv_z, p.sv_g, p.sv_v, p.sv_stride, (size_t)(t.ids ? p.N : 0) + n0, nv, rvl, tid);
+            PFT_STAMP(23);
             // ---- residual dropout, residual, LN2 statistics
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx & 15, f = idx >> 4;
@@ -711,6 +724,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 }
             }
             __syncthreads();
+            PFT_STAMP(24);
             // ---- backward: LN2
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx >> 7, f = idx & 127;
@@ -748,8 +762,10 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 L.gVX[row * VWS + q] = gvu[row * VWS + q] * drop_mul(p.c, st_res, (uint32_t)s_n[row] * 144u + 128u + (uint32_t)(q / 3));
             }
             __syncthreads();
+            PFT_STAMP(25);
             float *gs, *gv;
             chain_bwd(L, g, W, pk, !seen[nt], gp, gs, gv, tid, lane, wv, saved);
+            PFT_STAMP(26);
             seen[nt] = true;
             // ---- LN1 backward
             for (int idx = tid; idx < TR * 128; idx += NT) {
@@ -784,6 +800,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 }
             }
             __syncthreads();
+            PFT_STAMP(27);
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx >> 7, f = idx & 127;
                 if (row < nv) {

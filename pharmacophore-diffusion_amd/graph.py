@@ -76,9 +76,26 @@ class PocketGraph:
     def to(self, device) -> "PocketGraph":
         def mv(t):
             return None if t is None else t.to(device)
-        return replace(self, prot_x=mv(self.prot_x), prot_h=mv(self.prot_h), pharm_x0=mv(self.pharm_x0),
-                       pharm_h0=mv(self.pharm_h0), prot_ph_x=mv(self.prot_ph_x), prot_ph_h=mv(self.prot_ph_h),
-                       x_t=mv(self.x_t), h_t=mv(self.h_t))
+        out = replace(self, prot_x=mv(self.prot_x), prot_h=mv(self.prot_h), pharm_x0=mv(self.pharm_x0),
+                      pharm_h0=mv(self.pharm_h0), prot_ph_x=mv(self.prot_ph_x), prot_ph_h=mv(self.prot_ph_h),
+                      x_t=mv(self.x_t), h_t=mv(self.h_t))
+        if "_i32_cache" in self.__dict__:          # the index tensors are shared with the copy
+            out.__dict__["_i32_cache"] = self.__dict__["_i32_cache"]
+        return out
+
+    def index_arrays_i32(self):
+        """(prot_ptr, pharm_ptr, pp_src, pp_dst) as contiguous int32 numpy arrays -- the form pf_set_pocket_batch takes.
+        Made once per graph object (batch() does it at collate time, i.e. in the data loader and off the training step's
+        critical path: the int64 -> int32 conversion of ~1.3 M edge indices costs 0.3 ms per bind otherwise) and dropped
+        when an index tensor is replaced or written in place."""
+        idx = (self.prot_ptr, self.pharm_ptr, self.pp_src, self.pp_dst)
+        key = tuple((t.data_ptr(), t.numel(), t._version) for t in idx)
+        c = self.__dict__.get("_i32_cache")
+        if c is None or c[0] != key:
+            import numpy as np
+            c = (key, tuple(np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.int32) for t in idx))
+            self.__dict__["_i32_cache"] = c
+        return c[1]
 
     def batch_idxs(self) -> Dict[str, torch.Tensor]:
         return get_batch_idxs(self)
@@ -130,9 +147,11 @@ def batch(graphs: List[PocketGraph]) -> PocketGraph:
     if any(g.pocket_uid is not None for g in graphs):
         uid = torch.cat([g.pocket_uid if g.pocket_uid is not None else -((next(_pocket_uids) << 20) + torch.arange(g.batch_size))
                          for g in graphs])
-    return PocketGraph(cat("prot_x"), cat("prot_h"), _ptr(prot_counts), _ptr(pharm_counts), torch.cat(srcs), torch.cat(dsts),
-                       cat("pharm_x0"), cat("pharm_h0"), cat("prot_ph_x"), cat("prot_ph_h"), _ptr(ph_counts),
-                       cat("x_t"), cat("h_t"), pp_ptr, uid)
+    out = PocketGraph(cat("prot_x"), cat("prot_h"), _ptr(prot_counts), _ptr(pharm_counts), torch.cat(srcs), torch.cat(dsts),
+                      cat("pharm_x0"), cat("pharm_h0"), cat("prot_ph_x"), cat("prot_ph_h"), _ptr(ph_counts),
+                      cat("x_t"), cat("h_t"), pp_ptr, uid)
+    out.index_arrays_i32()          # the engine's int32 view of the index arrays, made here (collate time)
+    return out
 
 
 def unbatch(g: PocketGraph) -> List[PocketGraph]:

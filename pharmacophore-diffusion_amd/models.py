@@ -348,11 +348,12 @@ class PharmRecDynamicsGVP(nn.Module):
         to another batch (a temporary such as ``training_step(g.to(dev))`` is kept alive until the next bind)."""
         eng = self.engine()
         static = (g.prot_x if prot_x is None else prot_x, g.prot_h, g.pp_src, g.pp_dst)
+        pptr32, fptr32, src32, dst32 = g.index_arrays_i32()
         key = (tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in static),
-               tuple(g.prot_ptr.tolist()), tuple(g.pharm_ptr.tolist()),
+               pptr32.tobytes(), fptr32.tobytes(),
                None if g.pocket_uid is None else tuple(g.pocket_uid.tolist()))
         if key != self._batch_key:
-            eng.set_batch(static[0], g.prot_h, g.prot_ptr, g.pharm_ptr, g.pp_src, g.pp_dst,
+            eng.set_batch(static[0], g.prot_h, pptr32, fptr32, src32, dst32,
                           pocket_uid=g.pocket_uid if prot_x is None else None)
             self._batch_key = key
             self._bound_static = static
