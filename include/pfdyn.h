@@ -196,17 +196,22 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h /*[Nf,pharm_nf]*/, 
  * tables at t_int (:186-197: dev_alpha[k] = alpha(gamma(k / T)), likewise sigma), the COM of the noised centers is removed
  * when remove_com (:199-205), the dynamics run in train() mode (pf_train_forward), and dev_out receives
  *   [0] pos loss  [1] feat loss  (:208-232, weighted by 1 - t when weighted_loss)
- *   [2] position error  [3] weighted position error  [4] accuracy  [5] weighted accuracy  (:234-241).
+ *   [2] position error  [3] weighted position error  [4] accuracy  [5] weighted accuracy  (:234-241)
+ *   [6] total loss = [0] + [1]  [7] total error = [2] + 1 - [4]  [8] weighted total error = [3] + 1 - [5]  (what
+ *       training_step / validation_step derive, :274-277, :303-306).
  * dev_pharm_h0 are the raw feature one-hots (divided by feat_norm inside).  The protein coordinates are the bound ones.
  * pf_train_loss_backward(g_pos, g_feat) = d(g_pos * pos loss + g_feat * feat loss)/d(parameters), the two upstream
- * scalars read from device memory; it consumes the state of the forward (one backward per forward). */
+ * scalars read from device memory; it consumes the state of the forward (one backward per forward).
+ * pf_train_loss_backward_out takes the upstream gradient of all nine outputs instead (what autograd hands the node that
+ * produced dev_out): g_pos = g_out[0] + g_out[6], g_feat = g_out[1] + g_out[6]; the metrics' entries are ignored. */
 int pf_train_loss_forward(pf_handle* h, const float* dev_pharm_x0 /*[Nf,3]*/, const float* dev_pharm_h0 /*[Nf,pharm_nf]*/,
                           const int32_t* dev_t_int /*[B]*/, const float* dev_eps_x /*[Nf,3]*/, const float* dev_eps_h /*[Nf,pharm_nf]*/,
                           const float* dev_alpha /*[>= max t_int + 1]*/, const float* dev_sigma, int32_t n_timesteps, float feat_norm,
-                          int32_t remove_com, int32_t weighted_loss, float dropout_p, uint32_t seed, float* dev_out /*[6]*/,
+                          int32_t remove_com, int32_t weighted_loss, float dropout_p, uint32_t seed, float* dev_out /*[9]*/,
                           pf_stream stream);
 int pf_train_loss_backward(pf_handle* h, const float* dev_g_pos /*[1]*/, const float* dev_g_feat /*[1]*/,
                            float* dev_grad /*[n_params]*/, pf_stream stream);
+int pf_train_loss_backward_out(pf_handle* h, const float* dev_g_out /*[9]*/, float* dev_grad /*[n_params]*/, pf_stream stream);
 /* the flat parameter vector on the device: set = copy in + refresh the packed MFMA-fragment weights by a device gather
  * (what an optimiser step calls instead of 245 x pf_set_weight + pf_commit_weights); get = copy out */
 int pf_set_flat_params(pf_handle* h, const float* dev_flat /*[n_params]*/, pf_stream stream);

@@ -58,6 +58,7 @@ SYMBOLS = {
     "pf_train_loss_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_float, ctypes.c_int32,
                                              ctypes.c_int32, ctypes.c_float, ctypes.c_uint32, _P, _P]),
     "pf_train_loss_backward": (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    "pf_train_loss_backward_out": (ctypes.c_int, [_P, _P, _P, _P]),
     "pf_set_flat_params": (ctypes.c_int, [_P, _P, _P]),
     "pf_get_flat_params": (ctypes.c_int, [_P, _P, _P]),
     "pf_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _P]),

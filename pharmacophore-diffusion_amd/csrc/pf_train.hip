@@ -420,32 +420,46 @@ __device__ __forceinline__ void chain_fwd(const ChainLds& L, const GvpT* g, cons
 // ~30 k cycles per GVP of the recomputation.  The sh columns of every Sin are filled by gvp_bwd (fill_sh).
 __device__ __forceinline__ void chain_load(const ChainLds& L, const GvpT* g, const float* sv_z, const float* sv_g, const float* sv_v,
                                            const size_t stride, const size_t i0, const int nv, float* vout_last, const int tid) {
-    for (int l = 0; l < L.nlv; ++l) {
-        const bool last = l == L.nlv - 1;
-        const int so = g[l].so, vo = g[l].vo;
-        const float* zl = sv_z + ((size_t)l * stride + i0) * PF_S;
-        const float* gl = sv_g + ((size_t)l * stride + i0) * 16;
-        const float* vl = sv_v + ((size_t)l * stride + i0) * 48;
-        float* Zl = L.Z(l); float* act = last ? L.actl : L.Sin(l + 1);
-        float* gt = L.gate(l);
-        float* vout = last ? vout_last : L.Vin(l + 1);
-        const int astr = last ? ZS : SWS;
-        for (int idx = tid; idx < TR * so; idx += NT) {
-            const int row = idx / so, k = idx - row * so;
-            const float z = zl[(size_t)min(row, nv - 1) * PF_S + k];
-            Zl[row * ZS + k] = z;
-            act[row * astr + k] = t_silu(z);
+    // every level's rows are requested before any is consumed: one thread = one 16-byte piece of a Z row (16 rows x 32
+    // pieces = the block), the first 64 threads a piece of a gate row, the first 192 a piece of a vector row
+    const int zr = tid >> 5, zk = (tid & 31) * 4;
+    const int gr = (tid >> 2) & 15, gk = (tid & 3) * 4;
+    const int vr = min(tid / 12, 15), vk = (tid - (tid / 12) * 12) * 4;
+    float4 zq[PFT_MAX_CHAIN], gq[PFT_MAX_CHAIN], vq[PFT_MAX_CHAIN];
+#pragma unroll
+    for (int l = 0; l < PFT_MAX_CHAIN; ++l) {
+        zq[l] = gq[l] = vq[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l < L.nlv) {
+            const size_t r0 = (size_t)l * stride + i0;
+            zq[l] = *reinterpret_cast<const float4*>(sv_z + (r0 + min(zr, nv - 1)) * PF_S + zk);
+            if (tid < 64) gq[l] = *reinterpret_cast<const float4*>(sv_g + (r0 + min(gr, nv - 1)) * 16 + gk);
+            if (tid < 192) vq[l] = *reinterpret_cast<const float4*>(sv_v + (r0 + min(vr, nv - 1)) * 48 + vk);
         }
-        for (int idx = tid; idx < TR * vo; idx += NT) {
-            const int row = idx / vo, u = idx - row * vo;
-            gt[row * GTS + u] = gl[(size_t)min(row, nv - 1) * 16 + u];
-        }
-        if (vout != nullptr)
-            for (int idx = tid; idx < TR * vo * 3; idx += NT) {
-                const int row = idx / (vo * 3), q = idx - row * (vo * 3);
-                vout[row * VWS + q] = vl[(size_t)min(row, nv - 1) * 48 + q];
-            }
     }
+#pragma unroll
+    for (int l = 0; l < PFT_MAX_CHAIN; ++l)
+        if (l < L.nlv) {
+            const bool last = l == L.nlv - 1;
+            const int so = g[l].so, vo = g[l].vo;
+            float* Zl = L.Z(l); float* act = last ? L.actl : L.Sin(l + 1);
+            float* gt = L.gate(l);
+            float* vout = last ? vout_last : L.Vin(l + 1);
+            const int astr = last ? ZS : SWS;
+            const float zv[4] = {zq[l].x, zq[l].y, zq[l].z, zq[l].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (zk + q < so) { Zl[zr * ZS + zk + q] = zv[q]; act[zr * astr + zk + q] = t_silu(zv[q]); }
+            if (tid < 64) {
+                const float gv[4] = {gq[l].x, gq[l].y, gq[l].z, gq[l].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (gk + q < vo) gt[gr * GTS + gk + q] = gv[q];
+            }
+            if (vout != nullptr && tid < 192) {
+                const float vv[4] = {vq[l].x, vq[l].y, vq[l].z, vq[l].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (vk + q < vo * 3) vout[vr * VWS + vk + q] = vv[q];
+            }
+        }
     __syncthreads();
 }
 // backward through the chain: upstream gradients in L.gX ([row][so_last], stride SWS) and L.gVX; returns through
@@ -594,11 +608,54 @@ __device__ __forceinline__ void vec_ln_bwd_row(const float* v, const VecLn st, f
     }
 }
 
+// sum over the 128 features of row tid >> 5 of f(row, feature), inside a half wave (lane l of the half takes features l, l + 32,
+// l + 64, l + 96): no LDS, no barrier -- a row's scalar-LayerNorm statistics stay within the 32 lanes that also normalise it
+template <typename F>
+__device__ __forceinline__ float row_sum128_hw(F f, const int tid) {
+    const int row = tid >> 5, l = tid & 31;
+    float s = (f(row, l) + f(row, l + 32)) + (f(row, l + 64) + f(row, l + 96));
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+// the vector statistics of all 16 rows at once: thread (row = tid >> 4, channel = tid & 15) of the first 256
+__device__ __forceinline__ void vec_ln_stats_par(const float* v, VecLn* out, const int tid) {
+    if (tid < 256) {
+        const int row = tid >> 4, ch = tid & 15;
+        const float* q = v + row * VWS + ch * 3;
+        float m = fmaxf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2], 1e-8f);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m += __shfl_xor(m, o);
+        if (ch == 0) {
+            VecLn r;
+            r.sq = t_sqrt(m * (1.0f / PF_V) + 1e-5f);
+            r.den = r.sq + 1e-5f;
+            out[row] = r;
+        }
+    }
+}
+// vec_ln_bwd_row for all 16 rows: thread (row, channel) owns its three entries of g
+__device__ __forceinline__ void vec_ln_bwd_par(const float* v, const VecLn* st, float* g, const int tid) {
+    if (tid < 256) {
+        const int row = tid >> 4, ch = tid & 15;
+        const float* q = v + row * VWS + ch * 3;
+        float* gq = g + row * VWS + ch * 3;
+        float D = gq[0] * q[0] + gq[1] * q[1] + gq[2] * q[2];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) D += __shfl_xor(D, o);
+        const VecLn s = st[row];
+        const float coef = D / (s.den * s.den) / (PF_V * s.sq);
+        const float rden = 1.0f / s.den;
+        const float ind = (q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) > 1e-8f ? 1.0f : 0.0f;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) gq[cc] = gq[cc] * rden - coef * ind * q[cc];
+    }
+}
+
 __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
     __shared__ float lds[CHAIN_FLOATS(NODE_LVLS)];
     __shared__ float xh1[TR * ZS], xh2[TR * ZS], gu[TR * ZS];
     __shared__ float vy[TR * VWS], vz[TR * VWS], gvu[TR * VWS], rvl[TR * VWS];
-    __shared__ float red[NT];
     __shared__ float s_rstd1[TR], s_rstd2[TR], s_inv[TR];
     __shared__ VecLn s_vl1[TR], s_vl2[TR];
     __shared__ int s_n[TR];
@@ -609,6 +666,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
     zero_class(p.c, gp, PFT_CLS_NODE + p.layer, threadIdx.x);
     const PackPtr pk = {p.c.wpack_f, p.c.wpack_b};
     bool seen[2] = {false, false};          // weight-gradient tiles of a node type: the first unit stores onto the cleared copy without reading it
+    float a_ln[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // threads < 128: LayerNorm weight / bias gradients of feature tid, per node type, over all units
     const uint32_t st_msg = (uint32_t)p.layer * 2u, st_res = st_msg + 1u;
     // the non-empty 16-row units of the launch, dealt round-robin (k_compact_units): dealt by table index, the units of the
     // active-atom tiles (capacity 256 atoms per graph, ~60 in use) left every other block with half as much again to do
@@ -618,7 +676,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
         const NodeTile t = p.tiles[unit >> 1];
         const int nt = t.ntype;
         const GvpT* g = p.upd + nt * p.n_upd;
-        const int o_l1w = p.o_ln[nt][0], o_l1b = p.o_ln[nt][1], o_l2w = p.o_ln[nt][2], o_l2b = p.o_ln[nt][3];
+        const int o_l1w = p.o_ln[nt][0], o_l1b = p.o_ln[nt][1], o_l2w = p.o_ln[nt][2];
         int tn = t.n;
         if (t.cnt_idx >= 0) tn = min(tn, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
         for (int sub = unit & 1; sub == (unit & 1) && sub * TR < tn; sub += 2) {
@@ -675,18 +733,19 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
             PFT_STAMP(21);
             // ---- LN1: u -> Sin(0), vu -> Vin(0)
             {
-                const float mean = row_mean128([&](int r, int f) { return xh1[r * ZS + f]; }, red, tid);
-                const float var = row_mean128([&](int r, int f) { const float d = xh1[r * ZS + f] - mean; return d * d; }, red, tid);
+                const int row = tid >> 5, l32 = tid & 31;
+                const float mean = row_sum128_hw([&](int r, int f) { return xh1[r * ZS + f]; }, tid) * (1.0f / 128.0f);
+                const float var = row_sum128_hw([&](int r, int f) { const float d = xh1[r * ZS + f] - mean; return d * d; }, tid) * (1.0f / 128.0f);
                 const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
-                const int row = tid & 15, part = tid >> 4;
-                if (part == 0) { s_rstd1[row] = rstd; s_vl1[row] = vec_ln_stats(vy + row * VWS); }
+                if (l32 == 0) s_rstd1[row] = rstd;
 #pragma unroll
-                for (int q = 0; q < FPP; ++q) {
-                    const int f = part * FPP + q;
+                for (int q = 0; q < 4; ++q) {
+                    const int f = l32 + 32 * q;
                     const float xh = (xh1[row * ZS + f] - mean) * rstd;
                     xh1[row * ZS + f] = xh;
                     L.Sin(0)[row * SWS + f] = xh * W[o_l1w + f] + W[o_l1b + f];
                 }
+                vec_ln_stats_par(vy, s_vl1, tid);
             }
             __syncthreads();
             for (int idx = tid; idx < TR * 48; idx += NT) {
@@ -712,16 +771,17 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
             }
             __syncthreads();
             {
-                const float mean = row_mean128([&](int r, int f) { return xh2[r * ZS + f]; }, red, tid);
-                const float var = row_mean128([&](int r, int f) { const float d = xh2[r * ZS + f] - mean; return d * d; }, red, tid);
+                const int row = tid >> 5, l32 = tid & 31;
+                const float mean = row_sum128_hw([&](int r, int f) { return xh2[r * ZS + f]; }, tid) * (1.0f / 128.0f);
+                const float var = row_sum128_hw([&](int r, int f) { const float d = xh2[r * ZS + f] - mean; return d * d; }, tid) * (1.0f / 128.0f);
                 const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
-                const int row = tid & 15, part = tid >> 4;
-                if (part == 0) { s_rstd2[row] = rstd; s_vl2[row] = vec_ln_stats(vz + row * VWS); }
+                if (l32 == 0) s_rstd2[row] = rstd;
 #pragma unroll
-                for (int q = 0; q < FPP; ++q) {
-                    const int f = part * FPP + q;
+                for (int q = 0; q < 4; ++q) {
+                    const int f = l32 + 32 * q;
                     xh2[row * ZS + f] = (xh2[row * ZS + f] - mean) * rstd;
                 }
+                vec_ln_stats_par(vz, s_vl2, tid);
             }
             __syncthreads();
             PFT_STAMP(24);
@@ -738,23 +798,22 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
             if (tid < 128) {
                 float sw = 0.f, sb = 0.f;
                 for (int r = 0; r < TR; ++r) { const float go = gu[r * ZS + tid]; sw += go * xh2[r * ZS + tid]; sb += go; }
-                gp[o_l2w + tid] += sw;
-                gp[o_l2b + tid] += sb;
+                if (nt == 0) { a_ln[0][2] += sw; a_ln[0][3] += sb; } else { a_ln[1][2] += sw; a_ln[1][3] += sb; }
             }
             {
-                const float m1 = row_mean128([&](int r, int f) { return gu[r * ZS + f] * W[o_l2w + f]; }, red, tid);
-                const float m2 = row_mean128([&](int r, int f) { return gu[r * ZS + f] * W[o_l2w + f] * xh2[r * ZS + f]; }, red, tid);
-                const int row = tid & 15, part = tid >> 4;
+                const int row = tid >> 5, l32 = tid & 31;
+                const float m1 = row_sum128_hw([&](int r, int f) { return gu[r * ZS + f] * W[o_l2w + f]; }, tid) * (1.0f / 128.0f);
+                const float m2 = row_sum128_hw([&](int r, int f) { return gu[r * ZS + f] * W[o_l2w + f] * xh2[r * ZS + f]; }, tid) * (1.0f / 128.0f);
                 const float rstd = s_rstd2[row];
-                __syncthreads();
+                __syncthreads();                                                   // the column sums above have read gu
 #pragma unroll
-                for (int q = 0; q < FPP; ++q) {
-                    const int f = part * FPP + q;
+                for (int q = 0; q < 4; ++q) {
+                    const int f = l32 + 32 * q;
                     const float gz = rstd * (gu[row * ZS + f] * W[o_l2w + f] - m1 - xh2[row * ZS + f] * m2);
                     gu[row * ZS + f] = gz;                                     // dL/du (residual path)
                     L.gX[row * SWS + f] = gz * drop_mul(p.c, st_res, (uint32_t)s_n[row] * 144u + (uint32_t)f);
                 }
-                if (tid < TR) vec_ln_bwd_row(vz + tid * VWS, s_vl2[tid], gvu + tid * VWS);
+                vec_ln_bwd_par(vz, s_vl2, gvu, tid);
             }
             __syncthreads();
             for (int idx = tid; idx < TR * 48; idx += NT) {
@@ -780,24 +839,21 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
             if (tid < 128) {
                 float sw = 0.f, sb = 0.f;
                 for (int r = 0; r < TR; ++r) { const float go = gu[r * ZS + tid]; sw += go * xh1[r * ZS + tid]; sb += go; }
-                gp[o_l1w + tid] += sw;
-                gp[o_l1b + tid] += sb;
+                if (nt == 0) { a_ln[0][0] += sw; a_ln[0][1] += sb; } else { a_ln[1][0] += sw; a_ln[1][1] += sb; }
             }
             {
-                const float m1 = row_mean128([&](int r, int f) { return gu[r * ZS + f] * W[o_l1w + f]; }, red, tid);
-                const float m2 = row_mean128([&](int r, int f) { return gu[r * ZS + f] * W[o_l1w + f] * xh1[r * ZS + f]; }, red, tid);
-                const int row = tid & 15, part = tid >> 4;
+                const int row = tid >> 5, l32 = tid & 31;
+                const float m1 = row_sum128_hw([&](int r, int f) { return gu[r * ZS + f] * W[o_l1w + f]; }, tid) * (1.0f / 128.0f);
+                const float m2 = row_sum128_hw([&](int r, int f) { return gu[r * ZS + f] * W[o_l1w + f] * xh1[r * ZS + f]; }, tid) * (1.0f / 128.0f);
                 const float rstd = s_rstd1[row];
                 __syncthreads();
 #pragma unroll
-                for (int q = 0; q < FPP; ++q) {
-                    const int f = part * FPP + q;
+                for (int q = 0; q < 4; ++q) {
+                    const int f = l32 + 32 * q;
                     gu[row * ZS + f] = rstd * (gu[row * ZS + f] * W[o_l1w + f] - m1 - xh1[row * ZS + f] * m2);   // dL/dy
                 }
-                if (tid < TR) {
-                    // the LN divides vy by den: gvu currently holds dL/d vu
-                    vec_ln_bwd_row(vy + tid * VWS, s_vl1[tid], gvu + tid * VWS);
-                }
+                // the LN divides vy by den: gvu currently holds dL/d vu
+                vec_ln_bwd_par(vy, s_vl1, gvu, tid);
             }
             __syncthreads();
             PFT_STAMP(27);
@@ -822,6 +878,13 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
             __syncthreads();
         }
     }
+    // the LayerNorm parameters' gradients of this block (its copy was cleared by zero_class: stored, not added)
+    if (tid < 128)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            if (seen[nt])
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gp[p.o_ln[nt][k] + tid] = a_ln[nt][k];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1729,16 +1792,28 @@ __global__ __launch_bounds__(1024) void k_loss_eval(const LossParams p) {
             for (int q = 0; q < 6; ++q) red[q][tid] += red[q][tid + st];
         __syncthreads();
     }
-    if (tid < 6) {
+    if (tid == 0) {
         const float nfl = (float)p.Nf;
-        const float den = tid == 0 ? (float)(p.Nf * 3) : (tid == 1 ? (float)(p.Nf * p.nf) : nfl);
-        p.out[tid] = red[tid][0] / den;
+        float v[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float den = q == 0 ? (float)(p.Nf * 3) : (q == 1 ? (float)(p.Nf * p.nf) : nfl);
+            v[q] = red[q][0] / den;
+            p.out[q] = v[q];
+        }
+        // what training_step / validation_step derive from the six (pharmacodiff.py:274-277): total loss, total error,
+        // weighted total error -- here, so that the step does not spend framework launches on three additions
+        p.out[6] = v[0] + v[1];
+        p.out[7] = v[2] + 1.0f - v[4];
+        p.out[8] = v[3] + 1.0f - v[5];
     }
 }
-// g[i] *= *scale (the upstream gradient of a scalar loss)
-__global__ void k_scale_by(float* g, const int n, const float* scale) {
+// the unit gradients of the two losses times their upstream scalars (a + a2 for the coordinates, b + b2 for the features;
+// a2 / b2 may be null): one launch for both arrays
+__global__ void k_scale_loss(float* gx, const int nx, const float* a, const float* a2, float* gh, const int nh, const float* b, const float* b2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) g[i] *= scale[0];
+    if (i < nx) gx[i] *= a[0] + (a2 ? a2[0] : 0.f);
+    else if (i - nx < nh) gh[i - nx] *= b[0] + (b2 ? b2[0] : 0.f);
 }
 
 // dropout masks as the forward applies them, for tests: out[(node * 144 + elem)] in {0, 1/(1-p)}
@@ -1779,8 +1854,8 @@ void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, con
 }
 void pfk_loss_prepare(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_prepare, dim3(p->B), dim3(256), 0, s, *p); }
 void pfk_loss_eval(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_eval, dim3(1), dim3(1024), 0, s, *p); }
-void pfk_scale_by(float* g, int n, const float* scale, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_scale_by, dim3((n + 255) / 256), dim3(256), 0, s, g, n, scale);
+void pfk_scale_loss(float* gx, int nx, const float* a, const float* a2, float* gh, int nh, const float* b, const float* b2, hipStream_t s) {
+    if (nx + nh > 0) hipLaunchKernelGGL(k_scale_loss, dim3((nx + nh + 255) / 256), dim3(256), 0, s, gx, nx, a, a2, gh, nh, b, b2);
 }
 void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float* out_f, hipStream_t s) {
     if (n_gvps == 0) return;

@@ -211,13 +211,14 @@ class PfEngine:
     def train_loss_forward(self, pharm_x0, pharm_h0, t_int, eps_x, eps_h, alpha_tab, sigma_tab, n_timesteps, feat_norm,
                            remove_com=True, weighted_loss=False, dropout=0.0, seed=0):
         """PharmacophoreDiff.forward (pharmacodiff.py:162-243, noise parameterisation) around the bound batch as one call:
-        COM removal, noising, the train-mode dynamics, losses and metrics.  Returns a device tensor [6]: pos loss, feat
-        loss, position error, weighted position error, accuracy, weighted accuracy."""
+        COM removal, noising, the train-mode dynamics, losses and metrics.  Returns a device tensor [9]: pos loss, feat
+        loss, position error, weighted position error, accuracy, weighted accuracy, then what a step derives from them --
+        total loss, total error, weighted total error."""
         x0, h0 = _f32(pharm_x0, self.device), _f32(pharm_h0, self.device)
         ex, eh = _f32(eps_x, self.device), _f32(eps_h, self.device)
         ti = t_int.to(self.device, torch.int32).contiguous()
         al, sg = _f32(alpha_tab, self.device), _f32(sigma_tab, self.device)
-        out = torch.empty(6, device=self.device)
+        out = torch.empty(9, device=self.device)
         with torch.cuda.device(self.device):
             self._ck(self.lib.pf_train_loss_forward(self._h, _dptr(x0), _dptr(h0), _dptr(ti), _dptr(ex), _dptr(eh), _dptr(al),
                                                     _dptr(sg), int(n_timesteps), float(feat_norm), int(bool(remove_com)),
@@ -234,6 +235,17 @@ class PfEngine:
         with torch.cuda.device(self.device):
             self._ck(self.lib.pf_train_loss_backward(self._h, _dptr(gp), _dptr(gf), _dptr(grad), _stream_ptr()),
                      "pf_train_loss_backward")
+        return grad
+
+    def train_loss_backward_out(self, g_out):
+        """The same from the upstream gradient of train_loss_forward's whole output vector ([9]; entries 0, 1 and 6 count)."""
+        go = _f32(g_out, self.device).reshape(9)
+        if not hasattr(self, "n_params"):
+            self.param_layout()
+        grad = torch.empty(self.n_params, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_train_loss_backward_out(self._h, _dptr(go), _dptr(grad), _stream_ptr()),
+                     "pf_train_loss_backward_out")
         return grad
 
     def set_flat_params(self, flat):

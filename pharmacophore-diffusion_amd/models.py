@@ -164,7 +164,8 @@ class _DynamicsFn(torch.autograd.Function):
 class _LossFn(torch.autograd.Function):
     """PharmacophoreDiff.forward's loss (pharmacodiff.py:162-243, noise parameterisation) as one autograd node: forward =
     pf_train_loss_forward (COM removal, noising, train-mode dynamics, losses and metrics on the device), backward =
-    pf_train_loss_backward with the upstream gradients of the two losses.  Output: [pos loss, feat loss, four metrics]."""
+    pf_train_loss_backward_out with the upstream gradient of the output vector.  Output: [pos loss, feat loss, four metrics,
+    total loss, total error, weighted total error]."""
 
     @staticmethod
     def forward(ctx, mod, eng, x0, h0, t_int, eps_x, eps_h, tabs, T, feat_norm, remove_com, weighted, dropout, seed, flat_leaf):
@@ -180,8 +181,7 @@ class _LossFn(torch.autograd.Function):
         if ctx.token != mod._fwd_token:
             raise RuntimeError("backward of a loss forward that is not the most recent training forward: the engine keeps "
                                "the activations of one forward at a time")
-        g_out = g_out.contiguous()
-        return (None,) * 14 + (eng.train_loss_backward(g_out[0:1], g_out[1:2]),)
+        return (None,) * 14 + (eng.train_loss_backward_out(g_out),)
 
 
 class PharmRecDynamicsGVP(nn.Module):
@@ -760,6 +760,7 @@ class PharmacophoreDiff(_Base):
         its backward -- evaluated by the HIP kernels.  ``t_int`` / ``eps`` inject the random draws."""
         g = as_pocket_graph(g)
         dev = self.device
+        self.__dict__["_fused_sums"] = None
         if self.fused_loss and dev.type == "cuda" and not self.endpoint_param_feat and not self.endpoint_param_coord:
             return self._forward_fused(g, phase, t_int, eps)
         bidx = get_batch_idxs(g)
@@ -850,7 +851,7 @@ class PharmacophoreDiff(_Base):
         B = g.batch_size
         x0, h0 = g.pharm_x0.to(dev), g.pharm_h0.to(dev)
         if t_int is None:
-            t_int = torch.randint(0, self.n_timesteps, size=(B,), device=dev)
+            t_int = torch.randint(0, self.n_timesteps, size=(B,), device=dev, dtype=torch.int32)    # (the form the C ABI takes)
         else:
             self._check_injected_t(t_int, B)
         if eps is None:
@@ -869,6 +870,9 @@ class PharmacophoreDiff(_Base):
         m = out.detach()
         metrics = {phase + ' position error': m[2], phase + ' weighted position error': m[3],
                    phase + ' accuracy': m[4], phase + ' weighted accuracy': m[5]}
+        # the sums a step derives from these (total loss, total error, weighted total error) came out of the same kernel:
+        # training_step / validation_step pick them up instead of spending framework launches on three additions
+        self.__dict__["_fused_sums"] = (out[6], m[7], m[8])
         return losses, metrics
 
     def configure_optimizers(self):
@@ -928,10 +932,14 @@ class PharmacophoreDiff(_Base):
                 ph_quality_metrics = self.sample_and_analyze()
                 self.last_sample_marker = epoch_exact
         loss_dict, metrics_dict = self.forward(batch, phase=phase, t_int=t_int, eps=eps)
-        loss_dict[phase + ' total loss'] = torch.sum(torch.stack(list(loss_dict.values()), dim=0))
-        metrics_dict[phase + ' total error'] = metrics_dict[phase + ' position error'] + 1 - metrics_dict[phase + ' accuracy']
-        metrics_dict[phase + ' weighted total error'] = (metrics_dict[phase + ' weighted position error'] + 1
-                                                         - metrics_dict[phase + ' weighted accuracy'])
+        sums = self.__dict__.pop("_fused_sums", None)
+        if sums is not None:                       # (the fused loss path computed them with the losses)
+            loss_dict[phase + ' total loss'], metrics_dict[phase + ' total error'], metrics_dict[phase + ' weighted total error'] = sums
+        else:
+            loss_dict[phase + ' total loss'] = torch.sum(torch.stack(list(loss_dict.values()), dim=0))
+            metrics_dict[phase + ' total error'] = metrics_dict[phase + ' position error'] + 1 - metrics_dict[phase + ' accuracy']
+            metrics_dict[phase + ' weighted total error'] = (metrics_dict[phase + ' weighted position error'] + 1
+                                                             - metrics_dict[phase + ' weighted accuracy'])
         metrics_dict.update(ph_quality_metrics)
         if epoch_exact is not None:
             if tr.optimizer is not None:
@@ -957,10 +965,14 @@ class PharmacophoreDiff(_Base):
     def validation_step(self, batch, batch_idx):
         phase = 'val'
         loss_dict, metrics_dict = self.forward(batch, phase=phase)
-        loss_dict[phase + ' total loss'] = sum(list(loss_dict.values()))
-        metrics_dict[phase + ' total error'] = metrics_dict[phase + ' position error'] + 1 - metrics_dict[phase + ' accuracy']
-        metrics_dict[phase + ' weighted total error'] = (metrics_dict[phase + ' weighted position error'] + 1
-                                                         - metrics_dict[phase + ' weighted accuracy'])
+        sums = self.__dict__.pop("_fused_sums", None)
+        if sums is not None:
+            loss_dict[phase + ' total loss'], metrics_dict[phase + ' total error'], metrics_dict[phase + ' weighted total error'] = sums
+        else:
+            loss_dict[phase + ' total loss'] = sum(list(loss_dict.values()))
+            metrics_dict[phase + ' total error'] = metrics_dict[phase + ' position error'] + 1 - metrics_dict[phase + ' accuracy']
+            metrics_dict[phase + ' weighted total error'] = (metrics_dict[phase + ' weighted position error'] + 1
+                                                             - metrics_dict[phase + ' weighted accuracy'])
         loss_dict['epoch_exact'] = self.last_epoch_exact
         self.log_dict(loss_dict, on_step=False, on_epoch=True, prog_bar=True, logger=True, batch_size=batch.batch_size)
         self.log_dict(metrics_dict, on_step=False, on_epoch=True, prog_bar=True, logger=True, batch_size=batch.batch_size)
