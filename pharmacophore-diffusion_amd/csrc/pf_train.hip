@@ -27,6 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LVL_FLOATS (TR * (SWS + VWS + ZS + GTS))
 #define WORK_FLOATS (TR * (SWS * 2 + VWS * 5 + GTS))
 #define CHAIN_FLOATS(nlv) ((nlv) * LVL_FLOATS + TR * ZS + WORK_FLOATS)
+#define PFT_WST_FLOATS 3200   // >= vi h + h vo + vo so of any GVP (h = max(vi, vo) <= 17: 17 x 17 + 17 x 16 + 16 x 128 = 2609)
 
 __device__ __forceinline__ float t_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float t_silu(float x) { return x * t_sigmoid(x); }
@@ -258,11 +259,11 @@ struct ChainLds {
 };
 
 // Vh = Wh^T V and Vu = Wu^T Vh of one GVP for the 16 rows (gvp.py:97-101); sh goes to Sin[:, si:] when want_sh
-__device__ __forceinline__ void gvp_vec(const GvpT& g, const float* W, float* Sin, const float* Vin, float* Vh, float* Vu,
+__device__ __forceinline__ void gvp_vec(const GvpT& g, const float* Wh, const float* Wu, float* Sin, const float* Vin, float* Vh, float* Vu,
                                         const bool want_sh, const int tid, const int lane, const int wv) {
     const int KH = g.h, VI = g.vi, VO = g.vo;
     mm16<5>(KH, 3 * TR, VI,
-         [&](int i, int k) { return W[g.o_Wh + k * KH + i]; },
+         [&](int i, int k) { return Wh[k * KH + i]; },
          [&](int k, int j) { return Vin[(j & 15) * VWS + k * 3 + (j >> 4)]; },
          [&](int i, int j, float x) { Vh[(j & 15) * VWS + i * 3 + (j >> 4)] = x; }, lane, wv);
     __syncthreads();
@@ -273,7 +274,7 @@ __device__ __forceinline__ void gvp_vec(const GvpT& g, const float* W, float* Si
             Sin[row * SWS + g.si + hh] = t_sqrt(fmaxf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2], 1e-8f));
         }
     mm16<5>(VO, 3 * TR, KH,
-         [&](int i, int k) { return W[g.o_Wu + k * VO + i]; },
+         [&](int i, int k) { return Wu[k * VO + i]; },
          [&](int k, int j) { return Vh[(j & 15) * VWS + k * 3 + (j >> 4)]; },
          [&](int i, int j, float x) { Vu[(j & 15) * VWS + i * 3 + (j >> 4)] = x; }, lane, wv);
     __syncthreads();
@@ -287,7 +288,7 @@ __device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, const Pac
                                         const int tid, const int lane, const int wv) {
     const int VO = g.vo, SO = g.so, KM = g.si + g.h;
     PFT_STAMP(1);
-    gvp_vec(g, W, Sin, Vin, Vh, Vu, true, tid, lane, wv);
+    gvp_vec(g, W + g.o_Wh, W + g.o_Wu, Sin, Vin, Vh, Vu, true, tid, lane, wv);
     PFT_STAMP(2);
     mm16_packed<11>(reinterpret_cast<const f32x4*>(pk.f) + (size_t)g.pk * (8 * 11 * 64), (SO + 15) >> 4, (KM + 15) >> 4,
          [&](int k, int j) { return Sin[j * SWS + min(k, KM - 1)]; },         // (the fragments are zero beyond KM)
@@ -324,11 +325,23 @@ __device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, const Pac
 __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const PackPtr pk, const bool fresh, float* gp, const float* Sin, const float* Vin,
                                         const float* Z, const float* gate, const float* act, const int act_stride,
                                         float* gA, float* gS, float* gVo, float* gVi, float* Vh, float* Vu, float* gVh,
-                                        float* ggate, const int tid, const int lane, const int wv, const bool fill_sh = false) {
+                                        float* ggate, const int tid, const int lane, const int wv, const bool fill_sh = false,
+                                        float* wst = nullptr) {
     const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;
     PFT_STAMP(10);
+    // wst (PFT_WST_FLOATS of LDS, optional): the GVP's small matrices -- Wh, Wu and the gate weights, 12 KB -- are copied there
+    // once per level; five of this function's products read them element by element, and from global memory each such product
+    // starts with a dependent L2 round trip on strided addresses
+    const float *Wh = W + g.o_Wh, *Wu = W + g.o_Wu, *Wg = W + g.o_Wg;
+    if (wst != nullptr) {
+        const int nh = VI * KH, nu = KH * VO, ng = VO * SO;
+        for (int i = tid; i < nh + nu + ng; i += NT)
+            wst[i] = W[i < nh ? g.o_Wh + i : (i < nh + nu ? g.o_Wu + (i - nh) : g.o_Wg + (i - nh - nu))];
+        __syncthreads();
+        Wh = wst; Wu = wst + nh; Wg = wst + nh + nu;
+    }
     // (fill_sh: the level's rows came from the forward's saved pre-activations, the sh columns of Sin are still to be filled)
-    gvp_vec(g, W, const_cast<float*>(Sin), Vin, Vh, Vu, fill_sh, tid, lane, wv);
+    gvp_vec(g, Wh, Wu, const_cast<float*>(Sin), Vin, Vh, Vu, fill_sh, tid, lane, wv);
     PFT_STAMP(11);
     // gate: V' = f(gate) Vu
     for (int idx = tid; idx < TR * VO; idx += NT) {
@@ -345,7 +358,7 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const Pac
     __syncthreads();
     PFT_STAMP(12);
     mm16<4>(SO, TR, VO,
-         [&](int i, int k) { return W[g.o_Wg + k * SO + i]; },
+         [&](int i, int k) { return Wg[k * SO + i]; },
          [&](int k, int j) { return ggate[j * GTS + k]; },
          [&](int i, int j, float x) { gA[j * SWS + i] += x; }, lane, wv);
     mm16_acc<4>(VO, SO, TR,
@@ -381,7 +394,7 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const Pac
     __syncthreads();
     PFT_STAMP(16);
     mm16<4>(KH, 3 * TR, VO,
-         [&](int i, int k) { return W[g.o_Wu + i * VO + k]; },
+         [&](int i, int k) { return Wu[i * VO + k]; },
          [&](int k, int j) { return gVo[(j & 15) * VWS + k * 3 + (j >> 4)]; },
          [&](int i, int j, float x) {
              const int row = j & 15, cc = j >> 4;
@@ -396,7 +409,7 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const Pac
     __syncthreads();
     PFT_STAMP(17);
     mm16<5>(VI, 3 * TR, KH,
-         [&](int i, int k) { return W[g.o_Wh + i * KH + k]; },
+         [&](int i, int k) { return Wh[i * KH + k]; },
          [&](int k, int j) { return gVh[(j & 15) * VWS + k * 3 + (j >> 4)]; },
          [&](int i, int j, float x) { gVi[(j & 15) * VWS + i * 3 + (j >> 4)] = x; }, lane, wv);
     mm16_acc<4>(VI, KH, 3 * TR,
@@ -465,12 +478,13 @@ __device__ __forceinline__ void chain_load(const ChainLds& L, const GvpT* g, con
 // backward through the chain: upstream gradients in L.gX ([row][so_last], stride SWS) and L.gVX; returns through
 // gs_out / gv_out the buffers that hold dL/d Sin(0) and dL/d Vin(0)
 __device__ __forceinline__ void chain_bwd(const ChainLds& L, const GvpT* g, const float* W, const PackPtr pk, const bool fresh, float* gp,
-                                          float*& gs_out, float*& gv_out, const int tid, const int lane, const int wv, const bool fill_sh = false) {
+                                          float*& gs_out, float*& gv_out, const int tid, const int lane, const int wv, const bool fill_sh = false,
+                                          float* wst = nullptr) {
     float *ga = L.gX, *gs = L.gY, *gvo = L.gVX, *gvi = L.gVY;
     for (int l = L.nlv - 1; l >= 0; --l) {
         const bool last = l == L.nlv - 1;
         gvp_bwd(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
-                ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh);
+                ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh, wst);
         float* t0 = ga; ga = gs; gs = t0;
         float* t1 = gvo; gvo = gvi; gvi = t1;
     }
@@ -500,6 +514,7 @@ __device__ __forceinline__ float row_mean128(F f, float* red, const int tid) {
 __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
     __shared__ float lds[CHAIN_FLOATS(PFT_MAX_CHAIN)];
     __shared__ float s_ge[TR * 8];
+    __shared__ float s_wst[PFT_WST_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     ChainLds L; L.init(lds, p.n_gvps);
     const float* W = p.c.W;
@@ -565,7 +580,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
             __syncthreads();
             PFT_STAMP(43);
             float *gs, *gv;
-            chain_bwd(L, p.g, W, pk, unit == (int)blockIdx.x, gp, gs, gv, tid, lane, wv, saved);
+            chain_bwd(L, p.g, W, pk, unit == (int)blockIdx.x, gp, gs, gv, tid, lane, wv, saved, s_wst);
             PFT_STAMP(44);
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx >> 7, f = idx & 127;
