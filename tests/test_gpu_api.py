@@ -286,6 +286,60 @@ def test_bind_graph_rebinds_look_alike_batches():
     assert not torch.allclose(outs[0], outs[1])
 
 
+def test_back_to_back_binds_keep_their_own_tables():
+    """pf_set_pocket_batch uploads the table section on a copy stream into one of two alternating device buffers: six different
+    batches are bound and run back to back WITHOUT any synchronisation in between (the upload of bind k + 1 overlaps the
+    kernels of bind k, bind k + 2 reuses the buffer of bind k), and every result must equal that of a fresh engine that
+    sees only its batch."""
+    cfg = O.DynamicsConfig()
+    sd = {k: v for k, v in pfa.synthetic.make_state_dict(0).items()}
+    eng = pfa.PfEngine(device=torch.device("cuda", 0))
+    eng.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(5)
+    cases = []
+    for i, (n_atoms, sizes) in enumerate([(64, [3, 5, 4]), (48, [6]), (80, [2, 2, 7, 3]), (64, [5, 3, 4]), (40, [8, 1]), (72, [4, 4, 4])]):
+        b = O.concat_pockets([O.synthetic_batch([100 + 10 * i + j], n_atoms, n, cfg) for j, n in enumerate(sizes)])
+        Nf = int(b.pharm_ptr[-1])
+        cases.append((b, torch.randn(Nf, 3, generator=gen), torch.randn(Nf, 6, generator=gen), torch.rand(len(sizes), generator=gen)))
+    outs = []
+    for b, x, h, t in cases:                    # no synchronisation inside this loop
+        eng.set_batch(b.prot_x.cuda(), b.prot_h.cuda(), b.prot_ptr, b.pharm_ptr, b.pp_src, b.pp_dst)
+        outs.append(eng.dynamics(x.cuda(), h.cuda(), t.cuda()))
+    torch.cuda.synchronize()
+    for (b, x, h, t), (eh, ex) in zip(cases, outs):
+        fresh = pfa.PfEngine(device=torch.device("cuda", 0))
+        fresh.load_state_dict(sd)
+        fresh.set_batch(b.prot_x.cuda(), b.prot_h.cuda(), b.prot_ptr, b.pharm_ptr, b.pp_src, b.pp_dst)
+        fh, fx = fresh.dynamics(x.cuda(), h.cuda(), t.cuda())
+        assert torch.equal(eh, fh) and torch.equal(ex, fx)
+        oh, ox = O.dynamics_forward(O.make_state_dict(cfg, 0), cfg, b, b.prot_x, x, h, t)
+        torch.testing.assert_close(eh.cpu(), oh, rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(ex.cpu(), ox, rtol=2e-4, atol=2e-4)
+
+
+def test_loss_vector_carries_the_sums_a_step_derives():
+    """pf_train_loss_forward's entries 6..8 (total loss, total error, weighted total error) are what training_step reports, and
+    pf_train_loss_backward_out with a gradient on entry 6 equals pf_train_loss_backward with that gradient on both losses."""
+    z = load("train_fwd.npz")
+    m = make_model(int(z["T"]))
+    g = graph_from(batch_from(z), z["x0"], z["h0"]).to("cuda")
+    inj = dict(t_int=z["t_int"].long(), eps={'h': z["eps_h"], 'x': z["eps_x"]})
+    loss = m.training_step(g, 0, **inj)
+    lm = m.last_metrics
+    assert abs(float(loss.detach()) - (float(lm['train pos loss']) + float(lm['train feat loss']))) <= 1e-6 * max(1.0, abs(float(loss.detach())))
+    assert abs(float(lm['train total error']) - (float(lm['train position error']) + 1 - float(lm['train accuracy']))) <= 1e-6
+    assert abs(float(lm['train weighted total error'])
+               - (float(lm['train weighted position error']) + 1 - float(lm['train weighted accuracy']))) <= 1e-6
+    m.zero_grad(set_to_none=True)
+    loss.backward()
+    g_total = m.dynamics._last_flat_grad.clone()
+    m.zero_grad(set_to_none=True)
+    losses, _ = m.forward(g, 'train', **inj)
+    (losses['train pos loss'] + losses['train feat loss']).backward()
+    g_sum = m.dynamics._last_flat_grad
+    assert torch.equal(g_total, g_sum)
+
+
 def test_full_size_config2_batch_properties():
     """BASELINE config 2 at full size (B=32 x 256 atoms x 6 centers), 25 steps of the T=500 schedule:
     finite, bitwise reproducible, and invariant to a rigid motion of the whole input (the sampler's

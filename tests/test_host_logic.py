@@ -124,6 +124,26 @@ def test_batch_unbatch_copy_graph():
     assert copies[0].prot_x.data_ptr() != g1.prot_x.data_ptr() and torch.equal(copies[2].prot_x, g1.prot_x)
 
 
+def test_index_arrays_i32_are_cached_per_graph_and_follow_the_tensors():
+    """PocketGraph.index_arrays_i32: made at collate time (batch()), shared with .to() copies, rebuilt when an index tensor is
+    replaced or written in place."""
+    cfg = O.DynamicsConfig()
+    parts = [pfa.graph.PocketGraph(b.prot_x, b.prot_h, b.prot_ptr, b.pharm_ptr, b.pp_src, b.pp_dst)
+             for b in (O.synthetic_batch([3], 20, 2, cfg), O.synthetic_batch([4], 16, 3, cfg))]
+    g = pfa.graph.batch(parts)
+    assert "_i32_cache" in g.__dict__                      # made by batch()
+    a = g.index_arrays_i32()
+    assert all(x.dtype == np.int32 and x.flags["C_CONTIGUOUS"] for x in a)
+    assert np.array_equal(a[0], g.prot_ptr.numpy()) and np.array_equal(a[2], g.pp_src.numpy()) and np.array_equal(a[3], g.pp_dst.numpy())
+    assert g.index_arrays_i32()[2] is a[2]                 # cached
+    assert g.to("cpu").index_arrays_i32()[2] is a[2]       # carried by to()
+    g.pp_src[0] = g.pp_src[0]                              # an in-place write bumps the version: rebuilt
+    assert g.index_arrays_i32()[2] is not a[2]
+    g.pp_src = g.pp_src.clone()
+    b2 = g.index_arrays_i32()
+    assert np.array_equal(b2[2], a[2])
+
+
 def test_xyz_writer_matches_reference_output():
     z = load("traj_c1.npz")
     g = pocket(0, 64, 4)
