@@ -55,6 +55,8 @@ void pfk_bwd_head(const BwdHeadParams* p, int nblocks, hipStream_t s);
 void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s);
 void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, int nblocks, hipStream_t s);
 void pfk_fix_apply(long long* A, float* G, size_t n, const float* fix, hipStream_t s);
+void pfk_fix_apply_rows(const NodeTile* tiles, int ntiles, const int* dyn_cnt, const int* row_ids, long long* A_h, float* G_h,
+                        long long* A_v, float* G_v, const float* fix, hipStream_t s);
 void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* fix, hipStream_t s);
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
 void pfk_enc_group(const float* G_h, const int* prot_ptr, const int* ptype, int B, int rec_nf, float* Gg, hipStream_t s);
@@ -2655,8 +2657,14 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         e.A_h = h->t_A_h; e.A_v = h->t_A_v; e.fix = h->t_fix;
         e.wpack = h->d_wpack + (size_t)h->msg_base(l, 0) * PFT_WPACK_FLOATS;
         for (int lv = c.n_message_gvps - 1; lv >= 0; --lv) { e.level = lv; ProfScope ps(h, pf_handle::K_BWD_EDGE_LEVEL, s); pfk_bwd_edge_level(&e, nb, s); }
-        pfk_fix_apply(h->t_A_h, e.G_h_in, (size_t)N * PF_S, h->t_fix, s);
-        if (l != 0) pfk_fix_apply(h->t_A_v, e.G_v_in, (size_t)N * 48, h->t_fix, s);       // conv layer 0 has no vector input
+        // the last layer's ff / pf edges scatter into pharm rows and active protein atoms only (the pruned layout's node tiles)
+        if (last && l != 0 && h->prune && L >= 2 && h->d_act_ids != nullptr && h->n_node_tiles_act > 0)
+            pfk_fix_apply_rows(h->d_node_tiles_act, h->n_node_tiles_act, h->d_dyn_cnt, h->d_act_ids, h->t_A_h, e.G_h_in, h->t_A_v, e.G_v_in,
+                               h->t_fix, s);
+        else {
+            pfk_fix_apply(h->t_A_h, e.G_h_in, (size_t)N * PF_S, h->t_fix, s);
+            if (l != 0) pfk_fix_apply(h->t_A_v, e.G_v_in, (size_t)N * 48, h->t_fix, s);       // conv layer 0 has no vector input
+        }
         a ^= 1;
     }
     {

@@ -959,12 +959,13 @@ __global__ __launch_bounds__(256) void k_compact_units(const NodeTile* tiles, co
     if (tid == 0) ucnt[0] = base;
 }
 struct CompactParams { int et_tile0[5]; };
-__global__ __launch_bounds__(256) void k_compact_tiles(const EdgeTile* tiles, const CompactParams cp, const int* dyn_cnt, int* clist, int* ccnt) {
-    __shared__ int s_w[4];
+__global__ __launch_bounds__(1024) void k_compact_tiles(const EdgeTile* tiles, const CompactParams cp, const int* dyn_cnt, int* clist, int* ccnt) {
+    // one block per etype, 1024 tiles per round (the pp segment of a 256-pocket batch has 20 k tiles: 17 us at 256 per round)
+    __shared__ int s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int t0 = cp.et_tile0[blockIdx.x], t1 = cp.et_tile0[blockIdx.x + 1], seg0 = t0 - cp.et_tile0[0];     // one block per etype
     int base = 0;
-    for (int c = t0; c < t1; c += 256) {
+    for (int c = t0; c < t1; c += 1024) {
         const int ti = c + tid;
         bool ne = false;
         if (ti < t1) {
@@ -976,10 +977,11 @@ __global__ __launch_bounds__(256) void k_compact_tiles(const EdgeTile* tiles, co
         const unsigned long long m = __ballot(ne);
         if (lane == 0) s_w[wv] = __popcll(m);
         __syncthreads();
-        int off = base;
-        for (int w = 0; w < wv; ++w) off += s_w[w];
+        int off = base, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int x = s_w[w]; if (w < wv) off += x; tot += x; }
         if (ne) clist[seg0 + off + __popcll(m & ((1ull << lane) - 1ull))] = ti;
-        base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        base += tot;
         __syncthreads();
     }
     if (tid == 0) ccnt[blockIdx.x] = base;
@@ -1627,6 +1629,25 @@ __global__ void k_fix_apply(long long* A, float* G, const size_t n, const float*
         }
     }
 }
+// the same for the LAST conv layer, whose edges (ff, pf) have pharm nodes and active protein atoms as their only sources: one
+// block per node tile of the pruned layout (pharm tiles, then the per-graph active-atom tiles) instead of a pass over all
+// N rows of both accumulators (69 + 26 MB read at 256 pockets for ~7 k touched rows)
+__global__ __launch_bounds__(256) void k_fix_apply_rows(const NodeTile* tiles, const int* dyn_cnt, const int* row_ids,
+                                                        long long* A_h, float* G_h, long long* A_v, float* G_v, const float* fix) {
+    const NodeTile t = tiles[blockIdx.x];
+    int n = t.n;
+    if (t.cnt_idx >= 0) n = min(n, max(dyn_cnt[t.cnt_idx] - t.rel, 0));
+    const double inv = (double)fix[1];
+    for (int idx = threadIdx.x; idx < n * 176; idx += 256) {
+        const int r = idx / 176, q = idx - r * 176;
+        const int pos = t.n0 + r;
+        const size_t node = (size_t)(t.ids ? row_ids[pos] : pos);
+        long long* Ap = q < PF_S ? A_h + node * PF_S + q : A_v + node * 48 + (q - PF_S);
+        float* Gp = q < PF_S ? G_h + node * PF_S + q : G_v + node * 48 + (q - PF_S);
+        const long long a = *Ap;
+        if (a != 0) { *Gp += (float)((double)a * inv); *Ap = 0; }
+    }
+}
 // scale of the fixed-point scatter for one backward call: 2^(PFT_FIX_BITS - ceil(log2(max |upstream gradient|))) -- every
 // gradient of the call is linear in the upstream ones, so this keeps ~40 bits below and 23 bits above their largest entry
 __global__ __launch_bounds__(256) void k_fix_scale(const float* g_h, const int n_h, const float* g_x, const int n_x, float* fix) {
@@ -1865,7 +1886,7 @@ void pfk_compact_units(const NodeTile* tiles, int ntiles, const int* dyn_cnt, in
 void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s) {
     CompactParams cp;
     for (int et = 0; et <= 4; ++et) cp.et_tile0[et] = et_tile0[et];
-    hipLaunchKernelGGL(k_compact_tiles, dim3(n_et), dim3(256), 0, s, tiles, cp, dyn_cnt, clist, ccnt);
+    hipLaunchKernelGGL(k_compact_tiles, dim3(n_et), dim3(1024), 0, s, tiles, cp, dyn_cnt, clist, ccnt);
 }
 void pfk_loss_prepare(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_prepare, dim3(p->B), dim3(256), 0, s, *p); }
 void pfk_loss_eval(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_eval, dim3(1), dim3(1024), 0, s, *p); }
@@ -1879,6 +1900,10 @@ void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float
 void pfk_fix_apply(long long* A, float* G, size_t n, const float* fix, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_fix_apply, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, s, A, G, n, fix);
+}
+void pfk_fix_apply_rows(const NodeTile* tiles, int ntiles, const int* dyn_cnt, const int* row_ids, long long* A_h, float* G_h,
+                        long long* A_v, float* G_v, const float* fix, hipStream_t s) {
+    if (ntiles > 0) hipLaunchKernelGGL(k_fix_apply_rows, dim3(ntiles), dim3(256), 0, s, tiles, dyn_cnt, row_ids, A_h, G_h, A_v, G_v, fix);
 }
 void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* fix, hipStream_t s) {
     hipLaunchKernelGGL(k_fix_scale, dim3(1), dim3(256), 0, s, g_h, n_h, g_x, n_x, fix);
