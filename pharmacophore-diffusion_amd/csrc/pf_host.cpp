@@ -286,6 +286,11 @@ struct pf_handle {
     // n16_msg: every message chain with a full first GVP (M0F: what conv layers >= 1 run, and what pf_debug_chain tests)
     std::vector<size_t> n16_msg, n16_upd;
     size_t n16_msg_stride = 0, n16_upd_stride = 0;
+    // packed elements [n16_begin, n_packed) are the n16 streams: no training kernel reads them, so pf_set_flat_params (called
+    // after every optimiser step) refreshes only what precedes them and marks them stale; the first inference call afterwards
+    // (run_dynamics without train, pf_debug_chain) gathers them (n16_refresh)
+    size_t n16_begin = 0;
+    bool n16_stale = false;
     // conv layer 0's message chains in their own forms: protein sources (pf, pp) start from a type-table row (M0H),
     // centers (ff, fp) have zero node vectors (M0Z)
     size_t n16_l0[4] = {0, 0, 0, 0}, n16_l0_stride[4] = {0, 0, 0, 0};
@@ -876,9 +881,17 @@ static void l0_prepare_t(pf_handle* h, const float* tv, int n, hipStream_t s) {
 // sequence one dynamics call on the handle's state (xn, pharm_h, d_t).  train: keep every layer's input and message
 // rows (h->t_*), compute every tile (gradients need the full graph only where they are non-zero, but the first
 // version of the backward pass walks the dense tile lists) and apply dropout in the node update.
+// the n16 streams after pf_set_flat_params left them behind (see pf_handle::n16_begin)
+static void n16_refresh(pf_handle* h, hipStream_t s) {
+    if (!h->n16_stale) return;
+    pfk_gather_weights(h->d_flat, h->d_map + h->n16_begin, h->n_packed - h->n16_begin, h->d_w + h->n16_begin, s);
+    h->n16_stale = false;
+}
+
 static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s, const float* t_scalar = nullptr,
                         bool train = false) {
     const pf_config& c = h->cfg;
+    if (!train) n16_refresh(h, s);
     EncodeParams ep{};
     ep.Np = h->Np; ep.Nf = h->Nf;
     ep.prot_h0 = h->d_prot_h0; ep.pharm_h = h->d_pharm_h; ep.t = t_scalar ? nullptr : h->d_t; ep.gid = h->d_gid;
@@ -1419,6 +1432,7 @@ int pf_commit_weights(pf_handle* h) {
             st.resize(st.size() + (size_t)RG_TAIL_PAD * 256, 0.f);
             h->rgs_upd[(size_t)(c.n_convs - 1) * 2 + 1] = flush();
         }
+        h->n16_begin = h->h_w.size();            // everything packed from here on serves the n16 (inference-only) kernels
         if (c.n_message_gvps >= 2 && c.n_update_gvps >= 1) {   // n16 quad streams: per chain wave 0's stream, then waves 1..3
             h->n16_msg.assign((size_t)c.n_convs * 4, 0);
             h->n16_upd.assign((size_t)c.n_convs * 2, 0);
@@ -2433,7 +2447,9 @@ int pf_set_flat_params(pf_handle* h, const float* dev_flat, pf_stream stream) {
     if (!h->d_map) PF_FAIL(h, PF_ERR_STATE, "pf_set_flat_params: no gather map (more than 2^24 parameters)");
     hipStream_t s = (hipStream_t)stream;
     PF_HIP(h, hipMemcpyAsync(h->d_flat, dev_flat, h->nparams * sizeof(float), hipMemcpyDeviceToDevice, s));
-    pfk_gather_weights(h->d_flat, h->d_map, h->n_packed, h->d_w, s);
+    const size_t n_now = (h->n16_begin > 0 && h->n16_begin < h->n_packed) ? h->n16_begin : h->n_packed;
+    pfk_gather_weights(h->d_flat, h->d_map, n_now, h->d_w, s);
+    h->n16_stale = n_now < h->n_packed;
     ++h->w_version;
     h->t_have_fwd = false;
     return PF_OK;
@@ -2723,6 +2739,7 @@ int pf_debug_chain(pf_handle* h, int32_t kind, int32_t layer, int32_t sub, int32
     if (rc) return rc;
     const pf_config& c = h->cfg;
     if (kind == 16 || kind == 17) {           // the message / update chain in the n16 form (pf_n16.hip); rows as for kinds 0 / 1
+        n16_refresh(h, (hipStream_t)stream);
         if (n_rows < 0 || !dev_s_in || !dev_v_in || !dev_s_out || !dev_v_out) PF_FAIL(h, PF_ERR_ARG, "pf_debug_chain: bad argument");
         if (layer < 0 || layer >= c.n_convs || sub < 0 || sub > (kind == 16 ? 3 : 1)) PF_FAIL(h, PF_ERR_ARG, "pf_debug_chain: bad layer / sub index");
         if (h->n16_msg.empty()) PF_FAIL(h, PF_ERR_STATE, "pf_debug_chain: this architecture has no n16 streams (needs n_message_gvps >= 2)");
