@@ -1632,20 +1632,23 @@ __global__ void k_fix_apply(long long* A, float* G, const size_t n, const float*
 // the same for the LAST conv layer, whose edges (ff, pf) have pharm nodes and active protein atoms as their only sources: one
 // block per node tile of the pruned layout (pharm tiles, then the per-graph active-atom tiles) instead of a pass over all
 // N rows of both accumulators (69 + 26 MB read at 256 pockets for ~7 k touched rows)
-__global__ __launch_bounds__(256) void k_fix_apply_rows(const NodeTile* tiles, const int* dyn_cnt, const int* row_ids,
+__global__ __launch_bounds__(192) void k_fix_apply_rows(const NodeTile* tiles, const int* dyn_cnt, const int* row_ids,
                                                         long long* A_h, float* G_h, long long* A_v, float* G_v, const float* fix) {
-    const NodeTile t = tiles[blockIdx.x];
+    // one block per row slot (tile, row): 176 elements, one per thread -- two dependent loads deep, nothing sequential
+    const NodeTile t = tiles[blockIdx.x >> 5];
+    const int r = blockIdx.x & 31;
     int n = t.n;
     if (t.cnt_idx >= 0) n = min(n, max(dyn_cnt[t.cnt_idx] - t.rel, 0));
-    const double inv = (double)fix[1];
-    for (int idx = threadIdx.x; idx < n * 176; idx += 256) {
-        const int r = idx / 176, q = idx - r * 176;
-        const int pos = t.n0 + r;
-        const size_t node = (size_t)(t.ids ? row_ids[pos] : pos);
-        long long* Ap = q < PF_S ? A_h + node * PF_S + q : A_v + node * 48 + (q - PF_S);
+    const int q = threadIdx.x;
+    if (r >= n || q >= 176) return;
+    const int pos = t.n0 + r;
+    const size_t node = (size_t)(t.ids ? row_ids[pos] : pos);
+    long long* Ap = q < PF_S ? A_h + node * PF_S + q : A_v + node * 48 + (q - PF_S);
+    const long long a = *Ap;
+    if (a != 0) {
         float* Gp = q < PF_S ? G_h + node * PF_S + q : G_v + node * 48 + (q - PF_S);
-        const long long a = *Ap;
-        if (a != 0) { *Gp += (float)((double)a * inv); *Ap = 0; }
+        *Gp += (float)((double)a * (double)fix[1]);
+        *Ap = 0;
     }
 }
 // scale of the fixed-point scatter for one backward call: 2^(PFT_FIX_BITS - ceil(log2(max |upstream gradient|))) -- every
@@ -1903,7 +1906,7 @@ void pfk_fix_apply(long long* A, float* G, size_t n, const float* fix, hipStream
 }
 void pfk_fix_apply_rows(const NodeTile* tiles, int ntiles, const int* dyn_cnt, const int* row_ids, long long* A_h, float* G_h,
                         long long* A_v, float* G_v, const float* fix, hipStream_t s) {
-    if (ntiles > 0) hipLaunchKernelGGL(k_fix_apply_rows, dim3(ntiles), dim3(256), 0, s, tiles, dyn_cnt, row_ids, A_h, G_h, A_v, G_v, fix);
+    if (ntiles > 0) hipLaunchKernelGGL(k_fix_apply_rows, dim3(ntiles * 32), dim3(192), 0, s, tiles, dyn_cnt, row_ids, A_h, G_h, A_v, G_v, fix);
 }
 void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* fix, hipStream_t s) {
     hipLaunchKernelGGL(k_fix_scale, dim3(1), dim3(256), 0, s, g_h, n_h, g_x, n_x, fix);
