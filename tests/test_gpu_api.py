@@ -772,6 +772,12 @@ def test_pocket_claims_device_resident_batches_and_failed_binds():
     bad_src = batch.pp_src.clone(); bad_src[0] = int(batch.prot_ptr[1]) + 1
     with pytest.raises(pfa.PfError, match="crosses graphs"):
         eng.set_batch(batch.prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, bad_src, batch.pp_dst, pocket_uid=uid)
+    # (indices outside the batch, in the source and in the last destination: the vectorised pass hands them to the scalar one)
+    for col, where, val in (("src", 5, int(batch.prot_ptr[-1]) + 3), ("src", 2, -1), ("dst", -1, int(batch.prot_ptr[-1]))):
+        bs, bd = batch.pp_src.clone(), batch.pp_dst.clone()
+        (bs if col == "src" else bd)[where] = val
+        with pytest.raises(pfa.PfError, match="out of range"):
+            eng.set_batch(batch.prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, bs, bd)
     # ... leaves the previous batch usable, bitwise
     again = [v.cpu() for v in eng.dynamics(x_t, h_t, t)]
     assert torch.equal(again[0], ref[0]) and torch.equal(again[1], ref[1])
