@@ -68,6 +68,7 @@ void pfk_loss_eval(const LossParams* p, hipStream_t s);
 void pfk_scale_loss(float* gx, int nx, const float* a, const float* a2, float* gh, int nh, const float* b, const float* b2, hipStream_t s);
 void pfk_compact_units(const NodeTile* tiles, int ntiles, const int* dyn_cnt, int* ulist, int* ucnt, hipStream_t s);
 void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s);
+void pfk_compact_rows(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* rlist, int* ccnt, hipStream_t s);
 void pfk_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
               float bc1, float bc2_sqrt, hipStream_t s);
 void pfk_drop_masks(const TrainCommon* c, uint32_t stream, int n_elems, float* out, hipStream_t s);
@@ -361,8 +362,8 @@ struct pf_handle {
     float *t_lx0c = nullptr, *t_lag = nullptr, *t_lsg = nullptr, *t_lgx = nullptr, *t_lgh = nullptr, *t_lout = nullptr;   // pf_train_loss_forward
     bool t_have_loss = false;
     float* t_Gg = nullptr;                  // encoder backward: upstream gradient summed per (graph, element)
-    int* t_ulist = nullptr;                 // compact list of non-empty node units of the layer being differentiated (count: t_ccnt[32])
-    int *t_clist = nullptr, *t_ccnt = nullptr;   // compact list of non-empty edge tiles of the layer being differentiated
+    int* t_ulist = nullptr;                 // compact list of non-empty node units of the layer being differentiated (count: t_ccnt[96])
+    int *t_clist = nullptr, *t_ccnt = nullptr;   // dense list of the valid edge slots of the layer being differentiated (k_compact_rows), counts
     float* t_fix = nullptr;                 // [2] scale / inverse scale of the current backward call
     int t_nblk = 0;
     const float* t_mask_override = nullptr; // pf_debug_set_dropout_masks
@@ -2435,8 +2436,8 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
         h->t_A_v = reinterpret_cast<long long*>(reinterpret_cast<char*>(h->d_tA) + a_bytes);
     }
     h->t_fix = carve<float>(cur, 64);
-    h->t_ccnt = carve<int>(cur, 64);
-    h->t_clist = carve<int>(cur, (size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) + 64);
+    h->t_ccnt = carve<int>(cur, 128);            // [layer][16]: passes per etype, rows per etype at + 8; node units at [96]
+    h->t_clist = carve<int>(cur, (size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) * 32 + 64);    // dense row list of the layer being differentiated
     h->t_gpart_enc = carve<float>(cur, (size_t)PFT_ENC_BLOCKS * std::max(h->enc_n, 1));
     h->t_ulist = carve<int>(cur, (size_t)2 * std::max(h->n_node_tiles, h->n_node_tiles_act) + 64);
     h->t_Gg = carve<float>(cur, (size_t)h->B * c.rec_nf * PF_S);
@@ -2702,8 +2703,8 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         if ((int)h->t_node_saved.size() > l && h->t_node_saved[l]) {
             n.sv_z = h->t_nsv_z[l]; n.sv_g = h->t_nsv_g[l]; n.sv_v = h->t_nsv_v[l]; n.sv_stride = (size_t)2 * h->N;
         }
-        n.ulist = h->t_ulist; n.ucnt = h->t_ccnt + 32;
-        pfk_compact_units(n.tiles, n.ntiles, h->d_dyn_cnt, h->t_ulist, h->t_ccnt + 32, s);
+        n.ulist = h->t_ulist; n.ucnt = h->t_ccnt + 96;
+        pfk_compact_units(n.tiles, n.ntiles, h->d_dyn_cnt, h->t_ulist, h->t_ccnt + 96, s);
         rp.node_grid[l] = n.ntiles > 0 ? std::max(1, std::min(nb, 2 * n.ntiles)) : 0;
         { ProfScope ps(h, pf_handle::K_BWD_NODE, s); pfk_bwd_node(&n, rp.node_grid[l], s); }
         BwdEdgeLevelParams e{};
@@ -2712,9 +2713,9 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         const int* et0 = pruned ? h->et_tile0_act : h->et_tile0;
         for (int et = 0; et <= 4; ++et) e.et_tile0[et] = et0[et];
         e.n_et = last ? 2 : 4;                       // the last layer's fp / pp messages reach no output
-        e.clist = h->t_clist; e.ccnt = h->t_ccnt + 4 * l;
+        e.clist = h->t_clist; e.ccnt = h->t_ccnt + 16 * l;
         rp.n_et[l] = e.n_et;
-        pfk_compact_tiles(e.tiles, e.et_tile0, e.n_et, h->d_dyn_cnt, h->t_clist, h->t_ccnt + 4 * l, s);
+        pfk_compact_rows(e.tiles, e.et_tile0, e.n_et, h->d_dyn_cnt, h->t_clist, h->t_ccnt + 16 * l, s);
         e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;
         e.h = h->t_H[l]; e.v = h->t_V[l];
         e.gagg_s = h->t_gagg_s; e.gagg_v = h->t_gagg_v; e.in_cnt = h->d_in_cnt; e.N = N;

@@ -127,7 +127,8 @@ struct BwdEdgeLevelParams {
     TrainCommon c;
     const EdgeTile* tiles;
     int et_tile0[5]; int n_et;               // etype segments of the tile table; etypes [0, n_et) take part
-    const int* clist; const int* ccnt;       // k_compact_tiles: non-empty tiles per segment (same offsets) and their counts [4]
+    const int* clist; const int* ccnt;       // k_compact_rows: per etype segment (offset 32 x its first tile) the slots of the valid
+                                             // rows, densely, in table order; ccnt[et] = passes of 32 rows, ccnt[8 + et] = rows
     const int* dyn_cnt;
     const int* esrc; const int* edst;
     const float4* xn;

@@ -987,6 +987,40 @@ __global__ __launch_bounds__(1024) void k_compact_tiles(const EdgeTile* tiles, c
     if (tid == 0) ccnt[blockIdx.x] = base;
 }
 
+// the valid edge slots of each etype's segment of a tile table, densely and in table order: rlist[32 (et_tile0[et] - et_tile0[0]) + i],
+// i < rows; ccnt[et] = passes of 32 rows, ccnt[8 + et] = rows.  A backward pass then takes 32 consecutive entries whatever
+// regions they come from: the per-(graph, etype) regions of the dynamic etypes fill their 32-slot tiles to ~65 % (20-56 edges
+// per region), and a pass costs the same whatever it holds.
+__global__ __launch_bounds__(1024) void k_compact_rows(const EdgeTile* tiles, const CompactParams cp, const int* dyn_cnt, int* rlist, int* ccnt) {
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t0 = cp.et_tile0[blockIdx.x], t1 = cp.et_tile0[blockIdx.x + 1];     // one block per etype
+    int* out = rlist + (size_t)(t0 - cp.et_tile0[0]) * 32;
+    int base = 0;
+    for (int c = t0; c < t1; c += 1024) {
+        const int ti = c + tid;
+        int n = 0, e0 = 0;
+        if (ti < t1) {
+            const EdgeTile t = tiles[ti];
+            n = t.n; e0 = t.e0;
+            if (t.cnt_idx >= 0) n = min(n, max(dyn_cnt[t.cnt_idx] - t.rel, 0));
+        }
+        int incl = n;                                   // inclusive scan over the wave, then over the 16 waves
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        int off = base, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int x = s_w[w]; if (w < wv) off += x; tot += x; }
+        off += incl - n;
+        for (int r = 0; r < n; ++r) out[off + r] = e0 + r;
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) { ccnt[blockIdx.x] = (base + 31) >> 5; ccnt[8 + blockIdx.x] = base; }
+}
+
 // packed to_feats_out of every GVP (message, update and head GVPs in the order of the GvpT table; GvpT::pk):
 //   input-gradient product (blockIdx.y == 0): [gvp][m tile (11)][k block (8)][lane] x 4 -- lane (li, kq) of m tile mt, block sb
 //     holds W[k = 16 sb + 4 kq + t][i = 16 mt + li], t = 0..3 (zero for i >= si + h, k >= so)
@@ -1041,7 +1075,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
     __shared__ float gate[ER * GTS], ggate[ER * GTS];
     __shared__ float Vin[ER * VWS], Vh[ER * VWS], Vu[ER * VWS], gVo[ER * VWS], gVh[ER * VWS], gVi[ER * VWS];
     __shared__ float sWh[32 * E2_WHS], sWu[32 * 16], sWg[16 * 128];
-    __shared__ int s_src[ER], s_e[ER], s_te0[E2_TILES], s_tnv[E2_TILES];
+    __shared__ int s_src[ER], s_e[ER], s_tnv[E2_TILES];
+    __shared__ int s_slot[E2_TILES * ER];            // edge slots of this round's passes (dense row list, k_compact_rows)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
     const int tid_ = tid;
@@ -1055,7 +1090,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
         if ((int)blockIdx.x >= b0 && (int)blockIdx.x < b0 + nbk) { et = e; nb = nbk; my = blockIdx.x - b0; cnt_et = p.ccnt[e]; }
     }
     if (et < 0) return;                              // block-uniform: more gradient copies than work
-    const int* clist = p.clist + (p.et_tile0[et] - p.et_tile0[0]);
+    const int* rlist = p.clist + (size_t)(p.et_tile0[et] - p.et_tile0[0]) * 32;
+    const int nrows = p.ccnt[8 + et];
     const GvpT g = p.g[et * p.n_gvps + p.level];
     const float* W = p.c.W;
     const f32x4* Wp = reinterpret_cast<const f32x4*>(p.wpack) + (size_t)(et * p.n_gvps + p.level) * (11 * 8 * 64);
@@ -1102,10 +1138,11 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
     int rcA0 = 1, rcA1 = 1, rcV = 1, rsT = 0;
     // every load is unconditional (addresses are selected, not branched on) so that the fetches of a tile are issued back to
     // back; lanes without a vector row (tid >= 384) fetch row 0 again
-    auto load_idx = [&](const int e0, const int nv) {
+    auto load_idx = [&](const int j, const int nv) {
         const int m = max(nv, 1) - 1;
-        iA0 = e0 + min(rA, m); iA1 = e0 + min(rA + 16, m); iV = e0 + min(rV, m); iG = e0 + min(rG, m);
-        const int eT = e0 + min(tid & 31, m);
+        const int* sl = s_slot + j * ER;
+        iA0 = sl[min(rA, m)]; iA1 = sl[min(rA + 16, m)]; iV = sl[min(rV, m)]; iG = sl[min(rG, m)];
+        const int eT = sl[min(tid & 31, m)];
         isA0 = p.esrc[iA0]; isA1 = p.esrc[iA1]; isV = p.esrc[iV]; isT = p.esrc[eT];
         idA0 = p.edst[iA0]; idA1 = p.edst[iA1]; idV = p.edst[iV]; idT = p.edst[eT];
     };
@@ -1133,23 +1170,25 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
     const int npass = my < cnt_et ? (cnt_et - my + nb - 1) / nb : 0;
     for (int base = 0; base < npass; base += E2_TILES) {
         __syncthreads();
-        if (tid < E2_TILES) {                        // this round's tile descriptors
-            int e0 = 0, n = 0;
-            if (base + tid < npass) {
-                const EdgeTile t = p.tiles[clist[my + (base + tid) * nb]];
-                n = t.n; e0 = t.e0;
-                if (t.cnt_idx >= 0) n = min(n, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
-            }
-            s_te0[tid] = e0; s_tnv[tid] = n;
+        // this round's passes: pass base + j of this block is pass P = my + (base + j) nb of the etype = rows 32 P .. of its dense
+        // row list; their slots go to LDS once per round (one coalesced fetch instead of a dependent one per pass)
+        if (tid < E2_TILES) {
+            const int P = my + (base + tid) * nb;
+            s_tnv[tid] = (base + tid < npass) ? max(min(ER, nrows - ER * P), 0) : 0;
+        }
+        for (int idx = tid; idx < E2_TILES * ER; idx += NT) {
+            const int j = idx >> 5, r = idx & 31;
+            const int P = my + (base + j) * nb;
+            const int q = ER * P + r;
+            s_slot[idx] = (base + j < npass && q < nrows) ? rlist[q] : 0;
         }
         __syncthreads();
         const int cn = min(E2_TILES, npass - base);
-        load_idx(s_te0[0], s_tnv[0]);
+        load_idx(0, s_tnv[0]);
         load_rows();
-        if (cn > 1) load_idx(s_te0[1], s_tnv[1]);
+        if (cn > 1) load_idx(1, s_tnv[1]);
         for (int j = 0; j < cn; ++j) {
             const int nv = __builtin_amdgcn_readfirstlane(s_tnv[j]);
-            const int e0 = __builtin_amdgcn_readfirstlane(s_te0[j]);
             if (nv > 0) {
                 PFT_STAMP(30);
                 // ---- this tile's rows: registers -> LDS
@@ -1181,7 +1220,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                 }
                 gate[rG * GTS + uG] = rgt;
                 if (tid < ER) {
-                    s_e[tid] = e0 + min(tid, nv - 1);
+                    s_e[tid] = s_slot[j * ER + min(tid, nv - 1)];
                     s_src[tid] = rsT;
                     if (firstl) {
                         const float dx = rxs.x - rxd.x, dy = rxs.y - rxd.y, dz = rxs.z - rxd.z;
@@ -1345,7 +1384,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
             // tile after it.  Nothing below this point waits for a global load.
             __builtin_amdgcn_sched_barrier(0);       // the fetches stay behind the products above (hoisted into them they spill)
             if (j + 1 < cn) load_rows();
-            if (j + 2 < cn) load_idx(s_te0[j + 2], s_tnv[j + 2]);
+            if (j + 2 < cn) load_idx(j + 2, s_tnv[j + 2]);
             if (nv > 0) {
                 __syncthreads();
                 PFT_STAMP(36);
@@ -1703,7 +1742,7 @@ __global__ void k_train_reduce(const ReduceParams p) {
     else if (cls >= PFT_CLS_MSG) {
         const int l = (cls - PFT_CLS_MSG) >> 2, et = (cls - PFT_CLS_MSG) & 3;
         int nbk;
-        et_blocks(p.ccnt + 4 * l, p.n_et[l], p.NB, et, b0, nbk);
+        et_blocks(p.ccnt + 16 * l, p.n_et[l], p.NB, et, b0, nbk);
         b1 = b0 + nbk;
     } else if (cls >= PFT_CLS_NODE) b1 = p.node_grid[cls - PFT_CLS_NODE];
     float s = 0.f;
@@ -1890,6 +1929,12 @@ void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, con
     CompactParams cp;
     for (int et = 0; et <= 4; ++et) cp.et_tile0[et] = et_tile0[et];
     hipLaunchKernelGGL(k_compact_tiles, dim3(n_et), dim3(1024), 0, s, tiles, cp, dyn_cnt, clist, ccnt);
+}
+void pfk_compact_rows(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* rlist, int* ccnt, hipStream_t s) {
+    if (n_et <= 0) return;
+    CompactParams cp;
+    for (int et = 0; et <= 4; ++et) cp.et_tile0[et] = et_tile0[et];
+    hipLaunchKernelGGL(k_compact_rows, dim3(n_et), dim3(1024), 0, s, tiles, cp, dyn_cnt, rlist, ccnt);
 }
 void pfk_loss_prepare(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_prepare, dim3(p->B), dim3(256), 0, s, *p); }
 void pfk_loss_eval(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_eval, dim3(1), dim3(1024), 0, s, *p); }
