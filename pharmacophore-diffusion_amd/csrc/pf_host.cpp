@@ -66,7 +66,8 @@ void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float
 void pfk_loss_prepare(const LossParams* p, hipStream_t s);
 void pfk_loss_eval(const LossParams* p, hipStream_t s);
 void pfk_scale_loss(float* gx, int nx, const float* a, const float* a2, float* gh, int nh, const float* b, const float* b2, hipStream_t s);
-void pfk_compact_units(const NodeTile* tiles, int ntiles, const int* dyn_cnt, int* ulist, int* ucnt, hipStream_t s);
+void pfk_compact_node_rows(const NodeTile* tiles, int ntiles, const int* dyn_cnt, const int* row_ids, int N, int* list, int cap, int* ucnt,
+                           hipStream_t s);
 void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s);
 void pfk_compact_rows(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* rlist, int* ccnt, hipStream_t s);
 void pfk_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
@@ -362,7 +363,8 @@ struct pf_handle {
     float *t_lx0c = nullptr, *t_lag = nullptr, *t_lsg = nullptr, *t_lgx = nullptr, *t_lgh = nullptr, *t_lout = nullptr;   // pf_train_loss_forward
     bool t_have_loss = false;
     float* t_Gg = nullptr;                  // encoder backward: upstream gradient summed per (graph, element)
-    int* t_ulist = nullptr;                 // compact list of non-empty node units of the layer being differentiated (count: t_ccnt[96])
+    int* t_ulist = nullptr;                 // dense per-type row list of the layer being differentiated (k_compact_node_rows; counts: t_ccnt[97], [98])
+    int t_ucap = 0;
     int *t_clist = nullptr, *t_ccnt = nullptr;   // dense list of the valid edge slots of the layer being differentiated (k_compact_rows), counts
     float* t_fix = nullptr;                 // [2] scale / inverse scale of the current backward call
     int t_nblk = 0;
@@ -2439,7 +2441,8 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     h->t_ccnt = carve<int>(cur, 128);            // [layer][16]: passes per etype, rows per etype at + 8; node units at [96]
     h->t_clist = carve<int>(cur, (size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) * 32 + 64);    // dense row list of the layer being differentiated
     h->t_gpart_enc = carve<float>(cur, (size_t)PFT_ENC_BLOCKS * std::max(h->enc_n, 1));
-    h->t_ulist = carve<int>(cur, (size_t)2 * std::max(h->n_node_tiles, h->n_node_tiles_act) + 64);
+    h->t_ucap = 32 * std::max(h->n_node_tiles, h->n_node_tiles_act) + 16;      // rows per node type in the dense unit list
+    h->t_ulist = carve<int>(cur, (size_t)2 * 2 * h->t_ucap + 64);             // [2 types][t_ucap] x (node id, saved-level row)
     h->t_Gg = carve<float>(cur, (size_t)h->B * c.rec_nf * PF_S);
     h->t_lx0c = carve<float>(cur, (size_t)h->Nf * 3); h->t_lag = carve<float>(cur, (size_t)h->B); h->t_lsg = carve<float>(cur, (size_t)h->B);
     h->t_lgx = carve<float>(cur, (size_t)h->Nf * 3); h->t_lgh = carve<float>(cur, (size_t)h->Nf * c.pharm_nf); h->t_lout = carve<float>(cur, 64);
@@ -2703,8 +2706,8 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         if ((int)h->t_node_saved.size() > l && h->t_node_saved[l]) {
             n.sv_z = h->t_nsv_z[l]; n.sv_g = h->t_nsv_g[l]; n.sv_v = h->t_nsv_v[l]; n.sv_stride = (size_t)2 * h->N;
         }
-        n.ulist = h->t_ulist; n.ucnt = h->t_ccnt + 96;
-        pfk_compact_units(n.tiles, n.ntiles, h->d_dyn_cnt, h->t_ulist, h->t_ccnt + 96, s);
+        n.ulist = h->t_ulist; n.ucnt = h->t_ccnt + 96; n.ucap = h->t_ucap;
+        pfk_compact_node_rows(n.tiles, n.ntiles, h->d_dyn_cnt, h->d_act_ids, N, h->t_ulist, h->t_ucap, h->t_ccnt + 96, s);
         rp.node_grid[l] = n.ntiles > 0 ? std::max(1, std::min(nb, 2 * n.ntiles)) : 0;
         { ProfScope ps(h, pf_handle::K_BWD_NODE, s); pfk_bwd_node(&n, rp.node_grid[l], s); }
         BwdEdgeLevelParams e{};

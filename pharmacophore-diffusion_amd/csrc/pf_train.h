@@ -82,7 +82,8 @@ struct BwdHeadParams {
 struct BwdNodeParams {
     TrainCommon c;
     const NodeTile* tiles; int ntiles;
-    const int* ulist; const int* ucnt;       // k_compact_units: the non-empty 16-row units (2 * tile + half) and their number
+    const int* ulist; const int* ucnt;       // k_compact_node_rows: per node type (pharm at 0, prot at ucap entries) the valid rows of the
+    int ucap;                                // tile table, densely, as (node id, row in the saved levels); ucnt[1], ucnt[2] = their numbers
     const int* in_start; const int* in_cnt; int N;
     int pp_slot;                             // 1: all pp in-edges; 2: compact copy for the active atoms (pruned layer)
     const int* row_ids; const int* dyn_cnt;  // active-atom lists (tiles with ids != 0) and their lengths

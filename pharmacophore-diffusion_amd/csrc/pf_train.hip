@@ -432,7 +432,8 @@ __device__ __forceinline__ void chain_fwd(const ChainLds& L, const GvpT* g, cons
 // fill Z, gate and the next level's inputs (act = SiLU(Z), gated vectors) with independent loads -- one round trip instead of the
 // ~30 k cycles per GVP of the recomputation.  The sh columns of every Sin are filled by gvp_bwd (fill_sh).
 __device__ __forceinline__ void chain_load(const ChainLds& L, const GvpT* g, const float* sv_z, const float* sv_g, const float* sv_v,
-                                           const size_t stride, const size_t i0, const int nv, float* vout_last, const int tid) {
+                                           const size_t stride, const size_t i0, const int nv, float* vout_last, const int tid,
+                                           const int* rows = nullptr) {     // rows (LDS, 16 entries): row indices instead of i0 + row
     // every level's rows are requested before any is consumed: one thread = one 16-byte piece of a Z row (16 rows x 32
     // pieces = the block), the first 64 threads a piece of a gate row, the first 192 a piece of a vector row
     const int zr = tid >> 5, zk = (tid & 31) * 4;
@@ -444,9 +445,12 @@ __device__ __forceinline__ void chain_load(const ChainLds& L, const GvpT* g, con
         zq[l] = gq[l] = vq[l] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (l < L.nlv) {
             const size_t r0 = (size_t)l * stride + i0;
-            zq[l] = *reinterpret_cast<const float4*>(sv_z + (r0 + min(zr, nv - 1)) * PF_S + zk);
-            if (tid < 64) gq[l] = *reinterpret_cast<const float4*>(sv_g + (r0 + min(gr, nv - 1)) * 16 + gk);
-            if (tid < 192) vq[l] = *reinterpret_cast<const float4*>(sv_v + (r0 + min(vr, nv - 1)) * 48 + vk);
+            const size_t iz = rows ? (size_t)rows[min(zr, nv - 1)] : (size_t)min(zr, nv - 1);
+            const size_t ig = rows ? (size_t)rows[min(gr, nv - 1)] : (size_t)min(gr, nv - 1);
+            const size_t iv = rows ? (size_t)rows[min(vr, nv - 1)] : (size_t)min(vr, nv - 1);
+            zq[l] = *reinterpret_cast<const float4*>(sv_z + (r0 + iz) * PF_S + zk);
+            if (tid < 64) gq[l] = *reinterpret_cast<const float4*>(sv_g + (r0 + ig) * 16 + gk);
+            if (tid < 192) vq[l] = *reinterpret_cast<const float4*>(sv_v + (r0 + iv) * 48 + vk);
         }
     }
 #pragma unroll
@@ -673,7 +677,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
     __shared__ float vy[TR * VWS], vz[TR * VWS], gvu[TR * VWS], rvl[TR * VWS];
     __shared__ float s_rstd1[TR], s_rstd2[TR], s_inv[TR];
     __shared__ VecLn s_vl1[TR], s_vl2[TR];
-    __shared__ int s_n[TR];
+    __shared__ int s_n[TR], s_sv[TR];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     ChainLds L; L.init(lds, p.n_upd);
     const float* W = p.c.W;
@@ -685,23 +689,24 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
     const uint32_t st_msg = (uint32_t)p.layer * 2u, st_res = st_msg + 1u;
     // the non-empty 16-row units of the launch, dealt round-robin (k_compact_units): dealt by table index, the units of the
     // active-atom tiles (capacity 256 atoms per graph, ~60 in use) left every other block with half as much again to do
-    const int nunits = p.ucnt[0];
-    for (int ui = blockIdx.x; ui < nunits; ui += gridDim.x) {
-        const int unit = p.ulist[ui];
-        const NodeTile t = p.tiles[unit >> 1];
-        const int nt = t.ntype;
+    const int rows1 = p.ucnt[1], rows0 = p.ucnt[2];
+    const int U1 = (rows1 + TR - 1) / TR, U0 = (rows0 + TR - 1) / TR;
+    const int2* const list1 = reinterpret_cast<const int2*>(p.ulist);
+    const int2* const list0 = list1 + p.ucap;
+    for (int ui = blockIdx.x; ui < U1 + U0; ui += gridDim.x) {
+        const int nt = ui < U1 ? 1 : 0;
+        const int u0 = (nt ? ui : ui - U1) * TR;
+        const int2* const lst = nt ? list1 : list0;
         const GvpT* g = p.upd + nt * p.n_upd;
         const int o_l1w = p.o_ln[nt][0], o_l1b = p.o_ln[nt][1], o_l2w = p.o_ln[nt][2];
-        int tn = t.n;
-        if (t.cnt_idx >= 0) tn = min(tn, max(p.dyn_cnt[t.cnt_idx] - t.rel, 0));
-        for (int sub = unit & 1; sub == (unit & 1) && sub * TR < tn; sub += 2) {
-            const int nv = min(TR, tn - sub * TR);
-            const int n0 = t.n0 + sub * TR;
+        {
+            const int nv = min(TR, (nt ? rows1 : rows0) - u0);
             PFT_STAMP(20);
             if (tid < TR) {
-                const int pos = n0 + min(tid, nv - 1);
-                const int n = t.ids ? p.row_ids[pos] : pos;      // pruned layer: rows are positions in the active-atom list
+                const int2 ent = lst[u0 + min(tid, nv - 1)];
+                const int n = ent.x;
                 s_n[tid] = n;
+                s_sv[tid] = ent.y;
                 float inv = 1.0f;
                 if (p.norm_mode == 1) inv = 1.0f / p.norm_value;
                 else if (p.norm_mode == 2) inv = 1.0f / p.gnorm[nt * p.B + p.gid[n]];
@@ -771,7 +776,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
             PFT_STAMP(22);
             const bool saved = p.sv_z != nullptr;
             if (!saved) chain_fwd(L, g, W, pk, rvl, tid, lane, wv);
-            else chain_load(L, g, p.sv_z, p.sv_g, p.sv_v, p.sv_stride, (size_t)(t.ids ? p.N : 0) + n0, nv, rvl, tid);
+            else chain_load(L, g, p.sv_z, p.sv_g, p.sv_v, p.sv_stride, 0, nv, rvl, tid, s_sv);
             PFT_STAMP(23);
             // ---- residual dropout, residual, LN2 statistics
             for (int idx = tid; idx < TR * 128; idx += NT) {
@@ -934,29 +939,43 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
 // (a dynamic region's tiles cover its capacity; a backward block that is dealt tiles by table index gets whatever share
 // of the empty ones the layout gives it -- the ff blocks of config 5 walked four times the tiles of the pp blocks)
 // non-empty 16-row units (tile, half) of a node tile table, in table order
-__global__ __launch_bounds__(256) void k_compact_units(const NodeTile* tiles, const int ntiles, const int* dyn_cnt, int* ulist, int* ucnt) {
-    __shared__ int s_w[4];
+// the valid rows of a node tile table, densely and in table order, per node type: list[s * cap + i] = (node id, row in the saved
+// update-chain levels), s = 0 pharm, 1 prot; ucnt[1 + s] = rows.  A backward unit is 16 consecutive entries of one type: the
+// per-graph active-atom tiles of the pruned layer hold 20-40 of 256 slots, and a unit costs the same whatever it holds.
+__global__ __launch_bounds__(1024) void k_compact_node_rows(const NodeTile* tiles, const int ntiles, const int* dyn_cnt, const int* row_ids,
+                                                            const int N, int2* list, const int cap, int* ucnt) {
+    __shared__ int s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int type = blockIdx.x == 0 ? 1 : 0;
+    int2* out = list + (size_t)blockIdx.x * cap;
     int base = 0;
-    for (int c = 0; c < 2 * ntiles; c += 256) {
-        const int u = c + tid;
-        bool ne = false;
-        if (u < 2 * ntiles) {
-            const NodeTile t = tiles[u >> 1];
-            int n = t.n;
+    for (int c = 0; c < ntiles; c += 1024) {
+        const int ti = c + tid;
+        int n = 0;
+        NodeTile t{};
+        if (ti < ntiles) {
+            t = tiles[ti];
+            n = t.n;
             if (t.cnt_idx >= 0) n = min(n, max(dyn_cnt[t.cnt_idx] - t.rel, 0));
-            ne = (u & 1) * TR < n;
+            if (t.ntype != type) n = 0;
         }
-        const unsigned long long m = __ballot(ne);
-        if (lane == 0) s_w[wv] = __popcll(m);
+        int incl = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+        if (lane == 63) s_w[wv] = incl;
         __syncthreads();
-        int off = base;
-        for (int w = 0; w < wv; ++w) off += s_w[w];
-        if (ne) ulist[off + __popcll(m & ((1ull << lane) - 1ull))] = u;
-        base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        int off = base, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int x = s_w[w]; if (w < wv) off += x; tot += x; }
+        off += incl - n;
+        for (int r = 0; r < n; ++r) {
+            const int pos = t.n0 + r;
+            out[off + r] = make_int2(t.ids ? row_ids[pos] : pos, (t.ids ? N : 0) + pos);
+        }
+        base += tot;
         __syncthreads();
     }
-    if (tid == 0) ucnt[0] = base;
+    if (tid == 0) ucnt[1 + blockIdx.x] = base;
 }
 struct CompactParams { int et_tile0[5]; };
 __global__ __launch_bounds__(1024) void k_compact_tiles(const EdgeTile* tiles, const CompactParams cp, const int* dyn_cnt, int* clist, int* ccnt) {
@@ -1922,8 +1941,9 @@ void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, int nblocks, hipStream_t s)
     if (nblocks == 0 || p->et_tile0[p->n_et] == p->et_tile0[0]) return;
     hipLaunchKernelGGL(k_bwd_edge_level, dim3(nblocks), dim3(NT), 0, s, *p);
 }
-void pfk_compact_units(const NodeTile* tiles, int ntiles, const int* dyn_cnt, int* ulist, int* ucnt, hipStream_t s) {
-    hipLaunchKernelGGL(k_compact_units, dim3(1), dim3(256), 0, s, tiles, ntiles, dyn_cnt, ulist, ucnt);
+void pfk_compact_node_rows(const NodeTile* tiles, int ntiles, const int* dyn_cnt, const int* row_ids, int N, int* list, int cap, int* ucnt,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(k_compact_node_rows, dim3(2), dim3(1024), 0, s, tiles, ntiles, dyn_cnt, row_ids, N, reinterpret_cast<int2*>(list), cap, ucnt);
 }
 void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s) {
     CompactParams cp;
