@@ -68,7 +68,6 @@ void pfk_loss_eval(const LossParams* p, hipStream_t s);
 void pfk_scale_loss(float* gx, int nx, const float* a, const float* a2, float* gh, int nh, const float* b, const float* b2, hipStream_t s);
 void pfk_compact_node_rows(const NodeTile* tiles, int ntiles, const int* dyn_cnt, const int* row_ids, int N, int* list, int cap, int* ucnt,
                            hipStream_t s);
-void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s);
 void pfk_compact_rows(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* rlist, int* ccnt, hipStream_t s);
 void pfk_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
               float bc1, float bc2_sqrt, hipStream_t s);

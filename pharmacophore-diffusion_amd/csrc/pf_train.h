@@ -47,7 +47,7 @@ struct ReduceParams {
     int NB;                  // gradient copies = grid of the edge-level launches
     int head_grid, enc_grid, node_grid[4];
     int n_et[4];             // etypes that took part in layer l's edge-level launches
-    const int* ccnt;         // [layer][4] non-empty tiles per etype (k_compact_tiles)
+    const int* ccnt;         // [layer][16]: passes per etype (k_compact_rows), rows per etype at + 8
 };
 
 struct TrainCommon {

@@ -927,7 +927,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
 #define E2_ZS 144         // LDS row stride of Z rows [128] (16-byte aligned rows: b128 accesses)
 #define E2_SS 176         // ... of scalar rows [si + h] (<= 161): whole 16-column tiles
 #define E2_WHS 36         // ... of the staged Wh [vi][h], zero padded to [32][36]
-#define E2_TILES 64       // tile descriptors staged per round
+#define E2_TILES 64       // passes per round (their edge slots are staged in LDS together)
 // Every phase of a pass derives its lane coordinates from an OPAQUE copy of the thread id: otherwise the compiler hoists the
 // per-thread addresses of all ten phases out of the pass loop (~100 registers live across it, spilled in the prologue and
 // re-read from scratch at every use, and no room left for the rows fetched ahead)
@@ -935,10 +935,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
     const int li = lane & 15, kq = lane >> 4; (void)li; (void)kq
 
 
-// the non-empty tiles of each etype's segment of a tile table, in table order: clist[et_tile0[et] - et_tile0[0] + i], ccnt[et]
-// (a dynamic region's tiles cover its capacity; a backward block that is dealt tiles by table index gets whatever share
-// of the empty ones the layout gives it -- the ff blocks of config 5 walked four times the tiles of the pp blocks)
-// non-empty 16-row units (tile, half) of a node tile table, in table order
+// (a dynamic region's tiles cover its capacity and are partly empty: the backward kernels work on dense lists of what is valid)
 // the valid rows of a node tile table, densely and in table order, per node type: list[s * cap + i] = (node id, row in the saved
 // update-chain levels), s = 0 pharm, 1 prot; ucnt[1 + s] = rows.  A backward unit is 16 consecutive entries of one type: the
 // per-graph active-atom tiles of the pruned layer hold 20-40 of 256 slots, and a unit costs the same whatever it holds.
@@ -978,34 +975,6 @@ __global__ __launch_bounds__(1024) void k_compact_node_rows(const NodeTile* tile
     if (tid == 0) ucnt[1 + blockIdx.x] = base;
 }
 struct CompactParams { int et_tile0[5]; };
-__global__ __launch_bounds__(1024) void k_compact_tiles(const EdgeTile* tiles, const CompactParams cp, const int* dyn_cnt, int* clist, int* ccnt) {
-    // one block per etype, 1024 tiles per round (the pp segment of a 256-pocket batch has 20 k tiles: 17 us at 256 per round)
-    __shared__ int s_w[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int t0 = cp.et_tile0[blockIdx.x], t1 = cp.et_tile0[blockIdx.x + 1], seg0 = t0 - cp.et_tile0[0];     // one block per etype
-    int base = 0;
-    for (int c = t0; c < t1; c += 1024) {
-        const int ti = c + tid;
-        bool ne = false;
-        if (ti < t1) {
-            const EdgeTile t = tiles[ti];
-            int n = t.n;
-            if (t.cnt_idx >= 0) n = min(n, max(dyn_cnt[t.cnt_idx] - t.rel, 0));
-            ne = n > 0;
-        }
-        const unsigned long long m = __ballot(ne);
-        if (lane == 0) s_w[wv] = __popcll(m);
-        __syncthreads();
-        int off = base, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { const int x = s_w[w]; if (w < wv) off += x; tot += x; }
-        if (ne) clist[seg0 + off + __popcll(m & ((1ull << lane) - 1ull))] = ti;
-        base += tot;
-        __syncthreads();
-    }
-    if (tid == 0) ccnt[blockIdx.x] = base;
-}
-
 // the valid edge slots of each etype's segment of a tile table, densely and in table order: rlist[32 (et_tile0[et] - et_tile0[0]) + i],
 // i < rows; ccnt[et] = passes of 32 rows, ccnt[8 + et] = rows.  A backward pass then takes 32 consecutive entries whatever
 // regions they come from: the per-(graph, etype) regions of the dynamic etypes fill their 32-slot tiles to ~65 % (20-56 edges
@@ -1099,7 +1068,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
     const int tid_ = tid;
-    // blocks per etype in proportion to its non-empty tiles (k_compact_tiles), at least one where there are tiles: every
+    // blocks per etype in proportion to its passes (k_compact_rows), at least one where there are rows: every
     // block derives the same partition from the four counts
     int et = -1, nb = 0, my = 0, cnt_et = 0;
 #pragma unroll
@@ -1944,11 +1913,6 @@ void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, int nblocks, hipStream_t s)
 void pfk_compact_node_rows(const NodeTile* tiles, int ntiles, const int* dyn_cnt, const int* row_ids, int N, int* list, int cap, int* ucnt,
                            hipStream_t s) {
     hipLaunchKernelGGL(k_compact_node_rows, dim3(2), dim3(1024), 0, s, tiles, ntiles, dyn_cnt, row_ids, N, reinterpret_cast<int2*>(list), cap, ucnt);
-}
-void pfk_compact_tiles(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* clist, int* ccnt, hipStream_t s) {
-    CompactParams cp;
-    for (int et = 0; et <= 4; ++et) cp.et_tile0[et] = et_tile0[et];
-    hipLaunchKernelGGL(k_compact_tiles, dim3(n_et), dim3(1024), 0, s, tiles, cp, dyn_cnt, clist, ccnt);
 }
 void pfk_compact_rows(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* rlist, int* ccnt, hipStream_t s) {
     if (n_et <= 0) return;
