@@ -364,6 +364,8 @@ struct pf_handle {
     float* t_Gg = nullptr;                  // encoder backward: upstream gradient summed per (graph, element)
     int* t_ulist = nullptr;                 // dense per-type row list of the layer being differentiated (k_compact_node_rows; counts: t_ccnt[97], [98])
     int t_ucap = 0;
+    size_t t_clist_cap = 0, t_ulist_cap = 0;   // ints per conv layer in t_clist / t_ulist (one list per layer: they are built ahead, on the side stream)
+    hipEvent_t cmp_ev[2] = {nullptr, nullptr};
     int *t_clist = nullptr, *t_ccnt = nullptr;   // dense list of the valid edge slots of the layer being differentiated (k_compact_rows), counts
     float* t_fix = nullptr;                 // [2] scale / inverse scale of the current backward call
     int t_nblk = 0;
@@ -1241,6 +1243,7 @@ void pf_destroy(pf_handle* h) {
         if (h->tab_guard[k]) (void)hipEventDestroy(h->tab_guard[k]);
         if (h->tab_up[k]) (void)hipEventDestroy(h->tab_up[k]);
     }
+    for (int k = 0; k < 2; ++k) if (h->cmp_ev[k]) (void)hipEventDestroy(h->cmp_ev[k]);
     if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
     if (h->l0flag_host) (void)hipHostFree(h->l0flag_host);
     if (h->l0flag_ev) (void)hipEventDestroy(h->l0flag_ev);
@@ -2438,10 +2441,12 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     }
     h->t_fix = carve<float>(cur, 64);
     h->t_ccnt = carve<int>(cur, 128);            // [layer][16]: passes per etype, rows per etype at + 8; node units at [96]
-    h->t_clist = carve<int>(cur, (size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) * 32 + 64);    // dense row list of the layer being differentiated
+    h->t_clist_cap = (size_t)std::max(h->n_edge_tiles, h->n_edge_tiles_act) * 32 + 64;
+    h->t_clist = carve<int>(cur, h->t_clist_cap * L);                          // dense row lists, one per conv layer
     h->t_gpart_enc = carve<float>(cur, (size_t)PFT_ENC_BLOCKS * std::max(h->enc_n, 1));
     h->t_ucap = 32 * std::max(h->n_node_tiles, h->n_node_tiles_act) + 16;      // rows per node type in the dense unit list
-    h->t_ulist = carve<int>(cur, (size_t)2 * 2 * h->t_ucap + 64);             // [2 types][t_ucap] x (node id, saved-level row)
+    h->t_ulist_cap = (size_t)2 * 2 * h->t_ucap + 64;
+    h->t_ulist = carve<int>(cur, h->t_ulist_cap * L);                          // per conv layer: [2 types][t_ucap] x (node id, saved-level row)
     h->t_Gg = carve<float>(cur, (size_t)h->B * c.rec_nf * PF_S);
     h->t_lx0c = carve<float>(cur, (size_t)h->Nf * 3); h->t_lag = carve<float>(cur, (size_t)h->B); h->t_lsg = carve<float>(cur, (size_t)h->B);
     h->t_lgx = carve<float>(cur, (size_t)h->Nf * 3); h->t_lgh = carve<float>(cur, (size_t)h->Nf * c.pharm_nf); h->t_lout = carve<float>(cur, 64);
@@ -2651,6 +2656,29 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     pfk_fix_scale(dev_g_eps_h, h->Nf * c.pharm_nf, dev_g_eps_x, h->Nf * 3, h->t_fix, s);
     if (h->tA_dirty) PF_HIP(h, hipMemsetAsync(h->d_tA, 0, h->tA_capacity, s));      // an earlier pass stopped half way
     h->tA_dirty = true;
+    // The dense work lists of every conv layer (k_compact_rows, k_compact_node_rows: one or two workgroups each, 10-20 us) depend
+    // on the forward's edge counts only: they are built on the side stream while the head's backward runs here.
+    auto layer_tables = [&](int l, const NodeTile*& nt_tiles, int& nt_n, const EdgeTile*& e_tiles, const int*& et0, int& n_et) {
+        const bool last = l == L - 1, pruned = h->prune && L >= 2 && l == L - 2;
+        nt_tiles = pruned ? h->d_node_tiles_act : h->d_node_tiles;
+        nt_n = last ? h->n_node_tiles_last : (pruned ? h->n_node_tiles_act : h->n_node_tiles);
+        e_tiles = pruned ? h->d_edge_tiles_act : h->d_edge_tiles;
+        et0 = pruned ? h->et_tile0_act : h->et_tile0;
+        n_et = last ? 2 : 4;                         // the last layer's fp / pp messages reach no output
+    };
+    {
+        for (int k = 0; k < 2; ++k)
+            if (!h->cmp_ev[k]) PF_HIP(h, hipEventCreateWithFlags(&h->cmp_ev[k], hipEventDisableTiming));
+        hipStream_t side = h->s_copy ? h->s_copy : s;
+        if (side != s) { PF_HIP(h, hipEventRecord(h->cmp_ev[0], s)); PF_HIP(h, hipStreamWaitEvent(side, h->cmp_ev[0], 0)); }
+        for (int l = L - 1; l >= 0; --l) {
+            const NodeTile* ntt; const EdgeTile* ett; const int* et0; int ntn, n_et;
+            layer_tables(l, ntt, ntn, ett, et0, n_et);
+            pfk_compact_node_rows(ntt, ntn, h->d_dyn_cnt, h->d_act_ids, N, h->t_ulist + h->t_ulist_cap * l, h->t_ucap, h->t_ccnt + 96 + 4 * l, side);
+            pfk_compact_rows(ett, et0, n_et, h->d_dyn_cnt, h->t_clist + h->t_clist_cap * l, h->t_ccnt + 16 * l, side);
+        }
+        if (side != s) PF_HIP(h, hipEventRecord(h->cmp_ev[1], side));
+    }
     // (the head kernel stores dL/d(last layer output) for every pharm row, and the last layer's node kernel reads those rows
     // only: no clearing of t_G_*[0] here)
     {
@@ -2666,6 +2694,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         rp.head_grid = p.ntiles > 0 ? std::max(1, std::min(nb, 2 * p.ntiles)) : 0;
         { ProfScope ps(h, pf_handle::K_BWD_HEAD, s); pfk_bwd_head(&p, rp.head_grid, s); }
     }
+    if (h->s_copy && h->s_copy != s) PF_HIP(h, hipStreamWaitEvent(s, h->cmp_ev[1], 0));
     int a = 0;
     for (int l = L - 1; l >= 0; --l) {
         // The last conv layer's output is read on the pharm nodes only (dynamics_gvp.py:91): its protein rows have a
@@ -2705,8 +2734,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         if ((int)h->t_node_saved.size() > l && h->t_node_saved[l]) {
             n.sv_z = h->t_nsv_z[l]; n.sv_g = h->t_nsv_g[l]; n.sv_v = h->t_nsv_v[l]; n.sv_stride = (size_t)2 * h->N;
         }
-        n.ulist = h->t_ulist; n.ucnt = h->t_ccnt + 96; n.ucap = h->t_ucap;
-        pfk_compact_node_rows(n.tiles, n.ntiles, h->d_dyn_cnt, h->d_act_ids, N, h->t_ulist, h->t_ucap, h->t_ccnt + 96, s);
+        n.ulist = h->t_ulist + h->t_ulist_cap * l; n.ucnt = h->t_ccnt + 96 + 4 * l; n.ucap = h->t_ucap;
         rp.node_grid[l] = n.ntiles > 0 ? std::max(1, std::min(nb, 2 * n.ntiles)) : 0;
         { ProfScope ps(h, pf_handle::K_BWD_NODE, s); pfk_bwd_node(&n, rp.node_grid[l], s); }
         BwdEdgeLevelParams e{};
@@ -2715,9 +2743,8 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         const int* et0 = pruned ? h->et_tile0_act : h->et_tile0;
         for (int et = 0; et <= 4; ++et) e.et_tile0[et] = et0[et];
         e.n_et = last ? 2 : 4;                       // the last layer's fp / pp messages reach no output
-        e.clist = h->t_clist; e.ccnt = h->t_ccnt + 16 * l;
+        e.clist = h->t_clist + h->t_clist_cap * l; e.ccnt = h->t_ccnt + 16 * l;
         rp.n_et[l] = e.n_et;
-        pfk_compact_rows(e.tiles, e.et_tile0, e.n_et, h->d_dyn_cnt, h->t_clist, h->t_ccnt + 16 * l, s);
         e.esrc = h->d_esrc; e.edst = h->d_edst; e.xn = h->d_xn;
         e.h = h->t_H[l]; e.v = h->t_V[l];
         e.gagg_s = h->t_gagg_s; e.gagg_v = h->t_gagg_v; e.in_cnt = h->d_in_cnt; e.N = N;
