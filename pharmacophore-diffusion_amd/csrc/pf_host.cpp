@@ -238,6 +238,8 @@ struct pf_handle {
     bool tab_guard_set[2] = {false, false};
     int tab_next = 0;
     hipStream_t s_copy = nullptr;
+    hipStream_t s_side = nullptr;           // side stream of the backward pass (work lists, early gradient sums, encoders): NOT the copy
+                                            // stream -- the next bind's upload must not queue behind the end of this backward
     // one-hot check of the protein features (static hoist): 0 unknown (device flag pending), 1 one-hot, 2 not
     int l0_state = 0;
     int* l0flag_host = nullptr;             // pinned; written by an async copy of d_l0flag
@@ -1245,6 +1247,7 @@ void pf_destroy(pf_handle* h) {
     }
     for (int k = 0; k < 2; ++k) if (h->cmp_ev[k]) (void)hipEventDestroy(h->cmp_ev[k]);
     if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
+    if (h->s_side) (void)hipStreamDestroy(h->s_side);
     if (h->l0flag_host) (void)hipHostFree(h->l0flag_host);
     if (h->l0flag_ev) (void)hipEventDestroy(h->l0flag_ev);
     for (int k = 0; k < pf_handle::K_NUM; ++k)
@@ -2669,7 +2672,8 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     {
         for (int k = 0; k < 2; ++k)
             if (!h->cmp_ev[k]) PF_HIP(h, hipEventCreateWithFlags(&h->cmp_ev[k], hipEventDisableTiming));
-        hipStream_t side = h->s_copy ? h->s_copy : s;
+        if (!h->s_side) PF_HIP(h, hipStreamCreateWithFlags(&h->s_side, hipStreamNonBlocking));
+        hipStream_t side = h->s_side;
         if (side != s) { PF_HIP(h, hipEventRecord(h->cmp_ev[0], s)); PF_HIP(h, hipStreamWaitEvent(side, h->cmp_ev[0], 0)); }
         for (int l = L - 1; l >= 0; --l) {
             const NodeTile* ntt; const EdgeTile* ett; const int* et0; int ntn, n_et;
@@ -2694,8 +2698,9 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         rp.head_grid = p.ntiles > 0 ? std::max(1, std::min(nb, 2 * p.ntiles)) : 0;
         { ProfScope ps(h, pf_handle::K_BWD_HEAD, s); pfk_bwd_head(&p, rp.head_grid, s); }
     }
-    if (h->s_copy && h->s_copy != s) PF_HIP(h, hipStreamWaitEvent(s, h->cmp_ev[1], 0));
+    if (h->s_side != s) PF_HIP(h, hipStreamWaitEvent(s, h->cmp_ev[1], 0));
     int a = 0;
+    unsigned early_mask = 0;
     for (int l = L - 1; l >= 0; --l) {
         // The last conv layer's output is read on the pharm nodes only (dynamics_gvp.py:91): its protein rows have a
         // zero gradient, so -- as in the forward -- only the pharm node tiles and the ff / pf edge tiles do any work
@@ -2769,6 +2774,18 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
             if (l != 0) pfk_fix_apply(h->t_A_v, e.G_v_in, (size_t)N * 48, h->t_fix, s);       // conv layer 0 has no vector input
         }
         a ^= 1;
+        // the head's, this layer's node and message classes are complete: with more layers to go, their gradient copies are
+        // summed on the side stream now (bandwidth-bound, ~140 MB) under the next layer's kernels
+        if (last && L >= 2 && h->s_side != s) {
+            ReduceParams early = rp;
+            early.cls_mask = (1u << PFT_CLS_HEAD) | (1u << (PFT_CLS_NODE + l));
+            for (int et = 0; et < 4; ++et) early.cls_mask |= 1u << (PFT_CLS_MSG + l * 4 + et);
+            PF_HIP(h, hipEventRecord(h->cmp_ev[0], s));
+            PF_HIP(h, hipStreamWaitEvent(h->s_side, h->cmp_ev[0], 0));
+            pfk_train_reduce(&early, h->s_side);
+            PF_HIP(h, hipEventRecord(h->cmp_ev[1], h->s_side));
+            early_mask = early.cls_mask;
+        }
     }
     {
         BwdEncodeParams p{};
@@ -2788,7 +2805,9 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         rp.enc_grid = std::max(1, std::min(PFT_ENC_BLOCKS, tiles));
         pfk_bwd_encode(&p, rp.enc_grid, s);
     }
+    rp.cls_mask = ~early_mask;
     pfk_train_reduce(&rp, s);
+    if (early_mask) PF_HIP(h, hipStreamWaitEvent(s, h->cmp_ev[1], 0));       // the gradient is complete on the caller's stream
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     h->tA_dirty = false;

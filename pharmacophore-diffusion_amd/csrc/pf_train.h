@@ -48,6 +48,7 @@ struct ReduceParams {
     int head_grid, enc_grid, node_grid[4];
     int n_et[4];             // etypes that took part in layer l's edge-level launches
     const int* ccnt;         // [layer][16]: passes per etype (k_compact_rows), rows per etype at + 8
+    unsigned cls_mask;       // k_train_reduce: the classes this launch sums (bit = class number); the encoders' bit runs k_reduce_enc
 };
 
 struct TrainCommon {

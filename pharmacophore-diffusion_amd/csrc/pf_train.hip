@@ -1726,6 +1726,7 @@ __global__ void k_train_reduce(const ReduceParams p) {
     const int cls = p.tseg[lo].cls;
     int b0 = 0, b1 = 0;
     if (cls == PFT_CLS_ENC) return;                  // k_reduce_enc
+    if (cls < 0 || !((p.cls_mask >> cls) & 1u)) return;      // another launch's share (or an empty tensor)
     if (cls == PFT_CLS_HEAD) b1 = p.head_grid;
     else if (cls >= PFT_CLS_MSG) {
         const int l = (cls - PFT_CLS_MSG) >> 2, et = (cls - PFT_CLS_MSG) & 3;
@@ -1947,8 +1948,8 @@ void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s) {
     hipLaunchKernelGGL(k_bwd_encode, dim3(nblocks), dim3(NT), 0, s, *p);
 }
 void pfk_train_reduce(const ReduceParams* p, hipStream_t s) {
-    if (p->enc_n > 0) hipLaunchKernelGGL(k_reduce_enc, dim3((p->enc_n + 31) / 32), dim3(1024), 0, s, *p);
-    hipLaunchKernelGGL(k_train_reduce, dim3((p->nparams + 255) / 256), dim3(256), 0, s, *p);
+    if (p->enc_n > 0 && ((p->cls_mask >> PFT_CLS_ENC) & 1u)) hipLaunchKernelGGL(k_reduce_enc, dim3((p->enc_n + 31) / 32), dim3(1024), 0, s, *p);
+    if (p->cls_mask & ~(1u << PFT_CLS_ENC)) hipLaunchKernelGGL(k_train_reduce, dim3((p->nparams + 255) / 256), dim3(256), 0, s, *p);
 }
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s) {
     if (n == 0) return;
