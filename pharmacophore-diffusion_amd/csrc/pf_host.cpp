@@ -2656,7 +2656,6 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     rp.gpart = h->t_gpart; rp.nparams = (int)h->nparams; rp.grad = dev_grad; rp.tseg = h->d_tseg; rp.ntens = h->n_tseg;
     rp.NB = nb; rp.ccnt = h->t_ccnt;
     rp.gpart_enc = h->t_gpart_enc; rp.enc_begin = h->enc_begin; rp.enc_n = h->enc_n;
-    pfk_fix_scale(dev_g_eps_h, h->Nf * c.pharm_nf, dev_g_eps_x, h->Nf * 3, h->t_fix, s);
     if (h->tA_dirty) PF_HIP(h, hipMemsetAsync(h->d_tA, 0, h->tA_capacity, s));      // an earlier pass stopped half way
     h->tA_dirty = true;
     // The dense work lists of every conv layer (k_compact_rows, k_compact_node_rows: one or two workgroups each, 10-20 us) depend
@@ -2675,6 +2674,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         if (!h->s_side) PF_HIP(h, hipStreamCreateWithFlags(&h->s_side, hipStreamNonBlocking));
         hipStream_t side = h->s_side;
         if (side != s) { PF_HIP(h, hipEventRecord(h->cmp_ev[0], s)); PF_HIP(h, hipStreamWaitEvent(side, h->cmp_ev[0], 0)); }
+        pfk_fix_scale(dev_g_eps_h, h->Nf * c.pharm_nf, dev_g_eps_x, h->Nf * 3, h->t_fix, side);      // (first read by the last layer's edge kernels)
         for (int l = L - 1; l >= 0; --l) {
             const NodeTile* ntt; const EdgeTile* ett; const int* et0; int ntn, n_et;
             layer_tables(l, ntt, ntn, ett, et0, n_et);
