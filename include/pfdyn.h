@@ -21,9 +21,13 @@
  *     the library owns its packed weights and a workspace sized by pf_set_pocket_batch;
  *   - "dev" pointers are device memory of the current HIP device, "host" pointers host memory;
  *     all tensors are dense row-major fp32 (indices int32);
- *   - all work is enqueued on the caller's stream; no call synchronises the device except
- *     pf_create/pf_commit_weights/pf_set_pocket_batch (allocation + host->device copies of
- *     small tables) and the pf_debug_* readers;
+ *   - all work is ordered on the caller's stream: when the stream reaches the end of a call's work,
+ *     every output of the call is complete.  Two calls also use streams of the handle, joined to the
+ *     caller's stream by events -- pf_set_pocket_batch uploads its tables on a copy stream (the upload
+ *     of the next batch runs under the kernels of the current one), pf_train_backward builds its work
+ *     lists and sums finished gradient copies on a side stream.  No call synchronises the device
+ *     except pf_create / pf_commit_weights / pf_set_pocket_batch when an allocation has to grow, and
+ *     the pf_debug_* readers;
  *   - a handle is bound to one device and is not thread-safe (one handle per GPU / process).
  *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
  *     PF_ERR_HIP.
@@ -102,9 +106,11 @@ int pf_commit_weights(pf_handle* h);
 /* -- static per-batch data (the DGL-free batch container) -----------------------------------
  * B graphs; graph g owns prot atoms [prot_ptr[g], prot_ptr[g+1]) and pharmacophore centers
  * [pharm_ptr[g], pharm_ptr[g+1]).  pp edges (static prot->prot, batch-local prot ids) may be in
- * any order.  prot_x / prot_h are copied into the workspace.  Asynchronous: the host tables are staged in pinned
- * memory owned by the handle and uploaded with one copy on `stream`; the host arrays may be freed on return.  The call
- * synchronises the device only when the workspace has to grow. */
+ * any order (destination-sorted lists inside their graphs take a vectorised pass; anything else a scalar one that also
+ * reports what is wrong).  prot_x / prot_h are copied into the handle's memory.  Asynchronous: the host tables are built in
+ * pinned memory owned by the handle and uploaded with one copy (on the handle's copy stream, ordered before everything the
+ * caller enqueues on `stream` afterwards); the host arrays may be freed on return.  The call synchronises the device only
+ * when the workspace or a table buffer has to grow. */
 int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* host_prot_ptr, const int32_t* host_pharm_ptr,
                         const float* dev_prot_x, const float* dev_prot_h,
                         int64_t n_pp, const int32_t* host_pp_src, const int32_t* host_pp_dst, pf_stream stream);
