@@ -2085,7 +2085,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     PF_HIP(h, hipMemcpyAsync(h->l0flag_host, h->d_l0flag, 4, hipMemcpyDeviceToHost, s));
     PF_HIP(h, hipEventRecord(h->l0flag_ev, s));
     mark();      // 6: everything enqueued
-    if (timing) fprintf(stderr, "[pf_set_pocket_batch] B=%d tables %.2f ws %.2f stage-wait %.2f memcpy %.2f upload %.2f rest %.2f ms (fresh %d, %zu MB)\n",
+    if (timing) fprintf(stderr, "[pf_set_pocket_batch] B=%d checks+tables %.2f ws %.2f stage-wait %.2f index arrays (in staging) %.2f upload %.2f launches+waits %.2f ms (fresh %d, %zu MB)\n",
                         B, tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], tm[6] - tm[5], (int)fresh, bytes >> 20);
     h->l0_state = 0; h->l0_onehot = false;
     if (host_onehot >= 0) { h->l0_state = host_onehot ? 1 : 2; h->l0_onehot = host_onehot == 1; }
