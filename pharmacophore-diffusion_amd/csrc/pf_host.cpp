@@ -45,6 +45,7 @@ void pfk_load_coords(const float* src, float4* xn, int n, const int* gid, const 
 void pfk_load_noise0(const float* nz, float4* xn, float* hf, int n, int nf, hipStream_t s);
 void pfk_copy(const float* src, float* dst, size_t n, hipStream_t s);
 void pfk_zero_multi(const ZeroList* z, hipStream_t s);
+void pfk_copy2(const float* a, float* da, size_t na, const float* b, float* db, size_t nb, hipStream_t s);
 void pfk_scale_copy(const float* src, float* dst, size_t n, float sc, hipStream_t s);
 void pfk_segment_mean(const float4* xn, const int* ptr, int base, int B, float* out, hipStream_t s);
 void pfk_step_update(const StepParams* p, hipStream_t s);
@@ -2067,8 +2068,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     }
     h->zero_row = (int)Ecap;
     if (!from_host) {
-        pfk_copy(dev_prot_x, h->d_prot_x0, (size_t)Np * 3, s);
-        pfk_copy(dev_prot_h, h->d_prot_h0, (size_t)Np * c.rec_nf, s);
+        pfk_copy2(dev_prot_x, h->d_prot_x0, (size_t)Np * 3, dev_prot_h, h->d_prot_h0, (size_t)Np * c.rec_nf, s);
     }
     pfk_load_coords(h->d_prot_x0, h->d_xn, Np, h->d_gid, nullptr, 0.f, s);
     {

@@ -1717,6 +1717,12 @@ __global__ __launch_bounds__(256) void k_zero_multi(const ZeroList z) {
         }
     }
 }
+// two copies in one launch (the bind's coordinate and feature rows)
+__global__ void k_copy2(const float* a, float* da, const size_t na, const float* b, float* db, const size_t nb) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) da[i] = a[i];
+    else if (i - na < nb) db[i - na] = b[i - na];
+}
 // per-graph mean of coordinates (dgl.readout_nodes op='mean'); one wave per graph, fixed order
 __global__ __launch_bounds__(64) void k_segment_mean(const float4* xn, const int* ptr, const int base, float* out) {
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -2169,6 +2175,10 @@ void pfk_load_noise0(const float* nz, float4* xn, float* hf, int n, int nf, hipS
 void pfk_copy(const float* src, float* dst, size_t n, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+}
+void pfk_copy2(const float* a, float* da, size_t na, const float* b, float* db, size_t nb, hipStream_t s) {
+    if (na + nb == 0) return;
+    hipLaunchKernelGGL(k_copy2, dim3((unsigned)((na + nb + 255) / 256)), dim3(256), 0, s, a, da, na, b, db, nb);
 }
 void pfk_zero_multi(const ZeroList* z, hipStream_t s) {
     if (z->cnt == 0) return;

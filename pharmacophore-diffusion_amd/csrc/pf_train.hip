@@ -1818,7 +1818,7 @@ __global__ __launch_bounds__(256) void k_loss_prepare(const LossParams p) {
         p.xn[n] = make_float4(p.prot_x0[3 * n] - cx - mx, p.prot_x0[3 * n + 1] - cy - my, p.prot_x0[3 * n + 2] - cz - mz, 0.f);
 }
 __global__ __launch_bounds__(1024) void k_loss_eval(const LossParams p) {
-    __shared__ float red[6][1024];
+    __shared__ float red[6][16];
     const int tid = threadIdx.x;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float inv_x = 1.0f / (float)(p.Nf * 3), inv_h = 1.0f / (float)(p.Nf * p.nf);
@@ -1850,22 +1850,25 @@ __global__ __launch_bounds__(1024) void k_loss_eval(const LossParams p) {
         const float hit = ip == it ? 1.0f : 0.f;
         acc[0] += xl * wl; acc[1] += hl * wl; acc[2] += err; acc[3] += wm * err; acc[4] += hit; acc[5] += wm * hit;
     }
+    // fixed-order reduction: xor butterfly inside each wave, then the 16 wave sums in order (ten barrier-separated tree steps
+    // over six arrays were most of this kernel's 18 us)
 #pragma unroll
-    for (int q = 0; q < 6; ++q) red[q][tid] = acc[q];
-    __syncthreads();
-    for (int st = 512; st > 0; st >>= 1) {
-        if (tid < st)
+    for (int q = 0; q < 6; ++q) {
+        float v = acc[q];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) red[q][tid] += red[q][tid + st];
-        __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0) red[q][tid >> 6] = v;
     }
+    __syncthreads();
     if (tid == 0) {
         const float nfl = (float)p.Nf;
         float v[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
+            float tsum = 0.f;
+            for (int w = 0; w < 16; ++w) tsum += red[q][w];
             const float den = q == 0 ? (float)(p.Nf * 3) : (q == 1 ? (float)(p.Nf * p.nf) : nfl);
-            v[q] = red[q][0] / den;
+            v[q] = tsum / den;
             p.out[q] = v[q];
         }
         // what training_step / validation_step derive from the six (pharmacodiff.py:274-277): total loss, total error,
