@@ -129,7 +129,12 @@ int pf_set_pocket_batch_host(pf_handle* h, int32_t B, const int32_t* host_prot_p
  * verifies the claim (everything it can see on the host) and fails with PF_ERR_ARG if it does not hold.  Effect: during
  * sampling, copies at the same timestep share conv layer 0's protein->protein messages (computed once per pocket
  * instead of once per copy, gvp.py:545-549 being a pure function of pocket geometry, element types and t there);
- * outputs are the same up to fp32 summation order.  The groups apply to one bind only. */
+ * outputs are the same up to fp32 summation order.  The groups apply to one bind only -- the next bind call consumes the
+ * claim whether it succeeds or is rejected (argument checks included).  What "verifies" covers: ptr arrays and pp edges
+ * always (they are host arrays); coordinates and features only for pf_set_pocket_batch_host.  With pf_set_pocket_batch
+ * (DEVICE coordinates / features) the library cannot see those rows on the host and does NOT compare them: a false claim
+ * there makes copies silently share their representative's conv-layer-0 messages.  The Python engine compares the rows on
+ * the device before claiming (engine.py: set_batch); a C-ABI caller must do the same or not claim. */
 int pf_set_pocket_groups(pf_handle* h, int32_t B, const int32_t* host_rep);
 
 /* Optional, right after pf_set_pocket_batch: the caller states whether every row of prot_h is an element one-hot
@@ -271,7 +276,9 @@ int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges /
  * on the batch: pf_host.cpp LaunchPolicy): *rows_per_wave = 4 or 8 (row-group kernels, pf_rg.hip: k_rg_edge), 16 (16-row
  * items on the four waves of a workgroup, pf_n16.hip: k_n16_edge; 17 = the fused launch k_n16_fused, whose items also
  * compute conv layer 0's node update of their source rows), 32 (one wave per 32-row tile: k_edge_msg) or 128 (four waves per
- * 32-row tile: k_edge_msg_coop / coop2) */
+ * 32-row tile: k_edge_msg_coop / coop2).  layer == n_convs asks about the launch behind the last conv layer's edge messages:
+ * 16 when the last call was the dynamics call of a pf_denoise_step whose node update + noise head + sampler update + edge
+ * build ran as the tail launch (pf_n16.hip: k_n16_tail, one workgroup per graph), else 0 */
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave);
 /* static hoist of conv layer 0's protein-protein messages in the last dynamics call: *rows_per_wave = 0 (not used: training,
  * tile kernels, protein features that are not element one-hots, PFDYN_NO_L0_HOIST=1), 4 / 8 rows per hoisted wave (row-group

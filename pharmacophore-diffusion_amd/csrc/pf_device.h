@@ -310,6 +310,25 @@ struct FusedParams {
     const int* pharm_ptr; int Np, n_edge_items;      // store items: graph g's centers; items [0, n_edge_items) are edge items
 };
 
+// n16 tail launch (pf_n16.hip: k_n16_tail; pf_denoise_step only): ONE workgroup per graph runs the last conv layer's node
+// update of the graph's centers, the noise head, the p(z_s | z_t) update and the edge build of the next dynamics call
+// (pf_stepbuild.h) -- the centers of a graph are all the update + build of that graph waits for, so the step's last launch
+// boundary disappears and eps never leaves the compute unit.
+struct TailParams {
+    // the last conv layer's messages and where a center finds them (NodeParams of that layer: slot 0 ff, slot 1 pf)
+    const int* in_start; const int* in_cnt; int N;
+    const float* msg_s; const float* msg_v; int zero_row, grp;
+    const float* h_in; const float* v_in;            // the layer's input state of the centers
+    const int* gid; const float* gnorm; int B, norm_mode; float norm_value;
+    pf_gcf ln1_w, ln1_b, ln2_w, ln2_b;               // message / update layer norms of the centers
+    int n_upd, n_head;
+    // wave 0's quad stream: [update chain][head GVPs 0 .. n_head - 2][the head's last GVP, zero-padded to 128 + 16 outputs, with
+    // to_scalar_output in gate rows 1 .. pharm_nf (pf_host.cpp: pack_n16_head_last)]; wave w's chain_stride floats further
+    pf_gcf chain; int chain_stride;
+    int pharm_nf;
+    float* eps_h; float* eps_x;                      // [Nf][pharm_nf], [Nf][3]: also written to memory (debug / profiling readers)
+};
+
 struct HeadParams {
     const NodeTile* tiles; // pharm tiles
     int ntiles;

@@ -37,6 +37,7 @@ void pfk_rg_unit(const UnitParams* p, hipStream_t s);
 void pfk_n16_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, hipStream_t s);
 void pfk_n16_unit(const UnitParams* p, hipStream_t s);
 void pfk_n16_fused(const EdgeParams* p, const FusedParams* f, const EncodeParams* enc, hipStream_t s);
+void pfk_n16_tail(const TailParams* t, const StepParams* sp, const BuildParams* bp, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
 void pfk_encode_build_pre(const EncodeParams* e, const BuildParams* b, const PreParams* pp, hipStream_t s);
@@ -131,7 +132,8 @@ static void linspace_f32(float start, float end, int steps, float* out) {
 //
 // Every threshold can be overridden from the environment (tests force every form onto the goldens; sweeps: tools/):
 //   PFDYN_N16 (bit 0: conv layers >= 1, bit 1: conv layer 0, bit 2: conv layer 0's node update fused into the last layer's edge
-//   launch when n_convs = 2; default 7), PFDYN_N16_ROWS_MAX (sets both n16 thresholds), PFDYN_N16_FUSE_ROWS_MAX, PFDYN_RG_ROWS_MAX,
+//   launch when n_convs = 2, bit 3: the tail launch of a denoising step -- last node update + noise head + sampler update + edge
+//   build, one workgroup per graph; default 15), PFDYN_TAIL_GRAPHS_MAX, PFDYN_N16_ROWS_MAX (sets both n16 thresholds), PFDYN_N16_FUSE_ROWS_MAX, PFDYN_RG_ROWS_MAX,
 //   PFDYN_RG2_ROWS_MIN (sets all four 8-row thresholds) / _NODE / _HOIST, PFDYN_RG2P_ROWS_MIN, PFDYN_L0_RGA / PFDYN_L0_RGP (rows-per-
 //   wave factor of the full-chain / hoisted items of a compact layer-0 launch), PFDYN_RG_SPLIT_MAX (all three) / _NODE / _HEAD,
 //   PFDYN_COOP_EDGE_MAX, PFDYN_COOP2_EDGE_MAX, PFDYN_COOP_NODE_MAX.  Forcing a row-group form switches the n16 form off
@@ -139,7 +141,8 @@ static void linspace_f32(float start, float end, int steps, float* out) {
 // ------------------------------------------------------------------------------------------------------------------
 struct LaunchPolicy {
     static constexpr int kCUs = 256, kSIMDs = 4 * kCUs;
-    int n16_mask = 7;
+    int n16_mask = 15;                      // bit 3: the tail launch (node update of the last layer + noise head + sampler update + edge build in one launch)
+    int tail_graphs_max = 256;              // ... up to this many graphs (one four-wave workgroup per graph; it does not share a CU)
     long n16_fuse_rows_max = 20000;         // the fused launch (bit 2): +2-3 % up to 32 graphs of 256 atoms, -4 % at 40 (its items carry five blocks: throughput-bound earlier)
     long n16_rows_max = 24000;              // measured at 256-atom pockets (575 slots per graph): +5 % at 16 graphs, +10 % at 32, -3..-5 % at 64, -15 % at 256
     int rg_rows_max = 1 << 30;
@@ -173,6 +176,7 @@ struct LaunchPolicy {
                               "PFDYN_L0_RGP", "PFDYN_RG_ROWS_MAX"})
             if (getenv(v)) n16_mask = 0;
         geti("PFDYN_N16", n16_mask);
+        geti("PFDYN_TAIL_GRAPHS_MAX", tail_graphs_max);
         if (const char* e = getenv("PFDYN_N16_ROWS_MAX")) n16_rows_max = n16_fuse_rows_max = atol(e);
         if (const char* e = getenv("PFDYN_N16_FUSE_ROWS_MAX")) n16_fuse_rows_max = atol(e);
     }
@@ -300,6 +304,10 @@ struct pf_handle {
     size_t n16_l0[4] = {0, 0, 0, 0}, n16_l0_stride[4] = {0, 0, 0, 0};
     // fused launch (n_convs = 2): per etype of the last layer (ff, pf) [update chain of conv layer 0 for the source type][message chain]
     size_t n16_fused[2] = {0, 0}, n16_fused_stride[2] = {0, 0};
+    // tail launch (pf_n16.hip: k_n16_tail): [update chain of the centers in the last conv layer][noise head; its last GVP padded, with to_scalar_output]
+    size_t n16_tail = 0, n16_tail_stride = 0;
+    bool tail_done = false;                 // the last run_dynamics call of a denoising step also did the step's update + build
+    bool last_tail = false;                 // pf_debug_kernel_family(layer = n_convs)
     float *d_msg_s2 = nullptr, *d_msg_v2 = nullptr;   // the last conv layer's message rows when conv layer 0's are still being read (fused launch)
     std::vector<int> last_family;           // per conv layer: pf_debug_kernel_family
     int last_hoist = 0;                     // pf_debug_l0_hoist
@@ -693,17 +701,22 @@ static void pack_out_rg(pf_handle* h, std::vector<float>& out) {
 // of an A operand of v_mfma_f32_16x16x4_f32: lane 16 gq + i <-> output row i of the tile, k = gq of the k-step.
 // Scalar k-step ks <-> input feature 16 (ks >> 2) + 4 gq + (ks & 3); vector / rbf / sh k-step r <-> channel 4 gq + r.
 // ------------------------------------------------------------------------------------------------
-static void pack_n16(pf_handle* h, const GvpSpec& g, int kind, int w, std::vector<float>& out) {
+struct N16Raw {                                  // the six tensors of a GVP with 128 scalar and 16 vector outputs (g: its dimensions)
+    const std::vector<float>&W, &Bv, &Wg, &bg, &wh, &wu;
+    GvpSpec g;
+};
+static void pack_n16_raw(const N16Raw& rw, int kind, int w, std::vector<float>& out) {
+    const GvpSpec& g = rw.g;
     const N16Sched q = n16_sched(kind);
     const int H = std::max(g.vi, g.vo), Kin = H + g.si;
     const bool m0 = kind != N16_GEN, vz = kind == N16_M0Z || kind == N16_M0H;
     const int v0 = g.vi == 17 ? 1 : 0;
-    const std::vector<float>& W = h->raw[g.prefix + "to_feats_out.0.weight"].data;            // [so][si + H]
-    const std::vector<float>& Bv = h->raw[g.prefix + "to_feats_out.0.bias"].data;
-    const std::vector<float>& Wg = h->raw[g.prefix + "scalar_to_vector_gates.weight"].data;   // [vo][so]
-    const std::vector<float>& bg = h->raw[g.prefix + "scalar_to_vector_gates.bias"].data;
-    const std::vector<float>& wh = h->raw[g.prefix + "Wh"].data;                              // [vi][H]
-    const std::vector<float>& wu = h->raw[g.prefix + "Wu"].data;                              // [H][vo]
+    const std::vector<float>& W = rw.W;             // [so][si + H]
+    const std::vector<float>& Bv = rw.Bv;
+    const std::vector<float>& Wg = rw.Wg;           // [vo][so]
+    const std::vector<float>& bg = rw.bg;
+    const std::vector<float>& wh = rw.wh;           // [vi][H]
+    const std::vector<float>& wu = rw.wu;           // [H][vo]
     const size_t base = out.size();
     out.resize(base + (size_t)q.nq * 256, 0.f);
     auto at = [&](int quad, int lane, int j) -> float& { return out[base + ((size_t)quad * 64 + lane) * 4 + j]; };
@@ -747,6 +760,41 @@ static void pack_n16(pf_handle* h, const GvpSpec& g, int kind, int w, std::vecto
         for (int t = 0; t < 2; ++t)
             for (int r = 0; r < 4; ++r) at(q.q_gate + t, lane, r) = Wg[(size_t)i * g.so + 32 * w + 16 * t + 4 * gq + r];
     }
+}
+static void pack_n16(pf_handle* h, const GvpSpec& g, int kind, int w, std::vector<float>& out) {
+    const N16Raw rw{h->raw[g.prefix + "to_feats_out.0.weight"].data, h->raw[g.prefix + "to_feats_out.0.bias"].data,
+                    h->raw[g.prefix + "scalar_to_vector_gates.weight"].data, h->raw[g.prefix + "scalar_to_vector_gates.bias"].data,
+                    h->raw[g.prefix + "Wh"].data, h->raw[g.prefix + "Wu"].data, g};
+    pack_n16_raw(rw, kind, w, out);
+}
+// The noise head's last GVP (dynamics_gvp.py:17-20: 16 vectors -> 1, 128 scalars -> 64, identity vector gate) followed by
+// to_scalar_output (Linear 64 -> pharm_nf, :35,39) as ONE GEN block of the tail kernel: the GVP zero-padded to 128 scalar
+// and 16 vector outputs (SiLU(0) = 0: the padded scalars feed nothing), and to_scalar_output -- a Linear on the same SiLU
+// output as the gate Linear -- in the unused gate rows 1 .. pharm_nf (bias in the gate bias).  Pure data movement, like
+// every packing here (the gather map of pf_set_flat_params covers it).  Needs pharm_nf <= 15.
+static void pack_n16_head_last(pf_handle* h, const GvpSpec& g, int w, std::vector<float>& out) {
+    const int nf = h->cfg.pharm_nf, H = std::max(g.vi, g.vo), Kin = H + g.si;
+    const std::vector<float>& W = h->raw[g.prefix + "to_feats_out.0.weight"].data;            // [64][128 + 16]
+    const std::vector<float>& Bv = h->raw[g.prefix + "to_feats_out.0.bias"].data;
+    const std::vector<float>& Wg = h->raw[g.prefix + "scalar_to_vector_gates.weight"].data;   // [1][64]
+    const std::vector<float>& bg = h->raw[g.prefix + "scalar_to_vector_gates.bias"].data;
+    const std::vector<float>& wu = h->raw[g.prefix + "Wu"].data;                              // [16][1]
+    const std::vector<float>& Wo = h->raw["dynamics.noise_predictor.noise_predictor.to_scalar_output.weight"].data;   // [nf][64]
+    const std::vector<float>& bo = h->raw["dynamics.noise_predictor.noise_predictor.to_scalar_output.bias"].data;
+    std::vector<float> W2((size_t)PF_S * Kin, 0.f), B2(PF_S, 0.f), G2((size_t)16 * PF_S, 0.f), bg2(16, 0.f), U2((size_t)H * 16, 0.f);
+    for (int f = 0; f < g.so; ++f) {
+        for (int k = 0; k < Kin; ++k) W2[(size_t)f * Kin + k] = W[(size_t)f * Kin + k];
+        B2[f] = Bv[f];
+        G2[f] = Wg[f];                                                                         // gate row 0
+        for (int k = 0; k < nf; ++k) G2[(size_t)(1 + k) * PF_S + f] = Wo[(size_t)k * g.so + f];
+    }
+    bg2[0] = bg[0];
+    for (int k = 0; k < nf; ++k) bg2[1 + k] = bo[k];
+    for (int c = 0; c < H; ++c) U2[(size_t)c * 16] = wu[(size_t)c * g.vo];
+    GvpSpec g2 = g;
+    g2.vo = 16; g2.so = PF_S;
+    const N16Raw rw{W2, B2, G2, bg2, h->raw[g.prefix + "Wh"].data, U2, g2};
+    pack_n16_raw(rw, N16_GEN, w, out);
 }
 
 // keep_ws: the inference workspace stays allocated (pf_set_pocket_batch re-carves it when the next batch fits: a
@@ -895,9 +943,12 @@ static void n16_refresh(pf_handle* h, hipStream_t s) {
     h->n16_stale = false;
 }
 
+// step: this call is the dynamics call of a denoising step (pf_denoise_step) -- when the tail launch applies, the step's
+// sampler update and edge build run behind the noise head in the same launch and h->tail_done tells the caller
 static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s, const float* t_scalar = nullptr,
-                        bool train = false) {
+                        bool train = false, const StepParams* step = nullptr) {
     const pf_config& c = h->cfg;
+    h->tail_done = false; h->last_tail = false;
     if (!train) n16_refresh(h, s);
     EncodeParams ep{};
     ep.Np = h->Np; ep.Nf = h->Nf;
@@ -1105,7 +1156,27 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             const int rgn = (long)n.ntiles * 32 >= h->pol.rg2_rows_min_node ? 2 : 1;
             const bool fuse = last && !train && h->fuse_head && h->n_head_tiles == n.ntiles;
             const int nsplit = (!train && rgn == 1 && n.ntiles * 8 <= (fuse ? h->pol.rg_split_max_head : h->pol.rg_split_max_node)) ? 1 : 0;
-            if (fuse) {
+            // the tail launch: one workgroup per graph does the centers' node update, the head, the sampler update and the
+            // edge build (the fast build's shape: kNN pf edges, pockets of at most 512 atoms)
+            const bool tail = fuse && step != nullptr && l > 0 && (h->pol.n16_mask & 8) && h->n16_tail != 0 && h->B <= h->pol.tail_graphs_max &&
+                              enc_fly && c.pf_k > 0 && h->max_np <= 512 && h->step_build_fast;
+            if (tail) {
+                TailParams tp{};
+                tp.in_start = n.in_start; tp.in_cnt = n.in_cnt; tp.N = n.N;
+                tp.msg_s = n.msg_s; tp.msg_v = n.msg_v; tp.zero_row = n.zero_row; tp.grp = n.grp;
+                tp.h_in = n.h_in; tp.v_in = n.v_in;
+                tp.gid = n.gid; tp.gnorm = n.gnorm; tp.B = n.B; tp.norm_mode = n.norm_mode; tp.norm_value = n.norm_value;
+                tp.ln1_w = n.w[1].ln1_w; tp.ln1_b = n.w[1].ln1_b; tp.ln2_w = n.w[1].ln2_w; tp.ln2_b = n.w[1].ln2_b;
+                tp.n_upd = n.n_upd; tp.n_head = c.n_noise_gvps;
+                tp.chain = h->d_w + h->n16_tail; tp.chain_stride = (int)h->n16_tail_stride;
+                tp.pharm_nf = c.pharm_nf; tp.eps_h = eps_h; tp.eps_x = eps_x;
+                const bool share_next = (h->prune && c.n_convs == 2) && share_now(h);     // what the next denoising step's dynamics call will ask for
+                const BuildParams bpn = build_params(h, share_next);
+                { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_n16_tail(&tp, step, &bpn, s); }
+                build_done(h, share_next);
+                h->tail_done = true; h->last_tail = true;
+                head_done = true;
+            } else if (fuse) {
                 HeadParams hp{};
                 hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
                 hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
@@ -1166,7 +1237,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         head_done = true;
     }
     if (!head_done) { ProfScope ps(h, pf_handle::K_HEAD, s); if (hp.ntiles <= h->pol.coop_node_max) pfk_noise_head_coop(&hp, s); else pfk_noise_head(&hp, s); }
-    h->edges_built = false;                 // whoever moves the coordinates next decides (pf_denoise_step rebuilds)
+    h->edges_built = h->tail_done;          // whoever moves the coordinates next decides (pf_denoise_step rebuilds; the tail launch has)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return PF_OK;
@@ -1473,7 +1544,23 @@ int pf_commit_weights(pf_handle* h) {
             for (int l = 0; l < c.n_convs; ++l)
                 for (int nt = 0; nt < 2; ++nt)
                     h->n16_upd[(size_t)l * 2 + nt] = chain16([&](int j) { return upd_spec(c, l, nt, j); }, c.n_update_gvps, N16_GEN, h->n16_upd_stride);
-        } else { h->n16_msg.clear(); h->n16_upd.clear(); }
+            {   // tail launch: the centers' update chain of the last conv layer, then the noise head (its last GVP padded, with to_scalar_output)
+                const GvpSpec hl = head_spec(c, c.n_noise_gvps - 1);
+                h->n16_tail = 0;
+                if (c.pharm_nf <= 15 && c.n_noise_gvps >= 1 && hl.vi == 16 && hl.vo == 1 && hl.si == PF_S && hl.so == 64) {
+                    for (int w = 0; w < 4; ++w) {
+                        const size_t b0 = st.size();
+                        for (int j = 0; j < c.n_update_gvps; ++j) pack_n16(h, upd_spec(c, c.n_convs - 1, 1, j), N16_GEN, w, st);
+                        for (int k = 0; k + 1 < c.n_noise_gvps; ++k) pack_n16(h, head_spec(c, k), N16_GEN, w, st);
+                        pack_n16_head_last(h, hl, w, st);
+                        st.resize(st.size() + (size_t)N16_TAIL_PAD * 256, 0.f);
+                        h->n16_tail_stride = st.size() - b0;
+                    }
+                    h->n16_tail = push(h->h_w, st);
+                    st.clear();
+                }
+            }
+        } else { h->n16_msg.clear(); h->n16_upd.clear(); h->n16_tail = 0; }
         while (h->h_w.size() % 64) h->h_w.push_back(0.f);
     };
     {
@@ -2099,14 +2186,20 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
 int pf_set_pocket_batch(pf_handle* h, int32_t B, const int32_t* prot_ptr, const int32_t* pharm_ptr,
                         const float* dev_prot_x, const float* dev_prot_h, int64_t n_pp, const int32_t* pp_src,
                         const int32_t* pp_dst, pf_stream stream) {
-    if (h && (!dev_prot_x || !dev_prot_h)) PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_batch: bad argument");
+    if (h && (!dev_prot_x || !dev_prot_h)) {
+        h->pending_rep.clear();                  // a pocket-group claim never outlives the bind it was made for, rejected or not
+        PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_batch: bad argument");
+    }
     return set_pocket_batch_impl(h, B, prot_ptr, pharm_ptr, dev_prot_x, dev_prot_h, nullptr, nullptr, n_pp, pp_src, pp_dst, stream);
 }
 
 int pf_set_pocket_batch_host(pf_handle* h, int32_t B, const int32_t* prot_ptr, const int32_t* pharm_ptr,
                              const float* host_prot_x, const float* host_prot_h, int64_t n_pp, const int32_t* pp_src,
                              const int32_t* pp_dst, pf_stream stream) {
-    if (h && (!host_prot_x || !host_prot_h)) PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_batch_host: bad argument");
+    if (h && (!host_prot_x || !host_prot_h)) {
+        h->pending_rep.clear();
+        PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_batch_host: bad argument");
+    }
     return set_pocket_batch_impl(h, B, prot_ptr, pharm_ptr, nullptr, nullptr, host_prot_x, host_prot_h, n_pp, pp_src, pp_dst, stream);
 }
 
@@ -2210,14 +2303,15 @@ int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noi
     if (!coef || !dev_noise) PF_FAIL(h, PF_ERR_ARG, "pf_denoise_step: null argument");
     if (!h->sampling) PF_FAIL(h, PF_ERR_STATE, "pf_denoise_step before pf_sample_begin");
     hipStream_t s = (hipStream_t)stream;
-    rc = run_dynamics(h, h->d_eps_h, h->d_eps_x, s, &coef->t);      // every graph of the batch is at the same t
-    if (rc) return rc;
     StepParams sp{};
     sp.B = h->B; sp.Np_tot = h->Np; sp.prot_ptr = h->d_prot_ptr; sp.pharm_ptr = h->d_pharm_ptr;
     sp.xn = h->d_xn; sp.pharm_h = h->d_pharm_h; sp.eps_h = h->d_eps_h; sp.eps_x = h->d_eps_x; sp.noise = dev_noise;
     sp.nf = h->cfg.pharm_nf;
     sp.a_ts = coef->alpha_t_given_s; sp.var = coef->var_terms; sp.sigma = coef->sigma;
     sp.ep_zt = coef->ep_zt; sp.ep_pred = coef->ep_pred; sp.ep_coord = ep_coord; sp.ep_feat = ep_feat;
+    rc = run_dynamics(h, h->d_eps_h, h->d_eps_x, s, &coef->t, false, &sp);      // every graph of the batch is at the same t
+    if (rc) return rc;
+    if (h->tail_done) return PF_OK;         // the tail launch did the update and built the next call's edges
     if (encoders_on_the_fly(h)) {           // update + the edges of the next dynamics call in one launch
         const pf_config& cc = h->cfg;
         const bool share = (h->prune && cc.n_convs == 2) && share_now(h);     // what the next denoising step's dynamics call will ask for
@@ -2834,6 +2928,10 @@ int pf_debug_dropout_mask(pf_handle* h, int32_t layer, int32_t which, float drop
 
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave) {
     if (!h || !rows_per_wave) return PF_ERR_ARG;
+    if (layer == (int)h->last_family.size() && layer > 0) {      // one past the last conv layer: 16 when the last call's head ran in the tail launch
+        *rows_per_wave = h->last_tail ? 16 : 0;
+        return PF_OK;
+    }
     if (layer < 0 || layer >= (int)h->last_family.size()) PF_FAIL(h, PF_ERR_STATE, "pf_debug_kernel_family: no dynamics call yet, or bad layer");
     *rows_per_wave = h->last_family[layer];
     return PF_OK;

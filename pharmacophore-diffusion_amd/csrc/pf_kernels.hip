@@ -1256,48 +1256,11 @@ __device__ unsigned long long* g_build_stamps = nullptr;      // [B][32]
 #else
 #define BSTAMP(k)
 #endif
-__device__ __forceinline__ float sqdist_rn(const float4 a, const float4 b) {
-    const float dx = __fsub_rn(a.x, b.x), dy = __fsub_rn(a.y, b.y), dz = __fsub_rn(a.z, b.z);
-    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-}
-__device__ __forceinline__ unsigned long long dkey(const float d2, const int idx) {
-    return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)idx;
-}
-// wave-wide minimum of 64-bit keys on the DPP network (no LDS round trips): inclusive min-scan inside each row of 16
-// lanes (row_shr 1, 2, 4, 8), then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast15) and lane 31 into the upper
-// half (row_bcast31); lane 63 holds the result.  Lanes without a source keep `old` = all ones, the identity.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned long long dpp_min_u64(const unsigned long long k) {
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)(unsigned int)k, CTRL, ROW_MASK, 0xf, false);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)(unsigned int)(k >> 32), CTRL, ROW_MASK, 0xf, false);
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-    return o < k ? o : k;
-}
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k) {
-    k = dpp_min_u64<0x111, 0xf>(k);
-    k = dpp_min_u64<0x112, 0xf>(k);
-    k = dpp_min_u64<0x114, 0xf>(k);
-    k = dpp_min_u64<0x118, 0xf>(k);
-    k = dpp_min_u64<0x142, 0xa>(k);
-    k = dpp_min_u64<0x143, 0xc>(k);
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)k, 63);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(k >> 32), 63);
-    return ((unsigned long long)hi << 32) | lo;
-}
-// inclusive wave scan (sum) of a 32-bit value on the DPP network, same pattern
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned int dpp_add_u32(const unsigned int v) {
-    return v + (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ unsigned int wave_incl_scan_u32(unsigned int v) {
-    v = dpp_add_u32<0x111, 0xf>(v);
-    v = dpp_add_u32<0x112, 0xf>(v);
-    v = dpp_add_u32<0x114, 0xf>(v);
-    v = dpp_add_u32<0x118, 0xf>(v);
-    v = dpp_add_u32<0x142, 0xa>(v);
-    v = dpp_add_u32<0x143, 0xc>(v);
-    return v;
-}
+// (sqdist_rn, dkey, wave_min_u64, wave_incl_scan_u32 and the update + build body of the fast path live in pf_stepbuild.h:
+// k_n16_tail, pf_n16.hip, runs the same body behind its noise head)
+#define SB_STAMP(k) BSTAMP(k)
+#include "pf_stepbuild.h"
+using pfsb::sqdist_rn; using pfsb::dkey; using pfsb::wave_min_u64; using pfsb::wave_incl_scan_u32;
 // exclusive scan of one value per thread over a 256-thread block; returns this thread's offset, *total receives the
 // block total.  The value packs three counters (bits 0-15, 16-27, 28-63: the fp edges, the active-atom list and its pp
 // in-edges), scanned as two 32-bit halves (low: two 16/12-bit counters that cannot carry into each other at these
@@ -1801,250 +1764,15 @@ __global__ __launch_bounds__(256) void k_step_update(const StepParams p) { step_
 // coordinates stay in LDS for the neighbour searches (8 waves: one pharmacophore center each), and nothing is read back
 // from global memory.  Results are identical to k_step_build (same arithmetic, same orderings).
 // ---------------------------------------------------------------------------------------------
-// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for every global store
-// issued so far to be acknowledged (~2,000 cycles here), and nothing in this kernel reads its global stores back
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// (the leading scalar arguments repeat the fields round trip (A) needs: preloaded into scalar registers with the wave,
-// -mllvm -amdgpu-kernarg-preload-count in the Makefile, so (A) does not wait for the kernel-argument segment)
+// (the body: pf_stepbuild.h.  The leading scalar arguments repeat the fields round trip (A) needs: preloaded into scalar
+// registers with the wave, -mllvm -amdgpu-kernarg-preload-count in the Makefile, so (A) does not wait for the kernel-argument segment)
 __global__ __launch_bounds__(512) void k_step_build_fast(const int* __restrict__ a_prot_ptr, const int* __restrict__ a_pharm_ptr,
                                                          const int* __restrict__ a_reg, const int a_B, const int a_Np_tot,
                                                          const StepParams sp, const BuildParams p) {
-    constexpr int NT = 512, NW = NT / 64;
-    __shared__ float4 fx[PF_MAXF];                  // updated pharm coordinates (COM removed)
-    __shared__ float4 px[NT];                       // updated protein coordinates
-    __shared__ float red[NW][3];
-    __shared__ unsigned long long scratch[NW];
-    __shared__ unsigned int refm[NT][2];            // per atom: bit fl set <=> center fl has the atom among its k neighbours
-    // active atoms in list order: first slot of their pp in-edges in the "pa" region, node id, static in-edge start;
-    // a_src: the first 16 static sources of EVERY atom (prefetched, indexed by atom) -- the copy into the region is
-    // then done by ALL threads, one output slot each, with coalesced stores
-    __shared__ int a_d0[NT], a_node[NT], a_pst[NT];
-    __shared__ __attribute__((aligned(16))) int a_src[NT][16];
-    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    BSTAMP(0);
-    // ---- (A) pointers and regions
-    const int p0 = a_prot_ptr[g], p1 = a_prot_ptr[g + 1];
-    const int f0 = a_pharm_ptr[g], f1 = a_pharm_ptr[g + 1];
-    const int Np = p1 - p0, Nf = f1 - f0;
-    const int GF = a_Np_tot + f0;
-    const int reg_ff = a_reg[0 * a_B + g], reg_pf = a_reg[1 * a_B + g], reg_fp = a_reg[2 * a_B + g], reg_pa = a_reg[3 * a_B + g];
-    const int reg_act = p.act_ids ? p.reg_act[g] : 0;
-    int* in_start0 = p.in_start;          int* in_cnt0 = p.in_cnt;
-    int* in_start1 = p.in_start + p.N;    int* in_cnt1 = p.in_cnt + p.N;
-    int* in_start2 = p.in_start + 2 * p.N; int* in_cnt2 = p.in_cnt + 2 * p.N;
-    // ---- (B) every input row of this thread
-    const bool isf = tid < Nf, isp = tid < Np;
-    float4 xf = make_float4(0.f, 0.f, 0.f, 0.f), xp = xf;
-    float ex[3] = {0.f, 0.f, 0.f}, nzx[3] = {0.f, 0.f, 0.f};
-    if (isf) {
-        xf = sp.xn[GF + tid];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { ex[c] = sp.eps_x[(size_t)(f0 + tid) * 3 + c]; nzx[c] = sp.noise[(size_t)(f0 + tid) * (3 + sp.nf) + c]; }
-    }
-    int pst = 0, pdeg = 0;
-    if (isp) {
-        xp = sp.xn[p0 + tid];
-        if (p.act_ids && !p.pa_static) { pst = in_start1[p0 + tid]; pdeg = in_cnt1[p0 + tid]; }
-    }
-    // feature update of the pharm nodes (independent of everything else): load, update, store
-    if (isf) {
-        for (int k = 0; k < sp.nf; ++k) {
-            const size_t o = (size_t)(f0 + tid) * sp.nf + k;
-            const float hv = sp.pharm_h[o], e = sp.eps_h[o];
-            const float mu = sp.ep_feat ? (sp.ep_zt * hv + sp.ep_pred * e) : (hv / sp.a_ts - sp.var * e);
-            sp.pharm_h[o] = mu + sp.sigma * sp.noise[(size_t)(f0 + tid) * (3 + sp.nf) + 3 + k];
-        }
-    }
-    // ---- (C) static pp sources of this thread's atom (used only if the atom turns out to be active)
-    int psrc[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) psrc[k] = (isp && p.act_ids && !p.pa_static) ? p.esrc[pst + min(k, max(pdeg - 1, 0))] : 0;
-    // ---- coordinate update (pharmacodiff.py:397-426) and COM removal of pharm AND prot coordinates (:429)
-    float m[3] = {0.f, 0.f, 0.f};
-    if (isf) {
-        const float xi[3] = {xf.x, xf.y, xf.z};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float mu = sp.ep_coord ? (sp.ep_zt * xi[c] + sp.ep_pred * ex[c]) : (xi[c] / sp.a_ts - sp.var * ex[c]);
-            m[c] = mu + sp.sigma * nzx[c];
-        }
-    }
-    {   // per-graph mean in the summation order of step_update_body (thread-strided partial sums, xor butterfly, 4+4 waves)
-        float sx = m[0], sy = m[1], sz = m[2];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
-        if (lane == 0) { red[wave][0] = sx; red[wave][1] = sy; red[wave][2] = sz; }
-    }
-    lds_barrier();
-    BSTAMP(8);
-    float com[3];
-    {
-        const float n = (float)max(Nf, 1);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) com[c] = Nf > 0 ? (((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) / n) : 0.f;
-    }
-    if (isf) {
-        const float4 v = make_float4(m[0] - com[0], m[1] - com[1], m[2] - com[2], 0.f);
-        fx[tid] = v;
-        sp.xn[GF + tid] = v;
-    }
-    if (isp) { xp.x -= com[0]; xp.y -= com[1]; xp.z -= com[2]; sp.xn[p0 + tid] = xp; }
-    px[tid] = xp;
-    refm[tid][0] = 0u; refm[tid][1] = 0u;
-    lds_barrier();
-    // ---- ff (pharm -> pharm) on wave 0: counts, wave scan for the offsets, emission
-    const int kff = p.ff_k > 0 ? max(min(p.ff_k, Nf - 1), 0) : 0;
-    int ff_total = 0;                                 // valid in the last wave (it has no center to search while Nf < 8)
-    if (wave == NW - 1) {
-        int c = 0;
-        if (lane < Nf) {
-            if (p.ff_k > 0) c = kff;
-            else
-                for (int jn = 0; jn < Nf; ++jn)
-                    if (jn != lane && sqdist_rn(fx[jn], fx[lane]) < p.r2_ff) ++c;
-        }
-        const int incl = (int)wave_incl_scan_u32((unsigned int)c);
-        ff_total = __builtin_amdgcn_readlane(incl, 63);
-        if (lane == 0) p.dyn_cnt[0 * p.B + g] = ff_total;
-        if (lane < Nf) {
-            int e = reg_ff + incl - c;
-            in_start0[GF + lane] = e;
-            in_cnt0[GF + lane] = c;
-            if (p.ff_k > 0) {
-                unsigned long long prev = 0ull;
-                bool first = true;
-                for (int q = 0; q < kff; ++q) {
-                    unsigned long long best = ~0ull;
-                    for (int jn = 0; jn < Nf; ++jn) {
-                        if (jn == lane) continue;
-                        const unsigned long long k = dkey(sqdist_rn(fx[jn], fx[lane]), jn);
-                        if ((first || k > prev) && k < best) best = k;
-                    }
-                    prev = best; first = false;
-                    p.esrc[e] = GF + (int)(best & 0xffffffffu);
-                    p.edst[e] = GF + lane;
-                    ++e;
-                }
-            } else {
-                for (int jn = 0; jn < Nf; ++jn)
-                    if (jn != lane && sqdist_rn(fx[jn], fx[lane]) < p.r2_ff) { p.esrc[e] = GF + jn; p.edst[e] = GF + lane; ++e; }
-            }
-        }
-    }
-    BSTAMP(9);
-    // ---- pf (prot -> pharm): kNN, one center per wave, candidates (d^2, index) from LDS
-    const int kk = min(p.pf_k, Np);
-    for (int fl = wave; fl < Nf; fl += NW) {
-        const float4 q = fx[fl];
-        unsigned long long kc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = lane + 64 * i;
-            kc[i] = ~0ull;
-            if (64 * i < Np) kc[i] = c < Np ? dkey(sqdist_rn(px[c], q), c) : ~0ull;    // wave-uniform bound
-        }
-        unsigned long long prev = 0ull;
-        for (int r = 0; r < kk; ++r) {
-            unsigned long long best = ~0ull;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (64 * i < Np && (r == 0 || kc[i] > prev) && kc[i] < best) best = kc[i];
-            best = wave_min_u64(best);
-            prev = best;
-            if (lane == 0) {
-                const int pc = (int)(best & 0xffffffffu);
-                atomicOr(&refm[pc][fl >> 5], 1u << (fl & 31));
-                p.esrc[reg_pf + fl * kk + r] = p0 + pc;
-                p.edst[reg_pf + fl * kk + r] = GF + fl;
-            }
-        }
-        if (lane == 0) { in_start1[GF + fl] = reg_pf + fl * kk; in_cnt1[GF + fl] = kk; }
-    }
-    if (tid == 0) { p.dyn_cnt[1 * p.B + g] = Nf * kk; p.dyn_cnt[2 * p.B + g] = Nf * kk; }
-    {   // the prefetched pp sources go to LDS here, unconditionally: left to their only use (active atoms, below) the
-        // compiler sinks the loads into that branch and the round trip (C) is paid there, late and exposed
-        int4* st = reinterpret_cast<int4*>(&a_src[tid][0]);
-        st[0] = make_int4(psrc[0], psrc[1], psrc[2], psrc[3]);
-        st[1] = make_int4(psrc[4], psrc[5], psrc[6], psrc[7]);
-        st[2] = make_int4(psrc[8], psrc[9], psrc[10], psrc[11]);
-        st[3] = make_int4(psrc[12], psrc[13], psrc[14], psrc[15]);
-    }
-    lds_barrier();
-    BSTAMP(10);
-    // ---- fp = pf reversed, destination-major over the atoms; active atoms and the compact copy of their pp in-edges
-    {
-        const int c = tid;
-        // the centers that reference this atom, ascending: the bits of its mask (set by the kNN waves above)
-        const unsigned int m0 = isp ? refm[c][0] : 0u, m1 = isp ? refm[c][1] : 0u;
-        const int my = __popc(m0) + __popc(m1);
-        BSTAMP(12);                                   // references counted
-        const int act = (my > 0 && p.act_ids) ? 1 : 0;
-        const int deg = act ? pdeg : 0;
-        const unsigned long long val = (unsigned long long)my | ((unsigned long long)act << 16) | ((unsigned long long)deg << 28);
-        // block scan over 8 waves (same packing as block_excl_scan)
-        const unsigned int lo = (unsigned int)(val & 0xfffffffull), hi = (unsigned int)(val >> 28);
-        const unsigned int slo = wave_incl_scan_u32(lo), shi = wave_incl_scan_u32(hi);
-        if (lane == 63) scratch[wave] = (unsigned long long)slo | ((unsigned long long)shi << 28);
-        lds_barrier();
-        unsigned long long before = 0ull, all = 0ull;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const unsigned long long t = scratch[w];
-            if (w < wave) before += t;
-            all += t;
-        }
-        const unsigned long long o = before + ((unsigned long long)slo | ((unsigned long long)shi << 28)) - val;
-        BSTAMP(13);                                   // offsets known
-        if (isp) {
-            int e = reg_fp + (int)(o & 0xffffu);
-            in_start0[p0 + c] = e;
-            in_cnt0[p0 + c] = my;
-            {
-                unsigned int mm = m0;
-                while (mm) { const int fl = __ffs(mm) - 1; mm &= mm - 1; p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
-                mm = m1;
-                while (mm) { const int fl = 32 + __ffs(mm) - 1; mm &= mm - 1; p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
-            }
-            if (act) {
-                const int j = (int)((o >> 16) & 0xfffu);
-                p.act_ids[reg_act + j] = p0 + c;
-                if (p.pa_static) p.need[p.rep_base[g] + c] = p.need_stamp;
-                else {
-                    in_start2[p0 + c] = reg_pa + (int)(o >> 28);
-                    in_cnt2[p0 + c] = deg;
-                    a_d0[j] = (int)(o >> 28); a_node[j] = p0 + c; a_pst[j] = pst;
-                }
-            }
-        }
-        BSTAMP(14);                                   // fp edges / descriptors stored, active atoms staged
-        lds_barrier();
-        BSTAMP(15);
-        {   // the "pa" region: slot t belongs to the last active atom whose first slot is <= t (binary search in LDS)
-            const int n_pa = p.pa_static ? 0 : (int)(all >> 28), n_act = (int)((all >> 16) & 0xfffu);
-            for (int t = tid; t < n_pa; t += NT) {
-                int lo = 0, hi = n_act - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (a_d0[mid] <= t) lo = mid; else hi = mid - 1;
-                }
-                const int k = t - a_d0[lo];
-                const int src = k < 16 ? a_src[a_node[lo] - p0][k] : p.esrc[a_pst[lo] + k];
-                p.esrc[reg_pa + t] = src;
-                p.edst[reg_pa + t] = a_node[lo];
-                if (p.eorig) p.eorig[reg_pa + t] = a_pst[lo] + k;
-            }
-        }
-        if (tid == 0 && p.act_ids) {
-            p.dyn_cnt[3 * p.B + g] = p.pa_static ? p.pa_static[g] : (int)(all >> 28);
-            p.dyn_cnt[4 * p.B + g] = (int)((all >> 16) & 0xfffu);
-        }
-        if (tid == NT - 64 && p.norm_mode == 2) {     // per-graph normalisers for message_norm == 0 (gvp.py:504-507)
-            const int cpf = p.pfq_cnt ? p.pfq_cnt[g] : Nf * kk;
-            p.gnorm[1 * p.B + g] = (float)(ff_total + cpf) / (float)Nf + 1.0f;
-            p.gnorm[0 * p.B + g] = (float)(cpf + p.pp_cnt[g]) / (float)Np + 1.0f;
-        }
-    }
-    BSTAMP(11);
+    __shared__ pfsb::StepBuildLds L;
+    const int g = blockIdx.x;
+    const pfsb::EpsGlobal eps{sp.eps_x, sp.eps_h, a_pharm_ptr[g], sp.nf};
+    pfsb::step_build_fast_body<512>(g, a_prot_ptr, a_pharm_ptr, a_reg, a_B, a_Np_tot, sp, p, eps, L);
 }
 
 __global__ __launch_bounds__(256) void k_step_build(const StepParams sp, const BuildParams bp) {

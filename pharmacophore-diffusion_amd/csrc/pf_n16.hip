@@ -25,6 +25,7 @@
 #include <type_traits>
 #include <algorithm>
 #include "pf_device.h"
+#include "pf_stepbuild.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -147,9 +148,12 @@ struct N16In {
 //   LAST     last GVP of the chain: the SiLU output is not exchanged (XS is not written)
 // Barriers: A (Vh of the three coordinates -> sh; only the kinds with a vector input) and B (SiLU outputs, gate sums).
 // ---------------------------------------------------------------------------------------------
-template <int KIND, int OFF, bool LAST>
+//   SIG      the vector gate's activation: sigmoid (every GVP but the noise head's last one: identity, dynamics_gvp.py:20)
+//   gs       optional: receives the gate pre-activations (the K-split sums + bias; vector waves) -- the tail kernel packs
+//            to_scalar_output into the unused gate rows of the head's last GVP and reads eps_h from here
+template <int KIND, int OFF, bool LAST, bool SIG = true>
 __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float (&VB)[4], const N16In& in, f32x4 (&S)[2],
-                                          N16Lds* lds, const int lane, const int wq, int& sk) {
+                                          N16Lds* lds, const int lane, const int wq, int& sk, f32x4* gs = nullptr) {
     constexpr N16Sched Q = n16_sched(KIND);
     N16_STAMP(sk, lane, wq);                                          // block start
     constexpr bool M0 = KIND != N16_GEN;                              // 17 hidden vector channels, rbf inputs
@@ -278,7 +282,11 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
                     const f32x4 gc = *reinterpret_cast<const f32x4*>(&lds->g[(2 * 64 + lane) * 4]);
                     const f32x4 gd = *reinterpret_cast<const f32x4*>(&lds->g[(3 * 64 + lane) * 4]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) VB[r] = sigmoidf_((ga[r] + gb[r]) + (gc[r] + gd[r])) * vu[r];
+                    for (int r = 0; r < 4; ++r) {
+                        const float gpre = (ga[r] + gb[r]) + (gc[r] + gd[r]);
+                        if (gs) (*gs)[r] = gpre;
+                        VB[r] = (SIG ? sigmoidf_(gpre) : gpre) * vu[r];
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) VB[r] = 0.f;
@@ -786,6 +794,182 @@ __global__ __launch_bounds__(256) void k_n16_fused(const int* __restrict__ a_dyn
 }
 
 // ---------------------------------------------------------------------------------------------
+// The tail launch (TailParams; pf_denoise_step): workgroup g = graph g.  Its centers, 16 per pass, go through the last conv
+// layer's node update (gvp.py:488-536: partial-row sums, residual on the layer's input state, GVPLayerNorm, update chain,
+// residual, GVPLayerNorm) and the noise head (dynamics_gvp.py:37-42); the head's last GVP (64 scalars, 1 vector, identity
+// gate) runs as a zero-padded GEN block whose unused gate rows 1 .. pharm_nf carry to_scalar_output, so eps_x is the gated
+// channel 0 and eps_h the gate pre-activations of channels 1 .. pharm_nf.  eps stays in LDS, and the same workgroup
+// finishes with the sampler update + edge build of ITS graph (pf_stepbuild.h).
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) TailLds {
+    N16Lds n;
+    float ex[PF_MAXF * 4];
+    float eh[PF_MAXF * 16];
+    pfsb::StepBuildLds sb;
+};
+
+__device__ __forceinline__ void n16_node_update_last(const TailParams& t, N16Ring& ring, const int node, float (&XS)[32], float (&VB)[4],
+                                                     N16Lds* lds, const int lane, const int wq, int& sk) {
+    const int g = lane >> 4;
+    const int cw = wq < 3 ? wq : 0;
+    // one batch of loads: the descriptors of the two in-edge segments (ff: slot 0, pf: slot 1) and the residual rows
+    int st[2], cn[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        st[sl] = t.in_start[sl * t.N + node];
+        cn[sl] = t.in_cnt[sl * t.N + node];
+    }
+    float H[32], Vr0[4];
+    {
+        pf_gcf hp = (pf_gcf)t.h_in + (size_t)node * PF_S + 4 * g;
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+            const f32x4 x = *reinterpret_cast<const f32x4 PF_AS1*>(hp + 16 * T);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H[4 * T + r] = x[r];
+        }
+        pf_gcf vp = (pf_gcf)t.v_in + (size_t)node * 48 + 12 * g + cw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Vr0[r] = vp[3 * r];
+    }
+    // the partial rows of a segment [st, end) are the last slots of the aligned groups of grp slots it touches: the first two
+    // of each segment in one batch of loads (absent: the all-zero row), longer segments finish in a loop
+    const int gm = t.grp - 1;
+    f32x4 x[2][2][8];
+    float vv[2][2][4];
+    int nxt[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int end = st[sl] + cn[sl];
+        int e = st[sl];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool has = e < end;
+            const int rw = has ? min(e | gm, end - 1) : t.zero_row;
+            const f32x4 PF_AS1* mp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)t.msg_s + (size_t)rw * PF_S) + g;
+#pragma unroll
+            for (int T = 0; T < 8; ++T) x[sl][k][T] = mp[4 * T];
+            pf_gcf vp = (pf_gcf)t.msg_v + (size_t)rw * 48 + 12 * g + cw;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv[sl][k][r] = vp[3 * r];
+            e = has ? rw + 1 : e;
+        }
+        nxt[sl] = e;
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) XS[k] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) VB[r] = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int end = st[sl] + cn[sl];
+        float ps[32], pv[4];
+#pragma unroll
+        for (int T = 0; T < 8; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ps[4 * T + r] = x[sl][0][T][r] + x[sl][1][T][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] = vv[sl][0][r] + vv[sl][1][r];
+        int e = nxt[sl];
+        while (__any(e < end)) {                          // (rows that are done add the all-zero row)
+            const bool has = e < end;
+            const int rw = has ? min(e | gm, end - 1) : t.zero_row;
+            const f32x4 PF_AS1* mp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)t.msg_s + (size_t)rw * PF_S) + g;
+            f32x4 y[8];
+#pragma unroll
+            for (int T = 0; T < 8; ++T) y[T] = mp[4 * T];
+            pf_gcf vp = (pf_gcf)t.msg_v + (size_t)rw * 48 + 12 * g + cw;
+            float yv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[r] = vp[3 * r];
+#pragma unroll
+            for (int T = 0; T < 8; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ps[4 * T + r] += y[T][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[r] += yv[r];
+            e = has ? rw + 1 : e;
+        }
+        const float sc = (t.norm_mode == 0 && cn[sl] > 0) ? 1.0f / (float)cn[sl] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) XS[k] = fmaf(ps[k], sc, XS[k]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) VB[r] = fmaf(pv[r], sc, VB[r]);
+    }
+    float inv_norm = 1.0f;
+    if (t.norm_mode == 1) inv_norm = 1.0f / t.norm_value;
+    else if (t.norm_mode == 2) inv_norm = 1.0f / t.gnorm[1 * t.B + t.gid[node]];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) XS[k] = fmaf(XS[k], inv_norm, H[k]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) VB[r] = wq < 3 ? fmaf(VB[r], inv_norm, Vr0[r]) : 0.f;
+    n16_layernorm(t.ln1_w, t.ln1_b, XS, VB, lds, lane, wq);
+    float Xr[32], Vr[4];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) Xr[k] = XS[k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Vr[r] = VB[r];
+    N16In none{};
+    f32x4 S[2];
+    S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
+    for (int gi = 0; gi < t.n_upd; ++gi) n16_block<N16_GEN, 0, false>(ring, XS, VB, none, S, lds, lane, wq, sk);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) XS[k] += Xr[k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) VB[r] += Vr[r];
+    n16_layernorm(t.ln2_w, t.ln2_b, XS, VB, lds, lane, wq);
+}
+
+// (the leading scalar arguments: what round trip (A) of the update + build and the first loads of the node update need,
+// preloaded into scalar registers with the wave)
+__global__ __launch_bounds__(256) void k_n16_tail(const int* __restrict__ a_prot_ptr, const int* __restrict__ a_pharm_ptr,
+                                                  const int* __restrict__ a_reg, const int a_B, const int a_Np_tot,
+                                                  const TailParams t, const StepParams sp, const BuildParams bp) {
+    __shared__ TailLds L;
+    const int lane = threadIdx.x & 63;
+    const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = lane >> 4, j = lane & 15;
+    const int gq = (int)blockIdx.x;
+    const int f0 = a_pharm_ptr[gq], Nf = a_pharm_ptr[gq + 1] - f0;
+    int sk = 0;
+    N16_STAMP(sk, lane, wq);                              // kernel entry
+    for (int base = 0; base < Nf; base += 16) {           // workgroup-uniform
+        const int nv = __builtin_amdgcn_readfirstlane(min(16, Nf - base));
+        const int fl = base + min(j, nv - 1);
+        const int node = a_Np_tot + f0 + fl;
+        N16Ring ring;
+        ring_start(ring, t.chain + (size_t)wq * t.chain_stride, lane);
+        float XS[32], VB[4];
+        n16_node_update_last(t, ring, node, XS, VB, &L.n, lane, wq, sk);
+        N16In none{};
+        f32x4 S[2], GS = {0.f, 0.f, 0.f, 0.f};
+        S[0] = GS; S[1] = GS;
+        for (int gi = 0; gi + 1 < t.n_head; ++gi) n16_block<N16_GEN, 0, false>(ring, XS, VB, none, S, &L.n, lane, wq, sk);
+        n16_block<N16_GEN, 0, true, false>(ring, XS, VB, none, S, &L.n, lane, wq, sk, &GS);
+        N16_STAMP(sk, lane, wq);                          // head done
+        if (j < nv) {
+            if (wq < 3 && g == 0) {                       // gated channel 0 of coordinate wq
+                L.ex[fl * 4 + wq] = VB[0];
+                t.eps_x[(size_t)(f0 + fl) * 3 + wq] = VB[0];
+            }
+            if (wq == 0) {                                // gate rows 1 .. pharm_nf = to_scalar_output
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = 4 * g + r;
+                    if (ch >= 1 && ch <= t.pharm_nf) {
+                        L.eh[fl * 16 + ch - 1] = GS[r];
+                        t.eps_h[(size_t)(f0 + fl) * t.pharm_nf + ch - 1] = GS[r];
+                    }
+                }
+            }
+        }
+        lds_barrier();                                    // eps of this pass is in LDS; the chain's buffers are free again
+    }
+    const pfsb::EpsLds eps{L.ex, L.eh};
+    pfsb::step_build_fast_body<256>(gq, a_prot_ptr, a_pharm_ptr, a_reg, a_B, a_Np_tot, sp, bp, eps, L.sb);
+}
+
+// ---------------------------------------------------------------------------------------------
 // pf_debug_chain kinds 16 / 17: the message / update chain in the n16 form on caller-supplied rows (layouts of kinds 0 / 1)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_n16_unit(const UnitParams p) {
@@ -865,6 +1049,11 @@ void pfk_n16_fused(const EdgeParams* p, const FusedParams* f, const EncodeParams
     const int grid = f->n_edge_items + f->B * (PF_MAXF / 16);
     if (grid <= 0) return;
     hipLaunchKernelGGL(k_n16_fused, dim3(grid), dim3(256), 0, s, p->dyn_cnt, p->reg, p->nreg, p->regB, *p, *f, *enc);
+}
+// grid: one workgroup per graph
+void pfk_n16_tail(const TailParams* t, const StepParams* sp, const BuildParams* bp, hipStream_t s) {
+    if (sp->B <= 0) return;
+    hipLaunchKernelGGL(k_n16_tail, dim3(sp->B), dim3(256), 0, s, bp->prot_ptr, bp->pharm_ptr, bp->reg, bp->B, bp->Np_tot, *t, *sp, *bp);
 }
 void pfk_n16_unit(const UnitParams* p, hipStream_t s) {
     if (p->n <= 0) return;

@@ -89,13 +89,15 @@ class PocketGraph:
         critical path: the int64 -> int32 conversion of ~1.3 M edge indices costs 0.3 ms per bind otherwise) and dropped
         when an index tensor is replaced or written in place."""
         idx = (self.prot_ptr, self.pharm_ptr, self.pp_src, self.pp_dst)
-        key = tuple((t.data_ptr(), t.numel(), t._version) for t in idx)
+        vers = tuple(t._version for t in idx)
         c = self.__dict__.get("_i32_cache")
-        if c is None or c[0] != key:
+        # the entry holds the tensors themselves and is matched by identity: a replaced index tensor that happens to be
+        # allocated at a recycled address with the same length cannot hit a stale entry (ADVICE r3)
+        if c is None or c[1] != vers or any(a is not b for a, b in zip(c[0], idx)):
             import numpy as np
-            c = (key, tuple(np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.int32) for t in idx))
+            c = (idx, vers, tuple(np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.int32) for t in idx))
             self.__dict__["_i32_cache"] = c
-        return c[1]
+        return c[2]
 
     def batch_idxs(self) -> Dict[str, torch.Tensor]:
         return get_batch_idxs(self)

@@ -478,7 +478,21 @@ class FlatAdam:
             raise RuntimeError("FlatAdam.step(): no gradient (run loss.backward() on a training forward first)")
         # the engine that produced this gradient (the forward's bind checked the parameter views and synchronised it; another
         # pass over the 244 parameters here is 0.1 ms of a 1.6 ms step); engine() only when there is none yet
-        eng = dyn._engine if (dyn._engine is not None and dyn._flat is not None and dyn._flat.is_cuda) else dyn.engine()
+        # Cheap guard on that fast path: parameters re-materialised between backward() and step() (module.to(),
+        # an assignment to p.data) no longer view the flat vector; the first and the last view are checked every step,
+        # all of them every 64th, and a mismatch falls back to engine(), which re-homes and re-synchronises them.
+        fast = dyn._engine is not None and dyn._flat is not None and dyn._flat.is_cuda and bool(dyn._flat_views)
+        if fast:
+            base = dyn._flat.data_ptr()
+            ends = (dyn._flat_views[0], dyn._flat_views[-1])
+            fast = all(p.data_ptr() == base + 4 * off for p, off, _ in ends) and (self.t % 64 != 63 or dyn._views_intact())
+        if not fast:
+            eng = dyn.engine()
+            if g.numel() != dyn._flat.numel() or g.device != dyn._flat.device:
+                raise RuntimeError("FlatAdam.step(): the parameters were re-allocated after backward(); run the step's "
+                                   "forward and backward again")
+        else:
+            eng = dyn._engine
         if self.exp_avg is None:
             self.exp_avg, self.exp_avg_sq = torch.zeros_like(dyn._flat), torch.zeros_like(dyn._flat)
         self.t += 1

@@ -136,3 +136,52 @@ def test_n16_default_policy_on_random_ragged_batches_vs_oracle(norm):
             assert eng.kernel_family(0) == 16 and eng.kernel_family(1) == 17, (trial, eng.kernel_family(0), eng.kernel_family(1))
             oh, ox = O.dynamics_forward(sd, cfg, batch, batch.prot_x, x_t, h_t, t)
             close(eps_h, oh); close(eps_x, ox)
+
+
+@pytest.mark.parametrize("case", ["config1", "ragged", "knnff", "gnorm", "deep", "many_centers"])
+def test_tail_launch_steps_equal_separate_launches(case, monkeypatch):
+    """The tail launch (pf_n16.hip: k_n16_tail -- the centers' node update of the last conv layer, the noise head with
+    to_scalar_output packed into the padded last GVP, the p(z_s | z_t) update and the next call's edge build in ONE launch, one
+    workgroup per graph; pharmacodiff.py:395-429, dynamics_gvp.py:37-42,187-227) against the separate node + head and
+    update + build launches on the same states: three denoising steps each, state (x_t, h_t) within the single-call
+    tolerance after every step (steps 2 and 3 consume the edges the previous step's tail built) and the dynamic edge lists
+    of the next call IDENTICAL (same order: both forms run the same build body).  Cases: config-1 shape, ragged pockets
+    (some smaller than k) with 1-10 centers, kNN ff edges, per-graph normalisers, 3 conv layers / 2 head GVPs, and graphs
+    with more than 16 centers (two passes of the 16-row item)."""
+    cfg = {"config1": O.DynamicsConfig(), "ragged": O.DynamicsConfig(), "knnff": O.DynamicsConfig(ff_k=2, pf_k=3, message_norm=1),
+           "gnorm": O.DynamicsConfig(message_norm=0, pf_k=5),
+           "deep": O.DynamicsConfig(n_convs=3, n_message_gvps=2, n_update_gvps=3, n_noise_gvps=2),
+           "many_centers": O.DynamicsConfig()}[case]
+    sd = O.make_state_dict(cfg, 3)
+    if case == "config1":
+        n_prot, n_pharm = [64], [4]
+    elif case == "many_centers":
+        n_prot, n_pharm = [40, 90, 33], [17, 33, 5]
+    else:
+        n_prot, n_pharm = [3, 70, 12, 48, 7, 33], [1, 10, 3, 8, 2, 5]
+    batch = O.synthetic_batch([700 + i for i in range(len(n_prot))], n_prot, n_pharm, cfg)
+    Nf = int(batch.pharm_ptr[-1])
+    T, n = 100, 3
+    noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(17))
+    coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+    states, edges = {}, {}
+    for form, mask in (("tail", "15"), ("separate", "7")):
+        monkeypatch.setenv("PFDYN_N16", mask)
+        eng = engine_for(cfg, sd)
+        set_batch(eng, batch)
+        arr = eng.coef_array(coef, [40, 39, 38])
+        eng.sample_begin(noise[0])
+        st, ed = [], []
+        for i in range(n):
+            eng.denoise_step(arr[i], noise[i + 1])
+            assert eng.kernel_family(cfg.n_convs) == (16 if form == "tail" else 0)
+            x, h = eng.sample_frame()
+            st.append((x.cpu(), h.cpu()))
+            ed.append([tuple(t.clone() for t in eng.get_edges(et)) for et in range(3)])
+        states[form], edges[form] = st, ed
+    for i in range(n):
+        for a, b in zip(states["tail"][i], states["separate"][i]):
+            torch.testing.assert_close(a, b, rtol=2e-4 * (i + 1), atol=2e-4 * (i + 1))
+        for et in range(3):
+            (s1, d1), (s2, d2) = edges["tail"][i][et], edges["separate"][i][et]
+            assert torch.equal(s1, s2) and torch.equal(d1, d2), (case, i, et)
