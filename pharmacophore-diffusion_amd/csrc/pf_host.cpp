@@ -1159,7 +1159,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             // the tail launch: one workgroup per graph does the centers' node update, the head, the sampler update and the
             // edge build (the fast build's shape: kNN pf edges, pockets of at most 512 atoms)
             const bool tail = fuse && step != nullptr && l > 0 && (h->pol.n16_mask & 8) && h->n16_tail != 0 && h->B <= h->pol.tail_graphs_max &&
-                              enc_fly && c.pf_k > 0 && h->max_np <= 512 && h->step_build_fast;
+                              enc_fly && c.pf_k > 0 && h->max_np <= 512 && c.pharm_nf <= 16 && h->step_build_fast;
             if (tail) {
                 TailParams tp{};
                 tp.in_start = n.in_start; tp.in_cnt = n.in_cnt; tp.N = n.N;
@@ -2317,7 +2317,7 @@ int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noi
         const bool share = (h->prune && cc.n_convs == 2) && share_now(h);     // what the next denoising step's dynamics call will ask for
         const BuildParams bp = build_params(h, share);
         // kNN pf edges and pockets of at most 512 atoms: the latency-optimised kernel (one atom per thread)
-        const int fast = (h->cfg.pf_k > 0 && h->max_np <= 512 && h->step_build_fast) ? 1 : 0;
+        const int fast = (h->cfg.pf_k > 0 && h->max_np <= 512 && h->cfg.pharm_nf <= 16 && h->step_build_fast) ? 1 : 0;
         { ProfScope ps(h, pf_handle::K_STEP, s); pfk_step_build(&sp, &bp, fast, s); }
         build_done(h, share);
         h->edges_built = true;

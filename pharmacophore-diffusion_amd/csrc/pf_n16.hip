@@ -25,6 +25,20 @@
 #include <type_traits>
 #include <algorithm>
 #include "pf_device.h"
+#ifdef N16_STAMPS
+namespace {
+__device__ unsigned long long* g_n16_stamps = nullptr;
+__device__ int g_n16_stamp_off = 0;                   // first recorded workgroup
+__device__ int g_n16_stamp_kid = -1;                  // kernel filter (see N16_STAMP)
+}
+// the update + build body of the tail launch stamps slots 40 + k of its wave (k: the build's own phase numbers, <= 15)
+#define SB_STAMP(k)                                                                                                    \
+    do {                                                                                                               \
+        const int rb_ = (int)blockIdx.x - g_n16_stamp_off;                                                             \
+        if ((threadIdx.x & 63) == 0 && g_n16_stamps && rb_ >= 0 && rb_ < 64 && (g_n16_stamp_kid < 0 || g_n16_stamp_kid == 3)) \
+            g_n16_stamps[((size_t)rb_ * 4 + (threadIdx.x >> 6)) * 64 + 40 + (k)] = __builtin_amdgcn_s_memtime();       \
+    } while (0)
+#endif
 #include "pf_stepbuild.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -99,20 +113,42 @@ __device__ __forceinline__ void ring_start(N16Ring& r, pf_gcf stream, const int 
     static_for<0, N16_D>([&](auto I) { r.q[decltype(I)::value] = r.load(decltype(I)::value); });
 }
 
-// In-kernel cycle stamps (diagnostic builds only, -DN16_STAMPS: tools/probes/n16_chain_bench.hip): lane 0 of every wave of
-// the first 64 workgroups writes s_memtime at the phase boundaries of n16_block
+// In-kernel cycle stamps (diagnostic builds only, -DN16_STAMPS: tools/probes/n16_chain_bench.hip, tools/n16_stamps.py): lane 0 of
+// every wave of 64 workgroups writes s_memtime at the phase boundaries of n16_block.  The stamp counter `sk` carries the
+// kernel's id in bits 8.. (k_n16_edge<true> 0, <false> 1, k_n16_fused 2, k_n16_tail 3, k_n16_unit 4): g_n16_stamp_kid >= 0
+// records that kernel only (a step runs three of them over the same buffer)
 #ifdef N16_STAMPS
-__device__ unsigned long long* g_n16_stamps = nullptr;
-__device__ int g_n16_stamp_off = 0;                   // first recorded workgroup
 #define N16_STAMP(sk, lane, wq)                                                                                        \
     do {                                                                                                               \
         const int rb_ = (int)blockIdx.x - g_n16_stamp_off;                                                             \
-        if ((lane) == 0 && g_n16_stamps && rb_ >= 0 && rb_ < 64 && (sk) < 64)                                          \
-            g_n16_stamps[((size_t)rb_ * 4 + (wq)) * 64 + (sk)] = __builtin_amdgcn_s_memtime();                         \
+        const int k_ = (sk) & 255;                                                                                     \
+        if ((lane) == 0 && g_n16_stamps && rb_ >= 0 && rb_ < 64 && k_ < 64 && (g_n16_stamp_kid < 0 || g_n16_stamp_kid == ((sk) >> 8))) \
+            g_n16_stamps[((size_t)rb_ * 4 + (wq)) * 64 + k_] = __builtin_amdgcn_s_memtime();                           \
         ++(sk);                                                                                                        \
     } while (0)
 #else
 #define N16_STAMP(sk, lane, wq) do { } while (0)
+#endif
+// the five stamps inside every n16_block (-DN16_STAMPS_SPARSE: off -- each stamp waits for the wave's outstanding LDS
+// operations, and five per block stretch a chain by ~50 %; the sparse form keeps the phase boundaries outside the blocks)
+#if defined(N16_STAMPS) && !defined(N16_STAMPS_SPARSE)
+#define N16_STAMP_B(sk, lane, wq) N16_STAMP(sk, lane, wq)
+#else
+#define N16_STAMP_B(sk, lane, wq) do { } while (0)
+#endif
+
+// diagnostic builds (-DFUSED_CUT=k / -DTAIL_CUT=k): the workgroup stops at cut point k (timing only).  The value that
+// reached the cut point is kept alive by a store that never executes.
+#define N16_CUT_AT(which, k, val, ptr)                                                                                 \
+    do { if ((which) == (k)) { if ((val) == 1.2345e-33f) *(ptr) = (val); __builtin_amdgcn_endpgm(); } } while (0)
+#ifndef FUSED_CUT
+#define FUSED_CUT 0
+#endif
+#ifndef EDGE_CUT
+#define EDGE_CUT 0
+#endif
+#ifndef TAIL_CUT
+#define TAIL_CUT 0
 #endif
 
 // -DN16_TRACE (diagnostic builds): wave 0 of every workgroup of k_n16_edge records [start, end, HW_ID, XCC_ID | item kind]
@@ -155,7 +191,7 @@ template <int KIND, int OFF, bool LAST, bool SIG = true>
 __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float (&VB)[4], const N16In& in, f32x4 (&S)[2],
                                           N16Lds* lds, const int lane, const int wq, int& sk, f32x4* gs = nullptr) {
     constexpr N16Sched Q = n16_sched(KIND);
-    N16_STAMP(sk, lane, wq);                                          // block start
+    N16_STAMP_B(sk, lane, wq);                                          // block start
     constexpr bool M0 = KIND != N16_GEN;                              // 17 hidden vector channels, rbf inputs
     constexpr bool VZ = KIND == N16_M0Z || KIND == N16_M0H;           // the node vectors are zero: Vh = Wh[0] (x) xhat
     constexpr bool HOIST = KIND == N16_M0H;
@@ -217,9 +253,9 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
         } else if constexpr (qi >= Q.q_sh && qi < Q.q_sh + 2) {
             constexpr int r0 = 2 * (qi - Q.q_sh);
             if constexpr (r0 == 0 && !VZ) {           // barrier A: the three coordinates of Vh are in LDS
-                N16_STAMP(sk, lane, wq);              // main k-steps issued
+                N16_STAMP_B(sk, lane, wq);              // main k-steps issued
                 lds_barrier();
-                N16_STAMP(sk, lane, wq);              // barrier A passed
+                N16_STAMP_B(sk, lane, wq);              // barrier A passed
                 const f32x4 a = *reinterpret_cast<const f32x4*>(&lds->v[(0 * 64 + lane) * 4]);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(&lds->v[(1 * 64 + lane) * 4]);
                 const f32x4 c = *reinterpret_cast<const f32x4*>(&lds->v[(2 * 64 + lane) * 4]);
@@ -265,9 +301,9 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
                     *reinterpret_cast<f32x4*>(&lds->s[((2 * wq) * 64 + lane) * 4]) = S[0];
                     *reinterpret_cast<f32x4*>(&lds->s[((2 * wq + 1) * 64 + lane) * 4]) = S[1];
                 }
-                N16_STAMP(sk, lane, wq);              // sh / Vu / SiLU / gate k-steps issued
+                N16_STAMP_B(sk, lane, wq);              // sh / Vu / SiLU / gate k-steps issued
                 lds_barrier();
-                N16_STAMP(sk, lane, wq);              // barrier B passed
+                N16_STAMP_B(sk, lane, wq);              // barrier B passed
                 if constexpr (!LAST) {
 #pragma unroll
                     for (int T = 0; T < 8; ++T) {
@@ -477,6 +513,7 @@ __device__ __forceinline__ void n16_edge_item(const EdgeParams& p, const EncodeP
 #pragma unroll
         for (int r = 0; r < 4; ++r) VB[r] = 0.f;
     }
+    N16_CUT_AT(EDGE_CUT, 2, XS[0] + VB[0] + S[0][0] + rw.xs.x + rw.xd.x, p.msg_s);
     n16_edge_chain<KIND0>(p, ring, rw, XS, VB, S, lds, nv, lane, wq, sk);
 }
 
@@ -491,7 +528,7 @@ __global__ __launch_bounds__(256) void k_n16_edge(const int* __restrict__ a_dyn_
     const int lane = threadIdx.x & 63;
     const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int item = (int)blockIdx.x;
-    int sk = 0;
+    int sk = (L0 ? 0 : 1) << 8;
     N16_STAMP(sk, lane, wq);                              // kernel entry
     int e0, nv, et;
     if (a_nreg > 0) {
@@ -562,6 +599,7 @@ __global__ __launch_bounds__(256) void k_n16_edge(const int* __restrict__ a_dyn_
         g_n16_trace[(size_t)blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) | ((unsigned long long)et << 32) | ((unsigned long long)nv << 40);
     }
 #endif
+    N16_CUT_AT(EDGE_CUT, 1, (float)(e0 + nv), p.msg_s);
     if constexpr (L0) {
         // conv layer 0: every node vector is zero; protein sources (pf, pp) read the type tables of the static hoist
         // (h_src is one of rec_nf encoder outputs per t), centers (ff, fp) are encoded on the fly
@@ -621,70 +659,144 @@ __device__ __forceinline__ void n16_layernorm(pf_gcf lw, pf_gcf lb, float (&XS)[
 // GVPLayerNorm.  Leaves h' in XS (every wave: all 128 features) and v' in VB (wave c: coordinate c) -- exactly what the first
 // message GVP of the NEXT layer's edges takes, so nothing is written (k_n16_fused).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void n16_node_update_l0(const FusedParams& f, const EncodeParams& ep, N16Ring& ring, const int node, const int nt,
-                                                   float (&XS)[32], float (&VB)[4], N16Lds* lds, const int lane, const int wq, int& sk) {
+// where a node finds the partial rows of its in-edges: two segments [st, st + cn) of edge slots; the partial rows of a
+// segment are the last slots of the aligned groups of (gm + 1) slots it touches
+struct NodeDesc { int st[2], cn[2], gm[2]; };
+// Sum of a node's partial rows, each segment scaled by 1 / count under message_norm = 'mean' (norm_mode 0).  A wave gathers
+// only ITS quarter of the scalars -- tiles T = 2 wq + t, features 32 wq + 16 t + 4 g + r of row j, the D layout of its own
+// outputs -- and coordinate wq of the vectors: all four waves fetching whole rows (what the B operands need) moves 4 x the
+// bytes through one compute unit's memory path, and at ~35-70 GB/s per CU that, not latency, is what a gather costs here
+// (measured: 4.4 us of the fused launch).  The quarters meet in LDS afterwards (n16_quarters_to_rows).
+// The first two partial rows of each segment leave in ONE batch of loads (absent: the all-zero row) -- at these in-degrees
+// that is all of them -- and longer segments finish in a loop.
+struct RowQ {
+    f32x4 x[2][2][2];                           // [segment][row k][tile t]
+    float vv[2][2][4];
+    int nxt[2];
+};
+__device__ __forceinline__ void n16_rows_load(const float* msg_s, const float* msg_v, const int zero_row, const NodeDesc& nd, RowQ& q,
+                                              const int lane, const int wq) {
     const int g = lane >> 4;
     const int cw = wq < 3 ? wq : 0;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) XS[k] = 0.f;
+    for (int sl = 0; sl < 2; ++sl) {
+        const int end = nd.st[sl] + nd.cn[sl], gm = nd.gm[sl];
+        int e = nd.st[sl];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool has = e < end;
+            const int rw = has ? min(e | gm, end - 1) : zero_row;
+            const f32x4 PF_AS1* mp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)msg_s + (size_t)rw * PF_S + 32 * wq) + g;
+            q.x[sl][k][0] = mp[0]; q.x[sl][k][1] = mp[4];
+            pf_gcf vp = (pf_gcf)msg_v + (size_t)rw * 48 + 12 * g + cw;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q.vv[sl][k][r] = vp[3 * r];
+            e = has ? rw + 1 : e;
+        }
+        q.nxt[sl] = e;
+    }
+}
+// Q: this wave's two tiles of the sum; VB: coordinate wq of the vector sum
+__device__ __forceinline__ void n16_rows_sum(const float* msg_s, const float* msg_v, const int zero_row, const int norm_mode,
+                                             const NodeDesc& nd, const RowQ& q, f32x4 (&Q)[2], float (&VB)[4], const int lane, const int wq) {
+    const int g = lane >> 4;
+    const int cw = wq < 3 ? wq : 0;
+    Q[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; Q[1] = Q[0];
 #pragma unroll
     for (int r = 0; r < 4; ++r) VB[r] = 0.f;
-    // the two segments of the node's in-edges; their partial rows are the last slots of the aligned groups they touch
-    int st[2], cn[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int end = nd.st[sl] + nd.cn[sl], gm = nd.gm[sl];
+        f32x4 ps0 = q.x[sl][0][0] + q.x[sl][1][0], ps1 = q.x[sl][0][1] + q.x[sl][1][1];
+        float pv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] = q.vv[sl][0][r] + q.vv[sl][1][r];
+        int e = q.nxt[sl];
+        while (__any(e < end)) {                          // (rows that are done add the all-zero row)
+            const bool has = e < end;
+            const int rw = has ? min(e | gm, end - 1) : zero_row;
+            const f32x4 PF_AS1* mp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)msg_s + (size_t)rw * PF_S + 32 * wq) + g;
+            const f32x4 y0 = mp[0], y1 = mp[4];
+            pf_gcf vp = (pf_gcf)msg_v + (size_t)rw * 48 + 12 * g + cw;
+            float yv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[r] = vp[3 * r];
+            ps0 += y0; ps1 += y1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[r] += yv[r];
+            e = has ? rw + 1 : e;
+        }
+        const float sc = (norm_mode == 0 && nd.cn[sl] > 0) ? 1.0f / (float)nd.cn[sl] : 1.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Q[0][r] = fmaf(ps0[r], sc, Q[0][r]); Q[1][r] = fmaf(ps1[r], sc, Q[1][r]); VB[r] = fmaf(pv[r], sc, VB[r]); }
+    }
+}
+// the four waves' quarters of 16 rows -> every wave holds the whole rows as B operands (XS[4 T + r]: feature 16 T + 4 g + r).
+// One barrier; the caller keeps another barrier between this function's reads and the next write of lds->s.
+__device__ __forceinline__ void n16_quarters_to_rows(const f32x4 (&Q)[2], float (&XS)[32], N16Lds* lds, const int lane, const int wq) {
+    *reinterpret_cast<f32x4*>(&lds->s[((2 * wq) * 64 + lane) * 4]) = Q[0];
+    *reinterpret_cast<f32x4*>(&lds->s[((2 * wq + 1) * 64 + lane) * 4]) = Q[1];
+    lds_barrier();
+#pragma unroll
+    for (int T = 0; T < 8; ++T) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(&lds->s[(T * 64 + lane) * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) XS[4 * T + r] = x[r];
+    }
+}
+
+// descriptors of a node's in-edges in conv layer 0 (slot 0: ff | fp; second segment: pf of a center, the pp / "pa" edges of an atom)
+__device__ __forceinline__ void n16_node_desc_l0(const FusedParams& f, const int node, const int nt, NodeDesc& nd) {
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
         const int slot = sl == 0 ? 0 : (nt == 0 ? f.pp_slot : 1);
-        st[sl] = f.in_start[slot * f.N + node];
-        cn[sl] = f.in_cnt[slot * f.N + node];
+        nd.st[sl] = f.in_start[slot * f.N + node];
+        nd.cn[sl] = f.in_cnt[slot * f.N + node];
+        nd.gm[sl] = (sl == 0 ? f.grp : (nt == 0 ? f.grp_pa : f.grp)) - 1;
     }
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        const int end = st[sl] + cn[sl];
-        const int gm = (sl == 0 ? f.grp : (nt == 0 ? f.grp_pa : f.grp)) - 1;
-        const float sc = (f.norm_mode == 0 && cn[sl] > 0) ? 1.0f / (float)cn[sl] : 1.0f;
-        int e = st[sl];
-        while (__any(e < end)) {                          // (rows that are done add the all-zero row)
-            const bool has = e < end;
-            const int rw = has ? min(e | gm, end - 1) : f.zero_row;
-            const f32x4 PF_AS1* mp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)f.msg_s + (size_t)rw * PF_S) + g;
-            f32x4 x[8];
-#pragma unroll
-            for (int T = 0; T < 8; ++T) x[T] = mp[4 * T];
-            pf_gcf vp = (pf_gcf)f.msg_v + (size_t)rw * 48 + 12 * g + cw;
-            float vv[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) vv[r] = vp[3 * r];
-#pragma unroll
-            for (int T = 0; T < 8; ++T)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) XS[4 * T + r] = fmaf(x[T][r], sc, XS[4 * T + r]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) VB[r] = fmaf(vv[r], sc, VB[r]);
-            e = has ? rw + 1 : e;
-        }
+}
+// (nd: n16_node_desc_l0 of the node; pty: f.ptype[node] of an atom -- both requested by the caller together with whatever
+// else it loads at that level, so that a workgroup's prologue is four dependent round trips: work list, edge slots, descriptors
+// + coordinates + types, rows)
+__device__ __forceinline__ void n16_node_update_l0(const FusedParams& f, const EncodeParams& ep, N16Ring& ring, const int node, const int nt,
+                                                   const NodeDesc& nd, const int pty, float (&XS)[32], float (&VB)[4], N16Lds* lds,
+                                                   const int lane, const int wq, int& sk) {
+    const int g = lane >> 4;
+    // one batch of loads: the partial rows (this wave's quarter) and, for an atom, its quarter of the residual input -- the
+    // encoder output of its element type, a row of the timestep's type table
+    RowQ rq;
+    n16_rows_load(f.msg_s, f.msg_v, f.zero_row, nd, rq, lane, wq);
+    f32x4 Hq[2];
+    Hq[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; Hq[1] = Hq[0];
+    if (nt == 0) {
+        pf_gcf hp = (pf_gcf)f.htab + (f.htab_gstride ? (size_t)f.gid[node] * f.htab_gstride : 0) + (size_t)pty * PF_S + 32 * wq + 4 * g;
+        Hq[0] = *reinterpret_cast<const f32x4 PF_AS1*>(hp);
+        Hq[1] = *reinterpret_cast<const f32x4 PF_AS1*>(hp + 16);
     }
     float inv_norm = 1.0f;
     if (f.norm_mode == 1) inv_norm = 1.0f / f.norm_value;
     else if (f.norm_mode == 2) inv_norm = 1.0f / f.gnorm[nt * f.B + f.gid[node]];
-    // residual input: the encoder output of the node (a type-table row for protein atoms, encoded on the fly for centers)
+    // a center's residual input is encoded on the fly (its own exchange through lds->s, closed by a barrier), under the row loads
     float H[32];
-    if (nt == 0) {
-        pf_gcf hp = (pf_gcf)f.htab + (f.htab_gstride ? (size_t)f.gid[node] * f.htab_gstride : 0) + (size_t)f.ptype[node] * PF_S + 4 * g;
-#pragma unroll
-        for (int T = 0; T < 8; ++T) {
-            const f32x4 x = *reinterpret_cast<const f32x4 PF_AS1*>(hp + 16 * T);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) H[4 * T + r] = x[r];
-        }
-    } else {
+    if (nt != 0) {
         const float tt = ep.t ? ((pf_gcf)ep.t)[f.gid[node]] : ep.t_scalar;
         n16_encode_pharm(ep, (pf_gcf)ep.pharm_h + (size_t)(node - ep.Np) * ep.pharm_nf, tt, H, lds, lane, wq);
     }
+    f32x4 Q[2];
+    n16_rows_sum(f.msg_s, f.msg_v, f.zero_row, f.norm_mode, nd, rq, Q, VB, lane, wq);
+    N16_STAMP(sk, lane, wq);                              // partial rows summed
+    N16_CUT_AT(FUSED_CUT, 2, Q[0][0] + VB[0] + Hq[0][0], f.h_out);
 #pragma unroll
-    for (int k = 0; k < 32; ++k) XS[k] = fmaf(XS[k], inv_norm, H[k]);
+    for (int r = 0; r < 4; ++r) { Q[0][r] = fmaf(Q[0][r], inv_norm, Hq[0][r]); Q[1][r] = fmaf(Q[1][r], inv_norm, Hq[1][r]); }
+    n16_quarters_to_rows(Q, XS, lds, lane, wq);          // (the first LayerNorm's barrier closes the reads)
+    if (nt != 0) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) XS[k] += H[k];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) VB[r] = wq < 3 ? VB[r] * inv_norm : 0.f;
     n16_layernorm(f.ln1_w[nt], f.ln1_b[nt], XS, VB, lds, lane, wq);
+    N16_STAMP(sk, lane, wq);                              // residual input + first LayerNorm
     float Xr[32], Vr[4];
 #pragma unroll
     for (int k = 0; k < 32; ++k) Xr[k] = XS[k];
@@ -711,7 +823,7 @@ __global__ __launch_bounds__(256) void k_n16_fused(const int* __restrict__ a_dyn
     const int lane = threadIdx.x & 63;
     const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int g = lane >> 4, j = lane & 15;
-    int sk = 0;
+    int sk = 2 << 8;
     N16_STAMP(sk, lane, wq);                              // kernel entry
     float XS[32], VB[4];
     if ((int)blockIdx.x >= f.n_edge_items) {
@@ -724,7 +836,9 @@ __global__ __launch_bounds__(256) void k_n16_fused(const int* __restrict__ a_dyn
         const int node = f.Np + f0 + 16 * part + min(j, nv - 1);
         N16Ring ring;
         ring_start(ring, f.upd_pharm + (size_t)wq * f.upd_pharm_stride, lane);
-        n16_node_update_l0(f, ep, ring, node, 1, XS, VB, &lds, lane, wq, sk);
+        NodeDesc nd;
+        n16_node_desc_l0(f, node, 1, nd);
+        n16_node_update_l0(f, ep, ring, node, 1, nd, 0, XS, VB, &lds, lane, wq, sk);
         if (j < nv && wq == 0) {
             float* hp = f.h_out + (size_t)node * PF_S + 4 * g;
 #pragma unroll
@@ -780,14 +894,21 @@ __global__ __launch_bounds__(256) void k_n16_fused(const int* __restrict__ a_dyn
         nv = __builtin_amdgcn_readfirstlane(min(16, cnt - loc));
     }
     N16_STAMP(sk, lane, wq);                              // item known
+    N16_CUT_AT(FUSED_CUT, 1, (float)(e0 + nv), f.h_out);
     N16Ring ring;
     ring_start(ring, f.chain[et] + (size_t)wq * f.chain_stride[et], lane);
     N16Rows rw;
     rw.e = e0 + min(j, nv - 1);
     const int src = p.esrc[rw.e];
     rw.dst = p.edst[rw.e];
+    // one level of loads: coordinates, the source's in-edge descriptors, its element type
+    const int nt = et == ET_FF ? 1 : 0;
     rw.xs = p.xn[src]; rw.xd = p.xn[rw.dst];
-    n16_node_update_l0(f, ep, ring, src, et == ET_FF ? 1 : 0, XS, VB, &lds, lane, wq, sk);
+    NodeDesc nd;
+    n16_node_desc_l0(f, src, nt, nd);
+    const int pty = nt == 0 ? f.ptype[src] : 0;
+    n16_node_update_l0(f, ep, ring, src, nt, nd, pty, XS, VB, &lds, lane, wq, sk);
+    N16_CUT_AT(FUSED_CUT, 3, XS[0] + VB[0] + rw.xs.x + rw.xd.x, f.h_out);
     f32x4 S[2];
     S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
     n16_edge_chain<N16_M0F>(p, ring, rw, XS, VB, S, &lds, nv, lane, wq, sk);
@@ -808,102 +929,50 @@ struct __attribute__((aligned(16))) TailLds {
     pfsb::StepBuildLds sb;
 };
 
-__device__ __forceinline__ void n16_node_update_last(const TailParams& t, N16Ring& ring, const int node, float (&XS)[32], float (&VB)[4],
-                                                     N16Lds* lds, const int lane, const int wq, int& sk) {
-    const int g = lane >> 4;
-    const int cw = wq < 3 ? wq : 0;
-    // one batch of loads: the descriptors of the two in-edge segments (ff: slot 0, pf: slot 1) and the residual rows
-    int st[2], cn[2];
+// the descriptors of the two in-edge segments of a center in the last conv layer (ff: slot 0, pf: slot 1)
+__device__ __forceinline__ void n16_node_desc_last(const TailParams& t, const int node, NodeDesc& nd) {
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
-        st[sl] = t.in_start[sl * t.N + node];
-        cn[sl] = t.in_cnt[sl * t.N + node];
+        nd.st[sl] = t.in_start[sl * t.N + node];
+        nd.cn[sl] = t.in_cnt[sl * t.N + node];
+        nd.gm[sl] = t.grp - 1;
     }
-    float H[32], Vr0[4];
+}
+// hook(0): called once the gathers have been requested, hook(1): behind the first LayerNorm -- where the tail kernel issues
+// the loads of its update + build
+template <class Hook>
+__device__ __forceinline__ void n16_node_update_last(const TailParams& t, const NodeDesc& nd, N16Ring& ring, const int node, float (&XS)[32],
+                                                     float (&VB)[4], N16Lds* lds, const int lane, const int wq, int& sk, Hook&& hook) {
+    const int g = lane >> 4;
+    const int cw = wq < 3 ? wq : 0;
+    // one batch of loads: the partial rows and the residual rows -- the layer's input state of the center --, this wave's quarter
+    RowQ rq;
+    n16_rows_load(t.msg_s, t.msg_v, t.zero_row, nd, rq, lane, wq);
+    f32x4 Hq[2];
+    float Vr0[4];
     {
-        pf_gcf hp = (pf_gcf)t.h_in + (size_t)node * PF_S + 4 * g;
-#pragma unroll
-        for (int T = 0; T < 8; ++T) {
-            const f32x4 x = *reinterpret_cast<const f32x4 PF_AS1*>(hp + 16 * T);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) H[4 * T + r] = x[r];
-        }
+        pf_gcf hp = (pf_gcf)t.h_in + (size_t)node * PF_S + 32 * wq + 4 * g;
+        Hq[0] = *reinterpret_cast<const f32x4 PF_AS1*>(hp);
+        Hq[1] = *reinterpret_cast<const f32x4 PF_AS1*>(hp + 16);
         pf_gcf vp = (pf_gcf)t.v_in + (size_t)node * 48 + 12 * g + cw;
 #pragma unroll
         for (int r = 0; r < 4; ++r) Vr0[r] = vp[3 * r];
     }
-    // the partial rows of a segment [st, end) are the last slots of the aligned groups of grp slots it touches: the first two
-    // of each segment in one batch of loads (absent: the all-zero row), longer segments finish in a loop
-    const int gm = t.grp - 1;
-    f32x4 x[2][2][8];
-    float vv[2][2][4];
-    int nxt[2];
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        const int end = st[sl] + cn[sl];
-        int e = st[sl];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const bool has = e < end;
-            const int rw = has ? min(e | gm, end - 1) : t.zero_row;
-            const f32x4 PF_AS1* mp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)t.msg_s + (size_t)rw * PF_S) + g;
-#pragma unroll
-            for (int T = 0; T < 8; ++T) x[sl][k][T] = mp[4 * T];
-            pf_gcf vp = (pf_gcf)t.msg_v + (size_t)rw * 48 + 12 * g + cw;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) vv[sl][k][r] = vp[3 * r];
-            e = has ? rw + 1 : e;
-        }
-        nxt[sl] = e;
-    }
-#pragma unroll
-    for (int k = 0; k < 32; ++k) XS[k] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) VB[r] = 0.f;
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        const int end = st[sl] + cn[sl];
-        float ps[32], pv[4];
-#pragma unroll
-        for (int T = 0; T < 8; ++T)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ps[4 * T + r] = x[sl][0][T][r] + x[sl][1][T][r];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pv[r] = vv[sl][0][r] + vv[sl][1][r];
-        int e = nxt[sl];
-        while (__any(e < end)) {                          // (rows that are done add the all-zero row)
-            const bool has = e < end;
-            const int rw = has ? min(e | gm, end - 1) : t.zero_row;
-            const f32x4 PF_AS1* mp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)t.msg_s + (size_t)rw * PF_S) + g;
-            f32x4 y[8];
-#pragma unroll
-            for (int T = 0; T < 8; ++T) y[T] = mp[4 * T];
-            pf_gcf vp = (pf_gcf)t.msg_v + (size_t)rw * 48 + 12 * g + cw;
-            float yv[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) yv[r] = vp[3 * r];
-#pragma unroll
-            for (int T = 0; T < 8; ++T)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ps[4 * T + r] += y[T][r];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pv[r] += yv[r];
-            e = has ? rw + 1 : e;
-        }
-        const float sc = (t.norm_mode == 0 && cn[sl] > 0) ? 1.0f / (float)cn[sl] : 1.0f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) XS[k] = fmaf(ps[k], sc, XS[k]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) VB[r] = fmaf(pv[r], sc, VB[r]);
-    }
     float inv_norm = 1.0f;
     if (t.norm_mode == 1) inv_norm = 1.0f / t.norm_value;
     else if (t.norm_mode == 2) inv_norm = 1.0f / t.gnorm[1 * t.B + t.gid[node]];
+    hook(0);
+    f32x4 Q[2];
+    n16_rows_sum(t.msg_s, t.msg_v, t.zero_row, t.norm_mode, nd, rq, Q, VB, lane, wq);
+    N16_STAMP(sk, lane, wq);                              // partial rows summed
+    N16_CUT_AT(TAIL_CUT, 1, Q[0][0] + VB[0] + Hq[0][0] + Vr0[0], t.eps_h);
 #pragma unroll
-    for (int k = 0; k < 32; ++k) XS[k] = fmaf(XS[k], inv_norm, H[k]);
+    for (int r = 0; r < 4; ++r) { Q[0][r] = fmaf(Q[0][r], inv_norm, Hq[0][r]); Q[1][r] = fmaf(Q[1][r], inv_norm, Hq[1][r]); }
+    n16_quarters_to_rows(Q, XS, lds, lane, wq);          // (the first LayerNorm's barrier closes the reads)
 #pragma unroll
     for (int r = 0; r < 4; ++r) VB[r] = wq < 3 ? fmaf(VB[r], inv_norm, Vr0[r]) : 0.f;
     n16_layernorm(t.ln1_w, t.ln1_b, XS, VB, lds, lane, wq);
+    hook(1);
     float Xr[32], Vr[4];
 #pragma unroll
     for (int k = 0; k < 32; ++k) Xr[k] = XS[k];
@@ -930,9 +999,15 @@ __global__ __launch_bounds__(256) void k_n16_tail(const int* __restrict__ a_prot
     const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int g = lane >> 4, j = lane & 15;
     const int gq = (int)blockIdx.x;
-    const int f0 = a_pharm_ptr[gq], Nf = a_pharm_ptr[gq + 1] - f0;
-    int sk = 0;
+    int sk = 3 << 8;
     N16_STAMP(sk, lane, wq);                              // kernel entry
+    // what the update + build reads besides eps: trips (A) and (B) leave now, (C) behind the node update's descriptors -- all
+    // of it has landed long before the head is done
+    pfsb::SbPre<256> pre;
+    pfsb::sb_load_a<256>(pre, gq, a_prot_ptr, a_pharm_ptr, a_reg, a_B, a_Np_tot, bp);
+    const int f0 = pre.f0, Nf = pre.Nf;
+    bool c_loaded = false;
+    if (Nf == 0) pfsb::sb_load_b<256>(pre, a_Np_tot, sp, bp);       // (a graph without centers: nothing to put the loads under)
     for (int base = 0; base < Nf; base += 16) {           // workgroup-uniform
         const int nv = __builtin_amdgcn_readfirstlane(min(16, Nf - base));
         const int fl = base + min(j, nv - 1);
@@ -940,7 +1015,16 @@ __global__ __launch_bounds__(256) void k_n16_tail(const int* __restrict__ a_prot
         N16Ring ring;
         ring_start(ring, t.chain + (size_t)wq * t.chain_stride, lane);
         float XS[32], VB[4];
-        n16_node_update_last(t, ring, node, XS, VB, &L.n, lane, wq, sk);
+        NodeDesc nd;
+        n16_node_desc_last(t, node, nd);
+        // the node update's own gathers leave first (the memory counter is in-order: loads issued in front of them would delay
+        // them); trip (B) of the update + build follows underneath, trip (C) behind the first LayerNorm
+        n16_node_update_last(t, nd, ring, node, XS, VB, &L.n, lane, wq, sk, [&](const int phase) {
+            if (c_loaded) return;
+            if (phase == 0) pfsb::sb_load_b<256>(pre, a_Np_tot, sp, bp);
+            else { pfsb::sb_load_c<256>(pre, bp); c_loaded = true; }
+        });
+        N16_CUT_AT(TAIL_CUT, 2, XS[0] + VB[0], t.eps_h);
         N16In none{};
         f32x4 S[2], GS = {0.f, 0.f, 0.f, 0.f};
         S[0] = GS; S[1] = GS;
@@ -965,8 +1049,18 @@ __global__ __launch_bounds__(256) void k_n16_tail(const int* __restrict__ a_prot
         }
         lds_barrier();                                    // eps of this pass is in LDS; the chain's buffers are free again
     }
+    if (!c_loaded) pfsb::sb_load_c<256>(pre, bp);         // a graph without centers
+#if defined(TAIL_CUT) && TAIL_CUT == 3                    // diagnostic builds: the launch without its update + build (timing only)
+    return;
+#endif
     const pfsb::EpsLds eps{L.ex, L.eh};
-    pfsb::step_build_fast_body<256>(gq, a_prot_ptr, a_pharm_ptr, a_reg, a_B, a_Np_tot, sp, bp, eps, L.sb);
+    float ex[3] = {0.f, 0.f, 0.f}, eh[pfsb::SB_MAXNF];
+    const int fme = min((int)threadIdx.x, PF_MAXF - 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ex[c] = eps.x(fme, c);
+#pragma unroll
+    for (int k = 0; k < pfsb::SB_MAXNF; ++k) eh[k] = eps.h(fme, k);
+    pfsb::sb_finish<256>(pre, ex, eh, gq, sp, bp, L.sb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -982,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_n16_unit(const UnitParams p) {
     const int g = lane >> 4, j = lane & 15;
     const int row = e0 + min(j, nv - 1);
     const bool msg = p.kind == 16;
-    int sk = 0;
+    int sk = 4 << 8;
     N16_STAMP(sk, lane, wq);                              // item start
     const int sw = msg ? 144 : 128, vw = msg ? 51 : 48, v0 = msg ? 3 : 0;
     N16Ring ring;
@@ -1040,6 +1134,7 @@ int pfk_n16_set_stamp_buffer(unsigned long long* dev, int off) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_n16_stamp_off), &off, sizeof(off));
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_n16_stamps), &dev, sizeof(dev));
 }
+int pfk_n16_set_stamp_kernel(int kid) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_n16_stamp_kid), &kid, sizeof(kid)); }
 #endif
 #ifdef N16_TRACE
 int pfk_n16_set_trace_buffer(unsigned long long* dev) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_n16_trace), &dev, sizeof(dev)); }

@@ -12,7 +12,7 @@
 // ~2,000 cycles, and __syncthreads drains every outstanding load.  Three dependent trips: (A) the graph's pointers and
 // regions, (B) every input row -- pharm state, eps, noise, protein coordinates, the static in-edge descriptors -- (C) the
 // static pp sources of the thread's atoms.  The updated coordinates stay in LDS for the neighbour searches (one center per
-// wave), nothing is read back from global memory.  Shape limits: kNN pf edges, pockets of at most 512 atoms (SB_MAXA / NT
+// half wave), nothing is read back from global memory.  Shape limits: kNN pf edges, pockets of at most 512 atoms (SB_MAXA / NT
 // atoms per thread), at most PF_MAXF centers.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -21,14 +21,26 @@
 #ifndef SB_STAMP
 #define SB_STAMP(k)
 #endif
+// diagnostic builds (-DSB_CUT=k): the body returns at phase k (timing only: the step's results are then incomplete)
+#ifdef SB_CUT
+#define SB_PHASE(k) do { SB_STAMP(k); if ((k) == SB_CUT) __builtin_amdgcn_endpgm(); } while (0)
+#else
+#define SB_PHASE(k) SB_STAMP(k)
+#endif
 
 namespace pfsb {
 
 constexpr int SB_MAXA = 512;                    // atoms per pocket this path handles
+constexpr int SB_MAXNF = 16;                    // pharmacophore feature count this path handles (pharm_nf)
 
+// (dx*dx + dy*dy) + dz*dz with one rounding per operation, like oracle/pf_oracle.py:_d2 -- the pragma matters: hipcc's
+// __fmul_rn / __fadd_rn are plain * and +, which the device compiler contracts into v_fma_f32 by default (one rounding less:
+// a squared distance one ulp off the oracle's can flip a radius test or a kNN tie)
 __device__ __forceinline__ float sqdist_rn(const float4 a, const float4 b) {
-    const float dx = __fsub_rn(a.x, b.x), dy = __fsub_rn(a.y, b.y), dz = __fsub_rn(a.z, b.z);
-    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+#pragma clang fp contract(off)
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    return (xx + yy) + zz;
 }
 __device__ __forceinline__ unsigned long long dkey(const float d2, const int idx) {
     return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)idx;
@@ -54,6 +66,78 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
     const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(k >> 32), 63);
     return ((unsigned long long)hi << 32) | lo;
 }
+// kNN of one center per HALF wave (lanes 0..31 / 32..63): NC candidates per lane -- atom c = l32 + 32 i, its squared distance
+// as the bit pattern of a non-negative float (monotone as an unsigned integer; 0xffffffff: no atom) -- and k rounds of
+//   lane minimum (ascending i: the smaller atom index wins a tie), half-wave minimum of (distance, atom) in lexicographic
+//   order on the DPP network (row_shr 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3:
+//   lanes 31 / 63 hold the two halves' minima), removal of the winner from its lane's list.
+// The order of the k neighbours is (d^2, index) ascending -- what torch_cluster.knn returns (oracle/pf_oracle.py:knn).  All
+// 32-bit operations: the 64-bit keys of wave_min_u64 cost 6.8 us per graph here (branches around every candidate, 64-bit
+// compares), this form ~1 us.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_lexmin(unsigned int& bd, int& bc) {
+    const unsigned int od = (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)bd, CTRL, ROW_MASK, 0xf, false);
+    const int oc = __builtin_amdgcn_update_dpp(0x7fffffff, bc, CTRL, ROW_MASK, 0xf, false);
+    const bool take = od < bd || (od == bd && oc < bc);
+    bd = take ? od : bd;
+    bc = take ? oc : bc;
+}
+// returns, in lane l32 = r < kk of each half, the r-th nearest atom of that half's center (kk <= PF_MAXK <= 32)
+template <int NC>
+__device__ __forceinline__ int knn_halfwave(const float4* px, const float4 q, const int Np, const int kk, const int lane) {
+    const int hw = lane >> 5, l32 = lane & 31;
+    int mine = 0;
+    unsigned int d[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = l32 + 32 * i;                   // (px holds SB_MAXA rows: the read is in range whatever Np)
+        const float d2 = sqdist_rn(px[c], q);
+        d[i] = c < Np ? __float_as_uint(d2) : 0xffffffffu;
+    }
+    for (int r = 0; r < kk; ++r) {
+        unsigned int bd = 0xffffffffu;
+        int bc = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const bool take = d[i] < bd;
+            bd = take ? d[i] : bd;
+            bc = take ? l32 + 32 * i : bc;
+        }
+        dpp_lexmin<0x111, 0xf>(bd, bc);
+        dpp_lexmin<0x112, 0xf>(bd, bc);
+        dpp_lexmin<0x114, 0xf>(bd, bc);
+        dpp_lexmin<0x118, 0xf>(bd, bc);
+        dpp_lexmin<0x142, 0xa>(bd, bc);
+        const int w0 = __builtin_amdgcn_readlane(bc, 31), w1 = __builtin_amdgcn_readlane(bc, 63);
+        const int wc = hw ? w1 : w0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) d[i] = (wc == l32 + 32 * i) ? 0xffffffffu : d[i];
+        mine = l32 == r ? wc : mine;
+    }
+    return mine;
+}
+
+// x[l] + x[l ^ 32] + ... in the pairing order of the xor butterfly `for (o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o)` (what
+// step_update_body sums with: same bits), on the register network instead of six LDS-crossbar round trips: lane-half and
+// row swaps (v_permlane32_swap / v_permlane16_swap; asm: the compiler's builtins mis-assign their second result), row_ror:8,
+// one ds_swizzle for the xor-4 step, two quad_perm steps
+__device__ __forceinline__ float wave_xor_sum(float v) {
+    {
+        unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    }
+    {
+        unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    }
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));      // row_ror:8 = lane ^ 8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x101f));                          // lane ^ 4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));       // quad_perm [2,3,0,1] = lane ^ 2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));       // quad_perm [1,0,3,2] = lane ^ 1
+    return v;
+}
 // inclusive wave scan (sum) of a 32-bit value on the DPP network, same pattern
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned int dpp_add_u32(const unsigned int v) {
@@ -76,13 +160,14 @@ __device__ __forceinline__ void sb_lds_barrier() { asm volatile("s_waitcnt lgkmc
 struct __attribute__((aligned(16))) StepBuildLds {
     float4 fx[PF_MAXF];                         // updated pharm coordinates (COM removed)
     float4 px[SB_MAXA];                         // updated protein coordinates
-    float red[8][3];
+    float com[4];
     unsigned long long scratch[8];
     unsigned int refm[SB_MAXA][2];              // per atom: bit fl set <=> center fl has the atom among its k neighbours
-    // active atoms in list order: first slot of their pp in-edges in the "pa" region, node id, static in-edge start;
-    // a_src: the first 16 static sources of EVERY atom (prefetched, indexed by atom) -- the copy into the region is
-    // then done by ALL threads, one output slot each, with coalesced stores
-    int a_d0[SB_MAXA], a_node[SB_MAXA], a_pst[SB_MAXA];
+    // the compact copy of the active atoms' pp in-edges ("pa" region) is written one slot per thread: an active atom names
+    // itself the owner of its slots, a slot's thread looks its atom up and takes the source from a_src -- the first 16
+    // static sources of EVERY atom (prefetched, indexed by atom)
+    unsigned short owner[SB_MAXA * 16];         // [slot of the region] -> atom (local index)
+    int a_d0[SB_MAXA], a_pst[SB_MAXA];          // per atom: first slot of its in-edges in the region, static in-edge start
     __attribute__((aligned(16))) int a_src[SB_MAXA][16];
 };
 
@@ -98,87 +183,155 @@ struct EpsLds {                                  // [PF_MAXF][4] / [PF_MAXF][16]
     __device__ __forceinline__ float h(const int fl, const int k) const { return eh[fl * 16 + k]; }
 };
 
-// NT threads (a multiple of 64, >= 256; SB_MAXA / NT atoms per thread), every thread of the workgroup calls it.  The caller
-// has made the eps source readable by all threads (a barrier behind the LDS writes of EpsLds).
-template <int NT, class Eps>
-__device__ __forceinline__ void step_build_fast_body(const int g, const int* __restrict__ a_prot_ptr, const int* __restrict__ a_pharm_ptr,
-                                                     const int* __restrict__ a_reg, const int a_B, const int a_Np_tot,
-                                                     const StepParams& sp, const BuildParams& p, const Eps& eps, StepBuildLds& L) {
-    constexpr int NW = NT / 64, APT = SB_MAXA / NT;
-    static_assert(NT % 64 == 0 && NW >= 4 && NW <= 8 && APT * NT == SB_MAXA, "256 or 512 threads");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    SB_STAMP(0);
-    // ---- (A) pointers and regions
-    const int p0 = a_prot_ptr[g], p1 = a_prot_ptr[g + 1];
-    const int f0 = a_pharm_ptr[g], f1 = a_pharm_ptr[g + 1];
-    const int Np = p1 - p0, Nf = f1 - f0;
-    const int GF = a_Np_tot + f0;
-    const int reg_ff = a_reg[0 * a_B + g], reg_pf = a_reg[1 * a_B + g], reg_fp = a_reg[2 * a_B + g], reg_pa = a_reg[3 * a_B + g];
-    const int reg_act = p.act_ids ? p.reg_act[g] : 0;
-    int* in_start0 = p.in_start;          int* in_cnt0 = p.in_cnt;
-    int* in_start1 = p.in_start + p.N;    int* in_cnt1 = p.in_cnt + p.N;
-    int* in_start2 = p.in_start + 2 * p.N; int* in_cnt2 = p.in_cnt + 2 * p.N;
-    // ---- (B) every input row of this thread
-    const bool isf = tid < Nf;
-    bool isp[APT];
-    float4 xf = make_float4(0.f, 0.f, 0.f, 0.f), xp[APT];
-    float ex[3] = {0.f, 0.f, 0.f}, nzx[3] = {0.f, 0.f, 0.f};
-    if (isf) {
-        xf = sp.xn[GF + tid];
+// What the update + build of graph g reads that does NOT depend on the noise prediction: trips (A), (B) and (C).  A kernel that
+// computes eps itself (k_n16_tail) issues these loads in front of / underneath its chain, level by level with its own gathers.
+template <int NT>
+struct SbPre {
+    static constexpr int APT = SB_MAXA / NT;
+    int p0, Np, f0, Nf, GF, reg_ff, reg_pf, reg_fp, reg_pa, reg_act;
+    bool isf, isp[APT];
+    float4 xf, xp[APT];
+    float nzx[3];
+    float hv[SB_MAXNF], nzh[SB_MAXNF];              // the center's features and their noise (threads tid < Nf; nf <= SB_MAXNF)
+    int pst[APT], pdeg[APT], psrc[APT][16];
+};
+// (A) the graph's pointers and regions (scalar loads)
+template <int NT>
+__device__ __forceinline__ void sb_load_a(SbPre<NT>& q, const int g, const int* __restrict__ a_prot_ptr, const int* __restrict__ a_pharm_ptr,
+                                          const int* __restrict__ a_reg, const int a_B, const int a_Np_tot, const BuildParams& p) {
+    q.p0 = a_prot_ptr[g]; q.Np = a_prot_ptr[g + 1] - q.p0;
+    q.f0 = a_pharm_ptr[g]; q.Nf = a_pharm_ptr[g + 1] - q.f0;
+    q.GF = a_Np_tot + q.f0;
+    q.reg_ff = a_reg[0 * a_B + g]; q.reg_pf = a_reg[1 * a_B + g]; q.reg_fp = a_reg[2 * a_B + g]; q.reg_pa = a_reg[3 * a_B + g];
+    q.reg_act = p.act_ids ? p.reg_act[g] : 0;
+}
+// (B) every input row of this thread.  Branch-free: rows beyond the graph's counts are read at clamped indices and discarded, so
+// the number of loads in flight is a compile-time constant -- a caller that issues these loads underneath its own (k_n16_tail)
+// keeps counted vmcnt waits instead of vmcnt(0).
+// (Every load of the body is issued here and in sb_load_c, none behind its first store: gfx9 counts loads and stores in ONE
+// in-order counter, so a load that follows stores of a run-time count can only be waited for with vmcnt(0) -- which also
+// waits for every store before it, ~2,000 cycles each time.)
+template <int NT>
+__device__ __forceinline__ void sb_load_b(SbPre<NT>& q, const int a_Np_tot, const StepParams& sp, const BuildParams& p) {
+    constexpr int APT = SbPre<NT>::APT;
+    const int tid = threadIdx.x;
+    const int* in_start1 = p.in_start + p.N; const int* in_cnt1 = p.in_cnt + p.N;
+    const int nf_tot = p.N - a_Np_tot;                                // centers of the batch (>= 1 wherever a kernel runs this)
+    q.isf = tid < q.Nf;
+    const int frow = max(min(q.f0 + tid, nf_tot - 1), 0);            // clamped center row
+    {
+        const float4 x = sp.xn[a_Np_tot + frow];
+        q.xf = q.isf ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        pf_gcf nz = (pf_gcf)sp.noise + (size_t)frow * (3 + sp.nf);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { ex[c] = eps.x(tid, c); nzx[c] = sp.noise[(size_t)(f0 + tid) * (3 + sp.nf) + c]; }
+        for (int c = 0; c < 3; ++c) { const float v = nz[c]; q.nzx[c] = q.isf ? v : 0.f; }
+#pragma unroll
+        for (int k = 0; k < SB_MAXNF; ++k) {
+            const int kc = min(k, sp.nf - 1);
+            const float hvv = ((pf_gcf)sp.pharm_h)[(size_t)frow * sp.nf + kc], nzv = nz[3 + kc];
+            const bool on = q.isf && k < sp.nf;
+            q.hv[k] = on ? hvv : 0.f;
+            q.nzh[k] = on ? nzv : 0.f;
+        }
     }
-    int pst[APT], pdeg[APT];
+    const bool stat = p.act_ids && !p.pa_static;                      // kernel-uniform
 #pragma unroll
     for (int a = 0; a < APT; ++a) {
         const int c = APT * tid + a;
-        isp[a] = c < Np;
-        xp[a] = make_float4(0.f, 0.f, 0.f, 0.f);
-        pst[a] = 0; pdeg[a] = 0;
-        if (isp[a]) {
-            xp[a] = sp.xn[p0 + c];
-            if (p.act_ids && !p.pa_static) { pst[a] = in_start1[p0 + c]; pdeg[a] = in_cnt1[p0 + c]; }
+        q.isp[a] = c < q.Np;
+        const int arow = max(min(q.p0 + c, a_Np_tot - 1), 0);
+        const float4 x = sp.xn[arow];
+        q.xp[a] = q.isp[a] ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        q.pst[a] = 0; q.pdeg[a] = 0;
+        if (stat) {
+            const int s0 = in_start1[arow], d0 = in_cnt1[arow];
+            q.pst[a] = q.isp[a] ? s0 : 0;
+            q.pdeg[a] = q.isp[a] ? d0 : 0;
         }
     }
-    // feature update of the pharm nodes (independent of everything else): load, update, store
+}
+// (C) static pp sources of this thread's atoms (used only if an atom turns out to be active); branch-free like (B)
+template <int NT>
+__device__ __forceinline__ void sb_load_c(SbPre<NT>& q, const BuildParams& p) {
+    const bool stat = p.act_ids && !p.pa_static;                      // kernel-uniform
+#pragma unroll
+    for (int a = 0; a < SbPre<NT>::APT; ++a)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int v = 0;
+            if (stat) v = ((const int PF_AS1*)p.esrc)[q.pst[a] + min(k, max(q.pdeg[a] - 1, 0))];     // (an atom that is not there: slot 0)
+            q.psrc[a][k] = q.isp[a] ? v : 0;
+        }
+}
+
+// NT threads (a multiple of 64, >= 256; SB_MAXA / NT atoms per thread), every thread of the workgroup calls it.
+// ex / eh: eps_x [3] and eps_h [nf] of center tid (threads tid < Nf), read by the caller from wherever the head left them.
+// Five LDS-only barriers: COM known | shifted coordinates in LDS | neighbour masks complete | scan totals | slot owners.
+template <int NT>
+__device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[3], const float (&eh)[SB_MAXNF], const int g,
+                                          const StepParams& sp, const BuildParams& p, StepBuildLds& L) {
+    constexpr int NW = NT / 64, APT = SB_MAXA / NT;
+    static_assert(NT % 64 == 0 && NW >= 4 && NW <= 8 && APT * NT == SB_MAXA, "256 or 512 threads");
+    static_assert(PF_MAXF <= 64, "the centers of a graph are the first lanes of wave 0");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p0 = q.p0, Np = q.Np, f0 = q.f0, Nf = q.Nf, GF = q.GF;
+    const int reg_ff = q.reg_ff, reg_pf = q.reg_pf, reg_fp = q.reg_fp, reg_pa = q.reg_pa, reg_act = q.reg_act;
+    int* in_start0 = p.in_start;          int* in_cnt0 = p.in_cnt;
+    int* in_start1 = p.in_start + p.N;    int* in_cnt1 = p.in_cnt + p.N;
+    int* in_start2 = p.in_start + 2 * p.N; int* in_cnt2 = p.in_cnt + 2 * p.N;
+    const bool isf = q.isf;
+    bool isp[APT];
+    float4 xp[APT];
+    int pst[APT], pdeg[APT];
+#pragma unroll
+    for (int a = 0; a < APT; ++a) { isp[a] = q.isp[a]; xp[a] = q.xp[a]; pst[a] = q.pst[a]; pdeg[a] = q.pdeg[a]; }
+    if (p.act_ids && !p.pa_static) {                   // kernel-uniform
+        // the prefetched pp sources go to LDS first, in front of every store (see sb_load_b); their reader is the copy of the
+        // active atoms' in-edges at the very end
+#pragma unroll
+        for (int a = 0; a < APT; ++a) {
+            int4* st = reinterpret_cast<int4*>(&L.a_src[APT * tid + a][0]);
+            st[0] = make_int4(q.psrc[a][0], q.psrc[a][1], q.psrc[a][2], q.psrc[a][3]);
+            st[1] = make_int4(q.psrc[a][4], q.psrc[a][5], q.psrc[a][6], q.psrc[a][7]);
+            st[2] = make_int4(q.psrc[a][8], q.psrc[a][9], q.psrc[a][10], q.psrc[a][11]);
+            st[3] = make_int4(q.psrc[a][12], q.psrc[a][13], q.psrc[a][14], q.psrc[a][15]);
+        }
+    }
+    // ---- feature update of the pharm nodes (pharmacodiff.py:414-420; independent of everything else, inputs in registers)
     if (isf) {
-        for (int k = 0; k < sp.nf; ++k) {
-            const size_t o = (size_t)(f0 + tid) * sp.nf + k;
-            const float hv = sp.pharm_h[o], e = eps.h(tid, k);
-            const float mu = sp.ep_feat ? (sp.ep_zt * hv + sp.ep_pred * e) : (hv / sp.a_ts - sp.var * e);
-            sp.pharm_h[o] = mu + sp.sigma * sp.noise[(size_t)(f0 + tid) * (3 + sp.nf) + 3 + k];
+#pragma unroll
+        for (int k = 0; k < SB_MAXNF; ++k) {
+            if (k < sp.nf) {
+                const float hv = q.hv[k], e = eh[k];
+                const float mu = sp.ep_feat ? (sp.ep_zt * hv + sp.ep_pred * e) : (hv / sp.a_ts - sp.var * e);
+                sp.pharm_h[(size_t)(f0 + tid) * sp.nf + k] = mu + sp.sigma * q.nzh[k];
+            }
         }
     }
-    // ---- (C) static pp sources of this thread's atoms (used only if an atom turns out to be active)
-    int psrc[APT][16];
-#pragma unroll
-    for (int a = 0; a < APT; ++a)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) psrc[a][k] = (isp[a] && p.act_ids && !p.pa_static) ? p.esrc[pst[a] + min(k, max(pdeg[a] - 1, 0))] : 0;
-    // ---- coordinate update (pharmacodiff.py:397-426) and COM removal of pharm AND prot coordinates (:429)
+    // ---- coordinate update (pharmacodiff.py:397-426) and COM removal of pharm AND prot coordinates (:429).  The centers are
+    // threads 0 .. Nf - 1 of wave 0: the per-graph mean is that wave's butterfly sum -- the summation order of step_update_body
+    // (its other three wave sums are sums of zeros; they are added all the same: -0 + 0 = +0)
     float m[3] = {0.f, 0.f, 0.f};
     if (isf) {
-        const float xi[3] = {xf.x, xf.y, xf.z};
+        const float xi[3] = {q.xf.x, q.xf.y, q.xf.z};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float mu = sp.ep_coord ? (sp.ep_zt * xi[c] + sp.ep_pred * ex[c]) : (xi[c] / sp.a_ts - sp.var * ex[c]);
-            m[c] = mu + sp.sigma * nzx[c];
+            m[c] = mu + sp.sigma * q.nzx[c];
         }
     }
-    {   // per-graph mean in the summation order of step_update_body (thread-strided partial sums, xor butterfly, the first four waves)
-        float sx = m[0], sy = m[1], sz = m[2];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
-        if (lane == 0) { L.red[wave][0] = sx; L.red[wave][1] = sy; L.red[wave][2] = sz; }
-    }
-    sb_lds_barrier();
-    SB_STAMP(8);
-    float com[3];
-    {
+    if (wave == 0) {
         const float n = (float)max(Nf, 1);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) com[c] = Nf > 0 ? (((L.red[0][c] + L.red[1][c]) + (L.red[2][c] + L.red[3][c])) / n) : 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float r0 = wave_xor_sum(m[c]);
+            const float z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0));      // (an opaque zero: the additions stay)
+            if (lane == 0) L.com[c] = Nf > 0 ? (((r0 + z) + (z + z)) / n) : 0.f;
+        }
     }
+    sb_lds_barrier();
+    SB_PHASE(8);
+    const float com[3] = {L.com[0], L.com[1], L.com[2]};
     if (isf) {
         const float4 v = make_float4(m[0] - com[0], m[1] - com[1], m[2] - com[2], 0.f);
         L.fx[tid] = v;
@@ -213,7 +366,7 @@ __device__ __forceinline__ void step_build_fast_body(const int g, const int* __r
             if (p.ff_k > 0) {
                 unsigned long long prev = 0ull;
                 bool first = true;
-                for (int q = 0; q < kff; ++q) {
+                for (int qq = 0; qq < kff; ++qq) {
                     unsigned long long best = ~0ull;
                     for (int jn = 0; jn < Nf; ++jn) {
                         if (jn == lane) continue;
@@ -231,49 +384,25 @@ __device__ __forceinline__ void step_build_fast_body(const int g, const int* __r
             }
         }
     }
-    SB_STAMP(9);
-    // ---- pf (prot -> pharm): kNN, one center per wave, candidates (d^2, index) from LDS
+    SB_PHASE(9);
+    // ---- pf (prot -> pharm): kNN, one center per HALF wave (knn_halfwave), candidates from LDS; lane r of a half ends with
+    // the r-th neighbour of its center: one coalesced store per half
     const int kk = min(p.pf_k, Np);
-    for (int fl = wave; fl < Nf; fl += NW) {
-        const float4 q = L.fx[fl];
-        unsigned long long kc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = lane + 64 * i;
-            kc[i] = ~0ull;
-            if (64 * i < Np) kc[i] = c < Np ? dkey(sqdist_rn(L.px[c], q), c) : ~0ull;    // wave-uniform bound
+    const int hw = lane >> 5, l32 = lane & 31;
+    for (int fb = 2 * wave; fb < Nf; fb += 2 * NW) {
+        const int fl = fb + hw;                       // this half's center (fb + 1 may lie beyond the graph: that half searches
+        const float4 qc = L.fx[min(fl, Nf - 1)];      // the last center again and writes nothing)
+        const int pc = Np <= 256 ? knn_halfwave<8>(L.px, qc, Np, kk, lane) : knn_halfwave<16>(L.px, qc, Np, kk, lane);   // wave-uniform
+        if (l32 < kk && fl < Nf) {
+            atomicOr(&L.refm[pc][fl >> 5], 1u << (fl & 31));
+            p.esrc[reg_pf + fl * kk + l32] = p0 + pc;
+            p.edst[reg_pf + fl * kk + l32] = GF + fl;
         }
-        unsigned long long prev = 0ull;
-        for (int r = 0; r < kk; ++r) {
-            unsigned long long best = ~0ull;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (64 * i < Np && (r == 0 || kc[i] > prev) && kc[i] < best) best = kc[i];
-            best = wave_min_u64(best);
-            prev = best;
-            if (lane == 0) {
-                const int pc = (int)(best & 0xffffffffu);
-                atomicOr(&L.refm[pc][fl >> 5], 1u << (fl & 31));
-                p.esrc[reg_pf + fl * kk + r] = p0 + pc;
-                p.edst[reg_pf + fl * kk + r] = GF + fl;
-            }
-        }
-        if (lane == 0) { in_start1[GF + fl] = reg_pf + fl * kk; in_cnt1[GF + fl] = kk; }
+        if (l32 == 0 && fl < Nf) { in_start1[GF + fl] = reg_pf + fl * kk; in_cnt1[GF + fl] = kk; }
     }
     if (tid == 0) { p.dyn_cnt[1 * p.B + g] = Nf * kk; p.dyn_cnt[2 * p.B + g] = Nf * kk; }
-    {   // the prefetched pp sources go to LDS here, unconditionally: left to their only use (active atoms, below) the
-        // compiler sinks the loads into that branch and the round trip (C) is paid there, late and exposed
-#pragma unroll
-        for (int a = 0; a < APT; ++a) {
-            int4* st = reinterpret_cast<int4*>(&L.a_src[APT * tid + a][0]);
-            st[0] = make_int4(psrc[a][0], psrc[a][1], psrc[a][2], psrc[a][3]);
-            st[1] = make_int4(psrc[a][4], psrc[a][5], psrc[a][6], psrc[a][7]);
-            st[2] = make_int4(psrc[a][8], psrc[a][9], psrc[a][10], psrc[a][11]);
-            st[3] = make_int4(psrc[a][12], psrc[a][13], psrc[a][14], psrc[a][15]);
-        }
-    }
     sb_lds_barrier();
-    SB_STAMP(10);
+    SB_PHASE(10);
     // ---- fp = pf reversed, destination-major over the atoms; active atoms and the compact copy of their pp in-edges
     {
         // the centers that reference an atom, ascending: the bits of its mask (set by the kNN waves above)
@@ -290,7 +419,7 @@ __device__ __forceinline__ void step_build_fast_body(const int g, const int* __r
             val[a] = (unsigned long long)my[a] | ((unsigned long long)act[a] << 16) | ((unsigned long long)deg[a] << 28);
             tval += val[a];
         }
-        SB_STAMP(12);                                 // references counted
+        SB_PHASE(12);                                 // references counted
         // block scan over the waves: the value packs three counters (bits 0-15 fp edges, 16-27 active atoms, 28-63 their pp
         // in-edges), scanned as two 32-bit halves (the low two cannot carry into each other at these sizes)
         const unsigned int lo = (unsigned int)(tval & 0xfffffffull), hi = (unsigned int)(tval >> 28);
@@ -305,7 +434,8 @@ __device__ __forceinline__ void step_build_fast_body(const int g, const int* __r
             all += t;
         }
         unsigned long long o = before + ((unsigned long long)slo | ((unsigned long long)shi << 28)) - tval;
-        SB_STAMP(13);                                 // offsets known
+        const bool pa_big = (all >> 28) > (unsigned long long)(SB_MAXA * 16);      // workgroup-uniform
+        SB_PHASE(13);                                 // offsets known
 #pragma unroll
         for (int a = 0; a < APT; ++a) {
             const int c = APT * tid + a;
@@ -319,35 +449,43 @@ __device__ __forceinline__ void step_build_fast_body(const int g, const int* __r
                     mm = m1[a];
                     while (mm) { const int fl = 32 + __ffs(mm) - 1; mm &= mm - 1; p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
                 }
-                if (act[a]) {
-                    const int j = (int)((o >> 16) & 0xfffu);
-                    p.act_ids[reg_act + j] = p0 + c;
-                    if (p.pa_static) p.need[p.rep_base[g] + c] = p.need_stamp;
-                    else {
-                        in_start2[p0 + c] = reg_pa + (int)(o >> 28);
-                        in_cnt2[p0 + c] = deg[a];
-                        L.a_d0[j] = (int)(o >> 28); L.a_node[j] = p0 + c; L.a_pst[j] = pst[a];
+            }
+            // an active atom: its place in the list and (unless the pocket's pp messages are shared) the slots of the "pa" region
+            // that receive the compact copy of its static pp in-edges
+            if (isp[a] && act[a]) {
+                const int j = (int)((o >> 16) & 0xfffu);
+                p.act_ids[reg_act + j] = p0 + c;
+                if (p.pa_static) p.need[p.rep_base[g] + c] = p.need_stamp;
+                else {
+                    const int d0 = (int)(o >> 28);
+                    in_start2[p0 + c] = reg_pa + d0;
+                    in_cnt2[p0 + c] = deg[a];
+                    L.a_d0[c] = d0; L.a_pst[c] = pst[a];
+                    if (!pa_big) {
+                        for (int k = 0; k < deg[a]; ++k) L.owner[d0 + k] = (unsigned short)c;
+                    } else {                          // more slots than the owner map holds (in-degrees far beyond 16): the atom's
+                        for (int k = 0; k < deg[a]; ++k) {      // own thread copies them
+                            p.esrc[reg_pa + d0 + k] = p.esrc[pst[a] + k];
+                            p.edst[reg_pa + d0 + k] = p0 + c;
+                            if (p.eorig) p.eorig[reg_pa + d0 + k] = pst[a] + k;
+                        }
                     }
                 }
             }
             o += val[a];
         }
-        SB_STAMP(14);                                 // fp edges / descriptors stored, active atoms staged
+        SB_PHASE(14);                                 // fp edges / descriptors stored, active atoms staged
         sb_lds_barrier();
-        SB_STAMP(15);
-        {   // the "pa" region: slot t belongs to the last active atom whose first slot is <= t (binary search in LDS)
-            const int n_pa = p.pa_static ? 0 : (int)(all >> 28), n_act = (int)((all >> 16) & 0xfffu);
+        SB_PHASE(15);
+        {   // the "pa" region, one slot per thread: coalesced stores
+            const int n_pa = (p.pa_static || pa_big) ? 0 : (int)(all >> 28);
             for (int t = tid; t < n_pa; t += NT) {
-                int lo2 = 0, hi2 = n_act - 1;
-                while (lo2 < hi2) {
-                    const int mid = (lo2 + hi2 + 1) >> 1;
-                    if (L.a_d0[mid] <= t) lo2 = mid; else hi2 = mid - 1;
-                }
-                const int k = t - L.a_d0[lo2];
-                const int src = k < 16 ? L.a_src[L.a_node[lo2] - p0][k] : p.esrc[L.a_pst[lo2] + k];
+                const int c = (int)L.owner[t];
+                const int k = t - L.a_d0[c], ps = L.a_pst[c];
+                const int src = k < 16 ? L.a_src[c][k] : p.esrc[ps + k];
                 p.esrc[reg_pa + t] = src;
-                p.edst[reg_pa + t] = L.a_node[lo2];
-                if (p.eorig) p.eorig[reg_pa + t] = L.a_pst[lo2] + k;
+                p.edst[reg_pa + t] = p0 + c;
+                if (p.eorig) p.eorig[reg_pa + t] = ps + k;
             }
         }
         if (tid == 0 && p.act_ids) {
@@ -360,7 +498,25 @@ __device__ __forceinline__ void step_build_fast_body(const int g, const int* __r
             p.gnorm[0 * p.B + g] = (float)(cpf + p.pp_cnt[g]) / (float)Np + 1.0f;
         }
     }
-    SB_STAMP(11);
+    SB_PHASE(11);
+}
+
+// the three trips and the rest in one piece (k_step_build_fast: eps comes from memory, nothing to overlap the loads with)
+template <int NT, class Eps>
+__device__ __forceinline__ void step_build_fast_body(const int g, const int* __restrict__ a_prot_ptr, const int* __restrict__ a_pharm_ptr,
+                                                     const int* __restrict__ a_reg, const int a_B, const int a_Np_tot,
+                                                     const StepParams& sp, const BuildParams& p, const Eps& eps, StepBuildLds& L) {
+    SB_STAMP(0);
+    SbPre<NT> q;
+    sb_load_a<NT>(q, g, a_prot_ptr, a_pharm_ptr, a_reg, a_B, a_Np_tot, p);
+    sb_load_b<NT>(q, a_Np_tot, sp, p);
+    float ex[3] = {0.f, 0.f, 0.f}, eh[SB_MAXNF];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ex[c] = q.isf ? eps.x((int)threadIdx.x, c) : 0.f;               // with trip (B)
+#pragma unroll
+    for (int k = 0; k < SB_MAXNF; ++k) eh[k] = (q.isf && k < sp.nf) ? eps.h((int)threadIdx.x, k) : 0.f;
+    sb_load_c<NT>(q, p);
+    sb_finish<NT>(q, ex, eh, g, sp, p, L);
 }
 
 }  // namespace pfsb

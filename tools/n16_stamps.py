@@ -28,6 +28,11 @@ carr = eng.coef_array(coef, list(range(39, -1, -1)))
 noise = torch.randn(41, B * 6, 9, device=dev)
 lib = eng.lib
 lib.pfk_n16_set_stamp_buffer.argtypes = [ctypes.c_void_p, ctypes.c_int]
+# KID: record one kernel of the step only (0 k_n16_edge<true>, 1 <false>, 2 k_n16_fused, 3 k_n16_tail; default: all, the last writer wins)
+KID = int(os.environ.get("KID", "-1"))
+if hasattr(lib, "pfk_n16_set_stamp_kernel"):
+    lib.pfk_n16_set_stamp_kernel.argtypes = [ctypes.c_int]
+    lib.pfk_n16_set_stamp_kernel(KID)
 eng.sample_begin(noise[0])
 for i in range(30):
     eng.denoise_step(carr[i], noise[i + 1])
@@ -43,10 +48,14 @@ for off in [int(x) for x in os.environ.get("OFFS", "0").split(",")]:
     print(f"== workgroups from {off}: deltas between consecutive stamps of wave 0 (and the wave's total)")
     shown = 0
     for b in range(64):
-        r = [x for x in st[b][0] if x]
+        r = [x for x in st[b][0][:40] if x]
         if len(r) < 3:
             continue
         print(f"  wg {off + b:4d}: total {r[-1] - r[0]:6d} | " + " ".join(str(r[i + 1] - r[i]) for i in range(len(r) - 1)))
+        sb = [(k, x) for k, x in enumerate(st[b][0][40:56]) if x]          # the tail launch's update + build phases (pf_stepbuild.h)
+        if sb:
+            order = sorted(sb, key=lambda kv: kv[1])
+            print(f"           build: head done -> phase " + " ".join(f"{k}:+{x - r[-1]}" for k, x in order) + f" | kernel entry -> last {order[-1][1] - r[0]}")
         shown += 1
-        if shown >= 5:
+        if shown >= int(os.environ.get("SHOW", "5")):
             break
