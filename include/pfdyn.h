@@ -277,8 +277,9 @@ int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges /
  * items on the four waves of a workgroup, pf_n16.hip: k_n16_edge; 17 = the fused launch k_n16_fused, whose items also
  * compute conv layer 0's node update of their source rows), 32 (one wave per 32-row tile: k_edge_msg) or 128 (four waves per
  * 32-row tile: k_edge_msg_coop / coop2).  layer == n_convs asks about the launch behind the last conv layer's edge messages:
- * 16 when the last call was the dynamics call of a pf_denoise_step whose node update + noise head + sampler update + edge
- * build ran as the tail launch (pf_n16.hip: k_n16_tail, one workgroup per graph), else 0 */
+ * when the last call was the dynamics call of a pf_denoise_step whose node update + noise head + sampler update + edge build
+ * ran as ONE tail launch (one workgroup per graph): 4 (pf_rg.hip: k_rg_tail, two two-wave items of four centers) or 16
+ * (pf_n16.hip: k_n16_tail, PFDYN_TAIL_FORM=n16); else 0 */
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave);
 /* static hoist of conv layer 0's protein-protein messages in the last dynamics call: *rows_per_wave = 0 (not used: training,
  * tile kernels, protein features that are not element one-hots, PFDYN_NO_L0_HOIST=1), 4 / 8 rows per hoisted wave (row-group

@@ -308,6 +308,7 @@ struct FusedParams {
     const int* ptype;
     float* h_out; float* v_out;                      // conv layer 1's input state: written for the centers (the node + head launch reads it)
     const int* pharm_ptr; int Np, n_edge_items;      // store items: graph g's centers; items [0, n_edge_items) are edge items
+    int xcd_split, nff_cap, npf_cap;                 // XCD-aware item assignment (k_n16_fused): capacities of the ff / pf regions in 16-slot groups
 };
 
 // n16 tail launch (pf_n16.hip: k_n16_tail; pf_denoise_step only): ONE workgroup per graph runs the last conv layer's node

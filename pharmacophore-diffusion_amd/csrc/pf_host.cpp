@@ -38,6 +38,7 @@ void pfk_n16_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, hipS
 void pfk_n16_unit(const UnitParams* p, hipStream_t s);
 void pfk_n16_fused(const EdgeParams* p, const FusedParams* f, const EncodeParams* enc, hipStream_t s);
 void pfk_n16_tail(const TailParams* t, const StepParams* sp, const BuildParams* bp, hipStream_t s);
+void pfk_rg_tail(const NodeParams* p, const HeadParams* hp, const StepParams* sp, const BuildParams* bp, hipStream_t s);
 void pfk_encode(const EncodeParams* p, hipStream_t s);
 void pfk_encode_build(const EncodeParams* e, const BuildParams* b, hipStream_t s);
 void pfk_encode_build_pre(const EncodeParams* e, const BuildParams* b, const PreParams* pp, hipStream_t s);
@@ -133,7 +134,7 @@ static void linspace_f32(float start, float end, int steps, float* out) {
 // Every threshold can be overridden from the environment (tests force every form onto the goldens; sweeps: tools/):
 //   PFDYN_N16 (bit 0: conv layers >= 1, bit 1: conv layer 0, bit 2: conv layer 0's node update fused into the last layer's edge
 //   launch when n_convs = 2, bit 3: the tail launch of a denoising step -- last node update + noise head + sampler update + edge
-//   build, one workgroup per graph; default 15), PFDYN_TAIL_GRAPHS_MAX, PFDYN_N16_ROWS_MAX (sets both n16 thresholds), PFDYN_N16_FUSE_ROWS_MAX, PFDYN_RG_ROWS_MAX,
+//   build, one workgroup per graph: off unless asked for; default 7), PFDYN_TAIL_GRAPHS_MAX, PFDYN_TAIL_FORM (rg | n16), PFDYN_N16_ROWS_MAX (sets both n16 thresholds), PFDYN_N16_FUSE_ROWS_MAX, PFDYN_RG_ROWS_MAX,
 //   PFDYN_RG2_ROWS_MIN (sets all four 8-row thresholds) / _NODE / _HOIST, PFDYN_RG2P_ROWS_MIN, PFDYN_L0_RGA / PFDYN_L0_RGP (rows-per-
 //   wave factor of the full-chain / hoisted items of a compact layer-0 launch), PFDYN_RG_SPLIT_MAX (all three) / _NODE / _HEAD,
 //   PFDYN_COOP_EDGE_MAX, PFDYN_COOP2_EDGE_MAX, PFDYN_COOP_NODE_MAX.  Forcing a row-group form switches the n16 form off
@@ -141,8 +142,17 @@ static void linspace_f32(float start, float end, int steps, float* out) {
 // ------------------------------------------------------------------------------------------------------------------
 struct LaunchPolicy {
     static constexpr int kCUs = 256, kSIMDs = 4 * kCUs;
-    int n16_mask = 15;                      // bit 3: the tail launch (node update of the last layer + noise head + sampler update + edge build in one launch)
+    // bit 3: the tail launch (node update of the last layer + noise head + sampler update + edge build in one launch, one workgroup per
+    // graph).  OFF by default: measured on config 2 it LOSES to the separate launches in both forms -- 30.7 us (row-group form: two
+    // two-wave items per compute unit stream 192 KB of weights per block through one CU's memory path) and 28.0 us (n16 form: 2.0 us
+    // per block on a 16-row tile that holds six centers) against 14.7 + 10.3 us (profiles/r04/tail_forms.txt)
+    int n16_mask = 7;
     int tail_graphs_max = 256;              // ... up to this many graphs (one four-wave workgroup per graph; it does not share a CU)
+    // k_n16_fused: ff / store items on XCDs 0..3, pf items on XCDs 4..7 -- an XCD's L2 fetches half of the launch's weights: 19.3 -> 18.5 us
+    // at config 2 (PFDYN_XCD_SPLIT=0: off).  The same idea on the conv-layer-0 launch (pa / pf items on five XCDs, ff / fp items on three)
+    // LOST 1.6 us: that launch is throughput-bound with two items per compute unit, and the split unbalances it (profiles/r04)
+    int xcd_split = 1;
+    int tail_form = 4;                      // 4: the row-group form (k_rg_tail: two two-wave items of four centers), 16: the n16 form (k_n16_tail)
     long n16_fuse_rows_max = 20000;         // the fused launch (bit 2): +2-3 % up to 32 graphs of 256 atoms, -4 % at 40 (its items carry five blocks: throughput-bound earlier)
     long n16_rows_max = 24000;              // measured at 256-atom pockets (575 slots per graph): +5 % at 16 graphs, +10 % at 32, -3..-5 % at 64, -15 % at 256
     int rg_rows_max = 1 << 30;
@@ -177,6 +187,8 @@ struct LaunchPolicy {
             if (getenv(v)) n16_mask = 0;
         geti("PFDYN_N16", n16_mask);
         geti("PFDYN_TAIL_GRAPHS_MAX", tail_graphs_max);
+        geti("PFDYN_XCD_SPLIT", xcd_split);
+        if (const char* e = getenv("PFDYN_TAIL_FORM")) tail_form = (e[0] == 'n' || atoi(e) == 16) ? 16 : 4;
         if (const char* e = getenv("PFDYN_N16_ROWS_MAX")) n16_rows_max = n16_fuse_rows_max = atol(e);
         if (const char* e = getenv("PFDYN_N16_FUSE_ROWS_MAX")) n16_fuse_rows_max = atol(e);
     }
@@ -282,7 +294,7 @@ struct pf_handle {
     std::vector<char> t_node_saved;         // ... by the last pf_train_forward
     std::vector<int> t_grp;                 // per conv layer: slots per message partial-row group of the last training forward
     bool sampling = false;
-    int max_np = 0;                         // largest pocket of the batch
+    int max_np = 0, max_nf = 0;             // largest pocket of the batch, most centers in a graph
     bool edges_built = false;               // the dynamic edges of the current coordinates exist (built by k_step_build)
     bool edges_share = false;               // ... in the pocket-sharing form (no pa copies)
     // row-group kernels (pf_rg.hip): quad streams of the message chains [layer][etype] and update chains [layer][ntype]
@@ -307,7 +319,7 @@ struct pf_handle {
     // tail launch (pf_n16.hip: k_n16_tail): [update chain of the centers in the last conv layer][noise head; its last GVP padded, with to_scalar_output]
     size_t n16_tail = 0, n16_tail_stride = 0;
     bool tail_done = false;                 // the last run_dynamics call of a denoising step also did the step's update + build
-    bool last_tail = false;                 // pf_debug_kernel_family(layer = n_convs)
+    int last_tail = 0;                      // pf_debug_kernel_family(layer = n_convs): 0 / 4 (k_rg_tail) / 16 (k_n16_tail)
     float *d_msg_s2 = nullptr, *d_msg_v2 = nullptr;   // the last conv layer's message rows when conv layer 0's are still being read (fused launch)
     std::vector<int> last_family;           // per conv layer: pf_debug_kernel_family
     int last_hoist = 0;                     // pf_debug_l0_hoist
@@ -948,7 +960,7 @@ static void n16_refresh(pf_handle* h, hipStream_t s) {
 static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s, const float* t_scalar = nullptr,
                         bool train = false, const StepParams* step = nullptr) {
     const pf_config& c = h->cfg;
-    h->tail_done = false; h->last_tail = false;
+    h->tail_done = false; h->last_tail = 0;
     if (!train) n16_refresh(h, s);
     EncodeParams ep{};
     ep.Np = h->Np; ep.Nf = h->Nf;
@@ -1102,6 +1114,8 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             fz.htab = l0_ptab + (size_t)3 * c.rec_nf * PF_S; fz.htab_gstride = l0_gstride; fz.ptype = h->d_ptype;
             fz.h_out = h->d_h[cur]; fz.v_out = h->d_v[cur];          // (cur was flipped behind conv layer 0: its output side)
             fz.pharm_ptr = h->d_pharm_ptr; fz.Np = h->Np; fz.n_edge_items = e.ngroups_sel;
+            for (int r = 0; r < e.nreg; ++r) (r < h->B ? fz.nff_cap : fz.npf_cap) += region_groups(r, 16);
+            fz.xcd_split = ((h->pol.xcd_split & 1) && 2 * h->B <= 64 && h->max_nf <= 16) ? 1 : 0;
             h->last_family[l] = 17;                      // pf_debug_kernel_family: 16-row items with conv layer 0's node update in front
             ProfScope ps(h, pf_handle::K_EDGE_LAST, s);
             pfk_n16_fused(&e, &fz, &ep, s);
@@ -1158,9 +1172,22 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             const int nsplit = (!train && rgn == 1 && n.ntiles * 8 <= (fuse ? h->pol.rg_split_max_head : h->pol.rg_split_max_node)) ? 1 : 0;
             // the tail launch: one workgroup per graph does the centers' node update, the head, the sampler update and the
             // edge build (the fast build's shape: kNN pf edges, pockets of at most 512 atoms)
-            const bool tail = fuse && step != nullptr && l > 0 && (h->pol.n16_mask & 8) && h->n16_tail != 0 && h->B <= h->pol.tail_graphs_max &&
+            const bool tail = fuse && step != nullptr && l > 0 && (h->pol.n16_mask & 8) && h->B <= h->pol.tail_graphs_max &&
                               enc_fly && c.pf_k > 0 && h->max_np <= 512 && c.pharm_nf <= 16 && h->step_build_fast;
-            if (tail) {
+            const bool tail16 = tail && h->pol.tail_form == 16 && h->n16_tail != 0;
+            if (tail && !tail16) {                      // row-group form: the fused node + head item, two per workgroup
+                HeadParams hp{};
+                hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
+                hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
+                hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
+                hp.eps_h = eps_h; hp.eps_x = eps_x;
+                const bool share_next = (h->prune && c.n_convs == 2) && share_now(h);     // what the next denoising step's dynamics call will ask for
+                const BuildParams bpn = build_params(h, share_next);
+                { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_tail(&n, &hp, step, &bpn, s); }
+                build_done(h, share_next);
+                h->tail_done = true; h->last_tail = 4;
+                head_done = true;
+            } else if (tail16) {
                 TailParams tp{};
                 tp.in_start = n.in_start; tp.in_cnt = n.in_cnt; tp.N = n.N;
                 tp.msg_s = n.msg_s; tp.msg_v = n.msg_v; tp.zero_row = n.zero_row; tp.grp = n.grp;
@@ -1174,7 +1201,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 const BuildParams bpn = build_params(h, share_next);
                 { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_n16_tail(&tp, step, &bpn, s); }
                 build_done(h, share_next);
-                h->tail_done = true; h->last_tail = true;
+                h->tail_done = true; h->last_tail = 16;
                 head_done = true;
             } else if (fuse) {
                 HeadParams hp{};
@@ -1770,9 +1797,10 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     const int Np = prot_ptr[B], Nf = pharm_ptr[B], N = Np + Nf;
     // ---- host-side tables
     std::vector<int> gid(N);
-    int max_np = 0;
+    int max_np = 0, max_nf = 0;
     for (int g = 0; g < B; ++g) {
         max_np = std::max(max_np, prot_ptr[g + 1] - prot_ptr[g]);
+        max_nf = std::max(max_nf, pharm_ptr[g + 1] - pharm_ptr[g]);
         for (int i = prot_ptr[g]; i < prot_ptr[g + 1]; ++i) gid[i] = g;
         for (int i = pharm_ptr[g]; i < pharm_ptr[g + 1]; ++i) gid[Np + i] = g;
     }
@@ -1812,7 +1840,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     h->B = B; h->Np = Np; h->Nf = Nf; h->N = N; h->Epp = n_pp;
     h->h_prot_ptr.assign(prot_ptr, prot_ptr + B + 1);
     h->h_pharm_ptr.assign(pharm_ptr, pharm_ptr + B + 1);
-    h->max_np = max_np;
+    h->max_np = max_np; h->max_nf = max_nf;
     if (!deg_is_prefix)
         for (int i = 0; i < Np; ++i) deg[i + 1] += deg[i];
     std::vector<int> pp_cnt(B, 0);
@@ -2929,7 +2957,7 @@ int pf_debug_dropout_mask(pf_handle* h, int32_t layer, int32_t which, float drop
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave) {
     if (!h || !rows_per_wave) return PF_ERR_ARG;
     if (layer == (int)h->last_family.size() && layer > 0) {      // one past the last conv layer: 16 when the last call's head ran in the tail launch
-        *rows_per_wave = h->last_tail ? 16 : 0;
+        *rows_per_wave = h->last_tail;
         return PF_OK;
     }
     if (layer < 0 || layer >= (int)h->last_family.size()) PF_FAIL(h, PF_ERR_STATE, "pf_debug_kernel_family: no dynamics call yet, or bad layer");

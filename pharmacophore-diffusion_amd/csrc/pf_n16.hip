@@ -826,10 +826,8 @@ __global__ __launch_bounds__(256) void k_n16_fused(const int* __restrict__ a_dyn
     int sk = 2 << 8;
     N16_STAMP(sk, lane, wq);                              // kernel entry
     float XS[32], VB[4];
-    if ((int)blockIdx.x >= f.n_edge_items) {
-        // ---- store item: the centers [16 part, 16 part + 16) of graph gq
-        const int it = (int)blockIdx.x - f.n_edge_items;
-        const int gq = it / (PF_MAXF / 16), part = it % (PF_MAXF / 16);
+    // ---- store item: the centers [16 part, 16 part + 16) of graph gq
+    auto store_item = [&](const int gq, const int part) {
         const int f0 = f.pharm_ptr[gq], nf = f.pharm_ptr[gq + 1] - f0;
         const int nv = __builtin_amdgcn_readfirstlane(min(16, nf - 16 * part));
         if (nv <= 0) return;                             // workgroup-uniform
@@ -849,10 +847,49 @@ __global__ __launch_bounds__(256) void k_n16_fused(const int* __restrict__ a_dyn
 #pragma unroll
             for (int r = 0; r < 4; ++r) vp[3 * r] = VB[r];
         }
+    };
+    int e0, nv, et;
+    if (f.xcd_split) {
+        // XCD-aware assignment (workgroup b runs on XCD b % 8): ff edge items and the store items -- the centers' side: they stream
+        // the same update chain -- on XCDs 0..3, pf edge items on XCDs 4..7, so that an XCD's L2 fetches half of the launch's
+        // weights.  One scan pass over the 2 B regions (the host sets xcd_split only when they fit one pass and every graph has
+        // at most 16 centers).
+        const int b = (int)blockIdx.x, x = b & 7, kq = b >> 3;
+        const int r = min(lane, a_nreg - 1);
+        const int c = lane < a_nreg ? a_dyn_cnt[r] : 0;
+        const int rs0 = a_reg[r];
+        const int ng = (c + 15) >> 4;
+        int incl = ng;
+        incl += dpp_i<0x111>(incl); incl += dpp_i<0x112>(incl); incl += dpp_i<0x114>(incl); incl += dpp_i<0x118>(incl);
+        incl += dpp_ir<0x142, 0xa>(incl); incl += dpp_ir<0x143, 0xc>(incl);
+        const int ff_total = __builtin_amdgcn_readlane(incl, a_regB - 1), all_total = __builtin_amdgcn_readlane(incl, 63);
+        int w;
+        if (x < 4) {
+            const int idx = 4 * kq + x;
+            if (idx >= ff_total) {
+                if (idx - ff_total < f.B) store_item(idx - ff_total, 0);
+                return;
+            }
+            w = idx;
+        } else {
+            w = ff_total + 4 * kq + (x - 4);
+            if (w >= all_total) return;
+        }
+        const unsigned long long m = __ballot(incl > w);
+        const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+        const int first = __builtin_amdgcn_readlane(incl - ng, l);
+        const int cnt = __builtin_amdgcn_readlane(c, l), start = __builtin_amdgcn_readlane(rs0, l);
+        et = l / a_regB;
+        const int loc = (w - first) << 4;
+        e0 = start + loc;
+        nv = __builtin_amdgcn_readfirstlane(min(16, cnt - loc));
+    } else {
+    if ((int)blockIdx.x >= f.n_edge_items) {
+        const int it = (int)blockIdx.x - f.n_edge_items;
+        store_item(it / (PF_MAXF / 16), it % (PF_MAXF / 16));
         return;
     }
     // ---- edge item: the w-th non-empty 16-slot group of the launch's regions (see k_n16_edge)
-    int e0, nv, et;
     {
         constexpr int NP = 16;
         const int w = (int)blockIdx.x;
@@ -892,6 +929,7 @@ __global__ __launch_bounds__(256) void k_n16_fused(const int* __restrict__ a_dyn
         const int loc = (w - first) << 4;
         e0 = start + loc;
         nv = __builtin_amdgcn_readfirstlane(min(16, cnt - loc));
+    }
     }
     N16_STAMP(sk, lane, wq);                              // item known
     N16_CUT_AT(FUSED_CUT, 1, (float)(e0 + nv), f.h_out);
@@ -1141,7 +1179,8 @@ int pfk_n16_set_trace_buffer(unsigned long long* dev) { return (int)hipMemcpyToS
 #endif
 // grid: the edge launch's capacity in 16-slot groups (f->n_edge_items) + PF_MAXF / 16 store items per graph
 void pfk_n16_fused(const EdgeParams* p, const FusedParams* f, const EncodeParams* enc, hipStream_t s) {
-    const int grid = f->n_edge_items + f->B * (PF_MAXF / 16);
+    int grid = f->n_edge_items + f->B * (PF_MAXF / 16);
+    if (f->xcd_split) grid = 8 * std::max((f->nff_cap + f->B + 3) / 4, (f->npf_cap + 3) / 4);
     if (grid <= 0) return;
     hipLaunchKernelGGL(k_n16_fused, dim3(grid), dim3(256), 0, s, p->dyn_cnt, p->reg, p->nreg, p->regB, *p, *f, *enc);
 }

@@ -140,10 +140,11 @@ def test_n16_default_policy_on_random_ragged_batches_vs_oracle(norm):
 
 @pytest.mark.parametrize("case", ["config1", "ragged", "knnff", "gnorm", "deep", "many_centers"])
 def test_tail_launch_steps_equal_separate_launches(case, monkeypatch):
-    """The tail launch (pf_n16.hip: k_n16_tail -- the centers' node update of the last conv layer, the noise head with
-    to_scalar_output packed into the padded last GVP, the p(z_s | z_t) update and the next call's edge build in ONE launch, one
-    workgroup per graph; pharmacodiff.py:395-429, dynamics_gvp.py:37-42,187-227) against the separate node + head and
-    update + build launches on the same states: three denoising steps each, state (x_t, h_t) within the single-call
+    """The tail launch -- the centers' node update of the last conv layer, the noise head, the p(z_s | z_t) update and the next
+    call's edge build in ONE launch, one workgroup per graph (pharmacodiff.py:395-429, dynamics_gvp.py:37-42,187-227) -- in
+    both forms (pf_rg.hip: k_rg_tail, two two-wave items of four centers, the default; pf_n16.hip: k_n16_tail, a 16-row item
+    with to_scalar_output packed into the padded last head GVP) against the separate node + head and update + build launches
+    on the same states: three denoising steps each, state (x_t, h_t) within the single-call
     tolerance after every step (steps 2 and 3 consume the edges the previous step's tail built) and the dynamic edge lists
     of the next call IDENTICAL (same order: both forms run the same build body).  Cases: config-1 shape, ragged pockets
     (some smaller than k) with 1-10 centers, kNN ff edges, per-graph normalisers, 3 conv layers / 2 head GVPs, and graphs
@@ -165,8 +166,9 @@ def test_tail_launch_steps_equal_separate_launches(case, monkeypatch):
     noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(17))
     coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
     states, edges = {}, {}
-    for form, mask in (("tail", "15"), ("separate", "7")):
+    for form, mask, tform, fam in (("tail_rg", "15", "rg", 4), ("tail_n16", "15", "n16", 16), ("separate", "7", "rg", 0)):
         monkeypatch.setenv("PFDYN_N16", mask)
+        monkeypatch.setenv("PFDYN_TAIL_FORM", tform)
         eng = engine_for(cfg, sd)
         set_batch(eng, batch)
         arr = eng.coef_array(coef, [40, 39, 38])
@@ -174,14 +176,18 @@ def test_tail_launch_steps_equal_separate_launches(case, monkeypatch):
         st, ed = [], []
         for i in range(n):
             eng.denoise_step(arr[i], noise[i + 1])
-            assert eng.kernel_family(cfg.n_convs) == (16 if form == "tail" else 0)
+            assert eng.kernel_family(cfg.n_convs) == fam
             x, h = eng.sample_frame()
             st.append((x.cpu(), h.cpu()))
             ed.append([tuple(t.clone() for t in eng.get_edges(et)) for et in range(3)])
         states[form], edges[form] = st, ed
     for i in range(n):
-        for a, b in zip(states["tail"][i], states["separate"][i]):
-            torch.testing.assert_close(a, b, rtol=2e-4 * (i + 1), atol=2e-4 * (i + 1))
-        for et in range(3):
-            (s1, d1), (s2, d2) = edges["tail"][i][et], edges["separate"][i][et]
-            assert torch.equal(s1, s2) and torch.equal(d1, d2), (case, i, et)
+        for form in ("tail_rg", "tail_n16"):
+            for a, b in zip(states[form][i], states["separate"][i]):
+                torch.testing.assert_close(a, b, rtol=2e-4 * (i + 1), atol=2e-4 * (i + 1))
+            for et in range(3):
+                (s1, d1), (s2, d2) = edges[form][i][et], edges["separate"][i][et]
+                assert torch.equal(s1, s2) and torch.equal(d1, d2), (case, form, i, et)
+        # the row-group tail runs the very code of the separate node + head launch: same bits
+        for a, b in zip(states["tail_rg"][i], states["separate"][i]):
+            assert torch.equal(a, b), (case, i)

@@ -68,18 +68,27 @@ def test_conv_layer_nonzero_vectors(name):
     close(hf, z["conv_out_h_pharm"]); close(vf, z["conv_out_v_pharm"])
 
 
-@pytest.mark.parametrize("tail", [True, False])
+TAIL_FORMS = {"rg": 4, "n16": 16, "off": 0}      # PFDYN_TAIL_FORM -> pf_debug_kernel_family(n_convs)
+
+
+def set_tail(monkeypatch, tail):
+    """The end of a denoising step: one tail launch (row-group form, the default, or the n16 form) or separate launches."""
+    if tail != "off":                  # (off = the default policy)
+        monkeypatch.setenv("PFDYN_N16", "15")
+        monkeypatch.setenv("PFDYN_TAIL_FORM", tail)
+
+
+@pytest.mark.parametrize("tail", list(TAIL_FORMS))
 @pytest.mark.parametrize("name,ep", [("traj_c1.npz", False), ("traj_ragged.npz", False), ("traj_c1_T500.npz", False),
                                      ("traj_endpoint.npz", True)])
 def test_trajectory_vs_golden(name, ep, tail, monkeypatch):
     """pf_sample against the reference's own trajectories (its noise draws injected): config 1 at T=50 and over the whole
     T=500 schedule -- all 501 frames; with seeded random weights the centers drift to |x| ~ 480 A by the end, so the
     relative part of the tolerance carries the late frames --, a ragged batch, and the endpoint parameterisation of
-    coordinates and features (pharmacodiff.py:413-420).  Both forms of a step's end: the tail launch (default: node
-    update + noise head + sampler update + edge build, one workgroup per graph) and the separate node + head and
-    update + build launches (PFDYN_N16 without bit 3)."""
-    if not tail:
-        monkeypatch.setenv("PFDYN_N16", "7")
+    coordinates and features (pharmacodiff.py:413-420).  Every form of a step's end: the tail launch (node update + noise
+    head + sampler update + edge build, one workgroup per graph; row-group form = default, n16 form) and the separate
+    node + head and update + build launches (PFDYN_N16 without bit 3)."""
+    set_tail(monkeypatch, tail)
     z = load(name)
     cfg = O.DynamicsConfig()
     batch = batch_from(z)
@@ -91,21 +100,20 @@ def test_trajectory_vs_golden(name, ep, tail, monkeypatch):
     arr = eng.coef_array(coef, reversed(range(T)))
     traj = "pos_frames" in z
     res = eng.sample(arr, T, z["noise"], trajectory=traj, ep_coord=ep, ep_feat=ep)
-    assert eng.kernel_family(cfg.n_convs) == (16 if tail else 0)
+    assert eng.kernel_family(cfg.n_convs) == TAIL_FORMS[tail]
     close(res[0], z["x0"], 5e-3, 5e-3); close(res[1], z["h0"], 5e-3, 5e-3)
     if traj:
         close(res[2], z["pos_frames"], 5e-3, 5e-3); close(res[3], z["feat_frames"], 5e-3, 5e-3)
 
 
-@pytest.mark.parametrize("tail", [True, False])
+@pytest.mark.parametrize("tail", list(TAIL_FORMS))
 def test_bounded_T500_trajectory_every_frame_absolute(tail, monkeypatch):
     """The whole T = 500 reverse process in the regime a trained model lives in -- every center inside the pocket at every step,
     ff / pf / fp edges present throughout -- against the reference's own run (tests/golden/traj_c1_T500_bounded.npz: the
     reference's sampler with its `precision` argument at 0.25, which bounds 1 / alpha_T by 2; see make_golden.py for why
     scaled weights cannot do that): all 501 frames with an ABSOLUTE tolerance of 2e-2 A, no relative part; edge sets of the
     last step; and the same through the oracle."""
-    if not tail:
-        monkeypatch.setenv("PFDYN_N16", "7")
+    set_tail(monkeypatch, tail)
     z = load("traj_c1_T500_bounded.npz")
     cfg = O.DynamicsConfig()
     batch = batch_from(z)
@@ -121,7 +129,7 @@ def test_bounded_T500_trajectory_every_frame_absolute(tail, monkeypatch):
     set_batch(eng, batch)
     coef = O.step_coefficients(O.gamma_table(T, prec), T)
     res = eng.sample(eng.coef_array(coef, reversed(range(T))), T, z["noise"], trajectory=True)
-    assert eng.kernel_family(cfg.n_convs) == (16 if tail else 0)
+    assert eng.kernel_family(cfg.n_convs) == TAIL_FORMS[tail]
     for got, ref in ((res[0], z["x0"]), (res[1], z["h0"]), (res[2], z["pos_frames"]), (res[3], z["feat_frames"])):
         torch.testing.assert_close(got.cpu(), ref, rtol=0.0, atol=2e-2)
     Nf = int(batch.pharm_ptr[-1])
@@ -512,10 +520,8 @@ def test_fused_update_and_edge_build_variants_agree(case, monkeypatch):
     """A denoising step ends with k_step_build_fast (sampler update + the next call's edge build, one atom per
     thread, three dependent global round trips) when pf edges are kNN and pockets have at most 512 atoms.  It must
     reproduce the generic bodies (PFDYN_NO_FAST_BUILD=1: k_step_build) and the separate launches of the tile-kernel
-    path bit for bit: same edge sets, same orderings, same arithmetic -- ragged batch, several steps.  (The tail launch,
-    which runs the same fast body behind an n16-form node update + head, is switched off here: its eps differs from the
-    row-group head's in summation order; test_gpu_n16.py::test_tail_launch_steps_equal_separate_launches compares it.)"""
-    monkeypatch.setenv("PFDYN_N16", "7")
+    path bit for bit: same edge sets, same orderings, same arithmetic -- ragged batch, several steps.  (The optional tail
+    launch, which runs the same fast body behind the node update + head: test_gpu_n16.py::test_tail_launch_steps_equal_separate_launches.)"""
     kw = dict(ff_k=3) if case == "knn_ff" else (dict(message_norm=0) if case == "graph_norm" else {})
     cfg = O.DynamicsConfig(**kw)
     sd = O.make_state_dict(cfg, 3)
