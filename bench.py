@@ -20,6 +20,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MAX_SHARED_GPU_RANKS = 4         # --gpus N with fewer than N GPUs visible: the gloo dry run of the N-rank plumbing, at most this many ranks
 PEAK_F32_TFLOPS = 157.3          # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_EDGE = 136742.0         # message chain, 2 FLOP / MAC
@@ -84,7 +85,79 @@ def pmc_passes(inner_args):
                 d["fetch_kb" if counter == "FETCH_SIZE" else "write_kb"] = tot / n
         finally:
             shutil.rmtree(out, ignore_errors=True)
+    # a third pass without counters: rocprofv3's own per-kernel durations (the counter passes serialise and stretch the kernels)
+    out = tempfile.mkdtemp(prefix="pfbench_trace_", dir="/tmp")
+    try:
+        cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "--",
+               "python3", os.path.abspath(__file__)] + inner_args
+        _, err = _child_json(cmd, env=env, timeout=600)
+        if err is None:
+            for f in glob.glob(out + "/**/*kernel_stats.csv", recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        d = res.setdefault(row["Name"], {"fetch_kb": 0.0, "write_kb": 0.0, "launches": 0})
+                        d["calls"] = int(row["Calls"])
+                        d["avg_us"] = float(row["AverageNs"]) / 1e3
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
     return res, None
+
+
+# FLOPs of one GVP at 2 / MAC (the same formula as pf_debug_work)
+def gvp_flops(vi, vo, si, so):
+    hd = max(vi, vo)
+    return 2.0 * (vi * hd * 3 + hd * vo * 3 + (hd + si) * so + so * vo)
+
+
+G0, GG, GL = gvp_flops(17, 16, 144, 128), gvp_flops(16, 16, 128, 128), gvp_flops(16, 1, 128, 64)
+PER_EDGE, PER_NODE = G0 + 2 * GG, 2 * GG                         # 136,742 / 88,064 at dev.yml depths
+HEAD_FLOP = 3 * GG + GL + 2.0 * 64 * 6
+
+
+def step_launches(pmc, cnt, arch_dev, hoist16):
+    """roofline.launches: one entry per kernel a denoising step launches, from the rocprofv3 child passes (durations from the pass
+    without counters, FETCH_SIZE / WRITE_SIZE from the counter passes), with the FLOPs each launch stands for (algorithmic:
+    SURVEY 8(d) per-unit figures x the units the launch covers; executed: what its items really compute) computed from the
+    step's row / edge counts `cnt` (pf_debug_counts).  FLOP models exist for the dev.yml network's small-batch launches; other
+    kernels are listed with their time and traffic only."""
+    if not pmc:
+        return None
+    step_k = {k: v for k, v in pmc.items() if "avg_us" in v and any(t in k for t in ("k_n16_", "k_rg_", "k_step_", "k_edge_msg", "k_node_", "k_noise_head"))}
+    if not step_k:
+        return None
+    n_steps = max(v["calls"] for v in step_k.values())
+    out = []
+    l0 = cnt["ff"] + cnt["pf"] + cnt["fp"] + cnt["pa"]
+    l1 = cnt["ff"] + cnt["pf"]
+    for k, v in step_k.items():
+        if v["calls"] < 0.5 * n_steps:
+            continue                                     # set-up kernels (first edge build, tables): not part of a step
+        alg = ex = None
+        short = k[k.find("k_"):].split("(")[0]
+        if arch_dev:
+            if "k_n16_edge<true>" in k:
+                alg = PER_EDGE * l0
+                ex = alg - ((cnt["pa"] + cnt["pf"]) * (2.0 * 128 * 128 + 2.0 * 16 * 17 * 3) if hoist16 else 0.0)
+            elif "k_n16_fused" in k:
+                alg = PER_EDGE * l1 + PER_NODE * (cnt["centers"] + cnt["active_atoms"])
+                ex = (PER_EDGE + PER_NODE) * l1 + PER_NODE * cnt["centers"]
+            elif ("k_rg_node<false, 1, true" in k) or "k_rg_tail" in k or "k_n16_tail" in k:
+                alg = ex = (PER_NODE + HEAD_FLOP) * cnt["centers"]
+            elif "k_step_build" in k:
+                alg = ex = 0.0
+        lps = v["calls"] / n_steps
+        e = {"kernel": short[:60], "launches_per_step": round(lps, 3), "avg_us": v["avg_us"],
+             "algorithmic_flop": alg, "executed_flop": ex,
+             "frac": (alg / (v["avg_us"] * 1e-6) / 1e12 / PEAK_F32_TFLOPS) if alg else None,
+             "frac_executed": (ex / (v["avg_us"] * 1e-6) / 1e12 / PEAK_F32_TFLOPS) if ex else None,
+             # FETCH_SIZE under-reports 16-B-per-lane reads by 2x on gfx950 (MI355X_MICROARCH.md): the conv kernels' bulk reads are
+             # all of that shape (corrected figure), the build kernel's are 4..16-B rows (raw figure); both are given
+             "fetch_bytes_raw": v["fetch_kb"] * 1024.0, "fetch_bytes": (1.0 if "k_step_" in k else 2.0) * v["fetch_kb"] * 1024.0,
+             "write_bytes": v["write_kb"] * 1024.0}
+        out.append(e)
+    order = ["k_n16_edge", "k_rg_edge", "k_edge_msg", "k_n16_fused", "k_rg_node", "k_node_", "k_noise_head", "k_rg_tail", "k_n16_tail", "k_step_"]
+    out.sort(key=lambda e: next((i for i, t in enumerate(order) if t in e["kernel"]), 99))
+    return out
 
 
 def secondary_legs(args):
@@ -118,6 +191,22 @@ def secondary_legs(args):
     return out
 
 
+def gather_rank_times(dt, world, dev, backend, dist):
+    """(max over ranks, [every rank's own time]) of a per-rank wall time: what makes a scaling run auditable."""
+    where = dev if backend == "nccl" else "cpu"
+    own = torch.tensor([dt], device=where, dtype=torch.float64)
+    if world == 1:
+        return dt, [dt]
+    tl = [torch.zeros(1, device=where, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(tl, own)
+    per = [float(t_.item()) for t_ in tl]
+    return max(per), per
+
+
+def rccl_world_of(world, backend, dist):
+    return dist.get_world_size() if (world > 1 and backend == "nccl") else (1 if world == 1 else 0)
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh processes, one per GPU, BEFORE this process touches
     the GPU (counting devices does not initialise HIP), with the torchrun environment contract; rank 0 prints the JSON
@@ -127,6 +216,10 @@ def launch_ranks(n):
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs at least one MI355X (no CPU fallback)")
+    if n > ndev and n > MAX_SHARED_GPU_RANKS:
+        # ranks may share a card only in the plumbing dry run (gloo, no RCCL), and a card takes few processes at once
+        raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible here. One rank per GPU is the contract (RCCL); a dry run with "
+                         f"ranks sharing a card is limited to {MAX_SHARED_GPU_RANKS} ranks (it uses gloo and reports rccl_world 0).")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -263,7 +356,7 @@ def main():
     eng.prepare_timesteps(carr, W + KK)
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
 
-    EV_MASK = (1 << 2) | (1 << 6)                               # edge-message launches of conv layer 0
+    EV_MASK = (1 << 2) | (1 << 6) | (1 << 8) | (1 << 4)         # HIP events: edge launches of conv layer 0, of the last layer, node + head
     noise_buf = torch.empty(max(K, W, 20) + 1, Nf, 9, device=dev)
 
     def run(n, first, event_every=0):
@@ -299,8 +392,15 @@ def main():
     # the warm-up steps run with the events on: the library creates its event pairs on first use, and creating them
     # inside the timed region occasionally stalls the host for tens of milliseconds (observed at batch 128-256)
     run(W, True, event_every=1) if W > 0 else eng.sample_begin(torch.randn(Nf, 9, device=dev, generator=gen))
-    eng.profile_read()
+    wprof = eng.profile_read()
     eng.profile_enable(0)
+    # the warm-up steps bracket all three matrix launches of a step; the one that takes longest is the roofline kernel, and only
+    # that one is bracketed inside the timed region (an event pair costs ~3 us of stream time)
+    CLS_BIT = {"edge_msg": 2, "edge_msg_coop": 6, "edge_msg_last": 8, "noise_head": 4}
+    wavg = {k: (wprof[k][0] / wprof[k][1] if wprof[k][1] > 0 else 0.0) for k in CLS_BIT}
+    dom_cls = max(wavg, key=lambda k: wavg[k]) if any(v > 0 for v in wavg.values()) else "edge_msg_coop"
+    l0_cls = "edge_msg" if wprof["edge_msg"][1] > 0 else "edge_msg_coop"
+    EV_MASK = 1 << CLS_BIT[dom_cls]
     barrier()
     t0 = time.perf_counter()
     run(K, False, event_every=args.event_every)
@@ -308,7 +408,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_enable(0)
-    in_region = prof["edge_msg"][1] + prof["edge_msg_coop"][1]
+    in_region = prof[dom_cls][1]
     if 0 < in_region < 20:                      # short timed regions: top the sample up to 20 launches, outside `value`
         eng.profile_enable(EV_MASK)
         run(20 - in_region, False)
@@ -335,7 +435,8 @@ def main():
     # dominant kernel = the edge-message launch of conv layer 0; which kernel family runs it depends on the batch
     # (pf_debug_kernel_family): row-group kernel k_rg_edge (4 / 8 rows per wave), or the 32-row tile kernels;
     # FLOP = 136,742 per edge it actually processes
-    dom = "edge_msg" if prof["edge_msg"][1] > 0 else "edge_msg_coop"
+    dom = l0_cls
+    cnt = eng.counts()
     fam = eng.kernel_family(0)
     hoist_rows = eng.l0_hoist()
     # the template the launch really ran (pf_host.cpp: run_dynamics): the rocprofv3 kernel name starts with it
@@ -349,7 +450,7 @@ def main():
     else:
         dom_name = {32: "k_edge_msg<true>", 128: "k_edge_msg_coop<true>"}[fam]
         dom_match = dom_name[:-6]
-    edge_ms, edge_n = prof[dom]
+    edge_ms, edge_n = prof[dom] if dom == dom_cls else wprof[dom]      # (conv layer 0: inside the timed region only when it is the dominant launch)
     l0_edges = wk["executed_edges_per_layer"][0]
     edge_avg_s = edge_ms / max(edge_n, 1) * 1e-3
     edge_flops = FLOP_PER_EDGE * l0_edges
@@ -362,6 +463,27 @@ def main():
     if hoist_rows == 16:                        # n16 form: pp and pf edges start from a type-table row: the h_src block of the first
         hoisted_edges += ne[1]                  # scalar Linear (2 x 128 x 128) and the Vh matrix product (2 x 16 x 17 x 3) are not executed
         edge_flops_exec = edge_flops - (32768.0 + 1632.0) * max(hoisted_edges, 0)
+
+    # ---- the time-dominant launch (dom_cls): name, FLOPs, HIP-event time inside the timed region
+    dk_ms, dk_n = prof[dom_cls]
+    dk_avg_s = dk_ms / max(dk_n, 1) * 1e-3
+    l1_edges = wk["executed_edges_per_layer"][-1]
+    fam_last = eng.kernel_family(len(wk["executed_edges_per_layer"]) - 1)
+    if dom_cls == l0_cls:
+        dk_name, dk_match, dk_alg, dk_exec = dom_name, dom_match, edge_flops, edge_flops_exec
+    elif dom_cls == "edge_msg_last":
+        if fam_last == 17:
+            dk_name, dk_match = "k_n16_fused (last conv layer's edge messages with conv layer 0's node update of the source rows in front; 16-row items, v_mfma_f32_16x16x4_f32)", "k_n16_fused"
+            dk_alg = PER_EDGE * l1_edges + PER_NODE * (cnt["centers"] + cnt["active_atoms"])
+            dk_exec = (PER_EDGE + PER_NODE) * l1_edges + PER_NODE * cnt["centers"]
+        else:
+            dk_name = {16: "k_n16_edge<false>", 4: "k_rg_edge<false, 1, ...>", 8: "k_rg_edge<false, 2, ...>"}.get(fam_last, "k_edge_msg<false>") + " (last conv layer's edge messages)"
+            dk_match = dk_name.split(" ")[0].split(",")[0]
+            dk_alg = dk_exec = PER_EDGE * l1_edges
+    else:
+        dk_name, dk_match = "k_rg_node<false, ., true, .> (last conv layer's node update of the centers + noise head)", "k_rg_node<false"
+        dk_alg = dk_exec = (PER_NODE + HEAD_FLOP) * cnt["centers"]
+    dk_tf = dk_alg / dk_avg_s / 1e12 if dk_avg_s > 0 else 0.0
 
     out = {
         "metric": "denoising steps/sec (batch x T) at 256-atom pocket, 6 centers",
@@ -378,20 +500,26 @@ def main():
                    "edges_per_step": {"ff": ne[0], "pf": ne[1], "fp": ne[2], "pp": ne[3]},
                    "edges_computed_per_layer": wk["executed_edges_per_layer"],
                    "parallelism": f"graphs sharded over {world} GPU(s), no data-path collective"},
-        "roofline": {"bound": "mfma", "kernel": dom_name,
-                     # what the launch EXECUTES over its duration comes first; `achieved` / `frac` below are the contract's
-                     # algorithmic figures (SURVEY 8d's per-edge FLOPs x the edges the launch computes)
-                     "frac_executed": (edge_flops_exec / edge_avg_s / 1e12 / PEAK_F32_TFLOPS) if edge_avg_s > 0 else 0.0,
-                     "achieved_executed": (edge_flops_exec / edge_avg_s / 1e12) if edge_avg_s > 0 else 0.0,
-                     "achieved": achieved_tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F32_TFLOPS,
+        "roofline": {"bound": "mfma", "kernel": dk_name,
+                     # the TIME-dominant launch of a step (chosen by the warm-up's HIP events).  What it EXECUTES over its duration
+                     # comes first; `achieved` / `frac` are the contract's algorithmic figures (SURVEY 8d per-unit FLOPs x its units)
+                     "frac_executed": (dk_exec / dk_avg_s / 1e12 / PEAK_F32_TFLOPS) if dk_avg_s > 0 else 0.0,
+                     "achieved_executed": (dk_exec / dk_avg_s / 1e12) if dk_avg_s > 0 else 0.0,
+                     "achieved": dk_tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": dk_tf / PEAK_F32_TFLOPS,
                      "traffic": None, "traffic_unit": "bytes per launch", "traffic_detail": pmc_err,
-                     "kernel_avg_us": edge_avg_s * 1e6, "launches_timed": edge_n, "flop_per_launch": edge_flops,
-                     "executed_flop_per_launch": edge_flops_exec, "hoisted_edges_per_launch": hoisted_edges,
-                     "note": "edge-message launches of conv layer 0 timed by HIP events inside the timed region (an event pair adds ~3 us to "
-                             "what it brackets: rocprofv3 durations in profiles/ are that much shorter); algorithmic FLOP = 136,742 per edge "
-                             "(SURVEY 8d) x edges the launch computes; executed FLOP leaves out what the static hoist removes (DESIGN 4.1a: the "
-                             "h_src block of the first scalar Linear and the Vh product of edges whose source is a protein atom). Outputs equal the "
-                             "dense reference computation; rows/edges that cannot reach the output are not computed.",
+                     "kernel_avg_us": dk_avg_s * 1e6, "launches_timed": dk_n, "flop_per_launch": dk_alg,
+                     "executed_flop_per_launch": dk_exec,
+                     "note": "the launch a step spends most time in, timed by HIP events on the launch stream inside the timed region (an event "
+                             "pair adds ~3 us to what it brackets: the rocprofv3 durations in `launches` are that much shorter). Algorithmic "
+                             "FLOP: 136,742 per edge message + 88,064 per updated node (+ 153,056 per center for the noise head), SURVEY 8d; "
+                             "executed FLOP: what the launch's items really compute (the fused launch updates a source row once per edge item "
+                             "that reads it; conv layer 0 skips what the static hoist's type tables provide). Outputs equal the dense "
+                             "reference computation; rows / edges that cannot reach the output are not computed.",
+                     "conv_layer0_launch": {"kernel": dom_name, "kernel_avg_us": edge_avg_s * 1e6, "launches_timed": edge_n,
+                                            "timed": "inside the timed region" if dom == dom_cls else "warm-up steps",
+                                            "flop_per_launch": edge_flops, "executed_flop_per_launch": edge_flops_exec,
+                                            "hoisted_edges_per_launch": hoisted_edges, "frac": achieved_tf / PEAK_F32_TFLOPS,
+                                            "frac_executed": (edge_flops_exec / edge_avg_s / 1e12 / PEAK_F32_TFLOPS) if edge_avg_s > 0 else 0.0},
                      "whole_step": {"executed_flop": wk["executed_flops"], "executed_tflops": wk["executed_flops"] / (dt / K) / 1e12,
                                     "frac_f32_peak_executed": wk["executed_flops"] / (dt / K) / 1e12 / PEAK_F32_TFLOPS,
                                     "dense_reference_flop": flops, "dense_reference_bytes": bytes_,
@@ -402,24 +530,38 @@ def main():
         "per_rank_ms_per_step": per_rank_ms,
     }
     if pmc is not None:
-        hits = {k: v for k, v in pmc.items() if dom_match in k}
+        launches = step_launches(pmc, cnt, args.arch == "dev", hoist_rows == 16)
+        if launches:
+            out["roofline"]["launches"] = launches
+            out["roofline"]["launches_sum_us"] = sum(e["avg_us"] * e["launches_per_step"] for e in launches)
+            out["roofline"]["launches_note"] = ("every kernel a denoising step launches: avg_us = rocprofv3 --kernel-trace --stats of a child pass of this "
+                                                "script (no counters, --steps 20 --warmup 2); fetch / write bytes from two --pmc child passes; their sum "
+                                                "stays below ms_per_step (the rest: gaps between launches and the per-step noise draw)")
+        hits = {k: v for k, v in pmc.items() if dk_match in k and v.get("launches", 0) > 0}
         if hits:
             kname = max(hits, key=lambda k: hits[k]["launches"])
             d = hits[kname]
             fetch_b, write_b = 2.0 * d["fetch_kb"] * 1024.0, d["write_kb"] * 1024.0
+            if dk_match == "k_n16_fused":        # gathers: the edges' end points + the source rows' partial message rows and type-table rows; stores: partial rows
+                alg_b, alg_note = 736.0 * l1_edges + 5 * 704.0 * l1_edges + 704.0 * l1_edges / 3.0, \
+                    "per edge: 736 B of end-point rows (SURVEY 8d) + ~5 partial / residual rows of 704 B for its source's node update; one 704-B partial row stored per (item, destination) run"
+            else:
+                alg_b, alg_note = 736.0 * l0_edges + 704.0 * l0_edges / 3.0, \
+                    "gathers 736 B per edge (SURVEY 8d) + one 704-B partial message row per (item, destination) run (~1 in 3 edges)"
             out["roofline"]["traffic"] = fetch_b + write_b
             out["roofline"]["traffic_detail"] = {
                 "kernel": kname[:120], "launches": d["launches"], "FETCH_SIZE_KB": d["fetch_kb"], "WRITE_SIZE_KB": d["write_kb"],
-                "fetch_bytes_corrected": fetch_b, "write_bytes": write_b,
+                "fetch_bytes_corrected": fetch_b, "fetch_bytes_raw": d["fetch_kb"] * 1024.0, "write_bytes": write_b,
                 "correction": "FETCH_SIZE (KB) x 2: gfx950 tallies the 128-B requests of 16-B-per-lane reads at 64 B (MI355X_MICROARCH.md, "
-                              "HBM section); WRITE_SIZE (KB) exact; memory-side requests of the L2, Infinity-Cache hits included",
+                              "HBM section) -- the bulk reads of the conv kernels are all of that shape; WRITE_SIZE (KB) exact; memory-side "
+                              "requests of the L2, Infinity-Cache hits included",
                 "source": "two rocprofv3 --kernel-trace --pmc child passes of this script (--steps 20 --warmup 2), mean per launch",
-                "algorithmic_bytes_per_launch": 736.0 * l0_edges + 704.0 * l0_edges / 3.0,
-                "algorithmic_note": "gathers 736 B per edge (SURVEY 8d) + one 704-B partial message row per (item, destination) run (~1 in 3 edges)",
-                "per_step_all_kernels_bytes": sum((2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0 * v["launches"] for v in pmc.values())
-                                              / max(d["launches"], 1)}
+                "algorithmic_bytes_per_launch": alg_b, "algorithmic_note": alg_note,
+                "per_step_all_kernels_bytes": (sum((e["fetch_bytes"] + e["write_bytes"]) * e["launches_per_step"] for e in launches)
+                                               if launches else None),
+                "per_step_note": "sum over `launches` (corrected fetch for the conv kernels, raw for the build kernel), launches of one step only"}
         else:
-            out["roofline"]["traffic_detail"] = f"no kernel matching {dom_match!r} in the counter output"
+            out["roofline"]["traffic_detail"] = f"no kernel matching {dk_match!r} in the counter output"
     if secondary is not None:
         out["secondary"] = secondary
 
@@ -617,16 +759,17 @@ def slice_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
                         "frac": fl / avg / 1e12 / PEAK_F32_TFLOPS if avg > 0 else 0.0}
         except Exception as e:                       # informational: never costs the line
             dominant = {"dominant_kernel": None, "error": f"{type(e).__name__}: {e}"}
-    tt = torch.tensor([dt, float(n)], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+    dt, per_rank_s = gather_rank_times(dt, world, dev, backend, dist)
     if world > 1:
-        mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        dt, n = float(mx[0]), int(sm[1])
+        sm = torch.tensor([float(n)], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        n = int(sm[0])
     if rank == 0:
         print(json.dumps({
             "metric": "denoising steps/sec end to end through PharmacophoreDiff.sample (config-4 slice)", "value": n * T / dt,
             "unit": "sample-steps/s", "n_gpus": world, "steps": T, "warmup": 0, "ms_per_step": dt / T * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rccl_world": rccl_world_of(world, backend, dist), "per_rank_ms_per_step": [v / T * 1e3 for v in per_rank_s],
             "config": {"workload": f"BASELINE config 4 slice: {P} pockets per GPU x {S} pharmacophores (sizes 3-8), {args.n_prot}-atom "
                                    f"pockets, T={T}, max_batch_size {args.max_batch_size}, dev.yml network",
                        "pockets": P * world, "pharmacophores": n, "wall_s": dt, "ms_per_pocket": dt / max(P, 1) * 1e3,
@@ -710,10 +853,7 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.profile_read_train()
-    tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt, per_rank_s = gather_rank_times(dt, world, dev, backend, dist)
     # dominant kernel of the step: k_bwd_edge_level (one launch per message-GVP level and conv layer).  Algorithmic work
     # of the message chain's backward = 2 x its forward (one product for the input gradient, one for the weight
     # gradient, per Linear): 2 x 136,742 FLOP per edge the layer computes, over its n_message_gvps launches
@@ -730,6 +870,7 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
             "metric": "training graphs/sec (forward + backward + Adam), 256-atom pockets, 4-8 centers", "value": world * B * K / dt,
             "unit": "graphs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rccl_world": rccl_world_of(world, backend, dist), "per_rank_ms_per_step": [v / K * 1e3 for v in per_rank_s],
             "config": {"workload": f"BASELINE config 5: training step, batch={B} per GPU, {args.n_prot}-atom pockets, centers {lo}-{hi}, "
                                    "dropout 0.1, dev.yml network", "batch_per_gpu": B, "n_prot": args.n_prot,
                        "distinct_batches": len(graphs),

@@ -272,6 +272,10 @@ int pf_profile_read_train(pf_handle* h, double* total_ms /*[4]*/, int64_t* launc
  * kernels compute after dead-work elimination (last layer: pharm side only; layer before it: active atoms only). */
 int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges /*[4]*/, double* executed_flops,
                   int64_t* executed_edges /*[n_convs]*/, pf_stream stream);
+/* row / edge counts of the last dynamics call (or of the edges the last pf_denoise_step built): out[8] = ff, pf, fp, static pp edges,
+ * "pa" edges (pp edges into active atoms: what the pruned conv layer computes of the pp etype), active atoms, centers, atoms --
+ * what a per-launch FLOP count needs (bench.py: roofline.launches) */
+int pf_debug_counts(pf_handle* h, int64_t* out /*[8]*/, pf_stream stream);
 /* kernel family of the edge-message launch of conv layer `layer` in the last dynamics call (the launch policy depends
  * on the batch: pf_host.cpp LaunchPolicy): *rows_per_wave = 4 or 8 (row-group kernels, pf_rg.hip: k_rg_edge), 16 (16-row
  * items on the four waves of a workgroup, pf_n16.hip: k_n16_edge; 17 = the fused launch k_n16_fused, whose items also

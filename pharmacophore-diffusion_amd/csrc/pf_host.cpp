@@ -152,6 +152,7 @@ struct LaunchPolicy {
     // at config 2 (PFDYN_XCD_SPLIT=0: off).  The same idea on the conv-layer-0 launch (pa / pf items on five XCDs, ff / fp items on three)
     // LOST 1.6 us: that launch is throughput-bound with two items per compute unit, and the split unbalances it (profiles/r04)
     int xcd_split = 1;
+    int node_xcds = 2;                      // the fused node + head launch of a small batch runs on this many XCDs (PFDYN_NODE_XCDS; 0: all eight)
     int tail_form = 4;                      // 4: the row-group form (k_rg_tail: two two-wave items of four centers), 16: the n16 form (k_n16_tail)
     long n16_fuse_rows_max = 20000;         // the fused launch (bit 2): +2-3 % up to 32 graphs of 256 atoms, -4 % at 40 (its items carry five blocks: throughput-bound earlier)
     long n16_rows_max = 24000;              // measured at 256-atom pockets (575 slots per graph): +5 % at 16 graphs, +10 % at 32, -3..-5 % at 64, -15 % at 256
@@ -188,6 +189,7 @@ struct LaunchPolicy {
         geti("PFDYN_N16", n16_mask);
         geti("PFDYN_TAIL_GRAPHS_MAX", tail_graphs_max);
         geti("PFDYN_XCD_SPLIT", xcd_split);
+        geti("PFDYN_NODE_XCDS", node_xcds);
         if (const char* e = getenv("PFDYN_TAIL_FORM")) tail_form = (e[0] == 'n' || atoi(e) == 16) ? 16 : 4;
         if (const char* e = getenv("PFDYN_N16_ROWS_MAX")) n16_rows_max = n16_fuse_rows_max = atol(e);
         if (const char* e = getenv("PFDYN_N16_FUSE_ROWS_MAX")) n16_fuse_rows_max = atol(e);
@@ -1204,6 +1206,8 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 h->tail_done = true; h->last_tail = 16;
                 head_done = true;
             } else if (fuse) {
+                // few two-wave items: confined to node_xcds XCDs when they fit one per compute unit there (32 CUs per XCD)
+                if (nsplit && h->pol.node_xcds > 0 && n.ntiles * 8 <= 32 * h->pol.node_xcds) n.xcd_n = h->pol.node_xcds;
                 HeadParams hp{};
                 hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
                 hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
@@ -3042,6 +3046,23 @@ int pf_profile_read(pf_handle* h, double* total_ms, int64_t* launches, pf_stream
 }
 int pf_profile_read_train(pf_handle* h, double* total_ms, int64_t* launches, pf_stream stream) {
     return profile_read_range(h, pf_handle::K_BWD_HEAD, pf_handle::K_NUM, total_ms, launches, stream);
+}
+
+int pf_debug_counts(pf_handle* h, int64_t* out, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!out) PF_FAIL(h, PF_ERR_ARG, "pf_debug_counts: null argument");
+    PF_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+    std::vector<int> cnt((size_t)5 * h->B);
+    PF_HIP(h, hipMemcpy(cnt.data(), h->d_dyn_cnt, cnt.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int g = 0; g < h->B; ++g) {
+        for (int et = 0; et < 3; ++et) out[et] += cnt[(size_t)et * h->B + g];
+        out[4] += cnt[(size_t)3 * h->B + g];
+        out[5] += cnt[(size_t)4 * h->B + g];
+    }
+    out[3] = h->Epp; out[6] = h->Nf; out[7] = h->Np;
+    return PF_OK;
 }
 
 int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges, double* executed_flops,

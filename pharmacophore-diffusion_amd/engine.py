@@ -375,6 +375,13 @@ class PfEngine:
         return {"flops": fl.value, "bytes": by.value, "edges": list(ne), "executed_flops": ex.value,
                 "executed_edges_per_layer": list(el)}
 
+    def counts(self):
+        """Row / edge counts of the last dynamics call: dict(ff, pf, fp, pp, pa, active_atoms, centers, atoms)."""
+        out = (ctypes.c_int64 * 8)()
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_debug_counts(self._h, out, _stream_ptr()), "pf_debug_counts")
+        return dict(zip(("ff", "pf", "fp", "pp", "pa", "active_atoms", "centers", "atoms"), list(out)))
+
     def kernel_family(self, layer: int = 0) -> int:
         """Rows per wave of the edge-message launch of `layer` in the last dynamics call: 4 / 8 = row-group kernels
         (k_rg_edge), 16 = 16-row items on four waves (k_n16_edge; 17: the fused launch k_n16_fused, which also computes conv layer 0's

@@ -2,6 +2,9 @@
 on top of the C ABI: sampling against the reference's golden trajectories and xyz output,
 multi-pocket ragged sampling, training-loss forward, checkpoint round trip, and a full-size
 config-2 trajectory through size-independent properties."""
+import os
+import sys
+
 import pytest
 import torch
 
@@ -794,3 +797,47 @@ def test_pocket_claims_device_resident_batches_and_failed_binds():
     bad_t = z["t_int"].long().clone(); bad_t[0] = int(z["T"]) + 3
     with pytest.raises(ValueError, match="t_int must lie"):
         m.forward(g, 'val', t_int=bad_t, eps={'h': z["eps_h"], 'x': z["eps_x"]})
+
+
+def _bench_child(args, timeout=900):
+    """bench.py as a fresh child process (it starts its own ranks before touching the GPU); returns (returncode, last JSON line or None, stderr)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
+    line = None
+    for ln in reversed(r.stdout.strip().splitlines()):
+        if ln.strip().startswith("{"):
+            line = json.loads(ln)
+            break
+    return r.returncode, line, r.stderr
+
+
+@pytest.mark.parametrize("leg", ["headline", "train", "sample_slice"])
+def test_bench_two_rank_plumbing_on_one_gpu(leg):
+    """The N > 1 code of bench.py -- rank launch, process group, barriers, max-over-ranks timing, per-rank gather, the
+    work split of the config-4 slice, the gradient all-reduce of the training leg -- executed with TWO ranks on whatever
+    GPUs are here (one card: the ranks share it and the process group is gloo, rccl_world 0; two or more: RCCL).  What an
+    8-GPU driver pass runs, minus the hardware (pharmacodiff.py:516-578 for the slice's partitioning)."""
+    light = ["--no-cpu-baseline", "--no-dense-leg", "--no-full-trajectory", "--no-secondary", "--no-traffic"]
+    args = {"headline": ["--gpus", "2", "--steps", "10", "--warmup", "2"] + light,
+            "train": ["--gpus", "2", "--train", "--steps", "4", "--warmup", "1", "--batch", "64"] + light,
+            "sample_slice": ["--gpus", "2", "--sample-slice", "8", "--samples", "6", "--max-batch-size", "24"] + light}[leg]
+    rc, j, err = _bench_child(args)
+    assert rc == 0 and j is not None, err[-2000:]
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert len(j["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in j["per_rank_ms_per_step"])
+    assert j["rccl_world"] == (2 if torch.cuda.device_count() >= 2 else 0)
+    if leg == "headline":
+        assert j["config"]["batch_per_gpu"] == 32 and j["steps"] == 10 and j["warmup"] == 2
+
+
+def test_bench_rejects_more_ranks_than_a_shared_gpu_takes():
+    """`bench.py --gpus 8` where fewer than 8 GPUs are visible must fail at once with a message, not hang in a rendezvous or
+    pile eight processes onto one card."""
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("eight GPUs are visible here")
+    rc, j, err = _bench_child(["--gpus", "8", "--steps", "2", "--warmup", "1"], timeout=120)
+    assert rc != 0 and j is None
+    assert "--gpus 8" in err and "GPU(s) visible" in err

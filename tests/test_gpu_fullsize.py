@@ -329,3 +329,44 @@ def test_pocket_sharing_equals_the_per_copy_path():
     px = batch.prot_x.clone(); px[130] += 0.01                     # an atom of the second copy of the first pocket
     with pytest.raises(pfa.PfError, match="coordinates / features differ"):
         eng.set_batch(px, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst, pocket_uid=uid)
+
+
+def test_config2_whole_T500_reverse_process_vs_oracle():
+    """BASELINE config 2 exactly as stated -- 256-atom pockets, 6 centers, batch 32, ALL T = 500 steps of the reverse process
+    (pharmacodiff.py:433-514: the loop :466-472) -- against the oracle with shared noise, under the default launch policy: every
+    25th frame of the trajectory and the end point at 2e-2 A ABSOLUTE (features: 2e-2), in the bounded regime of
+    tests/golden/traj_c1_T500_bounded.npz (schedule precision 0.25: 1 / alpha_T <= 2, the centers stay inside the pockets, so
+    ff / pf / fp edges exist at every step and the tolerance needs no relative part).  ~2 min of CPU for the oracle."""
+    _no_policy_overrides()
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 0)
+    B, T, prec = 32, 500, 0.25
+    batch = O.synthetic_batch(range(1000, 1000 + B), 256, [6] * B, cfg)
+    Nf = int(batch.pharm_ptr[-1])
+    noise = torch.randn(T + 1, Nf, 9, generator=torch.Generator().manual_seed(42))
+    eng = _engine(cfg, sd)
+    eng.set_batch(batch.prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst)
+    coef = O.step_coefficients(O.gamma_table(T, prec), T)
+    res = eng.sample(eng.coef_array(coef, reversed(range(T))), T, noise, trajectory=True)
+    assert (eng.kernel_family(0), eng.kernel_family(1), eng.l0_hoist()) == (16, 17, 16)
+    ne = eng.work()[2]                                                        # edges of the last dynamics call (step s = 0)
+    # (most ordered pairs of centers are within the 9 A ff cutoff at the end; every center keeps its 5 nearest atoms)
+    assert 0.85 * B * 6 * 5 <= ne[0] <= B * 6 * 5 and ne[1] == 5 * Nf and ne[2] == ne[1] and ne[3] == batch.pp_src.numel()
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(16)                 # (the oracle's best thread count on the GPU boxes; their default oversubscribes: 100x slower)
+    try:
+        with torch.no_grad():
+            ox, oh, oframes = O.sample_given_receptor(sd, cfg, batch, T, prec, noise, return_traj=True)
+    finally:
+        torch.set_num_threads(nthr)
+    opos = torch.stack([f[0] for f in oframes]); ofeat = torch.stack([f[1] for f in oframes])
+    assert opos.shape[0] == T + 1
+    com = O.segment_mean(batch.prot_x, batch.prot_ptr)[batch.batch_idxs()["pharm"]]
+    assert float((opos - com).norm(dim=-1).max()) < 10.7                      # the centers never leave the pockets (radius 10.7 A)
+    sel = list(range(0, T + 1, 25))
+    worst = float((res[2].cpu()[sel] - opos[sel]).abs().max())
+    torch.testing.assert_close(res[2].cpu()[sel], opos[sel], rtol=0.0, atol=2e-2)
+    torch.testing.assert_close(res[3].cpu()[sel], ofeat[sel], rtol=0.0, atol=2e-2)
+    torch.testing.assert_close(res[0].cpu(), ox, rtol=0.0, atol=2e-2)
+    torch.testing.assert_close(res[1].cpu(), oh, rtol=0.0, atol=2e-2)
+    assert worst < 2e-2, worst
