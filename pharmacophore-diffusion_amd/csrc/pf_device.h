@@ -276,6 +276,7 @@ struct NodeParams {
     uint32_t drop_thr; float drop_scale; uint32_t seed; int layer;
     const float* mask_override;   // tests: externally supplied multipliers [n_convs * 2][N * 144] instead of the hash
     int xcd_n;             // two-wave node launches: confine the items to the first xcd_n XCDs (0: off; k_rg_node)
+    int st_n0, st_n;       // the launch covers the static tiling of the centers [st_n0, st_n0 + st_n) (fused node + head: k_rg_node_hs); st_n = 0: tile list
     int grp;               // edge slots per message partial row group: 32 (tile kernels) or 4*RG (row-group edge kernel)
     int grp_pa;            // ... of the pp / "pa" segment of the protein nodes (differs from grp under the static hoist)
     pf_gcf rg_upd[2];      // row-group kernels: quad stream of each node type's update chain (pharm of the last layer:

@@ -152,6 +152,7 @@ struct LaunchPolicy {
     // at config 2 (PFDYN_XCD_SPLIT=0: off).  The same idea on the conv-layer-0 launch (pa / pf items on five XCDs, ff / fp items on three)
     // LOST 1.6 us: that launch is throughput-bound with two items per compute unit, and the split unbalances it (profiles/r04)
     int xcd_split = 1;
+    int node_static = 1;                    // ... with its tiles computed, not loaded (k_rg_node_hs; PFDYN_NODE_STATIC=0: the tile-list kernel)
     int node_xcds = 2;                      // the fused node + head launch of a small batch runs on this many XCDs (PFDYN_NODE_XCDS; 0: all eight)
     int tail_form = 4;                      // 4: the row-group form (k_rg_tail: two two-wave items of four centers), 16: the n16 form (k_n16_tail)
     long n16_fuse_rows_max = 20000;         // the fused launch (bit 2): +2-3 % up to 32 graphs of 256 atoms, -4 % at 40 (its items carry five blocks: throughput-bound earlier)
@@ -189,7 +190,7 @@ struct LaunchPolicy {
         geti("PFDYN_N16", n16_mask);
         geti("PFDYN_TAIL_GRAPHS_MAX", tail_graphs_max);
         geti("PFDYN_XCD_SPLIT", xcd_split);
-        geti("PFDYN_NODE_XCDS", node_xcds);
+        geti("PFDYN_NODE_XCDS", node_xcds); geti("PFDYN_NODE_STATIC", node_static);
         if (const char* e = getenv("PFDYN_TAIL_FORM")) tail_form = (e[0] == 'n' || atoi(e) == 16) ? 16 : 4;
         if (const char* e = getenv("PFDYN_N16_ROWS_MAX")) n16_rows_max = n16_fuse_rows_max = atol(e);
         if (const char* e = getenv("PFDYN_N16_FUSE_ROWS_MAX")) n16_fuse_rows_max = atol(e);
@@ -1208,6 +1209,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             } else if (fuse) {
                 // few two-wave items: confined to node_xcds XCDs when they fit one per compute unit there (32 CUs per XCD)
                 if (nsplit && h->pol.node_xcds > 0 && n.ntiles * 8 <= 32 * h->pol.node_xcds) n.xcd_n = h->pol.node_xcds;
+                if (nsplit && l > 0 && h->pol.node_static) { n.st_n0 = h->Np; n.st_n = h->Nf; }      // (the last layer's node tiles ARE the static tiling of the centers)
                 HeadParams hp{};
                 hp.tiles = h->d_head_tiles; hp.ntiles = h->n_head_tiles; hp.node_base = h->Np;
                 hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
