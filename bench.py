@@ -188,6 +188,18 @@ def secondary_legs(args):
                              "note": "a new batch every step (4 distinct batches rotate); the backward kernels execute exactly the algorithmic FLOPs"}
     else:
         out["train_step"] = {"error": err}
+    # the labelled bf16 leg of the same step (never the headline: the reference trains in fp32)
+    j, err = _child_json(me + light + ["--train", "--train-dtype", "bf16", "--steps", "20", "--warmup", "4"])
+    if j:
+        r = j["roofline"]
+        out["train_step_bf16"] = {"workload": j["config"]["workload"], "dtype": "bf16", "value": j["value"], "unit": j["unit"],
+                                  "ms_per_step": j["ms_per_step"], "dominant_kernel": r["kernel"], "kernel_avg_us": r["kernel_avg_us"],
+                                  "note": "to_feats_out / gate products of the message chains' forward and of the gradient kernels on bf16 matrix "
+                                          "instructions (operands rounded to nearest even, fp32 accumulation), fp32 master weights, LayerNorm, "
+                                          "vector channel, scatter and Adam; contract: tests/test_gpu_train.py (per-tensor gradient cosine vs "
+                                          "the fp32 path); no fraction of a roof is formed (mixed f32 / bf16 instructions)"}
+    else:
+        out["train_step_bf16"] = {"error": err}
     return out
 
 
@@ -269,6 +281,9 @@ def main():
                     help="--train: number of distinct batches the steps rotate through (1: the same batch every step, no re-bind)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the compact objects of the other configurations (config 3, config-4 slice, training step)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
+    ap.add_argument("--train-dtype", choices=["f32", "bf16"], default="f32",
+                    help="--train: arithmetic of the dense Linears (f32: what the reference trains in and the line of record; bf16: the "
+                         "labelled bf16 leg -- bf16 matrix instructions, fp32 accumulation, fp32 master weights)")
     ap.add_argument("--train", action="store_true",
                     help="secondary benchmark (BASELINE config 5): training steps (forward, backward kernels, Adam) at "
                          "batch 256 per GPU instead of the sampling metric")
@@ -814,6 +829,7 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
     m.load_state_dict(sd, strict=True)
     m = m.to(dev).train()
     pockets = [synthetic.synthetic_pocket(1000 * rank + i, args.n_prot) for i in range(B)]
+    m.dynamics.set_train_precision(args.train_dtype)
     eng = m.dynamics.engine()
     gen = torch.Generator().manual_seed(7 + rank)
     # a rotating set of DISTINCT batches (other pocket order, other center counts: other ptr arrays and coordinates), as a
@@ -887,7 +903,7 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
         print(json.dumps({
             "metric": "training graphs/sec (forward + backward + Adam), 256-atom pockets, 4-8 centers", "value": world * B * K / dt,
             "unit": "graphs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.train_dtype, "data": "synthetic",
             "rccl_world": rccl_world_of(world, backend, dist), "per_rank_ms_per_step": [v / K * 1e3 for v in per_rank_s],
             "config": {"workload": f"BASELINE config 5: training step, batch={B} per GPU, {args.n_prot}-atom pockets, centers {lo}-{hi}, "
                                    "dropout 0.1, dev.yml network", "batch_per_gpu": B, "n_prot": args.n_prot,

@@ -232,6 +232,18 @@ int pf_get_flat_params(pf_handle* h, float* dev_flat /*[n_params]*/, pf_stream s
  * step counts from 1. */
 int pf_adam_step(pf_handle* h, float* dev_params, const float* dev_grad, float* dev_exp_avg, float* dev_exp_avg_sq,
                  int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay, pf_stream stream);
+/* Arithmetic of the training step's dense Linears.  The reference trains in fp32 (pharmacodiff.py:162-263; gvp.py:96,101 force
+ * .float()) and PF_TRAIN_F32 -- the default, and the only mode the parity tests against the reference's gradients use -- does
+ * the same.  PF_TRAIN_BF16 (BASELINE config 5's "bf16" leg; no reference counterpart) runs to_feats_out and
+ * scalar_to_vector_gates of the message chains' forward and the corresponding products of every gradient kernel (input and
+ * weight gradients of to_feats_out; in the message chains also of the gates) on bf16 matrix instructions: operands rounded to
+ * nearest even, fp32 accumulation.  Master weights, saved activations, LayerNorm, the vector channel, scatter sums, the loss
+ * and the optimiser stay fp32.  Contract (tests/test_gpu_train.py): per-tensor gradient cosine >= 0.999 against the fp32
+ * path.  Applies to the following pf_train_* calls; a forward of one precision cannot be followed by a backward of the other. */
+#define PF_TRAIN_F32 0
+#define PF_TRAIN_BF16 1
+int pf_train_set_precision(pf_handle* h, int32_t precision);
+int pf_train_get_precision(pf_handle* h, int32_t* precision);
 /* tests: make the following pf_train_forward / pf_train_backward calls on this batch use the given multipliers
  * [n_convs][2][N][144] (layout of pf_debug_dropout_mask) instead of the built-in generator; NULL restores it.  The
  * buffer must stay alive until the backward call has finished. */

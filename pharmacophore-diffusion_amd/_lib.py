@@ -62,6 +62,8 @@ SYMBOLS = {
     "pf_set_flat_params": (ctypes.c_int, [_P, _P, _P]),
     "pf_get_flat_params": (ctypes.c_int, [_P, _P, _P]),
     "pf_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _P]),
+    "pf_train_set_precision": (ctypes.c_int, [_P, _I32]),
+    "pf_train_get_precision": (ctypes.c_int, [_P, ctypes.POINTER(_I32)]),
     "pf_debug_set_dropout_masks": (ctypes.c_int, [_P, _P]),
     "pf_debug_dropout_mask": (ctypes.c_int, [_P, _I32, _I32, _F, ctypes.c_uint32, _P, _P]),
     "pf_debug_get_edges": (_I64, [_P, _I32, _P, _P, _I64, _P]),

@@ -171,6 +171,7 @@ struct EdgeParams {
     // training forward (one-wave kernel only): per message-GVP level l and edge slot e, Z (pre-activation scalars),
     // the gate pre-activations and the gated output vectors go to sv_*[(l * sv_stride + e)]; NULL: inference
     float* sv_z; float* sv_g; float* sv_v; size_t sv_stride;
+    int bf16;              // training forward of the bf16 leg (k_edge_msg<., SAVE, BF16>): dense Linears on bf16 matrix instructions
     pf_gcf rg[4];          // row-group kernels: quad stream of each etype's message chain (this layer)
     // row-group kernels, compact work list (nreg > 0): the launch covers regions [0, nreg) of reg / dyn_cnt (region
     // r = kind * regB + graph; kinds ff, pf, fp, pa); ngroups4 / ngroups8 = capacity in groups of 4 / 8 slots (the grid)

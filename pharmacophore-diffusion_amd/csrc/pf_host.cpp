@@ -292,6 +292,8 @@ struct pf_handle {
     bool train_rg_head = true;              // PFDYN_TRAIN_TILE_HEAD=1: the training forward's noise head on the tile kernel (the backward recomputes it)
     float *t_hsv_z = nullptr, *t_hsv_g = nullptr, *t_hsv_v = nullptr;   // head levels saved by the training forward [n_noise_gvps][Nf][128 / 16 / 48]
     bool t_head_saved = false;              // ... by the last pf_train_forward
+    bool train_bf16 = false;                // pf_train_set_precision: the bf16 leg (dense Linears of the message chains' forward and of every
+                                            // gradient kernel on bf16 matrix instructions; PFDYN_TRAIN_BF16=1 sets it at creation)
     bool train_node_save = true;            // PFDYN_TRAIN_NODE_RECOMPUTE=1: k_bwd_node recomputes the update chains instead of reading saved levels
     std::vector<float*> t_nsv_z, t_nsv_g, t_nsv_v;  // per conv layer: update-chain levels saved by the training forward [n_update_gvps][2 N][128 / 16 / 48]
     std::vector<char> t_node_saved;         // ... by the last pf_train_forward
@@ -356,6 +358,7 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_TRAIN_TILE_EDGE")) train_rg_edge = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_TRAIN_TILE_HEAD")) train_rg_head = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_TRAIN_NODE_RECOMPUTE")) train_node_save = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_TRAIN_BF16")) train_bf16 = atoi(e) != 0;
         pol.from_env();
     }
 
@@ -1067,7 +1070,9 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             if (shared) { e.need = h->d_need; e.need_stamp = h->edges_stamp; }
             for (int r = 0; r < e.nreg; ++r) { e.ngroups4 += region_groups(r, 4); e.ngroups8 += region_groups(r, 8); }
         }
-        int rg = train ? ((h->train_rg_edge && h->train_rg_node) ? h->pol.rg_mode(e.ntiles) : 0)
+        // (bf16 leg: the message chains run on the 32-slot tile kernel, whose to_feats_out / gate products have a bf16 form)
+        if (train && h->train_bf16) e.bf16 = 1;
+        int rg = train ? ((h->train_rg_edge && h->train_rg_node && !h->train_bf16) ? h->pol.rg_mode(e.ntiles) : 0)
                        : h->pol.rg_mode(shared ? (int)((h->share_rows + 31) / 32) : e.ntiles);           // the node launch of this layer follows (partial-row grouping)
         // static hoist: the hoisted ("pa") items of a compact layer-0 launch run a two-block chain and may take 8 rows
         // per wave while the full-chain items (ff, pf, fp) take 4
@@ -2688,6 +2693,7 @@ int pf_train_forward(pf_handle* h, const float* dev_prot_x, const float* dev_pha
     h->t_common.drop_scale = 1.0f / (1.0f - dropout_p);
     h->t_common.seed = seed;
     h->t_common.mask_override = h->t_mask_override; h->t_common.mask_N = h->N;
+    h->t_common.bf16 = h->train_bf16 ? 1 : 0;
     h->t_have_loss = false;
     load_state(h, dev_prot_x, dev_pharm_x, dev_pharm_h, s);
     pfk_copy(dev_t, h->d_t, (size_t)h->B, s);
@@ -2719,6 +2725,7 @@ int pf_train_loss_forward(pf_handle* h, const float* dev_pharm_x0, const float* 
     h->t_common.drop_scale = 1.0f / (1.0f - dropout_p);
     h->t_common.seed = seed;
     h->t_common.mask_override = h->t_mask_override; h->t_common.mask_N = h->N;
+    h->t_common.bf16 = h->train_bf16 ? 1 : 0;
     LossParams lp{};
     lp.B = h->B; lp.Np = h->Np; lp.Nf = h->Nf; lp.nf = h->cfg.pharm_nf; lp.T = n_timesteps; lp.remove_com = remove_com; lp.weighted = weighted_loss;
     lp.feat_norm = feat_norm;
@@ -2939,6 +2946,21 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PF_FAIL(h, PF_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     h->tA_dirty = false;
+    return PF_OK;
+}
+
+int pf_train_set_precision(pf_handle* h, int32_t precision) {
+    if (!h) return PF_ERR_ARG;
+    if (precision != PF_TRAIN_F32 && precision != PF_TRAIN_BF16) PF_FAIL(h, PF_ERR_ARG, "pf_train_set_precision: precision must be PF_TRAIN_F32 or PF_TRAIN_BF16");
+    h->train_bf16 = precision == PF_TRAIN_BF16;
+    h->t_have_fwd = false;                       // a forward of the other precision is not this backward's
+    h->t_have_loss = false;
+    return PF_OK;
+}
+
+int pf_train_get_precision(pf_handle* h, int32_t* precision) {
+    if (!h || !precision) return PF_ERR_ARG;
+    *precision = h->train_bf16 ? PF_TRAIN_BF16 : PF_TRAIN_F32;
     return PF_OK;
 }
 

@@ -33,6 +33,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PF_WPS_HEAD 1
 #endif
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// bf16 training leg (BASELINE config 5; no reference counterpart: the reference trains in fp32): the two dense Linears of a
+// GVP -- to_feats_out and scalar_to_vector_gates -- on v_mfma_f32_32x32x16_bf16, operands rounded to bf16 (round to nearest
+// even, v_cvt_pk_bf16_f32), fp32 accumulation.  One instruction covers eight f32 k-steps: lane half hl supplies the eight
+// k-values it would have fed to k-steps 8 kk .. 8 kk + 7 (A and B use the same assignment of K to (half, element), which is all
+// a dot product needs); the C/D layout is that of the f32 instruction, so the F-layout chain is unchanged.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ bf16x8 bf_pack8(const float (&x)[8]) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (__bf16)x[i];
+    return r;
+}
 
 // 1-ulp hardware reciprocal / sqrt / rsqrt (v_rcp_f32, v_sqrt_f32, v_rsq_f32): the IEEE-exact
 // expansions cost 10-15 VALU instructions each and parity is judged at 2e-4, not at 1 ulp.
@@ -66,7 +79,8 @@ __device__ __forceinline__ float siluf_(float x) { return x * rcpf_(1.0f + __exp
 __device__ __forceinline__ void store_vec_r(float* row, const int hl, const float (&V)[3][8]);
 //   SAVE   training forward: the pre-activation scalars Z, the gate pre-activations and the gated output vectors of
 //          this row are also written to sv_z [128] / sv_g [16] / sv_v [48] (what the level-by-level backward reads)
-template <int VI, int NEXTRA, int VO, int NMO, bool SIG, bool VROW0, bool PRE = false, bool SAVE = false>
+//   BF16   to_feats_out and the gate Linear on bf16 matrix instructions (training only: pf_train_set_precision)
+template <int VI, int NEXTRA, int VO, int NMO, bool SIG, bool VROW0, bool PRE = false, bool SAVE = false, bool BF16 = false>
 __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64], const float* ext,
                                           const float (&Vr)[3][8], const float* xhat,
                                           float (&s_out)[NMO * 16], float (&V_out)[3][8], const int lane,
@@ -132,12 +146,43 @@ __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64],
     }
     typedef float fragA __attribute__((ext_vector_type(NMO)));
     const fragA PF_AS1* ap = reinterpret_cast<const fragA PF_AS1*>(w.a_main) + KS0 * 64 + lane;
+    if constexpr (BF16) {
+        // eight f32 k-steps per instruction; the f32 fragments are rounded as they arrive (the packed table is shared with the
+        // f32 kernels: no second copy of the weights to keep current after every optimiser step)
+        constexpr int NKI = (NKS - KS0 + 7) / 8;
+#pragma unroll
+        for (int kk = 0; kk < NKI; ++kk) {
+            fragA af[8];
+            float b[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ks = KS0 + 8 * kk + i;
+                if (ks < NKS) af[i] = ap[(8 * kk + i) * 64];
+                else {
+#pragma unroll
+                    for (int mo = 0; mo < NMO; ++mo) af[i][mo] = 0.f;
+                }
+                if (ks < 64) b[i] = s_in[ks < 64 ? ks : 0];
+                else if (ks < 64 + NEXTRA / 2) b[i] = ext[(ks - 64) < (NEXTRA / 2 > 0 ? NEXTRA / 2 : 1) ? ks - 64 : 0];
+                else if (ks < NKS) b[i] = shsel[(ks - 64 - NEXTRA / 2) < NVK ? (ks - 64 - NEXTRA / 2) : 0];
+                else b[i] = 0.f;
+            }
+            const bf16x8 bb = bf_pack8(b);
+#pragma unroll
+            for (int mo = 0; mo < NMO; ++mo) {
+                float a8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a8[i] = af[i][mo];
+                acc[mo] = MFMA_BF(bf_pack8(a8), bb, acc[mo]);
+            }
+        }
+    }
     fragA abuf[2][CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i)
-        if (KS0 + i < NKS) abuf[0][i] = ap[i * 64];
+        if (!BF16 && KS0 + i < NKS) abuf[0][i] = ap[i * 64];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
+    for (int c = 0; c < (BF16 ? 0 : NCH); ++c) {
         if (c + 1 < NCH) {
 #pragma unroll
             for (int i = 0; i < CH; ++i)
@@ -173,12 +218,27 @@ __device__ __forceinline__ void gvp_apply(const GvpW w, const float (&s_in)[64],
     // ---- SiLU feeds the gate MFMAs just in time:  gate = Wg feats_out + bg      (gvp.py:105-111)
     constexpr int NG = NMO * 16;
     constexpr int LOOK = 4;
-#pragma unroll
-    for (int q = 0; q < LOOK; ++q) s_out[q] = siluf_(acc[q / 16][q % 16]);
     f32x16 g;
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = 0.f;
-    {
+    if constexpr (BF16) {
+        pf_gcf gp = w.a_gate + lane;
+#pragma unroll
+        for (int kk = 0; kk < NG / 8; ++kk) {
+            float a8[8], b8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                a8[i] = gp[(8 * kk + i) * 64];
+                b8[i] = siluf_(acc[(8 * kk + i) / 16][(8 * kk + i) % 16]);
+                s_out[8 * kk + i] = b8[i];
+            }
+            g = MFMA_BF(bf_pack8(a8), bf_pack8(b8), g);
+        }
+    } else {
+#pragma unroll
+    for (int q = 0; q < LOOK; ++q) s_out[q] = siluf_(acc[q / 16][q % 16]);
+    }
+    if constexpr (!BF16) {
         pf_gcf gp = w.a_gate + lane;
         float gbuf[2][CH];
 #pragma unroll
@@ -326,7 +386,7 @@ __device__ __forceinline__ int seg_tail(const int e, const int end) { return min
 // message rows (gvp.py:472-485, 540-551).  One wave per tile of 32 edge slots, all etypes in one
 // launch.  L0: conv layer 0, node vectors are identically zero.
 // ---------------------------------------------------------------------------------------------
-template <bool L0, bool SAVE = false>
+template <bool L0, bool SAVE = false, bool BF16 = false>
 __global__ __launch_bounds__(256, PF_WPS_EDGE) void k_edge_msg(const EdgeParams p) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
@@ -377,16 +437,16 @@ __global__ __launch_bounds__(256, PF_WPS_EDGE) void k_edge_msg(const EdgeParams 
         float s[64];
 #pragma unroll
         for (int q = 0; q < 64; ++q) s[q] = 0.f;
-        gvp_apply<17, PF_R, 16, 4, true, L0, true, SAVE>(wt[0], s, rb, V, xhat, s1, V1, lane, (pf_gcf)p.pre + (size_t)src * PF_S, svz, svg, svv);
+        gvp_apply<17, PF_R, 16, 4, true, L0, true, SAVE, BF16>(wt[0], s, rb, V, xhat, s1, V1, lane, (pf_gcf)p.pre + (size_t)src * PF_S, svz, svg, svv);
     } else {
         float s[64];
         load_row_f(p.h + (size_t)src * PF_S, hl, s);
-        gvp_apply<17, PF_R, 16, 4, true, L0, false, SAVE>(wt[0], s, rb, V, xhat, s1, V1, lane, nullptr, svz, svg, svv);
+        gvp_apply<17, PF_R, 16, 4, true, L0, false, SAVE, BF16>(wt[0], s, rb, V, xhat, s1, V1, lane, nullptr, svz, svg, svv);
     }
     for (int gi = 1; gi < p.n_gvps; ++gi) {
         float s2[64], V2[3][8];
         if constexpr (SAVE) { svz += p.sv_stride * PF_S; svg += p.sv_stride * 16; svv += p.sv_stride * 48; }
-        gvp_apply<16, 0, 16, 4, true, false, false, SAVE>(wt[gi], s1, nullptr, V1, nullptr, s2, V2, lane, nullptr, svz, svg, svv);
+        gvp_apply<16, 0, 16, 4, true, false, false, SAVE, BF16>(wt[gi], s1, nullptr, V1, nullptr, s2, V2, lane, nullptr, svz, svg, svv);
 #pragma unroll
         for (int q = 0; q < 64; ++q) s1[q] = s2[q];
 #pragma unroll
@@ -1856,6 +1916,11 @@ void pfk_noise_head_coop(const HeadParams* p, hipStream_t s) {
 void pfk_edge_msg(const EdgeParams* p, int layer0, hipStream_t s) {
     const int blocks = (p->ntiles + 3) / 4;
     if (blocks == 0) return;
+    if (p->sv_z != nullptr && p->bf16) {      // training forward of the bf16 leg
+        if (layer0) hipLaunchKernelGGL((k_edge_msg<true, true, true>), dim3(blocks), dim3(256), 0, s, *p);
+        else hipLaunchKernelGGL((k_edge_msg<false, true, true>), dim3(blocks), dim3(256), 0, s, *p);
+        return;
+    }
     if (p->sv_z != nullptr) {      // training forward: also write the per-level rows the backward pass reads
         if (layer0) hipLaunchKernelGGL((k_edge_msg<true, true>), dim3(blocks), dim3(256), 0, s, *p);
         else hipLaunchKernelGGL((k_edge_msg<false, true>), dim3(blocks), dim3(256), 0, s, *p);

@@ -64,6 +64,8 @@ struct TrainCommon {
     uint32_t seed;           // dropout stream of this step
     const float* mask_override;   // tests: multipliers [n_convs * 2 streams][N * 144] used instead of the hash, or NULL
     int mask_N;
+    int bf16;                // bf16 leg (pf_train_set_precision): to_feats_out / gate products of the gradient kernels on bf16 matrix
+                             // instructions (operands rounded to nearest even, fp32 accumulation); everything else stays fp32
 };
 
 struct BwdHeadParams {

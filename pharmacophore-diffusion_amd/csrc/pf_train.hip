@@ -29,6 +29,39 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CHAIN_FLOATS(nlv) ((nlv) * LVL_FLOATS + TR * ZS + WORK_FLOATS)
 #define PFT_WST_FLOATS 3200   // >= vi h + h vo + vo so of any GVP (h = max(vi, vo) <= 17: 17 x 17 + 17 x 16 + 16 x 128 = 2609)
 
+// ---- bf16 leg (TrainCommon::bf16): the products of to_feats_out and of the gate Linear run on v_mfma_f32_16x16x32_bf16 /
+// v_mfma_f32_16x16x16_bf16 with operands rounded to nearest even (v_cvt_pk_bf16_f32) and fp32 accumulation.  Lane (li, kq)
+// holds 8 (or 4) K-values of row / column li; A and B use the same assignment of K to (kq, element), which is all a dot
+// product needs, and the C/D layout is that of v_mfma_f32_16x16x4_f32 -- so the f32 code's fragment tables, LDS images and
+// accumulators are shared, only the operand fetch differs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 bf_pack8(const float (&x)[8]) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (__bf16)x[i];
+    return r;
+}
+__device__ __forceinline__ bf16x8 bf_pack8(const f32x4 lo, const f32x4 hi) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = (__bf16)lo[i]; r[4 + i] = (__bf16)hi[i]; }
+    return r;
+}
+__device__ __forceinline__ s16x4 bf_pack4(const float (&x)[4]) {
+    bf16x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (__bf16)x[i];
+    return __builtin_bit_cast(s16x4, r);
+}
+__device__ __forceinline__ f32x4 mfma_bf32(const bf16x8 a, const bf16x8 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const s16x4 a, const s16x4 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float t_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float t_silu(float x) { return x * t_sigmoid(x); }
 __device__ __forceinline__ float t_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -186,23 +219,54 @@ __device__ __forceinline__ void mm16_packed(const f32x4* P, const int mts, const
     }
 }
 
+// mm16_packed on bf16 matrix instructions (NSB even): instruction s covers k blocks 2 s and 2 s + 1 of the f32 table -- lane
+// (li, kq) holds A[.][16 (2 s) + 4 kq + t] and A[.][16 (2 s + 1) + 4 kq + t], t = 0..3, and fetches the same eight k of B
+template <int NSB, typename FB, typename FC>
+__device__ __forceinline__ void mm16_packed_bf(const f32x4* P, const int mts, const int nsb, FB b, FC c, const int lane, const int wv) {
+    static_assert(NSB % 2 == 0, "pairs of k blocks");
+    const int li = lane & 15, kq = lane >> 4;
+    for (int mt = wv; mt < mts; mt += NT / 64) {
+        const f32x4* pp = P + (size_t)mt * (NSB * 64) + lane;
+        f32x4 aq[NSB];
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) aq[sb] = pp[sb * 64];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sp = 0; sp < NSB / 2; ++sp)
+            if (2 * sp < nsb) {
+                const bool hi = 2 * sp + 1 < nsb;           // (block-uniform; beyond nsb the fragments are zero and B is not read)
+                float bv[8];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    bv[t] = b(32 * sp + 4 * kq + t, li);
+                    const float x = b(hi ? 32 * sp + 16 + 4 * kq + t : 32 * sp + 4 * kq + t, li);
+                    bv[4 + t] = hi ? x : 0.f;
+                }
+                acc = mfma_bf32(bf_pack8(aq[2 * sp], aq[2 * sp + 1]), bf_pack8(bv), acc);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c(mt * 16 + kq * 4 + r, li, acc[r]);
+    }
+}
+
 // G[M x N] += A^T-style weight gradient with the wave owning m tile wv (M <= 128): A[i][k] = a(i, k) is fetched once per wave for
 // the K = 16 rows of the unit and serves every n tile; fresh: the block's copy is known to be zero there (store, no read)
-template <typename FA, typename FB>
+template <bool BF16 = false, typename FA, typename FB>
 __device__ __forceinline__ void mm16_acc_rows(const int M, const int N, FA a, FB b, float* G, const int ld, const int lane, const int wv,
                                               const bool fresh) {
     const int li = lane & 15, kq = lane >> 4;
     if (wv * 16 >= M) return;
     const int ai = wv * 16 + li;
+    // (BF16: one v_mfma_f32_16x16x16_bf16 over the 16 rows, lane (li, kq) holding rows 4 kq + u; f32: four k-steps, rows 4 u + kq)
     float av[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const float x = a(min(ai, M - 1), 4 * u + kq); av[u] = ai < M ? x : 0.f; }
+    for (int u = 0; u < 4; ++u) { const float x = a(min(ai, M - 1), BF16 ? 4 * kq + u : 4 * u + kq); av[u] = ai < M ? x : 0.f; }
     const int nts = (N + 15) >> 4;
     for (int nt = 0; nt < nts; ++nt) {
         const int bj = nt * 16 + li;
         float bv[4], old[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const float x = b(4 * u + kq, min(bj, N - 1)); bv[u] = bj < N ? x : 0.f; }
+        for (int u = 0; u < 4; ++u) { const float x = b(BF16 ? 4 * kq + u : 4 * u + kq, min(bj, N - 1)); bv[u] = bj < N ? x : 0.f; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ci = wv * 16 + kq * 4 + r;
@@ -213,8 +277,11 @@ __device__ __forceinline__ void mm16_acc_rows(const int M, const int N, FA a, FB
             }
         }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF16) acc = mfma_bf16(bf_pack4(av), bf_pack4(bv), acc);
+        else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ci = wv * 16 + kq * 4 + r;
@@ -322,6 +389,7 @@ __device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, const Pac
 // backward of one GVP on the tile.  In: gA = dL/d act [row][so] (stride SWS), gVo = dL/d Vout [row][vo*3].
 // Out: gS = dL/d Sin[:, :si+h] (the first si entries are the input-scalar gradient), gVi = dL/d Vin.  gA and gVo are
 // overwritten (they become dL/dZ and dL/dVu).  Weight gradients are accumulated into gp (this block's copy).
+template <bool BF16>
 __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const PackPtr pk, const bool fresh, float* gp, const float* Sin, const float* Vin,
                                         const float* Z, const float* gate, const float* act, const int act_stride,
                                         float* gA, float* gS, float* gVo, float* gVi, float* Vh, float* Vu, float* gVh,
@@ -379,11 +447,16 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const Pac
     }
     __syncthreads();
     PFT_STAMP(14);
-    mm16_packed<8>(reinterpret_cast<const f32x4*>(pk.b) + (size_t)g.pk * (11 * 8 * 64), (KM + 15) >> 4, (SO + 15) >> 4,
-         [&](int k, int j) { return gA[j * SWS + k]; },
-         [&](int i, int j, float x) { if (i < KM) gS[j * SWS + i] = x; }, lane, wv);
+    if constexpr (BF16)
+        mm16_packed_bf<8>(reinterpret_cast<const f32x4*>(pk.b) + (size_t)g.pk * (11 * 8 * 64), (KM + 15) >> 4, (SO + 15) >> 4,
+             [&](int k, int j) { return gA[j * SWS + k]; },
+             [&](int i, int j, float x) { if (i < KM) gS[j * SWS + i] = x; }, lane, wv);
+    else
+        mm16_packed<8>(reinterpret_cast<const f32x4*>(pk.b) + (size_t)g.pk * (11 * 8 * 64), (KM + 15) >> 4, (SO + 15) >> 4,
+             [&](int k, int j) { return gA[j * SWS + k]; },
+             [&](int i, int j, float x) { if (i < KM) gS[j * SWS + i] = x; }, lane, wv);
     PFT_STAMP(15);
-    mm16_acc_rows(SO, KM,
+    mm16_acc_rows<BF16>(SO, KM,
          [&](int i, int k) { return gA[k * SWS + i]; },
          [&](int k, int j) { return Sin[k * SWS + j]; }, gp + g.o_Wm, KM, lane, wv, fresh);
     if (tid < SO) {
@@ -481,13 +554,14 @@ __device__ __forceinline__ void chain_load(const ChainLds& L, const GvpT* g, con
 }
 // backward through the chain: upstream gradients in L.gX ([row][so_last], stride SWS) and L.gVX; returns through
 // gs_out / gv_out the buffers that hold dL/d Sin(0) and dL/d Vin(0)
+template <bool BF16>
 __device__ __forceinline__ void chain_bwd(const ChainLds& L, const GvpT* g, const float* W, const PackPtr pk, const bool fresh, float* gp,
                                           float*& gs_out, float*& gv_out, const int tid, const int lane, const int wv, const bool fill_sh = false,
                                           float* wst = nullptr) {
     float *ga = L.gX, *gs = L.gY, *gvo = L.gVX, *gvi = L.gVY;
     for (int l = L.nlv - 1; l >= 0; --l) {
         const bool last = l == L.nlv - 1;
-        gvp_bwd(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+        gvp_bwd<BF16>(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
                 ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh, wst);
         float* t0 = ga; ga = gs; gs = t0;
         float* t1 = gvo; gvo = gvi; gvi = t1;
@@ -515,6 +589,7 @@ __device__ __forceinline__ float row_mean128(F f, float* red, const int tid) {
 // ---------------------------------------------------------------------------------------------
 // noise head backward (dynamics_gvp.py:37-42)
 // ---------------------------------------------------------------------------------------------
+template <bool BF16>
 __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
     __shared__ float lds[CHAIN_FLOATS(PFT_MAX_CHAIN)];
     __shared__ float s_ge[TR * 8];
@@ -584,7 +659,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
             __syncthreads();
             PFT_STAMP(43);
             float *gs, *gv;
-            chain_bwd(L, p.g, W, pk, unit == (int)blockIdx.x, gp, gs, gv, tid, lane, wv, saved, s_wst);
+            chain_bwd<BF16>(L, p.g, W, pk, unit == (int)blockIdx.x, gp, gs, gv, tid, lane, wv, saved, s_wst);
             PFT_STAMP(44);
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx >> 7, f = idx & 127;
@@ -671,6 +746,7 @@ __device__ __forceinline__ void vec_ln_bwd_par(const float* v, const VecLn* st, 
     }
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
     __shared__ float lds[CHAIN_FLOATS(NODE_LVLS)];
     __shared__ float xh1[TR * ZS], xh2[TR * ZS], gu[TR * ZS];
@@ -843,7 +919,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
             __syncthreads();
             PFT_STAMP(25);
             float *gs, *gv;
-            chain_bwd(L, g, W, pk, !seen[nt], gp, gs, gv, tid, lane, wv, saved);
+            chain_bwd<BF16>(L, g, W, pk, !seen[nt], gp, gs, gv, tid, lane, wv, saved);
             PFT_STAMP(26);
             seen[nt] = true;
             // ---- LN1 backward
@@ -1055,6 +1131,7 @@ __device__ __forceinline__ void mmcol(const int mts, FA a, FB b, FC c, const int
     }
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelParams p) {
     __shared__ __attribute__((aligned(16))) float Zb[ER * E2_ZS];
     __shared__ __attribute__((aligned(16))) float Sin[ER * E2_SS];
@@ -1273,15 +1350,23 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                 PFT_STAMP(33);
                 {   // ---- gZ = (gA + ggate Wg) SiLU'(Z) for features 16 wv .. +15 of all rows, on the accumulator fragments
                     E2_PHASE();
+                    // (BF16: the 16 gates are one v_mfma_f32_16x16x16_bf16, lane (li, kq) holding gates 4 kq + s)
                     float aw[4];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) aw[s] = sWg[(4 * s + kq) * 128 + wv * 16 + li];
+                    for (int s = 0; s < 4; ++s) aw[s] = sWg[(BF16 ? 4 * kq + s : 4 * s + kq) * 128 + wv * 16 + li];
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (BF16) {
+                            float gq[4];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) gq[s] = ggate[(16 * n + li) * GTS + 4 * kq + s];
+                            acc = mfma_bf16(bf_pack4(aw), bf_pack4(gq), acc);
+                        } else {
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
                             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s], ggate[(16 * n + li) * GTS + 4 * s + kq], acc, 0, 0, 0);
+                        }
                         const int row = 16 * n + li, f0 = wv * 16 + kq * 4;
                         float4* gap = reinterpret_cast<float4*>(gA + row * E2_SS + f0);
                         const float4 ga = *gap, z = *reinterpret_cast<const float4*>(Zb + row * E2_ZS + f0);
@@ -1295,10 +1380,21 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                         *gap = float4{o[0], o[1], o[2], o[3]};
                     }
                     // dWg tile (16 gates x features 16 wv .. +15) += ggate^T SiLU(Z)
+                    if constexpr (BF16) {                     // the 32 rows are one v_mfma_f32_16x16x32_bf16, lane (li, kq) holding rows 8 kq + u
+                        float a8[8], b8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int k = 8 * kq + u;
+                            a8[u] = ggate[k * GTS + li];
+                            b8[u] = t_silu(Zb[k * E2_ZS + wv * 16 + li]);
+                        }
+                        accWg = mfma_bf32(bf_pack8(a8), bf_pack8(b8), accWg);
+                    } else {
 #pragma unroll
                     for (int u = 0; u < ER / 4; ++u) {
                         const int k = 4 * u + kq;
                         accWg = __builtin_amdgcn_mfma_f32_16x16x4f32(ggate[k * GTS + li], t_silu(Zb[k * E2_ZS + wv * 16 + li]), accWg, 0, 0, 0);
+                    }
                     }
                     if (tid < VO) { float sm = 0.f; for (int r = 0; r < ER; ++r) sm += ggate[r * GTS + tid]; acc_bg += sm; }
                 }
@@ -1320,6 +1416,39 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                     __builtin_amdgcn_sched_barrier(0);
                     const float* b0p = gA + li * E2_SS + 4 * kq;
                     const float* b1p = gA + (16 + li) * E2_SS + 4 * kq;
+                    if constexpr (BF16) {
+                        // k blocks 2 s and 2 s + 1 of the f32 fragment table per instruction (lane (li, kq): features 32 s + 4 kq + t and
+                        // 32 s + 16 + 4 kq + t of both operands); the gZ pieces are shared by the wave's two m tiles
+                        bf16x8 bz0[4], bz1[4];
+#pragma unroll
+                        for (int sp = 0; sp < 4; ++sp) {
+                            bz0[sp] = bf_pack8(*reinterpret_cast<const f32x4*>(b0p + 32 * sp), *reinterpret_cast<const f32x4*>(b0p + 32 * sp + 16));
+                            bz1[sp] = bf_pack8(*reinterpret_cast<const f32x4*>(b1p + 32 * sp), *reinterpret_cast<const f32x4*>(b1p + 32 * sp + 16));
+                        }
+                        if (wv < nts) {
+                            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int sp = 0; sp < 4; ++sp) {
+                                const bf16x8 a = bf_pack8(aq0[2 * sp], aq0[2 * sp + 1]);
+                                acc0 = mfma_bf32(a, bz0[sp], acc0);
+                                acc1 = mfma_bf32(a, bz1[sp], acc1);
+                            }
+                            *reinterpret_cast<f32x4*>(gS + li * E2_SS + 16 * wv + 4 * kq) = acc0;
+                            *reinterpret_cast<f32x4*>(gS + (16 + li) * E2_SS + 16 * wv + 4 * kq) = acc1;
+                        }
+                        if (two) {
+                            const int mt = wv + NT / 64;
+                            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int sp = 0; sp < 4; ++sp) {
+                                const bf16x8 a = bf_pack8(aq1[2 * sp], aq1[2 * sp + 1]);
+                                acc0 = mfma_bf32(a, bz0[sp], acc0);
+                                acc1 = mfma_bf32(a, bz1[sp], acc1);
+                            }
+                            *reinterpret_cast<f32x4*>(gS + li * E2_SS + 16 * mt + 4 * kq) = acc0;
+                            *reinterpret_cast<f32x4*>(gS + (16 + li) * E2_SS + 16 * mt + 4 * kq) = acc1;
+                        }
+                    } else {
                     if (wv < nts) {
                         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1349,21 +1478,28 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                         *reinterpret_cast<f32x4*>(gS + li * E2_SS + 16 * mt + 4 * kq) = acc0;
                         *reinterpret_cast<f32x4*>(gS + (16 + li) * E2_SS + 16 * mt + 4 * kq) = acc1;
                     }
+                    }
                 }
                 PFT_STAMP(39);
                 {   // dWm tiles (features 16 wv .., inputs 16 x ..) += gZ^T [s, sh]
                     E2_PHASE();
+                    // (BF16: the 32 rows are one v_mfma_f32_16x16x32_bf16 per input tile, lane (li, kq) holding rows 8 kq + u)
                     float av[ER / 4];
 #pragma unroll
-                    for (int u = 0; u < ER / 4; ++u) av[u] = gA[(4 * u + kq) * E2_SS + wv * 16 + li];
+                    for (int u = 0; u < ER / 4; ++u) av[u] = gA[(BF16 ? 8 * kq + u : 4 * u + kq) * E2_SS + wv * 16 + li];
+                    bf16x8 avb;
+                    if constexpr (BF16) avb = bf_pack8(av);
 #pragma unroll
                     for (int x = 0; x < 11; ++x)
                         if (x < nts) {
                             float bv[ER / 4];
 #pragma unroll
-                            for (int u = 0; u < ER / 4; ++u) bv[u] = Sin[(4 * u + kq) * E2_SS + x * 16 + li];
+                            for (int u = 0; u < ER / 4; ++u) bv[u] = Sin[(BF16 ? 8 * kq + u : 4 * u + kq) * E2_SS + x * 16 + li];
+                            if constexpr (BF16) accWm[x] = mfma_bf32(avb, bf_pack8(bv), accWm[x]);
+                            else {
 #pragma unroll
                             for (int u = 0; u < ER / 4; ++u) accWm[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], accWm[x], 0, 0, 0);
+                            }
                         }
                     if (tid < SO) { float sm = 0.f; for (int r = 0; r < ER; ++r) sm += gA[r * E2_SS + tid]; acc_bm += sm; }
                 }
@@ -1904,15 +2040,18 @@ int pft_read_stamps(unsigned long long* host, int reset) {
 #endif
 void pfk_bwd_head(const BwdHeadParams* p, int nblocks, hipStream_t s) {
     if (p->ntiles == 0) return;
-    hipLaunchKernelGGL(k_bwd_head, dim3(nblocks), dim3(NT), 0, s, *p);
+    if (p->c.bf16) hipLaunchKernelGGL(k_bwd_head<true>, dim3(nblocks), dim3(NT), 0, s, *p);
+    else hipLaunchKernelGGL(k_bwd_head<false>, dim3(nblocks), dim3(NT), 0, s, *p);
 }
 void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s) {
     if (p->ntiles == 0) return;
-    hipLaunchKernelGGL(k_bwd_node, dim3(nblocks), dim3(NT), 0, s, *p);
+    if (p->c.bf16) hipLaunchKernelGGL(k_bwd_node<true>, dim3(nblocks), dim3(NT), 0, s, *p);
+    else hipLaunchKernelGGL(k_bwd_node<false>, dim3(nblocks), dim3(NT), 0, s, *p);
 }
 void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, int nblocks, hipStream_t s) {
     if (nblocks == 0 || p->et_tile0[p->n_et] == p->et_tile0[0]) return;
-    hipLaunchKernelGGL(k_bwd_edge_level, dim3(nblocks), dim3(NT), 0, s, *p);
+    if (p->c.bf16) hipLaunchKernelGGL(k_bwd_edge_level<true>, dim3(nblocks), dim3(NT), 0, s, *p);
+    else hipLaunchKernelGGL(k_bwd_edge_level<false>, dim3(nblocks), dim3(NT), 0, s, *p);
 }
 void pfk_compact_node_rows(const NodeTile* tiles, int ntiles, const int* dyn_cnt, const int* row_ids, int N, int* list, int cap, int* ucnt,
                            hipStream_t s) {

@@ -272,6 +272,19 @@ class PfEngine:
                                            float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
                                            _stream_ptr()), "pf_adam_step")
 
+    def set_train_precision(self, precision):
+        """'f32' (default; what the reference trains in) or 'bf16' (the labelled bf16 leg: dense Linears of the message chains'
+        forward and of the gradient kernels on bf16 matrix instructions, fp32 accumulation, fp32 master weights)."""
+        code = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}.get(str(precision).lower())
+        if code is None:
+            raise ValueError(f"train precision must be 'f32' or 'bf16', got {precision!r}")
+        self._ck(self.lib.pf_train_set_precision(self._h, code), "pf_train_set_precision")
+
+    def train_precision(self):
+        out = ctypes.c_int32(0)
+        self._ck(self.lib.pf_train_get_precision(self._h, ctypes.byref(out)), "pf_train_get_precision")
+        return "bf16" if out.value == 1 else "f32"
+
     def set_dropout_masks(self, masks):
         """tests: [n_convs, 2, N, 144] multipliers used instead of the built-in generator (None restores it)."""
         self._mask_keepalive = None if masks is None else _f32(masks, self.device)

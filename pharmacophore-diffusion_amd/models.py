@@ -225,6 +225,7 @@ class PharmRecDynamicsGVP(nn.Module):
                                "there is no CPU fallback")
         if self._engine is None or self._engine.device != dev:
             self._engine = PfEngine(device=dev, **self._arch)
+            self._engine.set_train_precision(getattr(self, "train_precision", "f32"))
             self._weights_stamp = None
             self._batch_key = None
             self._flat = None
@@ -240,6 +241,16 @@ class PharmRecDynamicsGVP(nn.Module):
             self._engine.set_flat_params(self._flat)
             self._weights_stamp = stamp
         return self._engine
+
+    def set_train_precision(self, precision: str):
+        """'f32' (default: what the reference trains in) or 'bf16' -- the labelled bf16 training leg (dense Linears of the message
+        chains' forward and of the gradient kernels on bf16 matrix instructions, fp32 accumulation, fp32 master weights and
+        optimiser).  No reference counterpart; inference is unaffected."""
+        if str(precision).lower() not in ("f32", "fp32", "float32", "bf16", "bfloat16"):
+            raise ValueError(f"train precision must be 'f32' or 'bf16', got {precision!r}")
+        self.train_precision = "bf16" if str(precision).lower() in ("bf16", "bfloat16") else "f32"
+        if self._engine is not None:
+            self._engine.set_train_precision(self.train_precision)
 
     def lane_engine(self, lane: int) -> PfEngine:
         """Engine of sampling lane ``lane``: lane 0 is engine(); further lanes are extra handles (own workspace) that carry

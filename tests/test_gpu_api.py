@@ -142,6 +142,41 @@ def test_training_step_gradients_match_reference_golden():
     assert live >= 150
 
 
+def test_bf16_training_leg_gradients_against_the_reference_golden():
+    """The same reference training_step through the bf16 leg (PharmRecDynamicsGVP.set_train_precision('bf16'); no reference
+    counterpart, the reference trains in fp32): loss within 1e-3 relative of the reference's, every parameter gradient with
+    cosine >= 0.999 and relative L2 error <= 2e-2 against the reference's own."""
+    z = load("train_grads.npz")
+    cfg = O.DynamicsConfig()
+    m = make_model(int(z["T"]))
+    m.train()
+    m.dynamics.set_train_precision("bf16")
+    b = batch_from(z)
+    g = graph_from(b, z["x0"], z["h0"]).to("cuda")
+    Np, Nf = int(b.prot_ptr[-1]), int(b.pharm_ptr[-1])
+    eng = m.dynamics.bind_graph(g)
+    assert eng.train_precision() == "bf16"
+    eng.set_dropout_masks(_golden_masks(z, cfg, Np, Nf))
+    loss = m.training_step(g, 0, t_int=z["t_int"].long(), eps={'h': z["eps_h"], 'x': z["eps_x"]})
+    ref_total = float(z["out_train_pos_loss"]) + float(z["out_train_feat_loss"])
+    assert abs(float(loss.detach()) - ref_total) <= 1e-3 * max(1.0, abs(ref_total))
+    loss.backward()
+    eng.set_dropout_masks(None)
+    live = 0
+    for k, p in m.named_parameters():
+        if p.numel() == 0 or not k.startswith("dynamics."):
+            continue
+        ref = z["grad_" + k].double().reshape(-1)
+        if float(ref.abs().max()) == 0.0:
+            continue
+        got = p.grad.cpu().double().reshape(-1)
+        live += 1
+        cos = float((ref * got).sum() / (ref.norm() * got.norm()))
+        rel = float((ref - got).norm() / ref.norm())
+        assert cos >= 0.999 and rel <= 2e-2, (k, cos, rel)
+    assert live >= 150
+
+
 def test_optimizer_steps_refresh_the_engine_and_reduce_the_loss():
     """Adam on the module's parameters (views of one flat device vector): after every step the engine sees the new
     values (device-side gather into the packed weights), the inference path agrees with the oracle on the updated

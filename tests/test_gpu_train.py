@@ -215,3 +215,111 @@ def test_training_forward_kernel_families_agree(name, monkeypatch):
         torch.testing.assert_close(res[0][0], other[0], rtol=2e-4, atol=2e-4)
         torch.testing.assert_close(res[0][1], other[1], rtol=2e-4, atol=2e-4)
         compare(res[0][2], {k: v for k, v in other[2].items()}, 2e-3, name)
+
+
+def _cos_rel(got, ref):
+    a, b = ref.double().reshape(-1), got.double().reshape(-1)
+    na = float(a.norm())
+    return float((a * b).sum() / (na * float(b.norm()) + 1e-300)), float((a - b).norm() / (na + 1e-300))
+
+
+@pytest.mark.parametrize("name", sorted(GRAD_CASES))
+def test_bf16_leg_gradients_against_the_fp32_path(name):
+    """The bf16 training leg (pf_train_set_precision(PF_TRAIN_BF16): to_feats_out / gate products of the message chains' forward
+    and of the gradient kernels on bf16 matrix instructions, fp32 accumulation) has no reference counterpart -- the reference
+    trains in fp32 (pharmacodiff.py:162-263).  Contract on the golden cases, same handle, same dropout masks: against the fp32
+    path (itself held to the oracle and the reference's gradients above) every tensor's gradient has cosine >= 0.999 and relative
+    L2 error <= 2e-2, the whole gradient vector cosine >= 0.9999; switching back to fp32 reproduces the fp32 gradients bit for
+    bit.  (tests/test_gpu_api.py holds the bf16 leg to the reference's own gradients, tests/test_gpu_fullsize.py to the oracle at
+    batch 256.)"""
+    z = load(name)
+    cfg = GRAD_CASES[name]
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    x_t, h_t, prot_x, t = noised_inputs(cfg, batch, z, int(z["T"]))
+    eng = make_engine(cfg, sd, batch)
+    gen = torch.Generator().manual_seed(6)
+    w_h, w_x = torch.randn(h_t.shape, generator=gen), torch.randn(x_t.shape, generator=gen)
+    res = {}
+    for mode in ("f32", "bf16", "f32 again"):
+        eng.set_train_precision(mode.split()[0])
+        assert eng.train_precision() == mode.split()[0]
+        eh, ex = eng.train_forward(x_t, h_t, t, prot_x=prot_x, dropout=0.1, seed=77)
+        res[mode] = (eh.cpu(), ex.cpu(), eng.train_backward(w_h, w_x).cpu())
+    assert torch.equal(res["f32"][2], res["f32 again"][2])
+    assert not torch.equal(res["f32"][2], res["bf16"][2])            # the bf16 kernels really ran
+    for q in (0, 1):
+        assert float((res["bf16"][q] - res["f32"][q]).norm() / res["f32"][q].norm()) <= 5e-3
+    g32, g16 = res["f32"][2], res["bf16"][2]
+    live = 0
+    for k, off, n in eng.param_layout():
+        r = g32[off:off + n]
+        if n == 0 or float(r.abs().max()) == 0.0:
+            continue
+        c, e = _cos_rel(g16[off:off + n], r)
+        live += 1
+        assert c >= 0.999 and e <= 2e-2, (name, k, c, e)
+    assert live >= 150
+    assert _cos_rel(g16, g32)[0] >= 0.9999
+
+
+def test_bf16_leg_rejects_a_backward_of_the_other_precision():
+    z = load(sorted(GRAD_CASES)[0])
+    cfg = GRAD_CASES[sorted(GRAD_CASES)[0]]
+    batch = batch_from(z)
+    eng = make_engine(cfg, O.make_state_dict(cfg, int(z["wseed"])), batch)
+    x_t, h_t, prot_x, t = noised_inputs(cfg, batch, z, int(z["T"]))
+    eh, ex = eng.train_forward(x_t, h_t, t, prot_x=prot_x, dropout=0.0, seed=1)
+    eng.set_train_precision("bf16")
+    with pytest.raises(Exception):
+        eng.train_backward(torch.zeros_like(eh), torch.zeros_like(ex))
+    with pytest.raises(ValueError):
+        eng.set_train_precision("fp8")
+
+
+def test_bf16_leg_loss_curve_tracks_fp32():
+    """200 optimiser steps (FlatAdam, dropout 0.1, a new noise draw and t every step from the same seeds) in both precisions: the
+    bf16 leg's loss, averaged over windows of 20 steps, stays within 2 % of the fp32 path's, and both go down."""
+    import pharmacoforge_amd as pfa
+    from pharmacoforge_amd import synthetic
+    B, n_prot, T = 32, 128, 100
+    dyn = dict(vector_size=16, n_convs=2, n_hidden_scalars=128, message_norm='mean', dropout=0.1, ff_k=0, pf_k=5,
+               n_message_gvps=3, n_update_gvps=2, n_noise_gvps=4)
+    pockets = [synthetic.synthetic_pocket(50 + i, n_prot) for i in range(B)]
+    sizes = [4 + (i % 5) for i in range(B)]
+    curves = {}
+    for mode in ("f32", "bf16"):
+        m = pfa.PharmacophoreDiff(6, 11, pfa.analysis.ph_idx_to_type, None, n_timesteps=T,
+                                  graph_config={'graph_cutoffs': {'pp': 3.5, 'pf': 8, 'fp': 8, 'ff': 9}}, dynamics_config=dyn,
+                                  precision=1e-5, lr_scheduler_config={'base_lr': 1e-3, 'weight_decay': 1e-12})
+        sd = dict(synthetic.make_state_dict(0))
+        sd["gamma.gamma"] = m.state_dict()["gamma.gamma"]
+        m.load_state_dict(sd, strict=True)
+        m = m.to("cuda").train()
+        m.dynamics.set_train_precision(mode)
+        eng = m.dynamics.engine()
+        assert eng.train_precision() == mode
+        gen = torch.Generator().manual_seed(11)
+        prot_x, prot_h = torch.cat([p[0] for p in pockets]), torch.cat([p[1] for p in pockets])
+        prot_ptr = torch.arange(B + 1, dtype=torch.int64) * n_prot
+        pharm_ptr = torch.tensor([0] + list(__import__("itertools").accumulate(sizes)), dtype=torch.int64)
+        pp_src, pp_dst = eng.build_pp_edges(prot_x.to("cuda"), prot_ptr)
+        Nf = int(pharm_ptr[-1])
+        x0 = torch.cat([pockets[i][0].mean(0, keepdim=True) + 2.0 * torch.randn(sizes[i], 3, generator=gen) for i in range(B)])
+        h0 = torch.nn.functional.one_hot(torch.randint(0, 6, (Nf,), generator=gen), 6).float()
+        g = pfa.PocketGraph(prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, pharm_x0=x0, pharm_h0=h0).to("cuda")
+        opt = pfa.FlatAdam(m.dynamics, lr=1e-3, weight_decay=1e-12)
+        torch.manual_seed(1234)
+        losses = []
+        for _ in range(200):
+            opt.zero_grad()
+            loss = m.training_step(g, 0)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        curves[mode] = torch.stack(losses).cpu().double()
+        assert bool(torch.isfinite(curves[mode]).all())
+    w32, w16 = curves["f32"].reshape(10, 20).mean(1), curves["bf16"].reshape(10, 20).mean(1)
+    assert float(w32[-1]) < 0.9 * float(w32[0]) and float(w16[-1]) < 0.9 * float(w16[0]), (w32, w16)
+    rel = ((w16 - w32).abs() / w32).max()
+    assert float(rel) <= 0.02, (w32, w16)

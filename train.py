@@ -43,6 +43,9 @@ def main():
     p.add_argument('--max_steps', type=int, default=None, help='stop after this many optimiser steps (smoke runs)')
     p.add_argument('--check_replicas', action='store_true',
                    help='data parallel: verify after every epoch that all ranks hold bitwise identical parameters')
+    p.add_argument('--train_precision', choices=['f32', 'bf16'], default='f32',
+                   help="arithmetic of the dense Linears in the training step: f32 (the reference's) or the bf16 leg (bf16 matrix "
+                        "instructions, fp32 accumulation, fp32 master weights and optimiser)")
     args = p.parse_args()
     import pharmacoforge_amd as pfa
     from pharmacoforge_amd.dataset import data_module_from_config
@@ -68,6 +71,7 @@ def main():
     if args.seed is not None:
         torch.manual_seed(args.seed)
     model = pfa.model_from_config(config).to(dev)
+    model.dynamics.set_train_precision(args.train_precision)
     lr_cfg = config['lr_scheduler']
     opt = pfa.FlatAdam(model.dynamics, lr=lr_cfg['base_lr'], weight_decay=lr_cfg.get('weight_decay', 0.0))
     plateau = dict(lr_cfg.get('reducelronplateau', {}))
