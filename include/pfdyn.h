@@ -295,8 +295,16 @@ int pf_debug_counts(pf_handle* h, int64_t* out /*[8]*/, pf_stream stream);
  * 32-row tile: k_edge_msg_coop / coop2).  layer == n_convs asks about the launch behind the last conv layer's edge messages:
  * when the last call was the dynamics call of a pf_denoise_step whose node update + noise head + sampler update + edge build
  * ran as ONE tail launch (one workgroup per graph): 4 (pf_rg.hip: k_rg_tail, two two-wave items of four centers) or 16
- * (pf_n16.hip: k_n16_tail, PFDYN_TAIL_FORM=n16); else 0 */
+ * (pf_n16.hip: k_n16_tail, PFDYN_TAIL_FORM=n16); 2 when the node + head items and the per-graph sampler update + edge build ran as
+ * different workgroups of one launch (pf_rg.hip: k_rg_node_hs_build, the default for small batches; PFDYN_HS_BUILD=0 switches it
+ * off); else 0 */
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave);
+/* k_rg_node_hs_build hands the noise prediction from its node + head workgroups to its update + build workgroups through polled
+ * exchange words; the poll loop is bounded, and a time-out (never observed: producers do not wait and the whole grid is resident)
+ * is counted here instead of hanging the device.  Synchronises the device.  A non-zero count means the trajectory is invalid. */
+int pf_debug_xchg_timeouts(pf_handle* h, int32_t* n);
+/* the noise prediction of the last dynamics call of a pf_denoise_step (what its sampler update consumed) */
+int pf_debug_last_eps(pf_handle* h, float* dev_eps_h /*[Nf,pharm_nf] or NULL*/, float* dev_eps_x /*[Nf,3] or NULL*/, pf_stream stream);
 /* static hoist of conv layer 0's protein-protein messages in the last dynamics call: *rows_per_wave = 0 (not used: training,
  * tile kernels, protein features that are not element one-hots, PFDYN_NO_L0_HOIST=1), 4 / 8 rows per hoisted wave (row-group
  * kernels: pp edges start at their second message GVP) or 16 (n16 kernels: pp AND pf edges start from a type-table row) */

@@ -345,7 +345,13 @@ struct HeadParams {
     int pharm_nf;
     float* eps_h;          // [Nf][pharm_nf]
     float* eps_x;          // [Nf][3]
+    // the merged node + head / update + build launch (k_rg_node_hs_build): eps of center f also goes, word by word with agent-scope
+    // stores, to xchg[f * PF_XCHG_STRIDE + (0..2: eps_x, 3..: eps_h)] -- every word is its own flag (PF_XCHG_EMPTY until written),
+    // which the graph's update + build workgroup of the SAME launch polls and re-arms.  NULL everywhere else.
+    unsigned int* xchg;
 };
+#define PF_XCHG_STRIDE 20
+#define PF_XCHG_EMPTY 0xffffffffu      // (a NaN pattern no arithmetic produces: hardware NaNs are 0x7fc00000 / 0xffc00000)
 
 struct EncodeParams {
     int Np, Nf;

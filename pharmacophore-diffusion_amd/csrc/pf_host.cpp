@@ -34,6 +34,8 @@ void pfk_rg_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, int r
 void pfk_l0_hoist(const L0HoistParams* p, int what, hipStream_t s);
 void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s);
 void pfk_rg_unit(const UnitParams* p, hipStream_t s);
+void pfk_rg_node_hs_build(const NodeParams* p, const HeadParams* hp, const StepParams* sp, const BuildParams* bp, int* xstat, int poll_sleep,
+                          int avoid, hipStream_t s);
 void pfk_n16_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, hipStream_t s);
 void pfk_n16_unit(const UnitParams* p, hipStream_t s);
 void pfk_n16_fused(const EdgeParams* p, const FusedParams* f, const EncodeParams* enc, hipStream_t s);
@@ -154,6 +156,9 @@ struct LaunchPolicy {
     int xcd_split = 1;
     int node_static = 1;                    // ... with its tiles computed, not loaded (k_rg_node_hs; PFDYN_NODE_STATIC=0: the tile-list kernel)
     int node_xcds = 2;                      // the fused node + head launch of a small batch runs on this many XCDs (PFDYN_NODE_XCDS; 0: all eight)
+    int xchg_sleep = 1, hsb_avoid = 0;      // its poll interval in units of ~0.2 us (PFDYN_XCHG_SLEEP); update + build workgroups kept off the first n XCDs (PFDYN_HSB_AVOID)
+    int hs_build = 1;                       // the merged last launch of a step (k_rg_node_hs_build: node + head items and the update + build of every
+                                            // graph as workgroups of one grid; PFDYN_HS_BUILD=0: two launches)
     int tail_form = 4;                      // 4: the row-group form (k_rg_tail: two two-wave items of four centers), 16: the n16 form (k_n16_tail)
     long n16_fuse_rows_max = 20000;         // the fused launch (bit 2): +2-3 % up to 32 graphs of 256 atoms, -4 % at 40 (its items carry five blocks: throughput-bound earlier)
     long n16_rows_max = 24000;              // measured at 256-atom pockets (575 slots per graph): +5 % at 16 graphs, +10 % at 32, -3..-5 % at 64, -15 % at 256
@@ -190,7 +195,7 @@ struct LaunchPolicy {
         geti("PFDYN_N16", n16_mask);
         geti("PFDYN_TAIL_GRAPHS_MAX", tail_graphs_max);
         geti("PFDYN_XCD_SPLIT", xcd_split);
-        geti("PFDYN_NODE_XCDS", node_xcds); geti("PFDYN_NODE_STATIC", node_static);
+        geti("PFDYN_NODE_XCDS", node_xcds); geti("PFDYN_NODE_STATIC", node_static); geti("PFDYN_HS_BUILD", hs_build); geti("PFDYN_XCHG_SLEEP", xchg_sleep); geti("PFDYN_HSB_AVOID", hsb_avoid);
         if (const char* e = getenv("PFDYN_TAIL_FORM")) tail_form = (e[0] == 'n' || atoi(e) == 16) ? 16 : 4;
         if (const char* e = getenv("PFDYN_N16_ROWS_MAX")) n16_rows_max = n16_fuse_rows_max = atol(e);
         if (const char* e = getenv("PFDYN_N16_FUSE_ROWS_MAX")) n16_fuse_rows_max = atol(e);
@@ -292,6 +297,9 @@ struct pf_handle {
     bool train_rg_head = true;              // PFDYN_TRAIN_TILE_HEAD=1: the training forward's noise head on the tile kernel (the backward recomputes it)
     float *t_hsv_z = nullptr, *t_hsv_g = nullptr, *t_hsv_v = nullptr;   // head levels saved by the training forward [n_noise_gvps][Nf][128 / 16 / 48]
     bool t_head_saved = false;              // ... by the last pf_train_forward
+    unsigned int* d_xchg = nullptr;         // exchange words of the merged launch [xchg_cap centers][PF_XCHG_STRIDE], all PF_XCHG_EMPTY between steps
+    int xchg_cap = 0;
+    int* d_xstat = nullptr;                 // [1] time-outs of the exchange (pf_debug_xchg_timeouts)
     bool train_bf16 = false;                // pf_train_set_precision: the bf16 leg (dense Linears of the message chains' forward and of every
                                             // gradient kernel on bf16 matrix instructions; PFDYN_TRAIN_BF16=1 sets it at creation)
     bool train_node_save = true;            // PFDYN_TRAIN_NODE_RECOMPUTE=1: k_bwd_node recomputes the update chains instead of reading saved levels
@@ -1220,7 +1228,31 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 hp.gvps = h->d_gvp + h->head_base(); hp.n_gvps = c.n_noise_gvps;
                 hp.a_out = h->d_w + h->out_a; hp.b_out = h->d_w + h->out_b; hp.pharm_nf = c.pharm_nf;
                 hp.eps_h = eps_h; hp.eps_x = eps_x;
-                { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node(&n, &hp, enc_fly ? &ep : nullptr, l == 0, rgn, nsplit, s); }
+                // a denoising step of a small batch: the step's update + build joins this launch as workgroups of its own (the fast
+                // build's shape: kNN pf edges, pockets of at most 512 atoms); timing the two separately needs the separate launches
+                const bool hsb = n.st_n > 0 && step != nullptr && h->pol.hs_build && enc_fly && c.pf_k > 0 && h->max_np <= 512 && c.pharm_nf <= 16 &&
+                                 h->step_build_fast && h->B <= 256 && !(h->prof_mask & (1u << pf_handle::K_STEP));
+                if (hsb) {
+                    if (h->xchg_cap < h->Nf) {
+                        PF_HIP(h, hipDeviceSynchronize());
+                        if (h->d_xchg) (void)hipFree(h->d_xchg);
+                        h->d_xchg = nullptr; h->xchg_cap = 0;
+                        const int want = h->Nf + h->Nf / 4 + 64;
+                        PF_HIP(h, hipMalloc((void**)&h->d_xchg, (size_t)want * PF_XCHG_STRIDE * sizeof(unsigned int)));
+                        PF_HIP(h, hipMemset(h->d_xchg, 0xff, (size_t)want * PF_XCHG_STRIDE * sizeof(unsigned int)));
+                        h->xchg_cap = want;
+                    }
+                    if (!h->d_xstat) {
+                        PF_HIP(h, hipMalloc((void**)&h->d_xstat, 64));
+                        PF_HIP(h, hipMemset(h->d_xstat, 0, 64));
+                    }
+                    hp.xchg = h->d_xchg;
+                    const bool share_next = (h->prune && c.n_convs == 2) && share_now(h);     // what the next denoising step's dynamics call will ask for
+                    const BuildParams bpn = build_params(h, share_next);
+                    { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node_hs_build(&n, &hp, step, &bpn, h->d_xstat, h->pol.xchg_sleep, h->pol.hsb_avoid, s); }
+                    build_done(h, share_next);
+                    h->tail_done = true; h->last_tail = 2;
+                } else { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node(&n, &hp, enc_fly ? &ep : nullptr, l == 0, rgn, nsplit, s); }
                 head_done = true;
             } else {
                 if (train && h->train_node_save) {
@@ -1344,6 +1376,8 @@ void pf_destroy(pf_handle* h) {
     if (h->d_gvp) (void)hipFree(h->d_gvp);
     if (h->d_flat) (void)hipFree(h->d_flat);
     if (h->d_wpack) (void)hipFree(h->d_wpack);
+    if (h->d_xchg) (void)hipFree(h->d_xchg);
+    if (h->d_xstat) (void)hipFree(h->d_xstat);
     if (h->d_tseg) (void)hipFree(h->d_tseg);
     if (h->d_gvpt) (void)hipFree(h->d_gvpt);
     if (h->d_map) (void)hipFree(h->d_map);
@@ -2990,6 +3024,24 @@ int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave) 
     }
     if (layer < 0 || layer >= (int)h->last_family.size()) PF_FAIL(h, PF_ERR_STATE, "pf_debug_kernel_family: no dynamics call yet, or bad layer");
     *rows_per_wave = h->last_family[layer];
+    return PF_OK;
+}
+
+int pf_debug_last_eps(pf_handle* h, float* dev_eps_h, float* dev_eps_x, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (dev_eps_h) PF_HIP(h, hipMemcpyAsync(dev_eps_h, h->d_eps_h, (size_t)h->Nf * h->cfg.pharm_nf * 4, hipMemcpyDeviceToDevice, s));
+    if (dev_eps_x) PF_HIP(h, hipMemcpyAsync(dev_eps_x, h->d_eps_x, (size_t)h->Nf * 3 * 4, hipMemcpyDeviceToDevice, s));
+    return PF_OK;
+}
+
+int pf_debug_xchg_timeouts(pf_handle* h, int32_t* n) {
+    if (!h || !n) return PF_ERR_ARG;
+    *n = 0;
+    if (!h->d_xstat) return PF_OK;
+    PF_HIP(h, hipDeviceSynchronize());
+    PF_HIP(h, hipMemcpy(n, h->d_xstat, sizeof(int32_t), hipMemcpyDeviceToHost));
     return PF_OK;
 }
 

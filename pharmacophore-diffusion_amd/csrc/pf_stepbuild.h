@@ -264,10 +264,29 @@ __device__ __forceinline__ void sb_load_c(SbPre<NT>& q, const BuildParams& p) {
         }
 }
 
+// the prefetched pp sources go to LDS first, in front of every store (see sb_load_b); their reader is the copy of the active
+// atoms' in-edges at the very end.  (A caller that has to wait for eps anyway -- k_rg_node_hs_build -- does this in front of its
+// wait: it is the first use of trip (C)'s loads, which the compiler otherwise sinks behind the wait.)
+template <int NT>
+__device__ __forceinline__ void sb_stage_sources(const SbPre<NT>& q, const BuildParams& p, StepBuildLds& L) {
+    constexpr int APT = SB_MAXA / NT;
+    const int tid = threadIdx.x;
+    if (p.act_ids && !p.pa_static) {                   // kernel-uniform
+#pragma unroll
+        for (int a = 0; a < APT; ++a) {
+            int4* st = reinterpret_cast<int4*>(&L.a_src[APT * tid + a][0]);
+            st[0] = make_int4(q.psrc[a][0], q.psrc[a][1], q.psrc[a][2], q.psrc[a][3]);
+            st[1] = make_int4(q.psrc[a][4], q.psrc[a][5], q.psrc[a][6], q.psrc[a][7]);
+            st[2] = make_int4(q.psrc[a][8], q.psrc[a][9], q.psrc[a][10], q.psrc[a][11]);
+            st[3] = make_int4(q.psrc[a][12], q.psrc[a][13], q.psrc[a][14], q.psrc[a][15]);
+        }
+    }
+}
+
 // NT threads (a multiple of 64, >= 256; SB_MAXA / NT atoms per thread), every thread of the workgroup calls it.
 // ex / eh: eps_x [3] and eps_h [nf] of center tid (threads tid < Nf), read by the caller from wherever the head left them.
 // Five LDS-only barriers: COM known | shifted coordinates in LDS | neighbour masks complete | scan totals | slot owners.
-template <int NT>
+template <int NT, bool STAGED = false>
 __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[3], const float (&eh)[SB_MAXNF], const int g,
                                           const StepParams& sp, const BuildParams& p, StepBuildLds& L) {
     constexpr int NW = NT / 64, APT = SB_MAXA / NT;
@@ -285,18 +304,7 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
     int pst[APT], pdeg[APT];
 #pragma unroll
     for (int a = 0; a < APT; ++a) { isp[a] = q.isp[a]; xp[a] = q.xp[a]; pst[a] = q.pst[a]; pdeg[a] = q.pdeg[a]; }
-    if (p.act_ids && !p.pa_static) {                   // kernel-uniform
-        // the prefetched pp sources go to LDS first, in front of every store (see sb_load_b); their reader is the copy of the
-        // active atoms' in-edges at the very end
-#pragma unroll
-        for (int a = 0; a < APT; ++a) {
-            int4* st = reinterpret_cast<int4*>(&L.a_src[APT * tid + a][0]);
-            st[0] = make_int4(q.psrc[a][0], q.psrc[a][1], q.psrc[a][2], q.psrc[a][3]);
-            st[1] = make_int4(q.psrc[a][4], q.psrc[a][5], q.psrc[a][6], q.psrc[a][7]);
-            st[2] = make_int4(q.psrc[a][8], q.psrc[a][9], q.psrc[a][10], q.psrc[a][11]);
-            st[3] = make_int4(q.psrc[a][12], q.psrc[a][13], q.psrc[a][14], q.psrc[a][15]);
-        }
-    }
+    if constexpr (!STAGED) sb_stage_sources<NT>(q, p, L);
     // ---- feature update of the pharm nodes (pharmacodiff.py:414-420; independent of everything else, inputs in registers)
     if (isf) {
 #pragma unroll
@@ -517,6 +525,67 @@ __device__ __forceinline__ void step_build_fast_body(const int g, const int* __r
     for (int k = 0; k < SB_MAXNF; ++k) eh[k] = (q.isf && k < sp.nf) ? eps.h((int)threadIdx.x, k) : 0.f;
     sb_load_c<NT>(q, p);
     sb_finish<NT>(q, ex, eh, g, sp, p, L);
+}
+
+// the same with eps arriving through the exchange words of a node + head item of the SAME launch (k_rg_node_hs_build): all three
+// trips are issued first, then the threads of the graph's centers poll their row's words (each word is its own flag: no ordering
+// between words is needed), take them and re-arm them for the next step.  Bounded: after SB_XCHG_POLLS rounds the thread counts a
+// time-out in xstat and goes on with zeros (the step's result is then invalid -- pf_debug_xchg_timeouts reports it).
+constexpr int SB_XCHG_POLLS = 1 << 16;
+template <int NT>
+__device__ __forceinline__ void step_build_wait_body(const int g, const int* __restrict__ a_prot_ptr, const int* __restrict__ a_pharm_ptr,
+                                                     const int* __restrict__ a_reg, const int a_B, const int a_Np_tot,
+                                                     const StepParams& sp, const BuildParams& p, unsigned int* xchg, int* xstat,
+                                                     StepBuildLds& L, const int poll_sleep) {
+    SbPre<NT> q;
+    sb_load_a<NT>(q, g, a_prot_ptr, a_pharm_ptr, a_reg, a_B, a_Np_tot, p);
+    sb_load_b<NT>(q, a_Np_tot, sp, p);
+    sb_load_c<NT>(q, p);
+    float ex[3] = {0.f, 0.f, 0.f}, eh[SB_MAXNF];
+#pragma unroll
+    for (int k = 0; k < SB_MAXNF; ++k) eh[k] = 0.f;
+    // everything the update + build reads is requested -- and has ARRIVED -- before the wait: the static sources go to LDS (their
+    // first use), the other rows are pinned in registers (an empty asm the compiler cannot move the loads across)
+    sb_stage_sources<NT>(q, p, L);
+    {
+        float4 pin = q.xf;
+#pragma unroll
+        for (int a = 0; a < SbPre<NT>::APT; ++a) { pin.x += q.xp[a].x; pin.y += q.xp[a].y; pin.z += q.xp[a].z; pin.w += (float)(q.pst[a] + q.pdeg[a]); }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pin.x += q.nzx[c];
+#pragma unroll
+        for (int k = 0; k < SB_MAXNF; ++k) pin.y += q.hv[k] + q.nzh[k];
+        asm volatile("" :: "v"(pin.x), "v"(pin.y), "v"(pin.z), "v"(pin.w) : "memory");
+    }
+    SB_STAMP(100);
+    if (q.isf) {
+        unsigned int* row = xchg + (size_t)(q.f0 + (int)threadIdx.x) * PF_XCHG_STRIDE;
+        unsigned int w[3 + SB_MAXNF];
+        bool ok = false;
+        for (int it = 0; it < SB_XCHG_POLLS; ++it) {
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < 3 + SB_MAXNF; ++k) {
+                w[k] = PF_XCHG_EMPTY;
+                if (k < 3 + sp.nf) {
+                    w[k] = __hip_atomic_load(row + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && w[k] != PF_XCHG_EMPTY;
+                }
+            }
+            if (ok) break;
+            for (int z = 0; z < poll_sleep; ++z) __builtin_amdgcn_s_sleep(2);      // ~50 ns each: the words come from memory (agent scope), not from a cache
+        }
+        if (!ok) atomicAdd(xstat, 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ex[c] = ok ? __builtin_bit_cast(float, w[c]) : 0.f;
+#pragma unroll
+        for (int k = 0; k < SB_MAXNF; ++k) eh[k] = (ok && k < sp.nf) ? __builtin_bit_cast(float, w[3 + k]) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3 + SB_MAXNF; ++k)
+            if (k < 3 + sp.nf) __hip_atomic_store(row + k, PF_XCHG_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    SB_STAMP(101);
+    sb_finish<NT, true>(q, ex, eh, g, sp, p, L);
 }
 
 }  // namespace pfsb

@@ -403,6 +403,19 @@ class PfEngine:
         self._ck(self.lib.pf_debug_kernel_family(self._h, int(layer), ctypes.byref(r)), "pf_debug_kernel_family")
         return int(r.value)
 
+    def last_eps(self):
+        """(eps_h, eps_x) of the last denoising step's dynamics call."""
+        eh = torch.empty(self.Nf, self.pharm_nf, device=self.device); ex = torch.empty(self.Nf, 3, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_debug_last_eps(self._h, _dptr(eh), _dptr(ex), _stream_ptr()), "pf_debug_last_eps")
+        return eh, ex
+
+    def xchg_timeouts(self) -> int:
+        """Time-outs of the merged last launch's exchange (k_rg_node_hs_build); anything but 0 invalidates the trajectory."""
+        r = ctypes.c_int32()
+        self._ck(self.lib.pf_debug_xchg_timeouts(self._h, ctypes.byref(r)), "pf_debug_xchg_timeouts")
+        return int(r.value)
+
     def l0_hoist(self) -> int:
         """Rows per hoisted wave of conv layer 0's pp messages in the last dynamics call (0: static hoist not used)."""
         r = ctypes.c_int32()

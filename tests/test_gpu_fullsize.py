@@ -54,6 +54,7 @@ def test_config2_batch32_steps_vs_oracle_under_the_default_policy():
     coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
     x0, h0 = eng.sample(eng.coef_array(coef, reversed(range(n))), n, noise)          # s = 2, 1, 0
     assert (eng.kernel_family(0), eng.kernel_family(1), eng.l0_hoist()) == (16, 17, 16)
+    assert eng.kernel_family(2) == 2 and eng.xchg_timeouts() == 0             # the step ends in the merged node + head / update + build launch
     ne = eng.work()[2]
     assert ne[1] == 5 * Nf and ne[2] == ne[1] and ne[3] == batch.pp_src.numel()
     bidx = batch.batch_idxs()
@@ -394,6 +395,7 @@ def test_config2_whole_T500_reverse_process_vs_oracle():
     coef = O.step_coefficients(O.gamma_table(T, prec), T)
     res = eng.sample(eng.coef_array(coef, reversed(range(T))), T, noise, trajectory=True)
     assert (eng.kernel_family(0), eng.kernel_family(1), eng.l0_hoist()) == (16, 17, 16)
+    assert eng.kernel_family(2) == 2 and eng.xchg_timeouts() == 0
     ne = eng.work()[2]                                                        # edges of the last dynamics call (step s = 0)
     # (most ordered pairs of centers are within the 9 A ff cutoff at the end; every center keeps its 5 nearest atoms)
     assert 0.85 * B * 6 * 5 <= ne[0] <= B * 6 * 5 and ne[1] == 5 * Nf and ne[2] == ne[1] and ne[3] == batch.pp_src.numel()

@@ -68,14 +68,17 @@ def test_conv_layer_nonzero_vectors(name):
     close(hf, z["conv_out_h_pharm"]); close(vf, z["conv_out_v_pharm"])
 
 
-TAIL_FORMS = {"rg": 4, "n16": 16, "off": 0}      # PFDYN_TAIL_FORM -> pf_debug_kernel_family(n_convs)
+TAIL_FORMS = {"rg": 4, "n16": 16, "merged": 2, "off": 0}      # form of a step's end -> pf_debug_kernel_family(n_convs)
 
 
 def set_tail(monkeypatch, tail):
-    """The end of a denoising step: one tail launch (row-group form, the default, or the n16 form) or separate launches."""
-    if tail != "off":                  # (off = the default policy)
+    """The end of a denoising step: the merged launch (the default policy: node + head items and every graph's update + build as
+    workgroups of one grid, k_rg_node_hs_build), one tail launch per graph (row-group or n16 form), or separate launches."""
+    if tail in ("rg", "n16"):
         monkeypatch.setenv("PFDYN_N16", "15")
         monkeypatch.setenv("PFDYN_TAIL_FORM", tail)
+    elif tail == "off":
+        monkeypatch.setenv("PFDYN_HS_BUILD", "0")
 
 
 @pytest.mark.parametrize("tail", list(TAIL_FORMS))
@@ -101,6 +104,7 @@ def test_trajectory_vs_golden(name, ep, tail, monkeypatch):
     traj = "pos_frames" in z
     res = eng.sample(arr, T, z["noise"], trajectory=traj, ep_coord=ep, ep_feat=ep)
     assert eng.kernel_family(cfg.n_convs) == TAIL_FORMS[tail]
+    assert eng.xchg_timeouts() == 0
     close(res[0], z["x0"], 5e-3, 5e-3); close(res[1], z["h0"], 5e-3, 5e-3)
     if traj:
         close(res[2], z["pos_frames"], 5e-3, 5e-3); close(res[3], z["feat_frames"], 5e-3, 5e-3)
@@ -130,6 +134,7 @@ def test_bounded_T500_trajectory_every_frame_absolute(tail, monkeypatch):
     coef = O.step_coefficients(O.gamma_table(T, prec), T)
     res = eng.sample(eng.coef_array(coef, reversed(range(T))), T, z["noise"], trajectory=True)
     assert eng.kernel_family(cfg.n_convs) == TAIL_FORMS[tail]
+    assert eng.xchg_timeouts() == 0
     for got, ref in ((res[0], z["x0"]), (res[1], z["h0"]), (res[2], z["pos_frames"]), (res[3], z["feat_frames"])):
         torch.testing.assert_close(got.cpu(), ref, rtol=0.0, atol=2e-2)
     Nf = int(batch.pharm_ptr[-1])
