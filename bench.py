@@ -514,7 +514,18 @@ def main():
             dk_match = dk_name.split(" ")[0].split(",")[0]
             dk_alg = dk_exec = PER_EDGE * l1_edges
     else:
-        dk_name, dk_match = "k_rg_node<false, ., true, .> / k_rg_node_hs (last conv layer's node update of the centers + noise head)", "k_rg_node"
+        merged = False
+        try:
+            merged = eng.kernel_family(len(wk["executed_edges_per_layer"])) == 2
+        except Exception:
+            pass
+        if merged:
+            dk_name = ("k_rg_node_hs_build (the step's last launch: the node + head items of the centers -- the only FLOPs counted -- and every "
+                       "graph's sampler update + edge build as workgroups of the same grid; ~14 us of its duration is the six-block chain, "
+                       "the rest the hand-over and the build)")
+        else:
+            dk_name = "k_rg_node<false, ., true, .> / k_rg_node_hs (last conv layer's node update of the centers + noise head)"
+        dk_match = "k_rg_node"
         dk_alg = dk_exec = (PER_NODE + HEAD_FLOP) * cnt["centers"]
     dk_tf = dk_alg / dk_avg_s / 1e12 if dk_avg_s > 0 else 0.0
 
