@@ -75,7 +75,7 @@ void pfk_compact_node_rows(const NodeTile* tiles, int ntiles, const int* dyn_cnt
                            hipStream_t s);
 void pfk_compact_rows(const EdgeTile* tiles, const int* et_tile0, int n_et, const int* dyn_cnt, int* rlist, int* ccnt, hipStream_t s);
 void pfk_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
-              float bc1, float bc2_sqrt, hipStream_t s);
+              float bc1, float bc2_sqrt, float* mirror, hipStream_t s);
 void pfk_drop_masks(const TrainCommon* c, uint32_t stream, int n_elems, float* out, hipStream_t s);
 void pfk_pp_radius(const float4* xn, const int* prot_ptr, int B, float r2, int maxn, int* deg, const int* row_off,
                    int* src, int* dst, int pass, hipStream_t s);
@@ -2573,7 +2573,7 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     for (int l = 0; l < L; ++l) { need((size_t)c.n_update_gvps * 2 * N * PF_S); need((size_t)c.n_update_gvps * 2 * N * 16); need((size_t)c.n_update_gvps * 2 * N * 48); }
     need((size_t)c.n_noise_gvps * std::max(h->Nf, 1) * PF_S); need((size_t)c.n_noise_gvps * std::max(h->Nf, 1) * 16);
     need((size_t)c.n_noise_gvps * std::max(h->Nf, 1) * 48);
-    need((size_t)h->t_nblk * h->nparams);
+    need((size_t)h->t_nblk * ((h->nparams + 63) / 64 * 64));
     const size_t Es = (size_t)std::max<int64_t>(h->Ecap, 1), ng = (size_t)c.n_message_gvps;
     for (int l = 0; l < L; ++l) { need(ng * Es * PF_S); need(ng * Es * 16); need(ng * Es * 48); }
     need(Es * PF_S); need(Es * 48);
@@ -2629,7 +2629,7 @@ static int ensure_train_ws(pf_handle* h, hipStream_t s) {
     h->t_hsv_z = carve<float>(cur, (size_t)c.n_noise_gvps * std::max(h->Nf, 1) * PF_S);
     h->t_hsv_g = carve<float>(cur, (size_t)c.n_noise_gvps * std::max(h->Nf, 1) * 16);
     h->t_hsv_v = carve<float>(cur, (size_t)c.n_noise_gvps * std::max(h->Nf, 1) * 48);
-    h->t_gpart = carve<float>(cur, (size_t)h->t_nblk * h->nparams);
+    h->t_gpart = carve<float>(cur, (size_t)h->t_nblk * ((h->nparams + 63) / 64 * 64));
     h->t_sv_z.assign(L, nullptr); h->t_sv_g.assign(L, nullptr); h->t_sv_v.assign(L, nullptr);
     for (int l = 0; l < L; ++l) {
         h->t_sv_z[l] = carve<float>(cur, ng * Es * PF_S); h->t_sv_g[l] = carve<float>(cur, ng * Es * 16);
@@ -2675,13 +2675,14 @@ int pf_param_layout(pf_handle* h, int32_t index, const char** name, int64_t* off
     return PF_OK;
 }
 
-int pf_set_flat_params(pf_handle* h, const float* dev_flat, pf_stream stream) {
+// copied: h->d_flat already holds the values (pf_adam_step's kernel wrote them)
+static int set_flat_params_impl(pf_handle* h, const float* dev_flat, pf_stream stream, bool copied) {
     int rc = check_ready(h, false);
     if (rc) return rc;
     if (!dev_flat) PF_FAIL(h, PF_ERR_ARG, "pf_set_flat_params: null argument");
     if (!h->d_map) PF_FAIL(h, PF_ERR_STATE, "pf_set_flat_params: no gather map (more than 2^24 parameters)");
     hipStream_t s = (hipStream_t)stream;
-    PF_HIP(h, hipMemcpyAsync(h->d_flat, dev_flat, h->nparams * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (!copied) PF_HIP(h, hipMemcpyAsync(h->d_flat, dev_flat, h->nparams * sizeof(float), hipMemcpyDeviceToDevice, s));
     const size_t n_now = (h->n16_begin > 0 && h->n16_begin < h->n_packed) ? h->n16_begin : h->n_packed;
     pfk_gather_weights(h->d_flat, h->d_map, n_now, h->d_w, s);
     h->n16_stale = n_now < h->n_packed;
@@ -2690,6 +2691,8 @@ int pf_set_flat_params(pf_handle* h, const float* dev_flat, pf_stream stream) {
     return PF_OK;
 }
 
+int pf_set_flat_params(pf_handle* h, const float* dev_flat, pf_stream stream) { return set_flat_params_impl(h, dev_flat, stream, false); }
+
 int pf_adam_step(pf_handle* h, float* dev_params, const float* dev_grad, float* dev_exp_avg, float* dev_exp_avg_sq,
                  int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay, pf_stream stream) {
     int rc = check_ready(h, false);
@@ -2697,9 +2700,10 @@ int pf_adam_step(pf_handle* h, float* dev_params, const float* dev_grad, float* 
     if (!dev_params || !dev_grad || !dev_exp_avg || !dev_exp_avg_sq || step < 1) PF_FAIL(h, PF_ERR_ARG, "pf_adam_step: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    const bool mirror = h->d_map != nullptr && dev_params != h->d_flat;
     pfk_adam(dev_params, dev_grad, dev_exp_avg, dev_exp_avg_sq, h->nparams, lr, beta1, beta2, eps, weight_decay, (float)bc1,
-             (float)std::sqrt(bc2), s);
-    return pf_set_flat_params(h, dev_params, stream);
+             (float)std::sqrt(bc2), mirror ? h->d_flat : nullptr, s);
+    return set_flat_params_impl(h, dev_params, stream, mirror);
 }
 
 int pf_get_flat_params(pf_handle* h, float* dev_flat, pf_stream stream) {
@@ -2721,6 +2725,7 @@ int pf_train_forward(pf_handle* h, const float* dev_prot_x, const float* dev_pha
     if (rc) return rc;
     h->t_common = TrainCommon{};
     h->t_common.W = h->d_flat; h->t_common.gpart = h->t_gpart; h->t_common.nparams = (int)h->nparams;
+    h->t_common.gstride = (int)((h->nparams + 63) / 64 * 64);
     h->t_common.tseg = h->d_tseg; h->t_common.ntens = h->n_tseg;
     h->t_common.gpart_enc = h->t_gpart_enc; h->t_common.enc_begin = h->enc_begin; h->t_common.enc_n = h->enc_n;
     h->t_common.drop_thr = dropout_p > 0.f ? (uint32_t)std::min(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
@@ -2753,6 +2758,7 @@ int pf_train_loss_forward(pf_handle* h, const float* dev_pharm_x0, const float* 
     h->t_have_loss = false;
     h->t_common = TrainCommon{};
     h->t_common.W = h->d_flat; h->t_common.gpart = h->t_gpart; h->t_common.nparams = (int)h->nparams;
+    h->t_common.gstride = (int)((h->nparams + 63) / 64 * 64);
     h->t_common.tseg = h->d_tseg; h->t_common.ntens = h->n_tseg;
     h->t_common.gpart_enc = h->t_gpart_enc; h->t_common.enc_begin = h->enc_begin; h->t_common.enc_n = h->enc_n;
     h->t_common.drop_thr = dropout_p > 0.f ? (uint32_t)std::min(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
@@ -2822,7 +2828,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     h->t_common.wpack_b = h->d_wpack; h->t_common.wpack_f = h->d_wpack + (size_t)h->n_gvpt * PFT_WPACK_FLOATS;
     const TrainCommon tc = h->t_common;
     ReduceParams rp{};
-    rp.gpart = h->t_gpart; rp.nparams = (int)h->nparams; rp.grad = dev_grad; rp.tseg = h->d_tseg; rp.ntens = h->n_tseg;
+    rp.gpart = h->t_gpart; rp.nparams = (int)h->nparams; rp.gstride = (int)((h->nparams + 63) / 64 * 64); rp.grad = dev_grad; rp.tseg = h->d_tseg; rp.ntens = h->n_tseg;
     rp.NB = nb; rp.ccnt = h->t_ccnt;
     rp.gpart_enc = h->t_gpart_enc; rp.enc_begin = h->enc_begin; rp.enc_n = h->enc_n;
     if (h->tA_dirty) PF_HIP(h, hipMemsetAsync(h->d_tA, 0, h->tA_capacity, s));      // an earlier pass stopped half way

@@ -42,6 +42,7 @@ struct GvpT {
 struct TensorSeg { int begin, end, cls, pad; };
 struct ReduceParams {
     const float* gpart; int nparams; float* grad;
+    int gstride;             // floats between consecutive gradient copies (nparams rounded up to a multiple of 64: 16-byte aligned rows)
     const float* gpart_enc; int enc_begin, enc_n;
     const TensorSeg* tseg; int ntens;
     int NB;                  // gradient copies = grid of the edge-level launches
@@ -53,8 +54,9 @@ struct ReduceParams {
 
 struct TrainCommon {
     const float* W;          // flat parameters
-    float* gpart;            // [gridDim.x][nparams]
+    float* gpart;            // [gridDim.x][gstride]
     int nparams;
+    int gstride;             // floats between consecutive copies (nparams rounded up to a multiple of 64)
     const TensorSeg* tseg; int ntens;
     float* gpart_enc; int enc_begin, enc_n;  // the encoders' parameters [enc_begin, enc_begin + enc_n) have their own, narrow gradient copies
                                              // [PFT_ENC_BLOCKS][enc_n]: k_bwd_encode is latency-bound per tile and runs several blocks per CU

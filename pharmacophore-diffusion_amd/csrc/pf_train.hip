@@ -12,6 +12,7 @@
 // data products and as the K dimension of the weight-gradient products.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <algorithm>
 #include "pf_train.h"
 
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     ChainLds L; L.init(lds, p.n_gvps);
     const float* W = p.c.W;
-    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
+    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.gstride;
     zero_class(p.c, gp, PFT_CLS_HEAD, threadIdx.x);
     const PackPtr pk = {p.c.wpack_f, p.c.wpack_b};
     const int NF = p.pharm_nf;
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     ChainLds L; L.init(lds, p.n_upd);
     const float* W = p.c.W;
-    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
+    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.gstride;
     zero_class(p.c, gp, PFT_CLS_NODE + p.layer, threadIdx.x);
     const PackPtr pk = {p.c.wpack_f, p.c.wpack_b};
     bool seen[2] = {false, false};          // weight-gradient tiles of a node type: the first unit stores onto the cleared copy without reading it
@@ -1160,7 +1161,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
     const GvpT g = p.g[et * p.n_gvps + p.level];
     const float* W = p.c.W;
     const f32x4* Wp = reinterpret_cast<const f32x4*>(p.wpack) + (size_t)(et * p.n_gvps + p.level) * (11 * 8 * 64);
-    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.nparams;
+    float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.gstride;
     const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;   // SO == 128, VO == 16; KH, VI <= 17 (message GVPs)
     const int nts = (KM + 15) >> 4;                  // <= 11
     const int mth = (KH + 15) >> 4, mti = (VI + 15) >> 4;
@@ -1851,6 +1852,7 @@ __global__ __launch_bounds__(1024) void k_reduce_enc(const ReduceParams p) {
         p.grad[p.enc_begin + i] = t;
     }
 }
+template <int UNR>
 __global__ void k_train_reduce(const ReduceParams p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.nparams) return;
@@ -1872,14 +1874,14 @@ __global__ void k_train_reduce(const ReduceParams p) {
     } else if (cls >= PFT_CLS_NODE) b1 = p.node_grid[cls - PFT_CLS_NODE];
     float s = 0.f;
     int b = b0;
-    for (; b + 8 <= b1; b += 8) {                    // eight copies in flight, summed in block order
-        float x[8];
+    for (; b + UNR <= b1; b += UNR) {                // UNR copies in flight, summed in block order
+        float x[UNR];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = __builtin_nontemporal_load(p.gpart + (size_t)(b + u) * p.nparams + i);
+        for (int u = 0; u < UNR; ++u) x[u] = __builtin_nontemporal_load(p.gpart + (size_t)(b + u) * p.gstride + i);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += x[u];
+        for (int u = 0; u < UNR; ++u) s += x[u];
     }
-    for (; b < b1; ++b) s += __builtin_nontemporal_load(p.gpart + (size_t)b * p.nparams + i);
+    for (; b < b1; ++b) s += __builtin_nontemporal_load(p.gpart + (size_t)b * p.gstride + i);
     p.grad[i] = s;
 }
 
@@ -1891,8 +1893,10 @@ __global__ void k_gather_weights(const float* flat, const int* map, const size_t
 
 // one Adam step (torch.optim.Adam semantics, pharmacodiff.py:253: L2 weight decay added to the gradient, bias-corrected
 // moments, no amsgrad) on flat vectors
+// (mirror: the handle's own copy of the flat parameter vector receives the new value in the same pass -- pf_adam_step used to copy
+// the 3 MB vector behind this kernel)
 __global__ void k_adam(float* p, const float* g, float* m, float* v, const size_t n, const float lr, const float b1,
-                       const float b2, const float eps, const float wd, const float bc1, const float bc2_sqrt) {
+                       const float b2, const float eps, const float wd, const float bc1, const float bc2_sqrt, float* mirror) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float gi = g[i];
@@ -1902,7 +1906,9 @@ __global__ void k_adam(float* p, const float* g, float* m, float* v, const size_
     const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - (lr / bc1) * (mi / denom);
+    const float pn = pi - (lr / bc1) * (mi / denom);
+    p[i] = pn;
+    if (mirror) mirror[i] = pn;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2091,16 +2097,18 @@ void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s) {
 }
 void pfk_train_reduce(const ReduceParams* p, hipStream_t s) {
     if (p->enc_n > 0 && ((p->cls_mask >> PFT_CLS_ENC) & 1u)) hipLaunchKernelGGL(k_reduce_enc, dim3((p->enc_n + 31) / 32), dim3(1024), 0, s, *p);
-    if (p->cls_mask & ~(1u << PFT_CLS_ENC)) hipLaunchKernelGGL(k_train_reduce, dim3((p->nparams + 255) / 256), dim3(256), 0, s, *p);
+    if (!(p->cls_mask & ~(1u << PFT_CLS_ENC))) return;
+    // 16 copies in flight per thread: 43 us per launch against 63 at 8 and 64 at 32 (16-byte loads, four parameters per thread: 97)
+    hipLaunchKernelGGL(k_train_reduce<16>, dim3((p->nparams + 255) / 256), dim3(256), 0, s, *p);
 }
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_gather_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flat, map, n, packed);
 }
 void pfk_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
-              float bc1, float bc2_sqrt, hipStream_t s) {
+              float bc1, float bc2_sqrt, float* mirror, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, mirror);
 }
 void pfk_drop_masks(const TrainCommon* c, uint32_t stream, int n_elems, float* out, hipStream_t s) {
     hipLaunchKernelGGL(k_drop_masks, dim3((n_elems + 255) / 256), dim3(256), 0, s, *c, stream, n_elems, out);
