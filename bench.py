@@ -691,12 +691,21 @@ def full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_ov
             lanes = batches_in_flight(args, eng2_factory, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, arr)
         except Exception as e:                                          # (e.g. no memory for the extra handles)
             lanes = {"error": f"{type(e).__name__}: {e}"}
-    return {"lanes": lanes, "bounded": bounded, "value": world * B * T / dt, "unit": "sample-steps/s", "T": T, "wall_ms": dt * 1e3, "ms_per_step": dt / T * 1e3,
-            "repetitions_ms": [round(t * 1e3, 3) for t in times], "finite": bool(torch.isfinite(x0).all() and torch.isfinite(h0).all()),
-            "max_abs_coordinate": float(x0.abs().max()),
-            "edges_last_step": dict(zip(("ff", "pf", "fp", "pp"), wk["edges"])),
-            "edges_computed_per_layer_last_step": wk["executed_edges_per_layer"],
-            "note": "whole T-step reverse process of the rank's batch through pf_sample, noise generation included"}
+    drifted = {"value": world * B * T / dt, "unit": "sample-steps/s", "wall_ms": dt * 1e3, "ms_per_step": dt / T * 1e3,
+               "repetitions_ms": [round(t * 1e3, 3) for t in times], "finite": bool(torch.isfinite(x0).all() and torch.isfinite(h0).all()),
+               "max_abs_coordinate": float(x0.abs().max()),
+               "edges_last_step": dict(zip(("ff", "pf", "fp", "pp"), wk["edges"])),
+               "edges_computed_per_layer_last_step": wk["executed_edges_per_layer"],
+               "note": "schedule precision 1e-5 with random-init weights: the centers drift out of the pockets (no ff edges at the end, "
+                       "fewer conv-layer-0 edges) -- a lighter workload than a trained model's, reported for continuity with rounds 1-3"}
+    # the figure of record is the bounded regime (what a trained model's trajectory looks like); the drifted one rides along
+    lead = bounded if bounded is not None else drifted
+    return {"lanes": lanes, "value": lead["value"], "unit": "sample-steps/s", "T": T, "wall_ms": lead["wall_ms"],
+            "ms_per_step": lead["wall_ms"] / T, "regime": "bounded (schedule precision 0.25)" if bounded is not None else "drifted (schedule precision 1e-5)",
+            "bounded": bounded, "drifted": drifted, "finite": lead["finite"], "max_abs_coordinate": lead["max_abs_coordinate"],
+            "edges_last_step": lead["edges_last_step"],
+            "note": "whole T-step reverse process of the rank's batch through pf_sample, noise generation included; `value` is the bounded "
+                    "regime's, where every center stays inside its pocket and the ff / pf / fp edges exist at every step"}
 
 
 def batches_in_flight(args, factory, coef, dev, rank, world, B, T, Nf, barrier, max_over_ranks, arr):

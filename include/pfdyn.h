@@ -301,7 +301,8 @@ int pf_debug_counts(pf_handle* h, int64_t* out /*[8]*/, pf_stream stream);
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave);
 /* k_rg_node_hs_build hands the noise prediction from its node + head workgroups to its update + build workgroups through polled
  * exchange words; the poll loop is bounded, and a time-out (never observed: producers do not wait and the whole grid is resident)
- * is counted here instead of hanging the device.  Synchronises the device.  A non-zero count means the trajectory is invalid. */
+ * is counted here instead of hanging the device.  Synchronises the device.  A non-zero count means the trajectory is invalid; the
+ * count also travels back behind every pf_sample_end and the next pf_sample_begin on the handle fails with PF_ERR_HIP if it was not 0. */
 int pf_debug_xchg_timeouts(pf_handle* h, int32_t* n);
 /* the noise prediction of the last dynamics call of a pf_denoise_step (what its sampler update consumed) */
 int pf_debug_last_eps(pf_handle* h, float* dev_eps_h /*[Nf,pharm_nf] or NULL*/, float* dev_eps_x /*[Nf,3] or NULL*/, pf_stream stream);

@@ -300,6 +300,8 @@ struct pf_handle {
     unsigned int* d_xchg = nullptr;         // exchange words of the merged launch [xchg_cap centers][PF_XCHG_STRIDE], all PF_XCHG_EMPTY between steps
     int xchg_cap = 0;
     int* d_xstat = nullptr;                 // [1] time-outs of the exchange (pf_debug_xchg_timeouts)
+    int* xstat_host = nullptr;              // pinned; an async copy of d_xstat follows every sampling run (pf_sample_end) and is looked at
+                                            // when the next one begins: a time-out there is reported, late but never silently
     bool train_bf16 = false;                // pf_train_set_precision: the bf16 leg (dense Linears of the message chains' forward and of every
                                             // gradient kernel on bf16 matrix instructions; PFDYN_TRAIN_BF16=1 sets it at creation)
     bool train_node_save = true;            // PFDYN_TRAIN_NODE_RECOMPUTE=1: k_bwd_node recomputes the update chains instead of reading saved levels
@@ -1378,6 +1380,7 @@ void pf_destroy(pf_handle* h) {
     if (h->d_wpack) (void)hipFree(h->d_wpack);
     if (h->d_xchg) (void)hipFree(h->d_xchg);
     if (h->d_xstat) (void)hipFree(h->d_xstat);
+    if (h->xstat_host) (void)hipHostFree(h->xstat_host);
     if (h->d_tseg) (void)hipFree(h->d_tseg);
     if (h->d_gvpt) (void)hipFree(h->d_gvpt);
     if (h->d_map) (void)hipFree(h->d_map);
@@ -2356,6 +2359,13 @@ int pf_sample_begin(pf_handle* h, const float* dev_init_pharm_com, const float* 
     int rc = check_ready(h, true);
     if (rc) return rc;
     if (!dev_noise0) PF_FAIL(h, PF_ERR_ARG, "pf_sample_begin: null noise");
+    if (h->xstat_host && *h->xstat_host != 0) {
+        const int n = *h->xstat_host;
+        *h->xstat_host = 0;
+        if (h->d_xstat) (void)hipMemset(h->d_xstat, 0, 64);
+        PF_FAIL(h, PF_ERR_HIP, "an earlier sampling run on this handle had %d time-out(s) in the merged launch's exchange (k_rg_node_hs_build): "
+                               "its results are invalid; PFDYN_HS_BUILD=0 uses the separate launches", n);
+    }
     hipStream_t s = (hipStream_t)stream;
     // init_prot_com = mean of the ORIGINAL protein coordinates (pharmacodiff.py:442)
     pfk_load_coords(h->d_prot_x0, h->d_xn, h->Np, h->d_gid, nullptr, 0.f, s);
@@ -2420,7 +2430,12 @@ int pf_sample_frame(pf_handle* h, float feat_norm_constant, float* dev_x, float*
 
 int pf_sample_end(pf_handle* h, float feat_norm_constant, float* dev_x0, float* dev_h0, pf_stream stream) {
     // x_0 = x_t - protein COM + initial protein COM ; h_0 = h_t * norm constant  (pharmacodiff.py:480-488)
-    return pf_sample_frame(h, feat_norm_constant, dev_x0, dev_h0, stream);
+    int rc = pf_sample_frame(h, feat_norm_constant, dev_x0, dev_h0, stream);
+    if (rc == PF_OK && h->d_xstat) {              // the merged launch ran on this handle: bring its time-out counter along
+        if (!h->xstat_host) { PF_HIP(h, hipHostMalloc((void**)&h->xstat_host, 64, hipHostMallocDefault)); *h->xstat_host = 0; }
+        PF_HIP(h, hipMemcpyAsync(h->xstat_host, h->d_xstat, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    }
+    return rc;
 }
 
 int pf_sample(pf_handle* h, int32_t n_steps, const pf_step_coef* host_coef, const float* dev_noise,
