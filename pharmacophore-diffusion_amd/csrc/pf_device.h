@@ -312,6 +312,9 @@ struct FusedParams {
     float* h_out; float* v_out;                      // conv layer 1's input state: written for the centers (the node + head launch reads it)
     const int* pharm_ptr; int Np, n_edge_items;      // store items: graph g's centers; items [0, n_edge_items) are edge items
     int xcd_split, nff_cap, npf_cap;                 // XCD-aware item assignment (k_n16_fused): capacities of the ff / pf regions in 16-slot groups
+    // every graph's ff / pf region has the same capacity (k_n16_fused_u): first region's start, stride between graphs' regions
+    // (ff | pf << 16), 16-slot groups per region (ff | pf << 8); uni_groups == 0: off
+    int uni_ff_base, uni_pf_base, uni_strides, uni_groups;
 };
 
 // n16 tail launch (pf_n16.hip: k_n16_tail; pf_denoise_step only): ONE workgroup per graph runs the last conv layer's node

@@ -156,6 +156,7 @@ struct LaunchPolicy {
     int xcd_split = 1;
     int node_static = 1;                    // ... with its tiles computed, not loaded (k_rg_node_hs; PFDYN_NODE_STATIC=0: the tile-list kernel)
     int node_xcds = 2;                      // the fused node + head launch of a small batch runs on this many XCDs (PFDYN_NODE_XCDS; 0: all eight)
+    int fused_uni = 1;                      // the fused launch's arithmetic tiling when every graph's regions have one capacity (PFDYN_FUSED_UNI)
     int xchg_sleep = 1, hsb_avoid = 0;      // its poll interval in units of ~0.2 us (PFDYN_XCHG_SLEEP); update + build workgroups kept off the first n XCDs (PFDYN_HSB_AVOID)
     int hs_build = 1;                       // the merged last launch of a step (k_rg_node_hs_build: node + head items and the update + build of every
                                             // graph as workgroups of one grid; PFDYN_HS_BUILD=0: two launches)
@@ -195,7 +196,7 @@ struct LaunchPolicy {
         geti("PFDYN_N16", n16_mask);
         geti("PFDYN_TAIL_GRAPHS_MAX", tail_graphs_max);
         geti("PFDYN_XCD_SPLIT", xcd_split);
-        geti("PFDYN_NODE_XCDS", node_xcds); geti("PFDYN_NODE_STATIC", node_static); geti("PFDYN_HS_BUILD", hs_build); geti("PFDYN_XCHG_SLEEP", xchg_sleep); geti("PFDYN_HSB_AVOID", hsb_avoid);
+        geti("PFDYN_NODE_XCDS", node_xcds); geti("PFDYN_NODE_STATIC", node_static); geti("PFDYN_HS_BUILD", hs_build); geti("PFDYN_FUSED_UNI", fused_uni); geti("PFDYN_XCHG_SLEEP", xchg_sleep); geti("PFDYN_HSB_AVOID", hsb_avoid);
         if (const char* e = getenv("PFDYN_TAIL_FORM")) tail_form = (e[0] == 'n' || atoi(e) == 16) ? 16 : 4;
         if (const char* e = getenv("PFDYN_N16_ROWS_MAX")) n16_rows_max = n16_fuse_rows_max = atol(e);
         if (const char* e = getenv("PFDYN_N16_FUSE_ROWS_MAX")) n16_fuse_rows_max = atol(e);
@@ -1134,6 +1135,24 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             fz.pharm_ptr = h->d_pharm_ptr; fz.Np = h->Np; fz.n_edge_items = e.ngroups_sel;
             for (int r = 0; r < e.nreg; ++r) (r < h->B ? fz.nff_cap : fz.npf_cap) += region_groups(r, 16);
             fz.xcd_split = ((h->pol.xcd_split & 1) && 2 * h->B <= 64 && h->max_nf <= 16) ? 1 : 0;
+            // every graph with regions of one capacity (the same number of centers everywhere): the regions of an etype sit at a fixed
+            // stride and the item map is arithmetic (k_n16_fused_u); PFDYN_FUSED_UNI=0: the work-list form
+            if (fz.xcd_split && h->pol.fused_uni && e.reg == h->d_reg && e.nreg == 2 * h->B) {
+                bool uni = true;
+                int stride[2] = {0, 0};
+                for (int et = 0; et < 2 && uni; ++et) {
+                    const size_t o = (size_t)et * h->B;
+                    if (h->B > 1) stride[et] = h->h_reg[o + 1] - h->h_reg[o];
+                    for (int g = 0; g < h->B && uni; ++g)
+                        uni = h->h_cap[o + g] == h->h_cap[o] && h->h_reg[o + g] == h->h_reg[o] + g * stride[et];
+                    uni = uni && stride[et] >= 0 && stride[et] < 65536 && (h->h_cap[o] + 15) / 16 < 256 && h->h_cap[o] > 0;
+                }
+                if (uni) {
+                    fz.uni_ff_base = h->h_reg[0]; fz.uni_pf_base = h->h_reg[(size_t)h->B];
+                    fz.uni_strides = stride[0] | (stride[1] << 16);
+                    fz.uni_groups = ((h->h_cap[0] + 15) / 16) | (((h->h_cap[(size_t)h->B] + 15) / 16) << 8);
+                }
+            }
             h->last_family[l] = 17;                      // pf_debug_kernel_family: 16-row items with conv layer 0's node update in front
             ProfScope ps(h, pf_handle::K_EDGE_LAST, s);
             pfk_n16_fused(&e, &fz, &ep, s);
