@@ -209,3 +209,45 @@ def test_tail_launch_steps_equal_separate_launches(case, monkeypatch):
         # the row-group tail runs the very code of the separate node + head launch: same bits
         for a, b in zip(states["tail_rg"][i], states["separate"][i]):
             assert torch.equal(a, b), (case, i)
+
+
+def test_fused_launch_arithmetic_tiling_equals_the_work_list_form(monkeypatch):
+    """The fused launch of a batch whose graphs all have the same number of centers maps items to (etype, graph, group) by arithmetic
+    on preloaded scalars (k_n16_fused_u: regions at a fixed stride, groups beyond a region's count leave at once); every other
+    batch -- and PFDYN_FUSED_UNI=0 -- walks the work list (k_n16_fused).  Same items, same code behind the map: three denoising
+    steps of a uniform batch agree bit for bit, edge lists included, and with the oracle within the single-call tolerance."""
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 5)
+    batch = O.synthetic_batch([810 + i for i in range(5)], 96, [6] * 5, cfg)
+    Nf = int(batch.pharm_ptr[-1])
+    T, n = 100, 3
+    noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(23))
+    coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+    out = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("PFDYN_FUSED_UNI", form)
+        eng = engine_for(cfg, sd)
+        set_batch(eng, batch)
+        arr = eng.coef_array(coef, [40, 39, 38])
+        eng.sample_begin(noise[0])
+        st = []
+        for i in range(n):
+            eng.denoise_step(arr[i], noise[i + 1])
+            assert eng.kernel_family(1) == 17                       # the fused launch ran
+            x, h = eng.sample_frame()
+            st.append((x.cpu(), h.cpu(), [tuple(t.clone() for t in eng.get_edges(et)) for et in range(3)]))
+        out[form] = st
+    for i in range(n):
+        assert torch.equal(out["1"][i][0], out["0"][i][0]) and torch.equal(out["1"][i][1], out["0"][i][1]), i
+        for et in range(3):
+            assert torch.equal(out["1"][i][2][et][0], out["0"][i][2][et][0]) and torch.equal(out["1"][i][2][et][1], out["0"][i][2][et][1])
+    # and against the oracle (the reference's semantics), first step
+    bidx = batch.batch_idxs()
+    init_com = O.segment_mean(batch.prot_x, batch.prot_ptr)
+    px = batch.prot_x - init_com[bidx["prot"]]
+    x_t, h_t = noise[0][:, :3].clone(), noise[0][:, 3:].clone()
+    with torch.no_grad():
+        px, x_t, h_t = O.sample_step(sd, cfg, batch, coef, 40, px, x_t, h_t, noise[1][:, :3], noise[1][:, 3:])
+    ox = x_t - O.segment_mean(px, batch.prot_ptr)[bidx["pharm"]] + init_com[bidx["pharm"]]
+    torch.testing.assert_close(out["1"][0][0], ox, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out["1"][0][1], h_t, rtol=1e-3, atol=1e-3)
