@@ -163,6 +163,7 @@ struct __attribute__((aligned(16))) N16Lds {
     float g[4 * 64 * 4];                      // K-split partial sums of the gate Linear per wave: [w][lane][r] = channel 4 g + r
     float v16[3 * 16];                        // first message GVP (17 hidden channels): Vh[16] per coordinate and row
     float vn[3 * 64 * 4];                     // GVPLayerNorm: squared vector components per coordinate (n16_layernorm)
+    float vx[4 * 16 * 48];                    // node updates: the first four vector partial rows of the 16 nodes, one per wave (n16_rows_sum)
 };
 
 // what the first message GVP of an edge needs besides the source row
@@ -669,15 +670,19 @@ struct NodeDesc { int st[2], cn[2], gm[2]; };
 // (measured: 4.4 us of the fused launch).  The quarters meet in LDS afterwards (n16_quarters_to_rows).
 // The first two partial rows of each segment leave in ONE batch of loads (absent: the all-zero row) -- at these in-degrees
 // that is all of them -- and longer segments finish in a loop.
+// The VECTOR partial rows (48 floats) are fetched whole, ONE of the four first rows per wave -- wave w: segment w >> 1, row w & 1;
+// lane (g, j): floats [12 g, 12 g + 12) of node j's row, three 16-byte loads -- and meet in LDS (n16_rows_sum): every wave
+// picking its coordinate out of every row with dword loads at a 12-byte stride cost ~900 cache-line requests per wave and item
+// against ~130 for the scalars, and a compute unit's vector memory path takes about one request per cycle.
 struct RowQ {
     f32x4 x[2][2][2];                           // [segment][row k][tile t]
-    float vv[2][2][4];
+    f32x4 vq[3];                                // this wave's vector partial row, floats [12 g, 12 g + 12)
     int nxt[2];
 };
 __device__ __forceinline__ void n16_rows_load(const float* msg_s, const float* msg_v, const int zero_row, const NodeDesc& nd, RowQ& q,
                                               const int lane, const int wq) {
     const int g = lane >> 4;
-    const int cw = wq < 3 ? wq : 0;
+    int rwv = zero_row;
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
         const int end = nd.st[sl] + nd.cn[sl], gm = nd.gm[sl];
@@ -688,19 +693,36 @@ __device__ __forceinline__ void n16_rows_load(const float* msg_s, const float* m
             const int rw = has ? min(e | gm, end - 1) : zero_row;
             const f32x4 PF_AS1* mp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)msg_s + (size_t)rw * PF_S + 32 * wq) + g;
             q.x[sl][k][0] = mp[0]; q.x[sl][k][1] = mp[4];
-            pf_gcf vp = (pf_gcf)msg_v + (size_t)rw * 48 + 12 * g + cw;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) q.vv[sl][k][r] = vp[3 * r];
+            rwv = (2 * sl + k == wq) ? rw : rwv;         // (wave-uniform choice of the row this wave fetches the vectors of)
             e = has ? rw + 1 : e;
         }
         q.nxt[sl] = e;
     }
+    const f32x4 PF_AS1* vp = reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)msg_v + (size_t)rwv * 48 + 12 * g);
+    q.vq[0] = vp[0]; q.vq[1] = vp[1]; q.vq[2] = vp[2];
 }
 // Q: this wave's two tiles of the sum; VB: coordinate wq of the vector sum
 __device__ __forceinline__ void n16_rows_sum(const float* msg_s, const float* msg_v, const int zero_row, const int norm_mode,
-                                             const NodeDesc& nd, const RowQ& q, f32x4 (&Q)[2], float (&VB)[4], const int lane, const int wq) {
-    const int g = lane >> 4;
+                                             const NodeDesc& nd, const RowQ& q, f32x4 (&Q)[2], float (&VB)[4], N16Lds* lds, const int lane,
+                                             const int wq) {
+    const int g = lane >> 4, j = lane & 15;
     const int cw = wq < 3 ? wq : 0;
+    // the four waves' vector rows meet: vx[wave][node j][48]; one barrier (the caller keeps barriers between this read and the
+    // next write: the node update's LayerNorms and blocks)
+    {
+        float* vw = &lds->vx[(wq * 16 + j) * 48 + 12 * g];
+        *reinterpret_cast<f32x4*>(vw) = q.vq[0];
+        *reinterpret_cast<f32x4*>(vw + 4) = q.vq[1];
+        *reinterpret_cast<f32x4*>(vw + 8) = q.vq[2];
+    }
+    lds_barrier();
+    float vv[2][2][4];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv[sl][k][r] = lds->vx[((2 * sl + k) * 16 + j) * 48 + 12 * g + 3 * r + cw];
     Q[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; Q[1] = Q[0];
 #pragma unroll
     for (int r = 0; r < 4; ++r) VB[r] = 0.f;
@@ -710,7 +732,7 @@ __device__ __forceinline__ void n16_rows_sum(const float* msg_s, const float* ms
         f32x4 ps0 = q.x[sl][0][0] + q.x[sl][1][0], ps1 = q.x[sl][0][1] + q.x[sl][1][1];
         float pv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pv[r] = q.vv[sl][0][r] + q.vv[sl][1][r];
+        for (int r = 0; r < 4; ++r) pv[r] = vv[sl][0][r] + vv[sl][1][r];
         int e = q.nxt[sl];
         while (__any(e < end)) {                          // (rows that are done add the all-zero row)
             const bool has = e < end;
@@ -783,7 +805,7 @@ __device__ __forceinline__ void n16_node_update_l0(const FusedParams& f, const E
         n16_encode_pharm(ep, (pf_gcf)ep.pharm_h + (size_t)(node - ep.Np) * ep.pharm_nf, tt, H, lds, lane, wq);
     }
     f32x4 Q[2];
-    n16_rows_sum(f.msg_s, f.msg_v, f.zero_row, f.norm_mode, nd, rq, Q, VB, lane, wq);
+    n16_rows_sum(f.msg_s, f.msg_v, f.zero_row, f.norm_mode, nd, rq, Q, VB, lds, lane, wq);
     N16_STAMP(sk, lane, wq);                              // partial rows summed
     N16_CUT_AT(FUSED_CUT, 2, Q[0][0] + VB[0] + Hq[0][0], f.h_out);
 #pragma unroll
@@ -1062,7 +1084,7 @@ __device__ __forceinline__ void n16_node_update_last(const TailParams& t, const 
     else if (t.norm_mode == 2) inv_norm = 1.0f / t.gnorm[1 * t.B + t.gid[node]];
     hook(0);
     f32x4 Q[2];
-    n16_rows_sum(t.msg_s, t.msg_v, t.zero_row, t.norm_mode, nd, rq, Q, VB, lane, wq);
+    n16_rows_sum(t.msg_s, t.msg_v, t.zero_row, t.norm_mode, nd, rq, Q, VB, lds, lane, wq);
     N16_STAMP(sk, lane, wq);                              // partial rows summed
     N16_CUT_AT(TAIL_CUT, 1, Q[0][0] + VB[0] + Hq[0][0] + Vr0[0], t.eps_h);
 #pragma unroll
