@@ -164,6 +164,7 @@ struct __attribute__((aligned(16))) N16Lds {
     float v16[3 * 16];                        // first message GVP (17 hidden channels): Vh[16] per coordinate and row
     float vn[3 * 64 * 4];                     // GVPLayerNorm: squared vector components per coordinate (n16_layernorm)
     float vx[4 * 16 * 48];                    // node updates: the first four vector partial rows of the 16 nodes, one per wave (n16_rows_sum)
+    float ln[4 * 128];                        // node updates: the two LayerNorms' weight / bias rows, requested when the item starts (n16_ln_stage)
 };
 
 // what the first message GVP of an edge needs besides the source row
@@ -624,7 +625,25 @@ __global__ __launch_bounds__(256) void k_n16_edge(const int* __restrict__ a_dyn_
 // coordinates of a channel, which live on three waves: the squares meet in LDS (lds->vn; one barrier).  Called by all
 // four waves (wave 3: VB = 0).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void n16_layernorm(pf_gcf lw, pf_gcf lb, float (&XS)[32], float (&VB)[4], N16Lds* lds, const int lane, const int wq) {
+// The LayerNorm parameters of a node update (2 x (weight, bias) x 128) are requested by the item's 256 threads the moment it starts,
+// two floats each, and parked in LDS in front of the first LayerNorm's barrier: loaded where they are used -- behind the chain's
+// scheduling barriers the compiler cannot move them up -- each LayerNorm opened with a cold round trip (~1 us).
+struct N16LnPre { float a, b; };
+__device__ __forceinline__ N16LnPre n16_ln_request(pf_gcf w1, pf_gcf b1, pf_gcf w2, pf_gcf b2, const int lane, const int wq) {
+    const int t = wq * 64 + lane;                         // 0..255: arrays 0 / 1 (first LayerNorm), then 2 / 3
+    N16LnPre q;
+    q.a = (t < 128 ? w1 : b1)[t & 127];
+    q.b = (t < 128 ? w2 : b2)[t & 127];
+    return q;
+}
+__device__ __forceinline__ void n16_ln_stage(const N16LnPre& q, N16Lds* lds, const int lane, const int wq) {      // (a barrier follows at the caller)
+    const int t = wq * 64 + lane;
+    lds->ln[t] = q.a;
+    lds->ln[256 + t] = q.b;
+}
+template <bool FROM_LDS = false>
+__device__ __forceinline__ void n16_layernorm(pf_gcf lw, pf_gcf lb, float (&XS)[32], float (&VB)[4], N16Lds* lds, const int lane, const int wq,
+                                              const int which = 0) {
     const int g = lane >> 4;
     float sum = 0.f;
 #pragma unroll
@@ -636,7 +655,14 @@ __device__ __forceinline__ void n16_layernorm(pf_gcf lw, pf_gcf lb, float (&XS)[
     const float rstd = rsqf_(gsum(var) * (1.0f / 128.0f) + 1e-5f);
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
-        const f32x4 w = *reinterpret_cast<const f32x4 PF_AS1*>(lw + 16 * T + 4 * g), b = *reinterpret_cast<const f32x4 PF_AS1*>(lb + 16 * T + 4 * g);
+        f32x4 w, b;
+        if constexpr (FROM_LDS) {
+            w = *reinterpret_cast<const f32x4*>(&lds->ln[256 * which + 16 * T + 4 * g]);
+            b = *reinterpret_cast<const f32x4*>(&lds->ln[256 * which + 128 + 16 * T + 4 * g]);
+        } else {
+            w = *reinterpret_cast<const f32x4 PF_AS1*>(lw + 16 * T + 4 * g);
+            b = *reinterpret_cast<const f32x4 PF_AS1*>(lb + 16 * T + 4 * g);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) XS[4 * T + r] = (XS[4 * T + r] - mean) * rstd * w[r] + b[r];
     }
@@ -786,6 +812,7 @@ __device__ __forceinline__ void n16_node_update_l0(const FusedParams& f, const E
     const int g = lane >> 4;
     // one batch of loads: the partial rows (this wave's quarter) and, for an atom, its quarter of the residual input -- the
     // encoder output of its element type, a row of the timestep's type table
+    const N16LnPre lnq = n16_ln_request(f.ln1_w[nt], f.ln1_b[nt], f.ln2_w[nt], f.ln2_b[nt], lane, wq);
     RowQ rq;
     n16_rows_load(f.msg_s, f.msg_v, f.zero_row, nd, rq, lane, wq);
     f32x4 Hq[2];
@@ -810,6 +837,7 @@ __device__ __forceinline__ void n16_node_update_l0(const FusedParams& f, const E
     N16_CUT_AT(FUSED_CUT, 2, Q[0][0] + VB[0] + Hq[0][0], f.h_out);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Q[0][r] = fmaf(Q[0][r], inv_norm, Hq[0][r]); Q[1][r] = fmaf(Q[1][r], inv_norm, Hq[1][r]); }
+    n16_ln_stage(lnq, lds, lane, wq);                    // (in front of the exchange's barrier)
     n16_quarters_to_rows(Q, XS, lds, lane, wq);          // (the first LayerNorm's barrier closes the reads)
     if (nt != 0) {
 #pragma unroll
@@ -817,7 +845,7 @@ __device__ __forceinline__ void n16_node_update_l0(const FusedParams& f, const E
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) VB[r] = wq < 3 ? VB[r] * inv_norm : 0.f;
-    n16_layernorm(f.ln1_w[nt], f.ln1_b[nt], XS, VB, lds, lane, wq);
+    n16_layernorm<true>(nullptr, nullptr, XS, VB, lds, lane, wq, 0);
     N16_STAMP(sk, lane, wq);                              // residual input + first LayerNorm
     float Xr[32], Vr[4];
 #pragma unroll
@@ -832,7 +860,7 @@ __device__ __forceinline__ void n16_node_update_l0(const FusedParams& f, const E
     for (int k = 0; k < 32; ++k) XS[k] += Xr[k];
 #pragma unroll
     for (int r = 0; r < 4; ++r) VB[r] += Vr[r];
-    n16_layernorm(f.ln2_w[nt], f.ln2_b[nt], XS, VB, lds, lane, wq);
+    n16_layernorm<true>(nullptr, nullptr, XS, VB, lds, lane, wq, 1);
 }
 
 // ---- store item of the fused launch: the centers [16 part, 16 part + 16) of graph gq
