@@ -55,6 +55,13 @@ for r in range(R):
         print(f"sample round {r + 1:3d}: {hist[-1]:9.1f} MiB in use on the device ({time.time() - t0:.0f} s)", flush=True)
 late = hist[len(hist) // 2:]
 print(f"sampling: max over the second half {max(late):.1f} MiB, min {min(late):.1f} MiB, first round {hist[0]:.1f} MiB")
+# the merged last launch of a step hands eps over through polled exchange words (k_rg_node_hs_build): no time-out on any handle, with
+# up to four batches in flight on as many streams
+engs = [m.dynamics.engine()] + [e[0] for e in m.dynamics.__dict__.get("_lane_engines", {}).values()]
+tmo = [e.xchg_timeouts() for e in engs]
+fam = [e.kernel_family(2) for e in engs]
+print(f"exchange time-outs per handle: {tmo}; form of the last step's end per handle (2 = merged launch): {fam}")
+assert sum(tmo) == 0
 
 # ---- training steps over changing batches (a new bind every step, FlatAdam as in bench.py --train)
 m.train()
@@ -77,6 +84,8 @@ for s in range(TS):
     x0 = torch.cat([xs[i].mean(0, keepdim=True) + 2.0 * torch.randn(sz[i], 3, generator=gen) for i in range(B)])
     h0 = torch.nn.functional.one_hot(torch.randint(0, 6, (Nf,), generator=gen), 6).float()
     g = pfa.PocketGraph(prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, pharm_x0=x0, pharm_h0=h0).to("cuda")
+    if s % 40 == 0:                                   # alternate the two precisions of the training step (a new forward each time)
+        m.dynamics.set_train_precision("bf16" if (s // 40) % 2 else "f32")
     opt.zero_grad()
     loss = m.training_step(g, 0)
     loss.backward(); opt.step()
