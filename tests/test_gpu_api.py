@@ -834,19 +834,37 @@ def test_pocket_claims_device_resident_batches_and_failed_binds():
         m.forward(g, 'val', t_int=bad_t, eps={'h': z["eps_h"], 'x': z["eps_x"]})
 
 
-def _bench_child(args, timeout=900):
-    """bench.py as a fresh child process (it starts its own ranks before touching the GPU); returns (returncode, last JSON line or None, stderr)."""
+def _bench_child(args, timeout=300):
+    """bench.py as a fresh child process (it starts its own ranks before touching the GPU); returns (returncode, last JSON line or None,
+    stderr).  Output goes to files (a rank that outlives its launcher keeps a pipe open and would hold the reader forever); a child
+    that does not finish in `timeout` seconds is killed with its whole process group and reported as a failure, never waited for."""
     import json
+    import signal
     import subprocess
+    import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
+    with tempfile.TemporaryDirectory() as td:
+        fo, fe = open(os.path.join(td, "out"), "w+"), open(os.path.join(td, "err"), "w+")
+        pr = subprocess.Popen([sys.executable, os.path.join(root, "bench.py")] + args, stdout=fo, stderr=fe, cwd=root, env=env,
+                              start_new_session=True)
+        try:
+            rc = pr.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(pr.pid, signal.SIGKILL)              # the launcher and the ranks it started (one session)
+            pr.wait()
+            rc = -9
+        fo.seek(0); fe.seek(0)
+        out, err = fo.read(), fe.read()
+        fo.close(); fe.close()
+    if rc == -9:
+        err += f"\n[test] bench.py {' '.join(args)} did not finish in {timeout} s and was killed"
     line = None
-    for ln in reversed(r.stdout.strip().splitlines()):
+    for ln in reversed(out.strip().splitlines()):
         if ln.strip().startswith("{"):
             line = json.loads(ln)
             break
-    return r.returncode, line, r.stderr
+    return rc, line, err
 
 
 @pytest.mark.parametrize("leg", ["headline", "train", "sample_slice"])
