@@ -165,6 +165,7 @@ struct __attribute__((aligned(16))) N16Lds {
     float vn[3 * 64 * 4];                     // GVPLayerNorm: squared vector components per coordinate (n16_layernorm)
     float vx[4 * 16 * 48];                    // node updates: the first four vector partial rows of the 16 nodes, one per wave (n16_rows_sum)
     float ln[4 * 128];                        // node updates: the two LayerNorms' weight / bias rows, requested when the item starts (n16_ln_stage)
+    float eln[2 * 128];                       // n16_encode_pharm: the encoder LayerNorm's weight / bias rows (requested with the encoder's inputs)
 };
 
 // what the first message GVP of an edge needs besides the source row
@@ -372,6 +373,10 @@ __device__ __forceinline__ void n16_encode_pharm(const EncodeParams& ep, pf_gcf 
     pf_gcf Wt = (pf_gcf)ep.w[1] + 32 * wq + 4 * g;                    // [nf + 1][128], input-major
     f32x4 z0 = *reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.b[1] + 32 * wq + 4 * g);
     f32x4 z1 = *reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.b[1] + 32 * wq + 16 + 4 * g);
+    // the LayerNorm's parameters leave with the encoder's inputs (one float per thread) and wait in LDS: loaded behind the
+    // barrier below, where they are used, they were a cold round trip of their own in every item that encodes centers
+    const int tl = wq * 64 + lane;
+    const float lnq = (tl < 128 ? (pf_gcf)ep.ln_w[1] : (pf_gcf)ep.ln_b[1])[tl & 127];
     // the encoder's inputs and weight rows are requested eight at a time with clamped indices (one round trip per batch: a
     // loop over the run-time input count would wait for every row in turn)
     for (int k0 = 0; k0 <= nf; k0 += 8) {
@@ -396,6 +401,7 @@ __device__ __forceinline__ void n16_encode_pharm(const EncodeParams& ep, pf_gcf 
     for (int r = 0; r < 4; ++r) { z0[r] = siluf_(z0[r]); z1[r] = siluf_(z1[r]); }
     *reinterpret_cast<f32x4*>(&lds->s[((2 * wq) * 64 + lane) * 4]) = z0;
     *reinterpret_cast<f32x4*>(&lds->s[((2 * wq + 1) * 64 + lane) * 4]) = z1;
+    lds->eln[tl] = lnq;
     lds_barrier();
     float sum = 0.f;
 #pragma unroll
@@ -411,8 +417,8 @@ __device__ __forceinline__ void n16_encode_pharm(const EncodeParams& ep, pf_gcf 
     const float rstd = rsqf_(gsum(var) * (1.0f / 128.0f) + 1e-5f);
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
-        const f32x4 lw = *reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.ln_w[1] + 16 * T + 4 * g);
-        const f32x4 lb = *reinterpret_cast<const f32x4 PF_AS1*>((pf_gcf)ep.ln_b[1] + 16 * T + 4 * g);
+        const f32x4 lw = *reinterpret_cast<const f32x4*>(&lds->eln[16 * T + 4 * g]);
+        const f32x4 lb = *reinterpret_cast<const f32x4*>(&lds->eln[128 + 16 * T + 4 * g]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) XS[4 * T + r] = (XS[4 * T + r] - mean) * rstd * lw[r] + lb[r];
     }
