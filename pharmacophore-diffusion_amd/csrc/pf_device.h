@@ -195,6 +195,10 @@ struct EdgeParams {
                            // groups are cut on absolute multiples of the group size (what the node kernel's e | (grp - 1) expects)
     // n16 kernels (pf_n16.hip): wave 0's quad stream of each etype's message chain; wave w's n16_stride[et] floats further
     pf_gcf n16[4]; int n16_stride[4];
+    // conv layer 0, every graph's ff / pf / fp region of one capacity (k_n16_edge_u): first region start per etype, strides
+    // (ff | pf << 16), stride_fp | groups_ff << 16 | groups_pf << 19 | groups_fp << 22 | (B - 1) << 25, capacity of the "pa" regions in 16-slot groups;
+    // uni_s2g == 0: off
+    int uni_base[3], uni_s01, uni_s2g, uni_pa_groups;
     int ptab16_off[4];     // conv layer 0: float offset of the etype's type table (bias folded in) inside ptab's slot, or -1
 };
 

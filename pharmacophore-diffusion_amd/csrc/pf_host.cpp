@@ -1119,6 +1119,26 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             if (l == 0) { e.zs = nullptr; rgp = 4; h->last_hoist = 16; }      // (ptab / ptype / l0_gid were set above)
             e.ngroups_sel = 0;
             for (int r = 0; r < e.nreg; ++r) e.ngroups_sel += region_groups(r, 16);
+            // conv layer 0, every graph with ff / pf / fp regions of one capacity: their items are mapped by arithmetic (k_n16_edge_u)
+            if (l == 0 && h->pol.fused_uni && !shared && e.reg == h->d_reg && e.nreg == 4 * h->B && h->B <= 64 && !e.pa_abs && !e.need) {
+                bool uni = true;
+                int stride[3] = {0, 0, 0}, grp[3] = {0, 0, 0};
+                for (int et = 0; et < 3 && uni; ++et) {
+                    const size_t o = (size_t)et * h->B;
+                    if (h->B > 1) stride[et] = h->h_reg[o + 1] - h->h_reg[o];
+                    for (int g = 0; g < h->B && uni; ++g)
+                        uni = h->h_cap[o + g] == h->h_cap[o] && h->h_reg[o + g] == h->h_reg[o] + g * stride[et];
+                    grp[et] = (h->h_cap[o] + 15) / 16;
+                    uni = uni && stride[et] >= 0 && stride[et] < 65536 && grp[et] > 0 && grp[et] < 8;
+                }
+                if (uni) {
+                    for (int et = 0; et < 3; ++et) e.uni_base[et] = h->h_reg[(size_t)et * h->B];
+                    e.uni_s01 = stride[0] | (stride[1] << 16);
+                    e.uni_s2g = stride[2] | (grp[0] << 16) | (grp[1] << 19) | (grp[2] << 22) | ((h->B - 1) << 25);
+                    e.uni_pa_groups = 0;
+                    for (int g = 0; g < h->B; ++g) e.uni_pa_groups += region_groups(3 * h->B + g, 16);
+                }
+            }
             rg = 4;                                  // 16 slots per partial-row group
         }
         h->last_family.resize(c.n_convs);

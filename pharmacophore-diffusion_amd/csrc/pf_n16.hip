@@ -479,17 +479,17 @@ __device__ __forceinline__ void n16_edge_chain(const EdgeParams& p, N16Ring& rin
 }
 
 // an item whose rows are gathered from global memory: slots -> (source, destination) -> coordinates / source rows -> type-table row
+// (e: the row's edge slot, src / dst its endpoints -- requested by the caller, with or ahead of the item's count)
 template <int KIND0>
-__device__ __forceinline__ void n16_edge_item(const EdgeParams& p, const EncodeParams& ep, N16Lds* lds, const int e0, const int nv,
-                                              const int et, const int lane, const int wq, int& sk) {
+__device__ __forceinline__ void n16_edge_item(const EdgeParams& p, const EncodeParams& ep, N16Lds* lds, const int e, const int src,
+                                              const int dst, const int nv, const int et, const int lane, const int wq, int& sk) {
     N16_STAMP(sk, lane, wq);                              // item known (work list scanned)
     N16Ring ring;
     ring_start(ring, p.n16[et] + (size_t)wq * p.n16_stride[et], lane);      // in flight under the gathers
-    const int g = lane >> 4, j = lane & 15;
+    const int g = lane >> 4;
     N16Rows rw;
-    rw.e = e0 + min(j, nv - 1);
-    const int src = p.esrc[rw.e];
-    rw.dst = p.edst[rw.e];
+    rw.e = e;
+    rw.dst = dst;
     rw.xs = p.xn[src]; rw.xd = p.xn[rw.dst];
     float XS[32], VB[4];
     f32x4 S[2];
@@ -617,12 +617,78 @@ __global__ __launch_bounds__(256) void k_n16_edge(const int* __restrict__ a_dyn_
             const int e = e0 + min(lane & 15, nv - 1);
             if (!__any(p.need[p.edst[e]] == p.need_stamp)) return;      // workgroup-uniform (every wave tests the same rows)
         }
-        if (et == ET_PP || et == ET_PF) n16_edge_item<N16_M0H>(p, ep, &lds, e0, nv, et, lane, wq, sk);
-        else n16_edge_item<N16_M0Z>(p, ep, &lds, e0, nv, et, lane, wq, sk);
-    } else n16_edge_item<N16_M0F>(p, ep, &lds, e0, nv, et, lane, wq, sk);
+        const int e = e0 + min(lane & 15, nv - 1);
+        const int src = p.esrc[e], dst = p.edst[e];
+        if (et == ET_PP || et == ET_PF) n16_edge_item<N16_M0H>(p, ep, &lds, e, src, dst, nv, et, lane, wq, sk);
+        else n16_edge_item<N16_M0Z>(p, ep, &lds, e, src, dst, nv, et, lane, wq, sk);
+    } else {
+        const int e = e0 + min(lane & 15, nv - 1);
+        n16_edge_item<N16_M0F>(p, ep, &lds, e, p.esrc[e], p.edst[e], nv, et, lane, wq, sk);
+    }
 #ifdef N16_TRACE
     if (g_n16_trace && threadIdx.x == 0) g_n16_trace[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
 #endif
+}
+
+// Conv layer 0 of a batch whose graphs all have ff / pf / fp regions of one capacity (the same number of centers everywhere; no pocket
+// sharing): the items of those regions -- the long ones: full first GVP on encoded centers, or the pf type-table form -- are mapped
+// by arithmetic on preloaded scalars, and with the edge arrays' addresses preloaded too their slots are requested the moment the
+// wave starts (groups beyond a region's count leave at once); the "pa" items behind them keep the work-list scan, over B regions
+// instead of 4 B.  Same item order as k_n16_edge's compact list: ff, pf, fp, pa.
+//   a_s01 = stride_ff | stride_pf << 16; a_s2g = stride_fp | groups_ff << 16 | groups_pf << 19 | groups_fp << 22 | (graphs - 1) << 25
+//   (the first eight arguments are preloaded: everything the static items' first loads need; a_reg, for the "pa" scan, is not)
+__global__ __launch_bounds__(256) void k_n16_edge_u(const int* __restrict__ a_dyn_cnt, const int* __restrict__ a_esrc,
+                                                    const int* __restrict__ a_edst, const int a_b0, const int a_b1, const int a_b2,
+                                                    const int a_s01, const int a_s2g, const int* __restrict__ a_reg,
+                                                    const EdgeParams p, const EncodeParams ep) {
+    __shared__ N16Lds lds;
+    const int lane = threadIdx.x & 63;
+    const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 15;
+    int sk = 0;
+    N16_STAMP(sk, lane, wq);                              // kernel entry
+    const int gff = (a_s2g >> 16) & 7, gpf = (a_s2g >> 19) & 7, gfp = (a_s2g >> 22) & 7, a_B = (int)((unsigned)a_s2g >> 25) + 1;
+    const int nff = a_B * gff, npf = a_B * gpf, nfp = a_B * gfp;
+    int w = (int)blockIdx.x;
+    if (w < nff + npf + nfp) {
+        int et, base, stride, gk;
+        if (w < nff) { et = ET_FF; base = a_b0; stride = a_s01 & 0xffff; gk = gff; }
+        else if (w < nff + npf) { w -= nff; et = ET_PF; base = a_b1; stride = (int)((unsigned)a_s01 >> 16); gk = gpf; }
+        else { w -= nff + npf; et = ET_FP; base = a_b2; stride = a_s2g & 0xffff; gk = gfp; }
+        const int g = w / gk, k = w - g * gk;
+        const int e0 = base + g * stride + 16 * k;
+        // one level: the region's count and the group's 16 slots (inside the region's 32-aligned capacity; slots beyond the count
+        // hold stale ids, which are never dereferenced: rows beyond nv shadow row nv - 1)
+        const int cnt = a_dyn_cnt[et * a_B + g];
+        const int src_raw = a_esrc[e0 + j], dst_raw = a_edst[e0 + j];
+        const int nv = __builtin_amdgcn_readfirstlane(min(16, cnt - 16 * k));
+        if (nv <= 0) return;                             // workgroup-uniform
+        const int jj = min(j, nv - 1);
+        const int from = 4 * ((lane & 48) | jj);
+        const int src = __builtin_amdgcn_ds_bpermute(from, src_raw), dst = __builtin_amdgcn_ds_bpermute(from, dst_raw);
+        if (et == ET_PF) n16_edge_item<N16_M0H>(p, ep, &lds, e0 + jj, src, dst, nv, et, lane, wq, sk);
+        else n16_edge_item<N16_M0Z>(p, ep, &lds, e0 + jj, src, dst, nv, et, lane, wq, sk);
+        return;
+    }
+    // ---- "pa" items: the (w - static items)-th non-empty 16-slot group of the B regions of kind 3 (one scan pass: B <= 64)
+    w -= nff + npf + nfp;
+    const int r = 3 * a_B + min(lane, a_B - 1);
+    const int c = lane < a_B ? a_dyn_cnt[r] : 0;
+    const int rs = a_reg[r];
+    const int ng = (c + 15) >> 4;
+    int incl = ng;
+    incl += dpp_i<0x111>(incl); incl += dpp_i<0x112>(incl); incl += dpp_i<0x114>(incl); incl += dpp_i<0x118>(incl);
+    incl += dpp_ir<0x142, 0xa>(incl); incl += dpp_ir<0x143, 0xc>(incl);
+    const unsigned long long m = __ballot(incl > w);
+    if (!m) return;                                      // workgroup-uniform: beyond the last group
+    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+    const int first = __builtin_amdgcn_readlane(incl - ng, l);
+    const int cnt = __builtin_amdgcn_readlane(c, l), start = __builtin_amdgcn_readlane(rs, l);
+    const int loc = (w - first) << 4;
+    const int e0 = start + loc;
+    const int nv = __builtin_amdgcn_readfirstlane(min(16, cnt - loc));
+    const int e = e0 + min(j, nv - 1);
+    n16_edge_item<N16_M0H>(p, ep, &lds, e, a_esrc[e], a_edst[e], nv, (int)ET_PP, lane, wq, sk);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1281,6 +1347,13 @@ void pfk_n16_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, hipS
     const int grid = p->nreg > 0 ? p->ngroups_sel : p->ntiles * 2;
     if (grid <= 0) return;
     const EncodeParams noenc{};
+    if (layer0 && p->uni_s2g != 0) {                     // ff / pf / fp regions at fixed strides: arithmetic tiling (k_n16_edge_u)
+        const int B = p->regB;
+        const int nstat = B * (((p->uni_s2g >> 16) & 7) + ((p->uni_s2g >> 19) & 7) + ((p->uni_s2g >> 22) & 7));
+        hipLaunchKernelGGL(k_n16_edge_u, dim3(nstat + p->uni_pa_groups), dim3(256), 0, s, p->dyn_cnt, p->esrc, p->edst, p->uni_base[0],
+                           p->uni_base[1], p->uni_base[2], p->uni_s01, p->uni_s2g, p->reg, *p, *enc);
+        return;
+    }
     if (layer0) hipLaunchKernelGGL((k_n16_edge<true>), dim3(grid), dim3(256), 0, s, p->dyn_cnt, p->reg, p->nreg, p->regB, p->pa_abs, *p, *enc);
     else hipLaunchKernelGGL((k_n16_edge<false>), dim3(grid), dim3(256), 0, s, p->dyn_cnt, p->reg, p->nreg, p->regB, p->pa_abs, *p, noenc);
 }

@@ -212,9 +212,10 @@ def test_tail_launch_steps_equal_separate_launches(case, monkeypatch):
 
 
 def test_fused_launch_arithmetic_tiling_equals_the_work_list_form(monkeypatch):
-    """The fused launch of a batch whose graphs all have the same number of centers maps items to (etype, graph, group) by arithmetic
-    on preloaded scalars (k_n16_fused_u: regions at a fixed stride, groups beyond a region's count leave at once); every other
-    batch -- and PFDYN_FUSED_UNI=0 -- walks the work list (k_n16_fused).  Same items, same code behind the map: three denoising
+    """The conv-layer-0 edge launch and the fused launch of a batch whose graphs all have the same number of centers map items to
+    (etype, graph, group) by arithmetic on preloaded scalars (k_n16_edge_u / k_n16_fused_u: regions at a fixed stride, groups beyond
+    a region's count leave at once, the edge slots requested with the wave's start); every other batch -- and PFDYN_FUSED_UNI=0 --
+    walks the work lists (k_n16_edge<true> / k_n16_fused).  Same items, same code behind the map: three denoising
     steps of a uniform batch agree bit for bit, edge lists included, and with the oracle within the single-call tolerance."""
     cfg = O.DynamicsConfig()
     sd = O.make_state_dict(cfg, 5)
