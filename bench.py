@@ -135,7 +135,7 @@ def step_launches(pmc, cnt, arch_dev, hoist16):
         alg = ex = None
         short = k[k.find("k_"):].split("(")[0]
         if arch_dev:
-            if "k_n16_edge<true>" in k:
+            if "k_n16_edge<true>" in k or "k_n16_edge_u" in k:
                 alg = PER_EDGE * l0
                 ex = alg - ((cnt["pa"] + cnt["pf"]) * (2.0 * 128 * 128 + 2.0 * 16 * 17 * 3) if hoist16 else 0.0)
             elif "k_n16_fused" in k:
@@ -180,7 +180,7 @@ def secondary_legs(args):
                                 "ms_per_pocket": j["config"]["ms_per_pocket"], "ms_per_step": j["ms_per_step"], **j.get("dominant", {})}
     else:
         out["config4_slice"] = {"error": err}
-    j, err = _child_json(me + light + ["--train", "--steps", "20", "--warmup", "4"])
+    j, err = _child_json(me + light + ["--train", "--steps", "40", "--warmup", "8"])
     if j:
         r = j["roofline"]
         out["train_step"] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
@@ -189,7 +189,7 @@ def secondary_legs(args):
     else:
         out["train_step"] = {"error": err}
     # the labelled bf16 leg of the same step (never the headline: the reference trains in fp32)
-    j, err = _child_json(me + light + ["--train", "--train-dtype", "bf16", "--steps", "20", "--warmup", "4"])
+    j, err = _child_json(me + light + ["--train", "--train-dtype", "bf16", "--steps", "40", "--warmup", "8"])
     if j:
         r = j["roofline"]
         out["train_step_bf16"] = {"workload": j["config"]["workload"], "dtype": "bf16", "value": j["value"], "unit": j["unit"],
@@ -419,7 +419,7 @@ def main():
         # rocprofv3's own durations (child pass, no counters) decide when they are there: an event pair stretches what it brackets
         # by 3-6 us, more on the small node + head launch than on the edge launches
         def cls_of(name):
-            if any(t in name for t in ("k_n16_edge<true>", "k_rg_edge<true", "k_edge_msg<true", "k_edge_msg_coop<true", "k_edge_msg_coop2<true")):
+            if any(t in name for t in ("k_n16_edge<true>", "k_n16_edge_u", "k_rg_edge<true", "k_edge_msg<true", "k_edge_msg_coop<true", "k_edge_msg_coop2<true")):
                 return l0_cls
             if any(t in name for t in ("k_n16_fused", "k_n16_edge<false>", "k_rg_edge<false", "k_edge_msg<false", "k_edge_msg_coop<false", "k_edge_msg_coop2<false")):
                 return "edge_msg_last"
@@ -474,7 +474,8 @@ def main():
     hoist_rows = eng.l0_hoist()
     # the template the launch really ran (pf_host.cpp: run_dynamics): the rocprofv3 kernel name starts with it
     if fam == 16:
-        dom_name, dom_match = "k_n16_edge<true> (conv layer 0: 16-row items on four waves, v_mfma_f32_16x16x4_f32)", "k_n16_edge<true>"
+        # (batches whose graphs all have the same number of centers run the arithmetic-tiling form k_n16_edge_u of the same items)
+        dom_name, dom_match = "k_n16_edge<true> / k_n16_edge_u (conv layer 0: 16-row items on four waves, v_mfma_f32_16x16x4_f32)", "k_n16_edge"
     elif fam in (4, 8):
         rg_a, rg_p = fam // 4, hoist_rows // 4
         dom_name = (f"k_rg_edge<true, {rg_a}, ., {rg_p}> (conv layer 0: {fam} rows per wave" +
