@@ -65,6 +65,8 @@ void pfk_fix_apply_rows(const NodeTile* tiles, int ntiles, const int* dyn_cnt, c
 void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* fix, hipStream_t s);
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
 void pfk_enc_group(const float* G_h, const int* prot_ptr, const int* ptype, int B, int rec_nf, float* Gg, hipStream_t s);
+void pfk_fix_enc_group(long long* A_h, float* G_h, const float* fix, const int* prot_ptr, const int* ptype, int B, int rec_nf, float* Gg,
+                       int Np, int Nf, hipStream_t s);
 void pfk_train_reduce(const ReduceParams* p, hipStream_t s);
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s);
 void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float* out_f, hipStream_t s);
@@ -303,6 +305,7 @@ struct pf_handle {
     int* d_xstat = nullptr;                 // [1] time-outs of the exchange (pf_debug_xchg_timeouts)
     int* xstat_host = nullptr;              // pinned; an async copy of d_xstat follows every sampling run (pf_sample_end) and is looked at
                                             // when the next one begins: a time-out there is reported, late but never silently
+    bool no_fix_fuse = false;               // PFDYN_NO_FIX_FUSE: k_fix_apply and k_enc_group as two launches (the A/B of k_fix_enc_group)
     bool train_bf16 = false;                // pf_train_set_precision: the bf16 leg (dense Linears of the message chains' forward and of every
                                             // gradient kernel on bf16 matrix instructions; PFDYN_TRAIN_BF16=1 sets it at creation)
     bool train_node_save = true;            // PFDYN_TRAIN_NODE_RECOMPUTE=1: k_bwd_node recomputes the update chains instead of reading saved levels
@@ -370,6 +373,7 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_TRAIN_TILE_HEAD")) train_rg_head = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_TRAIN_NODE_RECOMPUTE")) train_node_save = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_TRAIN_BF16")) train_bf16 = atoi(e) != 0;
+        if (const char* e = getenv("PFDYN_NO_FIX_FUSE")) no_fix_fuse = atoi(e) != 0;
         pol.from_env();
     }
 
@@ -390,6 +394,7 @@ struct pf_handle {
     float *t_G_h[2] = {nullptr, nullptr}, *t_G_v[2] = {nullptr, nullptr}, *t_gagg_s = nullptr, *t_gagg_v = nullptr,
           *t_gpart = nullptr, *t_geps_h = nullptr, *t_geps_x = nullptr;
     long long *t_A_h = nullptr, *t_A_v = nullptr;      // fixed-point accumulators of the level-0 scatter (kept clear between uses)
+    float* d_lpart = nullptr; size_t lpart_cap = 0;   // k_loss_eval's partial sums + its arrival counter (first 64 bytes)
     void* d_tA = nullptr;                   // their own allocation: it outlives the batches, so "kept clear" holds across them
     size_t tA_capacity = 0;                 // bytes
     bool tA_dirty = false;                  // a backward pass stopped between the scatter and pfk_fix_apply
@@ -832,6 +837,7 @@ static void free_ws(pf_handle* h, bool keep_ws = false) {
     if (h->d_ws && !keep_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; }
     if (h->d_tws && !keep_ws) { (void)hipFree(h->d_tws); h->d_tws = nullptr; h->tws_capacity = 0; }
     if (h->d_tA && !keep_ws) { (void)hipFree(h->d_tA); h->d_tA = nullptr; h->tA_capacity = 0; }
+    if (h->d_lpart && !keep_ws) { (void)hipFree(h->d_lpart); h->d_lpart = nullptr; h->lpart_cap = 0; }
     h->t_ws_ready = false;
     h->t_have_fwd = false;
     h->t_mask_override = nullptr;
@@ -2820,7 +2826,18 @@ int pf_train_loss_forward(pf_handle* h, const float* dev_pharm_x0, const float* 
     h->t_common.seed = seed;
     h->t_common.mask_override = h->t_mask_override; h->t_common.mask_N = h->N;
     h->t_common.bf16 = h->train_bf16 ? 1 : 0;
+    {
+        const size_t need = 64 + (size_t)((h->Nf + 63) / 64) * 8 * sizeof(float);
+        if (h->lpart_cap < need) {
+            PF_HIP(h, hipDeviceSynchronize());
+            if (h->d_lpart) { (void)hipFree(h->d_lpart); h->d_lpart = nullptr; h->lpart_cap = 0; }
+            PF_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->d_lpart), 2 * need));
+            h->lpart_cap = 2 * need;
+            PF_HIP(h, hipMemsetAsync(h->d_lpart, 0, 64, s));
+        }
+    }
     LossParams lp{};
+    lp.part = h->d_lpart + 16; lp.ticket = reinterpret_cast<int*>(h->d_lpart);
     lp.B = h->B; lp.Np = h->Np; lp.Nf = h->Nf; lp.nf = h->cfg.pharm_nf; lp.T = n_timesteps; lp.remove_com = remove_com; lp.weighted = weighted_loss;
     lp.feat_norm = feat_norm;
     lp.prot_ptr = h->d_prot_ptr; lp.pharm_ptr = h->d_pharm_ptr; lp.gid = h->d_gid; lp.prot_x0 = h->d_prot_x0;
@@ -2930,6 +2947,9 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     if (h->s_side != s) PF_HIP(h, hipStreamWaitEvent(s, h->cmp_ev[1], 0));
     int a = 0;
     unsigned early_mask = 0;
+    // (the encoders' backward differentiates the protein rows grouped by (graph, element) when the features can be one-hots)
+    const bool enc_grouped = c.rec_nf <= 16 && h->Np > 0;
+    bool enc_grouped_done = false;
     for (int l = L - 1; l >= 0; --l) {
         // The last conv layer's output is read on the pharm nodes only (dynamics_gvp.py:91): its protein rows have a
         // zero gradient, so -- as in the forward -- only the pharm node tiles and the ff / pf edge tiles do any work
@@ -2998,7 +3018,11 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         if (last && l != 0 && h->prune && L >= 2 && h->d_act_ids != nullptr && h->n_node_tiles_act > 0)
             pfk_fix_apply_rows(h->d_node_tiles_act, h->n_node_tiles_act, h->d_dyn_cnt, h->d_act_ids, h->t_A_h, e.G_h_in, h->t_A_v, e.G_v_in,
                                h->t_fix, s);
-        else {
+        else if (l == 0 && enc_grouped && !h->no_fix_fuse) {
+            // conv layer 0: the scalar sums join G_h in the same pass that groups the protein rows by (graph, element) for the encoders
+            pfk_fix_enc_group(h->t_A_h, e.G_h_in, h->t_fix, h->d_prot_ptr, h->d_ptype, h->B, c.rec_nf, h->t_Gg, h->Np, h->Nf, s);
+            enc_grouped_done = true;
+        } else {
             pfk_fix_apply(h->t_A_h, e.G_h_in, (size_t)N * PF_S, h->t_fix, s);
             if (l != 0) pfk_fix_apply(h->t_A_v, e.G_v_in, (size_t)N * 48, h->t_fix, s);       // conv layer 0 has no vector input
         }
@@ -3029,7 +3053,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         p.G_h = h->t_G_h[a];
         p.B = h->B; p.onehot_flag = h->d_l0flag;
         p.Gg = (c.rec_nf <= 16 && h->Np > 0) ? h->t_Gg : nullptr;
-        if (p.Gg) pfk_enc_group(p.G_h, h->d_prot_ptr, h->d_ptype, h->B, c.rec_nf, h->t_Gg, s);
+        if (p.Gg && !enc_grouped_done) pfk_enc_group(p.G_h, h->d_prot_ptr, h->d_ptype, h->B, c.rec_nf, h->t_Gg, s);
         const int tiles = (h->Np + PFT_ROWS - 1) / PFT_ROWS + (h->Nf + PFT_ROWS - 1) / PFT_ROWS;
         rp.enc_grid = std::max(1, std::min(PFT_ENC_BLOCKS, tiles));
         pfk_bwd_encode(&p, rp.enc_grid, s);

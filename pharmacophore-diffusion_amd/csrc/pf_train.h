@@ -183,6 +183,7 @@ struct LossParams {
     float* x0c; float* alpha_g; float* sigma_g;
     const float* dyn_h; const float* dyn_x;  // the dynamics' outputs
     float* g_x; float* g_h; float* out;      // unit upstream gradients, [6] losses and metrics
+    float* part; int* ticket;                // k_loss_eval: [blocks][8] partial sums; arrival counter (zero between launches)
 };
 
 // dropout keep-mask of (step seed, stream, element): identical in the forward node kernel and the backward pass.

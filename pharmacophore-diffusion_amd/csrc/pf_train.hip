@@ -1674,6 +1674,56 @@ __global__ __launch_bounds__(1024) void k_enc_group(const float* G_h, const int*
     }
 }
 
+// k_fix_apply of conv layer 0's scalar accumulator and k_enc_group in one pass over the rows: G_h += A_h / scale, A_h = 0, and the
+// per-(graph, element) sums of the updated protein rows (same per-element arithmetic and the same summation order as the two
+// kernels one after the other; the 34 MB of G_h are not read a second time).  Blocks [0, B): one graph's protein atoms; the blocks
+// behind them: the pharm rows [Np, Np + Nf), element by element
+__global__ __launch_bounds__(1024) void k_fix_enc_group(long long* A_h, float* G_h, const float* fix, const int* prot_ptr, const int* ptype,
+                                                        const int B, const int rec_nf, float* Gg, const int Np, const int Nf) {
+    __shared__ float acc[8][16][PF_S];
+    const int tid = threadIdx.x;
+    const double inv = (double)fix[1];
+    if ((int)blockIdx.x >= B) {
+        const size_t n = (size_t)Nf * PF_S, i = (size_t)(blockIdx.x - B) * 1024 + tid;
+        if (i < n) {
+            const size_t o = (size_t)Np * PF_S + i;
+            const long long a = A_h[o];
+            if (a != 0) { G_h[o] += (float)((double)a * inv); A_h[o] = 0; }
+        }
+        return;
+    }
+    const int g = blockIdx.x, ph = tid >> 7, f = tid & 127;
+    for (int e = 0; e < rec_nf; ++e) acc[ph][e][f] = 0.f;
+    const int p1 = prot_ptr[g + 1];
+    for (int n = prot_ptr[g] + ph; n < p1; n += 32) {          // four atoms per trip, all their loads in flight before the first add
+        long long a[4]; float x[4]; int e[4]; bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int nn = n + 8 * u;
+            on[u] = nn < p1;
+            const size_t o = (size_t)(on[u] ? nn : n) * PF_S + f;
+            a[u] = A_h[o]; x[u] = G_h[o];
+            e[u] = min(max(ptype[on[u] ? nn : n], 0), rec_nf - 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (on[u]) {
+                const size_t o = (size_t)(n + 8 * u) * PF_S + f;
+                float v = x[u];
+                if (a[u] != 0) { v += (float)((double)a[u] * inv); G_h[o] = v; A_h[o] = 0; }
+                acc[ph][e[u]][f] += v;
+            }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < rec_nf * PF_S; idx += 1024) {
+        const int e = idx >> 7, ff = idx & 127;
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += acc[q][e][ff];
+        Gg[((size_t)g * rec_nf + e) * PF_S + ff] = t;
+    }
+}
+
 __global__ __launch_bounds__(NT) void k_bwd_encode(const BwdEncodeParams p) {
     __shared__ float sin_[TR * 17], z[TR * ZS], xh[TR * ZS], gq[TR * ZS];
     __shared__ float red[NT];
@@ -1853,7 +1903,37 @@ __global__ __launch_bounds__(1024) void k_reduce_enc(const ReduceParams p) {
     }
 }
 template <int UNR>
-__global__ void k_train_reduce(const ReduceParams p) {
+__global__ __launch_bounds__(256) void k_train_reduce(const ReduceParams p, const int nb_main, const int with_enc) {
+    if ((int)blockIdx.x >= nb_main) {
+        // the encoders' narrow copies as the blocks behind the main ones (k_reduce_enc's plan on 256 threads: 32 parameters x 8
+        // slices of every eighth copy, the slices added in order) -- a launch of its own ran its ~100 latency-bound blocks in
+        // front of this bandwidth-bound grid instead of under it
+        __shared__ float part[8][33];
+        if (!with_enc) return;
+        const int pi = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        const int i = (blockIdx.x - nb_main) * 32 + pi;
+        float s = 0.f;
+        if (i < p.enc_n) {
+            int b = sl;
+            for (; b + 8 * 7 < p.enc_grid; b += 8 * 8) {
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = p.gpart_enc[(size_t)(b + 8 * u) * p.enc_n + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += x[u];
+            }
+            for (; b < p.enc_grid; b += 8) s += p.gpart_enc[(size_t)b * p.enc_n + i];
+        }
+        part[sl][pi] = s;
+        __syncthreads();
+        if (sl == 0 && i < p.enc_n) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += part[q][pi];
+            p.grad[p.enc_begin + i] = t;
+        }
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.nparams) return;
     int lo = 0, hi = p.ntens - 1;                    // last tensor that begins at or before i (empty tensors precede their successor)
@@ -1863,7 +1943,7 @@ __global__ void k_train_reduce(const ReduceParams p) {
     }
     const int cls = p.tseg[lo].cls;
     int b0 = 0, b1 = 0;
-    if (cls == PFT_CLS_ENC) return;                  // k_reduce_enc
+    if (cls == PFT_CLS_ENC) return;                  // the blocks behind nb_main
     if (cls < 0 || !((p.cls_mask >> cls) & 1u)) return;      // another launch's share (or an empty tensor)
     if (cls == PFT_CLS_HEAD) b1 = p.head_grid;
     else if (cls >= PFT_CLS_MSG) {
@@ -1889,6 +1969,14 @@ __global__ void k_train_reduce(const ReduceParams p) {
 __global__ void k_gather_weights(const float* flat, const int* map, const size_t n, float* packed) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const int m = map[i]; packed[i] = m >= 0 ? flat[m] : 0.f; }
+}
+// four consecutive entries per thread (map and packed 16-byte aligned): one 16-byte map load, four gathers in flight, one 16-byte store
+__global__ void k_gather_weights4(const float* flat, const int4* map, const size_t n4, float4* packed) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int4 m = map[i];
+    const float a = flat[max(m.x, 0)], b = flat[max(m.y, 0)], c = flat[max(m.z, 0)], d = flat[max(m.w, 0)];
+    packed[i] = make_float4(m.x >= 0 ? a : 0.f, m.y >= 0 ? b : 0.f, m.z >= 0 ? c : 0.f, m.w >= 0 ? d : 0.f);
 }
 
 // one Adam step (torch.optim.Adam semantics, pharmacodiff.py:253: L2 weight decay added to the gradient, bias-corrected
@@ -1959,65 +2047,87 @@ __global__ __launch_bounds__(256) void k_loss_prepare(const LossParams p) {
     for (int n = p.prot_ptr[g] + tid; n < p.prot_ptr[g + 1]; n += 256)
         p.xn[n] = make_float4(p.prot_x0[3 * n] - cx - mx, p.prot_x0[3 * n + 1] - cy - my, p.prot_x0[3 * n + 2] - cz - mz, 0.f);
 }
-__global__ __launch_bounds__(1024) void k_loss_eval(const LossParams p) {
-    __shared__ float red[6][16];
-    const int tid = threadIdx.x;
+// one center per thread, 64 centers per block (a single block spent its time issuing ~30 strided loads per center from one compute
+// unit: 18 us at 1,536 centers); every block leaves its six partial sums, the block that draws the last ticket adds them in block
+// order -- the result does not depend on which block that is -- and re-arms the ticket
+__global__ __launch_bounds__(64) void k_loss_eval(const LossParams p) {
+    const int lane = threadIdx.x;
+    const int f = blockIdx.x * 64 + lane;
+    const bool on = f < p.Nf;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float inv_x = 1.0f / (float)(p.Nf * 3), inv_h = 1.0f / (float)(p.Nf * p.nf);
-    for (int f = tid; f < p.Nf; f += 1024) {
+    if (on) {
+        // every load of the center is requested before the first is used (pharm_nf <= 8)
         const int g = p.gid[p.Np + f];
-        const float a = p.alpha_g[g], sg = p.sigma_g[g], wm = 1.0f - p.t[g], wl = p.weighted ? wm : 1.0f;
+        float ex[3], dx[3], xc[3], eh[8], dh[8], ph[8], h0v[8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { ex[c] = p.eps_x[3 * f + c]; dx[c] = p.dyn_x[3 * f + c]; xc[c] = p.x0c[3 * f + c]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < p.nf) {
+                const size_t o = (size_t)f * p.nf + k;
+                eh[k] = p.eps_h[o]; dh[k] = p.dyn_h[o]; ph[k] = p.pharm_h[o]; h0v[k] = p.h0[o];
+            } else eh[k] = dh[k] = ph[k] = h0v[k] = 0.f;
         const float4 xt = p.xn[p.Np + f];
+        const float a = p.alpha_g[g], sg = p.sigma_g[g], wm = 1.0f - p.t[g], wl = p.weighted ? wm : 1.0f;
         const float xtv[3] = {xt.x, xt.y, xt.z};
         float xl = 0.f, err = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float d = p.eps_x[3 * f + c] - p.dyn_x[3 * f + c];
+            const float d = ex[c] - dx[c];
             xl += d * d;
             p.g_x[3 * f + c] = -2.0f * wl * d * inv_x;
-            const float e = (xtv[c] - sg * p.dyn_x[3 * f + c]) / a - p.x0c[3 * f + c];
+            const float e = (xtv[c] - sg * dx[c]) / a - xc[c];
             err += e * e;
         }
         float hl = 0.f, bp = 0.f, bt = 0.f;
         int ip = 0, it = 0;
-        for (int k = 0; k < p.nf; ++k) {
-            const size_t o = (size_t)f * p.nf + k;
-            const float d = p.eps_h[o] - p.dyn_h[o];
-            hl += d * d;
-            p.g_h[o] = -2.0f * wl * d * inv_h;
-            const float hp = (p.pharm_h[o] - sg * p.dyn_h[o]) / a, ht = p.h0[o];
-            if (k == 0 || hp > bp) { bp = hp; ip = k; }                  // first maximum, like argmax
-            if (k == 0 || ht > bt) { bt = ht; it = k; }
-        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < p.nf) {
+                const float d = eh[k] - dh[k];
+                hl += d * d;
+                p.g_h[(size_t)f * p.nf + k] = -2.0f * wl * d * inv_h;
+                const float hp = (ph[k] - sg * dh[k]) / a, ht = h0v[k];
+                if (k == 0 || hp > bp) { bp = hp; ip = k; }                  // first maximum, like argmax
+                if (k == 0 || ht > bt) { bt = ht; it = k; }
+            }
         const float hit = ip == it ? 1.0f : 0.f;
-        acc[0] += xl * wl; acc[1] += hl * wl; acc[2] += err; acc[3] += wm * err; acc[4] += hit; acc[5] += wm * hit;
+        acc[0] = xl * wl; acc[1] = hl * wl; acc[2] = err; acc[3] = wm * err; acc[4] = hit; acc[5] = wm * hit;
     }
-    // fixed-order reduction: xor butterfly inside each wave, then the 16 wave sums in order (ten barrier-separated tree steps
-    // over six arrays were most of this kernel's 18 us)
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         float v = acc[q];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if ((tid & 63) == 0) red[q][tid >> 6] = v;
+        acc[q] = v;
     }
-    __syncthreads();
-    if (tid == 0) {
-        const float nfl = (float)p.Nf;
-        float v[6];
+    int last = 0;
+    if (lane == 0) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            float tsum = 0.f;
-            for (int w = 0; w < 16; ++w) tsum += red[q][w];
-            const float den = q == 0 ? (float)(p.Nf * 3) : (q == 1 ? (float)(p.Nf * p.nf) : nfl);
-            v[q] = tsum / den;
-            p.out[q] = v[q];
-        }
+        for (int q = 0; q < 6; ++q) p.part[(size_t)blockIdx.x * 8 + q] = acc[q];
+        __threadfence();
+        last = atomicAdd(p.ticket, 1) == (int)gridDim.x - 1;
+    }
+    last = __shfl(last, 0);
+    if (!last) return;
+    __threadfence();
+    if (lane < 6) {
+        float tsum = 0.f;
+        for (int b = 0; b < (int)gridDim.x; ++b) tsum += __builtin_nontemporal_load(p.part + (size_t)b * 8 + lane);
+        const float den = lane == 0 ? (float)(p.Nf * 3) : (lane == 1 ? (float)(p.Nf * p.nf) : (float)p.Nf);
+        acc[0] = tsum / den;
+    }
+    const float v0 = __shfl(acc[0], 0), v1 = __shfl(acc[0], 1), v2 = __shfl(acc[0], 2), v3 = __shfl(acc[0], 3), v4 = __shfl(acc[0], 4),
+                v5 = __shfl(acc[0], 5);
+    if (lane < 6) p.out[lane] = acc[0];
+    if (lane == 0) {
         // what training_step / validation_step derive from the six (pharmacodiff.py:274-277): total loss, total error,
         // weighted total error -- here, so that the step does not spend framework launches on three additions
-        p.out[6] = v[0] + v[1];
-        p.out[7] = v[2] + 1.0f - v[4];
-        p.out[8] = v[3] + 1.0f - v[5];
+        p.out[6] = v0 + v1;
+        p.out[7] = v2 + 1.0f - v4;
+        p.out[8] = v3 + 1.0f - v5;
+        *p.ticket = 0;
     }
 }
 // the unit gradients of the two losses times their upstream scalars (a + a2 for the coordinates, b + b2 for the features;
@@ -2070,7 +2180,7 @@ void pfk_compact_rows(const EdgeTile* tiles, const int* et_tile0, int n_et, cons
     hipLaunchKernelGGL(k_compact_rows, dim3(n_et), dim3(1024), 0, s, tiles, cp, dyn_cnt, rlist, ccnt);
 }
 void pfk_loss_prepare(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_prepare, dim3(p->B), dim3(256), 0, s, *p); }
-void pfk_loss_eval(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_eval, dim3(1), dim3(1024), 0, s, *p); }
+void pfk_loss_eval(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_loss_eval, dim3((p->Nf + 63) / 64), dim3(64), 0, s, *p); }
 void pfk_scale_loss(float* gx, int nx, const float* a, const float* a2, float* gh, int nh, const float* b, const float* b2, hipStream_t s) {
     if (nx + nh > 0) hipLaunchKernelGGL(k_scale_loss, dim3((nx + nh + 255) / 256), dim3(256), 0, s, gx, nx, a, a2, gh, nh, b, b2);
 }
@@ -2092,17 +2202,33 @@ void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* 
 void pfk_enc_group(const float* G_h, const int* prot_ptr, const int* ptype, int B, int rec_nf, float* Gg, hipStream_t s) {
     if (B > 0) hipLaunchKernelGGL(k_enc_group, dim3(B), dim3(1024), 0, s, G_h, prot_ptr, ptype, rec_nf, Gg);
 }
+void pfk_fix_enc_group(long long* A_h, float* G_h, const float* fix, const int* prot_ptr, const int* ptype, int B, int rec_nf, float* Gg,
+                       int Np, int Nf, hipStream_t s) {
+    const int extra = (int)(((size_t)Nf * PF_S + 1023) / 1024);
+    if (B + extra > 0) hipLaunchKernelGGL(k_fix_enc_group, dim3(B + extra), dim3(1024), 0, s, A_h, G_h, fix, prot_ptr, ptype, B, rec_nf, Gg, Np, Nf);
+}
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s) {
     hipLaunchKernelGGL(k_bwd_encode, dim3(nblocks), dim3(NT), 0, s, *p);
 }
 void pfk_train_reduce(const ReduceParams* p, hipStream_t s) {
-    if (p->enc_n > 0 && ((p->cls_mask >> PFT_CLS_ENC) & 1u)) hipLaunchKernelGGL(k_reduce_enc, dim3((p->enc_n + 31) / 32), dim3(1024), 0, s, *p);
-    if (!(p->cls_mask & ~(1u << PFT_CLS_ENC))) return;
+    const bool enc = p->enc_n > 0 && ((p->cls_mask >> PFT_CLS_ENC) & 1u);
+    const bool main_part = (p->cls_mask & ~(1u << PFT_CLS_ENC)) != 0;
+    if (!enc && !main_part) return;
     // 16 copies in flight per thread: 43 us per launch against 63 at 8 and 64 at 32 (16-byte loads, four parameters per thread: 97)
-    hipLaunchKernelGGL(k_train_reduce<16>, dim3((p->nparams + 255) / 256), dim3(256), 0, s, *p);
+    const int nb_main = main_part ? (p->nparams + 255) / 256 : 0;
+    const int nb_enc = enc ? (p->enc_n + 31) / 32 : 0;
+    hipLaunchKernelGGL(k_train_reduce<16>, dim3(nb_main + nb_enc), dim3(256), 0, s, *p, nb_main, enc ? 1 : 0);
 }
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s) {
     if (n == 0) return;
+    if ((((uintptr_t)map | (uintptr_t)packed) & 15) == 0 && n >= 4) {
+        const size_t n4 = n / 4;
+        hipLaunchKernelGGL(k_gather_weights4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, flat, reinterpret_cast<const int4*>(map), n4,
+                           reinterpret_cast<float4*>(packed));
+        const size_t rest = n - 4 * n4;
+        if (rest) hipLaunchKernelGGL(k_gather_weights, dim3(1), dim3(256), 0, s, flat, map + 4 * n4, rest, packed + 4 * n4);
+        return;
+    }
     hipLaunchKernelGGL(k_gather_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flat, map, n, packed);
 }
 void pfk_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,

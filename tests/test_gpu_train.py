@@ -217,6 +217,35 @@ def test_training_forward_kernel_families_agree(name, monkeypatch):
         compare(res[0][2], {k: v for k, v in other[2].items()}, 2e-3, name)
 
 
+@pytest.mark.parametrize("name", sorted(GRAD_CASES))
+def test_fused_fixed_point_join_equals_the_two_launch_form(name, monkeypatch):
+    """Conv layer 0's fixed-point sums join G_h in the pass that also groups the protein rows by (graph, element) for the encoders'
+    backward (k_fix_enc_group); PFDYN_NO_FIX_FUSE=1 runs k_fix_apply and k_enc_group one after the other.  Same per-element
+    arithmetic, same summation order: every gradient is bitwise the same, and a second backward (which finds the accumulators
+    cleared by the first) repeats it."""
+    z = load(name)
+    cfg = GRAD_CASES[name]
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    x_t, h_t, prot_x, t = noised_inputs(cfg, batch, z, int(z["T"]))
+    gen = torch.Generator().manual_seed(8)
+    w_h, w_x = torch.randn(h_t.shape, generator=gen), torch.randn(x_t.shape, generator=gen)
+    res = []
+    for two in (False, True):
+        if two:
+            monkeypatch.setenv("PFDYN_NO_FIX_FUSE", "1")
+        eng = make_engine(cfg, sd, batch)
+        eng.train_forward(x_t, h_t, t, prot_x=prot_x, dropout=0.1, seed=99)
+        first = flat_to_dict(eng, eng.train_backward(w_h, w_x))
+        again = flat_to_dict(eng, eng.train_backward(w_h, w_x))
+        for k in first:
+            assert torch.equal(first[k], again[k]), k
+        res.append(first)
+    assert any(k.endswith("prot_encoder.0.weight") and float(v.abs().max()) > 0 for k, v in res[0].items())
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+
+
 def _cos_rel(got, ref):
     a, b = ref.double().reshape(-1), got.double().reshape(-1)
     na = float(a.norm())
