@@ -2906,6 +2906,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     h->tA_dirty = true;
     // The dense work lists of every conv layer (k_compact_rows, k_compact_node_rows: one or two workgroups each, 10-20 us) depend
     // on the forward's edge counts only: they are built on the side stream while the head's backward runs here.
+    bool first_clear_done = false;
     auto layer_tables = [&](int l, const NodeTile*& nt_tiles, int& nt_n, const EdgeTile*& e_tiles, const int*& et0, int& n_et) {
         const bool last = l == L - 1, pruned = h->prune && L >= 2 && l == L - 2;
         nt_tiles = pruned ? h->d_node_tiles_act : h->d_node_tiles;
@@ -2927,7 +2928,15 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
             pfk_compact_node_rows(ntt, ntn, h->d_dyn_cnt, h->d_act_ids, N, h->t_ulist + h->t_ulist_cap * l, h->t_ucap, h->t_ccnt + 96 + 4 * l, side);
             pfk_compact_rows(ett, et0, n_et, h->d_dyn_cnt, h->t_clist + h->t_clist_cap * l, h->t_ccnt + 16 * l, side);
         }
-        if (side != s) PF_HIP(h, hipEventRecord(h->cmp_ev[1], side));
+        if (side != s) {
+            // the first layer of the loop below receives its input gradients in G[1]: cleared here, under the head's backward
+            ZeroBatch zb(side);
+            zb.add(h->t_G_h[1], (size_t)N * PF_S * 4);
+            if (L - 1 != 0) zb.add(h->t_G_v[1], (size_t)N * 48 * 4);
+            zb.flush();
+            first_clear_done = true;
+            PF_HIP(h, hipEventRecord(h->cmp_ev[1], side));
+        }
     }
     // (the head kernel stores dL/d(last layer output) for every pharm row, and the last layer's node kernel reads those rows
     // only: no clearing of t_G_*[0] here)
@@ -2959,10 +2968,10 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         // are the source of a pf edge (the active atoms); every other row of its output has a zero gradient.  Same
         // tile lists as the pruned forward.
         const bool pruned = h->prune && L >= 2 && l == L - 2;
-        {
+        if (!(last && first_clear_done)) {
             ZeroBatch zb(s);
             zb.add(h->t_G_h[a ^ 1], (size_t)N * PF_S * 4);
-            zb.add(h->t_G_v[a ^ 1], (size_t)N * 48 * 4);
+            if (l != 0) zb.add(h->t_G_v[a ^ 1], (size_t)N * 48 * 4);      // (conv layer 0 has no vector input: nobody writes or reads that gradient)
             zb.flush();
         }
         BwdNodeParams n{};

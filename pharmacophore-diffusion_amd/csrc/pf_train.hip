@@ -208,6 +208,7 @@ __device__ __forceinline__ void mm16_packed(const f32x4* P, const int mts, const
         f32x4 aq[NSB];
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) aq[sb] = pp[sb * 64];       // all NSB blocks exist in the table (zero padded): no branches between the loads
+        __builtin_amdgcn_sched_barrier(0);                            // (every fragment requested before the first product: sunk to their uses they are NSB round trips)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb)
@@ -231,6 +232,7 @@ __device__ __forceinline__ void mm16_packed_bf(const f32x4* P, const int mts, co
         f32x4 aq[NSB];
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) aq[sb] = pp[sb * 64];
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sp = 0; sp < NSB / 2; ++sp)
@@ -263,30 +265,48 @@ __device__ __forceinline__ void mm16_acc_rows(const int M, const int N, FA a, FB
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const float x = a(min(ai, M - 1), BF16 ? 4 * kq + u : 4 * u + kq); av[u] = ai < M ? x : 0.f; }
     const int nts = (N + 15) >> 4;
-    for (int nt = 0; nt < nts; ++nt) {
-        const int bj = nt * 16 + li;
-        float bv[4], old[4];
+    // n tiles in groups of four: the group's operands (and, when the copy is not fresh, its old values) are all requested before
+    // the first product, the products of the group are independent of each other, the stores follow -- one n tile at a time was a
+    // chain of LDS read -> four dependent matrix instructions -> store per tile (9 k cycles per GVP level for eleven tiles)
+    for (int nt0 = 0; nt0 < nts; nt0 += 4) {
+        float bv[4][4], old[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const float x = b(BF16 ? 4 * kq + u : 4 * u + kq, min(bj, N - 1)); bv[u] = bj < N ? x : 0.f; }
+        for (int x = 0; x < 4; ++x) {
+            const int bj = (nt0 + x) * 16 + li;
+            const bool on = nt0 + x < nts && bj < N;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ci = wv * 16 + kq * 4 + r;
-            old[r] = 0.f;
-            if (!fresh) {                                          // block-uniform
-                const float o = G[min(ci, M - 1) * ld + min(bj, N - 1)];
-                old[r] = (ci < M && bj < N) ? o : 0.f;
+            for (int u = 0; u < 4; ++u) { const float v = b(BF16 ? 4 * kq + u : 4 * u + kq, min(bj, N - 1)); bv[x][u] = on ? v : 0.f; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = wv * 16 + kq * 4 + r;
+                old[x][r] = 0.f;
+                if (!fresh) {                                      // block-uniform
+                    const float o = G[min(ci, M - 1) * ld + min(bj, N - 1)];
+                    old[x][r] = (ci < M && on) ? o : 0.f;
+                }
             }
         }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (BF16) acc = mfma_bf16(bf_pack4(av), bf_pack4(bv), acc);
-        else {
+        f32x4 acc[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int x = 0; x < 4; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF16) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[x] = mfma_bf16(bf_pack4(av), bf_pack4(bv[x]), acc[x]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[x][u], acc[x], 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ci = wv * 16 + kq * 4 + r;
-            if (ci < M && bj < N) G[ci * ld + bj] = old[r] + acc[r];
+        for (int x = 0; x < 4; ++x) {
+            const int bj = (nt0 + x) * 16 + li;
+            if (nt0 + x < nts && bj < N)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = wv * 16 + kq * 4 + r;
+                    if (ci < M) G[ci * ld + bj] = old[x][r] + acc[x][r];
+                }
         }
     }
 }
@@ -327,9 +347,13 @@ struct ChainLds {
 };
 
 // Vh = Wh^T V and Vu = Wu^T Vh of one GVP for the 16 rows (gvp.py:97-101); sh goes to Sin[:, si:] when want_sh
+// (FX: the GVP is the update / head shape -- 16 vector channels in, hidden and out, 128 scalars in and out: the dimensions are
+// compile-time constants in every product below, whose tile loops, index clamps and bounds predicates then fold away.  These
+// kernels are bound by the vector ALU instructions AROUND their matrix instructions, not by the products.)
+template <bool FX = false>
 __device__ __forceinline__ void gvp_vec(const GvpT& g, const float* Wh, const float* Wu, float* Sin, const float* Vin, float* Vh, float* Vu,
                                         const bool want_sh, const int tid, const int lane, const int wv) {
-    const int KH = g.h, VI = g.vi, VO = g.vo;
+    const int KH = FX ? 16 : g.h, VI = FX ? 16 : g.vi, VO = FX ? 16 : g.vo, SIv = FX ? 128 : g.si;
     mm16<5>(KH, 3 * TR, VI,
          [&](int i, int k) { return Wh[k * KH + i]; },
          [&](int k, int j) { return Vin[(j & 15) * VWS + k * 3 + (j >> 4)]; },
@@ -339,7 +363,7 @@ __device__ __forceinline__ void gvp_vec(const GvpT& g, const float* Wh, const fl
         for (int idx = tid; idx < TR * KH; idx += NT) {
             const int row = idx & 15, hh = idx >> 4;
             const float* q = Vh + row * VWS + hh * 3;
-            Sin[row * SWS + g.si + hh] = t_sqrt(fmaxf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2], 1e-8f));
+            Sin[row * SWS + SIv + hh] = t_sqrt(fmaxf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2], 1e-8f));
         }
     mm16<5>(VO, 3 * TR, KH,
          [&](int i, int k) { return Wu[k * VO + i]; },
@@ -390,14 +414,24 @@ __device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, const Pac
 // backward of one GVP on the tile.  In: gA = dL/d act [row][so] (stride SWS), gVo = dL/d Vout [row][vo*3].
 // Out: gS = dL/d Sin[:, :si+h] (the first si entries are the input-scalar gradient), gVi = dL/d Vin.  gA and gVo are
 // overwritten (they become dL/dZ and dL/dVu).  Weight gradients are accumulated into gp (this block's copy).
-template <bool BF16>
+template <bool BF16, bool FX = false>
 __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const PackPtr pk, const bool fresh, float* gp, const float* Sin, const float* Vin,
                                         const float* Z, const float* gate, const float* act, const int act_stride,
                                         float* gA, float* gS, float* gVo, float* gVi, float* Vh, float* Vu, float* gVh,
-                                        float* ggate, const int tid, const int lane, const int wv, const bool fill_sh = false,
+                                        float* ggate, const int tid_, const int lane_, const int wv, const bool fill_sh = false,
                                         float* wst = nullptr) {
-    const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;
+    // (an opaque copy of the thread id per call: with compile-time shapes every phase's per-lane addresses are loop invariants of the
+    // callers' level and unit loops, and hoisted there they do not fit the register file -- as in k_bwd_edge_level, E2_PHASE)
+    int zz_ = 0;
+    asm volatile("" : "+v"(zz_));
+    const int tid = tid_ + zz_, lane = tid & 63;
+    (void)lane_;
+    const int KH = FX ? 16 : g.h, VI = FX ? 16 : g.vi, VO = FX ? 16 : g.vo, SI = FX ? 128 : g.si, SO = FX ? 128 : g.so, KM = SI + KH;
     PFT_STAMP(10);
+    // the bias gradients' old values (a copy that is not fresh) are requested here and added where the sums are known: read
+    // there, the round trip sat between the sum and the barrier every wave of the block waits at
+    const float old_bg = (!fresh && tid < VO) ? gp[g.o_bg + tid] : 0.f;
+    const float old_bm = (!fresh && tid < SO) ? gp[g.o_bm + tid] : 0.f;
     // wst (PFT_WST_FLOATS of LDS, optional): the GVP's small matrices -- Wh, Wu and the gate weights, 12 KB -- are copied there
     // once per level; five of this function's products read them element by element, and from global memory each such product
     // starts with a dependent L2 round trip on strided addresses
@@ -410,7 +444,7 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const Pac
         Wh = wst; Wu = wst + nh; Wg = wst + nh + nu;
     }
     // (fill_sh: the level's rows came from the forward's saved pre-activations, the sh columns of Sin are still to be filled)
-    gvp_vec(g, Wh, Wu, const_cast<float*>(Sin), Vin, Vh, Vu, fill_sh, tid, lane, wv);
+    gvp_vec<FX>(g, Wh, Wu, const_cast<float*>(Sin), Vin, Vh, Vu, fill_sh, tid, lane, wv);
     PFT_STAMP(11);
     // gate: V' = f(gate) Vu
     for (int idx = tid; idx < TR * VO; idx += NT) {
@@ -436,7 +470,7 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const Pac
     if (tid < VO) {
         float s = 0.f;
         for (int r = 0; r < TR; ++r) s += ggate[r * GTS + tid];
-        gp[g.o_bg + tid] += s;
+        gp[g.o_bg + tid] = old_bg + s;
     }
     __syncthreads();
     PFT_STAMP(13);
@@ -463,7 +497,7 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const Pac
     if (tid < SO) {
         float s = 0.f;
         for (int r = 0; r < TR; ++r) s += gA[r * SWS + tid];
-        gp[g.o_bm + tid] += s;
+        gp[g.o_bm + tid] = old_bm + s;
     }
     __syncthreads();
     PFT_STAMP(16);
@@ -562,8 +596,13 @@ __device__ __forceinline__ void chain_bwd(const ChainLds& L, const GvpT* g, cons
     float *ga = L.gX, *gs = L.gY, *gvo = L.gVX, *gvi = L.gVY;
     for (int l = L.nlv - 1; l >= 0; --l) {
         const bool last = l == L.nlv - 1;
-        gvp_bwd<BF16>(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
-                ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh, wst);
+        const bool fx = g[l].vi == 16 && g[l].h == 16 && g[l].vo == 16 && g[l].si == 128 && g[l].so == 128 && g[l].sig;      // block-uniform
+        if (fx)
+            gvp_bwd<BF16, true>(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+                    ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh, wst);
+        else
+            gvp_bwd<BF16, false>(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+                    ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh, wst);
         float* t0 = ga; ga = gs; gs = t0;
         float* t1 = gvo; gvo = gvi; gvi = t1;
     }
@@ -636,22 +675,29 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
             else chain_load(L, p.g, p.sv_z, p.sv_g, p.sv_v, p.sv_stride, (size_t)(n0 - p.node_base), nv, nullptr, tid);
             PFT_STAMP(42);
             // to_scalar_output: eps_h = Wout act + b ; eps_x = the single output vector channel
+            const bool fresh_u = unit == (int)blockIdx.x;           // this block's first unit: its copy holds zeros (zero_class)
             for (int idx = tid; idx < TR * SOL; idx += NT) {
                 const int row = idx & 15, k = idx >> 4;
+                float wv8[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) wv8[o] = W[p.o_Wout + min(o, NF - 1) * SOL + k];     // (pharm_nf <= 8: one round trip)
                 float s = 0.f;
-                for (int o = 0; o < NF; ++o) s += W[p.o_Wout + o * SOL + k] * s_ge[row * 8 + o];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) if (o < NF) s += wv8[o] * s_ge[row * 8 + o];
                 L.gX[row * SWS + k] = s;
             }
             for (int idx = tid; idx < NF * SOL; idx += NT) {
                 const int o = idx / SOL, k = idx - o * SOL;
+                const float old = fresh_u ? 0.f : gp[p.o_Wout + idx];
                 float s = 0.f;
                 for (int r = 0; r < TR; ++r) s += s_ge[r * 8 + o] * L.actl[r * ZS + k];
-                gp[p.o_Wout + idx] += s;
+                gp[p.o_Wout + idx] = old + s;
             }
             if (tid < NF) {
+                const float old = fresh_u ? 0.f : gp[p.o_bout + tid];
                 float s = 0.f;
                 for (int r = 0; r < TR; ++r) s += s_ge[r * 8 + tid];
-                gp[p.o_bout + tid] += s;
+                gp[p.o_bout + tid] = old + s;
             }
             for (int idx = tid; idx < TR * 3; idx += NT) {
                 const int row = idx / 3, cc = idx - row * 3;
