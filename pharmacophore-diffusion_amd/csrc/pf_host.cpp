@@ -305,6 +305,7 @@ struct pf_handle {
     int* d_xstat = nullptr;                 // [1] time-outs of the exchange (pf_debug_xchg_timeouts)
     int* xstat_host = nullptr;              // pinned; an async copy of d_xstat follows every sampling run (pf_sample_end) and is looked at
                                             // when the next one begins: a time-out there is reported, late but never silently
+    bool no_fixed_shapes = false;           // PFDYN_NO_FIXED_SHAPES: k_bwd_edge_level reads every level's GVP shape from the table (the A/B of its FX forms)
     bool no_fix_fuse = false;               // PFDYN_NO_FIX_FUSE: k_fix_apply and k_enc_group as two launches (the A/B of k_fix_enc_group)
     bool train_bf16 = false;                // pf_train_set_precision: the bf16 leg (dense Linears of the message chains' forward and of every
                                             // gradient kernel on bf16 matrix instructions; PFDYN_TRAIN_BF16=1 sets it at creation)
@@ -374,6 +375,7 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_TRAIN_NODE_RECOMPUTE")) train_node_save = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_TRAIN_BF16")) train_bf16 = atoi(e) != 0;
         if (const char* e = getenv("PFDYN_NO_FIX_FUSE")) no_fix_fuse = atoi(e) != 0;
+        if (const char* e = getenv("PFDYN_NO_FIXED_SHAPES")) no_fixed_shapes = atoi(e) != 0;
         pol.from_env();
     }
 
@@ -3022,7 +3024,21 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         e.l0 = l == 0;
         e.A_h = h->t_A_h; e.A_v = h->t_A_v; e.fix = h->t_fix;
         e.wpack = h->d_wpack + (size_t)h->msg_base(l, 0) * PFT_WPACK_FLOATS;
-        for (int lv = c.n_message_gvps - 1; lv >= 0; --lv) { e.level = lv; ProfScope ps(h, pf_handle::K_BWD_EDGE_LEVEL, s); pfk_bwd_edge_level(&e, nb, s); }
+        for (int lv = c.n_message_gvps - 1; lv >= 0; --lv) {
+            e.level = lv;
+            e.fx = 0;
+            if (!h->no_fixed_shapes) {
+                bool f1 = true, f2 = true;
+                for (int et = 0; et < 4; ++et) {
+                    const GvpSpec gs = msg_spec(c, l, et, lv);
+                    f1 = f1 && gs.vi == 16 && gs.vo == 16 && gs.si == 128 && gs.so == 128;
+                    f2 = f2 && gs.vi == 17 && gs.vo == 16 && gs.si == 144 && gs.so == 128;
+                }
+                e.fx = f1 ? 1 : (f2 ? 2 : 0);
+            }
+            ProfScope ps(h, pf_handle::K_BWD_EDGE_LEVEL, s);
+            pfk_bwd_edge_level(&e, nb, s);
+        }
         // the last layer's ff / pf edges scatter into pharm rows and active protein atoms only (the pruned layout's node tiles)
         if (last && l != 0 && h->prune && L >= 2 && h->d_act_ids != nullptr && h->n_node_tiles_act > 0)
             pfk_fix_apply_rows(h->d_node_tiles_act, h->n_node_tiles_act, h->d_dyn_cnt, h->d_act_ids, h->t_A_h, e.G_h_in, h->t_A_v, e.G_v_in,

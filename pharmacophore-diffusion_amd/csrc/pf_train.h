@@ -153,6 +153,7 @@ struct BwdEdgeLevelParams {
     const float* sv_z; const float* sv_g; const float* sv_v; size_t sv_stride;
     float* gs_buf; float* gv_buf;            // dL/d(input scalars / vectors of the level above), per edge slot
     const GvpT* g; int n_gvps; int level;
+    int fx;                                  // shape class of this level's GVPs (k_bwd_edge_level's FX), 0: generic
     const float* wpack;                      // k_pack_gvp input-gradient fragments of this layer's message GVPs [et][level][PFT_WPACK_FLOATS]
     float rbf_mu[PF_R]; float rbf_inv_sigma;
     int l0;

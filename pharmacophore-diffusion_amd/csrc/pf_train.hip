@@ -1178,7 +1178,9 @@ __device__ __forceinline__ void mmcol(const int mts, FA a, FB b, FC c, const int
     }
 }
 
-template <bool BF16>
+// FX: the level's GVP shape as compile-time constants (1: message GVPs above the first -- 16 vector channels in / hidden / out, 128
+// scalars in; 2: the first message GVP -- 17 channels in / hidden, 144 scalars in; 0: read from the table), BwdEdgeLevelParams::fx
+template <bool BF16, int FX>
 __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelParams p) {
     __shared__ __attribute__((aligned(16))) float Zb[ER * E2_ZS];
     __shared__ __attribute__((aligned(16))) float Sin[ER * E2_SS];
@@ -1208,7 +1210,8 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
     const float* W = p.c.W;
     const f32x4* Wp = reinterpret_cast<const f32x4*>(p.wpack) + (size_t)(et * p.n_gvps + p.level) * (11 * 8 * 64);
     float* gp = p.c.gpart + (size_t)blockIdx.x * p.c.gstride;
-    const int KH = g.h, VI = g.vi, VO = g.vo, SI = g.si, SO = g.so, KM = SI + KH;   // SO == 128, VO == 16; KH, VI <= 17 (message GVPs)
+    const int KH = FX == 1 ? 16 : (FX == 2 ? 17 : g.h), VI = FX == 1 ? 16 : (FX == 2 ? 17 : g.vi), VO = FX ? 16 : g.vo;
+    const int SI = FX == 1 ? 128 : (FX == 2 ? 144 : g.si), SO = FX ? 128 : g.so, KM = SI + KH;   // SO == 128, VO == 16; KH, VI <= 17 (message GVPs)
     const int nts = (KM + 15) >> 4;                  // <= 11
     const int mth = (KH + 15) >> 4, mti = (VI + 15) >> 4;
     const bool lastl = p.level == p.n_gvps - 1, firstl = p.level == 0;
@@ -2212,8 +2215,9 @@ void pfk_bwd_node(const BwdNodeParams* p, int nblocks, hipStream_t s) {
 }
 void pfk_bwd_edge_level(const BwdEdgeLevelParams* p, int nblocks, hipStream_t s) {
     if (nblocks == 0 || p->et_tile0[p->n_et] == p->et_tile0[0]) return;
-    if (p->c.bf16) hipLaunchKernelGGL(k_bwd_edge_level<true>, dim3(nblocks), dim3(NT), 0, s, *p);
-    else hipLaunchKernelGGL(k_bwd_edge_level<false>, dim3(nblocks), dim3(NT), 0, s, *p);
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), 0, s, *p); };
+    if (p->c.bf16) { if (p->fx == 1) go(k_bwd_edge_level<true, 1>); else if (p->fx == 2) go(k_bwd_edge_level<true, 2>); else go(k_bwd_edge_level<true, 0>); }
+    else { if (p->fx == 1) go(k_bwd_edge_level<false, 1>); else if (p->fx == 2) go(k_bwd_edge_level<false, 2>); else go(k_bwd_edge_level<false, 0>); }
 }
 void pfk_compact_node_rows(const NodeTile* tiles, int ntiles, const int* dyn_cnt, const int* row_ids, int N, int* list, int cap, int* ucnt,
                            hipStream_t s) {

@@ -246,6 +246,28 @@ def test_fused_fixed_point_join_equals_the_two_launch_form(name, monkeypatch):
         assert torch.equal(res[0][k], res[1][k]), k
 
 
+@pytest.mark.parametrize("name", sorted(GRAD_CASES))
+def test_fixed_shape_level_kernels_equal_the_table_driven_form(name, monkeypatch):
+    """k_bwd_edge_level is instantiated with the two message-GVP shapes of the architecture as compile-time constants
+    (BwdEdgeLevelParams::fx); PFDYN_NO_FIXED_SHAPES=1 launches the form that reads the shape from the GVP table.  Same products in
+    the same order: the gradients agree to rounding of differently contracted multiply-adds."""
+    z = load(name)
+    cfg = GRAD_CASES[name]
+    batch = batch_from(z)
+    sd = O.make_state_dict(cfg, int(z["wseed"]))
+    x_t, h_t, prot_x, t = noised_inputs(cfg, batch, z, int(z["T"]))
+    gen = torch.Generator().manual_seed(9)
+    w_h, w_x = torch.randn(h_t.shape, generator=gen), torch.randn(x_t.shape, generator=gen)
+    res = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("PFDYN_NO_FIXED_SHAPES", "1")
+        eng = make_engine(cfg, sd, batch)
+        eng.train_forward(x_t, h_t, t, prot_x=prot_x, dropout=0.1, seed=123)
+        res.append(flat_to_dict(eng, eng.train_backward(w_h, w_x)))
+    compare(res[0], res[1], 2e-5, name)
+
+
 def _cos_rel(got, ref):
     a, b = ref.double().reshape(-1), got.double().reshape(-1)
     na = float(a.norm())
