@@ -539,30 +539,38 @@ __device__ __forceinline__ void chain_fwd(const ChainLds& L, const GvpT* g, cons
 // instead of chain_fwd: the forward left every level's pre-activations (rows i0 .. i0 + nv - 1 of [level][stride][128 / 16 / 48]):
 // fill Z, gate and the next level's inputs (act = SiLU(Z), gated vectors) with independent loads -- one round trip instead of the
 // ~30 k cycles per GVP of the recomputation.  The sh columns of every Sin are filled by gvp_bwd (fill_sh).
-__device__ __forceinline__ void chain_load(const ChainLds& L, const GvpT* g, const float* sv_z, const float* sv_g, const float* sv_v,
-                                           const size_t stride, const size_t i0, const int nv, float* vout_last, const int tid,
-                                           const int* rows = nullptr) {     // rows (LDS, 16 entries): row indices instead of i0 + row
+// (two halves, so that a caller can put its own loads between the request and the first use)
+template <int MAXL>
+struct ChainRows { float4 zq[MAXL], gq[MAXL], vq[MAXL]; };
+template <int MAXL>
+__device__ __forceinline__ void chain_request(const ChainLds& L, const float* sv_z, const float* sv_g, const float* sv_v, const size_t stride,
+                                              const size_t i0, const int nv, const int tid, const int* rows, ChainRows<MAXL>& R) {
     // every level's rows are requested before any is consumed: one thread = one 16-byte piece of a Z row (16 rows x 32
     // pieces = the block), the first 64 threads a piece of a gate row, the first 192 a piece of a vector row
     const int zr = tid >> 5, zk = (tid & 31) * 4;
     const int gr = (tid >> 2) & 15, gk = (tid & 3) * 4;
     const int vr = min(tid / 12, 15), vk = (tid - (tid / 12) * 12) * 4;
-    float4 zq[PFT_MAX_CHAIN], gq[PFT_MAX_CHAIN], vq[PFT_MAX_CHAIN];
 #pragma unroll
-    for (int l = 0; l < PFT_MAX_CHAIN; ++l) {
-        zq[l] = gq[l] = vq[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < MAXL; ++l) {
+        R.zq[l] = R.gq[l] = R.vq[l] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (l < L.nlv) {
             const size_t r0 = (size_t)l * stride + i0;
             const size_t iz = rows ? (size_t)rows[min(zr, nv - 1)] : (size_t)min(zr, nv - 1);
             const size_t ig = rows ? (size_t)rows[min(gr, nv - 1)] : (size_t)min(gr, nv - 1);
             const size_t iv = rows ? (size_t)rows[min(vr, nv - 1)] : (size_t)min(vr, nv - 1);
-            zq[l] = *reinterpret_cast<const float4*>(sv_z + (r0 + iz) * PF_S + zk);
-            if (tid < 64) gq[l] = *reinterpret_cast<const float4*>(sv_g + (r0 + ig) * 16 + gk);
-            if (tid < 192) vq[l] = *reinterpret_cast<const float4*>(sv_v + (r0 + iv) * 48 + vk);
+            R.zq[l] = *reinterpret_cast<const float4*>(sv_z + (r0 + iz) * PF_S + zk);
+            if (tid < 64) R.gq[l] = *reinterpret_cast<const float4*>(sv_g + (r0 + ig) * 16 + gk);
+            if (tid < 192) R.vq[l] = *reinterpret_cast<const float4*>(sv_v + (r0 + iv) * 48 + vk);
         }
     }
+}
+template <int MAXL>
+__device__ __forceinline__ void chain_commit(const ChainLds& L, const GvpT* g, const ChainRows<MAXL>& R, float* vout_last, const int tid) {
+    const int zr = tid >> 5, zk = (tid & 31) * 4;
+    const int gr = (tid >> 2) & 15, gk = (tid & 3) * 4;
+    const int vr = min(tid / 12, 15), vk = (tid - (tid / 12) * 12) * 4;
 #pragma unroll
-    for (int l = 0; l < PFT_MAX_CHAIN; ++l)
+    for (int l = 0; l < MAXL; ++l)
         if (l < L.nlv) {
             const bool last = l == L.nlv - 1;
             const int so = g[l].so, vo = g[l].vo;
@@ -570,21 +578,28 @@ __device__ __forceinline__ void chain_load(const ChainLds& L, const GvpT* g, con
             float* gt = L.gate(l);
             float* vout = last ? vout_last : L.Vin(l + 1);
             const int astr = last ? ZS : SWS;
-            const float zv[4] = {zq[l].x, zq[l].y, zq[l].z, zq[l].w};
+            const float zv[4] = {R.zq[l].x, R.zq[l].y, R.zq[l].z, R.zq[l].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (zk + q < so) { Zl[zr * ZS + zk + q] = zv[q]; act[zr * astr + zk + q] = t_silu(zv[q]); }
             if (tid < 64) {
-                const float gv[4] = {gq[l].x, gq[l].y, gq[l].z, gq[l].w};
+                const float gv[4] = {R.gq[l].x, R.gq[l].y, R.gq[l].z, R.gq[l].w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) if (gk + q < vo) gt[gr * GTS + gk + q] = gv[q];
             }
             if (vout != nullptr && tid < 192) {
-                const float vv[4] = {vq[l].x, vq[l].y, vq[l].z, vq[l].w};
+                const float vv[4] = {R.vq[l].x, R.vq[l].y, R.vq[l].z, R.vq[l].w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) if (vk + q < vo * 3) vout[vr * VWS + vk + q] = vv[q];
             }
         }
+}
+__device__ __forceinline__ void chain_load(const ChainLds& L, const GvpT* g, const float* sv_z, const float* sv_g, const float* sv_v,
+                                           const size_t stride, const size_t i0, const int nv, float* vout_last, const int tid,
+                                           const int* rows = nullptr) {     // rows (LDS, 16 entries): row indices instead of i0 + row
+    ChainRows<PFT_MAX_CHAIN> R;
+    chain_request<PFT_MAX_CHAIN>(L, sv_z, sv_g, sv_v, stride, i0, nv, tid, rows, R);
+    chain_commit<PFT_MAX_CHAIN>(L, g, R, vout_last, tid);
     __syncthreads();
 }
 // backward through the chain: upstream gradients in L.gX ([row][so_last], stride SWS) and L.gVX; returns through
@@ -649,6 +664,9 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
             const int nv = min(TR, t.n - sub * TR);
             const int n0 = t.n0 + sub * TR;
             PFT_STAMP(40);
+            const bool saved = p.sv_z != nullptr;
+            ChainRows<PFT_MAX_CHAIN> CR;         // the saved levels leave with the unit's input rows (one round trip for both)
+            if (saved) chain_request<PFT_MAX_CHAIN>(L, p.sv_z, p.sv_g, p.sv_v, p.sv_stride, (size_t)(n0 - p.node_base), nv, tid, nullptr, CR);
             float* S0 = L.Sin(0); float* V0 = L.Vin(0);
             for (int idx = tid; idx < TR * 32; idx += NT) {
                 const int row = idx >> 5, q = idx & 31;
@@ -668,11 +686,10 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
                 const int row = idx / NF, o = idx - row * NF;
                 s_ge[row * 8 + o] = row < nv ? p.g_eps_h[(size_t)(n0 - p.node_base + row) * NF + o] : 0.f;
             }
+            if (saved) chain_commit<PFT_MAX_CHAIN>(L, p.g, CR, nullptr, tid);
             __syncthreads();
             PFT_STAMP(41);
-            const bool saved = p.sv_z != nullptr;
             if (!saved) chain_fwd(L, p.g, W, pk, nullptr, tid, lane, wv);
-            else chain_load(L, p.g, p.sv_z, p.sv_g, p.sv_v, p.sv_stride, (size_t)(n0 - p.node_base), nv, nullptr, tid);
             PFT_STAMP(42);
             // to_scalar_output: eps_h = Wout act + b ; eps_x = the single output vector channel
             const bool fresh_u = unit == (int)blockIdx.x;           // this block's first unit: its copy holds zeros (zero_class)
@@ -836,40 +853,91 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
                 s_inv[tid] = inv;
             }
             __syncthreads();
-            // ---- aggregate the message partial rows (as k_node_update), dropout, residual
-            if (tid < 256) {
-                const int row = tid >> 4, part = tid & 15;
-                const int n = s_n[row];
-                float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mv[3] = {0, 0, 0};
-                for (int si = 0; si < 2; ++si) {
-                    const int slot = si == 0 ? 0 : (nt == 0 ? p.pp_slot : 1);
-                    const int st = p.in_start[slot * p.N + n];
-                    const int c = p.in_cnt[slot * p.N + n];
-                    const float sc = (p.norm_mode == 0 && c > 0) ? 1.0f / (float)c : 1.0f;
-                    int e = st;
-                    while (e < st + c) {
-                        const int r = min(e | (p.grp - 1), st + c - 1);
-                        const float4 a = reinterpret_cast<const float4*>(p.msg_s + (size_t)r * PF_S)[part * 2];
-                        const float4 b = reinterpret_cast<const float4*>(p.msg_s + (size_t)r * PF_S)[part * 2 + 1];
-                        ms[0] = fmaf(a.x, sc, ms[0]); ms[1] = fmaf(a.y, sc, ms[1]); ms[2] = fmaf(a.z, sc, ms[2]); ms[3] = fmaf(a.w, sc, ms[3]);
-                        ms[4] = fmaf(b.x, sc, ms[4]); ms[5] = fmaf(b.y, sc, ms[5]); ms[6] = fmaf(b.z, sc, ms[6]); ms[7] = fmaf(b.w, sc, ms[7]);
-                        const float* vr = p.msg_v + (size_t)r * 48 + part * 3;
-                        mv[0] = fmaf(vr[0], sc, mv[0]); mv[1] = fmaf(vr[1], sc, mv[1]); mv[2] = fmaf(vr[2], sc, mv[2]);
-                        e = r + 1;
+            // ---- aggregate the message partial rows (as k_node_update), dropout, residual.  One dependent round trip for what the
+            // unit needs of its nodes: the in-edge runs of both slots, the layer-input rows and the upstream gradients leave together;
+            // then the first two partial rows of BOTH runs (a run of ~7 slots spans one or two groups) -- taken one after the other,
+            // run by run and row by row, these were six round trips.  The sums keep their order (slot 0's rows, then the other slot's).
+            {
+                const int rowq = tid >> 5, q = tid & 31;
+                const float4 gq = reinterpret_cast<const float4*>(p.G_h_out + (size_t)s_n[rowq] * PF_S)[q];
+                float4 gvq = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int rowv = min(tid / 12, TR - 1), qv = tid - (tid / 12) * 12;
+                if (tid < TR * 12) gvq = reinterpret_cast<const float4*>(p.G_v_out + (size_t)s_n[rowv] * 48)[qv];
+                if (tid < 256) {
+                    const int row = tid >> 4, part = tid & 15;
+                    const int n = s_n[row];
+                    const int slot1 = nt == 0 ? p.pp_slot : 1;
+                    const int stv[2] = {p.in_start[n], p.in_start[slot1 * p.N + n]};
+                    const int cv[2] = {p.in_cnt[n], p.in_cnt[slot1 * p.N + n]};
+                    const float4 hq0 = reinterpret_cast<const float4*>(p.h_in + (size_t)n * PF_S)[part * 2];
+                    const float4 hq1 = reinterpret_cast<const float4*>(p.h_in + (size_t)n * PF_S)[part * 2 + 1];
+                    float v0[3] = {0.f, 0.f, 0.f};
+                    if (!p.l0) {
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) v0[cc] = p.v_in[(size_t)n * 48 + part * 3 + cc];
                     }
-                }
-                const float inv = s_inv[row];
-                const float* hin = p.h_in + (size_t)n * PF_S + part * 8;
+                    int rr[2][2]; bool on[2][2];
+                    float4 ra[2][2], rb[2][2]; float rv[2][2][3];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float dm = drop_mul(p.c, st_msg, (uint32_t)n * 144u + (uint32_t)(part * 8 + q));
-                    xh1[row * ZS + part * 8 + q] = hin[q] + ms[q] * inv * dm;
-                }
-                const float dmv = drop_mul(p.c, st_msg, (uint32_t)n * 144u + 128u + (uint32_t)part);
+                    for (int si = 0; si < 2; ++si) {
+                        const int end = stv[si] + cv[si];
+                        rr[si][0] = min(stv[si] | (p.grp - 1), end - 1); on[si][0] = cv[si] > 0;
+                        rr[si][1] = min((rr[si][0] + 1) | (p.grp - 1), end - 1); on[si][1] = on[si][0] && rr[si][0] + 1 < end;
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    const float v0 = p.l0 ? 0.f : p.v_in[(size_t)n * 48 + part * 3 + cc];
-                    vy[row * VWS + part * 3 + cc] = v0 + mv[cc] * inv * dmv;
+                        for (int k = 0; k < 2; ++k) {
+                            const size_t r = (size_t)(on[si][k] ? rr[si][k] : p.zero_row);
+                            ra[si][k] = reinterpret_cast<const float4*>(p.msg_s + r * PF_S)[part * 2];
+                            rb[si][k] = reinterpret_cast<const float4*>(p.msg_s + r * PF_S)[part * 2 + 1];
+#pragma unroll
+                            for (int cc = 0; cc < 3; ++cc) rv[si][k][cc] = p.msg_v[r * 48 + part * 3 + cc];
+                        }
+                    }
+                    float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mv[3] = {0, 0, 0};
+#pragma unroll
+                    for (int si = 0; si < 2; ++si) {
+                        const int st = stv[si], c = cv[si];
+                        const float sc = (p.norm_mode == 0 && c > 0) ? 1.0f / (float)c : 1.0f;
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+                            if (on[si][k]) {
+                                const float4 a = ra[si][k], b = rb[si][k];
+                                ms[0] = fmaf(a.x, sc, ms[0]); ms[1] = fmaf(a.y, sc, ms[1]); ms[2] = fmaf(a.z, sc, ms[2]); ms[3] = fmaf(a.w, sc, ms[3]);
+                                ms[4] = fmaf(b.x, sc, ms[4]); ms[5] = fmaf(b.y, sc, ms[5]); ms[6] = fmaf(b.z, sc, ms[6]); ms[7] = fmaf(b.w, sc, ms[7]);
+                                mv[0] = fmaf(rv[si][k][0], sc, mv[0]); mv[1] = fmaf(rv[si][k][1], sc, mv[1]); mv[2] = fmaf(rv[si][k][2], sc, mv[2]);
+                            }
+                        int e = on[si][1] ? rr[si][1] + 1 : st + c;             // (a run beyond two groups: the rest one at a time)
+                        while (e < st + c) {
+                            const int r = min(e | (p.grp - 1), st + c - 1);
+                            const float4 a = reinterpret_cast<const float4*>(p.msg_s + (size_t)r * PF_S)[part * 2];
+                            const float4 b = reinterpret_cast<const float4*>(p.msg_s + (size_t)r * PF_S)[part * 2 + 1];
+                            ms[0] = fmaf(a.x, sc, ms[0]); ms[1] = fmaf(a.y, sc, ms[1]); ms[2] = fmaf(a.z, sc, ms[2]); ms[3] = fmaf(a.w, sc, ms[3]);
+                            ms[4] = fmaf(b.x, sc, ms[4]); ms[5] = fmaf(b.y, sc, ms[5]); ms[6] = fmaf(b.z, sc, ms[6]); ms[7] = fmaf(b.w, sc, ms[7]);
+                            const float* vr = p.msg_v + (size_t)r * 48 + part * 3;
+                            mv[0] = fmaf(vr[0], sc, mv[0]); mv[1] = fmaf(vr[1], sc, mv[1]); mv[2] = fmaf(vr[2], sc, mv[2]);
+                            e = r + 1;
+                        }
+                    }
+                    const float inv = s_inv[row];
+                    const float hin[8] = {hq0.x, hq0.y, hq0.z, hq0.w, hq1.x, hq1.y, hq1.z, hq1.w};
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; ++q8) {
+                        const float dm = drop_mul(p.c, st_msg, (uint32_t)n * 144u + (uint32_t)(part * 8 + q8));
+                        xh1[row * ZS + part * 8 + q8] = hin[q8] + ms[q8] * inv * dm;
+                    }
+                    const float dmv = drop_mul(p.c, st_msg, (uint32_t)n * 144u + 128u + (uint32_t)part);
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) vy[row * VWS + part * 3 + cc] = v0[cc] + mv[cc] * inv * dmv;
+                }
+                // the upstream gradients of the unit's rows wait in LDS for the LayerNorm's backward (rows beyond nv: zeros)
+                {
+                    const bool ok = rowq < nv;
+                    float* d = gu + rowq * ZS + 4 * q;
+                    d[0] = ok ? gq.x : 0.f; d[1] = ok ? gq.y : 0.f; d[2] = ok ? gq.z : 0.f; d[3] = ok ? gq.w : 0.f;
+                    if (tid < TR * 12) {
+                        const bool okv = rowv < nv;
+                        float* dv = gvu + rowv * VWS + 4 * qv;
+                        dv[0] = okv ? gvq.x : 0.f; dv[1] = okv ? gvq.y : 0.f; dv[2] = okv ? gvq.z : 0.f; dv[3] = okv ? gvq.w : 0.f;
+                    }
                 }
             }
             __syncthreads();
@@ -897,6 +965,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
             }
             __syncthreads();
             PFT_STAMP(22);
+            // (requesting the saved levels with the first phase's loads, to save this round trip, measured no gain)
             const bool saved = p.sv_z != nullptr;
             if (!saved) chain_fwd(L, g, W, pk, rvl, tid, lane, wv);
             else chain_load(L, g, p.sv_z, p.sv_g, p.sv_v, p.sv_stride, 0, nv, rvl, tid, s_sv);
@@ -928,16 +997,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_node(const BwdNodeParams p) {
             }
             __syncthreads();
             PFT_STAMP(24);
-            // ---- backward: LN2
-            for (int idx = tid; idx < TR * 128; idx += NT) {
-                const int row = idx >> 7, f = idx & 127;
-                gu[row * ZS + f] = row < nv ? p.G_h_out[(size_t)s_n[row] * PF_S + f] : 0.f;
-            }
-            for (int idx = tid; idx < TR * 48; idx += NT) {
-                const int row = idx / 48, q = idx - row * 48;
-                gvu[row * VWS + q] = row < nv ? p.G_v_out[(size_t)s_n[row] * 48 + q] : 0.f;
-            }
-            __syncthreads();
+            // ---- backward: LN2 (gu / gvu: the upstream gradients, in LDS since the unit's first phase)
             if (tid < 128) {
                 float sw = 0.f, sb = 0.f;
                 for (int r = 0; r < TR; ++r) { const float go = gu[r * ZS + tid]; sw += go * xh2[r * ZS + tid]; sb += go; }
@@ -1453,9 +1513,12 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                 {   // ---- gS = gZ Wm: a wave owns m tiles wv and wv + 8; their packed weight fragments (16 x 1 KiB) are all
                     // requested before the first product, the gZ fragments come from LDS as they are used
                     E2_PHASE();
-                    const bool two = wv + NT / 64 < nts;               // wave-uniform
+                    // (FX == 1: nine m tiles on eight waves -- the ninth is dealt by row half to waves 0 and 1, which sit on different
+                    // SIMDs: whole on wave 0 it made SIMD 0 issue 192 matrix instructions of this phase against 128 on the others)
+                    constexpr bool SPLIT9 = FX == 1;
+                    const bool two = SPLIT9 ? wv < 2 : wv + NT / 64 < nts;               // wave-uniform
                     const f32x4* wp0 = Wp + (size_t)wv * (8 * 64) + lane;
-                    const f32x4* wp1 = Wp + (size_t)(two ? wv + NT / 64 : wv) * (8 * 64) + lane;
+                    const f32x4* wp1 = Wp + (size_t)(SPLIT9 ? (two ? 8 : wv) : (two ? wv + NT / 64 : wv)) * (8 * 64) + lane;
                     f32x4 aq0[8], aq1[8];
 #pragma unroll
                     for (int sb = 0; sb < 8; ++sb) aq0[sb] = wp0[sb * 64];
@@ -1486,7 +1549,14 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                             *reinterpret_cast<f32x4*>(gS + li * E2_SS + 16 * wv + 4 * kq) = acc0;
                             *reinterpret_cast<f32x4*>(gS + (16 + li) * E2_SS + 16 * wv + 4 * kq) = acc1;
                         }
-                        if (two) {
+                        if constexpr (SPLIT9) {
+                            if (two) {
+                                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                for (int sp = 0; sp < 4; ++sp) acc = mfma_bf32(bf_pack8(aq1[2 * sp], aq1[2 * sp + 1]), wv == 0 ? bz0[sp] : bz1[sp], acc);
+                                *reinterpret_cast<f32x4*>(gS + (16 * wv + li) * E2_SS + 16 * 8 + 4 * kq) = acc;
+                            }
+                        } else if (two) {
                             const int mt = wv + NT / 64;
                             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1513,7 +1583,19 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_edge_level(const BwdEdgeLevelPara
                         *reinterpret_cast<f32x4*>(gS + li * E2_SS + 16 * wv + 4 * kq) = acc0;
                         *reinterpret_cast<f32x4*>(gS + (16 + li) * E2_SS + 16 * wv + 4 * kq) = acc1;
                     }
-                    if (two) {
+                    if constexpr (SPLIT9) {
+                        if (two) {
+                            const float* bp = wv == 0 ? b0p : b1p;
+                            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int sb = 0; sb < 8; ++sb) {
+                                const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 16 * sb);
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq1[sb][t], b[t], acc, 0, 0, 0);
+                            }
+                            *reinterpret_cast<f32x4*>(gS + (16 * wv + li) * E2_SS + 16 * 8 + 4 * kq) = acc;
+                        }
+                    } else if (two) {
                         const int mt = wv + NT / 64;
                         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
