@@ -265,6 +265,42 @@ __device__ __forceinline__ void mm16_acc_rows(const int M, const int N, FA a, FB
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const float x = a(min(ai, M - 1), BF16 ? 4 * kq + u : 4 * u + kq); av[u] = ai < M ? x : 0.f; }
     const int nts = (N + 15) >> 4;
+    // Whole tiles (block-uniform): the product is taken TRANSPOSED -- the operands swap roles, a lane
+    // then holds four consecutive columns of one row -- and leaves as one 16-byte store per lane and tile instead of four 4-byte
+    // stores over four rows (36 -> 9 store instructions per wave and GVP level; the phase was bound by them)
+    // (the rows of the flat gradient are 4-byte aligned only: dwordx4 accesses at such addresses are what the hardware's unaligned
+    // access mode, the default under HSA, is for)
+    typedef f32x4 f32x4_u __attribute__((aligned(4)));
+    const bool quad = (M & 15) == 0 && (N & 15) == 0;
+    if (quad) {
+        for (int nt0 = 0; nt0 < nts; nt0 += 4) {
+            float bv[4][4];
+            f32x4 old[4], acc[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const bool on = nt0 + x < nts;
+                const int bj = (on ? nt0 + x : nt0) * 16 + li;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bv[x][u] = b(BF16 ? 4 * kq + u : 4 * u + kq, bj);
+                old[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!fresh && on) old[x] = *reinterpret_cast<const f32x4_u*>(G + (size_t)ai * ld + (nt0 + x) * 16 + 4 * kq);
+                acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if constexpr (BF16) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[x] = mfma_bf16(bf_pack4(bv[x]), bf_pack4(av), acc[x]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[x][u], av[u], acc[x], 0, 0, 0);
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                if (nt0 + x < nts) *reinterpret_cast<f32x4_u*>(G + (size_t)ai * ld + (nt0 + x) * 16 + 4 * kq) = old[x] + acc[x];
+        }
+        return;
+    }
     // n tiles in groups of four: the group's operands (and, when the copy is not fresh, its old values) are all requested before
     // the first product, the products of the group are independent of each other, the stores follow -- one n tile at a time was a
     // chain of LDS read -> four dependent matrix instructions -> store per tile (9 k cycles per GVP level for eleven tiles)
