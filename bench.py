@@ -891,8 +891,18 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # sustained clocks before the warm-up (see main).  Every step of this leg holds a collective (the gradient all-reduce), so the
+    # ranks must leave the loop after the SAME number of steps: a clock read per rank let one rank start a step its peers never
+    # joined (an intermittent hang of the two-rank run) -- rank 0's verdict is broadcast each round
     tp = time.perf_counter()
-    while (time.perf_counter() - tp) * 1e3 < args.prewarm_ms:      # sustained clocks before the warm-up (see main)
+    while True:
+        go = (time.perf_counter() - tp) * 1e3 < args.prewarm_ms
+        if world > 1:
+            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.broadcast(flag, src=0)
+            go = bool(int(flag.item()))
+        if not go:
+            break
         step()
         torch.cuda.synchronize()
     for _ in range(W):
