@@ -16,7 +16,7 @@ python3 bench.py --train --train-dtype bf16 --steps 100 --warmup 10 > $OUT/train
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_bf16_stats -- python3 bench.py --train --train-dtype bf16 --steps 20 --warmup 4 > $OUT/train_bf16_stats.log 2>&1
 cp $(ls $OUT/train_bf16_stats/*/*kernel_stats.csv | head -1) $OUT/train_bf16_kernel_stats.csv; rm -rf $OUT/train_bf16_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -- python3 bench.py --train --steps 20 --warmup 4 > $OUT/train_stats.log 2>&1
-cp $(ls $OUT/train_stats/*/*kernel_stats.csv | head -1) $OUT/train_kernel_stats.csv; rm -rf $OUT/train_stats
+cp $(ls $OUT/train_stats/*/*kernel_stats.csv | head -1) $OUT/train_kernel_stats.csv; python3 tools/train_step_timeline.py $OUT/train_stats > $OUT/train_step_timeline.txt 2>&1; rm -rf $OUT/train_stats
 python3 bench.py --sample-slice 64 > $OUT/config4_slice_bench.json 2>/dev/null; echo "slice rc=$?"
 python3 bench.py --sample-slice 1000 > $OUT/config4_full_bench.json 2>/dev/null; echo "full rc=$?"
 # the optional tail launches, both forms, next to the default
