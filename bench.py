@@ -875,7 +875,7 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
     opt = pfa.FlatAdam(m.dynamics, lr=1e-4, weight_decay=1e-12)
 
     def step():
-        opt.zero_grad()
+        opt.zero_grad(lazy=True)
         g = graphs[it[0] % len(graphs)]
         it[0] += 1
         loss = m.training_step(g, 0)

@@ -226,23 +226,30 @@ class PfEngine:
                                                     _dptr(out), _stream_ptr()), "pf_train_loss_forward")
         return out
 
-    def train_loss_backward(self, g_pos, g_feat):
-        """d(g_pos * pos loss + g_feat * feat loss)/d(parameters) of the last train_loss_forward, as one flat vector."""
-        gp, gf = _f32(g_pos, self.device).reshape(1), _f32(g_feat, self.device).reshape(1)
+    def _grad_out(self, out):
         if not hasattr(self, "n_params"):
             self.param_layout()
-        grad = torch.empty(self.n_params, device=self.device)
+        if out is None:
+            return torch.empty(self.n_params, device=self.device)
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != self.n_params or out.device != self.device:
+            raise ValueError("`out` must be a contiguous fp32 vector of n_params elements on the engine's device")
+        return out
+
+    def train_loss_backward(self, g_pos, g_feat, out=None):
+        """d(g_pos * pos loss + g_feat * feat loss)/d(parameters) of the last train_loss_forward, as one flat vector.
+        out: an existing flat fp32 device vector to receive the gradient (every element is stored, nothing is accumulated)."""
+        gp, gf = _f32(g_pos, self.device).reshape(1), _f32(g_feat, self.device).reshape(1)
+        grad = self._grad_out(out)
         with torch.cuda.device(self.device):
             self._ck(self.lib.pf_train_loss_backward(self._h, _dptr(gp), _dptr(gf), _dptr(grad), _stream_ptr()),
                      "pf_train_loss_backward")
         return grad
 
-    def train_loss_backward_out(self, g_out):
-        """The same from the upstream gradient of train_loss_forward's whole output vector ([9]; entries 0, 1 and 6 count)."""
+    def train_loss_backward_out(self, g_out, out=None):
+        """The same from the upstream gradient of train_loss_forward's whole output vector ([9]; entries 0, 1 and 6 count).
+        out: an existing flat fp32 device vector to receive the gradient (every element is stored, nothing is accumulated)."""
         go = _f32(g_out, self.device).reshape(9)
-        if not hasattr(self, "n_params"):
-            self.param_layout()
-        grad = torch.empty(self.n_params, device=self.device)
+        grad = self._grad_out(out)
         with torch.cuda.device(self.device):
             self._ck(self.lib.pf_train_loss_backward_out(self._h, _dptr(go), _dptr(grad), _stream_ptr()),
                      "pf_train_loss_backward_out")

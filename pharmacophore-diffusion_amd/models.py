@@ -173,15 +173,37 @@ class _LossFn(torch.autograd.Function):
                                      dropout=dropout, seed=seed)
         mod._fwd_token += 1
         ctx.mod, ctx.eng, ctx.token = mod, eng, mod._fwd_token
-        return out
+        ctx.set_materialize_grads(False)
+        # second output: the total loss (entry 6) as a 0-dim tensor of its own -- a step that differentiates only the total loss
+        # then hands its upstream scalar straight to the C ABI instead of scattering it into a [9] vector first (a zero fill and
+        # a copy launch per step)
+        return out, out[6]
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, g_total):
         mod, eng = ctx.mod, ctx.eng
         if ctx.token != mod._fwd_token:
             raise RuntimeError("backward of a loss forward that is not the most recent training forward: the engine keeps "
                                "the activations of one forward at a time")
-        return (None,) * 14 + (eng.train_loss_backward_out(g_out),)
+        if g_out is None and g_total is None:
+            return (None,) * 15
+        leaf = mod.__dict__.get("_flat_leaf")
+        # FlatAdam.zero_grad(lazy=True) left the clear to this backward: the gradient kernels STORE every element, so writing
+        # into the bound flat gradient is the clear and the accumulation at once (no fill, no add: two 3 MB launches per step);
+        # the parameters' .grad views stay bound, the accumulate hooks are not needed (no gradient is returned for the leaf)
+        into = leaf.grad if (mod.__dict__.get("_grad_lazy_zero") and leaf is not None and leaf.grad is not None) else None
+        if g_out is None:
+            g = eng.train_loss_backward(g_total, g_total, out=into)          # total loss = pos loss + feat loss
+        else:
+            if g_total is not None:
+                g_out = g_out.clone()
+                g_out[6] += g_total
+            g = eng.train_loss_backward_out(g_out, out=into)
+        if into is not None:
+            mod.__dict__["_grad_lazy_zero"] = False
+            mod._last_flat_grad = into
+            return (None,) * 15
+        return (None,) * 14 + (g,)
 
 
 class PharmRecDynamicsGVP(nn.Module):
@@ -303,6 +325,10 @@ class PharmRecDynamicsGVP(nn.Module):
 
     def _before_accumulate(self, grad):
         leaf = self.__dict__["_flat_leaf"]
+        if self.__dict__.get("_grad_lazy_zero"):        # a deferred clear (FlatAdam.zero_grad(lazy=True)) met by a backward that accumulates
+            self.__dict__["_grad_lazy_zero"] = False
+            if leaf.grad is not None:
+                leaf.grad.zero_()
         if leaf.grad is not None:
             p0 = next((p for p, _, _ in self._flat_views if p.requires_grad), None)
             if p0 is None or p0.grad is None or p0.grad.data_ptr() != leaf.grad.data_ptr() + 4 * next(o for q, o, _ in self._flat_views if q is p0):
@@ -404,18 +430,27 @@ class FlatAdam:
         self.exp_avg = self.exp_avg_sq = None
         self.param_groups = [{'lr': lr}]            # what LR schedulers / loggers look at
 
-    def zero_grad(self, set_to_none: bool = False):
+    def zero_grad(self, set_to_none: bool = False, lazy: bool = False):
         """Default (``set_to_none=False``): the flat gradient is zeroed IN PLACE -- one small kernel; the 244 parameters'
         ``.grad`` stay the views of it that the last backward bound, the next backward accumulates into it.  Clearing and
         re-creating 244 views per step costs ~0.8 ms of host time, which is what bounds a step that binds a new batch.
-        ``set_to_none=True`` drops everything, like torch.optim's default."""
+        ``set_to_none=True`` drops everything, like torch.optim's default.
+        ``lazy=True`` (training loops that call zero_grad -> backward -> step): nothing is launched here; the next backward of
+        the fused loss stores its gradient straight into the bound flat vector (clear and accumulation in one), any other
+        backward clears it first.  Until then ``.grad`` still shows the previous step's values."""
         views = self.dyn._flat_views
         leaf = self.dyn.__dict__.get("_flat_leaf")
         if not set_to_none and leaf is not None and leaf.grad is not None and views:
             p0, o0 = next(((p, o) for p, o, _ in views if p.requires_grad), (None, 0))
             if p0 is not None and p0.grad is not None and p0.grad.data_ptr() == leaf.grad.data_ptr() + 4 * o0:
-                leaf.grad.zero_()
+                if lazy:
+                    self.dyn.__dict__["_grad_lazy_zero"] = True
+                    self.dyn._last_flat_grad = None         # step() without a backward in between has no gradient
+                else:
+                    self.dyn.__dict__["_grad_lazy_zero"] = False
+                    leaf.grad.zero_()
                 return
+        self.dyn.__dict__["_grad_lazy_zero"] = False
         for p in ([p for p, _, _ in views] if views else self.dyn.parameters()):
             p.grad = None
         if leaf is not None:
@@ -890,17 +925,18 @@ class PharmacophoreDiff(_Base):
         args = (x0, h0, t_int, eps['x'], eps['h'], self._loss_tables(), self.n_timesteps, float(self.pharm_feat_norm_constant),
                 bool(self.remove_com), bool(self.weighted_loss), p_drop, seed)
         if need_grad:
-            out = _LossFn.apply(dyn, eng, *args, dyn.__dict__["_flat_leaf"])
+            out, total = _LossFn.apply(dyn, eng, *args, dyn.__dict__["_flat_leaf"])
         else:
             out = eng.train_loss_forward(args[0], args[1], args[2], args[3], args[4], args[5][0], args[5][1], *args[6:10],
                                          dropout=p_drop, seed=seed)
+            total = out[6]
         losses = {phase + ' pos loss': out[0], phase + ' feat loss': out[1]}
         m = out.detach()
         metrics = {phase + ' position error': m[2], phase + ' weighted position error': m[3],
                    phase + ' accuracy': m[4], phase + ' weighted accuracy': m[5]}
         # the sums a step derives from these (total loss, total error, weighted total error) came out of the same kernel:
         # training_step / validation_step pick them up instead of spending framework launches on three additions
-        self.__dict__["_fused_sums"] = (out[6], m[7], m[8])
+        self.__dict__["_fused_sums"] = (total, m[7], m[8])
         return losses, metrics
 
     def configure_optimizers(self):

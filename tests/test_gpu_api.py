@@ -745,6 +745,46 @@ def test_gradient_views_accumulate_clear_and_allreduce_in_place():
         dist.destroy_process_group()
 
 
+def test_flat_adam_lazy_clear_equals_the_eager_one():
+    """FlatAdam.zero_grad(lazy=True) launches nothing; the next fused-loss backward stores its gradient into the bound flat vector
+    (clear + accumulation in one).  Three optimiser steps give bitwise the parameters of the eager loop; a backward that accumulates
+    through autograd instead (the framework-op loss) clears first; step() without a backward in between refuses."""
+    z = load("train_grads.npz")
+    b = batch_from(z)
+    inj = dict(t_int=z["t_int"].long(), eps={'h': z["eps_h"], 'x': z["eps_x"]})
+
+    def run(lazy):
+        m = make_model(int(z["T"]))
+        m.train()
+        g = graph_from(b, z["x0"], z["h0"]).to("cuda")
+        opt = pfa.FlatAdam(m.dynamics, lr=1e-3)
+        for i in range(3):
+            opt.zero_grad(lazy=lazy)
+            torch.manual_seed(11 + i)
+            m.training_step(g, 0, **inj).backward()
+            opt.step()
+        return m, opt, g
+
+    m_e, _, _ = run(False)
+    m_l, opt, g = run(True)
+    for (k, a), (_, c) in zip(m_e.dynamics.state_dict().items(), m_l.dynamics.state_dict().items()):
+        assert torch.equal(a, c), k
+    # a deferred clear met by a backward that accumulates through autograd: cleared first, not added to the stale values
+    params = [p for p in m_l.dynamics.parameters() if p.numel() > 0]
+    opt.zero_grad(lazy=True)
+    with pytest.raises(RuntimeError):
+        opt.step()
+    torch.manual_seed(5)
+    m_l.training_step(g, 0, **inj).backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in params]).clone()
+    opt.zero_grad(lazy=True)
+    m_l.fused_loss = False
+    torch.manual_seed(5)
+    m_l.training_step(g, 0, **inj).backward()
+    got = torch.cat([p.grad.reshape(-1) for p in params])
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=1e-6)
+
+
 def test_flat_adam_resumes_from_a_per_parameter_adam_state():
     """A checkpoint written by the reference's Lightning run carries torch.optim.Adam's per-parameter state
     (pharmacodiff.py:253-263); FlatAdam.load_state_dict maps it into the flat moment vectors (parameter i = tensor i of

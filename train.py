@@ -115,7 +115,7 @@ def main():
         loader = dm.train_dataloader(shuffle=sampler is None, sampler=sampler)
         model.attach_trainer(dm, loader, current_epoch=epoch, optimizer=opt)
         for i, g in enumerate(loader):
-            opt.zero_grad()
+            opt.zero_grad(lazy=True)
             loss = model.training_step(g.to(dev), i)
             loss.backward()
             if world > 1:
