@@ -66,7 +66,7 @@ void pfk_fix_scale(const float* g_h, int n_h, const float* g_x, int n_x, float* 
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s);
 void pfk_enc_group(const float* G_h, const int* prot_ptr, const int* ptype, int B, int rec_nf, float* Gg, hipStream_t s);
 void pfk_fix_enc_group(long long* A_h, float* G_h, const float* fix, const int* prot_ptr, const int* ptype, int B, int rec_nf, float* Gg,
-                       int Np, int Nf, hipStream_t s);
+                       int Np, int Nf, const int* onehot_flag, hipStream_t s);
 void pfk_train_reduce(const ReduceParams* p, hipStream_t s);
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s);
 void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float* out_f, hipStream_t s);
@@ -3045,7 +3045,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
                                h->t_fix, s);
         else if (l == 0 && enc_grouped && !h->no_fix_fuse) {
             // conv layer 0: the scalar sums join G_h in the same pass that groups the protein rows by (graph, element) for the encoders
-            pfk_fix_enc_group(h->t_A_h, e.G_h_in, h->t_fix, h->d_prot_ptr, h->d_ptype, h->B, c.rec_nf, h->t_Gg, h->Np, h->Nf, s);
+            pfk_fix_enc_group(h->t_A_h, e.G_h_in, h->t_fix, h->d_prot_ptr, h->d_ptype, h->B, c.rec_nf, h->t_Gg, h->Np, h->Nf, h->d_l0flag, s);
             enc_grouped_done = true;
         } else {
             pfk_fix_apply(h->t_A_h, e.G_h_in, (size_t)N * PF_S, h->t_fix, s);

@@ -383,13 +383,14 @@ struct ChainLds {
 };
 
 // Vh = Wh^T V and Vu = Wu^T Vh of one GVP for the 16 rows (gvp.py:97-101); sh goes to Sin[:, si:] when want_sh
-// (FX: the GVP is the update / head shape -- 16 vector channels in, hidden and out, 128 scalars in and out: the dimensions are
+// (FX 1: the GVP is the update / head shape -- 16 vector channels in, hidden and out, 128 scalars in and out; FX 2: the noise head's last
+// GVP -- one vector channel out, 64 scalars out: the dimensions are
 // compile-time constants in every product below, whose tile loops, index clamps and bounds predicates then fold away.  These
 // kernels are bound by the vector ALU instructions AROUND their matrix instructions, not by the products.)
-template <bool FX = false>
+template <int FX = 0>
 __device__ __forceinline__ void gvp_vec(const GvpT& g, const float* Wh, const float* Wu, float* Sin, const float* Vin, float* Vh, float* Vu,
                                         const bool want_sh, const int tid, const int lane, const int wv) {
-    const int KH = FX ? 16 : g.h, VI = FX ? 16 : g.vi, VO = FX ? 16 : g.vo, SIv = FX ? 128 : g.si;
+    const int KH = FX ? 16 : g.h, VI = FX ? 16 : g.vi, VO = FX == 1 ? 16 : (FX == 2 ? 1 : g.vo), SIv = FX ? 128 : g.si;
     mm16<5>(KH, 3 * TR, VI,
          [&](int i, int k) { return Wh[k * KH + i]; },
          [&](int k, int j) { return Vin[(j & 15) * VWS + k * 3 + (j >> 4)]; },
@@ -450,7 +451,7 @@ __device__ __forceinline__ void gvp_fwd(const GvpT& g, const float* W, const Pac
 // backward of one GVP on the tile.  In: gA = dL/d act [row][so] (stride SWS), gVo = dL/d Vout [row][vo*3].
 // Out: gS = dL/d Sin[:, :si+h] (the first si entries are the input-scalar gradient), gVi = dL/d Vin.  gA and gVo are
 // overwritten (they become dL/dZ and dL/dVu).  Weight gradients are accumulated into gp (this block's copy).
-template <bool BF16, bool FX = false>
+template <bool BF16, int FX = 0>
 __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const PackPtr pk, const bool fresh, float* gp, const float* Sin, const float* Vin,
                                         const float* Z, const float* gate, const float* act, const int act_stride,
                                         float* gA, float* gS, float* gVo, float* gVi, float* Vh, float* Vu, float* gVh,
@@ -462,7 +463,8 @@ __device__ __forceinline__ void gvp_bwd(const GvpT& g, const float* W, const Pac
     asm volatile("" : "+v"(zz_));
     const int tid = tid_ + zz_, lane = tid & 63;
     (void)lane_;
-    const int KH = FX ? 16 : g.h, VI = FX ? 16 : g.vi, VO = FX ? 16 : g.vo, SI = FX ? 128 : g.si, SO = FX ? 128 : g.so, KM = SI + KH;
+    const int KH = FX ? 16 : g.h, VI = FX ? 16 : g.vi, VO = FX == 1 ? 16 : (FX == 2 ? 1 : g.vo), SI = FX ? 128 : g.si;
+    const int SO = FX == 1 ? 128 : (FX == 2 ? 64 : g.so), KM = SI + KH;
     PFT_STAMP(10);
     // the bias gradients' old values (a copy that is not fresh) are requested here and added where the sums are known: read
     // there, the round trip sat between the sum and the barrier every wave of the block waits at
@@ -640,7 +642,7 @@ __device__ __forceinline__ void chain_load(const ChainLds& L, const GvpT* g, con
 }
 // backward through the chain: upstream gradients in L.gX ([row][so_last], stride SWS) and L.gVX; returns through
 // gs_out / gv_out the buffers that hold dL/d Sin(0) and dL/d Vin(0)
-template <bool BF16>
+template <bool BF16, bool HEAD = false>
 __device__ __forceinline__ void chain_bwd(const ChainLds& L, const GvpT* g, const float* W, const PackPtr pk, const bool fresh, float* gp,
                                           float*& gs_out, float*& gv_out, const int tid, const int lane, const int wv, const bool fill_sh = false,
                                           float* wst = nullptr) {
@@ -648,11 +650,16 @@ __device__ __forceinline__ void chain_bwd(const ChainLds& L, const GvpT* g, cons
     for (int l = L.nlv - 1; l >= 0; --l) {
         const bool last = l == L.nlv - 1;
         const bool fx = g[l].vi == 16 && g[l].h == 16 && g[l].vo == 16 && g[l].si == 128 && g[l].so == 128 && g[l].sig;      // block-uniform
+        bool fx2 = false;
+        if constexpr (HEAD) fx2 = g[l].vi == 16 && g[l].h == 16 && g[l].vo == 1 && g[l].si == 128 && g[l].so == 64;      // the noise head's last GVP
         if (fx)
-            gvp_bwd<BF16, true>(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+            gvp_bwd<BF16, 1>(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+                    ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh, wst);
+        else if (HEAD && fx2)
+            gvp_bwd<BF16, HEAD ? 2 : 0>(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
                     ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh, wst);
         else
-            gvp_bwd<BF16, false>(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+            gvp_bwd<BF16, 0>(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
                     ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh, wst);
         float* t0 = ga; ga = gs; gs = t0;
         float* t1 = gvo; gvo = gvi; gvi = t1;
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(NT, 1) void k_bwd_head(const BwdHeadParams p) {
             __syncthreads();
             PFT_STAMP(43);
             float *gs, *gv;
-            chain_bwd<BF16>(L, p.g, W, pk, unit == (int)blockIdx.x, gp, gs, gv, tid, lane, wv, saved, s_wst);
+            chain_bwd<BF16, true>(L, p.g, W, pk, unit == (int)blockIdx.x, gp, gs, gv, tid, lane, wv, saved, s_wst);
             PFT_STAMP(44);
             for (int idx = tid; idx < TR * 128; idx += NT) {
                 const int row = idx >> 7, f = idx & 127;
@@ -1845,8 +1852,11 @@ __global__ __launch_bounds__(1024) void k_enc_group(const float* G_h, const int*
 // per-(graph, element) sums of the updated protein rows (same per-element arithmetic and the same summation order as the two
 // kernels one after the other; the 34 MB of G_h are not read a second time).  Blocks [0, B): one graph's protein atoms; the blocks
 // behind them: the pharm rows [Np, Np + Nf), element by element
+// (onehot_flag[0] == 0: the encoders' backward reads the protein rows' gradient from Gg only -- their updated G_h rows, which nothing
+// else reads after conv layer 0, are then not written back: 34 MB of stores less at 256 pockets)
 __global__ __launch_bounds__(1024) void k_fix_enc_group(long long* A_h, float* G_h, const float* fix, const int* prot_ptr, const int* ptype,
-                                                        const int B, const int rec_nf, float* Gg, const int Np, const int Nf) {
+                                                        const int B, const int rec_nf, float* Gg, const int Np, const int Nf,
+                                                        const int* onehot_flag) {
     __shared__ float acc[8][16][PF_S];
     const int tid = threadIdx.x;
     const double inv = (double)fix[1];
@@ -1860,6 +1870,7 @@ __global__ __launch_bounds__(1024) void k_fix_enc_group(long long* A_h, float* G
         return;
     }
     const int g = blockIdx.x, ph = tid >> 7, f = tid & 127;
+    const bool keep = onehot_flag[0] != 0;                      // block-uniform: the ungrouped encoders' backward reads G_h itself
     for (int e = 0; e < rec_nf; ++e) acc[ph][e][f] = 0.f;
     const int p1 = prot_ptr[g + 1];
     for (int n = prot_ptr[g] + ph; n < p1; n += 32) {          // four atoms per trip, all their loads in flight before the first add
@@ -1877,7 +1888,7 @@ __global__ __launch_bounds__(1024) void k_fix_enc_group(long long* A_h, float* G
             if (on[u]) {
                 const size_t o = (size_t)(n + 8 * u) * PF_S + f;
                 float v = x[u];
-                if (a[u] != 0) { v += (float)((double)a[u] * inv); G_h[o] = v; A_h[o] = 0; }
+                if (a[u] != 0) { v += (float)((double)a[u] * inv); if (keep) G_h[o] = v; A_h[o] = 0; }
                 acc[ph][e[u]][f] += v;
             }
     }
@@ -2371,9 +2382,10 @@ void pfk_enc_group(const float* G_h, const int* prot_ptr, const int* ptype, int 
     if (B > 0) hipLaunchKernelGGL(k_enc_group, dim3(B), dim3(1024), 0, s, G_h, prot_ptr, ptype, rec_nf, Gg);
 }
 void pfk_fix_enc_group(long long* A_h, float* G_h, const float* fix, const int* prot_ptr, const int* ptype, int B, int rec_nf, float* Gg,
-                       int Np, int Nf, hipStream_t s) {
+                       int Np, int Nf, const int* onehot_flag, hipStream_t s) {
     const int extra = (int)(((size_t)Nf * PF_S + 1023) / 1024);
-    if (B + extra > 0) hipLaunchKernelGGL(k_fix_enc_group, dim3(B + extra), dim3(1024), 0, s, A_h, G_h, fix, prot_ptr, ptype, B, rec_nf, Gg, Np, Nf);
+    if (B + extra > 0)
+        hipLaunchKernelGGL(k_fix_enc_group, dim3(B + extra), dim3(1024), 0, s, A_h, G_h, fix, prot_ptr, ptype, B, rec_nf, Gg, Np, Nf, onehot_flag);
 }
 void pfk_bwd_encode(const BwdEncodeParams* p, int nblocks, hipStream_t s) {
     hipLaunchKernelGGL(k_bwd_encode, dim3(nblocks), dim3(NT), 0, s, *p);
