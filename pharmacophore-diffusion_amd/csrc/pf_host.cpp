@@ -412,7 +412,7 @@ struct pf_handle {
     int* t_ulist = nullptr;                 // dense per-type row list of the layer being differentiated (k_compact_node_rows; counts: t_ccnt[97], [98])
     int t_ucap = 0;
     size_t t_clist_cap = 0, t_ulist_cap = 0;   // ints per conv layer in t_clist / t_ulist (one list per layer: they are built ahead, on the side stream)
-    hipEvent_t cmp_ev[2] = {nullptr, nullptr};
+    hipEvent_t cmp_ev[3] = {nullptr, nullptr, nullptr};
     int *t_clist = nullptr, *t_ccnt = nullptr;   // dense list of the valid edge slots of the layer being differentiated (k_compact_rows), counts
     float* t_fix = nullptr;                 // [2] scale / inverse scale of the current backward call
     int t_nblk = 0;
@@ -1439,7 +1439,7 @@ void pf_destroy(pf_handle* h) {
         if (h->tab_guard[k]) (void)hipEventDestroy(h->tab_guard[k]);
         if (h->tab_up[k]) (void)hipEventDestroy(h->tab_up[k]);
     }
-    for (int k = 0; k < 2; ++k) if (h->cmp_ev[k]) (void)hipEventDestroy(h->cmp_ev[k]);
+    for (int k = 0; k < 3; ++k) if (h->cmp_ev[k]) (void)hipEventDestroy(h->cmp_ev[k]);
     if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
     if (h->s_side) (void)hipStreamDestroy(h->s_side);
     if (h->l0flag_host) (void)hipHostFree(h->l0flag_host);
@@ -2918,18 +2918,21 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         n_et = last ? 2 : 4;                         // the last layer's fp / pp messages reach no output
     };
     {
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 3; ++k)
             if (!h->cmp_ev[k]) PF_HIP(h, hipEventCreateWithFlags(&h->cmp_ev[k], hipEventDisableTiming));
         if (!h->s_side) PF_HIP(h, hipStreamCreateWithFlags(&h->s_side, hipStreamNonBlocking));
         hipStream_t side = h->s_side;
         if (side != s) { PF_HIP(h, hipEventRecord(h->cmp_ev[0], s)); PF_HIP(h, hipStreamWaitEvent(side, h->cmp_ev[0], 0)); }
-        pfk_fix_scale(dev_g_eps_h, h->Nf * c.pharm_nf, dev_g_eps_x, h->Nf * 3, h->t_fix, side);      // (first read by the last layer's edge kernels)
-        for (int l = L - 1; l >= 0; --l) {
+        // two groups: what the first layer of the loop below needs at once (its work lists, its cleared input gradients: cmp_ev[1]),
+        // then the rest (the fixed-point scale, first read by that layer's edge kernels; the other layers' lists: cmp_ev[2], waited
+        // for behind that layer's node kernel) -- as one group the side stream outlasted the head's backward by 28 us once that took 59
+        auto lists = [&](int l) {
             const NodeTile* ntt; const EdgeTile* ett; const int* et0; int ntn, n_et;
             layer_tables(l, ntt, ntn, ett, et0, n_et);
             pfk_compact_node_rows(ntt, ntn, h->d_dyn_cnt, h->d_act_ids, N, h->t_ulist + h->t_ulist_cap * l, h->t_ucap, h->t_ccnt + 96 + 4 * l, side);
             pfk_compact_rows(ett, et0, n_et, h->d_dyn_cnt, h->t_clist + h->t_clist_cap * l, h->t_ccnt + 16 * l, side);
-        }
+        };
+        lists(L - 1);
         if (side != s) {
             // the first layer of the loop below receives its input gradients in G[1]: cleared here, under the head's backward
             ZeroBatch zb(side);
@@ -2939,6 +2942,9 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
             first_clear_done = true;
             PF_HIP(h, hipEventRecord(h->cmp_ev[1], side));
         }
+        pfk_fix_scale(dev_g_eps_h, h->Nf * c.pharm_nf, dev_g_eps_x, h->Nf * 3, h->t_fix, side);      // (first read by the last layer's edge kernels)
+        for (int l = L - 2; l >= 0; --l) lists(l);
+        if (side != s) PF_HIP(h, hipEventRecord(h->cmp_ev[2], side));
     }
     // (the head kernel stores dL/d(last layer output) for every pharm row, and the last layer's node kernel reads those rows
     // only: no clearing of t_G_*[0] here)
@@ -3002,6 +3008,7 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
         n.ulist = h->t_ulist + h->t_ulist_cap * l; n.ucnt = h->t_ccnt + 96 + 4 * l; n.ucap = h->t_ucap;
         rp.node_grid[l] = n.ntiles > 0 ? std::max(1, std::min(nb, 2 * n.ntiles)) : 0;
         { ProfScope ps(h, pf_handle::K_BWD_NODE, s); pfk_bwd_node(&n, rp.node_grid[l], s); }
+        if (last && h->s_side != s) PF_HIP(h, hipStreamWaitEvent(s, h->cmp_ev[2], 0));      // the side stream's second group (above)
         BwdEdgeLevelParams e{};
         e.c = tc; e.tiles = pruned ? h->d_edge_tiles_act : h->d_edge_tiles; e.dyn_cnt = h->d_dyn_cnt;
         e.pp_slot = pruned ? 2 : 1;
