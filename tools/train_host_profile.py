@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host time of the pieces of a training step (no synchronisation inside the step): where a step is host-bound.
-    python tools/train_host_profile.py [batches]"""
+    python tools/train_host_profile.py [batches]   (host enqueue time per step against the device-bound step time, then a cProfile of 100 steps)"""
 import itertools
 import os
 import sys
@@ -39,21 +39,24 @@ for r in range(nb):
     h0 = torch.nn.functional.one_hot(torch.randint(0, 6, (Nf,), generator=gen), 6).float()
     graphs.append(pfa.PocketGraph(prot_x, prot_h, prot_ptr, pharm_ptr, pp_src, pp_dst, pharm_x0=x0, pharm_h0=h0).to(dev))
 opt = pfa.FlatAdam(m.dynamics, lr=1e-4, weight_decay=1e-12)
-acc = [0.0] * 6
-K = 40
-for it in range(K + 10):
-    if it == 10:
-        torch.cuda.synchronize(); acc = [0.0] * 6; t_all = time.perf_counter()
-    t0 = time.perf_counter(); opt.zero_grad()
+import cProfile, pstats
+def step(it):
+    opt.zero_grad(lazy=True)
     g = graphs[it % nb]
-    t1 = time.perf_counter(); m.dynamics.bind_graph(g)
-    t2 = time.perf_counter(); loss = m.training_step(g, 0)
-    t3 = time.perf_counter(); loss.backward()
-    t4 = time.perf_counter(); opt.step()
-    t5 = time.perf_counter()
-    for k, d in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
-        acc[k] += d
+    loss = m.training_step(g, 0)
+    loss.backward()
+    opt.step()
+for it in range(20): step(it)
 torch.cuda.synchronize()
-tot = time.perf_counter() - t_all
-print(f"batches {nb}: step {1e3 * tot / K:.2f} ms; host: zero_grad {1e3 * acc[0] / K:.2f}  bind {1e3 * acc[1] / K:.2f}  training_step {1e3 * acc[2] / K:.2f}  "
-      f"backward {1e3 * acc[3] / K:.2f}  adam {1e3 * acc[4] / K:.2f}  = {1e3 * sum(acc[:5]) / K:.2f} ms")
+t0 = time.perf_counter()
+for it in range(200): step(it)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"200 steps: host enqueue {1e3 * (t1 - t0) / 200:.3f} ms per step, with the device {1e3 * (t2 - t0) / 200:.3f} ms per step")
+pr = cProfile.Profile()
+pr.enable()
+for it in range(100): step(it)
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
