@@ -420,10 +420,20 @@ struct pf_handle {
     bool t_have_fwd = false;
     bool t_ws_ready = false;                // d_tws is carved (and its zero rows set) for the current batch
     TrainCommon t_common{};
+    // (looked up ~26 times per backward pass: an index over the 244 names, rebuilt when the layout is -- a linear search with string
+    // compares was 50-100 us of a training step's host time, and that step is host-bound with a new batch every step)
+    mutable std::unordered_map<std::string, size_t> flat_index;
+    mutable bool flat_index_ok = false;
     size_t flat_offset(const std::string& name) const {
-        for (const auto& kv : flat_layout) if (kv.first == name) return kv.second.first;
-        return (size_t)-1;
+        if (!flat_index_ok) {
+            flat_index.clear();
+            for (const auto& kv : flat_layout) flat_index.emplace(kv.first, kv.second.first);
+            flat_index_ok = true;
+        }
+        const auto it = flat_index.find(name);
+        return it == flat_index.end() ? (size_t)-1 : it->second;
     }
+    std::vector<int> edge_fx;               // [conv layer][message GVP level]: k_bwd_edge_level's shape class (msg_spec is string-building host work)
 
     // ---- optional per-kernel timing with HIP events on the caller's stream (pf_profile_*)
     // classes 0..8: pf_profile_read (inference path); 9..12: pf_profile_read_train (gradient kernels)
@@ -1733,6 +1743,7 @@ int pf_commit_weights(pf_handle* h) {
     {   // gradient path: the parameters once more as one flat vector in state-dict order, and where each GVP's tensors sit
         std::vector<float> flat;
         h->flat_layout.clear();
+        h->flat_index.clear(); h->flat_index_ok = false; h->edge_fx.clear();
         for (const auto& kv : exp) {
             const RawTensor& t = h->raw[kv.first];
             h->flat_layout.push_back({kv.first, {flat.size(), t.data.size()}});
@@ -3035,13 +3046,20 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
             e.level = lv;
             e.fx = 0;
             if (!h->no_fixed_shapes) {
-                bool f1 = true, f2 = true;
-                for (int et = 0; et < 4; ++et) {
-                    const GvpSpec gs = msg_spec(c, l, et, lv);
-                    f1 = f1 && gs.vi == 16 && gs.vo == 16 && gs.si == 128 && gs.so == 128;
-                    f2 = f2 && gs.vi == 17 && gs.vo == 16 && gs.si == 144 && gs.so == 128;
+                if (h->edge_fx.empty()) {
+                    h->edge_fx.assign((size_t)L * c.n_message_gvps, 0);
+                    for (int ll = 0; ll < L; ++ll)
+                        for (int j = 0; j < c.n_message_gvps; ++j) {
+                            bool f1 = true, f2 = true;
+                            for (int et = 0; et < 4; ++et) {
+                                const GvpSpec gs = msg_spec(c, ll, et, j);
+                                f1 = f1 && gs.vi == 16 && gs.vo == 16 && gs.si == 128 && gs.so == 128;
+                                f2 = f2 && gs.vi == 17 && gs.vo == 16 && gs.si == 144 && gs.so == 128;
+                            }
+                            h->edge_fx[(size_t)ll * c.n_message_gvps + j] = f1 ? 1 : (f2 ? 2 : 0);
+                        }
                 }
-                e.fx = f1 ? 1 : (f2 ? 2 : 0);
+                e.fx = h->edge_fx[(size_t)l * c.n_message_gvps + lv];
             }
             ProfScope ps(h, pf_handle::K_BWD_EDGE_LEVEL, s);
             pfk_bwd_edge_level(&e, nb, s);
