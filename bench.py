@@ -905,8 +905,13 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
             break
         step()
         torch.cuda.synchronize()
+    # the warm-up steps run with the events on: the library creates its event pairs on first use, and creating them inside the
+    # timed region occasionally stalls the host for tens of milliseconds (one run in five of this leg read 1.35-1.6 ms per step
+    # for a 1.26 ms step until this was moved here, as in the headline leg)
+    eng.profile_enable(1 << 11)
     for _ in range(W):
         step()
+    eng.profile_enable(0)
     eng.profile_read_train()
     barrier()
     t0 = time.perf_counter()
