@@ -69,7 +69,7 @@ void pfk_fix_enc_group(long long* A_h, float* G_h, const float* fix, const int* 
                        int Np, int Nf, const int* onehot_flag, hipStream_t s);
 void pfk_train_reduce(const ReduceParams* p, hipStream_t s);
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s);
-void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float* out_f, hipStream_t s);
+void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float* out_f, const ScaleArgs* sa, hipStream_t s);
 void pfk_loss_prepare(const LossParams* p, hipStream_t s);
 void pfk_loss_eval(const LossParams* p, hipStream_t s);
 void pfk_scale_loss(float* gx, int nx, const float* a, const float* a2, float* gh, int nh, const float* b, const float* b2, hipStream_t s);
@@ -306,6 +306,7 @@ struct pf_handle {
     int* xstat_host = nullptr;              // pinned; an async copy of d_xstat follows every sampling run (pf_sample_end) and is looked at
                                             // when the next one begins: a time-out there is reported, late but never silently
     bool no_fixed_shapes = false;           // PFDYN_NO_FIXED_SHAPES: k_bwd_edge_level reads every level's GVP shape from the table (the A/B of its FX forms)
+    ScaleArgs pend_scale{}; bool has_pend_scale = false;    // loss_backward -> pf_train_backward: the unit gradients' scaling, not yet launched
     bool no_fix_fuse = false;               // PFDYN_NO_FIX_FUSE: k_fix_apply and k_enc_group as two launches (the A/B of k_fix_enc_group)
     bool train_bf16 = false;                // pf_train_set_precision: the bf16 leg (dense Linears of the message chains' forward and of every
                                             // gradient kernel on bf16 matrix instructions; PFDYN_TRAIN_BF16=1 sets it at creation)
@@ -2878,9 +2879,14 @@ static int loss_backward(pf_handle* h, const float* g_pos, const float* g_pos2, 
     if (rc) return rc;
     if (!h->t_have_fwd || !h->t_have_loss) PF_FAIL(h, PF_ERR_STATE, "%s: no pf_train_loss_forward on this batch", who);
     if (!g_pos || !g_feat || !dev_grad) PF_FAIL(h, PF_ERR_ARG, "%s: null argument", who);
-    pfk_scale_loss(h->t_lgx, h->Nf * 3, g_pos, g_pos2, h->t_lgh, h->Nf * h->cfg.pharm_nf, g_feat, g_feat2, (hipStream_t)stream);
+    // the unit gradients times their upstream scalars: as extra blocks of the backward's first launch (the fragment re-pack) when it
+    // has one, else as a launch of its own (pf_train_backward)
+    h->pend_scale = ScaleArgs{h->t_lgx, h->Nf * 3, g_pos, g_pos2, h->t_lgh, h->Nf * h->cfg.pharm_nf, g_feat, g_feat2};
+    h->has_pend_scale = true;
     h->t_have_loss = false;                      // the unit gradients are consumed
-    return pf_train_backward(h, h->t_lgh, h->t_lgx, dev_grad, stream);
+    rc = pf_train_backward(h, h->t_lgh, h->t_lgx, dev_grad, stream);
+    h->has_pend_scale = false;
+    return rc;
 }
 
 int pf_train_loss_backward(pf_handle* h, const float* dev_g_pos, const float* dev_g_feat, float* dev_grad, pf_stream stream) {
@@ -2903,11 +2909,16 @@ int pf_train_backward(pf_handle* h, const float* dev_g_eps_h, const float* dev_g
     hipStream_t s = (hipStream_t)stream;
     const pf_config& c = h->cfg;
     const int L = c.n_convs, N = h->N, nb = h->t_nblk;
+    const bool scale_now = h->has_pend_scale;
+    h->has_pend_scale = false;
     if (h->wpack_version != h->w_version) {         // packed to_feats_out fragments of the message GVPs for k_bwd_edge_level
         const int ng = h->n_gvpt;
         if (!h->d_wpack) PF_HIP(h, hipMalloc((void**)&h->d_wpack, (size_t)2 * std::max(ng, 1) * PFT_WPACK_FLOATS * sizeof(float)));
-        pfk_pack_gvp(h->d_flat, h->d_gvpt, ng, h->d_wpack, h->d_wpack + (size_t)ng * PFT_WPACK_FLOATS, s);
+        pfk_pack_gvp(h->d_flat, h->d_gvpt, ng, h->d_wpack, h->d_wpack + (size_t)ng * PFT_WPACK_FLOATS, scale_now ? &h->pend_scale : nullptr, s);
         h->wpack_version = h->w_version;
+    } else if (scale_now) {
+        const ScaleArgs& a = h->pend_scale;
+        pfk_scale_loss(a.gx, a.nx, a.a, a.a2, a.gh, a.nh, a.b, a.b2, s);
     }
     h->t_common.wpack_b = h->d_wpack; h->t_common.wpack_f = h->d_wpack + (size_t)h->n_gvpt * PFT_WPACK_FLOATS;
     const TrainCommon tc = h->t_common;

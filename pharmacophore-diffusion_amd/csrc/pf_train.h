@@ -172,6 +172,9 @@ struct BwdEncodeParams {
 };
 
 // the loss around the dynamics (k_loss_prepare / k_loss_eval, pf_train_loss_forward)
+// the loss's unit gradients (gx [nx], gh [nh]) times their upstream scalars a (+ a2), b (+ b2): device scalars, a2 / b2 may be null
+struct ScaleArgs { float* gx; int nx; const float* a; const float* a2; float* gh; int nh; const float* b; const float* b2; };
+
 struct LossParams {
     int B, Np, Nf, nf, T, remove_com, weighted;
     float feat_norm;

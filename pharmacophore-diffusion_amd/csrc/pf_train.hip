@@ -1239,7 +1239,16 @@ __global__ __launch_bounds__(1024) void k_compact_rows(const EdgeTile* tiles, co
 //   input-gradient product (blockIdx.y == 0): [gvp][m tile (11)][k block (8)][lane] x 4 -- lane (li, kq) of m tile mt, block sb
 //     holds W[k = 16 sb + 4 kq + t][i = 16 mt + li], t = 0..3 (zero for i >= si + h, k >= so)
 //   forward product (blockIdx.y == 1): [gvp][m tile (8)][k block (11)][lane] x 4 -- W[o = 16 mt + li][k = 16 sb + 4 kq + t]
-__global__ __launch_bounds__(64) void k_pack_gvp(const float* W, const GvpT* g, float* out_b, float* out_f) {
+// (blocks [npack, ...) of row 0: the loss's unit gradients times their upstream scalars -- k_scale_loss's work, which used to be a
+// launch of its own right in front of this one)
+__global__ __launch_bounds__(64) void k_pack_gvp(const float* W, const GvpT* g, float* out_b, float* out_f, const int npack, const ScaleArgs sa) {
+    if ((int)blockIdx.x >= npack) {
+        if (blockIdx.y != 0) return;
+        const int i = ((int)blockIdx.x - npack) * 64 + (int)threadIdx.x;
+        if (i < sa.nx) sa.gx[i] *= sa.a[0] + (sa.a2 ? sa.a2[0] : 0.f);
+        else if (i - sa.nx < sa.nh) sa.gh[i - sa.nx] *= sa.b[0] + (sa.b2 ? sa.b2[0] : 0.f);
+        return;
+    }
     const int gi = blockIdx.x / 88, rem = blockIdx.x - gi * 88;
     const int lane = threadIdx.x, li = lane & 15, kq = lane >> 4;
     const GvpT t = g[gi];
@@ -2363,9 +2372,12 @@ void pfk_loss_eval(const LossParams* p, hipStream_t s) { hipLaunchKernelGGL(k_lo
 void pfk_scale_loss(float* gx, int nx, const float* a, const float* a2, float* gh, int nh, const float* b, const float* b2, hipStream_t s) {
     if (nx + nh > 0) hipLaunchKernelGGL(k_scale_loss, dim3((nx + nh + 255) / 256), dim3(256), 0, s, gx, nx, a, a2, gh, nh, b, b2);
 }
-void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float* out_f, hipStream_t s) {
-    if (n_gvps == 0) return;
-    hipLaunchKernelGGL(k_pack_gvp, dim3(n_gvps * 88, 2), dim3(64), 0, s, W, g, out_b, out_f);
+void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float* out_f, const ScaleArgs* sa, hipStream_t s) {
+    ScaleArgs none{};
+    const ScaleArgs& a = sa ? *sa : none;
+    const int extra = (a.nx + a.nh + 63) / 64;
+    if (n_gvps == 0 && extra == 0) return;
+    hipLaunchKernelGGL(k_pack_gvp, dim3(n_gvps * 88 + extra, 2), dim3(64), 0, s, W, g, out_b, out_f, n_gvps * 88, a);
 }
 void pfk_fix_apply(long long* A, float* G, size_t n, const float* fix, hipStream_t s) {
     if (n == 0) return;
