@@ -2071,28 +2071,11 @@ __global__ __launch_bounds__(256) void k_fix_scale(const float* g_h, const int n
         fix[1] = ldexpf(1.0f, -k);
     }
 }
-// the encoders' gradient: up to PFT_ENC_BLOCKS narrow copies; 32 threads per parameter sum every 32nd copy, then their partial sums
-// are added in slice order (fixed order: deterministic)
-__global__ __launch_bounds__(1024) void k_reduce_enc(const ReduceParams p) {
-    __shared__ float part[32][33];
-    const int pi = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + pi;
-    float s = 0.f;
-    if (i < p.enc_n)
-        for (int b = sl; b < p.enc_grid; b += 32) s += p.gpart_enc[(size_t)b * p.enc_n + i];
-    part[sl][pi] = s;
-    __syncthreads();
-    if (sl == 0 && i < p.enc_n) {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) t += part[q][pi];
-        p.grad[p.enc_begin + i] = t;
-    }
-}
+// (the encoders' gradient -- up to PFT_ENC_BLOCKS narrow copies -- is summed by the blocks behind the main ones of k_train_reduce)
 template <int UNR>
 __global__ __launch_bounds__(256) void k_train_reduce(const ReduceParams p, const int nb_main, const int with_enc) {
     if ((int)blockIdx.x >= nb_main) {
-        // the encoders' narrow copies as the blocks behind the main ones (k_reduce_enc's plan on 256 threads: 32 parameters x 8
+        // the encoders' narrow copies as the blocks behind the main ones (256 threads: 32 parameters x 8
         // slices of every eighth copy, the slices added in order) -- a launch of its own ran its ~100 latency-bound blocks in
         // front of this bandwidth-bound grid instead of under it
         __shared__ float part[8][33];
