@@ -203,6 +203,16 @@ def secondary_legs(args):
     return out
 
 
+def settle_gc():
+    """Before a timed region: collect what the set-up left behind and move the survivors out of the collector's sight
+    (gc.freeze).  A full collection over the model, the engines and the set-up's tensors takes tens of milliseconds; when the
+    collector's thresholds happened to trip inside a 50-130 ms timed region it showed as a run 10-25 % slower than its
+    neighbours (about one training-leg run in ten).  The collector stays on; what it scans afterwards is what the region allocates."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def gather_rank_times(dt, world, dev, backend, dist):
     """(max over ranks, [every rank's own time]) of a per-rank wall time: what makes a scaling run auditable."""
     where = dev if backend == "nccl" else "cpu"
@@ -434,6 +444,7 @@ def main():
         if best:
             dom_cls = max(best, key=lambda k: best[k])
     EV_MASK = 1 << CLS_BIT[dom_cls]
+    settle_gc()
     barrier()
     t0 = time.perf_counter()
     run(K, False, event_every=args.event_every)
@@ -654,6 +665,7 @@ def full_trajectory(args, eng, coef, dev, rank, world, B, T, Nf, barrier, max_ov
     gen = torch.Generator(device=dev).manual_seed(4242 + rank)
     buf = torch.empty(T + 1, Nf, 9, device=dev)
     times = []
+    settle_gc()
     for rep in range(4):
         barrier()
         t0 = time.perf_counter()
@@ -766,6 +778,7 @@ def slice_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
     with torch.no_grad():
         torch.manual_seed(0)
         m.sample(pockets[:min(len(pockets), 8)], n_pharms[:min(len(pockets), 8)], max_batch_size=args.max_batch_size)   # handles, tables
+        settle_gc()
         barrier()
         torch.manual_seed(0)
         t0 = time.perf_counter()
@@ -913,6 +926,7 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
         step()
     eng.profile_enable(0)
     eng.profile_read_train()
+    settle_gc()
     barrier()
     t0 = time.perf_counter()
     ev_every = max(1, K // 8)                      # HIP events around the edge-message backward launches of every n-th step
