@@ -409,6 +409,7 @@ def main():
     # steps after set-up measured 1.1-2.3x slower than the following ones at batch 128-256); the W warm-up steps
     # (0.8 ms at config 2) do not cover that, so the device is kept busy for --prewarm-ms first, on the same pockets
     # (the reverse process is restarted by the warm-up below)
+    settle_gc()      # (in front of the pre-warm, not of the timed region: the device must not idle between the warm-up and the region)
     if args.prewarm_ms > 0:
         tp = time.perf_counter()
         while (time.perf_counter() - tp) * 1e3 < args.prewarm_ms:
@@ -444,7 +445,6 @@ def main():
         if best:
             dom_cls = max(best, key=lambda k: best[k])
     EV_MASK = 1 << CLS_BIT[dom_cls]
-    settle_gc()
     barrier()
     t0 = time.perf_counter()
     run(K, False, event_every=args.event_every)
@@ -907,6 +907,7 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
     # sustained clocks before the warm-up (see main).  Every step of this leg holds a collective (the gradient all-reduce), so the
     # ranks must leave the loop after the SAME number of steps: a clock read per rank let one rank start a step its peers never
     # joined (an intermittent hang of the two-rank run) -- rank 0's verdict is broadcast each round
+    settle_gc()      # (in front of the pre-warm: the device must not idle between the warm-up and the timed region)
     tp = time.perf_counter()
     while True:
         go = (time.perf_counter() - tp) * 1e3 < args.prewarm_ms
@@ -926,7 +927,6 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
         step()
     eng.profile_enable(0)
     eng.profile_read_train()
-    settle_gc()
     barrier()
     t0 = time.perf_counter()
     ev_every = max(1, K // 8)                      # HIP events around the edge-message backward launches of every n-th step
