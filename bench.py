@@ -167,6 +167,28 @@ def secondary_legs(args):
     me = [sys.executable, os.path.abspath(__file__)]
     light = ["--no-cpu-baseline", "--no-dense-leg", "--no-secondary", "--no-traffic", "--gpus", "1"]
     out = {}
+    # the training legs first: measured behind the config-4 slice (the most power-hungry child) two of their short runs in three read
+    # 10-60 % slow on some boxes, and never when run on their own; 100 steps each, so that a stall of tens of ms weighs less
+    j, err = _child_json(me + light + ["--train", "--steps", "100", "--warmup", "10"])
+    if j:
+        r = j["roofline"]
+        out["train_step"] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                             "dominant_kernel": r["kernel"], "kernel_avg_us": r["kernel_avg_us"], "frac_executed": r["frac"], "frac": r["frac"],
+                             "note": "a new batch every step (4 distinct batches rotate); the backward kernels execute exactly the algorithmic FLOPs"}
+    else:
+        out["train_step"] = {"error": err}
+    # the labelled bf16 leg of the same step (never the headline: the reference trains in fp32)
+    j, err = _child_json(me + light + ["--train", "--train-dtype", "bf16", "--steps", "100", "--warmup", "10"])
+    if j:
+        r = j["roofline"]
+        out["train_step_bf16"] = {"workload": j["config"]["workload"], "dtype": "bf16", "value": j["value"], "unit": j["unit"],
+                                  "ms_per_step": j["ms_per_step"], "dominant_kernel": r["kernel"], "kernel_avg_us": r["kernel_avg_us"],
+                                  "note": "to_feats_out / gate products of the message chains' forward and of the gradient kernels on bf16 matrix "
+                                          "instructions (operands rounded to nearest even, fp32 accumulation), fp32 master weights, LayerNorm, "
+                                          "vector channel, scatter and Adam; contract: tests/test_gpu_train.py (per-tensor gradient cosine vs "
+                                          "the fp32 path); no fraction of a roof is formed (mixed f32 / bf16 instructions)"}
+    else:
+        out["train_step_bf16"] = {"error": err}
     j, err = _child_json(me + light + ["--batch", "128", "--pharm-sizes", "3-8", "--steps", "50", "--warmup", "5", "--no-full-trajectory"])
     if j:
         r = j["roofline"]
@@ -180,26 +202,6 @@ def secondary_legs(args):
                                 "ms_per_pocket": j["config"]["ms_per_pocket"], "ms_per_step": j["ms_per_step"], **j.get("dominant", {})}
     else:
         out["config4_slice"] = {"error": err}
-    j, err = _child_json(me + light + ["--train", "--steps", "40", "--warmup", "8"])
-    if j:
-        r = j["roofline"]
-        out["train_step"] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
-                             "dominant_kernel": r["kernel"], "kernel_avg_us": r["kernel_avg_us"], "frac_executed": r["frac"], "frac": r["frac"],
-                             "note": "a new batch every step (4 distinct batches rotate); the backward kernels execute exactly the algorithmic FLOPs"}
-    else:
-        out["train_step"] = {"error": err}
-    # the labelled bf16 leg of the same step (never the headline: the reference trains in fp32)
-    j, err = _child_json(me + light + ["--train", "--train-dtype", "bf16", "--steps", "40", "--warmup", "8"])
-    if j:
-        r = j["roofline"]
-        out["train_step_bf16"] = {"workload": j["config"]["workload"], "dtype": "bf16", "value": j["value"], "unit": j["unit"],
-                                  "ms_per_step": j["ms_per_step"], "dominant_kernel": r["kernel"], "kernel_avg_us": r["kernel_avg_us"],
-                                  "note": "to_feats_out / gate products of the message chains' forward and of the gradient kernels on bf16 matrix "
-                                          "instructions (operands rounded to nearest even, fp32 accumulation), fp32 master weights, LayerNorm, "
-                                          "vector channel, scatter and Adam; contract: tests/test_gpu_train.py (per-tensor gradient cosine vs "
-                                          "the fp32 path); no fraction of a roof is formed (mixed f32 / bf16 instructions)"}
-    else:
-        out["train_step_bf16"] = {"error": err}
     return out
 
 
