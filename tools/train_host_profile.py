@@ -48,6 +48,28 @@ def step(it):
     opt.step()
 for it in range(20): step(it)
 torch.cuda.synchronize()
+if "--stalls" in sys.argv:
+    # per-step host time over 600 steps (no synchronisation inside): a stall shows as one long step; which call it sits in is
+    # narrowed down by the three marks inside the step
+    marks = []
+    def step_t(it):
+        a = time.perf_counter()
+        opt.zero_grad(lazy=True)
+        g = graphs[it % nb]
+        loss = m.training_step(g, 0)
+        b = time.perf_counter()
+        loss.backward()
+        c = time.perf_counter()
+        opt.step()
+        d = time.perf_counter()
+        marks.append((d - a, b - a, c - b, d - c))
+    for it in range(600): step_t(it)
+    torch.cuda.synchronize()
+    worst = sorted(range(len(marks)), key=lambda i: -marks[i][0])[:4]
+    med = sorted(x[0] for x in marks)[len(marks) // 2]
+    print(f"median step (host) {med * 1e3:.3f} ms; longest: " + "; ".join(
+        f"step {i}: {marks[i][0] * 1e3:.2f} ms (forward {marks[i][1] * 1e3:.2f}, backward {marks[i][2] * 1e3:.2f}, optimiser {marks[i][3] * 1e3:.2f})" for i in worst))
+    sys.exit(0)
 t0 = time.perf_counter()
 for it in range(200): step(it)
 t1 = time.perf_counter()
