@@ -51,7 +51,8 @@ typedef enum pf_status {
     PF_ERR_ARG = -1,           /* bad argument / unsupported configuration */
     PF_ERR_HIP = -2,           /* HIP runtime error (no device, OOM, launch failure) */
     PF_ERR_STATE = -3,         /* call order violated (weights not committed, no batch set ...) */
-    PF_ERR_WEIGHT = -4         /* unknown / missing / mis-shaped weight tensor */
+    PF_ERR_WEIGHT = -4,        /* unknown / missing / mis-shaped weight tensor */
+    PF_ERR_EXCHANGE = -5       /* pf_sample_status: a workgroup hand-over inside a launch timed out; the run is invalid, repeat it */
 } pf_status;
 
 /* message_norm of GVPMultiEdgeConv (gvp.py:351,373-389) */
@@ -167,6 +168,17 @@ int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noi
                     int32_t endpoint_param_coord, int32_t endpoint_param_feat, pf_stream stream);
 int pf_sample_end(pf_handle* h, float feat_norm_constant, float* dev_x0 /*[Nf,3]*/, float* dev_h0 /*[Nf,pharm_nf]*/,
                   pf_stream stream);
+/* Validity of the sampling runs that ended (pf_sample_end / pf_sample) since the last call.  For small batches a step's last
+ * launch hands the noise prediction from its node + head workgroups to its update + build workgroups through polled exchange
+ * words (k_rg_node_hs_build); the poll is bounded, so a hand-over that never arrives (never observed: producers do not wait and
+ * the whole grid is resident) ends the launch on zeros instead of hanging the device -- and the run is INVALID.  The count of
+ * such time-outs is copied to pinned host memory behind the results of pf_sample_end, on the caller's stream: call this AFTER
+ * waiting for x_0 / h_0 (stream or event synchronisation -- the call itself touches no device and never blocks) and BEFORE
+ * using them.  Returns PF_OK, or PF_ERR_EXCHANGE with *n_timeouts (may be NULL) = the new time-outs; the handle then runs the
+ * separate launches (as with PFDYN_HS_BUILD=0), so repeating the run on it is safe.  A caller that never asks is told by the
+ * next pf_sample_begin on the handle, which fails with the same code.  The reference has nothing to correspond: its
+ * sample_given_receptor (pharmacodiff.py:433-514) is host-sequenced. */
+int pf_sample_status(pf_handle* h, int32_t* n_timeouts);
 /* current frame in the caller's frame of reference (get_pos_feat_for_visual, pharmacodiff.py:360-378) */
 int pf_sample_frame(pf_handle* h, float feat_norm_constant, float* dev_x /*[Nf,3]*/, float* dev_h /*[Nf,pharm_nf]*/,
                     pf_stream stream);
@@ -299,11 +311,13 @@ int pf_debug_counts(pf_handle* h, int64_t* out /*[8]*/, pf_stream stream);
  * different workgroups of one launch (pf_rg.hip: k_rg_node_hs_build, the default for small batches; PFDYN_HS_BUILD=0 switches it
  * off); else 0 */
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave);
-/* k_rg_node_hs_build hands the noise prediction from its node + head workgroups to its update + build workgroups through polled
- * exchange words; the poll loop is bounded, and a time-out (never observed: producers do not wait and the whole grid is resident)
- * is counted here instead of hanging the device.  Synchronises the device.  A non-zero count means the trajectory is invalid; the
- * count also travels back behind every pf_sample_end and the next pf_sample_begin on the handle fails with PF_ERR_HIP if it was not 0. */
+/* the exchange time-outs of k_rg_node_hs_build counted on this handle since it was created (cumulative; pf_sample_status is the
+ * product-path check and reports new ones per run).  Synchronises the device. */
 int pf_debug_xchg_timeouts(pf_handle* h, int32_t* n);
+/* diagnostic: drop_word != 0 makes the producers of the merged launch skip one exchange word (word 0 of center 0), so that its
+ * consumer times out; poll_max > 0 shortens the poll bound (default 65,536 rounds) so that a forced time-out costs microseconds.
+ * (0, 0) restores the product behaviour.  tests/test_gpu_n16.py: the time-out must surface on the same run. */
+int pf_debug_xchg_fault(pf_handle* h, int32_t drop_word, int32_t poll_max);
 /* the noise prediction of the last dynamics call of a pf_denoise_step (what its sampler update consumed) */
 int pf_debug_last_eps(pf_handle* h, float* dev_eps_h /*[Nf,pharm_nf] or NULL*/, float* dev_eps_x /*[Nf,3] or NULL*/, pf_stream stream);
 /* static hoist of conv layer 0's protein-protein messages in the last dynamics call: *rows_per_wave = 0 (not used: training,

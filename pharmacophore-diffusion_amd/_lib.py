@@ -48,6 +48,7 @@ SYMBOLS = {
     "pf_sample_begin": (ctypes.c_int, [_P, _P, _P, _P]),
     "pf_denoise_step": (ctypes.c_int, [_P, ctypes.POINTER(PfStepCoef), _P, _I32, _I32, _P]),
     "pf_sample_end": (ctypes.c_int, [_P, _F, _P, _P, _P]),
+    "pf_sample_status": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int32)]),
     "pf_prepare_timesteps": (ctypes.c_int, [_P, _P, _I32, _P]),
     "pf_sample_frame": (ctypes.c_int, [_P, _F, _P, _P, _P]),
     "pf_sample": (ctypes.c_int, [_P, _I32, ctypes.POINTER(PfStepCoef), _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P]),
@@ -77,6 +78,7 @@ SYMBOLS = {
     "pf_debug_kernel_family": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     "pf_debug_last_eps": (ctypes.c_int, [_P, _P, _P, _P]),
     "pf_debug_xchg_timeouts": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int32)]),
+    "pf_debug_xchg_fault": (ctypes.c_int, [_P, _I32, _I32]),
     "pf_debug_l0_hoist": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int32)]),
     "pf_debug_chain": (ctypes.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
 }

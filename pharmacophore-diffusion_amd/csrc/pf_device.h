@@ -356,9 +356,19 @@ struct HeadParams {
     // stores, to xchg[f * PF_XCHG_STRIDE + (0..2: eps_x, 3..: eps_h)] -- every word is its own flag (PF_XCHG_EMPTY until written),
     // which the graph's update + build workgroup of the SAME launch polls and re-arms.  NULL everywhere else.
     unsigned int* xchg;
+    int xchg_fault;        // diagnostic (pf_debug_xchg_fault): 1 = the producers never store word 0 of center 0 -- its consumer times out
 };
 #define PF_XCHG_STRIDE 20
-#define PF_XCHG_EMPTY 0xffffffffu      // (a NaN pattern no arithmetic produces: hardware NaNs are 0x7fc00000 / 0xffc00000)
+// A NaN pattern the hardware does not generate (its own NaNs are 0x7fc00000 / 0xffc00000) but does PROPAGATE from an input: the
+// producers store pf_xchg_word(bits), which replaces an inherited all-ones NaN by the canonical quiet NaN, so a payload can never
+// read as "not yet written".
+#define PF_XCHG_EMPTY 0xffffffffu
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned int pf_xchg_word(const float v) {
+    const unsigned int b = __float_as_uint(v);
+    return b == PF_XCHG_EMPTY ? 0x7fc00000u : b;
+}
+#endif
 
 struct EncodeParams {
     int Np, Nf;

@@ -35,7 +35,7 @@ void pfk_l0_hoist(const L0HoistParams* p, int what, hipStream_t s);
 void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s);
 void pfk_rg_unit(const UnitParams* p, hipStream_t s);
 void pfk_rg_node_hs_build(const NodeParams* p, const HeadParams* hp, const StepParams* sp, const BuildParams* bp, int* xstat, int poll_sleep,
-                          int avoid, hipStream_t s);
+                          int avoid, int poll_max, hipStream_t s);
 void pfk_n16_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, hipStream_t s);
 void pfk_n16_unit(const UnitParams* p, hipStream_t s);
 void pfk_n16_fused(const EdgeParams* p, const FusedParams* f, const EncodeParams* enc, hipStream_t s);
@@ -300,10 +300,12 @@ struct pf_handle {
     bool train_rg_head = true;              // PFDYN_TRAIN_TILE_HEAD=1: the training forward's noise head on the tile kernel (the backward recomputes it)
     float *t_hsv_z = nullptr, *t_hsv_g = nullptr, *t_hsv_v = nullptr;   // head levels saved by the training forward [n_noise_gvps][Nf][128 / 16 / 48]
     bool t_head_saved = false;              // ... by the last pf_train_forward
-    unsigned int* d_xchg = nullptr;         // exchange words of the merged launch [xchg_cap centers][PF_XCHG_STRIDE], all PF_XCHG_EMPTY between steps
-    int xchg_cap = 0;
-    int* d_xstat = nullptr;                 // [1] time-outs of the exchange (pf_debug_xchg_timeouts)
-    int* xstat_host = nullptr;              // pinned; an async copy of d_xstat follows every sampling run (pf_sample_end) and is looked at
+    unsigned int* d_xchg = nullptr;         // exchange words of the merged launch [Nf centers][PF_XCHG_STRIDE]: part of the workspace (carved per
+                                            // bind), set to PF_XCHG_EMPTY by every pf_sample_begin on the caller's stream, re-armed word by word by the consumers
+    int* d_xstat = nullptr;                 // [1] time-outs of the exchange since the handle was created (cumulative, never cleared: no race with a run in flight)
+    int* xstat_host = nullptr;              // pinned; an async copy of d_xstat follows every sampling run (pf_sample_end)
+    int xstat_ack = 0;                      // the count already reported (pf_sample_status / pf_sample_begin / pf_debug_xchg_timeouts)
+    int xchg_fault = 0, xchg_poll_max = 0;  // diagnostics (pf_debug_xchg_fault)
                                             // when the next one begins: a time-out there is reported, late but never silently
     bool no_fixed_shapes = false;           // PFDYN_NO_FIXED_SHAPES: k_bwd_edge_level reads every level's GVP shape from the table (the A/B of its FX forms)
     ScaleArgs pend_scale{}; bool has_pend_scale = false;    // loss_backward -> pf_train_backward: the unit gradients' scaling, not yet launched
@@ -397,7 +399,7 @@ struct pf_handle {
     float *t_G_h[2] = {nullptr, nullptr}, *t_G_v[2] = {nullptr, nullptr}, *t_gagg_s = nullptr, *t_gagg_v = nullptr,
           *t_gpart = nullptr, *t_geps_h = nullptr, *t_geps_x = nullptr;
     long long *t_A_h = nullptr, *t_A_v = nullptr;      // fixed-point accumulators of the level-0 scatter (kept clear between uses)
-    float* d_lpart = nullptr; size_t lpart_cap = 0;   // k_loss_eval's partial sums + its arrival counter (first 64 bytes)
+    float* d_lpart = nullptr;               // k_loss_eval's arrival counter (first 64 bytes) + partial sums: in the workspace's zero section
     void* d_tA = nullptr;                   // their own allocation: it outlives the batches, so "kept clear" holds across them
     size_t tA_capacity = 0;                 // bytes
     bool tA_dirty = false;                  // a backward pass stopped between the scatter and pfk_fix_apply
@@ -847,10 +849,9 @@ static void pack_n16_head_last(pf_handle* h, const GvpSpec& g, int w, std::vecto
 // keep_ws: the inference workspace stays allocated (pf_set_pocket_batch re-carves it when the next batch fits: a
 // hipMalloc / hipFree pair of a few hundred MB per batch costs milliseconds)
 static void free_ws(pf_handle* h, bool keep_ws = false) {
-    if (h->d_ws && !keep_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; }
+    if (h->d_ws && !keep_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; h->d_xchg = nullptr; h->d_lpart = nullptr; }
     if (h->d_tws && !keep_ws) { (void)hipFree(h->d_tws); h->d_tws = nullptr; h->tws_capacity = 0; }
     if (h->d_tA && !keep_ws) { (void)hipFree(h->d_tA); h->d_tA = nullptr; h->tA_capacity = 0; }
-    if (h->d_lpart && !keep_ws) { (void)hipFree(h->d_lpart); h->d_lpart = nullptr; h->lpart_cap = 0; }
     h->t_ws_ready = false;
     h->t_have_fwd = false;
     h->t_mask_override = nullptr;
@@ -1291,25 +1292,12 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 // a denoising step of a small batch: the step's update + build joins this launch as workgroups of its own (the fast
                 // build's shape: kNN pf edges, pockets of at most 512 atoms); timing the two separately needs the separate launches
                 const bool hsb = n.st_n > 0 && step != nullptr && h->pol.hs_build && enc_fly && c.pf_k > 0 && h->max_np <= 512 && c.pharm_nf <= 16 &&
-                                 h->step_build_fast && h->B <= 256 && !(h->prof_mask & (1u << pf_handle::K_STEP));
+                                 h->step_build_fast && h->B <= 256 && !(h->prof_mask & (1u << pf_handle::K_STEP)) && h->d_xchg && h->d_xstat;
                 if (hsb) {
-                    if (h->xchg_cap < h->Nf) {
-                        PF_HIP(h, hipDeviceSynchronize());
-                        if (h->d_xchg) (void)hipFree(h->d_xchg);
-                        h->d_xchg = nullptr; h->xchg_cap = 0;
-                        const int want = h->Nf + h->Nf / 4 + 64;
-                        PF_HIP(h, hipMalloc((void**)&h->d_xchg, (size_t)want * PF_XCHG_STRIDE * sizeof(unsigned int)));
-                        PF_HIP(h, hipMemset(h->d_xchg, 0xff, (size_t)want * PF_XCHG_STRIDE * sizeof(unsigned int)));
-                        h->xchg_cap = want;
-                    }
-                    if (!h->d_xstat) {
-                        PF_HIP(h, hipMalloc((void**)&h->d_xstat, 64));
-                        PF_HIP(h, hipMemset(h->d_xstat, 0, 64));
-                    }
-                    hp.xchg = h->d_xchg;
+                    hp.xchg = h->d_xchg; hp.xchg_fault = h->xchg_fault;
                     const bool share_next = (h->prune && c.n_convs == 2) && share_now(h);     // what the next denoising step's dynamics call will ask for
                     const BuildParams bpn = build_params(h, share_next);
-                    { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node_hs_build(&n, &hp, step, &bpn, h->d_xstat, h->pol.xchg_sleep, h->pol.hsb_avoid, s); }
+                    { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node_hs_build(&n, &hp, step, &bpn, h->d_xstat, h->pol.xchg_sleep, h->pol.hsb_avoid, h->xchg_poll_max, s); }
                     build_done(h, share_next);
                     h->tail_done = true; h->last_tail = 2;
                 } else { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node(&n, &hp, enc_fly ? &ep : nullptr, l == 0, rgn, nsplit, s); }
@@ -1436,7 +1424,6 @@ void pf_destroy(pf_handle* h) {
     if (h->d_gvp) (void)hipFree(h->d_gvp);
     if (h->d_flat) (void)hipFree(h->d_flat);
     if (h->d_wpack) (void)hipFree(h->d_wpack);
-    if (h->d_xchg) (void)hipFree(h->d_xchg);
     if (h->d_xstat) (void)hipFree(h->d_xstat);
     if (h->xstat_host) (void)hipHostFree(h->xstat_host);
     if (h->d_tseg) (void)hipFree(h->d_tseg);
@@ -2060,7 +2047,8 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     off = 0;                                                       // the workspace proper starts with the zero section
     // zero section (cleared with one launch per bind)
     const size_t o_dyn = place((size_t)5 * B * 4), o_act = place((size_t)(act_total + 1) * 4), o_flag = place(256), o_gnorm = place((size_t)2 * B * 4),
-                 o_need = place((size_t)std::max(Np, 1) * 4);
+                 o_need = place((size_t)std::max(Np, 1) * 4),
+                 o_lpart = place(64 + (size_t)((Nf + 63) / 64) * 8 * sizeof(float));       // k_loss_eval's ticket (re-armed by its last block) + partial sums
     const size_t zero_bytes = off;
     // scratch
     // (a second set of message rows for the last conv layer: the fused launch of small n_convs = 2 batches writes them while conv
@@ -2073,7 +2061,8 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
                  o_ms2 = place(msg2 ? (size_t)(Ecap + 1) * PF_S * 4 : 16), o_mv2 = place(msg2 ? (size_t)(Ecap + 1) * 48 * 4 : 16),
                  o_eh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_ex = place((size_t)Nf * 3 * 4 + 16), o_c0 = place((size_t)B * 3 * 4), o_c1 = place((size_t)B * 3 * 4),
                  o_pre = place((size_t)std::max(Np, 1) * PF_S * 4), o_eorig = place(Ecap * 4), o_ptype = place((size_t)std::max(Np, 1) * 4),
-                 o_zs = place((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4), o_ptpg = place((size_t)B * L0_NTAB * c.rec_nf * PF_S * 4);
+                 o_zs = place((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4), o_ptpg = place((size_t)B * L0_NTAB * c.rec_nf * PF_S * 4),
+                 o_xchg = place((size_t)std::max(Nf, 1) * PF_XCHG_STRIDE * sizeof(unsigned int));
     const size_t bytes = off;
     bool fresh = false;
     if (h->ws_capacity < bytes + 4096) {
@@ -2087,6 +2076,12 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     }
     char* const base = reinterpret_cast<char*>(h->d_ws);
     auto at = [&](size_t o) { return base + o; };
+    if (!h->d_xstat) {                                           // once per handle: the exchange's time-out counter and its pinned mirror
+        PF_HIP(h, hipMalloc((void**)&h->d_xstat, 64));
+        PF_HIP(h, hipMemset(h->d_xstat, 0, 64));
+        PF_HIP(h, hipHostMalloc((void**)&h->xstat_host, 64, hipHostMallocDefault));
+        *h->xstat_host = 0; h->xstat_ack = 0;
+    }
     // the table buffer of this bind
     const int tw = h->tab_next;
     h->tab_next ^= 1;
@@ -2119,6 +2114,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     h->d_msg_s = (float*)at(o_ms); h->d_msg_v = (float*)at(o_mv); h->d_eps_h = (float*)at(o_eh); h->d_eps_x = (float*)at(o_ex);
     h->d_com_init = (float*)at(o_c0); h->d_com_tmp = (float*)at(o_c1); h->d_pre = (float*)at(o_pre); h->d_eorig = (int*)at(o_eorig);
     h->d_ptype = (int*)at(o_ptype); h->d_zs = (float*)at(o_zs); h->d_ptab_pg = (float*)at(o_ptpg);
+    h->d_xchg = (unsigned int*)at(o_xchg); h->d_lpart = (float*)at(o_lpart);
     mark();      // 2: workspace ready
     // ---- stage the tables in pinned memory and upload them with one asynchronous copy
     const int sb = h->stage_next;
@@ -2418,14 +2414,15 @@ int pf_sample_begin(pf_handle* h, const float* dev_init_pharm_com, const float* 
     int rc = check_ready(h, true);
     if (rc) return rc;
     if (!dev_noise0) PF_FAIL(h, PF_ERR_ARG, "pf_sample_begin: null noise");
-    if (h->xstat_host && *h->xstat_host != 0) {
-        const int n = *h->xstat_host;
-        *h->xstat_host = 0;
-        if (h->d_xstat) (void)hipMemset(h->d_xstat, 0, 64);
-        PF_FAIL(h, PF_ERR_HIP, "an earlier sampling run on this handle had %d time-out(s) in the merged launch's exchange (k_rg_node_hs_build): "
-                               "its results are invalid; PFDYN_HS_BUILD=0 uses the separate launches", n);
+    {                                       // a caller that never asked pf_sample_status still learns of an invalid run here
+        int32_t n = 0;
+        rc = pf_sample_status(h, &n);
+        if (rc) return rc;
     }
     hipStream_t s = (hipStream_t)stream;
+    // every run starts from armed exchange words, whatever the previous run on the handle left in them (a timed-out row is not
+    // re-armed by its consumer, pf_stepbuild.h); stream-ordered like everything else of the run
+    if (h->d_xchg) PF_HIP(h, hipMemsetAsync(h->d_xchg, 0xff, (size_t)std::max(h->Nf, 1) * PF_XCHG_STRIDE * sizeof(unsigned int), s));
     // init_prot_com = mean of the ORIGINAL protein coordinates (pharmacodiff.py:442)
     pfk_load_coords(h->d_prot_x0, h->d_xn, h->Np, h->d_gid, nullptr, 0.f, s);
     pfk_segment_mean(h->d_xn, h->d_prot_ptr, 0, h->B, h->d_com_init, s);
@@ -2490,11 +2487,33 @@ int pf_sample_frame(pf_handle* h, float feat_norm_constant, float* dev_x, float*
 int pf_sample_end(pf_handle* h, float feat_norm_constant, float* dev_x0, float* dev_h0, pf_stream stream) {
     // x_0 = x_t - protein COM + initial protein COM ; h_0 = h_t * norm constant  (pharmacodiff.py:480-488)
     int rc = pf_sample_frame(h, feat_norm_constant, dev_x0, dev_h0, stream);
-    if (rc == PF_OK && h->d_xstat) {              // the merged launch ran on this handle: bring its time-out counter along
-        if (!h->xstat_host) { PF_HIP(h, hipHostMalloc((void**)&h->xstat_host, 64, hipHostMallocDefault)); *h->xstat_host = 0; }
+    // the exchange's cumulative time-out count travels with the results: once the caller has waited for x_0 / h_0 it is on
+    // the host too, and pf_sample_status judges THIS run without touching the device
+    if (rc == PF_OK && h->d_xstat)
         PF_HIP(h, hipMemcpyAsync(h->xstat_host, h->d_xstat, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    }
     return rc;
+}
+
+int pf_sample_status(pf_handle* h, int32_t* n_timeouts) {
+    if (!h) return PF_ERR_ARG;
+    if (n_timeouts) *n_timeouts = 0;
+    if (!h->xstat_host) return PF_OK;
+    const int seen = *(volatile int*)h->xstat_host;
+    if (seen == h->xstat_ack) return PF_OK;
+    const int n = seen - h->xstat_ack;
+    h->xstat_ack = seen;
+    if (n_timeouts) *n_timeouts = n;
+    h->pol.hs_build = 0;                    // this handle goes on with the separate launches
+    PF_FAIL(h, PF_ERR_EXCHANGE, "%d time-out(s) in the exchange of the merged last launch (k_rg_node_hs_build): the sampling run(s) that "
+                                "ended since the last status call are invalid and must be repeated; the handle now uses the separate "
+                                "node + head and update + build launches", n);
+}
+
+int pf_debug_xchg_fault(pf_handle* h, int32_t drop_word, int32_t poll_max) {
+    if (!h) return PF_ERR_ARG;
+    h->xchg_fault = drop_word ? 1 : 0;
+    h->xchg_poll_max = poll_max > 0 ? poll_max : 0;
+    return PF_OK;
 }
 
 int pf_sample(pf_handle* h, int32_t n_steps, const pf_step_coef* host_coef, const float* dev_noise,
@@ -2840,16 +2859,6 @@ int pf_train_loss_forward(pf_handle* h, const float* dev_pharm_x0, const float* 
     h->t_common.seed = seed;
     h->t_common.mask_override = h->t_mask_override; h->t_common.mask_N = h->N;
     h->t_common.bf16 = h->train_bf16 ? 1 : 0;
-    {
-        const size_t need = 64 + (size_t)((h->Nf + 63) / 64) * 8 * sizeof(float);
-        if (h->lpart_cap < need) {
-            PF_HIP(h, hipDeviceSynchronize());
-            if (h->d_lpart) { (void)hipFree(h->d_lpart); h->d_lpart = nullptr; h->lpart_cap = 0; }
-            PF_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->d_lpart), 2 * need));
-            h->lpart_cap = 2 * need;
-            PF_HIP(h, hipMemsetAsync(h->d_lpart, 0, 64, s));
-        }
-    }
     LossParams lp{};
     lp.part = h->d_lpart + 16; lp.ticket = reinterpret_cast<int*>(h->d_lpart);
     lp.B = h->B; lp.Np = h->Np; lp.Nf = h->Nf; lp.nf = h->cfg.pharm_nf; lp.T = n_timesteps; lp.remove_com = remove_com; lp.weighted = weighted_loss;

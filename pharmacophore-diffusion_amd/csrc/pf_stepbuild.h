@@ -529,14 +529,17 @@ __device__ __forceinline__ void step_build_fast_body(const int g, const int* __r
 
 // the same with eps arriving through the exchange words of a node + head item of the SAME launch (k_rg_node_hs_build): all three
 // trips are issued first, then the threads of the graph's centers poll their row's words (each word is its own flag: no ordering
-// between words is needed), take them and re-arm them for the next step.  Bounded: after SB_XCHG_POLLS rounds the thread counts a
-// time-out in xstat and goes on with zeros (the step's result is then invalid -- pf_debug_xchg_timeouts reports it).
+// between words is needed), take them and re-arm them for the next step.  Bounded: after poll_max rounds (SB_XCHG_POLLS unless
+// pf_debug_xchg_fault shortened it) the thread counts a time-out in xstat and goes on with zeros.  The run is then invalid, and the
+// host says so on the same run: xstat is cumulative, its copy travels behind pf_sample_end and pf_sample_status compares it with
+// what was acknowledged.  A timed-out row is NOT re-armed here -- its producer may still store into it, and a re-armed word
+// filled late would read as "arrived" in every later step without ever being counted; pf_sample_begin re-arms every word.
 constexpr int SB_XCHG_POLLS = 1 << 16;
 template <int NT>
 __device__ __forceinline__ void step_build_wait_body(const int g, const int* __restrict__ a_prot_ptr, const int* __restrict__ a_pharm_ptr,
                                                      const int* __restrict__ a_reg, const int a_B, const int a_Np_tot,
                                                      const StepParams& sp, const BuildParams& p, unsigned int* xchg, int* xstat,
-                                                     StepBuildLds& L, const int poll_sleep) {
+                                                     StepBuildLds& L, const int poll_sleep, const int poll_max) {
     SbPre<NT> q;
     sb_load_a<NT>(q, g, a_prot_ptr, a_pharm_ptr, a_reg, a_B, a_Np_tot, p);
     sb_load_b<NT>(q, a_Np_tot, sp, p);
@@ -562,7 +565,7 @@ __device__ __forceinline__ void step_build_wait_body(const int g, const int* __r
         unsigned int* row = xchg + (size_t)(q.f0 + (int)threadIdx.x) * PF_XCHG_STRIDE;
         unsigned int w[3 + SB_MAXNF];
         bool ok = false;
-        for (int it = 0; it < SB_XCHG_POLLS; ++it) {
+        for (int it = 0; it < poll_max; ++it) {
             ok = true;
 #pragma unroll
             for (int k = 0; k < 3 + SB_MAXNF; ++k) {
@@ -580,9 +583,11 @@ __device__ __forceinline__ void step_build_wait_body(const int g, const int* __r
         for (int c = 0; c < 3; ++c) ex[c] = ok ? __builtin_bit_cast(float, w[c]) : 0.f;
 #pragma unroll
         for (int k = 0; k < SB_MAXNF; ++k) eh[k] = (ok && k < sp.nf) ? __builtin_bit_cast(float, w[3 + k]) : 0.f;
+        if (ok) {
 #pragma unroll
-        for (int k = 0; k < 3 + SB_MAXNF; ++k)
-            if (k < 3 + sp.nf) __hip_atomic_store(row + k, PF_XCHG_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < 3 + SB_MAXNF; ++k)
+                if (k < 3 + sp.nf) __hip_atomic_store(row + k, PF_XCHG_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     SB_STAMP(101);
     sb_finish<NT, true>(q, ex, eh, g, sp, p, L);

@@ -362,6 +362,13 @@ class PfEngine:
                                         _stream_ptr()), "pf_sample")
         return (x0, h0, tx, th) if trajectory else (x0, h0)
 
+    def sample_status(self):
+        """Validity of the sampling runs that ended on this handle since the last call (pf_sample_status): raises PfError when a
+        hand-over inside a merged launch timed out.  Call once the results have been waited for (stream / event synchronisation)
+        and before using them; touches no device."""
+        n = ctypes.c_int32()
+        self._ck(self.lib.pf_sample_status(self._h, ctypes.byref(n)), "pf_sample_status")
+
     # -- introspection -------------------------------------------------------------------------
     def get_edges(self, etype: int):
         with torch.cuda.device(self.device):
@@ -418,10 +425,15 @@ class PfEngine:
         return eh, ex
 
     def xchg_timeouts(self) -> int:
-        """Time-outs of the merged last launch's exchange (k_rg_node_hs_build); anything but 0 invalidates the trajectory."""
+        """Time-outs of the merged last launch's exchange (k_rg_node_hs_build) since the handle was created; synchronises the device.
+        The product-path check is sample_status()."""
         r = ctypes.c_int32()
         self._ck(self.lib.pf_debug_xchg_timeouts(self._h, ctypes.byref(r)), "pf_debug_xchg_timeouts")
         return int(r.value)
+
+    def xchg_fault(self, drop_word: bool, poll_max: int = 0):
+        """Diagnostic (pf_debug_xchg_fault): make the merged launch's producers skip one exchange word / shorten the poll bound."""
+        self._ck(self.lib.pf_debug_xchg_fault(self._h, int(bool(drop_word)), int(poll_max)), "pf_debug_xchg_fault")
 
     def l0_hoist(self) -> int:
         """Rows per hoisted wave of conv layer 0's pp messages in the last dynamics call (0: static hoist not used)."""

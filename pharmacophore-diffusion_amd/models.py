@@ -686,12 +686,14 @@ class PharmacophoreDiff(_Base):
                      for r in res)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
-        return g, host, visualize_trajectory, done
+        return g, host, visualize_trajectory, done, eng
 
     def _sample_fetch(self, pending):
-        """Results of an enqueued batch on the host (waits for that batch only)."""
-        g, host, traj, done = pending
+        """Results of an enqueued batch on the host (waits for that batch only).  The run's validity word arrived with them
+        (pf_sample_end): an exchange time-out inside a merged launch raises PfError HERE, before anything is built from x_0 / h_0."""
+        g, host, traj, done, eng = pending
         done.synchronize()
+        eng.sample_status()
         return g, host, traj
 
     def _sample_finish(self, pending) -> List[SampledPharmacophore]:

@@ -50,6 +50,26 @@ def test_sample_given_receptor_matches_reference_golden():
         assert all(abs(float(u) - float(v)) <= 6e-3 for u, v in zip(a[1:], b[1:]))
 
 
+def test_an_invalid_trajectory_is_never_returned():
+    """An exchange time-out inside a step's merged last launch (forced: pf_debug_xchg_fault) raises from the very
+    sample_given_receptor call whose results it spoiled -- nothing is built from x_0 / h_0 -- and the model goes on sampling
+    (the handle falls back to the separate launches): same result as before the fault to the merged-vs-separate ulp."""
+    z = load("traj_c1.npz")
+    m = make_model(int(z["T"]))
+    g = graph_from(batch_from(z)).to("cuda")
+    good = m.sample_given_receptor(g, noise=z["noise"])
+    eng = m.dynamics.engine()
+    assert eng.kernel_family(2) == 2
+    eng.xchg_fault(True, poll_max=64)
+    with pytest.raises(pfa.PfError, match="time-out"):
+        m.sample_given_receptor(g, noise=z["noise"])
+    eng.xchg_fault(False)
+    again = m.sample_given_receptor(g, noise=z["noise"])
+    assert eng.kernel_family(2) == 0
+    torch.testing.assert_close(again[0].ph_coords, good[0].ph_coords, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(again[0].ph_coords, z["x0"], rtol=5e-3, atol=5e-3)
+
+
 def test_dynamics_module_forward_signature():
     z = load("dynamics_ragged.npz")
     m = make_model(100)

@@ -252,3 +252,77 @@ def test_fused_launch_arithmetic_tiling_equals_the_work_list_form(monkeypatch):
     ox = x_t - O.segment_mean(px, batch.prot_ptr)[bidx["pharm"]] + init_com[bidx["pharm"]]
     torch.testing.assert_close(out["1"][0][0], ox, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(out["1"][0][1], h_t, rtol=1e-3, atol=1e-3)
+
+
+def test_exchange_timeout_surfaces_on_the_same_run_and_the_handle_recovers():
+    """The merged last launch (k_rg_node_hs_build) hands eps over through polled exchange words with a bounded poll; a hand-over
+    that never arrives must make THAT run fail, not the next one.  pf_debug_xchg_fault makes the
+    producers skip one word (and shortens the poll): pf_sample returns, the caller waits for x_0 as it always does, and
+    pf_sample_status reports PF_ERR_EXCHANGE for this run; the handle switches to the separate launches, its next run starts from
+    re-armed words and equals the PFDYN_HS_BUILD=0 result bit for bit; the status is then clean again."""
+    from pharmacoforge_amd import PfError
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 3)
+    batch = O.synthetic_batch([700 + i for i in range(4)], 64, [4, 6, 5, 6], cfg)
+    Nf = int(batch.pharm_ptr[-1])
+    T, n = 100, 4
+    noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(17))
+    coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    arr = eng.coef_array(coef, [40, 39, 38, 37])
+    x_ok, h_ok = eng.sample(arr, n, noise)
+    assert eng.kernel_family(cfg.n_convs) == 2                      # the merged launch is what ran
+    torch.cuda.synchronize()
+    eng.sample_status()                                             # clean
+    eng.xchg_fault(True, poll_max=64)
+    x_bad, h_bad = eng.sample(arr, n, noise)
+    torch.cuda.synchronize()                                        # (what a caller does before reading x_0)
+    with pytest.raises(PfError, match="time-out"):
+        eng.sample_status()
+    assert eng.xchg_timeouts() >= 1
+    eng.sample_status()                                             # reported once
+    eng.xchg_fault(False)
+    x2, h2 = eng.sample(arr, n, noise)                              # the same handle: separate launches now, words re-armed by begin
+    assert eng.kernel_family(cfg.n_convs) == 0
+    torch.cuda.synchronize()
+    eng.sample_status()
+    import os
+    os.environ["PFDYN_HS_BUILD"] = "0"
+    try:
+        ref = engine_for(cfg, sd)
+    finally:
+        del os.environ["PFDYN_HS_BUILD"]
+    set_batch(ref, batch)
+    xr, hr = ref.sample(arr, n, noise)
+    assert torch.equal(x2, xr) and torch.equal(h2, hr)
+    torch.testing.assert_close(x_ok, xr, rtol=1e-5, atol=1e-5)      # (merged vs separate: an ulp or two per step, see above)
+    # a caller that never asks is told by the next begin on the handle
+    eng2 = engine_for(cfg, sd)
+    set_batch(eng2, batch)
+    eng2.xchg_fault(True, poll_max=64)
+    eng2.sample(arr, n, noise)
+    torch.cuda.synchronize()
+    eng2.xchg_fault(False)
+    with pytest.raises(PfError, match="time-out"):
+        eng2.sample(arr, n, noise)
+    x3, h3 = eng2.sample(arr, n, noise)
+    assert torch.equal(x3, xr) and torch.equal(h3, hr)
+
+
+def test_exchange_words_canonicalise_an_all_ones_nan():
+    """An all-ones NaN is the exchange's 'not yet written' pattern; hardware propagates NaN payloads from inputs, so the producers
+    canonicalise it (pf_xchg_word): a batch whose noise carries that NaN ends in NaN results, not in a time-out."""
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 3)
+    batch = O.synthetic_batch([700], 64, [4], cfg)
+    noise = torch.randn(3, 4, 9, generator=torch.Generator().manual_seed(1))
+    noise[0, 0, 3] = torch.tensor([-1], dtype=torch.int32).view(torch.float32)[0]
+    assert noise[0].view(torch.int32)[0, 3] == -1
+    coef = O.step_coefficients(O.gamma_table(100, 1e-5), 100)
+    eng = engine_for(cfg, sd)
+    set_batch(eng, batch)
+    x, h = eng.sample(eng.coef_array(coef, [40, 39]), 2, noise)
+    torch.cuda.synchronize()
+    eng.sample_status()
+    assert eng.xchg_timeouts() == 0 and torch.isnan(h).any()
