@@ -102,27 +102,47 @@ constexpr int rg_main_quad(const RgSched& s, const int nh, const int k) {
 // once per GVP.  Every wave has its own quad stream per chain (wave w's stream n16_stride floats after wave w - 1's);
 // a block is one GVP, quads in consumption order (a quad = [64 lanes][4 images], image = one lane's share of an A
 // operand: lane 16 g + i <-> output row i, k = 4 ks + g of the k-step):
-//   GEN  [vh] [main x16] [sh x2] [vu] [bias x2] [gate x2]                               = 24   (128 + 16 -> 128 + 16)
+//   GEN  [main x VH_AT] [vh] [main x (16 - VH_AT)] [sh x2] [vu] [bias x2] [gate x2]     = 24   (128 + 16 -> 128 + 16)
 //   M0F  [x1] [vh] [w16] [main x16] [rbf x2] [sh x2] [vu] [bias x2] [gate x2]           = 28   first message GVP
 //   M0Z  [x1] [xh] [main x16] [rbf x2] [sh x2] [vu] [bias x2] [gate x2]                 = 27   ... when v_src == 0 (conv layer 0)
 //   M0H  [x1] [xh] [rbf x2] [sh x2] [vu] [gate x2]                                      = 9    ... and h_src is a row of a type table
+// (GEN: the vector product Vh = Wh^T V sits BEHIND the first main k-steps.  Its operand is the previous GVP's gated output --
+// sigmoid(gate sums from LDS) x Vu -- and a wave issues in order: in front of the main k-steps it made every block of a chain
+// wait for an LDS round trip, four sigmoids and four dependent matrix instructions before the first of its 64 main ones.)
 // Scalar k-step ks (0..31), lane group g <-> input feature 16 (ks >> 2) + 4 g + (ks & 3): the D fragment of tile T = 2 w + t
 // (lane 16 g + j, register r: feature 16 T + 4 g + r of row j) is the B operand of k-step 4 T + r without any data movement.
 #ifndef N16_D
 #define N16_D 12            // depth of the register prefetch ring in quads (GEN blocks are a multiple of it)
 #endif
+#ifndef N16_VH_AT
+#define N16_VH_AT 4         // GEN blocks: main quads in front of the vh quad (0: the vh quad leads the block)
+#endif
 #define N16_TAIL_PAD 24     // quads of read-ahead padding behind every wave's stream
 enum { N16_GEN = 0, N16_M0F = 1, N16_M0Z = 2, N16_M0H = 3 };
-struct N16Sched { int q_x1, q_vh, q_w16, q_main, q_rbf, q_sh, q_vu, q_b, q_gate, nq; };
+struct N16Sched {
+    int q_x1, q_vh, q_w16, q_main, q_rbf, q_sh, q_vu, q_b, q_gate, nq;
+    int vh_at;             // main quads [0, vh_at) sit in front of q_vh, the others behind it (GEN; 16 elsewhere: q_vh is outside the main run)
+    // stream position of main quad m (0..15), and the inverse (-1: quad qi is not a main quad)
+    constexpr int main_pos(const int m) const { return q_main + m + ((q_vh >= q_main && m >= vh_at) ? 1 : 0); }
+    constexpr int main_of(const int qi) const {
+        if (q_main < 0 || qi < q_main || qi == q_vh) return -1;
+        const int m = qi - q_main - ((q_vh >= q_main && qi > q_vh) ? 1 : 0);
+        return m < 16 ? m : -1;
+    }
+};
 constexpr N16Sched n16_sched(const int kind) {
     N16Sched s{};
     int q = 0;
     const bool m0 = kind != N16_GEN;
+    s.vh_at = 16;
     s.q_x1 = m0 ? q++ : -1;
-    s.q_vh = q++;
-    s.q_w16 = kind == N16_M0F ? q++ : -1;
-    s.q_main = kind != N16_M0H ? q : -1;
-    if (kind != N16_M0H) q += 16;
+    if (kind == N16_GEN) { s.q_main = 0; s.vh_at = N16_VH_AT; s.q_vh = N16_VH_AT; s.q_w16 = -1; q = 17; }
+    else {
+        s.q_vh = q++;
+        s.q_w16 = kind == N16_M0F ? q++ : -1;
+        s.q_main = kind != N16_M0H ? q : -1;
+        if (kind != N16_M0H) q += 16;
+    }
     s.q_rbf = m0 ? q : -1;
     if (m0) q += 2;
     s.q_sh = q; q += 2;

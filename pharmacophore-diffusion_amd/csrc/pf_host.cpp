@@ -788,8 +788,8 @@ static void pack_n16_raw(const N16Raw& rw, int kind, int w, std::vector<float>& 
             for (int qm = 0; qm < 16; ++qm)
                 for (int half = 0; half < 2; ++half) {
                     const int ks = 2 * qm + half, f = 16 * (ks >> 2) + 4 * gq + (ks & 3);
-                    at(q.q_main + qm, lane, 2 * half) = W[(size_t)f0 * Kin + f];
-                    at(q.q_main + qm, lane, 2 * half + 1) = W[(size_t)f1 * Kin + f];
+                    at(q.main_pos(qm), lane, 2 * half) = W[(size_t)f0 * Kin + f];
+                    at(q.main_pos(qm), lane, 2 * half + 1) = W[(size_t)f1 * Kin + f];
                 }
         for (int qq = 0; qq < 2; ++qq)
             for (int half = 0; half < 2; ++half) {

@@ -188,31 +188,67 @@ struct N16In {
 // Barriers: A (Vh of the three coordinates -> sh; only the kinds with a vector input) and B (SiLU outputs, gate sums).
 // ---------------------------------------------------------------------------------------------
 //   SIG      the vector gate's activation: sigmoid (every GVP but the noise head's last one: identity, dynamics_gvp.py:20)
+//   PEND     the previous block of the chain left its vector gate PENDING: VB holds its ungated Vu (waves 0..2), its gate sums wait
+//            in lds->g (written in front of its barrier B).  This block requests the sums under its first main k-steps and forms
+//            sigmoid(sum) x Vu in front of its vh quad, N16_VH_AT main quads into the block -- not in front of the first one.
+//            !PEND: VB is the vector input as it stands (first block of a chain).
+//   A block that is not LAST leaves its own gate pending; the chain's caller completes the last one (n16_gate_flush) or runs a
+//   LAST block, which completes its gate itself.
 //   gs       optional: receives the gate pre-activations (the K-split sums + bias; vector waves) -- the tail kernel packs
 //            to_scalar_output into the unused gate rows of the head's last GVP and reads eps_h from here
-template <int KIND, int OFF, bool LAST, bool SIG = true>
+__device__ __forceinline__ void n16_gate_request(f32x4 (&G)[4], const N16Lds* lds, const int lane) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) G[w] = *reinterpret_cast<const f32x4*>(&lds->g[(w * 64 + lane) * 4]);
+}
+template <bool SIG = true>
+__device__ __forceinline__ void n16_gate_apply(const f32x4 (&G)[4], float (&VB)[4], const bool vecw, f32x4* gs = nullptr) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float gpre = (G[0][r] + G[1][r]) + (G[2][r] + G[3][r]);
+        if (gs) (*gs)[r] = gpre;
+        VB[r] = vecw ? (SIG ? sigmoidf_(gpre) : gpre) * VB[r] : 0.f;
+    }
+}
+// completes the gate a chain's last non-LAST block left pending (all four waves; wave 3 ends with VB = 0)
+__device__ __forceinline__ void n16_gate_flush(float (&VB)[4], const N16Lds* lds, const int lane, const int wq) {
+    f32x4 G[4];
+    n16_gate_request(G, lds, lane);
+    n16_gate_apply<true>(G, VB, wq < 3);
+}
+
+template <int KIND, int OFF, bool LAST, bool SIG = true, bool PEND = false>
 __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float (&VB)[4], const N16In& in, f32x4 (&S)[2],
                                           N16Lds* lds, const int lane, const int wq, int& sk, f32x4* gs = nullptr) {
     constexpr N16Sched Q = n16_sched(KIND);
+    static_assert(!PEND || KIND == N16_GEN, "only GEN blocks follow another block of a chain");
     N16_STAMP_B(sk, lane, wq);                                          // block start
     constexpr bool M0 = KIND != N16_GEN;                              // 17 hidden vector channels, rbf inputs
     constexpr bool VZ = KIND == N16_M0Z || KIND == N16_M0H;           // the node vectors are zero: Vh = Wh[0] (x) xhat
     constexpr bool HOIST = KIND == N16_M0H;
+    // where the pending gate's sums are requested (two quads in front of the vh quad) and where barrier A and the reads of Vh sit
+    // (main quad 11: every wave wrote its Vh long before, sh is formed under the last main k-steps instead of behind them)
+    constexpr int Q_GREQ = PEND ? (Q.q_vh >= 2 ? Q.q_vh - 2 : 0) : -1;
+    constexpr int M_A = 11, M_SH = 14;
     const int g = lane >> 4;
     const bool vecw = wq < 3;                                         // wave-uniform
     const bool g0 = g == 0;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, vh = acc0, vu = acc0, gp = acc0;
     if constexpr (HOIST) { acc0 = S[0]; acc1 = S[1]; }
     f32x4 x1 = acc0, b0 = acc0, gbias = acc0, sh = acc0;
-    float vh16 = 0.f, sh16 = 0.f;
+    f32x4 G[4], va = acc0, vb = acc0, vc = acc0;
+    G[0] = acc0; G[1] = acc0; G[2] = acc0; G[3] = acc0;
+    float vh16 = 0.f, sh16 = 0.f, x6 = 0.f, y6 = 0.f, z6 = 0.f;
     const float xhc = M0 ? (wq == 0 ? in.xh[0] : (wq == 1 ? in.xh[1] : (wq == 2 ? in.xh[2] : 0.f))) : 0.f;
     static_for<0, Q.nq>([&](auto QI) {
         constexpr int qi = decltype(QI)::value;
+        constexpr int mq = Q.main_of(qi);                               // main quad number, or -1
         const f32x4 w = ring.q[(OFF + qi) % N16_D];
         ring.q[(OFF + qi) % N16_D] = ring.load(qi + N16_D);
+        if constexpr (PEND && qi == Q_GREQ) n16_gate_request(G, lds, lane);
         if constexpr (qi == Q.q_x1) {
             x1 = w;                                   // [sh16 column tile 0, tile 1, Wu[16][i], Wh[0][i] (lane 16: Wh[0][16])]
         } else if constexpr (qi == Q.q_vh) {
+            if constexpr (PEND) n16_gate_apply<true>(G, VB, vecw);
             if constexpr (VZ) {
                 // Vh[h][c] = Wh[0][h] xhat_c: this wave's coordinate for Vu, all three for sh (no exchange)
                 const float w016 = lane_bcast(x1[3], 16);
@@ -241,12 +277,26 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
                 *reinterpret_cast<f32x4*>(&lds->v[(wq * 64 + lane) * 4]) = vh;
                 if (g0) lds->v16[wq * 16 + (lane & 15)] = vh16;
             }
-        } else if constexpr (Q.q_main >= 0 && qi >= Q.q_main && qi < Q.q_main + 16) {
-            constexpr int ks = 2 * (qi - Q.q_main);
+        } else if constexpr (mq >= 0) {
+            constexpr int ks = 2 * mq;
             acc0 = mfma16(w[0], XS[ks], acc0);
             acc1 = mfma16(w[1], XS[ks], acc1);
             acc0 = mfma16(w[2], XS[ks + 1], acc0);
             acc1 = mfma16(w[3], XS[ks + 1], acc1);
+            if constexpr (!VZ && mq == M_A) {         // barrier A: the three coordinates of Vh are in LDS; their reads travel under the next k-steps
+                N16_STAMP_B(sk, lane, wq);              // main k-steps (mostly) issued
+                lds_barrier();
+                N16_STAMP_B(sk, lane, wq);              // barrier A passed
+                va = *reinterpret_cast<const f32x4*>(&lds->v[(0 * 64 + lane) * 4]);
+                vb = *reinterpret_cast<const f32x4*>(&lds->v[(1 * 64 + lane) * 4]);
+                vc = *reinterpret_cast<const f32x4*>(&lds->v[(2 * 64 + lane) * 4]);
+                if constexpr (M0) { x6 = lds->v16[lane & 15]; y6 = lds->v16[16 + (lane & 15)]; z6 = lds->v16[32 + (lane & 15)]; }
+            }
+            if constexpr (!VZ && mq == M_SH) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sh[r] = sqrtf_(fmaxf(va[r] * va[r] + vb[r] * vb[r] + vc[r] * vc[r], 1e-8f));
+                if constexpr (M0) sh16 = sqrtf_(fmaxf(x6 * x6 + y6 * y6 + z6 * z6, 1e-8f));
+            }
         } else if constexpr (M0 && qi >= Q.q_rbf && qi < Q.q_rbf + 2) {
             constexpr int r0 = 2 * (qi - Q.q_rbf);
             acc0 = mfma16(w[0], in.rb[r0], acc0);
@@ -255,20 +305,6 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
             acc1 = mfma16(w[3], in.rb[r0 + 1], acc1);
         } else if constexpr (qi >= Q.q_sh && qi < Q.q_sh + 2) {
             constexpr int r0 = 2 * (qi - Q.q_sh);
-            if constexpr (r0 == 0 && !VZ) {           // barrier A: the three coordinates of Vh are in LDS
-                N16_STAMP_B(sk, lane, wq);              // main k-steps issued
-                lds_barrier();
-                N16_STAMP_B(sk, lane, wq);              // barrier A passed
-                const f32x4 a = *reinterpret_cast<const f32x4*>(&lds->v[(0 * 64 + lane) * 4]);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(&lds->v[(1 * 64 + lane) * 4]);
-                const f32x4 c = *reinterpret_cast<const f32x4*>(&lds->v[(2 * 64 + lane) * 4]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sh[r] = sqrtf_(fmaxf(a[r] * a[r] + b[r] * b[r] + c[r] * c[r], 1e-8f));
-                if constexpr (M0) {
-                    const float x6 = lds->v16[lane & 15], y6 = lds->v16[16 + (lane & 15)], z6 = lds->v16[32 + (lane & 15)];
-                    sh16 = sqrtf_(fmaxf(x6 * x6 + y6 * y6 + z6 * z6, 1e-8f));
-                }
-            }
             acc0 = mfma16(w[0], sh[r0], acc0);
             acc1 = mfma16(w[1], sh[r0], acc1);
             acc0 = mfma16(w[2], sh[r0 + 1], acc0);
@@ -294,16 +330,16 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
             if constexpr (t == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { S[0][r] = siluf_(S[0][r]); S[1][r] = siluf_(S[1][r]); }
+                if constexpr (!LAST) {                // the SiLU outputs leave for LDS under the gate k-steps
+                    *reinterpret_cast<f32x4*>(&lds->s[((2 * wq) * 64 + lane) * 4]) = S[0];
+                    *reinterpret_cast<f32x4*>(&lds->s[((2 * wq + 1) * 64 + lane) * 4]) = S[1];
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) gp = mfma16(w[r], S[t][r], gp);
             if constexpr (t == 1) {                   // publish; barrier B; collect
                 if (!vecw) gp += gbias;
                 *reinterpret_cast<f32x4*>(&lds->g[(wq * 64 + lane) * 4]) = gp;
-                if constexpr (!LAST) {
-                    *reinterpret_cast<f32x4*>(&lds->s[((2 * wq) * 64 + lane) * 4]) = S[0];
-                    *reinterpret_cast<f32x4*>(&lds->s[((2 * wq + 1) * 64 + lane) * 4]) = S[1];
-                }
                 N16_STAMP_B(sk, lane, wq);              // sh / Vu / SiLU / gate k-steps issued
                 lds_barrier();
                 N16_STAMP_B(sk, lane, wq);              // barrier B passed
@@ -314,27 +350,30 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) XS[4 * T + r] = x[r];
                     }
-                }
-                if (vecw) {
-                    const f32x4 ga = *reinterpret_cast<const f32x4*>(&lds->g[(0 * 64 + lane) * 4]);
-                    const f32x4 gb = *reinterpret_cast<const f32x4*>(&lds->g[(1 * 64 + lane) * 4]);
-                    const f32x4 gc = *reinterpret_cast<const f32x4*>(&lds->g[(2 * 64 + lane) * 4]);
-                    const f32x4 gd = *reinterpret_cast<const f32x4*>(&lds->g[(3 * 64 + lane) * 4]);
+                    // the gate stays pending: VB = the ungated Vu, the sums wait in lds->g (next block, or n16_gate_flush)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float gpre = (ga[r] + gb[r]) + (gc[r] + gd[r]);
-                        if (gs) (*gs)[r] = gpre;
-                        VB[r] = (SIG ? sigmoidf_(gpre) : gpre) * vu[r];
-                    }
+                    for (int r = 0; r < 4; ++r) VB[r] = vecw ? vu[r] : 0.f;
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) VB[r] = 0.f;
+                    for (int r = 0; r < 4; ++r) VB[r] = vu[r];
+                    f32x4 GL[4];
+                    n16_gate_request(GL, lds, lane);
+                    n16_gate_apply<SIG>(GL, VB, vecw, gs);
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     });
     ring.advance(Q.nq);
+}
+
+// n GEN blocks in a row, none of them LAST, the first one taking VB as it stands: leaves the last one's gate pending (n > 0)
+template <int OFF>
+__device__ __forceinline__ void n16_gen_run(const int n, N16Ring& ring, float (&XS)[32], float (&VB)[4], const N16In& in, f32x4 (&S)[2],
+                                            N16Lds* lds, const int lane, const int wq, int& sk) {
+    if (n <= 0) return;
+    n16_block<N16_GEN, OFF, false, true, false>(ring, XS, VB, in, S, lds, lane, wq, sk);
+    for (int gi = 1; gi < n; ++gi) n16_block<N16_GEN, OFF, false, true, true>(ring, XS, VB, in, S, lds, lane, wq, sk);
 }
 
 // segmented inclusive scan over the 16 rows of an item (one 16-lane DPP row per lane group): rows are sorted by key
@@ -453,8 +492,8 @@ __device__ __forceinline__ void n16_edge_chain(const EdgeParams& p, N16Ring& rin
     }
     N16_STAMP(sk, lane, wq);                              // source rows gathered / encoded (as far as the compiler keeps the order)
     n16_block<KIND0, 0, false>(ring, XS, VB, in, S, lds, lane, wq, sk);
-    for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false>(ring, XS, VB, in, S, lds, lane, wq, sk);
-    n16_block<N16_GEN, OFF1, true>(ring, XS, VB, in, S, lds, lane, wq, sk);
+    for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false, true, true>(ring, XS, VB, in, S, lds, lane, wq, sk);
+    n16_block<N16_GEN, OFF1, true, true, true>(ring, XS, VB, in, S, lds, lane, wq, sk);
     N16_STAMP(sk, lane, wq);                              // chain done
     // per-destination sums in slot order, one partial row per (item, destination) run
     const SegMask16 sm = seg_masks16(rw.dst, j);
@@ -927,7 +966,8 @@ __device__ __forceinline__ void n16_node_update_l0(const FusedParams& f, const E
     N16In none{};
     f32x4 S[2];
     S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
-    for (int gi = 0; gi < f.n_upd; ++gi) n16_block<N16_GEN, 0, false>(ring, XS, VB, none, S, lds, lane, wq, sk);
+    n16_gen_run<0>(f.n_upd, ring, XS, VB, none, S, lds, lane, wq, sk);
+    n16_gate_flush(VB, lds, lane, wq);
 #pragma unroll
     for (int k = 0; k < 32; ++k) XS[k] += Xr[k];
 #pragma unroll
@@ -1202,7 +1242,8 @@ __device__ __forceinline__ void n16_node_update_last(const TailParams& t, const 
     N16In none{};
     f32x4 S[2];
     S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
-    for (int gi = 0; gi < t.n_upd; ++gi) n16_block<N16_GEN, 0, false>(ring, XS, VB, none, S, lds, lane, wq, sk);
+    n16_gen_run<0>(t.n_upd, ring, XS, VB, none, S, lds, lane, wq, sk);
+    n16_gate_flush(VB, lds, lane, wq);
 #pragma unroll
     for (int k = 0; k < 32; ++k) XS[k] += Xr[k];
 #pragma unroll
@@ -1249,8 +1290,9 @@ __global__ __launch_bounds__(256) void k_n16_tail(const int* __restrict__ a_prot
         N16In none{};
         f32x4 S[2], GS = {0.f, 0.f, 0.f, 0.f};
         S[0] = GS; S[1] = GS;
-        for (int gi = 0; gi + 1 < t.n_head; ++gi) n16_block<N16_GEN, 0, false>(ring, XS, VB, none, S, &L.n, lane, wq, sk);
-        n16_block<N16_GEN, 0, true, false>(ring, XS, VB, none, S, &L.n, lane, wq, sk, &GS);
+        n16_gen_run<0>(t.n_head - 1, ring, XS, VB, none, S, &L.n, lane, wq, sk);
+        if (t.n_head > 1) n16_block<N16_GEN, 0, true, false, true>(ring, XS, VB, none, S, &L.n, lane, wq, sk, &GS);
+        else n16_block<N16_GEN, 0, true, false, false>(ring, XS, VB, none, S, &L.n, lane, wq, sk, &GS);
         N16_STAMP(sk, lane, wq);                          // head done
         if (j < nv) {
             if (wq < 3 && g == 0) {                       // gated channel 0 of coordinate wq
@@ -1319,11 +1361,12 @@ __global__ __launch_bounds__(256) void k_n16_unit(const UnitParams p) {
     if (msg) {
         constexpr int OFF1 = n16_sched(N16_M0F).nq % N16_D;
         n16_block<N16_M0F, 0, false>(ring, XS, VB, in, S, &lds, lane, wq, sk);
-        for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false>(ring, XS, VB, in, S, &lds, lane, wq, sk);
-        n16_block<N16_GEN, OFF1, true>(ring, XS, VB, in, S, &lds, lane, wq, sk);
+        for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false, true, true>(ring, XS, VB, in, S, &lds, lane, wq, sk);
+        n16_block<N16_GEN, OFF1, true, true, true>(ring, XS, VB, in, S, &lds, lane, wq, sk);
     } else {
-        for (int gi = 0; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, 0, false>(ring, XS, VB, in, S, &lds, lane, wq, sk);
-        n16_block<N16_GEN, 0, true>(ring, XS, VB, in, S, &lds, lane, wq, sk);
+        n16_gen_run<0>(p.n_gvps - 1, ring, XS, VB, in, S, &lds, lane, wq, sk);
+        if (p.n_gvps > 1) n16_block<N16_GEN, 0, true, true, true>(ring, XS, VB, in, S, &lds, lane, wq, sk);
+        else n16_block<N16_GEN, 0, true, true, false>(ring, XS, VB, in, S, &lds, lane, wq, sk);
     }
     N16_STAMP(sk, lane, wq);                              // chain done
     if (j < nv) {
