@@ -390,6 +390,64 @@ def golden_sample_multi(cfg, name, pockets, n_pharms, max_batch_size, T, noise_s
     npz(name, **out)
 
 
+def golden_metrics(name, n_samples=24, seed=31):
+    """SampleAnalyzer.analyze / pharm_feat_freq and compute_complementarity(return_count=True) of the reference
+    (analysis/metrics.py:9-51, 53-86) on its own SampledPharmacophore objects (analysis/pharm_builder.py:7-30): seeded synthetic
+    samples -- 1-8 centers with arbitrary feature logits next to 0-12 receptor pharmacophore nodes -- plus hand-placed cases
+    at the edges of the rule: a center exactly at its type's matching distance (<=), just beyond it, a complementary type out
+    of range next to a non-complementary one in range, Aromatic <-> PositiveIon in both directions, argmax ties (first index
+    wins).  Every sample has at least one receptor node (torch.cdist over zero columns yields an empty mask and any() is False
+    there too; the reference never meets a pocket without prot_ph nodes) and validity is the quantity the metrics all-reduce
+    carries."""
+    from pharmacoforge.analysis import metrics as ref_metrics
+    from pharmacoforge.analysis.pharm_builder import SampledPharmacophore as RefSP
+    gen = torch.Generator().manual_seed(seed)
+    cases = []                                                  # (pharm_x, pharm_h, prot_ph_x, prot_ph_h)
+    eye = torch.eye(6)
+    for i in range(n_samples):
+        nf = int(torch.randint(1, 9, (1,), generator=gen))
+        nr = int(torch.randint(1, 13, (1,), generator=gen))
+        px = torch.randn(nf, 3, generator=gen) * 3.0
+        ph = torch.randn(nf, 6, generator=gen)
+        rx = torch.randn(nr, 3, generator=gen) * 4.0
+        rh = eye[torch.randint(0, 6, (nr,), generator=gen)]
+        cases.append((px, ph, rx, rh))
+    t = {n: i for i, n in enumerate(PH_TYPES)}
+    z3 = torch.zeros(1, 3)
+
+    def at(d):
+        return torch.tensor([[float(d), 0.0, 0.0]])
+    for ctype, rtype, dist in (("HydrogenDonor", "HydrogenAcceptor", 4.0), ("HydrogenDonor", "HydrogenAcceptor", 4.0001),
+                               ("Aromatic", "PositiveIon", 7.0), ("PositiveIon", "Aromatic", 5.0), ("PositiveIon", "Aromatic", 5.5),
+                               ("Hydrophobic", "Hydrophobic", 5.0), ("NegativeIon", "PositiveIon", 4.99), ("NegativeIon", "NegativeIon", 1.0),
+                               ("HydrogenAcceptor", "HydrogenDonor", 3.0), ("Aromatic", "Aromatic", 7.0001)):
+        cases.append((z3.clone(), eye[t[ctype]][None].clone(), at(dist), eye[t[rtype]][None].clone()))
+    # complementary type out of range next to a non-complementary one in range; two centers sharing one receptor node
+    cases.append((z3.clone(), eye[t["HydrogenDonor"]][None].clone(), torch.cat([at(6.0), at(1.0)]),
+                  torch.stack([eye[t["HydrogenAcceptor"]], eye[t["HydrogenDonor"]]])))
+    cases.append((torch.cat([z3, at(1.0)]), torch.stack([eye[t["Hydrophobic"]], eye[t["Hydrophobic"]]]), at(4.5), eye[t["Hydrophobic"]][None].clone()))
+    # argmax ties: the first index wins (Aromatic over HydrogenDonor; receptor HydrogenAcceptor over NegativeIon)
+    cases.append((z3.clone(), torch.tensor([[1.0, 1.0, 0.0, 0.0, 0.0, 0.0]]), at(3.5), torch.tensor([[0.0, 0.0, 1.0, 0.0, 1.0, 0.0]])))
+    samples, counts = [], []
+    for px, ph, rx, rh in cases:
+        g = dgl.heterograph({('prot', 'pp', 'prot'): ([], []), ('prot', 'pf', 'pharm'): ([], []), ('pharm', 'ff', 'pharm'): ([], []),
+                             ('pharm', 'fp', 'prot'): ([], [])}, num_nodes_dict={'prot': 0, 'pharm': px.shape[0], 'prot_ph': rx.shape[0]})
+        g.nodes['pharm'].data['x_0'] = px; g.nodes['pharm'].data['h_0'] = ph
+        g.nodes['prot_ph'].data['x_0'] = rx; g.nodes['prot_ph'].data['h_0'] = rh
+        sp = RefSP(g, PH_TYPES)
+        samples.append(sp)
+        rt = [ref_metrics.ph_idx_to_type[int(k)] for k in rh.argmax(dim=1)]
+        counts.append(int(ref_metrics.compute_complementarity(sp.ph_types, sp.ph_coords, rt, rx, return_count=True)))
+    an = ref_metrics.SampleAnalyzer()
+    out = dict(n=len(cases), validity=an.analyze(samples)["validity"], freq=an.pharm_feat_freq(samples), counts=torch.tensor(counts),
+               validity_first_half=an.analyze(samples[:len(samples) // 2])["validity"],
+               pharm_ptr=torch.tensor([0] + list(np.cumsum([c[0].shape[0] for c in cases]))),
+               prot_ph_ptr=torch.tensor([0] + list(np.cumsum([c[2].shape[0] for c in cases]))),
+               pharm_x=torch.cat([c[0] for c in cases]), pharm_h=torch.cat([c[1] for c in cases]),
+               prot_ph_x=torch.cat([c[2] for c in cases]), prot_ph_h=torch.cat([c[3] for c in cases]))
+    npz(name, **out)
+
+
 def golden_pp_edges(name, pockets, cutoff=3.5):
     """The static prot->prot edges exactly as build_initial_complex_graph emits them
     (dataset/protein_pharm_dataset.py:234-236: radius_graph(r, max_num_neighbors=100) on one pocket), in its order."""
@@ -525,7 +583,13 @@ def main():
         # own `precision` argument (pharmacodiff.py:41,64) at 0.25 gives alpha_T >= 0.5 -- same sampler code, every step with
         # ff / pf / fp edges between centers 1-5 A apart, 3.4 A from the pocket centre at most.
         "traj_c1_T500_bounded.npz": lambda n: golden_trajectory(cfg, n, seeds=[0], n_prot=64, n_pharm=4, T=500, precision=0.25),
+        # ---- round 5 -------------------------------------------------------------------------------------------
+        # the validity metric and the feature-type counts (what the RCCL metrics all-reduce carries)
+        "metrics.npz": lambda n: golden_metrics(n),
     }
+    # one thread: the reductions inside the reference's backward then add in one order, and every fixture -- the parameter
+    # gradients included -- regenerates bit for bit (eight threads: 9e-13 differences in train_grads.npz)
+    torch.set_num_threads(1)
     want = sys.argv[1:] or list(jobs)
     for name in want:
         jobs[name](name)

@@ -517,6 +517,33 @@ def test_generate_pharmacophores_cli_end_to_end(tmp_path):
     assert (pdir / "reference_files" / "rec.pdb").exists() and (pdir / "reference_files" / "lig.sdf").exists()
     # 20 residues within 8 A of the ligand, 5 heavy atoms each
     assert sum(l.startswith("ATOM") for l in (pdir / "pocket.pdb").read_text().splitlines()) == 100
+    # ---- value level: the file against the CPU oracle on the same pocket and the same draws.  The CLI seeds torch (--seed 1),
+    # builds the model on the host and draws each chunk's noise on the device as one randn(T + 1, Nf, 9) (models.py:
+    # _sample_enqueue) -- the same two draws here.  Pocket: pocket_io on the same files with the ORACLE's radius graph (so the
+    # GPU radius graph, the ingestion, copy_graph, the sampler and the xyz writer are all inside the comparison).
+    from pharmacoforge_amd import pocket_io as P
+    emap, _ = P.get_prot_atom_ph_type_maps(cfg['dataset'])
+    res = P.select_pocket_residues(P.read_pdb(tmp_path / "rec.pdb"), P.parse_ligand(tmp_path / "lig.sdf", True)[1], 8.0)
+    pos = torch.tensor([a.coord.tolist() for r in res for a in r.atoms])
+    e = O.radius_graph(pos, 3.5, torch.tensor([0, pos.shape[0]]), 100)
+    pk = P.process_ligand_and_pocket(tmp_path / "rec.pdb", None, emap, cfg['graph']['graph_cutoffs'], 8.0, lig_file=tmp_path / "lig.sdf",
+                                     pp_edges=(e[0], e[1]))
+    pocket1 = O.PocketBatch(pk.prot_x, pk.prot_h, torch.tensor([0, pk.prot_x.shape[0]]), torch.tensor([0, 1]), pk.pp_src.long(), pk.pp_dst.long())
+    T = 12
+    torch.manual_seed(1)
+    noises = [torch.randn(T + 1, n, 9, device="cuda").cpu() for n in (12, 7)]           # chunks [3, 4, 5] and [3, 4]
+    want = []
+    with torch.no_grad():
+        for sizes, nz in zip(([3, 4, 5], [3, 4]), noises):
+            b = O.concat_pockets([O.copy_pocket(pocket1, n) for n in sizes])
+            x0, h0 = O.sample_given_receptor(sd, O.DynamicsConfig(), b, T, float(cfg['diffusion'].get('precision', 1e-5)), nz)
+            want += list(zip(x0.tolist(), h0.argmax(1).tolist()))
+    rows = [l.split() for l in xyz if len(l.split()) == 4]
+    assert len(rows) == len(want) == 19
+    scale = max(abs(float(v)) for r in rows for v in r[1:])
+    for r, (xw, kw) in zip(rows, want):
+        assert r[0] == "PSFNOC"[kw], (r, kw)
+        assert all(abs(float(u) - v) <= 5e-3 * max(1.0, scale) for u, v in zip(r[1:], xw)), (r, xw)
 
 
 def test_train_driver_smoke(tmp_path):

@@ -166,6 +166,30 @@ def test_validity_metric():
     assert pfa.SampleAnalyzer().pharm_feat_freq([ph]).tolist() == [0, 1, 0, 0, 0, 1]
 
 
+def test_metrics_match_the_reference_analyzer():
+    """analysis.SampleAnalyzer / compute_complementarity against tests/golden/metrics.npz -- the reference's own
+    SampleAnalyzer.analyze, pharm_feat_freq and compute_complementarity(return_count=True) (analysis/metrics.py:9-86) run on its own
+    SampledPharmacophore objects: 24 seeded samples plus the edges of the rule (a center exactly at the matching distance, just
+    beyond it, complementary-but-far next to close-but-not-complementary, argmax ties).  Counts per sample exact, validity to the
+    reference's float32 division."""
+    z = load("metrics.npz")
+    fp, rp = z["pharm_ptr"].tolist(), z["prot_ph_ptr"].tolist()
+    samples, counts = [], []
+    for i in range(int(z["n"])):
+        g = pocket(3, 5, fp[i + 1] - fp[i])
+        g.pharm_x0, g.pharm_h0 = z["pharm_x"][fp[i]:fp[i + 1]], z["pharm_h"][fp[i]:fp[i + 1]]
+        g.prot_ph_x, g.prot_ph_h = z["prot_ph_x"][rp[i]:rp[i + 1]], z["prot_ph_h"][rp[i]:rp[i + 1]]
+        ph = pfa.SampledPharmacophore(g, pfa.analysis.ph_idx_to_type)
+        samples.append(ph)
+        rt = [pfa.analysis.ph_idx_to_type[int(k)] for k in g.prot_ph_h.argmax(dim=1)]
+        counts.append(int(pfa.analysis.compute_complementarity(ph.ph_types, ph.ph_coords, rt, g.prot_ph_x, return_count=True)))
+    assert counts == z["counts"].tolist()
+    an = pfa.SampleAnalyzer()
+    assert abs(an.analyze(samples)["validity"] - float(z["validity"])) < 1e-7
+    assert abs(an.analyze(samples[:len(samples) // 2])["validity"] - float(z["validity_first_half"])) < 1e-7
+    assert an.pharm_feat_freq(samples).tolist() == z["freq"].tolist()
+
+
 def _rank_fn(rank, world, port, q):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)

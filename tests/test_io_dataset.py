@@ -87,6 +87,16 @@ def test_pdb_sdf_pocket(tmp_path):
     assert g.prot_h.shape == (7, 11) and g.prot_h.sum(1).eq(1).all()
     assert g.prot_h[:, :3].sum(0).tolist() == [4.0, 2.0, 1.0]            # 4 C, 2 N, 1 O
     assert torch.allclose(g.pharm_x0, pos.mean(0, keepdim=True)) and g.pharm_h0.shape == (1, 6)
+    # value level, written out by hand (generate_pharmacophores.py:148-220 on these files): the atom set in file order, its
+    # one-hots over prot_elements, the ligand centre, and the static pp edges -- every pair closer than 3.5 A, both directions
+    # (O -- CB of the alanine are 3.523 A apart: no edge; the methionine's N -- CA are the only pair of the second residue)
+    want_xyz = [(0, 0, 0), (1.4, 0, 0), (2.0, 1.3, 0), (1.4, 2.3, 0), (2.1, -1.1, 0.6), (6, 0, 0), (7.4, 0, 0)]
+    want_elem = ["N", "C", "C", "O", "C", "N", "C"]
+    assert torch.allclose(g.prot_x, torch.tensor(want_xyz, dtype=torch.float32))
+    assert g.prot_h.argmax(1).tolist() == [PROT_ELEMENTS.index(e) for e in want_elem]
+    assert torch.allclose(g.pharm_x0, torch.tensor([[2.5 / 3, 2.5 / 3, 0.0]]))          # mean of the ligand's heavy atoms C, O, N
+    undirected = {(0, 1), (0, 2), (0, 3), (0, 4), (1, 2), (1, 3), (1, 4), (2, 3), (2, 4), (5, 6)}
+    assert set(zip(g.pp_src.tolist(), g.pp_dst.tolist())) == undirected | {(b, a) for a, b in undirected}
     out = (tmp_path / "pocket.pdb").read_text().splitlines()
     assert sum(l.startswith("ATOM") for l in out) == 9 and not any("HOH" in l or "GLY" in l for l in out)
     # residue-list variant: centre = mean of ALL atoms of the listed residues (hydrogens included), :170-173
