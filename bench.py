@@ -18,6 +18,32 @@ import time
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+HOST_SHARE = {}
+
+
+def pin_host_threads(local_rank, local_world):
+    """sharding.pin_host_threads, loaded from its file: this runs first in a rank process, before the package (and with it the
+    engine, the models, the HIP runtime) is imported."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_pf_sharding", os.path.join(ROOT, "pharmacophore-diffusion_amd", "sharding.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.pin_host_threads(local_rank, local_world)
+
+
+def step_time_stats(host_s, dev_ms):
+    """Per-step times of a timed region: what the host spent enqueuing each step and what the device's timeline shows between the
+    events recorded behind consecutive steps.  A stall shows up as ONE step far beyond the median, on one side or on both."""
+    def stats(v, scale):
+        if not v:
+            return None
+        srt = sorted(v)
+        med = srt[len(srt) // 2]
+        worst = max(range(len(v)), key=lambda i: v[i])
+        return {"mean": sum(v) / len(v) * scale, "median": med * scale, "max": v[worst] * scale, "argmax": worst,
+                "over_3x_median": [[i, round(x * scale, 4)] for i, x in enumerate(v) if x > 3 * med][:8]}
+    return {"host_enqueue_ms": stats(host_s, 1e3), "device_timeline_ms": stats(dev_ms, 1.0)}
+
 sys.path.insert(0, ROOT)
 
 MAX_SHARED_GPU_RANKS = 4         # --gpus N with fewer than N GPUs visible: the gloo dry run of the N-rank plumbing, at most this many ranks
@@ -306,6 +332,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # one process per GPU shares the host with its peers: its CPU slice and pool sizes are fixed before anything touches the GPU
+    # or starts a thread pool (one node: LOCAL_WORLD_SIZE = WORLD_SIZE unless the launcher says otherwise)
+    global HOST_SHARE
+    HOST_SHARE = pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     # children first: nothing in this process has touched the GPU yet (a process that has must not start other programs)
     headline = not args.train and args.sample_slice == 0
     pmc, pmc_err, secondary = None, "not collected (--no-traffic, or a multi-rank run)", None
@@ -585,6 +615,7 @@ def main():
                                             "(SURVEY 8d formulas): information only -- the kernels do not execute or move it (dead-work "
                                             "elimination is exact), so no fraction is formed from it"}},
         "rccl_world": (dist.get_world_size() if (world > 1 and backend == "nccl") else (1 if world == 1 else 0)),
+        "host": HOST_SHARE,
         "per_rank_ms_per_step": per_rank_ms,
     }
     if pmc is not None:
@@ -839,6 +870,7 @@ def slice_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
             "unit": "sample-steps/s", "n_gpus": world, "steps": T, "warmup": 0, "ms_per_step": dt / T * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rccl_world": rccl_world_of(world, backend, dist), "per_rank_ms_per_step": [v / T * 1e3 for v in per_rank_s],
+            "host": HOST_SHARE,
             "config": {"workload": f"BASELINE config 4 slice: {P} pockets per GPU x {S} pharmacophores (sizes 3-8), {args.n_prot}-atom "
                                    f"pockets, T={T}, max_batch_size {args.max_batch_size}, dev.yml network",
                        "pockets": P * world, "pharmacophores": n, "wall_s": dt, "ms_per_pocket": dt / max(P, 1) * 1e3,
@@ -929,16 +961,28 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
         step()
     eng.profile_enable(0)
     eng.profile_read_train()
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    for e in step_ev:
+        e.record()                                 # (created AND first recorded out here: see above)
     barrier()
+    step_ev[0].record()
     t0 = time.perf_counter()
     ev_every = max(1, K // 8)                      # HIP events around the edge-message backward launches of every n-th step
+    host_s = []
     for i in range(K):
+        th = time.perf_counter()
         eng.profile_enable((1 << 11) if i % ev_every == 0 else 0)
         loss = step()
+        step_ev[i + 1].record()                    # (one event record per step: the device's own timeline of the region)
+        host_s.append(time.perf_counter() - th)
     eng.profile_enable(0)
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.profile_read_train()
+    dev_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(K)]
+    per_step = step_time_stats(host_s, dev_ms)
+    host_mean = sum(host_s) / max(len(host_s), 1)
+    _, per_rank_host = gather_rank_times(host_mean, world, dev, backend, dist)
     dt, per_rank_s = gather_rank_times(dt, world, dev, backend, dist)
     # dominant kernel of the step: k_bwd_edge_level (one launch per message-GVP level and conv layer).  Algorithmic work
     # of the message chain's backward = 2 x its forward (one product for the input gradient, one for the weight
@@ -957,6 +1001,7 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
             "unit": "graphs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.train_dtype, "data": "synthetic",
             "rccl_world": rccl_world_of(world, backend, dist), "per_rank_ms_per_step": [v / K * 1e3 for v in per_rank_s],
+            "per_rank_host_enqueue_ms": [v * 1e3 for v in per_rank_host], "per_step": per_step, "host": HOST_SHARE,
             "config": {"workload": f"BASELINE config 5: training step, batch={B} per GPU, {args.n_prot}-atom pockets, centers {lo}-{hi}, "
                                    "dropout 0.1, dev.yml network", "batch_per_gpu": B, "n_prot": args.n_prot,
                        "distinct_batches": len(graphs),

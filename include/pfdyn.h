@@ -132,10 +132,11 @@ int pf_set_pocket_batch_host(pf_handle* h, int32_t B, const int32_t* host_prot_p
  * instead of once per copy, gvp.py:545-549 being a pure function of pocket geometry, element types and t there);
  * outputs are the same up to fp32 summation order.  The groups apply to one bind only -- the next bind call consumes the
  * claim whether it succeeds or is rejected (argument checks included).  What "verifies" covers: ptr arrays and pp edges
- * always (they are host arrays); coordinates and features only for pf_set_pocket_batch_host.  With pf_set_pocket_batch
- * (DEVICE coordinates / features) the library cannot see those rows on the host and does NOT compare them: a false claim
- * there makes copies silently share their representative's conv-layer-0 messages.  The Python engine compares the rows on
- * the device before claiming (engine.py: set_batch); a C-ABI caller must do the same or not claim. */
+ * always (they are host arrays), coordinates and features on the host for pf_set_pocket_batch_host.  With pf_set_pocket_batch
+ * (DEVICE coordinates / features) the rows are compared on the device by a small launch of the bind (bit patterns, every atom
+ * against the same atom of its representative); the verdict comes back through pinned memory and the first call that would
+ * share messages (pf_dynamics_forward / pf_denoise_step / pf_sample of that batch) reads it and fails with PF_ERR_ARG if the
+ * claim is false -- nothing is ever computed on a false claim. */
 int pf_set_pocket_groups(pf_handle* h, int32_t B, const int32_t* host_rep);
 
 /* Optional, right after pf_set_pocket_batch: the caller states whether every row of prot_h is an element one-hot

@@ -50,6 +50,8 @@ void pfk_load_noise0(const float* nz, float4* xn, float* hf, int n, int nf, hipS
 void pfk_copy(const float* src, float* dst, size_t n, hipStream_t s);
 void pfk_zero_multi(const ZeroList* z, hipStream_t s);
 void pfk_copy2(const float* a, float* da, size_t na, const float* b, float* db, size_t nb, hipStream_t s);
+void pfk_verify_copies(const float* x0, const float* h0, const int* gid, const int* prot_ptr, const int* rep_base, int Np, int rec_nf,
+                       int* flag, hipStream_t s);
 void pfk_scale_copy(const float* src, float* dst, size_t n, float sc, hipStream_t s);
 void pfk_segment_mean(const float4* xn, const int* ptr, int base, int B, float* out, hipStream_t s);
 void pfk_step_update(const StepParams* p, hipStream_t s);
@@ -287,6 +289,8 @@ struct pf_handle {
     // next bind verifies the claim and, when it pays, prepares the tables of the sharing mode
     std::vector<int> pending_rep;           // consumed by the next pf_set_pocket_batch*
     bool share_ok = false;                  // tables of the sharing mode exist for this batch
+    int share_check = 1;                    // the claim's rows: 1 verified (host rows, or nothing claimed), 0 compared on the device and not
+                                            // read back yet (l0flag_host[1], behind l0flag_ev), 2 found false
     int* d_reg_share = nullptr;             // [4][B]: d_reg with the kind-3 entries of representatives at their static pp edges
     int* d_pa_static = nullptr;             // [B]: static pp edge count of a representative, 0 for a copy
     int* d_rep_base = nullptr;              // [B]: node id of the first atom of each graph's representative
@@ -889,6 +893,11 @@ static bool l0_hoist_ok(pf_handle* h);
 // pocket sharing applies to inference calls at one common t whose conv layer 0 is the pruned layer under the static hoist
 static bool share_now(pf_handle* h) {
     const pf_config& c = h->cfg;
+    if (h->share_ok && h->share_check == 0) {        // device rows: the comparison's verdict arrived with the one-hot flag
+        if (h->l0flag_ev) (void)hipEventSynchronize(h->l0flag_ev);
+        h->share_check = (h->l0flag_host && h->l0flag_host[1] == 0) ? 1 : 2;
+    }
+    if (h->share_check == 2) return false;           // (run_dynamics fails the call: a false claim is the caller's bug, not a mode)
     return h->share_ok && !h->share_disable && h->prune && c.n_convs == 2 && h->rg_compact && l0_hoist_ok(h);
 }
 // a build with these parameters has been enqueued: its stamp is what the next shared edge launch looks for
@@ -1015,7 +1024,11 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     // -- unless the previous denoising step's update launch has built the edges of these coordinates already
     const bool enc_fly = !train && encoders_on_the_fly(h);
     // pocket sharing: copies of a pocket read one set of layer-0 pp messages (calls at one common t only)
+    if (h->share_ok && h->share_check == 0) (void)share_now(h);                    // a claim about device rows: its verdict, whatever this call shares
     const bool share = enc_fly && t_scalar != nullptr && prune_layer == 0 && share_now(h);
+    if (h->share_check == 2)
+        PF_FAIL(h, PF_ERR_ARG, "pf_set_pocket_groups: the claim made for this batch is false -- a graph differs from its representative in "
+                               "coordinates or features (compared on the device); bind the batch again without the claim");
     if (h->edges_built && h->edges_share != share) h->edges_built = false;       // built for the other mode: rebuild
     BuildParams bp = build_params(h, share);
     bool pre_ready = false;
@@ -2288,6 +2301,11 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     if (!from_host) {
         pfk_copy2(dev_prot_x, h->d_prot_x0, (size_t)Np * 3, dev_prot_h, h->d_prot_h0, (size_t)Np * c.rec_nf, s);
     }
+    h->share_check = 1;
+    if (!from_host && h->share_ok) {             // the claim's rows are on the device only: compared there, verdict read back lazily
+        pfk_verify_copies(h->d_prot_x0, h->d_prot_h0, h->d_gid, h->d_prot_ptr, h->d_rep_base, Np, c.rec_nf, h->d_l0flag + 1, s);
+        h->share_check = 0;
+    }
     pfk_load_coords(h->d_prot_x0, h->d_xn, Np, h->d_gid, nullptr, 0.f, s);
     {
         L0HoistParams lp{};
@@ -2299,8 +2317,8 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     if (!h->l0flag_host) PF_HIP(h, hipHostMalloc((void**)&h->l0flag_host, 64, hipHostMallocDefault));
     if (!h->l0flag_ev) PF_HIP(h, hipEventCreateWithFlags(&h->l0flag_ev, hipEventDisableTiming));
     else PF_HIP(h, hipEventSynchronize(h->l0flag_ev));           // the previous bind's read-back (long done) before its target is reused
-    *h->l0flag_host = 1;
-    PF_HIP(h, hipMemcpyAsync(h->l0flag_host, h->d_l0flag, 4, hipMemcpyDeviceToHost, s));
+    h->l0flag_host[0] = 1; h->l0flag_host[1] = 1;
+    PF_HIP(h, hipMemcpyAsync(h->l0flag_host, h->d_l0flag, 8, hipMemcpyDeviceToHost, s));
     PF_HIP(h, hipEventRecord(h->l0flag_ev, s));
     mark();      // 6: everything enqueued
     if (timing) fprintf(stderr, "[pf_set_pocket_batch] B=%d checks+tables %.2f ws %.2f stage-wait %.2f index arrays (in staging) %.2f upload %.2f launches+waits %.2f ms (fresh %d, %zu MB)\n",

@@ -1746,6 +1746,22 @@ __global__ void k_copy2(const float* a, float* da, const size_t na, const float*
     if (i < na) da[i] = a[i];
     else if (i - na < nb) db[i - na] = b[i - na];
 }
+// pf_set_pocket_groups with DEVICE rows (pf_set_pocket_batch): the claim "graph g is a copy of its representative" is checked where
+// the rows are -- atom i of graph g against the same atom of the representative (coordinates and features, bit patterns);
+// any difference sets *flag, which travels to the host with the one-hot verdict and fails the first call that would share
+__global__ void k_verify_copies(const float* __restrict__ x0, const float* __restrict__ h0, const int* __restrict__ gid,
+                                const int* __restrict__ prot_ptr, const int* __restrict__ rep_base, const int Np, const int rec_nf,
+                                int* __restrict__ flag) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= Np) return;
+    const int g = gid[i];
+    const int j = rep_base[g] + (i - prot_ptr[g]);
+    if (j == i) return;
+    bool same = true;
+    for (int c = 0; c < 3; ++c) same = same && __float_as_uint(x0[(size_t)i * 3 + c]) == __float_as_uint(x0[(size_t)j * 3 + c]);
+    for (int k = 0; k < rec_nf; ++k) same = same && __float_as_uint(h0[(size_t)i * rec_nf + k]) == __float_as_uint(h0[(size_t)j * rec_nf + k]);
+    if (!same) atomicOr(flag, 1);
+}
 // per-graph mean of coordinates (dgl.readout_nodes op='mean'); one wave per graph, fixed order
 __global__ __launch_bounds__(64) void k_segment_mean(const float4* xn, const int* ptr, const int base, float* out) {
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -1968,6 +1984,11 @@ void pfk_load_noise0(const float* nz, float4* xn, float* hf, int n, int nf, hipS
 void pfk_copy(const float* src, float* dst, size_t n, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+}
+void pfk_verify_copies(const float* x0, const float* h0, const int* gid, const int* prot_ptr, const int* rep_base, int Np, int rec_nf,
+                       int* flag, hipStream_t s) {
+    if (Np <= 0) return;
+    hipLaunchKernelGGL(k_verify_copies, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, s, x0, h0, gid, prot_ptr, rep_base, Np, rec_nf, flag);
 }
 void pfk_copy2(const float* a, float* da, size_t na, const float* b, float* db, size_t nb, hipStream_t s) {
     if (na + nb == 0) return;

@@ -322,6 +322,21 @@ class PharmRecDynamicsGVP(nn.Module):
         leaf.register_post_accumulate_grad_hook(self._bind_grads)
         self.__dict__["_flat_leaf"] = leaf
         self._last_flat_grad = None
+        # a gradient that reaches a parameter DIRECTLY (a regulariser on p, any loss term outside the fused nodes) accumulates
+        # into p.grad -- a view of the flat gradient -- without passing the leaf: a deferred clear (FlatAdam.zero_grad(lazy=True))
+        # has to happen in front of that too, whichever of the two arrives first in a backward
+        for p, _, _ in views:
+            if p.requires_grad and not getattr(p, "_pf_lazy_hook", False):
+                p.register_hook(self._param_grad_arrives)
+                p._pf_lazy_hook = True
+
+    def _param_grad_arrives(self, grad):
+        if self.__dict__.get("_grad_lazy_zero"):
+            self.__dict__["_grad_lazy_zero"] = False
+            leaf = self.__dict__.get("_flat_leaf")
+            if leaf is not None and leaf.grad is not None:
+                leaf.grad.zero_()
+        return grad
 
     def _before_accumulate(self, grad):
         leaf = self.__dict__["_flat_leaf"]
@@ -436,8 +451,9 @@ class FlatAdam:
         re-creating 244 views per step costs ~0.8 ms of host time, which is what bounds a step that binds a new batch.
         ``set_to_none=True`` drops everything, like torch.optim's default.
         ``lazy=True`` (training loops that call zero_grad -> backward -> step): nothing is launched here; the next backward of
-        the fused loss stores its gradient straight into the bound flat vector (clear and accumulation in one), any other
-        backward clears it first.  Until then ``.grad`` still shows the previous step's values."""
+        the fused loss stores its gradient straight into the bound flat vector (clear and accumulation in one); any other
+        gradient -- through the flat leaf or straight into a parameter (a regulariser on p) -- performs the deferred clear
+        first, in whichever order a backward delivers them.  Until then ``.grad`` still shows the previous step's values."""
         views = self.dyn._flat_views
         leaf = self.dyn.__dict__.get("_flat_leaf")
         if not set_to_none and leaf is not None and leaf.grad is not None and views:

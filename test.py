@@ -65,6 +65,8 @@ def init_ranks():
     """-> (rank, world, device, process group or None).  RCCL when every rank owns a GPU, gloo for dry runs on fewer."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    from pharmacoforge_amd.sharding import pin_host_threads
+    pin_host_threads(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))       # before anything touches the GPU
     ndev = torch.cuda.device_count()
     torch.cuda.set_device(local % ndev)
     device = torch.device('cuda', local % ndev)

@@ -116,6 +116,55 @@ def test_config3_ragged_batch128_steps_vs_oracle():
     torch.testing.assert_close(h1.cpu(), oh1, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("arch", ["dev", "radius_pf"])
+def test_pockets_above_512_atoms_vs_oracle(arch):
+    """Pockets beyond the fast forms' gate (the latency-optimised update + build, the fused and the merged launch all need
+    max_np <= 512: pf_host.cpp LaunchPolicy; dynamics_gvp.py:187-227 has no such bound): a batch of 700-, 540-, 96- and 820-atom
+    pockets takes the general build, and must give the oracle's steps and exactly its edges -- three denoising steps at both
+    ends of the schedule, kNN pf edges (dev.yml) and radius pf edges (the class defaults' pf_k = 0), default launch policy
+    (VERDICT r4 missing #4: no test covered more than 475 atoms)."""
+    _no_policy_overrides()
+    cfg = O.DynamicsConfig() if arch == "dev" else O.DynamicsConfig(pf_k=0, message_norm=1)
+    sd = O.make_state_dict(cfg, 0)
+    n_prot, sizes = [700, 540, 96, 820], [6, 8, 3, 5]
+    batch = O.synthetic_batch([2000 + i for i in range(4)], n_prot, sizes, cfg)
+    assert int(batch.prot_ptr[-1]) == sum(n_prot)
+    T, n = 500, 3
+    Nf = int(batch.pharm_ptr[-1])
+    noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(7))
+    eng = _engine(cfg, sd)
+    eng.set_batch(batch.prot_x, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, batch.pp_src, batch.pp_dst)
+    coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+    x0, h0 = eng.sample(eng.coef_array(coef, reversed(range(n))), n, noise)          # s = 2, 1, 0
+    assert eng.kernel_family(cfg.n_convs) == 0                                        # neither a tail nor the merged launch: the general build ran
+    bidx = batch.batch_idxs()
+    init_com = O.segment_mean(batch.prot_x, batch.prot_ptr)
+    px = batch.prot_x - init_com[bidx["prot"]]
+    x_t, h_t = noise[0][:, :3].clone(), noise[0][:, 3:].clone()
+    with torch.no_grad():
+        for i, s in enumerate(reversed(range(n))):
+            px, x_t, h_t = O.sample_step(sd, cfg, batch, coef, s, px, x_t, h_t, noise[1 + i][:, :3], noise[1 + i][:, 3:])
+    ox = x_t - O.segment_mean(px, batch.prot_ptr)[bidx["pharm"]] + init_com[bidx["pharm"]]
+    torch.testing.assert_close(x0.cpu(), ox, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(h0.cpu(), h_t, rtol=1e-3, atol=1e-3)
+    # the edges the LAST step's build emitted for the next call, against the oracle's on its own final state: exact sets
+    edges = O.build_dynamic_edges(cfg, batch, px, x_t)
+    for et, name in enumerate(("ff", "pf", "fp")):
+        s_, d_ = eng.get_edges(et)
+        os_, od_ = edges[name]
+        assert set(zip(s_.tolist(), d_.tolist())) == set(zip(os_.tolist(), od_.tolist())), (arch, name)
+    x1, h1 = eng.sample(eng.coef_array(coef, reversed(range(T))), n, noise)           # s = 499, 498, 497
+    ox1, oh1 = O.sample_given_receptor(sd, cfg, batch, T, 1e-5, noise, n_steps=n)
+    torch.testing.assert_close(x1.cpu(), ox1, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(h1.cpu(), oh1, rtol=1e-3, atol=1e-3)
+    gen = torch.Generator().manual_seed(4)
+    xt, ht, t = 2.0 * torch.randn(Nf, 3, generator=gen), torch.randn(Nf, 6, generator=gen), torch.rand(4, generator=gen)
+    eh, ex = eng.dynamics(xt, ht, t, prot_x=batch.prot_x)
+    oh, oxx = O.dynamics_forward(sd, cfg, batch, batch.prot_x, xt, ht, t)
+    torch.testing.assert_close(eh.cpu(), oh, rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(ex.cpu(), oxx, rtol=2e-4, atol=2e-4)
+
+
 _CONFIG5 = {}
 
 

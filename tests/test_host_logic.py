@@ -321,3 +321,28 @@ def test_shard_by_work_two_ranks_gloo():
     out = sorted(q.get(timeout=120) for _ in range(2))
     [p.join(30) for p in procs]
     assert all(ratio <= 1.1 and cover for _, ratio, cover in out), out
+
+
+def test_rank_processes_take_disjoint_slices_of_the_host():
+    """sharding.host_share / pin_host_threads (what every rank process of bench.py / train.py / test.py calls before touching the
+    GPU): the shares of the ranks of a node are disjoint, contiguous and cover the allowed CPUs; a rank pins itself to its share
+    and sizes torch's pool to it; a single-rank run is left alone.  (In a child process: the affinity change is for good.)"""
+    import subprocess
+    import sys
+    from pharmacoforge_amd import sharding as S
+    cpus = list(range(3, 259))
+    shares = [S.host_share(r, 8, cpus) for r in range(8)]
+    assert all(n == 32 for _, n in shares)
+    assert sorted(c for sh, _ in shares for c in sh) == cpus
+    assert all(sh == list(range(sh[0], sh[0] + 32)) for sh, _ in shares)
+    assert S.host_share(1, 3, [0, 1])[1] == 1                       # more ranks than CPUs: one each, wrapping
+    code = ("import os, json, sys; sys.path.insert(0, %r); import torch; from pharmacoforge_amd.sharding import pin_host_threads; "
+            "a = pin_host_threads(0, 1); n0 = len(os.sched_getaffinity(0)); b = pin_host_threads(1, 2); "
+            "print(json.dumps([a, b, n0, sorted(os.sched_getaffinity(0)), torch.get_num_threads(), os.environ['OMP_NUM_THREADS']]))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1500:]
+    import json
+    a, b, n0, aff, nthr, omp = json.loads(out.stdout.strip().splitlines()[-1])
+    assert a["pinned"] is False and a["host_threads_per_rank"] == n0
+    if n0 >= 2:
+        assert b["pinned"] is True and len(aff) == n0 // 2 and b["host_threads_per_rank"] == min(n0 // 2, 16) == nthr == int(omp)

@@ -52,6 +52,11 @@ def main():
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # the rank's slice of the host and its pool sizes, before anything touches the GPU (a step is as long on the host as on the device)
+    from pharmacoforge_amd.sharding import pin_host_threads
+    host = pin_host_threads(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    if world > 1:
+        print(f"[rank {rank}] host share: {host}", flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("train.py needs an MI355X: the kernels have no CPU fallback")
     ndev = torch.cuda.device_count()
