@@ -111,37 +111,50 @@ constexpr int rg_main_quad(const RgSched& s, const int nh, const int k) {
 // wait for an LDS round trip, four sigmoids and four dependent matrix instructions before the first of its 64 main ones.)
 // Scalar k-step ks (0..31), lane group g <-> input feature 16 (ks >> 2) + 4 g + (ks & 3): the D fragment of tile T = 2 w + t
 // (lane 16 g + j, register r: feature 16 T + 4 g + r of row j) is the B operand of k-step 4 T + r without any data movement.
+// -DN16_SPLIT=1 (the variant library libpfdyn_split.so, Makefile; never the default build): the 128-input scalar Linear of every
+// block -- its "main" k-steps, 64 of a GEN block's 88 matrix instructions -- runs on v_mfma_f32_16x16x32_bf16 with both operands
+// split into three bf16 planes (x = x0 + x1 + x2, 8 mantissa bits each: 24 together) and the six products with i + j <= 2
+// accumulated in fp32: 48 instructions of half the issue time, the rounding of an fp32 product within a factor ~1 (measured on a
+// ten-layer chain against fp64: 4.0e-7 of the largest output, the exact-fp32 form 5.0e-7: tools/probes/split_bf16_chain.hip,
+// profiles/r05/split_bf16_chain.txt).  A main quad is then one 16-byte load = 8 bf16 of ONE plane: quad m <-> chunk m / 6 of K
+// (32 inputs = tiles 2 c, 2 c + 1), output tile (m / 3) % 2, plane m % 3; element e of lane 16 g + i <-> input 16 (2 c + e / 4) +
+// 4 g + e % 4 -- the order in which the lane's own D fragments of the previous block line up as the B operand.  Weight bytes of the
+// main run x 1.5.  Everything else of a block (vector channel, rbf / sh k-steps, gates) stays on the exact-fp32 instructions.
+#ifndef N16_SPLIT
+#define N16_SPLIT 0
+#endif
+#define N16_NQM (N16_SPLIT ? 24 : 16)       // quads of a block's main run
 #ifndef N16_D
-#define N16_D 12            // depth of the register prefetch ring in quads (GEN blocks are a multiple of it)
+#define N16_D (N16_SPLIT ? 16 : 12)         // depth of the register prefetch ring in quads (GEN blocks are a multiple of it)
 #endif
 #ifndef N16_VH_AT
-#define N16_VH_AT 4         // GEN blocks: main quads in front of the vh quad (0: the vh quad leads the block)
+#define N16_VH_AT (N16_SPLIT ? 6 : 4)       // GEN blocks: main quads in front of the vh quad (0: the vh quad leads the block)
 #endif
 #define N16_TAIL_PAD 24     // quads of read-ahead padding behind every wave's stream
 enum { N16_GEN = 0, N16_M0F = 1, N16_M0Z = 2, N16_M0H = 3 };
 struct N16Sched {
     int q_x1, q_vh, q_w16, q_main, q_rbf, q_sh, q_vu, q_b, q_gate, nq;
     int vh_at;             // main quads [0, vh_at) sit in front of q_vh, the others behind it (GEN; 16 elsewhere: q_vh is outside the main run)
-    // stream position of main quad m (0..15), and the inverse (-1: quad qi is not a main quad)
+    // stream position of main quad m (0 .. N16_NQM - 1), and the inverse (-1: quad qi is not a main quad)
     constexpr int main_pos(const int m) const { return q_main + m + ((q_vh >= q_main && m >= vh_at) ? 1 : 0); }
     constexpr int main_of(const int qi) const {
         if (q_main < 0 || qi < q_main || qi == q_vh) return -1;
         const int m = qi - q_main - ((q_vh >= q_main && qi > q_vh) ? 1 : 0);
-        return m < 16 ? m : -1;
+        return m < N16_NQM ? m : -1;
     }
 };
 constexpr N16Sched n16_sched(const int kind) {
     N16Sched s{};
     int q = 0;
     const bool m0 = kind != N16_GEN;
-    s.vh_at = 16;
+    s.vh_at = N16_NQM;
     s.q_x1 = m0 ? q++ : -1;
-    if (kind == N16_GEN) { s.q_main = 0; s.vh_at = N16_VH_AT; s.q_vh = N16_VH_AT; s.q_w16 = -1; q = 17; }
+    if (kind == N16_GEN) { s.q_main = 0; s.vh_at = N16_VH_AT; s.q_vh = N16_VH_AT; s.q_w16 = -1; q = N16_NQM + 1; }
     else {
         s.q_vh = q++;
         s.q_w16 = kind == N16_M0F ? q++ : -1;
         s.q_main = kind != N16_M0H ? q : -1;
-        if (kind != N16_M0H) q += 16;
+        if (kind != N16_M0H) q += N16_NQM;
     }
     s.q_rbf = m0 ? q : -1;
     if (m0) q += 2;

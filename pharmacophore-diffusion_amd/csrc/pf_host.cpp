@@ -71,6 +71,7 @@ void pfk_fix_enc_group(long long* A_h, float* G_h, const float* fix, const int* 
                        int Np, int Nf, const int* onehot_flag, hipStream_t s);
 void pfk_train_reduce(const ReduceParams* p, hipStream_t s);
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s);
+void pfk_n16_split_words(const float* flat, const int4* tab, size_t n, float* packed, hipStream_t s);
 void pfk_pack_gvp(const float* W, const GvpT* g, int n_gvps, float* out_b, float* out_f, const ScaleArgs* sa, hipStream_t s);
 void pfk_loss_prepare(const LossParams* p, hipStream_t s);
 void pfk_loss_eval(const LossParams* p, hipStream_t s);
@@ -338,6 +339,12 @@ struct pf_handle {
     // (run_dynamics without train, pf_debug_chain) gathers them (n16_refresh)
     size_t n16_begin = 0;
     bool n16_stale = false;
+    // -DN16_SPLIT builds: the main quads of the n16 streams hold bf16 planes, two weights per 32-bit word -- not a gather.  While the
+    // index-valued packing pass runs (split_record) pack_n16_raw notes (word position, flat index a, flat index b, plane) per word;
+    // n16_refresh re-derives those words from the flat vector behind the gather (k_n16_split_words)
+    bool split_record = false;
+    std::vector<int4> split_pending, split_tab;     // positions relative to the stream being packed / to h_w
+    int4* d_split_tab = nullptr; size_t n_split_tab = 0;
     // conv layer 0's message chains in their own forms: protein sources (pf, pp) start from a type-table row (M0H),
     // centers (ff, fp) have zero node vectors (M0Z)
     size_t n16_l0[4] = {0, 0, 0, 0}, n16_l0_stride[4] = {0, 0, 0, 0};
@@ -758,7 +765,20 @@ struct N16Raw {                                  // the six tensors of a GVP wit
     const std::vector<float>&W, &Bv, &Wg, &bg, &wh, &wu;
     GvpSpec g;
 };
-static void pack_n16_raw(const N16Raw& rw, int kind, int w, std::vector<float>& out) {
+// plane p (0..2) of x = p0 + p1 + p2 as a bf16 bit pattern: round-to-nearest-even of what the earlier planes left (the device's
+// n16_split8 / k_n16_split_words do the same arithmetic)
+[[maybe_unused]] static uint32_t n16_bf16_plane(float x, int p) {
+    uint32_t bits = 0;
+    for (int k = 0; k <= p; ++k) {
+        uint32_t u; memcpy(&u, &x, 4);
+        bits = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+        const uint32_t hi = bits << 16;
+        float back; memcpy(&back, &hi, 4);
+        x -= back;
+    }
+    return bits & 0xffffu;
+}
+static void pack_n16_raw(const N16Raw& rw, int kind, int w, std::vector<float>& out, std::vector<int4>* split_rec = nullptr) {
     const GvpSpec& g = rw.g;
     const N16Sched q = n16_sched(kind);
     const int H = std::max(g.vi, g.vo), Kin = H + g.si;
@@ -788,6 +808,29 @@ static void pack_n16_raw(const N16Raw& rw, int kind, int w, std::vector<float>& 
             if (q.q_w16 >= 0 && w < 3) at(q.q_w16, lane, r) = wh[(size_t)(v0 + 4 * gq + r) * H + 16];
             at(q.q_vu, lane, r) = w < 3 ? wu[(size_t)(4 * gq + r) * g.vo + i] : bg[4 * gq + r];
         }
+#if N16_SPLIT
+        // main quad m = plane m % 3 of the weights of output tile (m / 3) % 2 over K chunk m / 6; a 32-bit word = elements 2 d, 2 d + 1
+        if (q.q_main >= 0)
+            for (int qm = 0; qm < N16_NQM; ++qm) {
+                const int cch = qm / 6, tt = (qm / 3) % 2, pl = qm % 3;
+                const int frow = tt ? f1 : f0;
+                for (int d = 0; d < 4; ++d) {
+                    float v[2];
+                    for (int k = 0; k < 2; ++k) {
+                        const int e = 2 * d + k;
+                        v[k] = W[(size_t)frow * Kin + 16 * (2 * cch + e / 4) + 4 * gq + e % 4];
+                    }
+                    float& word = at(q.main_pos(qm), lane, d);
+                    if (split_rec) {                 // index-valued pass: v = flat index + 1 (0: a padded row)
+                        word = 0.f;
+                        split_rec->push_back(make_int4((int)(&word - out.data()), (int)v[0] - 1, (int)v[1] - 1, pl));
+                    } else {
+                        const uint32_t bits = n16_bf16_plane(v[0], pl) | (n16_bf16_plane(v[1], pl) << 16);
+                        memcpy(&word, &bits, 4);
+                    }
+                }
+            }
+#else
         if (q.q_main >= 0)
             for (int qm = 0; qm < 16; ++qm)
                 for (int half = 0; half < 2; ++half) {
@@ -795,6 +838,7 @@ static void pack_n16_raw(const N16Raw& rw, int kind, int w, std::vector<float>& 
                     at(q.main_pos(qm), lane, 2 * half) = W[(size_t)f0 * Kin + f];
                     at(q.main_pos(qm), lane, 2 * half + 1) = W[(size_t)f1 * Kin + f];
                 }
+#endif
         for (int qq = 0; qq < 2; ++qq)
             for (int half = 0; half < 2; ++half) {
                 const int r = 2 * qq + half;
@@ -818,7 +862,7 @@ static void pack_n16(pf_handle* h, const GvpSpec& g, int kind, int w, std::vecto
     const N16Raw rw{h->raw[g.prefix + "to_feats_out.0.weight"].data, h->raw[g.prefix + "to_feats_out.0.bias"].data,
                     h->raw[g.prefix + "scalar_to_vector_gates.weight"].data, h->raw[g.prefix + "scalar_to_vector_gates.bias"].data,
                     h->raw[g.prefix + "Wh"].data, h->raw[g.prefix + "Wu"].data, g};
-    pack_n16_raw(rw, kind, w, out);
+    pack_n16_raw(rw, kind, w, out, h->split_record ? &h->split_pending : nullptr);
 }
 // The noise head's last GVP (dynamics_gvp.py:17-20: 16 vectors -> 1, 128 scalars -> 64, identity vector gate) followed by
 // to_scalar_output (Linear 64 -> pharm_nf, :35,39) as ONE GEN block of the tail kernel: the GVP zero-padded to 128 scalar
@@ -847,7 +891,7 @@ static void pack_n16_head_last(pf_handle* h, const GvpSpec& g, int w, std::vecto
     GvpSpec g2 = g;
     g2.vo = 16; g2.so = PF_S;
     const N16Raw rw{W2, B2, G2, bg2, h->raw[g.prefix + "Wh"].data, U2, g2};
-    pack_n16_raw(rw, N16_GEN, w, out);
+    pack_n16_raw(rw, N16_GEN, w, out, h->split_record ? &h->split_pending : nullptr);
 }
 
 // keep_ws: the inference workspace stays allocated (pf_set_pocket_batch re-carves it when the next batch fits: a
@@ -998,6 +1042,7 @@ static void l0_prepare_t(pf_handle* h, const float* tv, int n, hipStream_t s) {
 static void n16_refresh(pf_handle* h, hipStream_t s) {
     if (!h->n16_stale) return;
     pfk_gather_weights(h->d_flat, h->d_map + h->n16_begin, h->n_packed - h->n16_begin, h->d_w + h->n16_begin, s);
+    if (h->n_split_tab) pfk_n16_split_words(h->d_flat, h->d_split_tab, h->n_split_tab, h->d_w, s);     // (-DN16_SPLIT: the bf16-plane words)
     h->n16_stale = false;
 }
 
@@ -1442,6 +1487,7 @@ void pf_destroy(pf_handle* h) {
     if (h->d_tseg) (void)hipFree(h->d_tseg);
     if (h->d_gvpt) (void)hipFree(h->d_gvpt);
     if (h->d_map) (void)hipFree(h->d_map);
+    if (h->d_split_tab) (void)hipFree(h->d_split_tab);
     if (h->d_l0c) (void)hipFree(h->d_l0c);
     if (h->d_ptab) (void)hipFree(h->d_ptab);
     for (int k = 0; k < 2; ++k) { if (h->stage[k]) (void)hipHostFree(h->stage[k]); if (h->stage_ev[k]) (void)hipEventDestroy(h->stage_ev[k]); }
@@ -1659,6 +1705,8 @@ int pf_commit_weights(pf_handle* h) {
                     stride = st.size() - b0;
                 }
                 const size_t off = push(h->h_w, st);
+                for (int4 r : h->split_pending) { r.x += (int)off; h->split_tab.push_back(r); }
+                h->split_pending.clear();
                 st.clear();
                 return off;
             };
@@ -1690,6 +1738,8 @@ int pf_commit_weights(pf_handle* h) {
                         h->n16_tail_stride = st.size() - b0;
                     }
                     h->n16_tail = push(h->h_w, st);
+                    for (int4 r : h->split_pending) { r.x += (int)h->n16_tail; h->split_tab.push_back(r); }
+                    h->split_pending.clear();
                     st.clear();
                 }
             }
@@ -1709,8 +1759,11 @@ int pf_commit_weights(pf_handle* h) {
             h->raw[kv.first] = std::move(t);
         }
         h->h_map.clear();
+        h->split_tab.clear(); h->split_pending.clear();
         if (off < (size_t(1) << 24)) {           // indices are exact in fp32
+            h->split_record = N16_SPLIT != 0;
             pack_all();
+            h->split_record = false;
             h->h_map.resize(h->h_w.size());
             for (size_t i = 0; i < h->h_w.size(); ++i) h->h_map[i] = (int)h->h_w[i] - 1;      // -1: zero padding
         }
@@ -1729,6 +1782,13 @@ int pf_commit_weights(pf_handle* h) {
         PF_HIP(h, hipMemcpy(h->d_map, h->h_map.data(), h->h_map.size() * sizeof(int), hipMemcpyHostToDevice));
         h->h_map.clear();
         h->h_map.shrink_to_fit();
+    }
+    if (h->d_split_tab) { (void)hipFree(h->d_split_tab); h->d_split_tab = nullptr; }
+    h->n_split_tab = h->split_tab.size();
+    if (h->n_split_tab) {
+        PF_HIP(h, hipMalloc((void**)&h->d_split_tab, h->n_split_tab * sizeof(int4)));
+        PF_HIP(h, hipMemcpy(h->d_split_tab, h->split_tab.data(), h->n_split_tab * sizeof(int4), hipMemcpyHostToDevice));
+        h->split_tab.clear(); h->split_tab.shrink_to_fit();
     }
     for (const GvpOff& o : offs) {
         GvpW g;

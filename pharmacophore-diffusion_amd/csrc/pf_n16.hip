@@ -91,6 +91,47 @@ __device__ __forceinline__ float lane_bcast(const float v, const int L) {
 // orders LDS only: __syncthreads() would also drain the weight ring's outstanding global loads
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- -DN16_SPLIT=1 (pf_device.h): the scalar activations of a block as three bf16 planes, this lane's B operands of the four K chunks
+#if N16_SPLIT
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct N16P { u32x4 b[3][4]; };                      // [plane][chunk]: 8 bf16, element e <-> XS[8 chunk + e]
+__device__ __forceinline__ unsigned bf16_rne(const float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+// x = p0 + p1 + p2 to 24 bits: each plane the round-to-nearest-even bf16 of what the planes before it left over (exact subtractions)
+__device__ __forceinline__ void n16_split8(const float (&x)[8], u32x4 (&o)[3]) {
+    unsigned q[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        q[0][e] = bf16_rne(x[e]);
+        const float r1 = x[e] - __uint_as_float(q[0][e] << 16);
+        q[1][e] = bf16_rne(r1);
+        q[2][e] = bf16_rne(r1 - __uint_as_float(q[1][e] << 16));
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[p][d] = q[p][2 * d] | (q[p][2 * d + 1] << 16);
+}
+__device__ __forceinline__ void n16_split_rows(const float (&XS)[32], N16P& P) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float x[8];
+        u32x4 o[3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = XS[8 * c + e];
+        n16_split8(x, o);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) P.b[p][c] = o[p];
+    }
+}
+#else
+struct N16P {};
+__device__ __forceinline__ void n16_split_rows(const float (&)[32], N16P&) {}
+#endif
+
 // register prefetch ring over a wave's quad stream (the stream is read through a buffer descriptor: scalar base and
 // stream position, the lane's 16 bytes in one vector register -- no per-quad vector address arithmetic)
 struct N16Ring {
@@ -166,6 +207,9 @@ struct __attribute__((aligned(16))) N16Lds {
     float vx[4 * 16 * 48];                    // node updates: the first four vector partial rows of the 16 nodes, one per wave (n16_rows_sum)
     float ln[4 * 128];                        // node updates: the two LayerNorms' weight / bias rows, requested when the item starts (n16_ln_stage)
     float eln[2 * 128];                       // n16_encode_pharm: the encoder LayerNorm's weight / bias rows (requested with the encoder's inputs)
+#if N16_SPLIT
+    unsigned pb[3 * 4 * 64 * 4];              // SiLU outputs as bf16 planes: [plane][chunk = producing wave][lane][4 dwords = 8 bf16]
+#endif
 };
 
 // what the first message GVP of an edge needs besides the source row
@@ -216,9 +260,12 @@ __device__ __forceinline__ void n16_gate_flush(float (&VB)[4], const N16Lds* lds
     n16_gate_apply<true>(G, VB, wq < 3);
 }
 
-template <int KIND, int OFF, bool LAST, bool SIG = true, bool PEND = false>
-__device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float (&VB)[4], const N16In& in, f32x4 (&S)[2],
+//   OUTF32   (-DN16_SPLIT builds; !LAST) the SiLU outputs leave as fp32 rows in XS -- what a caller that is not a block reads (residual,
+//            LayerNorm); false: as bf16 planes in XP, what the next block's main k-steps read.  Without N16_SPLIT: always XS.
+template <int KIND, int OFF, bool LAST, bool SIG = true, bool PEND = false, bool OUTF32 = true>
+__device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], N16P& XP, float (&VB)[4], const N16In& in, f32x4 (&S)[2],
                                           N16Lds* lds, const int lane, const int wq, int& sk, f32x4* gs = nullptr) {
+    constexpr bool PLANES_OUT = N16_SPLIT && !OUTF32 && !LAST;
     constexpr N16Sched Q = n16_sched(KIND);
     static_assert(!PEND || KIND == N16_GEN, "only GEN blocks follow another block of a chain");
     N16_STAMP_B(sk, lane, wq);                                          // block start
@@ -228,22 +275,31 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
     // where the pending gate's sums are requested (two quads in front of the vh quad) and where barrier A and the reads of Vh sit
     // (main quad 11: every wave wrote its Vh long before, sh is formed under the last main k-steps instead of behind them)
     constexpr int Q_GREQ = PEND ? (Q.q_vh >= 2 ? Q.q_vh - 2 : 0) : -1;
-    constexpr int M_A = 11, M_SH = 14;
+    constexpr int M_A = N16_SPLIT ? 16 : 11, M_SH = N16_SPLIT ? 21 : 14;
     const int g = lane >> 4;
     const bool vecw = wq < 3;                                         // wave-uniform
     const bool g0 = g == 0;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, vh = acc0, vu = acc0, gp = acc0;
-    if constexpr (HOIST) { acc0 = S[0]; acc1 = S[1]; }
     f32x4 x1 = acc0, b0 = acc0, gbias = acc0, sh = acc0;
+#if N16_SPLIT
+    f32x4 sacc[2][3];
+#pragma unroll
+    for (int t_ = 0; t_ < 2; ++t_)
+#pragma unroll
+        for (int p_ = 0; p_ < 3; ++p_) sacc[t_][p_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
     f32x4 G[4], va = acc0, vb = acc0, vc = acc0;
     G[0] = acc0; G[1] = acc0; G[2] = acc0; G[3] = acc0;
+    if constexpr (HOIST) { acc0 = S[0]; acc1 = S[1]; }
     float vh16 = 0.f, sh16 = 0.f, x6 = 0.f, y6 = 0.f, z6 = 0.f;
     const float xhc = M0 ? (wq == 0 ? in.xh[0] : (wq == 1 ? in.xh[1] : (wq == 2 ? in.xh[2] : 0.f))) : 0.f;
     static_for<0, Q.nq>([&](auto QI) {
         constexpr int qi = decltype(QI)::value;
         constexpr int mq = Q.main_of(qi);                               // main quad number, or -1
         const f32x4 w = ring.q[(OFF + qi) % N16_D];
+#ifndef N16_PROBE_NOLOAD                              // (diagnostic builds: the ring is never refilled -- what a block costs without its weight stream)
         ring.q[(OFF + qi) % N16_D] = ring.load(qi + N16_D);
+#endif
         if constexpr (PEND && qi == Q_GREQ) n16_gate_request(G, lds, lane);
         if constexpr (qi == Q.q_x1) {
             x1 = w;                                   // [sh16 column tile 0, tile 1, Wu[16][i], Wh[0][i] (lane 16: Wh[0][16])]
@@ -278,11 +334,22 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
                 if (g0) lds->v16[wq * 16 + (lane & 15)] = vh16;
             }
         } else if constexpr (mq >= 0) {
+#if N16_SPLIT
+            // quad mq = 8 bf16 of plane p of the weights (output tile t, K chunk c): it meets planes 0 .. 2 - p of the activations
+            // (one accumulator per activation plane and tile: a 4-pass instruction that waits for the one issued just before it stalls
+            // the wave -- the six of a (chunk, tile) on one accumulator ran no faster than the 8-pass fp32 instructions they replace)
+            constexpr int c = mq / 6, t = (mq / 3) % 2, p = mq % 3;
+            const bf16x8 a = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+            for (int pb = 0; pb + p < 3; ++pb)
+                sacc[t][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, XP.b[pb][c]), sacc[t][pb], 0, 0, 0);
+#else
             constexpr int ks = 2 * mq;
             acc0 = mfma16(w[0], XS[ks], acc0);
             acc1 = mfma16(w[1], XS[ks], acc1);
             acc0 = mfma16(w[2], XS[ks + 1], acc0);
             acc1 = mfma16(w[3], XS[ks + 1], acc1);
+#endif
             if constexpr (!VZ && mq == M_A) {         // barrier A: the three coordinates of Vh are in LDS; their reads travel under the next k-steps
                 N16_STAMP_B(sk, lane, wq);              // main k-steps (mostly) issued
                 lds_barrier();
@@ -323,14 +390,29 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
         } else if constexpr (Q.q_b >= 0 && qi == Q.q_b) {
             b0 = w;
         } else if constexpr (Q.q_b >= 0 && qi == Q.q_b + 1) {
+#if N16_SPLIT
+            S[0] = ((sacc[0][0] + sacc[0][1]) + (sacc[0][2] + acc0)) + b0;
+            S[1] = ((sacc[1][0] + sacc[1][1]) + (sacc[1][2] + acc1)) + w;
+#else
             S[0] = acc0 + b0;
             S[1] = acc1 + w;
+#endif
         } else if constexpr (qi >= Q.q_gate && qi < Q.q_gate + 2) {
             constexpr int t = qi - Q.q_gate;
             if constexpr (t == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { S[0][r] = siluf_(S[0][r]); S[1][r] = siluf_(S[1][r]); }
-                if constexpr (!LAST) {                // the SiLU outputs leave for LDS under the gate k-steps
+                if constexpr (PLANES_OUT) {           // the producer splits its own eight outputs: chunk wq of the next block's K
+#if N16_SPLIT
+                    float x8[8];
+                    u32x4 o3[3];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { x8[r] = S[0][r]; x8[4 + r] = S[1][r]; }
+                    n16_split8(x8, o3);
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<u32x4*>(&lds->pb[((pp * 4 + wq) * 64 + lane) * 4]) = o3[pp];
+#endif
+                } else if constexpr (!LAST) {         // the SiLU outputs leave for LDS under the gate k-steps
                     *reinterpret_cast<f32x4*>(&lds->s[((2 * wq) * 64 + lane) * 4]) = S[0];
                     *reinterpret_cast<f32x4*>(&lds->s[((2 * wq + 1) * 64 + lane) * 4]) = S[1];
                 }
@@ -344,11 +426,20 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
                 lds_barrier();
                 N16_STAMP_B(sk, lane, wq);              // barrier B passed
                 if constexpr (!LAST) {
+                    if constexpr (PLANES_OUT) {
+#if N16_SPLIT
 #pragma unroll
-                    for (int T = 0; T < 8; ++T) {
-                        const f32x4 x = *reinterpret_cast<const f32x4*>(&lds->s[(T * 64 + lane) * 4]);
+                        for (int pp = 0; pp < 3; ++pp)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) XS[4 * T + r] = x[r];
+                            for (int cc = 0; cc < 4; ++cc) XP.b[pp][cc] = *reinterpret_cast<const u32x4*>(&lds->pb[((pp * 4 + cc) * 64 + lane) * 4]);
+#endif
+                    } else {
+#pragma unroll
+                        for (int T = 0; T < 8; ++T) {
+                            const f32x4 x = *reinterpret_cast<const f32x4*>(&lds->s[(T * 64 + lane) * 4]);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) XS[4 * T + r] = x[r];
+                        }
                     }
                     // the gate stays pending: VB = the ungated Vu, the sums wait in lds->g (next block, or n16_gate_flush)
 #pragma unroll
@@ -368,12 +459,17 @@ __device__ __forceinline__ void n16_block(N16Ring& ring, float (&XS)[32], float 
 }
 
 // n GEN blocks in a row, none of them LAST, the first one taking VB as it stands: leaves the last one's gate pending (n > 0)
-template <int OFF>
-__device__ __forceinline__ void n16_gen_run(const int n, N16Ring& ring, float (&XS)[32], float (&VB)[4], const N16In& in, f32x4 (&S)[2],
-                                            N16Lds* lds, const int lane, const int wq, int& sk) {
+// OUTF32: the run's last block leaves fp32 rows in XS (its reader is not a block); false: bf16 planes in XP (N16_SPLIT builds).
+// The run takes its input from XS and splits it itself.
+template <int OFF, bool OUTF32 = true>
+__device__ __forceinline__ void n16_gen_run(const int n, N16Ring& ring, float (&XS)[32], N16P& XP, float (&VB)[4], const N16In& in,
+                                            f32x4 (&S)[2], N16Lds* lds, const int lane, const int wq, int& sk) {
     if (n <= 0) return;
-    n16_block<N16_GEN, OFF, false, true, false>(ring, XS, VB, in, S, lds, lane, wq, sk);
-    for (int gi = 1; gi < n; ++gi) n16_block<N16_GEN, OFF, false, true, true>(ring, XS, VB, in, S, lds, lane, wq, sk);
+    n16_split_rows(XS, XP);
+    if (n == 1) { n16_block<N16_GEN, OFF, false, true, false, OUTF32>(ring, XS, XP, VB, in, S, lds, lane, wq, sk); return; }
+    n16_block<N16_GEN, OFF, false, true, false, false>(ring, XS, XP, VB, in, S, lds, lane, wq, sk);
+    for (int gi = 1; gi + 1 < n; ++gi) n16_block<N16_GEN, OFF, false, true, true, false>(ring, XS, XP, VB, in, S, lds, lane, wq, sk);
+    n16_block<N16_GEN, OFF, false, true, true, OUTF32>(ring, XS, XP, VB, in, S, lds, lane, wq, sk);
 }
 
 // segmented inclusive scan over the 16 rows of an item (one 16-lane DPP row per lane group): rows are sorted by key
@@ -491,9 +587,11 @@ __device__ __forceinline__ void n16_edge_chain(const EdgeParams& p, N16Ring& rin
         }
     }
     N16_STAMP(sk, lane, wq);                              // source rows gathered / encoded (as far as the compiler keeps the order)
-    n16_block<KIND0, 0, false>(ring, XS, VB, in, S, lds, lane, wq, sk);
-    for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false, true, true>(ring, XS, VB, in, S, lds, lane, wq, sk);
-    n16_block<N16_GEN, OFF1, true, true, true>(ring, XS, VB, in, S, lds, lane, wq, sk);
+    N16P XP;
+    if constexpr (KIND0 != N16_M0H) n16_split_rows(XS, XP);
+    n16_block<KIND0, 0, false, true, false, false>(ring, XS, XP, VB, in, S, lds, lane, wq, sk);
+    for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false, true, true, false>(ring, XS, XP, VB, in, S, lds, lane, wq, sk);
+    n16_block<N16_GEN, OFF1, true, true, true>(ring, XS, XP, VB, in, S, lds, lane, wq, sk);
     N16_STAMP(sk, lane, wq);                              // chain done
     // per-destination sums in slot order, one partial row per (item, destination) run
     const SegMask16 sm = seg_masks16(rw.dst, j);
@@ -966,7 +1064,8 @@ __device__ __forceinline__ void n16_node_update_l0(const FusedParams& f, const E
     N16In none{};
     f32x4 S[2];
     S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
-    n16_gen_run<0>(f.n_upd, ring, XS, VB, none, S, lds, lane, wq, sk);
+    N16P XP;
+    n16_gen_run<0>(f.n_upd, ring, XS, XP, VB, none, S, lds, lane, wq, sk);
     n16_gate_flush(VB, lds, lane, wq);
 #pragma unroll
     for (int k = 0; k < 32; ++k) XS[k] += Xr[k];
@@ -1242,7 +1341,8 @@ __device__ __forceinline__ void n16_node_update_last(const TailParams& t, const 
     N16In none{};
     f32x4 S[2];
     S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
-    n16_gen_run<0>(t.n_upd, ring, XS, VB, none, S, lds, lane, wq, sk);
+    N16P XP;
+    n16_gen_run<0>(t.n_upd, ring, XS, XP, VB, none, S, lds, lane, wq, sk);
     n16_gate_flush(VB, lds, lane, wq);
 #pragma unroll
     for (int k = 0; k < 32; ++k) XS[k] += Xr[k];
@@ -1290,9 +1390,10 @@ __global__ __launch_bounds__(256) void k_n16_tail(const int* __restrict__ a_prot
         N16In none{};
         f32x4 S[2], GS = {0.f, 0.f, 0.f, 0.f};
         S[0] = GS; S[1] = GS;
-        n16_gen_run<0>(t.n_head - 1, ring, XS, VB, none, S, &L.n, lane, wq, sk);
-        if (t.n_head > 1) n16_block<N16_GEN, 0, true, false, true>(ring, XS, VB, none, S, &L.n, lane, wq, sk, &GS);
-        else n16_block<N16_GEN, 0, true, false, false>(ring, XS, VB, none, S, &L.n, lane, wq, sk, &GS);
+        N16P XP;
+        n16_gen_run<0, false>(t.n_head - 1, ring, XS, XP, VB, none, S, &L.n, lane, wq, sk);
+        if (t.n_head > 1) n16_block<N16_GEN, 0, true, false, true>(ring, XS, XP, VB, none, S, &L.n, lane, wq, sk, &GS);
+        else { n16_split_rows(XS, XP); n16_block<N16_GEN, 0, true, false, false>(ring, XS, XP, VB, none, S, &L.n, lane, wq, sk, &GS); }
         N16_STAMP(sk, lane, wq);                          // head done
         if (j < nv) {
             if (wq < 3 && g == 0) {                       // gated channel 0 of coordinate wq
@@ -1358,15 +1459,17 @@ __global__ __launch_bounds__(256) void k_n16_unit(const UnitParams p) {
     for (int r = 0; r < 4; ++r) in.rb[r] = msg ? p.s_in[(size_t)row * sw + 128 + 4 * g + r] : 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) in.xh[c] = msg ? p.v_in[(size_t)row * vw + c] : 0.f;
+    N16P XP;
     if (msg) {
         constexpr int OFF1 = n16_sched(N16_M0F).nq % N16_D;
-        n16_block<N16_M0F, 0, false>(ring, XS, VB, in, S, &lds, lane, wq, sk);
-        for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false, true, true>(ring, XS, VB, in, S, &lds, lane, wq, sk);
-        n16_block<N16_GEN, OFF1, true, true, true>(ring, XS, VB, in, S, &lds, lane, wq, sk);
+        n16_split_rows(XS, XP);
+        n16_block<N16_M0F, 0, false, true, false, false>(ring, XS, XP, VB, in, S, &lds, lane, wq, sk);
+        for (int gi = 1; gi + 1 < p.n_gvps; ++gi) n16_block<N16_GEN, OFF1, false, true, true, false>(ring, XS, XP, VB, in, S, &lds, lane, wq, sk);
+        n16_block<N16_GEN, OFF1, true, true, true>(ring, XS, XP, VB, in, S, &lds, lane, wq, sk);
     } else {
-        n16_gen_run<0>(p.n_gvps - 1, ring, XS, VB, in, S, &lds, lane, wq, sk);
-        if (p.n_gvps > 1) n16_block<N16_GEN, 0, true, true, true>(ring, XS, VB, in, S, &lds, lane, wq, sk);
-        else n16_block<N16_GEN, 0, true, true, false>(ring, XS, VB, in, S, &lds, lane, wq, sk);
+        n16_gen_run<0, false>(p.n_gvps - 1, ring, XS, XP, VB, in, S, &lds, lane, wq, sk);
+        if (p.n_gvps > 1) n16_block<N16_GEN, 0, true, true, true>(ring, XS, XP, VB, in, S, &lds, lane, wq, sk);
+        else { n16_split_rows(XS, XP); n16_block<N16_GEN, 0, true, true, false>(ring, XS, XP, VB, in, S, &lds, lane, wq, sk); }
     }
     N16_STAMP(sk, lane, wq);                              // chain done
     if (j < nv) {

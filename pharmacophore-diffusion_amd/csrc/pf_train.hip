@@ -2140,6 +2140,27 @@ __global__ void k_gather_weights(const float* flat, const int* map, const size_t
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const int m = map[i]; packed[i] = m >= 0 ? flat[m] : 0.f; }
 }
+// -DN16_SPLIT builds: the words of the n16 streams that hold two bf16 of one plane of the split weights (pf_host.cpp: pack_n16_raw):
+// tab[i] = (word position in the packed buffer, flat index a, flat index b, plane); -1: a padded weight (zero)
+__global__ void k_n16_split_words(const float* flat, const int4* tab, const size_t n, unsigned int* packed) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 t = tab[i];
+    unsigned int word = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int src = k ? t.z : t.y;
+        float x = src >= 0 ? flat[src] : 0.f;
+        unsigned int bits = 0;
+        for (int p = 0; p <= t.w; ++p) {
+            const unsigned int u = __float_as_uint(x);
+            bits = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+            x -= __uint_as_float(bits << 16);
+        }
+        word |= (bits & 0xffffu) << (16 * k);
+    }
+    packed[t.x] = word;
+}
 // four consecutive entries per thread (map and packed 16-byte aligned): one 16-byte map load, four gathers in flight, one 16-byte store
 __global__ void k_gather_weights4(const float* flat, const int4* map, const size_t n4, float4* packed) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2393,6 +2414,10 @@ void pfk_train_reduce(const ReduceParams* p, hipStream_t s) {
     const int nb_main = main_part ? (p->nparams + 255) / 256 : 0;
     const int nb_enc = enc ? (p->enc_n + 31) / 32 : 0;
     hipLaunchKernelGGL(k_train_reduce<16>, dim3(nb_main + nb_enc), dim3(256), 0, s, *p, nb_main, enc ? 1 : 0);
+}
+void pfk_n16_split_words(const float* flat, const int4* tab, size_t n, float* packed, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_n16_split_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flat, tab, n, reinterpret_cast<unsigned int*>(packed));
 }
 void pfk_gather_weights(const float* flat, const int* map, size_t n, float* packed, hipStream_t s) {
     if (n == 0) return;

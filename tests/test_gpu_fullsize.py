@@ -33,7 +33,7 @@ def _engine(cfg, sd):
 
 def _no_policy_overrides():
     import os
-    assert not [k for k in os.environ if k.startswith("PFDYN_")], "these tests check the DEFAULT launch policy"
+    assert not [k for k in os.environ if k.startswith("PFDYN_") and k != "PFDYN_LIB"], "these tests check the DEFAULT launch policy"      # (PFDYN_LIB: which build of the library, not a policy)
 
 
 def test_config2_batch32_steps_vs_oracle_under_the_default_policy():

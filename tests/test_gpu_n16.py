@@ -326,3 +326,25 @@ def test_exchange_words_canonicalise_an_all_ones_nan():
     torch.cuda.synchronize()
     eng.sample_status()
     assert eng.xchg_timeouts() == 0 and torch.isnan(h).any()
+
+
+def test_split_bf16x6_variant_library_passes_the_chain_and_trajectory_goldens():
+    """libpfdyn_split.so (make split; pf_device.h N16_SPLIT): the n16 blocks' 128-input scalar Linears on bf16 matrix instructions with
+    both operands split into three bf16 planes and fp32 accumulation -- an A/B variant, never the default (profiles/r05/
+    split_bf16x6_ab.txt).  Its claim is fp32-class arithmetic, so it must pass the same tests at the SAME tolerances: here the n16
+    chain tests (reference modules, oracle) and the reference's trajectories, in a child process that loads the variant through
+    PFDYN_LIB.  (The whole n16 / parity / full-size suites passed under it when it was built.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "pharmacophore-diffusion_amd", "csrc", "libpfdyn_split.so")
+    if not os.path.exists(lib):
+        pytest.skip("libpfdyn_split.so has not been built (make -C pharmacophore-diffusion_amd/csrc split)")
+    env = dict(os.environ, PFDYN_LIB=lib)
+    sel = ("test_n16_chain_units_vs_reference_modules or test_n16_every_chain_vs_oracle or test_trajectory_vs_golden or test_bounded_T500 or "
+           "test_fused_launch_arithmetic_tiling or test_dynamics_vs_golden_and_oracle")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_gpu_n16.py"),
+                        os.path.join(root, "tests", "test_gpu_parity.py"), "-k", sel], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout
