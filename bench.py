@@ -317,6 +317,9 @@ def main():
                          "and HIP stream each; 1: skip)")
     ap.add_argument("--train-batches", type=int, default=4,
                     help="--train: number of distinct batches the steps rotate through (1: the same batch every step, no re-bind)")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="--train: bind the NEXT batch on the dynamics' twin handle from a worker thread while a step is enqueued (host time of a "
+                         "step 0.94-1.02 -> 0.70 ms; the device-bound step itself pays ~1.5 %% for the twin's weight refresh, so it is off by default)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the compact objects of the other configurations (config 3, config-4 slice, training step)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
     ap.add_argument("--train-dtype", choices=["f32", "bf16"], default="f32",
@@ -926,6 +929,10 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
         g = graphs[it[0] % len(graphs)]
         it[0] += 1
         loss = m.training_step(g, 0)
+        if len(graphs) > 1 and args.prefetch:
+            # what a data loader's look-ahead allows: the NEXT batch is bound on the twin handle by a worker thread while this
+            # thread enqueues the backward and the optimiser step (models.PharmRecDynamicsGVP.prefetch_graph)
+            m.dynamics.prefetch_graph(graphs[it[0] % len(graphs)])
         loss.backward()
         if world > 1:
             m.dynamics.allreduce_gradients()
@@ -981,6 +988,16 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
     prof = eng.profile_read_train()
     dev_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(K)]
     per_step = step_time_stats(host_s, dev_ms)
+    # what a step costs the HOST when the queue is empty (inside the region the host runs ahead until the queue is full, and its
+    # time per step then mirrors the device's): a few steps with a synchronisation behind each, outside every timed figure
+    idle = []
+    for i in range(12):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step()
+        idle.append(time.perf_counter() - th)
+    barrier()
+    per_step["host_enqueue_idle_queue_ms"] = sorted(idle[2:])[len(idle[2:]) // 2] * 1e3
     host_mean = sum(host_s) / max(len(host_s), 1)
     _, per_rank_host = gather_rank_times(host_mean, world, dev, backend, dist)
     dt, per_rank_s = gather_rank_times(dt, world, dev, backend, dist)
@@ -1004,7 +1021,7 @@ def train_leg(args, pfa, synthetic, dev, rank, world, backend, dist):
             "per_rank_host_enqueue_ms": [v * 1e3 for v in per_rank_host], "per_step": per_step, "host": HOST_SHARE,
             "config": {"workload": f"BASELINE config 5: training step, batch={B} per GPU, {args.n_prot}-atom pockets, centers {lo}-{hi}, "
                                    "dropout 0.1, dev.yml network", "batch_per_gpu": B, "n_prot": args.n_prot,
-                       "distinct_batches": len(graphs),
+                       "distinct_batches": len(graphs), "bind_prefetch": bool(len(graphs) > 1 and args.prefetch),
                        "parallelism": f"data parallel over {world} GPU(s): one all-reduce of the flat gradient per step"},
             "roofline": {"bound": "mfma", "kernel": "k_bwd_edge_level (all levels of a step)", "achieved": ach, "peak": PEAK_F32_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS, "traffic": None, "traffic_detail": "profiles/r03/train_pmc_hbm.csv (rocprofv3 --pmc passes of this command)",

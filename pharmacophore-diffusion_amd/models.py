@@ -248,6 +248,8 @@ class PharmRecDynamicsGVP(nn.Module):
         if self._engine is None or self._engine.device != dev:
             self._engine = PfEngine(device=dev, **self._arch)
             self._engine.set_train_precision(getattr(self, "train_precision", "f32"))
+            self._join_prefetch()
+            self.__dict__["_twin"] = None           # (prefetch_graph makes a new one on this device)
             self._weights_stamp = None
             self._batch_key = None
             self._flat = None
@@ -273,6 +275,10 @@ class PharmRecDynamicsGVP(nn.Module):
         self.train_precision = "bf16" if str(precision).lower() in ("bf16", "bfloat16") else "f32"
         if self._engine is not None:
             self._engine.set_train_precision(self.train_precision)
+        twin = self.__dict__.get("_twin")
+        if twin is not None:
+            self._join_prefetch()
+            twin.set_train_precision(self.train_precision)
 
     def lane_engine(self, lane: int) -> PfEngine:
         """Engine of sampling lane ``lane``: lane 0 is engine(); further lanes are extra handles (own workspace) that carry
@@ -400,17 +406,77 @@ class PharmRecDynamicsGVP(nn.Module):
         to those tensors while they are bound -- so neither CPython nor the caching allocator can hand their addresses
         to another batch (a temporary such as ``training_step(g.to(dev))`` is kept alive until the next bind)."""
         eng = self.engine()
-        static = (g.prot_x if prot_x is None else prot_x, g.prot_h, g.pp_src, g.pp_dst)
-        pptr32, fptr32, src32, dst32 = g.index_arrays_i32()
-        key = (tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in static),
-               pptr32.tobytes(), fptr32.tobytes(),
-               None if g.pocket_uid is None else tuple(g.pocket_uid.tolist()))
+        static, idx, key = self._bind_key(g, prot_x)
         if key != self._batch_key:
-            eng.set_batch(static[0], g.prot_h, pptr32, fptr32, src32, dst32,
-                          pocket_uid=g.pocket_uid if prot_x is None else None)
+            pf = self.__dict__.get("_prefetch")
+            if pf is not None:
+                self._join_prefetch()
+                if pf["key"] == key and prot_x is None:
+                    # the batch is bound already -- on the twin handle, by prefetch_graph's worker while the previous step was being
+                    # enqueued.  The twin becomes THE engine (everything else keeps reading self._engine); it takes the current
+                    # weights with one device-side gather (the optimiser stepped on the other handle since the twin last ran)
+                    self._engine, self._twin = self._twin, self._engine
+                    eng = self._engine
+                    eng.set_flat_params(self._flat)
+                    self._batch_key = key
+                    self._bound_static = pf["static"]
+                    return eng
+            eng.set_batch(static[0], g.prot_h, *idx, pocket_uid=g.pocket_uid if prot_x is None else None)
             self._batch_key = key
             self._bound_static = static
         return eng
+
+    @staticmethod
+    def _bind_key(g: PocketGraph, prot_x=None):
+        static = (g.prot_x if prot_x is None else prot_x, g.prot_h, g.pp_src, g.pp_dst)
+        idx = g.index_arrays_i32()
+        key = (tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in static),
+               idx[0].tobytes(), idx[1].tobytes(),
+               None if g.pocket_uid is None else tuple(g.pocket_uid.tolist()))
+        return static, idx, key
+
+    def prefetch_graph(self, g: PocketGraph) -> None:
+        """Training loops that know their NEXT batch: bind it now, on a second handle (the "twin": own workspace, same weights),
+        from a worker thread -- pf_set_pocket_batch is half a step's host time (the pass over 0.65 M pp edges at 256 pockets, the
+        index tables, the staging copy: ~0.5 ms), and a training step costs the host as much as the device.  Call it once the
+        current step's forward has been issued; the worker's C call runs (GIL released) while this thread enqueues the backward
+        and the optimiser step, and the next bind_graph(g) adopts the twin instead of binding.  Both handles enqueue on the
+        caller's stream, so the device sees the same order of work as without it; results are those of the single-handle loop
+        bit for bit (tests/test_gpu_train.py).  Optional: without the call nothing changes."""
+        import threading
+        g = as_pocket_graph(g)
+        self.engine()
+        self._join_prefetch()
+        static, idx, key = self._bind_key(g)
+        if key == self._batch_key:
+            return
+        twin = self.__dict__.get("_twin")
+        if twin is None or twin.device != self._engine.device:
+            twin = PfEngine(device=self._engine.device, **self._arch)
+            twin.load_state_dict({k: v for k, v in self.state_dict().items()}, prefix="")
+            twin.set_train_precision(getattr(self, "train_precision", "f32"))
+            self.__dict__["_twin"] = twin
+        stream = torch.cuda.current_stream(twin.device)
+        pf = {"key": key, "static": static, "err": None}
+
+        def work():
+            try:
+                with torch.cuda.stream(stream):
+                    twin.set_batch(static[0], g.prot_h, *idx, pocket_uid=g.pocket_uid)
+            except BaseException as e:          # noqa: BLE001  (re-raised by the thread that joins)
+                pf["err"] = e
+        pf["thread"] = threading.Thread(target=work, name="pfdyn-prefetch", daemon=True)
+        self.__dict__["_prefetch"] = pf
+        pf["thread"].start()
+
+    def _join_prefetch(self):
+        pf = self.__dict__.get("_prefetch")
+        if pf is None:
+            return
+        pf["thread"].join()
+        self.__dict__["_prefetch"] = None
+        if pf["err"] is not None:
+            raise pf["err"]
 
     def forward(self, g, timestep: torch.Tensor, batch_idxs: Dict[str, torch.Tensor] = None):
         """(eps_h, eps_x) = dynamics(g, t): reads g.x_t, g.h_t (pharm) and g.prot_x, like the reference

@@ -577,7 +577,8 @@ def test_train_driver_smoke(tmp_path):
     cfg['training'].setdefault('trainer_args', {})['max_epochs'] = 1
     cfg.setdefault('wandb', {})['name'] = 'smoke'
     yaml.dump(cfg, open(tmp_path / "cfg.yml", "w"))
-    r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--config", str(tmp_path / "cfg.yml"), "--seed", "0"],
+    r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--config", str(tmp_path / "cfg.yml"), "--seed", "0",
+                        "--bind_prefetch"],                  # (the look-ahead bind on the twin handle: same results, exercised here)
                        capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "val total loss" in r.stdout
@@ -848,6 +849,56 @@ def test_flat_adam_lazy_clear_equals_the_eager_one():
     want = torch.zeros_like(ref)
     want[off:off + p_reg.numel()] = p_reg.detach().reshape(-1)
     torch.testing.assert_close(got, want, rtol=1e-6, atol=0)
+
+
+def test_bind_prefetch_on_the_twin_handle_equals_the_plain_loop():
+    """PharmRecDynamicsGVP.prefetch_graph: the next batch is bound on a second handle by a worker thread while the current step's
+    backward and optimiser step are enqueued, and the next step adopts that handle.  Six optimiser steps over three rotating
+    batches (different graphs, sizes, pp edges), dropout on: parameters, Adam moments and every step's loss bitwise those of the
+    loop that binds on its own thread; a prefetch that is not used (another batch comes next) and a prefetch of the batch that is
+    already bound are harmless."""
+    cfg = O.DynamicsConfig()
+    parts = [O.synthetic_batch([900 + 7 * k + i for i in range(5)], [40, 52, 33, 61, 47][k % 5:] + [40, 52, 33, 61, 47][:k % 5],
+                               [4 + (i + k) % 4 for i in range(5)], cfg) for k in range(3)]
+    gen = torch.Generator().manual_seed(3)
+
+    def graphs():
+        out = []
+        for b in parts:
+            nf = int(b.pharm_ptr[-1])
+            x0 = torch.randn(nf, 3, generator=torch.Generator().manual_seed(nf))
+            h0 = torch.nn.functional.one_hot(torch.randint(0, 6, (nf,), generator=torch.Generator().manual_seed(nf + 1)), 6).float()
+            out.append(graph_from(b, x0, h0).to("cuda"))
+        return out
+
+    def run(prefetch):
+        m = make_model(100)
+        m.train()
+        gs = graphs()
+        opt = pfa.FlatAdam(m.dynamics, lr=1e-3)
+        losses = []
+        for i in range(6):
+            opt.zero_grad(lazy=True)
+            torch.manual_seed(50 + i)
+            loss = m.training_step(gs[i % 3], i)
+            if prefetch:
+                m.dynamics.prefetch_graph(gs[(i + 1) % 3])
+                if i == 2:
+                    m.dynamics.prefetch_graph(gs[i % 3])           # the batch that is bound already: nothing happens
+                if i == 3:
+                    m.dynamics.prefetch_graph(gs[(i + 2) % 3])     # not the batch that comes next: joined and dropped by the next bind
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        return m, opt, losses
+
+    m0, o0, l0 = run(False)
+    m1, o1, l1 = run(True)
+    assert l0 == l1
+    for (k, a), (_, c) in zip(m0.dynamics.state_dict().items(), m1.dynamics.state_dict().items()):
+        assert torch.equal(a, c), k
+    assert torch.equal(o0.exp_avg, o1.exp_avg) and torch.equal(o0.exp_avg_sq, o1.exp_avg_sq)
+    assert m1.dynamics.__dict__.get("_twin") is not None
 
 
 def test_flat_adam_resumes_from_a_per_parameter_adam_state():
