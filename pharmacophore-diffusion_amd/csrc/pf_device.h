@@ -233,6 +233,10 @@ struct EdgeParams {
     // uni_s2g == 0: off
     int uni_base[3], uni_s01, uni_s2g, uni_pa_groups;
     int ptab16_off[4];     // conv layer 0: float offset of the etype's type table (bias folded in) inside ptab's slot, or -1
+    // conv layer 0, center hoist (CenHoistParams): P rows of the ff ([0]) and fp ([1]) etypes, [2][pcen_nf][128] -- W_et[:, :128] h_c + b_et
+    // for every center c, left by the previous denoising step -- or NULL: the items of those etypes encode their source center
+    // themselves (n16 kind M0Z)
+    const float* pcen; int pcen_nf;
 };
 
 // static-hoist source block in the packed weights (pure copies of the first pp message GVP of conv layer 0 and of the
@@ -247,6 +251,13 @@ struct EdgeParams {
 #define L0H_WHT_PF 21120   // [128 k][128 f]    the pf etype's first message GVP: to_feats_out columns 0..127, k-major
 #define L0H_B_PF 37504     // [128]             ... its bias
 #define L0H_SIZE (37504 + 128)
+// center hoist (pf_cenhoist.h): the first message GVPs of the etypes whose SOURCE is a center (ff, fp) -- to_feats_out columns 0..127
+// (h_src), k-major, and bias -- pure copies like the block above; offsets in floats
+#define L0C_WHT_FF 0       // [128 k][128 f]
+#define L0C_B_FF 16384     // [128]
+#define L0C_WHT_FP 16512   // [128 k][128 f]
+#define L0C_B_FP 32896     // [128]
+#define L0C_SIZE (32896 + 128)
 // type tables of one timestep (k_l0_ptab): L0_NTAB tables of [rec_nf][128]: 0 pp without bias (row-group kernels: the bias
 // sits in zs), 1 pp with bias, 2 pf with bias (n16 kernels), 3 the protein encoder's output itself (the residual input of
 // conv layer 0's node update: n16 fused launch)
@@ -352,6 +363,7 @@ struct FusedParams {
     // every graph's ff / pf region has the same capacity (k_n16_fused_u): first region's start, stride between graphs' regions
     // (ff | pf << 16), 16-slot groups per region (ff | pf << 8); uni_groups == 0: off
     int uni_ff_base, uni_pf_base, uni_strides, uni_groups;
+    const float* hcen;                               // center hoist: the centers' encoder outputs [Nf][128] (residual input of their node update), or NULL
 };
 
 // n16 tail launch (pf_n16.hip: k_n16_tail; pf_denoise_step only): ONE workgroup per graph runs the last conv layer's node
@@ -390,6 +402,7 @@ struct HeadParams {
     // which the graph's update + build workgroup of the SAME launch polls and re-arms.  NULL everywhere else.
     unsigned int* xchg;
     int xchg_fault;        // diagnostic (pf_debug_xchg_fault): 1 = the producers never store word 0 of center 0 -- its consumer times out
+    unsigned int* xchg2;   // center hoist: a second copy of eps_h's words (xchg2[f * PF_XCHG_STRIDE + u]) for the hoist workgroups, or NULL
 };
 #define PF_XCHG_STRIDE 20
 // A NaN pattern the hardware does not generate (its own NaNs are 0x7fc00000 / 0xffc00000) but does PROPAGATE from an input: the
@@ -402,6 +415,26 @@ __device__ __forceinline__ unsigned int pf_xchg_word(const float v) {
     return b == PF_XCHG_EMPTY ? 0x7fc00000u : b;
 }
 #endif
+
+// Center hoist (round 5; k_rg_node_hs_build's third kind of workgroup, pf_cenhoist.h).  Conv layer 0's ff / fp items read their source
+// center through the encoder h_c = LayerNorm(SiLU(W_enc [h_t, t] + b)) (dynamics_gvp.py:107-117, 143-151) and the h_src block of the
+// first message Linear, P_et = W_et[:, :128] h_c + b_et (gvp.py:545-549) -- per EDGE, 3.5 instead of 2.3 blocks per 16-row item, on the
+// conv-layer-0 launch's busiest compute units.  Both are functions of the center alone, and a denoising step knows the NEXT call's
+// timestep (pf_prepare_timesteps): four centers per hoist workgroup take the head's eps_h of THIS step from a second copy of the
+// exchange words, apply the step's feature update (the very expression of the update + build), encode, and leave h_c and P_ff / P_fp in
+// tables -- under the update + build of the same launch, which outlasts them.  The next call's ff / fp items then start from a table
+// row like its pf / pp items (n16 kind M0H), and the fused launch reads the centers' residual input from h_c.
+struct CenHoistParams {
+    int on, Nf, nf;                // nf = pharm_nf
+    float t_next;                  // timestep of the next dynamics call
+    const float* pharm_h;          // [Nf][nf] features BEFORE this step's update (the hoist reads them before the build overwrites them: see pf_cenhoist.h)
+    const float* noise;            // [Nf][3 + nf] this step's draws
+    float a_ts, var, sigma, ep_zt, ep_pred; int ep_feat;
+    const float* enc_w; const float* enc_b; const float* enc_lw; const float* enc_lb;     // pharm encoder ([nf + 1][128] input-major)
+    const float* blk;              // L0C_* block
+    float* cen_h; float* cen_p;    // out: [Nf][128], [2][Nf][128]
+    unsigned int* xchg2;
+};
 
 struct EncodeParams {
     int Np, Nf;
@@ -456,7 +489,19 @@ struct StepParams {
     int nf;
     float a_ts, var, sigma, ep_zt, ep_pred;
     int ep_coord, ep_feat;
+    // center hoist: the updated features ALSO go here (two alternating snapshots: the hoist workgroups of the NEXT step's launch read the
+    // features as they were before that step's update, while its update + build overwrites pharm_h), or NULL
+    float* h_snap_out;
 };
+#ifdef __HIPCC__
+// the feature update of sample_p_zs_given_zt (pharmacodiff.py:414-426) for one value -- ONE body for the update + build and for the
+// center hoist's copy of it, so that both produce the same bits
+__device__ __forceinline__ float pf_feat_update(const float hv, const float e, const float nz, const float a_ts, const float var,
+                                                const float sigma, const float ep_zt, const float ep_pred, const int ep_feat) {
+    const float mu = ep_feat ? (ep_zt * hv + ep_pred * e) : (hv / a_ts - var * e);
+    return mu + sigma * nz;
+}
+#endif
 
 
 struct PreParams {         // protein encoder + pp precompute (encode_pre_tile)

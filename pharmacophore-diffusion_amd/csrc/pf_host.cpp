@@ -35,7 +35,7 @@ void pfk_l0_hoist(const L0HoistParams* p, int what, hipStream_t s);
 void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s);
 void pfk_rg_unit(const UnitParams* p, hipStream_t s);
 void pfk_rg_node_hs_build(const NodeParams* p, const HeadParams* hp, const StepParams* sp, const BuildParams* bp, int* xstat, int poll_sleep,
-                          int avoid, int poll_max, hipStream_t s);
+                          int avoid, int poll_max, const CenHoistParams* cp, hipStream_t s);
 void pfk_n16_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, hipStream_t s);
 void pfk_n16_unit(const UnitParams* p, hipStream_t s);
 void pfk_n16_fused(const EdgeParams* p, const FusedParams* f, const EncodeParams* enc, hipStream_t s);
@@ -311,6 +311,18 @@ struct pf_handle {
     int* xstat_host = nullptr;              // pinned; an async copy of d_xstat follows every sampling run (pf_sample_end)
     int xstat_ack = 0;                      // the count already reported (pf_sample_status / pf_sample_begin / pf_debug_xchg_timeouts)
     int xchg_fault = 0, xchg_poll_max = 0;  // diagnostics (pf_debug_xchg_fault)
+    // center hoist (CenHoistParams; pf_cenhoist.h): M0H streams of conv layer 0's chains for EVERY etype, the L0C block, the per-batch
+    // tables and exchange copy, two alternating snapshots of the centers' features, the announced timestep plan (pf_prepare_timesteps)
+    // that tells a denoising step the NEXT call's t, and what the tables currently hold
+    size_t n16_l0h[4] = {0, 0, 0, 0}, n16_l0h_stride[4] = {0, 0, 0, 0};
+    size_t l0c_off = 0;
+    bool cen_hoist = true;                  // PFDYN_NO_CENTER_HOIST=1: off
+    float *d_cen_h = nullptr, *d_cen_p = nullptr, *d_snap[2] = {nullptr, nullptr};
+    unsigned int* d_xchg2 = nullptr;
+    int snap_cur = -1;                      // which snapshot holds the features as they are now (-1: none)
+    std::vector<float> t_plan; size_t plan_pos = 0;
+    bool cen_valid = false; float cen_t = 0.f; uint64_t cen_wver = 0;
+    bool last_cen = false;                  // the last dynamics call started its ff / fp items from the tables (pf_debug_kernel_family(n_convs + 1))
                                             // when the next one begins: a time-out there is reported, late but never silently
     bool no_fixed_shapes = false;           // PFDYN_NO_FIXED_SHAPES: k_bwd_edge_level reads every level's GVP shape from the table (the A/B of its FX forms)
     ScaleArgs pend_scale{}; bool has_pend_scale = false;    // loss_backward -> pf_train_backward: the unit gradients' scaling, not yet launched
@@ -382,6 +394,7 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_NO_COMPACT")) rg_compact = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_FAST_BUILD")) step_build_fast = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_L0_HOIST")) l0_hoist = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_NO_CENTER_HOIST")) cen_hoist = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_POCKET_SHARE")) share_disable = atoi(e) != 0;
         if (const char* e = getenv("PFDYN_TRAIN_TILE_NODE")) train_rg_node = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_TRAIN_TILE_EDGE")) train_rg_edge = atoi(e) == 0;
@@ -897,7 +910,7 @@ static void pack_n16_head_last(pf_handle* h, const GvpSpec& g, int w, std::vecto
 // keep_ws: the inference workspace stays allocated (pf_set_pocket_batch re-carves it when the next batch fits: a
 // hipMalloc / hipFree pair of a few hundred MB per batch costs milliseconds)
 static void free_ws(pf_handle* h, bool keep_ws = false) {
-    if (h->d_ws && !keep_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; h->d_xchg = nullptr; h->d_lpart = nullptr; }
+    if (h->d_ws && !keep_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; h->d_xchg = nullptr; h->d_lpart = nullptr; h->d_xchg2 = nullptr; h->d_cen_h = h->d_cen_p = nullptr; h->d_snap[0] = h->d_snap[1] = nullptr; }
     if (h->d_tws && !keep_ws) { (void)hipFree(h->d_tws); h->d_tws = nullptr; h->tws_capacity = 0; }
     if (h->d_tA && !keep_ws) { (void)hipFree(h->d_tA); h->d_tA = nullptr; h->tA_capacity = 0; }
     h->t_ws_ready = false;
@@ -1052,6 +1065,9 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                         bool train = false, const StepParams* step = nullptr) {
     const pf_config& c = h->cfg;
     h->tail_done = false; h->last_tail = 0;
+    // center hoist: the previous denoising step left h_c and P_ff / P_fp of every center for THIS call's timestep
+    const bool cen_have = !train && h->cen_valid && h->edges_built && t_scalar != nullptr && *t_scalar == h->cen_t && h->cen_wver == h->w_version;
+    h->cen_valid = false; h->last_cen = false;
     if (!train) n16_refresh(h, s);
     EncodeParams ep{};
     ep.Np = h->Np; ep.Nf = h->Nf;
@@ -1195,6 +1211,11 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 e.ptab16_off[et] = et == ET_PP ? c.rec_nf * PF_S : (et == ET_PF ? 2 * c.rec_nf * PF_S : -1);
             }
             if (l == 0) { e.zs = nullptr; rgp = 4; h->last_hoist = 16; }      // (ptab / ptype / l0_gid were set above)
+            if (l == 0 && cen_have && h->n16_l0h[ET_FF] != 0) {              // ff / fp items start from the center hoist's tables (kind M0H)
+                for (int et : {(int)ET_FF, (int)ET_FP}) { e.n16[et] = h->d_w + h->n16_l0h[et]; e.n16_stride[et] = (int)h->n16_l0h_stride[et]; }
+                e.pcen = h->d_cen_p; e.pcen_nf = h->Nf;
+                h->last_cen = true;
+            }
             e.ngroups_sel = 0;
             for (int r = 0; r < e.nreg; ++r) e.ngroups_sel += region_groups(r, 16);
             // conv layer 0, every graph with ff / pf / fp regions of one capacity: their items are mapped by arithmetic (k_n16_edge_u)
@@ -1229,6 +1250,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
             fz.chain[ET_PF] = h->d_w + h->n16_fused[1]; fz.chain_stride[ET_PF] = (int)h->n16_fused_stride[1];
             fz.upd_pharm = h->d_w + h->n16_upd[(size_t)0 * 2 + 1]; fz.upd_pharm_stride = (int)h->n16_upd_stride;
             fz.htab = l0_ptab + (size_t)3 * c.rec_nf * PF_S; fz.htab_gstride = l0_gstride; fz.ptype = h->d_ptype;
+            fz.hcen = h->last_cen ? h->d_cen_h : nullptr;
             fz.h_out = h->d_h[cur]; fz.v_out = h->d_v[cur];          // (cur was flipped behind conv layer 0: its output side)
             fz.pharm_ptr = h->d_pharm_ptr; fz.Np = h->Np; fz.n_edge_items = e.ngroups_sel;
             for (int r = 0; r < e.nreg; ++r) (r < h->B ? fz.nff_cap : fz.npf_cap) += region_groups(r, 16);
@@ -1353,9 +1375,33 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                                  h->step_build_fast && h->B <= 256 && !(h->prof_mask & (1u << pf_handle::K_STEP)) && h->d_xchg && h->d_xstat;
                 if (hsb) {
                     hp.xchg = h->d_xchg; hp.xchg_fault = h->xchg_fault;
+                    // center hoist for the NEXT call: its timestep from the announced plan (the entry behind this step's t); the tables
+                    // serve a call that runs conv layer 0 on the n16 kernels with the type tables (as this one did); this step's
+                    // features before the update must be in a snapshot (pf_sample_begin / the previous step left it)
+                    CenHoistParams cp{};
+                    float t_next = NAN;
+                    if (h->cen_hoist && t_scalar && !h->t_plan.empty() && h->last_hoist == 16 && h->l0c_off != 0 && h->n16_l0h[ET_FF] != 0 &&
+                        h->snap_cur >= 0 && step->h_snap_out != nullptr && h->d_xchg2 && fuse_l0node) {
+                        const size_t n = h->t_plan.size();
+                        for (size_t k = 0; k < n; ++k) {
+                            const size_t i = (h->plan_pos + k) % n;
+                            if (h->t_plan[i] == *t_scalar) { h->plan_pos = i; if (i + 1 < n) t_next = h->t_plan[i + 1]; break; }
+                        }
+                    }
+                    if (t_next == t_next) {
+                        cp.on = 1; cp.Nf = h->Nf; cp.nf = c.pharm_nf; cp.t_next = t_next;
+                        cp.pharm_h = h->d_snap[h->snap_cur]; cp.noise = step->noise;
+                        cp.a_ts = step->a_ts; cp.var = step->var; cp.sigma = step->sigma; cp.ep_zt = step->ep_zt; cp.ep_pred = step->ep_pred;
+                        cp.ep_feat = step->ep_feat;
+                        cp.enc_w = h->d_w + h->enc_w[1]; cp.enc_b = h->d_w + h->enc_b[1];
+                        cp.enc_lw = h->d_w + h->enc_lw[1]; cp.enc_lb = h->d_w + h->enc_lb[1];
+                        cp.blk = h->d_w + h->l0c_off; cp.cen_h = h->d_cen_h; cp.cen_p = h->d_cen_p; cp.xchg2 = h->d_xchg2;
+                        hp.xchg2 = h->d_xchg2;
+                        h->cen_valid = true; h->cen_t = t_next; h->cen_wver = h->w_version;
+                    }
                     const bool share_next = (h->prune && c.n_convs == 2) && share_now(h);     // what the next denoising step's dynamics call will ask for
                     const BuildParams bpn = build_params(h, share_next);
-                    { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node_hs_build(&n, &hp, step, &bpn, h->d_xstat, h->pol.xchg_sleep, h->pol.hsb_avoid, h->xchg_poll_max, s); }
+                    { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node_hs_build(&n, &hp, step, &bpn, h->d_xstat, h->pol.xchg_sleep, h->pol.hsb_avoid, h->xchg_poll_max, &cp, s); }
                     build_done(h, share_next);
                     h->tail_done = true; h->last_tail = 2;
                 } else { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node(&n, &hp, enc_fly ? &ep : nullptr, l == 0, rgn, nsplit, s); }
@@ -1630,6 +1676,23 @@ int pf_commit_weights(pf_handle* h) {
                 }
             }
             h->l0h_off = push(h->h_w, blk);
+            // center hoist (pf_cenhoist.h): the h_src blocks and biases of the ff / fp etypes' first message GVP, k-major
+            h->l0c_off = 0;
+            if (g.vi == 17 && g.so == PF_S && g.si == PF_S + PF_R && g.vo == 16) {
+                std::vector<float> cb(L0C_SIZE, 0.f);
+                const int Kin = g.si + 17;
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const GvpSpec gc = msg_spec(c, 0, k2 == 0 ? ET_FF : ET_FP, 0);
+                    const std::vector<float>& Wc = h->raw[gc.prefix + "to_feats_out.0.weight"].data;
+                    const std::vector<float>& bc = h->raw[gc.prefix + "to_feats_out.0.bias"].data;
+                    const size_t wo = k2 == 0 ? L0C_WHT_FF : L0C_WHT_FP, bo = k2 == 0 ? L0C_B_FF : L0C_B_FP;
+                    for (int f = 0; f < PF_S; ++f) {
+                        for (int k = 0; k < PF_S; ++k) cb[wo + (size_t)k * PF_S + f] = Wc[(size_t)f * Kin + k];
+                        cb[bo + f] = bc[f];
+                    }
+                }
+                h->l0c_off = push(h->h_w, cb);
+            }
         }
         {   // row-group quad streams, one contiguous stream per chain.  The pharm update chain of the last conv layer
             // comes last and is followed by the noise head's chain and to_scalar_output: the fused node + head kernel
@@ -1716,6 +1779,8 @@ int pf_commit_weights(pf_handle* h) {
             for (int et = 0; et < 4; ++et)
                 h->n16_l0[et] = chain16([&](int j) { return msg_spec(c, 0, et, j); }, c.n_message_gvps,
                                         (et == ET_PP || et == ET_PF) ? N16_M0H : N16_M0Z, h->n16_l0_stride[et]);
+            for (int et = 0; et < 4; ++et)      // center hoist: every etype's chain with a hoisted first block (ff / fp start from P_et rows)
+                h->n16_l0h[et] = chain16([&](int j) { return msg_spec(c, 0, et, j); }, c.n_message_gvps, N16_M0H, h->n16_l0h_stride[et]);
             if (c.n_convs == 2)          // fused launch: conv layer 0's update chain of the source type, then the last layer's message chain
                 for (int k = 0; k < 2; ++k) {
                     const int et = k == 0 ? ET_FF : ET_PF, nt = k == 0 ? 1 : 0;
@@ -1743,7 +1808,7 @@ int pf_commit_weights(pf_handle* h) {
                     st.clear();
                 }
             }
-        } else { h->n16_msg.clear(); h->n16_upd.clear(); h->n16_tail = 0; }
+        } else { h->n16_msg.clear(); h->n16_upd.clear(); h->n16_tail = 0; for (int et = 0; et < 4; ++et) h->n16_l0h[et] = 0; }
         while (h->h_w.size() % 64) h->h_w.push_back(0.f);
     };
     {
@@ -2135,7 +2200,9 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
                  o_eh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_ex = place((size_t)Nf * 3 * 4 + 16), o_c0 = place((size_t)B * 3 * 4), o_c1 = place((size_t)B * 3 * 4),
                  o_pre = place((size_t)std::max(Np, 1) * PF_S * 4), o_eorig = place(Ecap * 4), o_ptype = place((size_t)std::max(Np, 1) * 4),
                  o_zs = place((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4), o_ptpg = place((size_t)B * L0_NTAB * c.rec_nf * PF_S * 4),
-                 o_xchg = place((size_t)std::max(Nf, 1) * PF_XCHG_STRIDE * sizeof(unsigned int));
+                 o_xchg = place((size_t)2 * std::max(Nf, 1) * PF_XCHG_STRIDE * sizeof(unsigned int)),      // (+ the center hoist's copy)
+                 o_cenh = place((size_t)std::max(Nf, 1) * PF_S * 4), o_cenp = place((size_t)2 * std::max(Nf, 1) * PF_S * 4),
+                 o_snap = place((size_t)2 * (std::max(Nf, 1) * c.pharm_nf + 4) * 4);
     const size_t bytes = off;
     bool fresh = false;
     if (h->ws_capacity < bytes + 4096) {
@@ -2188,6 +2255,10 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     h->d_com_init = (float*)at(o_c0); h->d_com_tmp = (float*)at(o_c1); h->d_pre = (float*)at(o_pre); h->d_eorig = (int*)at(o_eorig);
     h->d_ptype = (int*)at(o_ptype); h->d_zs = (float*)at(o_zs); h->d_ptab_pg = (float*)at(o_ptpg);
     h->d_xchg = (unsigned int*)at(o_xchg); h->d_lpart = (float*)at(o_lpart);
+    h->d_xchg2 = h->d_xchg + (size_t)std::max(Nf, 1) * PF_XCHG_STRIDE;
+    h->d_cen_h = (float*)at(o_cenh); h->d_cen_p = (float*)at(o_cenp);
+    h->d_snap[0] = (float*)at(o_snap); h->d_snap[1] = h->d_snap[0] + (size_t)std::max(Nf, 1) * c.pharm_nf + 4;
+    h->cen_valid = false; h->snap_cur = -1;
     mark();      // 2: workspace ready
     // ---- stage the tables in pinned memory and upload them with one asynchronous copy
     const int sb = h->stage_next;
@@ -2500,13 +2571,18 @@ int pf_sample_begin(pf_handle* h, const float* dev_init_pharm_com, const float* 
     hipStream_t s = (hipStream_t)stream;
     // every run starts from armed exchange words, whatever the previous run on the handle left in them (a timed-out row is not
     // re-armed by its consumer, pf_stepbuild.h); stream-ordered like everything else of the run
-    if (h->d_xchg) PF_HIP(h, hipMemsetAsync(h->d_xchg, 0xff, (size_t)std::max(h->Nf, 1) * PF_XCHG_STRIDE * sizeof(unsigned int), s));
+    if (h->d_xchg) PF_HIP(h, hipMemsetAsync(h->d_xchg, 0xff, (size_t)2 * std::max(h->Nf, 1) * PF_XCHG_STRIDE * sizeof(unsigned int), s));
     // init_prot_com = mean of the ORIGINAL protein coordinates (pharmacodiff.py:442)
     pfk_load_coords(h->d_prot_x0, h->d_xn, h->Np, h->d_gid, nullptr, 0.f, s);
     pfk_segment_mean(h->d_xn, h->d_prot_ptr, 0, h->B, h->d_com_init, s);
     const float* shift = dev_init_pharm_com ? dev_init_pharm_com : h->d_com_init;      // :448-452
     pfk_load_coords(h->d_prot_x0, h->d_xn, h->Np, h->d_gid, shift, -1.f, s);
     pfk_load_noise0(dev_noise0, h->d_xn + h->Np, h->d_pharm_h, h->Nf, h->cfg.pharm_nf, s);  // :455-456
+    h->cen_valid = false; h->snap_cur = -1;
+    if (h->cen_hoist && h->d_snap[0] && h->l0c_off != 0) {      // center hoist: the features as they are, for the first step's hoist workgroups
+        pfk_copy(h->d_pharm_h, h->d_snap[0], (size_t)h->Nf * h->cfg.pharm_nf, s);
+        h->snap_cur = 0;
+    }
     h->coords_custom = false;               // a rigid translate of the batch's own coordinates from here on
     h->sampling = true;
     h->edges_built = false;
@@ -2526,8 +2602,14 @@ int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noi
     sp.nf = h->cfg.pharm_nf;
     sp.a_ts = coef->alpha_t_given_s; sp.var = coef->var_terms; sp.sigma = coef->sigma;
     sp.ep_zt = coef->ep_zt; sp.ep_pred = coef->ep_pred; sp.ep_coord = ep_coord; sp.ep_feat = ep_feat;
+    // center hoist: the updated features also go to the snapshot the NEXT step's hoist workgroups read (they must not race with that
+    // step's update of pharm_h); only the paths through pf_stepbuild.h write it
+    const int snap_next = h->snap_cur < 0 ? 0 : (h->snap_cur ^ 1);
+    sp.h_snap_out = (h->cen_hoist && h->d_snap[0] && h->l0c_off != 0) ? h->d_snap[snap_next] : nullptr;
     rc = run_dynamics(h, h->d_eps_h, h->d_eps_x, s, &coef->t, false, &sp);      // every graph of the batch is at the same t
     if (rc) return rc;
+    h->snap_cur = (sp.h_snap_out && h->tail_done && h->last_tail == 2) ? snap_next : -1;
+    if (h->snap_cur < 0) h->cen_valid = false;
     if (h->tail_done) return PF_OK;         // the tail launch did the update and built the next call's edges
     if (encoders_on_the_fly(h)) {           // update + the edges of the next dynamics call in one launch
         const pf_config& cc = h->cfg;
@@ -2546,6 +2628,7 @@ int pf_prepare_timesteps(pf_handle* h, const float* host_t, int32_t n, pf_stream
     int rc = check_ready(h, true);
     if (rc) return rc;
     if (n < 0 || (n && !host_t)) PF_FAIL(h, PF_ERR_ARG, "pf_prepare_timesteps: bad argument");
+    h->t_plan.assign(host_t, host_t + n); h->plan_pos = 0;   // (a denoising step finds the NEXT call's timestep here: center hoist)
     if (n > L0_PTAB_SLOTS - 64) n = L0_PTAB_SLOTS - 64;      // the rest are computed when their steps arrive
     if (l0_hoist_ok(h)) l0_prepare_t(h, host_t, n, (hipStream_t)stream);
     return PF_OK;
@@ -3250,6 +3333,10 @@ int pf_debug_dropout_mask(pf_handle* h, int32_t layer, int32_t which, float drop
 
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave) {
     if (!h || !rows_per_wave) return PF_ERR_ARG;
+    if (layer == (int)h->last_family.size() + 1 && layer > 1) {  // two past: 1 when the last call started conv layer 0's ff / fp items from the center-hoist tables
+        *rows_per_wave = h->last_cen ? 1 : 0;
+        return PF_OK;
+    }
     if (layer == (int)h->last_family.size() && layer > 0) {      // one past the last conv layer: 16 when the last call's head ran in the tail launch
         *rows_per_wave = h->last_tail;
         return PF_OK;
@@ -3415,7 +3502,7 @@ int pf_debug_work(pf_handle* h, double* flops, double* bytes, int64_t* n_edges, 
         // static hoist (last call): the pp edges of layer 0 skip their first message GVP but for its gates
         // (n16 form, last_hoist == 16: the pp AND pf edges skip the h_src block of the first scalar Linear and the Vh matrix product
         // -- a type-table row and 17 x 3 multiplications instead)
-        if (l == 0 && h->last_hoist == 16) ex -= (double)((l == prune_layer ? n_pa : (l == c.n_convs - 1 ? 0 : ne[3])) + ne[1]) * (2.0 * 128 * 128 + 2.0 * 16 * 17 * 3);
+        if (l == 0 && h->last_hoist == 16) ex -= (double)((l == prune_layer ? n_pa : (l == c.n_convs - 1 ? 0 : ne[3])) + ne[1] + (h->last_cen ? ne[0] + ne[2] : 0)) * (2.0 * 128 * 128 + 2.0 * 16 * 17 * 3);
         else if (l == 0 && h->last_hoist) ex -= (double)(l == prune_layer ? n_pa : (l == c.n_convs - 1 ? 0 : ne[3])) * (g0 - 2.0 * 128 * 16);
         if (executed_edges) executed_edges[l] = (int64_t)el;
     }

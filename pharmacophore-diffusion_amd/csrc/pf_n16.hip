@@ -632,10 +632,15 @@ __device__ __forceinline__ void n16_edge_item(const EdgeParams& p, const EncodeP
     f32x4 S[2];
     S[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; S[1] = S[0];
     if constexpr (KIND0 == N16_M0H) {
-        // the h_src block of the first message Linear (+ its bias) is a row of the etype's type table
-        int ty = p.ptype[src] * PF_S + p.ptab16_off[et];
-        if (p.ptab_gstride) ty += p.l0_gid[src] * p.ptab_gstride;
-        pf_gcf tp = (pf_gcf)p.ptab + ty + 32 * wq + 4 * g;
+        // the h_src block of the first message Linear (+ its bias) is a row of a table: of the etype's type table when the source is a
+        // protein atom (pf, pp), of the center hoist's P_et when it is a center (ff, fp; wave-uniform choice)
+        pf_gcf tp;
+        if (et == ET_PP || et == ET_PF) {
+            int ty = p.ptype[src] * PF_S + p.ptab16_off[et];
+            if (p.ptab_gstride) ty += p.l0_gid[src] * p.ptab_gstride;
+            tp = (pf_gcf)p.ptab + ty;
+        } else tp = (pf_gcf)p.pcen + ((size_t)(et == ET_FP ? p.pcen_nf : 0) + (size_t)(src - ep.Np)) * PF_S;
+        tp += 32 * wq + 4 * g;
         S[0] = *reinterpret_cast<const f32x4 PF_AS1*>(tp);
         S[1] = *reinterpret_cast<const f32x4 PF_AS1*>(tp + 16);
     }
@@ -756,7 +761,7 @@ __global__ __launch_bounds__(256) void k_n16_edge(const int* __restrict__ a_dyn_
         }
         const int e = e0 + min(lane & 15, nv - 1);
         const int src = p.esrc[e], dst = p.edst[e];
-        if (et == ET_PP || et == ET_PF) n16_edge_item<N16_M0H>(p, ep, &lds, e, src, dst, nv, et, lane, wq, sk);
+        if (et == ET_PP || et == ET_PF || p.pcen) n16_edge_item<N16_M0H>(p, ep, &lds, e, src, dst, nv, et, lane, wq, sk);
         else n16_edge_item<N16_M0Z>(p, ep, &lds, e, src, dst, nv, et, lane, wq, sk);
     } else {
         const int e = e0 + min(lane & 15, nv - 1);
@@ -803,7 +808,7 @@ __global__ __launch_bounds__(256) void k_n16_edge_u(const int* __restrict__ a_dy
         const int jj = min(j, nv - 1);
         const int from = 4 * ((lane & 48) | jj);
         const int src = __builtin_amdgcn_ds_bpermute(from, src_raw), dst = __builtin_amdgcn_ds_bpermute(from, dst_raw);
-        if (et == ET_PF) n16_edge_item<N16_M0H>(p, ep, &lds, e0 + jj, src, dst, nv, et, lane, wq, sk);
+        if (et == ET_PF || p.pcen) n16_edge_item<N16_M0H>(p, ep, &lds, e0 + jj, src, dst, nv, et, lane, wq, sk);
         else n16_edge_item<N16_M0Z>(p, ep, &lds, e0 + jj, src, dst, nv, et, lane, wq, sk);
         return;
     }
@@ -1034,9 +1039,16 @@ __device__ __forceinline__ void n16_node_update_l0(const FusedParams& f, const E
     float inv_norm = 1.0f;
     if (f.norm_mode == 1) inv_norm = 1.0f / f.norm_value;
     else if (f.norm_mode == 2) inv_norm = 1.0f / f.gnorm[nt * f.B + f.gid[node]];
-    // a center's residual input is encoded on the fly (its own exchange through lds->s, closed by a barrier), under the row loads
+    // a center's residual input: a row of the center hoist's table (this wave's quarter, with the row loads), or encoded on the fly
+    // (its own exchange through lds->s, closed by a barrier) under the row loads
     float H[32];
-    if (nt != 0) {
+    const bool enc_here = nt != 0 && f.hcen == nullptr;                 // workgroup-uniform
+    if (nt != 0 && f.hcen != nullptr) {
+        pf_gcf hp = (pf_gcf)f.hcen + (size_t)(node - ep.Np) * PF_S + 32 * wq + 4 * g;
+        Hq[0] = *reinterpret_cast<const f32x4 PF_AS1*>(hp);
+        Hq[1] = *reinterpret_cast<const f32x4 PF_AS1*>(hp + 16);
+    }
+    if (enc_here) {
         const float tt = ep.t ? ((pf_gcf)ep.t)[f.gid[node]] : ep.t_scalar;
         n16_encode_pharm(ep, (pf_gcf)ep.pharm_h + (size_t)(node - ep.Np) * ep.pharm_nf, tt, H, lds, lane, wq);
     }
@@ -1048,7 +1060,7 @@ __device__ __forceinline__ void n16_node_update_l0(const FusedParams& f, const E
     for (int r = 0; r < 4; ++r) { Q[0][r] = fmaf(Q[0][r], inv_norm, Hq[0][r]); Q[1][r] = fmaf(Q[1][r], inv_norm, Hq[1][r]); }
     n16_ln_stage(lnq, lds, lane, wq);                    // (in front of the exchange's barrier)
     n16_quarters_to_rows(Q, XS, lds, lane, wq);          // (the first LayerNorm's barrier closes the reads)
-    if (nt != 0) {
+    if (enc_here) {
 #pragma unroll
         for (int k = 0; k < 32; ++k) XS[k] += H[k];
     }

@@ -310,9 +310,9 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
 #pragma unroll
         for (int k = 0; k < SB_MAXNF; ++k) {
             if (k < sp.nf) {
-                const float hv = q.hv[k], e = eh[k];
-                const float mu = sp.ep_feat ? (sp.ep_zt * hv + sp.ep_pred * e) : (hv / sp.a_ts - sp.var * e);
-                sp.pharm_h[(size_t)(f0 + tid) * sp.nf + k] = mu + sp.sigma * q.nzh[k];
+                const float hn = pf_feat_update(q.hv[k], eh[k], q.nzh[k], sp.a_ts, sp.var, sp.sigma, sp.ep_zt, sp.ep_pred, sp.ep_feat);
+                sp.pharm_h[(size_t)(f0 + tid) * sp.nf + k] = hn;
+                if (sp.h_snap_out) sp.h_snap_out[(size_t)(f0 + tid) * sp.nf + k] = hn;
             }
         }
     }

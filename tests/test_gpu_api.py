@@ -66,7 +66,7 @@ def test_an_invalid_trajectory_is_never_returned():
     eng.xchg_fault(False)
     again = m.sample_given_receptor(g, noise=z["noise"])
     assert eng.kernel_family(2) == 0
-    torch.testing.assert_close(again[0].ph_coords, good[0].ph_coords, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(again[0].ph_coords, good[0].ph_coords, rtol=5e-3, atol=5e-3)
     torch.testing.assert_close(again[0].ph_coords, z["x0"], rtol=5e-3, atol=5e-3)
 
 

@@ -527,6 +527,7 @@ def test_fused_update_and_edge_build_variants_agree(case, monkeypatch):
     reproduce the generic bodies (PFDYN_NO_FAST_BUILD=1: k_step_build) and the separate launches of the tile-kernel
     path bit for bit: same edge sets, same orderings, same arithmetic -- ragged batch, several steps.  (The optional tail
     launch, which runs the same fast body behind the node update + head: test_gpu_n16.py::test_tail_launch_steps_equal_separate_launches.)"""
+    monkeypatch.setenv("PFDYN_NO_CENTER_HOIST", "1")       # (only the merged launch leaves the center-hoist tables: its own test compares them)
     kw = dict(ff_k=3) if case == "knn_ff" else (dict(message_norm=0) if case == "graph_norm" else {})
     cfg = O.DynamicsConfig(**kw)
     sd = O.make_state_dict(cfg, 3)
@@ -655,10 +656,11 @@ def test_static_hoist_follows_coordinates_weights_and_features():
     close(eh, oh); close(ex, ox)
 
 
-def test_static_hoist_type_tables_announced_or_on_arrival():
+def test_static_hoist_type_tables_announced_or_on_arrival(monkeypatch):
     """The per-timestep type tables of the static hoist: announced by pf_sample (several launches of 64 timesteps),
     computed on arrival by un-announced pf_denoise_step calls, announced by the caller (pf_prepare_timesteps) -- the
     three give bitwise the same trajectory, and the same as a handle that saw other timesteps before."""
+    monkeypatch.setenv("PFDYN_NO_CENTER_HOIST", "1")       # (the center hoist also reads the announced plan and changes the summation order of the calls it serves)
     cfg = O.DynamicsConfig()
     sd = O.make_state_dict(cfg, 0)
     batch = O.synthetic_batch([7, 8, 9], 96, [3, 5, 4], cfg)
