@@ -237,6 +237,13 @@ struct EdgeParams {
     // for every center c, left by the previous denoising step -- or NULL: the items of those etypes encode their source center
     // themselves (n16 kind M0Z)
     const float* pcen; int pcen_nf;
+    // conv layer 0 inside a sampling run: the protein moves rigidly, so a pp edge's geometry comes from the batch's ORIGINAL coordinates
+    // ([Np][3], never written) instead of the per-step shifted copy -- the same bits in every step, and no race with the update + build
+    // that shifts xn while speculative pp items of the next call read it.  NULL: xn (pf_dynamics_forward with other coordinates).
+    const float* x0_static;
+    // [B] or NULL: graphs whose "pa" region this launch skips -- their partial rows were computed ahead (k_n16_pa_spec) and the previous
+    // step's build found the region unchanged (BuildParams::pa_same)
+    const int* pa_skip;
 };
 
 // static-hoist source block in the packed weights (pure copies of the first pp message GVP of conv layer 0 and of the
@@ -478,6 +485,13 @@ struct BuildParams {
                            // (dynamics_gvp.py:220 looks center indices up in the protein batch vector); used instead of
                            // the true counts by the per-graph normalisers
     int norm_mode;
+    // speculative "pa" messages (round 5; EdgeParams::pa_skip, k_n16_pa_spec): conv layer 0's messages along the pp edges into the active
+    // atoms depend on the timestep, the element types and the STATIC pocket geometry only -- not on the centers -- so the NEXT call's
+    // can be computed while this step's latency-bound last launch runs, for the active atoms of THIS call; they are the next call's if its
+    // "pa" region comes out the same.  The build says so per graph: pa_stamp[atom] = step_id for every active atom; an atom counts as
+    // unchanged if it carried step_id - 1 and its slot-2 in-edge range is the one it had; pa_same[g] = 1 iff no atom of graph g changed
+    // (none joined, none left, none moved).  NULL: off.
+    int* pa_stamp; int step_id; int* pa_same;
 };
 
 struct StepParams {

@@ -35,7 +35,8 @@ void pfk_l0_hoist(const L0HoistParams* p, int what, hipStream_t s);
 void pfk_rg_node(const NodeParams* p, const HeadParams* hp, const EncodeParams* enc, int layer0, int rg, int split, hipStream_t s);
 void pfk_rg_unit(const UnitParams* p, hipStream_t s);
 void pfk_rg_node_hs_build(const NodeParams* p, const HeadParams* hp, const StepParams* sp, const BuildParams* bp, int* xstat, int poll_sleep,
-                          int avoid, int poll_max, const CenHoistParams* cp, hipStream_t s);
+                          int avoid, int poll_max, const CenHoistParams* cp, const EdgeParams* es, const EncodeParams* ees, int spec_groups,
+                          hipStream_t s);
 void pfk_n16_edge(const EdgeParams* p, const EncodeParams* enc, int layer0, hipStream_t s);
 void pfk_n16_unit(const UnitParams* p, hipStream_t s);
 void pfk_n16_fused(const EdgeParams* p, const FusedParams* f, const EncodeParams* enc, hipStream_t s);
@@ -323,6 +324,15 @@ struct pf_handle {
     std::vector<float> t_plan; size_t plan_pos = 0;
     bool cen_valid = false; float cen_t = 0.f; uint64_t cen_wver = 0;
     bool last_cen = false;                  // the last dynamics call started its ff / fp items from the tables (pf_debug_kernel_family(n_convs + 1))
+    // speculative "pa" messages (BuildParams::pa_same, k_n16_pa_spec): a side stream, the events that order it against the caller's
+    // stream, a per-handle step counter (never reset: stamps of an earlier trajectory must not look recent), the conv-layer-0 launch's
+    // parameters of the current call, and what the rows computed ahead are for
+    bool pa_spec = true;                    // PFDYN_NO_PA_SPEC=1: off
+    bool spec_valid = false; float spec_t = 0.f; uint64_t spec_wver = 0;
+    int step_id = 2;
+    int *d_pa_stamp = nullptr, *d_pa_same = nullptr;
+    bool e0_saved = false; EdgeParams e0{}; EncodeParams ep0{}; int e0_groups = 0;
+    int last_spec = 0;                      // the last dynamics call skipped "pa" regions computed ahead (pf_debug_kernel_family(n_convs + 2): 1)
                                             // when the next one begins: a time-out there is reported, late but never silently
     bool no_fixed_shapes = false;           // PFDYN_NO_FIXED_SHAPES: k_bwd_edge_level reads every level's GVP shape from the table (the A/B of its FX forms)
     ScaleArgs pend_scale{}; bool has_pend_scale = false;    // loss_backward -> pf_train_backward: the unit gradients' scaling, not yet launched
@@ -395,6 +405,7 @@ struct pf_handle {
         if (const char* e = getenv("PFDYN_NO_FAST_BUILD")) step_build_fast = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_L0_HOIST")) l0_hoist = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_CENTER_HOIST")) cen_hoist = atoi(e) == 0;
+        if (const char* e = getenv("PFDYN_NO_PA_SPEC")) pa_spec = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_NO_POCKET_SHARE")) share_disable = atoi(e) != 0;
         if (const char* e = getenv("PFDYN_TRAIN_TILE_NODE")) train_rg_node = atoi(e) == 0;
         if (const char* e = getenv("PFDYN_TRAIN_TILE_EDGE")) train_rg_edge = atoi(e) == 0;
@@ -910,7 +921,7 @@ static void pack_n16_head_last(pf_handle* h, const GvpSpec& g, int w, std::vecto
 // keep_ws: the inference workspace stays allocated (pf_set_pocket_batch re-carves it when the next batch fits: a
 // hipMalloc / hipFree pair of a few hundred MB per batch costs milliseconds)
 static void free_ws(pf_handle* h, bool keep_ws = false) {
-    if (h->d_ws && !keep_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; h->d_xchg = nullptr; h->d_lpart = nullptr; h->d_xchg2 = nullptr; h->d_cen_h = h->d_cen_p = nullptr; h->d_snap[0] = h->d_snap[1] = nullptr; }
+    if (h->d_ws && !keep_ws) { (void)hipFree(h->d_ws); h->d_ws = nullptr; h->ws_capacity = 0; h->d_xchg = nullptr; h->d_lpart = nullptr; h->d_xchg2 = nullptr; h->d_cen_h = h->d_cen_p = nullptr; h->d_snap[0] = h->d_snap[1] = nullptr; h->d_pa_stamp = h->d_pa_same = nullptr; }
     if (h->d_tws && !keep_ws) { (void)hipFree(h->d_tws); h->d_tws = nullptr; h->tws_capacity = 0; }
     if (h->d_tA && !keep_ws) { (void)hipFree(h->d_tA); h->d_tA = nullptr; h->tA_capacity = 0; }
     h->t_ws_ready = false;
@@ -972,6 +983,7 @@ static BuildParams build_params(pf_handle* h, bool share = false) {
     bp.ff_k = c.ff_k; bp.pf_k = c.pf_k;
     bp.r2_ff = c.cutoff_ff * c.cutoff_ff; bp.r2_pf = c.cutoff_pf * c.cutoff_pf;
     bp.gnorm = h->d_gnorm; bp.pp_cnt = h->d_pp_cnt; bp.pfq_cnt = h->d_pfq_cnt; bp.norm_mode = c.message_norm_mode;
+    if (h->pa_spec && h->sampling && h->d_pa_stamp && !share) { bp.pa_stamp = h->d_pa_stamp; bp.step_id = h->step_id; bp.pa_same = h->d_pa_same; }
     const int prune_layer = (h->prune && c.n_convs >= 2) ? c.n_convs - 2 : -1;
     bp.act_ids = prune_layer >= 0 ? h->d_act_ids : nullptr; bp.reg_act = h->d_reg_act;
     bp.eorig = h->d_eorig;
@@ -1068,6 +1080,9 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
     // center hoist: the previous denoising step left h_c and P_ff / P_fp of every center for THIS call's timestep
     const bool cen_have = !train && h->cen_valid && h->edges_built && t_scalar != nullptr && *t_scalar == h->cen_t && h->cen_wver == h->w_version;
     h->cen_valid = false; h->last_cen = false;
+    // rows computed ahead for this call's "pa" regions (the speculative items of the previous step's merged launch)
+    const bool spec_have = !train && h->spec_valid && h->edges_built && t_scalar != nullptr && *t_scalar == h->spec_t && h->spec_wver == h->w_version;
+    h->spec_valid = false; h->last_spec = 0; h->e0_saved = false;
     if (!train) n16_refresh(h, s);
     EncodeParams ep{};
     ep.Np = h->Np; ep.Nf = h->Nf;
@@ -1211,6 +1226,13 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 e.ptab16_off[et] = et == ET_PP ? c.rec_nf * PF_S : (et == ET_PF ? 2 * c.rec_nf * PF_S : -1);
             }
             if (l == 0) { e.zs = nullptr; rgp = 4; h->last_hoist = 16; }      // (ptab / ptype / l0_gid were set above)
+            if (l == 0 && step != nullptr && h->sampling && !h->coords_custom) {
+                // a sampling run: pp geometry from the original coordinates (the same bits in every step, with or without the rows
+                // computed ahead; no race with the build that shifts xn under the speculative items)
+                e.x0_static = h->d_prot_x0;
+                // "pa" regions whose rows were computed ahead (k_n16_pa_spec) and still apply are skipped
+                if (spec_have && h->pa_spec && !shared && h->B <= 64 && !e.need) { e.pa_skip = h->d_pa_same; h->last_spec = 1; }
+            }
             if (l == 0 && cen_have && h->n16_l0h[ET_FF] != 0) {              // ff / fp items start from the center hoist's tables (kind M0H)
                 for (int et : {(int)ET_FF, (int)ET_FP}) { e.n16[et] = h->d_w + h->n16_l0h[et]; e.n16_stride[et] = (int)h->n16_l0h_stride[et]; }
                 e.pcen = h->d_cen_p; e.pcen_nf = h->Nf;
@@ -1239,6 +1261,11 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 }
             }
             rg = 4;                                  // 16 slots per partial-row group
+            if (l == 0 && e.x0_static && h->pa_spec && !shared && h->B <= 64 && !e.need) {      // what k_n16_pa_spec needs of this launch (the regions, streams and tables of conv layer 0)
+                h->e0 = e; h->ep0 = ep; h->e0_saved = true;
+                h->e0_groups = 0;
+                for (int g = 0; g < h->B; ++g) h->e0_groups += region_groups(3 * h->B + g, 16);
+            }
         }
         h->last_family.resize(c.n_convs);
         h->last_family[l] = rg ? 4 * rg : ((!train && e.ntiles <= ((last || pruned) ? std::max(h->pol.coop_edge_max, h->pol.coop2_edge_max) : std::max(h->pol.coop_edge_max, h->pol.coop2_dense_max))) ? 128 : 32);
@@ -1274,8 +1301,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                 }
             }
             h->last_family[l] = 17;                      // pf_debug_kernel_family: 16-row items with conv layer 0's node update in front
-            ProfScope ps(h, pf_handle::K_EDGE_LAST, s);
-            pfk_n16_fused(&e, &fz, &ep, s);
+            { ProfScope ps(h, pf_handle::K_EDGE_LAST, s); pfk_n16_fused(&e, &fz, &ep, s); }
         }
         else if (n16e) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_n16_edge(&e, &ep, l == 0, s); }
         else if (rg) { ProfScope ps(h, (last && c.n_convs > 1) ? pf_handle::K_EDGE_LAST : pf_handle::K_EDGE_COOP, s); pfk_rg_edge(&e, enc_fly ? &ep : nullptr, l == 0, rg, esplit, rgp, s); }
@@ -1388,6 +1414,30 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                             if (h->t_plan[i] == *t_scalar) { h->plan_pos = i; if (i + 1 < n) t_next = h->t_plan[i + 1]; break; }
                         }
                     }
+                    // ---- the NEXT call's "pa" messages, ahead of time, as workgroups of this launch (BuildParams::pa_same): conv layer 0's rows
+                    // of this call have been consumed by the fused launch, the next timestep's type tables exist (or are made now)
+                    EdgeParams es{};
+                    EncodeParams ees{};
+                    int spec_groups = 0;
+                    if (h->e0_saved && h->pa_spec && !h->t_plan.empty() && t_scalar && h->d_pa_stamp && !(h->prune && c.n_convs == 2 && share_now(h))) {
+                        float tn = NAN;
+                        const size_t n = h->t_plan.size();
+                        for (size_t k = 0; k < n; ++k) {
+                            const size_t i = (h->plan_pos + k) % n;
+                            if (h->t_plan[i] == *t_scalar) { if (i + 1 < n) tn = h->t_plan[i + 1]; break; }
+                        }
+                        if (tn == tn) {
+                            l0_prepare_t(h, &tn, 1, s);                  // (a no-op when the plan was announced)
+                            uint32_t bits; memcpy(&bits, &tn, 4);
+                            es = h->e0;
+                            es.ptab = h->d_ptab + (size_t)h->ptab_slot[bits] * L0_NTAB * c.rec_nf * PF_S;
+                            es.pa_skip = nullptr; es.pcen = nullptr;
+                            for (int et = 0; et < 4; ++et) { es.n16[et] = h->d_w + h->n16_l0[et]; es.n16_stride[et] = (int)h->n16_l0_stride[et]; }
+                            ees = h->ep0; ees.t_scalar = tn;
+                            spec_groups = h->e0_groups;
+                            h->spec_valid = true; h->spec_t = tn; h->spec_wver = h->w_version;
+                        }
+                    }
                     if (t_next == t_next) {
                         cp.on = 1; cp.Nf = h->Nf; cp.nf = c.pharm_nf; cp.t_next = t_next;
                         cp.pharm_h = h->d_snap[h->snap_cur]; cp.noise = step->noise;
@@ -1401,7 +1451,7 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                     }
                     const bool share_next = (h->prune && c.n_convs == 2) && share_now(h);     // what the next denoising step's dynamics call will ask for
                     const BuildParams bpn = build_params(h, share_next);
-                    { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node_hs_build(&n, &hp, step, &bpn, h->d_xstat, h->pol.xchg_sleep, h->pol.hsb_avoid, h->xchg_poll_max, &cp, s); }
+                    { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node_hs_build(&n, &hp, step, &bpn, h->d_xstat, h->pol.xchg_sleep, h->pol.hsb_avoid, h->xchg_poll_max, &cp, &es, &ees, spec_groups, s); }
                     build_done(h, share_next);
                     h->tail_done = true; h->last_tail = 2;
                 } else { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node(&n, &hp, enc_fly ? &ep : nullptr, l == 0, rgn, nsplit, s); }
@@ -2186,7 +2236,8 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     // zero section (cleared with one launch per bind)
     const size_t o_dyn = place((size_t)5 * B * 4), o_act = place((size_t)(act_total + 1) * 4), o_flag = place(256), o_gnorm = place((size_t)2 * B * 4),
                  o_need = place((size_t)std::max(Np, 1) * 4),
-                 o_lpart = place(64 + (size_t)((Nf + 63) / 64) * 8 * sizeof(float));       // k_loss_eval's ticket (re-armed by its last block) + partial sums
+                 o_lpart = place(64 + (size_t)((Nf + 63) / 64) * 8 * sizeof(float)),       // k_loss_eval's ticket (re-armed by its last block) + partial sums
+                 o_pastamp = place((size_t)std::max(Np, 1) * 4), o_pasame = place((size_t)B * 4);      // speculative "pa" messages: per-atom step stamps, per-graph verdicts
     const size_t zero_bytes = off;
     // scratch
     // (a second set of message rows for the last conv layer: the fused launch of small n_convs = 2 batches writes them while conv
@@ -2259,6 +2310,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     h->d_cen_h = (float*)at(o_cenh); h->d_cen_p = (float*)at(o_cenp);
     h->d_snap[0] = (float*)at(o_snap); h->d_snap[1] = h->d_snap[0] + (size_t)std::max(Nf, 1) * c.pharm_nf + 4;
     h->cen_valid = false; h->snap_cur = -1;
+    h->d_pa_stamp = (int*)at(o_pastamp); h->d_pa_same = (int*)at(o_pasame); h->spec_valid = false; h->e0_saved = false;
     mark();      // 2: workspace ready
     // ---- stage the tables in pinned memory and upload them with one asynchronous copy
     const int sb = h->stage_next;
@@ -2579,6 +2631,7 @@ int pf_sample_begin(pf_handle* h, const float* dev_init_pharm_com, const float* 
     pfk_load_coords(h->d_prot_x0, h->d_xn, h->Np, h->d_gid, shift, -1.f, s);
     pfk_load_noise0(dev_noise0, h->d_xn + h->Np, h->d_pharm_h, h->Nf, h->cfg.pharm_nf, s);  // :455-456
     h->cen_valid = false; h->snap_cur = -1;
+    h->spec_valid = false; h->step_id += 2;      // (a gap: no stamp of the run before reads as "the previous step")
     if (h->cen_hoist && h->d_snap[0] && h->l0c_off != 0) {      // center hoist: the features as they are, for the first step's hoist workgroups
         pfk_copy(h->d_pharm_h, h->d_snap[0], (size_t)h->Nf * h->cfg.pharm_nf, s);
         h->snap_cur = 0;
@@ -2604,6 +2657,7 @@ int pf_denoise_step(pf_handle* h, const pf_step_coef* coef, const float* dev_noi
     sp.ep_zt = coef->ep_zt; sp.ep_pred = coef->ep_pred; sp.ep_coord = ep_coord; sp.ep_feat = ep_feat;
     // center hoist: the updated features also go to the snapshot the NEXT step's hoist workgroups read (they must not race with that
     // step's update of pharm_h); only the paths through pf_stepbuild.h write it
+    ++h->step_id;
     const int snap_next = h->snap_cur < 0 ? 0 : (h->snap_cur ^ 1);
     sp.h_snap_out = (h->cen_hoist && h->d_snap[0] && h->l0c_off != 0) ? h->d_snap[snap_next] : nullptr;
     rc = run_dynamics(h, h->d_eps_h, h->d_eps_x, s, &coef->t, false, &sp);      // every graph of the batch is at the same t
@@ -3333,6 +3387,10 @@ int pf_debug_dropout_mask(pf_handle* h, int32_t layer, int32_t which, float drop
 
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave) {
     if (!h || !rows_per_wave) return PF_ERR_ARG;
+    if (layer == (int)h->last_family.size() + 2 && layer > 2) {  // three past: 1 when the last call skipped "pa" regions whose rows had been computed ahead
+        *rows_per_wave = h->last_spec;
+        return PF_OK;
+    }
     if (layer == (int)h->last_family.size() + 1 && layer > 1) {  // two past: 1 when the last call started conv layer 0's ff / fp items from the center-hoist tables
         *rows_per_wave = h->last_cen ? 1 : 0;
         return PF_OK;

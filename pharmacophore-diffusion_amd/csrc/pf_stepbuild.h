@@ -168,6 +168,7 @@ struct __attribute__((aligned(16))) StepBuildLds {
     // static sources of EVERY atom (prefetched, indexed by atom)
     unsigned short owner[SB_MAXA * 16];         // [slot of the region] -> atom (local index)
     int a_d0[SB_MAXA], a_pst[SB_MAXA];          // per atom: first slot of its in-edges in the region, static in-edge start
+    int chg;                                    // BuildParams::pa_same: set by any atom whose place in the "pa" region changed
     __attribute__((aligned(16))) int a_src[SB_MAXA][16];
 };
 
@@ -194,6 +195,7 @@ struct SbPre {
     float nzx[3];
     float hv[SB_MAXNF], nzh[SB_MAXNF];              // the center's features and their noise (threads tid < Nf; nf <= SB_MAXNF)
     int pst[APT], pdeg[APT], psrc[APT][16];
+    int ost[APT], ocn[APT], ostamp[APT];            // BuildParams::pa_same: the atom's slot-2 range and stamp as the previous step left them
 };
 // (A) the graph's pointers and regions (scalar loads)
 template <int NT>
@@ -247,6 +249,10 @@ __device__ __forceinline__ void sb_load_b(SbPre<NT>& q, const int a_Np_tot, cons
             const int s0 = in_start1[arow], d0 = in_cnt1[arow];
             q.pst[a] = q.isp[a] ? s0 : 0;
             q.pdeg[a] = q.isp[a] ? d0 : 0;
+        }
+        q.ost[a] = 0; q.ocn[a] = 0; q.ostamp[a] = 0;
+        if (p.pa_stamp) {                                             // kernel-uniform
+            q.ost[a] = p.in_start[2 * p.N + arow]; q.ocn[a] = p.in_cnt[2 * p.N + arow]; q.ostamp[a] = p.pa_stamp[arow];
         }
     }
 }
@@ -305,6 +311,7 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
 #pragma unroll
     for (int a = 0; a < APT; ++a) { isp[a] = q.isp[a]; xp[a] = q.xp[a]; pst[a] = q.pst[a]; pdeg[a] = q.pdeg[a]; }
     if constexpr (!STAGED) sb_stage_sources<NT>(q, p, L);
+    if (tid == 0) L.chg = 0;                          // (read behind three barriers)
     // ---- feature update of the pharm nodes (pharmacodiff.py:414-420; independent of everything else, inputs in registers)
     if (isf) {
 #pragma unroll
@@ -460,6 +467,13 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
             }
             // an active atom: its place in the list and (unless the pocket's pp messages are shared) the slots of the "pa" region
             // that receive the compact copy of its static pp in-edges
+            if (p.pa_stamp && isp[a]) {
+                // unchanged = active in the previous step too, at the same slots (its stamp is that step's, its slot-2 range the same)
+                const bool was = q.ostamp[a] == p.step_id - 1;
+                const bool same = act[a] ? (was && !p.pa_static && q.ost[a] == reg_pa + (int)(o >> 28) && q.ocn[a] == deg[a]) : !was;
+                if (!same) L.chg = 1;
+                if (act[a]) p.pa_stamp[p0 + c] = p.step_id;
+            }
             if (isp[a] && act[a]) {
                 const int j = (int)((o >> 16) & 0xfffu);
                 p.act_ids[reg_act + j] = p0 + c;
@@ -499,6 +513,7 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
         if (tid == 0 && p.act_ids) {
             p.dyn_cnt[3 * p.B + g] = p.pa_static ? p.pa_static[g] : (int)(all >> 28);
             p.dyn_cnt[4 * p.B + g] = (int)((all >> 16) & 0xfffu);
+            if (p.pa_same) p.pa_same[g] = (L.chg == 0 && !pa_big && !p.pa_static) ? 1 : 0;
         }
         if (tid == NT - 64 && p.norm_mode == 2) {     // per-graph normalisers for message_norm == 0 (gvp.py:504-507)
             const int cpf = p.pfq_cnt ? p.pfq_cnt[g] : Nf * kk;

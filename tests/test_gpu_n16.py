@@ -256,6 +256,42 @@ def test_center_hoist_equals_on_the_fly_encoding(case, monkeypatch):
     torch.testing.assert_close(res["hoist"][1], h_t, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("case", ["uniform", "ragged"])
+def test_pa_messages_computed_ahead_equal_the_launch_s_own(case, monkeypatch):
+    """Speculative "pa" messages (k_n16_pa_spec; BuildParams::pa_same): conv layer 0's messages along the pp edges into the active
+    atoms depend on the timestep, the element types and the static pocket geometry only, so a denoising step computes the NEXT call's
+    on a side stream under its own last launch, and the next call skips the "pa" region of every graph whose region came out unchanged
+    (same atoms, same slots: stamped per atom by the update + build).  Same item code, same tables, same slots: a run with the
+    speculation equals a run without it (PFDYN_NO_PA_SPEC=1) BIT FOR BIT -- 40 steps from the noisy end of the schedule (regions change
+    every step: nothing may be skipped wrongly) and 40 from its quiet end (most regions stay: rows computed ahead are what the fused
+    launch reads), trajectories included; and the quiet run did skip."""
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 5)
+    n_prot, n_pharm = ([96] * 6, [6] * 6) if case == "uniform" else ([30, 70, 112, 48, 64, 33], [3, 8, 5, 6, 4, 7])
+    batch = O.synthetic_batch([820 + i for i in range(len(n_prot))], n_prot, n_pharm, cfg)
+    Nf = int(batch.pharm_ptr[-1])
+    T, n = 500, 40
+    noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(29))
+    coef = O.step_coefficients(O.gamma_table(T, 0.25), T)           # (bounded schedule: the centers stay inside the pocket)
+    res, skipped = {}, {}
+    for form in ("spec", "plain"):
+        if form == "plain":
+            monkeypatch.setenv("PFDYN_NO_PA_SPEC", "1")
+        eng = engine_for(cfg, sd)
+        set_batch(eng, batch)
+        out = []
+        for order in (list(reversed(range(T - n, T))), list(reversed(range(n)))):      # s = 499 .. 460, then s = 39 .. 0
+            x, h, tx, th = eng.sample(eng.coef_array(coef, order), n, noise, trajectory=True)
+            torch.cuda.synchronize()
+            eng.sample_status()
+            out += [x.cpu(), h.cpu(), tx.cpu(), th.cpu()]
+            skipped[(form, order[0])] = eng.kernel_family(cfg.n_convs + 2)
+        res[form] = out
+    for a, b in zip(res["spec"], res["plain"]):
+        assert torch.equal(a, b)
+    assert skipped[("spec", n - 1)] == 1 and skipped[("plain", n - 1)] == 0
+
+
 def test_fused_launch_arithmetic_tiling_equals_the_work_list_form(monkeypatch):
     """The conv-layer-0 edge launch and the fused launch of a batch whose graphs all have the same number of centers map items to
     (etype, graph, group) by arithmetic on preloaded scalars (k_n16_edge_u / k_n16_fused_u: regions at a fixed stride, groups beyond
