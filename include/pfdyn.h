@@ -312,6 +312,13 @@ int pf_debug_counts(pf_handle* h, int64_t* out /*[8]*/, pf_stream stream);
  * different workgroups of one launch (pf_rg.hip: k_rg_node_hs_build, the default for small batches; PFDYN_HS_BUILD=0 switches it
  * off); else 0 */
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave);
+/* Work a denoising step's merged last launch did AHEAD for the next dynamics call (after a pf_denoise_step whose timestep plan was
+ * announced; zeros otherwise).  out[0] = "pa" edges (pp edges into the active atoms) of conv layer 0 whose messages the next call will
+ * NOT compute -- they were computed ahead and the update + build found their graphs' regions unchanged; out[1] = "pa" edges computed
+ * ahead; out[2] = 1 if the centers' encoder outputs and h_src products were left in tables (center hoist), out[3] = centers covered.
+ * Also: pf_debug_kernel_family(layer = n_convs + 1) = 1 when the LAST call's ff / fp items started from those tables, (n_convs + 2) = 1
+ * when it skipped regions computed ahead.  Synchronises the stream. */
+int pf_debug_ahead(pf_handle* h, int64_t* out /*[4]*/, pf_stream stream);
 /* the exchange time-outs of k_rg_node_hs_build counted on this handle since it was created (cumulative; pf_sample_status is the
  * product-path check and reports new ones per run).  Synchronises the device. */
 int pf_debug_xchg_timeouts(pf_handle* h, int32_t* n);

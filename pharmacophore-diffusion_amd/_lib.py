@@ -79,6 +79,7 @@ SYMBOLS = {
     "pf_debug_last_eps": (ctypes.c_int, [_P, _P, _P, _P]),
     "pf_debug_xchg_timeouts": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int32)]),
     "pf_debug_xchg_fault": (ctypes.c_int, [_P, _I32, _I32]),
+    "pf_debug_ahead": (ctypes.c_int, [_P, ctypes.POINTER(_I64), _P]),
     "pf_debug_l0_hoist": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int32)]),
     "pf_debug_chain": (ctypes.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
 }

@@ -3385,6 +3385,23 @@ int pf_debug_dropout_mask(pf_handle* h, int32_t layer, int32_t which, float drop
     return PF_OK;
 }
 
+int pf_debug_ahead(pf_handle* h, int64_t* out, pf_stream stream) {
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    if (!out) PF_FAIL(h, PF_ERR_ARG, "pf_debug_ahead: null argument");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    PF_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+    const int B = h->B;
+    if (h->spec_valid && h->d_pa_same && h->d_dyn_cnt) {
+        std::vector<int> cnt((size_t)5 * B), same(B);
+        PF_HIP(h, hipMemcpy(cnt.data(), h->d_dyn_cnt, (size_t)5 * B * 4, hipMemcpyDeviceToHost));
+        PF_HIP(h, hipMemcpy(same.data(), h->d_pa_same, (size_t)B * 4, hipMemcpyDeviceToHost));
+        for (int g = 0; g < B; ++g) { out[1] += cnt[(size_t)3 * B + g]; if (same[g]) out[0] += cnt[(size_t)3 * B + g]; }
+    }
+    if (h->cen_valid) { out[2] = 1; out[3] = h->Nf; }
+    return PF_OK;
+}
+
 int pf_debug_kernel_family(pf_handle* h, int32_t layer, int32_t* rows_per_wave) {
     if (!h || !rows_per_wave) return PF_ERR_ARG;
     if (layer == (int)h->last_family.size() + 2 && layer > 2) {  // three past: 1 when the last call skipped "pa" regions whose rows had been computed ahead

@@ -435,6 +435,14 @@ class PfEngine:
         """Diagnostic (pf_debug_xchg_fault): make the merged launch's producers skip one exchange word / shorten the poll bound."""
         self._ck(self.lib.pf_debug_xchg_fault(self._h, int(bool(drop_word)), int(poll_max)), "pf_debug_xchg_fault")
 
+    def ahead(self):
+        """What the last denoising step's merged launch did ahead for the next call (pf_debug_ahead): dict(pa_skipped, pa_ahead,
+        center_hoist, centers)."""
+        out = (ctypes.c_int64 * 4)()
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.pf_debug_ahead(self._h, out, _stream_ptr()), "pf_debug_ahead")
+        return dict(zip(("pa_skipped", "pa_ahead", "center_hoist", "centers"), list(out)))
+
     def l0_hoist(self) -> int:
         """Rows per hoisted wave of conv layer 0's pp messages in the last dynamics call (0: static hoist not used)."""
         r = ctypes.c_int32()
