@@ -117,6 +117,89 @@ __device__ __forceinline__ int knn_halfwave(const float4* px, const float4 q, co
     return mine;
 }
 
+// The same result with a third of the instructions (round 5; the search is ~1/3 of what a step waits for behind eps).  Keys are the
+// distance bits with the candidate's slot i in their low log2(NC) bits: a lane sorts its NC keys once (bitonic network of v_min /
+// v_max), a round is then the half-wave minimum of the lanes' heads (v_min_u32 on the DPP network), two v_readlane, the winner lane
+// by s_ff1 of a ballot, and a pop of the winner's list (v_cndmask under a scalar mask).  Truncating the distance is exact unless two
+// of the k + 1 smallest keys share a bucket (distances equal in all but their low bits: ~1e-6 of the searches, always for
+// duplicated atoms) or a key is the "no atom" pattern: then `exact` comes back false (wave-uniform) and the caller runs
+// knn_halfwave.  Selected keys with pairwise different buckets are ordered as their distances are, and everything not selected
+// is no smaller than the (k + 1)-th key.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned int dpp_umin(const unsigned int v) {
+    const unsigned int o = (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+// lane l: bit l of the scalar mask set ? b : a -- as ONE v_cndmask (written as `win ? key[j + 1] : key[j]` over an array, the compiler
+// turns the pop into indexed reads of the array, i.e. a compare chain of NC selects per element)
+__device__ __forceinline__ unsigned int sel_by_mask(const unsigned int a, const unsigned int b, const unsigned long long m) {
+    unsigned int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+    return r;
+}
+template <int NC>
+__device__ __forceinline__ void knn_sort_keys(unsigned int (&k)[NC]) {
+#pragma unroll
+    for (int sz = 2; sz <= NC; sz <<= 1)
+#pragma unroll
+        for (int j = sz >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned int a = k[i], b = k[l];
+                    const unsigned int lo = a < b ? a : b, hi = a < b ? b : a;
+                    const bool up = (i & sz) == 0;
+                    k[i] = up ? lo : hi;
+                    k[l] = up ? hi : lo;
+                }
+            }
+}
+template <int NC>
+__device__ __forceinline__ int knn_halfwave_keys(const float4* px, const float4 q, const int Np, const int kk, const int lane, bool& exact) {
+    static_assert(NC == 8 || NC == 16, "slots per lane");
+    constexpr unsigned int IM = NC - 1;
+    constexpr int LOG = NC == 8 ? 3 : 4;
+    const int hw = lane >> 5, l32 = lane & 31;
+    unsigned int key[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = l32 + 32 * i;
+        const float d2 = sqdist_rn(px[c], q);
+        key[i] = c < Np ? ((__float_as_uint(d2) & ~IM) | (unsigned int)i) : 0xffffffffu;
+    }
+    knn_sort_keys<NC>(key);
+    int mine = 0;
+    unsigned int pb0 = 0u, pb1 = 0u;
+    bool amb = false;                                  // (from v_readlane results: scalar)
+    for (int r = 0; r <= kk; ++r) {
+        unsigned int m = key[0];
+        m = dpp_umin<0x111, 0xf>(m);
+        m = dpp_umin<0x112, 0xf>(m);
+        m = dpp_umin<0x114, 0xf>(m);
+        m = dpp_umin<0x118, 0xf>(m);
+        m = dpp_umin<0x142, 0xa>(m);
+        const unsigned int k0 = (unsigned int)__builtin_amdgcn_readlane((int)m, 31), k1 = (unsigned int)__builtin_amdgcn_readlane((int)m, 63);
+        const unsigned int b0 = k0 >> LOG, b1 = k1 >> LOG;
+        if (r > 0) amb = amb || b0 == pb0 || b1 == pb1;
+        if (r == kk) break;
+        amb = amb || b0 == (0xffffffffu >> LOG) || b1 == (0xffffffffu >> LOG);
+        pb0 = b0; pb1 = b1;
+        const unsigned int kmin = hw ? k1 : k0;
+        const unsigned long long eq = __builtin_amdgcn_ballot_w64(key[0] == kmin);
+        const unsigned int e0 = (unsigned int)eq, e1 = (unsigned int)(eq >> 32);      // (neither is 0: the minimum came from a lane)
+        const int wl0 = __builtin_ctz(e0 | 0x80000000u), wl1 = __builtin_ctz(e1 | 0x80000000u);
+        const unsigned long long wm = (1ull << wl0) | (1ull << (32 + wl1));
+        const int wc0 = wl0 + 32 * (int)(k0 & IM), wc1 = wl1 + 32 * (int)(k1 & IM);
+#pragma unroll
+        for (int j = 0; j + 1 < NC; ++j) key[j] = sel_by_mask(key[j], key[j + 1], wm);
+        key[NC - 1] = sel_by_mask(key[NC - 1], 0xffffffffu, wm);
+        mine = l32 == r ? (hw ? wc1 : wc0) : mine;
+    }
+    exact = !amb;
+    return mine;
+}
+
 // x[l] + x[l ^ 32] + ... in the pairing order of the xor butterfly `for (o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o)` (what
 // step_update_body sums with: same bits), on the register network instead of six LDS-crossbar round trips: lane-half and
 // row swaps (v_permlane32_swap / v_permlane16_swap; asm: the compiler's builtins mis-assign their second result), row_ror:8,
@@ -137,6 +220,31 @@ __device__ __forceinline__ float wave_xor_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));       // quad_perm [2,3,0,1] = lane ^ 2
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));       // quad_perm [1,0,3,2] = lane ^ 1
     return v;
+}
+// three sums at once: the same operations per value in the same order (same bits), the three chains' latencies overlapped
+__device__ __forceinline__ void wave_xor_sum3(float (&v)[3]) {
+    unsigned a[3], b[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a[c] = __builtin_bit_cast(unsigned, v[c]); b[c] = a[c]; }
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5"
+                 : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { v[c] = __builtin_bit_cast(float, a[c]) + __builtin_bit_cast(float, b[c]); a[c] = __builtin_bit_cast(unsigned, v[c]); b[c] = a[c]; }
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5"
+                 : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = __builtin_bit_cast(float, a[c]) + __builtin_bit_cast(float, b[c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[c]), 0x128, 0xf, 0xf, false));
+    float w[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) w[c] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v[c]), 0x101f));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] += w[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[c]), 0x4e, 0xf, 0xf, false));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[c]), 0xb1, 0xf, 0xf, false));
 }
 // inclusive wave scan (sum) of a 32-bit value on the DPP network, same pattern
 template <int CTRL, int ROW_MASK>
@@ -163,11 +271,13 @@ struct __attribute__((aligned(16))) StepBuildLds {
     float com[4];
     unsigned long long scratch[8];
     unsigned int refm[SB_MAXA][2];              // per atom: bit fl set <=> center fl has the atom among its k neighbours
-    // the compact copy of the active atoms' pp in-edges ("pa" region) is written one slot per thread: an active atom names
-    // itself the owner of its slots, a slot's thread looks its atom up and takes the source from a_src -- the first 16
-    // static sources of EVERY atom (prefetched, indexed by atom)
-    unsigned short owner[SB_MAXA * 16];         // [slot of the region] -> atom (local index)
-    int a_d0[SB_MAXA], a_pst[SB_MAXA];          // per atom: first slot of its in-edges in the region, static in-edge start
+    // fp edges (destination-major) are stored one per (center, neighbour) PAIR: the kNN lanes leave their pair here, an atom's
+    // thread the first slot of the atom's fp in-edges, and a pair's slot is that plus the referencing centers below its own
+    int pairs[PF_MAXF * PF_MAXK];               // [center * k + rank] = atom (local index) | center << 16
+    int a_e0[SB_MAXA];                          // per atom: first slot of its fp in-edges
+    // the compact copy of the active atoms' pp in-edges ("pa" region) is written by 16 threads per active atom from a_src -- the
+    // first 16 static sources of EVERY atom (prefetched, indexed by atom); thread 15 of an atom also copies what lies beyond 16
+    __attribute__((aligned(16))) int4 act4[SB_MAXA];   // [j-th active atom] = (atom, first slot in the region, in-degree, static in-edge start)
     int chg;                                    // BuildParams::pa_same: set by any atom whose place in the "pa" region changed
     __attribute__((aligned(16))) int a_src[SB_MAXA][16];
 };
@@ -213,7 +323,9 @@ __device__ __forceinline__ void sb_load_a(SbPre<NT>& q, const int g, const int* 
 // (Every load of the body is issued here and in sb_load_c, none behind its first store: gfx9 counts loads and stores in ONE
 // in-order counter, so a load that follows stores of a run-time count can only be waited for with vmcnt(0) -- which also
 // waits for every store before it, ~2,000 cycles each time.)
-template <int NT>
+// FEAT = false: the caller updates the features itself (step_build_wait_body: on other lanes) -- the center threads' feature rows
+// are not loaded.
+template <int NT, bool FEAT = true>
 __device__ __forceinline__ void sb_load_b(SbPre<NT>& q, const int a_Np_tot, const StepParams& sp, const BuildParams& p) {
     constexpr int APT = SbPre<NT>::APT;
     const int tid = threadIdx.x;
@@ -229,11 +341,14 @@ __device__ __forceinline__ void sb_load_b(SbPre<NT>& q, const int a_Np_tot, cons
         for (int c = 0; c < 3; ++c) { const float v = nz[c]; q.nzx[c] = q.isf ? v : 0.f; }
 #pragma unroll
         for (int k = 0; k < SB_MAXNF; ++k) {
-            const int kc = min(k, sp.nf - 1);
-            const float hvv = ((pf_gcf)sp.pharm_h)[(size_t)frow * sp.nf + kc], nzv = nz[3 + kc];
-            const bool on = q.isf && k < sp.nf;
-            q.hv[k] = on ? hvv : 0.f;
-            q.nzh[k] = on ? nzv : 0.f;
+            q.hv[k] = 0.f; q.nzh[k] = 0.f;
+            if constexpr (FEAT) {
+                const int kc = min(k, sp.nf - 1);
+                const float hvv = ((pf_gcf)sp.pharm_h)[(size_t)frow * sp.nf + kc], nzv = nz[3 + kc];
+                const bool on = q.isf && k < sp.nf;
+                q.hv[k] = on ? hvv : 0.f;
+                q.nzh[k] = on ? nzv : 0.f;
+            }
         }
     }
     const bool stat = p.act_ids && !p.pa_static;                      // kernel-uniform
@@ -291,8 +406,9 @@ __device__ __forceinline__ void sb_stage_sources(const SbPre<NT>& q, const Build
 
 // NT threads (a multiple of 64, >= 256; SB_MAXA / NT atoms per thread), every thread of the workgroup calls it.
 // ex / eh: eps_x [3] and eps_h [nf] of center tid (threads tid < Nf), read by the caller from wherever the head left them.
-// Five LDS-only barriers: COM known | shifted coordinates in LDS | neighbour masks complete | scan totals | slot owners.
-template <int NT, bool STAGED = false>
+// Five LDS-only barriers: COM known | shifted coordinates in LDS | neighbour masks complete | scan totals | first slots and active list.
+// FEAT = false: the caller has updated the features (sb_load_b<NT, false>).
+template <int NT, bool STAGED = false, bool FEAT = true>
 __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[3], const float (&eh)[SB_MAXNF], const int g,
                                           const StepParams& sp, const BuildParams& p, StepBuildLds& L) {
     constexpr int NW = NT / 64, APT = SB_MAXA / NT;
@@ -313,13 +429,15 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
     if constexpr (!STAGED) sb_stage_sources<NT>(q, p, L);
     if (tid == 0) L.chg = 0;                          // (read behind three barriers)
     // ---- feature update of the pharm nodes (pharmacodiff.py:414-420; independent of everything else, inputs in registers)
-    if (isf) {
+    if constexpr (FEAT) {
+        if (isf) {
 #pragma unroll
-        for (int k = 0; k < SB_MAXNF; ++k) {
-            if (k < sp.nf) {
-                const float hn = pf_feat_update(q.hv[k], eh[k], q.nzh[k], sp.a_ts, sp.var, sp.sigma, sp.ep_zt, sp.ep_pred, sp.ep_feat);
-                sp.pharm_h[(size_t)(f0 + tid) * sp.nf + k] = hn;
-                if (sp.h_snap_out) sp.h_snap_out[(size_t)(f0 + tid) * sp.nf + k] = hn;
+            for (int k = 0; k < SB_MAXNF; ++k) {
+                if (k < sp.nf) {
+                    const float hn = pf_feat_update(q.hv[k], eh[k], q.nzh[k], sp.a_ts, sp.var, sp.sigma, sp.ep_zt, sp.ep_pred, sp.ep_feat);
+                    sp.pharm_h[(size_t)(f0 + tid) * sp.nf + k] = hn;
+                    if (sp.h_snap_out) sp.h_snap_out[(size_t)(f0 + tid) * sp.nf + k] = hn;
+                }
             }
         }
     }
@@ -337,11 +455,12 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
     }
     if (wave == 0) {
         const float n = (float)max(Nf, 1);
+        float r0[3] = {m[0], m[1], m[2]};
+        wave_xor_sum3(r0);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float r0 = wave_xor_sum(m[c]);
             const float z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0));      // (an opaque zero: the additions stay)
-            if (lane == 0) L.com[c] = Nf > 0 ? (((r0 + z) + (z + z)) / n) : 0.f;
+            if (lane == 0) L.com[c] = Nf > 0 ? (((r0[c] + z) + (z + z)) / n) : 0.f;
         }
     }
     sb_lds_barrier();
@@ -365,11 +484,23 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
     int ff_total = 0;                                 // valid in the last wave
     if (wave == NW - 1) {
         int c = 0;
-        if (lane < Nf) {
-            if (p.ff_k > 0) c = kff;
-            else
-                for (int jn = 0; jn < Nf; ++jn)
-                    if (jn != lane && sqdist_rn(L.fx[jn], L.fx[lane]) < p.r2_ff) ++c;
+        unsigned long long inr = 0ull;                // radius mode: bit jn set <=> center jn lies within the radius of center `lane`
+        if (p.ff_k > 0) c = lane < Nf ? kff : 0;
+        else {
+            const float4 me = L.fx[min(lane, max(Nf - 1, 0))];
+            for (int j0 = 0; j0 < Nf; j0 += 4) {      // four LDS reads in flight (the sources are broadcast reads)
+                float4 o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[u] = L.fx[min(j0 + u, Nf - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jn = j0 + u;
+                    const bool in = jn < Nf && jn != lane && sqdist_rn(o[u], me) < p.r2_ff;
+                    inr |= in ? (1ull << jn) : 0ull;
+                }
+            }
+            if (lane >= Nf) inr = 0ull;
+            c = __popcll(inr);
         }
         const int incl = (int)wave_incl_scan_u32((unsigned int)c);
         ff_total = __builtin_amdgcn_readlane(incl, 63);
@@ -394,10 +525,10 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
                     ++e;
                 }
             } else {
-                for (int jn = 0; jn < Nf; ++jn)
-                    if (jn != lane && sqdist_rn(L.fx[jn], L.fx[lane]) < p.r2_ff) { p.esrc[e] = GF + jn; p.edst[e] = GF + lane; ++e; }
+                while (inr) { const int jn = __ffsll((long long)inr) - 1; inr &= inr - 1; p.esrc[e] = GF + jn; p.edst[e] = GF + lane; ++e; }
             }
         }
+        SB_STAMP(21);
     }
     SB_PHASE(9);
     // ---- pf (prot -> pharm): kNN, one center per HALF wave (knn_halfwave), candidates from LDS; lane r of a half ends with
@@ -407,15 +538,19 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
     for (int fb = 2 * wave; fb < Nf; fb += 2 * NW) {
         const int fl = fb + hw;                       // this half's center (fb + 1 may lie beyond the graph: that half searches
         const float4 qc = L.fx[min(fl, Nf - 1)];      // the last center again and writes nothing)
-        const int pc = Np <= 256 ? knn_halfwave<8>(L.px, qc, Np, kk, lane) : knn_halfwave<16>(L.px, qc, Np, kk, lane);   // wave-uniform
+        bool exact;
+        int pc = Np <= 256 ? knn_halfwave_keys<8>(L.px, qc, Np, kk, lane, exact) : knn_halfwave_keys<16>(L.px, qc, Np, kk, lane, exact);   // wave-uniform
+        if (!exact) pc = Np <= 256 ? knn_halfwave<8>(L.px, qc, Np, kk, lane) : knn_halfwave<16>(L.px, qc, Np, kk, lane);          // (wave-uniform, rare)
         if (l32 < kk && fl < Nf) {
             atomicOr(&L.refm[pc][fl >> 5], 1u << (fl & 31));
+            L.pairs[fl * kk + l32] = pc | (fl << 16);
             p.esrc[reg_pf + fl * kk + l32] = p0 + pc;
             p.edst[reg_pf + fl * kk + l32] = GF + fl;
         }
         if (l32 == 0 && fl < Nf) { in_start1[GF + fl] = reg_pf + fl * kk; in_cnt1[GF + fl] = kk; }
     }
     if (tid == 0) { p.dyn_cnt[1 * p.B + g] = Nf * kk; p.dyn_cnt[2 * p.B + g] = Nf * kk; }
+    SB_STAMP(20);
     sb_lds_barrier();
     SB_PHASE(10);
     // ---- fp = pf reversed, destination-major over the atoms; active atoms and the compact copy of their pp in-edges
@@ -449,21 +584,15 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
             all += t;
         }
         unsigned long long o = before + ((unsigned long long)slo | ((unsigned long long)shi << 28)) - tval;
-        const bool pa_big = (all >> 28) > (unsigned long long)(SB_MAXA * 16);      // workgroup-uniform
         SB_PHASE(13);                                 // offsets known
 #pragma unroll
         for (int a = 0; a < APT; ++a) {
             const int c = APT * tid + a;
             if (isp[a]) {
-                int e = reg_fp + (int)(o & 0xffffu);
+                const int e = reg_fp + (int)(o & 0xffffu);
                 in_start0[p0 + c] = e;
                 in_cnt0[p0 + c] = my[a];
-                {
-                    unsigned int mm = m0[a];
-                    while (mm) { const int fl = __ffs(mm) - 1; mm &= mm - 1; p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
-                    mm = m1[a];
-                    while (mm) { const int fl = 32 + __ffs(mm) - 1; mm &= mm - 1; p.esrc[e] = GF + fl; p.edst[e] = p0 + c; ++e; }
-                }
+                L.a_e0[c] = e;
             }
             // an active atom: its place in the list and (unless the pocket's pp messages are shared) the slots of the "pa" region
             // that receive the compact copy of its static pp in-edges
@@ -482,38 +611,47 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
                     const int d0 = (int)(o >> 28);
                     in_start2[p0 + c] = reg_pa + d0;
                     in_cnt2[p0 + c] = deg[a];
-                    L.a_d0[c] = d0; L.a_pst[c] = pst[a];
-                    if (!pa_big) {
-                        for (int k = 0; k < deg[a]; ++k) L.owner[d0 + k] = (unsigned short)c;
-                    } else {                          // more slots than the owner map holds (in-degrees far beyond 16): the atom's
-                        for (int k = 0; k < deg[a]; ++k) {      // own thread copies them
-                            p.esrc[reg_pa + d0 + k] = p.esrc[pst[a] + k];
-                            p.edst[reg_pa + d0 + k] = p0 + c;
-                            if (p.eorig) p.eorig[reg_pa + d0 + k] = pst[a] + k;
-                        }
-                    }
+                    L.act4[j] = make_int4(c, d0, deg[a], pst[a]);
                 }
             }
             o += val[a];
         }
-        SB_PHASE(14);                                 // fp edges / descriptors stored, active atoms staged
+        SB_PHASE(14);                                 // descriptors stored, first slots and active atoms staged
         sb_lds_barrier();
         SB_PHASE(15);
-        {   // the "pa" region, one slot per thread: coalesced stores
-            const int n_pa = (p.pa_static || pa_big) ? 0 : (int)(all >> 28);
-            for (int t = tid; t < n_pa; t += NT) {
-                const int c = (int)L.owner[t];
-                const int k = t - L.a_d0[c], ps = L.a_pst[c];
-                const int src = k < 16 ? L.a_src[c][k] : p.esrc[ps + k];
-                p.esrc[reg_pa + t] = src;
-                p.edst[reg_pa + t] = p0 + c;
-                if (p.eorig) p.eorig[reg_pa + t] = ps + k;
+        {   // fp edges: one per (center, neighbour) pair, at the atom's first slot + the referencing centers below this one
+            const int npairs = Nf * kk;
+            for (int t = tid; t < npairs; t += NT) {
+                const int pr = L.pairs[t], pc = pr & 0xffff, fl = pr >> 16;
+                const unsigned int r0 = L.refm[pc][0], r1 = L.refm[pc][1];
+                const int below = fl < 32 ? __popc(r0 & ((1u << fl) - 1u)) : __popc(r0) + __popc(r1 & ((1u << (fl - 32)) - 1u));
+                const int e = L.a_e0[pc] + below;
+                p.esrc[e] = GF + fl;
+                p.edst[e] = p0 + pc;
+            }
+        }
+        if (p.act_ids && !p.pa_static) {              // the "pa" region, 16 threads per active atom: runs of coalesced stores (kernel-uniform)
+            const int n_act = (int)((all >> 16) & 0xfffu);
+            for (int t = tid; t < n_act * 16; t += NT) {
+                const int4 a4 = L.act4[t >> 4];
+                const int k = t & 15, c = a4.x, e0 = reg_pa + a4.y, dg = a4.z, ps = a4.w;
+                if (k < dg) {
+                    p.esrc[e0 + k] = L.a_src[c][k];
+                    p.edst[e0 + k] = p0 + c;
+                    if (p.eorig) p.eorig[e0 + k] = ps + k;
+                }
+                if (k == 15)
+                    for (int k2 = 16; k2 < dg; ++k2) {    // (in-degrees beyond 16: their sources were not prefetched)
+                        p.esrc[e0 + k2] = p.esrc[ps + k2];
+                        p.edst[e0 + k2] = p0 + c;
+                        if (p.eorig) p.eorig[e0 + k2] = ps + k2;
+                    }
             }
         }
         if (tid == 0 && p.act_ids) {
             p.dyn_cnt[3 * p.B + g] = p.pa_static ? p.pa_static[g] : (int)(all >> 28);
             p.dyn_cnt[4 * p.B + g] = (int)((all >> 16) & 0xfffu);
-            if (p.pa_same) p.pa_same[g] = (L.chg == 0 && !pa_big && !p.pa_static) ? 1 : 0;
+            if (p.pa_same) p.pa_same[g] = (L.chg == 0 && !p.pa_static) ? 1 : 0;
         }
         if (tid == NT - 64 && p.norm_mode == 2) {     // per-graph normalisers for message_norm == 0 (gvp.py:504-507)
             const int cpf = p.pfq_cnt ? p.pfq_cnt[g] : Nf * kk;
@@ -550,15 +688,41 @@ __device__ __forceinline__ void step_build_fast_body(const int g, const int* __r
 // what was acknowledged.  A timed-out row is NOT re-armed here -- its producer may still store into it, and a re-armed word
 // filled late would read as "arrived" in every later step without ever being counted; pf_sample_begin re-arms every word.
 constexpr int SB_XCHG_POLLS = 1 << 16;
+// one word of a row: polled until it holds a payload (true) or poll_max rounds have passed (false: counted in xstat)
+__device__ __forceinline__ bool sb_poll_word(unsigned int* w, unsigned int& bits, int* xstat, const int poll_sleep, const int poll_max) {
+    bits = PF_XCHG_EMPTY;
+    for (int it = 0; it < poll_max; ++it) {
+        bits = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bits != PF_XCHG_EMPTY) return true;
+        for (int z = 0; z < poll_sleep; ++z) __builtin_amdgcn_s_sleep(2);      // ~50 ns each: the words come from memory (agent scope), not from a cache
+    }
+    atomicAdd(xstat, 1);
+    return false;
+}
+// Who waits for what (round 5): a center's thread (wave 0) polls the THREE coordinate words of its row, all three loads in flight at
+// once; the feature words are polled one per lane by the threads behind wave 0 (lane j of them: feature j % nf of center j / nf),
+// which update the features there and then -- off the path COM -> kNN that the step waits for.  (The first form polled a row's 3 + nf
+// words from one thread with a branch per word: nine dependent round trips to memory per poll round, ~2 us of every step.)
 template <int NT>
 __device__ __forceinline__ void step_build_wait_body(const int g, const int* __restrict__ a_prot_ptr, const int* __restrict__ a_pharm_ptr,
                                                      const int* __restrict__ a_reg, const int a_B, const int a_Np_tot,
                                                      const StepParams& sp, const BuildParams& p, unsigned int* xchg, int* xstat,
                                                      StepBuildLds& L, const int poll_sleep, const int poll_max) {
+    const int tid = threadIdx.x;
     SbPre<NT> q;
     sb_load_a<NT>(q, g, a_prot_ptr, a_pharm_ptr, a_reg, a_B, a_Np_tot, p);
-    sb_load_b<NT>(q, a_Np_tot, sp, p);
+    sb_load_b<NT, false>(q, a_Np_tot, sp, p);
     sb_load_c<NT>(q, p);
+    // the feature lanes' old value and draw (the first round of their loop; a graph with more than NT - 64 feature words loads the rest on demand)
+    const int nfeat = q.Nf * sp.nf, fj = tid - 64;
+    const int nf_tot = p.N - a_Np_tot;
+    float f_hv = 0.f, f_nz = 0.f;
+    {
+        const int jc = max(min(fj, nfeat - 1), 0), fc = jc / sp.nf, kc = jc - fc * sp.nf;
+        const int frow = max(min(q.f0 + fc, nf_tot - 1), 0);
+        f_hv = ((pf_gcf)sp.pharm_h)[(size_t)frow * sp.nf + kc];
+        f_nz = ((pf_gcf)sp.noise)[(size_t)frow * (3 + sp.nf) + 3 + kc];
+    }
     float ex[3] = {0.f, 0.f, 0.f}, eh[SB_MAXNF];
 #pragma unroll
     for (int k = 0; k < SB_MAXNF; ++k) eh[k] = 0.f;
@@ -568,44 +732,48 @@ __device__ __forceinline__ void step_build_wait_body(const int g, const int* __r
     {
         float4 pin = q.xf;
 #pragma unroll
-        for (int a = 0; a < SbPre<NT>::APT; ++a) { pin.x += q.xp[a].x; pin.y += q.xp[a].y; pin.z += q.xp[a].z; pin.w += (float)(q.pst[a] + q.pdeg[a]); }
+        for (int a = 0; a < SbPre<NT>::APT; ++a) { pin.x += q.xp[a].x; pin.y += q.xp[a].y; pin.z += q.xp[a].z; pin.w += (float)(q.pst[a] + q.pdeg[a] + q.ost[a] + q.ocn[a] + q.ostamp[a]); }
 #pragma unroll
         for (int c = 0; c < 3; ++c) pin.x += q.nzx[c];
-#pragma unroll
-        for (int k = 0; k < SB_MAXNF; ++k) pin.y += q.hv[k] + q.nzh[k];
+        pin.y += f_hv + f_nz;
         asm volatile("" :: "v"(pin.x), "v"(pin.y), "v"(pin.z), "v"(pin.w) : "memory");
     }
     SB_STAMP(100);
-    if (q.isf) {
-        unsigned int* row = xchg + (size_t)(q.f0 + (int)threadIdx.x) * PF_XCHG_STRIDE;
-        unsigned int w[3 + SB_MAXNF];
+    if (q.isf) {                                       // (threads of wave 0: PF_MAXF <= 64)
+        unsigned int* row = xchg + (size_t)(q.f0 + tid) * PF_XCHG_STRIDE;
+        unsigned int w[3];
         bool ok = false;
         for (int it = 0; it < poll_max; ++it) {
-            ok = true;
 #pragma unroll
-            for (int k = 0; k < 3 + SB_MAXNF; ++k) {
-                w[k] = PF_XCHG_EMPTY;
-                if (k < 3 + sp.nf) {
-                    w[k] = __hip_atomic_load(row + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = ok && w[k] != PF_XCHG_EMPTY;
-                }
-            }
+            for (int c = 0; c < 3; ++c) w[c] = __hip_atomic_load(row + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = w[0] != PF_XCHG_EMPTY && w[1] != PF_XCHG_EMPTY && w[2] != PF_XCHG_EMPTY;
             if (ok) break;
-            for (int z = 0; z < poll_sleep; ++z) __builtin_amdgcn_s_sleep(2);      // ~50 ns each: the words come from memory (agent scope), not from a cache
+            for (int z = 0; z < poll_sleep; ++z) __builtin_amdgcn_s_sleep(2);
         }
         if (!ok) atomicAdd(xstat, 1);
 #pragma unroll
         for (int c = 0; c < 3; ++c) ex[c] = ok ? __builtin_bit_cast(float, w[c]) : 0.f;
-#pragma unroll
-        for (int k = 0; k < SB_MAXNF; ++k) eh[k] = (ok && k < sp.nf) ? __builtin_bit_cast(float, w[3 + k]) : 0.f;
         if (ok) {
 #pragma unroll
-            for (int k = 0; k < 3 + SB_MAXNF; ++k)
-                if (k < 3 + sp.nf) __hip_atomic_store(row + k, PF_XCHG_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int c = 0; c < 3; ++c) __hip_atomic_store(row + c, PF_XCHG_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (fj >= 0) {
+        for (int j = fj; j < nfeat; j += NT - 64) {
+            const int fc = j / sp.nf, k = j - fc * sp.nf;
+            const size_t fr = (size_t)(q.f0 + fc);
+            float hv = f_hv, nz = f_nz;
+            if (j != fj) { hv = ((pf_gcf)sp.pharm_h)[fr * sp.nf + k]; nz = ((pf_gcf)sp.noise)[fr * (3 + sp.nf) + 3 + k]; }
+            unsigned int* w = xchg + fr * PF_XCHG_STRIDE + 3 + k;
+            unsigned int bits;
+            const bool ok = sb_poll_word(w, bits, xstat, poll_sleep, poll_max);
+            const float hn = pf_feat_update(hv, ok ? __builtin_bit_cast(float, bits) : 0.f, nz, sp.a_ts, sp.var, sp.sigma, sp.ep_zt, sp.ep_pred, sp.ep_feat);
+            sp.pharm_h[fr * sp.nf + k] = hn;
+            if (sp.h_snap_out) sp.h_snap_out[fr * sp.nf + k] = hn;
+            if (ok) __hip_atomic_store(w, PF_XCHG_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     SB_STAMP(101);
-    sb_finish<NT, true>(q, ex, eh, g, sp, p, L);
+    sb_finish<NT, true, false>(q, ex, eh, g, sp, p, L);
 }
 
 }  // namespace pfsb

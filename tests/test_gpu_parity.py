@@ -520,7 +520,7 @@ def test_endpoint_parameterisation_step():
     close(x0, ox, 1e-3, 1e-3); close(h0, oh, 1e-3, 1e-3)
 
 
-@pytest.mark.parametrize("case", ["knn_pf", "knn_ff", "graph_norm", "endpoint"])
+@pytest.mark.parametrize("case", ["knn_pf", "knn_ff", "graph_norm", "endpoint", "near_ties"])
 def test_fused_update_and_edge_build_variants_agree(case, monkeypatch):
     """A denoising step ends with k_step_build_fast (sampler update + the next call's edge build, one atom per
     thread, three dependent global round trips) when pf edges are kNN and pockets have at most 512 atoms.  It must
@@ -531,7 +531,25 @@ def test_fused_update_and_edge_build_variants_agree(case, monkeypatch):
     kw = dict(ff_k=3) if case == "knn_ff" else (dict(message_norm=0) if case == "graph_norm" else {})
     cfg = O.DynamicsConfig(**kw)
     sd = O.make_state_dict(cfg, 3)
-    batch = O.synthetic_batch([61, 62, 63, 64], 300, [3, 8, 5, 6], cfg)
+    batch = O.synthetic_batch([61, 62, 63, 64], [300, 256, 300, 256] if case == "near_ties" else 300, [3, 8, 5, 6], cfg)
+    if case == "near_ties":
+        # The fast body's neighbour search orders truncated distance keys (pf_stepbuild.h: knn_halfwave_keys) and must notice when
+        # that is not exact: 100-120 atoms of every pocket get a twin one or two ulps away along x (both directions, so the nearer
+        # twin has the larger index half of the time), ~30 an exact duplicate -- the generic body orders by (d^2, index) on the full
+        # bits.  Pockets of 256 and of 300 atoms: 8 and 16 candidates per lane.
+        px = batch.prot_x.clone()
+        for g in range(4):
+            p0, n = int(batch.prot_ptr[g]), int(batch.prot_ptr[g + 1] - batch.prot_ptr[g])
+            nt = 100 if n == 256 else 120
+            for j in range(nt):
+                x = px[p0 + j].clone()
+                step = (1 + j % 2) * (1 if (j // 2) % 2 else -1)
+                x[0] = (x[0:1].view(torch.int32) + step).view(torch.float32)[0]
+                px[p0 + nt + 30 + j] = x
+            nd = n - (2 * nt + 30)
+            px[p0 + 2 * nt + 30:p0 + n] = px[p0 + nt:p0 + nt + nd]
+        src, dst = O.build_pp_edges(px, batch.prot_ptr, cfg.cutoff_pp, 100)
+        batch = O.PocketBatch(px, batch.prot_h, batch.prot_ptr, batch.pharm_ptr, src, dst)
     T = 50
     gen = torch.Generator().manual_seed(9)
     noise = torch.randn(6, int(batch.pharm_ptr[-1]), 9, generator=gen)

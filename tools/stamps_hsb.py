@@ -22,7 +22,8 @@ coef = schedule.step_coefficients(schedule.PredefinedNoiseSchedule('polynomial_2
 carr = eng.coef_array(coef, list(range(39, -1, -1)))
 noise = torch.randn(41, B * 6, 9, device=dev)
 G = 512
-buf = torch.zeros(G * 8, dtype=torch.int64, device=dev)
+S = 16
+buf = torch.zeros(G * S, dtype=torch.int64, device=dev)
 lib = eng.lib
 lib.pfk_hsb_set_stamp_buffer.argtypes = [ctypes.c_void_p]
 eng.sample_begin(noise[0])
@@ -34,7 +35,7 @@ assert lib.pfk_hsb_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
 eng.denoise_step(carr[30], noise[31])
 torch.cuda.synchronize()
 lib.pfk_hsb_set_stamp_buffer(None)
-st = buf.cpu().view(G, 8)
+st = buf.cpu().view(G, S)
 live = [b for b in range(G) if int(st[b, 0]) != 0]
 t0 = min(int(st[b, 0]) for b in live)
 heads = [b for b in live if int(st[b, 2]) == 0 and int(st[b, 1]) != 0]
@@ -45,7 +46,10 @@ print("node + head workgroups: start / end")
 for b in heads[:6] + heads[-3:]:
     print(f"  wg {b:3d}: {us(st[b, 0]):6.2f} -> {us(st[b, 1]):6.2f}")
 print("  last head end:", max(us(st[b, 1]) for b in heads))
-print("update + build workgroups: start | loads issued | eps arrived | COM | kNN | fp stored | body end | wg end")
+print("update + build workgroups: start | loads issued | eps arrived | COM known | coordinates in LDS | ff wave done | wave 0 kNN done | barrier passed | references counted | offsets known | fp stored | slot owners | body end | wg end")
 for b in builds[:6] + builds[-3:]:
-    print(f"  wg {b:3d}: " + " | ".join(f"{us(st[b, k]):6.2f}" for k in (0, 2, 3, 4, 5, 6, 7, 1)))
+    print(f"  wg {b:3d}: " + " | ".join(f"{us(st[b, k]):6.2f}" for k in (0, 2, 3, 4, 8, 10, 9, 5, 11, 12, 6, 13, 7, 1)))
+import statistics
+ks = (3, 4, 8, 10, 9, 5, 11, 12, 6, 13, 7, 1)
+print("  median from eps arrived: " + " | ".join(f"{statistics.median(us(st[b, k]) - us(st[b, 3]) for b in builds):6.2f}" for k in ks))
 print("  last build end:", max(us(st[b, 1]) for b in builds))
