@@ -1312,7 +1312,7 @@ __device__ __forceinline__ void encode_group(const EncodeParams& p, const int nt
 // ---------------------------------------------------------------------------------------------
 #ifdef PF_STAMPS
 __device__ unsigned long long* g_build_stamps = nullptr;      // [B][32]
-#define BSTAMP(k) do { if (threadIdx.x == 0 && g_build_stamps) g_build_stamps[blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BSTAMP(k) do { if ((k) < 32 && threadIdx.x == 0 && g_build_stamps) g_build_stamps[blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define BSTAMP(k)
 #endif

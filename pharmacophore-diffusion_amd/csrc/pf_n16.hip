@@ -35,7 +35,7 @@ __device__ int g_n16_stamp_kid = -1;                  // kernel filter (see N16_
 #define SB_STAMP(k)                                                                                                    \
     do {                                                                                                               \
         const int rb_ = (int)blockIdx.x - g_n16_stamp_off;                                                             \
-        if ((threadIdx.x & 63) == 0 && g_n16_stamps && rb_ >= 0 && rb_ < 64 && (g_n16_stamp_kid < 0 || g_n16_stamp_kid == 3)) \
+        if ((k) < 16 && (threadIdx.x & 63) == 0 && g_n16_stamps && rb_ >= 0 && rb_ < 64 && (g_n16_stamp_kid < 0 || g_n16_stamp_kid == 3)) \
             g_n16_stamps[((size_t)rb_ * 4 + (threadIdx.x >> 6)) * 64 + 40 + (k)] = __builtin_amdgcn_s_memtime();       \
     } while (0)
 #endif

@@ -162,16 +162,19 @@ __device__ __forceinline__ int knn_halfwave_keys(const float4* px, const float4 
     constexpr int LOG = NC == 8 ? 3 : 4;
     const int hw = lane >> 5, l32 = lane & 31;
     unsigned int key[NC];
+    float4 cand[NC];                                   // every candidate requested before the first is used (left to itself the
+#pragma unroll                                         // compiler reads, waits and computes one at a time: NC LDS round trips)
+    for (int i = 0; i < NC; ++i) cand[i] = px[l32 + 32 * i];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int c = l32 + 32 * i;
-        const float d2 = sqdist_rn(px[c], q);
+        const float d2 = sqdist_rn(cand[i], q);
         key[i] = c < Np ? ((__float_as_uint(d2) & ~IM) | (unsigned int)i) : 0xffffffffu;
     }
     knn_sort_keys<NC>(key);
     int mine = 0;
-    unsigned int pb0 = 0u, pb1 = 0u;
-    bool amb = false;                                  // (from v_readlane results: scalar)
+    unsigned int kms = 0xffffffffu;                    // lane r of a half: the r-th smallest key of the half (r <= kk)
     for (int r = 0; r <= kk; ++r) {
         unsigned int m = key[0];
         m = dpp_umin<0x111, 0xf>(m);
@@ -180,12 +183,9 @@ __device__ __forceinline__ int knn_halfwave_keys(const float4* px, const float4 
         m = dpp_umin<0x118, 0xf>(m);
         m = dpp_umin<0x142, 0xa>(m);
         const unsigned int k0 = (unsigned int)__builtin_amdgcn_readlane((int)m, 31), k1 = (unsigned int)__builtin_amdgcn_readlane((int)m, 63);
-        const unsigned int b0 = k0 >> LOG, b1 = k1 >> LOG;
-        if (r > 0) amb = amb || b0 == pb0 || b1 == pb1;
-        if (r == kk) break;
-        amb = amb || b0 == (0xffffffffu >> LOG) || b1 == (0xffffffffu >> LOG);
-        pb0 = b0; pb1 = b1;
         const unsigned int kmin = hw ? k1 : k0;
+        kms = l32 == r ? kmin : kms;
+        if (r == kk) break;
         const unsigned long long eq = __builtin_amdgcn_ballot_w64(key[0] == kmin);
         const unsigned int e0 = (unsigned int)eq, e1 = (unsigned int)(eq >> 32);      // (neither is 0: the minimum came from a lane)
         const int wl0 = __builtin_ctz(e0 | 0x80000000u), wl1 = __builtin_ctz(e1 | 0x80000000u);
@@ -196,6 +196,15 @@ __device__ __forceinline__ int knn_halfwave_keys(const float4* px, const float4 
         key[NC - 1] = sel_by_mask(key[NC - 1], 0xffffffffu, wm);
         mine = l32 == r ? (hw ? wc1 : wc0) : mine;
     }
+    // exact unless two consecutive ones of the kk + 1 smallest keys share a bucket or a selected key is the "no atom" pattern: lane r
+    // of a half compares its key's bucket with lane r + 1's (row_shl:1 inside the rows of 16, the row boundary 15 | 16 through lane 16's
+    // value read by v_readlane -- kk <= 16 < 32, so only that one boundary exists)
+    const unsigned int bk = kms >> LOG;
+    unsigned int nb = (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)bk, 0x101, 0xf, 0xf, false);     // row_shl:1 = lane + 1's value (lane 15 of a row: -1)
+    const unsigned int b16lo = (unsigned int)__builtin_amdgcn_readlane((int)bk, 16), b16hi = (unsigned int)__builtin_amdgcn_readlane((int)bk, 48);
+    if (l32 == 15) nb = hw ? b16hi : b16lo;
+    const bool bad = (l32 < kk && (bk == nb || bk == (0xffffffffu >> LOG)));
+    const bool amb = __builtin_amdgcn_ballot_w64(bad) != 0ull;
     exact = !amb;
     return mine;
 }
@@ -492,6 +501,7 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
                 float4 o[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) o[u] = L.fx[min(j0 + u, Nf - 1)];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int jn = j0 + u;

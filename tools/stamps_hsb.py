@@ -21,8 +21,8 @@ eng.set_batch(px, ph, pptr, fptr, s, d)
 coef = schedule.step_coefficients(schedule.PredefinedNoiseSchedule('polynomial_2', T, 1e-5).gamma, T)
 carr = eng.coef_array(coef, list(range(39, -1, -1)))
 noise = torch.randn(41, B * 6, 9, device=dev)
-G = 512
-S = 16
+G = 1024
+S = 24
 buf = torch.zeros(G * S, dtype=torch.int64, device=dev)
 lib = eng.lib
 lib.pfk_hsb_set_stamp_buffer.argtypes = [ctypes.c_void_p]
@@ -38,7 +38,8 @@ lib.pfk_hsb_set_stamp_buffer(None)
 st = buf.cpu().view(G, S)
 live = [b for b in range(G) if int(st[b, 0]) != 0]
 t0 = min(int(st[b, 0]) for b in live)
-heads = [b for b in live if int(st[b, 2]) == 0 and int(st[b, 1]) != 0]
+heads = [b for b in live if b < 192 and int(st[b, 2]) == 0 and int(st[b, 1]) != 0]
+ahead = [b for b in live if b >= 224 and int(st[b, 1]) != 0]
 builds = [b for b in live if int(st[b, 2]) != 0]
 us = lambda v: (int(v) - t0) / 100.0
 print(f"{len(live)} workgroups stamped: {len(heads)} node + head, {len(builds)} update + build; times in us from the first workgroup's start")
@@ -52,4 +53,12 @@ for b in builds[:6] + builds[-3:]:
 import statistics
 ks = (3, 4, 8, 10, 9, 5, 11, 12, 6, 13, 7, 1)
 print("  median from eps arrived: " + " | ".join(f"{statistics.median(us(st[b, k]) - us(st[b, 3]) for b in builds):6.2f}" for k in ks))
+if all(int(st[b, 14]) != 0 for b in builds):     # (only in builds that stamp ids 30.. inside knn_halfwave_keys)
+    print("  inside wave 0's neighbour search, from 'coordinates in LDS' (medians): " + " | ".join(f"{statistics.median(us(st[b, k]) - us(st[b, 8]) for b in builds):6.2f}" for k in (14, 15, 16, 17)))
 print("  last build end:", max(us(st[b, 1]) for b in builds))
+if ahead:
+    hoist = [b for b in ahead if b < 224 + 64]
+    spec = [b for b in ahead if b >= 224 + 64]
+    for nm, ws in (("center hoist", hoist), ("speculative pa", spec)):
+        if ws:
+            print(f"  {nm}: {len(ws)} workgroups, start {min(us(st[b, 0]) for b in ws):.2f} .. {max(us(st[b, 0]) for b in ws):.2f}, end {min(us(st[b, 1]) for b in ws):.2f} .. {max(us(st[b, 1]) for b in ws):.2f}")
