@@ -163,8 +163,10 @@ def step_launches(pmc, cnt, arch_dev, hoist16):
         if arch_dev:
             hoisted = 2.0 * 128 * 128 + 2.0 * 16 * 17 * 3           # what a type-table / center-table row replaces of an edge's first GVP
             if "k_n16_edge<true>" in k or "k_n16_edge_u" in k:
-                alg = PER_EDGE * l0
-                ex = alg - ((cnt["pa"] + cnt["pf"]) * hoisted if hoist16 else 0.0)
+                # (the launch's units are the edges it computes: the "pa" edges whose rows the previous step's last launch computed
+                # ahead -- and this launch skipped -- are that launch's units, below)
+                alg = PER_EDGE * (l0 - cnt.get("pa_skipped", 0))
+                ex = PER_EDGE * l0 - ((cnt["pa"] + cnt["pf"]) * hoisted if hoist16 else 0.0)
                 if cnt.get("center_hoist"):
                     ex -= (cnt["ff"] + cnt["fp"]) * hoisted         # ff / fp items start from the center hoist's tables too
                 ex -= cnt.get("pa_skipped", 0) * (PER_EDGE - hoisted)     # "pa" regions computed ahead by the previous step's last launch
@@ -174,6 +176,7 @@ def step_launches(pmc, cnt, arch_dev, hoist16):
             elif ("k_rg_node<false, 1, true" in k) or "k_rg_node_hs" in k or "k_rg_tail" in k or "k_n16_tail" in k:
                 alg = ex = (PER_NODE + HEAD_FLOP) * cnt["centers"]
                 if "k_rg_node_hs_build" in k:                       # + the next call's "pa" items computed ahead, + the center hoist's encoders and products
+                    alg = alg + PER_EDGE * cnt.get("pa_skipped", 0)  # (algorithmic: the rows computed ahead that the next call USED; executed: all of them)
                     ex = ex + cnt.get("pa_ahead", 0) * (PER_EDGE - hoisted) + (cnt["centers"] * (2.0 * 128 * 7 + 2 * 2.0 * 128 * 128) if cnt.get("center_hoist") else 0.0)
             elif "k_step_build" in k:
                 alg = ex = 0.0
@@ -579,15 +582,17 @@ def main():
         except Exception:
             pass
         if merged:
-            dk_name = ("k_rg_node_hs_build (the step's last launch: the node + head items of the centers -- the algorithmic FLOPs -- every "
-                       "graph's sampler update + edge build, and, executed ahead for the NEXT call, its conv-layer-0 'pa' items and the "
-                       "centers' encoder / h_src tables, all as workgroups of one grid; ~14 us of its duration is the six-block chain, the "
-                       "rest the hand-over and the build)")
+            dk_name = ("k_rg_node_hs_build (the step's last launch: the node + head items of the centers, every graph's sampler update + "
+                       "edge build, and, computed ahead for the NEXT call, its conv-layer-0 'pa' messages -- algorithmic FLOPs: the centers' "
+                       "node update + head and the 'pa' edges the next call takes from here instead of computing them -- and the centers' "
+                       "encoder / h_src tables, all as workgroups of one grid; ~14 us of its duration is the six-block chain, the rest the "
+                       "hand-over and the build)")
         else:
             dk_name = "k_rg_node<false, ., true, .> / k_rg_node_hs (last conv layer's node update of the centers + noise head)"
         dk_match = "k_rg_node"
         dk_alg = dk_exec = (PER_NODE + HEAD_FLOP) * cnt["centers"]
         if merged:      # + what the launch computes ahead for the next call: its "pa" items and the center hoist's encoders / products
+            dk_alg += PER_EDGE * cnt.get("pa_skipped", 0)       # (its units: the "pa" edges whose rows the next call takes from it instead of computing them)
             dk_exec += cnt.get("pa_ahead", 0) * (PER_EDGE - (2.0 * 128 * 128 + 2.0 * 16 * 17 * 3)) + \
                 (cnt["centers"] * (2.0 * 128 * 7 + 2 * 2.0 * 128 * 128) if cnt.get("center_hoist") else 0.0)
     dk_tf = dk_alg / dk_avg_s / 1e12 if dk_avg_s > 0 else 0.0
