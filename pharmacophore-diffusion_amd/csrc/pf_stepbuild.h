@@ -278,7 +278,7 @@ struct __attribute__((aligned(16))) StepBuildLds {
     float4 fx[PF_MAXF];                         // updated pharm coordinates (COM removed)
     float4 px[SB_MAXA];                         // updated protein coordinates
     float com[4];
-    unsigned long long scratch[8];
+    unsigned long long scratch[2][8];             // [pass][wave]
     unsigned int refm[SB_MAXA][2];              // per atom: bit fl set <=> center fl has the atom among its k neighbours
     // fp edges (destination-major) are stored one per (center, neighbour) PAIR: the kNN lanes leave their pair here, an atom's
     // thread the first slot of the atom's fp in-edges, and a pair's slot is that plus the referencing centers below its own
@@ -305,6 +305,11 @@ struct EpsLds {                                  // [PF_MAXF][4] / [PF_MAXF][16]
 
 // What the update + build of graph g reads that does NOT depend on the noise prediction: trips (A), (B) and (C).  A kernel that
 // computes eps itself (k_n16_tail) issues these loads in front of / underneath its chain, level by level with its own gathers.
+// atom a of thread tid: pass a covers atoms [NT a, NT a + NT) -- a pocket of at most NT atoms gives every thread ONE atom and pass 1
+// nothing (dealt as 2 tid + a, a 256-atom pocket kept half of a 256-thread workgroup idle in every per-atom phase and the other half
+// working through two atoms one after the other)
+template <int NT>
+__device__ __forceinline__ int sb_atom(const int tid, const int a) { return tid + NT * a; }
 template <int NT>
 struct SbPre {
     static constexpr int APT = SB_MAXA / NT;
@@ -363,7 +368,7 @@ __device__ __forceinline__ void sb_load_b(SbPre<NT>& q, const int a_Np_tot, cons
     const bool stat = p.act_ids && !p.pa_static;                      // kernel-uniform
 #pragma unroll
     for (int a = 0; a < APT; ++a) {
-        const int c = APT * tid + a;
+        const int c = sb_atom<NT>(tid, a);
         q.isp[a] = c < q.Np;
         const int arow = max(min(q.p0 + c, a_Np_tot - 1), 0);
         const float4 x = sp.xn[arow];
@@ -404,7 +409,7 @@ __device__ __forceinline__ void sb_stage_sources(const SbPre<NT>& q, const Build
     if (p.act_ids && !p.pa_static) {                   // kernel-uniform
 #pragma unroll
         for (int a = 0; a < APT; ++a) {
-            int4* st = reinterpret_cast<int4*>(&L.a_src[APT * tid + a][0]);
+            int4* st = reinterpret_cast<int4*>(&L.a_src[sb_atom<NT>(tid, a)][0]);
             st[0] = make_int4(q.psrc[a][0], q.psrc[a][1], q.psrc[a][2], q.psrc[a][3]);
             st[1] = make_int4(q.psrc[a][4], q.psrc[a][5], q.psrc[a][6], q.psrc[a][7]);
             st[2] = make_int4(q.psrc[a][8], q.psrc[a][9], q.psrc[a][10], q.psrc[a][11]);
@@ -480,12 +485,15 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
         L.fx[tid] = v;
         sp.xn[GF + tid] = v;
     }
+    const bool two = Np > NT;                         // workgroup-uniform: pass 1 has atoms
 #pragma unroll
     for (int a = 0; a < APT; ++a) {
-        const int c = APT * tid + a;
+        const int c = sb_atom<NT>(tid, a);
         if (isp[a]) { xp[a].x -= com[0]; xp[a].y -= com[1]; xp[a].z -= com[2]; sp.xn[p0 + c] = xp[a]; }
-        L.px[c] = xp[a];
-        L.refm[c][0] = 0u; L.refm[c][1] = 0u;
+        if (a == 0 || two) {                          // (the neighbour search reads atoms beyond NT only when there are any)
+            L.px[c] = xp[a];
+            L.refm[c][0] = 0u; L.refm[c][1] = 0u;
+        }
     }
     sb_lds_barrier();
     // ---- ff (pharm -> pharm) on the last wave: counts, wave scan for the offsets, emission
@@ -568,36 +576,53 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
         // the centers that reference an atom, ascending: the bits of its mask (set by the kNN waves above)
         unsigned int m0[APT], m1[APT];
         int my[APT], act[APT], deg[APT];
-        unsigned long long val[APT], tval = 0ull;
+        unsigned long long val[APT], incl[APT];
 #pragma unroll
         for (int a = 0; a < APT; ++a) {
-            const int c = APT * tid + a;
-            m0[a] = isp[a] ? L.refm[c][0] : 0u; m1[a] = isp[a] ? L.refm[c][1] : 0u;
+            const int c = sb_atom<NT>(tid, a);
+            m0[a] = 0u; m1[a] = 0u;
+            if (a == 0 || two) { m0[a] = isp[a] ? L.refm[c][0] : 0u; m1[a] = isp[a] ? L.refm[c][1] : 0u; }
             my[a] = __popc(m0[a]) + __popc(m1[a]);
             act[a] = (my[a] > 0 && p.act_ids) ? 1 : 0;
             deg[a] = act[a] ? pdeg[a] : 0;
             val[a] = (unsigned long long)my[a] | ((unsigned long long)act[a] << 16) | ((unsigned long long)deg[a] << 28);
-            tval += val[a];
         }
         SB_PHASE(12);                                 // references counted
-        // block scan over the waves: the value packs three counters (bits 0-15 fp edges, 16-27 active atoms, 28-63 their pp
-        // in-edges), scanned as two 32-bit halves (the low two cannot carry into each other at these sizes)
-        const unsigned int lo = (unsigned int)(tval & 0xfffffffull), hi = (unsigned int)(tval >> 28);
-        const unsigned int slo = wave_incl_scan_u32(lo), shi = wave_incl_scan_u32(hi);
-        if (lane == 63) L.scratch[wave] = (unsigned long long)slo | ((unsigned long long)shi << 28);
-        sb_lds_barrier();
-        unsigned long long before = 0ull, all = 0ull;
+        // block scan in atom order = (pass, thread): the value packs three counters (bits 0-15 fp edges, 16-27 active atoms, 28-63 their
+        // pp in-edges), scanned as two 32-bit halves (the low two cannot carry into each other at these sizes); one wave scan per pass
+        // that has atoms, the waves' totals through LDS
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const unsigned long long t = L.scratch[w];
-            if (w < wave) before += t;
-            all += t;
+        for (int a = 0; a < APT; ++a) {
+            incl[a] = 0ull;
+            if (a == 0 || two) {
+                const unsigned int lo = (unsigned int)(val[a] & 0xfffffffull), hi = (unsigned int)(val[a] >> 28);
+                const unsigned int slo = wave_incl_scan_u32(lo), shi = wave_incl_scan_u32(hi);
+                incl[a] = (unsigned long long)slo | ((unsigned long long)shi << 28);
+                if (lane == 63) L.scratch[a][wave] = incl[a];
+            }
         }
-        unsigned long long o = before + ((unsigned long long)slo | ((unsigned long long)shi << 28)) - tval;
+        sb_lds_barrier();
+        unsigned long long obase[APT], all = 0ull;
+#pragma unroll
+        for (int a = 0; a < APT; ++a) {
+            obase[a] = all;                           // everything of the passes below
+            if (a == 0 || two) {
+                unsigned long long before = 0ull;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const unsigned long long t = L.scratch[a][w];
+                    if (w < wave) before += t;
+                    all += t;
+                }
+                obase[a] += before + incl[a] - val[a];
+            }
+        }
         SB_PHASE(13);                                 // offsets known
 #pragma unroll
         for (int a = 0; a < APT; ++a) {
-            const int c = APT * tid + a;
+            if (a > 0 && !two) break;                 // workgroup-uniform
+            const int c = sb_atom<NT>(tid, a);
+            const unsigned long long o = obase[a];
             if (isp[a]) {
                 const int e = reg_fp + (int)(o & 0xffffu);
                 in_start0[p0 + c] = e;
@@ -624,39 +649,55 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
                     L.act4[j] = make_int4(c, d0, deg[a], pst[a]);
                 }
             }
-            o += val[a];
         }
         SB_PHASE(14);                                 // descriptors stored, first slots and active atoms staged
         sb_lds_barrier();
         SB_PHASE(15);
-        {   // fp edges: one per (center, neighbour) pair, at the atom's first slot + the referencing centers below this one
-            const int npairs = Nf * kk;
-            for (int t = tid; t < npairs; t += NT) {
-                const int pr = L.pairs[t], pc = pr & 0xffff, fl = pr >> 16;
-                const unsigned int r0 = L.refm[pc][0], r1 = L.refm[pc][1];
-                const int below = fl < 32 ? __popc(r0 & ((1u << fl) - 1u)) : __popc(r0) + __popc(r1 & ((1u << (fl - 32)) - 1u));
-                const int e = L.a_e0[pc] + below;
-                p.esrc[e] = GF + fl;
-                p.edst[e] = p0 + pc;
+        // fp edges: one per (center, neighbour) pair, at the atom's first slot + the referencing centers below this one.  The "pa"
+        // region: 16 threads per active atom, runs of coalesced stores from the prefetched static sources.  Both are two LDS round
+        // trips in front of their stores: the first pass of each (what a 256-atom pocket with <= 32 active atoms needs) shares them.
+        const int npairs = Nf * kk;
+        const bool pa_on = p.act_ids && !p.pa_static;                                   // kernel-uniform
+        const int n_pa16 = pa_on ? 16 * (int)((all >> 16) & 0xfffu) : 0;
+        auto fp_store = [&](const int pr, const unsigned int r0, const unsigned int r1, const int e0) {
+            const int pc = pr & 0xffff, fl = pr >> 16;
+            const int below = fl < 32 ? __popc(r0 & ((1u << fl) - 1u)) : __popc(r0) + __popc(r1 & ((1u << (fl - 32)) - 1u));
+            p.esrc[e0 + below] = GF + fl;
+            p.edst[e0 + below] = p0 + pc;
+        };
+        auto pa_store = [&](const int4 a4, const int k, const int src) {
+            const int c = a4.x, e0 = reg_pa + a4.y, dg = a4.z, ps = a4.w;
+            if (k < dg) {
+                p.esrc[e0 + k] = src;
+                p.edst[e0 + k] = p0 + c;
+                if (p.eorig) p.eorig[e0 + k] = ps + k;
             }
-        }
-        if (p.act_ids && !p.pa_static) {              // the "pa" region, 16 threads per active atom: runs of coalesced stores (kernel-uniform)
-            const int n_act = (int)((all >> 16) & 0xfffu);
-            for (int t = tid; t < n_act * 16; t += NT) {
-                const int4 a4 = L.act4[t >> 4];
-                const int k = t & 15, c = a4.x, e0 = reg_pa + a4.y, dg = a4.z, ps = a4.w;
-                if (k < dg) {
-                    p.esrc[e0 + k] = L.a_src[c][k];
-                    p.edst[e0 + k] = p0 + c;
-                    if (p.eorig) p.eorig[e0 + k] = ps + k;
+            if (k == 15)
+                for (int k2 = 16; k2 < dg; ++k2) {        // (in-degrees beyond 16: their sources were not prefetched)
+                    p.esrc[e0 + k2] = p.esrc[ps + k2];
+                    p.edst[e0 + k2] = p0 + c;
+                    if (p.eorig) p.eorig[e0 + k2] = ps + k2;
                 }
-                if (k == 15)
-                    for (int k2 = 16; k2 < dg; ++k2) {    // (in-degrees beyond 16: their sources were not prefetched)
-                        p.esrc[e0 + k2] = p.esrc[ps + k2];
-                        p.edst[e0 + k2] = p0 + c;
-                        if (p.eorig) p.eorig[e0 + k2] = ps + k2;
-                    }
-            }
+        };
+        {
+            const bool hp = tid < npairs, h0 = tid < n_pa16, h1 = tid + NT < n_pa16;
+            const int pr = L.pairs[hp ? tid : 0];
+            const int4 a40 = L.act4[h0 ? tid >> 4 : 0], a41 = L.act4[h1 ? (tid + NT) >> 4 : 0];
+            const int pc = hp ? (pr & 0xffff) : 0, k = tid & 15;
+            const unsigned int r0 = L.refm[pc][0], r1 = L.refm[pc][1];
+            const int e0 = L.a_e0[pc];
+            const int s0 = L.a_src[h0 ? a40.x : 0][k], s1 = L.a_src[h1 ? a41.x : 0][k];
+            if (hp) fp_store(pr, r0, r1, e0);
+            if (h0) pa_store(a40, k, s0);
+            if (h1) pa_store(a41, k, s1);
+        }
+        for (int t = tid + NT; t < npairs; t += NT) {
+            const int pr = L.pairs[t], pc = pr & 0xffff;
+            fp_store(pr, L.refm[pc][0], L.refm[pc][1], L.a_e0[pc]);
+        }
+        for (int t = tid + 2 * NT; t < n_pa16; t += NT) {
+            const int4 a4 = L.act4[t >> 4];
+            pa_store(a4, t & 15, L.a_src[a4.x][t & 15]);
         }
         if (tid == 0 && p.act_ids) {
             p.dyn_cnt[3 * p.B + g] = p.pa_static ? p.pa_static[g] : (int)(all >> 28);

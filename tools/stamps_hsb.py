@@ -21,11 +21,12 @@ eng.set_batch(px, ph, pptr, fptr, s, d)
 coef = schedule.step_coefficients(schedule.PredefinedNoiseSchedule('polynomial_2', T, 1e-5).gamma, T)
 carr = eng.coef_array(coef, list(range(39, -1, -1)))
 noise = torch.randn(41, B * 6, 9, device=dev)
-G = 1024
+G = 4096
 S = 24
 buf = torch.zeros(G * S, dtype=torch.int64, device=dev)
 lib = eng.lib
 lib.pfk_hsb_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+eng.prepare_timesteps(carr)            # (announced timesteps: the launch also computes the next call's center tables and 'pa' rows)
 eng.sample_begin(noise[0])
 for i in range(30):
     eng.denoise_step(carr[i], noise[i + 1])
@@ -57,8 +58,13 @@ if all(int(st[b, 14]) != 0 for b in builds):     # (only in builds that stamp id
     print("  inside wave 0's neighbour search, from 'coordinates in LDS' (medians): " + " | ".join(f"{statistics.median(us(st[b, k]) - us(st[b, 8]) for b in builds):6.2f}" for k in (14, 15, 16, 17)))
 print("  last build end:", max(us(st[b, 1]) for b in builds))
 if ahead:
-    hoist = [b for b in ahead if b < 224 + 64]
-    spec = [b for b in ahead if b >= 224 + 64]
-    for nm, ws in (("center hoist", hoist), ("speculative pa", spec)):
+    # slot order: node + head | update + build | speculative "pa" items | center hoist (the hoist's workgroups read 19 or more words: they
+    # are the ones whose end comes after eps)
+    late = [b for b in ahead if us(st[b, 1]) > min(us(st[b2, 3]) for b2 in builds)]
+    early = [b for b in ahead if b not in late]
+    for nm, ws in (("ahead workgroups done before eps (speculative pa items)", early), ("ahead workgroups done after eps (center hoist)", late)):
         if ws:
-            print(f"  {nm}: {len(ws)} workgroups, start {min(us(st[b, 0]) for b in ws):.2f} .. {max(us(st[b, 0]) for b in ws):.2f}, end {min(us(st[b, 1]) for b in ws):.2f} .. {max(us(st[b, 1]) for b in ws):.2f}")
+            print(f"  {nm}: {len(ws)}, start {min(us(st[b, 0]) for b in ws):.2f} .. {max(us(st[b, 0]) for b in ws):.2f}, end {min(us(st[b, 1]) for b in ws):.2f} .. {max(us(st[b, 1]) for b in ws):.2f}")
+    noend = [b for b in live if b >= 224 and int(st[b, 1]) == 0]
+    print(f"  slots >= 224 that started and left without an item: {len(noend)}")
+print("what the step computed ahead (pf_debug_ahead):", eng.ahead())
