@@ -241,8 +241,8 @@ struct EdgeParams {
     // ([Np][3], never written) instead of the per-step shifted copy -- the same bits in every step, and no race with the update + build
     // that shifts xn while speculative pp items of the next call read it.  NULL: xn (pf_dynamics_forward with other coordinates).
     const float* x0_static;
-    // [B] or NULL: graphs whose "pa" region this launch skips -- their partial rows were computed ahead (k_n16_pa_spec) and the previous
-    // step's build found the region unchanged (BuildParams::pa_same)
+    // [B] or NULL: per graph, the number of leading 16-slot groups of the "pa" region this launch skips -- their partial rows were
+    // computed ahead (the previous step's last launch) and that step's build found the region unchanged up to there (BuildParams::pa_same)
     const int* pa_skip;
 };
 
@@ -489,8 +489,10 @@ struct BuildParams {
     // atoms depend on the timestep, the element types and the STATIC pocket geometry only -- not on the centers -- so the NEXT call's
     // can be computed while this step's latency-bound last launch runs, for the active atoms of THIS call; they are the next call's if its
     // "pa" region comes out the same.  The build says so per graph: pa_stamp[atom] = step_id for every active atom; an atom counts as
-    // unchanged if it carried step_id - 1 and its slot-2 in-edge range is the one it had; pa_same[g] = 1 iff no atom of graph g changed
-    // (none joined, none left, none moved).  NULL: off.
+    // unchanged if it carried step_id - 1 and its slot-2 in-edge range is the one it had; pa_same[g] = the number of leading 16-slot groups
+    // of graph g's region in front of the first slot at which anything changed (an atom joined, left or moved): 0x7fffffff when nothing
+    // did.  A group's partial rows depend on its own 16 slots only, so the groups in front of the first change are the rows computed
+    // ahead, bit for bit.  NULL: off.
     int* pa_stamp; int step_id; int* pa_same;
 };
 

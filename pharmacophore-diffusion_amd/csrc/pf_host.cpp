@@ -3396,7 +3396,11 @@ int pf_debug_ahead(pf_handle* h, int64_t* out, pf_stream stream) {
         std::vector<int> cnt((size_t)5 * B), same(B);
         PF_HIP(h, hipMemcpy(cnt.data(), h->d_dyn_cnt, (size_t)5 * B * 4, hipMemcpyDeviceToHost));
         PF_HIP(h, hipMemcpy(same.data(), h->d_pa_same, (size_t)B * 4, hipMemcpyDeviceToHost));
-        for (int g = 0; g < B; ++g) { out[1] += cnt[(size_t)3 * B + g]; if (same[g]) out[0] += cnt[(size_t)3 * B + g]; }
+        for (int g = 0; g < B; ++g) {                      // same[g]: leading 16-slot groups of the region that still apply (BuildParams::pa_same)
+            const int64_t c = cnt[(size_t)3 * B + g];
+            out[1] += c;
+            out[0] += std::min<int64_t>(c, (int64_t)std::min(same[g], 1 << 26) * 16);
+        }
     }
     if (h->cen_valid) { out[2] = 1; out[3] = h->Nf; }
     return PF_OK;

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_n16_edge(const int* __restrict__ a_dyn_
             if (64 * k < a_nreg) {
                 const int r = min(64 * k + lane, a_nreg - 1);
                 int c = a_dyn_cnt[r];
-                if (L0 && p.pa_skip && r >= 3 * a_regB && p.pa_skip[r - 3 * a_regB]) c = 0;      // (see k_n16_edge_u)
+                if (L0 && p.pa_skip && r >= 3 * a_regB && p.pa_skip[r - 3 * a_regB] >= ((c + 15) >> 4)) c = 0;      // (see k_n16_edge_u; a partly valid region is computed whole here)
                 rs[k] = a_reg[r];
                 cs[k] = 64 * k + lane < a_nreg ? c : 0;
             }
@@ -196,10 +196,12 @@ __global__ __launch_bounds__(256) void k_n16_edge_u(const int* __restrict__ a_dy
     // ---- "pa" items: the (w - static items)-th non-empty 16-slot group of the B regions of kind 3 (one scan pass: B <= 64)
     w -= nff + npf + nfp;
     const int r = 3 * a_B + min(lane, a_B - 1);
-    int c = lane < a_B ? a_dyn_cnt[r] : 0;
-    if (p.pa_skip && p.pa_skip[min(lane, a_B - 1)]) c = 0;      // this graph's "pa" rows were computed ahead (k_n16_pa_spec) and still apply
+    const int c = lane < a_B ? a_dyn_cnt[r] : 0;
+    // the leading groups of this graph's region whose rows were computed ahead by the previous step's last launch and still apply
+    // (BuildParams::pa_same: all of them when the graph's active set did not change, those in front of the first change otherwise)
+    const int keep = p.pa_skip ? min(p.pa_skip[min(lane, a_B - 1)], (c + 15) >> 4) : 0;
     const int rs = a_reg[r];
-    const int ng = (c + 15) >> 4;
+    const int ng = ((c + 15) >> 4) - keep;
     int incl = ng;
     incl += dpp_i<0x111>(incl); incl += dpp_i<0x112>(incl); incl += dpp_i<0x114>(incl); incl += dpp_i<0x118>(incl);
     incl += dpp_ir<0x142, 0xa>(incl); incl += dpp_ir<0x143, 0xc>(incl);
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void k_n16_edge_u(const int* __restrict__ a_dy
     const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
     const int first = __builtin_amdgcn_readlane(incl - ng, l);
     const int cnt = __builtin_amdgcn_readlane(c, l), start = __builtin_amdgcn_readlane(rs, l);
-    const int loc = (w - first) << 4;
+    const int loc = (w - first + __builtin_amdgcn_readlane(keep, l)) << 4;
     const int e0 = start + loc;
     const int nv = __builtin_amdgcn_readfirstlane(min(16, cnt - loc));
     const int e = e0 + min(j, nv - 1);

@@ -287,7 +287,7 @@ struct __attribute__((aligned(16))) StepBuildLds {
     // the compact copy of the active atoms' pp in-edges ("pa" region) is written by 16 threads per active atom from a_src -- the
     // first 16 static sources of EVERY atom (prefetched, indexed by atom); thread 15 of an atom also copies what lies beyond 16
     __attribute__((aligned(16))) int4 act4[SB_MAXA];   // [j-th active atom] = (atom, first slot in the region, in-degree, static in-edge start)
-    int chg;                                    // BuildParams::pa_same: set by any atom whose place in the "pa" region changed
+    int chgmin;                                 // BuildParams::pa_same: the first slot of the "pa" region (relative) at which anything changed
     __attribute__((aligned(16))) int a_src[SB_MAXA][16];
 };
 
@@ -441,7 +441,7 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
 #pragma unroll
     for (int a = 0; a < APT; ++a) { isp[a] = q.isp[a]; xp[a] = q.xp[a]; pst[a] = q.pst[a]; pdeg[a] = q.pdeg[a]; }
     if constexpr (!STAGED) sb_stage_sources<NT>(q, p, L);
-    if (tid == 0) L.chg = 0;                          // (read behind three barriers)
+    if (tid == 0) L.chgmin = 0x7fffffff;              // (written behind three barriers, read behind a fourth)
     // ---- feature update of the pharm nodes (pharmacodiff.py:414-420; independent of everything else, inputs in registers)
     if constexpr (FEAT) {
         if (isf) {
@@ -632,10 +632,17 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
             // an active atom: its place in the list and (unless the pocket's pp messages are shared) the slots of the "pa" region
             // that receive the compact copy of its static pp in-edges
             if (p.pa_stamp && isp[a]) {
-                // unchanged = active in the previous step too, at the same slots (its stamp is that step's, its slot-2 range the same)
+                // unchanged = active in the previous step too, at the same slots (its stamp is that step's, its slot-2 range the same).
+                // The region is valid up to the first slot anything changed at: where a new or moved atom now starts, where a moved
+                // or departed atom used to start
                 const bool was = q.ostamp[a] == p.step_id - 1;
-                const bool same = act[a] ? (was && !p.pa_static && q.ost[a] == reg_pa + (int)(o >> 28) && q.ocn[a] == deg[a]) : !was;
-                if (!same) L.chg = 1;
+                const int nd0 = (int)(o >> 28), od0 = q.ost[a] - reg_pa;
+                int first = 0x7fffffff;
+                if (act[a]) {
+                    const bool same = was && !p.pa_static && od0 == nd0 && q.ocn[a] == deg[a];
+                    if (!same) first = was ? min(od0, nd0) : nd0;
+                } else if (was) first = od0;
+                if (first != 0x7fffffff) atomicMin(&L.chgmin, max(first, 0));
                 if (act[a]) p.pa_stamp[p0 + c] = p.step_id;
             }
             if (isp[a] && act[a]) {
@@ -702,7 +709,8 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
         if (tid == 0 && p.act_ids) {
             p.dyn_cnt[3 * p.B + g] = p.pa_static ? p.pa_static[g] : (int)(all >> 28);
             p.dyn_cnt[4 * p.B + g] = (int)((all >> 16) & 0xfffu);
-            if (p.pa_same) p.pa_same[g] = (L.chg == 0 && !p.pa_static) ? 1 : 0;
+            // the number of leading 16-slot groups of the region whose rows, computed ahead, still apply (everything: 0x7fffffff)
+            if (p.pa_same) p.pa_same[g] = p.pa_static ? 0 : (L.chgmin == 0x7fffffff ? 0x7fffffff : (L.chgmin >> 4));
         }
         if (tid == NT - 64 && p.norm_mode == 2) {     // per-graph normalisers for message_norm == 0 (gvp.py:504-507)
             const int cpf = p.pfq_cnt ? p.pfq_cnt[g] : Nf * kk;
