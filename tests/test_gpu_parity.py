@@ -520,7 +520,7 @@ def test_endpoint_parameterisation_step():
     close(x0, ox, 1e-3, 1e-3); close(h0, oh, 1e-3, 1e-3)
 
 
-@pytest.mark.parametrize("case", ["knn_pf", "knn_ff", "graph_norm", "endpoint", "near_ties"])
+@pytest.mark.parametrize("case", ["knn_pf", "knn_ff", "graph_norm", "endpoint", "near_ties", "near_ties_k16"])
 def test_fused_update_and_edge_build_variants_agree(case, monkeypatch):
     """A denoising step ends with k_step_build_fast (sampler update + the next call's edge build, one atom per
     thread, three dependent global round trips) when pf edges are kNN and pockets have at most 512 atoms.  It must
@@ -528,11 +528,14 @@ def test_fused_update_and_edge_build_variants_agree(case, monkeypatch):
     path bit for bit: same edge sets, same orderings, same arithmetic -- ragged batch, several steps.  (The optional tail
     launch, which runs the same fast body behind the node update + head: test_gpu_n16.py::test_tail_launch_steps_equal_separate_launches.)"""
     monkeypatch.setenv("PFDYN_NO_CENTER_HOIST", "1")       # (only the merged launch leaves the center-hoist tables: its own test compares them)
-    kw = dict(ff_k=3) if case == "knn_ff" else (dict(message_norm=0) if case == "graph_norm" else {})
+    kw = dict(ff_k=3) if case == "knn_ff" else (dict(message_norm=0) if case == "graph_norm" else (dict(pf_k=16) if case == "near_ties_k16" else {}))
     cfg = O.DynamicsConfig(**kw)
     sd = O.make_state_dict(cfg, 3)
-    batch = O.synthetic_batch([61, 62, 63, 64], [300, 256, 300, 256] if case == "near_ties" else 300, [3, 8, 5, 6], cfg)
-    if case == "near_ties":
+    ties = case.startswith("near_ties")
+    # (near_ties_k16: 16 neighbours per center -- the selected keys fill a whole row of 16 lanes and the extra one sits in the next row --
+    # and 40 / 33 centers in a graph: several rounds of the search per wave, fp reference masks beyond 32 bits)
+    batch = O.synthetic_batch([61, 62, 63, 64], [300, 256, 300, 256] if ties else 300, [40, 12, 33, 6] if case == "near_ties_k16" else [3, 8, 5, 6], cfg)
+    if ties:
         # The fast body's neighbour search orders truncated distance keys (pf_stepbuild.h: knn_halfwave_keys) and must notice when
         # that is not exact: 100-120 atoms of every pocket get a twin one or two ulps away along x (both directions, so the nearer
         # twin has the larger index half of the time), ~30 an exact duplicate -- the generic body orders by (d^2, index) on the full
