@@ -26,6 +26,7 @@
 #include <algorithm>
 #include "pf_device.h"
 #ifdef N16_STAMPS
+#define N16_STAMP_GLOBALS 1
 namespace {
 __device__ unsigned long long* g_n16_stamps = nullptr;
 __device__ int g_n16_stamp_off = 0;                   // first recorded workgroup
@@ -173,6 +174,9 @@ __global__ __launch_bounds__(256) void k_n16_edge_u(const int* __restrict__ a_dy
     const int gff = (a_s2g >> 16) & 7, gpf = (a_s2g >> 19) & 7, gfp = (a_s2g >> 22) & 7, a_B = (int)((unsigned)a_s2g >> 25) + 1;
     const int nff = a_B * gff, npf = a_B * gpf, nfp = a_B * gfp;
     int w = (int)blockIdx.x;
+#ifdef EDGE_U_SWAP                                        // (diagnostic: ff and fp items trade places in the grid; needs nff == nfp)
+    if (w < nff) w += nff + npf; else if (w >= nff + npf && w < nff + npf + nfp) w -= nff + npf;
+#endif
     if (w < nff + npf + nfp) {
         int et, base, stride, gk;
         if (w < nff) { et = ET_FF; base = a_b0; stride = a_s01 & 0xffff; gk = gff; }

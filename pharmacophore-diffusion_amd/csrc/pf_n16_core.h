@@ -125,7 +125,7 @@ __device__ __forceinline__ void ring_start(N16Ring& r, pf_gcf stream, const int 
 // every wave of 64 workgroups writes s_memtime at the phase boundaries of n16_block.  The stamp counter `sk` carries the
 // kernel's id in bits 8.. (k_n16_edge<true> 0, <false> 1, k_n16_fused 2, k_n16_tail 3, k_n16_unit 4): g_n16_stamp_kid >= 0
 // records that kernel only (a step runs three of them over the same buffer)
-#ifdef N16_STAMPS
+#if defined(N16_STAMPS) && defined(N16_STAMP_GLOBALS)     // (pf_n16.hip declares the stamp buffer's symbols in front of this header; pf_rg.hip does not stamp)
 #define N16_STAMP(sk, lane, wq)                                                                                        \
     do {                                                                                                               \
         const int rb_ = (int)blockIdx.x - g_n16_stamp_off;                                                             \
@@ -139,7 +139,7 @@ __device__ __forceinline__ void ring_start(N16Ring& r, pf_gcf stream, const int 
 #endif
 // the five stamps inside every n16_block (-DN16_STAMPS_SPARSE: off -- each stamp waits for the wave's outstanding LDS
 // operations, and five per block stretch a chain by ~50 %; the sparse form keeps the phase boundaries outside the blocks)
-#if defined(N16_STAMPS) && !defined(N16_STAMPS_SPARSE)
+#if defined(N16_STAMPS) && defined(N16_STAMP_GLOBALS) && !defined(N16_STAMPS_SPARSE)
 #define N16_STAMP_B(sk, lane, wq) N16_STAMP(sk, lane, wq)
 #else
 #define N16_STAMP_B(sk, lane, wq) do { } while (0)

@@ -33,6 +33,7 @@ KID = int(os.environ.get("KID", "-1"))
 if hasattr(lib, "pfk_n16_set_stamp_kernel"):
     lib.pfk_n16_set_stamp_kernel.argtypes = [ctypes.c_int]
     lib.pfk_n16_set_stamp_kernel(KID)
+eng.prepare_timesteps(carr)            # (the shipped path: center tables and 'pa' rows computed ahead)
 eng.sample_begin(noise[0])
 for i in range(30):
     eng.denoise_step(carr[i], noise[i + 1])

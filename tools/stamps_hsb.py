@@ -68,3 +68,7 @@ if ahead:
     noend = [b for b in live if b >= 224 and int(st[b, 1]) == 0]
     print(f"  slots >= 224 that started and left without an item: {len(noend)}")
 print("what the step computed ahead (pf_debug_ahead):", eng.ahead())
+if os.environ.get("HSB_DUMP"):                  # start + duration of every ahead workgroup, by slot
+    rows = [(b, us(st[b, 0]), us(st[b, 1])) for b in range(224, G) if int(st[b, 1]) != 0]
+    for k in range(0, len(rows), 8):
+        print(" ".join(f"{b}:{s_:.1f}+{e_ - s_:.1f}" for b, s_, e_ in rows[k:k + 8]))
