@@ -171,6 +171,11 @@ __global__ __launch_bounds__(256) void k_n16_edge_u(const int* __restrict__ a_dy
     const int j = lane & 15;
     int sk = 0;
     N16_STAMP(sk, lane, wq);                              // kernel entry
+#ifdef N16_STAMPS                                         // (kernel filter 100: start / end of every workgroup on the device-wide 100 MHz clock instead)
+    struct WgTimes { __device__ ~WgTimes() { if (on) g_n16_stamps[(size_t)blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime(); } bool on; } wgt_;
+    wgt_.on = g_n16_stamp_kid == 100 && g_n16_stamps && threadIdx.x == 0 && blockIdx.x < 8192;
+    if (wgt_.on) g_n16_stamps[(size_t)blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int gff = (a_s2g >> 16) & 7, gpf = (a_s2g >> 19) & 7, gfp = (a_s2g >> 22) & 7, a_B = (int)((unsigned)a_s2g >> 25) + 1;
     const int nff = a_B * gff, npf = a_B * gpf, nfp = a_B * gfp;
     int w = (int)blockIdx.x;
@@ -641,6 +646,11 @@ __global__ __launch_bounds__(256) void k_n16_fused_u(const int* __restrict__ a_d
     const int j = lane & 15;
     int sk = 2 << 8;
     N16_STAMP(sk, lane, wq);                              // kernel entry
+#ifdef N16_STAMPS                                         // (kernel filter 101: start / end of every workgroup on the device-wide 100 MHz clock)
+    struct WgTimes { __device__ ~WgTimes() { if (on) g_n16_stamps[(size_t)blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime(); } bool on; } wgt_;
+    wgt_.on = g_n16_stamp_kid == 101 && g_n16_stamps && threadIdx.x == 0 && blockIdx.x < 8192;
+    if (wgt_.on) g_n16_stamps[(size_t)blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+#endif
     float XS[32], VB[4];
     const int nffg = a_groups & 255, npfg = (a_groups >> 8) & 255, a_B = (int)((unsigned)a_groups >> 16);
     const int b = (int)blockIdx.x, x = b & 7, kq = b >> 3;
