@@ -370,6 +370,10 @@ struct FusedParams {
     // every graph's ff / pf region has the same capacity (k_n16_fused_u): first region's start, stride between graphs' regions
     // (ff | pf << 16), 16-slot groups per region (ff | pf << 8); uni_groups == 0: off
     int uni_ff_base, uni_pf_base, uni_strides, uni_groups;
+    // edge records of the ff / pf slots (BuildParams::rec, written by the previous step's update + build), or NULL: what an edge item's
+    // prologue otherwise collects in two dependent round trips -- slot -> (source, destination) -> the source's in-edge descriptors,
+    // element type and both coordinates -- in one
+    const int4* rec;
     const float* hcen;                               // center hoist: the centers' encoder outputs [Nf][128] (residual input of their node update), or NULL
 };
 
@@ -494,6 +498,13 @@ struct BuildParams {
     // did.  A group's partial rows depend on its own 16 slots only, so the groups in front of the first change are the rows computed
     // ahead, bit for bit.  NULL: off.
     int* pa_stamp; int step_id; int* pa_same;
+    // edge records for the NEXT call's fused launch (FusedParams::rec; pf_stepbuild.h only), three 16-byte words per ff / pf slot e:
+    //   [3 e]     source coordinates (shifted), source node | element type << 24 (atoms)
+    //   [3 e + 1] destination coordinates, destination node
+    //   [3 e + 2] the SOURCE's conv-layer-0 in-edge descriptors: slot 0 (ff | fp) start, count; second segment (a center's pf, an atom's
+    //             "pa" region) start, count -- the values in_start / in_cnt hold for it
+    // ptype: element type per atom (the static hoist's), needed for the records.  NULL: no records.
+    int4* rec; const int* ptype;
 };
 
 struct StepParams {

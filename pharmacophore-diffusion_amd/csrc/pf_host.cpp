@@ -160,6 +160,7 @@ struct LaunchPolicy {
     // at config 2 (PFDYN_XCD_SPLIT=0: off).  The same idea on the conv-layer-0 launch (pa / pf items on five XCDs, ff / fp items on three)
     // LOST 1.6 us: that launch is throughput-bound with two items per compute unit, and the split unbalances it (profiles/r04)
     int xcd_split = 1;
+    int edge_rec = 1;                          // PFDYN_EDGE_REC: edge records for the fused launch (BuildParams::rec)
     int node_static = 1;                    // ... with its tiles computed, not loaded (k_rg_node_hs; PFDYN_NODE_STATIC=0: the tile-list kernel)
     int node_xcds = 2;                      // the fused node + head launch of a small batch runs on this many XCDs (PFDYN_NODE_XCDS; 0: all eight)
     int fused_uni = 1;                      // the fused launch's arithmetic tiling when every graph's regions have one capacity (PFDYN_FUSED_UNI)
@@ -202,6 +203,7 @@ struct LaunchPolicy {
         geti("PFDYN_N16", n16_mask);
         geti("PFDYN_TAIL_GRAPHS_MAX", tail_graphs_max);
         geti("PFDYN_XCD_SPLIT", xcd_split);
+        geti("PFDYN_EDGE_REC", edge_rec);
         geti("PFDYN_NODE_XCDS", node_xcds); geti("PFDYN_NODE_STATIC", node_static); geti("PFDYN_HS_BUILD", hs_build); geti("PFDYN_FUSED_UNI", fused_uni); geti("PFDYN_XCHG_SLEEP", xchg_sleep); geti("PFDYN_HSB_AVOID", hsb_avoid);
         if (const char* e = getenv("PFDYN_TAIL_FORM")) tail_form = (e[0] == 'n' || atoi(e) == 16) ? 16 : 4;
         if (const char* e = getenv("PFDYN_N16_ROWS_MAX")) n16_rows_max = n16_fuse_rows_max = atol(e);
@@ -391,6 +393,9 @@ struct pf_handle {
     float* d_ptab = nullptr;                // [L0_PTAB_SLOTS][L0_NTAB][rec_nf][128] tables of the timesteps seen (scalar-t calls)
     std::unordered_map<uint32_t, int> ptab_slot;
     int *d_eorig = nullptr, *d_ptype = nullptr, *d_l0flag = nullptr;
+    // edge records of the ff / pf slots (BuildParams::rec / FusedParams::rec): written by the merged launch's update + build for the next
+    // call's fused launch; rec_valid: the edges in place are the ones that build emitted, with their records
+    int4* d_rec = nullptr; bool rec_valid = false;
     float *d_zs = nullptr, *d_ptab_pg = nullptr;
     bool enc_on_the_fly = true;             // PFDYN_NO_ENC_FLY=1: always launch the encoders
     bool step_build_fast = true;            // PFDYN_NO_FAST_BUILD=1: the generic update + build bodies
@@ -969,7 +974,8 @@ static bool share_now(pf_handle* h) {
     return h->share_ok && !h->share_disable && h->prune && c.n_convs == 2 && h->rg_compact && l0_hoist_ok(h);
 }
 // a build with these parameters has been enqueued: its stamp is what the next shared edge launch looks for
-static void build_done(pf_handle* h, bool share) {
+static void build_done(pf_handle* h, bool share, bool with_records = false) {
+    h->rec_valid = with_records;
     h->edges_share = share;
     if (share) h->edges_stamp = ++h->need_stamp;
 }
@@ -1340,6 +1346,8 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
         }
         if (fuse_l0node && l == 0) {       // no node launch: the last layer's edge items (and its store items) compute these rows
             fz.in_start = n.in_start; fz.in_cnt = n.in_cnt; fz.N = n.N; fz.pp_slot = n.pp_slot;
+            // (records describe the sources' in-edges as the update + build left them: the "pa" region as an atom's second segment)
+            fz.rec = (h->rec_valid && h->d_rec && n.pp_slot == 2 && !shared) ? h->d_rec : nullptr;
             fz.msg_s = n.msg_s; fz.msg_v = n.msg_v; fz.zero_row = n.zero_row; fz.grp = n.grp; fz.grp_pa = n.grp_pa;
             fz.gid = n.gid; fz.gnorm = n.gnorm; fz.B = n.B; fz.norm_mode = n.norm_mode; fz.norm_value = n.norm_value;
             for (int nt = 0; nt < 2; ++nt) {
@@ -1450,9 +1458,12 @@ static int run_dynamics(pf_handle* h, float* eps_h, float* eps_x, hipStream_t s,
                         h->cen_valid = true; h->cen_t = t_next; h->cen_wver = h->w_version;
                     }
                     const bool share_next = (h->prune && c.n_convs == 2) && share_now(h);     // what the next denoising step's dynamics call will ask for
-                    const BuildParams bpn = build_params(h, share_next);
+                    BuildParams bpn = build_params(h, share_next);
+                    // edge records for the next call's fused launch: radius ff edges, compact "pa" regions, the static hoist's element types
+                    const bool with_rec = h->d_rec && !share_next && c.ff_k == 0 && bpn.act_ids && !bpn.pa_static && h->last_hoist == 16 && fuse_l0node;
+                    if (with_rec) { bpn.rec = h->d_rec; bpn.ptype = h->d_ptype; }
                     { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node_hs_build(&n, &hp, step, &bpn, h->d_xstat, h->pol.xchg_sleep, h->pol.hsb_avoid, h->xchg_poll_max, &cp, &es, &ees, spec_groups, s); }
-                    build_done(h, share_next);
+                    build_done(h, share_next, with_rec);
                     h->tail_done = true; h->last_tail = 2;
                 } else { ProfScope ps(h, pf_handle::K_HEAD, s); pfk_rg_node(&n, &hp, enc_fly ? &ep : nullptr, l == 0, rgn, nsplit, s); }
                 head_done = true;
@@ -2243,6 +2254,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     // (a second set of message rows for the last conv layer: the fused launch of small n_convs = 2 batches writes them while conv
     // layer 0's are still being read)
     const bool msg2 = c.n_convs == 2 && (long)h->n_edge_tiles_act * 32 <= h->pol.n16_rows_max;
+    const int64_t rec_slots = B <= 64 ? Ecap : 0;      // edge records: small batches only (the n16 fused launch)
     const size_t o_xn = place((size_t)N * 16),
                  o_fh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_t = place((size_t)B * 4),
                  o_h0 = place((size_t)N * PF_S * 4), o_h1 = place((size_t)N * PF_S * 4), o_v0 = place((size_t)N * 48 * 4), o_v1 = place((size_t)N * 48 * 4),
@@ -2250,6 +2262,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
                  o_ms2 = place(msg2 ? (size_t)(Ecap + 1) * PF_S * 4 : 16), o_mv2 = place(msg2 ? (size_t)(Ecap + 1) * 48 * 4 : 16),
                  o_eh = place((size_t)Nf * c.pharm_nf * 4 + 16), o_ex = place((size_t)Nf * 3 * 4 + 16), o_c0 = place((size_t)B * 3 * 4), o_c1 = place((size_t)B * 3 * 4),
                  o_pre = place((size_t)std::max(Np, 1) * PF_S * 4), o_eorig = place(Ecap * 4), o_ptype = place((size_t)std::max(Np, 1) * 4),
+                 o_rec = place((size_t)(h->pol.edge_rec ? 3 * rec_slots : 0) * 16 + 16),
                  o_zs = place((size_t)std::max<int64_t>(n_pp, 1) * PF_S * 4), o_ptpg = place((size_t)B * L0_NTAB * c.rec_nf * PF_S * 4),
                  o_xchg = place((size_t)2 * std::max(Nf, 1) * PF_XCHG_STRIDE * sizeof(unsigned int)),      // (+ the center hoist's copy)
                  o_cenh = place((size_t)std::max(Nf, 1) * PF_S * 4), o_cenp = place((size_t)2 * std::max(Nf, 1) * PF_S * 4),
@@ -2305,6 +2318,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     h->d_msg_s = (float*)at(o_ms); h->d_msg_v = (float*)at(o_mv); h->d_eps_h = (float*)at(o_eh); h->d_eps_x = (float*)at(o_ex);
     h->d_com_init = (float*)at(o_c0); h->d_com_tmp = (float*)at(o_c1); h->d_pre = (float*)at(o_pre); h->d_eorig = (int*)at(o_eorig);
     h->d_ptype = (int*)at(o_ptype); h->d_zs = (float*)at(o_zs); h->d_ptab_pg = (float*)at(o_ptpg);
+    h->d_rec = (h->pol.edge_rec && rec_slots > 0) ? (int4*)at(o_rec) : nullptr; h->rec_valid = false;
     h->d_xchg = (unsigned int*)at(o_xchg); h->d_lpart = (float*)at(o_lpart);
     h->d_xchg2 = h->d_xchg + (size_t)std::max(Nf, 1) * PF_XCHG_STRIDE;
     h->d_cen_h = (float*)at(o_cenh); h->d_cen_p = (float*)at(o_cenp);

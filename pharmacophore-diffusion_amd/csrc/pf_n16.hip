@@ -504,20 +504,30 @@ __device__ __forceinline__ void n16_fused_store_item(const FusedParams& f, const
     }
 }
 // ---- edge item of the fused launch: row j = edge slot e (source src, destination dst; rows beyond nv shadow row nv - 1)
+// rec: the row's edge record (FusedParams::rec: three 16-byte words) or NULL
 __device__ __forceinline__ void n16_fused_edge_item(const EdgeParams& p, const FusedParams& f, const EncodeParams& ep, N16Lds* lds, const int e,
                                                     const int src, const int dst, const int nv, const int et, float (&XS)[32],
-                                                    float (&VB)[4], const int lane, const int wq, int& sk) {
+                                                    float (&VB)[4], const int lane, const int wq, int& sk, const int4* rec = nullptr) {
     N16Ring ring;
     ring_start(ring, f.chain[et] + (size_t)wq * f.chain_stride[et], lane);
     N16Rows rw;
     rw.e = e;
     rw.dst = dst;
-    // one level of loads: coordinates, the source's in-edge descriptors, its element type
     const int nt = et == ET_FF ? 1 : 0;
-    rw.xs = p.xn[src]; rw.xd = p.xn[dst];
     NodeDesc nd;
-    n16_node_desc_l0(f, src, nt, nd);
-    const int pty = nt == 0 ? f.ptype[src] : 0;
+    int pty;
+    if (rec) {                                           // (workgroup-uniform) the slot's edge record: everything of this level, already here
+        rw.xs = make_float4(__builtin_bit_cast(float, rec[0].x), __builtin_bit_cast(float, rec[0].y), __builtin_bit_cast(float, rec[0].z), 0.f);
+        rw.xd = make_float4(__builtin_bit_cast(float, rec[1].x), __builtin_bit_cast(float, rec[1].y), __builtin_bit_cast(float, rec[1].z), 0.f);
+        nd.st[0] = rec[2].x; nd.cn[0] = rec[2].y; nd.st[1] = rec[2].z; nd.cn[1] = rec[2].w;
+        nd.gm[0] = f.grp - 1; nd.gm[1] = (nt == 0 ? f.grp_pa : f.grp) - 1;
+        pty = (int)((unsigned)rec[0].w >> 24);
+    } else {
+        // one level of loads: coordinates, the source's in-edge descriptors, its element type
+        rw.xs = p.xn[src]; rw.xd = p.xn[dst];
+        n16_node_desc_l0(f, src, nt, nd);
+        pty = nt == 0 ? f.ptype[src] : 0;
+    }
     n16_node_update_l0(f, ep, ring, src, nt, nd, pty, XS, VB, lds, lane, wq, sk);
     N16_CUT_AT(FUSED_CUT, 3, XS[0] + VB[0] + rw.xs.x + rw.xd.x, f.h_out);
     f32x4 S[2];
@@ -674,6 +684,22 @@ __global__ __launch_bounds__(256) void k_n16_fused_u(const int* __restrict__ a_d
     // one level: the region's count and the 16 slots of the group (inside the region's 32-aligned capacity whatever the count;
     // slots beyond the count hold stale ids, which are never dereferenced: the rows beyond nv shadow row nv - 1)
     const int cnt = a_dyn_cnt[cidx];
+    if (f.rec) {                                         // (kernel-uniform) the slots' edge records instead of their end points: one level less
+        const int4* rp = f.rec + (size_t)3 * (e0 + j);
+        int4 r[3] = {rp[0], rp[1], rp[2]};
+        const int nv = __builtin_amdgcn_readfirstlane(min(16, cnt - 16 * k));
+        if (nv <= 0) return;                             // workgroup-uniform
+        N16_STAMP(sk, lane, wq);                          // item known
+        const int jj = min(j, nv - 1);
+        const int from = 4 * ((lane & 48) | jj);         // (rows beyond nv shadow row nv - 1: its record, through the LDS crossbar)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            r[u].x = __builtin_amdgcn_ds_bpermute(from, r[u].x); r[u].y = __builtin_amdgcn_ds_bpermute(from, r[u].y);
+            r[u].z = __builtin_amdgcn_ds_bpermute(from, r[u].z); r[u].w = __builtin_amdgcn_ds_bpermute(from, r[u].w);
+        }
+        n16_fused_edge_item(p, f, ep, &lds, e0 + jj, r[0].w & 0xffffff, r[1].w, nv, et, XS, VB, lane, wq, sk, r);
+        return;
+    }
     const int src_raw = a_esrc[e0 + j], dst_raw = a_edst[e0 + j];
     const int nv = __builtin_amdgcn_readfirstlane(min(16, cnt - 16 * k));
     if (nv <= 0) return;                                 // workgroup-uniform

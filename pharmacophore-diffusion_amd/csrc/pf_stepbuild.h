@@ -287,6 +287,9 @@ struct __attribute__((aligned(16))) StepBuildLds {
     // the compact copy of the active atoms' pp in-edges ("pa" region) is written by 16 threads per active atom from a_src -- the
     // first 16 static sources of EVERY atom (prefetched, indexed by atom); thread 15 of an atom also copies what lies beyond 16
     __attribute__((aligned(16))) int4 act4[SB_MAXA];   // [j-th active atom] = (atom, first slot in the region, in-degree, static in-edge start)
+    int2 a_pa[SB_MAXA];                         // BuildParams::rec: per ACTIVE atom, its "pa" descriptor (first slot absolute, in-degree)
+    int2 ffd[PF_MAXF];                          // BuildParams::rec: per center, its ff in-edge descriptor (first slot absolute, count)
+    unsigned char a_ty[SB_MAXA];                // BuildParams::rec: per atom, its element type
     int chgmin;                                 // BuildParams::pa_same: the first slot of the "pa" region (relative) at which anything changed
     __attribute__((aligned(16))) int a_src[SB_MAXA][16];
 };
@@ -319,6 +322,7 @@ struct SbPre {
     float nzx[3];
     float hv[SB_MAXNF], nzh[SB_MAXNF];              // the center's features and their noise (threads tid < Nf; nf <= SB_MAXNF)
     int pst[APT], pdeg[APT], psrc[APT][16];
+    int pty[APT];                                   // BuildParams::rec: the atom's element type
     int ost[APT], ocn[APT], ostamp[APT];            // BuildParams::pa_same: the atom's slot-2 range and stamp as the previous step left them
 };
 // (A) the graph's pointers and regions (scalar loads)
@@ -379,6 +383,8 @@ __device__ __forceinline__ void sb_load_b(SbPre<NT>& q, const int a_Np_tot, cons
             q.pst[a] = q.isp[a] ? s0 : 0;
             q.pdeg[a] = q.isp[a] ? d0 : 0;
         }
+        q.pty[a] = 0;
+        if (p.rec) q.pty[a] = p.ptype[arow];                          // kernel-uniform
         q.ost[a] = 0; q.ocn[a] = 0; q.ostamp[a] = 0;
         if (p.pa_stamp) {                                             // kernel-uniform
             q.ost[a] = p.in_start[2 * p.N + arow]; q.ocn[a] = p.in_cnt[2 * p.N + arow]; q.ostamp[a] = p.pa_stamp[arow];
@@ -491,6 +497,7 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
         const int c = sb_atom<NT>(tid, a);
         if (isp[a]) { xp[a].x -= com[0]; xp[a].y -= com[1]; xp[a].z -= com[2]; sp.xn[p0 + c] = xp[a]; }
         if (a == 0 || two) {                          // (the neighbour search reads atoms beyond NT only when there are any)
+            if (p.rec) L.a_ty[c] = (unsigned char)q.pty[a];
             L.px[c] = xp[a];
             L.refm[c][0] = 0u; L.refm[c][1] = 0u;
         }
@@ -523,11 +530,14 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
         const int incl = (int)wave_incl_scan_u32((unsigned int)c);
         ff_total = __builtin_amdgcn_readlane(incl, 63);
         if (lane == 0) p.dyn_cnt[0 * p.B + g] = ff_total;
+        const int my_e0 = reg_ff + incl - c;
         if (lane < Nf) {
-            int e = reg_ff + incl - c;
-            in_start0[GF + lane] = e;
+            in_start0[GF + lane] = my_e0;
             in_cnt0[GF + lane] = c;
-            if (p.ff_k > 0) {
+        }
+        if (p.ff_k > 0) {                                 // (kernel-uniform; no edge records in this mode: the host does not ask for them)
+            if (lane < Nf) {
+                int e = my_e0;
                 unsigned long long prev = 0ull;
                 bool first = true;
                 for (int qq = 0; qq < kff; ++qq) {
@@ -542,8 +552,36 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
                     p.edst[e] = GF + lane;
                     ++e;
                 }
-            } else {
-                while (inr) { const int jn = __ffsll((long long)inr) - 1; inr &= inr - 1; p.esrc[e] = GF + jn; p.edst[e] = GF + lane; ++e; }
+            }
+        } else {
+            // every lane walks its in-range centers in ascending order; the loop is wave-uniform (as many rounds as the longest list) so
+            // that, for BuildParams::rec, an edge's record can take the SOURCE center's descriptors and coordinates out of lane jn's
+            // registers through the LDS crossbar (ds_bpermute reads active lanes only: five requests in flight, no memory)
+            const float4 my_x = L.fx[min(lane, max(Nf - 1, 0))];
+            const int kk_pf = min(p.pf_k, Np);
+            int e = my_e0;
+            while (__builtin_amdgcn_ballot_w64(inr != 0ull) != 0ull) {
+                const bool has = inr != 0ull;
+                const int jn = has ? __ffsll((long long)inr) - 1 : 0;
+                inr &= inr - 1ull;                        // (0 stays 0)
+                int se = 0, sc = 0, sx = 0, sy = 0, sz = 0;
+                if (p.rec) {                              // kernel-uniform
+                    const int a4 = 4 * jn;
+                    se = __builtin_amdgcn_ds_bpermute(a4, my_e0); sc = __builtin_amdgcn_ds_bpermute(a4, c);
+                    sx = __builtin_amdgcn_ds_bpermute(a4, __builtin_bit_cast(int, my_x.x));
+                    sy = __builtin_amdgcn_ds_bpermute(a4, __builtin_bit_cast(int, my_x.y));
+                    sz = __builtin_amdgcn_ds_bpermute(a4, __builtin_bit_cast(int, my_x.z));
+                }
+                if (has) {
+                    p.esrc[e] = GF + jn; p.edst[e] = GF + lane;
+                    if (p.rec) {
+                        int4* r = p.rec + (size_t)3 * e;
+                        r[0] = make_int4(sx, sy, sz, GF + jn);
+                        r[1] = make_int4(__builtin_bit_cast(int, my_x.x), __builtin_bit_cast(int, my_x.y), __builtin_bit_cast(int, my_x.z), GF + lane);
+                        r[2] = make_int4(se, sc, reg_pf + jn * kk_pf, kk_pf);
+                    }
+                    ++e;
+                }
             }
         }
         SB_STAMP(21);
@@ -654,6 +692,7 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
                     in_start2[p0 + c] = reg_pa + d0;
                     in_cnt2[p0 + c] = deg[a];
                     L.act4[j] = make_int4(c, d0, deg[a], pst[a]);
+                    if (p.rec) L.a_pa[c] = make_int2(reg_pa + d0, deg[a]);
                 }
             }
         }
@@ -666,11 +705,22 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
         const int npairs = Nf * kk;
         const bool pa_on = p.act_ids && !p.pa_static;                                   // kernel-uniform
         const int n_pa16 = pa_on ? 16 * (int)((all >> 16) & 0xfffu) : 0;
-        auto fp_store = [&](const int pr, const unsigned int r0, const unsigned int r1, const int e0) {
+        // t: the pair's index = its pf slot behind reg_pf.  BuildParams::rec: the pf edge's record -- the source atom's coordinates, type and
+        // in-edge descriptors (its fp in-edges: first slot and count, the popcount of its reference mask; its "pa" region)
+        auto fp_store = [&](const int t, const int pr, const unsigned int r0, const unsigned int r1, const int e0) {
             const int pc = pr & 0xffff, fl = pr >> 16;
             const int below = fl < 32 ? __popc(r0 & ((1u << fl) - 1u)) : __popc(r0) + __popc(r1 & ((1u << (fl - 32)) - 1u));
             p.esrc[e0 + below] = GF + fl;
             p.edst[e0 + below] = p0 + pc;
+            if (p.rec) {                                  // kernel-uniform
+                const float4 xs = L.px[pc], xd = L.fx[fl];
+                const int2 pa = L.a_pa[pc];
+                const int ty = (int)L.a_ty[pc];
+                int4* r = p.rec + (size_t)3 * (reg_pf + t);
+                r[0] = make_int4(__builtin_bit_cast(int, xs.x), __builtin_bit_cast(int, xs.y), __builtin_bit_cast(int, xs.z), (p0 + pc) | (ty << 24));
+                r[1] = make_int4(__builtin_bit_cast(int, xd.x), __builtin_bit_cast(int, xd.y), __builtin_bit_cast(int, xd.z), GF + fl);
+                r[2] = make_int4(e0, __popc(r0) + __popc(r1), pa.x, pa.y);
+            }
         };
         auto pa_store = [&](const int4 a4, const int k, const int src) {
             const int c = a4.x, e0 = reg_pa + a4.y, dg = a4.z, ps = a4.w;
@@ -694,13 +744,13 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
             const unsigned int r0 = L.refm[pc][0], r1 = L.refm[pc][1];
             const int e0 = L.a_e0[pc];
             const int s0 = L.a_src[h0 ? a40.x : 0][k], s1 = L.a_src[h1 ? a41.x : 0][k];
-            if (hp) fp_store(pr, r0, r1, e0);
+            if (hp) fp_store(tid, pr, r0, r1, e0);
             if (h0) pa_store(a40, k, s0);
             if (h1) pa_store(a41, k, s1);
         }
         for (int t = tid + NT; t < npairs; t += NT) {
             const int pr = L.pairs[t], pc = pr & 0xffff;
-            fp_store(pr, L.refm[pc][0], L.refm[pc][1], L.a_e0[pc]);
+            fp_store(t, pr, L.refm[pc][0], L.refm[pc][1], L.a_e0[pc]);
         }
         for (int t = tid + 2 * NT; t < n_pa16; t += NT) {
             const int4 a4 = L.act4[t >> 4];

@@ -292,6 +292,36 @@ def test_pa_messages_computed_ahead_equal_the_launch_s_own(case, monkeypatch):
     assert skipped[("spec", n - 1)] == 1 and skipped[("plain", n - 1)] == 0
 
 
+def test_edge_records_equal_the_chased_descriptors(monkeypatch):
+    """Edge records (BuildParams::rec / FusedParams::rec): the merged launch's update + build leaves, per ff / pf slot, what the next
+    call's fused launch otherwise collects in two dependent round trips (end points -> the source's in-edge descriptors, element
+    type, both coordinates).  Same values from another place: a run equals PFDYN_EDGE_REC=0 bit for bit -- uniform batch (the
+    arithmetic-tiling kernel that reads the records), 40 noisy and 40 quiet steps of the bounded schedule, trajectories included --
+    and matches the oracle's trajectory end."""
+    cfg = O.DynamicsConfig()
+    sd = O.make_state_dict(cfg, 6)
+    batch = O.synthetic_batch([840 + i for i in range(6)], [96] * 6, [6] * 6, cfg)
+    Nf = int(batch.pharm_ptr[-1])
+    T, n = 500, 40
+    noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(31))
+    coef = O.step_coefficients(O.gamma_table(T, 0.25), T)
+    res = {}
+    for form in ("rec", "plain"):
+        if form == "plain":
+            monkeypatch.setenv("PFDYN_EDGE_REC", "0")
+        eng = engine_for(cfg, sd)
+        set_batch(eng, batch)
+        out = []
+        for order in (list(reversed(range(T - n, T))), list(reversed(range(n)))):
+            x, h, tx, th = eng.sample(eng.coef_array(coef, order), n, noise, trajectory=True)
+            torch.cuda.synchronize()
+            eng.sample_status()
+            out += [x.cpu(), h.cpu(), tx.cpu(), th.cpu()]
+        res[form] = out
+    for a, b in zip(res["rec"], res["plain"]):
+        assert torch.equal(a, b)
+
+
 def test_fused_launch_arithmetic_tiling_equals_the_work_list_form(monkeypatch):
     """The conv-layer-0 edge launch and the fused launch of a batch whose graphs all have the same number of centers map items to
     (etype, graph, group) by arithmetic on preloaded scalars (k_n16_edge_u / k_n16_fused_u: regions at a fixed stride, groups beyond
