@@ -570,7 +570,10 @@ __device__ __forceinline__ void chain_fwd(const ChainLds& L, const GvpT* g, cons
                                           const int tid, const int lane, const int wv) {
     for (int l = 0; l < L.nlv; ++l) {
         const bool last = l == L.nlv - 1;
-        gvp_fwd(g[l], W, pk, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+        // (a COPY of the level's table entry: through the reference into global memory every use of a field inside the products'
+        // store callbacks -- W[g.o_bg + i] -- was a load of the field, a wait, the load of the weight, a wait, per element)
+        const GvpT gl = g[l];
+        gvp_fwd(gl, W, pk, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
                 last ? vout_last : L.Vin(l + 1), L.Vh, L.Vu, tid, lane, wv);
     }
 }
@@ -649,17 +652,18 @@ __device__ __forceinline__ void chain_bwd(const ChainLds& L, const GvpT* g, cons
     float *ga = L.gX, *gs = L.gY, *gvo = L.gVX, *gvi = L.gVY;
     for (int l = L.nlv - 1; l >= 0; --l) {
         const bool last = l == L.nlv - 1;
-        const bool fx = g[l].vi == 16 && g[l].h == 16 && g[l].vo == 16 && g[l].si == 128 && g[l].so == 128 && g[l].sig;      // block-uniform
+        const GvpT gl = g[l];                           // (a copy: see chain_fwd)
+        const bool fx = gl.vi == 16 && gl.h == 16 && gl.vo == 16 && gl.si == 128 && gl.so == 128 && gl.sig;      // block-uniform
         bool fx2 = false;
-        if constexpr (HEAD) fx2 = g[l].vi == 16 && g[l].h == 16 && g[l].vo == 1 && g[l].si == 128 && g[l].so == 64;      // the noise head's last GVP
+        if constexpr (HEAD) fx2 = gl.vi == 16 && gl.h == 16 && gl.vo == 1 && gl.si == 128 && gl.so == 64;      // the noise head's last GVP
         if (fx)
-            gvp_bwd<BF16, 1>(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+            gvp_bwd<BF16, 1>(gl, W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
                     ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh, wst);
         else if (HEAD && fx2)
-            gvp_bwd<BF16, HEAD ? 2 : 0>(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+            gvp_bwd<BF16, HEAD ? 2 : 0>(gl, W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
                     ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh, wst);
         else
-            gvp_bwd<BF16, 0>(g[l], W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
+            gvp_bwd<BF16, 0>(gl, W, pk, fresh, gp, L.Sin(l), L.Vin(l), L.Z(l), L.gate(l), last ? L.actl : L.Sin(l + 1), last ? ZS : SWS,
                     ga, gs, gvo, gvi, L.Vh, L.Vu, L.gVh, L.ggate, tid, lane, wv, fill_sh, wst);
         float* t0 = ga; ga = gs; gs = t0;
         float* t1 = gvo; gvo = gvi; gvi = t1;
