@@ -521,12 +521,19 @@ struct StepParams {
     float* h_snap_out;
 };
 #ifdef __HIPCC__
-// the feature update of sample_p_zs_given_zt (pharmacodiff.py:414-426) for one value -- ONE body for the update + build and for the
-// center hoist's copy of it, so that both produce the same bits
+// The p(z_s | z_t) update of sample_p_zs_given_zt (pharmacodiff.py:397-426) for ONE value -- coordinate or feature -- and the only place
+// it is written: the generic update, the latency-optimised one (center threads / feature lanes) and the center hoist's copy all call
+// this, with FP contraction OFF.  Left to the compiler, whether `hv / a_ts - var * e` and `mu + sigma * nz` become fused multiply-adds
+// depends on the code around the expression: the forms of a step agreed bit for bit only as long as the compiler happened to decide
+// alike in every one of them.  One rounding per operation is also what the reference's tensor expressions do.
 __device__ __forceinline__ float pf_feat_update(const float hv, const float e, const float nz, const float a_ts, const float var,
                                                 const float sigma, const float ep_zt, const float ep_pred, const int ep_feat) {
-    const float mu = ep_feat ? (ep_zt * hv + ep_pred * e) : (hv / a_ts - var * e);
-    return mu + sigma * nz;
+#pragma clang fp contract(off)
+    float mu;
+    if (ep_feat) { const float a = ep_zt * hv, b = ep_pred * e; mu = a + b; }
+    else { const float a = hv / a_ts, b = var * e; mu = a - b; }
+    const float n = sigma * nz;
+    return mu + n;
 }
 #endif
 

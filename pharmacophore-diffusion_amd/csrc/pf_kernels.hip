@@ -1793,16 +1793,14 @@ __device__ __forceinline__ void step_update_body(const StepParams& p, const int 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float e = p.eps_x[(size_t)f * 3 + c];
-            const float mu = p.ep_coord ? (p.ep_zt * xi[c] + p.ep_pred * e) : (xi[c] / p.a_ts - p.var * e);
-            m[c] = mu + p.sigma * nz[c];
+            m[c] = pf_feat_update(xi[c], e, nz[c], p.a_ts, p.var, p.sigma, p.ep_zt, p.ep_pred, p.ep_coord);      // (pf_device.h: the one place the update is written)
         }
         p.xn[p.Np_tot + f] = make_float4(m[0], m[1], m[2], 0.f);
         sx += m[0]; sy += m[1]; sz += m[2];
         for (int k = 0; k < p.nf; ++k) {
             const float hv = p.pharm_h[(size_t)f * p.nf + k];
             const float e = p.eps_h[(size_t)f * p.nf + k];
-            const float mu = p.ep_feat ? (p.ep_zt * hv + p.ep_pred * e) : (hv / p.a_ts - p.var * e);
-            p.pharm_h[(size_t)f * p.nf + k] = mu + p.sigma * nz[3 + k];
+            p.pharm_h[(size_t)f * p.nf + k] = pf_feat_update(hv, e, nz[3 + k], p.a_ts, p.var, p.sigma, p.ep_zt, p.ep_pred, p.ep_feat);
         }
     }
 #pragma unroll

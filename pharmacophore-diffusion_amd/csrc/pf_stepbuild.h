@@ -469,8 +469,7 @@ __device__ __forceinline__ void sb_finish(const SbPre<NT>& q, const float (&ex)[
         const float xi[3] = {q.xf.x, q.xf.y, q.xf.z};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float mu = sp.ep_coord ? (sp.ep_zt * xi[c] + sp.ep_pred * ex[c]) : (xi[c] / sp.a_ts - sp.var * ex[c]);
-            m[c] = mu + sp.sigma * q.nzx[c];
+            m[c] = pf_feat_update(xi[c], ex[c], q.nzx[c], sp.a_ts, sp.var, sp.sigma, sp.ep_zt, sp.ep_pred, sp.ep_coord);
         }
     }
     if (wave == 0) {

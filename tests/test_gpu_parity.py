@@ -577,6 +577,48 @@ def test_fused_update_and_edge_build_variants_agree(case, monkeypatch):
     close(res[0][0], ox, 5e-3, 5e-3); close(res[0][1], oh, 5e-3, 5e-3)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_update_and_edge_build_random_shapes_fast_equals_generic(seed, monkeypatch):
+    """The latency-optimised update + build (pf_stepbuild.h: key-sorted neighbour search with its exact fallback, ff edges from
+    bit masks, fp edges one per pair, 16 threads per active atom, atoms dealt by pass, edge records) against the generic body over
+    random shapes it must all handle: 1..20 centers per graph (graphs with a single center included), 1..16 neighbours per
+    center, pockets of 20..512 atoms (one and two passes, 8 and 16 candidates per lane, pockets smaller than k), radius and kNN ff
+    edges -- four steps each, bit for bit, and against the oracle."""
+    import random
+    monkeypatch.setenv("PFDYN_NO_CENTER_HOIST", "1")       # (the hoist's tables equal the on-the-fly encoding up to summation order: its own test)
+    rng = random.Random(seed)
+    for trial in range(4):
+        B = rng.choice([1, 3, 5])
+        n_prot = [rng.choice([20, 70, 200, 256, 257, 400, 512]) for _ in range(B)]
+        n_pharm = [rng.choice([1, 2, 6, 11, 20]) for _ in range(B)]
+        kw = dict(pf_k=rng.choice([1, 3, 5, 9, 16]))
+        if rng.random() < 0.3:
+            kw["ff_k"] = rng.choice([1, 2, 4])
+        cfg = O.DynamicsConfig(**kw)
+        sd = O.make_state_dict(cfg, 40 + seed)
+        batch = O.synthetic_batch([900 + 10 * seed + trial * 5 + i for i in range(B)], n_prot, n_pharm, cfg)
+        T, n = 50, 4
+        noise = torch.randn(n + 1, int(batch.pharm_ptr[-1]), 9, generator=torch.Generator().manual_seed(100 * seed + trial))
+        coef = O.step_coefficients(O.gamma_table(T, 1e-5), T)
+        res = []
+        for env in ({}, {"PFDYN_NO_FAST_BUILD": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            eng = engine_for(cfg, sd)
+            for k in env:
+                monkeypatch.delenv(k)
+            set_batch(eng, batch)
+            x0, h0 = eng.sample(eng.coef_array(coef, reversed(range(T))), n, noise)
+            torch.cuda.synchronize()
+            eng.sample_status()
+            res.append((x0.cpu(), h0.cpu()))
+        what = f"seed {seed} trial {trial}: atoms {n_prot}, centers {n_pharm}, {kw}"
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), what
+        ox, oh = O.sample_given_receptor(sd, cfg, batch, T, 1e-5, noise, n_steps=n)
+        torch.testing.assert_close(res[0][0], ox, rtol=5e-3, atol=5e-3, msg=what)
+        torch.testing.assert_close(res[0][1], oh, rtol=5e-3, atol=5e-3, msg=what)
+
+
 def test_kernel_family_reporting(monkeypatch):
     """pf_debug_kernel_family reports what the launch policy chose for a layer's edge messages: the row-group kernels by
     default (the n16 form for small launches; with it off, 4 rows per wave), the 32-row tile kernels when they are switched off."""
