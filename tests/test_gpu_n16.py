@@ -292,6 +292,45 @@ def test_pa_messages_computed_ahead_equal_the_launch_s_own(case, monkeypatch):
     assert skipped[("spec", n - 1)] == 1 and skipped[("plain", n - 1)] == 0
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_work_done_ahead_random_shapes_bitwise(seed, monkeypatch):
+    """The rows computed ahead (whole regions and kept prefixes of changed ones: BuildParams::pa_same) and the edge records over random
+    batch shapes -- 1..9 graphs, 1..12 centers, 1..9 neighbours, pockets of 24..300 atoms -- 16 steps from the noisy end of a bounded
+    schedule and 16 from its quiet end: equal to PFDYN_NO_PA_SPEC=1 + PFDYN_EDGE_REC=0 bit for bit, trajectories included."""
+    import random
+    rng = random.Random(seed)
+    for trial in range(3):
+        B = rng.choice([1, 2, 5, 9])
+        n_prot = [rng.choice([24, 60, 96, 200, 256, 300]) for _ in range(B)]
+        n_pharm = [rng.choice([1, 2, 4, 6, 12]) for _ in range(B)]
+        cfg = O.DynamicsConfig(pf_k=rng.choice([1, 3, 5, 9]))
+        sd = O.make_state_dict(cfg, 60 + seed)
+        batch = O.synthetic_batch([700 + 20 * seed + 7 * trial + i for i in range(B)], n_prot, n_pharm, cfg)
+        Nf = int(batch.pharm_ptr[-1])
+        T, n = 500, 16
+        noise = torch.randn(n + 1, Nf, 9, generator=torch.Generator().manual_seed(seed * 10 + trial))
+        coef = O.step_coefficients(O.gamma_table(T, 0.25), T)
+        res = {}
+        for form in ("ahead", "plain"):
+            if form == "plain":
+                monkeypatch.setenv("PFDYN_NO_PA_SPEC", "1")
+                monkeypatch.setenv("PFDYN_EDGE_REC", "0")
+            eng = engine_for(cfg, sd)
+            if form == "plain":
+                monkeypatch.delenv("PFDYN_NO_PA_SPEC")
+                monkeypatch.delenv("PFDYN_EDGE_REC")
+            set_batch(eng, batch)
+            out = []
+            for order in (list(reversed(range(T - n, T))), list(reversed(range(n)))):
+                x, h, tx, th = eng.sample(eng.coef_array(coef, order), n, noise, trajectory=True)
+                torch.cuda.synchronize()
+                eng.sample_status()
+                out += [x.cpu(), h.cpu(), tx.cpu(), th.cpu()]
+            res[form] = out
+        for a, b in zip(res["ahead"], res["plain"]):
+            assert torch.equal(a, b), f"seed {seed} trial {trial}: atoms {n_prot}, centers {n_pharm}, pf_k {cfg.pf_k}"
+
+
 def test_edge_records_equal_the_chased_descriptors(monkeypatch):
     """Edge records (BuildParams::rec / FusedParams::rec): the merged launch's update + build leaves, per ff / pf slot, what the next
     call's fused launch otherwise collects in two dependent round trips (end points -> the source's in-edge descriptors, element
