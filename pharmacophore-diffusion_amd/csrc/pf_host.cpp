@@ -2525,7 +2525,7 @@ static int set_pocket_batch_impl(pf_handle* h, int32_t B, const int32_t* prot_pt
     h->zs_version = 0; h->zs_batch_coords = false; h->coords_custom = false;
     h->have_batch = true;
     h->sampling = false;
-    h->edges_built = false;
+    h->edges_built = false; h->rec_valid = false;
     return PF_OK;
 }
 
@@ -2607,7 +2607,7 @@ int64_t pf_build_pp_edges(pf_handle* h, int32_t B, const int32_t* prot_ptr, cons
 }
 
 static int load_state(pf_handle* h, const float* dev_prot_x, const float* dev_pharm_x, const float* dev_pharm_h, hipStream_t s) {
-    h->edges_built = false;
+    h->edges_built = false; h->rec_valid = false;
     if (dev_prot_x) { pfk_load_coords(dev_prot_x, h->d_xn, h->Np, h->d_gid, nullptr, 0.f, s); h->coords_custom = true; }
     if (dev_pharm_x) pfk_load_coords(dev_pharm_x, h->d_xn + h->Np, h->Nf, h->d_gid, nullptr, 0.f, s);
     if (dev_pharm_h) pfk_copy(dev_pharm_h, h->d_pharm_h, (size_t)h->Nf * h->cfg.pharm_nf, s);
@@ -2652,7 +2652,7 @@ int pf_sample_begin(pf_handle* h, const float* dev_init_pharm_com, const float* 
     }
     h->coords_custom = false;               // a rigid translate of the batch's own coordinates from here on
     h->sampling = true;
-    h->edges_built = false;
+    h->edges_built = false; h->rec_valid = false;
     return PF_OK;
 }
 
@@ -3098,7 +3098,7 @@ int pf_train_loss_forward(pf_handle* h, const float* dev_pharm_x0, const float* 
     lp.xn = h->d_xn; lp.pharm_h = h->d_pharm_h; lp.t = h->d_t;
     lp.x0c = h->t_lx0c; lp.alpha_g = h->t_lag; lp.sigma_g = h->t_lsg;
     lp.dyn_h = h->d_eps_h; lp.dyn_x = h->d_eps_x; lp.g_x = h->t_lgx; lp.g_h = h->t_lgh; lp.out = dev_out;
-    h->edges_built = false;
+    h->edges_built = false; h->rec_valid = false;
     h->coords_custom = true;                     // the pocket moved with the centers' COM: trajectory constants of the bound coordinates do not apply
     pfk_loss_prepare(&lp, s);
     rc = run_dynamics(h, h->d_eps_h, h->d_eps_x, s, nullptr, true);
